@@ -1,0 +1,125 @@
+"""CPU: the oracle (oracle/ksw2_oracle.c) against every golden vector produced by the compiled reference.
+
+This is what pins the oracle: the known-answer table of section 4.2 and 3600 seeded
+random cases, all outputs of the unmodified reference (oracle/gen_golden.py).
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests import golden_util as gu
+
+
+def _check(res, exp, fields):
+    for f in fields:
+        assert res[f] == exp[f], (f, res[f], exp[f])
+
+
+def test_struct_layout():
+    import ctypes
+    assert ctypes.sizeof(po.Ez) == 56 and po.Ez.cigar.offset == 48 and po.Ez.score.offset == 28
+
+
+def test_t1q1_known_answers():
+    ka = gu.known_answers()
+    _, ts = gu.read_fasta("t1.fa")
+    _, qs = gu.read_fasta("q1.fa")
+    mat = gu.simple_mat(5, 2, 4, 0)
+    expected_extz = [(-2, 4, 1, 1, "2M1D"), (-12, 2, 0, 0, "2D7M2D4M4D"),
+                     (12, 48, 35, 33, "5M2D27M6D7M2D4M3D3M3D2M2D6M"), (-18, 0, -1, -1, "11D4M"), (8, 10, 4, 4, "34M")]
+    for k, rec in enumerate(ka["t1q1"]):
+        q, t = qs[k], ts[k]
+        for flag in (0, po.RIGHT):
+            for func in ("extz", "extd"):
+                exp = rec["ksw_%s/flag=%d" % (func, flag)]
+                res = po.align("oracle", func, q, t, mat, 4, 2, 13, 1, flag=flag)
+                _check(res, exp, gu.FIELDS)
+                assert gu.cigar_string(res["cigar"]) == exp["cigar"]
+        # SURVEY.md section 4.2 literal table (ksw2-test -t extz test/t1.fa test/q1.fa)
+        res = po.align("oracle", "extz", q, t, mat, 4, 2)
+        sc, mx, mt, mq, cg = expected_extz[k]
+        assert (res["score"], res["max"], res["max_t"], res["max_q"], gu.cigar_string(res["cigar"])) == (sc, mx, mt, mq, cg)
+        for g in ("gg", "gg2"):
+            s, c = po.global_align("oracle", g, q, t, mat, 4, 2, w=-1)
+            assert s == rec["ksw_" + g]["score"] and gu.cigar_string(c) == rec["ksw_" + g]["cigar"]
+        # gg2_sse agrees with gg on these inputs, so the same oracle call covers it
+        assert rec["ksw_gg2_sse"]["score"] == rec["ksw_gg"]["score"] and rec["ksw_gg2_sse"]["cigar"] == rec["ksw_gg"]["cigar"]
+        key = "ksw_extz/A1B9O16E1w10"
+        if key in rec:
+            res = po.align("oracle", "extz", q, t, gu.simple_mat(5, 1, 9, 0), 16, 1, w=10)
+            _check(res, rec[key], gu.FIELDS)
+
+
+def test_random_cases_scalar_contract():
+    rc = gu.RandomCases()
+    n = {"ksw_extz": 0, "ksw_extd": 0}
+    for k in range(rc.n):
+        c = rc.case(k)
+        if c["func"] not in n:
+            continue
+        func = c["func"][4:]
+        res = po.align("oracle", func, c["q"], c["t"], c["mat"], c["gq"], c["ge"], c["gq2"], c["ge2"], w=c["w"], zdrop=c["zdrop"],
+                       flag=c["flag"])
+        _check(res, c["expect"], gu.FIELDS + ["cigar"])
+        # the "...2" contract with explicit matrix scoring and no end bonus is the same function
+        res2 = po.align("oracle", func + "2", c["q"], c["t"], c["mat"], c["gq"], c["ge"], c["gq2"], c["ge2"], w=c["w"],
+                        zdrop=c["zdrop"], end_bonus=0, flag=c["flag"] | po.GENERIC_SC)
+        if not (c["flag"] & po.EXTZ_ONLY):
+            _check(res2, c["expect"], gu.FIELDS + ["cigar"])
+        n[c["func"]] += 1
+    assert min(n.values()) > 500
+
+
+def test_random_cases_sse_signature():
+    """end_bonus / reach_end / implicit wildcard scoring: compared with the SSE kernels on loose bands."""
+    rc = gu.RandomCases()
+    n = 0
+    for k in range(rc.n):
+        c = rc.case(k)
+        if not c["func"].endswith("2_sse"):
+            continue
+        func = "extz2" if "extz" in c["func"] else "extd2"
+        res = po.align("oracle", func, c["q"], c["t"], c["mat"], c["gq"], c["ge"], c["gq2"], c["ge2"], w=c["w"], zdrop=c["zdrop"],
+                       end_bonus=c["end_bonus"], flag=c["flag"])
+        _check(res, c["expect"], gu.SSE_LOOSE_FIELDS)
+        if res["max_t"] == c["expect"]["max_t"] and res["max_q"] == c["expect"]["max_q"]:
+            assert res["cigar"] == c["expect"]["cigar"]          # F4: CIGAR follows the max cell under EXTZ_ONLY
+        n += 1
+    assert n > 500
+
+
+@pytest.mark.parametrize("idx", range(10))
+def test_mt_pair(idx):
+    """16.5 kb mitochondrial pair; ~1-2 s per setting on one core."""
+    ka = gu.known_answers()["mt"]
+    _, ts = gu.read_fasta("MT-human.fa")
+    _, qs = gu.read_fasta("MT-orang.fa")
+    exp = ka[idx]
+    mat = gu.simple_mat(5, 2, 4, 0)
+    res = po.align("oracle", exp["func"][4:], qs[0], ts[0], mat, 4, 2, 13, 1, w=exp["w"], zdrop=exp["zdrop"], flag=exp["flag"])
+    _check(res, exp, gu.FIELDS)
+    s = gu.cigar_string(res["cigar"])
+    assert s == exp["cigar"]
+    assert hashlib.md5((s + "\n").encode()).hexdigest()[:12] == exp["cigar_md5_12"]
+
+
+def test_mt_survey_anchors():
+    """The literal anchors of BASELINE.md section 4 (independent of the JSON file's content)."""
+    ka = {(r["func"], r["w"], r.get("flag", 0), r.get("zdrop", -1)): r for r in gu.known_answers()["mt"]}
+    r = ka[("ksw_extz", -1, 0, -1)]
+    assert (r["score"], r["max"], r["max_t"], r["max_q"], r["cigar_md5_12"]) == (16102, 17054, 16568, 16024, "ea0524d904ed")
+    r = ka[("ksw_extd", -1, 0, -1)]
+    assert (r["score"], r["max"], r["max_t"], r["max_q"], r["cigar_md5_12"]) == (17127, 17614, 16568, 16024, "df0e77e43f48")
+    r = ka[("ksw_extz", 500, 0, -1)]
+    assert (r["score"], r["max"], r["cigar_md5_12"]) == (-13510, 2, "c07fce86940f")
+    assert ka[("ksw_extz", -1, po.RIGHT, -1)]["cigar_md5_12"] == "db8b671f4dbf"
+    assert ka[("ksw_extd", -1, po.RIGHT, -1)]["cigar_md5_12"] == "8e2c9cfb877a"
+
+
+def test_band_cells():
+    assert po.band_cells(512, 512, 64) == 61888          # SURVEY section 8 config sizes
+    assert po.band_cells(2048, 2048, 256) == 984832
+    assert po.band_cells(10000, 10000, 500) == 9759500
+    assert po.band_cells(16499, 16569, -1) == 16499 * 16569
