@@ -1,0 +1,151 @@
+/*
+ * ksw2_amd.h -- C-ABI of libksw2_amd.so: MI355X (gfx950) implementation of ksw2's banded
+ * extension / global alignment hot path.
+ *
+ * Part 1 is the ksw2 calling surface (same symbol names, argument order and meaning, ksw_extz_t layout
+ * and CIGAR encoding as the reference's ksw2.h), so a minimap2-style caller that was compiled against
+ * the reference header links against this library unchanged.  Part 2 is the batched front-end the
+ * reference does not have: thousands of independent (query, target, band) pairs per launch.
+ *
+ * Result contract: every function evaluates the alignment on the GPU with the exact
+ * band |i-j| <= w and the row-wise Z-drop of the reference's scalar ksw_extz / ksw_extd, and returns
+ * bit-identical score / max / max_q / max_t / mqe / mqe_t / mte / mte_q / zdropped / reach_end / CIGAR.
+ * There is no CPU fallback: without a usable gfx950 device the ksw2-named entry points print the error
+ * to stderr and abort(); the ksw2amd_* entry points return a negative code (see ksw2amd_last_error()).
+ *
+ * Reference interface each declaration replaces is cited as (ksw2.h:LINE).
+ */
+#ifndef KSW2_AMD_H_
+#define KSW2_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ Part 1: the ksw2 surface */
+#ifndef KSW2_H_          /* a caller may include the reference's ksw2.h instead: identical ABI */
+
+#define KSW_NEG_INF        (-0x40000000)          /* (ksw2.h:6)  */
+
+#define KSW_EZ_SCORE_ONLY  0x01                   /* (ksw2.h:8)  no CIGAR */
+#define KSW_EZ_RIGHT       0x02                   /* (ksw2.h:9)  right-align gaps */
+#define KSW_EZ_GENERIC_SC  0x04                   /* (ksw2.h:10) use mat[] for every residue pair */
+#define KSW_EZ_APPROX_MAX  0x08                   /* (ksw2.h:11) accepted; computed exactly */
+#define KSW_EZ_APPROX_DROP 0x10                   /* (ksw2.h:12) accepted; computed exactly */
+#define KSW_EZ_EXTZ_ONLY   0x40                   /* (ksw2.h:13) extension only */
+#define KSW_EZ_REV_CIGAR   0x80                   /* (ksw2.h:14) CIGAR in end->start order */
+#define KSW_EZ_EQX         0x800                  /* (ksw2.h:18) =/X instead of M (extd2 only) */
+
+#define KSW_CIGAR_MATCH  0                        /* (ksw2.h:22-27) */
+#define KSW_CIGAR_INS    1
+#define KSW_CIGAR_DEL    2
+#define KSW_CIGAR_N_SKIP 3
+#define KSW_CIGAR_EQ     7
+#define KSW_CIGAR_X      8
+
+/* (ksw2.h:33-42) 56 bytes; cigar[k] = len<<4 | op; the callee reuses and grows `cigar` (capacity
+ * m_cigar), the caller zero-initialises the struct once and finally frees `cigar`. */
+typedef struct {
+	uint32_t max:31, zdropped:1;
+	int max_q, max_t;
+	int mqe, mqe_t;
+	int mte, mte_q;
+	int score;
+	int m_cigar, n_cigar;
+	int reach_end;
+	uint32_t *cigar;
+} ksw_extz_t;
+
+#endif /* KSW2_H_ */
+
+/* `km`: NULL -> CIGAR memory comes from libc realloc (caller frees with free()); non-NULL -> the
+ * caller's kalloc pool: the library calls the process's krealloc(km, ..) (kalloc.h:14), resolved at run time. */
+
+/* (ksw2.h:64-65) single affine gap, replaces ksw_extz2_sse (ksw2_extz2_sse.c:23-304) */
+void ksw_extz2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                   int8_t q, int8_t e, int w, int zdrop, int end_bonus, int flag, ksw_extz_t *ez);
+/* (ksw2.h:70-71) two-piece affine gap, replaces ksw_extd2_sse (ksw2_extd2_sse.c:34-409) */
+void ksw_extd2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                   int8_t gapo, int8_t gape, int8_t gapo2, int8_t gape2, int w, int zdrop, int end_bonus, int flag, ksw_extz_t *ez);
+/* (ksw2.h:89-90) global alignment, replace ksw_gg2 (ksw2_gg2.c:4-114) and ksw_gg2_sse (ksw2_gg2_sse.c:11-126).
+ * ksw_gg2: all three CIGAR pointers NULL -> score only.  Band that cannot reach the corner
+ * (w < |tlen-qlen|): returns KSW_NEG_INF with *n_cigar_ = 0 (undefined in the reference). */
+int ksw_gg2(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+            int8_t gapo, int8_t gape, int w, int *m_cigar_, int *n_cigar_, uint32_t **cigar_);
+int ksw_gg2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                int8_t gapo, int8_t gape, int w, int *m_cigar_, int *n_cigar_, uint32_t **cigar_);
+/* (ksw2.h:61-62, 67-68, 88) the scalar entry points, evaluated by the same GPU kernels
+ * (they are the functions whose results define the contract) */
+void ksw_extz(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+              int8_t q, int8_t e, int w, int zdrop, int flag, ksw_extz_t *ez);
+void ksw_extd(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+              int8_t gapo, int8_t gape, int8_t gapo2, int8_t gape2, int w, int zdrop, int flag, ksw_extz_t *ez);
+int ksw_gg(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+           int8_t gapo, int8_t gape, int w, int *m_cigar_, int *n_cigar_, uint32_t **cigar_);
+/* multi-ISA builds of the reference export these names under KSW_CPU_DISPATCH
+ * (ksw2_extz2_sse.c:16-24, ksw2_extd2_sse.c:25-36); same functions */
+void ksw_extz2_sse41(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                     int8_t q, int8_t e, int w, int zdrop, int end_bonus, int flag, ksw_extz_t *ez);
+void ksw_extz2_sse2(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                    int8_t q, int8_t e, int w, int zdrop, int end_bonus, int flag, ksw_extz_t *ez);
+void ksw_extd2_sse41(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                     int8_t gapo, int8_t gape, int8_t gapo2, int8_t gape2, int w, int zdrop, int end_bonus, int flag, ksw_extz_t *ez);
+void ksw_extd2_sse2(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                    int8_t gapo, int8_t gape, int8_t gapo2, int8_t gape2, int w, int zdrop, int end_bonus, int flag, ksw_extz_t *ez);
+
+/* ------------------------------------------------------------------ Part 2: batched front-end */
+
+/* scoring shared by every pair of a batch (the arguments m, mat, q, e[, q2, e2] of the calls above) */
+typedef struct {
+	int32_t m;                 /* residue codes 0..m-1, last one is the wildcard; m <= 5 in this release */
+	const int8_t *mat;         /* m*m, mat[target*m + query] */
+	int8_t q, e, q2, e2;       /* q2/e2 only read by the two-piece (extd) entry points */
+} ksw2amd_scoring_t;
+
+/* one alignment = the per-call arguments of ksw_extz2_sse / ksw_extd2_sse */
+typedef struct {
+	const uint8_t *query, *target;
+	int32_t qlen, tlen;
+	int32_t w, zdrop, end_bonus, flag;
+} ksw2amd_pair_t;
+
+#define KSW2AMD_OK            0
+#define KSW2AMD_E_NODEVICE   (-1)      /* no usable gfx950 device / HIP runtime error */
+#define KSW2AMD_E_PARAM      (-2)      /* argument outside what this release supports (see last_error) */
+#define KSW2AMD_E_NOMEM      (-3)
+
+const char *ksw2amd_last_error(void);  /* message of the calling thread's last failing call */
+const char *ksw2amd_backend(void);     /* "hip:gfx950" */
+int ksw2amd_device_count(void);
+int ksw2amd_set_device(int device);    /* device used by the calling thread's subsequent calls */
+
+/* n independent alignments; ez[i] ends up exactly as after
+ *   ksw_extz2_sse(km, pairs[i].qlen, pairs[i].query, ..., sc->m, sc->mat, sc->q, sc->e, w, zdrop, end_bonus, flag, &ez[i])
+ * (resp. ksw_extd2_sse).  ez[] must be zero-initialised (or hold reusable cigar buffers) like for the
+ * single calls.  Large batches are split internally to fit device memory. */
+int ksw2amd_extz_batch(void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez);
+int ksw2amd_extd_batch(void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez);
+
+/* The same in three phases, for callers that keep batches resident in HBM (and for benchmarking the
+ * device part alone): create = pack + upload, run = kernels only (asynchronous on `stream`, a hipStream_t
+ * or NULL), fetch = wait + download + fill ez[]. */
+typedef struct ksw2amd_plan_s ksw2amd_plan_t;
+ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs);
+int  ksw2amd_plan_run(ksw2amd_plan_t *plan, void *stream);
+int  ksw2amd_plan_fetch(ksw2amd_plan_t *plan, void *km, ksw_extz_t *ez);
+void ksw2amd_plan_destroy(ksw2amd_plan_t *plan);
+/* device time of the last ksw2amd_plan_run (HIP events on its stream), fill kernels only / fill + traceback; ms */
+int  ksw2amd_plan_timing(ksw2amd_plan_t *plan, float *fill_ms, float *total_ms);
+/* in-band DP cells of the plan (exact band, all rows counted even if Z-drop stops early) and device bytes held */
+int64_t ksw2amd_plan_cells(const ksw2amd_plan_t *plan);
+int64_t ksw2amd_plan_device_bytes(const ksw2amd_plan_t *plan);
+/* raw device results without the host-side ez[] assembly: 16 int32 per pair
+ * {max, zdropped, max_q, max_t, mqe, mqe_t, mte, mte_q, score, reach_end, n_cigar, rows_done, ti, tj, 0, 0} */
+int  ksw2amd_plan_fetch_raw(ksw2amd_plan_t *plan, int32_t *out16);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,325 @@
+"""ksw2_amd -- ctypes binding of libksw2_amd.so, the MI355X (gfx950) implementation of ksw2's banded
+extension / global alignment hot path (C-ABI in include/ksw2_amd.h).
+
+The binding mirrors the reference's C interface (ksw2.h:61-90): same function names, argument order and
+meaning, same ksw_extz_t fields.  There is no CPU fallback: if the HIP library is missing or no GPU is
+usable the calls raise / abort loudly.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_SO = os.path.join(HERE, "libksw2_amd.so")
+
+KSW_NEG_INF = -0x40000000
+KSW_EZ_SCORE_ONLY, KSW_EZ_RIGHT, KSW_EZ_GENERIC_SC, KSW_EZ_APPROX_MAX, KSW_EZ_APPROX_DROP = 0x01, 0x02, 0x04, 0x08, 0x10
+KSW_EZ_EXTZ_ONLY, KSW_EZ_REV_CIGAR, KSW_EZ_EQX = 0x40, 0x80, 0x800
+
+FIELDS = ["score", "max", "max_t", "max_q", "mqe", "mqe_t", "mte", "mte_q", "zdropped", "reach_end", "n_cigar"]
+
+
+class KswExtz(ctypes.Structure):
+    """ksw_extz_t (ksw2.h:33-42)."""
+    _fields_ = [("max_zd", ctypes.c_uint32), ("max_q", ctypes.c_int), ("max_t", ctypes.c_int),
+                ("mqe", ctypes.c_int), ("mqe_t", ctypes.c_int), ("mte", ctypes.c_int), ("mte_q", ctypes.c_int),
+                ("score", ctypes.c_int), ("m_cigar", ctypes.c_int), ("n_cigar", ctypes.c_int),
+                ("reach_end", ctypes.c_int), ("cigar", ctypes.POINTER(ctypes.c_uint32))]
+
+
+class Scoring(ctypes.Structure):
+    _fields_ = [("m", ctypes.c_int32), ("mat", ctypes.POINTER(ctypes.c_int8)),
+                ("q", ctypes.c_int8), ("e", ctypes.c_int8), ("q2", ctypes.c_int8), ("e2", ctypes.c_int8)]
+
+
+class Pair(ctypes.Structure):
+    _fields_ = [("query", ctypes.c_void_p), ("target", ctypes.c_void_p), ("qlen", ctypes.c_int32), ("tlen", ctypes.c_int32),
+                ("w", ctypes.c_int32), ("zdrop", ctypes.c_int32), ("end_bonus", ctypes.c_int32), ("flag", ctypes.c_int32)]
+
+
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_i8p = ctypes.POINTER(ctypes.c_int8)
+_i8 = ctypes.c_int8
+_int = ctypes.c_int
+_libc = ctypes.CDLL(None)
+_libc.free.argtypes = [ctypes.c_void_p]
+
+EXPORTS = ["ksw_extz2_sse", "ksw_extd2_sse", "ksw_gg2", "ksw_gg2_sse", "ksw_extz", "ksw_extd", "ksw_gg",
+           "ksw_extz2_sse41", "ksw_extz2_sse2", "ksw_extd2_sse41", "ksw_extd2_sse2",
+           "ksw2amd_last_error", "ksw2amd_backend", "ksw2amd_device_count", "ksw2amd_set_device",
+           "ksw2amd_extz_batch", "ksw2amd_extd_batch", "ksw2amd_plan_create", "ksw2amd_plan_run", "ksw2amd_plan_fetch",
+           "ksw2amd_plan_destroy", "ksw2amd_plan_timing", "ksw2amd_plan_cells", "ksw2amd_plan_device_bytes",
+           "ksw2amd_plan_fetch_raw"]
+
+
+class Ksw2Error(RuntimeError):
+    pass
+
+
+def ez_to_dict(ez, free_cigar=False):
+    n = ez.n_cigar
+    d = dict(max=int(ez.max_zd & 0x7fffffff), zdropped=int(ez.max_zd >> 31), max_q=ez.max_q, max_t=ez.max_t, mqe=ez.mqe,
+             mqe_t=ez.mqe_t, mte=ez.mte, mte_q=ez.mte_q, score=ez.score, reach_end=ez.reach_end, n_cigar=n,
+             m_cigar=ez.m_cigar, cigar=[int(ez.cigar[i]) for i in range(n)] if n > 0 else [])
+    if free_cigar and ez.cigar:
+        _libc.free(ctypes.cast(ez.cigar, ctypes.c_void_p))
+    return d
+
+
+def cigar_string(cigar):
+    return "".join("%d%s" % (c >> 4, "MIDN"[c & 0xf] if (c & 0xf) < 4 else {7: "=", 8: "X"}[c & 0xf]) for c in cigar)
+
+
+class Library:
+    """One loaded libksw2_amd.so (tests/sim loads its simulator build through the same class)."""
+
+    def __init__(self, path=DEFAULT_SO):
+        if not os.path.exists(path):
+            raise Ksw2Error("%s not found: build it with `make -C ksw2_amd/csrc` (or __graft_entry__.build()); "
+                            "there is no CPU fallback" % path)
+        self.path = path
+        L = self.lib = ctypes.CDLL(path)
+        km = ctypes.c_void_p
+        ezp = ctypes.POINTER(KswExtz)
+        z2 = [km, _int, _u8p, _int, _u8p, _i8, _i8p, _i8, _i8, _int, _int, _int, _int, ezp]
+        d2 = [km, _int, _u8p, _int, _u8p, _i8, _i8p, _i8, _i8, _i8, _i8, _int, _int, _int, _int, ezp]
+        for name in ("ksw_extz2_sse", "ksw_extz2_sse41", "ksw_extz2_sse2"):
+            getattr(L, name).argtypes = z2
+            getattr(L, name).restype = None
+        for name in ("ksw_extd2_sse", "ksw_extd2_sse41", "ksw_extd2_sse2"):
+            getattr(L, name).argtypes = d2
+            getattr(L, name).restype = None
+        L.ksw_extz.argtypes = [km, _int, _u8p, _int, _u8p, _i8, _i8p, _i8, _i8, _int, _int, _int, ezp]
+        L.ksw_extz.restype = None
+        L.ksw_extd.argtypes = [km, _int, _u8p, _int, _u8p, _i8, _i8p, _i8, _i8, _i8, _i8, _int, _int, _int, ezp]
+        L.ksw_extd.restype = None
+        gg = [km, _int, _u8p, _int, _u8p, _i8, _i8p, _i8, _i8, _int, ctypes.POINTER(_int), ctypes.POINTER(_int),
+              ctypes.POINTER(ctypes.POINTER(ctypes.c_uint32))]
+        for name in ("ksw_gg", "ksw_gg2", "ksw_gg2_sse"):
+            getattr(L, name).argtypes = gg
+            getattr(L, name).restype = _int
+        L.ksw2amd_last_error.restype = ctypes.c_char_p
+        L.ksw2amd_backend.restype = ctypes.c_char_p
+        L.ksw2amd_set_device.argtypes = [_int]
+        bt = [km, ctypes.POINTER(Scoring), _int, ctypes.POINTER(Pair), ezp]
+        L.ksw2amd_extz_batch.argtypes = bt
+        L.ksw2amd_extd_batch.argtypes = bt
+        L.ksw2amd_plan_create.argtypes = [_int, ctypes.POINTER(Scoring), _int, ctypes.POINTER(Pair)]
+        L.ksw2amd_plan_create.restype = ctypes.c_void_p
+        L.ksw2amd_plan_run.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.ksw2amd_plan_fetch.argtypes = [ctypes.c_void_p, km, ezp]
+        L.ksw2amd_plan_destroy.argtypes = [ctypes.c_void_p]
+        L.ksw2amd_plan_destroy.restype = None
+        L.ksw2amd_plan_timing.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+        L.ksw2amd_plan_cells.argtypes = [ctypes.c_void_p]
+        L.ksw2amd_plan_cells.restype = ctypes.c_int64
+        L.ksw2amd_plan_device_bytes.argtypes = [ctypes.c_void_p]
+        L.ksw2amd_plan_device_bytes.restype = ctypes.c_int64
+        L.ksw2amd_plan_fetch_raw.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]
+
+    # ---- info
+    def backend(self):
+        return self.lib.ksw2amd_backend().decode()
+
+    def device_count(self):
+        return int(self.lib.ksw2amd_device_count())
+
+    def set_device(self, dev):
+        self._check(self.lib.ksw2amd_set_device(int(dev)))
+
+    def last_error(self):
+        return self.lib.ksw2amd_last_error().decode()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise Ksw2Error("libksw2_amd error %d: %s" % (rc, self.last_error()))
+
+    # ---- single-pair calls, signatures of ksw2.h:61-71
+    @staticmethod
+    def _seq(a):
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        return a, a.ctypes.data_as(_u8p)
+
+    def extz2(self, query, target, mat, q, e, w=-1, zdrop=-1, end_bonus=0, flag=0, m=None, ez=None):
+        """ksw_extz2_sse(km=NULL, ...) -> dict of ksw_extz_t fields (+ CIGAR list)."""
+        qa, qp = self._seq(query)
+        ta, tp = self._seq(target)
+        mat = np.ascontiguousarray(mat, dtype=np.int8)
+        m = int(round(len(mat) ** 0.5)) if m is None else m
+        own = ez is None
+        ez = KswExtz() if own else ez
+        self.lib.ksw_extz2_sse(None, len(qa), qp, len(ta), tp, m, mat.ctypes.data_as(_i8p), q, e, w, zdrop, end_bonus, flag, ez)
+        return ez_to_dict(ez, free_cigar=own)
+
+    def extd2(self, query, target, mat, q, e, q2, e2, w=-1, zdrop=-1, end_bonus=0, flag=0, m=None, ez=None):
+        qa, qp = self._seq(query)
+        ta, tp = self._seq(target)
+        mat = np.ascontiguousarray(mat, dtype=np.int8)
+        m = int(round(len(mat) ** 0.5)) if m is None else m
+        own = ez is None
+        ez = KswExtz() if own else ez
+        self.lib.ksw_extd2_sse(None, len(qa), qp, len(ta), tp, m, mat.ctypes.data_as(_i8p), q, e, q2, e2, w, zdrop, end_bonus, flag, ez)
+        return ez_to_dict(ez, free_cigar=own)
+
+    def extz(self, query, target, mat, q, e, w=-1, zdrop=-1, flag=0, m=None):
+        qa, qp = self._seq(query)
+        ta, tp = self._seq(target)
+        mat = np.ascontiguousarray(mat, dtype=np.int8)
+        m = int(round(len(mat) ** 0.5)) if m is None else m
+        ez = KswExtz()
+        self.lib.ksw_extz(None, len(qa), qp, len(ta), tp, m, mat.ctypes.data_as(_i8p), q, e, w, zdrop, flag, ez)
+        return ez_to_dict(ez, free_cigar=True)
+
+    def extd(self, query, target, mat, q, e, q2, e2, w=-1, zdrop=-1, flag=0, m=None):
+        qa, qp = self._seq(query)
+        ta, tp = self._seq(target)
+        mat = np.ascontiguousarray(mat, dtype=np.int8)
+        m = int(round(len(mat) ** 0.5)) if m is None else m
+        ez = KswExtz()
+        self.lib.ksw_extd(None, len(qa), qp, len(ta), tp, m, mat.ctypes.data_as(_i8p), q, e, q2, e2, w, zdrop, flag, ez)
+        return ez_to_dict(ez, free_cigar=True)
+
+    def gg(self, func, query, target, mat, q, e, w=-1, with_cigar=True, m=None):
+        """ksw_gg / ksw_gg2 / ksw_gg2_sse -> (score, CIGAR list)."""
+        qa, qp = self._seq(query)
+        ta, tp = self._seq(target)
+        mat = np.ascontiguousarray(mat, dtype=np.int8)
+        m = int(round(len(mat) ** 0.5)) if m is None else m
+        f = getattr(self.lib, "ksw_" + func)
+        mc, nc = _int(0), _int(0)
+        cig = ctypes.POINTER(ctypes.c_uint32)()
+        args = (None, len(qa), qp, len(ta), tp, m, mat.ctypes.data_as(_i8p), q, e, w)
+        if with_cigar:
+            score = f(*args, ctypes.byref(mc), ctypes.byref(nc), ctypes.byref(cig))
+        else:
+            score = f(*args, None, None, None)
+        out = [int(cig[i]) for i in range(nc.value)]
+        if cig:
+            _libc.free(ctypes.cast(cig, ctypes.c_void_p))
+        return int(score), out
+
+    # ---- batches
+    def make_batch(self, queries, targets, mat, q, e, q2=0, e2=0, w=-1, zdrop=-1, end_bonus=0, flag=0, m=None):
+        return Batch(self, queries, targets, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, m)
+
+    def extz_batch(self, queries, targets, mat, q, e, **kw):
+        b = self.make_batch(queries, targets, mat, q, e, 0, 0, **kw)
+        return b.run_oneshot(dual=False)
+
+    def extd_batch(self, queries, targets, mat, q, e, q2, e2, **kw):
+        b = self.make_batch(queries, targets, mat, q, e, q2, e2, **kw)
+        return b.run_oneshot(dual=True)
+
+
+def _per_pair(v, n):
+    a = np.asarray(v, dtype=np.int64)
+    if a.ndim == 0:
+        a = np.full(n, int(a), dtype=np.int64)
+    assert len(a) == n
+    return a
+
+
+class Batch:
+    """Host-side description of n pairs (the arguments of n ksw_ext?2_sse calls)."""
+
+    def __init__(self, lib, queries, targets, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, m):
+        self.L = lib
+        n = len(queries)
+        assert len(targets) == n
+        self.n = n
+        # keep the sequences alive: 2-D arrays are used row by row without copying
+        if isinstance(queries, np.ndarray) and queries.ndim == 2:
+            self.qa = np.ascontiguousarray(queries, dtype=np.uint8)
+            qptr = self.qa.ctypes.data + np.arange(n, dtype=np.int64) * self.qa.shape[1]
+            qlen = np.full(n, self.qa.shape[1], dtype=np.int64)
+        else:
+            self.qa = [np.ascontiguousarray(x, dtype=np.uint8) for x in queries]
+            qptr = np.array([x.ctypes.data for x in self.qa], dtype=np.int64)
+            qlen = np.array([len(x) for x in self.qa], dtype=np.int64)
+        if isinstance(targets, np.ndarray) and targets.ndim == 2:
+            self.ta = np.ascontiguousarray(targets, dtype=np.uint8)
+            tptr = self.ta.ctypes.data + np.arange(n, dtype=np.int64) * self.ta.shape[1]
+            tlen = np.full(n, self.ta.shape[1], dtype=np.int64)
+        else:
+            self.ta = [np.ascontiguousarray(x, dtype=np.uint8) for x in targets]
+            tptr = np.array([x.ctypes.data for x in self.ta], dtype=np.int64)
+            tlen = np.array([len(x) for x in self.ta], dtype=np.int64)
+        rec = np.zeros(n, dtype=np.dtype([("query", "<u8"), ("target", "<u8"), ("qlen", "<i4"), ("tlen", "<i4"), ("w", "<i4"),
+                                          ("zdrop", "<i4"), ("end_bonus", "<i4"), ("flag", "<i4")]))
+        assert rec.dtype.itemsize == ctypes.sizeof(Pair)
+        rec["query"], rec["target"], rec["qlen"], rec["tlen"] = qptr, tptr, qlen, tlen
+        rec["w"], rec["zdrop"] = _per_pair(w, n), _per_pair(zdrop, n)
+        rec["end_bonus"], rec["flag"] = _per_pair(end_bonus, n), _per_pair(flag, n)
+        self.rec = rec
+        self.pairs = rec.ctypes.data_as(ctypes.POINTER(Pair))
+        self.mat = np.ascontiguousarray(mat, dtype=np.int8)
+        self.sc = Scoring(int(round(len(self.mat) ** 0.5)) if m is None else m, self.mat.ctypes.data_as(_i8p), q, e, q2, e2)
+        self.qlen, self.tlen = qlen, tlen
+
+    def run_oneshot(self, dual):
+        """ksw2amd_ext?_batch: upload, run, download; list of result dicts."""
+        ez = (KswExtz * max(self.n, 1))()
+        f = self.L.lib.ksw2amd_extd_batch if dual else self.L.lib.ksw2amd_extz_batch
+        self.L._check(f(None, ctypes.byref(self.sc), self.n, self.pairs, ez))
+        return [ez_to_dict(ez[i], free_cigar=True) for i in range(self.n)]
+
+    def plan(self, dual):
+        return Plan(self, dual)
+
+
+class Plan:
+    """ksw2amd_plan_*: batch resident in HBM; run() enqueues kernels only."""
+
+    def __init__(self, batch, dual):
+        self.b, self.L = batch, batch.L
+        self.h = self.L.lib.ksw2amd_plan_create(1 if dual else 0, ctypes.byref(batch.sc), batch.n, batch.pairs)
+        if not self.h:
+            raise Ksw2Error("plan_create failed: " + self.L.last_error())
+
+    def run(self, stream=None):
+        self.L._check(self.L.lib.ksw2amd_plan_run(self.h, stream))
+
+    def timing(self):
+        a, b = ctypes.c_float(0), ctypes.c_float(0)
+        self.L._check(self.L.lib.ksw2amd_plan_timing(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def cells(self):
+        return int(self.L.lib.ksw2amd_plan_cells(self.h))
+
+    def device_bytes(self):
+        return int(self.L.lib.ksw2amd_plan_device_bytes(self.h))
+
+    def fetch(self):
+        ez = (KswExtz * max(self.b.n, 1))()
+        self.L._check(self.L.lib.ksw2amd_plan_fetch(self.h, None, ez))
+        return [ez_to_dict(ez[i], free_cigar=True) for i in range(self.b.n)]
+
+    def fetch_raw(self):
+        """int32 [n, 16]: max, zdropped, max_q, max_t, mqe, mqe_t, mte, mte_q, score, reach_end, n_cigar, rows_done, ti, tj, 0, 0"""
+        out = np.zeros((max(self.b.n, 1), 16), dtype=np.int32)
+        self.L._check(self.L.lib.ksw2amd_plan_fetch_raw(self.h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))
+        return out[:self.b.n]
+
+    def close(self):
+        if self.h:
+            self.L.lib.ksw2amd_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default = None
+
+
+def library():
+    """The product library (HIP).  Raises if it has not been built: there is no fallback."""
+    global _default
+    if _default is None:
+        _default = Library(DEFAULT_SO)
+    return _default

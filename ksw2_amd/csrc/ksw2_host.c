@@ -1,0 +1,585 @@
+/*
+ * ksw2_host.c -- C host side of libksw2_amd.so (the drop-in boundary, include/ksw2_amd.h).
+ *
+ * What lives here: argument checks and early rejects of the "...2_sse" signatures
+ * (ksw2_extz2_sse.c:56-82, ksw2_extd2_sse.c:75-100), the implicit match/mismatch/wildcard scoring
+ * (ksw2_extz2_sse.c:66-69,125-140), packing of a batch into device arenas, the choice of kernel
+ * geometry per pair, and the assembly of ksw_extz_t results including CIGAR buffer growth with the
+ * reference's doubling rule (ksw2.h:113-123) through libc or the caller's kalloc (ksw2.h:103-111).
+ * All DP work happens in the kernels behind ksw2_shim.h; there is no CPU alignment code in this file.
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/ksw2_amd.h"
+#include "ksw2_shim.h"
+
+#define F_SCALAR_CONTRACT 0x40000000   /* internal: call came through ksw_extz / ksw_extd / ksw_gg* */
+#define NCLS_MAX (K2A_NCFG * 3 * 2)
+
+static __thread char g_err[512];
+
+const char *ksw2amd_last_error(void) { return g_err; }
+const char *ksw2amd_backend(void) { return k2a_shim_backend(); }
+int ksw2amd_device_count(void) { return k2a_shim_device_count(); }
+
+static int fail(int code, const char *fmt, const char *detail)
+{
+	snprintf(g_err, sizeof(g_err), fmt, detail ? detail : "");
+	return code;
+}
+
+int ksw2amd_set_device(int device)
+{
+	if (k2a_shim_set_device(device)) return fail(KSW2AMD_E_NODEVICE, "set_device: %s", k2a_shim_last_error());
+	return KSW2AMD_OK;
+}
+
+/* ---------------------------------------------------------------- CIGAR memory */
+
+typedef void *(*krealloc_fn)(void *km, void *p, size_t size);
+
+static void *cigar_realloc(void *km, void *p, size_t size)
+{
+	static krealloc_fn kr = 0;
+	if (km == 0) return realloc(p, size);
+	if (kr == 0) kr = (krealloc_fn)dlsym(RTLD_DEFAULT, "krealloc");
+	if (kr == 0) {
+		fprintf(stderr, "[ksw2_amd] km != NULL but the process exports no krealloc() (kalloc.h:14)\n");
+		abort();
+	}
+	return kr(km, p, size);
+}
+
+static void ez_reset(ksw_extz_t *ez)           /* ksw2.h:184-189; cigar and m_cigar survive */
+{
+	ez->max_q = ez->max_t = ez->mqe_t = ez->mte_q = -1;
+	ez->max = 0; ez->score = ez->mqe = ez->mte = KSW_NEG_INF;
+	ez->n_cigar = 0; ez->zdropped = 0; ez->reach_end = 0;
+}
+
+static void ez_reserve(void *km, ksw_extz_t *ez, int n)   /* capacity sequence of ksw_push_cigar, ksw2.h:116-119 */
+{
+	int m = ez->m_cigar;
+	if (n <= m) return;
+	while (m < n) m = m ? m << 1 : 4;
+	ez->cigar = (uint32_t*)cigar_realloc(km, ez->cigar, (size_t)m << 2);
+	ez->m_cigar = m;
+}
+
+/* ---------------------------------------------------------------- plan */
+
+typedef struct {
+	int cfg, mode, generic, first, count;
+	K2aScoring sc;
+} cls_t;
+
+struct ksw2amd_plan_s {
+	int dual, n, reject_all, ran, ncls;
+	int m;
+	K2aPair *h_pairs;
+	int8_t *h_cls;                 /* class index per pair, -1 = rejected before the device */
+	int32_t *h_flag;               /* caller's flag per pair */
+	uint32_t *h_order;
+	int ntasks;
+	cls_t cls[NCLS_MAX];
+	uint8_t *h_seq;
+	size_t seq_bytes, tb_bytes, cig_words;
+	uint8_t *d_seq, *d_tb;
+	K2aPair *d_pairs;
+	K2aResult *d_res, *h_res;
+	uint32_t *d_order, *d_cig;
+	void *ev[3];
+	void *stream;
+	int64_t cells;
+};
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static int imin(int a, int b) { return a < b ? a : b; }
+static int imax(int a, int b) { return a > b ? a : b; }
+
+static int64_t band_cells(int qlen, int tlen, int w)
+{
+	int64_t n = 0;
+	int i;
+	for (i = 0; i < tlen; ++i) {
+		int st = imax(0, i - w), en = imin(qlen - 1, i + w);
+		if (st <= en) n += en - st + 1;
+	}
+	return n;
+}
+
+/* does a (G,C) systolic array hold the band?  all strips resident at once, or a lane is done with
+ * strip S before strip S+G starts */
+static int cfg_fits(int cfg, int tlen_eff, int w)
+{
+	const int G = k2a_cfg_G[cfg], C = k2a_cfg_C[cfg];
+	const int nstrips = (tlen_eff + C - 1) / C;
+	return nstrips <= G || 2 * (int64_t)w < (int64_t)G * (C + 1) - C + 1;
+}
+
+static void build_scoring(int dual, int m, const int8_t *mat, int q, int e, int q2, int e2, int generic, K2aScoring *sc)
+{
+	int8_t eff[25];
+	int a, b;
+	memset(sc, 0, sizeof(*sc));
+	sc->q = q; sc->e = e; sc->q2 = dual ? q2 : 0; sc->e2 = dual ? e2 : 0;
+	if (generic) memcpy(eff, mat, (size_t)m * m);
+	else {   /* ksw2_extz2_sse.c:66-69,125-140; ksw2_extd2_sse.c:85-88,166-180 */
+		int scN = mat[m * m - 1] == 0 ? -(dual ? e2 : e) : mat[m * m - 1];
+		for (a = 0; a < m; ++a)
+			for (b = 0; b < m; ++b)
+				eff[a * m + b] = (int8_t)((a == m - 1 || b == m - 1) ? scN : a == b ? mat[0] : mat[1]);
+	}
+	for (a = 0; a < m; ++a) {
+		uint32_t p = 0;
+		for (b = 0; b < 4 && b < m; ++b) p |= (uint32_t)(uint8_t)eff[a * m + b] << (8 * b);
+		sc->prof[a] = p;
+		sc->colw[a] = m == 5 ? eff[a * m + 4] : 0;
+	}
+}
+
+void ksw2amd_plan_destroy(ksw2amd_plan_t *p)
+{
+	int i;
+	if (!p) return;
+	k2a_shim_free(p->d_seq); k2a_shim_free(p->d_tb); k2a_shim_free(p->d_pairs); k2a_shim_free(p->d_res);
+	k2a_shim_free(p->d_order); k2a_shim_free(p->d_cig);
+	for (i = 0; i < 3; ++i) if (p->ev[i]) k2a_shim_event_destroy(p->ev[i]);
+	free(p->h_pairs); free(p->h_cls); free(p->h_flag); free(p->h_order); free(p->h_seq); free(p->h_res);
+	free(p);
+}
+
+typedef struct { int64_t cost; uint32_t idx; } sort_t;
+static int cmp_cost_desc(const void *a, const void *b)
+{
+	const sort_t *x = (const sort_t*)a, *y = (const sort_t*)b;
+	if (x->cost != y->cost) return x->cost > y->cost ? -1 : 1;
+	return x->idx < y->idx ? -1 : x->idx > y->idx;
+}
+
+ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs)
+{
+	ksw2amd_plan_t *p;
+	int i, k, q, e, q2, e2, m, lo, ci;
+	size_t off;
+	sort_t *srt = 0;
+	int cls_count[NCLS_MAX], cls_fill[NCLS_MAX];
+
+	g_err[0] = 0;
+	if (n < 0 || (n > 0 && !pairs) || !sc) { fail(KSW2AMD_E_PARAM, "plan_create: bad arguments%s", 0); return 0; }
+	if (k2a_shim_device_count() <= 0) { fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend()); return 0; }
+	p = (ksw2amd_plan_t*)calloc(1, sizeof(*p));
+	p->dual = !!dual; p->n = n; p->m = m = sc->m;
+	q = sc->q; e = sc->e; q2 = sc->q2; e2 = sc->e2;
+	p->h_cls = (int8_t*)malloc((size_t)n + 1);
+	p->h_flag = (int32_t*)malloc(sizeof(int32_t) * ((size_t)n + 1));
+	p->h_pairs = (K2aPair*)calloc((size_t)n + 1, sizeof(K2aPair));
+	p->h_res = (K2aResult*)calloc((size_t)n + 1, sizeof(K2aResult));
+	for (i = 0; i < n; ++i) { p->h_cls[i] = -1; p->h_flag[i] = pairs[i].flag; }
+
+	/* batch-level early rejects of the "...2_sse" signatures; the scalar-contract entry points skip the
+	 * mismatch-vs-gap test (ksw_extz has none) but still need a usable matrix */
+	{
+		int scalar = n > 0 && (pairs[0].flag & F_SCALAR_CONTRACT);
+		if (m <= 0 || (dual && m <= 1) || !sc->mat) p->reject_all = 1;
+		else if (m > 5) { fail(KSW2AMD_E_PARAM, "m > 5 residue types is not supported by this release%s", 0); goto err; }
+		else {
+			/* ksw2_extd2_sse.c:78: cheaper-to-open piece first (the scalar ksw_extd keeps the caller's order) */
+			if (dual && !scalar && q2 + e2 < q + e) { int t = q; q = q2; q2 = t; t = e; e = e2; e2 = t; }
+			for (k = 1, lo = sc->mat[m * m > 1 ? 1 : 0]; k < m * m; ++k) lo = imin(lo, sc->mat[k]);
+			if (!scalar && -lo > 2 * (q + e)) p->reject_all = 1;                                     /* ksw2_extz2_sse.c:78-82 */
+		}
+	}
+	if (p->reject_all || n == 0) return p;
+
+	/* classify */
+	memset(cls_count, 0, sizeof(cls_count));
+	off = 0;
+	for (i = 0; i < n; ++i) {
+		const ksw2amd_pair_t *a = &pairs[i];
+		K2aPair *d = &p->h_pairs[i];
+		int w = a->w, cfg, mode, generic, mx;
+		if (a->qlen <= 0 || a->tlen <= 0) continue;                                                 /* ksw2_extz2_sse.c:57 */
+		if (!a->query || !a->target) { fail(KSW2AMD_E_PARAM, "plan_create: NULL sequence%s", 0); goto err; }
+		mx = imax(a->qlen, a->tlen);
+		if (w < 0 || w > mx) w = mx;                                                               /* ksw2_extz2_sse.c:72 */
+		d->qlen = a->qlen; d->tlen_full = a->tlen; d->w = w;
+		d->tlen = (int64_t)a->qlen + w < a->tlen ? a->qlen + w : a->tlen;      /* rows i with i-w <= qlen-1 */
+		d->zdrop = a->zdrop;
+		d->end_bonus = (a->flag & F_SCALAR_CONTRACT) ? K2A_NEG : a->end_bonus;
+		d->flag = a->flag & (KSW_EZ_EXTZ_ONLY | KSW_EZ_REV_CIGAR | KSW_EZ_SCORE_ONLY);
+		for (cfg = 0; cfg < K2A_NCFG; ++cfg) if (cfg_fits(cfg, d->tlen, w)) break;
+		if (cfg == K2A_NCFG) {
+			snprintf(g_err, sizeof(g_err), "pair %d: band %d on %d target rows exceeds the resident-band kernels of this release", i, w, d->tlen);
+			goto err;
+		}
+		mode = (a->flag & KSW_EZ_SCORE_ONLY) ? K2A_MODE_SCORE : (a->flag & KSW_EZ_RIGHT) ? K2A_MODE_RIGHT : K2A_MODE_LEFT;
+		generic = (a->flag & (KSW_EZ_GENERIC_SC | F_SCALAR_CONTRACT)) ? 1 : 0;
+		ci = (cfg * 3 + mode) * 2 + generic;
+		p->h_cls[i] = (int8_t)ci;
+		++cls_count[ci];
+		/* sequence arena: query 4-aligned, target 16-aligned and readable one strip past its end */
+		off = align_up(off, 4); d->qoff = (uint32_t)off; off += (size_t)a->qlen;
+		off = align_up(off, 16); d->toff = (uint32_t)off; off += (size_t)a->tlen + 64;
+		if (off > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "plan_create: more than 4 GiB of sequence in one plan%s", 0); goto err; }
+		p->cells += band_cells(a->qlen, a->tlen, w);
+		/* traceback block and CIGAR scratch */
+		if (mode != K2A_MODE_SCORE) {
+			const int G = k2a_cfg_G[cfg], C = k2a_cfg_C[cfg];
+			const int nstrips = (d->tlen + C - 1) / C;
+			const size_t steps = (size_t)(nstrips - 1) + (size_t)imin(a->qlen - 1, d->tlen - 1 + w) + 1;
+			const size_t wb = (size_t)C * (dual ? 8 : 4) / 8;
+			d->tb_off = p->tb_bytes;
+			p->tb_bytes += align_up(steps * G * wb, 256);
+			d->cig_off = (uint32_t)p->cig_words;
+			p->cig_words += (size_t)a->qlen + a->tlen + 2;
+			if (p->cig_words > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "plan_create: CIGAR scratch over 16 GiB in one plan%s", 0); goto err; }
+		}
+	}
+	p->seq_bytes = align_up(off + 64, 256);
+
+	/* task lists per class, most expensive first (similar shapes end up in the same wavefront) */
+	p->ncls = 0;
+	for (ci = 0, k = 0; ci < NCLS_MAX; ++ci) {
+		cls_fill[ci] = -1;
+		if (cls_count[ci] == 0) continue;
+		cls_t *c = &p->cls[p->ncls];
+		c->cfg = ci / 6; c->mode = (ci / 2) % 3; c->generic = ci & 1; c->first = k; c->count = cls_count[ci];
+		build_scoring(dual, m, sc->mat, q, e, q2, e2, c->generic, &c->sc);
+		cls_fill[ci] = p->ncls++;
+		k += cls_count[ci];
+	}
+	p->ntasks = k;
+	p->h_order = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)k + 1));
+	srt = (sort_t*)malloc(sizeof(sort_t) * ((size_t)n + 1));
+	for (ci = 0; ci < NCLS_MAX; ++ci) {
+		int cnt = 0;
+		if (cls_fill[ci] < 0) continue;
+		for (i = 0; i < n; ++i)
+			if (p->h_cls[i] == ci) {
+				srt[cnt].idx = (uint32_t)i;
+				srt[cnt].cost = ((int64_t)p->h_pairs[i].qlen << 40) + ((int64_t)p->h_pairs[i].tlen << 16) + p->h_pairs[i].w;
+				++cnt;
+			}
+		qsort(srt, (size_t)cnt, sizeof(sort_t), cmp_cost_desc);
+		for (i = 0; i < cnt; ++i) p->h_order[p->cls[cls_fill[ci]].first + i] = srt[i].idx;
+	}
+	free(srt); srt = 0;
+
+	/* pack + upload */
+	p->h_seq = (uint8_t*)calloc(p->seq_bytes, 1);
+	for (i = 0; i < n; ++i) {
+		if (p->h_cls[i] < 0) continue;
+		memcpy(p->h_seq + p->h_pairs[i].qoff, pairs[i].query, (size_t)pairs[i].qlen);
+		memcpy(p->h_seq + p->h_pairs[i].toff, pairs[i].target, (size_t)pairs[i].tlen);
+	}
+	p->d_seq = (uint8_t*)k2a_shim_malloc(p->seq_bytes);
+	p->d_pairs = (K2aPair*)k2a_shim_malloc(sizeof(K2aPair) * ((size_t)n + 1));
+	p->d_res = (K2aResult*)k2a_shim_malloc(sizeof(K2aResult) * ((size_t)n + 1));
+	p->d_order = (uint32_t*)k2a_shim_malloc(sizeof(uint32_t) * ((size_t)p->ntasks + 1));
+	p->d_tb = p->tb_bytes ? (uint8_t*)k2a_shim_malloc(p->tb_bytes) : 0;
+	p->d_cig = p->cig_words ? (uint32_t*)k2a_shim_malloc(p->cig_words * 4) : 0;
+	if (!p->d_seq || !p->d_pairs || !p->d_res || !p->d_order || (p->tb_bytes && !p->d_tb) || (p->cig_words && !p->d_cig)) {
+		fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error());
+		goto err;
+	}
+	if (k2a_shim_h2d(p->d_seq, p->h_seq, p->seq_bytes, 0) || k2a_shim_h2d(p->d_pairs, p->h_pairs, sizeof(K2aPair) * (size_t)n, 0) ||
+	    k2a_shim_h2d(p->d_order, p->h_order, sizeof(uint32_t) * (size_t)p->ntasks, 0) ||
+	    k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)n, 0) || k2a_shim_stream_sync(0)) {
+		fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error());
+		goto err;
+	}
+	for (i = 0; i < 3; ++i) p->ev[i] = k2a_shim_event_create();
+	return p;
+err:
+	free(srt);
+	ksw2amd_plan_destroy(p);
+	return 0;
+}
+
+int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
+{
+	int c;
+	if (!p) return fail(KSW2AMD_E_PARAM, "plan_run: NULL plan%s", 0);
+	p->stream = stream; p->ran = 1;
+	if (p->reject_all || p->ntasks == 0) return KSW2AMD_OK;
+	if (k2a_shim_event_record(p->ev[0], stream)) goto err;
+	for (c = 0; c < p->ncls; ++c) {
+		const cls_t *k = &p->cls[c];
+		if (k2a_shim_launch_fill(k->cfg, p->dual, k->mode, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
+		                         p->d_res, stream)) goto err;
+	}
+	if (k2a_shim_event_record(p->ev[1], stream)) goto err;
+	for (c = 0; c < p->ncls; ++c) {
+		const cls_t *k = &p->cls[c];
+		if (k->mode == K2A_MODE_SCORE) continue;
+		if (k2a_shim_launch_trace(k->cfg, p->dual, p->d_pairs, p->d_order + k->first, k->count, p->d_tb, p->d_res, p->d_cig, stream)) goto err;
+	}
+	if (k2a_shim_event_record(p->ev[2], stream)) goto err;
+	return KSW2AMD_OK;
+err:
+	return fail(KSW2AMD_E_NODEVICE, "plan_run: %s", k2a_shim_last_error());
+}
+
+int ksw2amd_plan_timing(ksw2amd_plan_t *p, float *fill_ms, float *total_ms)
+{
+	if (!p || !p->ran) return fail(KSW2AMD_E_PARAM, "plan_timing: plan has not run%s", 0);
+	if (p->reject_all || p->ntasks == 0) { if (fill_ms) *fill_ms = 0; if (total_ms) *total_ms = 0; return KSW2AMD_OK; }
+	if (fill_ms) *fill_ms = k2a_shim_event_ms(p->ev[0], p->ev[1]);
+	if (total_ms) *total_ms = k2a_shim_event_ms(p->ev[0], p->ev[2]);
+	return KSW2AMD_OK;
+}
+
+int64_t ksw2amd_plan_cells(const ksw2amd_plan_t *p) { return p ? p->cells : 0; }
+int64_t ksw2amd_plan_device_bytes(const ksw2amd_plan_t *p)
+{
+	if (!p) return 0;
+	return (int64_t)(p->seq_bytes + p->tb_bytes + p->cig_words * 4 + (sizeof(K2aPair) + sizeof(K2aResult)) * (size_t)p->n + 4 * (size_t)p->ntasks);
+}
+
+static int fetch_results(ksw2amd_plan_t *p)
+{
+	if (!p || !p->ran) return fail(KSW2AMD_E_PARAM, "plan_fetch: plan has not run%s", 0);
+	if (p->reject_all || p->ntasks == 0) return KSW2AMD_OK;
+	if (k2a_shim_stream_sync(p->stream) || k2a_shim_d2h(p->h_res, p->d_res, sizeof(K2aResult) * (size_t)p->n, p->stream) ||
+	    k2a_shim_stream_sync(p->stream))
+		return fail(KSW2AMD_E_NODEVICE, "plan_fetch: %s", k2a_shim_last_error());
+	return KSW2AMD_OK;
+}
+
+int ksw2amd_plan_fetch_raw(ksw2amd_plan_t *p, int32_t *out16)
+{
+	int i, rc = fetch_results(p);
+	if (rc) return rc;
+	memset(out16, 0, sizeof(int32_t) * 16 * (size_t)p->n);
+	for (i = 0; i < p->n; ++i)
+		if (p->h_cls[i] >= 0 && !p->reject_all) memcpy(out16 + 16 * (size_t)i, &p->h_res[i], sizeof(K2aResult));
+		else {
+			int32_t *o = out16 + 16 * (size_t)i;
+			o[2] = o[3] = o[5] = o[7] = -1; o[4] = o[6] = o[8] = KSW_NEG_INF; o[12] = o[13] = -1;
+		}
+	return KSW2AMD_OK;
+}
+
+/* M runs -> =/X runs (KSW_EZ_EQX, ksw2_extd2_sse.c:399-406 / ksw2.h:163-182) */
+static void eqx_rewrite(void *km, const uint8_t *query, const uint8_t *target, ksw_extz_t *ez)
+{
+	int n0 = ez->n_cigar, k, i, x = 0, y = 0, n = 0;
+	uint32_t *old = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n0 + 1));
+	memcpy(old, ez->cigar, sizeof(uint32_t) * (size_t)n0);
+	ez->n_cigar = 0;
+	for (k = 0; k < n0; ++k) {
+		uint32_t op = old[k] & 0xf, len = old[k] >> 4;
+		if (op == KSW_CIGAR_MATCH) {
+			for (i = 0; i < (int)len; ++i) {
+				uint32_t o = target[x + i] == query[y + i] ? KSW_CIGAR_EQ : KSW_CIGAR_X;
+				if (n > 0 && (ez->cigar[n - 1] & 0xf) == o) ez->cigar[n - 1] += 1u << 4;
+				else { ez_reserve(km, ez, n + 1); ez->cigar[n++] = 1u << 4 | o; }
+			}
+			x += (int)len; y += (int)len;
+		} else {
+			if (n > 0 && (ez->cigar[n - 1] & 0xf) == op) ez->cigar[n - 1] += len << 4;
+			else { ez_reserve(km, ez, n + 1); ez->cigar[n++] = len << 4 | op; }
+			if (op == KSW_CIGAR_DEL || op == KSW_CIGAR_N_SKIP) x += (int)len;
+			else if (op == KSW_CIGAR_INS) y += (int)len;
+		}
+	}
+	ez->n_cigar = n;
+	free(old);
+}
+
+int ksw2amd_plan_fetch(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez)
+{
+	int i, rc = fetch_results(p);
+	uint32_t *pool = 0;
+	size_t total = 0, *pos = 0;
+	if (rc) return rc;
+	if (!p->reject_all && p->cig_words) {
+		/* bring every CIGAR back with one D2H: prefix-sum the counts, compact on the device, download the pool */
+		uint32_t *hpos = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)p->n + 1)), *d_pos = 0, *d_pool = 0;
+		int bad = 0;
+		pos = (size_t*)malloc(sizeof(size_t) * ((size_t)p->n + 1));
+		for (i = 0; i < p->n; ++i) {
+			if (p->h_cls[i] < 0) p->h_res[i].n_cigar = 0;
+			pos[i] = total; hpos[i] = (uint32_t)total;
+			total += (size_t)p->h_res[i].n_cigar;
+		}
+		pool = (uint32_t*)malloc(sizeof(uint32_t) * (total + 1));
+		if (total > 0) {
+			d_pos = (uint32_t*)k2a_shim_malloc(sizeof(uint32_t) * (size_t)p->n);
+			d_pool = (uint32_t*)k2a_shim_malloc(sizeof(uint32_t) * total);
+			bad = !d_pos || !d_pool || total > 0xfff00000u ||
+			      k2a_shim_h2d(d_pos, hpos, sizeof(uint32_t) * (size_t)p->n, p->stream) ||
+			      k2a_shim_launch_compact(p->d_pairs, p->d_res, d_pos, p->n, p->d_cig, d_pool, p->stream) ||
+			      k2a_shim_d2h(pool, d_pool, sizeof(uint32_t) * total, p->stream) || k2a_shim_stream_sync(p->stream);
+			k2a_shim_free(d_pos); k2a_shim_free(d_pool);
+		}
+		free(hpos);
+		if (bad) { free(pos); free(pool); return fail(KSW2AMD_E_NODEVICE, "plan_fetch: %s", k2a_shim_last_error()); }
+	}
+	for (i = 0; i < p->n; ++i) {
+		ksw_extz_t *z = &ez[i];
+		const K2aResult *r = &p->h_res[i];
+		ez_reset(z);
+		if (p->reject_all || p->h_cls[i] < 0) continue;
+		z->max = (uint32_t)r->max; z->zdropped = (uint32_t)r->zdropped;
+		z->max_q = r->max_q; z->max_t = r->max_t; z->mqe = r->mqe; z->mqe_t = r->mqe_t;
+		z->mte = r->mte; z->mte_q = r->mte_q; z->score = r->score; z->reach_end = r->reach_end;
+		if (r->n_cigar > 0) {
+			const uint32_t *src = pool + pos[i];
+			int k, nc = r->n_cigar;
+			ez_reserve(km, z, nc);
+			if (p->h_flag[i] & KSW_EZ_REV_CIGAR) memcpy(z->cigar, src, sizeof(uint32_t) * (size_t)nc);
+			else for (k = 0; k < nc; ++k) z->cigar[k] = src[nc - 1 - k];        /* ksw2.h:157-159 */
+			z->n_cigar = nc;
+			if (p->dual && (p->h_flag[i] & KSW_EZ_EQX) && !(p->h_flag[i] & F_SCALAR_CONTRACT))
+				eqx_rewrite(km, p->h_seq + p->h_pairs[i].qoff, p->h_seq + p->h_pairs[i].toff, z);
+		}
+	}
+	free(pos); free(pool);
+	return KSW2AMD_OK;
+}
+
+/* ---------------------------------------------------------------- batch entry points */
+
+static size_t pair_device_bytes(int dual, const ksw2amd_pair_t *a)
+{
+	/* upper bound of what plan_create allocates for this pair */
+	size_t b = (size_t)imax(a->qlen, 0) + (size_t)imax(a->tlen, 0) + 96 + sizeof(K2aPair) + sizeof(K2aResult) + 4;
+	if (a->qlen > 0 && a->tlen > 0 && !(a->flag & KSW_EZ_SCORE_ONLY)) {
+		int mx = imax(a->qlen, a->tlen), w = (a->w < 0 || a->w > mx) ? mx : a->w;
+		size_t steps = (size_t)a->qlen + (size_t)a->tlen / 8 + 2;
+		size_t lanes = (size_t)imin(64, (2 * w + 16) / 9 + 2);
+		(void)lanes;
+		b += steps * 64 * (dual ? 32 : 16) / (w <= 68 ? 8 : w <= 284 ? 4 : w <= 536 ? 2 : 1) + 256;
+		b += ((size_t)a->qlen + a->tlen + 2) * 4;
+	}
+	return b;
+}
+
+static int run_batch(int dual, void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez)
+{
+	size_t budget, free_b = 0, total_b = 0, acc;
+	const char *env = getenv("KSW2AMD_MAX_BYTES");
+	int beg = 0, end;
+	if (n <= 0) return KSW2AMD_OK;
+	if (k2a_shim_device_count() <= 0) return fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend());
+	if (k2a_shim_mem_info(&free_b, &total_b)) return fail(KSW2AMD_E_NODEVICE, "mem_info: %s", k2a_shim_last_error());
+	budget = free_b / 10 * 7;
+	if (env && atoll(env) > 0) budget = (size_t)atoll(env);
+	while (beg < n) {
+		ksw2amd_plan_t *p;
+		int rc;
+		for (end = beg, acc = 0; end < n; ++end) {
+			size_t b = pair_device_bytes(dual, &pairs[end]);
+			if (end > beg && (acc + b > budget || end - beg >= (1 << 22))) break;
+			acc += b;
+		}
+		p = ksw2amd_plan_create(dual, sc, end - beg, pairs + beg);
+		if (!p) return g_err[0] ? (strstr(g_err, "alloc") ? KSW2AMD_E_NOMEM : KSW2AMD_E_PARAM) : KSW2AMD_E_PARAM;
+		rc = ksw2amd_plan_run(p, 0);
+		if (rc == KSW2AMD_OK) rc = ksw2amd_plan_fetch(p, km, ez + beg);
+		ksw2amd_plan_destroy(p);
+		if (rc) return rc;
+		beg = end;
+	}
+	return KSW2AMD_OK;
+}
+
+int ksw2amd_extz_batch(void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez)
+{
+	return run_batch(0, km, sc, n, pairs, ez);
+}
+
+int ksw2amd_extd_batch(void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez)
+{
+	return run_batch(1, km, sc, n, pairs, ez);
+}
+
+/* ---------------------------------------------------------------- the ksw2-named single-pair calls */
+
+static void die_loudly(const char *fn)
+{
+	fprintf(stderr, "[ksw2_amd] %s: %s -- libksw2_amd has no CPU fallback, aborting\n", fn, g_err);
+	abort();
+}
+
+static void one_pair(const char *fn, int dual, void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m,
+                     const int8_t *mat, int8_t q, int8_t e, int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag,
+                     ksw_extz_t *ez)
+{
+	ksw2amd_scoring_t sc;
+	ksw2amd_pair_t pr;
+	sc.m = m; sc.mat = mat; sc.q = q; sc.e = e; sc.q2 = q2; sc.e2 = e2;
+	pr.query = query; pr.target = target; pr.qlen = qlen; pr.tlen = tlen;
+	pr.w = w; pr.zdrop = zdrop; pr.end_bonus = end_bonus; pr.flag = flag;
+	if (run_batch(dual, km, &sc, 1, &pr, ez) != KSW2AMD_OK) die_loudly(fn);
+}
+
+void ksw_extz2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                   int8_t q, int8_t e, int w, int zdrop, int end_bonus, int flag, ksw_extz_t *ez)
+{
+	one_pair("ksw_extz2_sse", 0, km, qlen, query, tlen, target, m, mat, q, e, 0, 0, w, zdrop, end_bonus, flag & ~F_SCALAR_CONTRACT, ez);
+}
+
+void ksw_extd2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                   int8_t q, int8_t e, int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, ksw_extz_t *ez)
+{
+	one_pair("ksw_extd2_sse", 1, km, qlen, query, tlen, target, m, mat, q, e, q2, e2, w, zdrop, end_bonus, flag & ~F_SCALAR_CONTRACT, ez);
+}
+
+void ksw_extz2_sse41(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                     int8_t q, int8_t e, int w, int zdrop, int end_bonus, int flag, ksw_extz_t *ez)
+{ ksw_extz2_sse(km, qlen, query, tlen, target, m, mat, q, e, w, zdrop, end_bonus, flag, ez); }
+void ksw_extz2_sse2(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                    int8_t q, int8_t e, int w, int zdrop, int end_bonus, int flag, ksw_extz_t *ez)
+{ ksw_extz2_sse(km, qlen, query, tlen, target, m, mat, q, e, w, zdrop, end_bonus, flag, ez); }
+void ksw_extd2_sse41(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                     int8_t q, int8_t e, int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, ksw_extz_t *ez)
+{ ksw_extd2_sse(km, qlen, query, tlen, target, m, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez); }
+void ksw_extd2_sse2(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                    int8_t q, int8_t e, int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, ksw_extz_t *ez)
+{ ksw_extd2_sse(km, qlen, query, tlen, target, m, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez); }
+
+/* scalar-named entry points: matrix always used as given, no end bonus, no mismatch-vs-gap reject */
+void ksw_extz(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+              int8_t q, int8_t e, int w, int zdrop, int flag, ksw_extz_t *ez)
+{
+	one_pair("ksw_extz", 0, km, qlen, query, tlen, target, m, mat, q, e, 0, 0, w, zdrop, 0, flag | F_SCALAR_CONTRACT, ez);
+}
+
+void ksw_extd(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+              int8_t q, int8_t e, int8_t q2, int8_t e2, int w, int zdrop, int flag, ksw_extz_t *ez)
+{
+	one_pair("ksw_extd", 1, km, qlen, query, tlen, target, m, mat, q, e, q2, e2, w, zdrop, 0, flag | F_SCALAR_CONTRACT, ez);
+}
+
+static int global_align(const char *fn, void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m,
+                        const int8_t *mat, int8_t q, int8_t e, int w, int *m_cigar_, int *n_cigar_, uint32_t **cigar_)
+{
+	/* ksw2_gg.c:6-102 == extension kernel with Z-drop off, matrix scoring, left-aligned gaps, corner start */
+	ksw_extz_t ez;
+	const int with_cigar = m_cigar_ && n_cigar_ && cigar_;
+	memset(&ez, 0, sizeof(ez));
+	if (with_cigar) { ez.cigar = *cigar_; ez.m_cigar = *m_cigar_; *n_cigar_ = 0; }
+	one_pair(fn, 0, km, qlen, query, tlen, target, m, mat, q, e, 0, 0, w, -1, 0,
+	         (with_cigar ? 0 : KSW_EZ_SCORE_ONLY) | F_SCALAR_CONTRACT, &ez);
+	if (with_cigar) {
+		*cigar_ = ez.cigar; *m_cigar_ = ez.m_cigar;
+		*n_cigar_ = ez.zdropped ? 0 : ez.n_cigar;
+	}
+	return ez.zdropped ? KSW_NEG_INF : ez.score;
+}
+
+int ksw_gg(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+           int8_t q, int8_t e, int w, int *m_cigar_, int *n_cigar_, uint32_t **cigar_)
+{ return global_align("ksw_gg", km, qlen, query, tlen, target, m, mat, q, e, w, m_cigar_, n_cigar_, cigar_); }
+int ksw_gg2(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+            int8_t q, int8_t e, int w, int *m_cigar_, int *n_cigar_, uint32_t **cigar_)
+{ return global_align("ksw_gg2", km, qlen, query, tlen, target, m, mat, q, e, w, m_cigar_, n_cigar_, cigar_); }
+int ksw_gg2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                int8_t q, int8_t e, int w, int *m_cigar_, int *n_cigar_, uint32_t **cigar_)
+{ return global_align("ksw_gg2_sse", km, qlen, query, tlen, target, m, mat, q, e, w, m_cigar_, n_cigar_, cigar_); }

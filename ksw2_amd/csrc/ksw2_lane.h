@@ -1,0 +1,348 @@
+/*
+ * ksw2_lane.h -- per-lane code of the MI355X banded extension kernels (extz2 / extd2 / gg2 hot path).
+ *
+ * Replaces the per-diagonal inner loops of ksw_extz2_sse (ksw2_extz2_sse.c:101-289) and
+ * ksw_extd2_sse (ksw2_extd2_sse.c:131-387); results follow the exact-band / row-wise Z-drop contract
+ * of the scalar ksw_extz / ksw_extd (ksw2_extz.c:38-125, ksw2_extd.c:44-165).
+ *
+ * Mapping: one alignment per lane group of G lanes (G = 64: one per wavefront,
+ * G = 16: four per wavefront).  Target rows are cut into strips of C consecutive rows; strip S is owned
+ * by lane S mod G and walks the query one column per step, skewed by one step per strip:
+ *
+ *        step k, strip S  ->  column jj = k - S, rows S*C .. S*C+C-1
+ *
+ * so all active lanes sit on one anti-diagonal of the (strip, column) grid.  Inside a lane the C rows
+ * are a register-resident chain (E and the diagonal H flow down the rows without any lane traffic);
+ * between lanes only the bottom row's (H, E[, E~]) moves, one lane up per step (DPP rotate).  Each row
+ * keeps int32 H(i, jj-1), F, running row maximum and arg-max in registers, so the scalar reference's
+ * per-row bookkeeping (mqe, mte, Z-drop, score) falls out in row order when a strip finishes.
+ *
+ * The file is plain C++: the HIP kernel (ksw2_kernels.hip) instantiates it per thread; tests/sim
+ * instantiates the same code on the host, 64 "lanes" in lock step, to check the schedule without a GPU.
+ */
+#ifndef KSW2_LANE_H_
+#define KSW2_LANE_H_
+
+#include <stdint.h>
+
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+#define K2A_FN __device__ __forceinline__
+#else
+#define K2A_FN inline
+#endif
+
+#include "ksw2_types.h"
+
+K2A_FN int k2a_min(int a, int b) { return a < b ? a : b; }
+K2A_FN int k2a_max(int a, int b) { return a > b ? a : b; }
+K2A_FN int k2a_max3(int a, int b, int c) { return k2a_max(k2a_max(a, b), c); }
+
+/* H on the virtual row -1 / column -1 at distance k >= 0 from the origin */
+template<bool DUAL>
+K2A_FN int k2a_border(const K2aScoring &sc, int k)
+{
+	int a = -(sc.q + k * sc.e);
+	if (DUAL) { int b = -(sc.q2 + k * sc.e2); a = a > b ? a : b; }
+	return k <= 0 ? 0 : a;
+}
+
+K2A_FN void k2a_book_reset(K2aBook *b)
+{
+	b->max = 0; b->max_t = b->max_q = b->mqe_t = b->mte_q = -1;
+	b->mqe = b->mte = b->score = K2A_NEG; b->dropped = 0; b->rows = 0;
+}
+
+/* traceback cell encodings (our own layout; the walk in k2a_trace_pair() is the only reader)
+ *   single gap (4 bits): bits 0-1 winner {0 diag, 1 E, 2 F}, bit 2 E continues, bit 3 F continues
+ *   dual gap   (8 bits): bits 0-2 winner {0..4}, bits 3-6 E / F / E~ / F~ continue   (as ksw2.h:125-128) */
+template<bool DUAL> struct K2aTb { enum { BITS = DUAL ? 8 : 4 }; };
+
+template<int G, int C, bool DUAL, int MODE>
+struct K2aLane {
+	enum { TBBITS = K2aTb<DUAL>::BITS, TBWORDS = (C * TBBITS + 31) / 32 };
+
+	/* group-uniform */
+	int qlen, tlen, tlen_full, w, nstrips;
+	const uint8_t *qry, *tgt;
+	/* schedule */
+	int gl, S, i0, je, Snext, knext;
+	/* systolic ports: what this lane produced for the strip below at the previous step */
+	int hout, eout, e2out;
+	int hd0;                      /* H(i0-1, jj-1) */
+	int hu_prev;                  /* H(i0-1, jj-1) candidate received last step */
+	int qb;                       /* query code for this step's column */
+	/* rows */
+	int hl[C], f[C], f2[DUAL ? C : 1], rmax[C], rmj[C];
+	uint32_t P[C];
+	uint32_t tbp[(C + 3) / 4];    /* packed target codes (only needed against the query wildcard) */
+	uint32_t tnext[(C + 3) / 4];  /* prefetched target codes of strip Snext */
+
+	K2A_FN static int kstart(int S_, int w_) { return S_ + k2a_max(0, S_ * C - w_); }
+
+	K2A_FN void load_tnext()
+	{
+		/* target arena is padded, any strip start is readable for C bytes; rows >= tlen are never live */
+		if (Snext < nstrips) {
+			const uint32_t *p = (const uint32_t*)(tgt + (size_t)Snext * C);
+#pragma unroll
+			for (int x = 0; x < (C + 3) / 4; ++x) tnext[x] = p[x];
+		}
+	}
+
+	K2A_FN void setup(const K2aPair &pr, const uint8_t *seq, int lane_in_group, bool valid)
+	{
+		qlen = pr.qlen; tlen = pr.tlen; tlen_full = pr.tlen_full; w = pr.w;
+		qry = seq + pr.qoff; tgt = seq + pr.toff;
+		nstrips = valid ? (tlen + C - 1) / C : 0;
+		gl = lane_in_group;
+		S = -1; i0 = 0; je = -1;
+		Snext = gl;
+		knext = Snext < nstrips ? kstart(Snext, w) : K2A_KNONE;
+		hout = eout = e2out = K2A_NEG; hd0 = K2A_NEG; hu_prev = K2A_NEG; qb = 0;
+#pragma unroll
+		for (int c = 0; c < C; ++c) { hl[c] = f[c] = K2A_NEG; rmax[c] = K2A_NEG; rmj[c] = 0; P[c] = 0; if (DUAL) f2[c] = K2A_NEG; }
+		if (!DUAL) f2[0] = 0;
+#pragma unroll
+		for (int x = 0; x < (C + 3) / 4; ++x) tbp[x] = tnext[x] = 0;
+		load_tnext();
+	}
+
+	/* last step at which any lane of this alignment computes a live cell */
+	K2A_FN int last_step() const
+	{
+		int Sl = nstrips - 1;
+		return nstrips > 0 ? Sl + k2a_min(qlen - 1, tlen - 1 + w) : -1;
+	}
+
+	K2A_FN bool need_init(int k) const { return k == knext; }
+
+	/* start strip Snext at step k (its first column): row state from the virtual column -1 or -inf */
+	K2A_FN void do_init(const K2aScoring &sc)
+	{
+		S = Snext; i0 = S * C;
+		je = k2a_min(qlen - 1, k2a_min(i0 + C - 1, tlen - 1) + w);
+		const int js = k2a_max(0, i0 - w);
+#pragma unroll
+		for (int x = 0; x < (C + 3) / 4; ++x) tbp[x] = tnext[x];
+#pragma unroll
+		for (int c = 0; c < C; ++c) {
+			const int i = i0 + c;
+			const uint32_t tb = (tbp[c >> 2] >> (8 * (c & 3))) & 0xff;
+			const uint32_t tbc = tb < 4 ? tb : 4;
+			P[c] = tbc == 0 ? sc.prof[0] : tbc == 1 ? sc.prof[1] : tbc == 2 ? sc.prof[2] : tbc == 3 ? sc.prof[3] : sc.prof[4];
+			/* rows that start at column 0 see the virtual column -1 (ksw2_extz.c:43-44, ksw2_extd.c:49-52) */
+			const bool edge = i <= w;
+			const int hb = k2a_border<DUAL>(sc, i + 1);
+			hl[c] = edge ? hb : K2A_NEG;
+			f[c] = edge ? hb - (sc.q + sc.e) : K2A_NEG;
+			if (DUAL) f2[c] = edge ? hb - (sc.q2 + sc.e2) : K2A_NEG;
+			rmax[c] = K2A_NEG; rmj[c] = 0;
+		}
+		if (js == 0) hd0 = k2a_border<DUAL>(sc, i0);       /* H(i0-1,-1); 0 at the origin */
+		else hd0 = hu_prev;                               /* H(i0-1, js-1), received one step ago */
+		Snext += G;
+		knext = Snext < nstrips ? kstart(Snext, w) : K2A_KNONE;
+		load_tnext();
+	}
+
+	/* One step: column jj = k - S for the C rows of the current strip.
+	 *   hin/ein/e2in: bottom-row outputs of the previous lane at the previous step (already rotated in)
+	 *   tbw: traceback word(s) out (MODE != SCORE)
+	 * returns true when this lane computed live cells (so tbw is meaningful). */
+	K2A_FN bool step(const K2aScoring &sc, int k, int hin, int ein, int e2in, uint32_t *tbw)
+	{
+		const int jj = k - S;
+		const bool act = (S >= 0) && (jj <= je) && (jj >= 0);
+		const int qe = sc.q + sc.e, qe2 = sc.q2 + sc.e2;
+		/* inputs from above: virtual row -1 for the first strip, else the rotated ports; the cell above is
+		 * outside the band when jj - (i0-1) > w */
+		int hu = hin, e = ein, e2 = e2in;
+		if (S == 0) {
+			const int hb = k2a_border<DUAL>(sc, jj + 1);
+			hu = hb; e = hb - qe; e2 = hb - qe2;
+			if (jj > w) { e = K2A_NEG; e2 = K2A_NEG; }
+		} else if (jj - i0 >= w) { e = K2A_NEG; e2 = K2A_NEG; }
+		hu_prev = hin;
+		/* live rows of this strip at column jj: lo <= c <= hi */
+		const int lo = k2a_max(0, jj - w - i0);
+		const int hi = k2a_min(k2a_min(C - 1, jj + w - i0), tlen - 1 - i0);
+		uint32_t live = 0;
+		if (act && lo <= hi) live = (2u << hi) - (1u << lo);
+		/* query code of this column; wildcard columns take the slow score path */
+		const int qcode = qb;
+		const int qsh = (qcode & 3) * 8;
+		const bool qwild = qcode >= 4;
+		int hd = hd0;
+		uint32_t tw[TBWORDS];
+#pragma unroll
+		for (int x = 0; x < TBWORDS; ++x) tw[x] = 0;
+#pragma unroll
+		for (int c = 0; c < C; ++c) {
+			int s = (int)(int8_t)(P[c] >> qsh);
+			if (qwild) {
+				const uint32_t tb = (tbp[c >> 2] >> (8 * (c & 3))) & 0xff;
+				const uint32_t tbc = tb < 4 ? tb : 4;
+				s = tbc == 0 ? sc.colw[0] : tbc == 1 ? sc.colw[1] : tbc == 2 ? sc.colw[2] : tbc == 3 ? sc.colw[3] : sc.colw[4];
+			}
+			int h = hd + s;
+			const int fc = f[c];
+			uint32_t d = 0;
+			if (MODE == K2A_MODE_SCORE) {
+				h = k2a_max3(h, e, fc);
+				if (DUAL) h = k2a_max3(h, e2, f2[c]);
+			} else if (MODE == K2A_MODE_LEFT) {           /* ksw2_extz.c:72-75, ksw2_extd.c:88-95 */
+				d = h >= e ? 0u : 1u;  h = k2a_max(h, e);
+				d = h >= fc ? d : 2u;  h = k2a_max(h, fc);
+				if (DUAL) {
+					d = h >= e2 ? d : 3u;    h = k2a_max(h, e2);
+					d = h >= f2[c] ? d : 4u; h = k2a_max(h, f2[c]);
+				}
+			} else {                                      /* ksw2_extz.c:98-101, ksw2_extd.c:126-133 */
+				d = h > e ? 0u : 1u;   h = k2a_max(h, e);
+				d = h > fc ? d : 2u;   h = k2a_max(h, fc);
+				if (DUAL) {
+					d = h > e2 ? d : 3u;     h = k2a_max(h, e2);
+					d = h > f2[c] ? d : 4u;  h = k2a_max(h, f2[c]);
+				}
+			}
+			const bool lv = (live >> c) & 1u;
+			h = lv ? h : K2A_NEG;
+			/* running row maximum; ties to the last column unless extz + RIGHT + CIGAR (SURVEY 8a rule 3) */
+			const bool upd = (!DUAL && MODE == K2A_MODE_RIGHT) ? (h > rmax[c]) : (h >= rmax[c]);
+			rmj[c] = upd ? jj : rmj[c];
+			rmax[c] = k2a_max(rmax[c], h);
+			/* gaps leaving this cell */
+			const int t = h - qe;
+			const int ex = e - sc.e, fx = fc - sc.e;
+			if (MODE == K2A_MODE_LEFT) {
+				d |= (ex > t ? 1u : 0u) << (DUAL ? 3 : 2);
+				d |= (fx > t ? 1u : 0u) << (DUAL ? 4 : 3);
+			} else if (MODE == K2A_MODE_RIGHT) {
+				d |= (ex >= t ? 1u : 0u) << (DUAL ? 3 : 2);
+				d |= (fx >= t ? 1u : 0u) << (DUAL ? 4 : 3);
+			}
+			e = k2a_max(ex, t);
+			f[c] = k2a_max(fx, t);
+			if (DUAL) {
+				const int t2 = h - qe2;
+				const int ex2 = e2 - sc.e2, fx2 = f2[c] - sc.e2;
+				if (MODE == K2A_MODE_LEFT)  { d |= (ex2 > t2 ? 1u : 0u) << 5;  d |= (fx2 > t2 ? 1u : 0u) << 6; }
+				if (MODE == K2A_MODE_RIGHT) { d |= (ex2 >= t2 ? 1u : 0u) << 5; d |= (fx2 >= t2 ? 1u : 0u) << 6; }
+				e2 = k2a_max(ex2, t2);
+				f2[c] = k2a_max(fx2, t2);
+			}
+			if (MODE != K2A_MODE_SCORE) tw[(c * TBBITS) >> 5] |= d << ((c * TBBITS) & 31);
+			hd = hl[c];
+			hl[c] = h;
+		}
+		hd0 = hu;
+		hout = hl[C - 1]; eout = e; e2out = e2;
+		if (MODE != K2A_MODE_SCORE) {
+#pragma unroll
+			for (int x = 0; x < TBWORDS; ++x) tbw[x] = tw[x];
+		}
+		return live != 0;
+	}
+
+	/* prefetch the query code of the column this lane will see at step k+1 */
+	K2A_FN int next_query_code(int k) const
+	{
+		const int Sn = (k + 1 == knext) ? Snext : S;
+		const int j = k + 1 - Sn;
+		return (Sn >= 0 && j >= 0 && j < qlen) ? (int)qry[j] : 0;
+	}
+
+	K2A_FN bool need_fin(int k) const { return S >= 0 && k - S == je; }
+
+	/* The strip's last column is done: replay the scalar reference's per-row epilogue for its rows, in row
+	 * order (ksw2_extz.c:116-124, ksw2_extd.c:156-164; Z-drop test ksw2.h:191-207 with is_rot = 0). */
+	K2A_FN void do_fin(const K2aScoring &sc, K2aBook *b, int zdrop)
+	{
+		const int zslope = DUAL ? sc.e2 : sc.e;
+		int bmax = b->max, bmax_t = b->max_t, bmax_q = b->max_q, bmqe = b->mqe, bmqe_t = b->mqe_t;
+		int bmte = b->mte, bmte_q = b->mte_q, bscore = b->score, bdrop = b->dropped, brows = b->rows;
+#pragma unroll
+		for (int c = 0; c < C; ++c) {
+			const int i = i0 + c;
+			if (i < tlen && !bdrop) {
+				const bool reach = i + w >= qlen - 1;           /* the row's last cell is column qlen-1 */
+				const int hend = hl[c], H = rmax[c], j = rmj[c];
+				if (reach && hend > bmqe) { bmqe = hend; bmqe_t = i; }
+				if (i == tlen_full - 1) { bmte = H; bmte_q = j; }
+				if (H > bmax) { bmax = H; bmax_t = i; bmax_q = j; }
+				else if (i >= bmax_t && j >= bmax_q) {
+					const int dt = i - bmax_t, dq = j - bmax_q;
+					const int skew = dt > dq ? dt - dq : dq - dt;
+					if (zdrop >= 0 && bmax - H > zdrop + skew * zslope) bdrop = 1;
+				}
+				if (!bdrop && i == tlen_full - 1 && reach) bscore = hend;
+				brows = i + 1;
+			}
+		}
+		b->max = bmax; b->max_t = bmax_t; b->max_q = bmax_q; b->mqe = bmqe; b->mqe_t = bmqe_t;
+		b->mte = bmte; b->mte_q = bmte_q; b->score = bscore; b->dropped = bdrop; b->rows = brows;
+		S = -1; je = -1;
+	}
+};
+
+/* ------------------------------------------------------------------------------------------------
+ * Traceback walk for one alignment (K5).  Same state machine as ksw_backtrack (ksw2.h:129-161) on
+ * our own bit layout: cell (i,j) lives in the word written at step k = i/C + j by lane (i/C) % G.
+ * Writes the CIGAR in walk order (end -> start) to `out`, returns the number of operations.
+ * ------------------------------------------------------------------------------------------------ */
+template<int G, int C, bool DUAL>
+K2A_FN int k2a_trace_pair(const uint8_t *tb, int i, int j, uint32_t *out)
+{
+	enum { BITS = K2aTb<DUAL>::BITS, WB = C * BITS / 8 };
+	int n = 0, state = 0;
+	uint32_t last_op = 0xffffffffu, run = 0;
+	while (i >= 0 && j >= 0) {
+		const int S = i / C, c = i - S * C;
+		const size_t word = ((size_t)(S + j) * G + (S % G)) * WB;
+		const uint32_t byte = tb[word + ((c * BITS) >> 3)];
+		const uint32_t raw = DUAL ? byte : ((byte >> ((c * BITS) & 7)) & 0xf);
+		uint32_t d;                                   /* re-expand to the reference's byte layout */
+		if (DUAL) d = raw;
+		else d = (raw & 3u) | ((raw & 4u) << 1) | ((raw & 8u) << 1);
+		if (state == 0) state = d & 7;
+		else if (!((d >> (state + 2)) & 1)) state = 0;
+		if (state == 0) state = d & 7;
+		uint32_t op;
+		if (state == 0) { op = 0; --i; --j; }
+		else if (state == 1 || state == 3) { op = 2; --i; }
+		else { op = 1; --j; }
+		if (op == last_op) ++run;
+		else { if (run) out[n++] = run << 4 | last_op; last_op = op; run = 1; }
+	}
+	if (i >= 0) {                                     /* leading deletion */
+		if (last_op == 2) run += i + 1;
+		else { if (run) out[n++] = run << 4 | last_op; last_op = 2; run = i + 1; }
+	}
+	if (j >= 0) {                                     /* leading insertion */
+		if (last_op == 1) run += j + 1;
+		else { if (run) out[n++] = run << 4 | last_op; last_op = 1; run = j + 1; }
+	}
+	if (run) out[n++] = run << 4 | last_op;
+	return n;
+}
+
+/* Finish one alignment after the fill: turn the bookkeeping state into the ksw_extz_t fields and pick
+ * the traceback start (ksw2_extz2_sse.c:292-301 / ksw2_extz.c:127-133; SURVEY 8a rules 6-7). */
+K2A_FN void k2a_finish(const K2aPair &pr, const K2aBook &b, K2aResult *r)
+{
+	int dropped = b.dropped;
+	/* rows, or the corner column, that the band cannot reach: stop like the SSE kernels do */
+	if (!dropped && (pr.tlen < pr.tlen_full || (pr.tlen_full - 1) + pr.w < pr.qlen - 1)) dropped = 1;
+	r->max = b.max; r->zdropped = dropped; r->max_q = b.max_q; r->max_t = b.max_t;
+	r->mqe = b.mqe; r->mqe_t = b.mqe_t; r->mte = b.mte; r->mte_q = b.mte_q; r->score = b.score;
+	r->reach_end = 0; r->n_cigar = 0; r->rows_done = b.rows;
+	int ti = -1, tj = -1;
+	if (pr.flag & K2A_F_SCORE_ONLY) { /* no traceback, reach_end stays 0 (ksw2_extz2_sse.c:292) */ }
+	else if (!dropped && !(pr.flag & K2A_F_EXTZ_ONLY)) { ti = pr.tlen_full - 1; tj = pr.qlen - 1; }
+	else if (!dropped && (pr.flag & K2A_F_EXTZ_ONLY) && b.mqe + pr.end_bonus > b.max) {
+		r->reach_end = 1; ti = b.mqe_t; tj = pr.qlen - 1;
+	} else if (b.max_t >= 0 && b.max_q >= 0) { ti = b.max_t; tj = b.max_q; }
+	r->ti = ti; r->tj = tj; r->pad[0] = r->pad[1] = 0;
+}
+
+#endif

@@ -1,0 +1,65 @@
+/*
+ * ksw2_shim.h -- the thin C-ABI between the C host (ksw2_host.c) and the device runtime.
+ *
+ * The product library links ksw2_shim_hip.hip (HIP runtime + gfx950 kernels).  tests/sim/ links the very
+ * same host code against a host-memory, lock-step wave simulator of the same interface so that the
+ * packing / scheduling logic can be checked without a GPU; that simulator is test infrastructure and is
+ * never part of libksw2_amd.so.
+ */
+#ifndef KSW2_SHIM_H_
+#define KSW2_SHIM_H_
+
+#include <stddef.h>
+#include "ksw2_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* kernel geometry classes: lanes per alignment (G) x target rows per lane (C) */
+#define K2A_NCFG 4
+static const int k2a_cfg_G[K2A_NCFG] = { 16, 64, 64, 64 };
+static const int k2a_cfg_C[K2A_NCFG] = {  8,  8, 16, 32 };
+
+const char *k2a_shim_backend(void);                /* "hip:gfx950" or "sim" */
+const char *k2a_shim_last_error(void);
+int   k2a_shim_device_count(void);
+int   k2a_shim_set_device(int dev);
+int   k2a_shim_mem_info(size_t *free_b, size_t *total_b);
+
+void *k2a_shim_malloc(size_t bytes);               /* device memory */
+void  k2a_shim_free(void *p);
+void *k2a_shim_host_malloc(size_t bytes);          /* pinned host staging */
+void  k2a_shim_host_free(void *p);
+int   k2a_shim_h2d(void *dst, const void *src, size_t bytes, void *stream);
+int   k2a_shim_d2h(void *dst, const void *src, size_t bytes, void *stream);
+int   k2a_shim_memset(void *dst, int v, size_t bytes, void *stream);
+
+void *k2a_shim_stream_create(void);
+void  k2a_shim_stream_destroy(void *stream);
+int   k2a_shim_stream_sync(void *stream);
+void *k2a_shim_event_create(void);
+void  k2a_shim_event_destroy(void *ev);
+int   k2a_shim_event_record(void *ev, void *stream);
+float k2a_shim_event_ms(void *start, void *stop);  /* blocks on `stop` */
+
+/*
+ * Fill kernel: ntasks alignments (order[t] = index into pairs/res) on geometry class `cfg`.
+ *   dual: 0 single affine gap (extz2 / gg2), 1 two-piece (extd2);  mode: K2A_MODE_*
+ * Trace kernel: walks the traceback blocks written by a fill launch of the same class and writes each
+ * CIGAR (end -> start order) into cig[pairs[i].cig_off ...], count in res[i].n_cigar.
+ */
+int k2a_shim_launch_fill(int cfg, int dual, int mode, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order,
+                         int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, void *stream);
+int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb,
+                          K2aResult *res, uint32_t *cig, void *stream);
+
+/* Compaction: pool[pos[i] .. pos[i]+res[i].n_cigar) = cig[pairs[i].cig_off ..) for the n pairs of a plan
+ * (pos = exclusive prefix sum of n_cigar, computed by the host), so that one D2H brings every CIGAR back. */
+int k2a_shim_launch_compact(const K2aPair *pairs, const K2aResult *res, const uint32_t *pos, int n, const uint32_t *cig,
+                            uint32_t *pool, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

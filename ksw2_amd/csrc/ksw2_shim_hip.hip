@@ -1,0 +1,256 @@
+/*
+ * ksw2_shim_hip.hip -- gfx950 kernels + HIP runtime side of the shim (ksw2_shim.h).
+ *
+ * K1-K4 (fill): k2a_fill_kernel<G, C, DUAL, MODE>   one alignment per group of G lanes, see ksw2_lane.h
+ * K5 (trace):   k2a_trace_kernel<G, C, DUAL>        one thread per alignment walks its traceback block
+ *
+ * The lane-to-lane hand-off of the bottom row's (H, E[, E~]) is a single DPP rotate per value per step:
+ * wave_ror:1 for G = 64, row_ror:1 for G = 16 (four independent alignments per wavefront).
+ */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include "ksw2_shim.h"
+#include "ksw2_lane.h"
+
+#define K2A_WPB 4          /* wavefronts per workgroup; waves never synchronise with each other */
+
+static thread_local char g_err[512] = "";
+
+static int set_err(hipError_t e, const char *what)
+{
+	if (e == hipSuccess) return 0;
+	snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+	return -1;
+}
+#define CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return set_err(e_, #call); } while (0)
+
+template<int G>
+__device__ __forceinline__ int k2a_rot1(int v)
+{
+	/* lane l <- lane l-1 inside its group (lane 0 <- lane G-1) */
+	if (G == 64) return __builtin_amdgcn_update_dpp(0, v, 0x13C /* wave_ror:1 */, 0xf, 0xf, false);
+	else         return __builtin_amdgcn_update_dpp(0, v, 0x121 /* row_ror:1  */, 0xf, 0xf, false);
+}
+
+template<int G, int C, bool DUAL, int MODE>
+__global__ void __launch_bounds__(64 * K2A_WPB)
+k2a_fill_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
+                const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, K2aResult *__restrict__ res)
+{
+	constexpr int NG = 64 / G;
+	typedef K2aLane<G, C, DUAL, MODE> Lane;
+	__shared__ K2aBook book[K2A_WPB][NG];
+
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int grp = lane / G, gl = lane % G;
+	const int task = (blockIdx.x * K2A_WPB + wave) * NG + grp;
+	const bool valid = task < ntasks;
+	const uint32_t pi = order[valid ? task : 0];
+	const K2aPair pr = pairs[pi];
+
+	Lane L;
+	L.setup(pr, seq, gl, valid);
+	K2aBook *bk = &book[wave][grp];
+	if (gl == 0) k2a_book_reset(bk);
+	__builtin_amdgcn_wave_barrier();
+
+	const int klast = L.last_step();                  /* group-uniform; -1 for an idle group */
+	int kmax = klast;
+	if (G == 16) {
+		kmax = max(max(__builtin_amdgcn_readlane(klast, 0), __builtin_amdgcn_readlane(klast, 16)),
+		           max(__builtin_amdgcn_readlane(klast, 32), __builtin_amdgcn_readlane(klast, 48)));
+	} else kmax = __builtin_amdgcn_readfirstlane(klast);
+
+	uint8_t *tbp = tb + pr.tb_off + (size_t)gl * (Lane::TBWORDS * 4);
+	bool gdone = !valid;
+	L.qb = L.next_query_code(-1);
+
+	for (int k = 0; k <= kmax; ++k) {
+		const int hin = k2a_rot1<G>(L.hout);
+		const int ein = k2a_rot1<G>(L.eout);
+		const int e2in = DUAL ? k2a_rot1<G>(L.e2out) : 0;
+
+		const bool ninit = L.need_init(k);
+		if (__builtin_amdgcn_ballot_w64(ninit) != 0) {
+			if (ninit) L.do_init(sc);
+		}
+		const int qnext = L.next_query_code(k);
+
+		uint32_t tw[Lane::TBWORDS];
+		const bool live = L.step(sc, k, hin, ein, e2in, tw);
+		if (MODE != K2A_MODE_SCORE) {
+			if (live) {
+				uint32_t *dst = (uint32_t*)(tbp + (size_t)k * (G * Lane::TBWORDS * 4));
+				if (Lane::TBWORDS == 1) dst[0] = tw[0];
+				else if (Lane::TBWORDS == 2) *(uint2*)dst = make_uint2(tw[0], tw[1]);
+				else {
+#pragma unroll
+					for (int x = 0; x < Lane::TBWORDS; x += 4)
+						*(uint4*)(dst + x) = make_uint4(tw[x], tw[x + 1 < Lane::TBWORDS ? x + 1 : x], tw[x + 2 < Lane::TBWORDS ? x + 2 : x],
+						                               tw[x + 3 < Lane::TBWORDS ? x + 3 : x]);
+				}
+			}
+		}
+
+		const bool nfin = L.need_fin(k);
+		if (__builtin_amdgcn_ballot_w64(nfin) != 0) {
+			if (nfin) L.do_fin(sc, bk, pr.zdrop);
+			__builtin_amdgcn_wave_barrier();
+			if (bk->dropped) gdone = true;
+		}
+		L.qb = qnext;
+		if (__builtin_amdgcn_ballot_w64(!(gdone || k >= klast)) == 0) break;
+	}
+	__builtin_amdgcn_wave_barrier();
+	if (valid && gl == 0) {
+		const K2aBook b = *bk;
+		k2a_finish(pr, b, &res[pi]);
+	}
+}
+
+template<int G, int C, bool DUAL>
+__global__ void __launch_bounds__(64)
+k2a_trace_kernel(const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
+                 const uint8_t *__restrict__ tb, K2aResult *__restrict__ res, uint32_t *__restrict__ cig)
+{
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= ntasks) return;
+	const uint32_t pi = order[t];
+	const K2aPair pr = pairs[pi];
+	const int ti = res[pi].ti, tj = res[pi].tj;
+	int n = 0;
+	if (ti >= 0 && tj >= 0) n = k2a_trace_pair<G, C, DUAL>(tb + pr.tb_off, ti, tj, cig + pr.cig_off);
+	res[pi].n_cigar = n;
+}
+
+__global__ void __launch_bounds__(64)
+k2a_compact_kernel(const K2aPair *__restrict__ pairs, const K2aResult *__restrict__ res, const uint32_t *__restrict__ pos, int n,
+                   const uint32_t *__restrict__ cig, uint32_t *__restrict__ pool)
+{
+	const int i = blockIdx.x;
+	if (i >= n) return;
+	const int nc = res[i].n_cigar;
+	const uint32_t *src = cig + pairs[i].cig_off;
+	uint32_t *dst = pool + pos[i];
+	for (int k = threadIdx.x; k < nc; k += 64) dst[k] = src[k];
+}
+
+/* ---------------------------------------------------------------- dispatch tables */
+
+typedef void (*fill_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*);
+typedef void (*trace_fn)(const K2aPair*, const uint32_t*, int, const uint8_t*, K2aResult*, uint32_t*);
+
+#define FILL_ROW(G, C) { { k2a_fill_kernel<G, C, false, 0>, k2a_fill_kernel<G, C, false, 1>, k2a_fill_kernel<G, C, false, 2> }, \
+                         { k2a_fill_kernel<G, C, true, 0>,  k2a_fill_kernel<G, C, true, 1>,  k2a_fill_kernel<G, C, true, 2> } }
+static const fill_fn g_fill[K2A_NCFG][2][3] = { FILL_ROW(16, 8), FILL_ROW(64, 8), FILL_ROW(64, 16), FILL_ROW(64, 32) };
+#define TRACE_ROW(G, C) { k2a_trace_kernel<G, C, false>, k2a_trace_kernel<G, C, true> }
+static const trace_fn g_trace[K2A_NCFG][2] = { TRACE_ROW(16, 8), TRACE_ROW(64, 8), TRACE_ROW(64, 16), TRACE_ROW(64, 32) };
+
+extern "C" {
+
+const char *k2a_shim_backend(void) { return "hip:gfx950"; }
+const char *k2a_shim_last_error(void) { return g_err; }
+
+int k2a_shim_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+int k2a_shim_set_device(int dev) { CHECK(hipSetDevice(dev)); return 0; }
+
+int k2a_shim_mem_info(size_t *free_b, size_t *total_b) { CHECK(hipMemGetInfo(free_b, total_b)); return 0; }
+
+void *k2a_shim_malloc(size_t bytes)
+{
+	void *p = 0;
+	if (set_err(hipMalloc(&p, bytes ? bytes : 16), "hipMalloc")) return 0;
+	return p;
+}
+void k2a_shim_free(void *p) { if (p) (void)hipFree(p); }
+
+void *k2a_shim_host_malloc(size_t bytes)
+{
+	void *p = 0;
+	if (set_err(hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault), "hipHostMalloc")) return 0;
+	return p;
+}
+void k2a_shim_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+int k2a_shim_h2d(void *dst, const void *src, size_t bytes, void *stream)
+{
+	if (bytes) CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+	return 0;
+}
+int k2a_shim_d2h(void *dst, const void *src, size_t bytes, void *stream)
+{
+	if (bytes) CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+	return 0;
+}
+int k2a_shim_memset(void *dst, int v, size_t bytes, void *stream)
+{
+	if (bytes) CHECK(hipMemsetAsync(dst, v, bytes, (hipStream_t)stream));
+	return 0;
+}
+
+void *k2a_shim_stream_create(void)
+{
+	hipStream_t s = 0;
+	if (set_err(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate")) return 0;
+	return (void*)s;
+}
+void k2a_shim_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy((hipStream_t)stream); }
+int k2a_shim_stream_sync(void *stream) { CHECK(hipStreamSynchronize((hipStream_t)stream)); return 0; }
+
+void *k2a_shim_event_create(void)
+{
+	hipEvent_t e = 0;
+	if (set_err(hipEventCreate(&e), "hipEventCreate")) return 0;
+	return (void*)e;
+}
+void k2a_shim_event_destroy(void *ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+int k2a_shim_event_record(void *ev, void *stream) { CHECK(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream)); return 0; }
+float k2a_shim_event_ms(void *start, void *stop)
+{
+	float ms = -1.0f;
+	if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess) return -1.0f;
+	if (hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) return -1.0f;
+	return ms;
+}
+
+int k2a_shim_launch_fill(int cfg, int dual, int mode, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order,
+                         int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, void *stream)
+{
+	if (ntasks <= 0) return 0;
+	if (cfg < 0 || cfg >= K2A_NCFG || mode < 0 || mode > 2) { snprintf(g_err, sizeof(g_err), "bad kernel class"); return -1; }
+	const int per_block = K2A_WPB * (64 / k2a_cfg_G[cfg]);
+	const int blocks = (ntasks + per_block - 1) / per_block;
+	hipLaunchKernelGGL(g_fill[cfg][dual ? 1 : 0][mode], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
+	                   *sc, pairs, order, ntasks, seq, tb, res);
+	CHECK(hipGetLastError());
+	return 0;
+}
+
+int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb,
+                          K2aResult *res, uint32_t *cig, void *stream)
+{
+	if (ntasks <= 0) return 0;
+	if (cfg < 0 || cfg >= K2A_NCFG) { snprintf(g_err, sizeof(g_err), "bad kernel class"); return -1; }
+	hipLaunchKernelGGL(g_trace[cfg][dual ? 1 : 0], dim3((ntasks + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+	                   pairs, order, ntasks, tb, res, cig);
+	CHECK(hipGetLastError());
+	return 0;
+}
+
+int k2a_shim_launch_compact(const K2aPair *pairs, const K2aResult *res, const uint32_t *pos, int n, const uint32_t *cig,
+                            uint32_t *pool, void *stream)
+{
+	if (n <= 0) return 0;
+	hipLaunchKernelGGL(k2a_compact_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, pairs, res, pos, n, cig, pool);
+	CHECK(hipGetLastError());
+	return 0;
+}
+
+} /* extern "C" */

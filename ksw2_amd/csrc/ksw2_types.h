@@ -1,0 +1,54 @@
+/*
+ * ksw2_types.h -- plain-C data layout shared by the C host (ksw2_host.c), the device shim
+ * (ksw2_shim_hip.hip) and the per-lane kernel code (ksw2_lane.h).
+ */
+#ifndef KSW2_TYPES_H_
+#define KSW2_TYPES_H_
+
+#include <stdint.h>
+
+#define K2A_NEG      (-0x40000000)
+#define K2A_KNONE    0x7fffffff
+
+/* flag bits the device code looks at (numerically the KSW_EZ_* values, ksw2.h:8-18) */
+#define K2A_F_SCORE_ONLY 0x01
+#define K2A_F_EXTZ_ONLY 0x40
+#define K2A_F_REV_CIGAR 0x80
+
+/* kernel MODE */
+#define K2A_MODE_SCORE 0     /* no traceback                                      */
+#define K2A_MODE_LEFT  1     /* traceback bits, gaps left-aligned  (default)       */
+#define K2A_MODE_RIGHT 2     /* traceback bits, gaps right-aligned (KSW_EZ_RIGHT)  */
+
+/* batch-uniform scoring, passed by value to the kernel */
+typedef struct K2aScoring {
+	int32_t q, e, q2, e2;        /* gap open / extend; (q2,e2) only for the two-piece model, q+e <= q2+e2 */
+	uint32_t prof[5];            /* prof[t] = bytes { s(t,0), s(t,1), s(t,2), s(t,3) } for target code t   */
+	int32_t colw[5];             /* colw[t] = s(t, 4): score against the query wildcard (code 4)          */
+} K2aScoring;
+
+/* one alignment, device-resident */
+typedef struct K2aPair {
+	uint32_t qoff, toff;         /* byte offsets of query / target in the sequence arena                  */
+	int32_t qlen, tlen;          /* tlen = rows that own at least one in-band cell (<= true target length) */
+	int32_t tlen_full;           /* true target length (mte / score need the real last row)               */
+	int32_t w;                   /* effective band, 1 <= w <= max(qlen, tlen)                             */
+	int32_t zdrop, end_bonus, flag;
+	uint32_t cig_off;            /* dword offset of this pair's CIGAR scratch                              */
+	uint64_t tb_off;             /* byte offset of this pair's traceback block                            */
+} K2aPair;
+
+/* what the reference keeps in ksw_extz_t (ksw2.h:33-42), one per alignment */
+typedef struct K2aResult {
+	int32_t max, zdropped, max_q, max_t, mqe, mqe_t, mte, mte_q, score, reach_end, n_cigar, rows_done;
+	int32_t ti, tj;                  /* traceback start cell chosen by k2a_finish(); -1 = no CIGAR          */
+	int32_t pad[2];
+} K2aResult;
+
+/* per-group bookkeeping state (LDS on the GPU): the scalar reference's ez fields while rows complete */
+typedef struct K2aBook {
+	int32_t max, max_t, max_q, mqe, mqe_t, mte, mte_q, score, dropped, rows;
+} K2aBook;
+
+
+#endif

@@ -1,0 +1,184 @@
+"""GPU: the HIP path through the C-ABI (libksw2_amd.so) against the oracle and the golden vectors. Bit-exact."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import ksw2_amd as ka
+from ksw2_amd import synth
+from oracle import pyoracle as po
+from tests import golden_util as gu
+from tests.parity_util import check_batch, diff, CMP_FIELDS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    L = ka.library()                      # raises if the HIP library is missing: no fallback
+    assert L.backend() == "hip:gfx950"
+    assert L.device_count() >= 1
+    return L
+
+
+def test_t1q1_golden(lib):
+    ka_ = gu.known_answers()
+    _, ts = gu.read_fasta("t1.fa")
+    _, qs = gu.read_fasta("q1.fa")
+    mat = gu.simple_mat(5, 2, 4, 0)
+    for k, rec in enumerate(ka_["t1q1"]):
+        for flag in (0, po.RIGHT):
+            exp = rec["ksw_extz/flag=%d" % flag]
+            res = lib.extz(qs[k], ts[k], mat, 4, 2, flag=flag)
+            for f in gu.FIELDS:
+                assert res[f] == exp[f], (k, f)
+            assert gu.cigar_string(res["cigar"]) == exp["cigar"]
+            exp = rec["ksw_extd/flag=%d" % flag]
+            res = lib.extd(qs[k], ts[k], mat, 4, 2, 13, 1, flag=flag)
+            for f in gu.FIELDS:
+                assert res[f] == exp[f], (k, f)
+            assert gu.cigar_string(res["cigar"]) == exp["cigar"]
+        for g in ("gg", "gg2", "gg2_sse"):
+            s, c = lib.gg(g, qs[k], ts[k], mat, 4, 2, w=-1)
+            assert s == rec["ksw_gg"]["score"] and gu.cigar_string(c) == rec["ksw_gg"]["cigar"]
+
+
+def test_random_golden_cases(lib):
+    """All 3600 committed random cases (outputs of the compiled reference), batched per (function, scoring)."""
+    rc = gu.RandomCases()
+    groups = {}
+    for k in range(rc.n):
+        c = rc.case(k)
+        key = (c["func"], c["mat"].tobytes(), c["gq"], c["ge"], c["gq2"], c["ge2"])
+        groups.setdefault(key, []).append(c)
+    nchk = 0
+    for (func, _, gq, ge, gq2, ge2), cs in groups.items():
+        dual = "extd" in func
+        scalar = not func.endswith("2_sse")
+        qs, ts = [c["q"] for c in cs], [c["t"] for c in cs]
+        w = np.array([c["w"] for c in cs]); zd = np.array([c["zdrop"] for c in cs])
+        eb = np.array([c["end_bonus"] for c in cs])
+        fl = np.array([c["flag"] | (po.GENERIC_SC if scalar else 0) for c in cs])
+        if dual:
+            res = lib.extd_batch(qs, ts, cs[0]["mat"], gq, ge, gq2, ge2, w=w, zdrop=zd, end_bonus=eb, flag=fl)
+        else:
+            res = lib.extz_batch(qs, ts, cs[0]["mat"], gq, ge, w=w, zdrop=zd, end_bonus=eb, flag=fl)
+        for c, r in zip(cs, res):
+            exp = c["expect"]
+            if scalar:
+                if c["flag"] & po.EXTZ_ONLY:
+                    # the scalar functions have no end bonus branch: compare through the scalar-named entry point
+                    r = (lib.extd(c["q"], c["t"], c["mat"], gq, ge, gq2, ge2, w=c["w"], zdrop=c["zdrop"], flag=c["flag"]) if dual else
+                         lib.extz(c["q"], c["t"], c["mat"], gq, ge, w=c["w"], zdrop=c["zdrop"], flag=c["flag"]))
+                assert not diff(exp, r, gu.FIELDS + ["cigar"]), (func, c["w"], c["zdrop"], c["flag"])
+            else:
+                assert not diff(exp, r, gu.SSE_LOOSE_FIELDS), (func, c["w"], c["flag"])
+                if r["max_t"] == exp["max_t"] and r["max_q"] == exp["max_q"]:
+                    assert r["cigar"] == exp["cigar"]
+            nchk += 1
+    assert nchk == rc.n
+
+
+@pytest.mark.parametrize("dual", [False, True])
+@pytest.mark.parametrize("mode", [po.SCORE_ONLY, 0, po.RIGHT])
+def test_ragged_batches_vs_oracle(lib, dual, mode):
+    """Ragged lengths, every band class boundary, Z-drop on/off, extension flags, wildcards, several pairs per wavefront."""
+    rng = np.random.Generator(np.random.PCG64(1234 + mode + 10 * dual))
+    mat, q, e, q2, e2 = synth.simple_mat(5, 2, 4, -1), 4, 2, 24, 1
+    tot = 0
+    for rnd in range(6):
+        n = 150
+        pairs = synth.ragged_pairs(rng, n, 1, [120, 700, 2200][rnd % 3], sub=0.05, ind=0.12, n_rate=0.01 if rnd % 2 else 0.0)
+        qs, ts = [p[0] for p in pairs], [p[1] for p in pairs]
+        w = rng.choice([-1, 0, 1, 5, 20, 64, 68, 69, 100, 284, 285, 500, 536, 537, 1040], size=n)
+        zd = rng.choice([-1, 50, 200, 400], size=n)
+        eb = rng.choice([0, 10, 50], size=n)
+        fl = np.array([mode | (po.EXTZ_ONLY if rng.random() < 0.3 else 0) | (po.REV_CIGAR if rng.random() < 0.3 else 0) |
+                       (po.GENERIC_SC if rng.random() < 0.3 else 0) for _ in range(n)])
+        k, _ = check_batch(lib, dual, qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl)
+        tot += k
+    assert tot == 900
+
+
+def test_cfg2_shape_subset(lib):
+    """BASELINE config 2 shape (512 x 512, w=64, extz2 score-only): 4096 pairs, every pair checked."""
+    n = 4096
+    q, t = synth.fixed_batch(2, n, 512, 512, sub=0.05, ind=0.06)
+    mat = synth.simple_mat(5, 2, 4, -1)
+    k, _ = check_batch(lib, False, q, t, mat, 4, 2, 0, 0, w=64, zdrop=-1, flag=po.SCORE_ONLY)
+    assert k == n
+
+
+def test_cfg3_shape_subset(lib):
+    """BASELINE config 3 shape (2048 x 2048, w=256, extd2, Z-drop 400, CIGAR): 256 pairs, 10 % with a random tail."""
+    n = 256
+    q, t = synth.fixed_batch(3, n, 2048, 2048, sub=0.05, ind=0.10, tail_random_frac=0.25, tail_pairs=0.10)
+    mat = synth.simple_mat(5, 2, 4, -1)
+    k, res = check_batch(lib, True, q, t, mat, 4, 2, 24, 1, w=256, zdrop=400, flag=0)
+    assert k == n
+    assert sum(r["zdropped"] for r in res) > 0          # the Z-drop path is exercised
+
+
+def test_10k_banded(lib):
+    """Headline shape of the north star: 10 000 x 10 000, w=500, zdrop=400, extz2, score-only and CIGAR."""
+    n = 8
+    q, t = synth.fixed_batch(6, n, 10000, 10000, sub=0.05, ind=0.06)
+    mat = synth.simple_mat(5, 2, 4, -1)
+    check_batch(lib, False, q, t, mat, 4, 2, 0, 0, w=500, zdrop=400, flag=po.SCORE_ONLY)
+    check_batch(lib, False, q, t, mat, 4, 2, 0, 0, w=500, zdrop=400, flag=0)
+
+
+def test_edge_cases(lib):
+    mat = synth.simple_mat(5, 2, 4, -1)
+    one = np.array([1], dtype=np.uint8)
+    # empty inputs -> reset record (ksw2_extz2_sse.c:57)
+    r = lib.extz2(np.zeros(0, np.uint8), one, mat, 4, 2)
+    assert (r["score"], r["max"], r["max_t"], r["n_cigar"], r["zdropped"]) == (ka.KSW_NEG_INF, 0, -1, 0, 0)
+    # mismatch penalty larger than 2(q+e) -> reset record (ksw2_extz2_sse.c:78-82)
+    r = lib.extz2(one, one, synth.simple_mat(5, 1, 20, -1), 4, 2)
+    assert r["score"] == ka.KSW_NEG_INF and r["n_cigar"] == 0
+    # 1 x 1
+    for a, b in ((1, 1), (1, 2)):
+        exp = po.align("oracle", "extz2", np.array([a], np.uint8), np.array([b], np.uint8), mat, 4, 2)
+        res = lib.extz2(np.array([a], np.uint8), np.array([b], np.uint8), mat, 4, 2)
+        assert not diff(exp, res)
+    # band that cannot reach the corner: stop like the SSE kernels (zdropped, no score)
+    rng = np.random.Generator(np.random.PCG64(5))
+    t = rng.integers(0, 4, 300, dtype=np.uint8)
+    qv = t[:100].copy()
+    for qq, tt in ((qv, t), (t, qv)):
+        exp = po.align("oracle", "extz2", qq, tt, mat, 4, 2, w=10)
+        res = lib.extz2(qq, tt, mat, 4, 2, w=10)
+        assert not diff(exp, res) and res["zdropped"] == 1 and res["score"] == ka.KSW_NEG_INF
+
+
+def test_cigar_buffer_reuse(lib):
+    """ez is reused across calls like cli.c does: capacity persists and grows by doubling from 4 (ksw2.h:116-119)."""
+    rng = np.random.Generator(np.random.PCG64(9))
+    mat = synth.simple_mat(5, 2, 4, -1)
+    ez = ka.KswExtz()
+    caps = []
+    for L in (5, 200, 50):
+        (qq, tt), = synth.ragged_pairs(rng, 1, L, L, sub=0.1, ind=0.2)
+        r = lib.extz2(qq, tt, mat, 4, 2, ez=ez)
+        exp = po.align("oracle", "extz2", qq, tt, mat, 4, 2)
+        assert r["cigar"] == exp["cigar"]
+        caps.append(r["m_cigar"])
+        assert r["m_cigar"] >= r["n_cigar"] and (r["m_cigar"] & (r["m_cigar"] - 1)) == 0
+    assert caps[2] == caps[1] >= caps[0]
+
+
+def test_mt_pair_banded(lib):
+    """MT-human x MT-orang with w=500 (golden: score -13510, CIGAR md5 c07fce86940f)."""
+    ka_ = {(r["func"], r["w"], r.get("flag", 0), r.get("zdrop", -1)): r for r in gu.known_answers()["mt"]}
+    _, ts = gu.read_fasta("MT-human.fa")
+    _, qs = gu.read_fasta("MT-orang.fa")
+    mat = gu.simple_mat(5, 2, 4, 0)
+    exp = ka_[("ksw_extz", 500, 0, -1)]
+    res = lib.extz(qs[0], ts[0], mat, 4, 2, w=500)
+    assert (res["score"], res["max"], res["max_t"], res["max_q"]) == (exp["score"], exp["max"], exp["max_t"], exp["max_q"])
+    s = gu.cigar_string(res["cigar"])
+    assert hashlib.md5((s + "\n").encode()).hexdigest()[:12] == "c07fce86940f"
+    exp = ka_[("ksw_extd", 500, 0, -1)]
+    res = lib.extd(qs[0], ts[0], mat, 4, 2, 13, 1, w=500)
+    assert res["score"] == exp["score"] and gu.cigar_string(res["cigar"]) == exp["cigar"]
