@@ -86,8 +86,9 @@ struct ksw2amd_plan_s {
 	int ntasks;
 	cls_t cls[NCLS_MAX];
 	uint8_t *h_seq;
-	size_t seq_bytes, tb_bytes, cig_words;
+	size_t seq_bytes, tb_bytes, cig_words, bnd_words;
 	uint8_t *d_seq, *d_tb;
+	int32_t *d_bnd;
 	K2aPair *d_pairs;
 	K2aResult *d_res, *h_res;
 	uint32_t *d_order, *d_cig;
@@ -111,11 +112,26 @@ static int64_t band_cells(int qlen, int tlen, int w)
 	return n;
 }
 
+/* steps of the generation-serial schedule; must match k2a_gen_cols() in ksw2_lane.h */
+static size_t mp_total_steps(int G, int C, int qlen, int tlen, int w)
+{
+	const int R = G * C, ngen = (tlen + R - 1) / R;
+	size_t tot = 0;
+	int g;
+	for (g = 0; g < ngen; ++g) {
+		const int lo = imax(0, g * R - w), hi = imin(qlen - 1, imin(g * R + R - 1, tlen - 1) + w);
+		const int nl = imin(G, (tlen - g * R + C - 1) / C);
+		if (hi >= lo) tot += (size_t)(hi - lo + 1) + (size_t)(nl - 1);
+	}
+	return tot;
+}
+
 /* does a (G,C) systolic array hold the band?  all strips resident at once, or a lane is done with
  * strip S before strip S+G starts */
 static int cfg_fits(int cfg, int tlen_eff, int w)
 {
 	const int G = k2a_cfg_G[cfg], C = k2a_cfg_C[cfg];
+	if (cfg == K2A_CFG_MP) return 1;                       /* generation-serial: any band */
 	const int nstrips = (tlen_eff + C - 1) / C;
 	return nstrips <= G || 2 * (int64_t)w < (int64_t)G * (C + 1) - C + 1;
 }
@@ -146,7 +162,7 @@ void ksw2amd_plan_destroy(ksw2amd_plan_t *p)
 	int i;
 	if (!p) return;
 	k2a_shim_free(p->d_seq); k2a_shim_free(p->d_tb); k2a_shim_free(p->d_pairs); k2a_shim_free(p->d_res);
-	k2a_shim_free(p->d_order); k2a_shim_free(p->d_cig);
+	k2a_shim_free(p->d_order); k2a_shim_free(p->d_cig); k2a_shim_free(p->d_bnd);
 	for (i = 0; i < 3; ++i) if (p->ev[i]) k2a_shim_event_destroy(p->ev[i]);
 	free(p->h_pairs); free(p->h_cls); free(p->h_flag); free(p->h_order); free(p->h_seq); free(p->h_res);
 	free(p);
@@ -212,10 +228,6 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 		d->end_bonus = (a->flag & F_SCALAR_CONTRACT) ? K2A_NEG : a->end_bonus;
 		d->flag = a->flag & (KSW_EZ_EXTZ_ONLY | KSW_EZ_REV_CIGAR | KSW_EZ_SCORE_ONLY);
 		for (cfg = 0; cfg < K2A_NCFG; ++cfg) if (cfg_fits(cfg, d->tlen, w)) break;
-		if (cfg == K2A_NCFG) {
-			snprintf(g_err, sizeof(g_err), "pair %d: band %d on %d target rows exceeds the resident-band kernels of this release", i, w, d->tlen);
-			goto err;
-		}
 		mode = (a->flag & KSW_EZ_SCORE_ONLY) ? K2A_MODE_SCORE : (a->flag & KSW_EZ_RIGHT) ? K2A_MODE_RIGHT : K2A_MODE_LEFT;
 		generic = (a->flag & (KSW_EZ_GENERIC_SC | F_SCALAR_CONTRACT)) ? 1 : 0;
 		ci = (cfg * 3 + mode) * 2 + generic;
@@ -226,12 +238,18 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 		off = align_up(off, 16); d->toff = (uint32_t)off; off += (size_t)a->tlen + 64;
 		if (off > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "plan_create: more than 4 GiB of sequence in one plan%s", 0); goto err; }
 		p->cells += band_cells(a->qlen, a->tlen, w);
+		if (cfg == K2A_CFG_MP) {                              /* boundary rows H, E, E~ between generations */
+			d->bnd_off = (uint32_t)p->bnd_words;
+			p->bnd_words += 3 * (size_t)a->qlen + 16;
+			if (p->bnd_words > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "plan_create: boundary rows over 16 GiB in one plan%s", 0); goto err; }
+		}
 		/* traceback block and CIGAR scratch */
 		if (mode != K2A_MODE_SCORE) {
 			const int G = k2a_cfg_G[cfg], C = k2a_cfg_C[cfg];
 			const int nstrips = (d->tlen + C - 1) / C;
-			const size_t steps = (size_t)(nstrips - 1) + (size_t)imin(a->qlen - 1, d->tlen - 1 + w) + 1;
+			size_t steps = (size_t)(nstrips - 1) + (size_t)imin(a->qlen - 1, d->tlen - 1 + w) + 1;
 			const size_t wb = (size_t)C * (dual ? 8 : 4) / 8;
+			if (cfg == K2A_CFG_MP) steps = mp_total_steps(G, C, a->qlen, d->tlen, w);
 			d->tb_off = p->tb_bytes;
 			p->tb_bytes += align_up(steps * G * wb, 256);
 			d->cig_off = (uint32_t)p->cig_words;
@@ -282,13 +300,16 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 	p->d_order = (uint32_t*)k2a_shim_malloc(sizeof(uint32_t) * ((size_t)p->ntasks + 1));
 	p->d_tb = p->tb_bytes ? (uint8_t*)k2a_shim_malloc(p->tb_bytes) : 0;
 	p->d_cig = p->cig_words ? (uint32_t*)k2a_shim_malloc(p->cig_words * 4) : 0;
-	if (!p->d_seq || !p->d_pairs || !p->d_res || !p->d_order || (p->tb_bytes && !p->d_tb) || (p->cig_words && !p->d_cig)) {
+	p->d_bnd = p->bnd_words ? (int32_t*)k2a_shim_malloc(p->bnd_words * 4) : 0;
+	if (!p->d_seq || !p->d_pairs || !p->d_res || !p->d_order || (p->tb_bytes && !p->d_tb) || (p->cig_words && !p->d_cig) ||
+	    (p->bnd_words && !p->d_bnd)) {
 		fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error());
 		goto err;
 	}
 	if (k2a_shim_h2d(p->d_seq, p->h_seq, p->seq_bytes, 0) || k2a_shim_h2d(p->d_pairs, p->h_pairs, sizeof(K2aPair) * (size_t)n, 0) ||
 	    k2a_shim_h2d(p->d_order, p->h_order, sizeof(uint32_t) * (size_t)p->ntasks, 0) ||
-	    k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)n, 0) || k2a_shim_stream_sync(0)) {
+	    k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)n, 0) ||
+	    (p->bnd_words && k2a_shim_memset(p->d_bnd, 0xC0, p->bnd_words * 4, 0)) || k2a_shim_stream_sync(0)) {
 		fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error());
 		goto err;
 	}
@@ -310,7 +331,7 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 	for (c = 0; c < p->ncls; ++c) {
 		const cls_t *k = &p->cls[c];
 		if (k2a_shim_launch_fill(k->cfg, p->dual, k->mode, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
-		                         p->d_res, stream)) goto err;
+		                         p->d_bnd, p->d_res, stream)) goto err;
 	}
 	if (k2a_shim_event_record(p->ev[1], stream)) goto err;
 	for (c = 0; c < p->ncls; ++c) {
@@ -337,7 +358,7 @@ int64_t ksw2amd_plan_cells(const ksw2amd_plan_t *p) { return p ? p->cells : 0; }
 int64_t ksw2amd_plan_device_bytes(const ksw2amd_plan_t *p)
 {
 	if (!p) return 0;
-	return (int64_t)(p->seq_bytes + p->tb_bytes + p->cig_words * 4 + (sizeof(K2aPair) + sizeof(K2aResult)) * (size_t)p->n + 4 * (size_t)p->ntasks);
+	return (int64_t)(p->seq_bytes + p->tb_bytes + p->cig_words * 4 + p->bnd_words * 4 + (sizeof(K2aPair) + sizeof(K2aResult)) * (size_t)p->n + 4 * (size_t)p->ntasks);
 }
 
 static int fetch_results(ksw2amd_plan_t *p)
@@ -454,7 +475,10 @@ static size_t pair_device_bytes(int dual, const ksw2amd_pair_t *a)
 		size_t steps = (size_t)a->qlen + (size_t)a->tlen / 8 + 2;
 		size_t lanes = (size_t)imin(64, (2 * w + 16) / 9 + 2);
 		(void)lanes;
-		b += steps * 64 * (dual ? 32 : 16) / (w <= 68 ? 8 : w <= 284 ? 4 : w <= 536 ? 2 : 1) + 256;
+		if (w <= 1040 || a->tlen <= 2048)
+			b += steps * 64 * (dual ? 32 : 16) / (w <= 68 ? 8 : w <= 284 ? 4 : w <= 536 ? 2 : 1) + 256;
+		else   /* generation-serial: one (qlen + 63)-step sweep per 1024 rows, 64 lanes x 16 rows per step */
+			b += ((size_t)a->tlen / 1024 + 1) * ((size_t)a->qlen + 64) * 64 * (dual ? 16 : 8) + 12 * (size_t)a->qlen + 320;
 		b += ((size_t)a->qlen + a->tlen + 2) * 4;
 	}
 	return b;

@@ -64,8 +64,8 @@ struct K2aLane {
 	/* group-uniform */
 	int qlen, tlen, tlen_full, w, nstrips;
 	const uint8_t *qry, *tgt;
-	/* schedule */
-	int gl, S, i0, je, Snext, knext;
+	/* schedule: a lane sees column jj = k - koff at step k while it owns strip S */
+	int gl, S, i0, je, koff, Snext, knext, koff_next;
 	/* systolic ports: what this lane produced for the strip below at the previous step */
 	int hout, eout, e2out;
 	int hd0;                      /* H(i0-1, jj-1) */
@@ -77,7 +77,14 @@ struct K2aLane {
 	uint32_t tbp[(C + 3) / 4];    /* packed target codes (only needed against the query wildcard) */
 	uint32_t tnext[(C + 3) / 4];  /* prefetched target codes of strip Snext */
 
-	K2A_FN static int kstart(int S_, int w_) { return S_ + k2a_max(0, S_ * C - w_); }
+	K2A_FN static int first_col(int S_, int w_) { return k2a_max(0, S_ * C - w_); }
+
+	/* resident-band schedule: strip S is skewed by S steps, a lane moves on to strip S+G when done */
+	K2A_FN void schedule_next_resident()
+	{
+		koff_next = Snext;
+		knext = Snext < nstrips ? koff_next + first_col(Snext, w) : K2A_KNONE;
+	}
 
 	K2A_FN void load_tnext()
 	{
@@ -95,9 +102,9 @@ struct K2aLane {
 		qry = seq + pr.qoff; tgt = seq + pr.toff;
 		nstrips = valid ? (tlen + C - 1) / C : 0;
 		gl = lane_in_group;
-		S = -1; i0 = 0; je = -1;
+		S = -1; i0 = 0; je = -1; koff = 0;
 		Snext = gl;
-		knext = Snext < nstrips ? kstart(Snext, w) : K2A_KNONE;
+		schedule_next_resident();
 		hout = eout = e2out = K2A_NEG; hd0 = K2A_NEG; hu_prev = K2A_NEG; qb = 0;
 #pragma unroll
 		for (int c = 0; c < C; ++c) { hl[c] = f[c] = K2A_NEG; rmax[c] = K2A_NEG; rmj[c] = 0; P[c] = 0; if (DUAL) f2[c] = K2A_NEG; }
@@ -116,10 +123,24 @@ struct K2aLane {
 
 	K2A_FN bool need_init(int k) const { return k == knext; }
 
+	/* Generation-serial schedule (bands too wide to stay resident): generation g =
+	 * strips g*G .. g*G+G-1, all columns of their band [jlo, jhi], then the next generation; lane l is skewed
+	 * by l steps.  The bottom row of a generation reaches the next one through a boundary buffer in HBM. */
+	K2A_FN void begin_generation(int g, int jlo)
+	{
+		S = -1; je = -1;
+		Snext = g * G + gl;
+		koff_next = gl - jlo;
+		knext = Snext < nstrips ? koff_next + first_col(Snext, w) : K2A_KNONE;
+		hout = eout = e2out = K2A_NEG; hu_prev = K2A_NEG;
+		load_tnext();
+	}
+
 	/* start strip Snext at step k (its first column): row state from the virtual column -1 or -inf */
+	template<bool RESIDENT>
 	K2A_FN void do_init(const K2aScoring &sc)
 	{
-		S = Snext; i0 = S * C;
+		S = Snext; i0 = S * C; koff = koff_next;
 		je = k2a_min(qlen - 1, k2a_min(i0 + C - 1, tlen - 1) + w);
 		const int js = k2a_max(0, i0 - w);
 #pragma unroll
@@ -140,18 +161,20 @@ struct K2aLane {
 		}
 		if (js == 0) hd0 = k2a_border<DUAL>(sc, i0);       /* H(i0-1,-1); 0 at the origin */
 		else hd0 = hu_prev;                               /* H(i0-1, js-1), received one step ago */
-		Snext += G;
-		knext = Snext < nstrips ? kstart(Snext, w) : K2A_KNONE;
-		load_tnext();
+		if (RESIDENT) {
+			Snext += G;
+			schedule_next_resident();
+			load_tnext();
+		} else knext = K2A_KNONE;
 	}
 
-	/* One step: column jj = k - S for the C rows of the current strip.
+	/* One step: column jj = k - koff for the C rows of the current strip.
 	 *   hin/ein/e2in: bottom-row outputs of the previous lane at the previous step (already rotated in)
 	 *   tbw: traceback word(s) out (MODE != SCORE)
 	 * returns true when this lane computed live cells (so tbw is meaningful). */
 	K2A_FN bool step(const K2aScoring &sc, int k, int hin, int ein, int e2in, uint32_t *tbw)
 	{
-		const int jj = k - S;
+		const int jj = k - koff;
 		const bool act = (S >= 0) && (jj <= je) && (jj >= 0);
 		const int qe = sc.q + sc.e, qe2 = sc.q2 + sc.e2;
 		/* inputs from above: virtual row -1 for the first strip, else the rotated ports; the cell above is
@@ -247,12 +270,13 @@ struct K2aLane {
 	/* prefetch the query code of the column this lane will see at step k+1 */
 	K2A_FN int next_query_code(int k) const
 	{
-		const int Sn = (k + 1 == knext) ? Snext : S;
-		const int j = k + 1 - Sn;
-		return (Sn >= 0 && j >= 0 && j < qlen) ? (int)qry[j] : 0;
+		const bool starts = (k + 1 == knext);
+		const int j = k + 1 - (starts ? koff_next : koff);
+		return ((starts || S >= 0) && j >= 0 && j < qlen) ? (int)qry[j] : 0;
 	}
 
-	K2A_FN bool need_fin(int k) const { return S >= 0 && k - S == je; }
+	K2A_FN bool need_fin(int k) const { return S >= 0 && k - koff == je; }
+	K2A_FN int column(int k) const { return k - koff; }
 
 	/* The strip's last column is done: replay the scalar reference's per-row epilogue for its rows, in row
 	 * order (ksw2_extz.c:116-124, ksw2_extd.c:156-164; Z-drop test ksw2.h:191-207 with is_rot = 0). */
@@ -290,15 +314,47 @@ struct K2aLane {
  * our own bit layout: cell (i,j) lives in the word written at step k = i/C + j by lane (i/C) % G.
  * Writes the CIGAR in walk order (end -> start) to `out`, returns the number of operations.
  * ------------------------------------------------------------------------------------------------ */
-template<int G, int C, bool DUAL>
-K2A_FN int k2a_trace_pair(const uint8_t *tb, int i, int j, uint32_t *out)
+/* generation-serial layout: steps of generation g start at kbase(g); lane l of it sees column j at local
+ * step j - jlo(g) + l.  These two helpers are the single definition used by the fill and by the walk. */
+template<int G, int C>
+K2A_FN void k2a_gen_cols(int g, int qlen, int tlen, int w, int *jlo, int *nsteps)
+{
+	const int R = G * C;
+	const int lo = k2a_max(0, g * R - w);
+	const int hi = k2a_min(qlen - 1, k2a_min(g * R + R - 1, tlen - 1) + w);
+	const int nl = k2a_min(G, (tlen - g * R + C - 1) / C);      /* strips in this generation */
+	*jlo = lo;
+	*nsteps = hi >= lo ? (hi - lo + 1) + (nl - 1) : 0;
+}
+
+template<int G, int C, bool DUAL, bool MP>
+K2A_FN int k2a_trace_pair(const uint8_t *tb, int i, int j, uint32_t *out, int qlen, int tlen, int w)
 {
 	enum { BITS = K2aTb<DUAL>::BITS, WB = C * BITS / 8 };
 	int n = 0, state = 0;
 	uint32_t last_op = 0xffffffffu, run = 0;
+	int gcur = -1, gjlo = 0;
+	size_t gbase = 0;
 	while (i >= 0 && j >= 0) {
 		const int S = i / C, c = i - S * C;
-		const size_t word = ((size_t)(S + j) * G + (S % G)) * WB;
+		size_t word;
+		if (!MP) word = ((size_t)(S + j) * G + (S % G)) * WB;
+		else {
+			const int g = S / G;
+			if (g != gcur) {                          /* (re)locate the generation: rare, the walk only moves up */
+				int ns;
+				if (gcur < 0) {
+					gbase = 0;
+					for (int x = 0; x < g; ++x) { k2a_gen_cols<G, C>(x, qlen, tlen, w, &gjlo, &ns); gbase += (size_t)ns; }
+				} else {
+					for (int x = gcur - 1; x >= g; --x) { k2a_gen_cols<G, C>(x, qlen, tlen, w, &gjlo, &ns); gbase -= (size_t)ns; }
+				}
+				k2a_gen_cols<G, C>(g, qlen, tlen, w, &gjlo, &ns);
+				gcur = g;
+			}
+			const int l = S - g * G;
+			word = ((gbase + (size_t)(j - gjlo + l)) * G + l) * WB;
+		}
 		const uint32_t byte = tb[word + ((c * BITS) >> 3)];
 		const uint32_t raw = DUAL ? byte : ((byte >> ((c * BITS) & 7)) & 0xf);
 		uint32_t d;                                   /* re-expand to the reference's byte layout */

@@ -17,9 +17,10 @@ extern "C" {
 #endif
 
 /* kernel geometry classes: lanes per alignment (G) x target rows per lane (C) */
-#define K2A_NCFG 4
-static const int k2a_cfg_G[K2A_NCFG] = { 16, 64, 64, 64 };
-static const int k2a_cfg_C[K2A_NCFG] = {  8,  8, 16, 32 };
+#define K2A_NCFG 5
+#define K2A_CFG_MP 4      /* generation-serial class: any band, boundary rows through HBM */
+static const int k2a_cfg_G[K2A_NCFG] = { 16, 64, 64, 64, 64 };
+static const int k2a_cfg_C[K2A_NCFG] = {  8,  8, 16, 32, 16 };
 
 const char *k2a_shim_backend(void);                /* "hip:gfx950" or "sim" */
 const char *k2a_shim_last_error(void);
@@ -50,7 +51,7 @@ float k2a_shim_event_ms(void *start, void *stop);  /* blocks on `stop` */
  * CIGAR (end -> start order) into cig[pairs[i].cig_off ...], count in res[i].n_cigar.
  */
 int k2a_shim_launch_fill(int cfg, int dual, int mode, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order,
-                         int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, void *stream);
+                         int ntasks, const uint8_t *seq, uint8_t *tb, int32_t *bnd, K2aResult *res, void *stream);
 int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb,
                           K2aResult *res, uint32_t *cig, void *stream);
 

@@ -73,7 +73,7 @@ k2a_fill_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const ui
 
 		const bool ninit = L.need_init(k);
 		if (__builtin_amdgcn_ballot_w64(ninit) != 0) {
-			if (ninit) L.do_init(sc);
+			if (ninit) L.template do_init<true>(sc);
 		}
 		const int qnext = L.next_query_code(k);
 
@@ -109,7 +109,117 @@ k2a_fill_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const ui
 	}
 }
 
-template<int G, int C, bool DUAL>
+/* Generation-serial fill (class K2A_CFG_MP): bands too wide to keep resident.  One alignment per wavefront;
+ * generation g = rows g*G*C .. (g+1)*G*C-1 over all their in-band columns.  Lane G-1 streams its bottom row
+ * (H, E[, E~]) to the boundary buffer, lane 0 of the next generation streams it back in (L1-bypassing loads,
+ * the producer wrote them thousands of steps earlier from this same wavefront). */
+template<int G, int C, bool DUAL, int MODE>
+__global__ void __launch_bounds__(64 * K2A_WPB)
+k2a_fill_mp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
+                   const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, int32_t *bnd, K2aResult *__restrict__ res)
+{
+	static_assert(G == 64, "one alignment per wavefront");
+	typedef K2aLane<G, C, DUAL, MODE> Lane;
+	__shared__ K2aBook book[K2A_WPB];
+
+	const int gl = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int task = blockIdx.x * K2A_WPB + wave;
+	const bool valid = task < ntasks;
+	const uint32_t pi = order[valid ? task : 0];
+	const K2aPair pr = pairs[pi];
+
+	Lane L;
+	L.setup(pr, seq, gl, valid);
+	K2aBook *bk = &book[wave];
+	if (gl == 0) k2a_book_reset(bk);
+	__builtin_amdgcn_wave_barrier();
+
+	int32_t *Bh = bnd + pr.bnd_off, *Be = Bh + pr.qlen, *Be2 = Be + pr.qlen;
+	uint8_t *tbp = tb + pr.tb_off + (size_t)gl * (Lane::TBWORDS * 4);
+	const int R = G * C;
+	const int ngen = valid ? (pr.tlen + R - 1) / R : 0;
+	size_t kbase = 0;
+	bool dropped = false;
+
+	for (int g = 0; g < ngen && !dropped; ++g) {
+		int jlo, nsteps;
+		k2a_gen_cols<G, C>(g, pr.qlen, pr.tlen, pr.w, &jlo, &nsteps);
+		L.begin_generation(g, jlo);
+		const bool feeder = (gl == 0 && g > 0);             /* takes its top row from the boundary buffer */
+		const bool drain = (gl == G - 1);                   /* bottom row of the generation */
+		/* two-deep prefetch of the boundary row for lane 0 */
+		int ph0 = K2A_NEG, pe0 = K2A_NEG, pe20 = K2A_NEG, ph1 = K2A_NEG, pe1 = K2A_NEG, pe21 = K2A_NEG;
+		if (feeder) {
+			if (jlo > 0) L.hu_prev = __hip_atomic_load(&Bh[jlo - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			ph0 = __hip_atomic_load(&Bh[jlo], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			pe0 = __hip_atomic_load(&Be[jlo], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (DUAL) pe20 = __hip_atomic_load(&Be2[jlo], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (jlo + 1 < pr.qlen) {
+				ph1 = __hip_atomic_load(&Bh[jlo + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				pe1 = __hip_atomic_load(&Be[jlo + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (DUAL) pe21 = __hip_atomic_load(&Be2[jlo + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+		L.qb = L.next_query_code(-1);
+		for (int k = 0; k < nsteps; ++k) {
+			int hin = k2a_rot1<G>(L.hout);
+			int ein = k2a_rot1<G>(L.eout);
+			int e2in = DUAL ? k2a_rot1<G>(L.e2out) : 0;
+			if (feeder) {
+				hin = ph0; ein = pe0; e2in = pe20;
+				ph0 = ph1; pe0 = pe1; pe20 = pe21;
+				const int jn = jlo + k + 2;
+				if (jn < pr.qlen) {
+					ph1 = __hip_atomic_load(&Bh[jn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					pe1 = __hip_atomic_load(&Be[jn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if (DUAL) pe21 = __hip_atomic_load(&Be2[jn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+			}
+			const bool ninit = L.need_init(k);
+			if (__builtin_amdgcn_ballot_w64(ninit) != 0) {
+				if (ninit) L.template do_init<false>(sc);
+			}
+			const int qnext = L.next_query_code(k);
+			uint32_t tw[Lane::TBWORDS];
+			const int jj = L.column(k);
+			const bool mine = L.S >= 0 && jj >= 0 && jj <= L.je;
+			const bool live = L.step(sc, k, hin, ein, e2in, tw);
+			if (MODE != K2A_MODE_SCORE) {
+				if (live) {
+					uint32_t *dst = (uint32_t*)(tbp + (kbase + (size_t)k) * (G * Lane::TBWORDS * 4));
+					if (Lane::TBWORDS == 1) dst[0] = tw[0];
+					else if (Lane::TBWORDS == 2) *(uint2*)dst = make_uint2(tw[0], tw[1]);
+					else {
+#pragma unroll
+						for (int x = 0; x < Lane::TBWORDS; x += 4)
+							*(uint4*)(dst + x) = make_uint4(tw[x], tw[x + 1 < Lane::TBWORDS ? x + 1 : x], tw[x + 2 < Lane::TBWORDS ? x + 2 : x],
+							                               tw[x + 3 < Lane::TBWORDS ? x + 3 : x]);
+					}
+				}
+			}
+			if (drain && mine) {
+				Bh[jj] = L.hout; Be[jj] = L.eout;
+				if (DUAL) Be2[jj] = L.e2out;
+			}
+			const bool nfin = L.need_fin(k);
+			if (__builtin_amdgcn_ballot_w64(nfin) != 0) {
+				if (nfin) L.do_fin(sc, bk, pr.zdrop);
+				__builtin_amdgcn_wave_barrier();
+				if (bk->dropped) dropped = true;
+			}
+			L.qb = qnext;
+			if (dropped) break;
+		}
+		kbase += (size_t)nsteps;
+	}
+	__builtin_amdgcn_wave_barrier();
+	if (valid && gl == 0) {
+		const K2aBook b = *bk;
+		k2a_finish(pr, b, &res[pi]);
+	}
+}
+
+template<int G, int C, bool DUAL, bool MP>
 __global__ void __launch_bounds__(64)
 k2a_trace_kernel(const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
                  const uint8_t *__restrict__ tb, K2aResult *__restrict__ res, uint32_t *__restrict__ cig)
@@ -120,7 +230,7 @@ k2a_trace_kernel(const K2aPair *__restrict__ pairs, const uint32_t *__restrict__
 	const K2aPair pr = pairs[pi];
 	const int ti = res[pi].ti, tj = res[pi].tj;
 	int n = 0;
-	if (ti >= 0 && tj >= 0) n = k2a_trace_pair<G, C, DUAL>(tb + pr.tb_off, ti, tj, cig + pr.cig_off);
+	if (ti >= 0 && tj >= 0) n = k2a_trace_pair<G, C, DUAL, MP>(tb + pr.tb_off, ti, tj, cig + pr.cig_off, pr.qlen, pr.tlen, pr.w);
 	res[pi].n_cigar = n;
 }
 
@@ -143,9 +253,14 @@ typedef void (*trace_fn)(const K2aPair*, const uint32_t*, int, const uint8_t*, K
 
 #define FILL_ROW(G, C) { { k2a_fill_kernel<G, C, false, 0>, k2a_fill_kernel<G, C, false, 1>, k2a_fill_kernel<G, C, false, 2> }, \
                          { k2a_fill_kernel<G, C, true, 0>,  k2a_fill_kernel<G, C, true, 1>,  k2a_fill_kernel<G, C, true, 2> } }
-static const fill_fn g_fill[K2A_NCFG][2][3] = { FILL_ROW(16, 8), FILL_ROW(64, 8), FILL_ROW(64, 16), FILL_ROW(64, 32) };
-#define TRACE_ROW(G, C) { k2a_trace_kernel<G, C, false>, k2a_trace_kernel<G, C, true> }
-static const trace_fn g_trace[K2A_NCFG][2] = { TRACE_ROW(16, 8), TRACE_ROW(64, 8), TRACE_ROW(64, 16), TRACE_ROW(64, 32) };
+static const fill_fn g_fill[4][2][3] = { FILL_ROW(16, 8), FILL_ROW(64, 8), FILL_ROW(64, 16), FILL_ROW(64, 32) };
+typedef void (*fill_mp_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, int32_t*, K2aResult*);
+static const fill_mp_fn g_fill_mp[2][3] = {
+	{ k2a_fill_mp_kernel<64, 16, false, 0>, k2a_fill_mp_kernel<64, 16, false, 1>, k2a_fill_mp_kernel<64, 16, false, 2> },
+	{ k2a_fill_mp_kernel<64, 16, true, 0>,  k2a_fill_mp_kernel<64, 16, true, 1>,  k2a_fill_mp_kernel<64, 16, true, 2> } };
+#define TRACE_ROW(G, C, MP) { k2a_trace_kernel<G, C, false, MP>, k2a_trace_kernel<G, C, true, MP> }
+static const trace_fn g_trace[K2A_NCFG][2] = { TRACE_ROW(16, 8, false), TRACE_ROW(64, 8, false), TRACE_ROW(64, 16, false),
+                                               TRACE_ROW(64, 32, false), TRACE_ROW(64, 16, true) };
 
 extern "C" {
 
@@ -221,14 +336,18 @@ float k2a_shim_event_ms(void *start, void *stop)
 }
 
 int k2a_shim_launch_fill(int cfg, int dual, int mode, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order,
-                         int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, void *stream)
+                         int ntasks, const uint8_t *seq, uint8_t *tb, int32_t *bnd, K2aResult *res, void *stream)
 {
 	if (ntasks <= 0) return 0;
 	if (cfg < 0 || cfg >= K2A_NCFG || mode < 0 || mode > 2) { snprintf(g_err, sizeof(g_err), "bad kernel class"); return -1; }
 	const int per_block = K2A_WPB * (64 / k2a_cfg_G[cfg]);
 	const int blocks = (ntasks + per_block - 1) / per_block;
-	hipLaunchKernelGGL(g_fill[cfg][dual ? 1 : 0][mode], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
-	                   *sc, pairs, order, ntasks, seq, tb, res);
+	if (cfg == K2A_CFG_MP)
+		hipLaunchKernelGGL(g_fill_mp[dual ? 1 : 0][mode], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
+		                   *sc, pairs, order, ntasks, seq, tb, bnd, res);
+	else
+		hipLaunchKernelGGL(g_fill[cfg][dual ? 1 : 0][mode], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
+		                   *sc, pairs, order, ntasks, seq, tb, res);
 	CHECK(hipGetLastError());
 	return 0;
 }

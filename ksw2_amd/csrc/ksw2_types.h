@@ -36,6 +36,8 @@ typedef struct K2aPair {
 	int32_t zdrop, end_bonus, flag;
 	uint32_t cig_off;            /* dword offset of this pair's CIGAR scratch                              */
 	uint64_t tb_off;             /* byte offset of this pair's traceback block                            */
+	uint32_t bnd_off;            /* int32 offset of this pair's generation boundary rows (3 x qlen ints)   */
+	uint32_t pad;
 } K2aPair;
 
 /* what the reference keeps in ksw_extz_t (ksw2.h:33-42), one per alignment */

@@ -51,7 +51,7 @@ static void sim_fill(const K2aScoring sc, const K2aPair *pairs, const uint32_t *
 			bool anyfin = false;
 			bool nfin[64];
 			for (int lane = 0; lane < 64; ++lane) {
-				if (L[lane].need_init(k)) L[lane].do_init(sc);
+				if (L[lane].need_init(k)) L[lane].template do_init<true>(sc);
 				qnext[lane] = L[lane].next_query_code(k);
 				uint32_t tw[Lane::TBWORDS];
 				const bool live = L[lane].step(sc, k, hin[lane], ein[lane], e2in[lane], tw);
@@ -78,14 +78,76 @@ static void sim_fill(const K2aScoring sc, const K2aPair *pairs, const uint32_t *
 	}
 }
 
-template<int G, int C, bool DUAL>
+/* mirrors k2a_fill_mp_kernel */
+template<int G, int C, bool DUAL, int MODE>
+static void sim_fill_mp(const K2aScoring sc, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, uint8_t *tb,
+                        int32_t *bnd, K2aResult *res)
+{
+	typedef K2aLane<G, C, DUAL, MODE> Lane;
+	for (int task = 0; task < ntasks; ++task) {
+		static Lane L[64];
+		K2aBook book;
+		const uint32_t pi = order[task];
+		const K2aPair pr = pairs[pi];
+		for (int gl = 0; gl < 64; ++gl) L[gl].setup(pr, seq, gl, true);
+		k2a_book_reset(&book);
+		int32_t *Bh = bnd + pr.bnd_off, *Be = Bh + pr.qlen, *Be2 = Be + pr.qlen;
+		const int R = G * C, ngen = (pr.tlen + R - 1) / R;
+		size_t kbase = 0;
+		bool dropped = false;
+		for (int g = 0; g < ngen && !dropped; ++g) {
+			int jlo, nsteps;
+			k2a_gen_cols<G, C>(g, pr.qlen, pr.tlen, pr.w, &jlo, &nsteps);
+			for (int gl = 0; gl < 64; ++gl) { L[gl].begin_generation(g, jlo); }
+			if (g > 0 && jlo > 0) L[0].hu_prev = Bh[jlo - 1];
+			for (int gl = 0; gl < 64; ++gl) L[gl].qb = L[gl].next_query_code(-1);
+			for (int k = 0; k < nsteps; ++k) {
+				int hin[64], ein[64], e2in[64], qnext[64];
+				for (int gl = 0; gl < 64; ++gl) {
+					const int src = (gl + G - 1) % G;
+					hin[gl] = L[src].hout; ein[gl] = L[src].eout; e2in[gl] = DUAL ? L[src].e2out : 0;
+				}
+				if (g > 0) {
+					const int j = jlo + k;
+					hin[0] = j < pr.qlen ? Bh[j] : K2A_NEG; ein[0] = j < pr.qlen ? Be[j] : K2A_NEG;
+					e2in[0] = (DUAL && j < pr.qlen) ? Be2[j] : K2A_NEG;
+				}
+				bool nfin[64], anyfin = false;
+				for (int gl = 0; gl < 64; ++gl) {
+					if (L[gl].need_init(k)) L[gl].template do_init<false>(sc);
+					qnext[gl] = L[gl].next_query_code(k);
+					uint32_t tw[Lane::TBWORDS];
+					const int jj = L[gl].column(k);
+					const bool mine = L[gl].S >= 0 && jj >= 0 && jj <= L[gl].je;
+					const bool live = L[gl].step(sc, k, hin[gl], ein[gl], e2in[gl], tw);
+					if (MODE != K2A_MODE_SCORE && live)
+						memcpy(tb + pr.tb_off + ((kbase + (size_t)k) * G + gl) * (Lane::TBWORDS * 4), tw, sizeof(tw));
+					if (gl == G - 1 && mine) { Bh[jj] = L[gl].hout; Be[jj] = L[gl].eout; if (DUAL) Be2[jj] = L[gl].e2out; }
+					nfin[gl] = L[gl].need_fin(k);
+					anyfin |= nfin[gl];
+				}
+				if (anyfin) {
+					for (int gl = 0; gl < 64; ++gl) if (nfin[gl]) L[gl].do_fin(sc, &book, pr.zdrop);
+					if (book.dropped) dropped = true;
+				}
+				for (int gl = 0; gl < 64; ++gl) L[gl].qb = qnext[gl];
+				if (dropped) break;
+			}
+			kbase += (size_t)nsteps;
+		}
+		k2a_finish(pr, book, &res[pi]);
+	}
+}
+
+template<int G, int C, bool DUAL, bool MP>
 static void sim_trace(const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb, K2aResult *res, uint32_t *cig)
 {
 	for (int t = 0; t < ntasks; ++t) {
 		const uint32_t pi = order[t];
 		const K2aPair pr = pairs[pi];
 		int n = 0;
-		if (res[pi].ti >= 0 && res[pi].tj >= 0) n = k2a_trace_pair<G, C, DUAL>(tb + pr.tb_off, res[pi].ti, res[pi].tj, cig + pr.cig_off);
+		if (res[pi].ti >= 0 && res[pi].tj >= 0)
+			n = k2a_trace_pair<G, C, DUAL, MP>(tb + pr.tb_off, res[pi].ti, res[pi].tj, cig + pr.cig_off, pr.qlen, pr.tlen, pr.w);
 		res[pi].n_cigar = n;
 	}
 }
@@ -94,9 +156,14 @@ typedef void (*fill_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, 
 typedef void (*trace_fn)(const K2aPair*, const uint32_t*, int, const uint8_t*, K2aResult*, uint32_t*);
 #define FILL_ROW(G, C) { { sim_fill<G, C, false, 0>, sim_fill<G, C, false, 1>, sim_fill<G, C, false, 2> }, \
                          { sim_fill<G, C, true, 0>,  sim_fill<G, C, true, 1>,  sim_fill<G, C, true, 2> } }
-static const fill_fn g_fill[K2A_NCFG][2][3] = { FILL_ROW(16, 8), FILL_ROW(64, 8), FILL_ROW(64, 16), FILL_ROW(64, 32) };
-#define TRACE_ROW(G, C) { sim_trace<G, C, false>, sim_trace<G, C, true> }
-static const trace_fn g_trace[K2A_NCFG][2] = { TRACE_ROW(16, 8), TRACE_ROW(64, 8), TRACE_ROW(64, 16), TRACE_ROW(64, 32) };
+static const fill_fn g_fill[4][2][3] = { FILL_ROW(16, 8), FILL_ROW(64, 8), FILL_ROW(64, 16), FILL_ROW(64, 32) };
+typedef void (*fill_mp_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, int32_t*, K2aResult*);
+static const fill_mp_fn g_fill_mp[2][3] = {
+	{ sim_fill_mp<64, 16, false, 0>, sim_fill_mp<64, 16, false, 1>, sim_fill_mp<64, 16, false, 2> },
+	{ sim_fill_mp<64, 16, true, 0>,  sim_fill_mp<64, 16, true, 1>,  sim_fill_mp<64, 16, true, 2> } };
+#define TRACE_ROW(G, C, MP) { sim_trace<G, C, false, MP>, sim_trace<G, C, true, MP> }
+static const trace_fn g_trace[K2A_NCFG][2] = { TRACE_ROW(16, 8, false), TRACE_ROW(64, 8, false), TRACE_ROW(64, 16, false),
+                                               TRACE_ROW(64, 32, false), TRACE_ROW(64, 16, true) };
 
 extern "C" {
 
@@ -125,9 +192,11 @@ int k2a_shim_event_record(void *ev, void *)
 float k2a_shim_event_ms(void *a, void *b) { return (float)(*(double*)b - *(double*)a); }
 
 int k2a_shim_launch_fill(int cfg, int dual, int mode, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order,
-                         int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, void *)
+                         int ntasks, const uint8_t *seq, uint8_t *tb, int32_t *bnd, K2aResult *res, void *)
 {
-	if (ntasks > 0) g_fill[cfg][dual ? 1 : 0][mode](*sc, pairs, order, ntasks, seq, tb, res);
+	if (ntasks <= 0) return 0;
+	if (cfg == K2A_CFG_MP) g_fill_mp[dual ? 1 : 0][mode](*sc, pairs, order, ntasks, seq, tb, bnd, res);
+	else g_fill[cfg][dual ? 1 : 0][mode](*sc, pairs, order, ntasks, seq, tb, res);
 	return 0;
 }
 int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb,

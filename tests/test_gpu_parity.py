@@ -182,3 +182,44 @@ def test_mt_pair_banded(lib):
     exp = ka_[("ksw_extd", 500, 0, -1)]
     res = lib.extd(qs[0], ts[0], mat, 4, 2, 13, 1, w=500)
     assert res["score"] == exp["score"] and gu.cigar_string(res["cigar"]) == exp["cigar"]
+
+
+def test_mt_pair_unbanded(lib):
+    """BASELINE config 4 input: MT-human x MT-orang, w=-1, full global with CIGAR (generation-serial kernels).
+    Golden: 16102 / 17054 / 16568 / 16024, CIGAR md5 ea0524d904ed (extz), df0e77e43f48 (extd), -r db8b671f4dbf."""
+    ka_ = {(r["func"], r["w"], r.get("flag", 0), r.get("zdrop", -1)): r for r in gu.known_answers()["mt"]}
+    _, ts = gu.read_fasta("MT-human.fa")
+    _, qs = gu.read_fasta("MT-orang.fa")
+    mat = gu.simple_mat(5, 2, 4, 0)
+    for func, flag, md5 in (("extz", 0, "ea0524d904ed"), ("extz", po.RIGHT, "db8b671f4dbf"), ("extd", 0, "df0e77e43f48"),
+                            ("extd", po.RIGHT, "8e2c9cfb877a")):
+        exp = ka_[("ksw_" + func, -1, flag, -1)]
+        res = lib.extz(qs[0], ts[0], mat, 4, 2, w=-1, flag=flag) if func == "extz" else lib.extd(qs[0], ts[0], mat, 4, 2, 13, 1, w=-1, flag=flag)
+        for f in gu.FIELDS:
+            assert res[f] == exp[f], (func, flag, f, res[f], exp[f])
+        s = gu.cigar_string(res["cigar"])
+        assert s == exp["cigar"] and hashlib.md5((s + "\n").encode()).hexdigest()[:12] == md5
+    # replicated batch: every replica is computed and identical (config 4 replicates this pair 4096 x)
+    n = 8
+    res = lib.extz_batch([qs[0]] * n, [ts[0]] * n, mat, 4, 2, w=-1, zdrop=-1, flag=po.GENERIC_SC)
+    exp = ka_[("ksw_extz", -1, 0, -1)]
+    for r in res:
+        assert r["score"] == exp["score"] and gu.cigar_string(r["cigar"]) == exp["cigar"]
+    s, c = lib.gg("gg2_sse", qs[0], ts[0], mat, 4, 2, w=-1)
+    assert s == 16102 and gu.cigar_string(c) == exp["cigar"]
+
+
+@pytest.mark.parametrize("dual", [False, True])
+def test_wide_band_ragged(lib, dual):
+    """Bands beyond the resident kernels (w > 1040 on > 2048 rows): generation-serial class, Z-drop and flags."""
+    rng = np.random.Generator(np.random.PCG64(77 + dual))
+    mat, q, e, q2, e2 = synth.simple_mat(5, 2, 4, -1), 4, 2, 24, 1
+    for mode in (po.SCORE_ONLY, 0, po.RIGHT):
+        n = 24
+        pairs = synth.ragged_pairs(rng, n, 2100, 5200, sub=0.05, ind=0.12, indel_mean=4.0, n_rate=0.005)
+        qs, ts = [p[0] for p in pairs], [p[1] for p in pairs]
+        w = rng.choice([-1, 1041, 1100, 2000, 3000], size=n)
+        zd = rng.choice([-1, 200, 400, 2000], size=n)
+        eb = rng.choice([0, 10, 50], size=n)
+        fl = np.array([mode | (po.EXTZ_ONLY if rng.random() < 0.3 else 0) | (po.REV_CIGAR if rng.random() < 0.3 else 0) for _ in range(n)])
+        check_batch(lib, dual, qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl)

@@ -1,0 +1,119 @@
+"""CPU: the product's host code (ksw2_host.c) and per-lane kernel code (ksw2_lane.h) linked against the
+host-memory lock-step wave simulator (tests/sim), checked against the oracle through the same C-ABI.
+
+This does not replace the GPU parity tests (tests/test_gpu_parity.py): it pins the packing, geometry choice,
+strip schedule, band masks, row bookkeeping and traceback layout on every commit without a GPU.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import ksw2_amd as ka
+from ksw2_amd import synth
+from oracle import pyoracle as po
+from tests import golden_util as gu
+from tests.parity_util import check_batch, diff
+
+SIM_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sim")
+
+
+@pytest.fixture(scope="module")
+def sim():
+    subprocess.run(["make", "-C", SIM_DIR], check=True, capture_output=True)
+    L = ka.Library(os.path.join(SIM_DIR, "libksw2_amd_sim.so"))
+    assert L.backend() == "sim"
+    return L
+
+
+@pytest.mark.parametrize("dual", [False, True])
+@pytest.mark.parametrize("mode", [po.SCORE_ONLY, 0, po.RIGHT])
+def test_sim_ragged(sim, dual, mode):
+    rng = np.random.Generator(np.random.PCG64(4321 + mode + 10 * dual))
+    mat, q, e, q2, e2 = synth.simple_mat(5, 2, 4, -1), 4, 2, 24, 1
+    for rnd in range(3):
+        n = 40
+        pairs = synth.ragged_pairs(rng, n, 1, [120, 700, 2200][rnd], sub=0.05, ind=0.12, n_rate=0.01 if rnd % 2 else 0.0)
+        qs, ts = [p[0] for p in pairs], [p[1] for p in pairs]
+        w = rng.choice([-1, 0, 1, 5, 20, 64, 68, 69, 100, 284, 285, 500, 536, 537, 1040, 1041], size=n)
+        zd = rng.choice([-1, 50, 200, 400], size=n)
+        eb = rng.choice([0, 10, 50], size=n)
+        fl = np.array([mode | (po.EXTZ_ONLY if rng.random() < 0.3 else 0) | (po.REV_CIGAR if rng.random() < 0.3 else 0) |
+                       (po.GENERIC_SC if rng.random() < 0.3 else 0) for _ in range(n)])
+        check_batch(sim, dual, qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl)
+
+
+def test_sim_generation_serial(sim):
+    rng = np.random.Generator(np.random.PCG64(99))
+    mat, q, e, q2, e2 = synth.simple_mat(5, 2, 4, -1), 4, 2, 24, 1
+    pairs = synth.ragged_pairs(rng, 6, 2100, 4200, sub=0.05, ind=0.12, indel_mean=4.0)
+    qs, ts = [p[0] for p in pairs], [p[1] for p in pairs]
+    for dual, flag in ((False, 0), (True, po.RIGHT), (False, po.SCORE_ONLY)):
+        check_batch(sim, dual, qs, ts, mat, q, e, q2, e2, w=np.array([-1, 1041, 2000, -1, 3000, 1100]),
+                    zdrop=np.array([-1, 400, -1, 200, 2000, -1]), flag=flag)
+
+
+def test_sim_golden_subset(sim):
+    """Every 6th committed random case (reference outputs) through the simulator build."""
+    rc = gu.RandomCases()
+    n = 0
+    for k in range(0, rc.n, 6):
+        c = rc.case(k)
+        dual = "extd" in c["func"]
+        if c["func"].endswith("2_sse"):
+            r = (sim.extd2(c["q"], c["t"], c["mat"], c["gq"], c["ge"], c["gq2"], c["ge2"], w=c["w"], zdrop=c["zdrop"], end_bonus=c["end_bonus"],
+                           flag=c["flag"]) if dual else
+                 sim.extz2(c["q"], c["t"], c["mat"], c["gq"], c["ge"], w=c["w"], zdrop=c["zdrop"], end_bonus=c["end_bonus"], flag=c["flag"]))
+            assert not diff(c["expect"], r, gu.SSE_LOOSE_FIELDS)
+        else:
+            r = (sim.extd(c["q"], c["t"], c["mat"], c["gq"], c["ge"], c["gq2"], c["ge2"], w=c["w"], zdrop=c["zdrop"], flag=c["flag"]) if dual else
+                 sim.extz(c["q"], c["t"], c["mat"], c["gq"], c["ge"], w=c["w"], zdrop=c["zdrop"], flag=c["flag"]))
+            assert not diff(c["expect"], r, gu.FIELDS + ["cigar"]), (c["func"], c["w"], c["zdrop"], c["flag"])
+        n += 1
+    assert n == 600
+
+
+def test_sim_t1q1_and_gg(sim):
+    ka_ = gu.known_answers()
+    _, ts = gu.read_fasta("t1.fa")
+    _, qs = gu.read_fasta("q1.fa")
+    mat = gu.simple_mat(5, 2, 4, 0)
+    for k, rec in enumerate(ka_["t1q1"]):
+        res = sim.extz(qs[k], ts[k], mat, 4, 2)
+        assert not diff(rec["ksw_extz/flag=0"], res, gu.FIELDS)
+        assert gu.cigar_string(res["cigar"]) == rec["ksw_extz/flag=0"]["cigar"]
+        for g in ("gg", "gg2", "gg2_sse"):
+            s, c = sim.gg(g, qs[k], ts[k], mat, 4, 2, w=-1)
+            assert s == rec["ksw_gg"]["score"] and gu.cigar_string(c) == rec["ksw_gg"]["cigar"]
+        s, _ = sim.gg("gg2", qs[k], ts[k], mat, 4, 2, w=-1, with_cigar=False)
+        assert s == rec["ksw_gg"]["score"]
+
+
+def test_sim_edge_cases(sim):
+    mat = synth.simple_mat(5, 2, 4, -1)
+    one = np.array([1], dtype=np.uint8)
+    r = sim.extz2(np.zeros(0, np.uint8), one, mat, 4, 2)
+    assert (r["score"], r["max"], r["max_t"], r["n_cigar"], r["zdropped"]) == (ka.KSW_NEG_INF, 0, -1, 0, 0)
+    r = sim.extz2(one, one, synth.simple_mat(5, 1, 20, -1), 4, 2)
+    assert r["score"] == ka.KSW_NEG_INF and r["n_cigar"] == 0
+    rng = np.random.Generator(np.random.PCG64(5))
+    t = rng.integers(0, 4, 300, dtype=np.uint8)
+    qv = t[:100].copy()
+    for qq, tt in ((qv, t), (t, qv)):
+        exp = po.align("oracle", "extz2", qq, tt, mat, 4, 2, w=10)
+        res = sim.extz2(qq, tt, mat, 4, 2, w=10)
+        assert not diff(exp, res) and res["zdropped"] == 1 and res["score"] == ka.KSW_NEG_INF
+    # m > 5 is refused loudly, not computed some other way
+    with pytest.raises(ka.Ksw2Error):
+        sim.extz_batch([one], [one], np.zeros(36, np.int8), 4, 2, m=6)
+
+
+def test_sim_eqx(sim):
+    rng = np.random.Generator(np.random.PCG64(3))
+    mat = synth.simple_mat(5, 2, 4, -1)
+    for _ in range(20):
+        (qq, tt), = synth.ragged_pairs(rng, 1, 20, 200, sub=0.1, ind=0.1)
+        exp = po.align("oracle", "extd2", qq, tt, mat, 4, 2, 24, 1, flag=po.EQX)
+        res = sim.extd2(qq, tt, mat, 4, 2, 24, 1, flag=po.EQX)
+        assert res["cigar"] == exp["cigar"] and all((c & 0xf) != 0 for c in res["cigar"])
