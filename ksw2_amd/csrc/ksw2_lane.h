@@ -138,7 +138,7 @@ struct K2aLane {
 
 	/* start strip Snext at step k (its first column): row state from the virtual column -1 or -inf */
 	template<bool RESIDENT>
-	K2A_FN void do_init(const K2aScoring &sc)
+	K2A_FN void do_init(const K2aScoring &sc, const uint32_t *ptab)
 	{
 		S = Snext; i0 = S * C; koff = koff_next;
 		je = k2a_min(qlen - 1, k2a_min(i0 + C - 1, tlen - 1) + w);
@@ -150,7 +150,7 @@ struct K2aLane {
 			const int i = i0 + c;
 			const uint32_t tb = (tbp[c >> 2] >> (8 * (c & 3))) & 0xff;
 			const uint32_t tbc = tb < 4 ? tb : 4;
-			P[c] = tbc == 0 ? sc.prof[0] : tbc == 1 ? sc.prof[1] : tbc == 2 ? sc.prof[2] : tbc == 3 ? sc.prof[3] : sc.prof[4];
+			P[c] = ptab[tbc];                                 /* score profile of this row's target code (LDS table) */
 			/* rows that start at column 0 see the virtual column -1 (ksw2_extz.c:43-44, ksw2_extd.c:49-52) */
 			const bool edge = i <= w;
 			const int hb = k2a_border<DUAL>(sc, i + 1);
@@ -171,8 +171,11 @@ struct K2aLane {
 	/* One step: column jj = k - koff for the C rows of the current strip.
 	 *   hin/ein/e2in: bottom-row outputs of the previous lane at the previous step (already rotated in)
 	 *   tbw: traceback word(s) out (MODE != SCORE)
+	 *   WILD: some lane of the wavefront sees the query wildcard in this column (wave-uniform, rare): scores
+	 *         come from the per-target-code column table `ctab` instead of the 4-entry register profile
 	 * returns true when this lane computed live cells (so tbw is meaningful). */
-	K2A_FN bool step(const K2aScoring &sc, int k, int hin, int ein, int e2in, uint32_t *tbw)
+	template<bool WILD>
+	K2A_FN bool step(const K2aScoring &sc, const uint32_t *ctab, int k, int hin, int ein, int e2in, uint32_t *tbw)
 	{
 		const int jj = k - koff;
 		const bool act = (S >= 0) && (jj <= je) && (jj >= 0);
@@ -202,10 +205,10 @@ struct K2aLane {
 #pragma unroll
 		for (int c = 0; c < C; ++c) {
 			int s = (int)(int8_t)(P[c] >> qsh);
-			if (qwild) {
+			if (WILD) {
 				const uint32_t tb = (tbp[c >> 2] >> (8 * (c & 3))) & 0xff;
-				const uint32_t tbc = tb < 4 ? tb : 4;
-				s = tbc == 0 ? sc.colw[0] : tbc == 1 ? sc.colw[1] : tbc == 2 ? sc.colw[2] : tbc == 3 ? sc.colw[3] : sc.colw[4];
+				const int sw = (int)ctab[tb < 4 ? tb : 4];
+				s = qwild ? sw : s;
 			}
 			int h = hd + s;
 			const int fc = f[c];

@@ -41,6 +41,9 @@ k2a_fill_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const ui
 	constexpr int NG = 64 / G;
 	typedef K2aLane<G, C, DUAL, MODE> Lane;
 	__shared__ K2aBook book[K2A_WPB][NG];
+	__shared__ uint32_t tabs[16];                     /* [0..4] row profiles, [8..12] scores against the query wildcard */
+	if (threadIdx.x < 5) { tabs[threadIdx.x] = sc.prof[threadIdx.x]; tabs[8 + threadIdx.x] = (uint32_t)sc.colw[threadIdx.x]; }
+	__syncthreads();
 
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int grp = lane / G, gl = lane % G;
@@ -73,12 +76,13 @@ k2a_fill_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const ui
 
 		const bool ninit = L.need_init(k);
 		if (__builtin_amdgcn_ballot_w64(ninit) != 0) {
-			if (ninit) L.template do_init<true>(sc);
+			if (ninit) L.template do_init<true>(sc, tabs);
 		}
 		const int qnext = L.next_query_code(k);
 
 		uint32_t tw[Lane::TBWORDS];
-		const bool live = L.step(sc, k, hin, ein, e2in, tw);
+		const bool wild = __builtin_amdgcn_ballot_w64(L.qb >= 4) != 0;
+		const bool live = wild ? L.template step<true>(sc, tabs + 8, k, hin, ein, e2in, tw) : L.template step<false>(sc, tabs + 8, k, hin, ein, e2in, tw);
 		if (MODE != K2A_MODE_SCORE) {
 			if (live) {
 				uint32_t *dst = (uint32_t*)(tbp + (size_t)k * (G * Lane::TBWORDS * 4));
@@ -121,6 +125,9 @@ k2a_fill_mp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	static_assert(G == 64, "one alignment per wavefront");
 	typedef K2aLane<G, C, DUAL, MODE> Lane;
 	__shared__ K2aBook book[K2A_WPB];
+	__shared__ uint32_t tabs[16];
+	if (threadIdx.x < 5) { tabs[threadIdx.x] = sc.prof[threadIdx.x]; tabs[8 + threadIdx.x] = (uint32_t)sc.colw[threadIdx.x]; }
+	__syncthreads();
 
 	const int gl = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int task = blockIdx.x * K2A_WPB + wave;
@@ -177,13 +184,14 @@ k2a_fill_mp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 			}
 			const bool ninit = L.need_init(k);
 			if (__builtin_amdgcn_ballot_w64(ninit) != 0) {
-				if (ninit) L.template do_init<false>(sc);
+				if (ninit) L.template do_init<false>(sc, tabs);
 			}
 			const int qnext = L.next_query_code(k);
 			uint32_t tw[Lane::TBWORDS];
 			const int jj = L.column(k);
 			const bool mine = L.S >= 0 && jj >= 0 && jj <= L.je;
-			const bool live = L.step(sc, k, hin, ein, e2in, tw);
+			const bool wild = __builtin_amdgcn_ballot_w64(L.qb >= 4) != 0;
+			const bool live = wild ? L.template step<true>(sc, tabs + 8, k, hin, ein, e2in, tw) : L.template step<false>(sc, tabs + 8, k, hin, ein, e2in, tw);
 			if (MODE != K2A_MODE_SCORE) {
 				if (live) {
 					uint32_t *dst = (uint32_t*)(tbp + (kbase + (size_t)k) * (G * Lane::TBWORDS * 4));

@@ -14,6 +14,11 @@
 
 static char g_err[256] = "";
 
+static void make_tabs(const K2aScoring &sc, uint32_t *tabs)
+{
+	for (int x = 0; x < 5; ++x) { tabs[x] = sc.prof[x]; tabs[8 + x] = (uint32_t)sc.colw[x]; }
+}
+
 template<int G, int C, bool DUAL, int MODE>
 static void sim_fill(const K2aScoring sc, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, uint8_t *tb,
                      K2aResult *res)
@@ -21,6 +26,8 @@ static void sim_fill(const K2aScoring sc, const K2aPair *pairs, const uint32_t *
 	constexpr int NG = 64 / G;
 	typedef K2aLane<G, C, DUAL, MODE> Lane;
 	const int nwaves = (ntasks + NG - 1) / NG;
+	uint32_t tabs[16] = {0};
+	make_tabs(sc, tabs);
 	for (int wv = 0; wv < nwaves; ++wv) {
 		static Lane L[64];
 		K2aBook book[NG];
@@ -48,13 +55,17 @@ static void sim_fill(const K2aScoring sc, const K2aPair *pairs, const uint32_t *
 				const int grp = lane / G, gl = lane % G, src = grp * G + (gl + G - 1) % G;
 				hin[lane] = L[src].hout; ein[lane] = L[src].eout; e2in[lane] = DUAL ? L[src].e2out : 0;
 			}
-			bool anyfin = false;
+			bool anyfin = false, wild = false;
 			bool nfin[64];
+			for (int lane = 0; lane < 64; ++lane) {      /* init events first: the wave-uniform wildcard test follows them */
+				if (L[lane].need_init(k)) L[lane].template do_init<true>(sc, tabs);
+				wild |= L[lane].qb >= 4;
+			}
 			for (int lane = 0; lane < 64; ++lane) {
-				if (L[lane].need_init(k)) L[lane].template do_init<true>(sc);
 				qnext[lane] = L[lane].next_query_code(k);
 				uint32_t tw[Lane::TBWORDS];
-				const bool live = L[lane].step(sc, k, hin[lane], ein[lane], e2in[lane], tw);
+				const bool live = wild ? L[lane].template step<true>(sc, tabs + 8, k, hin[lane], ein[lane], e2in[lane], tw)
+				                       : L[lane].template step<false>(sc, tabs + 8, k, hin[lane], ein[lane], e2in[lane], tw);
 				if (MODE != K2A_MODE_SCORE && live)
 					memcpy(tbp[lane] + (size_t)k * (G * Lane::TBWORDS * 4), tw, sizeof(tw));
 				nfin[lane] = L[lane].need_fin(k);
@@ -89,6 +100,8 @@ static void sim_fill_mp(const K2aScoring sc, const K2aPair *pairs, const uint32_
 		K2aBook book;
 		const uint32_t pi = order[task];
 		const K2aPair pr = pairs[pi];
+		uint32_t tabs[16] = {0};
+		make_tabs(sc, tabs);
 		for (int gl = 0; gl < 64; ++gl) L[gl].setup(pr, seq, gl, true);
 		k2a_book_reset(&book);
 		int32_t *Bh = bnd + pr.bnd_off, *Be = Bh + pr.qlen, *Be2 = Be + pr.qlen;
@@ -112,14 +125,18 @@ static void sim_fill_mp(const K2aScoring sc, const K2aPair *pairs, const uint32_
 					hin[0] = j < pr.qlen ? Bh[j] : K2A_NEG; ein[0] = j < pr.qlen ? Be[j] : K2A_NEG;
 					e2in[0] = (DUAL && j < pr.qlen) ? Be2[j] : K2A_NEG;
 				}
-				bool nfin[64], anyfin = false;
+				bool nfin[64], anyfin = false, wild = false;
 				for (int gl = 0; gl < 64; ++gl) {
-					if (L[gl].need_init(k)) L[gl].template do_init<false>(sc);
+					if (L[gl].need_init(k)) L[gl].template do_init<false>(sc, tabs);
+					wild |= L[gl].qb >= 4;
+				}
+				for (int gl = 0; gl < 64; ++gl) {
 					qnext[gl] = L[gl].next_query_code(k);
 					uint32_t tw[Lane::TBWORDS];
 					const int jj = L[gl].column(k);
 					const bool mine = L[gl].S >= 0 && jj >= 0 && jj <= L[gl].je;
-					const bool live = L[gl].step(sc, k, hin[gl], ein[gl], e2in[gl], tw);
+					const bool live = wild ? L[gl].template step<true>(sc, tabs + 8, k, hin[gl], ein[gl], e2in[gl], tw)
+					                       : L[gl].template step<false>(sc, tabs + 8, k, hin[gl], ein[gl], e2in[gl], tw);
 					if (MODE != K2A_MODE_SCORE && live)
 						memcpy(tb + pr.tb_off + ((kbase + (size_t)k) * G + gl) * (Lane::TBWORDS * 4), tw, sizeof(tw));
 					if (gl == G - 1 && mine) { Bh[jj] = L[gl].hout; Be[jj] = L[gl].eout; if (DUAL) Be2[jj] = L[gl].e2out; }
