@@ -14,7 +14,6 @@ import ctypes
 import json
 import os
 import sys
-import threading
 import time
 
 import numpy as np
@@ -49,62 +48,35 @@ def make_batch(wl, rank, n_override=None):
 
 
 def cpu_baseline(wl, q, t, mat, seconds=10.0):
-    """Reference ksw_extz2_sse / ksw_extd2_sse (oracle/_ref, -O2 -msse4.1) on this box's host cores, bounded sample."""
+    """Reference ksw_extz2_sse / ksw_extd2_sse (oracle/_ref, gcc -O2 -msse4.1) on this box's host cores: a bounded sample of
+    the same batch, 1 thread and all cores, pthread loop in oracle/cpu_bench.c."""
     from oracle import pyoracle as po
-    lib = po.ref_lib()
-    kind = "reference"
-    if lib is None:
-        lib, kind = po.oracle_lib(), "port"
+    olib = po.oracle_lib()
+    ref = po.ref_lib()
+    kind = "reference" if ref is not None else "port"
+    name = ("ksw_extd2_sse" if wl["dual"] else "ksw_extz2_sse") if ref is not None else ("kso_extd2_km" if wl["dual"] else "kso_extz2_km")
+    fn = ctypes.cast(getattr(ref if ref is not None else olib, name), ctypes.c_void_p)
+    olib.kso_cpu_bench.restype = ctypes.c_long
+    olib.kso_cpu_bench.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int8, ctypes.c_void_p, ctypes.c_int8, ctypes.c_int8,
+                                   ctypes.c_int8, ctypes.c_int8, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
     cells_pair = synth.band_cells(wl["qlen"], wl["tlen"], wl["w"])
-    matp = mat.ctypes.data_as(ctypes.POINTER(ctypes.c_int8))
-    u8 = ctypes.POINTER(ctypes.c_uint8)
     S = SCORING
-
-    def one(i, ez):
-        qp, tp = q[i].ctypes.data_as(u8), t[i].ctypes.data_as(u8)
-        if kind == "reference":
-            if wl["dual"]:
-                lib.ksw_extd2_sse(None, wl["qlen"], qp, wl["tlen"], tp, 5, matp, S["q"], S["e"], S["q2"], S["e2"], wl["w"], wl["zdrop"], 0, wl["flag"], ez)
-            else:
-                lib.ksw_extz2_sse(None, wl["qlen"], qp, wl["tlen"], tp, 5, matp, S["q"], S["e"], wl["w"], wl["zdrop"], 0, wl["flag"], ez)
-        else:
-            if wl["dual"]:
-                lib.kso_extd2(wl["qlen"], qp, wl["tlen"], tp, 5, matp, S["q"], S["e"], S["q2"], S["e2"], wl["w"], wl["zdrop"], 0, wl["flag"], ez)
-            else:
-                lib.kso_extz2(wl["qlen"], qp, wl["tlen"], tp, 5, matp, S["q"], S["e"], wl["w"], wl["zdrop"], 0, wl["flag"], ez)
-
-    def worker(counter, lock, deadline, done):
-        ez = po.Ez()
-        n = 0
-        while time.perf_counter() < deadline:
-            with lock:
-                i = counter[0]
-                counter[0] += 1
-            one(i % len(q), ez)
-            n += 1
-        if ez.cigar:
-            po._libc.free(ctypes.cast(ez.cigar, ctypes.c_void_p))
-        done.append(n)
-
+    qa, ta = np.ascontiguousarray(q), np.ascontiguousarray(t)
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     out = {}
-    for threads in (1, os.cpu_count() or 1):
-        counter, lock, done = [0], threading.Lock(), []
-        t0 = time.perf_counter()
-        th = [threading.Thread(target=worker, args=(counter, lock, t0 + seconds, done)) for _ in range(threads)]
-        [x.start() for x in th]
-        [x.join() for x in th]
-        dt = time.perf_counter() - t0
-        out[threads] = (sum(done), dt, sum(done) * cells_pair / dt / 1e9)
-        if threads == (os.cpu_count() or 1):
-            break
+    for threads in sorted({1, ncores}):
+        el = ctypes.c_double(0)
+        done = olib.kso_cpu_bench(fn, int(wl["dual"]), threads, seconds, len(qa), wl["qlen"], wl["tlen"], qa.ctypes.data, ta.ctypes.data,
+                                  5, mat.ctypes.data, S["q"], S["e"], S["q2"], S["e2"], wl["w"], wl["zdrop"], wl["flag"], ctypes.byref(el))
+        out[threads] = (done, el.value, done * cells_pair / el.value / 1e9)
     n1, dt1, g1 = out[1]
+    what = "reference %s, gcc -O2 -msse4.1, exact-max mode" % name if kind == "reference" else "oracle int32 scalar port (reference artefact absent: not comparable)"
     res = {"value": round(g1, 4), "unit": "GCUPS", "cores": 1, "kind": kind,
-           "sample": "%d pairs of the same batch in %.1f s, 1 thread, %s" % (n1, dt1, "reference ksw_ext%s2_sse gcc -O2 -msse4.1" % ("d" if wl["dual"] else "z") if kind == "reference" else "oracle int32 scalar port"),
-           "pairs_per_s": round(n1 / dt1, 1)}
-    tn = os.cpu_count() or 1
-    if tn in out and tn != 1:
-        nn, dtn, gn = out[tn]
-        res["all_cores"] = {"value": round(gn, 4), "cores": tn, "pairs_per_s": round(nn / dtn, 1)}
+           "sample": "%d pairs of the same batch in %.1f s on 1 thread; %s" % (n1, dt1, what), "pairs_per_s": round(n1 / dt1, 1)}
+    if ncores > 1:
+        nn, dtn, gn = out[ncores]
+        res["all_cores"] = {"value": round(gn, 4), "cores": ncores, "pairs_per_s": round(nn / dtn, 1)}
     return res
 
 

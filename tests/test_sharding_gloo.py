@@ -1,0 +1,68 @@
+"""CPU, world_size 2, gloo: the multi-GPU front-end (ksw2_amd/parallel.py) scatters a batch from rank 0, each rank
+aligns its shard (simulator build of the library stands in for the per-rank GPU), rank 0 gathers; results must equal
+the oracle in the original order.  On the GPU box the same code runs over RCCL with the HIP library."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+import ksw2_amd as ka
+from ksw2_amd import synth, parallel
+from oracle import pyoracle as po
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+lib = ka.Library(os.path.join(%(root)r, "tests", "sim", "libksw2_amd_sim.so"))
+rank = dist.get_rank()
+mat, q, e, q2, e2 = synth.simple_mat(5, 2, 4, -1), 4, 2, 24, 1
+ok = True
+for dual in (False, True):
+    qs = ts = w = zd = fl = None
+    if rank == 0:
+        rng = np.random.Generator(np.random.PCG64(17 + dual))
+        pairs = synth.ragged_pairs(rng, 37, 1, 400, sub=0.05, ind=0.12)
+        qs, ts = [p[0] for p in pairs], [p[1] for p in pairs]
+        w = rng.choice([-1, 5, 64, 100], size=37); zd = rng.choice([-1, 100], size=37)
+        fl = rng.choice([0, po.SCORE_ONLY, po.RIGHT, po.EXTZ_ONLY], size=37)
+    res = parallel.sharded_align(lib, dual, qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=5, flag=fl)
+    if rank == 0:
+        for i in range(37):
+            exp = po.align("oracle", "extd2" if dual else "extz2", qs[i], ts[i], mat, q, e, q2, e2, w=int(w[i]), zdrop=int(zd[i]), end_bonus=5, flag=int(fl[i]))
+            for k in ("score", "max", "max_t", "max_q", "mqe", "mqe_t", "mte", "mte_q", "zdropped", "reach_end", "n_cigar", "cigar"):
+                ok &= exp[k] == res[i][k]
+    else:
+        assert res is None
+# an empty shard (more ranks than pairs) must work too
+res = parallel.sharded_align(lib, False, [np.array([1, 2], np.uint8)] if rank == 0 else None, [np.array([1, 2], np.uint8)] if rank == 0 else None, mat, q, e)
+if rank == 0:
+    ok &= res[0]["score"] == 4
+    print("SHARD_OK" if ok else "SHARD_BAD")
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_scatter_gather(tmp_path):
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "sim")], check=True, capture_output=True)
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "SHARD_OK" in outs[0][0], outs
+
+
+def test_lpt_partition_balances():
+    from ksw2_amd.parallel import lpt_partition
+    rng = np.random.Generator(np.random.PCG64(1))
+    costs = rng.integers(1, 1000, size=500)
+    shards = lpt_partition(costs, 8)
+    assert sorted(np.concatenate(shards).tolist()) == list(range(500))
+    loads = np.array([costs[s].sum() for s in shards])
+    assert loads.max() - loads.min() <= costs.max()
