@@ -80,6 +80,17 @@ def cpu_baseline(wl, q, t, mat, seconds=10.0):
     return res
 
 
+def recorded_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE
+    need their own rocprofv3 --pmc runs, so they cannot be sampled inside this process); None if never recorded."""
+    import glob
+    cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc.json" % workload)))
+    if not cand:
+        return None, None
+    d = json.load(open(cand[-1]))
+    return d["derived"]["hbm_bytes_gfx950_corrected"], os.path.relpath(cand[-1], ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,6 +163,7 @@ def main():
         fill_only_ms = float(np.mean(fill_ms))
         achieved = cells * ops / (kern_ms * 1e-3)
         alg_bytes = n * (wl["qlen"] + wl["tlen"] + 56) + (0 if score_only else cells)
+        traffic, traffic_src = recorded_traffic(args.workload) if not args.pairs else (None, None)
         out = {
             "metric": "GCUPS (DP cells/s) + pairs/s at fixed (qlen,tlen,band)",
             "value": round(cells_all * args.steps / dt / 1e9, 3), "unit": "GCUPS",
@@ -162,10 +174,10 @@ def main():
                 args.workload, n, wl["qlen"], wl["tlen"], wl["w"], wl["zdrop"], "extd2 dual-gap" if wl["dual"] else "extz2 affine",
                 "score-only" if score_only else "CIGAR"), "cells_per_gpu": cells, "parallelism": "pairs sharded over %d GPU(s), no collective" % world},
             "roofline": {"bound": "valu", "achieved": round(achieved / 1e12, 4), "peak": VALU_PEAK_PK16 / 1e12, "unit": "Tiop/s",
-                         "frac": round(achieved / VALU_PEAK_PK16, 5), "traffic": None,
+                         "frac": round(achieved / VALU_PEAK_PK16, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "ops_per_cell": ops, "kernel_ms": round(kern_ms, 4), "fill_kernel_ms": round(fill_only_ms, 4),
                          "kernel_gcups": round(cells / (kern_ms * 1e-3) / 1e9, 2),
-                         "hbm_algorithmic_GBps": round(alg_bytes / (kern_ms * 1e-3) / 1e9, 2), "hbm_peak_GBps": HBM_PEAK / 1e9,
+                         "algorithmic_bytes": alg_bytes, "hbm_algorithmic_GBps": round(alg_bytes / (kern_ms * 1e-3) / 1e9, 2), "hbm_peak_GBps": HBM_PEAK / 1e9,
                          "note": "integer-VALU bound (no dense contraction, SURVEY 8d); peak = packed-int16 rate 256CU x 4SIMD x 32 lanes x 2.4GHz x 2; "
                                  "the kernel computes in int32 (peak 78.6 Tiop/s)"},
         }
