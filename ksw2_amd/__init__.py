@@ -49,7 +49,7 @@ EXPORTS = ["ksw_extz2_sse", "ksw_extd2_sse", "ksw_gg2", "ksw_gg2_sse", "ksw_extz
            "ksw_extz2_sse41", "ksw_extz2_sse2", "ksw_extd2_sse41", "ksw_extd2_sse2",
            "ksw2amd_last_error", "ksw2amd_backend", "ksw2amd_device_count", "ksw2amd_set_device",
            "ksw2amd_extz_batch", "ksw2amd_extd_batch", "ksw2amd_plan_create", "ksw2amd_plan_run", "ksw2amd_plan_fetch",
-           "ksw2amd_plan_destroy", "ksw2amd_plan_timing", "ksw2amd_plan_cells", "ksw2amd_plan_device_bytes",
+           "ksw2amd_plan_destroy", "ksw2amd_plan_timing", "ksw2amd_plan_cells", "ksw2amd_plan_device_bytes", "ksw2amd_plan_packed_pairs",
            "ksw2amd_plan_fetch_raw"]
 
 
@@ -116,6 +116,8 @@ class Library:
         L.ksw2amd_plan_cells.restype = ctypes.c_int64
         L.ksw2amd_plan_device_bytes.argtypes = [ctypes.c_void_p]
         L.ksw2amd_plan_device_bytes.restype = ctypes.c_int64
+        L.ksw2amd_plan_packed_pairs.argtypes = [ctypes.c_void_p]
+        L.ksw2amd_plan_packed_pairs.restype = ctypes.c_int64
         L.ksw2amd_plan_fetch_raw.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]
 
     # ---- info
@@ -287,6 +289,9 @@ class Plan:
 
     def cells(self):
         return int(self.L.lib.ksw2amd_plan_cells(self.h))
+
+    def packed_pairs(self):
+        return int(self.L.lib.ksw2amd_plan_packed_pairs(self.h))
 
     def device_bytes(self):
         return int(self.L.lib.ksw2amd_plan_device_bytes(self.h))

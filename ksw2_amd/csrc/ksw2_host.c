@@ -18,6 +18,7 @@
 
 #define F_SCALAR_CONTRACT 0x40000000   /* internal: call came through ksw_extz / ksw_extd / ksw_gg* */
 #define NCLS_MAX (K2A_NCFG * 3 * 2)
+#define NCLS_ENTRIES (2 * NCLS_MAX)
 
 static __thread char g_err[512];
 
@@ -72,7 +73,7 @@ static void ez_reserve(void *km, ksw_extz_t *ez, int n)   /* capacity sequence o
 /* ---------------------------------------------------------------- plan */
 
 typedef struct {
-	int cfg, mode, generic, first, count;
+	int cfg, mode, generic, pk, first, count;   /* pk: packed-int16 tasks, two h_order entries per task */
 	K2aScoring sc;
 } cls_t;
 
@@ -84,7 +85,8 @@ struct ksw2amd_plan_s {
 	int32_t *h_flag;               /* caller's flag per pair */
 	uint32_t *h_order;
 	int ntasks;
-	cls_t cls[NCLS_MAX];
+	cls_t cls[NCLS_ENTRIES];
+	int norder;
 	uint8_t *h_seq;
 	size_t seq_bytes, tb_bytes, cig_words, bnd_words;
 	uint8_t *d_seq, *d_tb;
@@ -157,6 +159,47 @@ static void build_scoring(int dual, int m, const int8_t *mat, int q, int e, int 
 	}
 }
 
+/* Packed-int16 class (ksw2_lane_pk.h): the scoring must be match / mismatch / wildcard on a 5-letter alphabet ... */
+typedef struct { int ok, a, b, n, smax, smin, qemax, q, e; } pkinfo_t;
+
+static void pk_scoring(int dual, int m, const int8_t *mat, int q, int e, int q2, int e2, int generic, pkinfo_t *o)
+{
+	K2aScoring t;
+	int x, y, ok = (m == 5);
+	memset(o, 0, sizeof(*o));
+	if (ok) {
+		int8_t eff[25];
+		build_scoring(dual, m, mat, q, e, q2, e2, generic, &t);
+		for (x = 0; x < 5; ++x)
+			for (y = 0; y < 5; ++y)
+				eff[x * 5 + y] = y < 4 ? (int8_t)(t.prof[x] >> (8 * y)) : (int8_t)t.colw[x];
+		o->a = eff[0]; o->b = eff[1]; o->n = eff[24];
+		o->smax = o->smin = eff[0];
+		for (x = 0; x < 5; ++x)
+			for (y = 0; y < 5; ++y) {
+				const int want = (x == 4 || y == 4) ? o->n : x == y ? o->a : o->b;
+				if (eff[x * 5 + y] != want) ok = 0;
+				o->smax = imax(o->smax, eff[x * 5 + y]); o->smin = imin(o->smin, eff[x * 5 + y]);
+			}
+	}
+	o->q = q; o->e = e;
+	o->qemax = dual ? imax(q + e, q2 + e2) : q + e;
+	o->ok = ok;
+}
+
+/* ... and every in-band H, E, F must provably stay inside (-16384 + qemax, 16383 - qemax):
+ *   H(i,j) <= smax * min(qlen, tlen);   H(i,j) >= Hb(|i-j|) + (min(i,j)+1) * smin >= -(q + e*w) + min(qlen,tlen) * min(smin,0)
+ * (gap along the border, then the diagonal: a path that stays inside the band). */
+static int pk_eligible(const pkinfo_t *k, int qlen, int tlen, int w)
+{
+	const int64_t L = imin(qlen, tlen);
+	int64_t hmax, hmin;
+	if (k->ok <= 0 || qlen > 32000 || tlen > 32000) return 0;
+	hmax = (int64_t)imax(k->smax, 0) * L;
+	hmin = -((int64_t)k->q + (int64_t)k->e * (w + 1)) + (int64_t)imin(k->smin, 0) * L;
+	return hmax < 16383 - 2 * k->qemax - 8 && hmin > -16384 + 2 * k->qemax + 8;
+}
+
 void ksw2amd_plan_destroy(ksw2amd_plan_t *p)
 {
 	int i;
@@ -182,7 +225,9 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 	int i, k, q, e, q2, e2, m, lo, ci;
 	size_t off;
 	sort_t *srt = 0;
-	int cls_count[NCLS_MAX], cls_fill[NCLS_MAX];
+	pkinfo_t pkinfo[2];
+	uint8_t *pk_ok = 0;
+	const int use_pk = !getenv("KSW2AMD_NO_PK");
 
 	g_err[0] = 0;
 	if (n < 0 || (n > 0 && !pairs) || !sc) { fail(KSW2AMD_E_PARAM, "plan_create: bad arguments%s", 0); return 0; }
@@ -211,9 +256,9 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 	}
 	if (p->reject_all || n == 0) return p;
 
-	/* classify */
-	memset(cls_count, 0, sizeof(cls_count));
-	off = 0;
+	/* pass 1: geometry class, traceback / CIGAR / boundary space, packed-int16 eligibility per pair */
+	pkinfo[0].ok = pkinfo[1].ok = -1;
+	pk_ok = (uint8_t*)calloc((size_t)n + 1, 1);
 	for (i = 0; i < n; ++i) {
 		const ksw2amd_pair_t *a = &pairs[i];
 		K2aPair *d = &p->h_pairs[i];
@@ -232,19 +277,15 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 		generic = (a->flag & (KSW_EZ_GENERIC_SC | F_SCALAR_CONTRACT)) ? 1 : 0;
 		ci = (cfg * 3 + mode) * 2 + generic;
 		p->h_cls[i] = (int8_t)ci;
-		++cls_count[ci];
-		/* sequence arena: query 4-aligned, target 16-aligned and readable one strip past its end */
-		off = align_up(off, 4); d->qoff = (uint32_t)off; off += (size_t)a->qlen;
-		off = align_up(off, 16); d->toff = (uint32_t)off; off += (size_t)a->tlen + 64;
-		if (off > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "plan_create: more than 4 GiB of sequence in one plan%s", 0); goto err; }
 		p->cells += band_cells(a->qlen, a->tlen, w);
+		if (pkinfo[generic].ok < 0) pk_scoring(dual, m, sc->mat, q, e, q2, e2, generic, &pkinfo[generic]);
+		pk_ok[i] = (uint8_t)(use_pk && mode == K2A_MODE_SCORE && cfg <= 2 && pk_eligible(&pkinfo[generic], a->qlen, d->tlen, w));
 		if (cfg == K2A_CFG_MP) {                              /* boundary rows H, E, E~ between generations */
 			d->bnd_off = (uint32_t)p->bnd_words;
 			p->bnd_words += 3 * (size_t)a->qlen + 16;
 			if (p->bnd_words > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "plan_create: boundary rows over 16 GiB in one plan%s", 0); goto err; }
 		}
-		/* traceback block and CIGAR scratch */
-		if (mode != K2A_MODE_SCORE) {
+		if (mode != K2A_MODE_SCORE) {                          /* traceback block and CIGAR scratch */
 			const int G = k2a_cfg_G[cfg], C = k2a_cfg_C[cfg];
 			const int nstrips = (d->tlen + C - 1) / C;
 			size_t steps = (size_t)(nstrips - 1) + (size_t)imin(a->qlen - 1, d->tlen - 1 + w) + 1;
@@ -257,47 +298,86 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 			if (p->cig_words > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "plan_create: CIGAR scratch over 16 GiB in one plan%s", 0); goto err; }
 		}
 	}
-	p->seq_bytes = align_up(off + 64, 256);
 
-	/* task lists per class, most expensive first (similar shapes end up in the same wavefront) */
-	p->ncls = 0;
-	for (ci = 0, k = 0; ci < NCLS_MAX; ++ci) {
-		cls_fill[ci] = -1;
-		if (cls_count[ci] == 0) continue;
-		cls_t *c = &p->cls[p->ncls];
-		c->cfg = ci / 6; c->mode = (ci / 2) % 3; c->generic = ci & 1; c->first = k; c->count = cls_count[ci];
-		build_scoring(dual, m, sc->mat, q, e, q2, e2, c->generic, &c->sc);
-		cls_fill[ci] = p->ncls++;
-		k += cls_count[ci];
-	}
-	p->ntasks = k;
-	p->h_order = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)k + 1));
+	/* pass 2: task lists per class, most expensive first (similar shapes end up in the same wavefront).  Packed-int16
+	 * candidates of a class are paired up with a neighbour of identical (qlen, tlen, w); a leftover is paired with itself. */
+	p->ncls = 0; p->ntasks = 0;
+	p->h_order = (uint32_t*)malloc(sizeof(uint32_t) * (2 * (size_t)n + 2));
 	srt = (sort_t*)malloc(sizeof(sort_t) * ((size_t)n + 1));
-	for (ci = 0; ci < NCLS_MAX; ++ci) {
-		int cnt = 0;
-		if (cls_fill[ci] < 0) continue;
-		for (i = 0; i < n; ++i)
-			if (p->h_cls[i] == ci) {
-				srt[cnt].idx = (uint32_t)i;
-				srt[cnt].cost = ((int64_t)p->h_pairs[i].qlen << 40) + ((int64_t)p->h_pairs[i].tlen << 16) + p->h_pairs[i].w;
-				++cnt;
+	for (ci = 0, k = 0; ci < NCLS_MAX; ++ci) {
+		int pass;
+		for (pass = 0; pass < 2; ++pass) {                     /* 0: one alignment per lane group, 1: packed pairs */
+			int cnt = 0, ntask = 0;
+			cls_t *c;
+			for (i = 0; i < n; ++i)
+				if (p->h_cls[i] == ci && pk_ok[i] == pass) {
+					srt[cnt].idx = (uint32_t)i;
+					srt[cnt].cost = ((int64_t)p->h_pairs[i].qlen << 40) + ((int64_t)p->h_pairs[i].tlen << 16) + p->h_pairs[i].w;
+					++cnt;
+				}
+			if (cnt == 0) continue;
+			qsort(srt, (size_t)cnt, sizeof(sort_t), cmp_cost_desc);
+			c = &p->cls[p->ncls++];
+			c->cfg = ci / 6; c->mode = (ci / 2) % 3; c->generic = ci & 1; c->pk = pass; c->first = k;
+			build_scoring(dual, m, sc->mat, q, e, q2, e2, c->generic, &c->sc);
+			c->sc.pk_a = pkinfo[c->generic].a; c->sc.pk_b = pkinfo[c->generic].b; c->sc.pk_n = pkinfo[c->generic].n;
+			if (!pass) {
+				for (i = 0; i < cnt; ++i) p->h_order[k++] = srt[i].idx;
+				ntask = cnt;
+			} else {
+				for (i = 0; i < cnt; ++ntask) {
+					const uint32_t ia = srt[i].idx;
+					uint32_t ib = ia;
+					if (i + 1 < cnt && srt[i + 1].cost == srt[i].cost) { ib = srt[i + 1].idx; i += 2; } else i += 1;
+					p->h_order[k++] = ia; p->h_order[k++] = ib;
+				}
 			}
-		qsort(srt, (size_t)cnt, sizeof(sort_t), cmp_cost_desc);
-		for (i = 0; i < cnt; ++i) p->h_order[p->cls[cls_fill[ci]].first + i] = srt[i].idx;
+			c->count = ntask;
+			p->ntasks += ntask;
+		}
 	}
+	p->norder = k;
 	free(srt); srt = 0;
+
+	/* pass 3: sequence arena.  Plain tasks: query 4-aligned, target 16-aligned and readable one strip past its end.
+	 * Packed tasks: the two queries (targets) byte-interleaved, x[2p] = A, x[2p+1] = B, shared by both K2aPair entries. */
+	off = 0;
+	for (k = 0; k < p->ncls; ++k) {
+		const cls_t *c = &p->cls[k];
+		for (i = 0; i < c->count; ++i) {
+			const uint32_t ia = p->h_order[c->first + (c->pk ? 2 * i : i)];
+			const uint32_t ib = c->pk ? p->h_order[c->first + 2 * i + 1] : ia;
+			K2aPair *da = &p->h_pairs[ia], *db = &p->h_pairs[ib];
+			const size_t mul = c->pk ? 2 : 1;
+			off = align_up(off, 4); da->qoff = db->qoff = (uint32_t)off; off += mul * (size_t)da->qlen;
+			off = align_up(off, 16); da->toff = db->toff = (uint32_t)off; off += mul * (size_t)da->tlen_full + 64;
+			if (off > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "plan_create: more than 4 GiB of sequence in one plan%s", 0); goto err; }
+		}
+	}
+	p->seq_bytes = align_up(off + 64, 256);
 
 	/* pack + upload */
 	p->h_seq = (uint8_t*)calloc(p->seq_bytes, 1);
-	for (i = 0; i < n; ++i) {
-		if (p->h_cls[i] < 0) continue;
-		memcpy(p->h_seq + p->h_pairs[i].qoff, pairs[i].query, (size_t)pairs[i].qlen);
-		memcpy(p->h_seq + p->h_pairs[i].toff, pairs[i].target, (size_t)pairs[i].tlen);
+	for (k = 0; k < p->ncls; ++k) {
+		const cls_t *c = &p->cls[k];
+		for (i = 0; i < c->count; ++i) {
+			if (!c->pk) {
+				const uint32_t ia = p->h_order[c->first + i];
+				memcpy(p->h_seq + p->h_pairs[ia].qoff, pairs[ia].query, (size_t)pairs[ia].qlen);
+				memcpy(p->h_seq + p->h_pairs[ia].toff, pairs[ia].target, (size_t)pairs[ia].tlen);
+			} else {
+				const uint32_t ia = p->h_order[c->first + 2 * i], ib = p->h_order[c->first + 2 * i + 1];
+				uint8_t *dq = p->h_seq + p->h_pairs[ia].qoff, *dt = p->h_seq + p->h_pairs[ia].toff;
+				int x;
+				for (x = 0; x < pairs[ia].qlen; ++x) { dq[2 * x] = pairs[ia].query[x]; dq[2 * x + 1] = pairs[ib].query[x]; }
+				for (x = 0; x < pairs[ia].tlen; ++x) { dt[2 * x] = pairs[ia].target[x]; dt[2 * x + 1] = pairs[ib].target[x]; }
+			}
+		}
 	}
 	p->d_seq = (uint8_t*)k2a_shim_malloc(p->seq_bytes);
 	p->d_pairs = (K2aPair*)k2a_shim_malloc(sizeof(K2aPair) * ((size_t)n + 1));
 	p->d_res = (K2aResult*)k2a_shim_malloc(sizeof(K2aResult) * ((size_t)n + 1));
-	p->d_order = (uint32_t*)k2a_shim_malloc(sizeof(uint32_t) * ((size_t)p->ntasks + 1));
+	p->d_order = (uint32_t*)k2a_shim_malloc(sizeof(uint32_t) * ((size_t)p->norder + 1));
 	p->d_tb = p->tb_bytes ? (uint8_t*)k2a_shim_malloc(p->tb_bytes) : 0;
 	p->d_cig = p->cig_words ? (uint32_t*)k2a_shim_malloc(p->cig_words * 4) : 0;
 	p->d_bnd = p->bnd_words ? (int32_t*)k2a_shim_malloc(p->bnd_words * 4) : 0;
@@ -307,16 +387,17 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 		goto err;
 	}
 	if (k2a_shim_h2d(p->d_seq, p->h_seq, p->seq_bytes, 0) || k2a_shim_h2d(p->d_pairs, p->h_pairs, sizeof(K2aPair) * (size_t)n, 0) ||
-	    k2a_shim_h2d(p->d_order, p->h_order, sizeof(uint32_t) * (size_t)p->ntasks, 0) ||
+	    k2a_shim_h2d(p->d_order, p->h_order, sizeof(uint32_t) * (size_t)p->norder, 0) ||
 	    k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)n, 0) ||
 	    (p->bnd_words && k2a_shim_memset(p->d_bnd, 0xC0, p->bnd_words * 4, 0)) || k2a_shim_stream_sync(0)) {
 		fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error());
 		goto err;
 	}
 	for (i = 0; i < 3; ++i) p->ev[i] = k2a_shim_event_create();
+	free(pk_ok);
 	return p;
 err:
-	free(srt);
+	free(srt); free(pk_ok);
 	ksw2amd_plan_destroy(p);
 	return 0;
 }
@@ -330,8 +411,10 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 	if (k2a_shim_event_record(p->ev[0], stream)) goto err;
 	for (c = 0; c < p->ncls; ++c) {
 		const cls_t *k = &p->cls[c];
-		if (k2a_shim_launch_fill(k->cfg, p->dual, k->mode, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
-		                         p->d_bnd, p->d_res, stream)) goto err;
+		if (k->pk) {
+			if (k2a_shim_launch_fill_pk(k->cfg, p->dual, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_res, stream)) goto err;
+		} else if (k2a_shim_launch_fill(k->cfg, p->dual, k->mode, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
+		                                p->d_bnd, p->d_res, stream)) goto err;
 	}
 	if (k2a_shim_event_record(p->ev[1], stream)) goto err;
 	for (c = 0; c < p->ncls; ++c) {
@@ -355,10 +438,21 @@ int ksw2amd_plan_timing(ksw2amd_plan_t *p, float *fill_ms, float *total_ms)
 }
 
 int64_t ksw2amd_plan_cells(const ksw2amd_plan_t *p) { return p ? p->cells : 0; }
+int64_t ksw2amd_plan_packed_pairs(const ksw2amd_plan_t *p)
+{
+	int64_t n = 0;
+	int c, i;
+	if (!p) return 0;
+	for (c = 0; c < p->ncls; ++c)
+		if (p->cls[c].pk)
+			for (i = 0; i < p->cls[c].count; ++i)
+				n += p->h_order[p->cls[c].first + 2 * i] == p->h_order[p->cls[c].first + 2 * i + 1] ? 1 : 2;
+	return n;
+}
 int64_t ksw2amd_plan_device_bytes(const ksw2amd_plan_t *p)
 {
 	if (!p) return 0;
-	return (int64_t)(p->seq_bytes + p->tb_bytes + p->cig_words * 4 + p->bnd_words * 4 + (sizeof(K2aPair) + sizeof(K2aResult)) * (size_t)p->n + 4 * (size_t)p->ntasks);
+	return (int64_t)(p->seq_bytes + p->tb_bytes + p->cig_words * 4 + p->bnd_words * 4 + (sizeof(K2aPair) + sizeof(K2aResult)) * (size_t)p->n + 4 * (size_t)p->norder);
 }
 
 static int fetch_results(ksw2amd_plan_t *p)

@@ -1,0 +1,258 @@
+/*
+ * ksw2_lane_pk.h -- packed-int16 variant of the per-lane kernel code: every lane carries TWO alignments of
+ * identical shape (qlen, tlen, w) in the low / high halves of its 32-bit registers.
+ *
+ * Same schedule, band masks and row bookkeeping as K2aLane (ksw2_lane.h; replaces the same reference loops,
+ * ksw2_extz2_sse.c:101-289 / ksw2_extd2_sse.c:131-387, with the scalar ksw_extz / ksw_extd semantics), but the
+ * Gotoh cell update runs on v_pk_add/sub/max_i16: one VALU instruction advances two cells, and every per-step
+ * control instruction (live mask, schedule, DPP rotate, loop) is shared by the two alignments.
+ *
+ * Preconditions, checked by the host (ksw2_host.c::pk_eligible): m = 5 with a match / mismatch / wildcard score
+ * structure (always true without KSW_EZ_GENERIC_SC), and every in-band H, E, F provably inside
+ * (-16384 + max(q+e, q2+e2), 16383 - max(q+e, q2+e2)) so that -16384 can stand for -infinity.
+ */
+#ifndef KSW2_LANE_PK_H_
+#define KSW2_LANE_PK_H_
+
+#include "ksw2_lane.h"
+
+typedef uint32_t k2a_pk;                 /* { int16 lo = alignment A, int16 hi = alignment B } */
+#define K2A_NEG16 (-16384)
+
+K2A_FN k2a_pk k2a_pk2(int v) { return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16); }
+K2A_FN int k2a_pk_lo(k2a_pk v) { return (int)(int16_t)(v & 0xffffu); }
+K2A_FN int k2a_pk_hi(k2a_pk v) { return (int)(int16_t)(v >> 16); }
+K2A_FN k2a_pk k2a_pk_sel(k2a_pk m, k2a_pk a, k2a_pk b) { return (m & a) | (~m & b); }   /* v_bfi / v_bitop3 */
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef short k2a_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short k2a_u2 __attribute__((ext_vector_type(2)));
+K2A_FN k2a_pk k2a_pk_add(k2a_pk a, k2a_pk b) { return __builtin_bit_cast(k2a_pk, (k2a_s2)(__builtin_bit_cast(k2a_s2, a) + __builtin_bit_cast(k2a_s2, b))); }
+K2A_FN k2a_pk k2a_pk_sub(k2a_pk a, k2a_pk b) { return __builtin_bit_cast(k2a_pk, (k2a_s2)(__builtin_bit_cast(k2a_s2, a) - __builtin_bit_cast(k2a_s2, b))); }
+K2A_FN k2a_pk k2a_pk_max(k2a_pk a, k2a_pk b) { return __builtin_bit_cast(k2a_pk, __builtin_elementwise_max(__builtin_bit_cast(k2a_s2, a), __builtin_bit_cast(k2a_s2, b))); }
+K2A_FN k2a_pk k2a_pk_minu(k2a_pk a, k2a_pk b)
+{
+	k2a_pk d;      /* asm keeps this arithmetic: hipcc would turn min(x,1)*k back into compare + select per half */
+	asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+	return d;
+}
+K2A_FN k2a_pk k2a_pk_mad(k2a_pk a, k2a_pk b, k2a_pk c)
+{
+	k2a_pk d;
+	asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+	return d;
+}
+K2A_FN k2a_pk k2a_pk_sign(k2a_pk a)     /* per half: 0xffff if negative else 0 */
+{
+	k2a_pk d;
+	asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(d) : "v"(a));
+	return d;
+}
+K2A_FN k2a_pk k2a_spread16(uint32_t v)  /* bytes {b0,b1,..} -> halves {b0, b1} */
+{
+	return __builtin_amdgcn_perm(0u, v, 0x0c010c00u);
+}
+K2A_FN k2a_pk k2a_bit_mask(uint32_t bits, int c) { return (k2a_pk)__builtin_amdgcn_sbfe((int)bits, c, 1); }
+#else
+K2A_FN k2a_pk k2a_pk_mk(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+K2A_FN k2a_pk k2a_pk_add(k2a_pk a, k2a_pk b) { return k2a_pk_mk(k2a_pk_lo(a) + k2a_pk_lo(b), k2a_pk_hi(a) + k2a_pk_hi(b)); }
+K2A_FN k2a_pk k2a_pk_sub(k2a_pk a, k2a_pk b) { return k2a_pk_mk(k2a_pk_lo(a) - k2a_pk_lo(b), k2a_pk_hi(a) - k2a_pk_hi(b)); }
+K2A_FN k2a_pk k2a_pk_max(k2a_pk a, k2a_pk b) { return k2a_pk_mk(k2a_max(k2a_pk_lo(a), k2a_pk_lo(b)), k2a_max(k2a_pk_hi(a), k2a_pk_hi(b))); }
+K2A_FN k2a_pk k2a_pk_minu(k2a_pk a, k2a_pk b)
+{
+	const uint32_t al = a & 0xffffu, ah = a >> 16, bl = b & 0xffffu, bh = b >> 16;
+	return (al < bl ? al : bl) | ((ah < bh ? ah : bh) << 16);
+}
+K2A_FN k2a_pk k2a_pk_mad(k2a_pk a, k2a_pk b, k2a_pk c) { return k2a_pk_mk(k2a_pk_lo(a) * k2a_pk_lo(b) + k2a_pk_lo(c), k2a_pk_hi(a) * k2a_pk_hi(b) + k2a_pk_hi(c)); }
+K2A_FN k2a_pk k2a_pk_sign(k2a_pk a) { return ((a & 0x8000u) ? 0xffffu : 0u) | ((a & 0x80000000u) ? 0xffff0000u : 0u); }
+K2A_FN k2a_pk k2a_spread16(uint32_t v) { return (v & 0xffu) | ((v & 0xff00u) << 8); }
+K2A_FN k2a_pk k2a_bit_mask(uint32_t bits, int c) { return ((bits >> c) & 1u) ? 0xffffffffu : 0u; }
+#endif
+
+template<int G, int C, bool DUAL>
+struct K2aLanePk {
+	/* group-uniform (both alignments share the shape) */
+	int qlen, tlen, tlen_full, w, nstrips;
+	const uint8_t *qi, *ti;            /* byte-interleaved sequences: x[2p] = code of A, x[2p+1] = code of B */
+	/* schedule, identical to K2aLane */
+	int gl, S, i0, je, koff, Snext, knext, koff_next;
+	/* systolic ports */
+	k2a_pk hout, eout, e2out, hd0, hu_prev;
+	uint32_t qb;                        /* { query code A, query code B } of this step's column */
+	bool has_n;                         /* a wildcard among this strip's target codes */
+	/* rows */
+	k2a_pk hl[C], f[C], f2[DUAL ? C : 1], rmax[C], rmj[C], tc[C];
+	uint32_t tnext[(C + 1) / 2];
+
+	K2A_FN static int first_col(int S_, int w_) { return k2a_max(0, S_ * C - w_); }
+
+	K2A_FN void schedule_next()
+	{
+		koff_next = Snext;
+		knext = Snext < nstrips ? koff_next + first_col(Snext, w) : K2A_KNONE;
+	}
+
+	K2A_FN void load_tnext()
+	{
+		if (Snext < nstrips) {
+			const uint32_t *p = (const uint32_t*)(ti + (size_t)Snext * C * 2);
+#pragma unroll
+			for (int x = 0; x < (C + 1) / 2; ++x) tnext[x] = p[x];
+		}
+	}
+
+	K2A_FN void setup(const K2aPair &pr, const uint8_t *seq, int lane_in_group, bool valid)
+	{
+		qlen = pr.qlen; tlen = pr.tlen; tlen_full = pr.tlen_full; w = pr.w;
+		qi = seq + pr.qoff; ti = seq + pr.toff;
+		nstrips = valid ? (tlen + C - 1) / C : 0;
+		gl = lane_in_group;
+		S = -1; i0 = 0; je = -1; koff = 0;
+		Snext = gl;
+		schedule_next();
+		const k2a_pk neg = k2a_pk2(K2A_NEG16);
+		hout = eout = e2out = hd0 = hu_prev = neg; qb = 0; has_n = false;
+#pragma unroll
+		for (int c = 0; c < C; ++c) { hl[c] = f[c] = rmax[c] = neg; rmj[c] = 0; tc[c] = 0; if (DUAL) f2[c] = neg; }
+		if (!DUAL) f2[0] = 0;
+#pragma unroll
+		for (int x = 0; x < (C + 1) / 2; ++x) tnext[x] = 0;
+		load_tnext();
+	}
+
+	K2A_FN int last_step() const { return nstrips > 0 ? (nstrips - 1) + k2a_min(qlen - 1, tlen - 1 + w) : -1; }
+	K2A_FN bool need_init(int k) const { return k == knext; }
+	K2A_FN bool need_fin(int k) const { return S >= 0 && k - koff == je; }
+	K2A_FN bool sees_wildcard() const { return (S >= 0 && has_n) || ((qb & 0x00040004u) != 0); }
+
+	K2A_FN void do_init(const K2aScoring &sc)
+	{
+		S = Snext; i0 = S * C; koff = koff_next;
+		je = k2a_min(qlen - 1, k2a_min(i0 + C - 1, tlen - 1) + w);
+		const int js = k2a_max(0, i0 - w);
+		const k2a_pk neg = k2a_pk2(K2A_NEG16);
+		uint32_t any = 0;
+#pragma unroll
+		for (int c = 0; c < C; ++c) {
+			const int i = i0 + c;
+			const uint32_t two = (tnext[c >> 1] >> (16 * (c & 1))) & 0xffffu;
+			tc[c] = k2a_spread16(two);
+			any |= tc[c];
+			const bool edge = i <= w;                        /* virtual column -1: ksw2_extz.c:43-44, ksw2_extd.c:49-52 */
+			const int hb = k2a_border<DUAL>(sc, i + 1);
+			hl[c] = edge ? k2a_pk2(hb) : neg;
+			f[c] = edge ? k2a_pk2(hb - (sc.q + sc.e)) : neg;
+			if (DUAL) f2[c] = edge ? k2a_pk2(hb - (sc.q2 + sc.e2)) : neg;
+			rmax[c] = neg; rmj[c] = 0;
+		}
+		has_n = (any & 0x00040004u) != 0;
+		if (js == 0) hd0 = k2a_pk2(k2a_border<DUAL>(sc, i0));
+		else hd0 = hu_prev;
+		Snext += G;
+		schedule_next();
+		load_tnext();
+	}
+
+	/* one column for the C rows of both alignments; WILD = some lane of the wavefront touches a wildcard */
+	template<bool WILD>
+	K2A_FN void step(const K2aScoring &sc, int k, k2a_pk hin, k2a_pk ein, k2a_pk e2in)
+	{
+		const int jj = k - koff;
+		const bool act = (S >= 0) && (jj <= je) && (jj >= 0);
+		const k2a_pk neg = k2a_pk2(K2A_NEG16);
+		const k2a_pk qe = k2a_pk2(sc.q + sc.e), ge = k2a_pk2(sc.e), qe2 = k2a_pk2(sc.q2 + sc.e2), ge2 = k2a_pk2(sc.e2);
+		const k2a_pk mat_a = k2a_pk2(sc.pk_a), mat_bma = k2a_pk2(sc.pk_b - sc.pk_a), mat_n = k2a_pk2(sc.pk_n);
+		k2a_pk hu = hin, e = ein, e2 = e2in;
+		if (S == 0) {                                          /* virtual row -1 */
+			const int hb = k2a_border<DUAL>(sc, jj + 1);
+			hu = k2a_pk2(hb); e = k2a_pk2(hb - (sc.q + sc.e)); e2 = k2a_pk2(hb - (sc.q2 + sc.e2));
+			if (jj > w) { e = neg; e2 = neg; }
+		} else if (jj - i0 >= w) { e = neg; e2 = neg; }
+		hu_prev = hin;
+		const int lo = k2a_max(0, jj - w - i0);
+		const int hi = k2a_min(k2a_min(C - 1, jj + w - i0), tlen - 1 - i0);
+		uint32_t live = 0;
+		if (act && lo <= hi) live = (2u << hi) - (1u << lo);
+		const k2a_pk qcode = qb;
+		const k2a_pk jjpk = k2a_pk2(jj);
+		k2a_pk hd = hd0;
+#pragma unroll
+		for (int c = 0; c < C; ++c) {
+			/* score: a on equal codes, b otherwise, wildcard score if either code is 4 */
+			const k2a_pk ne01 = k2a_pk_minu(tc[c] ^ qcode, 0x00010001u);
+			k2a_pk s = k2a_pk_mad(ne01, mat_bma, mat_a);
+			if (WILD) {
+				const k2a_pk isn = ((tc[c] | qcode) & 0x00040004u) << 13;       /* bit 2 -> sign bit of each half */
+				s = k2a_pk_sel(k2a_pk_sign(isn), mat_n, s);
+			}
+			k2a_pk h = k2a_pk_add(hd, s);
+			const k2a_pk fc = f[c];
+			h = k2a_pk_max(k2a_pk_max(h, e), fc);
+			if (DUAL) h = k2a_pk_max(k2a_pk_max(h, e2), f2[c]);
+			h = k2a_pk_sel(k2a_bit_mask(live, c), h, neg);
+			/* running row maximum, ties to the last column: keep the old arg-max only where h < max */
+			const k2a_pk keep = k2a_pk_sign(k2a_pk_sub(h, rmax[c]));
+			rmj[c] = k2a_pk_sel(keep, rmj[c], jjpk);
+			rmax[c] = k2a_pk_max(rmax[c], h);
+			const k2a_pk t = k2a_pk_sub(h, qe);
+			e = k2a_pk_max(k2a_pk_sub(e, ge), t);
+			f[c] = k2a_pk_max(k2a_pk_sub(fc, ge), t);
+			if (DUAL) {
+				const k2a_pk t2 = k2a_pk_sub(h, qe2);
+				e2 = k2a_pk_max(k2a_pk_sub(e2, ge2), t2);
+				f2[c] = k2a_pk_max(k2a_pk_sub(f2[c], ge2), t2);
+			}
+			hd = hl[c];
+			hl[c] = h;
+		}
+		hd0 = hu;
+		hout = hl[C - 1]; eout = e; e2out = e2;
+	}
+
+	K2A_FN uint32_t next_query_codes(int k) const
+	{
+		const bool starts = (k + 1 == knext);
+		const int j = k + 1 - (starts ? koff_next : koff);
+		uint32_t two = 0;
+		if ((starts || S >= 0) && j >= 0 && j < qlen) two = *(const uint16_t*)(qi + 2 * (size_t)j);
+		return k2a_spread16(two);
+	}
+
+	/* per-row epilogue of the scalar reference for the strip's rows, once per alignment (K2aLane::do_fin) */
+	K2A_FN void do_fin(const K2aScoring &sc, K2aBook *bA, K2aBook *bB, int zdropA, int zdropB)
+	{
+		const int zslope = DUAL ? sc.e2 : sc.e;
+#pragma unroll
+		for (int half = 0; half < 2; ++half) {
+			K2aBook *b = half ? bB : bA;
+			const int zdrop = half ? zdropB : zdropA;
+			int bmax = b->max, bmax_t = b->max_t, bmax_q = b->max_q, bmqe = b->mqe, bmqe_t = b->mqe_t;
+			int bmte = b->mte, bmte_q = b->mte_q, bscore = b->score, bdrop = b->dropped, brows = b->rows;
+#pragma unroll
+			for (int c = 0; c < C; ++c) {
+				const int i = i0 + c;
+				if (i < tlen && !bdrop) {
+					const bool reach = i + w >= qlen - 1;
+					const int hend = half ? k2a_pk_hi(hl[c]) : k2a_pk_lo(hl[c]);
+					const int H = half ? k2a_pk_hi(rmax[c]) : k2a_pk_lo(rmax[c]);
+					const int j = half ? k2a_pk_hi(rmj[c]) : k2a_pk_lo(rmj[c]);
+					if (reach && hend > bmqe) { bmqe = hend; bmqe_t = i; }
+					if (i == tlen_full - 1) { bmte = H; bmte_q = j; }
+					if (H > bmax) { bmax = H; bmax_t = i; bmax_q = j; }
+					else if (i >= bmax_t && j >= bmax_q) {
+						const int dt = i - bmax_t, dq = j - bmax_q;
+						const int skew = dt > dq ? dt - dq : dq - dt;
+						if (zdrop >= 0 && bmax - H > zdrop + skew * zslope) bdrop = 1;
+					}
+					if (!bdrop && i == tlen_full - 1 && reach) bscore = hend;
+					brows = i + 1;
+				}
+			}
+			b->max = bmax; b->max_t = bmax_t; b->max_q = bmax_q; b->mqe = bmqe; b->mqe_t = bmqe_t;
+			b->mte = bmte; b->mte_q = bmte_q; b->score = bscore; b->dropped = bdrop; b->rows = brows;
+		}
+		S = -1; je = -1;
+	}
+};
+
+#endif

@@ -55,6 +55,12 @@ int k2a_shim_launch_fill(int cfg, int dual, int mode, const K2aScoring *sc, cons
 int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb,
                           K2aResult *res, uint32_t *cig, void *stream);
 
+/* Packed-int16 fill (score-only): ntasks tasks of TWO same-shape alignments each, order2[2t], order2[2t+1] = their
+ * indices (equal for an unpaired leftover); both K2aPair entries point at the task's byte-interleaved sequences.
+ * Classes 0..2 of the table above. */
+int k2a_shim_launch_fill_pk(int cfg, int dual, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2, int ntasks,
+                            const uint8_t *seq, K2aResult *res, void *stream);
+
 /* Compaction: pool[pos[i] .. pos[i]+res[i].n_cigar) = cig[pairs[i].cig_off ..) for the n pairs of a plan
  * (pos = exclusive prefix sum of n_cigar, computed by the host), so that one D2H brings every CIGAR back. */
 int k2a_shim_launch_compact(const K2aPair *pairs, const K2aResult *res, const uint32_t *pos, int n, const uint32_t *cig,

@@ -12,6 +12,7 @@
 #include <string.h>
 #include "ksw2_shim.h"
 #include "ksw2_lane.h"
+#include "ksw2_lane_pk.h"
 
 #define K2A_WPB 4          /* wavefronts per workgroup; waves never synchronise with each other */
 
@@ -110,6 +111,71 @@ k2a_fill_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const ui
 	if (valid && gl == 0) {
 		const K2aBook b = *bk;
 		k2a_finish(pr, b, &res[pi]);
+	}
+}
+
+/* Packed-int16 resident fill, score-only: two same-shape alignments per lane group (ksw2_lane_pk.h). */
+template<int G, int C, bool DUAL>
+__global__ void __launch_bounds__(64 * K2A_WPB)
+k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
+                   const uint8_t *__restrict__ seq, K2aResult *__restrict__ res)
+{
+	constexpr int NG = 64 / G;
+	typedef K2aLanePk<G, C, DUAL> Lane;
+	__shared__ K2aBook book[K2A_WPB][NG][2];
+
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int grp = lane / G, gl = lane % G;
+	const int task = (blockIdx.x * K2A_WPB + wave) * NG + grp;
+	const bool valid = task < ntasks;
+	const uint32_t piA = order2[valid ? 2 * task : 0], piB = order2[valid ? 2 * task + 1 : 0];
+	const K2aPair prA = pairs[piA];
+	const int zdropA = prA.zdrop, zdropB = pairs[piB].zdrop;
+
+	Lane L;
+	L.setup(prA, seq, gl, valid);
+	K2aBook *bkA = &book[wave][grp][0], *bkB = &book[wave][grp][1];
+	if (gl == 0) { k2a_book_reset(bkA); k2a_book_reset(bkB); }
+	__builtin_amdgcn_wave_barrier();
+
+	const int klast = L.last_step();
+	int kmax = klast;
+	if (G == 16) {
+		kmax = max(max(__builtin_amdgcn_readlane(klast, 0), __builtin_amdgcn_readlane(klast, 16)),
+		           max(__builtin_amdgcn_readlane(klast, 32), __builtin_amdgcn_readlane(klast, 48)));
+	} else kmax = __builtin_amdgcn_readfirstlane(klast);
+
+	bool gdone = !valid;
+	L.qb = L.next_query_codes(-1);
+
+	for (int k = 0; k <= kmax; ++k) {
+		const k2a_pk hin = (k2a_pk)k2a_rot1<G>((int)L.hout);
+		const k2a_pk ein = (k2a_pk)k2a_rot1<G>((int)L.eout);
+		const k2a_pk e2in = DUAL ? (k2a_pk)k2a_rot1<G>((int)L.e2out) : 0u;
+
+		const bool ninit = L.need_init(k);
+		if (__builtin_amdgcn_ballot_w64(ninit) != 0) {
+			if (ninit) L.do_init(sc);
+		}
+		const uint32_t qnext = L.next_query_codes(k);
+
+		if (__builtin_amdgcn_ballot_w64(L.sees_wildcard()) != 0) L.template step<true>(sc, k, hin, ein, e2in);
+		else L.template step<false>(sc, k, hin, ein, e2in);
+
+		const bool nfin = L.need_fin(k);
+		if (__builtin_amdgcn_ballot_w64(nfin) != 0) {
+			if (nfin) L.do_fin(sc, bkA, bkB, zdropA, zdropB);
+			__builtin_amdgcn_wave_barrier();
+			if (bkA->dropped && bkB->dropped) gdone = true;
+		}
+		L.qb = qnext;
+		if (__builtin_amdgcn_ballot_w64(!(gdone || k >= klast)) == 0) break;
+	}
+	__builtin_amdgcn_wave_barrier();
+	if (valid && gl == 0) {
+		const K2aBook a = *bkA, b = *bkB;
+		k2a_finish(prA, a, &res[piA]);
+		if (piB != piA) k2a_finish(pairs[piB], b, &res[piB]);
 	}
 }
 
@@ -367,6 +433,24 @@ int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_
 	if (cfg < 0 || cfg >= K2A_NCFG) { snprintf(g_err, sizeof(g_err), "bad kernel class"); return -1; }
 	hipLaunchKernelGGL(g_trace[cfg][dual ? 1 : 0], dim3((ntasks + 63) / 64), dim3(64), 0, (hipStream_t)stream,
 	                   pairs, order, ntasks, tb, res, cig);
+	CHECK(hipGetLastError());
+	return 0;
+}
+
+typedef void (*fill_pk_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, K2aResult*);
+static const fill_pk_fn g_fill_pk[3][2] = { { k2a_fill_pk_kernel<16, 8, false>, k2a_fill_pk_kernel<16, 8, true> },
+                                            { k2a_fill_pk_kernel<64, 8, false>, k2a_fill_pk_kernel<64, 8, true> },
+                                            { k2a_fill_pk_kernel<64, 16, false>, k2a_fill_pk_kernel<64, 16, true> } };
+
+int k2a_shim_launch_fill_pk(int cfg, int dual, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2, int ntasks,
+                            const uint8_t *seq, K2aResult *res, void *stream)
+{
+	if (ntasks <= 0) return 0;
+	if (cfg < 0 || cfg > 2) { snprintf(g_err, sizeof(g_err), "bad packed kernel class"); return -1; }
+	const int per_block = K2A_WPB * (64 / k2a_cfg_G[cfg]);
+	const int blocks = (ntasks + per_block - 1) / per_block;
+	hipLaunchKernelGGL(g_fill_pk[cfg][dual ? 1 : 0], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
+	                   *sc, pairs, order2, ntasks, seq, res);
 	CHECK(hipGetLastError());
 	return 0;
 }

@@ -25,6 +25,7 @@ typedef struct K2aScoring {
 	int32_t q, e, q2, e2;        /* gap open / extend; (q2,e2) only for the two-piece model, q+e <= q2+e2 */
 	uint32_t prof[5];            /* prof[t] = bytes { s(t,0), s(t,1), s(t,2), s(t,3) } for target code t   */
 	int32_t colw[5];             /* colw[t] = s(t, 4): score against the query wildcard (code 4)          */
+	int32_t pk_a, pk_b, pk_n;    /* match / mismatch / wildcard score when the matrix has that structure   */
 } K2aScoring;
 
 /* one alignment, device-resident */

@@ -11,6 +11,7 @@
 #include <cstring>
 #include "../../ksw2_amd/csrc/ksw2_shim.h"
 #include "../../ksw2_amd/csrc/ksw2_lane.h"
+#include "../../ksw2_amd/csrc/ksw2_lane_pk.h"
 
 static char g_err[256] = "";
 
@@ -86,6 +87,73 @@ static void sim_fill(const K2aScoring sc, const K2aPair *pairs, const uint32_t *
 		}
 		for (int lane = 0; lane < 64; ++lane)
 			if (valid[lane] && lane % G == 0) k2a_finish(pr[lane], book[lane / G], &res[pi[lane]]);
+	}
+}
+
+/* mirrors k2a_fill_pk_kernel */
+template<int G, int C, bool DUAL>
+static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *seq, K2aResult *res)
+{
+	constexpr int NG = 64 / G;
+	typedef K2aLanePk<G, C, DUAL> Lane;
+	const int nwaves = (ntasks + NG - 1) / NG;
+	for (int wv = 0; wv < nwaves; ++wv) {
+		static Lane L[64];
+		K2aBook book[NG][2];
+		K2aPair prA[64];
+		uint32_t piA[64], piB[64];
+		int zdA[64], zdB[64], klast[64], kmax = -1;
+		bool valid[64], gdone[64];
+		for (int lane = 0; lane < 64; ++lane) {
+			const int grp = lane / G, gl = lane % G, task = wv * NG + grp;
+			valid[lane] = task < ntasks;
+			piA[lane] = order2[valid[lane] ? 2 * task : 0]; piB[lane] = order2[valid[lane] ? 2 * task + 1 : 0];
+			prA[lane] = pairs[piA[lane]];
+			zdA[lane] = prA[lane].zdrop; zdB[lane] = pairs[piB[lane]].zdrop;
+			L[lane].setup(prA[lane], seq, gl, valid[lane]);
+			if (gl == 0) { k2a_book_reset(&book[grp][0]); k2a_book_reset(&book[grp][1]); }
+			klast[lane] = L[lane].last_step();
+			if (klast[lane] > kmax) kmax = klast[lane];
+			gdone[lane] = !valid[lane];
+			L[lane].qb = L[lane].next_query_codes(-1);
+		}
+		for (int k = 0; k <= kmax; ++k) {
+			k2a_pk hin[64], ein[64], e2in[64];
+			uint32_t qnext[64];
+			for (int lane = 0; lane < 64; ++lane) {
+				const int grp = lane / G, gl = lane % G, src = grp * G + (gl + G - 1) % G;
+				hin[lane] = L[src].hout; ein[lane] = L[src].eout; e2in[lane] = DUAL ? L[src].e2out : 0;
+			}
+			bool wild = false, anyfin = false, nfin[64];
+			for (int lane = 0; lane < 64; ++lane) {
+				if (L[lane].need_init(k)) L[lane].do_init(sc);
+				qnext[lane] = L[lane].next_query_codes(k);
+			}
+			for (int lane = 0; lane < 64; ++lane) wild |= L[lane].sees_wildcard();
+			for (int lane = 0; lane < 64; ++lane) {
+				if (wild) L[lane].template step<true>(sc, k, hin[lane], ein[lane], e2in[lane]);
+				else L[lane].template step<false>(sc, k, hin[lane], ein[lane], e2in[lane]);
+				nfin[lane] = L[lane].need_fin(k);
+				anyfin |= nfin[lane];
+			}
+			if (anyfin) {
+				for (int lane = 0; lane < 64; ++lane)
+					if (nfin[lane]) L[lane].do_fin(sc, &book[lane / G][0], &book[lane / G][1], zdA[lane], zdB[lane]);
+				for (int lane = 0; lane < 64; ++lane)
+					if (book[lane / G][0].dropped && book[lane / G][1].dropped) gdone[lane] = true;
+			}
+			bool all_done = true;
+			for (int lane = 0; lane < 64; ++lane) {
+				L[lane].qb = qnext[lane];
+				if (!(gdone[lane] || k >= klast[lane])) all_done = false;
+			}
+			if (all_done) break;
+		}
+		for (int lane = 0; lane < 64; ++lane)
+			if (valid[lane] && lane % G == 0) {
+				k2a_finish(prA[lane], book[lane / G][0], &res[piA[lane]]);
+				if (piB[lane] != piA[lane]) k2a_finish(pairs[piB[lane]], book[lane / G][1], &res[piB[lane]]);
+			}
 	}
 }
 
@@ -214,6 +282,16 @@ int k2a_shim_launch_fill(int cfg, int dual, int mode, const K2aScoring *sc, cons
 	if (ntasks <= 0) return 0;
 	if (cfg == K2A_CFG_MP) g_fill_mp[dual ? 1 : 0][mode](*sc, pairs, order, ntasks, seq, tb, bnd, res);
 	else g_fill[cfg][dual ? 1 : 0][mode](*sc, pairs, order, ntasks, seq, tb, res);
+	return 0;
+}
+typedef void (*fill_pk_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, K2aResult*);
+static const fill_pk_fn g_fill_pk[3][2] = { { sim_fill_pk<16, 8, false>, sim_fill_pk<16, 8, true> },
+                                            { sim_fill_pk<64, 8, false>, sim_fill_pk<64, 8, true> },
+                                            { sim_fill_pk<64, 16, false>, sim_fill_pk<64, 16, true> } };
+int k2a_shim_launch_fill_pk(int cfg, int dual, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2, int ntasks,
+                            const uint8_t *seq, K2aResult *res, void *)
+{
+	if (ntasks > 0) g_fill_pk[cfg][dual ? 1 : 0](*sc, pairs, order2, ntasks, seq, res);
 	return 0;
 }
 int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb,

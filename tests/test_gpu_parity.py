@@ -223,3 +223,36 @@ def test_wide_band_ragged(lib, dual):
         eb = rng.choice([0, 10, 50], size=n)
         fl = np.array([mode | (po.EXTZ_ONLY if rng.random() < 0.3 else 0) | (po.REV_CIGAR if rng.random() < 0.3 else 0) for _ in range(n)])
         check_batch(lib, dual, qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl)
+
+
+def test_packed_and_int32_score_only_agree(lib, monkeypatch):
+    """Config-2 shape through both score-only code paths: packed int16 (default) and int32 (KSW2AMD_NO_PK=1)."""
+    n = 1024
+    q, t = synth.fixed_batch(2, n, 512, 512, sub=0.05, ind=0.06, stream=3)
+    mat = synth.simple_mat(5, 2, 4, -1)
+    b = lib.make_batch(q, t, mat, 4, 2, 24, 1, w=64, zdrop=-1, flag=po.SCORE_ONLY)
+    p = b.plan(False); assert p.packed_pairs() == n; p.run(); r1 = p.fetch_raw().copy(); p.close()
+    monkeypatch.setenv("KSW2AMD_NO_PK", "1")
+    p = b.plan(False); assert p.packed_pairs() == 0; p.run(); r0 = p.fetch_raw().copy(); p.close()
+    assert (r0 == r1).all()
+    k, _ = check_batch(lib, False, q, t, mat, 4, 2, 0, 0, w=64, zdrop=-1, flag=po.SCORE_ONLY, sample=range(0, n, 8))
+    assert k == 128
+
+
+@pytest.mark.parametrize("dual", [False, True])
+def test_packed_fixed_shape_batches(lib, dual):
+    """Packed-int16 class on the GPU: wildcards, per-pair Z-drop / flags, odd leftovers, all three geometries."""
+    rng = np.random.Generator(np.random.PCG64(50 + dual))
+    for rnd in range(18):
+        mat, q, e, q2, e2 = [(synth.simple_mat(5, 2, 4, -1), 4, 2, 24, 1), (synth.simple_mat(5, 1, 3, 0), 5, 1, 20, 1),
+                             (synth.simple_mat(5, 2, 4, -3), 4, 2, 13, 1)][rnd % 3]
+        n = int(rng.integers(3, 60))
+        ql = int(rng.integers(50, 900)); tl = max(1, ql + int(rng.integers(-30, 30)))
+        w = int(rng.choice([20, 64, 68, 100, 284, 400, -1]))
+        qs, ts = synth.fixed_batch(200 + rnd, n, ql, tl, sub=0.05, ind=0.08, tail_random_frac=0.3, tail_pairs=0.3)
+        if rnd % 2:
+            qs, ts = qs.copy(), ts.copy()
+            qs[rng.random(qs.shape) < 0.01] = 4; ts[rng.random(ts.shape) < 0.01] = 4
+        zd = rng.choice([-1, 30, 100, 400], size=n); eb = rng.choice([0, 10, 50], size=n)
+        fl = np.array([po.SCORE_ONLY | (po.EXTZ_ONLY if rng.random() < 0.3 else 0) | (po.GENERIC_SC if rnd % 3 == 0 else 0) for _ in range(n)])
+        check_batch(lib, dual, qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl)

@@ -117,3 +117,57 @@ def test_sim_eqx(sim):
         exp = po.align("oracle", "extd2", qq, tt, mat, 4, 2, 24, 1, flag=po.EQX)
         res = sim.extd2(qq, tt, mat, 4, 2, 24, 1, flag=po.EQX)
         assert res["cigar"] == exp["cigar"] and all((c & 0xf) != 0 for c in res["cigar"])
+
+
+def _fixed_shape_cases(rng, rnd):
+    mat, q, e, q2, e2 = [(synth.simple_mat(5, 2, 4, -1), 4, 2, 24, 1), (synth.simple_mat(5, 1, 3, 0), 5, 1, 20, 1),
+                         (synth.simple_mat(5, 2, 4, -3), 4, 2, 13, 1)][rnd % 3]
+    n = int(rng.integers(3, 30))
+    ql = int(rng.integers(50, 700))
+    tl = max(1, ql + int(rng.integers(-30, 30)))
+    w = int(rng.choice([20, 64, 68, 100, 284, 400, -1]))
+    qs, ts = synth.fixed_batch(100 + rnd, n, ql, tl, sub=0.05, ind=0.08, tail_random_frac=0.3, tail_pairs=0.3)
+    if rnd % 2:
+        qs, ts = qs.copy(), ts.copy()
+        qs[rng.random(qs.shape) < 0.01] = 4
+        ts[rng.random(ts.shape) < 0.01] = 4
+    zd = rng.choice([-1, 30, 100, 400], size=n)
+    eb = rng.choice([0, 10, 50], size=n)
+    fl = np.array([po.SCORE_ONLY | (po.EXTZ_ONLY if rng.random() < 0.3 else 0) | (po.GENERIC_SC if rnd % 3 == 0 else 0) |
+                   (po.RIGHT if rng.random() < 0.2 else 0) for _ in range(n)])
+    return mat, q, e, q2, e2, qs, ts, w, zd, eb, fl
+
+
+def test_sim_packed_int16_class(sim):
+    """Same-shape score-only batches go through the packed-int16 kernels (two alignments per lane): wildcards,
+    per-pair Z-drop, odd leftovers, every resident geometry class."""
+    rng = np.random.Generator(np.random.PCG64(5))
+    npk = 0
+    for rnd in range(24):
+        mat, q, e, q2, e2, qs, ts, w, zd, eb, fl = _fixed_shape_cases(rng, rnd)
+        for dual in (False, True):
+            b = sim.make_batch(qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl)
+            p = b.plan(dual)
+            npk += p.packed_pairs()
+            p.close()
+            check_batch(sim, dual, qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl)
+    assert npk > 500
+
+
+def test_sim_packed_range_guard(sim):
+    """Shapes whose scores could leave the int16 window must stay on the int32 kernels."""
+    mat = synth.simple_mat(5, 2, 4, -1)
+    q, t = synth.fixed_batch(6, 2, 9000, 9000)
+    p = sim.make_batch(q, t, mat, 4, 2, 24, 1, w=100, zdrop=-1, flag=po.SCORE_ONLY).plan(False)
+    assert p.packed_pairs() == 0
+    p.close()
+    q, t = synth.fixed_batch(2, 4, 512, 512)
+    p = sim.make_batch(q, t, mat, 4, 2, 24, 1, w=64, zdrop=-1, flag=po.SCORE_ONLY).plan(False)
+    assert p.packed_pairs() == 4
+    p.close()
+    # a generic matrix without match/mismatch structure is not packed
+    m2 = mat.copy(); m2[1] = -3
+    p = sim.make_batch(q, t, m2, 4, 2, 24, 1, w=64, zdrop=-1, flag=po.SCORE_ONLY | po.GENERIC_SC).plan(False)
+    assert p.packed_pairs() == 0
+    p.close()
+    check_batch(sim, False, q, t, m2, 4, 2, 0, 0, w=64, flag=po.SCORE_ONLY | po.GENERIC_SC)
