@@ -18,7 +18,7 @@
 
 #define F_SCALAR_CONTRACT 0x40000000   /* internal: call came through ksw_extz / ksw_extd / ksw_gg* */
 #define NCLS_MAX (K2A_NCFG * 3 * 2)
-#define NCLS_ENTRIES (2 * NCLS_MAX)
+#define NCLS_ENTRIES (NCLS_MAX * (1 + K2A_NPKCFG))
 
 static __thread char g_err[512];
 
@@ -130,12 +130,16 @@ static size_t mp_total_steps(int G, int C, int qlen, int tlen, int w)
 
 /* does a (G,C) systolic array hold the band?  all strips resident at once, or a lane is done with
  * strip S before strip S+G starts */
-static int cfg_fits(int cfg, int tlen_eff, int w)
+static int geom_fits(int G, int C, int tlen_eff, int w)
 {
-	const int G = k2a_cfg_G[cfg], C = k2a_cfg_C[cfg];
-	if (cfg == K2A_CFG_MP) return 1;                       /* generation-serial: any band */
 	const int nstrips = (tlen_eff + C - 1) / C;
 	return nstrips <= G || 2 * (int64_t)w < (int64_t)G * (C + 1) - C + 1;
+}
+
+static int cfg_fits(int cfg, int tlen_eff, int w)
+{
+	if (cfg == K2A_CFG_MP) return 1;                       /* generation-serial: any band */
+	return geom_fits(k2a_cfg_G[cfg], k2a_cfg_C[cfg], tlen_eff, w);
 }
 
 static void build_scoring(int dual, int m, const int8_t *mat, int q, int e, int q2, int e2, int generic, K2aScoring *sc)
@@ -279,7 +283,11 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 		p->h_cls[i] = (int8_t)ci;
 		p->cells += band_cells(a->qlen, a->tlen, w);
 		if (pkinfo[generic].ok < 0) pk_scoring(dual, m, sc->mat, q, e, q2, e2, generic, &pkinfo[generic]);
-		pk_ok[i] = (uint8_t)(use_pk && mode == K2A_MODE_SCORE && cfg <= 2 && pk_eligible(&pkinfo[generic], a->qlen, d->tlen, w));
+		if (use_pk && mode == K2A_MODE_SCORE && pk_eligible(&pkinfo[generic], a->qlen, d->tlen, w)) {
+			int pc;                                            /* packed class: first geometry that holds the band, 1-based */
+			for (pc = 0; pc < K2A_NPKCFG; ++pc) if (geom_fits(k2a_pkcfg_G[pc], k2a_pkcfg_C[pc], d->tlen, w)) break;
+			if (pc < K2A_NPKCFG) pk_ok[i] = (uint8_t)(1 + pc);
+		}
 		if (cfg == K2A_CFG_MP) {                              /* boundary rows H, E, E~ between generations */
 			d->bnd_off = (uint32_t)p->bnd_words;
 			p->bnd_words += 3 * (size_t)a->qlen + 16;
@@ -306,7 +314,7 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 	srt = (sort_t*)malloc(sizeof(sort_t) * ((size_t)n + 1));
 	for (ci = 0, k = 0; ci < NCLS_MAX; ++ci) {
 		int pass;
-		for (pass = 0; pass < 2; ++pass) {                     /* 0: one alignment per lane group, 1: packed pairs */
+		for (pass = 0; pass <= K2A_NPKCFG; ++pass) {           /* 0: one alignment per lane group, 1 + pc: packed class pc */
 			int cnt = 0, ntask = 0;
 			cls_t *c;
 			for (i = 0; i < n; ++i)
@@ -318,7 +326,7 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 			if (cnt == 0) continue;
 			qsort(srt, (size_t)cnt, sizeof(sort_t), cmp_cost_desc);
 			c = &p->cls[p->ncls++];
-			c->cfg = ci / 6; c->mode = (ci / 2) % 3; c->generic = ci & 1; c->pk = pass; c->first = k;
+			c->cfg = pass ? pass - 1 : ci / 6; c->mode = (ci / 2) % 3; c->generic = ci & 1; c->pk = pass != 0; c->first = k;
 			build_scoring(dual, m, sc->mat, q, e, q2, e2, c->generic, &c->sc);
 			c->sc.pk_a = pkinfo[c->generic].a; c->sc.pk_b = pkinfo[c->generic].b; c->sc.pk_n = pkinfo[c->generic].n;
 			if (!pass) {
@@ -354,7 +362,7 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 			if (off > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "plan_create: more than 4 GiB of sequence in one plan%s", 0); goto err; }
 		}
 	}
-	p->seq_bytes = align_up(off + 64, 256);
+	p->seq_bytes = align_up(off + 65536, 256);      /* idle lanes may prefetch codes a few hundred bytes past the last pair */
 
 	/* pack + upload */
 	p->h_seq = (uint8_t*)calloc(p->seq_bytes, 1);

@@ -21,6 +21,10 @@ extern "C" {
 #define K2A_CFG_MP 4      /* generation-serial class: any band, boundary rows through HBM */
 static const int k2a_cfg_G[K2A_NCFG] = { 16, 64, 64, 64, 64 };
 static const int k2a_cfg_C[K2A_NCFG] = {  8,  8, 16, 32, 16 };
+/* geometry classes of the packed-int16 kernels (two same-shape alignments per lane group) */
+#define K2A_NPKCFG 4
+static const int k2a_pkcfg_G[K2A_NPKCFG] = {  8, 16, 64, 64 };
+static const int k2a_pkcfg_C[K2A_NPKCFG] = { 20,  8,  8, 16 };
 
 const char *k2a_shim_backend(void);                /* "hip:gfx950" or "sim" */
 const char *k2a_shim_last_error(void);
@@ -57,7 +61,7 @@ int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_
 
 /* Packed-int16 fill (score-only): ntasks tasks of TWO same-shape alignments each, order2[2t], order2[2t+1] = their
  * indices (equal for an unpaired leftover); both K2aPair entries point at the task's byte-interleaved sequences.
- * Classes 0..2 of the table above. */
+ * cfg indexes the k2a_pkcfg_* table. */
 int k2a_shim_launch_fill_pk(int cfg, int dual, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2, int ntasks,
                             const uint8_t *seq, K2aResult *res, void *stream);
 

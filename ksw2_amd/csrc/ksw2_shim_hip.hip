@@ -31,7 +31,14 @@ __device__ __forceinline__ int k2a_rot1(int v)
 {
 	/* lane l <- lane l-1 inside its group (lane 0 <- lane G-1) */
 	if (G == 64) return __builtin_amdgcn_update_dpp(0, v, 0x13C /* wave_ror:1 */, 0xf, 0xf, false);
-	else         return __builtin_amdgcn_update_dpp(0, v, 0x121 /* row_ror:1  */, 0xf, 0xf, false);
+	else if (G == 16) return __builtin_amdgcn_update_dpp(0, v, 0x121 /* row_ror:1  */, 0xf, 0xf, false);
+	else {
+		/* G == 8: two groups per 16-lane row.  row_shr:1 serves lanes 1..7 and 9..15; lanes 0 and 8 take lanes 7 and 15,
+		 * which row_ror:9 delivers (lane l <- lane (l-9) mod 16). */
+		const int shifted = __builtin_amdgcn_update_dpp(0, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+		const int wrapped = __builtin_amdgcn_update_dpp(0, v, 0x129 /* row_ror:9 */, 0xf, 0xf, false);
+		return (threadIdx.x & 7) == 0 ? wrapped : shifted;
+	}
 }
 
 template<int G, int C, bool DUAL, int MODE>
@@ -139,11 +146,9 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	__builtin_amdgcn_wave_barrier();
 
 	const int klast = L.last_step();
-	int kmax = klast;
-	if (G == 16) {
-		kmax = max(max(__builtin_amdgcn_readlane(klast, 0), __builtin_amdgcn_readlane(klast, 16)),
-		           max(__builtin_amdgcn_readlane(klast, 32), __builtin_amdgcn_readlane(klast, 48)));
-	} else kmax = __builtin_amdgcn_readfirstlane(klast);
+	int kmax = __builtin_amdgcn_readfirstlane(klast);
+#pragma unroll
+	for (int g = 1; g < NG; ++g) kmax = max(kmax, __builtin_amdgcn_readlane(klast, g * G));
 
 	bool gdone = !valid;
 	L.qb = L.next_query_codes(-1);
@@ -438,16 +443,17 @@ int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_
 }
 
 typedef void (*fill_pk_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, K2aResult*);
-static const fill_pk_fn g_fill_pk[3][2] = { { k2a_fill_pk_kernel<16, 8, false>, k2a_fill_pk_kernel<16, 8, true> },
-                                            { k2a_fill_pk_kernel<64, 8, false>, k2a_fill_pk_kernel<64, 8, true> },
-                                            { k2a_fill_pk_kernel<64, 16, false>, k2a_fill_pk_kernel<64, 16, true> } };
+static const fill_pk_fn g_fill_pk[K2A_NPKCFG][2] = { { k2a_fill_pk_kernel<8, 20, false>, k2a_fill_pk_kernel<8, 20, true> },
+                                                     { k2a_fill_pk_kernel<16, 8, false>, k2a_fill_pk_kernel<16, 8, true> },
+                                                     { k2a_fill_pk_kernel<64, 8, false>, k2a_fill_pk_kernel<64, 8, true> },
+                                                     { k2a_fill_pk_kernel<64, 16, false>, k2a_fill_pk_kernel<64, 16, true> } };
 
 int k2a_shim_launch_fill_pk(int cfg, int dual, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2, int ntasks,
                             const uint8_t *seq, K2aResult *res, void *stream)
 {
 	if (ntasks <= 0) return 0;
-	if (cfg < 0 || cfg > 2) { snprintf(g_err, sizeof(g_err), "bad packed kernel class"); return -1; }
-	const int per_block = K2A_WPB * (64 / k2a_cfg_G[cfg]);
+	if (cfg < 0 || cfg >= K2A_NPKCFG) { snprintf(g_err, sizeof(g_err), "bad packed kernel class"); return -1; }
+	const int per_block = K2A_WPB * (64 / k2a_pkcfg_G[cfg]);
 	const int blocks = (ntasks + per_block - 1) / per_block;
 	hipLaunchKernelGGL(g_fill_pk[cfg][dual ? 1 : 0], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
 	                   *sc, pairs, order2, ntasks, seq, res);

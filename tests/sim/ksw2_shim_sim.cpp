@@ -285,9 +285,10 @@ int k2a_shim_launch_fill(int cfg, int dual, int mode, const K2aScoring *sc, cons
 	return 0;
 }
 typedef void (*fill_pk_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, K2aResult*);
-static const fill_pk_fn g_fill_pk[3][2] = { { sim_fill_pk<16, 8, false>, sim_fill_pk<16, 8, true> },
-                                            { sim_fill_pk<64, 8, false>, sim_fill_pk<64, 8, true> },
-                                            { sim_fill_pk<64, 16, false>, sim_fill_pk<64, 16, true> } };
+static const fill_pk_fn g_fill_pk[K2A_NPKCFG][2] = { { sim_fill_pk<8, 20, false>, sim_fill_pk<8, 20, true> },
+                                                     { sim_fill_pk<16, 8, false>, sim_fill_pk<16, 8, true> },
+                                                     { sim_fill_pk<64, 8, false>, sim_fill_pk<64, 8, true> },
+                                                     { sim_fill_pk<64, 16, false>, sim_fill_pk<64, 16, true> } };
 int k2a_shim_launch_fill_pk(int cfg, int dual, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2, int ntasks,
                             const uint8_t *seq, K2aResult *res, void *)
 {
