@@ -204,6 +204,16 @@ static int pk_eligible(const pkinfo_t *k, int qlen, int tlen, int w)
 	return hmax < 16383 - 2 * k->qemax - 8 && hmin > -16384 + 2 * k->qemax + 8;
 }
 
+/* any residue code >= 4 (the wildcard of a 5-letter alphabet)?  8 codes per probe */
+static int has_wildcard(const uint8_t *s, int n)
+{
+	int i = 0;
+	uint64_t acc = 0, v;
+	for (; i + 8 <= n; i += 8) { memcpy(&v, s + i, 8); acc |= v; }
+	for (; i < n; ++i) acc |= s[i];
+	return (acc & 0xfcfcfcfcfcfcfcfcull) != 0;
+}
+
 void ksw2amd_plan_destroy(ksw2amd_plan_t *p)
 {
 	int i;
@@ -283,7 +293,8 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 		p->h_cls[i] = (int8_t)ci;
 		p->cells += band_cells(a->qlen, a->tlen, w);
 		if (pkinfo[generic].ok < 0) pk_scoring(dual, m, sc->mat, q, e, q2, e2, generic, &pkinfo[generic]);
-		if (use_pk && mode == K2A_MODE_SCORE && pk_eligible(&pkinfo[generic], a->qlen, d->tlen, w)) {
+		if (use_pk && mode == K2A_MODE_SCORE && pk_eligible(&pkinfo[generic], a->qlen, d->tlen, w) &&
+		    !has_wildcard(a->query, a->qlen) && !has_wildcard(a->target, a->tlen)) {
 			int pc;                                            /* packed class: first geometry that holds the band, 1-based */
 			for (pc = 0; pc < K2A_NPKCFG; ++pc) if (geom_fits(k2a_pkcfg_G[pc], k2a_pkcfg_C[pc], d->tlen, w)) break;
 			if (pc < K2A_NPKCFG) pk_ok[i] = (uint8_t)(1 + pc);

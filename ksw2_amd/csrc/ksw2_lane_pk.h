@@ -8,8 +8,9 @@
  * control instruction (live mask, schedule, DPP rotate, loop) is shared by the two alignments.
  *
  * Preconditions, checked by the host (ksw2_host.c::pk_eligible): m = 5 with a match / mismatch / wildcard score
- * structure (always true without KSW_EZ_GENERIC_SC), and every in-band H, E, F provably inside
- * (-16384 + max(q+e, q2+e2), 16383 - max(q+e, q2+e2)) so that -16384 can stand for -infinity.
+ * structure (always true without KSW_EZ_GENERIC_SC), no wildcard code in either sequence (such pairs take the
+ * int32 kernels), and every in-band H, E, F provably inside (-16384 + max(q+e, q2+e2), 16383 - max(q+e, q2+e2))
+ * so that -16384 can stand for -infinity.
  */
 #ifndef KSW2_LANE_PK_H_
 #define KSW2_LANE_PK_H_
@@ -53,7 +54,9 @@ K2A_FN k2a_pk k2a_spread16(uint32_t v)  /* bytes {b0,b1,..} -> halves {b0, b1} *
 	return __builtin_amdgcn_perm(0u, v, 0x0c010c00u);
 }
 K2A_FN k2a_pk k2a_bit_mask(uint32_t bits, int c) { return (k2a_pk)__builtin_amdgcn_sbfe((int)bits, c, 1); }
+#define K2A_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
+#define K2A_SCHED_FENCE() do {} while (0)
 K2A_FN k2a_pk k2a_pk_mk(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
 K2A_FN k2a_pk k2a_pk_add(k2a_pk a, k2a_pk b) { return k2a_pk_mk(k2a_pk_lo(a) + k2a_pk_lo(b), k2a_pk_hi(a) + k2a_pk_hi(b)); }
 K2A_FN k2a_pk k2a_pk_sub(k2a_pk a, k2a_pk b) { return k2a_pk_mk(k2a_pk_lo(a) - k2a_pk_lo(b), k2a_pk_hi(a) - k2a_pk_hi(b)); }
@@ -79,10 +82,8 @@ struct K2aLanePk {
 	/* systolic ports */
 	k2a_pk hout, eout, e2out, hd0, hu_prev;
 	uint32_t qb;                        /* { query code A, query code B } of this step's column */
-	bool has_n;                         /* a wildcard among this strip's target codes */
 	/* rows */
 	k2a_pk hl[C], f[C], f2[DUAL ? C : 1], rmax[C], rmj[C], tc[C];
-	uint32_t tnext[(C + 1) / 2];
 
 	K2A_FN static int first_col(int S_, int w_) { return k2a_max(0, S_ * C - w_); }
 
@@ -90,15 +91,6 @@ struct K2aLanePk {
 	{
 		koff_next = Snext;
 		knext = Snext < nstrips ? koff_next + first_col(Snext, w) : K2A_KNONE;
-	}
-
-	K2A_FN void load_tnext()
-	{
-		if (Snext < nstrips) {
-			const uint32_t *p = (const uint32_t*)(ti + (size_t)Snext * C * 2);
-#pragma unroll
-			for (int x = 0; x < (C + 1) / 2; ++x) tnext[x] = p[x];
-		}
 	}
 
 	K2A_FN void setup(const K2aPair &pr, const uint8_t *seq, int lane_in_group, bool valid)
@@ -111,19 +103,16 @@ struct K2aLanePk {
 		Snext = gl;
 		schedule_next();
 		const k2a_pk neg = k2a_pk2(K2A_NEG16);
-		hout = eout = e2out = hd0 = hu_prev = neg; qb = 0; has_n = false;
+		hout = eout = e2out = hd0 = hu_prev = neg; qb = 0;
+		local_reset();
 #pragma unroll
 		for (int c = 0; c < C; ++c) { hl[c] = f[c] = rmax[c] = neg; rmj[c] = 0; tc[c] = 0; if (DUAL) f2[c] = neg; }
 		if (!DUAL) f2[0] = 0;
-#pragma unroll
-		for (int x = 0; x < (C + 1) / 2; ++x) tnext[x] = 0;
-		load_tnext();
 	}
 
 	K2A_FN int last_step() const { return nstrips > 0 ? (nstrips - 1) + k2a_min(qlen - 1, tlen - 1 + w) : -1; }
 	K2A_FN bool need_init(int k) const { return k == knext; }
 	K2A_FN bool need_fin(int k) const { return S >= 0 && k - koff == je; }
-	K2A_FN bool sees_wildcard() const { return (S >= 0 && has_n) || ((qb & 0x00040004u) != 0); }
 
 	K2A_FN void do_init(const K2aScoring &sc)
 	{
@@ -131,13 +120,17 @@ struct K2aLanePk {
 		je = k2a_min(qlen - 1, k2a_min(i0 + C - 1, tlen - 1) + w);
 		const int js = k2a_max(0, i0 - w);
 		const k2a_pk neg = k2a_pk2(K2A_NEG16);
-		uint32_t any = 0;
+		/* target codes of the strip's rows (2*C bytes, 4-byte aligned; the arena is padded past the last row).
+		 * Not prefetched: one L2 round trip per strip is noise next to the strip's ~2w+C steps. */
+		const uint32_t *tp = (const uint32_t*)(ti + (size_t)S * C * 2);
+		uint32_t tw[(C + 1) / 2];
+#pragma unroll
+		for (int x = 0; x < (C + 1) / 2; ++x) tw[x] = tp[x];
 #pragma unroll
 		for (int c = 0; c < C; ++c) {
 			const int i = i0 + c;
-			const uint32_t two = (tnext[c >> 1] >> (16 * (c & 1))) & 0xffffu;
+			const uint32_t two = (tw[c >> 1] >> (16 * (c & 1))) & 0xffffu;
 			tc[c] = k2a_spread16(two);
-			any |= tc[c];
 			const bool edge = i <= w;                        /* virtual column -1: ksw2_extz.c:43-44, ksw2_extd.c:49-52 */
 			const int hb = k2a_border<DUAL>(sc, i + 1);
 			hl[c] = edge ? k2a_pk2(hb) : neg;
@@ -145,23 +138,20 @@ struct K2aLanePk {
 			if (DUAL) f2[c] = edge ? k2a_pk2(hb - (sc.q2 + sc.e2)) : neg;
 			rmax[c] = neg; rmj[c] = 0;
 		}
-		has_n = (any & 0x00040004u) != 0;
 		if (js == 0) hd0 = k2a_pk2(k2a_border<DUAL>(sc, i0));
 		else hd0 = hu_prev;
 		Snext += G;
 		schedule_next();
-		load_tnext();
 	}
 
-	/* one column for the C rows of both alignments; WILD = some lane of the wavefront touches a wildcard */
-	template<bool WILD>
+	/* one column for the C rows of both alignments */
 	K2A_FN void step(const K2aScoring &sc, int k, k2a_pk hin, k2a_pk ein, k2a_pk e2in)
 	{
 		const int jj = k - koff;
 		const bool act = (S >= 0) && (jj <= je) && (jj >= 0);
 		const k2a_pk neg = k2a_pk2(K2A_NEG16);
 		const k2a_pk qe = k2a_pk2(sc.q + sc.e), ge = k2a_pk2(sc.e), qe2 = k2a_pk2(sc.q2 + sc.e2), ge2 = k2a_pk2(sc.e2);
-		const k2a_pk mat_a = k2a_pk2(sc.pk_a), mat_bma = k2a_pk2(sc.pk_b - sc.pk_a), mat_n = k2a_pk2(sc.pk_n);
+		const k2a_pk mat_a = k2a_pk2(sc.pk_a), mat_bma = k2a_pk2(sc.pk_b - sc.pk_a);
 		k2a_pk hu = hin, e = ein, e2 = e2in;
 		if (S == 0) {                                          /* virtual row -1 */
 			const int hb = k2a_border<DUAL>(sc, jj + 1);
@@ -178,14 +168,9 @@ struct K2aLanePk {
 		k2a_pk hd = hd0;
 #pragma unroll
 		for (int c = 0; c < C; ++c) {
-			/* score: a on equal codes, b otherwise, wildcard score if either code is 4 */
+			/* score: a on equal codes, b otherwise (no wildcards in this class) */
 			const k2a_pk ne01 = k2a_pk_minu(tc[c] ^ qcode, 0x00010001u);
-			k2a_pk s = k2a_pk_mad(ne01, mat_bma, mat_a);
-			if (WILD) {
-				const k2a_pk isn = ((tc[c] | qcode) & 0x00040004u) << 13;       /* bit 2 -> sign bit of each half */
-				s = k2a_pk_sel(k2a_pk_sign(isn), mat_n, s);
-			}
-			k2a_pk h = k2a_pk_add(hd, s);
+			k2a_pk h = k2a_pk_add(hd, k2a_pk_mad(ne01, mat_bma, mat_a));
 			const k2a_pk fc = f[c];
 			h = k2a_pk_max(k2a_pk_max(h, e), fc);
 			if (DUAL) h = k2a_pk_max(k2a_pk_max(h, e2), f2[c]);
@@ -204,6 +189,9 @@ struct K2aLanePk {
 			}
 			hd = hl[c];
 			hl[c] = h;
+			/* keep hipcc from hoisting every row's score / mask computation to the top of the step: with C = 20 that
+			 * costs ~70 extra live registers and a wave of occupancy for no gain on a VALU-bound loop */
+			if (C > 8 && (c & 1) == 1) K2A_SCHED_FENCE();
 		}
 		hd0 = hu;
 		hout = hl[C - 1]; eout = e; e2out = e2;
@@ -218,24 +206,34 @@ struct K2aLanePk {
 		return k2a_spread16(two);
 	}
 
-	/* per-row epilogue of the scalar reference for the strip's rows, once per alignment (K2aLane::do_fin) */
-	K2A_FN void do_fin(const K2aScoring &sc, K2aBook *bA, K2aBook *bB, int zdropA, int zdropB)
+	/* Strip epilogues.  Both forms first stage the strip's rows {H(i, last column), row max, arg-max} in an LDS row
+	 * buffer (3*C words per lane group) and then walk them in a ROLLED loop: unrolled, hipcc materialises every row's
+	 * constants and unpacked halves at once and the kernel loses a wave of occupancy for code that runs once per strip. */
+	K2A_FN void stage_rows(uint32_t *rowbuf) const
+	{
+#pragma unroll
+		for (int c = 0; c < C; ++c) { rowbuf[c] = hl[c]; rowbuf[C + c] = rmax[c]; rowbuf[2 * C + c] = rmj[c]; }
+	}
+
+	/* Sequential form (needed as soon as a Z-drop test is active): the scalar reference's per-row epilogue
+	 * (K2aLane::do_fin), once per alignment. */
+	K2A_FN void do_fin_seq(const K2aScoring &sc, K2aBook *bA, K2aBook *bB, int zdropA, int zdropB, const uint32_t *rowbuf)
 	{
 		const int zslope = DUAL ? sc.e2 : sc.e;
-#pragma unroll
+#pragma nounroll
 		for (int half = 0; half < 2; ++half) {
 			K2aBook *b = half ? bB : bA;
 			const int zdrop = half ? zdropB : zdropA;
+			const int sh = half ? 16 : 0;
 			int bmax = b->max, bmax_t = b->max_t, bmax_q = b->max_q, bmqe = b->mqe, bmqe_t = b->mqe_t;
 			int bmte = b->mte, bmte_q = b->mte_q, bscore = b->score, bdrop = b->dropped, brows = b->rows;
-#pragma unroll
+#pragma nounroll
 			for (int c = 0; c < C; ++c) {
 				const int i = i0 + c;
 				if (i < tlen && !bdrop) {
 					const bool reach = i + w >= qlen - 1;
-					const int hend = half ? k2a_pk_hi(hl[c]) : k2a_pk_lo(hl[c]);
-					const int H = half ? k2a_pk_hi(rmax[c]) : k2a_pk_lo(rmax[c]);
-					const int j = half ? k2a_pk_hi(rmj[c]) : k2a_pk_lo(rmj[c]);
+					const int hend = (int)(int16_t)(rowbuf[c] >> sh), H = (int)(int16_t)(rowbuf[C + c] >> sh);
+					const int j = (int)(int16_t)(rowbuf[2 * C + c] >> sh);
 					if (reach && hend > bmqe) { bmqe = hend; bmqe_t = i; }
 					if (i == tlen_full - 1) { bmte = H; bmte_q = j; }
 					if (H > bmax) { bmax = H; bmax_t = i; bmax_q = j; }
@@ -253,6 +251,58 @@ struct K2aLanePk {
 		}
 		S = -1; je = -1;
 	}
+
+	/* Local form (no Z-drop test anywhere in the wavefront, so nothing can stop early): every lane keeps its own best
+	 * (max, row, column) and best end-of-query (mqe, row) for both alignments in packed registers.  "H > max" in row
+	 * order == first row reaching the maximum; a lane sees its rows in increasing order, and the final merge across
+	 * lanes (k2a_merge_local) breaks ties towards the smaller row, so the result is the sequential one. */
+	k2a_pk lmax, lmax_t, lmax_q, lmqe, lmqe_t;
+	k2a_pk last_h, last_m, last_j;         /* last target row: H(tlen-1, last column), row max, arg-max */
+
+	K2A_FN void local_reset()
+	{
+		lmax = 0; lmax_t = lmax_q = 0xffffffffu; lmqe = k2a_pk2(K2A_NEG16); lmqe_t = 0xffffffffu;
+		last_h = last_m = last_j = 0;
+	}
+
+	K2A_FN void do_fin_local(const uint32_t *rowbuf)
+	{
+#pragma nounroll
+		for (int c = 0; c < C; ++c) {
+			const int i = i0 + c;
+			const k2a_pk ph = rowbuf[c], pm = rowbuf[C + c], pj = rowbuf[2 * C + c];
+			const k2a_pk ipk = k2a_pk2(i);
+			/* rows past the target end kept rmax = hl = -inf and can never win */
+			const k2a_pk up = k2a_pk_sign(k2a_pk_sub(lmax, pm));                /* max < H */
+			lmax_t = k2a_pk_sel(up, ipk, lmax_t);
+			lmax_q = k2a_pk_sel(up, pj, lmax_q);
+			lmax = k2a_pk_max(lmax, pm);
+			const k2a_pk reach = (i + w >= qlen - 1) ? 0xffffffffu : 0u;        /* the row's last cell is column qlen-1 */
+			const k2a_pk uq = k2a_pk_sign(k2a_pk_sub(lmqe, ph)) & reach;
+			lmqe_t = k2a_pk_sel(uq, ipk, lmqe_t);
+			lmqe = k2a_pk_sel(uq, ph, lmqe);
+			if (i == tlen_full - 1 && tlen == tlen_full) { last_h = ph; last_m = pm; last_j = pj; }   /* mte / mte_q / score */
+		}
+		S = -1; je = -1;
+	}
 };
+
+/* merge the lane-local bests of one alignment (half = 0/1) of a lane group: loc[l*5 + {0..4}] = lane l's
+ * {lmax, lmax_t, lmax_q, lmqe, lmqe_t}.  Ties go to the smaller row, as in the sequential scan. */
+K2A_FN void k2a_merge_local(const uint32_t *loc, int G, int half, K2aBook *b)
+{
+	int bmax = 0, bmax_t = -1, bmax_q = -1, bmqe = K2A_NEG, bmqe_t = -1;
+	for (int l = 0; l < G; ++l) {
+		const uint32_t *r = loc + l * 5;
+		const int m = half ? k2a_pk_hi(r[0]) : k2a_pk_lo(r[0]);
+		const int mt = half ? k2a_pk_hi(r[1]) : k2a_pk_lo(r[1]);
+		const int mq = half ? k2a_pk_hi(r[2]) : k2a_pk_lo(r[2]);
+		const int qe = half ? k2a_pk_hi(r[3]) : k2a_pk_lo(r[3]);
+		const int qt = half ? k2a_pk_hi(r[4]) : k2a_pk_lo(r[4]);
+		if (mt >= 0 && (m > bmax || (m == bmax && bmax_t >= 0 && mt < bmax_t))) { bmax = m; bmax_t = mt; bmax_q = mq; }
+		if (qt >= 0 && (qe > bmqe || (qe == bmqe && qt < bmqe_t))) { bmqe = qe; bmqe_t = qt; }
+	}
+	b->max = bmax; b->max_t = bmax_t; b->max_q = bmax_q; b->mqe = bmqe; b->mqe_t = bmqe_t;
+}
 
 #endif

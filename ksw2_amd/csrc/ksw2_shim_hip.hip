@@ -130,6 +130,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	constexpr int NG = 64 / G;
 	typedef K2aLanePk<G, C, DUAL> Lane;
 	__shared__ K2aBook book[K2A_WPB][NG][2];
+	__shared__ uint32_t stage[K2A_WPB][(NG * 3 * C > 64 * 5) ? NG * 3 * C : 64 * 5];   /* row buffers / final lane records */
 
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int grp = lane / G, gl = lane % G;
@@ -138,6 +139,8 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	const uint32_t piA = order2[valid ? 2 * task : 0], piB = order2[valid ? 2 * task + 1 : 0];
 	const K2aPair prA = pairs[piA];
 	const int zdropA = prA.zdrop, zdropB = pairs[piB].zdrop;
+	/* a Z-drop test anywhere in the wavefront selects the sequential strip epilogue for all of it */
+	const bool zseq = __builtin_amdgcn_ballot_w64(valid && (zdropA >= 0 || zdropB >= 0)) != 0;
 
 	Lane L;
 	L.setup(prA, seq, gl, valid);
@@ -164,19 +167,43 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 		}
 		const uint32_t qnext = L.next_query_codes(k);
 
-		if (__builtin_amdgcn_ballot_w64(L.sees_wildcard()) != 0) L.template step<true>(sc, k, hin, ein, e2in);
-		else L.template step<false>(sc, k, hin, ein, e2in);
+		L.step(sc, k, hin, ein, e2in);
 
 		const bool nfin = L.need_fin(k);
 		if (__builtin_amdgcn_ballot_w64(nfin) != 0) {
-			if (nfin) L.do_fin(sc, bkA, bkB, zdropA, zdropB);
-			__builtin_amdgcn_wave_barrier();
-			if (bkA->dropped && bkB->dropped) gdone = true;
+			uint32_t *rowbuf = &stage[wave][grp * 3 * C];
+			if (nfin) L.stage_rows(rowbuf);
+			if (zseq) {
+				if (nfin) L.do_fin_seq(sc, bkA, bkB, zdropA, zdropB, rowbuf);
+				__builtin_amdgcn_wave_barrier();
+				if (bkA->dropped && bkB->dropped) gdone = true;
+			} else if (nfin) L.do_fin_local(rowbuf);
 		}
 		L.qb = qnext;
 		if (__builtin_amdgcn_ballot_w64(!(gdone || k >= klast)) == 0) break;
 	}
 	__builtin_amdgcn_wave_barrier();
+	if (!zseq) {
+		/* merge the lane-local bests of each group; the lane that finished the last target row adds mte / score */
+		uint32_t *loc = &stage[wave][0];
+		loc[lane * 5 + 0] = L.lmax; loc[lane * 5 + 1] = L.lmax_t; loc[lane * 5 + 2] = L.lmax_q;
+		loc[lane * 5 + 3] = L.lmqe; loc[lane * 5 + 4] = L.lmqe_t;
+		__builtin_amdgcn_wave_barrier();
+		if (valid && gl == 0) {
+			k2a_merge_local(loc + grp * G * 5, G, 0, bkA);
+			k2a_merge_local(loc + grp * G * 5, G, 1, bkB);
+			bkA->rows = bkB->rows = prA.tlen;
+		}
+		__builtin_amdgcn_wave_barrier();
+		const int Slast = (prA.tlen_full - 1) / C;
+		if (valid && prA.tlen == prA.tlen_full && gl == Slast % G) {
+			const bool reach = prA.tlen_full - 1 + prA.w >= prA.qlen - 1;
+			bkA->mte = k2a_pk_lo(L.last_m); bkA->mte_q = k2a_pk_lo(L.last_j);
+			bkB->mte = k2a_pk_hi(L.last_m); bkB->mte_q = k2a_pk_hi(L.last_j);
+			if (reach) { bkA->score = k2a_pk_lo(L.last_h); bkB->score = k2a_pk_hi(L.last_h); }
+		}
+		__builtin_amdgcn_wave_barrier();
+	}
 	if (valid && gl == 0) {
 		const K2aBook a = *bkA, b = *bkB;
 		k2a_finish(prA, a, &res[piA]);

@@ -101,9 +101,9 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 		static Lane L[64];
 		K2aBook book[NG][2];
 		K2aPair prA[64];
-		uint32_t piA[64], piB[64];
+		uint32_t piA[64], piB[64], stage[(NG * 3 * C > 64 * 5) ? NG * 3 * C : 64 * 5];
 		int zdA[64], zdB[64], klast[64], kmax = -1;
-		bool valid[64], gdone[64];
+		bool valid[64], gdone[64], zseq = false;
 		for (int lane = 0; lane < 64; ++lane) {
 			const int grp = lane / G, gl = lane % G, task = wv * NG + grp;
 			valid[lane] = task < ntasks;
@@ -116,6 +116,7 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 			if (klast[lane] > kmax) kmax = klast[lane];
 			gdone[lane] = !valid[lane];
 			L[lane].qb = L[lane].next_query_codes(-1);
+			zseq |= valid[lane] && (zdA[lane] >= 0 || zdB[lane] >= 0);
 		}
 		for (int k = 0; k <= kmax; ++k) {
 			k2a_pk hin[64], ein[64], e2in[64];
@@ -124,23 +125,27 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 				const int grp = lane / G, gl = lane % G, src = grp * G + (gl + G - 1) % G;
 				hin[lane] = L[src].hout; ein[lane] = L[src].eout; e2in[lane] = DUAL ? L[src].e2out : 0;
 			}
-			bool wild = false, anyfin = false, nfin[64];
+			bool anyfin = false, nfin[64];
 			for (int lane = 0; lane < 64; ++lane) {
 				if (L[lane].need_init(k)) L[lane].do_init(sc);
 				qnext[lane] = L[lane].next_query_codes(k);
 			}
-			for (int lane = 0; lane < 64; ++lane) wild |= L[lane].sees_wildcard();
 			for (int lane = 0; lane < 64; ++lane) {
-				if (wild) L[lane].template step<true>(sc, k, hin[lane], ein[lane], e2in[lane]);
-				else L[lane].template step<false>(sc, k, hin[lane], ein[lane], e2in[lane]);
+				L[lane].step(sc, k, hin[lane], ein[lane], e2in[lane]);
 				nfin[lane] = L[lane].need_fin(k);
 				anyfin |= nfin[lane];
 			}
 			if (anyfin) {
-				for (int lane = 0; lane < 64; ++lane)
-					if (nfin[lane]) L[lane].do_fin(sc, &book[lane / G][0], &book[lane / G][1], zdA[lane], zdB[lane]);
-				for (int lane = 0; lane < 64; ++lane)
-					if (book[lane / G][0].dropped && book[lane / G][1].dropped) gdone[lane] = true;
+				for (int lane = 0; lane < 64; ++lane) {
+					if (!nfin[lane]) continue;
+					uint32_t *rowbuf = &stage[(lane / G) * 3 * C];
+					L[lane].stage_rows(rowbuf);
+					if (zseq) L[lane].do_fin_seq(sc, &book[lane / G][0], &book[lane / G][1], zdA[lane], zdB[lane], rowbuf);
+					else L[lane].do_fin_local(rowbuf);
+				}
+				if (zseq)
+					for (int lane = 0; lane < 64; ++lane)
+						if (book[lane / G][0].dropped && book[lane / G][1].dropped) gdone[lane] = true;
 			}
 			bool all_done = true;
 			for (int lane = 0; lane < 64; ++lane) {
@@ -148,6 +153,27 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 				if (!(gdone[lane] || k >= klast[lane])) all_done = false;
 			}
 			if (all_done) break;
+		}
+		if (!zseq) {
+			for (int lane = 0; lane < 64; ++lane) {
+				stage[lane * 5 + 0] = L[lane].lmax; stage[lane * 5 + 1] = L[lane].lmax_t; stage[lane * 5 + 2] = L[lane].lmax_q;
+				stage[lane * 5 + 3] = L[lane].lmqe; stage[lane * 5 + 4] = L[lane].lmqe_t;
+			}
+			for (int lane = 0; lane < 64; ++lane)
+				if (valid[lane] && lane % G == 0) {
+					k2a_merge_local(stage + (lane / G) * G * 5, G, 0, &book[lane / G][0]);
+					k2a_merge_local(stage + (lane / G) * G * 5, G, 1, &book[lane / G][1]);
+					book[lane / G][0].rows = book[lane / G][1].rows = prA[lane].tlen;
+				}
+			for (int lane = 0; lane < 64; ++lane) {
+				const K2aPair &pr = prA[lane];
+				if (valid[lane] && pr.tlen == pr.tlen_full && lane % G == ((pr.tlen_full - 1) / C) % G) {
+					K2aBook *a = &book[lane / G][0], *b = &book[lane / G][1];
+					a->mte = k2a_pk_lo(L[lane].last_m); a->mte_q = k2a_pk_lo(L[lane].last_j);
+					b->mte = k2a_pk_hi(L[lane].last_m); b->mte_q = k2a_pk_hi(L[lane].last_j);
+					if (pr.tlen_full - 1 + pr.w >= pr.qlen - 1) { a->score = k2a_pk_lo(L[lane].last_h); b->score = k2a_pk_hi(L[lane].last_h); }
+				}
+			}
 		}
 		for (int lane = 0; lane < 64; ++lane)
 			if (valid[lane] && lane % G == 0) {

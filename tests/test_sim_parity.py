@@ -151,7 +151,7 @@ def test_sim_packed_int16_class(sim):
             npk += p.packed_pairs()
             p.close()
             check_batch(sim, dual, qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl)
-    assert npk > 500
+    assert npk > 300          # batches with wildcards stay on the int32 kernels
 
 
 def test_sim_packed_range_guard(sim):
