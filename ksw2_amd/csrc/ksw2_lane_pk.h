@@ -79,6 +79,7 @@ struct K2aLanePk {
 	const uint8_t *qi, *ti;            /* byte-interleaved sequences: x[2p] = code of A, x[2p+1] = code of B */
 	/* schedule, identical to K2aLane */
 	int gl, S, i0, je, koff, Snext, knext, koff_next;
+	int kfin, kd, rows_m1, wup;         /* last step of the strip, koff + i0, live-row clamp (-1 = no strip), band reach upwards */
 	/* systolic ports */
 	k2a_pk hout, eout, e2out, hd0, hu_prev;
 	uint32_t qb;                        /* { query code A, query code B } of this step's column */
@@ -99,7 +100,7 @@ struct K2aLanePk {
 		qi = seq + pr.qoff; ti = seq + pr.toff;
 		nstrips = valid ? (tlen + C - 1) / C : 0;
 		gl = lane_in_group;
-		S = -1; i0 = 0; je = -1; koff = 0;
+		S = -1; i0 = 0; je = -1; koff = 0; kfin = K2A_KNONE; kd = 0; rows_m1 = -1; wup = w;
 		Snext = gl;
 		schedule_next();
 		const k2a_pk neg = k2a_pk2(K2A_NEG16);
@@ -112,12 +113,16 @@ struct K2aLanePk {
 
 	K2A_FN int last_step() const { return nstrips > 0 ? (nstrips - 1) + k2a_min(qlen - 1, tlen - 1 + w) : -1; }
 	K2A_FN bool need_init(int k) const { return k == knext; }
-	K2A_FN bool need_fin(int k) const { return S >= 0 && k - koff == je; }
+	K2A_FN bool need_fin(int k) const { return k == kfin; }
 
 	K2A_FN void do_init(const K2aScoring &sc)
 	{
 		S = Snext; i0 = S * C; koff = koff_next;
 		je = k2a_min(qlen - 1, k2a_min(i0 + C - 1, tlen - 1) + w);
+		kfin = koff + je;
+		kd = koff + i0;
+		rows_m1 = k2a_min(C - 1, tlen - 1 - i0);
+		wup = w + (S == 0 ? 1 : 0);                        /* the virtual row -1 reaches one column further (E(0,w) exists) */
 		const int js = k2a_max(0, i0 - w);
 		const k2a_pk neg = k2a_pk2(K2A_NEG16);
 		/* target codes of the strip's rows (2*C bytes, 4-byte aligned; the arena is padded past the last row).
@@ -128,15 +133,19 @@ struct K2aLanePk {
 		for (int x = 0; x < (C + 1) / 2; ++x) tw[x] = tp[x];
 #pragma unroll
 		for (int c = 0; c < C; ++c) {
-			const int i = i0 + c;
-			const uint32_t two = (tw[c >> 1] >> (16 * (c & 1))) & 0xffffu;
-			tc[c] = k2a_spread16(two);
-			const bool edge = i <= w;                        /* virtual column -1: ksw2_extz.c:43-44, ksw2_extd.c:49-52 */
-			const int hb = k2a_border<DUAL>(sc, i + 1);
-			hl[c] = edge ? k2a_pk2(hb) : neg;
-			f[c] = edge ? k2a_pk2(hb - (sc.q + sc.e)) : neg;
-			if (DUAL) f2[c] = edge ? k2a_pk2(hb - (sc.q2 + sc.e2)) : neg;
+			tc[c] = k2a_spread16((tw[c >> 1] >> (16 * (c & 1))) & 0xffffu);
+			hl[c] = neg; f[c] = neg; if (DUAL) f2[c] = neg;
 			rmax[c] = neg; rmj[c] = 0;
+		}
+		if (i0 <= w) {                                          /* some rows start at column 0: virtual column -1 */
+#pragma unroll
+			for (int c = 0; c < C; ++c) {                        /* ksw2_extz.c:43-44, ksw2_extd.c:49-52 */
+				const int hb = k2a_border<DUAL>(sc, i0 + c + 1);
+				if (i0 + c <= w) {
+					hl[c] = k2a_pk2(hb); f[c] = k2a_pk2(hb - (sc.q + sc.e));
+					if (DUAL) f2[c] = k2a_pk2(hb - (sc.q2 + sc.e2));
+				}
+			}
 		}
 		if (js == 0) hd0 = k2a_pk2(k2a_border<DUAL>(sc, i0));
 		else hd0 = hu_prev;
@@ -144,35 +153,44 @@ struct K2aLanePk {
 		schedule_next();
 	}
 
-	/* one column for the C rows of both alignments */
+	/* first strip only: the cells above row 0 are the virtual row -1 (ksw2_extz.c:32-35, ksw2_extd.c:33-41) */
+	K2A_FN void top_inputs(const K2aScoring &sc, int k, k2a_pk &hin, k2a_pk &ein, k2a_pk &e2in) const
+	{
+		if (S == 0) {
+			const int hb = k2a_border<DUAL>(sc, k - koff + 1);
+			hin = k2a_pk2(hb); ein = k2a_pk2(hb - (sc.q + sc.e)); e2in = k2a_pk2(hb - (sc.q2 + sc.e2));
+		}
+	}
+
+	/* One column for the C rows of both alignments.  hin/ein/e2in = bottom row of the strip above at this column.
+	 * Phase 1 forms every row's diagonal candidate H(i-1,j-1) + s(i,j) while the old H row is still intact, phase 2 runs
+	 * the E chain down the rows and writes the new H row in place (no register shuffling at the loop back-edge). */
 	K2A_FN void step(const K2aScoring &sc, int k, k2a_pk hin, k2a_pk ein, k2a_pk e2in)
 	{
-		const int jj = k - koff;
-		const bool act = (S >= 0) && (jj <= je) && (jj >= 0);
+		const int dd = k - kd;                                 /* jj - i0 */
 		const k2a_pk neg = k2a_pk2(K2A_NEG16);
 		const k2a_pk qe = k2a_pk2(sc.q + sc.e), ge = k2a_pk2(sc.e), qe2 = k2a_pk2(sc.q2 + sc.e2), ge2 = k2a_pk2(sc.e2);
 		const k2a_pk mat_a = k2a_pk2(sc.pk_a), mat_bma = k2a_pk2(sc.pk_b - sc.pk_a);
-		k2a_pk hu = hin, e = ein, e2 = e2in;
-		if (S == 0) {                                          /* virtual row -1 */
-			const int hb = k2a_border<DUAL>(sc, jj + 1);
-			hu = k2a_pk2(hb); e = k2a_pk2(hb - (sc.q + sc.e)); e2 = k2a_pk2(hb - (sc.q2 + sc.e2));
-			if (jj > w) { e = neg; e2 = neg; }
-		} else if (jj - i0 >= w) { e = neg; e2 = neg; }
-		hu_prev = hin;
-		const int lo = k2a_max(0, jj - w - i0);
-		const int hi = k2a_min(k2a_min(C - 1, jj + w - i0), tlen - 1 - i0);
-		uint32_t live = 0;
-		if (act && lo <= hi) live = (2u << hi) - (1u << lo);
+		k2a_pk e = ein, e2 = e2in;
+		if (dd >= wup) { e = neg; e2 = neg; }                  /* the cell above is outside the band */
+		/* live rows lo..hi of this strip at this column (none while the lane owns no strip: rows_m1 = -1) */
+		const int lo = k2a_max(0, dd - w);
+		const int hi = k2a_min(rows_m1, dd + w);
+		const int cnt = k2a_max(hi - lo + 1, 0);
+		const uint32_t live = ((1u << cnt) - 1u) << lo;
 		const k2a_pk qcode = qb;
-		const k2a_pk jjpk = k2a_pk2(jj);
-		k2a_pk hd = hd0;
+		const k2a_pk jjpk = k2a_pk2(k - koff);
+		k2a_pk cand[C];
 #pragma unroll
 		for (int c = 0; c < C; ++c) {
 			/* score: a on equal codes, b otherwise (no wildcards in this class) */
 			const k2a_pk ne01 = k2a_pk_minu(tc[c] ^ qcode, 0x00010001u);
-			k2a_pk h = k2a_pk_add(hd, k2a_pk_mad(ne01, mat_bma, mat_a));
+			cand[c] = k2a_pk_add(c == 0 ? hd0 : hl[c - 1], k2a_pk_mad(ne01, mat_bma, mat_a));
+		}
+#pragma unroll
+		for (int c = 0; c < C; ++c) {
 			const k2a_pk fc = f[c];
-			h = k2a_pk_max(k2a_pk_max(h, e), fc);
+			k2a_pk h = k2a_pk_max(k2a_pk_max(cand[c], e), fc);
 			if (DUAL) h = k2a_pk_max(k2a_pk_max(h, e2), f2[c]);
 			h = k2a_pk_sel(k2a_bit_mask(live, c), h, neg);
 			/* running row maximum, ties to the last column: keep the old arg-max only where h < max */
@@ -187,23 +205,18 @@ struct K2aLanePk {
 				e2 = k2a_pk_max(k2a_pk_sub(e2, ge2), t2);
 				f2[c] = k2a_pk_max(k2a_pk_sub(f2[c], ge2), t2);
 			}
-			hd = hl[c];
 			hl[c] = h;
-			/* keep hipcc from hoisting every row's score / mask computation to the top of the step: with C = 20 that
-			 * costs ~70 extra live registers and a wave of occupancy for no gain on a VALU-bound loop */
-			if (C > 8 && (c & 1) == 1) K2A_SCHED_FENCE();
 		}
-		hd0 = hu;
+		hd0 = hin;
 		hout = hl[C - 1]; eout = e; e2out = e2;
 	}
 
+	/* query codes of the column this lane sees at step k+1; idle lanes read a clamped (valid, unused) column */
 	K2A_FN uint32_t next_query_codes(int k) const
 	{
-		const bool starts = (k + 1 == knext);
-		const int j = k + 1 - (starts ? koff_next : koff);
-		uint32_t two = 0;
-		if ((starts || S >= 0) && j >= 0 && j < qlen) two = *(const uint16_t*)(qi + 2 * (size_t)j);
-		return k2a_spread16(two);
+		const int j = k + 1 - ((k + 1 == knext) ? koff_next : koff);
+		const int jc = k2a_min(k2a_max(j, 0), qlen - 1);
+		return k2a_spread16(*(const uint16_t*)(qi + 2 * (size_t)jc));
 	}
 
 	/* Strip epilogues.  Both forms first stage the strip's rows {H(i, last column), row max, arg-max} in an LDS row
@@ -249,7 +262,7 @@ struct K2aLanePk {
 			b->max = bmax; b->max_t = bmax_t; b->max_q = bmax_q; b->mqe = bmqe; b->mqe_t = bmqe_t;
 			b->mte = bmte; b->mte_q = bmte_q; b->score = bscore; b->dropped = bdrop; b->rows = brows;
 		}
-		S = -1; je = -1;
+		S = -1; je = -1; kfin = K2A_KNONE; rows_m1 = -1;
 	}
 
 	/* Local form (no Z-drop test anywhere in the wavefront, so nothing can stop early): every lane keeps its own best
@@ -283,7 +296,7 @@ struct K2aLanePk {
 			lmqe = k2a_pk_sel(uq, ph, lmqe);
 			if (i == tlen_full - 1 && tlen == tlen_full) { last_h = ph; last_m = pm; last_j = pj; }   /* mte / mte_q / score */
 		}
-		S = -1; je = -1;
+		S = -1; je = -1; kfin = K2A_KNONE; rows_m1 = -1;
 	}
 };
 

@@ -153,19 +153,27 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 #pragma unroll
 	for (int g = 1; g < NG; ++g) kmax = max(kmax, __builtin_amdgcn_readlane(klast, g * G));
 
+	/* the first strip of an alignment reads the virtual row -1 instead of a neighbour lane: steps 0..ktop only */
+	const int ktop1 = valid ? min(prA.qlen - 1, min(C - 1, prA.tlen - 1) + prA.w) : -1;
+	int ktop = __builtin_amdgcn_readfirstlane(ktop1);
+#pragma unroll
+	for (int g = 1; g < NG; ++g) ktop = max(ktop, __builtin_amdgcn_readlane(ktop1, g * G));
+
 	bool gdone = !valid;
 	L.qb = L.next_query_codes(-1);
 
 	for (int k = 0; k <= kmax; ++k) {
-		const k2a_pk hin = (k2a_pk)k2a_rot1<G>((int)L.hout);
-		const k2a_pk ein = (k2a_pk)k2a_rot1<G>((int)L.eout);
-		const k2a_pk e2in = DUAL ? (k2a_pk)k2a_rot1<G>((int)L.e2out) : 0u;
+		k2a_pk hin = (k2a_pk)k2a_rot1<G>((int)L.hout);
+		k2a_pk ein = (k2a_pk)k2a_rot1<G>((int)L.eout);
+		k2a_pk e2in = DUAL ? (k2a_pk)k2a_rot1<G>((int)L.e2out) : 0u;
 
 		const bool ninit = L.need_init(k);
 		if (__builtin_amdgcn_ballot_w64(ninit) != 0) {
-			if (ninit) L.do_init(sc);
+			if (ninit) L.do_init(sc);                         /* uses hu_prev = what arrived one step ago */
 		}
+		L.hu_prev = hin;
 		const uint32_t qnext = L.next_query_codes(k);
+		if (k <= ktop) L.top_inputs(sc, k, hin, ein, e2in);
 
 		L.step(sc, k, hin, ein, e2in);
 
@@ -180,7 +188,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 			} else if (nfin) L.do_fin_local(rowbuf);
 		}
 		L.qb = qnext;
-		if (__builtin_amdgcn_ballot_w64(!(gdone || k >= klast)) == 0) break;
+		if (zseq && __builtin_amdgcn_ballot_w64(!(gdone || k >= klast)) == 0) break;   /* only a Z-drop ends a group early */
 	}
 	__builtin_amdgcn_wave_barrier();
 	if (!zseq) {

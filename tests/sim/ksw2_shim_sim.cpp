@@ -102,7 +102,7 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 		K2aBook book[NG][2];
 		K2aPair prA[64];
 		uint32_t piA[64], piB[64], stage[(NG * 3 * C > 64 * 5) ? NG * 3 * C : 64 * 5];
-		int zdA[64], zdB[64], klast[64], kmax = -1;
+		int zdA[64], zdB[64], klast[64], kmax = -1, ktop = -1;
 		bool valid[64], gdone[64], zseq = false;
 		for (int lane = 0; lane < 64; ++lane) {
 			const int grp = lane / G, gl = lane % G, task = wv * NG + grp;
@@ -117,6 +117,10 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 			gdone[lane] = !valid[lane];
 			L[lane].qb = L[lane].next_query_codes(-1);
 			zseq |= valid[lane] && (zdA[lane] >= 0 || zdB[lane] >= 0);
+			if (valid[lane]) {
+				const int kt = k2a_min(prA[lane].qlen - 1, k2a_min(C - 1, prA[lane].tlen - 1) + prA[lane].w);
+				if (kt > ktop) ktop = kt;
+			}
 		}
 		for (int k = 0; k <= kmax; ++k) {
 			k2a_pk hin[64], ein[64], e2in[64];
@@ -128,7 +132,9 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 			bool anyfin = false, nfin[64];
 			for (int lane = 0; lane < 64; ++lane) {
 				if (L[lane].need_init(k)) L[lane].do_init(sc);
+				L[lane].hu_prev = hin[lane];
 				qnext[lane] = L[lane].next_query_codes(k);
+				if (k <= ktop) L[lane].top_inputs(sc, k, hin[lane], ein[lane], e2in[lane]);
 			}
 			for (int lane = 0; lane < 64; ++lane) {
 				L[lane].step(sc, k, hin[lane], ein[lane], e2in[lane]);
@@ -152,7 +158,7 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 				L[lane].qb = qnext[lane];
 				if (!(gdone[lane] || k >= klast[lane])) all_done = false;
 			}
-			if (all_done) break;
+			if (zseq && all_done) break;
 		}
 		if (!zseq) {
 			for (int lane = 0; lane < 64; ++lane) {
