@@ -164,12 +164,14 @@ def main():
         achieved = cells * ops / (kern_ms * 1e-3)
         alg_bytes = n * (wl["qlen"] + wl["tlen"] + 56) + (0 if score_only else cells)
         traffic, traffic_src = recorded_traffic(args.workload) if not args.pairs else (None, None)
+        npk = plan.packed_pairs()
+        dtype = "int16x2 (packed, two alignments per lane)" if npk == n else "int32" if npk == 0 else "int16x2 + int32"
         out = {
             "metric": "GCUPS (DP cells/s) + pairs/s at fixed (qlen,tlen,band)",
             "value": round(cells_all * args.steps / dt / 1e9, 3), "unit": "GCUPS",
             "pairs_per_s": round(pairs_all * args.steps / dt, 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "%s: %d pairs/GPU, qlen=%d tlen=%d band=%d zdrop=%d %s %s" % (
                 args.workload, n, wl["qlen"], wl["tlen"], wl["w"], wl["zdrop"], "extd2 dual-gap" if wl["dual"] else "extz2 affine",
                 "score-only" if score_only else "CIGAR"), "cells_per_gpu": cells, "parallelism": "pairs sharded over %d GPU(s), no collective" % world},
@@ -179,7 +181,8 @@ def main():
                          "kernel_gcups": round(cells / (kern_ms * 1e-3) / 1e9, 2),
                          "algorithmic_bytes": alg_bytes, "hbm_algorithmic_GBps": round(alg_bytes / (kern_ms * 1e-3) / 1e9, 2), "hbm_peak_GBps": HBM_PEAK / 1e9,
                          "note": "integer-VALU bound (no dense contraction, SURVEY 8d); peak = packed-int16 rate 256CU x 4SIMD x 32 lanes x 2.4GHz x 2; "
-                                 "the kernel computes in int32 (peak 78.6 Tiop/s)"},
+                                 "measured issue rate of integer VALU ops (incl. v_pk_*_i16) on gfx950 is one wave64 instruction per 4 cycles per SIMD "
+                                 "(SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles, profiles/), i.e. 39.3 T lane-instr/s, which this kernel saturates"},
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(wl, q, t, mat, seconds=args.cpu_seconds)

@@ -123,7 +123,7 @@ k2a_fill_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const ui
 
 /* Packed-int16 resident fill, score-only: two same-shape alignments per lane group (ksw2_lane_pk.h). */
 template<int G, int C, bool DUAL>
-__global__ void __launch_bounds__(64 * K2A_WPB)
+__global__ void __launch_bounds__(64 * K2A_WPB)      /* no occupancy floor: capping at 168 VGPRs spills and is 18 % slower */
 k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
                    const uint8_t *__restrict__ seq, K2aResult *__restrict__ res)
 {
