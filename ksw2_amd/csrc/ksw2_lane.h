@@ -66,6 +66,7 @@ struct K2aLane {
 	const uint8_t *qry, *tgt;
 	/* schedule: a lane sees column jj = k - koff at step k while it owns strip S */
 	int gl, S, i0, je, koff, Snext, knext, koff_next;
+	int kfin, kd, rows_m1, wup;   /* last step of the strip, koff + i0, live-row clamp (-1 = no strip), band reach upwards */
 	/* systolic ports: what this lane produced for the strip below at the previous step */
 	int hout, eout, e2out;
 	int hd0;                      /* H(i0-1, jj-1) */
@@ -102,7 +103,7 @@ struct K2aLane {
 		qry = seq + pr.qoff; tgt = seq + pr.toff;
 		nstrips = valid ? (tlen + C - 1) / C : 0;
 		gl = lane_in_group;
-		S = -1; i0 = 0; je = -1; koff = 0;
+		S = -1; i0 = 0; je = -1; koff = 0; kfin = K2A_KNONE; kd = 0; rows_m1 = -1; wup = w;
 		Snext = gl;
 		schedule_next_resident();
 		hout = eout = e2out = K2A_NEG; hd0 = K2A_NEG; hu_prev = K2A_NEG; qb = 0;
@@ -128,7 +129,7 @@ struct K2aLane {
 	 * by l steps.  The bottom row of a generation reaches the next one through a boundary buffer in HBM. */
 	K2A_FN void begin_generation(int g, int jlo)
 	{
-		S = -1; je = -1;
+		S = -1; je = -1; kfin = K2A_KNONE; rows_m1 = -1;
 		Snext = g * G + gl;
 		koff_next = gl - jlo;
 		knext = Snext < nstrips ? koff_next + first_col(Snext, w) : K2A_KNONE;
@@ -142,22 +143,29 @@ struct K2aLane {
 	{
 		S = Snext; i0 = S * C; koff = koff_next;
 		je = k2a_min(qlen - 1, k2a_min(i0 + C - 1, tlen - 1) + w);
+		kfin = koff + je;
+		kd = koff + i0;
+		rows_m1 = k2a_min(C - 1, tlen - 1 - i0);
+		wup = w + (S == 0 ? 1 : 0);                        /* the virtual row -1 reaches one column further (E(0,w) exists) */
 		const int js = k2a_max(0, i0 - w);
 #pragma unroll
 		for (int x = 0; x < (C + 3) / 4; ++x) tbp[x] = tnext[x];
 #pragma unroll
 		for (int c = 0; c < C; ++c) {
-			const int i = i0 + c;
 			const uint32_t tb = (tbp[c >> 2] >> (8 * (c & 3))) & 0xff;
-			const uint32_t tbc = tb < 4 ? tb : 4;
-			P[c] = ptab[tbc];                                 /* score profile of this row's target code (LDS table) */
-			/* rows that start at column 0 see the virtual column -1 (ksw2_extz.c:43-44, ksw2_extd.c:49-52) */
-			const bool edge = i <= w;
-			const int hb = k2a_border<DUAL>(sc, i + 1);
-			hl[c] = edge ? hb : K2A_NEG;
-			f[c] = edge ? hb - (sc.q + sc.e) : K2A_NEG;
-			if (DUAL) f2[c] = edge ? hb - (sc.q2 + sc.e2) : K2A_NEG;
+			P[c] = ptab[tb < 4 ? tb : 4];                     /* score profile of this row's target code (LDS table) */
+			hl[c] = K2A_NEG; f[c] = K2A_NEG; if (DUAL) f2[c] = K2A_NEG;
 			rmax[c] = K2A_NEG; rmj[c] = 0;
+		}
+		if (i0 <= w) {                                      /* some rows start at column 0: virtual column -1 */
+#pragma unroll
+			for (int c = 0; c < C; ++c) {                    /* ksw2_extz.c:43-44, ksw2_extd.c:49-52 */
+				const int hb = k2a_border<DUAL>(sc, i0 + c + 1);
+				if (i0 + c <= w) {
+					hl[c] = hb; f[c] = hb - (sc.q + sc.e);
+					if (DUAL) f2[c] = hb - (sc.q2 + sc.e2);
+				}
+			}
 		}
 		if (js == 0) hd0 = k2a_border<DUAL>(sc, i0);       /* H(i0-1,-1); 0 at the origin */
 		else hd0 = hu_prev;                               /* H(i0-1, js-1), received one step ago */
@@ -168,49 +176,58 @@ struct K2aLane {
 		} else knext = K2A_KNONE;
 	}
 
+	/* first strip only: the cells above row 0 are the virtual row -1 (ksw2_extz.c:32-35, ksw2_extd.c:33-41) */
+	K2A_FN void top_inputs(const K2aScoring &sc, int k, int &hin, int &ein, int &e2in) const
+	{
+		if (S == 0) {
+			const int hb = k2a_border<DUAL>(sc, k - koff + 1);
+			hin = hb; ein = hb - (sc.q + sc.e); e2in = hb - (sc.q2 + sc.e2);
+		}
+	}
+
 	/* One step: column jj = k - koff for the C rows of the current strip.
-	 *   hin/ein/e2in: bottom-row outputs of the previous lane at the previous step (already rotated in)
+	 *   hin/ein/e2in: bottom row of the strip above at this column (rotated in from the previous lane, or the
+	 *                 virtual row -1 / the boundary buffer, see the kernels)
 	 *   tbw: traceback word(s) out (MODE != SCORE)
-	 *   WILD: some lane of the wavefront sees the query wildcard in this column (wave-uniform, rare): scores
-	 *         come from the per-target-code column table `ctab` instead of the 4-entry register profile
-	 * returns true when this lane computed live cells (so tbw is meaningful). */
-	template<bool WILD>
-	K2A_FN bool step(const K2aScoring &sc, const uint32_t *ctab, int k, int hin, int ein, int e2in, uint32_t *tbw)
+	 *   wild: some lane of the wavefront sees the query wildcard in this column (wave-uniform, rare): scores
+	 *         come from the per-target-code column table `ctab` instead of the 4-entry register profile; the branch
+	 *         wraps phase 1 only, so just the C candidates merge (a whole-step if/else costs ~60 registers)
+	 * Phase 1 forms every row's diagonal candidate H(i-1,j-1) + s(i,j) while the old H row is intact, phase 2 runs the
+	 * E chain down the rows and rewrites the H row in place.  Returns true when the lane computed live cells. */
+	K2A_FN bool step(const K2aScoring &sc, const uint32_t *ctab, bool wild, int k, int hin, int ein, int e2in, uint32_t *tbw)
 	{
 		const int jj = k - koff;
-		const bool act = (S >= 0) && (jj <= je) && (jj >= 0);
+		const int dd = k - kd;                               /* jj - i0 */
 		const int qe = sc.q + sc.e, qe2 = sc.q2 + sc.e2;
-		/* inputs from above: virtual row -1 for the first strip, else the rotated ports; the cell above is
-		 * outside the band when jj - (i0-1) > w */
-		int hu = hin, e = ein, e2 = e2in;
-		if (S == 0) {
-			const int hb = k2a_border<DUAL>(sc, jj + 1);
-			hu = hb; e = hb - qe; e2 = hb - qe2;
-			if (jj > w) { e = K2A_NEG; e2 = K2A_NEG; }
-		} else if (jj - i0 >= w) { e = K2A_NEG; e2 = K2A_NEG; }
-		hu_prev = hin;
-		/* live rows of this strip at column jj: lo <= c <= hi */
-		const int lo = k2a_max(0, jj - w - i0);
-		const int hi = k2a_min(k2a_min(C - 1, jj + w - i0), tlen - 1 - i0);
-		uint32_t live = 0;
-		if (act && lo <= hi) live = (2u << hi) - (1u << lo);
+		int e = ein, e2 = e2in;
+		if (dd >= wup) { e = K2A_NEG; e2 = K2A_NEG; }        /* the cell above is outside the band */
+		/* live rows lo..hi of this strip at this column (none while the lane owns no strip: rows_m1 = -1) */
+		const int lo = k2a_max(0, dd - w);
+		const int hi = k2a_min(rows_m1, dd + w);
+		const int cnt = k2a_max(hi - lo + 1, 0);
+		const uint32_t live = cnt >= 32 ? 0xffffffffu : ((1u << cnt) - 1u) << lo;
 		/* query code of this column; wildcard columns take the slow score path */
 		const int qcode = qb;
 		const int qsh = (qcode & 3) * 8;
 		const bool qwild = qcode >= 4;
-		int hd = hd0;
+		int cand[C];
+		if (!wild) {
+#pragma unroll
+			for (int c = 0; c < C; ++c) cand[c] = (c == 0 ? hd0 : hl[c - 1]) + (int)(int8_t)(P[c] >> qsh);
+		} else {
+#pragma unroll
+			for (int c = 0; c < C; ++c) {
+				const uint32_t tb = (tbp[c >> 2] >> (8 * (c & 3))) & 0xff;
+				const int sw = (int)ctab[tb < 4 ? tb : 4];
+				cand[c] = (c == 0 ? hd0 : hl[c - 1]) + (qwild ? sw : (int)(int8_t)(P[c] >> qsh));
+			}
+		}
 		uint32_t tw[TBWORDS];
 #pragma unroll
 		for (int x = 0; x < TBWORDS; ++x) tw[x] = 0;
 #pragma unroll
 		for (int c = 0; c < C; ++c) {
-			int s = (int)(int8_t)(P[c] >> qsh);
-			if (WILD) {
-				const uint32_t tb = (tbp[c >> 2] >> (8 * (c & 3))) & 0xff;
-				const int sw = (int)ctab[tb < 4 ? tb : 4];
-				s = qwild ? sw : s;
-			}
-			int h = hd + s;
+			int h = cand[c];
 			const int fc = f[c];
 			uint32_t d = 0;
 			if (MODE == K2A_MODE_SCORE) {
@@ -258,10 +275,9 @@ struct K2aLane {
 				f2[c] = k2a_max(fx2, t2);
 			}
 			if (MODE != K2A_MODE_SCORE) tw[(c * TBBITS) >> 5] |= d << ((c * TBBITS) & 31);
-			hd = hl[c];
 			hl[c] = h;
 		}
-		hd0 = hu;
+		hd0 = hin;
 		hout = hl[C - 1]; eout = e; e2out = e2;
 		if (MODE != K2A_MODE_SCORE) {
 #pragma unroll
@@ -270,30 +286,33 @@ struct K2aLane {
 		return live != 0;
 	}
 
-	/* prefetch the query code of the column this lane will see at step k+1 */
+	/* query code of the column this lane sees at step k+1; idle lanes read a clamped (valid, unused) column */
 	K2A_FN int next_query_code(int k) const
 	{
-		const bool starts = (k + 1 == knext);
-		const int j = k + 1 - (starts ? koff_next : koff);
-		return ((starts || S >= 0) && j >= 0 && j < qlen) ? (int)qry[j] : 0;
+		const int j = k + 1 - ((k + 1 == knext) ? koff_next : koff);
+		return (int)qry[k2a_min(k2a_max(j, 0), qlen - 1)];
 	}
 
-	K2A_FN bool need_fin(int k) const { return S >= 0 && k - koff == je; }
+	K2A_FN bool need_fin(int k) const { return k == kfin; }
 	K2A_FN int column(int k) const { return k - koff; }
 
-	/* The strip's last column is done: replay the scalar reference's per-row epilogue for its rows, in row
-	 * order (ksw2_extz.c:116-124, ksw2_extd.c:156-164; Z-drop test ksw2.h:191-207 with is_rot = 0). */
-	K2A_FN void do_fin(const K2aScoring &sc, K2aBook *b, int zdrop)
+	/* The strip's last column is done: replay the scalar reference's per-row epilogue for its rows, in row order
+	 * (ksw2_extz.c:116-124, ksw2_extd.c:156-164; Z-drop test ksw2.h:191-207 with is_rot = 0).  The rows are staged in an
+	 * LDS row buffer (3*C words per lane group) and walked in a ROLLED loop: unrolled, hipcc keeps every row's values
+	 * live at once and the kernels lose a wave of occupancy for code that runs once per strip. */
+	K2A_FN void do_fin(const K2aScoring &sc, K2aBook *b, int zdrop, int *rowbuf)
 	{
 		const int zslope = DUAL ? sc.e2 : sc.e;
+#pragma unroll
+		for (int c = 0; c < C; ++c) { rowbuf[c] = hl[c]; rowbuf[C + c] = rmax[c]; rowbuf[2 * C + c] = rmj[c]; }
 		int bmax = b->max, bmax_t = b->max_t, bmax_q = b->max_q, bmqe = b->mqe, bmqe_t = b->mqe_t;
 		int bmte = b->mte, bmte_q = b->mte_q, bscore = b->score, bdrop = b->dropped, brows = b->rows;
-#pragma unroll
+#pragma nounroll
 		for (int c = 0; c < C; ++c) {
 			const int i = i0 + c;
 			if (i < tlen && !bdrop) {
 				const bool reach = i + w >= qlen - 1;           /* the row's last cell is column qlen-1 */
-				const int hend = hl[c], H = rmax[c], j = rmj[c];
+				const int hend = rowbuf[c], H = rowbuf[C + c], j = rowbuf[2 * C + c];
 				if (reach && hend > bmqe) { bmqe = hend; bmqe_t = i; }
 				if (i == tlen_full - 1) { bmte = H; bmte_q = j; }
 				if (H > bmax) { bmax = H; bmax_t = i; bmax_q = j; }
@@ -308,7 +327,7 @@ struct K2aLane {
 		}
 		b->max = bmax; b->max_t = bmax_t; b->max_q = bmax_q; b->mqe = bmqe; b->mqe_t = bmqe_t;
 		b->mte = bmte; b->mte_q = bmte_q; b->score = bscore; b->dropped = bdrop; b->rows = brows;
-		S = -1; je = -1;
+		S = -1; je = -1; kfin = K2A_KNONE; rows_m1 = -1;
 	}
 };
 

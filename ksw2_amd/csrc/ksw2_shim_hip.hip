@@ -50,6 +50,7 @@ k2a_fill_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const ui
 	typedef K2aLane<G, C, DUAL, MODE> Lane;
 	__shared__ K2aBook book[K2A_WPB][NG];
 	__shared__ uint32_t tabs[16];                     /* [0..4] row profiles, [8..12] scores against the query wildcard */
+	__shared__ int rowbuf[K2A_WPB][NG][3 * C];        /* strip epilogue staging */
 	if (threadIdx.x < 5) { tabs[threadIdx.x] = sc.prof[threadIdx.x]; tabs[8 + threadIdx.x] = (uint32_t)sc.colw[threadIdx.x]; }
 	__syncthreads();
 
@@ -67,30 +68,37 @@ k2a_fill_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const ui
 	__builtin_amdgcn_wave_barrier();
 
 	const int klast = L.last_step();                  /* group-uniform; -1 for an idle group */
-	int kmax = klast;
-	if (G == 16) {
-		kmax = max(max(__builtin_amdgcn_readlane(klast, 0), __builtin_amdgcn_readlane(klast, 16)),
-		           max(__builtin_amdgcn_readlane(klast, 32), __builtin_amdgcn_readlane(klast, 48)));
-	} else kmax = __builtin_amdgcn_readfirstlane(klast);
+	int kmax = __builtin_amdgcn_readfirstlane(klast);
+#pragma unroll
+	for (int g = 1; g < NG; ++g) kmax = max(kmax, __builtin_amdgcn_readlane(klast, g * G));
 
 	uint8_t *tbp = tb + pr.tb_off + (size_t)gl * (Lane::TBWORDS * 4);
 	bool gdone = !valid;
 	L.qb = L.next_query_code(-1);
+	/* the first strip of an alignment reads the virtual row -1 instead of a neighbour lane: steps 0..ktop only */
+	const int ktop1 = valid ? min(pr.qlen - 1, min(C - 1, pr.tlen - 1) + pr.w) : -1;
+	int ktop = __builtin_amdgcn_readfirstlane(ktop1);
+#pragma unroll
+	for (int g = 1; g < NG; ++g) ktop = max(ktop, __builtin_amdgcn_readlane(ktop1, g * G));
+	/* only a Z-drop can end a group before its last step */
+	const bool zany = __builtin_amdgcn_ballot_w64(valid && pr.zdrop >= 0) != 0;
 
 	for (int k = 0; k <= kmax; ++k) {
-		const int hin = k2a_rot1<G>(L.hout);
-		const int ein = k2a_rot1<G>(L.eout);
-		const int e2in = DUAL ? k2a_rot1<G>(L.e2out) : 0;
+		int hin = k2a_rot1<G>(L.hout);
+		int ein = k2a_rot1<G>(L.eout);
+		int e2in = DUAL ? k2a_rot1<G>(L.e2out) : 0;
 
 		const bool ninit = L.need_init(k);
 		if (__builtin_amdgcn_ballot_w64(ninit) != 0) {
-			if (ninit) L.template do_init<true>(sc, tabs);
+			if (ninit) L.template do_init<true>(sc, tabs);      /* uses hu_prev = what arrived one step ago */
 		}
+		L.hu_prev = hin;
 		const int qnext = L.next_query_code(k);
+		if (k <= ktop) L.top_inputs(sc, k, hin, ein, e2in);
 
 		uint32_t tw[Lane::TBWORDS];
 		const bool wild = __builtin_amdgcn_ballot_w64(L.qb >= 4) != 0;
-		const bool live = wild ? L.template step<true>(sc, tabs + 8, k, hin, ein, e2in, tw) : L.template step<false>(sc, tabs + 8, k, hin, ein, e2in, tw);
+		const bool live = L.step(sc, tabs + 8, wild, k, hin, ein, e2in, tw);
 		if (MODE != K2A_MODE_SCORE) {
 			if (live) {
 				uint32_t *dst = (uint32_t*)(tbp + (size_t)k * (G * Lane::TBWORDS * 4));
@@ -107,12 +115,12 @@ k2a_fill_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const ui
 
 		const bool nfin = L.need_fin(k);
 		if (__builtin_amdgcn_ballot_w64(nfin) != 0) {
-			if (nfin) L.do_fin(sc, bk, pr.zdrop);
+			if (nfin) L.do_fin(sc, bk, pr.zdrop, rowbuf[wave][grp]);
 			__builtin_amdgcn_wave_barrier();
 			if (bk->dropped) gdone = true;
 		}
 		L.qb = qnext;
-		if (__builtin_amdgcn_ballot_w64(!(gdone || k >= klast)) == 0) break;
+		if (zany && __builtin_amdgcn_ballot_w64(!(gdone || k >= klast)) == 0) break;
 	}
 	__builtin_amdgcn_wave_barrier();
 	if (valid && gl == 0) {
@@ -231,6 +239,7 @@ k2a_fill_mp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	static_assert(G == 64, "one alignment per wavefront");
 	typedef K2aLane<G, C, DUAL, MODE> Lane;
 	__shared__ K2aBook book[K2A_WPB];
+	__shared__ int rowbuf[K2A_WPB][3 * C];
 	__shared__ uint32_t tabs[16];
 	if (threadIdx.x < 5) { tabs[threadIdx.x] = sc.prof[threadIdx.x]; tabs[8 + threadIdx.x] = (uint32_t)sc.colw[threadIdx.x]; }
 	__syncthreads();
@@ -253,6 +262,7 @@ k2a_fill_mp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	const int ngen = valid ? (pr.tlen + R - 1) / R : 0;
 	size_t kbase = 0;
 	bool dropped = false;
+	const int ktop = __builtin_amdgcn_readfirstlane(valid ? min(pr.qlen - 1, min(C - 1, pr.tlen - 1) + pr.w) : -1);
 
 	for (int g = 0; g < ngen && !dropped; ++g) {
 		int jlo, nsteps;
@@ -292,12 +302,14 @@ k2a_fill_mp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 			if (__builtin_amdgcn_ballot_w64(ninit) != 0) {
 				if (ninit) L.template do_init<false>(sc, tabs);
 			}
+			L.hu_prev = hin;
 			const int qnext = L.next_query_code(k);
+			if (g == 0 && k <= ktop) L.top_inputs(sc, k, hin, ein, e2in);
 			uint32_t tw[Lane::TBWORDS];
 			const int jj = L.column(k);
 			const bool mine = L.S >= 0 && jj >= 0 && jj <= L.je;
 			const bool wild = __builtin_amdgcn_ballot_w64(L.qb >= 4) != 0;
-			const bool live = wild ? L.template step<true>(sc, tabs + 8, k, hin, ein, e2in, tw) : L.template step<false>(sc, tabs + 8, k, hin, ein, e2in, tw);
+			const bool live = L.step(sc, tabs + 8, wild, k, hin, ein, e2in, tw);
 			if (MODE != K2A_MODE_SCORE) {
 				if (live) {
 					uint32_t *dst = (uint32_t*)(tbp + (kbase + (size_t)k) * (G * Lane::TBWORDS * 4));
@@ -317,7 +329,7 @@ k2a_fill_mp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 			}
 			const bool nfin = L.need_fin(k);
 			if (__builtin_amdgcn_ballot_w64(nfin) != 0) {
-				if (nfin) L.do_fin(sc, bk, pr.zdrop);
+				if (nfin) L.do_fin(sc, bk, pr.zdrop, rowbuf[wave]);
 				__builtin_amdgcn_wave_barrier();
 				if (bk->dropped) dropped = true;
 			}

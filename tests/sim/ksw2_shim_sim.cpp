@@ -32,10 +32,12 @@ static void sim_fill(const K2aScoring sc, const K2aPair *pairs, const uint32_t *
 	for (int wv = 0; wv < nwaves; ++wv) {
 		static Lane L[64];
 		K2aBook book[NG];
+		int rowbuf[NG][3 * C];
 		K2aPair pr[64];
 		uint32_t pi[64];
 		bool valid[64], gdone[64];
-		int klast[64], kmax = -1;
+		int klast[64], kmax = -1, ktop = -1;
+		bool zany = false;
 		uint8_t *tbp[64];
 		for (int lane = 0; lane < 64; ++lane) {
 			const int grp = lane / G, gl = lane % G, task = wv * NG + grp;
@@ -49,6 +51,10 @@ static void sim_fill(const K2aScoring sc, const K2aPair *pairs, const uint32_t *
 			tbp[lane] = tb + pr[lane].tb_off + (size_t)gl * (Lane::TBWORDS * 4);
 			gdone[lane] = !valid[lane];
 			L[lane].qb = L[lane].next_query_code(-1);
+			if (valid[lane]) {
+				ktop = k2a_max(ktop, k2a_min(pr[lane].qlen - 1, k2a_min(C - 1, pr[lane].tlen - 1) + pr[lane].w));
+				zany |= pr[lane].zdrop >= 0;
+			}
 		}
 		for (int k = 0; k <= kmax; ++k) {
 			int hin[64], ein[64], e2in[64], qnext[64];
@@ -60,13 +66,14 @@ static void sim_fill(const K2aScoring sc, const K2aPair *pairs, const uint32_t *
 			bool nfin[64];
 			for (int lane = 0; lane < 64; ++lane) {      /* init events first: the wave-uniform wildcard test follows them */
 				if (L[lane].need_init(k)) L[lane].template do_init<true>(sc, tabs);
+				L[lane].hu_prev = hin[lane];
 				wild |= L[lane].qb >= 4;
 			}
 			for (int lane = 0; lane < 64; ++lane) {
 				qnext[lane] = L[lane].next_query_code(k);
+				if (k <= ktop) L[lane].top_inputs(sc, k, hin[lane], ein[lane], e2in[lane]);
 				uint32_t tw[Lane::TBWORDS];
-				const bool live = wild ? L[lane].template step<true>(sc, tabs + 8, k, hin[lane], ein[lane], e2in[lane], tw)
-				                       : L[lane].template step<false>(sc, tabs + 8, k, hin[lane], ein[lane], e2in[lane], tw);
+				const bool live = L[lane].step(sc, tabs + 8, wild, k, hin[lane], ein[lane], e2in[lane], tw);
 				if (MODE != K2A_MODE_SCORE && live)
 					memcpy(tbp[lane] + (size_t)k * (G * Lane::TBWORDS * 4), tw, sizeof(tw));
 				nfin[lane] = L[lane].need_fin(k);
@@ -74,7 +81,7 @@ static void sim_fill(const K2aScoring sc, const K2aPair *pairs, const uint32_t *
 			}
 			if (anyfin) {
 				for (int lane = 0; lane < 64; ++lane)
-					if (nfin[lane]) L[lane].do_fin(sc, &book[lane / G], pr[lane].zdrop);
+					if (nfin[lane]) L[lane].do_fin(sc, &book[lane / G], pr[lane].zdrop, rowbuf[lane / G]);
 				for (int lane = 0; lane < 64; ++lane)
 					if (book[lane / G].dropped) gdone[lane] = true;
 			}
@@ -83,7 +90,7 @@ static void sim_fill(const K2aScoring sc, const K2aPair *pairs, const uint32_t *
 				L[lane].qb = qnext[lane];
 				if (!(gdone[lane] || k >= klast[lane])) all_done = false;
 			}
-			if (all_done) break;
+			if (zany && all_done) break;
 		}
 		for (int lane = 0; lane < 64; ++lane)
 			if (valid[lane] && lane % G == 0) k2a_finish(pr[lane], book[lane / G], &res[pi[lane]]);
@@ -198,6 +205,7 @@ static void sim_fill_mp(const K2aScoring sc, const K2aPair *pairs, const uint32_
 	for (int task = 0; task < ntasks; ++task) {
 		static Lane L[64];
 		K2aBook book;
+		int rowbuf[3 * C];
 		const uint32_t pi = order[task];
 		const K2aPair pr = pairs[pi];
 		uint32_t tabs[16] = {0};
@@ -208,6 +216,7 @@ static void sim_fill_mp(const K2aScoring sc, const K2aPair *pairs, const uint32_
 		const int R = G * C, ngen = (pr.tlen + R - 1) / R;
 		size_t kbase = 0;
 		bool dropped = false;
+		const int ktop = k2a_min(pr.qlen - 1, k2a_min(C - 1, pr.tlen - 1) + pr.w);
 		for (int g = 0; g < ngen && !dropped; ++g) {
 			int jlo, nsteps;
 			k2a_gen_cols<G, C>(g, pr.qlen, pr.tlen, pr.w, &jlo, &nsteps);
@@ -228,15 +237,16 @@ static void sim_fill_mp(const K2aScoring sc, const K2aPair *pairs, const uint32_
 				bool nfin[64], anyfin = false, wild = false;
 				for (int gl = 0; gl < 64; ++gl) {
 					if (L[gl].need_init(k)) L[gl].template do_init<false>(sc, tabs);
+					L[gl].hu_prev = hin[gl];
 					wild |= L[gl].qb >= 4;
 				}
 				for (int gl = 0; gl < 64; ++gl) {
 					qnext[gl] = L[gl].next_query_code(k);
+					if (g == 0 && k <= ktop) L[gl].top_inputs(sc, k, hin[gl], ein[gl], e2in[gl]);
 					uint32_t tw[Lane::TBWORDS];
 					const int jj = L[gl].column(k);
 					const bool mine = L[gl].S >= 0 && jj >= 0 && jj <= L[gl].je;
-					const bool live = wild ? L[gl].template step<true>(sc, tabs + 8, k, hin[gl], ein[gl], e2in[gl], tw)
-					                       : L[gl].template step<false>(sc, tabs + 8, k, hin[gl], ein[gl], e2in[gl], tw);
+					const bool live = L[gl].step(sc, tabs + 8, wild, k, hin[gl], ein[gl], e2in[gl], tw);
 					if (MODE != K2A_MODE_SCORE && live)
 						memcpy(tb + pr.tb_off + ((kbase + (size_t)k) * G + gl) * (Lane::TBWORDS * 4), tw, sizeof(tw));
 					if (gl == G - 1 && mine) { Bh[jj] = L[gl].hout; Be[jj] = L[gl].eout; if (DUAL) Be2[jj] = L[gl].e2out; }
@@ -244,7 +254,7 @@ static void sim_fill_mp(const K2aScoring sc, const K2aPair *pairs, const uint32_
 					anyfin |= nfin[gl];
 				}
 				if (anyfin) {
-					for (int gl = 0; gl < 64; ++gl) if (nfin[gl]) L[gl].do_fin(sc, &book, pr.zdrop);
+					for (int gl = 0; gl < 64; ++gl) if (nfin[gl]) L[gl].do_fin(sc, &book, pr.zdrop, rowbuf);
 					if (book.dropped) dropped = true;
 				}
 				for (int gl = 0; gl < 64; ++gl) L[gl].qb = qnext[gl];

@@ -256,3 +256,38 @@ def test_packed_fixed_shape_batches(lib, dual):
         zd = rng.choice([-1, 30, 100, 400], size=n); eb = rng.choice([0, 10, 50], size=n)
         fl = np.array([po.SCORE_ONLY | (po.EXTZ_ONLY if rng.random() < 0.3 else 0) | (po.GENERIC_SC if rnd % 3 == 0 else 0) for _ in range(n)])
         check_batch(lib, dual, qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl)
+
+
+def test_cfg5_ont_like_mix(lib):
+    """BASELINE config 5 shape: ragged ONT-like pairs, qlen in [300, 20000], 15 % indels, band 500, extd2 with
+    Z-drop 400 and CIGAR.  48 pairs here (the oracle needs ~0.1 s per long pair); every field and CIGAR compared."""
+    rng = np.random.Generator(np.random.PCG64(20260005))
+    mat = synth.simple_mat(5, 2, 4, -1)
+    qs, ts = [], []
+    while len(qs) < 48:
+        tl = int(rng.integers(300, 20001))
+        t = rng.integers(0, 4, size=tl, dtype=np.uint8)
+        q = synth.mutate_one(t, rng, sub=0.03, ind=0.15, indel_mean=1.5)
+        if abs(len(q) - tl) > 450 or len(q) < 300:
+            continue
+        qs.append(q); ts.append(t)
+    k, res = check_batch(lib, True, qs, ts, mat, 4, 2, 24, 1, w=500, zdrop=400, flag=0)
+    assert k == 48 and all(r["n_cigar"] > 0 for r in res)
+
+
+def test_cfg4_replicas_sharded_plan(lib):
+    """Config 4 replicates the MT pair; a plan larger than the device budget must be split transparently
+    (KSW2AMD_MAX_BYTES forces the split with 6 replicas) and every replica must be identical."""
+    import os
+    _, ts = gu.read_fasta("MT-human.fa")
+    _, qs = gu.read_fasta("MT-orang.fa")
+    mat = gu.simple_mat(5, 2, 4, 0)
+    os.environ["KSW2AMD_MAX_BYTES"] = str(400 << 20)          # ~2 replicas of 144 MB traceback per sub-batch
+    try:
+        res = lib.extz_batch([qs[0]] * 6, [ts[0]] * 6, mat, 4, 2, w=-1, zdrop=-1, flag=0)
+    finally:
+        del os.environ["KSW2AMD_MAX_BYTES"]
+    import hashlib
+    for r in res:
+        assert (r["score"], r["max"], r["max_t"], r["max_q"]) == (16102, 17054, 16568, 16024)
+        assert hashlib.md5((gu.cigar_string(r["cigar"]) + "\n").encode()).hexdigest()[:12] == "ea0524d904ed"
