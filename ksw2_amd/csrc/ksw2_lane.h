@@ -349,6 +349,31 @@ K2A_FN void k2a_gen_cols(int g, int qlen, int tlen, int w, int *jlo, int *nsteps
 	*nsteps = hi >= lo ? (hi - lo + 1) + (nl - 1) : 0;
 }
 
+/* Traceback block layout: one WB-byte word per (step, lane).  Lane-major -- word (lane, step) at (lane*nsteps + step) --
+ * keeps the words a walk visits along a diagonal (same lane, consecutive steps) in the same cache lines, which is what
+ * the latency-bound walk needs; the fill pays with 64 narrow stores per wave-step instead of one wide one, but it is
+ * VALU-bound and has the memory pipeline to spare. */
+K2A_FN size_t k2a_tb_word(size_t step, int lane, size_t nsteps, int G, int WB)
+{
+#ifdef K2A_TB_STEP_MAJOR
+	(void)nsteps;
+	return (step * (size_t)G + (size_t)lane) * (size_t)WB;
+#else
+	(void)G;
+	return ((size_t)lane * nsteps + step) * (size_t)WB;
+#endif
+}
+
+template<int G, int C, bool MP>
+K2A_FN size_t k2a_tb_steps(int qlen, int tlen, int w)
+{
+	if (!MP) return (size_t)((tlen + C - 1) / C - 1) + (size_t)k2a_min(qlen - 1, tlen - 1 + w) + 1;
+	const int R = G * C, ngen = (tlen + R - 1) / R;
+	size_t tot = 0;
+	for (int g = 0; g < ngen; ++g) { int jlo, ns; k2a_gen_cols<G, C>(g, qlen, tlen, w, &jlo, &ns); tot += (size_t)ns; }
+	return tot;
+}
+
 template<int G, int C, bool DUAL, bool MP>
 K2A_FN int k2a_trace_pair(const uint8_t *tb, int i, int j, uint32_t *out, int qlen, int tlen, int w)
 {
@@ -357,10 +382,11 @@ K2A_FN int k2a_trace_pair(const uint8_t *tb, int i, int j, uint32_t *out, int ql
 	uint32_t last_op = 0xffffffffu, run = 0;
 	int gcur = -1, gjlo = 0;
 	size_t gbase = 0;
+	const size_t nsteps = k2a_tb_steps<G, C, MP>(qlen, tlen, w);
 	while (i >= 0 && j >= 0) {
 		const int S = i / C, c = i - S * C;
 		size_t word;
-		if (!MP) word = ((size_t)(S + j) * G + (S % G)) * WB;
+		if (!MP) word = k2a_tb_word((size_t)(S + j), S % G, nsteps, G, WB);
 		else {
 			const int g = S / G;
 			if (g != gcur) {                          /* (re)locate the generation: rare, the walk only moves up */
@@ -375,7 +401,7 @@ K2A_FN int k2a_trace_pair(const uint8_t *tb, int i, int j, uint32_t *out, int ql
 				gcur = g;
 			}
 			const int l = S - g * G;
-			word = ((gbase + (size_t)(j - gjlo + l)) * G + l) * WB;
+			word = k2a_tb_word(gbase + (size_t)(j - gjlo + l), l, nsteps, G, WB);
 		}
 		const uint32_t byte = tb[word + ((c * BITS) >> 3)];
 		const uint32_t raw = DUAL ? byte : ((byte >> ((c * BITS) & 7)) & 0xf);

@@ -15,6 +15,7 @@
 #include "ksw2_lane_pk.h"
 
 #define K2A_WPB 4          /* wavefronts per workgroup; waves never synchronise with each other */
+#define K2A_TRACE_PPW 8    /* alignments walked per wavefront by the traceback kernel */
 
 static thread_local char g_err[512] = "";
 
@@ -72,7 +73,8 @@ k2a_fill_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const ui
 #pragma unroll
 	for (int g = 1; g < NG; ++g) kmax = max(kmax, __builtin_amdgcn_readlane(klast, g * G));
 
-	uint8_t *tbp = tb + pr.tb_off + (size_t)gl * (Lane::TBWORDS * 4);
+	const size_t tbsteps = (size_t)(klast + 1);
+	uint8_t *tbp = tb + pr.tb_off;
 	bool gdone = !valid;
 	L.qb = L.next_query_code(-1);
 	/* the first strip of an alignment reads the virtual row -1 instead of a neighbour lane: steps 0..ktop only */
@@ -101,7 +103,7 @@ k2a_fill_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const ui
 		const bool live = L.step(sc, tabs + 8, wild, k, hin, ein, e2in, tw);
 		if (MODE != K2A_MODE_SCORE) {
 			if (live) {
-				uint32_t *dst = (uint32_t*)(tbp + (size_t)k * (G * Lane::TBWORDS * 4));
+				uint32_t *dst = (uint32_t*)(tbp + k2a_tb_word((size_t)k, gl, tbsteps, G, Lane::TBWORDS * 4));
 				if (Lane::TBWORDS == 1) dst[0] = tw[0];
 				else if (Lane::TBWORDS == 2) *(uint2*)dst = make_uint2(tw[0], tw[1]);
 				else {
@@ -257,7 +259,8 @@ k2a_fill_mp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	__builtin_amdgcn_wave_barrier();
 
 	int32_t *Bh = bnd + pr.bnd_off, *Be = Bh + pr.qlen, *Be2 = Be + pr.qlen;
-	uint8_t *tbp = tb + pr.tb_off + (size_t)gl * (Lane::TBWORDS * 4);
+	uint8_t *tbp = tb + pr.tb_off;
+	const size_t tbsteps = (MODE != K2A_MODE_SCORE && valid) ? k2a_tb_steps<G, C, true>(pr.qlen, pr.tlen, pr.w) : 0;
 	const int R = G * C;
 	const int ngen = valid ? (pr.tlen + R - 1) / R : 0;
 	size_t kbase = 0;
@@ -312,7 +315,7 @@ k2a_fill_mp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 			const bool live = L.step(sc, tabs + 8, wild, k, hin, ein, e2in, tw);
 			if (MODE != K2A_MODE_SCORE) {
 				if (live) {
-					uint32_t *dst = (uint32_t*)(tbp + (kbase + (size_t)k) * (G * Lane::TBWORDS * 4));
+					uint32_t *dst = (uint32_t*)(tbp + k2a_tb_word(kbase + (size_t)k, gl, tbsteps, G, Lane::TBWORDS * 4));
 					if (Lane::TBWORDS == 1) dst[0] = tw[0];
 					else if (Lane::TBWORDS == 2) *(uint2*)dst = make_uint2(tw[0], tw[1]);
 					else {
@@ -350,7 +353,10 @@ __global__ void __launch_bounds__(64)
 k2a_trace_kernel(const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
                  const uint8_t *__restrict__ tb, K2aResult *__restrict__ res, uint32_t *__restrict__ cig)
 {
-	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	/* the walk is a chain of dependent, scattered byte loads: a few walks per wavefront on many wavefronts beats
+	 * 64 walks whose loads serialise in one texture-address unit */
+	if (threadIdx.x >= K2A_TRACE_PPW) return;
+	const int t = blockIdx.x * K2A_TRACE_PPW + threadIdx.x;
 	if (t >= ntasks) return;
 	const uint32_t pi = order[t];
 	const K2aPair pr = pairs[pi];
@@ -483,7 +489,7 @@ int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_
 {
 	if (ntasks <= 0) return 0;
 	if (cfg < 0 || cfg >= K2A_NCFG) { snprintf(g_err, sizeof(g_err), "bad kernel class"); return -1; }
-	hipLaunchKernelGGL(g_trace[cfg][dual ? 1 : 0], dim3((ntasks + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+	hipLaunchKernelGGL(g_trace[cfg][dual ? 1 : 0], dim3((ntasks + K2A_TRACE_PPW - 1) / K2A_TRACE_PPW), dim3(64), 0, (hipStream_t)stream,
 	                   pairs, order, ntasks, tb, res, cig);
 	CHECK(hipGetLastError());
 	return 0;

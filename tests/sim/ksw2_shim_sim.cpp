@@ -48,7 +48,7 @@ static void sim_fill(const K2aScoring sc, const K2aPair *pairs, const uint32_t *
 			if (gl == 0) k2a_book_reset(&book[grp]);
 			klast[lane] = L[lane].last_step();
 			if (klast[lane] > kmax) kmax = klast[lane];
-			tbp[lane] = tb + pr[lane].tb_off + (size_t)gl * (Lane::TBWORDS * 4);
+			tbp[lane] = tb + pr[lane].tb_off;
 			gdone[lane] = !valid[lane];
 			L[lane].qb = L[lane].next_query_code(-1);
 			if (valid[lane]) {
@@ -75,7 +75,7 @@ static void sim_fill(const K2aScoring sc, const K2aPair *pairs, const uint32_t *
 				uint32_t tw[Lane::TBWORDS];
 				const bool live = L[lane].step(sc, tabs + 8, wild, k, hin[lane], ein[lane], e2in[lane], tw);
 				if (MODE != K2A_MODE_SCORE && live)
-					memcpy(tbp[lane] + (size_t)k * (G * Lane::TBWORDS * 4), tw, sizeof(tw));
+					memcpy(tbp[lane] + k2a_tb_word((size_t)k, lane % G, (size_t)(klast[lane] + 1), G, Lane::TBWORDS * 4), tw, sizeof(tw));
 				nfin[lane] = L[lane].need_fin(k);
 				anyfin |= nfin[lane];
 			}
@@ -217,6 +217,7 @@ static void sim_fill_mp(const K2aScoring sc, const K2aPair *pairs, const uint32_
 		size_t kbase = 0;
 		bool dropped = false;
 		const int ktop = k2a_min(pr.qlen - 1, k2a_min(C - 1, pr.tlen - 1) + pr.w);
+		const size_t tbsteps = k2a_tb_steps<G, C, true>(pr.qlen, pr.tlen, pr.w);
 		for (int g = 0; g < ngen && !dropped; ++g) {
 			int jlo, nsteps;
 			k2a_gen_cols<G, C>(g, pr.qlen, pr.tlen, pr.w, &jlo, &nsteps);
@@ -248,7 +249,7 @@ static void sim_fill_mp(const K2aScoring sc, const K2aPair *pairs, const uint32_
 					const bool mine = L[gl].S >= 0 && jj >= 0 && jj <= L[gl].je;
 					const bool live = L[gl].step(sc, tabs + 8, wild, k, hin[gl], ein[gl], e2in[gl], tw);
 					if (MODE != K2A_MODE_SCORE && live)
-						memcpy(tb + pr.tb_off + ((kbase + (size_t)k) * G + gl) * (Lane::TBWORDS * 4), tw, sizeof(tw));
+						memcpy(tb + pr.tb_off + k2a_tb_word(kbase + (size_t)k, gl, tbsteps, G, Lane::TBWORDS * 4), tw, sizeof(tw));
 					if (gl == G - 1 && mine) { Bh[jj] = L[gl].hout; Be[jj] = L[gl].eout; if (DUAL) Be2[jj] = L[gl].e2out; }
 					nfin[gl] = L[gl].need_fin(k);
 					anyfin |= nfin[gl];
