@@ -291,3 +291,30 @@ def test_cfg4_replicas_sharded_plan(lib):
     for r in res:
         assert (r["score"], r["max"], r["max_t"], r["max_q"]) == (16102, 17054, 16568, 16024)
         assert hashlib.md5((gu.cigar_string(r["cigar"]) + "\n").encode()).hexdigest()[:12] == "ea0524d904ed"
+
+
+def test_cli_matches_reference_cli(lib):
+    """tools/ksw2-test-amd against the reference's own ksw2-test (oracle/_ref, built from /root/reference/cli.c):
+    byte-identical stdout on config 1 (test/t1.fa x test/q1.fa) and on the MT pair, scalar algorithms and options."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ours, ref = os.path.join(root, "tools", "ksw2-test-amd"), os.path.join(root, "oracle", "_ref", "ksw2-test")
+    if not os.path.exists(ours):
+        subprocess.run(["make", "-C", os.path.join(root, "tools")], check=True, capture_output=True)
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/ksw2-test not built (needs /root/reference)")
+    d = os.path.join(root, "tests", "golden", "data")
+    t1, q1, mh, mo = (os.path.join(d, f) for f in ("t1.fa", "q1.fa", "MT-human.fa", "MT-orang.fa"))
+    runs = [(["-t", "extz"], t1, q1), (["-t", "extd"], t1, q1), (["-t", "extz", "-r"], t1, q1), (["-t", "extd", "-s"], t1, q1),
+            (["-t", "gg"], t1, q1), (["-t", "gg2"], t1, q1), (["-t", "extz", "-A1", "-B3", "-O5", "-E1"], t1, q1), (["-t", "extd", "-a"], t1, q1),
+            (["-t", "extz", "-w", "500"], mh, mo), (["-t", "extd", "-w", "500", "-r"], mh, mo), (["-t", "extz"], mh, mo), (["-t", "gg2", "-s"], mh, mo)]
+    for opts, t, q in runs:
+        a = subprocess.run([ours] + opts + [t, q], capture_output=True, text=True)
+        b = subprocess.run([ref] + opts + [t, q], capture_output=True, text=True)
+        assert a.returncode == 0, a.stderr
+        assert a.stdout == b.stdout, (opts, a.stdout[:300], b.stdout[:300])
+    # batched mode prints the same lines as the per-pair mode
+    a = subprocess.run([ours, "-t", "extz2_sse", "-b", t1, q1], capture_output=True, text=True)
+    b = subprocess.run([ours, "-t", "extz2_sse", t1, q1], capture_output=True, text=True)
+    assert a.returncode == 0 and a.stdout == b.stdout and a.stdout.count("\n") == 5
