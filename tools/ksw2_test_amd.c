@@ -98,7 +98,7 @@ static uint8_t *encode(const rec_t *r)
 int main(int argc, char *argv[])
 {
 	int8_t a = 2, b = 4, q = 4, e = 2, q2 = 13, e2 = 1, mat[25];
-	int c, i, w = -1, flag = 0, rep = 1, zdrop = -1, pair = 1, batch = 0;
+	int c, i, w = -1, flag = 0, rep = 1, zdrop = -1, pair = 1, batch = 0, njob = 0, *jobs = 0;
 	const char *algo = "extd";              /* cli.c:164 */
 	char *s;
 	recs_t T = {0, 0, 0}, Q = {0, 0, 0};
@@ -128,54 +128,58 @@ int main(int argc, char *argv[])
 	if (read_fasta(argv[optind], &T) < 0) push_rec(&T, "target", argv[optind], (int)strlen(argv[optind]));
 	if (read_fasta(argv[optind + 1], &Q) < 0) push_rec(&Q, "query", argv[optind + 1], (int)strlen(argv[optind + 1]));
 
+	/* alignment jobs in the reference's output order: lock-step pairs, or for every query all targets (cli.c:220-243) */
+	{
+		int j;
+		njob = 0;
+		jobs = (int*)malloc(sizeof(int) * 2 * ((size_t)T.n * (size_t)(pair ? 1 : Q.n) + 1));
+		if (pair) { for (i = 0; i < T.n && i < Q.n; ++i) { jobs[2 * njob] = i; jobs[2 * njob + 1] = i; ++njob; } }
+		else for (j = 0; j < Q.n; ++j) for (i = 0; i < T.n; ++i) { jobs[2 * njob] = i; jobs[2 * njob + 1] = j; ++njob; }
+	}
 	memset(&ez, 0, sizeof(ez));
 	if (batch && (strcmp(algo, "extz2_sse") == 0 || strcmp(algo, "extd2_sse") == 0)) {
 		const int dual = strcmp(algo, "extd2_sse") == 0;
-		const int n = pair ? (T.n < Q.n ? T.n : Q.n) : T.n * Q.n;
+		const int n = njob;
 		ksw2amd_pair_t *p = (ksw2amd_pair_t*)calloc((size_t)n + 1, sizeof(*p));
 		ksw_extz_t *res = (ksw_extz_t*)calloc((size_t)n + 1, sizeof(*res));
 		uint8_t **te = (uint8_t**)calloc((size_t)T.n + 1, sizeof(*te)), **qe = (uint8_t**)calloc((size_t)Q.n + 1, sizeof(*qe));
 		ksw2amd_scoring_t sc;
-		int k = 0, j, rc = 0;
+		int k, rc = 0;
 		for (i = 0; i < T.n; ++i) te[i] = encode(&T.a[i]);
 		for (i = 0; i < Q.n; ++i) qe[i] = encode(&Q.a[i]);
-		for (i = 0; i < T.n; ++i)
-			for (j = pair ? i : 0; j < (pair ? (i < Q.n ? i + 1 : 0) : Q.n); ++j, ++k) {
-				p[k].query = qe[j]; p[k].target = te[i]; p[k].qlen = Q.a[j].len; p[k].tlen = T.a[i].len;
-				p[k].w = w; p[k].zdrop = zdrop; p[k].end_bonus = 0; p[k].flag = flag;
-			}
+		for (k = 0; k < n; ++k) {
+			const int ti = jobs[2 * k], qj = jobs[2 * k + 1];
+			p[k].query = qe[qj]; p[k].target = te[ti]; p[k].qlen = Q.a[qj].len; p[k].tlen = T.a[ti].len;
+			p[k].w = w; p[k].zdrop = zdrop; p[k].end_bonus = 0; p[k].flag = flag;
+		}
 		sc.m = 5; sc.mat = mat; sc.q = q; sc.e = e; sc.q2 = q2; sc.e2 = e2;
 		for (i = 0; i < rep && rc == 0; ++i)
-			rc = dual ? ksw2amd_extd_batch(0, &sc, k, p, res) : ksw2amd_extz_batch(0, &sc, k, p, res);
+			rc = dual ? ksw2amd_extd_batch(0, &sc, n, p, res) : ksw2amd_extz_batch(0, &sc, n, p, res);
 		if (rc) { fprintf(stderr, "ERROR: %s\n", ksw2amd_last_error()); return 1; }
-		for (i = 0, k = 0; i < T.n; ++i)
-			for (j = pair ? i : 0; j < (pair ? (i < Q.n ? i + 1 : 0) : Q.n); ++j, ++k) print_aln(T.a[i].name, Q.a[j].name, &res[k]);
+		for (k = 0; k < n; ++k) print_aln(T.a[jobs[2 * k]].name, Q.a[jobs[2 * k + 1]].name, &res[k]);
 		return 0;
 	}
-	for (i = 0; i < T.n; ++i) {
-		int j, j0 = pair ? i : 0, j1 = pair ? (i < Q.n ? i + 1 : 0) : Q.n, r;
-		uint8_t *ts = encode(&T.a[i]);
-		for (j = j0; j < j1; ++j) {
-			uint8_t *qs = encode(&Q.a[j]);
-			const int ql = Q.a[j].len, tl = T.a[i].len;
-			for (r = 0; r < rep; ++r) {
-				/* cli.c:53-55 resets these per call; the callee resets the rest */
-				ez.max_q = ez.max_t = ez.mqe_t = ez.mte_q = -1; ez.max = 0; ez.mqe = ez.mte = KSW_NEG_INF; ez.n_cigar = 0;
-				if (strcmp(algo, "gg") == 0 || strcmp(algo, "gg2") == 0 || strcmp(algo, "gg2_sse") == 0) {
-					int (*f)(void*, int, const uint8_t*, int, const uint8_t*, int8_t, const int8_t*, int8_t, int8_t, int, int*, int*, uint32_t**) =
-						strcmp(algo, "gg") == 0 ? ksw_gg : strcmp(algo, "gg2") == 0 ? ksw_gg2 : ksw_gg2_sse;
-					if ((flag & KSW_EZ_SCORE_ONLY) && strcmp(algo, "gg2_sse") != 0) ez.score = f(0, ql, qs, tl, ts, 5, mat, q, e, w, 0, 0, 0);
-					else ez.score = f(0, ql, qs, tl, ts, 5, mat, q, e, w, &ez.m_cigar, &ez.n_cigar, &ez.cigar);
-				} else if (strcmp(algo, "extz") == 0) ksw_extz(0, ql, qs, tl, ts, 5, mat, q, e, w, zdrop, flag, &ez);
-				else if (strcmp(algo, "extz2_sse") == 0) ksw_extz2_sse(0, ql, qs, tl, ts, 5, mat, q, e, w, zdrop, 0, flag, &ez);
-				else if (strcmp(algo, "extd") == 0) ksw_extd(0, ql, qs, tl, ts, 5, mat, q, e, q2, e2, w, zdrop, flag, &ez);
-				else if (strcmp(algo, "extd2_sse") == 0) ksw_extd2_sse(0, ql, qs, tl, ts, 5, mat, q, e, q2, e2, w, zdrop, 0, flag, &ez);
-				else { fprintf(stderr, "ERROR: can't find algorithm '%s'\n", algo); return 1; }
-			}
-			print_aln(T.a[i].name, Q.a[j].name, &ez);
-			free(qs);
+	for (i = 0; i < njob; ++i) {
+		const rec_t *tr = &T.a[jobs[2 * i]], *qr = &Q.a[jobs[2 * i + 1]];
+		uint8_t *ts = encode(tr), *qs = encode(qr);
+		const int ql = qr->len, tl = tr->len;
+		int r;
+		for (r = 0; r < rep; ++r) {
+			/* cli.c:53-55 resets these per call; the callee resets the rest */
+			ez.max_q = ez.max_t = ez.mqe_t = ez.mte_q = -1; ez.max = 0; ez.mqe = ez.mte = KSW_NEG_INF; ez.n_cigar = 0;
+			if (strcmp(algo, "gg") == 0 || strcmp(algo, "gg2") == 0 || strcmp(algo, "gg2_sse") == 0) {
+				int (*f)(void*, int, const uint8_t*, int, const uint8_t*, int8_t, const int8_t*, int8_t, int8_t, int, int*, int*, uint32_t**) =
+					strcmp(algo, "gg") == 0 ? ksw_gg : strcmp(algo, "gg2") == 0 ? ksw_gg2 : ksw_gg2_sse;
+				if ((flag & KSW_EZ_SCORE_ONLY) && strcmp(algo, "gg2_sse") != 0) ez.score = f(0, ql, qs, tl, ts, 5, mat, q, e, w, 0, 0, 0);
+				else ez.score = f(0, ql, qs, tl, ts, 5, mat, q, e, w, &ez.m_cigar, &ez.n_cigar, &ez.cigar);
+			} else if (strcmp(algo, "extz") == 0) ksw_extz(0, ql, qs, tl, ts, 5, mat, q, e, w, zdrop, flag, &ez);
+			else if (strcmp(algo, "extz2_sse") == 0) ksw_extz2_sse(0, ql, qs, tl, ts, 5, mat, q, e, w, zdrop, 0, flag, &ez);
+			else if (strcmp(algo, "extd") == 0) ksw_extd(0, ql, qs, tl, ts, 5, mat, q, e, q2, e2, w, zdrop, flag, &ez);
+			else if (strcmp(algo, "extd2_sse") == 0) ksw_extd2_sse(0, ql, qs, tl, ts, 5, mat, q, e, q2, e2, w, zdrop, 0, flag, &ez);
+			else { fprintf(stderr, "ERROR: can't find algorithm '%s'\n", algo); return 1; }
 		}
-		free(ts);
+		print_aln(tr->name, qr->name, &ez);
+		free(qs); free(ts);
 	}
 	free(ez.cigar);
 	return 0;
