@@ -293,28 +293,17 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 		p->h_cls[i] = (int8_t)ci;
 		p->cells += band_cells(a->qlen, a->tlen, w);
 		if (pkinfo[generic].ok < 0) pk_scoring(dual, m, sc->mat, q, e, q2, e2, generic, &pkinfo[generic]);
-		if (use_pk && mode == K2A_MODE_SCORE && pk_eligible(&pkinfo[generic], a->qlen, d->tlen, w) &&
+		if (use_pk && pk_eligible(&pkinfo[generic], a->qlen, d->tlen, w) &&
 		    !has_wildcard(a->query, a->qlen) && !has_wildcard(a->target, a->tlen)) {
 			int pc;                                            /* packed class: first geometry that holds the band, 1-based */
-			for (pc = 0; pc < K2A_NPKCFG; ++pc) if (geom_fits(k2a_pkcfg_G[pc], k2a_pkcfg_C[pc], d->tlen, w)) break;
+			/* (8 lanes x 20 rows) needs every register with traceback on: score-only pairs only */
+			for (pc = (mode == K2A_MODE_SCORE ? 0 : 1); pc < K2A_NPKCFG; ++pc) if (geom_fits(k2a_pkcfg_G[pc], k2a_pkcfg_C[pc], d->tlen, w)) break;
 			if (pc < K2A_NPKCFG) pk_ok[i] = (uint8_t)(1 + pc);
 		}
 		if (cfg == K2A_CFG_MP) {                              /* boundary rows H, E, E~ between generations */
 			d->bnd_off = (uint32_t)p->bnd_words;
 			p->bnd_words += 3 * (size_t)a->qlen + 16;
 			if (p->bnd_words > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "plan_create: boundary rows over 16 GiB in one plan%s", 0); goto err; }
-		}
-		if (mode != K2A_MODE_SCORE) {                          /* traceback block and CIGAR scratch */
-			const int G = k2a_cfg_G[cfg], C = k2a_cfg_C[cfg];
-			const int nstrips = (d->tlen + C - 1) / C;
-			size_t steps = (size_t)(nstrips - 1) + (size_t)imin(a->qlen - 1, d->tlen - 1 + w) + 1;
-			const size_t wb = (size_t)C * (dual ? 8 : 4) / 8;
-			if (cfg == K2A_CFG_MP) steps = mp_total_steps(G, C, a->qlen, d->tlen, w);
-			d->tb_off = p->tb_bytes;
-			p->tb_bytes += align_up(steps * G * wb, 256);
-			d->cig_off = (uint32_t)p->cig_words;
-			p->cig_words += (size_t)a->qlen + a->tlen + 2;
-			if (p->cig_words > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "plan_create: CIGAR scratch over 16 GiB in one plan%s", 0); goto err; }
 		}
 	}
 
@@ -371,6 +360,19 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 			off = align_up(off, 4); da->qoff = db->qoff = (uint32_t)off; off += mul * (size_t)da->qlen;
 			off = align_up(off, 16); da->toff = db->toff = (uint32_t)off; off += mul * (size_t)da->tlen_full + 64;
 			if (off > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "plan_create: more than 4 GiB of sequence in one plan%s", 0); goto err; }
+			if (c->mode != K2A_MODE_SCORE) {                   /* traceback block (shared by a packed task) and CIGAR scratch */
+				const int G = c->pk ? k2a_pkcfg_G[c->cfg] : k2a_cfg_G[c->cfg], C = c->pk ? k2a_pkcfg_C[c->cfg] : k2a_cfg_C[c->cfg];
+				const int nstrips = (da->tlen + C - 1) / C;
+				size_t steps = (size_t)(nstrips - 1) + (size_t)imin(da->qlen - 1, da->tlen - 1 + da->w) + 1;
+				const size_t wb = c->pk ? 2 * (size_t)C : (size_t)C * (dual ? 8 : 4) / 8;
+				if (!c->pk && c->cfg == K2A_CFG_MP) steps = mp_total_steps(G, C, da->qlen, da->tlen, da->w);
+				da->tb_off = db->tb_off = p->tb_bytes;
+				p->tb_bytes += align_up(steps * G * wb, 256);
+				da->cig_off = (uint32_t)p->cig_words;
+				p->cig_words += (size_t)da->qlen + da->tlen_full + 2;
+				if (ib != ia) { db->cig_off = (uint32_t)p->cig_words; p->cig_words += (size_t)db->qlen + db->tlen_full + 2; }
+				if (p->cig_words > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "plan_create: CIGAR scratch over 16 GiB in one plan%s", 0); goto err; }
+			}
 		}
 	}
 	p->seq_bytes = align_up(off + 65536, 256);      /* idle lanes may prefetch codes a few hundred bytes past the last pair */
@@ -431,7 +433,8 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 	for (c = 0; c < p->ncls; ++c) {
 		const cls_t *k = &p->cls[c];
 		if (k->pk) {
-			if (k2a_shim_launch_fill_pk(k->cfg, p->dual, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_res, stream)) goto err;
+			if (k2a_shim_launch_fill_pk(k->cfg, p->dual, k->mode, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
+			                            p->d_res, stream)) goto err;
 		} else if (k2a_shim_launch_fill(k->cfg, p->dual, k->mode, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
 		                                p->d_bnd, p->d_res, stream)) goto err;
 	}
@@ -439,7 +442,9 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 	for (c = 0; c < p->ncls; ++c) {
 		const cls_t *k = &p->cls[c];
 		if (k->mode == K2A_MODE_SCORE) continue;
-		if (k2a_shim_launch_trace(k->cfg, p->dual, p->d_pairs, p->d_order + k->first, k->count, p->d_tb, p->d_res, p->d_cig, stream)) goto err;
+		if (k->pk) {
+			if (k2a_shim_launch_trace_pk(k->cfg, p->d_pairs, p->d_order + k->first, k->count, p->d_tb, p->d_res, p->d_cig, stream)) goto err;
+		} else if (k2a_shim_launch_trace(k->cfg, p->dual, p->d_pairs, p->d_order + k->first, k->count, p->d_tb, p->d_res, p->d_cig, stream)) goto err;
 	}
 	if (k2a_shim_event_record(p->ev[2], stream)) goto err;
 	return KSW2AMD_OK;

@@ -54,6 +54,10 @@ K2A_FN k2a_pk k2a_spread16(uint32_t v)  /* bytes {b0,b1,..} -> halves {b0, b1} *
 	return __builtin_amdgcn_perm(0u, v, 0x0c010c00u);
 }
 K2A_FN k2a_pk k2a_bit_mask(uint32_t bits, int c) { return (k2a_pk)__builtin_amdgcn_sbfe((int)bits, c, 1); }
+K2A_FN uint32_t k2a_pack_dirs(k2a_pk d0, k2a_pk d1)   /* low bytes of the four halves -> one word */
+{
+	return __builtin_amdgcn_perm(d1, d0, 0x06040200u);
+}
 #define K2A_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
 #define K2A_SCHED_FENCE() do {} while (0)
@@ -70,10 +74,18 @@ K2A_FN k2a_pk k2a_pk_mad(k2a_pk a, k2a_pk b, k2a_pk c) { return k2a_pk_mk(k2a_pk
 K2A_FN k2a_pk k2a_pk_sign(k2a_pk a) { return ((a & 0x8000u) ? 0xffffu : 0u) | ((a & 0x80000000u) ? 0xffff0000u : 0u); }
 K2A_FN k2a_pk k2a_spread16(uint32_t v) { return (v & 0xffu) | ((v & 0xff00u) << 8); }
 K2A_FN k2a_pk k2a_bit_mask(uint32_t bits, int c) { return ((bits >> c) & 1u) ? 0xffffffffu : 0u; }
+K2A_FN uint32_t k2a_pack_dirs(k2a_pk d0, k2a_pk d1)
+{
+	return (d0 & 0xffu) | ((d0 >> 16 & 0xffu) << 8) | ((d1 & 0xffu) << 16) | ((d1 >> 16 & 0xffu) << 24);
+}
 #endif
 
-template<int G, int C, bool DUAL>
+/* packed traceback: one byte per cell and alignment in the reference's own layout (ksw2.h:125-128): bits 0-2 winner
+ * {0 diag, 1 E, 2 F, 3 E~, 4 F~}, 0x08/0x10/0x20/0x40 = the E/F/E~/F~ gap leaving the cell is an extension.
+ * A lane-step word holds C cells x 2 alignments: byte 2c = alignment A, byte 2c+1 = alignment B. */
+template<int G, int C, bool DUAL, int MODE = K2A_MODE_SCORE>
 struct K2aLanePk {
+	enum { TBWORDS = C / 2 };
 	/* group-uniform (both alignments share the shape) */
 	int qlen, tlen, tlen_full, w, nstrips;
 	const uint8_t *qi, *ti;            /* byte-interleaved sequences: x[2p] = code of A, x[2p+1] = code of B */
@@ -164,8 +176,11 @@ struct K2aLanePk {
 
 	/* One column for the C rows of both alignments.  hin/ein/e2in = bottom row of the strip above at this column.
 	 * Phase 1 forms every row's diagonal candidate H(i-1,j-1) + s(i,j) while the old H row is still intact, phase 2 runs
-	 * the E chain down the rows and writes the new H row in place (no register shuffling at the loop back-edge). */
-	K2A_FN void step(const K2aScoring &sc, int k, k2a_pk hin, k2a_pk ein, k2a_pk e2in)
+	 * the E chain down the rows and writes the new H row in place (no register shuffling at the loop back-edge).
+	 * With MODE != SCORE every comparison of the reference's direction logic (ksw2_extz.c:72-86 / 98-112, ksw2_extd.c:88-114 /
+	 * 126-152) becomes sign(difference) in packed arithmetic; tbw receives C/2 words of direction bytes.
+	 * Returns true when the lane computed live cells. */
+	K2A_FN bool step(const K2aScoring &sc, int k, k2a_pk hin, k2a_pk ein, k2a_pk e2in, uint32_t *tbw)
 	{
 		const int dd = k - kd;                                 /* jj - i0 */
 		const k2a_pk neg = k2a_pk2(K2A_NEG16);
@@ -187,28 +202,68 @@ struct K2aLanePk {
 			const k2a_pk ne01 = k2a_pk_minu(tc[c] ^ qcode, 0x00010001u);
 			cand[c] = k2a_pk_add(c == 0 ? hd0 : hl[c - 1], k2a_pk_mad(ne01, mat_bma, mat_a));
 		}
+		k2a_pk dprev = 0;
 #pragma unroll
 		for (int c = 0; c < C; ++c) {
 			const k2a_pk fc = f[c];
-			k2a_pk h = k2a_pk_max(k2a_pk_max(cand[c], e), fc);
-			if (DUAL) h = k2a_pk_max(k2a_pk_max(h, e2), f2[c]);
+			k2a_pk h = cand[c], d = 0;
+			if (MODE == K2A_MODE_SCORE) {
+				h = k2a_pk_max(k2a_pk_max(h, e), fc);
+				if (DUAL) h = k2a_pk_max(k2a_pk_max(h, e2), f2[c]);
+			} else if (MODE == K2A_MODE_LEFT) {            /* winner changes only on a strictly larger gap state */
+				d = k2a_pk_sign(k2a_pk_sub(h, e)) & 0x00010001u;                     h = k2a_pk_max(h, e);
+				d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, fc)), 0x00020002u, d);      h = k2a_pk_max(h, fc);
+				if (DUAL) {
+					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, e2)), 0x00030003u, d);    h = k2a_pk_max(h, e2);
+					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, f2[c])), 0x00040004u, d); h = k2a_pk_max(h, f2[c]);
+				}
+			} else {                                       /* right-aligned: a tie already moves to the gap state */
+				d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e, h)), 0u, 0x00010001u);      h = k2a_pk_max(h, e);
+				d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(fc, h)), d, 0x00020002u);      h = k2a_pk_max(h, fc);
+				if (DUAL) {
+					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e2, h)), d, 0x00030003u);    h = k2a_pk_max(h, e2);
+					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(f2[c], h)), d, 0x00040004u); h = k2a_pk_max(h, f2[c]);
+				}
+			}
 			h = k2a_pk_sel(k2a_bit_mask(live, c), h, neg);
-			/* running row maximum, ties to the last column: keep the old arg-max only where h < max */
-			const k2a_pk keep = k2a_pk_sign(k2a_pk_sub(h, rmax[c]));
-			rmj[c] = k2a_pk_sel(keep, rmj[c], jjpk);
+			/* running row maximum: ties to the last column (keep the old arg-max only where h < max), except
+			 * extz + RIGHT + CIGAR where the first column wins (take the new one only where max < h); SURVEY 8a rule 3 */
+			if (!DUAL && MODE == K2A_MODE_RIGHT) rmj[c] = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(rmax[c], h)), jjpk, rmj[c]);
+			else rmj[c] = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, rmax[c])), rmj[c], jjpk);
 			rmax[c] = k2a_pk_max(rmax[c], h);
 			const k2a_pk t = k2a_pk_sub(h, qe);
-			e = k2a_pk_max(k2a_pk_sub(e, ge), t);
-			f[c] = k2a_pk_max(k2a_pk_sub(fc, ge), t);
+			const k2a_pk ex = k2a_pk_sub(e, ge), fx = k2a_pk_sub(fc, ge);
+			if (MODE == K2A_MODE_LEFT) {                   /* extension strictly better than opening */
+				d |= k2a_pk_sign(k2a_pk_sub(t, ex)) & 0x00080008u;
+				d |= k2a_pk_sign(k2a_pk_sub(t, fx)) & 0x00100010u;
+			} else if (MODE == K2A_MODE_RIGHT) {           /* extension at least as good as opening */
+				d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(ex, t)), 0u, 0x00080008u);
+				d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(fx, t)), 0u, 0x00100010u);
+			}
+			e = k2a_pk_max(ex, t);
+			f[c] = k2a_pk_max(fx, t);
 			if (DUAL) {
 				const k2a_pk t2 = k2a_pk_sub(h, qe2);
-				e2 = k2a_pk_max(k2a_pk_sub(e2, ge2), t2);
-				f2[c] = k2a_pk_max(k2a_pk_sub(f2[c], ge2), t2);
+				const k2a_pk ex2 = k2a_pk_sub(e2, ge2), fx2 = k2a_pk_sub(f2[c], ge2);
+				if (MODE == K2A_MODE_LEFT) {
+					d |= k2a_pk_sign(k2a_pk_sub(t2, ex2)) & 0x00200020u;
+					d |= k2a_pk_sign(k2a_pk_sub(t2, fx2)) & 0x00400040u;
+				} else if (MODE == K2A_MODE_RIGHT) {
+					d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(ex2, t2)), 0u, 0x00200020u);
+					d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(fx2, t2)), 0u, 0x00400040u);
+				}
+				e2 = k2a_pk_max(ex2, t2);
+				f2[c] = k2a_pk_max(fx2, t2);
+			}
+			if (MODE != K2A_MODE_SCORE) {
+				if (c & 1) tbw[c >> 1] = k2a_pack_dirs(dprev, d);    /* bytes {A(c-1), B(c-1), A(c), B(c)} */
+				else dprev = d;
 			}
 			hl[c] = h;
 		}
 		hd0 = hin;
 		hout = hl[C - 1]; eout = e; e2out = e2;
+		return live != 0;
 	}
 
 	/* query codes of the column this lane sees at step k+1; idle lanes read a clamped (valid, unused) column */
@@ -299,6 +354,40 @@ struct K2aLanePk {
 		S = -1; je = -1; kfin = K2A_KNONE; rows_m1 = -1;
 	}
 };
+
+/* Traceback walk for one alignment (half = 0/1) of a packed task: same state machine as k2a_trace_pair, direction
+ * bytes in the reference layout at byte 2c + half of the (step, lane) word. */
+template<int G, int C>
+K2A_FN int k2a_trace_pair_pk(const uint8_t *tb, int half, int i, int j, uint32_t *out, int qlen, int tlen, int w)
+{
+	enum { WB = 2 * C };
+	int n = 0, state = 0;
+	uint32_t last_op = 0xffffffffu, run = 0;
+	const size_t nsteps = k2a_tb_steps<G, C, false>(qlen, tlen, w);
+	while (i >= 0 && j >= 0) {
+		const int S = i / C, c = i - S * C;
+		const uint32_t d = tb[k2a_tb_word((size_t)(S + j), S % G, nsteps, G, WB) + 2 * c + half];
+		if (state == 0) state = d & 7;
+		else if (!((d >> (state + 2)) & 1)) state = 0;
+		if (state == 0) state = d & 7;
+		uint32_t op;
+		if (state == 0) { op = 0; --i; --j; }
+		else if (state == 1 || state == 3) { op = 2; --i; }
+		else { op = 1; --j; }
+		if (op == last_op) ++run;
+		else { if (run) out[n++] = run << 4 | last_op; last_op = op; run = 1; }
+	}
+	if (i >= 0) {
+		if (last_op == 2) run += i + 1;
+		else { if (run) out[n++] = run << 4 | last_op; last_op = 2; run = i + 1; }
+	}
+	if (j >= 0) {
+		if (last_op == 1) run += j + 1;
+		else { if (run) out[n++] = run << 4 | last_op; last_op = 1; run = j + 1; }
+	}
+	if (run) out[n++] = run << 4 | last_op;
+	return n;
+}
 
 /* merge the lane-local bests of one alignment (half = 0/1) of a lane group: loc[l*5 + {0..4}] = lane l's
  * {lmax, lmax_t, lmax_q, lmqe, lmqe_t}.  Ties go to the smaller row, as in the sequential scan. */

@@ -59,11 +59,14 @@ int k2a_shim_launch_fill(int cfg, int dual, int mode, const K2aScoring *sc, cons
 int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb,
                           K2aResult *res, uint32_t *cig, void *stream);
 
-/* Packed-int16 fill (score-only): ntasks tasks of TWO same-shape alignments each, order2[2t], order2[2t+1] = their
- * indices (equal for an unpaired leftover); both K2aPair entries point at the task's byte-interleaved sequences.
- * cfg indexes the k2a_pkcfg_* table. */
-int k2a_shim_launch_fill_pk(int cfg, int dual, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2, int ntasks,
-                            const uint8_t *seq, K2aResult *res, void *stream);
+/* Packed-int16 fill: ntasks tasks of TWO same-shape alignments each, order2[2t], order2[2t+1] = their indices (equal
+ * for an unpaired leftover); both K2aPair entries point at the task's byte-interleaved sequences and, with
+ * mode != SCORE, at the task's shared traceback block (2*C bytes per lane-step).  cfg indexes the k2a_pkcfg_* table.
+ * The packed trace kernel walks 2*ntasks alignments of such a launch. */
+int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2, int ntasks,
+                            const uint8_t *seq, uint8_t *tb, K2aResult *res, void *stream);
+int k2a_shim_launch_trace_pk(int cfg, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb,
+                             K2aResult *res, uint32_t *cig, void *stream);
 
 /* Compaction: pool[pos[i] .. pos[i]+res[i].n_cigar) = cig[pairs[i].cig_off ..) for the n pairs of a plan
  * (pos = exclusive prefix sum of n_cigar, computed by the host), so that one D2H brings every CIGAR back. */

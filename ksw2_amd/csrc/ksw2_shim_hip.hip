@@ -131,14 +131,14 @@ k2a_fill_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const ui
 	}
 }
 
-/* Packed-int16 resident fill, score-only: two same-shape alignments per lane group (ksw2_lane_pk.h). */
-template<int G, int C, bool DUAL>
+/* Packed-int16 resident fill: two same-shape alignments per lane group (ksw2_lane_pk.h). */
+template<int G, int C, bool DUAL, int MODE>
 __global__ void __launch_bounds__(64 * K2A_WPB)      /* no occupancy floor: capping at 168 VGPRs spills and is 18 % slower */
 k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
-                   const uint8_t *__restrict__ seq, K2aResult *__restrict__ res)
+                   const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, K2aResult *__restrict__ res)
 {
 	constexpr int NG = 64 / G;
-	typedef K2aLanePk<G, C, DUAL> Lane;
+	typedef K2aLanePk<G, C, DUAL, MODE> Lane;
 	__shared__ K2aBook book[K2A_WPB][NG][2];
 	__shared__ uint32_t stage[K2A_WPB][(NG * 3 * C > 64 * 5) ? NG * 3 * C : 64 * 5];   /* row buffers / final lane records */
 
@@ -171,6 +171,8 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 
 	bool gdone = !valid;
 	L.qb = L.next_query_codes(-1);
+	const size_t tbsteps = (size_t)(klast + 1);
+	uint8_t *tbp = tb + prA.tb_off;
 
 	for (int k = 0; k <= kmax; ++k) {
 		k2a_pk hin = (k2a_pk)k2a_rot1<G>((int)L.hout);
@@ -185,7 +187,16 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 		const uint32_t qnext = L.next_query_codes(k);
 		if (k <= ktop) L.top_inputs(sc, k, hin, ein, e2in);
 
-		L.step(sc, k, hin, ein, e2in);
+		uint32_t tw[Lane::TBWORDS];
+		const bool live = L.step(sc, k, hin, ein, e2in, tw);
+		if (MODE != K2A_MODE_SCORE) {
+			if (live) {
+				uint32_t *dst = (uint32_t*)(tbp + k2a_tb_word((size_t)k, gl, tbsteps, G, Lane::TBWORDS * 4));
+#pragma unroll
+				for (int x = 0; x + 3 < Lane::TBWORDS; x += 4) *(uint4*)(dst + x) = make_uint4(tw[x], tw[x + 1], tw[x + 2], tw[x + 3]);
+				if (Lane::TBWORDS & 2) *(uint2*)(dst + (Lane::TBWORDS & ~3)) = make_uint2(tw[Lane::TBWORDS & ~3], tw[(Lane::TBWORDS & ~3) + 1]);
+			}
+		}
 
 		const bool nfin = L.need_fin(k);
 		if (__builtin_amdgcn_ballot_w64(nfin) != 0) {
@@ -394,6 +405,33 @@ static const fill_mp_fn g_fill_mp[2][3] = {
 static const trace_fn g_trace[K2A_NCFG][2] = { TRACE_ROW(16, 8, false), TRACE_ROW(64, 8, false), TRACE_ROW(64, 16, false),
                                                TRACE_ROW(64, 32, false), TRACE_ROW(64, 16, true) };
 
+/* packed walk: thread t = alignment (t & 1) of task (t >> 1) */
+template<int G, int C>
+__global__ void __launch_bounds__(64)
+k2a_trace_pk_kernel(const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
+                    const uint8_t *__restrict__ tb, K2aResult *__restrict__ res, uint32_t *__restrict__ cig)
+{
+	if (threadIdx.x >= K2A_TRACE_PPW) return;
+	const int t = blockIdx.x * K2A_TRACE_PPW + threadIdx.x;
+	if (t >= 2 * ntasks) return;
+	const int half = t & 1;
+	const uint32_t piA = order2[t & ~1], pi = order2[t];
+	if (half && pi == piA) return;                    /* unpaired leftover: the task holds one alignment */
+	const K2aPair pr = pairs[pi];
+	const int ti = res[pi].ti, tj = res[pi].tj;
+	int n = 0;
+	if (ti >= 0 && tj >= 0) n = k2a_trace_pair_pk<G, C>(tb + pr.tb_off, half, ti, tj, cig + pr.cig_off, pr.qlen, pr.tlen, pr.w);
+	res[pi].n_cigar = n;
+}
+
+typedef void (*fill_pk_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*);
+#define PK_ROW(G, C) { { k2a_fill_pk_kernel<G, C, false, 0>, k2a_fill_pk_kernel<G, C, false, 1>, k2a_fill_pk_kernel<G, C, false, 2> }, \
+                       { k2a_fill_pk_kernel<G, C, true, 0>,  k2a_fill_pk_kernel<G, C, true, 1>,  k2a_fill_pk_kernel<G, C, true, 2> } }
+static const fill_pk_fn g_fill_pk[K2A_NPKCFG][2][3] = { PK_ROW(8, 20), PK_ROW(16, 8), PK_ROW(64, 8), PK_ROW(64, 16) };
+static const trace_fn g_trace_pk[K2A_NPKCFG] = { k2a_trace_pk_kernel<8, 20>, k2a_trace_pk_kernel<16, 8>, k2a_trace_pk_kernel<64, 8>,
+                                                 k2a_trace_pk_kernel<64, 16> };
+
+
 extern "C" {
 
 const char *k2a_shim_backend(void) { return "hip:gfx950"; }
@@ -495,21 +533,26 @@ int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_
 	return 0;
 }
 
-typedef void (*fill_pk_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, K2aResult*);
-static const fill_pk_fn g_fill_pk[K2A_NPKCFG][2] = { { k2a_fill_pk_kernel<8, 20, false>, k2a_fill_pk_kernel<8, 20, true> },
-                                                     { k2a_fill_pk_kernel<16, 8, false>, k2a_fill_pk_kernel<16, 8, true> },
-                                                     { k2a_fill_pk_kernel<64, 8, false>, k2a_fill_pk_kernel<64, 8, true> },
-                                                     { k2a_fill_pk_kernel<64, 16, false>, k2a_fill_pk_kernel<64, 16, true> } };
+int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2, int ntasks,
+                            const uint8_t *seq, uint8_t *tb, K2aResult *res, void *stream)
+{
+	if (ntasks <= 0) return 0;
+	if (cfg < 0 || cfg >= K2A_NPKCFG || mode < 0 || mode > 2) { snprintf(g_err, sizeof(g_err), "bad packed kernel class"); return -1; }
+	const int per_block = K2A_WPB * (64 / k2a_pkcfg_G[cfg]);
+	const int blocks = (ntasks + per_block - 1) / per_block;
+	hipLaunchKernelGGL(g_fill_pk[cfg][dual ? 1 : 0][mode], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
+	                   *sc, pairs, order2, ntasks, seq, tb, res);
+	CHECK(hipGetLastError());
+	return 0;
+}
 
-int k2a_shim_launch_fill_pk(int cfg, int dual, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2, int ntasks,
-                            const uint8_t *seq, K2aResult *res, void *stream)
+int k2a_shim_launch_trace_pk(int cfg, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb,
+                             K2aResult *res, uint32_t *cig, void *stream)
 {
 	if (ntasks <= 0) return 0;
 	if (cfg < 0 || cfg >= K2A_NPKCFG) { snprintf(g_err, sizeof(g_err), "bad packed kernel class"); return -1; }
-	const int per_block = K2A_WPB * (64 / k2a_pkcfg_G[cfg]);
-	const int blocks = (ntasks + per_block - 1) / per_block;
-	hipLaunchKernelGGL(g_fill_pk[cfg][dual ? 1 : 0], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
-	                   *sc, pairs, order2, ntasks, seq, res);
+	hipLaunchKernelGGL(g_trace_pk[cfg], dim3((2 * ntasks + K2A_TRACE_PPW - 1) / K2A_TRACE_PPW), dim3(64), 0, (hipStream_t)stream,
+	                   pairs, order2, ntasks, tb, res, cig);
 	CHECK(hipGetLastError());
 	return 0;
 }

@@ -98,11 +98,12 @@ static void sim_fill(const K2aScoring sc, const K2aPair *pairs, const uint32_t *
 }
 
 /* mirrors k2a_fill_pk_kernel */
-template<int G, int C, bool DUAL>
-static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *seq, K2aResult *res)
+template<int G, int C, bool DUAL, int MODE>
+static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *seq, uint8_t *tb,
+                        K2aResult *res)
 {
 	constexpr int NG = 64 / G;
-	typedef K2aLanePk<G, C, DUAL> Lane;
+	typedef K2aLanePk<G, C, DUAL, MODE> Lane;
 	const int nwaves = (ntasks + NG - 1) / NG;
 	for (int wv = 0; wv < nwaves; ++wv) {
 		static Lane L[64];
@@ -144,7 +145,10 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 				if (k <= ktop) L[lane].top_inputs(sc, k, hin[lane], ein[lane], e2in[lane]);
 			}
 			for (int lane = 0; lane < 64; ++lane) {
-				L[lane].step(sc, k, hin[lane], ein[lane], e2in[lane]);
+				uint32_t tw[Lane::TBWORDS];
+				const bool live = L[lane].step(sc, k, hin[lane], ein[lane], e2in[lane], tw);
+				if (MODE != K2A_MODE_SCORE && live)
+					memcpy(tb + prA[lane].tb_off + k2a_tb_word((size_t)k, lane % G, (size_t)(klast[lane] + 1), G, Lane::TBWORDS * 4), tw, sizeof(tw));
 				nfin[lane] = L[lane].need_fin(k);
 				anyfin |= nfin[lane];
 			}
@@ -293,6 +297,27 @@ static const fill_mp_fn g_fill_mp[2][3] = {
 static const trace_fn g_trace[K2A_NCFG][2] = { TRACE_ROW(16, 8, false), TRACE_ROW(64, 8, false), TRACE_ROW(64, 16, false),
                                                TRACE_ROW(64, 32, false), TRACE_ROW(64, 16, true) };
 
+template<int G, int C>
+static void sim_trace_pk(const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb, K2aResult *res, uint32_t *cig)
+{
+	for (int t = 0; t < 2 * ntasks; ++t) {
+		const int half = t & 1;
+		const uint32_t piA = order2[t & ~1], pi = order2[t];
+		if (half && pi == piA) continue;
+		const K2aPair pr = pairs[pi];
+		int n = 0;
+		if (res[pi].ti >= 0 && res[pi].tj >= 0)
+			n = k2a_trace_pair_pk<G, C>(tb + pr.tb_off, half, res[pi].ti, res[pi].tj, cig + pr.cig_off, pr.qlen, pr.tlen, pr.w);
+		res[pi].n_cigar = n;
+	}
+}
+
+typedef void (*fill_pk_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*);
+#define PK_ROW(G, C) { { sim_fill_pk<G, C, false, 0>, sim_fill_pk<G, C, false, 1>, sim_fill_pk<G, C, false, 2> }, \
+                       { sim_fill_pk<G, C, true, 0>,  sim_fill_pk<G, C, true, 1>,  sim_fill_pk<G, C, true, 2> } }
+static const fill_pk_fn g_fill_pk[K2A_NPKCFG][2][3] = { PK_ROW(8, 20), PK_ROW(16, 8), PK_ROW(64, 8), PK_ROW(64, 16) };
+static const trace_fn g_trace_pk[K2A_NPKCFG] = { sim_trace_pk<8, 20>, sim_trace_pk<16, 8>, sim_trace_pk<64, 8>, sim_trace_pk<64, 16> };
+
 extern "C" {
 
 const char *k2a_shim_backend(void) { return "sim"; }
@@ -327,15 +352,16 @@ int k2a_shim_launch_fill(int cfg, int dual, int mode, const K2aScoring *sc, cons
 	else g_fill[cfg][dual ? 1 : 0][mode](*sc, pairs, order, ntasks, seq, tb, res);
 	return 0;
 }
-typedef void (*fill_pk_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, K2aResult*);
-static const fill_pk_fn g_fill_pk[K2A_NPKCFG][2] = { { sim_fill_pk<8, 20, false>, sim_fill_pk<8, 20, true> },
-                                                     { sim_fill_pk<16, 8, false>, sim_fill_pk<16, 8, true> },
-                                                     { sim_fill_pk<64, 8, false>, sim_fill_pk<64, 8, true> },
-                                                     { sim_fill_pk<64, 16, false>, sim_fill_pk<64, 16, true> } };
-int k2a_shim_launch_fill_pk(int cfg, int dual, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2, int ntasks,
-                            const uint8_t *seq, K2aResult *res, void *)
+int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2, int ntasks,
+                            const uint8_t *seq, uint8_t *tb, K2aResult *res, void *)
 {
-	if (ntasks > 0) g_fill_pk[cfg][dual ? 1 : 0](*sc, pairs, order2, ntasks, seq, res);
+	if (ntasks > 0) g_fill_pk[cfg][dual ? 1 : 0][mode](*sc, pairs, order2, ntasks, seq, tb, res);
+	return 0;
+}
+int k2a_shim_launch_trace_pk(int cfg, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb,
+                             K2aResult *res, uint32_t *cig, void *)
+{
+	if (ntasks > 0) g_trace_pk[cfg](pairs, order2, ntasks, tb, res, cig);
 	return 0;
 }
 int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb,
