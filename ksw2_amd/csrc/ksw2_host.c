@@ -82,6 +82,7 @@ struct ksw2amd_plan_s {
 	int m;
 	K2aPair *h_pairs;
 	int8_t *h_cls;                 /* class index per pair, -1 = rejected before the device */
+	uint8_t *h_half;               /* 0 = own sequence copy, 1 / 2 = alignment A / B of a packed task (interleaved copy) */
 	int32_t *h_flag;               /* caller's flag per pair */
 	uint32_t *h_order;
 	int ntasks;
@@ -221,7 +222,7 @@ void ksw2amd_plan_destroy(ksw2amd_plan_t *p)
 	k2a_shim_free(p->d_seq); k2a_shim_free(p->d_tb); k2a_shim_free(p->d_pairs); k2a_shim_free(p->d_res);
 	k2a_shim_free(p->d_order); k2a_shim_free(p->d_cig); k2a_shim_free(p->d_bnd);
 	for (i = 0; i < 3; ++i) if (p->ev[i]) k2a_shim_event_destroy(p->ev[i]);
-	free(p->h_pairs); free(p->h_cls); free(p->h_flag); free(p->h_order); free(p->h_seq); free(p->h_res);
+	free(p->h_pairs); free(p->h_cls); free(p->h_half); free(p->h_flag); free(p->h_order); free(p->h_seq); free(p->h_res);
 	free(p);
 }
 
@@ -250,6 +251,7 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 	p->dual = !!dual; p->n = n; p->m = m = sc->m;
 	q = sc->q; e = sc->e; q2 = sc->q2; e2 = sc->e2;
 	p->h_cls = (int8_t*)malloc((size_t)n + 1);
+	p->h_half = (uint8_t*)calloc((size_t)n + 1, 1);
 	p->h_flag = (int32_t*)malloc(sizeof(int32_t) * ((size_t)n + 1));
 	p->h_pairs = (K2aPair*)calloc((size_t)n + 1, sizeof(K2aPair));
 	p->h_res = (K2aResult*)calloc((size_t)n + 1, sizeof(K2aResult));
@@ -390,6 +392,7 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 				const uint32_t ia = p->h_order[c->first + 2 * i], ib = p->h_order[c->first + 2 * i + 1];
 				uint8_t *dq = p->h_seq + p->h_pairs[ia].qoff, *dt = p->h_seq + p->h_pairs[ia].toff;
 				int x;
+				p->h_half[ia] = 1; if (ib != ia) p->h_half[ib] = 2;
 				for (x = 0; x < pairs[ia].qlen; ++x) { dq[2 * x] = pairs[ia].query[x]; dq[2 * x + 1] = pairs[ib].query[x]; }
 				for (x = 0; x < pairs[ia].tlen; ++x) { dt[2 * x] = pairs[ia].target[x]; dt[2 * x + 1] = pairs[ib].target[x]; }
 			}
@@ -504,7 +507,8 @@ int ksw2amd_plan_fetch_raw(ksw2amd_plan_t *p, int32_t *out16)
 }
 
 /* M runs -> =/X runs (KSW_EZ_EQX, ksw2_extd2_sse.c:399-406 / ksw2.h:163-182) */
-static void eqx_rewrite(void *km, const uint8_t *query, const uint8_t *target, ksw_extz_t *ez)
+/* `stride` = 1 for plain sequences, 2 for the byte-interleaved copies of a packed task (pointer already at the right half) */
+static void eqx_rewrite(void *km, const uint8_t *query, const uint8_t *target, int stride, ksw_extz_t *ez)
 {
 	int n0 = ez->n_cigar, k, i, x = 0, y = 0, n = 0;
 	uint32_t *old = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n0 + 1));
@@ -514,7 +518,7 @@ static void eqx_rewrite(void *km, const uint8_t *query, const uint8_t *target, k
 		uint32_t op = old[k] & 0xf, len = old[k] >> 4;
 		if (op == KSW_CIGAR_MATCH) {
 			for (i = 0; i < (int)len; ++i) {
-				uint32_t o = target[x + i] == query[y + i] ? KSW_CIGAR_EQ : KSW_CIGAR_X;
+				uint32_t o = target[(size_t)(x + i) * stride] == query[(size_t)(y + i) * stride] ? KSW_CIGAR_EQ : KSW_CIGAR_X;
 				if (n > 0 && (ez->cigar[n - 1] & 0xf) == o) ez->cigar[n - 1] += 1u << 4;
 				else { ez_reserve(km, ez, n + 1); ez->cigar[n++] = 1u << 4 | o; }
 			}
@@ -575,7 +579,8 @@ int ksw2amd_plan_fetch(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez)
 			else for (k = 0; k < nc; ++k) z->cigar[k] = src[nc - 1 - k];        /* ksw2.h:157-159 */
 			z->n_cigar = nc;
 			if (p->dual && (p->h_flag[i] & KSW_EZ_EQX) && !(p->h_flag[i] & F_SCALAR_CONTRACT))
-				eqx_rewrite(km, p->h_seq + p->h_pairs[i].qoff, p->h_seq + p->h_pairs[i].toff, z);
+				eqx_rewrite(km, p->h_seq + p->h_pairs[i].qoff + (p->h_half[i] == 2), p->h_seq + p->h_pairs[i].toff + (p->h_half[i] == 2),
+				            p->h_half[i] ? 2 : 1, z);
 		}
 	}
 	free(pos); free(pool);
