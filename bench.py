@@ -117,13 +117,20 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # KSW2_BENCH_BACKEND=gloo + KSW2_BENCH_ONE_DEVICE=1 exist only to exercise the multi-rank code path on a 1-GPU box
+    backend = os.environ.get("KSW2_BENCH_BACKEND", "nccl")
+    dev = 0 if os.environ.get("KSW2_BENCH_ONE_DEVICE") else local_rank
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     lib = ksw2_amd.library()
-    lib.set_device(local_rank)
+    lib.set_device(dev)
     wl = WORKLOADS[args.workload]
     S = SCORING
     mat = synth.simple_mat(5, S["a"], S["b"], 0 if wl.get("mt") else S["sc_n"])
@@ -154,10 +161,10 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        cc = torch.tensor([cells], dtype=torch.float64, device="cuda")
+        cc = torch.tensor([cells], dtype=torch.float64, device=red_dev)
         dist.all_reduce(cc, op=dist.ReduceOp.SUM)
         cells_all = float(cc.item())
         pairs_all = n * world

@@ -200,7 +200,7 @@ static int pk_eligible(const pkinfo_t *k, int qlen, int tlen, int w)
 	const int64_t L = imin(qlen, tlen);
 	int64_t hmax, hmin;
 	if (k->ok <= 0 || qlen > 32000 || tlen > 32000) return 0;
-	hmax = (int64_t)imax(k->smax, 0) * L;
+	hmax = (int64_t)imax(k->smax, 0) * L + (int64_t)k->e * tlen;     /* + row bias e*i carried by the packed kernels */
 	hmin = -((int64_t)k->q + (int64_t)k->e * (w + 1)) + (int64_t)imin(k->smin, 0) * L;
 	return hmax < 16383 - 2 * k->qemax - 8 && hmin > -16384 + 2 * k->qemax + 8;
 }

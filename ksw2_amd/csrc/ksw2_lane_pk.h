@@ -7,6 +7,11 @@
  * Gotoh cell update runs on v_pk_add/sub/max_i16: one VALU instruction advances two cells, and every per-step
  * control instruction (live mask, schedule, DPP rotate, loop) is shared by the two alignments.
  *
+ * Row bias: every value of target row i (H, E, F and the second-piece E~, F~) is stored with + e*i added.  Along a
+ * column the first-piece E then needs no extension subtract at all -- E'(i+1,j) = max(E'(i,j), H'(i,j) - q) -- the
+ * diagonal absorbs the bias into the score constants (s + e), and comparisons inside a row are unaffected; strip
+ * epilogues subtract e*i again.  One instruction less per cell.
+ *
  * Preconditions, checked by the host (ksw2_host.c::pk_eligible): m = 5 with a match / mismatch / wildcard score
  * structure (always true without KSW_EZ_GENERIC_SC), no wildcard code in either sequence (such pairs take the
  * int32 kernels), and every in-band H, E, F provably inside (-16384 + max(q+e, q2+e2), 16383 - max(q+e, q2+e2))
@@ -151,15 +156,15 @@ struct K2aLanePk {
 		}
 		if (i0 <= w) {                                          /* some rows start at column 0: virtual column -1 */
 #pragma unroll
-			for (int c = 0; c < C; ++c) {                        /* ksw2_extz.c:43-44, ksw2_extd.c:49-52 */
-				const int hb = k2a_border<DUAL>(sc, i0 + c + 1);
+			for (int c = 0; c < C; ++c) {                        /* ksw2_extz.c:43-44, ksw2_extd.c:49-52; row bias e*i */
+				const int hb = k2a_border<DUAL>(sc, i0 + c + 1) + sc.e * (i0 + c);
 				if (i0 + c <= w) {
 					hl[c] = k2a_pk2(hb); f[c] = k2a_pk2(hb - (sc.q + sc.e));
 					if (DUAL) f2[c] = k2a_pk2(hb - (sc.q2 + sc.e2));
 				}
 			}
 		}
-		if (js == 0) hd0 = k2a_pk2(k2a_border<DUAL>(sc, i0));
+		if (js == 0) hd0 = k2a_pk2(k2a_border<DUAL>(sc, i0) + sc.e * (i0 - 1));   /* H(i0-1,-1) carries the bias of row i0-1 */
 		else hd0 = hu_prev;
 		Snext += G;
 		schedule_next();
@@ -170,7 +175,8 @@ struct K2aLanePk {
 	{
 		if (S == 0) {
 			const int hb = k2a_border<DUAL>(sc, k - koff + 1);
-			hin = k2a_pk2(hb); ein = k2a_pk2(hb - (sc.q + sc.e)); e2in = k2a_pk2(hb - (sc.q2 + sc.e2));
+			hin = k2a_pk2(hb - sc.e);                          /* row -1 carries bias -e, E(0,.) and E~(0,.) bias 0 */
+			ein = k2a_pk2(hb - (sc.q + sc.e)); e2in = k2a_pk2(hb - (sc.q2 + sc.e2));
 		}
 	}
 
@@ -184,8 +190,8 @@ struct K2aLanePk {
 	{
 		const int dd = k - kd;                                 /* jj - i0 */
 		const k2a_pk neg = k2a_pk2(K2A_NEG16);
-		const k2a_pk qe = k2a_pk2(sc.q + sc.e), ge = k2a_pk2(sc.e), qe2 = k2a_pk2(sc.q2 + sc.e2), ge2 = k2a_pk2(sc.e2);
-		const k2a_pk mat_a = k2a_pk2(sc.pk_a), mat_bma = k2a_pk2(sc.pk_b - sc.pk_a);
+		const k2a_pk gq = k2a_pk2(sc.q), ge = k2a_pk2(sc.e), gq2 = k2a_pk2(sc.q2), ge2 = k2a_pk2(sc.e2), de2 = k2a_pk2(sc.e2 - sc.e);
+		const k2a_pk mat_a = k2a_pk2(sc.pk_a + sc.e), mat_bma = k2a_pk2(sc.pk_b - sc.pk_a);     /* score + row-bias step */
 		k2a_pk e = ein, e2 = e2in;
 		if (dd >= wup) { e = neg; e2 = neg; }                  /* the cell above is outside the band */
 		/* live rows lo..hi of this strip at this column (none while the lane owns no strip: rows_m1 = -1) */
@@ -231,29 +237,30 @@ struct K2aLanePk {
 			if (!DUAL && MODE == K2A_MODE_RIGHT) rmj[c] = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(rmax[c], h)), jjpk, rmj[c]);
 			else rmj[c] = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, rmax[c])), rmj[c], jjpk);
 			rmax[c] = k2a_pk_max(rmax[c], h);
-			const k2a_pk t = k2a_pk_sub(h, qe);
-			const k2a_pk ex = k2a_pk_sub(e, ge), fx = k2a_pk_sub(fc, ge);
+			/* gaps leaving the cell, all in row-biased form: opening = H' - q; the extension cost cancels against the bias
+			 * for E (next row), stays e for F (same row), becomes e2 - e for E~ and stays e2 for F~.  "extension beats
+			 * opening" (ksw2_extz.c:79-86 / 105-112) compares the gap state with the opening value directly. */
+			const k2a_pk t = k2a_pk_sub(h, gq);
 			if (MODE == K2A_MODE_LEFT) {                   /* extension strictly better than opening */
-				d |= k2a_pk_sign(k2a_pk_sub(t, ex)) & 0x00080008u;
-				d |= k2a_pk_sign(k2a_pk_sub(t, fx)) & 0x00100010u;
+				d |= k2a_pk_sign(k2a_pk_sub(t, e)) & 0x00080008u;
+				d |= k2a_pk_sign(k2a_pk_sub(t, fc)) & 0x00100010u;
 			} else if (MODE == K2A_MODE_RIGHT) {           /* extension at least as good as opening */
-				d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(ex, t)), 0u, 0x00080008u);
-				d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(fx, t)), 0u, 0x00100010u);
+				d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e, t)), 0u, 0x00080008u);
+				d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(fc, t)), 0u, 0x00100010u);
 			}
-			e = k2a_pk_max(ex, t);
-			f[c] = k2a_pk_max(fx, t);
+			e = k2a_pk_max(e, t);
+			f[c] = k2a_pk_sub(k2a_pk_max(fc, t), ge);
 			if (DUAL) {
-				const k2a_pk t2 = k2a_pk_sub(h, qe2);
-				const k2a_pk ex2 = k2a_pk_sub(e2, ge2), fx2 = k2a_pk_sub(f2[c], ge2);
+				const k2a_pk t2 = k2a_pk_sub(h, gq2);
 				if (MODE == K2A_MODE_LEFT) {
-					d |= k2a_pk_sign(k2a_pk_sub(t2, ex2)) & 0x00200020u;
-					d |= k2a_pk_sign(k2a_pk_sub(t2, fx2)) & 0x00400040u;
+					d |= k2a_pk_sign(k2a_pk_sub(t2, e2)) & 0x00200020u;
+					d |= k2a_pk_sign(k2a_pk_sub(t2, f2[c])) & 0x00400040u;
 				} else if (MODE == K2A_MODE_RIGHT) {
-					d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(ex2, t2)), 0u, 0x00200020u);
-					d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(fx2, t2)), 0u, 0x00400040u);
+					d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e2, t2)), 0u, 0x00200020u);
+					d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(f2[c], t2)), 0u, 0x00400040u);
 				}
-				e2 = k2a_pk_max(ex2, t2);
-				f2[c] = k2a_pk_max(fx2, t2);
+				e2 = k2a_pk_sub(k2a_pk_max(e2, t2), de2);
+				f2[c] = k2a_pk_sub(k2a_pk_max(f2[c], t2), ge2);
 			}
 			if (MODE != K2A_MODE_SCORE) {
 				if (c & 1) tbw[c >> 1] = k2a_pack_dirs(dprev, d);    /* bytes {A(c-1), B(c-1), A(c), B(c)} */
@@ -300,7 +307,7 @@ struct K2aLanePk {
 				const int i = i0 + c;
 				if (i < tlen && !bdrop) {
 					const bool reach = i + w >= qlen - 1;
-					const int hend = (int)(int16_t)(rowbuf[c] >> sh), H = (int)(int16_t)(rowbuf[C + c] >> sh);
+					const int hend = (int)(int16_t)(rowbuf[c] >> sh) - sc.e * i, H = (int)(int16_t)(rowbuf[C + c] >> sh) - sc.e * i;   /* minus row bias */
 					const int j = (int)(int16_t)(rowbuf[2 * C + c] >> sh);
 					if (reach && hend > bmqe) { bmqe = hend; bmqe_t = i; }
 					if (i == tlen_full - 1) { bmte = H; bmte_q = j; }
@@ -333,13 +340,16 @@ struct K2aLanePk {
 		last_h = last_m = last_j = 0;
 	}
 
-	K2A_FN void do_fin_local(const uint32_t *rowbuf)
+	K2A_FN void do_fin_local(const K2aScoring &sc, const uint32_t *rowbuf)
 	{
 #pragma nounroll
 		for (int c = 0; c < C; ++c) {
 			const int i = i0 + c;
-			const k2a_pk ph = rowbuf[c], pm = rowbuf[C + c], pj = rowbuf[2 * C + c];
-			const k2a_pk ipk = k2a_pk2(i);
+			const k2a_pk bias = k2a_pk2(sc.e * i);
+			const k2a_pk pj = rowbuf[2 * C + c], ipk = k2a_pk2(i);
+			/* un-bias; rows past the target end hold -inf, which must stay below every real score */
+			const k2a_pk ph = (i < tlen) ? k2a_pk_sub(rowbuf[c], bias) : k2a_pk2(K2A_NEG16);
+			const k2a_pk pm = (i < tlen) ? k2a_pk_sub(rowbuf[C + c], bias) : k2a_pk2(K2A_NEG16);
 			/* rows past the target end kept rmax = hl = -inf and can never win */
 			const k2a_pk up = k2a_pk_sign(k2a_pk_sub(lmax, pm));                /* max < H */
 			lmax_t = k2a_pk_sel(up, ipk, lmax_t);

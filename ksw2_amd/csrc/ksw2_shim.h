@@ -24,7 +24,7 @@ static const int k2a_cfg_C[K2A_NCFG] = {  8,  8, 16, 32, 16 };
 /* geometry classes of the packed-int16 kernels (two same-shape alignments per lane group) */
 #define K2A_NPKCFG 4
 static const int k2a_pkcfg_G[K2A_NPKCFG] = {  8, 16, 64, 64 };
-static const int k2a_pkcfg_C[K2A_NPKCFG] = { 20,  8,  8, 16 };
+static const int k2a_pkcfg_C[K2A_NPKCFG] = { 18,  8,  8, 16 };
 
 const char *k2a_shim_backend(void);                /* "hip:gfx950" or "sim" */
 const char *k2a_shim_last_error(void);

@@ -206,7 +206,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 				if (nfin) L.do_fin_seq(sc, bkA, bkB, zdropA, zdropB, rowbuf);
 				__builtin_amdgcn_wave_barrier();
 				if (bkA->dropped && bkB->dropped) gdone = true;
-			} else if (nfin) L.do_fin_local(rowbuf);
+			} else if (nfin) L.do_fin_local(sc, rowbuf);
 		}
 		L.qb = qnext;
 		if (zseq && __builtin_amdgcn_ballot_w64(!(gdone || k >= klast)) == 0) break;   /* only a Z-drop ends a group early */
@@ -427,8 +427,8 @@ k2a_trace_pk_kernel(const K2aPair *__restrict__ pairs, const uint32_t *__restric
 typedef void (*fill_pk_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*);
 #define PK_ROW(G, C) { { k2a_fill_pk_kernel<G, C, false, 0>, k2a_fill_pk_kernel<G, C, false, 1>, k2a_fill_pk_kernel<G, C, false, 2> }, \
                        { k2a_fill_pk_kernel<G, C, true, 0>,  k2a_fill_pk_kernel<G, C, true, 1>,  k2a_fill_pk_kernel<G, C, true, 2> } }
-static const fill_pk_fn g_fill_pk[K2A_NPKCFG][2][3] = { PK_ROW(8, 20), PK_ROW(16, 8), PK_ROW(64, 8), PK_ROW(64, 16) };
-static const trace_fn g_trace_pk[K2A_NPKCFG] = { k2a_trace_pk_kernel<8, 20>, k2a_trace_pk_kernel<16, 8>, k2a_trace_pk_kernel<64, 8>,
+static const fill_pk_fn g_fill_pk[K2A_NPKCFG][2][3] = { PK_ROW(8, 18), PK_ROW(16, 8), PK_ROW(64, 8), PK_ROW(64, 16) };
+static const trace_fn g_trace_pk[K2A_NPKCFG] = { k2a_trace_pk_kernel<8, 18>, k2a_trace_pk_kernel<16, 8>, k2a_trace_pk_kernel<64, 8>,
                                                  k2a_trace_pk_kernel<64, 16> };
 
 

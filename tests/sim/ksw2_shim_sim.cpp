@@ -158,7 +158,7 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 					uint32_t *rowbuf = &stage[(lane / G) * 3 * C];
 					L[lane].stage_rows(rowbuf);
 					if (zseq) L[lane].do_fin_seq(sc, &book[lane / G][0], &book[lane / G][1], zdA[lane], zdB[lane], rowbuf);
-					else L[lane].do_fin_local(rowbuf);
+					else L[lane].do_fin_local(sc, rowbuf);
 				}
 				if (zseq)
 					for (int lane = 0; lane < 64; ++lane)
@@ -315,8 +315,8 @@ static void sim_trace_pk(const K2aPair *pairs, const uint32_t *order2, int ntask
 typedef void (*fill_pk_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*);
 #define PK_ROW(G, C) { { sim_fill_pk<G, C, false, 0>, sim_fill_pk<G, C, false, 1>, sim_fill_pk<G, C, false, 2> }, \
                        { sim_fill_pk<G, C, true, 0>,  sim_fill_pk<G, C, true, 1>,  sim_fill_pk<G, C, true, 2> } }
-static const fill_pk_fn g_fill_pk[K2A_NPKCFG][2][3] = { PK_ROW(8, 20), PK_ROW(16, 8), PK_ROW(64, 8), PK_ROW(64, 16) };
-static const trace_fn g_trace_pk[K2A_NPKCFG] = { sim_trace_pk<8, 20>, sim_trace_pk<16, 8>, sim_trace_pk<64, 8>, sim_trace_pk<64, 16> };
+static const fill_pk_fn g_fill_pk[K2A_NPKCFG][2][3] = { PK_ROW(8, 18), PK_ROW(16, 8), PK_ROW(64, 8), PK_ROW(64, 16) };
+static const trace_fn g_trace_pk[K2A_NPKCFG] = { sim_trace_pk<8, 18>, sim_trace_pk<16, 8>, sim_trace_pk<64, 8>, sim_trace_pk<64, 16> };
 
 extern "C" {
 
