@@ -120,6 +120,8 @@ const char *ksw2amd_last_error(void);  /* message of the calling thread's last f
 const char *ksw2amd_backend(void);     /* "hip:gfx950" */
 int ksw2amd_device_count(void);
 int ksw2amd_set_device(int device);    /* device used by the calling thread's subsequent calls */
+/* each thread keeps the device / pinned buffers of its last batch for reuse (allocation costs milliseconds); this returns them */
+void ksw2amd_release_cache(void);
 
 /* n independent alignments; ez[i] ends up exactly as after
  *   ksw_extz2_sse(km, pairs[i].qlen, pairs[i].query, ..., sc->m, sc->mat, sc->q, sc->e, w, zdrop, end_bonus, flag, &ez[i])

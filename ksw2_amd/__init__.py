@@ -47,7 +47,7 @@ _libc.free.argtypes = [ctypes.c_void_p]
 
 EXPORTS = ["ksw_extz2_sse", "ksw_extd2_sse", "ksw_gg2", "ksw_gg2_sse", "ksw_extz", "ksw_extd", "ksw_gg",
            "ksw_extz2_sse41", "ksw_extz2_sse2", "ksw_extd2_sse41", "ksw_extd2_sse2",
-           "ksw2amd_last_error", "ksw2amd_backend", "ksw2amd_device_count", "ksw2amd_set_device",
+           "ksw2amd_last_error", "ksw2amd_backend", "ksw2amd_device_count", "ksw2amd_set_device", "ksw2amd_release_cache",
            "ksw2amd_extz_batch", "ksw2amd_extd_batch", "ksw2amd_plan_create", "ksw2amd_plan_run", "ksw2amd_plan_fetch",
            "ksw2amd_plan_destroy", "ksw2amd_plan_timing", "ksw2amd_plan_cells", "ksw2amd_plan_device_bytes", "ksw2amd_plan_packed_pairs",
            "ksw2amd_plan_fetch_raw"]

@@ -32,10 +32,49 @@ static int fail(int code, const char *fmt, const char *detail)
 	return code;
 }
 
+void ksw2amd_release_cache(void);
+
 int ksw2amd_set_device(int device)
 {
+	ksw2amd_release_cache();                                /* cached buffers belong to the previous device */
 	if (k2a_shim_set_device(device)) return fail(KSW2AMD_E_NODEVICE, "set_device: %s", k2a_shim_last_error());
 	return KSW2AMD_OK;
+}
+
+/* ---------------------------------------------------------------- buffer cache
+ * Device allocations and page-locking cost milliseconds; a minimap2-style caller issues many batches (or single-pair
+ * calls) from the same thread.  Each thread therefore keeps the buffers of its last plan (one per kind) and hands them to
+ * the next plan when they are large enough.  ksw2amd_release_cache() returns them; switching device flushes them. */
+enum { BUF_HSEQ, BUF_SEQ, BUF_PAIRS, BUF_RES, BUF_ORDER, BUF_TB, BUF_CIG, BUF_BND, BUF_KINDS };
+static __thread struct { void *p; size_t cap; } g_cache[BUF_KINDS];
+
+static void cache_free_raw(int kind, void *p) { if (kind == BUF_HSEQ) k2a_shim_host_free(p); else k2a_shim_free(p); }
+
+static void *cache_get(int kind, size_t bytes, size_t *cap)
+{
+	void *p;
+	if (g_cache[kind].p && g_cache[kind].cap >= bytes) {
+		p = g_cache[kind].p; *cap = g_cache[kind].cap;
+		g_cache[kind].p = 0; g_cache[kind].cap = 0;
+		return p;
+	}
+	*cap = bytes + bytes / 8 + 256;                       /* a little slack so slightly larger follow-up batches still fit */
+	return kind == BUF_HSEQ ? k2a_shim_host_malloc(*cap) : k2a_shim_malloc(*cap);
+}
+
+static void cache_put(int kind, void *p, size_t cap)
+{
+	if (!p) return;
+	if (g_cache[kind].p == 0 || g_cache[kind].cap < cap) {
+		if (g_cache[kind].p) cache_free_raw(kind, g_cache[kind].p);
+		g_cache[kind].p = p; g_cache[kind].cap = cap;
+	} else cache_free_raw(kind, p);
+}
+
+void ksw2amd_release_cache(void)
+{
+	int k;
+	for (k = 0; k < BUF_KINDS; ++k) { if (g_cache[k].p) cache_free_raw(k, g_cache[k].p); g_cache[k].p = 0; g_cache[k].cap = 0; }
 }
 
 /* ---------------------------------------------------------------- CIGAR memory */
@@ -90,6 +129,7 @@ struct ksw2amd_plan_s {
 	int norder;
 	uint8_t *h_seq;
 	size_t seq_bytes, tb_bytes, cig_words, bnd_words;
+	size_t cap[BUF_KINDS];         /* capacities of the (possibly recycled) buffers */
 	uint8_t *d_seq, *d_tb;
 	int32_t *d_bnd;
 	K2aPair *d_pairs;
@@ -97,6 +137,7 @@ struct ksw2amd_plan_s {
 	uint32_t *d_order, *d_cig;
 	void *ev[3];
 	void *stream;
+	int stream_used;
 	int64_t cells;
 };
 
@@ -104,15 +145,16 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static int imin(int a, int b) { return a < b ? a : b; }
 static int imax(int a, int b) { return a > b ? a : b; }
 
+/* in-band cells of the exact band |i-j| <= w: sum over target rows i of min(qlen-1, i+w) - max(0, i-w) + 1, closed form */
 static int64_t band_cells(int qlen, int tlen, int w)
 {
-	int64_t n = 0;
-	int i;
-	for (i = 0; i < tlen; ++i) {
-		int st = imax(0, i - w), en = imin(qlen - 1, i + w);
-		if (st <= en) n += en - st + 1;
-	}
-	return n;
+	const int64_t T = (int64_t)qlen + w < tlen ? (int64_t)qlen + w : tlen;    /* rows that own a cell */
+	const int64_t a = (int64_t)qlen - 1 - w;                                   /* last row whose right end is i+w */
+	const int64_t na = a < 0 ? 0 : (a + 1 < T ? a + 1 : T);                    /* rows 0..na-1: en = i+w, then en = qlen-1 */
+	const int64_t nb = (int64_t)w + 1 < T ? (int64_t)w + 1 : T;                /* rows 0..nb-1: st = 0, then st = i-w */
+	const int64_t sum_en = na * (na - 1) / 2 + na * w + (T - na) * ((int64_t)qlen - 1);
+	const int64_t sum_st = (T - nb) * (T - 1 + nb) / 2 - (T - nb) * (int64_t)w;
+	return T <= 0 ? 0 : sum_en - sum_st + T;
 }
 
 /* steps of the generation-serial schedule; must match k2a_gen_cols() in ksw2_lane.h */
@@ -219,10 +261,14 @@ void ksw2amd_plan_destroy(ksw2amd_plan_t *p)
 {
 	int i;
 	if (!p) return;
-	k2a_shim_free(p->d_seq); k2a_shim_free(p->d_tb); k2a_shim_free(p->d_pairs); k2a_shim_free(p->d_res);
-	k2a_shim_free(p->d_order); k2a_shim_free(p->d_cig); k2a_shim_free(p->d_bnd);
+	if (p->stream_used) k2a_shim_stream_sync(p->stream);     /* nothing may still be running on buffers that get recycled */
+	cache_put(BUF_SEQ, p->d_seq, p->cap[BUF_SEQ]); cache_put(BUF_TB, p->d_tb, p->cap[BUF_TB]);
+	cache_put(BUF_PAIRS, p->d_pairs, p->cap[BUF_PAIRS]); cache_put(BUF_RES, p->d_res, p->cap[BUF_RES]);
+	cache_put(BUF_ORDER, p->d_order, p->cap[BUF_ORDER]); cache_put(BUF_CIG, p->d_cig, p->cap[BUF_CIG]);
+	cache_put(BUF_BND, p->d_bnd, p->cap[BUF_BND]);
 	for (i = 0; i < 3; ++i) if (p->ev[i]) k2a_shim_event_destroy(p->ev[i]);
-	free(p->h_pairs); free(p->h_cls); free(p->h_half); free(p->h_flag); free(p->h_order); free(p->h_seq); free(p->h_res);
+	free(p->h_pairs); free(p->h_cls); free(p->h_half); free(p->h_flag); free(p->h_order); free(p->h_res);
+	cache_put(BUF_HSEQ, p->h_seq, p->cap[BUF_HSEQ]);
 	free(p);
 }
 
@@ -311,100 +357,101 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 
 	/* pass 2: task lists per class, most expensive first (similar shapes end up in the same wavefront).  Packed-int16
 	 * candidates of a class are paired up with a neighbour of identical (qlen, tlen, w); a leftover is paired with itself. */
-	p->ncls = 0; p->ntasks = 0;
-	p->h_order = (uint32_t*)malloc(sizeof(uint32_t) * (2 * (size_t)n + 2));
-	srt = (sort_t*)malloc(sizeof(sort_t) * ((size_t)n + 1));
-	for (ci = 0, k = 0; ci < NCLS_MAX; ++ci) {
-		int pass;
-		for (pass = 0; pass <= K2A_NPKCFG; ++pass) {           /* 0: one alignment per lane group, 1 + pc: packed class pc */
-			int cnt = 0, ntask = 0;
+	{
+		enum { NB = NCLS_MAX * (1 + K2A_NPKCFG) };
+		int bcnt[NB], bpos[NB], b;
+		p->ncls = 0; p->ntasks = 0;
+		p->h_order = (uint32_t*)malloc(sizeof(uint32_t) * (2 * (size_t)n + 2));
+		srt = (sort_t*)malloc(sizeof(sort_t) * ((size_t)n + 1));
+		memset(bcnt, 0, sizeof(bcnt));
+		for (i = 0; i < n; ++i) if (p->h_cls[i] >= 0) ++bcnt[p->h_cls[i] * (1 + K2A_NPKCFG) + pk_ok[i]];
+		for (b = 0, k = 0; b < NB; ++b) { bpos[b] = k; k += bcnt[b]; }
+		for (i = 0; i < n; ++i)
+			if (p->h_cls[i] >= 0) {
+				sort_t *e_ = &srt[bpos[p->h_cls[i] * (1 + K2A_NPKCFG) + pk_ok[i]]++];
+				e_->idx = (uint32_t)i;
+				e_->cost = ((int64_t)p->h_pairs[i].qlen << 40) + ((int64_t)p->h_pairs[i].tlen << 16) + p->h_pairs[i].w;
+			}
+		for (b = 0, k = 0; b < NB; ++b) {
+			const int cnt = bcnt[b], pass = b % (1 + K2A_NPKCFG);   /* 0: one alignment per lane group, 1 + pc: packed class pc */
+			sort_t *g = srt + (bpos[b] - cnt);
+			int ntask = 0;
 			cls_t *c;
-			for (i = 0; i < n; ++i)
-				if (p->h_cls[i] == ci && pk_ok[i] == pass) {
-					srt[cnt].idx = (uint32_t)i;
-					srt[cnt].cost = ((int64_t)p->h_pairs[i].qlen << 40) + ((int64_t)p->h_pairs[i].tlen << 16) + p->h_pairs[i].w;
-					++cnt;
-				}
 			if (cnt == 0) continue;
-			qsort(srt, (size_t)cnt, sizeof(sort_t), cmp_cost_desc);
+			ci = b / (1 + K2A_NPKCFG);
+			qsort(g, (size_t)cnt, sizeof(sort_t), cmp_cost_desc);
 			c = &p->cls[p->ncls++];
 			c->cfg = pass ? pass - 1 : ci / 6; c->mode = (ci / 2) % 3; c->generic = ci & 1; c->pk = pass != 0; c->first = k;
 			build_scoring(dual, m, sc->mat, q, e, q2, e2, c->generic, &c->sc);
 			c->sc.pk_a = pkinfo[c->generic].a; c->sc.pk_b = pkinfo[c->generic].b; c->sc.pk_n = pkinfo[c->generic].n;
 			if (!pass) {
-				for (i = 0; i < cnt; ++i) p->h_order[k++] = srt[i].idx;
+				for (i = 0; i < cnt; ++i) p->h_order[k++] = g[i].idx;
 				ntask = cnt;
 			} else {
 				for (i = 0; i < cnt; ++ntask) {
-					const uint32_t ia = srt[i].idx;
+					const uint32_t ia = g[i].idx;
 					uint32_t ib = ia;
-					if (i + 1 < cnt && srt[i + 1].cost == srt[i].cost) { ib = srt[i + 1].idx; i += 2; } else i += 1;
+					if (i + 1 < cnt && g[i + 1].cost == g[i].cost) { ib = g[i + 1].idx; i += 2; } else i += 1;
 					p->h_order[k++] = ia; p->h_order[k++] = ib;
 				}
 			}
 			c->count = ntask;
 			p->ntasks += ntask;
 		}
+		p->norder = k;
+		free(srt); srt = 0;
 	}
-	p->norder = k;
-	free(srt); srt = 0;
 
-	/* pass 3: sequence arena.  Plain tasks: query 4-aligned, target 16-aligned and readable one strip past its end.
-	 * Packed tasks: the two queries (targets) byte-interleaved, x[2p] = A, x[2p+1] = B, shared by both K2aPair entries. */
+	/* pass 3: sequence arena (query 4-aligned, target 16-aligned and readable one strip past its end), traceback blocks
+	 * (one per task: the two alignments of a packed task share theirs) and CIGAR scratch */
 	off = 0;
+	for (i = 0; i < n; ++i) {
+		K2aPair *d = &p->h_pairs[i];
+		if (p->h_cls[i] < 0) continue;
+		off = align_up(off, 4); d->qoff = (uint32_t)off; off += (size_t)d->qlen;
+		off = align_up(off, 16); d->toff = (uint32_t)off; off += (size_t)d->tlen_full + 64;
+		if (off > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "plan_create: more than 4 GiB of sequence in one plan%s", 0); goto err; }
+	}
 	for (k = 0; k < p->ncls; ++k) {
 		const cls_t *c = &p->cls[k];
+		if (c->mode == K2A_MODE_SCORE) continue;
 		for (i = 0; i < c->count; ++i) {
 			const uint32_t ia = p->h_order[c->first + (c->pk ? 2 * i : i)];
 			const uint32_t ib = c->pk ? p->h_order[c->first + 2 * i + 1] : ia;
 			K2aPair *da = &p->h_pairs[ia], *db = &p->h_pairs[ib];
-			const size_t mul = c->pk ? 2 : 1;
-			off = align_up(off, 4); da->qoff = db->qoff = (uint32_t)off; off += mul * (size_t)da->qlen;
-			off = align_up(off, 16); da->toff = db->toff = (uint32_t)off; off += mul * (size_t)da->tlen_full + 64;
-			if (off > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "plan_create: more than 4 GiB of sequence in one plan%s", 0); goto err; }
-			if (c->mode != K2A_MODE_SCORE) {                   /* traceback block (shared by a packed task) and CIGAR scratch */
-				const int G = c->pk ? k2a_pkcfg_G[c->cfg] : k2a_cfg_G[c->cfg], C = c->pk ? k2a_pkcfg_C[c->cfg] : k2a_cfg_C[c->cfg];
-				const int nstrips = (da->tlen + C - 1) / C;
-				size_t steps = (size_t)(nstrips - 1) + (size_t)imin(da->qlen - 1, da->tlen - 1 + da->w) + 1;
-				const size_t wb = c->pk ? 2 * (size_t)C : (size_t)C * (dual ? 8 : 4) / 8;
-				if (!c->pk && c->cfg == K2A_CFG_MP) steps = mp_total_steps(G, C, da->qlen, da->tlen, da->w);
-				da->tb_off = db->tb_off = p->tb_bytes;
-				p->tb_bytes += align_up(steps * G * wb, 256);
-				da->cig_off = (uint32_t)p->cig_words;
-				p->cig_words += (size_t)da->qlen + da->tlen_full + 2;
-				if (ib != ia) { db->cig_off = (uint32_t)p->cig_words; p->cig_words += (size_t)db->qlen + db->tlen_full + 2; }
-				if (p->cig_words > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "plan_create: CIGAR scratch over 16 GiB in one plan%s", 0); goto err; }
-			}
+			const int G = c->pk ? k2a_pkcfg_G[c->cfg] : k2a_cfg_G[c->cfg], C = c->pk ? k2a_pkcfg_C[c->cfg] : k2a_cfg_C[c->cfg];
+			const int nstrips = (da->tlen + C - 1) / C;
+			size_t steps = (size_t)(nstrips - 1) + (size_t)imin(da->qlen - 1, da->tlen - 1 + da->w) + 1;
+			const size_t wb = c->pk ? 2 * (size_t)C : (size_t)C * (dual ? 8 : 4) / 8;
+			if (!c->pk && c->cfg == K2A_CFG_MP) steps = mp_total_steps(G, C, da->qlen, da->tlen, da->w);
+			da->tb_off = db->tb_off = p->tb_bytes;
+			p->tb_bytes += align_up(steps * G * wb, 256);
+			da->cig_off = (uint32_t)p->cig_words;
+			p->cig_words += (size_t)da->qlen + da->tlen_full + 2;
+			if (ib != ia) { db->cig_off = (uint32_t)p->cig_words; p->cig_words += (size_t)db->qlen + db->tlen_full + 2; }
+			if (p->cig_words > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "plan_create: CIGAR scratch over 16 GiB in one plan%s", 0); goto err; }
+			p->h_half[ia] = c->pk ? 1 : 0;
+			if (ib != ia) p->h_half[ib] = 2;
 		}
 	}
 	p->seq_bytes = align_up(off + 65536, 256);      /* idle lanes may prefetch codes a few hundred bytes past the last pair */
 
-	/* pack + upload */
-	p->h_seq = (uint8_t*)calloc(p->seq_bytes, 1);
-	for (k = 0; k < p->ncls; ++k) {
-		const cls_t *c = &p->cls[k];
-		for (i = 0; i < c->count; ++i) {
-			if (!c->pk) {
-				const uint32_t ia = p->h_order[c->first + i];
-				memcpy(p->h_seq + p->h_pairs[ia].qoff, pairs[ia].query, (size_t)pairs[ia].qlen);
-				memcpy(p->h_seq + p->h_pairs[ia].toff, pairs[ia].target, (size_t)pairs[ia].tlen);
-			} else {
-				const uint32_t ia = p->h_order[c->first + 2 * i], ib = p->h_order[c->first + 2 * i + 1];
-				uint8_t *dq = p->h_seq + p->h_pairs[ia].qoff, *dt = p->h_seq + p->h_pairs[ia].toff;
-				int x;
-				p->h_half[ia] = 1; if (ib != ia) p->h_half[ib] = 2;
-				for (x = 0; x < pairs[ia].qlen; ++x) { dq[2 * x] = pairs[ia].query[x]; dq[2 * x + 1] = pairs[ib].query[x]; }
-				for (x = 0; x < pairs[ia].tlen; ++x) { dt[2 * x] = pairs[ia].target[x]; dt[2 * x + 1] = pairs[ib].target[x]; }
-			}
-		}
+	/* pack (pinned staging, so the upload runs at PCIe speed) + upload */
+	p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, p->seq_bytes, &p->cap[BUF_HSEQ]);
+	if (!p->h_seq) { fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
+	for (i = 0; i < n; ++i) {
+		if (p->h_cls[i] < 0) continue;
+		memcpy(p->h_seq + p->h_pairs[i].qoff, pairs[i].query, (size_t)pairs[i].qlen);
+		memcpy(p->h_seq + p->h_pairs[i].toff, pairs[i].target, (size_t)pairs[i].tlen);
+		memset(p->h_seq + p->h_pairs[i].toff + pairs[i].tlen, 0, 64);        /* rows read past the target end */
 	}
-	p->d_seq = (uint8_t*)k2a_shim_malloc(p->seq_bytes);
-	p->d_pairs = (K2aPair*)k2a_shim_malloc(sizeof(K2aPair) * ((size_t)n + 1));
-	p->d_res = (K2aResult*)k2a_shim_malloc(sizeof(K2aResult) * ((size_t)n + 1));
-	p->d_order = (uint32_t*)k2a_shim_malloc(sizeof(uint32_t) * ((size_t)p->norder + 1));
-	p->d_tb = p->tb_bytes ? (uint8_t*)k2a_shim_malloc(p->tb_bytes) : 0;
-	p->d_cig = p->cig_words ? (uint32_t*)k2a_shim_malloc(p->cig_words * 4) : 0;
-	p->d_bnd = p->bnd_words ? (int32_t*)k2a_shim_malloc(p->bnd_words * 4) : 0;
+	p->d_seq = (uint8_t*)cache_get(BUF_SEQ, p->seq_bytes, &p->cap[BUF_SEQ]);
+	p->d_pairs = (K2aPair*)cache_get(BUF_PAIRS, sizeof(K2aPair) * ((size_t)n + 1), &p->cap[BUF_PAIRS]);
+	p->d_res = (K2aResult*)cache_get(BUF_RES, sizeof(K2aResult) * ((size_t)n + 1), &p->cap[BUF_RES]);
+	p->d_order = (uint32_t*)cache_get(BUF_ORDER, sizeof(uint32_t) * ((size_t)p->norder + 1), &p->cap[BUF_ORDER]);
+	p->d_tb = p->tb_bytes ? (uint8_t*)cache_get(BUF_TB, p->tb_bytes, &p->cap[BUF_TB]) : 0;
+	p->d_cig = p->cig_words ? (uint32_t*)cache_get(BUF_CIG, p->cig_words * 4, &p->cap[BUF_CIG]) : 0;
+	p->d_bnd = p->bnd_words ? (int32_t*)cache_get(BUF_BND, p->bnd_words * 4, &p->cap[BUF_BND]) : 0;
 	if (!p->d_seq || !p->d_pairs || !p->d_res || !p->d_order || (p->tb_bytes && !p->d_tb) || (p->cig_words && !p->d_cig) ||
 	    (p->bnd_words && !p->d_bnd)) {
 		fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error());
@@ -430,7 +477,7 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 {
 	int c;
 	if (!p) return fail(KSW2AMD_E_PARAM, "plan_run: NULL plan%s", 0);
-	p->stream = stream; p->ran = 1;
+	p->stream = stream; p->ran = 1; p->stream_used = 1;
 	if (p->reject_all || p->ntasks == 0) return KSW2AMD_OK;
 	if (k2a_shim_event_record(p->ev[0], stream)) goto err;
 	for (c = 0; c < p->ncls; ++c) {
@@ -579,8 +626,7 @@ int ksw2amd_plan_fetch(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez)
 			else for (k = 0; k < nc; ++k) z->cigar[k] = src[nc - 1 - k];        /* ksw2.h:157-159 */
 			z->n_cigar = nc;
 			if (p->dual && (p->h_flag[i] & KSW_EZ_EQX) && !(p->h_flag[i] & F_SCALAR_CONTRACT))
-				eqx_rewrite(km, p->h_seq + p->h_pairs[i].qoff + (p->h_half[i] == 2), p->h_seq + p->h_pairs[i].toff + (p->h_half[i] == 2),
-				            p->h_half[i] ? 2 : 1, z);
+				eqx_rewrite(km, p->h_seq + p->h_pairs[i].qoff, p->h_seq + p->h_pairs[i].toff, 1, z);
 		}
 	}
 	free(pos); free(pool);

@@ -29,6 +29,7 @@ K2A_FN k2a_pk k2a_pk2(int v) { return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 
 K2A_FN int k2a_pk_lo(k2a_pk v) { return (int)(int16_t)(v & 0xffffu); }
 K2A_FN int k2a_pk_hi(k2a_pk v) { return (int)(int16_t)(v >> 16); }
 K2A_FN k2a_pk k2a_pk_sel(k2a_pk m, k2a_pk a, k2a_pk b) { return (m & a) | (~m & b); }   /* v_bfi / v_bitop3 */
+K2A_FN k2a_pk k2a_pair16(uint32_t lo, uint32_t hi) { return lo | (hi << 16); }                /* two small codes -> halves */
 
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef short k2a_s2 __attribute__((ext_vector_type(2)));
@@ -54,10 +55,6 @@ K2A_FN k2a_pk k2a_pk_sign(k2a_pk a)     /* per half: 0xffff if negative else 0 *
 	asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(d) : "v"(a));
 	return d;
 }
-K2A_FN k2a_pk k2a_spread16(uint32_t v)  /* bytes {b0,b1,..} -> halves {b0, b1} */
-{
-	return __builtin_amdgcn_perm(0u, v, 0x0c010c00u);
-}
 K2A_FN k2a_pk k2a_bit_mask(uint32_t bits, int c) { return (k2a_pk)__builtin_amdgcn_sbfe((int)bits, c, 1); }
 K2A_FN uint32_t k2a_pack_dirs(k2a_pk d0, k2a_pk d1)   /* low bytes of the four halves -> one word */
 {
@@ -77,7 +74,6 @@ K2A_FN k2a_pk k2a_pk_minu(k2a_pk a, k2a_pk b)
 }
 K2A_FN k2a_pk k2a_pk_mad(k2a_pk a, k2a_pk b, k2a_pk c) { return k2a_pk_mk(k2a_pk_lo(a) * k2a_pk_lo(b) + k2a_pk_lo(c), k2a_pk_hi(a) * k2a_pk_hi(b) + k2a_pk_hi(c)); }
 K2A_FN k2a_pk k2a_pk_sign(k2a_pk a) { return ((a & 0x8000u) ? 0xffffu : 0u) | ((a & 0x80000000u) ? 0xffff0000u : 0u); }
-K2A_FN k2a_pk k2a_spread16(uint32_t v) { return (v & 0xffu) | ((v & 0xff00u) << 8); }
 K2A_FN k2a_pk k2a_bit_mask(uint32_t bits, int c) { return ((bits >> c) & 1u) ? 0xffffffffu : 0u; }
 K2A_FN uint32_t k2a_pack_dirs(k2a_pk d0, k2a_pk d1)
 {
@@ -93,7 +89,7 @@ struct K2aLanePk {
 	enum { TBWORDS = C / 2 };
 	/* group-uniform (both alignments share the shape) */
 	int qlen, tlen, tlen_full, w, nstrips;
-	const uint8_t *qi, *ti;            /* byte-interleaved sequences: x[2p] = code of A, x[2p+1] = code of B */
+	const uint8_t *qa, *qbp, *ta, *tbq;   /* query / target codes of alignment A and of alignment B */
 	/* schedule, identical to K2aLane */
 	int gl, S, i0, je, koff, Snext, knext, koff_next;
 	int kfin, kd, rows_m1, wup;         /* last step of the strip, koff + i0, live-row clamp (-1 = no strip), band reach upwards */
@@ -111,10 +107,10 @@ struct K2aLanePk {
 		knext = Snext < nstrips ? koff_next + first_col(Snext, w) : K2A_KNONE;
 	}
 
-	K2A_FN void setup(const K2aPair &pr, const uint8_t *seq, int lane_in_group, bool valid)
+	K2A_FN void setup(const K2aPair &pr, const K2aPair &prB, const uint8_t *seq, int lane_in_group, bool valid)
 	{
 		qlen = pr.qlen; tlen = pr.tlen; tlen_full = pr.tlen_full; w = pr.w;
-		qi = seq + pr.qoff; ti = seq + pr.toff;
+		qa = seq + pr.qoff; ta = seq + pr.toff; qbp = seq + prB.qoff; tbq = seq + prB.toff;
 		nstrips = valid ? (tlen + C - 1) / C : 0;
 		gl = lane_in_group;
 		S = -1; i0 = 0; je = -1; koff = 0; kfin = K2A_KNONE; kd = 0; rows_m1 = -1; wup = w;
@@ -142,15 +138,18 @@ struct K2aLanePk {
 		wup = w + (S == 0 ? 1 : 0);                        /* the virtual row -1 reaches one column further (E(0,w) exists) */
 		const int js = k2a_max(0, i0 - w);
 		const k2a_pk neg = k2a_pk2(K2A_NEG16);
-		/* target codes of the strip's rows (2*C bytes, 4-byte aligned; the arena is padded past the last row).
-		 * Not prefetched: one L2 round trip per strip is noise next to the strip's ~2w+C steps. */
-		const uint32_t *tp = (const uint32_t*)(ti + (size_t)S * C * 2);
-		uint32_t tw[(C + 1) / 2];
+		/* target codes of the strip's rows, two rows per 16-bit load and alignment (C is even and targets are 16-byte
+		 * aligned, the arena is padded past the last row).  Not prefetched: one L2 round trip per strip is noise next
+		 * to the strip's ~2w+C steps. */
+		const uint16_t *tpa = (const uint16_t*)(ta + (size_t)S * C), *tpb = (const uint16_t*)(tbq + (size_t)S * C);
 #pragma unroll
-		for (int x = 0; x < (C + 1) / 2; ++x) tw[x] = tp[x];
+		for (int c = 0; c < C; c += 2) {
+			const uint32_t ua = tpa[c >> 1], ub = tpb[c >> 1];
+			tc[c] = k2a_pair16(ua & 0xffu, ub & 0xffu);
+			if (c + 1 < C) tc[c + 1] = k2a_pair16(ua >> 8, ub >> 8);
+		}
 #pragma unroll
 		for (int c = 0; c < C; ++c) {
-			tc[c] = k2a_spread16((tw[c >> 1] >> (16 * (c & 1))) & 0xffffu);
 			hl[c] = neg; f[c] = neg; if (DUAL) f2[c] = neg;
 			rmax[c] = neg; rmj[c] = 0;
 		}
@@ -278,7 +277,7 @@ struct K2aLanePk {
 	{
 		const int j = k + 1 - ((k + 1 == knext) ? koff_next : koff);
 		const int jc = k2a_min(k2a_max(j, 0), qlen - 1);
-		return k2a_spread16(*(const uint16_t*)(qi + 2 * (size_t)jc));
+		return k2a_pair16(qa[jc], qbp[jc]);
 	}
 
 	/* Strip epilogues.  Both forms first stage the strip's rows {H(i, last column), row max, arg-max} in an LDS row

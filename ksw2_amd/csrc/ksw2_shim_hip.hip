@@ -147,13 +147,13 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	const int task = (blockIdx.x * K2A_WPB + wave) * NG + grp;
 	const bool valid = task < ntasks;
 	const uint32_t piA = order2[valid ? 2 * task : 0], piB = order2[valid ? 2 * task + 1 : 0];
-	const K2aPair prA = pairs[piA];
-	const int zdropA = prA.zdrop, zdropB = pairs[piB].zdrop;
+	const K2aPair prA = pairs[piA], prB = pairs[piB];
+	const int zdropA = prA.zdrop, zdropB = prB.zdrop;
 	/* a Z-drop test anywhere in the wavefront selects the sequential strip epilogue for all of it */
 	const bool zseq = __builtin_amdgcn_ballot_w64(valid && (zdropA >= 0 || zdropB >= 0)) != 0;
 
 	Lane L;
-	L.setup(prA, seq, gl, valid);
+	L.setup(prA, prB, seq, gl, valid);
 	K2aBook *bkA = &book[wave][grp][0], *bkB = &book[wave][grp][1];
 	if (gl == 0) { k2a_book_reset(bkA); k2a_book_reset(bkB); }
 	__builtin_amdgcn_wave_barrier();
@@ -236,7 +236,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	if (valid && gl == 0) {
 		const K2aBook a = *bkA, b = *bkB;
 		k2a_finish(prA, a, &res[piA]);
-		if (piB != piA) k2a_finish(pairs[piB], b, &res[piB]);
+		if (piB != piA) k2a_finish(prB, b, &res[piB]);
 	}
 }
 

@@ -118,7 +118,7 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 			piA[lane] = order2[valid[lane] ? 2 * task : 0]; piB[lane] = order2[valid[lane] ? 2 * task + 1 : 0];
 			prA[lane] = pairs[piA[lane]];
 			zdA[lane] = prA[lane].zdrop; zdB[lane] = pairs[piB[lane]].zdrop;
-			L[lane].setup(prA[lane], seq, gl, valid[lane]);
+			L[lane].setup(prA[lane], pairs[piB[lane]], seq, gl, valid[lane]);
 			if (gl == 0) { k2a_book_reset(&book[grp][0]); k2a_book_reset(&book[grp][1]); }
 			klast[lane] = L[lane].last_step();
 			if (klast[lane] > kmax) kmax = klast[lane];
