@@ -47,6 +47,7 @@ int ksw2amd_set_device(int device)
  * the next plan when they are large enough.  ksw2amd_release_cache() returns them; switching device flushes them. */
 enum { BUF_HSEQ, BUF_SEQ, BUF_PAIRS, BUF_RES, BUF_ORDER, BUF_TB, BUF_CIG, BUF_BND, BUF_KINDS };
 static __thread struct { void *p; size_t cap; } g_cache[BUF_KINDS];
+static __thread void *g_ev_cache[3];
 
 static void cache_free_raw(int kind, void *p) { if (kind == BUF_HSEQ) k2a_shim_host_free(p); else k2a_shim_free(p); }
 
@@ -75,6 +76,7 @@ void ksw2amd_release_cache(void)
 {
 	int k;
 	for (k = 0; k < BUF_KINDS; ++k) { if (g_cache[k].p) cache_free_raw(k, g_cache[k].p); g_cache[k].p = 0; g_cache[k].cap = 0; }
+	for (k = 0; k < 3; ++k) { if (g_ev_cache[k]) k2a_shim_event_destroy(g_ev_cache[k]); g_ev_cache[k] = 0; }
 }
 
 /* ---------------------------------------------------------------- CIGAR memory */
@@ -266,7 +268,7 @@ void ksw2amd_plan_destroy(ksw2amd_plan_t *p)
 	cache_put(BUF_PAIRS, p->d_pairs, p->cap[BUF_PAIRS]); cache_put(BUF_RES, p->d_res, p->cap[BUF_RES]);
 	cache_put(BUF_ORDER, p->d_order, p->cap[BUF_ORDER]); cache_put(BUF_CIG, p->d_cig, p->cap[BUF_CIG]);
 	cache_put(BUF_BND, p->d_bnd, p->cap[BUF_BND]);
-	for (i = 0; i < 3; ++i) if (p->ev[i]) k2a_shim_event_destroy(p->ev[i]);
+	for (i = 0; i < 3; ++i) if (p->ev[i]) { if (!g_ev_cache[i]) g_ev_cache[i] = p->ev[i]; else k2a_shim_event_destroy(p->ev[i]); }
 	free(p->h_pairs); free(p->h_cls); free(p->h_half); free(p->h_flag); free(p->h_order); free(p->h_res);
 	cache_put(BUF_HSEQ, p->h_seq, p->cap[BUF_HSEQ]);
 	free(p);
@@ -464,7 +466,7 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 		fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error());
 		goto err;
 	}
-	for (i = 0; i < 3; ++i) p->ev[i] = k2a_shim_event_create();
+	for (i = 0; i < 3; ++i) { p->ev[i] = g_ev_cache[i] ? g_ev_cache[i] : k2a_shim_event_create(); g_ev_cache[i] = 0; }
 	free(pk_ok);
 	return p;
 err:
@@ -660,9 +662,16 @@ static int run_batch(int dual, void *km, const ksw2amd_scoring_t *sc, int n, con
 	int beg = 0, end;
 	if (n <= 0) return KSW2AMD_OK;
 	if (k2a_shim_device_count() <= 0) return fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend());
-	if (k2a_shim_mem_info(&free_b, &total_b)) return fail(KSW2AMD_E_NODEVICE, "mem_info: %s", k2a_shim_last_error());
-	budget = free_b / 10 * 7;
 	if (env && atoll(env) > 0) budget = (size_t)atoll(env);
+	else {
+		/* small batches (the single-pair entry points above all) skip the free-memory query: it costs ~0.1 ms */
+		for (end = 0, acc = 0; end < n && acc <= ((size_t)256 << 20); ++end) acc += pair_device_bytes(dual, &pairs[end]);
+		if (acc <= ((size_t)256 << 20)) budget = (size_t)1 << 30;
+		else {
+			if (k2a_shim_mem_info(&free_b, &total_b)) return fail(KSW2AMD_E_NODEVICE, "mem_info: %s", k2a_shim_last_error());
+			budget = free_b / 10 * 7;
+		}
+	}
 	while (beg < n) {
 		ksw2amd_plan_t *p;
 		int rc;
