@@ -355,13 +355,8 @@ K2A_FN void k2a_gen_cols(int g, int qlen, int tlen, int w, int *jlo, int *nsteps
  * VALU-bound and has the memory pipeline to spare. */
 K2A_FN size_t k2a_tb_word(size_t step, int lane, size_t nsteps, int G, int WB)
 {
-#ifdef K2A_TB_STEP_MAJOR
-	(void)nsteps;
-	return (step * (size_t)G + (size_t)lane) * (size_t)WB;
-#else
 	(void)G;
 	return ((size_t)lane * nsteps + step) * (size_t)WB;
-#endif
 }
 
 template<int G, int C, bool MP>
@@ -374,19 +369,31 @@ K2A_FN size_t k2a_tb_steps(int qlen, int tlen, int w)
 	return tot;
 }
 
-template<int G, int C, bool DUAL, bool MP>
-K2A_FN int k2a_trace_pair(const uint8_t *tb, int i, int j, uint32_t *out, int qlen, int tlen, int w)
-{
-	enum { BITS = K2aTb<DUAL>::BITS, WB = C * BITS / 8 };
-	int n = 0, state = 0;
-	uint32_t last_op = 0xffffffffu, run = 0;
-	int gcur = -1, gjlo = 0;
-	size_t gbase = 0;
-	const size_t nsteps = k2a_tb_steps<G, C, MP>(qlen, tlen, w);
-	while (i >= 0 && j >= 0) {
-		const int S = i / C, c = i - S * C;
-		size_t word;
-		if (!MP) word = k2a_tb_word((size_t)(S + j), S % G, nsteps, G, WB);
+/* Walker over one alignment's direction codes.  Inside a strip every move is an increment: a diagonal or insertion step
+ * goes one lane-step back (-WB bytes in the lane-major block), a deletion stays in the same word; only crossing into the
+ * strip above (c < 0) re-derives the address.  LAYOUT 0/1: the int32 kernels' 4-bit / 8-bit cells; LAYOUT 2: packed
+ * tasks, byte 2c + half of a 2C-byte word. */
+template<int G, int C, int LAYOUT, bool MP>
+struct K2aWalk {
+	enum { WB = LAYOUT == 2 ? 2 * C : LAYOUT == 1 ? C : C / 2 };
+	const uint8_t *tb, *p;          /* block, current word */
+	int qlen, tlen, w, half;
+	size_t nsteps, gbase;
+	int gcur, gjlo;
+	int c;                          /* row inside the strip */
+
+	K2A_FN void init(const uint8_t *tb_, int qlen_, int tlen_, int w_, int half_)
+	{
+		tb = tb_; qlen = qlen_; tlen = tlen_; w = w_; half = half_;
+		nsteps = k2a_tb_steps<G, C, MP>(qlen, tlen, w);
+		gcur = -1; gjlo = 0; gbase = 0; p = tb; c = 0;
+	}
+
+	K2A_FN void locate(int i, int j)
+	{
+		const int S = i / C;
+		c = i - S * C;
+		if (!MP) p = tb + k2a_tb_word((size_t)(S + j), S % G, nsteps, G, WB);
 		else {
 			const int g = S / G;
 			if (g != gcur) {                          /* (re)locate the generation: rare, the walk only moves up */
@@ -401,20 +408,39 @@ K2A_FN int k2a_trace_pair(const uint8_t *tb, int i, int j, uint32_t *out, int ql
 				gcur = g;
 			}
 			const int l = S - g * G;
-			word = k2a_tb_word(gbase + (size_t)(j - gjlo + l), l, nsteps, G, WB);
+			p = tb + k2a_tb_word(gbase + (size_t)(j - gjlo + l), l, nsteps, G, WB);
 		}
-		const uint32_t byte = tb[word + ((c * BITS) >> 3)];
-		const uint32_t raw = DUAL ? byte : ((byte >> ((c * BITS) & 7)) & 0xf);
-		uint32_t d;                                   /* re-expand to the reference's byte layout */
-		if (DUAL) d = raw;
-		else d = (raw & 3u) | ((raw & 4u) << 1) | ((raw & 8u) << 1);
+	}
+
+	/* direction code of the current cell in the reference's byte layout (ksw2.h:125-128) */
+	K2A_FN uint32_t code() const
+	{
+		if (LAYOUT == 2) return p[2 * c + half];
+		if (LAYOUT == 1) return p[c];
+		const uint32_t raw = (p[c >> 1] >> ((c & 1) * 4)) & 0xfu;
+		return (raw & 3u) | ((raw & 4u) << 1) | ((raw & 8u) << 1);
+	}
+};
+
+/* ksw_backtrack (ksw2.h:129-161) on a K2aWalk: writes the CIGAR in walk order (end -> start), returns the op count */
+template<int G, int C, int LAYOUT, bool MP>
+K2A_FN int k2a_trace_walk(const uint8_t *tb, int half, int i, int j, uint32_t *out, int qlen, int tlen, int w)
+{
+	K2aWalk<G, C, LAYOUT, MP> W;
+	int n = 0, state = 0;
+	uint32_t last_op = 0xffffffffu, run = 0;
+	W.init(tb, qlen, tlen, w, half);
+	if (i >= 0 && j >= 0) W.locate(i, j);
+	while (i >= 0 && j >= 0) {
+		const uint32_t d = W.code();
 		if (state == 0) state = d & 7;
 		else if (!((d >> (state + 2)) & 1)) state = 0;
 		if (state == 0) state = d & 7;
 		uint32_t op;
-		if (state == 0) { op = 0; --i; --j; }
-		else if (state == 1 || state == 3) { op = 2; --i; }
-		else { op = 1; --j; }
+		if (state == 0) { op = 0; --i; --j; --W.c; W.p -= W.WB; }                  /* M: previous row, previous lane-step */
+		else if (state == 1 || state == 3) { op = 2; --i; --W.c; }                 /* D: previous row, same lane-step */
+		else { op = 1; --j; W.p -= W.WB; }                                         /* I: same row, previous lane-step */
+		if (W.c < 0 && i >= 0 && j >= 0) W.locate(i, j);                           /* crossed into the strip above */
 		if (op == last_op) ++run;
 		else { if (run) out[n++] = run << 4 | last_op; last_op = op; run = 1; }
 	}
@@ -428,6 +454,12 @@ K2A_FN int k2a_trace_pair(const uint8_t *tb, int i, int j, uint32_t *out, int ql
 	}
 	if (run) out[n++] = run << 4 | last_op;
 	return n;
+}
+
+template<int G, int C, bool DUAL, bool MP>
+K2A_FN int k2a_trace_pair(const uint8_t *tb, int i, int j, uint32_t *out, int qlen, int tlen, int w)
+{
+	return k2a_trace_walk<G, C, DUAL ? 1 : 0, MP>(tb, 0, i, j, out, qlen, tlen, w);
 }
 
 /* Finish one alignment after the fill: turn the bookkeeping state into the ksw_extz_t fields and pick

@@ -364,38 +364,12 @@ struct K2aLanePk {
 	}
 };
 
-/* Traceback walk for one alignment (half = 0/1) of a packed task: same state machine as k2a_trace_pair, direction
- * bytes in the reference layout at byte 2c + half of the (step, lane) word. */
+/* Traceback walk for one alignment (half = 0/1) of a packed task: direction bytes in the reference layout at byte
+ * 2c + half of the (step, lane) word (K2aWalk layout 2). */
 template<int G, int C>
 K2A_FN int k2a_trace_pair_pk(const uint8_t *tb, int half, int i, int j, uint32_t *out, int qlen, int tlen, int w)
 {
-	enum { WB = 2 * C };
-	int n = 0, state = 0;
-	uint32_t last_op = 0xffffffffu, run = 0;
-	const size_t nsteps = k2a_tb_steps<G, C, false>(qlen, tlen, w);
-	while (i >= 0 && j >= 0) {
-		const int S = i / C, c = i - S * C;
-		const uint32_t d = tb[k2a_tb_word((size_t)(S + j), S % G, nsteps, G, WB) + 2 * c + half];
-		if (state == 0) state = d & 7;
-		else if (!((d >> (state + 2)) & 1)) state = 0;
-		if (state == 0) state = d & 7;
-		uint32_t op;
-		if (state == 0) { op = 0; --i; --j; }
-		else if (state == 1 || state == 3) { op = 2; --i; }
-		else { op = 1; --j; }
-		if (op == last_op) ++run;
-		else { if (run) out[n++] = run << 4 | last_op; last_op = op; run = 1; }
-	}
-	if (i >= 0) {
-		if (last_op == 2) run += i + 1;
-		else { if (run) out[n++] = run << 4 | last_op; last_op = 2; run = i + 1; }
-	}
-	if (j >= 0) {
-		if (last_op == 1) run += j + 1;
-		else { if (run) out[n++] = run << 4 | last_op; last_op = 1; run = j + 1; }
-	}
-	if (run) out[n++] = run << 4 | last_op;
-	return n;
+	return k2a_trace_walk<G, C, 2, false>(tb, half, i, j, out, qlen, tlen, w);
 }
 
 /* merge the lane-local bests of one alignment (half = 0/1) of a lane group: loc[l*5 + {0..4}] = lane l's
