@@ -674,14 +674,25 @@ static int run_batch(int dual, void *km, const ksw2amd_scoring_t *sc, int n, con
 	}
 	while (beg < n) {
 		ksw2amd_plan_t *p;
-		int rc;
+		int rc, limit = n - beg;
+		size_t seq = 0, cig = 0;
+		/* a plan addresses its sequence arena and CIGAR scratch with 32-bit offsets: stay below 3 G bytes / words each */
 		for (end = beg, acc = 0; end < n; ++end) {
-			size_t b = pair_device_bytes(dual, &pairs[end]);
-			if (end > beg && (acc + b > budget || end - beg >= (1 << 22))) break;
-			acc += b;
+			const size_t b = pair_device_bytes(dual, &pairs[end]);
+			const size_t sq = (size_t)imax(pairs[end].qlen, 0) + (size_t)imax(pairs[end].tlen, 0) + 96;
+			const size_t cg = (pairs[end].flag & KSW_EZ_SCORE_ONLY) ? 0 : sq;
+			if (end > beg && (acc + b > budget || seq + sq > 3000000000u || cig + cg > 3000000000u || end - beg >= (1 << 22))) break;
+			acc += b; seq += sq; cig += cg;
 		}
-		p = ksw2amd_plan_create(dual, sc, end - beg, pairs + beg);
-		if (!p) return g_err[0] ? (strstr(g_err, "alloc") ? KSW2AMD_E_NOMEM : KSW2AMD_E_PARAM) : KSW2AMD_E_PARAM;
+		/* the footprint estimate is an upper bound in practice; should the device still run out, retry with half the pairs */
+		for (p = 0; p == 0; ) {
+			if (end - beg > limit) end = beg + limit;
+			p = ksw2amd_plan_create(dual, sc, end - beg, pairs + beg);
+			if (p) break;
+			if (!strstr(g_err, "alloc") || end - beg <= 1) return strstr(g_err, "alloc") ? KSW2AMD_E_NOMEM : g_err[0] && strstr(g_err, "device") ? KSW2AMD_E_NODEVICE : KSW2AMD_E_PARAM;
+			ksw2amd_release_cache();
+			limit = (end - beg) / 2;
+		}
 		rc = ksw2amd_plan_run(p, 0);
 		if (rc == KSW2AMD_OK) rc = ksw2amd_plan_fetch(p, km, ez + beg);
 		ksw2amd_plan_destroy(p);
