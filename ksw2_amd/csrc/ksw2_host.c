@@ -18,7 +18,8 @@
 
 #define F_SCALAR_CONTRACT 0x40000000   /* internal: call came through ksw_extz / ksw_extd / ksw_gg* */
 #define NCLS_MAX (K2A_NCFG * 3 * 2)
-#define NCLS_ENTRIES (NCLS_MAX * (1 + K2A_NPKCFG))
+#define NPASS (1 + 2 * K2A_NPKCFG)     /* per class: one alignment per lane group | packed class pc | re-based packed class pc */
+#define NCLS_ENTRIES (NCLS_MAX * NPASS)
 
 static __thread char g_err[512];
 
@@ -114,7 +115,7 @@ static void ez_reserve(void *km, ksw_extz_t *ez, int n)   /* capacity sequence o
 /* ---------------------------------------------------------------- plan */
 
 typedef struct {
-	int cfg, mode, generic, pk, first, count;   /* pk: packed-int16 tasks, two h_order entries per task */
+	int cfg, mode, generic, pk, rb, first, count;   /* pk: packed-int16 tasks, two h_order entries per task; rb: per-strip bases */
 	K2aScoring sc;
 } cls_t;
 
@@ -209,7 +210,7 @@ static void build_scoring(int dual, int m, const int8_t *mat, int q, int e, int 
 }
 
 /* Packed-int16 class (ksw2_lane_pk.h): the scoring must be match / mismatch / wildcard on a 5-letter alphabet ... */
-typedef struct { int ok, a, b, n, smax, smin, qemax, q, e; } pkinfo_t;
+typedef struct { int ok, a, b, n, smax, smin, qemax, qemin, q, e; } pkinfo_t;
 
 static void pk_scoring(int dual, int m, const int8_t *mat, int q, int e, int q2, int e2, int generic, pkinfo_t *o)
 {
@@ -233,6 +234,7 @@ static void pk_scoring(int dual, int m, const int8_t *mat, int q, int e, int q2,
 	}
 	o->q = q; o->e = e;
 	o->qemax = dual ? imax(q + e, q2 + e2) : q + e;
+	o->qemin = dual ? imin(q + e, q2 + e2) : q + e;
 	o->ok = ok;
 }
 
@@ -247,6 +249,19 @@ static int pk_eligible(const pkinfo_t *k, int qlen, int tlen, int w)
 	hmax = (int64_t)imax(k->smax, 0) * L + (int64_t)k->e * tlen;     /* + row bias e*i carried by the packed kernels */
 	hmin = -((int64_t)k->q + (int64_t)k->e * (w + 1)) + (int64_t)imin(k->smin, 0) * L;
 	return hmax < 16383 - 2 * k->qemax - 8 && hmin > -16384 + 2 * k->qemax + 8;
+}
+
+/* Re-based packed kernels: a strip's values are relative to the H diagonally above its first cell, so what has to fit is
+ * the spread over the cells a strip holds at once: at most 2w + 2C + 2 unit steps away from that corner, each step
+ * changing H by at most D = max(smax + qemin, -smin) (the usual difference bounds of the affine recurrence with qemin =
+ * the cheapest one-residue gap; they also hold at the band edges) plus e of row bias; E, F sit at most qemax + D below
+ * their H.  The -inf sentinel is -16384, and
+ * up to two base shifts (<= 2C * D each) plus one score are added to it before it is clamped again. */
+static int pk_window_ok(const pkinfo_t *k, int qlen, int tlen, int w, int C)
+{
+	const int64_t D = imax(imax(k->smax, 0) + k->qemin, -k->smin) + k->e;
+	if (k->ok <= 0 || qlen > 32000 || tlen > 32000) return 0;
+	return ((int64_t)2 * w + 2 * C + 2) * D + 2 * k->qemax + (int64_t)4 * C * D + 64 <= 12000;
 }
 
 /* any residue code >= 4 (the wildcard of a 5-letter alphabet)?  8 codes per probe */
@@ -290,7 +305,7 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 	sort_t *srt = 0;
 	pkinfo_t pkinfo[2];
 	uint8_t *pk_ok = 0;
-	const int use_pk = !getenv("KSW2AMD_NO_PK");
+	const int use_pk = !getenv("KSW2AMD_NO_PK"), use_rb = !getenv("KSW2AMD_NO_RB");
 
 	g_err[0] = 0;
 	if (n < 0 || (n > 0 && !pairs) || !sc) { fail(KSW2AMD_E_PARAM, "plan_create: bad arguments%s", 0); return 0; }
@@ -343,12 +358,17 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 		p->h_cls[i] = (int8_t)ci;
 		p->cells += band_cells(a->qlen, a->tlen, w);
 		if (pkinfo[generic].ok < 0) pk_scoring(dual, m, sc->mat, q, e, q2, e2, generic, &pkinfo[generic]);
-		if (use_pk && pk_eligible(&pkinfo[generic], a->qlen, d->tlen, w) &&
+		if (use_pk && pkinfo[generic].ok > 0 && a->qlen <= 32000 && a->tlen <= 32000 &&
 		    !has_wildcard(a->query, a->qlen) && !has_wildcard(a->target, a->tlen)) {
-			int pc;                                            /* packed class: first geometry that holds the band, 1-based */
-			/* (8 lanes x 20 rows) needs every register with traceback on: score-only pairs only */
-			for (pc = (mode == K2A_MODE_SCORE ? 0 : 1); pc < K2A_NPKCFG; ++pc) if (geom_fits(k2a_pkcfg_G[pc], k2a_pkcfg_C[pc], d->tlen, w)) break;
-			if (pc < K2A_NPKCFG) pk_ok[i] = (uint8_t)(1 + pc);
+			/* packed class: first geometry that holds the band, 1-based; scores that fit 16 bits outright use the plain
+			 * kernels, longer reads the re-based ones as long as the band window fits */
+			const int plain = pk_eligible(&pkinfo[generic], a->qlen, d->tlen, w);
+			int pc;
+			/* (8 lanes x 18 rows) needs every register with traceback on: score-only pairs only */
+			for (pc = (mode == K2A_MODE_SCORE ? 0 : 1); pc < K2A_NPKCFG; ++pc)
+				if (geom_fits(k2a_pkcfg_G[pc], k2a_pkcfg_C[pc], d->tlen, w) &&
+				    (plain || (use_rb && pk_window_ok(&pkinfo[generic], a->qlen, d->tlen, w, k2a_pkcfg_C[pc])))) break;
+			if (pc < K2A_NPKCFG) pk_ok[i] = (uint8_t)(1 + pc + (plain ? 0 : K2A_NPKCFG));
 		}
 		if (cfg == K2A_CFG_MP) {                              /* boundary rows H, E, E~ between generations */
 			d->bnd_off = (uint32_t)p->bnd_words;
@@ -357,33 +377,54 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 		}
 	}
 
+	/* A packed launch has half the wavefronts of the int32 launch of the same pairs.  When that leaves SIMDs without a
+	 * wavefront (a few hundred long reads), the wider int32 launch finishes earlier: measured on MI355X, 1024 pairs of
+	 * 10k x 10k, w = 500: 512 packed wavefronts 11.5 ms, 1024 int32 wavefronts 8.8 ms.  Below 0.6 wavefronts per SIMD the
+	 * packed candidates of a class go back to the int32 kernels (KSW2AMD_SIMDS overrides the device's SIMD count, 0 = off). */
+	{
+		const char *ev = getenv("KSW2AMD_SIMDS");
+		const int simds = ev ? atoi(ev) : k2a_shim_simd_count();
+		if (simds > 0) {
+			int cnt[NCLS_MAX * NPASS], b;
+			memset(cnt, 0, sizeof(cnt));
+			for (i = 0; i < n; ++i) if (p->h_cls[i] >= 0 && pk_ok[i]) ++cnt[p->h_cls[i] * NPASS + pk_ok[i]];
+			for (b = 0; b < NCLS_MAX * NPASS; ++b)
+				if (cnt[b]) {
+					const int G = k2a_pkcfg_G[(b % NPASS - 1) % K2A_NPKCFG];
+					const int64_t waves = ((int64_t)(cnt[b] + 1) / 2 * G + 63) / 64;
+					cnt[b] = waves * 10 < (int64_t)simds * 6;        /* 1 = demote */
+				}
+			for (i = 0; i < n; ++i) if (p->h_cls[i] >= 0 && pk_ok[i] && cnt[p->h_cls[i] * NPASS + pk_ok[i]]) pk_ok[i] = 0;
+		}
+	}
+
 	/* pass 2: task lists per class, most expensive first (similar shapes end up in the same wavefront).  Packed-int16
 	 * candidates of a class are paired up with a neighbour of identical (qlen, tlen, w); a leftover is paired with itself. */
 	{
-		enum { NB = NCLS_MAX * (1 + K2A_NPKCFG) };
+		enum { NB = NCLS_MAX * NPASS };
 		int bcnt[NB], bpos[NB], b;
 		p->ncls = 0; p->ntasks = 0;
 		p->h_order = (uint32_t*)malloc(sizeof(uint32_t) * (2 * (size_t)n + 2));
 		srt = (sort_t*)malloc(sizeof(sort_t) * ((size_t)n + 1));
 		memset(bcnt, 0, sizeof(bcnt));
-		for (i = 0; i < n; ++i) if (p->h_cls[i] >= 0) ++bcnt[p->h_cls[i] * (1 + K2A_NPKCFG) + pk_ok[i]];
+		for (i = 0; i < n; ++i) if (p->h_cls[i] >= 0) ++bcnt[p->h_cls[i] * NPASS + pk_ok[i]];
 		for (b = 0, k = 0; b < NB; ++b) { bpos[b] = k; k += bcnt[b]; }
 		for (i = 0; i < n; ++i)
 			if (p->h_cls[i] >= 0) {
-				sort_t *e_ = &srt[bpos[p->h_cls[i] * (1 + K2A_NPKCFG) + pk_ok[i]]++];
+				sort_t *e_ = &srt[bpos[p->h_cls[i] * NPASS + pk_ok[i]]++];
 				e_->idx = (uint32_t)i;
 				e_->cost = ((int64_t)p->h_pairs[i].qlen << 40) + ((int64_t)p->h_pairs[i].tlen << 16) + p->h_pairs[i].w;
 			}
 		for (b = 0, k = 0; b < NB; ++b) {
-			const int cnt = bcnt[b], pass = b % (1 + K2A_NPKCFG);   /* 0: one alignment per lane group, 1 + pc: packed class pc */
+			const int cnt = bcnt[b], pass = b % NPASS;   /* 0: one alignment per lane group, 1 + pc (+ NPKCFG): packed class pc */
 			sort_t *g = srt + (bpos[b] - cnt);
 			int ntask = 0;
 			cls_t *c;
 			if (cnt == 0) continue;
-			ci = b / (1 + K2A_NPKCFG);
+			ci = b / NPASS;
 			qsort(g, (size_t)cnt, sizeof(sort_t), cmp_cost_desc);
 			c = &p->cls[p->ncls++];
-			c->cfg = pass ? pass - 1 : ci / 6; c->mode = (ci / 2) % 3; c->generic = ci & 1; c->pk = pass != 0; c->first = k;
+			c->cfg = pass ? (pass - 1) % K2A_NPKCFG : ci / 6; c->rb = pass > K2A_NPKCFG; c->mode = (ci / 2) % 3; c->generic = ci & 1; c->pk = pass != 0; c->first = k;
 			build_scoring(dual, m, sc->mat, q, e, q2, e2, c->generic, &c->sc);
 			c->sc.pk_a = pkinfo[c->generic].a; c->sc.pk_b = pkinfo[c->generic].b; c->sc.pk_n = pkinfo[c->generic].n;
 			if (!pass) {
@@ -485,7 +526,7 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 	for (c = 0; c < p->ncls; ++c) {
 		const cls_t *k = &p->cls[c];
 		if (k->pk) {
-			if (k2a_shim_launch_fill_pk(k->cfg, p->dual, k->mode, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
+			if (k2a_shim_launch_fill_pk(k->cfg, p->dual, k->mode, k->rb, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
 			                            p->d_res, stream)) goto err;
 		} else if (k2a_shim_launch_fill(k->cfg, p->dual, k->mode, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
 		                                p->d_bnd, p->d_res, stream)) goto err;

@@ -12,7 +12,13 @@
  * diagonal absorbs the bias into the score constants (s + e), and comparisons inside a row are unaffected; strip
  * epilogues subtract e*i again.  One instruction less per cell.
  *
- * Preconditions, checked by the host (ksw2_host.c::pk_eligible): m = 5 with a match / mismatch / wildcard score
+ * Re-based variant (RB = true) for reads of any length: every strip stores its values relative to a per-alignment base
+ * = the (biased) H of the cell diagonally above its first cell, so only the score spread inside a strip's window --
+ * at most (2w + 2C)(smax + q + e), a property of the band, not of the read length -- has to fit 16 bits.  The bottom
+ * row handed to the next lane is shifted by the difference of the two bases (`delta`, one v_pk_add per value per step),
+ * and the strip epilogue adds the base back.  Re-based launches always use the sequential epilogue.
+ *
+ * Preconditions, checked by the host (ksw2_host.c::pk_eligible / pk_window_ok): m = 5 with a match / mismatch / wildcard score
  * structure (always true without KSW_EZ_GENERIC_SC), no wildcard code in either sequence (such pairs take the
  * int32 kernels), and every in-band H, E, F provably inside (-16384 + max(q+e, q2+e2), 16383 - max(q+e, q2+e2))
  * so that -16384 can stand for -infinity.
@@ -84,7 +90,7 @@ K2A_FN uint32_t k2a_pack_dirs(k2a_pk d0, k2a_pk d1)
 /* packed traceback: one byte per cell and alignment in the reference's own layout (ksw2.h:125-128): bits 0-2 winner
  * {0 diag, 1 E, 2 F, 3 E~, 4 F~}, 0x08/0x10/0x20/0x40 = the E/F/E~/F~ gap leaving the cell is an extension.
  * A lane-step word holds C cells x 2 alignments: byte 2c = alignment A, byte 2c+1 = alignment B. */
-template<int G, int C, bool DUAL, int MODE = K2A_MODE_SCORE>
+template<int G, int C, bool DUAL, int MODE = K2A_MODE_SCORE, bool RB = false>
 struct K2aLanePk {
 	enum { TBWORDS = C / 2 };
 	/* group-uniform (both alignments share the shape) */
@@ -95,6 +101,8 @@ struct K2aLanePk {
 	int kfin, kd, rows_m1, wup;         /* last step of the strip, koff + i0, live-row clamp (-1 = no strip), band reach upwards */
 	/* systolic ports */
 	k2a_pk hout, eout, e2out, hd0, hu_prev;
+	int baseA, baseB;                   /* RB: absolute (row-biased) score that the strip's packed values are relative to */
+	k2a_pk delta;                       /* RB: base of the strip above minus this strip's base, added to incoming ports */
 	uint32_t qb;                        /* { query code A, query code B } of this step's column */
 	/* rows */
 	k2a_pk hl[C], f[C], f2[DUAL ? C : 1], rmax[C], rmj[C], tc[C];
@@ -118,6 +126,7 @@ struct K2aLanePk {
 		schedule_next();
 		const k2a_pk neg = k2a_pk2(K2A_NEG16);
 		hout = eout = e2out = hd0 = hu_prev = neg; qb = 0;
+		baseA = baseB = 0; delta = 0;
 		local_reset();
 #pragma unroll
 		for (int c = 0; c < C; ++c) { hl[c] = f[c] = rmax[c] = neg; rmj[c] = 0; tc[c] = 0; if (DUAL) f2[c] = neg; }
@@ -128,7 +137,8 @@ struct K2aLanePk {
 	K2A_FN bool need_init(int k) const { return k == knext; }
 	K2A_FN bool need_fin(int k) const { return k == kfin; }
 
-	K2A_FN void do_init(const K2aScoring &sc)
+	/* bsA / bsB: bases of the lane that owns the strip above (RB only; rotated in by the kernel) */
+	K2A_FN void do_init(const K2aScoring &sc, int bsA = 0, int bsB = 0)
 	{
 		S = Snext; i0 = S * C; koff = koff_next;
 		je = k2a_min(qlen - 1, k2a_min(i0 + C - 1, tlen - 1) + w);
@@ -153,17 +163,26 @@ struct K2aLanePk {
 			hl[c] = neg; f[c] = neg; if (DUAL) f2[c] = neg;
 			rmax[c] = neg; rmj[c] = 0;
 		}
+		const int hcorner = k2a_border<DUAL>(sc, i0) + sc.e * (i0 - 1);   /* H(i0-1,-1), carrying the bias of row i0-1 */
+		if (RB) {
+			/* new base = the diagonal input of the strip's first cell; hu_prev is still relative to the base above */
+			const int nbA = js == 0 ? hcorner : bsA + k2a_pk_lo(hu_prev), nbB = js == 0 ? hcorner : bsB + k2a_pk_hi(hu_prev);
+			delta = S == 0 ? 0u : k2a_pair16((uint32_t)(bsA - nbA) & 0xffffu, (uint32_t)(bsB - nbB) & 0xffffu);
+			baseA = nbA; baseB = nbB;
+		}
 		if (i0 <= w) {                                          /* some rows start at column 0: virtual column -1 */
 #pragma unroll
 			for (int c = 0; c < C; ++c) {                        /* ksw2_extz.c:43-44, ksw2_extd.c:49-52; row bias e*i */
 				const int hb = k2a_border<DUAL>(sc, i0 + c + 1) + sc.e * (i0 + c);
 				if (i0 + c <= w) {
-					hl[c] = k2a_pk2(hb); f[c] = k2a_pk2(hb - (sc.q + sc.e));
-					if (DUAL) f2[c] = k2a_pk2(hb - (sc.q2 + sc.e2));
+					hl[c] = k2a_pair16((uint32_t)(hb - baseA) & 0xffffu, (uint32_t)(hb - baseB) & 0xffffu);
+					f[c] = k2a_pk_sub(hl[c], k2a_pk2(sc.q + sc.e));
+					if (DUAL) f2[c] = k2a_pk_sub(hl[c], k2a_pk2(sc.q2 + sc.e2));
 				}
 			}
 		}
-		if (js == 0) hd0 = k2a_pk2(k2a_border<DUAL>(sc, i0) + sc.e * (i0 - 1));   /* H(i0-1,-1) carries the bias of row i0-1 */
+		if (RB) hd0 = 0;                                        /* by construction of the base */
+		else if (js == 0) hd0 = k2a_pk2(hcorner);
 		else hd0 = hu_prev;
 		Snext += G;
 		schedule_next();
@@ -174,8 +193,9 @@ struct K2aLanePk {
 	{
 		if (S == 0) {
 			const int hb = k2a_border<DUAL>(sc, k - koff + 1);
-			hin = k2a_pk2(hb - sc.e);                          /* row -1 carries bias -e, E(0,.) and E~(0,.) bias 0 */
-			ein = k2a_pk2(hb - (sc.q + sc.e)); e2in = k2a_pk2(hb - (sc.q2 + sc.e2));
+			const k2a_pk h0 = k2a_pair16((uint32_t)(hb - baseA) & 0xffffu, (uint32_t)(hb - baseB) & 0xffffu);
+			hin = k2a_pk_sub(h0, k2a_pk2(sc.e));               /* row -1 carries bias -e, E(0,.) and E~(0,.) bias 0 */
+			ein = k2a_pk_sub(h0, k2a_pk2(sc.q + sc.e)); e2in = k2a_pk_sub(h0, k2a_pk2(sc.q2 + sc.e2));
 		}
 	}
 
@@ -306,7 +326,8 @@ struct K2aLanePk {
 				const int i = i0 + c;
 				if (i < tlen && !bdrop) {
 					const bool reach = i + w >= qlen - 1;
-					const int hend = (int)(int16_t)(rowbuf[c] >> sh) - sc.e * i, H = (int)(int16_t)(rowbuf[C + c] >> sh) - sc.e * i;   /* minus row bias */
+					const int unb = (half ? baseB : baseA) - sc.e * i;                                       /* plus base, minus row bias */
+					const int hend = (int)(int16_t)(rowbuf[c] >> sh) + unb, H = (int)(int16_t)(rowbuf[C + c] >> sh) + unb;
 					const int j = (int)(int16_t)(rowbuf[2 * C + c] >> sh);
 					if (reach && hend > bmqe) { bmqe = hend; bmqe_t = i; }
 					if (i == tlen_full - 1) { bmte = H; bmte_q = j; }

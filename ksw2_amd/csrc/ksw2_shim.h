@@ -29,6 +29,7 @@ static const int k2a_pkcfg_C[K2A_NPKCFG] = { 18,  8,  8, 16 };
 const char *k2a_shim_backend(void);                /* "hip:gfx950" or "sim" */
 const char *k2a_shim_last_error(void);
 int   k2a_shim_device_count(void);
+int   k2a_shim_simd_count(void);               /* SIMDs (wavefront slots side by side) of the current device; 0 = unknown */
 int   k2a_shim_set_device(int dev);
 int   k2a_shim_mem_info(size_t *free_b, size_t *total_b);
 
@@ -62,9 +63,10 @@ int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_
 /* Packed-int16 fill: ntasks tasks of TWO same-shape alignments each, order2[2t], order2[2t+1] = their indices (equal
  * for an unpaired leftover); both K2aPair entries point at the task's byte-interleaved sequences and, with
  * mode != SCORE, at the task's shared traceback block (2*C bytes per lane-step).  cfg indexes the k2a_pkcfg_* table.
+ * rebased: per-strip score bases (reads of any length whose band window fits 16 bits).
  * The packed trace kernel walks 2*ntasks alignments of such a launch. */
-int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2, int ntasks,
-                            const uint8_t *seq, uint8_t *tb, K2aResult *res, void *stream);
+int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2,
+                            int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, void *stream);
 int k2a_shim_launch_trace_pk(int cfg, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb,
                              K2aResult *res, uint32_t *cig, void *stream);
 

@@ -132,13 +132,13 @@ k2a_fill_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const ui
 }
 
 /* Packed-int16 resident fill: two same-shape alignments per lane group (ksw2_lane_pk.h). */
-template<int G, int C, bool DUAL, int MODE>
+template<int G, int C, bool DUAL, int MODE, bool RB>
 __global__ void __launch_bounds__(64 * K2A_WPB)      /* no occupancy floor: capping at 168 VGPRs spills and is 18 % slower */
 k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
                    const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, K2aResult *__restrict__ res)
 {
 	constexpr int NG = 64 / G;
-	typedef K2aLanePk<G, C, DUAL, MODE> Lane;
+	typedef K2aLanePk<G, C, DUAL, MODE, RB> Lane;
 	__shared__ K2aBook book[K2A_WPB][NG][2];
 	__shared__ uint32_t stage[K2A_WPB][(NG * 3 * C > 64 * 5) ? NG * 3 * C : 64 * 5];   /* row buffers / final lane records */
 
@@ -150,7 +150,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	const K2aPair prA = pairs[piA], prB = pairs[piB];
 	const int zdropA = prA.zdrop, zdropB = prB.zdrop;
 	/* a Z-drop test anywhere in the wavefront selects the sequential strip epilogue for all of it */
-	const bool zseq = __builtin_amdgcn_ballot_w64(valid && (zdropA >= 0 || zdropB >= 0)) != 0;
+	const bool zseq = RB || __builtin_amdgcn_ballot_w64(valid && (zdropA >= 0 || zdropB >= 0)) != 0;
 
 	Lane L;
 	L.setup(prA, prB, seq, gl, valid);
@@ -181,9 +181,11 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 
 		const bool ninit = L.need_init(k);
 		if (__builtin_amdgcn_ballot_w64(ninit) != 0) {
-			if (ninit) L.do_init(sc);                         /* uses hu_prev = what arrived one step ago */
+			const int bsA = RB ? k2a_rot1<G>(L.baseA) : 0, bsB = RB ? k2a_rot1<G>(L.baseB) : 0;
+			if (ninit) L.do_init(sc, bsA, bsB);               /* uses hu_prev = what arrived one step ago */
 		}
 		L.hu_prev = hin;
+		if (RB) { hin = k2a_pk_add(hin, L.delta); ein = k2a_pk_add(ein, L.delta); if (DUAL) e2in = k2a_pk_add(e2in, L.delta); }
 		const uint32_t qnext = L.next_query_codes(k);
 		if (k <= ktop) L.top_inputs(sc, k, hin, ein, e2in);
 
@@ -425,9 +427,10 @@ k2a_trace_pk_kernel(const K2aPair *__restrict__ pairs, const uint32_t *__restric
 }
 
 typedef void (*fill_pk_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*);
-#define PK_ROW(G, C) { { k2a_fill_pk_kernel<G, C, false, 0>, k2a_fill_pk_kernel<G, C, false, 1>, k2a_fill_pk_kernel<G, C, false, 2> }, \
-                       { k2a_fill_pk_kernel<G, C, true, 0>,  k2a_fill_pk_kernel<G, C, true, 1>,  k2a_fill_pk_kernel<G, C, true, 2> } }
-static const fill_pk_fn g_fill_pk[K2A_NPKCFG][2][3] = { PK_ROW(8, 18), PK_ROW(16, 8), PK_ROW(64, 8), PK_ROW(64, 16) };
+#define PK_ROW(G, C, RB) { { k2a_fill_pk_kernel<G, C, false, 0, RB>, k2a_fill_pk_kernel<G, C, false, 1, RB>, k2a_fill_pk_kernel<G, C, false, 2, RB> }, \
+                           { k2a_fill_pk_kernel<G, C, true, 0, RB>,  k2a_fill_pk_kernel<G, C, true, 1, RB>,  k2a_fill_pk_kernel<G, C, true, 2, RB> } }
+static const fill_pk_fn g_fill_pk[2][K2A_NPKCFG][2][3] = { { PK_ROW(8, 18, false), PK_ROW(16, 8, false), PK_ROW(64, 8, false), PK_ROW(64, 16, false) },
+                                                          { PK_ROW(8, 18, true),  PK_ROW(16, 8, true),  PK_ROW(64, 8, true),  PK_ROW(64, 16, true) } };
 static const trace_fn g_trace_pk[K2A_NPKCFG] = { k2a_trace_pk_kernel<8, 18>, k2a_trace_pk_kernel<16, 8>, k2a_trace_pk_kernel<64, 8>,
                                                  k2a_trace_pk_kernel<64, 16> };
 
@@ -442,6 +445,16 @@ int k2a_shim_device_count(void)
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
 	return n;
+}
+
+int k2a_shim_simd_count(void)
+{
+	static int simds[64];
+	int dev = 0, cus = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+	if (simds[dev]) return simds[dev];
+	if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+	return simds[dev] = 4 * cus;
 }
 
 int k2a_shim_set_device(int dev) { CHECK(hipSetDevice(dev)); return 0; }
@@ -533,14 +546,14 @@ int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_
 	return 0;
 }
 
-int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2, int ntasks,
-                            const uint8_t *seq, uint8_t *tb, K2aResult *res, void *stream)
+int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2,
+                            int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, void *stream)
 {
 	if (ntasks <= 0) return 0;
 	if (cfg < 0 || cfg >= K2A_NPKCFG || mode < 0 || mode > 2) { snprintf(g_err, sizeof(g_err), "bad packed kernel class"); return -1; }
 	const int per_block = K2A_WPB * (64 / k2a_pkcfg_G[cfg]);
 	const int blocks = (ntasks + per_block - 1) / per_block;
-	hipLaunchKernelGGL(g_fill_pk[cfg][dual ? 1 : 0][mode], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
+	hipLaunchKernelGGL(g_fill_pk[rebased ? 1 : 0][cfg][dual ? 1 : 0][mode], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
 	                   *sc, pairs, order2, ntasks, seq, tb, res);
 	CHECK(hipGetLastError());
 	return 0;

@@ -98,12 +98,12 @@ static void sim_fill(const K2aScoring sc, const K2aPair *pairs, const uint32_t *
 }
 
 /* mirrors k2a_fill_pk_kernel */
-template<int G, int C, bool DUAL, int MODE>
+template<int G, int C, bool DUAL, int MODE, bool RB>
 static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *seq, uint8_t *tb,
                         K2aResult *res)
 {
 	constexpr int NG = 64 / G;
-	typedef K2aLanePk<G, C, DUAL, MODE> Lane;
+	typedef K2aLanePk<G, C, DUAL, MODE, RB> Lane;
 	const int nwaves = (ntasks + NG - 1) / NG;
 	for (int wv = 0; wv < nwaves; ++wv) {
 		static Lane L[64];
@@ -111,7 +111,7 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 		K2aPair prA[64];
 		uint32_t piA[64], piB[64], stage[(NG * 3 * C > 64 * 5) ? NG * 3 * C : 64 * 5];
 		int zdA[64], zdB[64], klast[64], kmax = -1, ktop = -1;
-		bool valid[64], gdone[64], zseq = false;
+		bool valid[64], gdone[64], zseq = RB;
 		for (int lane = 0; lane < 64; ++lane) {
 			const int grp = lane / G, gl = lane % G, task = wv * NG + grp;
 			valid[lane] = task < ntasks;
@@ -138,9 +138,18 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 				hin[lane] = L[src].hout; ein[lane] = L[src].eout; e2in[lane] = DUAL ? L[src].e2out : 0;
 			}
 			bool anyfin = false, nfin[64];
+			int bsA[64], bsB[64];
 			for (int lane = 0; lane < 64; ++lane) {
-				if (L[lane].need_init(k)) L[lane].do_init(sc);
+				const int src = (lane / G) * G + (lane % G + G - 1) % G;
+				bsA[lane] = L[src].baseA; bsB[lane] = L[src].baseB;
+			}
+			for (int lane = 0; lane < 64; ++lane) {
+				if (L[lane].need_init(k)) L[lane].do_init(sc, bsA[lane], bsB[lane]);
 				L[lane].hu_prev = hin[lane];
+				if (RB) {
+					hin[lane] = k2a_pk_add(hin[lane], L[lane].delta); ein[lane] = k2a_pk_add(ein[lane], L[lane].delta);
+					if (DUAL) e2in[lane] = k2a_pk_add(e2in[lane], L[lane].delta);
+				}
 				qnext[lane] = L[lane].next_query_codes(k);
 				if (k <= ktop) L[lane].top_inputs(sc, k, hin[lane], ein[lane], e2in[lane]);
 			}
@@ -313,9 +322,10 @@ static void sim_trace_pk(const K2aPair *pairs, const uint32_t *order2, int ntask
 }
 
 typedef void (*fill_pk_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*);
-#define PK_ROW(G, C) { { sim_fill_pk<G, C, false, 0>, sim_fill_pk<G, C, false, 1>, sim_fill_pk<G, C, false, 2> }, \
-                       { sim_fill_pk<G, C, true, 0>,  sim_fill_pk<G, C, true, 1>,  sim_fill_pk<G, C, true, 2> } }
-static const fill_pk_fn g_fill_pk[K2A_NPKCFG][2][3] = { PK_ROW(8, 18), PK_ROW(16, 8), PK_ROW(64, 8), PK_ROW(64, 16) };
+#define PK_ROW(G, C, RB) { { sim_fill_pk<G, C, false, 0, RB>, sim_fill_pk<G, C, false, 1, RB>, sim_fill_pk<G, C, false, 2, RB> }, \
+                           { sim_fill_pk<G, C, true, 0, RB>,  sim_fill_pk<G, C, true, 1, RB>,  sim_fill_pk<G, C, true, 2, RB> } }
+static const fill_pk_fn g_fill_pk[2][K2A_NPKCFG][2][3] = { { PK_ROW(8, 18, false), PK_ROW(16, 8, false), PK_ROW(64, 8, false), PK_ROW(64, 16, false) },
+                                                          { PK_ROW(8, 18, true),  PK_ROW(16, 8, true),  PK_ROW(64, 8, true),  PK_ROW(64, 16, true) } };
 static const trace_fn g_trace_pk[K2A_NPKCFG] = { sim_trace_pk<8, 18>, sim_trace_pk<16, 8>, sim_trace_pk<64, 8>, sim_trace_pk<64, 16> };
 
 extern "C" {
@@ -323,6 +333,7 @@ extern "C" {
 const char *k2a_shim_backend(void) { return "sim"; }
 const char *k2a_shim_last_error(void) { return g_err; }
 int k2a_shim_device_count(void) { return 1; }
+int k2a_shim_simd_count(void) { return 0; }
 int k2a_shim_set_device(int dev) { return dev == 0 ? 0 : -1; }
 int k2a_shim_mem_info(size_t *free_b, size_t *total_b) { *free_b = (size_t)8 << 30; *total_b = (size_t)8 << 30; return 0; }
 void *k2a_shim_malloc(size_t bytes) { return calloc(bytes ? bytes : 16, 1); }
@@ -352,10 +363,10 @@ int k2a_shim_launch_fill(int cfg, int dual, int mode, const K2aScoring *sc, cons
 	else g_fill[cfg][dual ? 1 : 0][mode](*sc, pairs, order, ntasks, seq, tb, res);
 	return 0;
 }
-int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2, int ntasks,
-                            const uint8_t *seq, uint8_t *tb, K2aResult *res, void *)
+int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2,
+                            int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, void *)
 {
-	if (ntasks > 0) g_fill_pk[cfg][dual ? 1 : 0][mode](*sc, pairs, order2, ntasks, seq, tb, res);
+	if (ntasks > 0) g_fill_pk[rebased ? 1 : 0][cfg][dual ? 1 : 0][mode](*sc, pairs, order2, ntasks, seq, tb, res);
 	return 0;
 }
 int k2a_shim_launch_trace_pk(int cfg, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb,

@@ -13,6 +13,13 @@ from tests.parity_util import check_batch, diff, CMP_FIELDS
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _small_batches_stay_packed(monkeypatch):
+    """Test batches are far too small to fill 1024 SIMDs; without this the host would send their packed-int16 candidates
+    back to the int32 kernels (ksw2_host.c, "0.6 wavefronts per SIMD") and the packed kernels would go untested."""
+    monkeypatch.setenv("KSW2AMD_SIMDS", "0")
+
+
 @pytest.fixture(scope="module")
 def lib():
     L = ka.library()                      # raises if the HIP library is missing: no fallback
@@ -256,6 +263,48 @@ def test_packed_fixed_shape_batches(lib, dual):
         zd = rng.choice([-1, 30, 100, 400], size=n); eb = rng.choice([0, 10, 50], size=n)
         fl = np.array([po.SCORE_ONLY | (po.EXTZ_ONLY if rng.random() < 0.3 else 0) | (po.GENERIC_SC if rnd % 3 == 0 else 0) for _ in range(n)])
         check_batch(lib, dual, qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl)
+
+
+@pytest.mark.parametrize("dual", [False, True])
+def test_packed_rebased_long_reads(lib, dual):
+    """Reads whose absolute scores leave 16 bits: packed kernels with per-strip bases.  Fixed-shape batches, score-only
+    and both traceback modes, bands up to the window limit, all-match / all-mismatch pairs, Z-drop on and off."""
+    rng = np.random.Generator(np.random.PCG64(91 + dual))
+    scs = [(synth.simple_mat(5, 2, 4, -1), 4, 2, 24, 1), (synth.simple_mat(5, 10, 12, 0), 12, 4, 40, 2),
+           (synth.simple_mat(5, 1, 3, 0), 5, 1, 20, 1), (synth.simple_mat(5, 6, 9, -3), 9, 3, 30, 1)]
+    wide = [[400, 500, 536, 560], [140, 170, 180], [500, 600, 700], [200, 250, 270]]
+    npk = ntot = 0
+    for rnd in range(12):
+        mat, q, e, q2, e2 = scs[rnd % 4]
+        n = int(rng.integers(3, 24))
+        ql = int(rng.integers(4000, 21000)) if rnd % 4 in (0, 2) else int(rng.integers(1500, 6000))
+        tl = ql + int(rng.integers(-60, 60))
+        w = int(rng.choice([10, 20, 64, 68, 100, 150])) if rnd < 6 else int(rng.choice(wide[rnd % 4]))
+        qs, ts = synth.fixed_batch(1900 + rnd, n, ql, tl, sub=0.05, ind=0.1, tail_random_frac=0.3, tail_pairs=0.3)
+        qs, ts = qs.copy(), ts.copy()
+        qs[0, :] = 0; ts[0, :] = 0
+        qs[1, :] = 1; ts[1, :] = 2
+        zd = rng.choice([-1, 100, 400, 2000], size=n)
+        eb = rng.choice([0, 10, 50], size=n)
+        mode = [po.SCORE_ONLY, 0, po.RIGHT][rnd % 3]
+        fl = np.array([mode | (po.EXTZ_ONLY if rng.random() < 0.3 else 0) | (po.REV_CIGAR if rng.random() < 0.3 else 0) for _ in range(n)])
+        p = lib.make_batch(qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl).plan(dual)
+        npk += p.packed_pairs(); ntot += n
+        p.close()
+        check_batch(lib, dual, qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl, sample=[0, 1] + list(range(2, n, 2)))
+    assert npk > ntot // 2
+
+
+def test_small_packed_class_goes_back_to_int32(lib, monkeypatch):
+    """Fewer packed wavefronts than 0.6 per SIMD: the class runs on the int32 kernels instead; same results."""
+    n = 64
+    q, t = synth.fixed_batch(2, n, 512, 512, sub=0.05, ind=0.06, stream=3)
+    mat = synth.simple_mat(5, 2, 4, -1)
+    b = lib.make_batch(q, t, mat, 4, 2, 24, 1, w=64, zdrop=-1, flag=po.SCORE_ONLY)
+    p = b.plan(False); assert p.packed_pairs() == n; p.run(); r1 = p.fetch_raw().copy(); p.close()
+    monkeypatch.delenv("KSW2AMD_SIMDS")
+    p = b.plan(False); assert p.packed_pairs() == 0; p.run(); r0 = p.fetch_raw().copy(); p.close()
+    assert (r0 == r1).all()
 
 
 def test_cfg5_ont_like_mix(lib):

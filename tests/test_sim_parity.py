@@ -154,13 +154,56 @@ def test_sim_packed_int16_class(sim):
     assert npk > 300          # batches with wildcards stay on the int32 kernels
 
 
+def test_sim_packed_rebased(sim):
+    """Reads too long for absolute 16-bit scores: per-strip bases (K2aLanePk RB = true).  Score-only and both traceback
+    modes, Z-drop on and off, all-match / all-mismatch rows (fastest drift of the base), bands up to the window limit."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    scs = [(synth.simple_mat(5, 2, 4, -1), 4, 2, 24, 1), (synth.simple_mat(5, 10, 12, 0), 12, 4, 40, 2),
+           (synth.simple_mat(5, 1, 3, 0), 5, 1, 20, 1), (synth.simple_mat(5, 6, 9, -3), 9, 3, 30, 1)]
+    wide = [[400, 536, 560], [140, 170, 180], [500, 600, 700], [200, 250, 270]]
+    npk = ntot = 0
+    for rnd in range(12):
+        mat, q, e, q2, e2 = scs[rnd % 4]
+        n = int(rng.integers(2, 6))
+        ql = int(rng.integers(1500, 4000))
+        tl = ql + int(rng.integers(-60, 60))
+        w = int(rng.choice([10, 20, 64, 68, 100, 150])) if rnd < 8 else int(rng.choice(wide[rnd % 4]))
+        qs, ts = synth.fixed_batch(900 + rnd, n, ql, tl, sub=0.05, ind=0.1, tail_random_frac=0.3, tail_pairs=0.3)
+        qs, ts = qs.copy(), ts.copy()
+        if rnd % 5 == 1:
+            qs[0, :] = 0; ts[0, :] = 0
+        if rnd % 5 == 2:
+            qs[0, :] = 1; ts[0, :] = 2
+        zd = rng.choice([-1, 100, 400, 2000], size=n)
+        eb = rng.choice([0, 10, 50], size=n)
+        mode = [po.SCORE_ONLY, 0, po.RIGHT][rnd % 3]
+        fl = np.array([mode | (po.EXTZ_ONLY if rng.random() < 0.3 else 0) | (po.REV_CIGAR if rng.random() < 0.3 else 0) |
+                       (po.GENERIC_SC if rnd % 4 == 0 else 0) for _ in range(n)])
+        for dual in (False, True):
+            p = sim.make_batch(qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl).plan(dual)
+            npk += p.packed_pairs(); ntot += n
+            p.close()
+            check_batch(sim, dual, qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl)
+    assert npk > ntot // 2
+
+
 def test_sim_packed_range_guard(sim):
     """Shapes whose scores could leave the int16 window must stay on the int32 kernels."""
     mat = synth.simple_mat(5, 2, 4, -1)
     q, t = synth.fixed_batch(6, 2, 9000, 9000)
     p = sim.make_batch(q, t, mat, 4, 2, 24, 1, w=100, zdrop=-1, flag=po.SCORE_ONLY).plan(False)
-    assert p.packed_pairs() == 0
+    assert p.packed_pairs() == 2       # long reads, narrow band: re-based packed kernels
     p.close()
+    p = sim.make_batch(q, t, mat, 4, 2, 24, 1, w=700, zdrop=-1, flag=po.SCORE_ONLY).plan(False)
+    assert p.packed_pairs() == 0       # band window too wide for 16 bits
+    p.close()
+    os.environ["KSW2AMD_NO_RB"] = "1"
+    try:
+        p = sim.make_batch(q, t, mat, 4, 2, 24, 1, w=100, zdrop=-1, flag=po.SCORE_ONLY).plan(False)
+        assert p.packed_pairs() == 0
+        p.close()
+    finally:
+        del os.environ["KSW2AMD_NO_RB"]
     q, t = synth.fixed_batch(2, 4, 512, 512)
     p = sim.make_batch(q, t, mat, 4, 2, 24, 1, w=64, zdrop=-1, flag=po.SCORE_ONLY).plan(False)
     assert p.packed_pairs() == 4
