@@ -28,6 +28,7 @@
 
 #include "ksw2_lane.h"
 
+#define K2A_PK_STAGE(C) (3 * (C) + 2)    /* LDS words per lane group for a strip's staged rows: H, row max, arg-max, first row */
 typedef uint32_t k2a_pk;                 /* { int16 lo = alignment A, int16 hi = alignment B } */
 #define K2A_NEG16 (-16384)
 
@@ -61,6 +62,12 @@ K2A_FN k2a_pk k2a_pk_sign(k2a_pk a)     /* per half: 0xffff if negative else 0 *
 	asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(d) : "v"(a));
 	return d;
 }
+K2A_FN k2a_pk k2a_pk_selv(k2a_pk m, k2a_pk a, k2a_pk b)   /* k2a_pk_sel on three registers */
+{
+	k2a_pk d;      /* asm: with the mask coming out of the asm above, hipcc expands the select into and / not / and / or */
+	asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(m), "v"(a), "v"(b));
+	return d;
+}
 K2A_FN k2a_pk k2a_bit_mask(uint32_t bits, int c) { return (k2a_pk)__builtin_amdgcn_sbfe((int)bits, c, 1); }
 K2A_FN uint32_t k2a_pack_dirs(k2a_pk d0, k2a_pk d1)   /* low bytes of the four halves -> one word */
 {
@@ -80,6 +87,7 @@ K2A_FN k2a_pk k2a_pk_minu(k2a_pk a, k2a_pk b)
 }
 K2A_FN k2a_pk k2a_pk_mad(k2a_pk a, k2a_pk b, k2a_pk c) { return k2a_pk_mk(k2a_pk_lo(a) * k2a_pk_lo(b) + k2a_pk_lo(c), k2a_pk_hi(a) * k2a_pk_hi(b) + k2a_pk_hi(c)); }
 K2A_FN k2a_pk k2a_pk_sign(k2a_pk a) { return ((a & 0x8000u) ? 0xffffu : 0u) | ((a & 0x80000000u) ? 0xffff0000u : 0u); }
+K2A_FN k2a_pk k2a_pk_selv(k2a_pk m, k2a_pk a, k2a_pk b) { return k2a_pk_sel(m, a, b); }
 K2A_FN k2a_pk k2a_bit_mask(uint32_t bits, int c) { return ((bits >> c) & 1u) ? 0xffffffffu : 0u; }
 K2A_FN uint32_t k2a_pack_dirs(k2a_pk d0, k2a_pk d1)
 {
@@ -253,8 +261,8 @@ struct K2aLanePk {
 			h = k2a_pk_sel(k2a_bit_mask(live, c), h, neg);
 			/* running row maximum: ties to the last column (keep the old arg-max only where h < max), except
 			 * extz + RIGHT + CIGAR where the first column wins (take the new one only where max < h); SURVEY 8a rule 3 */
-			if (!DUAL && MODE == K2A_MODE_RIGHT) rmj[c] = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(rmax[c], h)), jjpk, rmj[c]);
-			else rmj[c] = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, rmax[c])), rmj[c], jjpk);
+			if (!DUAL && MODE == K2A_MODE_RIGHT) rmj[c] = k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(rmax[c], h)), jjpk, rmj[c]);
+			else rmj[c] = k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(h, rmax[c])), rmj[c], jjpk);
 			rmax[c] = k2a_pk_max(rmax[c], h);
 			/* gaps leaving the cell, all in row-biased form: opening = H' - q; the extension cost cancels against the bias
 			 * for E (next row), stays e for F (same row), becomes e2 - e for E~ and stays e2 for F~.  "extension beats
@@ -301,12 +309,13 @@ struct K2aLanePk {
 	}
 
 	/* Strip epilogues.  Both forms first stage the strip's rows {H(i, last column), row max, arg-max} in an LDS row
-	 * buffer (3*C words per lane group) and then walk them in a ROLLED loop: unrolled, hipcc materialises every row's
+	 * buffer (K2A_PK_STAGE(C) words per lane group) and then walk them in a ROLLED loop: unrolled, hipcc materialises every row's
 	 * constants and unpacked halves at once and the kernel loses a wave of occupancy for code that runs once per strip. */
 	K2A_FN void stage_rows(uint32_t *rowbuf) const
 	{
 #pragma unroll
 		for (int c = 0; c < C; ++c) { rowbuf[c] = hl[c]; rowbuf[C + c] = rmax[c]; rowbuf[2 * C + c] = rmj[c]; }
+		rowbuf[3 * C] = (uint32_t)i0;
 	}
 
 	/* Sequential form (needed as soon as a Z-drop test is active): the scalar reference's per-row epilogue
@@ -348,9 +357,11 @@ struct K2aLanePk {
 	}
 
 	/* Local form (no Z-drop test anywhere in the wavefront, so nothing can stop early): every lane keeps its own best
-	 * (max, row, column) and best end-of-query (mqe, row) for both alignments in packed registers.  "H > max" in row
-	 * order == first row reaching the maximum; a lane sees its rows in increasing order, and the final merge across
-	 * lanes (k2a_merge_local) breaks ties towards the smaller row, so the result is the sequential one. */
+	 * (max, row, column) and best end-of-query (mqe, row) for both alignments in packed registers, and ALL lanes of the
+	 * group share the rows of the strip that just ended (row c goes to lane c mod G), so an epilogue costs ceil(C / G)
+	 * row updates of latency instead of C.  "H > max" in row order == first row reaching the maximum; every lane sees
+	 * its rows in increasing order (inside a strip and from strip to strip), and the final merge across lanes
+	 * (k2a_merge_local) breaks ties towards the smaller row, so the result is the sequential one. */
 	k2a_pk lmax, lmax_t, lmax_q, lmqe, lmqe_t;
 	k2a_pk last_h, last_m, last_j;         /* last target row: H(tlen-1, last column), row max, arg-max */
 
@@ -360,11 +371,12 @@ struct K2aLanePk {
 		last_h = last_m = last_j = 0;
 	}
 
-	K2A_FN void do_fin_local(const K2aScoring &sc, const uint32_t *rowbuf)
+	K2A_FN void fin_local_rows(const K2aScoring &sc, const uint32_t *rowbuf)
 	{
+		const int fi0 = (int)rowbuf[3 * C];                                    /* first row of the strip that ended */
 #pragma nounroll
-		for (int c = 0; c < C; ++c) {
-			const int i = i0 + c;
+		for (int c = gl; c < C; c += G) {
+			const int i = fi0 + c;
 			const k2a_pk bias = k2a_pk2(sc.e * i);
 			const k2a_pk pj = rowbuf[2 * C + c], ipk = k2a_pk2(i);
 			/* un-bias; rows past the target end hold -inf, which must stay below every real score */
@@ -381,8 +393,8 @@ struct K2aLanePk {
 			lmqe = k2a_pk_sel(uq, ph, lmqe);
 			if (i == tlen_full - 1 && tlen == tlen_full) { last_h = ph; last_m = pm; last_j = pj; }   /* mte / mte_q / score */
 		}
-		S = -1; je = -1; kfin = K2A_KNONE; rows_m1 = -1;
 	}
+	K2A_FN void end_strip() { S = -1; je = -1; kfin = K2A_KNONE; rows_m1 = -1; }
 };
 
 /* Traceback walk for one alignment (half = 0/1) of a packed task: direction bytes in the reference layout at byte

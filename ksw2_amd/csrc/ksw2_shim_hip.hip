@@ -140,7 +140,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	constexpr int NG = 64 / G;
 	typedef K2aLanePk<G, C, DUAL, MODE, RB> Lane;
 	__shared__ K2aBook book[K2A_WPB][NG][2];
-	__shared__ uint32_t stage[K2A_WPB][(NG * 3 * C > 64 * 5) ? NG * 3 * C : 64 * 5];   /* row buffers / final lane records */
+	__shared__ uint32_t stage[K2A_WPB][(NG * K2A_PK_STAGE(C) > 64 * 5) ? NG * K2A_PK_STAGE(C) : 64 * 5];   /* row buffers / final lane records */
 
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int grp = lane / G, gl = lane % G;
@@ -201,14 +201,21 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 		}
 
 		const bool nfin = L.need_fin(k);
-		if (__builtin_amdgcn_ballot_w64(nfin) != 0) {
-			uint32_t *rowbuf = &stage[wave][grp * 3 * C];
+		const uint64_t finmask = __builtin_amdgcn_ballot_w64(nfin);
+		if (finmask != 0) {
+			uint32_t *rowbuf = &stage[wave][grp * K2A_PK_STAGE(C)];
 			if (nfin) L.stage_rows(rowbuf);
 			if (zseq) {
 				if (nfin) L.do_fin_seq(sc, bkA, bkB, zdropA, zdropB, rowbuf);
 				__builtin_amdgcn_wave_barrier();
 				if (bkA->dropped && bkB->dropped) gdone = true;
-			} else if (nfin) L.do_fin_local(sc, rowbuf);
+			} else {
+				/* at most one strip per group ends at a step; all lanes of that group share its rows */
+				__builtin_amdgcn_wave_barrier();
+				if (((finmask >> (grp * G)) & (G == 64 ? ~0ull : (1ull << (G & 63)) - 1)) != 0) L.fin_local_rows(sc, rowbuf);
+				if (nfin) L.end_strip();
+				__builtin_amdgcn_wave_barrier();
+			}
 		}
 		L.qb = qnext;
 		if (zseq && __builtin_amdgcn_ballot_w64(!(gdone || k >= klast)) == 0) break;   /* only a Z-drop ends a group early */
@@ -226,8 +233,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 			bkA->rows = bkB->rows = prA.tlen;
 		}
 		__builtin_amdgcn_wave_barrier();
-		const int Slast = (prA.tlen_full - 1) / C;
-		if (valid && prA.tlen == prA.tlen_full && gl == Slast % G) {
+		if (valid && prA.tlen == prA.tlen_full && gl == ((prA.tlen_full - 1) % C) % G) {   /* the lane that took the last row */
 			const bool reach = prA.tlen_full - 1 + prA.w >= prA.qlen - 1;
 			bkA->mte = k2a_pk_lo(L.last_m); bkA->mte_q = k2a_pk_lo(L.last_j);
 			bkB->mte = k2a_pk_hi(L.last_m); bkB->mte_q = k2a_pk_hi(L.last_j);

@@ -5,6 +5,7 @@
  * tests/sim/libksw2_amd_sim.so so the packing / geometry / scheduling / bookkeeping logic can be checked
  * against the oracle in the CPU test tier.  It is never part of the product library libksw2_amd.so.
  */
+#include <assert.h>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -109,7 +110,7 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 		static Lane L[64];
 		K2aBook book[NG][2];
 		K2aPair prA[64];
-		uint32_t piA[64], piB[64], stage[(NG * 3 * C > 64 * 5) ? NG * 3 * C : 64 * 5];
+		uint32_t piA[64], piB[64], stage[(NG * K2A_PK_STAGE(C) > 64 * 5) ? NG * K2A_PK_STAGE(C) : 64 * 5];
 		int zdA[64], zdB[64], klast[64], kmax = -1, ktop = -1;
 		bool valid[64], gdone[64], zseq = RB;
 		for (int lane = 0; lane < 64; ++lane) {
@@ -162,13 +163,21 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 				anyfin |= nfin[lane];
 			}
 			if (anyfin) {
+				bool gfin[NG];
+				for (int g = 0; g < NG; ++g) gfin[g] = false;
 				for (int lane = 0; lane < 64; ++lane) {
 					if (!nfin[lane]) continue;
-					uint32_t *rowbuf = &stage[(lane / G) * 3 * C];
+					uint32_t *rowbuf = &stage[(lane / G) * K2A_PK_STAGE(C)];
+					assert(!gfin[lane / G]);                          /* one strip per group and step */
+					gfin[lane / G] = true;
 					L[lane].stage_rows(rowbuf);
 					if (zseq) L[lane].do_fin_seq(sc, &book[lane / G][0], &book[lane / G][1], zdA[lane], zdB[lane], rowbuf);
-					else L[lane].do_fin_local(sc, rowbuf);
 				}
+				if (!zseq)
+					for (int lane = 0; lane < 64; ++lane) {
+						if (gfin[lane / G]) L[lane].fin_local_rows(sc, &stage[(lane / G) * K2A_PK_STAGE(C)]);
+						if (nfin[lane]) L[lane].end_strip();
+					}
 				if (zseq)
 					for (int lane = 0; lane < 64; ++lane)
 						if (book[lane / G][0].dropped && book[lane / G][1].dropped) gdone[lane] = true;
@@ -193,7 +202,7 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 				}
 			for (int lane = 0; lane < 64; ++lane) {
 				const K2aPair &pr = prA[lane];
-				if (valid[lane] && pr.tlen == pr.tlen_full && lane % G == ((pr.tlen_full - 1) / C) % G) {
+				if (valid[lane] && pr.tlen == pr.tlen_full && lane % G == ((pr.tlen_full - 1) % C) % G) {
 					K2aBook *a = &book[lane / G][0], *b = &book[lane / G][1];
 					a->mte = k2a_pk_lo(L[lane].last_m); a->mte_q = k2a_pk_lo(L[lane].last_j);
 					b->mte = k2a_pk_hi(L[lane].last_m); b->mte_q = k2a_pk_hi(L[lane].last_j);

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 output of tools/scripts/profile_round.sh into the files kept under profiles/:
+<tag>_<workload>_kernel_stats.csv (verbatim --stats table) and <tag>_<workload>_pmc.json (counter means per launch of
+every kernel + derived figures for the dominant one; HBM bytes corrected as MI355X_MICROARCH.md's HBM section says)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "")
+
+
+def main():
+    tag, wl, out, dst, steps = sys.argv[1:6]
+    os.makedirs(dst, exist_ok=True)
+    ks = glob.glob(os.path.join(out, "kt", "**", "*kernel_stats.csv"), recursive=True)
+    if ks:
+        shutil.copy(ks[0], os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, wl)))
+    per = {}          # kernel -> counter -> [sum, dispatches]
+    for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+        disp = {}
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            key = (k, r["Dispatch_Id"], r["Counter_Name"])
+            disp[key] = disp.get(key, 0.0) + float(r["Counter_Value"])
+        for (k, _, c), v in disp.items():
+            e = per.setdefault(k, {}).setdefault(c, [0.0, 0])
+            e[0] += v
+            e[1] += 1
+    kernels = {k: {c: s / n for c, (s, n) in cs.items()} for k, cs in per.items()}
+    trace = {}
+    for f in glob.glob(os.path.join(out, "kt", "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            e = trace.setdefault(short(r["Kernel_Name"]), [0.0, 0])
+            e[0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
+            e[1] += 1
+    res = {"command": "rocprofv3 --kernel-trace [--stats | --pmc <counters>] --output-format csv -- python3 bench.py --workload %s --steps %s "
+                      "--warmup 2 --no-cpu  (one pass per counter group, MI355X)" % (wl, steps),
+           "kernel_trace_ms": {k: {"launches": n, "avg_ms": s / n, "total_ms": s} for k, (s, n) in trace.items()},
+           "per_launch": kernels, "derived": {}}
+    if trace:
+        dom = max(trace, key=lambda k: trace[k][0])
+        c = kernels.get(dom, {})
+        d = res["derived"]
+        d["dominant_kernel"] = dom
+        d["avg_ms"] = trace[dom][0] / trace[dom][1]
+        if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
+            rd, wr = c.get("FETCH_SIZE", 0.0) * 1024, c.get("WRITE_SIZE", 0.0) * 1024      # counters are in KB
+            d["hbm_bytes_uncorrected"] = rd + wr
+            d["hbm_bytes_gfx950_corrected"] = 2 * rd + wr
+            d["note"] = "gfx950 FETCH_SIZE counts 64 B per 128-B request (MI355X_MICROARCH.md, HBM section): read side doubled"
+        if "SQ_INSTS_VALU" in c and "SQ_WAVES" in c and c["SQ_WAVES"]:
+            d["valu_insts_per_wave"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
+            d["salu_insts_per_wave"] = c.get("SQ_INSTS_SALU", 0.0) / c["SQ_WAVES"]
+        if "GRBM_GUI_ACTIVE" in c and "SQ_ACTIVE_INST_VALU" in c:
+            cyc = c["GRBM_GUI_ACTIVE"] / 8.0                       # summed over 8 XCDs
+            d["shader_cycles_per_xcd"] = cyc
+            d["shader_clock_GHz"] = cyc / (d["avg_ms"] * 1e6)
+            # SQ_ACTIVE_INST_VALU is in quad-cycles, summed over the 1024 SIMDs
+            d["valu_pipe_busy_fraction"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 1024)
+            d["valu_cycles_per_inst"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"] if c.get("SQ_INSTS_VALU") else None
+            d["mean_resident_waves_per_simd"] = c.get("SQ_WAVE_CYCLES", 0.0) * 4.0 / (cyc * 1024)
+    with open(os.path.join(dst, "%s_%s_pmc.json" % (tag, wl)), "w") as fp:
+        json.dump(res, fp, indent=1)
+    print(json.dumps(res["derived"], indent=1))
+
+
+if __name__ == "__main__":
+    main()
