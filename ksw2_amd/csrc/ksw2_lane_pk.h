@@ -28,7 +28,7 @@
 
 #include "ksw2_lane.h"
 
-#define K2A_PK_STAGE(C) (3 * (C) + 2)    /* LDS words per lane group for a strip's staged rows: H, row max, arg-max, first row */
+#define K2A_PK_STAGE(C) (3 * (C) + 4)    /* LDS words per lane group for a strip's staged rows: H, row max, arg-max; first row, bases */
 typedef uint32_t k2a_pk;                 /* { int16 lo = alignment A, int16 hi = alignment B } */
 #define K2A_NEG16 (-16384)
 
@@ -44,6 +44,7 @@ typedef unsigned short k2a_u2 __attribute__((ext_vector_type(2)));
 K2A_FN k2a_pk k2a_pk_add(k2a_pk a, k2a_pk b) { return __builtin_bit_cast(k2a_pk, (k2a_s2)(__builtin_bit_cast(k2a_s2, a) + __builtin_bit_cast(k2a_s2, b))); }
 K2A_FN k2a_pk k2a_pk_sub(k2a_pk a, k2a_pk b) { return __builtin_bit_cast(k2a_pk, (k2a_s2)(__builtin_bit_cast(k2a_s2, a) - __builtin_bit_cast(k2a_s2, b))); }
 K2A_FN k2a_pk k2a_pk_max(k2a_pk a, k2a_pk b) { return __builtin_bit_cast(k2a_pk, __builtin_elementwise_max(__builtin_bit_cast(k2a_s2, a), __builtin_bit_cast(k2a_s2, b))); }
+K2A_FN k2a_pk k2a_pk_min(k2a_pk a, k2a_pk b) { return __builtin_bit_cast(k2a_pk, __builtin_elementwise_min(__builtin_bit_cast(k2a_s2, a), __builtin_bit_cast(k2a_s2, b))); }
 K2A_FN k2a_pk k2a_pk_minu(k2a_pk a, k2a_pk b)
 {
 	k2a_pk d;      /* asm keeps this arithmetic: hipcc would turn min(x,1)*k back into compare + select per half */
@@ -80,6 +81,7 @@ K2A_FN k2a_pk k2a_pk_mk(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((ui
 K2A_FN k2a_pk k2a_pk_add(k2a_pk a, k2a_pk b) { return k2a_pk_mk(k2a_pk_lo(a) + k2a_pk_lo(b), k2a_pk_hi(a) + k2a_pk_hi(b)); }
 K2A_FN k2a_pk k2a_pk_sub(k2a_pk a, k2a_pk b) { return k2a_pk_mk(k2a_pk_lo(a) - k2a_pk_lo(b), k2a_pk_hi(a) - k2a_pk_hi(b)); }
 K2A_FN k2a_pk k2a_pk_max(k2a_pk a, k2a_pk b) { return k2a_pk_mk(k2a_max(k2a_pk_lo(a), k2a_pk_lo(b)), k2a_max(k2a_pk_hi(a), k2a_pk_hi(b))); }
+K2A_FN k2a_pk k2a_pk_min(k2a_pk a, k2a_pk b) { return k2a_pk_mk(k2a_min(k2a_pk_lo(a), k2a_pk_lo(b)), k2a_min(k2a_pk_hi(a), k2a_pk_hi(b))); }
 K2A_FN k2a_pk k2a_pk_minu(k2a_pk a, k2a_pk b)
 {
 	const uint32_t al = a & 0xffffu, ah = a >> 16, bl = b & 0xffffu, bh = b >> 16;
@@ -316,6 +318,7 @@ struct K2aLanePk {
 #pragma unroll
 		for (int c = 0; c < C; ++c) { rowbuf[c] = hl[c]; rowbuf[C + c] = rmax[c]; rowbuf[2 * C + c] = rmj[c]; }
 		rowbuf[3 * C] = (uint32_t)i0;
+		if (RB) { rowbuf[3 * C + 1] = (uint32_t)baseA; rowbuf[3 * C + 2] = (uint32_t)baseB; }
 	}
 
 	/* Sequential form (needed as soon as a Z-drop test is active): the scalar reference's per-row epilogue
@@ -354,6 +357,44 @@ struct K2aLanePk {
 			b->mte = bmte; b->mte_q = bmte_q; b->score = bscore; b->dropped = bdrop; b->rows = brows;
 		}
 		S = -1; je = -1; kfin = K2A_KNONE; rows_m1 = -1;
+	}
+
+	/* Shortcut in front of the sequential form, in registers and for both alignments at once.  For a full strip that
+	 * neither holds the last target row nor reaches the query end, all the sequential scan can do is (a) move the
+	 * running maximum to the first row of the strip that beats it and (b) Z-drop.  With M = max(book max, strip max) and
+	 * m = the smallest row maximum of the strip, no row can drop when M - m <= zdrop (its own test sees at most M - m on the
+	 * left and at least zdrop on the right), and then (a) is a plain first-occurrence arg-max over the C rows.
+	 * Returns false -- having written nothing -- whenever any of this does not hold; the caller then runs do_fin_seq. */
+	K2A_FN bool fin_fast(const K2aScoring &sc, K2aBook *bA, K2aBook *bB, int zdropA, int zdropB)
+	{
+		if (i0 + C >= tlen || i0 + C - 1 + w >= qlen - 1) return false;
+		/* rows compare without their bias: v_c = rmax[c] - e*c = H(row) + (e*i0 - base) */
+		k2a_pk m = rmax[0], mn = rmax[0], arg = 0, argj = rmj[0];
+#pragma unroll
+		for (int c = 1; c < C; ++c) {
+			const k2a_pk v = k2a_pk_sub(rmax[c], k2a_pk2(sc.e * c));
+			const k2a_pk gt = k2a_pk_sign(k2a_pk_sub(m, v));                        /* strictly larger: first row keeps a tie */
+			arg = k2a_pk_sel(gt, k2a_pk2(c), arg);
+			argj = k2a_pk_sel(gt, rmj[c], argj);
+			m = k2a_pk_max(m, v);
+			mn = k2a_pk_min(mn, v);
+		}
+		const int offA = (RB ? baseA : 0) - sc.e * i0, offB = (RB ? baseB : 0) - sc.e * i0;
+		const int MA = k2a_pk_lo(m) + offA, MB = k2a_pk_hi(m) + offB, mA = k2a_pk_lo(mn) + offA, mB = k2a_pk_hi(mn) + offB;
+		const int bmA = bA->max, bmB = bB->max;
+		const bool deadA = bA->dropped != 0, deadB = bB->dropped != 0;
+		if (!deadA && zdropA >= 0 && k2a_max(bmA, MA) - mA > zdropA) return false;
+		if (!deadB && zdropB >= 0 && k2a_max(bmB, MB) - mB > zdropB) return false;
+		if (!deadA) {
+			if (MA > bmA) { bA->max = MA; bA->max_t = i0 + k2a_pk_lo(arg); bA->max_q = k2a_pk_lo(argj); }
+			bA->rows = i0 + C;
+		}
+		if (!deadB) {
+			if (MB > bmB) { bB->max = MB; bB->max_t = i0 + k2a_pk_hi(arg); bB->max_q = k2a_pk_hi(argj); }
+			bB->rows = i0 + C;
+		}
+		end_strip();
+		return true;
 	}
 
 	/* Local form (no Z-drop test anywhere in the wavefront, so nothing can stop early): every lane keeps its own best

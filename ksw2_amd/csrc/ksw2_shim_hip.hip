@@ -204,15 +204,20 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 		const uint64_t finmask = __builtin_amdgcn_ballot_w64(nfin);
 		if (finmask != 0) {
 			uint32_t *rowbuf = &stage[wave][grp * K2A_PK_STAGE(C)];
-			if (nfin) L.stage_rows(rowbuf);
 			if (zseq) {
-				if (nfin) L.do_fin_seq(sc, bkA, bkB, zdropA, zdropB, rowbuf);
-				__builtin_amdgcn_wave_barrier();
-				if (bkA->dropped && bkB->dropped) gdone = true;
+				/* most strips fold into the books from registers; the rest take the row-by-row scan */
+				const bool slow = nfin && !L.fin_fast(sc, bkA, bkB, zdropA, zdropB);
+				if (__builtin_amdgcn_ballot_w64(slow) != 0) {
+					if (slow) { L.stage_rows(rowbuf); L.do_fin_seq(sc, bkA, bkB, zdropA, zdropB, rowbuf); }
+					__builtin_amdgcn_wave_barrier();
+					if (bkA->dropped && bkB->dropped) gdone = true;
+				}
 			} else {
 				/* at most one strip per group ends at a step; all lanes of that group share its rows */
+				const bool gfin = ((finmask >> (grp * G)) & (G == 64 ? ~0ull : (1ull << (G & 63)) - 1)) != 0;
+				if (nfin) L.stage_rows(rowbuf);
 				__builtin_amdgcn_wave_barrier();
-				if (((finmask >> (grp * G)) & (G == 64 ? ~0ull : (1ull << (G & 63)) - 1)) != 0) L.fin_local_rows(sc, rowbuf);
+				if (gfin) L.fin_local_rows(sc, rowbuf);
 				if (nfin) L.end_strip();
 				__builtin_amdgcn_wave_barrier();
 			}

@@ -170,8 +170,12 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 					uint32_t *rowbuf = &stage[(lane / G) * K2A_PK_STAGE(C)];
 					assert(!gfin[lane / G]);                          /* one strip per group and step */
 					gfin[lane / G] = true;
-					L[lane].stage_rows(rowbuf);
-					if (zseq) L[lane].do_fin_seq(sc, &book[lane / G][0], &book[lane / G][1], zdA[lane], zdB[lane], rowbuf);
+					if (zseq) {
+						if (!L[lane].fin_fast(sc, &book[lane / G][0], &book[lane / G][1], zdA[lane], zdB[lane])) {
+							L[lane].stage_rows(rowbuf);
+							L[lane].do_fin_seq(sc, &book[lane / G][0], &book[lane / G][1], zdA[lane], zdB[lane], rowbuf);
+						}
+					} else L[lane].stage_rows(rowbuf);
 				}
 				if (!zseq)
 					for (int lane = 0; lane < 64; ++lane) {
