@@ -99,7 +99,7 @@ void ksw_extd2_sse2(void *km, int qlen, const uint8_t *query, int tlen, const ui
 
 /* scoring shared by every pair of a batch (the arguments m, mat, q, e[, q2, e2] of the calls above) */
 typedef struct {
-	int32_t m;                 /* residue codes 0..m-1, last one is the wildcard; m <= 5 in this release */
+	int32_t m;                 /* residue codes 0..m-1, last one is the wildcard (m <= 127) */
 	const int8_t *mat;         /* m*m, mat[target*m + query] */
 	int8_t q, e, q2, e2;       /* q2/e2 only read by the two-piece (extd) entry points */
 } ksw2amd_scoring_t;

@@ -188,19 +188,29 @@ static int cfg_fits(int cfg, int tlen_eff, int w)
 	return geom_fits(k2a_cfg_G[cfg], k2a_cfg_C[cfg], tlen_eff, w);
 }
 
-static void build_scoring(int dual, int m, const int8_t *mat, int q, int e, int q2, int e2, int generic, K2aScoring *sc)
+/* the scores the kernels use: the caller's matrix with KSW_EZ_GENERIC_SC, else match / mismatch / wildcard built from
+ * mat[0], mat[1] and the last entry (ksw2_extz2_sse.c:66-69,125-140; ksw2_extd2_sse.c:85-88,166-180) */
+static void build_eff(int dual, int m, const int8_t *mat, int e, int e2, int generic, int8_t *eff)
 {
-	int8_t eff[25];
 	int a, b;
-	memset(sc, 0, sizeof(*sc));
-	sc->q = q; sc->e = e; sc->q2 = dual ? q2 : 0; sc->e2 = dual ? e2 : 0;
 	if (generic) memcpy(eff, mat, (size_t)m * m);
-	else {   /* ksw2_extz2_sse.c:66-69,125-140; ksw2_extd2_sse.c:85-88,166-180 */
+	else {
 		int scN = mat[m * m - 1] == 0 ? -(dual ? e2 : e) : mat[m * m - 1];
 		for (a = 0; a < m; ++a)
 			for (b = 0; b < m; ++b)
 				eff[a * m + b] = (int8_t)((a == m - 1 || b == m - 1) ? scN : a == b ? mat[0] : mat[1]);
 	}
+}
+
+static void build_scoring(int dual, int m, const int8_t *mat, int q, int e, int q2, int e2, int generic, K2aScoring *sc)
+{
+	int8_t eff[K2A_MAXM * K2A_MAXM];
+	int a, b;
+	memset(sc, 0, sizeof(*sc));
+	sc->q = q; sc->e = e; sc->q2 = dual ? q2 : 0; sc->e2 = dual ? e2 : 0;
+	sc->m = m;
+	build_eff(dual, m, mat, e, e2, generic, eff);
+	if (m > 5) return;                                     /* wide alphabets read the matrix itself (sc->mat, set once it is uploaded) */
 	for (a = 0; a < m; ++a) {
 		uint32_t p = 0;
 		for (b = 0; b < 4 && b < m; ++b) p |= (uint32_t)(uint8_t)eff[a * m + b] << (8 * b);
@@ -301,7 +311,7 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 {
 	ksw2amd_plan_t *p;
 	int i, k, q, e, q2, e2, m, lo, ci;
-	size_t off;
+	size_t off, mat_off = 0;
 	sort_t *srt = 0;
 	pkinfo_t pkinfo[2];
 	uint8_t *pk_ok = 0;
@@ -325,7 +335,7 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 	{
 		int scalar = n > 0 && (pairs[0].flag & F_SCALAR_CONTRACT);
 		if (m <= 0 || (dual && m <= 1) || !sc->mat) p->reject_all = 1;
-		else if (m > 5) { fail(KSW2AMD_E_PARAM, "m > 5 residue types is not supported by this release%s", 0); goto err; }
+		else if (m > K2A_MAXM) { fail(KSW2AMD_E_PARAM, "more than 127 residue types (int8_t m, ksw2.h:61)%s", 0); goto err; }
 		else {
 			/* ksw2_extd2_sse.c:78: cheaper-to-open piece first (the scalar ksw_extd keeps the caller's order) */
 			if (dual && !scalar && q2 + e2 < q + e) { int t = q; q = q2; q2 = t; t = e; e = e2; e2 = t; }
@@ -477,7 +487,9 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 			if (ib != ia) p->h_half[ib] = 2;
 		}
 	}
-	p->seq_bytes = align_up(off + 65536, 256);      /* idle lanes may prefetch codes a few hundred bytes past the last pair */
+	off = align_up(off + 65536, 256);               /* idle lanes may prefetch codes a few hundred bytes past the last pair */
+	if (m > 5) { mat_off = off; off = align_up(off + 2 * (size_t)m * m, 256); }   /* wide alphabets: effective matrices, simple | generic */
+	p->seq_bytes = off;
 
 	/* pack (pinned staging, so the upload runs at PCIe speed) + upload */
 	p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, p->seq_bytes, &p->cap[BUF_HSEQ]);
@@ -487,6 +499,10 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 		memcpy(p->h_seq + p->h_pairs[i].qoff, pairs[i].query, (size_t)pairs[i].qlen);
 		memcpy(p->h_seq + p->h_pairs[i].toff, pairs[i].target, (size_t)pairs[i].tlen);
 		memset(p->h_seq + p->h_pairs[i].toff + pairs[i].tlen, 0, 64);        /* rows read past the target end */
+	}
+	if (m > 5) {
+		build_eff(dual, m, sc->mat, e, e2, 0, (int8_t*)p->h_seq + mat_off);
+		build_eff(dual, m, sc->mat, e, e2, 1, (int8_t*)p->h_seq + mat_off + (size_t)m * m);
 	}
 	p->d_seq = (uint8_t*)cache_get(BUF_SEQ, p->seq_bytes, &p->cap[BUF_SEQ]);
 	p->d_pairs = (K2aPair*)cache_get(BUF_PAIRS, sizeof(K2aPair) * ((size_t)n + 1), &p->cap[BUF_PAIRS]);
@@ -507,6 +523,7 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 		fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error());
 		goto err;
 	}
+	if (m > 5) for (k = 0; k < p->ncls; ++k) p->cls[k].sc.mat = (const int8_t*)p->d_seq + mat_off + (p->cls[k].generic ? (size_t)m * m : 0);
 	for (i = 0; i < 3; ++i) { p->ev[i] = g_ev_cache[i] ? g_ev_cache[i] : k2a_shim_event_create(); g_ev_cache[i] = 0; }
 	free(pk_ok);
 	return p;

@@ -189,12 +189,12 @@ struct K2aLane {
 	 *   hin/ein/e2in: bottom row of the strip above at this column (rotated in from the previous lane, or the
 	 *                 virtual row -1 / the boundary buffer, see the kernels)
 	 *   tbw: traceback word(s) out (MODE != SCORE)
-	 *   wild: some lane of the wavefront sees the query wildcard in this column (wave-uniform, rare): scores
+	 *   wild: some lane of the wavefront sees the query wildcard in this column (wave-uniform, rare), or m > 5: scores
 	 *         come from the per-target-code column table `ctab` instead of the 4-entry register profile; the branch
-	 *         wraps phase 1 only, so just the C candidates merge (a whole-step if/else costs ~60 registers)
+	 *         (m > 5: from the LDS copy `mtab` of the whole matrix); the branch wraps phase 1 only, so just the C candidates merge (a whole-step if/else costs ~60 registers)
 	 * Phase 1 forms every row's diagonal candidate H(i-1,j-1) + s(i,j) while the old H row is intact, phase 2 runs the
 	 * E chain down the rows and rewrites the H row in place.  Returns true when the lane computed live cells. */
-	K2A_FN bool step(const K2aScoring &sc, const uint32_t *ctab, bool wild, int k, int hin, int ein, int e2in, uint32_t *tbw)
+	K2A_FN bool step(const K2aScoring &sc, const uint32_t *ctab, const int8_t *mtab, bool wild, int k, int hin, int ein, int e2in, uint32_t *tbw)
 	{
 		const int jj = k - koff;
 		const int dd = k - kd;                               /* jj - i0 */
@@ -214,12 +214,18 @@ struct K2aLane {
 		if (!wild) {
 #pragma unroll
 			for (int c = 0; c < C; ++c) cand[c] = (c == 0 ? hd0 : hl[c - 1]) + (int)(int8_t)(P[c] >> qsh);
-		} else {
+		} else if (sc.m <= 5) {
 #pragma unroll
 			for (int c = 0; c < C; ++c) {
 				const uint32_t tb = (tbp[c >> 2] >> (8 * (c & 3))) & 0xff;
 				const int sw = (int)ctab[tb < 4 ? tb : 4];
 				cand[c] = (c == 0 ? hd0 : hl[c - 1]) + (qwild ? sw : (int)(int8_t)(P[c] >> qsh));
+			}
+		} else {                                             /* wide alphabets: one LDS byte per cell, mat[target*m + query] */
+#pragma unroll
+			for (int c = 0; c < C; ++c) {
+				const uint32_t tb = (tbp[c >> 2] >> (8 * (c & 3))) & 0xff;
+				cand[c] = (c == 0 ? hd0 : hl[c - 1]) + (int)mtab[tb * (uint32_t)sc.m + (uint32_t)qcode];
 			}
 		}
 		uint32_t tw[TBWORDS];

@@ -52,7 +52,9 @@ k2a_fill_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const ui
 	__shared__ K2aBook book[K2A_WPB][NG];
 	__shared__ uint32_t tabs[16];                     /* [0..4] row profiles, [8..12] scores against the query wildcard */
 	__shared__ int rowbuf[K2A_WPB][NG][3 * C];        /* strip epilogue staging */
+	__shared__ int8_t mtab[K2A_MAXM * K2A_MAXM];      /* m > 5: the whole matrix, one byte per residue pair */
 	if (threadIdx.x < 5) { tabs[threadIdx.x] = sc.prof[threadIdx.x]; tabs[8 + threadIdx.x] = (uint32_t)sc.colw[threadIdx.x]; }
+	if (sc.m > 5) for (int x = threadIdx.x; x < sc.m * sc.m; x += blockDim.x) mtab[x] = sc.mat[x];
 	__syncthreads();
 
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -99,8 +101,8 @@ k2a_fill_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const ui
 		if (k <= ktop) L.top_inputs(sc, k, hin, ein, e2in);
 
 		uint32_t tw[Lane::TBWORDS];
-		const bool wild = __builtin_amdgcn_ballot_w64(L.qb >= 4) != 0;
-		const bool live = L.step(sc, tabs + 8, wild, k, hin, ein, e2in, tw);
+		const bool wild = sc.m > 5 || __builtin_amdgcn_ballot_w64(L.qb >= 4) != 0;
+		const bool live = L.step(sc, tabs + 8, mtab, wild, k, hin, ein, e2in, tw);
 		if (MODE != K2A_MODE_SCORE) {
 			if (live) {
 				uint32_t *dst = (uint32_t*)(tbp + k2a_tb_word((size_t)k, gl, tbsteps, G, Lane::TBWORDS * 4));
@@ -267,7 +269,9 @@ k2a_fill_mp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	__shared__ K2aBook book[K2A_WPB];
 	__shared__ int rowbuf[K2A_WPB][3 * C];
 	__shared__ uint32_t tabs[16];
+	__shared__ int8_t mtab[K2A_MAXM * K2A_MAXM];      /* m > 5: the whole matrix, one byte per residue pair */
 	if (threadIdx.x < 5) { tabs[threadIdx.x] = sc.prof[threadIdx.x]; tabs[8 + threadIdx.x] = (uint32_t)sc.colw[threadIdx.x]; }
+	if (sc.m > 5) for (int x = threadIdx.x; x < sc.m * sc.m; x += blockDim.x) mtab[x] = sc.mat[x];
 	__syncthreads();
 
 	const int gl = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -335,8 +339,8 @@ k2a_fill_mp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 			uint32_t tw[Lane::TBWORDS];
 			const int jj = L.column(k);
 			const bool mine = L.S >= 0 && jj >= 0 && jj <= L.je;
-			const bool wild = __builtin_amdgcn_ballot_w64(L.qb >= 4) != 0;
-			const bool live = L.step(sc, tabs + 8, wild, k, hin, ein, e2in, tw);
+			const bool wild = sc.m > 5 || __builtin_amdgcn_ballot_w64(L.qb >= 4) != 0;
+			const bool live = L.step(sc, tabs + 8, mtab, wild, k, hin, ein, e2in, tw);
 			if (MODE != K2A_MODE_SCORE) {
 				if (live) {
 					uint32_t *dst = (uint32_t*)(tbp + k2a_tb_word(kbase + (size_t)k, gl, tbsteps, G, Lane::TBWORDS * 4));

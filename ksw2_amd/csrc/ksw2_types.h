@@ -9,6 +9,7 @@
 
 #define K2A_NEG      (-0x40000000)
 #define K2A_KNONE    0x7fffffff
+#define K2A_MAXM     127             /* residue types (int8_t m, ksw2.h:61) */
 
 /* flag bits the device code looks at (numerically the KSW_EZ_* values, ksw2.h:8-18) */
 #define K2A_F_SCORE_ONLY 0x01
@@ -26,6 +27,8 @@ typedef struct K2aScoring {
 	uint32_t prof[5];            /* prof[t] = bytes { s(t,0), s(t,1), s(t,2), s(t,3) } for target code t   */
 	int32_t colw[5];             /* colw[t] = s(t, 4): score against the query wildcard (code 4)          */
 	int32_t pk_a, pk_b, pk_n;    /* match / mismatch / wildcard score when the matrix has that structure   */
+	int32_t m;                   /* residue types; m > 5: scores come from `mat` (staged in LDS), prof/colw unused */
+	const int8_t *mat;           /* device copy of the effective m x m matrix, mat[target*m + query]       */
 } K2aScoring;
 
 /* one alignment, device-resident */

@@ -18,19 +18,19 @@ def oracle_batch(dual, qs, ts, mat, q, e, q2, e2, w, zdrop, end_bonus, flag):
                      end_bonus=int(end_bonus[i]), flag=int(flag[i])) for i in range(n)]
 
 
-def check_batch(lib, dual, qs, ts, mat, q, e, q2, e2, w=-1, zdrop=-1, end_bonus=0, flag=0, sample=None, fields=CMP_FIELDS):
+def check_batch(lib, dual, qs, ts, mat, q, e, q2, e2, w=-1, zdrop=-1, end_bonus=0, flag=0, sample=None, fields=CMP_FIELDS, m=None):
     """Run the batch through lib, compare (all pairs, or the index list `sample`) with the oracle; returns #checked."""
     if dual:
-        res = lib.extd_batch(qs, ts, mat, q, e, q2, e2, w=w, zdrop=zdrop, end_bonus=end_bonus, flag=flag)
+        res = lib.extd_batch(qs, ts, mat, q, e, q2, e2, w=w, zdrop=zdrop, end_bonus=end_bonus, flag=flag, m=m)
     else:
-        res = lib.extz_batch(qs, ts, mat, q, e, w=w, zdrop=zdrop, end_bonus=end_bonus, flag=flag)
+        res = lib.extz_batch(qs, ts, mat, q, e, w=w, zdrop=zdrop, end_bonus=end_bonus, flag=flag, m=m)
     n = len(qs)
     idx = range(n) if sample is None else sample
     bc = lambda v: np.full(n, v) if np.ndim(v) == 0 else np.asarray(v)
     w, zdrop, end_bonus, flag = bc(w), bc(zdrop), bc(end_bonus), bc(flag)
     for i in idx:
         exp = po.align("oracle", "extd2" if dual else "extz2", qs[i], ts[i], mat, q, e, q2, e2, w=int(w[i]), zdrop=int(zdrop[i]),
-                       end_bonus=int(end_bonus[i]), flag=int(flag[i]))
+                       end_bonus=int(end_bonus[i]), flag=int(flag[i]), m=m)
         d = diff(exp, res[i], fields)
         assert not d, ("pair %d dual=%s w=%d zdrop=%d flag=%d qlen=%d tlen=%d" % (i, dual, w[i], zdrop[i], flag[i], len(qs[i]), len(ts[i])),
                        {k: (exp[k], res[i][k]) for k in d if k != "cigar"})

@@ -63,7 +63,7 @@ static void sim_fill(const K2aScoring sc, const K2aPair *pairs, const uint32_t *
 				const int grp = lane / G, gl = lane % G, src = grp * G + (gl + G - 1) % G;
 				hin[lane] = L[src].hout; ein[lane] = L[src].eout; e2in[lane] = DUAL ? L[src].e2out : 0;
 			}
-			bool anyfin = false, wild = false;
+			bool anyfin = false, wild = sc.m > 5;
 			bool nfin[64];
 			for (int lane = 0; lane < 64; ++lane) {      /* init events first: the wave-uniform wildcard test follows them */
 				if (L[lane].need_init(k)) L[lane].template do_init<true>(sc, tabs);
@@ -74,7 +74,7 @@ static void sim_fill(const K2aScoring sc, const K2aPair *pairs, const uint32_t *
 				qnext[lane] = L[lane].next_query_code(k);
 				if (k <= ktop) L[lane].top_inputs(sc, k, hin[lane], ein[lane], e2in[lane]);
 				uint32_t tw[Lane::TBWORDS];
-				const bool live = L[lane].step(sc, tabs + 8, wild, k, hin[lane], ein[lane], e2in[lane], tw);
+				const bool live = L[lane].step(sc, tabs + 8, sc.mat, wild, k, hin[lane], ein[lane], e2in[lane], tw);
 				if (MODE != K2A_MODE_SCORE && live)
 					memcpy(tbp[lane] + k2a_tb_word((size_t)k, lane % G, (size_t)(klast[lane] + 1), G, Lane::TBWORDS * 4), tw, sizeof(tw));
 				nfin[lane] = L[lane].need_fin(k);
@@ -261,7 +261,7 @@ static void sim_fill_mp(const K2aScoring sc, const K2aPair *pairs, const uint32_
 					hin[0] = j < pr.qlen ? Bh[j] : K2A_NEG; ein[0] = j < pr.qlen ? Be[j] : K2A_NEG;
 					e2in[0] = (DUAL && j < pr.qlen) ? Be2[j] : K2A_NEG;
 				}
-				bool nfin[64], anyfin = false, wild = false;
+				bool nfin[64], anyfin = false, wild = sc.m > 5;
 				for (int gl = 0; gl < 64; ++gl) {
 					if (L[gl].need_init(k)) L[gl].template do_init<false>(sc, tabs);
 					L[gl].hu_prev = hin[gl];
@@ -273,7 +273,7 @@ static void sim_fill_mp(const K2aScoring sc, const K2aPair *pairs, const uint32_
 					uint32_t tw[Lane::TBWORDS];
 					const int jj = L[gl].column(k);
 					const bool mine = L[gl].S >= 0 && jj >= 0 && jj <= L[gl].je;
-					const bool live = L[gl].step(sc, tabs + 8, wild, k, hin[gl], ein[gl], e2in[gl], tw);
+					const bool live = L[gl].step(sc, tabs + 8, sc.mat, wild, k, hin[gl], ein[gl], e2in[gl], tw);
 					if (MODE != K2A_MODE_SCORE && live)
 						memcpy(tb + pr.tb_off + k2a_tb_word(kbase + (size_t)k, gl, tbsteps, G, Lane::TBWORDS * 4), tw, sizeof(tw));
 					if (gl == G - 1 && mine) { Bh[jj] = L[gl].hout; Be[jj] = L[gl].eout; if (DUAL) Be2[jj] = L[gl].e2out; }

@@ -307,6 +307,19 @@ def test_small_packed_class_goes_back_to_int32(lib, monkeypatch):
     assert (r0 == r1).all()
 
 
+def test_wide_alphabets(lib):
+    """m > 5 residue types through the int32 kernels with the matrix in LDS; the single-call entry points too."""
+    from tests.test_sim_parity import _wide_alphabet_cases
+    rng = np.random.Generator(np.random.PCG64(18))
+    for rnd in range(12):
+        m, mat, qs, ts, w, zd, fl = _wide_alphabet_cases(rng, rnd)
+        for dual in (False, True):
+            check_batch(lib, dual, qs, ts, mat, 6, 2, 20, 1, w=w, zdrop=zd, flag=fl, m=m)
+    m, mat, qs, ts, w, zd, fl = _wide_alphabet_cases(rng, 0)
+    exp = po.align("oracle", "extz2", qs[0], ts[0], mat, 6, 2, w=-1, flag=po.GENERIC_SC, m=m)
+    assert not diff(exp, lib.extz2(qs[0], ts[0], mat, 6, 2, w=-1, flag=po.GENERIC_SC, m=m))
+
+
 def test_cfg5_ont_like_mix(lib):
     """BASELINE config 5 shape: ragged ONT-like pairs, qlen in [300, 20000], 15 % indels, band 500, extd2 with
     Z-drop 400 and CIGAR.  48 pairs here (the oracle needs ~0.1 s per long pair); every field and CIGAR compared."""

@@ -104,9 +104,44 @@ def test_sim_edge_cases(sim):
         exp = po.align("oracle", "extz2", qq, tt, mat, 4, 2, w=10)
         res = sim.extz2(qq, tt, mat, 4, 2, w=10)
         assert not diff(exp, res) and res["zdropped"] == 1 and res["score"] == ka.KSW_NEG_INF
-    # m > 5 is refused loudly, not computed some other way
+    # more residue types than int8_t m can hold are refused loudly
     with pytest.raises(ka.Ksw2Error):
-        sim.extz_batch([one], [one], np.zeros(36, np.int8), 4, 2, m=6)
+        sim.extz_batch([one], [one], np.zeros(128 * 128, np.int8), 4, 2, m=128)
+
+
+def _wide_alphabet_cases(rng, rnd):
+    m = int(rng.choice([6, 21, 24, 64, 127]))
+    mat = rng.integers(-6, 3, size=(m, m)).astype(np.int8)
+    mat = np.minimum(mat, mat.T)
+    np.fill_diagonal(mat, rng.integers(2, 9, size=m))
+    mat[m - 1, :] = -1
+    mat[:, m - 1] = -1
+    n = int(rng.integers(2, 12))
+    qs, ts = [], []
+    for _ in range(n):
+        tl = int(rng.integers(1, 500))
+        t = rng.integers(0, m, tl, dtype=np.uint8)
+        qq = t.copy()
+        mask = rng.random(tl) < 0.15
+        qq[mask] = rng.integers(0, m, int(mask.sum()), dtype=np.uint8)
+        if rng.random() < 0.5 and tl > 20:
+            qq = np.delete(qq, slice(5, 5 + int(rng.integers(1, 10))))
+        qs.append(qq)
+        ts.append(t)
+    w = rng.choice([-1, 5, 30, 100], size=n)
+    zd = rng.choice([-1, 50, 200], size=n)
+    mode = [0, po.RIGHT, po.SCORE_ONLY][rnd % 3]
+    fl = np.array([mode | (po.GENERIC_SC if rng.random() < 0.7 else 0) | (po.EXTZ_ONLY if rng.random() < 0.3 else 0) for _ in range(n)])
+    return m, mat.reshape(-1).copy(), qs, ts, w, zd, fl
+
+
+def test_sim_wide_alphabets(sim):
+    """m > 5 residue types (protein-sized matrices): scores come from the LDS copy of the matrix (K2aLane::step)."""
+    rng = np.random.Generator(np.random.PCG64(8))
+    for rnd in range(9):
+        m, mat, qs, ts, w, zd, fl = _wide_alphabet_cases(rng, rnd)
+        for dual in (False, True):
+            check_batch(sim, dual, qs, ts, mat, 6, 2, 20, 1, w=w, zdrop=zd, flag=fl, m=m)
 
 
 def test_sim_eqx(sim):
