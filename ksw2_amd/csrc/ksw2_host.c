@@ -245,6 +245,8 @@ static void pk_scoring(int dual, int m, const int8_t *mat, int q, int e, int q2,
 	o->q = q; o->e = e;
 	o->qemax = dual ? imax(q + e, q2 + e2) : q + e;
 	o->qemin = dual ? imin(q + e, q2 + e2) : q + e;
+	/* the fill loop adds these as unsigned 32-bit constants to both halves at once (ksw2_lane_pk.h, offset form) */
+	if (q < 0 || e < 0 || (dual && (q2 < 0 || e2 < 0)) || o->a + e < 0 || o->a - o->b < 0) ok = 0;
 	o->ok = ok;
 }
 

@@ -18,9 +18,18 @@
  * row handed to the next lane is shifted by the difference of the two bases (`delta`, one v_pk_add per value per step),
  * and the strip epilogue adds the base back.  Re-based launches always use the sequential epilogue.
  *
+ * Number format inside the fill loop: every DP value v is held as v + 0x8000 per half ("offset" form, K2A_OFS).  Order is
+ * preserved under unsigned compare (v_pk_max_u16), differences of two values are unchanged, and -- the point -- adding
+ * or subtracting a small non-negative constant can then be ONE 32-bit v_add_u32 / v_sub_u32 for both halves, because the
+ * low half can neither carry nor borrow while values stay inside the 16-bit window.  On gfx950 v_add_u32, v_sub_u32,
+ * v_xor_b32, v_bitop3_b32 issue a wave64 in 2 cycles, every v_pk_*_i16 (and v_bfi, v_bfe, v_max_i32) in 4
+ * (tools/probe/valu_rate.hip, profiles/r1d_valu_rate.txt).  Score-only kernels also keep the target codes as two bit
+ * planes pre-multiplied with D = match - mismatch, so "mismatch ? D : 0" is xor + one v_bitop3 and the diagonal
+ * candidate is H + (match + e) - that: 8 cycles instead of 14.  Cold code (init, epilogues) converts at its edges.
+ *
  * Preconditions, checked by the host (ksw2_host.c::pk_eligible / pk_window_ok): m = 5 with a match / mismatch / wildcard score
  * structure (always true without KSW_EZ_GENERIC_SC), no wildcard code in either sequence (such pairs take the
- * int32 kernels), and every in-band H, E, F provably inside (-16384 + max(q+e, q2+e2), 16383 - max(q+e, q2+e2))
+ * int32 kernels), gap costs and match + e and match - mismatch non-negative, and every in-band H, E, F provably inside (-16384 + max(q+e, q2+e2), 16383 - max(q+e, q2+e2))
  * so that -16384 can stand for -infinity.
  */
 #ifndef KSW2_LANE_PK_H_
@@ -31,12 +40,18 @@
 #define K2A_PK_STAGE(C) (3 * (C) + 4)    /* LDS words per lane group for a strip's staged rows: H, row max, arg-max; first row, bases */
 typedef uint32_t k2a_pk;                 /* { int16 lo = alignment A, int16 hi = alignment B } */
 #define K2A_NEG16 (-16384)
+#define K2A_OFS   0x80008000u            /* offset form of the fill loop: value + 0x8000 per half */
 
 K2A_FN k2a_pk k2a_pk2(int v) { return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16); }
 K2A_FN int k2a_pk_lo(k2a_pk v) { return (int)(int16_t)(v & 0xffffu); }
 K2A_FN int k2a_pk_hi(k2a_pk v) { return (int)(int16_t)(v >> 16); }
 K2A_FN k2a_pk k2a_pk_sel(k2a_pk m, k2a_pk a, k2a_pk b) { return (m & a) | (~m & b); }   /* v_bfi / v_bitop3 */
 K2A_FN k2a_pk k2a_pair16(uint32_t lo, uint32_t hi) { return lo | (hi << 16); }                /* two small codes -> halves */
+K2A_FN k2a_pk k2a_pku(int v) { return k2a_pk2(v) ^ K2A_OFS; }                                   /* constant in offset form */
+/* both halves at once with one 32-bit op: exact as long as the low half neither carries nor borrows (offset form,
+ * non-negative addend); the simulator build runs the very same 32-bit arithmetic, so a violated range shows up there */
+K2A_FN k2a_pk k2a_add32(k2a_pk a, k2a_pk b) { return a + b; }
+K2A_FN k2a_pk k2a_sub32(k2a_pk a, k2a_pk b) { return a - b; }
 
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef short k2a_s2 __attribute__((ext_vector_type(2)));
@@ -45,6 +60,13 @@ K2A_FN k2a_pk k2a_pk_add(k2a_pk a, k2a_pk b) { return __builtin_bit_cast(k2a_pk,
 K2A_FN k2a_pk k2a_pk_sub(k2a_pk a, k2a_pk b) { return __builtin_bit_cast(k2a_pk, (k2a_s2)(__builtin_bit_cast(k2a_s2, a) - __builtin_bit_cast(k2a_s2, b))); }
 K2A_FN k2a_pk k2a_pk_max(k2a_pk a, k2a_pk b) { return __builtin_bit_cast(k2a_pk, __builtin_elementwise_max(__builtin_bit_cast(k2a_s2, a), __builtin_bit_cast(k2a_s2, b))); }
 K2A_FN k2a_pk k2a_pk_min(k2a_pk a, k2a_pk b) { return __builtin_bit_cast(k2a_pk, __builtin_elementwise_min(__builtin_bit_cast(k2a_s2, a), __builtin_bit_cast(k2a_s2, b))); }
+K2A_FN k2a_pk k2a_pk_maxu(k2a_pk a, k2a_pk b) { return __builtin_bit_cast(k2a_pk, __builtin_elementwise_max(__builtin_bit_cast(k2a_u2, a), __builtin_bit_cast(k2a_u2, b))); }
+K2A_FN k2a_pk k2a_or_xor(k2a_pk a, k2a_pk b, k2a_pk c)     /* a | (b ^ c) */
+{
+	k2a_pk d;
+	asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xf6" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+	return d;
+}
 K2A_FN k2a_pk k2a_pk_minu(k2a_pk a, k2a_pk b)
 {
 	k2a_pk d;      /* asm keeps this arithmetic: hipcc would turn min(x,1)*k back into compare + select per half */
@@ -65,8 +87,9 @@ K2A_FN k2a_pk k2a_pk_sign(k2a_pk a)     /* per half: 0xffff if negative else 0 *
 }
 K2A_FN k2a_pk k2a_pk_selv(k2a_pk m, k2a_pk a, k2a_pk b)   /* k2a_pk_sel on three registers */
 {
-	k2a_pk d;      /* asm: with the mask coming out of the asm above, hipcc expands the select into and / not / and / or */
-	asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(m), "v"(a), "v"(b));
+	k2a_pk d;      /* asm: with the mask coming out of the asm above, hipcc expands the select into and / not / and / or.
+	                * v_bitop3_b32 issues in 2 cycles per wave64, v_bfi_b32 in 4 (profiles/r1d_valu_rate.txt); 0xe4 = src2 ? src0 : src1 */
+	asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe4" : "=v"(d) : "v"(a), "v"(b), "v"(m));
 	return d;
 }
 K2A_FN k2a_pk k2a_bit_mask(uint32_t bits, int c) { return (k2a_pk)__builtin_amdgcn_sbfe((int)bits, c, 1); }
@@ -82,6 +105,12 @@ K2A_FN k2a_pk k2a_pk_add(k2a_pk a, k2a_pk b) { return k2a_pk_mk(k2a_pk_lo(a) + k
 K2A_FN k2a_pk k2a_pk_sub(k2a_pk a, k2a_pk b) { return k2a_pk_mk(k2a_pk_lo(a) - k2a_pk_lo(b), k2a_pk_hi(a) - k2a_pk_hi(b)); }
 K2A_FN k2a_pk k2a_pk_max(k2a_pk a, k2a_pk b) { return k2a_pk_mk(k2a_max(k2a_pk_lo(a), k2a_pk_lo(b)), k2a_max(k2a_pk_hi(a), k2a_pk_hi(b))); }
 K2A_FN k2a_pk k2a_pk_min(k2a_pk a, k2a_pk b) { return k2a_pk_mk(k2a_min(k2a_pk_lo(a), k2a_pk_lo(b)), k2a_min(k2a_pk_hi(a), k2a_pk_hi(b))); }
+K2A_FN k2a_pk k2a_pk_maxu(k2a_pk a, k2a_pk b)
+{
+	const uint32_t al = a & 0xffffu, ah = a >> 16, bl = b & 0xffffu, bh = b >> 16;
+	return (al > bl ? al : bl) | ((ah > bh ? ah : bh) << 16);
+}
+K2A_FN k2a_pk k2a_or_xor(k2a_pk a, k2a_pk b, k2a_pk c) { return a | (b ^ c); }
 K2A_FN k2a_pk k2a_pk_minu(k2a_pk a, k2a_pk b)
 {
 	const uint32_t al = a & 0xffffu, ah = a >> 16, bl = b & 0xffffu, bh = b >> 16;
@@ -115,7 +144,10 @@ struct K2aLanePk {
 	k2a_pk delta;                       /* RB: base of the strip above minus this strip's base, added to incoming ports */
 	uint32_t qb;                        /* { query code A, query code B } of this step's column */
 	/* rows */
-	k2a_pk hl[C], f[C], f2[DUAL ? C : 1], rmax[C], rmj[C], tc[C];
+	/* target codes as bit planes x D: one register more per row, so only where the kernel keeps its occupancy */
+	enum { PLANES = MODE == K2A_MODE_SCORE && (!DUAL || C <= 16) };
+	k2a_pk hl[C], f[C], f2[DUAL ? C : 1], rmax[C], rmj[C];       /* hl, f, f2, rmax and the ports above: offset form */
+	k2a_pk tc[C], tc1[PLANES ? C : 1];                           /* target codes {A, B}; PLANES: bit 0 / bit 1 of the codes, times D */
 
 	K2A_FN static int first_col(int S_, int w_) { return k2a_max(0, S_ * C - w_); }
 
@@ -134,13 +166,14 @@ struct K2aLanePk {
 		S = -1; i0 = 0; je = -1; koff = 0; kfin = K2A_KNONE; kd = 0; rows_m1 = -1; wup = w;
 		Snext = gl;
 		schedule_next();
-		const k2a_pk neg = k2a_pk2(K2A_NEG16);
+		const k2a_pk neg = k2a_pku(K2A_NEG16);
 		hout = eout = e2out = hd0 = hu_prev = neg; qb = 0;
 		baseA = baseB = 0; delta = 0;
 		local_reset();
 #pragma unroll
-		for (int c = 0; c < C; ++c) { hl[c] = f[c] = rmax[c] = neg; rmj[c] = 0; tc[c] = 0; if (DUAL) f2[c] = neg; }
+		for (int c = 0; c < C; ++c) { hl[c] = f[c] = rmax[c] = neg; rmj[c] = 0; tc[c] = 0; if (PLANES) tc1[c] = 0; if (DUAL) f2[c] = neg; }
 		if (!DUAL) f2[0] = 0;
+		if (!PLANES) tc1[0] = 0;
 	}
 
 	K2A_FN int last_step() const { return nstrips > 0 ? (nstrips - 1) + k2a_min(qlen - 1, tlen - 1 + w) : -1; }
@@ -157,7 +190,8 @@ struct K2aLanePk {
 		rows_m1 = k2a_min(C - 1, tlen - 1 - i0);
 		wup = w + (S == 0 ? 1 : 0);                        /* the virtual row -1 reaches one column further (E(0,w) exists) */
 		const int js = k2a_max(0, i0 - w);
-		const k2a_pk neg = k2a_pk2(K2A_NEG16);
+		const k2a_pk neg = k2a_pku(K2A_NEG16);
+		const uint32_t dmis = (uint32_t)(sc.pk_a - sc.pk_b);                 /* D */
 		/* target codes of the strip's rows, two rows per 16-bit load and alignment (C is even and targets are 16-byte
 		 * aligned, the arena is padded past the last row).  Not prefetched: one L2 round trip per strip is noise next
 		 * to the strip's ~2w+C steps. */
@@ -165,8 +199,14 @@ struct K2aLanePk {
 #pragma unroll
 		for (int c = 0; c < C; c += 2) {
 			const uint32_t ua = tpa[c >> 1], ub = tpb[c >> 1];
-			tc[c] = k2a_pair16(ua & 0xffu, ub & 0xffu);
-			if (c + 1 < C) tc[c + 1] = k2a_pair16(ua >> 8, ub >> 8);
+			const k2a_pk c0 = k2a_pair16(ua & 0xffu, ub & 0xffu), c1 = k2a_pair16(ua >> 8, ub >> 8);
+			if (PLANES) {
+				tc[c] = (c0 & 0x00010001u) * dmis; tc1[c] = ((c0 >> 1) & 0x00010001u) * dmis;
+				if (c + 1 < C) { tc[c + 1] = (c1 & 0x00010001u) * dmis; tc1[c + 1] = ((c1 >> 1) & 0x00010001u) * dmis; }
+			} else {
+				tc[c] = c0;
+				if (c + 1 < C) tc[c + 1] = c1;
+			}
 		}
 #pragma unroll
 		for (int c = 0; c < C; ++c) {
@@ -176,7 +216,7 @@ struct K2aLanePk {
 		const int hcorner = k2a_border<DUAL>(sc, i0) + sc.e * (i0 - 1);   /* H(i0-1,-1), carrying the bias of row i0-1 */
 		if (RB) {
 			/* new base = the diagonal input of the strip's first cell; hu_prev is still relative to the base above */
-			const int nbA = js == 0 ? hcorner : bsA + k2a_pk_lo(hu_prev), nbB = js == 0 ? hcorner : bsB + k2a_pk_hi(hu_prev);
+			const int nbA = js == 0 ? hcorner : bsA + k2a_pk_lo(hu_prev ^ K2A_OFS), nbB = js == 0 ? hcorner : bsB + k2a_pk_hi(hu_prev ^ K2A_OFS);
 			delta = S == 0 ? 0u : k2a_pair16((uint32_t)(bsA - nbA) & 0xffffu, (uint32_t)(bsB - nbB) & 0xffffu);
 			baseA = nbA; baseB = nbB;
 		}
@@ -185,14 +225,14 @@ struct K2aLanePk {
 			for (int c = 0; c < C; ++c) {                        /* ksw2_extz.c:43-44, ksw2_extd.c:49-52; row bias e*i */
 				const int hb = k2a_border<DUAL>(sc, i0 + c + 1) + sc.e * (i0 + c);
 				if (i0 + c <= w) {
-					hl[c] = k2a_pair16((uint32_t)(hb - baseA) & 0xffffu, (uint32_t)(hb - baseB) & 0xffffu);
+					hl[c] = k2a_pair16((uint32_t)(hb - baseA) & 0xffffu, (uint32_t)(hb - baseB) & 0xffffu) ^ K2A_OFS;
 					f[c] = k2a_pk_sub(hl[c], k2a_pk2(sc.q + sc.e));
 					if (DUAL) f2[c] = k2a_pk_sub(hl[c], k2a_pk2(sc.q2 + sc.e2));
 				}
 			}
 		}
-		if (RB) hd0 = 0;                                        /* by construction of the base */
-		else if (js == 0) hd0 = k2a_pk2(hcorner);
+		if (RB) hd0 = K2A_OFS;                                  /* 0 by construction of the base */
+		else if (js == 0) hd0 = k2a_pku(hcorner);
 		else hd0 = hu_prev;
 		Snext += G;
 		schedule_next();
@@ -203,7 +243,7 @@ struct K2aLanePk {
 	{
 		if (S == 0) {
 			const int hb = k2a_border<DUAL>(sc, k - koff + 1);
-			const k2a_pk h0 = k2a_pair16((uint32_t)(hb - baseA) & 0xffffu, (uint32_t)(hb - baseB) & 0xffffu);
+			const k2a_pk h0 = k2a_pair16((uint32_t)(hb - baseA) & 0xffffu, (uint32_t)(hb - baseB) & 0xffffu) ^ K2A_OFS;
 			hin = k2a_pk_sub(h0, k2a_pk2(sc.e));               /* row -1 carries bias -e, E(0,.) and E~(0,.) bias 0 */
 			ein = k2a_pk_sub(h0, k2a_pk2(sc.q + sc.e)); e2in = k2a_pk_sub(h0, k2a_pk2(sc.q2 + sc.e2));
 		}
@@ -218,7 +258,7 @@ struct K2aLanePk {
 	K2A_FN bool step(const K2aScoring &sc, int k, k2a_pk hin, k2a_pk ein, k2a_pk e2in, uint32_t *tbw)
 	{
 		const int dd = k - kd;                                 /* jj - i0 */
-		const k2a_pk neg = k2a_pk2(K2A_NEG16);
+		const k2a_pk neg = k2a_pku(K2A_NEG16);
 		const k2a_pk gq = k2a_pk2(sc.q), ge = k2a_pk2(sc.e), gq2 = k2a_pk2(sc.q2), ge2 = k2a_pk2(sc.e2), de2 = k2a_pk2(sc.e2 - sc.e);
 		const k2a_pk mat_a = k2a_pk2(sc.pk_a + sc.e), mat_bma = k2a_pk2(sc.pk_b - sc.pk_a);     /* score + row-bias step */
 		k2a_pk e = ein, e2 = e2in;
@@ -231,11 +271,20 @@ struct K2aLanePk {
 		const k2a_pk qcode = qb;
 		const k2a_pk jjpk = k2a_pk2(k - koff);
 		k2a_pk cand[C];
+		if (PLANES) {
+			/* mismatch ? D : 0 from the bit planes: (t0 ^ q0) | (t1 ^ q1), everything pre-multiplied with D */
+			const uint32_t dmis = (uint32_t)(sc.pk_a - sc.pk_b);
+			const k2a_pk q0 = (qcode & 0x00010001u) * dmis, q1 = ((qcode >> 1) & 0x00010001u) * dmis;
 #pragma unroll
-		for (int c = 0; c < C; ++c) {
-			/* score: a on equal codes, b otherwise (no wildcards in this class) */
-			const k2a_pk ne01 = k2a_pk_minu(tc[c] ^ qcode, 0x00010001u);
-			cand[c] = k2a_pk_add(c == 0 ? hd0 : hl[c - 1], k2a_pk_mad(ne01, mat_bma, mat_a));
+			for (int c = 0; c < C; ++c)
+				cand[c] = k2a_sub32(k2a_add32(c == 0 ? hd0 : hl[c - 1], mat_a), k2a_or_xor(tc[c] ^ q0, tc1[c], q1));
+		} else {
+#pragma unroll
+			for (int c = 0; c < C; ++c) {
+				/* score: a on equal codes, b otherwise (no wildcards in this class) */
+				const k2a_pk ne01 = k2a_pk_minu(tc[c] ^ qcode, 0x00010001u);
+				cand[c] = k2a_pk_add(c == 0 ? hd0 : hl[c - 1], k2a_pk_mad(ne01, mat_bma, mat_a));
+			}
 		}
 		k2a_pk dprev = 0;
 #pragma unroll
@@ -243,21 +292,21 @@ struct K2aLanePk {
 			const k2a_pk fc = f[c];
 			k2a_pk h = cand[c], d = 0;
 			if (MODE == K2A_MODE_SCORE) {
-				h = k2a_pk_max(k2a_pk_max(h, e), fc);
-				if (DUAL) h = k2a_pk_max(k2a_pk_max(h, e2), f2[c]);
+				h = k2a_pk_maxu(k2a_pk_maxu(h, e), fc);
+				if (DUAL) h = k2a_pk_maxu(k2a_pk_maxu(h, e2), f2[c]);
 			} else if (MODE == K2A_MODE_LEFT) {            /* winner changes only on a strictly larger gap state */
-				d = k2a_pk_sign(k2a_pk_sub(h, e)) & 0x00010001u;                     h = k2a_pk_max(h, e);
-				d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, fc)), 0x00020002u, d);      h = k2a_pk_max(h, fc);
+				d = k2a_pk_sign(k2a_pk_sub(h, e)) & 0x00010001u;                     h = k2a_pk_maxu(h, e);
+				d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, fc)), 0x00020002u, d);      h = k2a_pk_maxu(h, fc);
 				if (DUAL) {
-					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, e2)), 0x00030003u, d);    h = k2a_pk_max(h, e2);
-					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, f2[c])), 0x00040004u, d); h = k2a_pk_max(h, f2[c]);
+					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, e2)), 0x00030003u, d);    h = k2a_pk_maxu(h, e2);
+					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, f2[c])), 0x00040004u, d); h = k2a_pk_maxu(h, f2[c]);
 				}
 			} else {                                       /* right-aligned: a tie already moves to the gap state */
-				d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e, h)), 0u, 0x00010001u);      h = k2a_pk_max(h, e);
-				d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(fc, h)), d, 0x00020002u);      h = k2a_pk_max(h, fc);
+				d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e, h)), 0u, 0x00010001u);      h = k2a_pk_maxu(h, e);
+				d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(fc, h)), d, 0x00020002u);      h = k2a_pk_maxu(h, fc);
 				if (DUAL) {
-					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e2, h)), d, 0x00030003u);    h = k2a_pk_max(h, e2);
-					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(f2[c], h)), d, 0x00040004u); h = k2a_pk_max(h, f2[c]);
+					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e2, h)), d, 0x00030003u);    h = k2a_pk_maxu(h, e2);
+					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(f2[c], h)), d, 0x00040004u); h = k2a_pk_maxu(h, f2[c]);
 				}
 			}
 			h = k2a_pk_sel(k2a_bit_mask(live, c), h, neg);
@@ -265,11 +314,11 @@ struct K2aLanePk {
 			 * extz + RIGHT + CIGAR where the first column wins (take the new one only where max < h); SURVEY 8a rule 3 */
 			if (!DUAL && MODE == K2A_MODE_RIGHT) rmj[c] = k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(rmax[c], h)), jjpk, rmj[c]);
 			else rmj[c] = k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(h, rmax[c])), rmj[c], jjpk);
-			rmax[c] = k2a_pk_max(rmax[c], h);
+			rmax[c] = k2a_pk_maxu(rmax[c], h);
 			/* gaps leaving the cell, all in row-biased form: opening = H' - q; the extension cost cancels against the bias
 			 * for E (next row), stays e for F (same row), becomes e2 - e for E~ and stays e2 for F~.  "extension beats
 			 * opening" (ksw2_extz.c:79-86 / 105-112) compares the gap state with the opening value directly. */
-			const k2a_pk t = k2a_pk_sub(h, gq);
+			const k2a_pk t = k2a_sub32(h, gq);
 			if (MODE == K2A_MODE_LEFT) {                   /* extension strictly better than opening */
 				d |= k2a_pk_sign(k2a_pk_sub(t, e)) & 0x00080008u;
 				d |= k2a_pk_sign(k2a_pk_sub(t, fc)) & 0x00100010u;
@@ -277,10 +326,10 @@ struct K2aLanePk {
 				d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e, t)), 0u, 0x00080008u);
 				d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(fc, t)), 0u, 0x00100010u);
 			}
-			e = k2a_pk_max(e, t);
-			f[c] = k2a_pk_sub(k2a_pk_max(fc, t), ge);
+			e = k2a_pk_maxu(e, t);
+			f[c] = k2a_sub32(k2a_pk_maxu(fc, t), ge);
 			if (DUAL) {
-				const k2a_pk t2 = k2a_pk_sub(h, gq2);
+				const k2a_pk t2 = k2a_sub32(h, gq2);
 				if (MODE == K2A_MODE_LEFT) {
 					d |= k2a_pk_sign(k2a_pk_sub(t2, e2)) & 0x00200020u;
 					d |= k2a_pk_sign(k2a_pk_sub(t2, f2[c])) & 0x00400040u;
@@ -288,8 +337,8 @@ struct K2aLanePk {
 					d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e2, t2)), 0u, 0x00200020u);
 					d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(f2[c], t2)), 0u, 0x00400040u);
 				}
-				e2 = k2a_pk_sub(k2a_pk_max(e2, t2), de2);
-				f2[c] = k2a_pk_sub(k2a_pk_max(f2[c], t2), ge2);
+				e2 = k2a_pk_sub(k2a_pk_maxu(e2, t2), de2);           /* e2 - e may be negative: packed subtract */
+				f2[c] = k2a_sub32(k2a_pk_maxu(f2[c], t2), ge2);
 			}
 			if (MODE != K2A_MODE_SCORE) {
 				if (c & 1) tbw[c >> 1] = k2a_pack_dirs(dprev, d);    /* bytes {A(c-1), B(c-1), A(c), B(c)} */
@@ -316,7 +365,7 @@ struct K2aLanePk {
 	K2A_FN void stage_rows(uint32_t *rowbuf) const
 	{
 #pragma unroll
-		for (int c = 0; c < C; ++c) { rowbuf[c] = hl[c]; rowbuf[C + c] = rmax[c]; rowbuf[2 * C + c] = rmj[c]; }
+		for (int c = 0; c < C; ++c) { rowbuf[c] = hl[c] ^ K2A_OFS; rowbuf[C + c] = rmax[c] ^ K2A_OFS; rowbuf[2 * C + c] = rmj[c]; }   /* plain int16 halves */
 		rowbuf[3 * C] = (uint32_t)i0;
 		if (RB) { rowbuf[3 * C + 1] = (uint32_t)baseA; rowbuf[3 * C + 2] = (uint32_t)baseB; }
 	}
@@ -369,10 +418,10 @@ struct K2aLanePk {
 	{
 		if (i0 + C >= tlen || i0 + C - 1 + w >= qlen - 1) return false;
 		/* rows compare without their bias: v_c = rmax[c] - e*c = H(row) + (e*i0 - base) */
-		k2a_pk m = rmax[0], mn = rmax[0], arg = 0, argj = rmj[0];
+		k2a_pk m = rmax[0] ^ K2A_OFS, mn = m, arg = 0, argj = rmj[0];
 #pragma unroll
 		for (int c = 1; c < C; ++c) {
-			const k2a_pk v = k2a_pk_sub(rmax[c], k2a_pk2(sc.e * c));
+			const k2a_pk v = k2a_pk_sub(rmax[c] ^ K2A_OFS, k2a_pk2(sc.e * c));
 			const k2a_pk gt = k2a_pk_sign(k2a_pk_sub(m, v));                        /* strictly larger: first row keeps a tie */
 			arg = k2a_pk_sel(gt, k2a_pk2(c), arg);
 			argj = k2a_pk_sel(gt, rmj[c], argj);
