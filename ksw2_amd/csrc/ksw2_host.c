@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <pthread.h>
 #include <string.h>
 #include "../../include/ksw2_amd.h"
 #include "ksw2_shim.h"
@@ -49,6 +50,31 @@ int ksw2amd_set_device(int device)
 enum { BUF_HSEQ, BUF_SEQ, BUF_PAIRS, BUF_RES, BUF_ORDER, BUF_TB, BUF_CIG, BUF_BND, BUF_KINDS };
 static __thread struct { void *p; size_t cap; } g_cache[BUF_KINDS];
 static __thread void *g_ev_cache[3];
+/* Every host thread uploads and (in the one-shot entry points) computes on a stream of its own, so concurrent callers --
+ * a minimap2-style thread pool -- overlap their copies and kernels instead of queueing on the device's default stream. */
+static __thread void *g_stream;
+/* a worker thread that exits gives its cached buffers and stream back (pthread key destructor) */
+static pthread_key_t g_exit_key;
+static pthread_once_t g_exit_once = PTHREAD_ONCE_INIT;
+/* ... unless the process is already on its way out: the HIP runtime must not be called while it unloads.  The atexit
+ * hook waits for destructors that are in flight and turns the later ones into no-ops. */
+static pthread_mutex_t g_exit_mu = PTHREAD_MUTEX_INITIALIZER;
+static int g_exiting;
+static void process_exit_cb(void) { pthread_mutex_lock(&g_exit_mu); g_exiting = 1; pthread_mutex_unlock(&g_exit_mu); }
+static void thread_exit_cb(void *unused)
+{
+	(void)unused;
+	pthread_mutex_lock(&g_exit_mu);
+	if (!g_exiting) ksw2amd_release_cache();
+	pthread_mutex_unlock(&g_exit_mu);
+}
+static void thread_exit_init(void) { pthread_key_create(&g_exit_key, thread_exit_cb); atexit(process_exit_cb); }
+static void thread_owns_cache(void)
+{
+	pthread_once(&g_exit_once, thread_exit_init);
+	if (!pthread_getspecific(g_exit_key)) pthread_setspecific(g_exit_key, (void*)1);
+}
+static void *thread_stream(void) { if (!g_stream) { thread_owns_cache(); g_stream = k2a_shim_stream_create(); } return g_stream; }
 
 static void cache_free_raw(int kind, void *p) { if (kind == BUF_HSEQ) k2a_shim_host_free(p); else k2a_shim_free(p); }
 
@@ -67,6 +93,7 @@ static void *cache_get(int kind, size_t bytes, size_t *cap)
 static void cache_put(int kind, void *p, size_t cap)
 {
 	if (!p) return;
+	thread_owns_cache();
 	if (g_cache[kind].p == 0 || g_cache[kind].cap < cap) {
 		if (g_cache[kind].p) cache_free_raw(kind, g_cache[kind].p);
 		g_cache[kind].p = p; g_cache[kind].cap = cap;
@@ -78,6 +105,7 @@ void ksw2amd_release_cache(void)
 	int k;
 	for (k = 0; k < BUF_KINDS; ++k) { if (g_cache[k].p) cache_free_raw(k, g_cache[k].p); g_cache[k].p = 0; g_cache[k].cap = 0; }
 	for (k = 0; k < 3; ++k) { if (g_ev_cache[k]) k2a_shim_event_destroy(g_ev_cache[k]); g_ev_cache[k] = 0; }
+	if (g_stream) { k2a_shim_stream_sync(g_stream); k2a_shim_stream_destroy(g_stream); g_stream = 0; }
 }
 
 /* ---------------------------------------------------------------- CIGAR memory */
@@ -314,6 +342,7 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 	ksw2amd_plan_t *p;
 	int i, k, q, e, q2, e2, m, lo, ci;
 	size_t off, mat_off = 0;
+	void *up;
 	sort_t *srt = 0;
 	pkinfo_t pkinfo[2];
 	uint8_t *pk_ok = 0;
@@ -392,7 +421,8 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 	/* A packed launch has half the wavefronts of the int32 launch of the same pairs.  When that leaves SIMDs without a
 	 * wavefront (a few hundred long reads), the wider int32 launch finishes earlier: measured on MI355X, 1024 pairs of
 	 * 10k x 10k, w = 500: 512 packed wavefronts 11.5 ms, 1024 int32 wavefronts 8.8 ms.  Below 0.6 wavefronts per SIMD the
-	 * packed candidates of a class go back to the int32 kernels (KSW2AMD_SIMDS overrides the device's SIMD count, 0 = off). */
+	 * packed candidates of a one-alignment-per-wavefront class go back to the int32 kernels (KSW2AMD_SIMDS overrides the
+	 * device's SIMD count, 0 = off). */
 	{
 		const char *ev = getenv("KSW2AMD_SIMDS");
 		const int simds = ev ? atoi(ev) : k2a_shim_simd_count();
@@ -404,7 +434,9 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 				if (cnt[b]) {
 					const int G = k2a_pkcfg_G[(b % NPASS - 1) % K2A_NPKCFG];
 					const int64_t waves = ((int64_t)(cnt[b] + 1) / 2 * G + 63) / 64;
-					cnt[b] = waves * 10 < (int64_t)simds * 6;        /* 1 = demote */
+					/* one-alignment-per-wavefront classes only: for the short shapes of the multi-group geometries the gain is a
+					 * fraction of a millisecond per call and costs 2-3 x the SIMD time, which concurrent callers would rather keep */
+					cnt[b] = G == 64 && waves * 10 < (int64_t)simds * 6;        /* 1 = demote */
 				}
 			for (i = 0; i < n; ++i) if (p->h_cls[i] >= 0 && pk_ok[i] && cnt[p->h_cls[i] * NPASS + pk_ok[i]]) pk_ok[i] = 0;
 		}
@@ -518,10 +550,11 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 		fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error());
 		goto err;
 	}
-	if (k2a_shim_h2d(p->d_seq, p->h_seq, p->seq_bytes, 0) || k2a_shim_h2d(p->d_pairs, p->h_pairs, sizeof(K2aPair) * (size_t)n, 0) ||
-	    k2a_shim_h2d(p->d_order, p->h_order, sizeof(uint32_t) * (size_t)p->norder, 0) ||
-	    k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)n, 0) ||
-	    (p->bnd_words && k2a_shim_memset(p->d_bnd, 0xC0, p->bnd_words * 4, 0)) || k2a_shim_stream_sync(0)) {
+	up = thread_stream();
+	if (k2a_shim_h2d(p->d_seq, p->h_seq, p->seq_bytes, up) || k2a_shim_h2d(p->d_pairs, p->h_pairs, sizeof(K2aPair) * (size_t)n, up) ||
+	    k2a_shim_h2d(p->d_order, p->h_order, sizeof(uint32_t) * (size_t)p->norder, up) ||
+	    k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)n, up) ||
+	    (p->bnd_words && k2a_shim_memset(p->d_bnd, 0xC0, p->bnd_words * 4, up)) || k2a_shim_stream_sync(up)) {
 		fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error());
 		goto err;
 	}
@@ -753,7 +786,7 @@ static int run_batch(int dual, void *km, const ksw2amd_scoring_t *sc, int n, con
 			ksw2amd_release_cache();
 			limit = (end - beg) / 2;
 		}
-		rc = ksw2amd_plan_run(p, 0);
+		rc = ksw2amd_plan_run(p, thread_stream());
 		if (rc == KSW2AMD_OK) rc = ksw2amd_plan_fetch(p, km, ez + beg);
 		ksw2amd_plan_destroy(p);
 		if (rc) return rc;

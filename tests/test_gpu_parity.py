@@ -298,9 +298,9 @@ def test_packed_rebased_long_reads(lib, dual):
 def test_small_packed_class_goes_back_to_int32(lib, monkeypatch):
     """Fewer packed wavefronts than 0.6 per SIMD: the class runs on the int32 kernels instead; same results."""
     n = 64
-    q, t = synth.fixed_batch(2, n, 512, 512, sub=0.05, ind=0.06, stream=3)
+    q, t = synth.fixed_batch(2, n, 1500, 1500, sub=0.05, ind=0.06, stream=3)
     mat = synth.simple_mat(5, 2, 4, -1)
-    b = lib.make_batch(q, t, mat, 4, 2, 24, 1, w=64, zdrop=-1, flag=po.SCORE_ONLY)
+    b = lib.make_batch(q, t, mat, 4, 2, 24, 1, w=200, zdrop=-1, flag=po.SCORE_ONLY)        # (64,8): one packed pair per wavefront
     p = b.plan(False); assert p.packed_pairs() == n; p.run(); r1 = p.fetch_raw().copy(); p.close()
     monkeypatch.delenv("KSW2AMD_SIMDS")
     p = b.plan(False); assert p.packed_pairs() == 0; p.run(); r0 = p.fetch_raw().copy(); p.close()
@@ -318,6 +318,34 @@ def test_wide_alphabets(lib):
     m, mat, qs, ts, w, zd, fl = _wide_alphabet_cases(rng, 0)
     exp = po.align("oracle", "extz2", qs[0], ts[0], mat, 6, 2, w=-1, flag=po.GENERIC_SC, m=m)
     assert not diff(exp, lib.extz2(qs[0], ts[0], mat, 6, 2, w=-1, flag=po.GENERIC_SC, m=m))
+
+
+def test_concurrent_host_threads(lib):
+    """minimap2-style callers align from many host threads at once (threading): every thread has its own
+    stream-less plan, staging and buffer cache; single calls and batches interleave and stay bit-exact."""
+    import threading
+    mat = synth.simple_mat(5, 2, 4, -1)
+    errors = []
+
+    def worker(tid):
+        try:
+            rng = np.random.Generator(np.random.PCG64(1000 + tid))
+            for it in range(6):
+                pairs = synth.ragged_pairs(rng, 12, 30, 900, sub=0.05, ind=0.1, n_rate=0.005 if tid % 2 else 0.0)
+                qs, ts = [p[0] for p in pairs], [p[1] for p in pairs]
+                fl = [0, po.RIGHT, po.SCORE_ONLY][(tid + it) % 3]
+                check_batch(lib, bool(tid & 1), qs, ts, mat, 4, 2, 24, 1, w=int(rng.choice([-1, 20, 100])), zdrop=int(rng.choice([-1, 200])), flag=fl)
+                exp = po.align("oracle", "extz2", qs[0], ts[0], mat, 4, 2, w=50, zdrop=100, flag=0)
+                assert not diff(exp, lib.extz2(qs[0], ts[0], mat, 4, 2, w=50, zdrop=100, flag=0))
+        except Exception as ex:                                  # noqa: BLE001 - reported below with the thread id
+            errors.append((tid, repr(ex)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
 
 
 def test_cfg5_ont_like_mix(lib):
