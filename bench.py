@@ -38,9 +38,10 @@ WORKLOADS = {
     # 1024 SIMDs need a few wavefronts each (1024 pairs leave half of them empty; the host then picks the int32 kernels)
     "10k": dict(idx=6, n=4096, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=ksw2_amd.KSW_EZ_SCORE_ONLY, sub=0.05, ind=0.06),
     "10k-cigar": dict(idx=6, n=4096, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=0, sub=0.05, ind=0.06),
-    # config 4: MT-human x MT-orang (tests/golden/data), full global extz2 with CIGAR, replicated; 512 replicas per GPU here
-    # (4096 x 144 MB of traceback does not fit one GPU at once; the batch entry points split such batches)
-    "cfg4": dict(idx=4, n=512, qlen=16499, tlen=16569, w=-1, zdrop=-1, dual=False, flag=0, mt=True),
+    # config 4: MT-human x MT-orang (tests/golden/data), full global extz2 with CIGAR, replicated; 1024 replicas per GPU here:
+    # 147 GB of traceback (144 MB per pair at 4 bits per cell), one wavefront per SIMD.  4096 replicas do not fit one GPU at
+    # once; the batch entry points split such batches.
+    "cfg4": dict(idx=4, n=1024, qlen=16499, tlen=16569, w=-1, zdrop=-1, dual=False, flag=0, mt=True),
     # config 5: ONT-like mix, target length uniform in [300, 20000] (64 length buckets), 3 % substitutions + 15 % indels, band 500,
     # extd2 with Z-drop 400 and CIGAR; 16384 pairs per GPU here (the full config shards 1 M pairs over 8 GPUs)
     "cfg5": dict(idx=5, n=16384, qlen=0, tlen=0, w=500, zdrop=400, dual=True, flag=0, sub=0.03, ind=0.15, ragged=True),
