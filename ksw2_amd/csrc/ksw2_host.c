@@ -304,13 +304,18 @@ static int pk_window_ok(const pkinfo_t *k, int qlen, int tlen, int w, int C)
 	return ((int64_t)2 * w + 2 * C + 2) * D + 2 * k->qemax + (int64_t)4 * C * D + 64 <= 12000;
 }
 
-/* any residue code >= 4 (the wildcard of a 5-letter alphabet)?  8 codes per probe */
-static int has_wildcard(const uint8_t *s, int n)
+/* copy a sequence into the staging arena and report whether it holds a residue code >= 4 (the wildcard of a 5-letter
+ * alphabet): one pass over the bytes instead of a scan plus a memcpy */
+static int copy_scan(uint8_t *dst, const uint8_t *src, int n)
 {
 	int i = 0;
-	uint64_t acc = 0, v;
-	for (; i + 8 <= n; i += 8) { memcpy(&v, s + i, 8); acc |= v; }
-	for (; i < n; ++i) acc |= s[i];
+	uint64_t acc = 0, v0, v1, v2, v3;
+	for (; i + 32 <= n; i += 32) {
+		memcpy(&v0, src + i, 8); memcpy(&v1, src + i + 8, 8); memcpy(&v2, src + i + 16, 8); memcpy(&v3, src + i + 24, 8);
+		memcpy(dst + i, &v0, 8); memcpy(dst + i + 8, &v1, 8); memcpy(dst + i + 16, &v2, 8); memcpy(dst + i + 24, &v3, 8);
+		acc |= (v0 | v1) | (v2 | v3);
+	}
+	for (; i < n; ++i) { dst[i] = src[i]; acc |= src[i]; }
 	return (acc & 0xfcfcfcfcfcfcfcfcull) != 0;
 }
 
@@ -376,15 +381,33 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 	}
 	if (p->reject_all || n == 0) return p;
 
-	/* pass 1: geometry class, traceback / CIGAR / boundary space, packed-int16 eligibility per pair */
+	/* pass 0: sequence arena (query 4-aligned, target 16-aligned and readable one strip past its end) in pinned staging */
+	off = 0;
+	for (i = 0; i < n; ++i) {
+		const ksw2amd_pair_t *a = &pairs[i];
+		if (a->qlen <= 0 || a->tlen <= 0) continue;                                                 /* ksw2_extz2_sse.c:57 */
+		if (!a->query || !a->target) { fail(KSW2AMD_E_PARAM, "plan_create: NULL sequence%s", 0); goto err; }
+		off = align_up(off, 4); p->h_pairs[i].qoff = (uint32_t)off; off += (size_t)a->qlen;
+		off = align_up(off, 16); p->h_pairs[i].toff = (uint32_t)off; off += (size_t)a->tlen + 64;
+		if (off > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "plan_create: more than 4 GiB of sequence in one plan%s", 0); goto err; }
+	}
+	off = align_up(off + 65536, 256);               /* idle lanes may prefetch codes a few hundred bytes past the last pair */
+	if (m > 5) { mat_off = off; off = align_up(off + 2 * (size_t)m * m, 256); }   /* wide alphabets: effective matrices, simple | generic */
+	p->seq_bytes = off;
+	p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, p->seq_bytes, &p->cap[BUF_HSEQ]);
+	if (!p->h_seq) { fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
+
+	/* pass 1: copy the codes; geometry class, traceback / CIGAR / boundary space, packed-int16 eligibility per pair */
 	pkinfo[0].ok = pkinfo[1].ok = -1;
 	pk_ok = (uint8_t*)calloc((size_t)n + 1, 1);
 	for (i = 0; i < n; ++i) {
 		const ksw2amd_pair_t *a = &pairs[i];
 		K2aPair *d = &p->h_pairs[i];
-		int w = a->w, cfg, mode, generic, mx;
-		if (a->qlen <= 0 || a->tlen <= 0) continue;                                                 /* ksw2_extz2_sse.c:57 */
-		if (!a->query || !a->target) { fail(KSW2AMD_E_PARAM, "plan_create: NULL sequence%s", 0); goto err; }
+		int w = a->w, cfg, mode, generic, mx, wild;
+		if (a->qlen <= 0 || a->tlen <= 0) continue;
+		wild = copy_scan(p->h_seq + d->qoff, a->query, a->qlen);
+		wild |= copy_scan(p->h_seq + d->toff, a->target, a->tlen);
+		memset(p->h_seq + d->toff + a->tlen, 0, 64);                                                /* rows read past the target end */
 		mx = imax(a->qlen, a->tlen);
 		if (w < 0 || w > mx) w = mx;                                                               /* ksw2_extz2_sse.c:72 */
 		d->qlen = a->qlen; d->tlen_full = a->tlen; d->w = w;
@@ -399,8 +422,7 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 		p->h_cls[i] = (int8_t)ci;
 		p->cells += band_cells(a->qlen, a->tlen, w);
 		if (pkinfo[generic].ok < 0) pk_scoring(dual, m, sc->mat, q, e, q2, e2, generic, &pkinfo[generic]);
-		if (use_pk && pkinfo[generic].ok > 0 && a->qlen <= 32000 && a->tlen <= 32000 &&
-		    !has_wildcard(a->query, a->qlen) && !has_wildcard(a->target, a->tlen)) {
+		if (use_pk && pkinfo[generic].ok > 0 && a->qlen <= 32000 && a->tlen <= 32000 && !wild) {
 			/* packed class: first geometry that holds the band, 1-based; scores that fit 16 bits outright use the plain
 			 * kernels, longer reads the re-based ones as long as the band window fits */
 			const int plain = pk_eligible(&pkinfo[generic], a->qlen, d->tlen, w);
@@ -441,6 +463,17 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 			for (i = 0; i < n; ++i) if (p->h_cls[i] >= 0 && pk_ok[i] && cnt[p->h_cls[i] * NPASS + pk_ok[i]]) pk_ok[i] = 0;
 		}
 	}
+
+	/* the sequence arena goes up while the host sorts out the task lists (pinned staging: the copy is asynchronous) */
+	if (m > 5) {
+		build_eff(dual, m, sc->mat, e, e2, 0, (int8_t*)p->h_seq + mat_off);
+		build_eff(dual, m, sc->mat, e, e2, 1, (int8_t*)p->h_seq + mat_off + (size_t)m * m);
+	}
+	p->d_seq = (uint8_t*)cache_get(BUF_SEQ, p->seq_bytes, &p->cap[BUF_SEQ]);
+	if (!p->d_seq) { fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error()); goto err; }
+	up = thread_stream();
+	p->stream = up; p->stream_used = 1;              /* plan_destroy waits for it before the buffers are recycled */
+	if (k2a_shim_h2d(p->d_seq, p->h_seq, p->seq_bytes, up)) { fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error()); goto err; }
 
 	/* pass 2: task lists per class, most expensive first (similar shapes end up in the same wavefront).  Packed-int16
 	 * candidates of a class are paired up with a neighbour of identical (qlen, tlen, w); a leftover is paired with itself. */
@@ -489,16 +522,7 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 		free(srt); srt = 0;
 	}
 
-	/* pass 3: sequence arena (query 4-aligned, target 16-aligned and readable one strip past its end), traceback blocks
-	 * (one per task: the two alignments of a packed task share theirs) and CIGAR scratch */
-	off = 0;
-	for (i = 0; i < n; ++i) {
-		K2aPair *d = &p->h_pairs[i];
-		if (p->h_cls[i] < 0) continue;
-		off = align_up(off, 4); d->qoff = (uint32_t)off; off += (size_t)d->qlen;
-		off = align_up(off, 16); d->toff = (uint32_t)off; off += (size_t)d->tlen_full + 64;
-		if (off > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "plan_create: more than 4 GiB of sequence in one plan%s", 0); goto err; }
-	}
+	/* pass 3: traceback blocks (one per task: the two alignments of a packed task share theirs) and CIGAR scratch */
 	for (k = 0; k < p->ncls; ++k) {
 		const cls_t *c = &p->cls[k];
 		if (c->mode == K2A_MODE_SCORE) continue;
@@ -521,37 +545,20 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 			if (ib != ia) p->h_half[ib] = 2;
 		}
 	}
-	off = align_up(off + 65536, 256);               /* idle lanes may prefetch codes a few hundred bytes past the last pair */
-	if (m > 5) { mat_off = off; off = align_up(off + 2 * (size_t)m * m, 256); }   /* wide alphabets: effective matrices, simple | generic */
-	p->seq_bytes = off;
 
-	/* pack (pinned staging, so the upload runs at PCIe speed) + upload */
-	p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, p->seq_bytes, &p->cap[BUF_HSEQ]);
-	if (!p->h_seq) { fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
-	for (i = 0; i < n; ++i) {
-		if (p->h_cls[i] < 0) continue;
-		memcpy(p->h_seq + p->h_pairs[i].qoff, pairs[i].query, (size_t)pairs[i].qlen);
-		memcpy(p->h_seq + p->h_pairs[i].toff, pairs[i].target, (size_t)pairs[i].tlen);
-		memset(p->h_seq + p->h_pairs[i].toff + pairs[i].tlen, 0, 64);        /* rows read past the target end */
-	}
-	if (m > 5) {
-		build_eff(dual, m, sc->mat, e, e2, 0, (int8_t*)p->h_seq + mat_off);
-		build_eff(dual, m, sc->mat, e, e2, 1, (int8_t*)p->h_seq + mat_off + (size_t)m * m);
-	}
-	p->d_seq = (uint8_t*)cache_get(BUF_SEQ, p->seq_bytes, &p->cap[BUF_SEQ]);
+	/* upload the rest */
 	p->d_pairs = (K2aPair*)cache_get(BUF_PAIRS, sizeof(K2aPair) * ((size_t)n + 1), &p->cap[BUF_PAIRS]);
 	p->d_res = (K2aResult*)cache_get(BUF_RES, sizeof(K2aResult) * ((size_t)n + 1), &p->cap[BUF_RES]);
 	p->d_order = (uint32_t*)cache_get(BUF_ORDER, sizeof(uint32_t) * ((size_t)p->norder + 1), &p->cap[BUF_ORDER]);
 	p->d_tb = p->tb_bytes ? (uint8_t*)cache_get(BUF_TB, p->tb_bytes, &p->cap[BUF_TB]) : 0;
 	p->d_cig = p->cig_words ? (uint32_t*)cache_get(BUF_CIG, p->cig_words * 4, &p->cap[BUF_CIG]) : 0;
 	p->d_bnd = p->bnd_words ? (int32_t*)cache_get(BUF_BND, p->bnd_words * 4, &p->cap[BUF_BND]) : 0;
-	if (!p->d_seq || !p->d_pairs || !p->d_res || !p->d_order || (p->tb_bytes && !p->d_tb) || (p->cig_words && !p->d_cig) ||
+	if (!p->d_pairs || !p->d_res || !p->d_order || (p->tb_bytes && !p->d_tb) || (p->cig_words && !p->d_cig) ||
 	    (p->bnd_words && !p->d_bnd)) {
 		fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error());
 		goto err;
 	}
-	up = thread_stream();
-	if (k2a_shim_h2d(p->d_seq, p->h_seq, p->seq_bytes, up) || k2a_shim_h2d(p->d_pairs, p->h_pairs, sizeof(K2aPair) * (size_t)n, up) ||
+	if (k2a_shim_h2d(p->d_pairs, p->h_pairs, sizeof(K2aPair) * (size_t)n, up) ||
 	    k2a_shim_h2d(p->d_order, p->h_order, sizeof(uint32_t) * (size_t)p->norder, up) ||
 	    k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)n, up) ||
 	    (p->bnd_words && k2a_shim_memset(p->d_bnd, 0xC0, p->bnd_words * 4, up)) || k2a_shim_stream_sync(up)) {
