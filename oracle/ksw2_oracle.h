@@ -20,6 +20,7 @@
  *                 (ksw2_extz2_sse.c:56-82,292-301; ksw2_extd2_sse.c:75-100,389-406; ksw2_gg2_sse.c:11-126)
  *                 evaluated with the scalar cell semantics above: this is the contract the
  *                 MI355X kernels implement (SURVEY.md section 8a rules 1-10).
+ *   kso_exts2  <- ksw_exts2_sse ksw2_exts2_sse.c:33-415 (splice-aware; ksw2_oracle_exts.c; the SSE code is the only definition)
  *   helpers    <- ksw2.h:113-123 (CIGAR push), :129-161 (traceback state machine, row-major case),
  *                 :163-182 (EQX rewrite), :184-189 (reset), :191-207 (Z-drop test)
  */
@@ -42,6 +43,9 @@ extern "C" {
 #define KSO_APPROX_DROP 0x10
 #define KSO_EXTZ_ONLY   0x40
 #define KSO_REV_CIGAR   0x80
+#define KSO_SPLICE_FOR   0x100
+#define KSO_SPLICE_REV   0x200
+#define KSO_SPLICE_FLANK 0x400
 #define KSO_EQX         0x800
 
 /* Same memory layout as ksw_extz_t (ksw2.h:33-42): 56 bytes, cigar pointer at offset 48. */
@@ -74,6 +78,14 @@ int  kso_gg2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, in
 
 /* number of DP cells inside the exact band |i-j|<=w (SURVEY.md section 8d metric definition) */
 int64_t kso_band_cells(int qlen, int tlen, int w);
+
+/* splice-aware extension (ksw2_oracle_exts.c): contract of ksw_exts2_sse, ksw2.h:73-74 */
+void kso_exts2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+               int8_t q, int8_t e, int8_t q2, int8_t noncan, int zdrop, int8_t junc_bonus, int flag, const uint8_t *junc,
+               kso_extz_t *ez);
+void kso_splice_signals(int tlen, const uint8_t *target, int noncan, int junc_bonus, int flag, const uint8_t *junc,
+                        int8_t *donor, int8_t *acceptor);
+int kso_long_thres(int q, int e, int q2);
 
 #ifdef __cplusplus
 }

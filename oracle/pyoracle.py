@@ -70,6 +70,9 @@ def oracle_lib():
         lib.kso_gg2.restype = _int
         lib.kso_band_cells.argtypes = [_int, _int, _int]
         lib.kso_band_cells.restype = ctypes.c_int64
+        lib.kso_exts2.argtypes = [_int, _u8p, _int, _u8p, _i8, _i8p, _i8, _i8, _i8, _i8, _int, _i8, _int, _u8p, ctypes.POINTER(Ez)]
+        lib.kso_long_thres.argtypes = [_int, _int, _int]
+        lib.kso_long_thres.restype = _int
         _cache["o"] = lib
     return _cache["o"]
 
@@ -87,6 +90,8 @@ def ref_lib():
             lib.ksw_extd2_sse.argtypes = [km, _int, _u8p, _int, _u8p, _i8, _i8p, _i8, _i8, _i8, _i8, _int, _int, _int, _int, ctypes.POINTER(Ez)]
             gg = [km, _int, _u8p, _int, _u8p, _i8, _i8p, _i8, _i8, _int, ctypes.POINTER(_int), ctypes.POINTER(_int),
                   ctypes.POINTER(ctypes.POINTER(ctypes.c_uint32))]
+            if hasattr(lib, "ksw_exts2_sse"):
+                lib.ksw_exts2_sse.argtypes = [km, _int, _u8p, _int, _u8p, _i8, _i8p, _i8, _i8, _i8, _i8, _int, _i8, _int, _u8p, ctypes.POINTER(Ez)]
             for name in ("ksw_gg", "ksw_gg2", "ksw_gg2_sse"):
                 getattr(lib, name).argtypes = gg
                 getattr(lib, name).restype = _int
@@ -192,3 +197,29 @@ def band_cells(qlen, tlen, w):
 
 def cigar_string(cigar):
     return "".join("%d%s" % (c >> 4, "MIDN===X"[c & 0xf] if (c & 0xf) < 4 else {7: "=", 8: "X"}[c & 0xf]) for c in cigar)
+
+
+SPLICE_FOR, SPLICE_REV, SPLICE_FLANK = 0x100, 0x200, 0x400
+
+
+def exts2(which, query, target, mat, q, e, q2, noncan, zdrop=-1, junc_bonus=0, flag=0, junc=None, m=None):
+    """ksw_exts2_sse (which='ref') or its restatement kso_exts2 (which='oracle'); dict of ksw_extz_t fields + CIGAR."""
+    query = np.ascontiguousarray(query, dtype=np.uint8)
+    target = np.ascontiguousarray(target, dtype=np.uint8)
+    mat = np.ascontiguousarray(mat, dtype=np.int8)
+    if m is None:
+        m = int(round(len(mat) ** 0.5))
+    jp = None
+    if junc is not None:
+        junc = np.ascontiguousarray(junc, dtype=np.uint8)
+        jp = _p8(junc)
+    ez = Ez()
+    matp = mat.ctypes.data_as(_i8p)
+    if which == "oracle":
+        oracle_lib().kso_exts2(len(query), _p8(query), len(target), _p8(target), m, matp, q, e, q2, noncan, zdrop, junc_bonus, flag, jp, ez)
+    else:
+        lib = ref_lib()
+        if lib is None or not hasattr(lib, "ksw_exts2_sse"):
+            raise RuntimeError("oracle/_ref/libksw2ref.so not built (make -C oracle ref)")
+        lib.ksw_exts2_sse(None, len(query), _p8(query), len(target), _p8(target), m, matp, q, e, q2, noncan, zdrop, junc_bonus, flag, jp, ez)
+    return _ez_to_dict(ez)
