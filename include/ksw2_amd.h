@@ -36,6 +36,9 @@ extern "C" {
 #define KSW_EZ_APPROX_DROP 0x10                   /* (ksw2.h:12) accepted; computed exactly */
 #define KSW_EZ_EXTZ_ONLY   0x40                   /* (ksw2.h:13) extension only */
 #define KSW_EZ_REV_CIGAR   0x80                   /* (ksw2.h:14) CIGAR in end->start order */
+#define KSW_EZ_SPLICE_FOR   0x100                  /* (ksw2.h:15) exts2: GT..AG signals (forward transcript strand) */
+#define KSW_EZ_SPLICE_REV   0x200                  /* (ksw2.h:16) exts2: CT..AC signals (reverse strand) */
+#define KSW_EZ_SPLICE_FLANK 0x400                  /* (ksw2.h:17) exts2: half penalty for GT / AG without the preferred flank */
 #define KSW_EZ_EQX         0x800                  /* (ksw2.h:18) =/X instead of M (extd2 only) */
 
 #define KSW_CIGAR_MATCH  0                        /* (ksw2.h:22-27) */
@@ -95,6 +98,19 @@ void ksw_extd2_sse41(void *km, int qlen, const uint8_t *query, int tlen, const u
 void ksw_extd2_sse2(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
                     int8_t gapo, int8_t gape, int8_t gapo2, int8_t gape2, int w, int zdrop, int end_bonus, int flag, ksw_extz_t *ez);
 
+/* (ksw2.h:73-74) splice-aware extension, replaces ksw_exts2_sse (ksw2_exts2_sse.c:33-415): affine gap (q, e) plus a long
+ * target-consuming gap ("intron") with open cost q2, no extension cost, penalty `noncan` at non-canonical donor /
+ * acceptor sites (flag KSW_EZ_SPLICE_FOR / _REV / _FLANK), junc[t] bits 1/2 (forward donor/acceptor), 8/4 (reverse)
+ * rewarded with junc_bonus.  Unbanded; Z-drop, max and mqe / mte per anti-diagonal exactly like the reference,
+ * CIGAR with N for introns.  Bit-exact against the reference's SSE kernel in exact-max mode.
+ * This release handles min(qlen, tlen) <= 1472 (one diagonal must fit a wavefront's register window); longer ones abort. */
+void ksw_exts2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                   int8_t gapo, int8_t gape, int8_t gapo2, int8_t noncan, int zdrop, int8_t junc_bonus, int flag, const uint8_t *junc, ksw_extz_t *ez);
+void ksw_exts2_sse41(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                     int8_t gapo, int8_t gape, int8_t gapo2, int8_t noncan, int zdrop, int8_t junc_bonus, int flag, const uint8_t *junc, ksw_extz_t *ez);
+void ksw_exts2_sse2(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                    int8_t gapo, int8_t gape, int8_t gapo2, int8_t noncan, int zdrop, int8_t junc_bonus, int flag, const uint8_t *junc, ksw_extz_t *ez);
+
 /* ------------------------------------------------------------------ Part 2: batched front-end */
 
 /* scoring shared by every pair of a batch (the arguments m, mat, q, e[, q2, e2] of the calls above) */
@@ -129,6 +145,19 @@ void ksw2amd_release_cache(void);
  * single calls.  Large batches are split internally to fit device memory. */
 int ksw2amd_extz_batch(void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez);
 int ksw2amd_extd_batch(void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez);
+
+/* splice-aware batches: the arguments of ksw_exts2_sse, scoring shared by the batch */
+typedef struct {
+	int32_t m;
+	const int8_t *mat;
+	int8_t q, e, q2, noncan, junc_bonus;
+} ksw2amd_splice_t;
+typedef struct {
+	const uint8_t *query, *target, *junc;        /* junc may be NULL */
+	int32_t qlen, tlen;
+	int32_t zdrop, flag;
+} ksw2amd_spair_t;
+int ksw2amd_exts_batch(void *km, const ksw2amd_splice_t *sc, int n, const ksw2amd_spair_t *pairs, ksw_extz_t *ez);
 
 /* The same in three phases, for callers that keep batches resident in HBM (and for benchmarking the
  * device part alone): create = pack + upload, run = kernels only (asynchronous on `stream`, a hipStream_t

@@ -33,6 +33,16 @@ class Scoring(ctypes.Structure):
                 ("q", ctypes.c_int8), ("e", ctypes.c_int8), ("q2", ctypes.c_int8), ("e2", ctypes.c_int8)]
 
 
+class SpliceScoring(ctypes.Structure):
+    _fields_ = [("m", ctypes.c_int32), ("mat", ctypes.POINTER(ctypes.c_int8)),
+                ("q", ctypes.c_int8), ("e", ctypes.c_int8), ("q2", ctypes.c_int8), ("noncan", ctypes.c_int8), ("junc_bonus", ctypes.c_int8)]
+
+
+class SplicePair(ctypes.Structure):
+    _fields_ = [("query", ctypes.c_void_p), ("target", ctypes.c_void_p), ("junc", ctypes.c_void_p), ("qlen", ctypes.c_int32),
+                ("tlen", ctypes.c_int32), ("zdrop", ctypes.c_int32), ("flag", ctypes.c_int32)]
+
+
 class Pair(ctypes.Structure):
     _fields_ = [("query", ctypes.c_void_p), ("target", ctypes.c_void_p), ("qlen", ctypes.c_int32), ("tlen", ctypes.c_int32),
                 ("w", ctypes.c_int32), ("zdrop", ctypes.c_int32), ("end_bonus", ctypes.c_int32), ("flag", ctypes.c_int32)]
@@ -50,7 +60,8 @@ EXPORTS = ["ksw_extz2_sse", "ksw_extd2_sse", "ksw_gg2", "ksw_gg2_sse", "ksw_extz
            "ksw2amd_last_error", "ksw2amd_backend", "ksw2amd_device_count", "ksw2amd_set_device", "ksw2amd_release_cache",
            "ksw2amd_extz_batch", "ksw2amd_extd_batch", "ksw2amd_plan_create", "ksw2amd_plan_run", "ksw2amd_plan_fetch",
            "ksw2amd_plan_destroy", "ksw2amd_plan_timing", "ksw2amd_plan_cells", "ksw2amd_plan_device_bytes", "ksw2amd_plan_packed_pairs",
-           "ksw2amd_plan_fetch_raw"]
+           "ksw2amd_plan_fetch_raw", "ksw_exts2_sse", "ksw_exts2_sse41", "ksw_exts2_sse2", "ksw2amd_exts_batch"]
+KSW_EZ_SPLICE_FOR, KSW_EZ_SPLICE_REV, KSW_EZ_SPLICE_FLANK = 0x100, 0x200, 0x400
 
 
 class Ksw2Error(RuntimeError):
@@ -99,6 +110,11 @@ class Library:
         for name in ("ksw_gg", "ksw_gg2", "ksw_gg2_sse"):
             getattr(L, name).argtypes = gg
             getattr(L, name).restype = _int
+        s2 = [km, _int, _u8p, _int, _u8p, _i8, _i8p, _i8, _i8, _i8, _i8, _int, _i8, _int, _u8p, ezp]
+        for name in ("ksw_exts2_sse", "ksw_exts2_sse41", "ksw_exts2_sse2"):
+            getattr(L, name).argtypes = s2
+            getattr(L, name).restype = None
+        L.ksw2amd_exts_batch.argtypes = [km, ctypes.POINTER(SpliceScoring), _int, ctypes.POINTER(SplicePair), ezp]
         L.ksw2amd_last_error.restype = ctypes.c_char_p
         L.ksw2amd_backend.restype = ctypes.c_char_p
         L.ksw2amd_set_device.argtypes = [_int]
@@ -163,6 +179,36 @@ class Library:
         ez = KswExtz() if own else ez
         self.lib.ksw_extd2_sse(None, len(qa), qp, len(ta), tp, m, mat.ctypes.data_as(_i8p), q, e, q2, e2, w, zdrop, end_bonus, flag, ez)
         return ez_to_dict(ez, free_cigar=own)
+
+    def exts2(self, query, target, mat, q, e, q2, noncan, zdrop=-1, junc_bonus=0, flag=0, junc=None, m=None):
+        """ksw_exts2_sse(km=NULL, ...): splice-aware extension -> dict of ksw_extz_t fields (+ CIGAR list)."""
+        qa, qp = self._seq(query)
+        ta, tp = self._seq(target)
+        mat = np.ascontiguousarray(mat, dtype=np.int8)
+        m = int(round(len(mat) ** 0.5)) if m is None else m
+        ja, jp = (None, None) if junc is None else self._seq(junc)
+        ez = KswExtz()
+        self.lib.ksw_exts2_sse(None, len(qa), qp, len(ta), tp, m, mat.ctypes.data_as(_i8p), q, e, q2, noncan, zdrop, junc_bonus, flag, jp, ez)
+        return ez_to_dict(ez, free_cigar=True)
+
+    def exts_batch(self, queries, targets, mat, q, e, q2, noncan, zdrop=-1, junc_bonus=0, flag=0, juncs=None, m=None):
+        """ksw2amd_exts_batch: n independent splice-aware extensions -> list of dicts."""
+        n = len(queries)
+        mat = np.ascontiguousarray(mat, dtype=np.int8)
+        m = int(round(len(mat) ** 0.5)) if m is None else m
+        qs = [np.ascontiguousarray(x, dtype=np.uint8) for x in queries]
+        ts = [np.ascontiguousarray(x, dtype=np.uint8) for x in targets]
+        js = [None if (juncs is None or juncs[i] is None) else np.ascontiguousarray(juncs[i], dtype=np.uint8) for i in range(n)]
+        bc = lambda v: np.full(n, v) if np.ndim(v) == 0 else np.asarray(v)      # noqa: E731
+        zdrop, flag = bc(zdrop), bc(flag)
+        sc = SpliceScoring(m, mat.ctypes.data_as(_i8p), q, e, q2, noncan, junc_bonus)
+        pairs = (SplicePair * max(n, 1))()
+        for i in range(n):
+            pairs[i] = SplicePair(qs[i].ctypes.data, ts[i].ctypes.data, None if js[i] is None else js[i].ctypes.data, len(qs[i]), len(ts[i]),
+                                  int(zdrop[i]), int(flag[i]))
+        ez = (KswExtz * max(n, 1))()
+        self._check(self.lib.ksw2amd_exts_batch(None, ctypes.byref(sc), n, pairs, ez))
+        return [ez_to_dict(ez[i], free_cigar=True) for i in range(n)]
 
     def extz(self, query, target, mat, q, e, w=-1, zdrop=-1, flag=0, m=None):
         qa, qp = self._seq(query)

@@ -170,6 +170,9 @@ struct ksw2amd_plan_s {
 	void *stream;
 	int stream_used;
 	int64_t cells;
+	/* splice-aware plans (exts_plan_create): tasks of h_order grouped by kernel mode x matrix variant */
+	int splice, s_first[3][2], s_count[3][2];
+	K2aSplice s_par[2];
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -575,10 +578,13 @@ err:
 	return 0;
 }
 
+static int exts_plan_run(ksw2amd_plan_t *p, void *stream);
+
 int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 {
 	int c;
 	if (!p) return fail(KSW2AMD_E_PARAM, "plan_run: NULL plan%s", 0);
+	if (p->splice) return exts_plan_run(p, stream);
 	p->stream = stream; p->ran = 1; p->stream_used = 1;
 	if (p->reject_all || p->ntasks == 0) return KSW2AMD_OK;
 	if (k2a_shim_event_record(p->ev[0], stream)) goto err;
@@ -896,3 +902,228 @@ int ksw_gg2(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *t
 int ksw_gg2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
                 int8_t q, int8_t e, int w, int *m_cigar_, int *n_cigar_, uint32_t **cigar_)
 { return global_align("ksw_gg2_sse", km, qlen, query, tlen, target, m, mat, q, e, w, m_cigar_, n_cigar_, cigar_); }
+
+/* ---------------------------------------------------------------- splice-aware extension (ksw_exts2_sse) */
+
+/* donor[t] / acceptor[t] of the reference's splice model (ksw2_exts2_sse.c:121-173; residues 0/1/2/3 = A/C/G/T):
+ * -noncan everywhere, 0 where an intron may start after t (G T | C T on the reverse strand, read through a reversed
+ * CIGAR as G A | C A) resp. end at t (A G | A C, reversed T G | T C) with the preferred flanking base, half the penalty
+ * (KSW_EZ_SPLICE_FLANK) or 0 without it; junc_bonus on annotated junction positions.  Packed with the residue code. */
+static void splice_constants(const ksw2amd_splice_t *sc, const ksw2amd_spair_t *a, uint32_t *out)
+{
+	const int tlen = a->tlen, fl = a->flag;
+	const uint8_t *T = a->target, *J = a->junc;
+	const int fwd = !!(fl & KSW_EZ_SPLICE_FOR), rev = !!(fl & KSW_EZ_SPLICE_REV), rc = !!(fl & KSW_EZ_REV_CIGAR);
+	const int on = fwd || rev, base = on ? -sc->noncan : 0, semi = (fl & KSW_EZ_SPLICE_FLANK) ? -sc->noncan / 2 : 0;
+	/* motif bases seen from position t: donor looks at t+1, t+2 (flank t+3), acceptor at t-1, t (flank t-2) */
+	const int d1f = 2, d1r = 1, d2 = rc ? 0 : 3, a1 = rc ? 3 : 0, a2f = 2, a2r = 1;
+	const int jd_f = rc ? 2 : 1, jd_r = rc ? 4 : 8, ja_f = rc ? 1 : 2, ja_r = rc ? 8 : 4;
+	int t;
+	for (t = 0; t < tlen; ++t) {
+		int don = base, acc = base;
+		if (on) {
+			if (t < tlen - 4 && T[t + 2] == d2 && ((fwd && T[t + 1] == d1f) || (rev && T[t + 1] == d1r))) {
+				const int flank = rc ? (T[t + 3] == 1 || T[t + 3] == 3) : (T[t + 3] == 0 || T[t + 3] == 2);
+				don = flank ? 0 : semi;
+			}
+			if (J && t < tlen - 1 && ((fwd && (J[t + 1] & jd_f)) || (rev && (J[t + 1] & jd_r)))) don = (int8_t)(don + sc->junc_bonus);
+			if (t >= 2 && T[t - 1] == a1 && ((fwd && T[t] == a2f) || (rev && T[t] == a2r))) {
+				const int flank = rc ? (T[t - 2] == 0 || T[t - 2] == 2) : (T[t - 2] == 1 || T[t - 2] == 3);
+				acc = flank ? 0 : semi;
+			}
+			if (J && ((fwd && (J[t] & ja_f)) || (rev && (J[t] & ja_r)))) acc = (int8_t)(acc + sc->junc_bonus);
+		}
+		out[t] = (uint32_t)T[t] | (uint32_t)(uint8_t)(int8_t)don << 8 | (uint32_t)(uint8_t)(int8_t)acc << 16;
+	}
+}
+
+static int exts_long_thres(int q, int e, int q2)           /* ksw2_exts2_sse.c:102-104 */
+{
+	int lt = (q2 - q) / e - 1;
+	if (q2 > q + e + lt * e) ++lt;
+	return lt;
+}
+
+static ksw2amd_plan_t *exts_plan_create(const ksw2amd_splice_t *sc, int n, const ksw2amd_spair_t *pairs)
+{
+	ksw2amd_plan_t *p;
+	const int m = sc ? sc->m : 0;
+	int i, k, g, lo;
+	size_t off, mat_off;
+	void *up;
+	uint32_t fill[3][2];
+
+	g_err[0] = 0;
+	if (n < 0 || (n > 0 && !pairs) || !sc) { fail(KSW2AMD_E_PARAM, "exts: bad arguments%s", 0); return 0; }
+	if (k2a_shim_device_count() <= 0) { fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend()); return 0; }
+	p = (ksw2amd_plan_t*)calloc(1, sizeof(*p));
+	p->splice = 1; p->n = n; p->m = m;
+	p->h_cls = (int8_t*)malloc((size_t)n + 1);
+	p->h_half = (uint8_t*)calloc((size_t)n + 1, 1);
+	p->h_flag = (int32_t*)malloc(sizeof(int32_t) * ((size_t)n + 1));
+	p->h_pairs = (K2aPair*)calloc((size_t)n + 1, sizeof(K2aPair));
+	p->h_res = (K2aResult*)calloc((size_t)n + 1, sizeof(K2aResult));
+	p->h_order = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n + 1));
+	for (i = 0; i < n; ++i) { p->h_cls[i] = -1; p->h_flag[i] = pairs[i].flag; }
+	/* ksw2_exts2_sse.c:74,91: unusable model or a mismatch no gap pair could undercut -> results stay reset */
+	if (m <= 1 || !sc->mat || sc->q2 <= sc->q + sc->e) p->reject_all = 1;
+	else if (m > K2A_MAXM || sc->e <= 0) { fail(KSW2AMD_E_PARAM, "exts: m > 127 or gap extension <= 0%s", 0); goto err; }
+	else {
+		for (k = 1, lo = sc->mat[1]; k < m * m; ++k) lo = imin(lo, sc->mat[k]);
+		if (-lo > 2 * (sc->q + sc->e)) p->reject_all = 1;
+	}
+	if (p->reject_all || n == 0) return p;
+
+	/* arena: query bytes (4-aligned) + one dword of constants per target position; the two effective matrices at the end */
+	memset(p->s_count, 0, sizeof(p->s_count));
+	off = 0;
+	for (i = 0; i < n; ++i) {
+		const ksw2amd_spair_t *a = &pairs[i];
+		K2aPair *d = &p->h_pairs[i];
+		int mode, generic;
+		if (a->qlen <= 0 || a->tlen <= 0) continue;
+		if (!a->query || !a->target) { fail(KSW2AMD_E_PARAM, "exts: NULL sequence%s", 0); goto err; }
+		if (imin(a->qlen, a->tlen) > 24 * 64 - 64) {
+			fail(KSW2AMD_E_PARAM, "exts: min(qlen, tlen) > 1472 is not supported by this release%s", 0);
+			goto err;
+		}
+		mode = (a->flag & KSW_EZ_SCORE_ONLY) ? K2A_MODE_SCORE : (a->flag & KSW_EZ_RIGHT) ? K2A_MODE_RIGHT : K2A_MODE_LEFT;
+		generic = (a->flag & KSW_EZ_GENERIC_SC) ? 1 : 0;
+		p->h_cls[i] = (int8_t)(mode * 2 + generic);
+		++p->s_count[mode][generic];
+		d->qlen = a->qlen; d->tlen = d->tlen_full = a->tlen;
+		d->w = imax(a->qlen, a->tlen);                 /* no band: k2a_finish must never see an unreachable corner */
+		d->zdrop = a->zdrop; d->end_bonus = K2A_NEG;   /* no end bonus in this function */
+		d->flag = a->flag & (KSW_EZ_EXTZ_ONLY | KSW_EZ_REV_CIGAR | KSW_EZ_SCORE_ONLY);
+		off = align_up(off, 4); d->qoff = (uint32_t)off; off += (size_t)a->qlen;
+		off = align_up(off, 4); d->bnd_off = (uint32_t)(off / 4); off += 4 * (size_t)a->tlen;
+		if (off > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "exts: more than 4 GiB of sequence in one plan%s", 0); goto err; }
+		p->cells += (int64_t)a->qlen * a->tlen;
+		if (mode != K2A_MODE_SCORE) {
+			d->tb_off = p->tb_bytes;
+			p->tb_bytes += align_up((size_t)(a->qlen + a->tlen - 1) * (size_t)imin(a->qlen, a->tlen), 256);
+			d->cig_off = (uint32_t)p->cig_words;
+			p->cig_words += (size_t)a->qlen + a->tlen + 2;
+			if (p->cig_words > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "exts: CIGAR scratch over 16 GiB in one plan%s", 0); goto err; }
+		}
+	}
+	off = align_up(off + 256, 256);
+	mat_off = off; off = align_up(off + 2 * (size_t)m * m, 256);
+	p->seq_bytes = off;
+	p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, p->seq_bytes, &p->cap[BUF_HSEQ]);
+	if (!p->h_seq) { fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
+	for (k = 0, i = 0; i < 3; ++i)
+		for (g = 0; g < 2; ++g) { p->s_first[i][g] = k; fill[i][g] = (uint32_t)k; k += p->s_count[i][g]; }
+	p->ntasks = p->norder = k;
+	for (i = 0; i < n; ++i) {
+		const ksw2amd_spair_t *a = &pairs[i];
+		if (p->h_cls[i] < 0) continue;
+		memcpy(p->h_seq + p->h_pairs[i].qoff, a->query, (size_t)a->qlen);
+		splice_constants(sc, a, (uint32_t*)p->h_seq + p->h_pairs[i].bnd_off);
+		p->h_order[fill[p->h_cls[i] / 2][p->h_cls[i] & 1]++] = (uint32_t)i;
+	}
+	build_eff(0, m, sc->mat, sc->e, 0, 0, (int8_t*)p->h_seq + mat_off);
+	build_eff(0, m, sc->mat, sc->e, 0, 1, (int8_t*)p->h_seq + mat_off + (size_t)m * m);
+
+	p->d_seq = (uint8_t*)cache_get(BUF_SEQ, p->seq_bytes, &p->cap[BUF_SEQ]);
+	p->d_pairs = (K2aPair*)cache_get(BUF_PAIRS, sizeof(K2aPair) * ((size_t)n + 1), &p->cap[BUF_PAIRS]);
+	p->d_res = (K2aResult*)cache_get(BUF_RES, sizeof(K2aResult) * ((size_t)n + 1), &p->cap[BUF_RES]);
+	p->d_order = (uint32_t*)cache_get(BUF_ORDER, sizeof(uint32_t) * ((size_t)p->norder + 1), &p->cap[BUF_ORDER]);
+	p->d_tb = p->tb_bytes ? (uint8_t*)cache_get(BUF_TB, p->tb_bytes, &p->cap[BUF_TB]) : 0;
+	p->d_cig = p->cig_words ? (uint32_t*)cache_get(BUF_CIG, p->cig_words * 4, &p->cap[BUF_CIG]) : 0;
+	if (!p->d_seq || !p->d_pairs || !p->d_res || !p->d_order || (p->tb_bytes && !p->d_tb) || (p->cig_words && !p->d_cig)) {
+		fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error());
+		goto err;
+	}
+	up = thread_stream();
+	p->stream = up; p->stream_used = 1;
+	if (k2a_shim_h2d(p->d_seq, p->h_seq, p->seq_bytes, up) || k2a_shim_h2d(p->d_pairs, p->h_pairs, sizeof(K2aPair) * (size_t)n, up) ||
+	    k2a_shim_h2d(p->d_order, p->h_order, sizeof(uint32_t) * (size_t)p->norder, up) ||
+	    k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)n, up) || k2a_shim_stream_sync(up)) {
+		fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error());
+		goto err;
+	}
+	for (g = 0; g < 2; ++g) {
+		p->s_par[g].q = sc->q; p->s_par[g].e = sc->e; p->s_par[g].q2 = sc->q2; p->s_par[g].m = m;
+		p->s_par[g].long_thres = exts_long_thres(sc->q, sc->e, sc->q2);
+		p->s_par[g].mat = (const int8_t*)p->d_seq + mat_off + (g ? (size_t)m * m : 0);
+	}
+	for (i = 0; i < 3; ++i) { p->ev[i] = g_ev_cache[i] ? g_ev_cache[i] : k2a_shim_event_create(); g_ev_cache[i] = 0; }
+	return p;
+err:
+	ksw2amd_plan_destroy(p);
+	return 0;
+}
+
+static int exts_plan_run(ksw2amd_plan_t *p, void *stream)
+{
+	int mode, g;
+	p->stream = stream; p->ran = 1; p->stream_used = 1;
+	if (p->reject_all || p->ntasks == 0) return KSW2AMD_OK;
+	if (k2a_shim_event_record(p->ev[0], stream)) goto err;
+	for (mode = 0; mode < 3; ++mode)
+		for (g = 0; g < 2; ++g)
+			if (p->s_count[mode][g] &&
+			    k2a_shim_launch_exts(mode, &p->s_par[g], p->d_pairs, p->d_order + p->s_first[mode][g], p->s_count[mode][g], p->d_seq, p->d_tb,
+			                         p->d_res, stream)) goto err;
+	if (k2a_shim_event_record(p->ev[1], stream)) goto err;
+	for (mode = 1; mode < 3; ++mode)
+		for (g = 0; g < 2; ++g)
+			if (p->s_count[mode][g] &&
+			    k2a_shim_launch_exts_trace(&p->s_par[g], p->d_pairs, p->d_order + p->s_first[mode][g], p->s_count[mode][g], p->d_tb, p->d_res,
+			                               p->d_cig, stream)) goto err;
+	if (k2a_shim_event_record(p->ev[2], stream)) goto err;
+	return KSW2AMD_OK;
+err:
+	return fail(KSW2AMD_E_NODEVICE, "exts run: %s", k2a_shim_last_error());
+}
+
+int ksw2amd_exts_batch(void *km, const ksw2amd_splice_t *sc, int n, const ksw2amd_spair_t *pairs, ksw_extz_t *ez)
+{
+	int beg = 0;
+	size_t budget, free_b = 0, total_b = 0;
+	const char *env = getenv("KSW2AMD_MAX_BYTES");
+	if (n <= 0) return KSW2AMD_OK;
+	if (k2a_shim_device_count() <= 0) return fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend());
+	if (env && atoll(env) > 0) budget = (size_t)atoll(env);
+	else if (n == 1) budget = (size_t)1 << 34;
+	else {
+		if (k2a_shim_mem_info(&free_b, &total_b)) return fail(KSW2AMD_E_NODEVICE, "mem_info: %s", k2a_shim_last_error());
+		budget = free_b / 10 * 7;
+	}
+	while (beg < n) {
+		ksw2amd_plan_t *p;
+		size_t acc = 0, seq = 0;
+		int end, rc;
+		for (end = beg; end < n; ++end) {
+			const size_t ql = (size_t)imax(pairs[end].qlen, 0), tl = (size_t)imax(pairs[end].tlen, 0);
+			const size_t b = ql + 4 * tl + 256 + ((pairs[end].flag & KSW_EZ_SCORE_ONLY) ? 0 : (ql + tl) * (ql < tl ? ql : tl) + 4 * (ql + tl) + 512);
+			if (end > beg && (acc + b > budget || seq + ql + 4 * tl > 3000000000u || end - beg >= (1 << 22))) break;
+			acc += b; seq += ql + 4 * tl + 16;
+		}
+		p = exts_plan_create(sc, end - beg, pairs + beg);
+		if (!p) return strstr(g_err, "alloc") ? KSW2AMD_E_NOMEM : strstr(g_err, "device") ? KSW2AMD_E_NODEVICE : KSW2AMD_E_PARAM;
+		rc = ksw2amd_plan_run(p, thread_stream());
+		if (rc == KSW2AMD_OK) rc = ksw2amd_plan_fetch(p, km, ez + beg);
+		ksw2amd_plan_destroy(p);
+		if (rc) return rc;
+		beg = end;
+	}
+	return KSW2AMD_OK;
+}
+
+void ksw_exts2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                   int8_t q, int8_t e, int8_t q2, int8_t noncan, int zdrop, int8_t junc_bonus, int flag, const uint8_t *junc, ksw_extz_t *ez)
+{
+	ksw2amd_splice_t sc;
+	ksw2amd_spair_t pr;
+	sc.m = m; sc.mat = mat; sc.q = q; sc.e = e; sc.q2 = q2; sc.noncan = noncan; sc.junc_bonus = junc_bonus;
+	pr.query = query; pr.target = target; pr.junc = junc; pr.qlen = qlen; pr.tlen = tlen; pr.zdrop = zdrop; pr.flag = flag;
+	if (ksw2amd_exts_batch(km, &sc, 1, &pr, ez) != KSW2AMD_OK) die_loudly("ksw_exts2_sse");
+}
+void ksw_exts2_sse41(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                     int8_t q, int8_t e, int8_t q2, int8_t noncan, int zdrop, int8_t junc_bonus, int flag, const uint8_t *junc, ksw_extz_t *ez)
+{ ksw_exts2_sse(km, qlen, query, tlen, target, m, mat, q, e, q2, noncan, zdrop, junc_bonus, flag, junc, ez); }
+void ksw_exts2_sse2(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                    int8_t q, int8_t e, int8_t q2, int8_t noncan, int zdrop, int8_t junc_bonus, int flag, const uint8_t *junc, ksw_extz_t *ez)
+{ ksw_exts2_sse(km, qlen, query, tlen, target, m, mat, q, e, q2, noncan, zdrop, junc_bonus, flag, junc, ez); }

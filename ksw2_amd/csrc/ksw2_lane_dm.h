@@ -1,0 +1,136 @@
+/*
+ * ksw2_lane_dm.h -- per-lane code of the splice-aware extension (replaces ksw_exts2_sse, ksw2_exts2_sse.c:33-415).
+ *
+ * Unlike the banded kernels (ksw2_lane.h) this function is unbanded and does its bookkeeping -- running maximum,
+ * Z-drop, mqe / mte -- once per ANTI-DIAGONAL r = i + j on the diagonal's best cell (ksw2_exts2_sse.c:345-384), with
+ * ties inside a diagonal resolved by the reference's own scan order.  So the kernel is diagonal-major like the
+ * reference: one alignment per wavefront, lane <-> target position t (64 per register "slot", K2A_DM_SLOTS slots in a
+ * window that slides with the diagonal), one step per diagonal.  A lane keeps H of the last two diagonals and the gap
+ * states leaving its cell; the values a cell needs from row t-1 arrive by a one-lane shift (DPP wave_shr:1 with the
+ * previous slot's last lane carried in).  Everything is int32 absolute scores (the reference's int8 differences, summed).
+ *
+ *   H(i,j)    = max{ H(i-1,j-1) + s(i,j), E(i,j), F(i,j), E~(i,j) + acceptor[i] }
+ *   E(i+1,j)  = max{ E(i,j), H(i,j) - q } - e         F(i,j+1) likewise
+ *   E~(i+1,j) = max{ E~(i,j), H(i,j) - q2 + donor[i] }                  (long gap: no extension cost)
+ *   row -1 / column -1: Hb(k) = -(q + k e) for k <= long_thres, else -q2      (ksw2_exts2_sse.c:102-105,196-213)
+ *
+ * Direction byte (ksw2.h:125-128): bits 0-2 winner {0 diag, 1 E, 2 F, 3 E~}, 0x08 / 0x10 / 0x20 = the E / F / E~ leaving
+ * the cell continues a gap; strictness of every comparison as in ksw2_exts2_sse.c:262-343 (left / right alignment).
+ */
+#ifndef KSW2_LANE_DM_H_
+#define KSW2_LANE_DM_H_
+
+#include "ksw2_lane.h"
+
+#define K2A_DM_SLOTS 24                                  /* 64 target positions each: diagonals up to 24*64 - 64 cells */
+#define K2A_DM_MAXDIAG (K2A_DM_SLOTS * 64 - 64)
+
+/* virtual row -1 / column -1 at distance k from the origin */
+K2A_FN int k2a_dm_border(const K2aSplice &sp, int k)
+{
+	return k <= 0 ? 0 : k <= sp.long_thres ? -(sp.q + k * sp.e) : -sp.q2;
+}
+
+/* per-target-position constants, packed by the host: bits 0-7 residue code, 8-15 donor[t], 16-23 acceptor[t] (int8) */
+K2A_FN uint32_t k2a_dm_pack(uint32_t code, int donor, int acceptor)
+{
+	return (code & 0xffu) | ((uint32_t)(uint8_t)(int8_t)donor << 8) | ((uint32_t)(uint8_t)(int8_t)acceptor << 16);
+}
+
+/* one cell.  diag = H(i-1,j-1), ein / e2in / fin = E, E~, F entering the cell, s = score, cst = packed constants of row i.
+ * MODE as in the banded kernels (0 score only, 1 left-aligned, 2 right-aligned gaps). */
+template<int MODE>
+K2A_FN void k2a_dm_cell(const K2aSplice &sp, int diag, int ein, int e2in, int fin, int s, uint32_t cst,
+                        int &z, int &en, int &e2n, int &fn, uint32_t &dir)
+{
+	const int donor = (int)(int8_t)(cst >> 8), acceptor = (int)(int8_t)(cst >> 16);
+	const int a2a = e2in + acceptor;
+	uint32_t d = 0;
+	z = diag + s;
+	if (MODE == K2A_MODE_RIGHT) {
+		d = z > ein ? 0u : 1u;  z = k2a_max(z, ein);
+		d = z > fin ? d : 2u;   z = k2a_max(z, fin);
+		d = z > a2a ? d : 3u;   z = k2a_max(z, a2a);
+	} else {
+		d = ein > z ? 1u : 0u;  z = k2a_max(z, ein);
+		d = fin > z ? 2u : d;   z = k2a_max(z, fin);
+		d = a2a > z ? 3u : d;   z = k2a_max(z, a2a);
+	}
+	const int t1 = z - sp.q, t2 = z - sp.q2 + donor;
+	if (MODE == K2A_MODE_LEFT) {
+		d |= ein > t1 ? 0x08u : 0u; d |= fin > t1 ? 0x10u : 0u; d |= e2in > t2 ? 0x20u : 0u;
+	} else if (MODE == K2A_MODE_RIGHT) {
+		d |= ein >= t1 ? 0x08u : 0u; d |= fin >= t1 ? 0x10u : 0u; d |= e2in >= t2 ? 0x20u : 0u;
+	}
+	en = k2a_max(ein, t1) - sp.e;
+	fn = k2a_max(fin, t1) - sp.e;
+	e2n = k2a_max(e2in, t2);
+	dir = d;
+}
+
+/* The best cell of a diagonal in the reference's scan order (ksw2_exts2_sse.c:347-377): the diagonal's last cell en0 first;
+ * it is replaced only by a strictly larger cell of the "4-lane region" [st0, en1), among which the larger H, then the
+ * smaller (t - st0) mod 4, then the smaller t wins; then by a strictly larger cell of the tail [en1, en0) in ascending t.
+ * Lanes turn their best region cell into a key whose maximum over the wavefront is that winner. */
+K2A_FN uint64_t k2a_dm_key(int H, int t, int st0)
+{
+	const uint32_t i = (uint32_t)(t - st0) & 3u;
+	return ((uint64_t)((uint32_t)H ^ 0x80000000u) << 32) | (uint64_t)(0xffffffffu - ((i << 28) | (uint32_t)t));
+}
+K2A_FN int k2a_dm_key_H(uint64_t key) { return (int)((uint32_t)(key >> 32) ^ 0x80000000u); }
+K2A_FN int k2a_dm_key_t(uint64_t key) { return (int)((0xffffffffu - (uint32_t)key) & 0x0fffffffu); }
+
+/* per-diagonal bookkeeping on uniform values (ksw2_exts2_sse.c:371-377, ksw_apply_zdrop with is_rot = 1 and e = 0):
+ * A = H at en0, Bkey = region winner (0 = empty region), T[x] = H at en1 + x, S = H at st0.  Returns 1 on a Z-drop. */
+K2A_FN int k2a_dm_book(K2aBook *b, int r, int st0, int en0, int qlen, int tlen, int zdrop, int A, uint64_t Bkey, const int *T, int S)
+{
+	const int en1 = st0 + (en0 - st0) / 4 * 4;
+	int max_H = A, max_t = en0;
+	if (Bkey != 0 && k2a_dm_key_H(Bkey) > max_H) { max_H = k2a_dm_key_H(Bkey); max_t = k2a_dm_key_t(Bkey); }
+	for (int x = 0; x < 3; ++x)
+		if (en1 + x < en0 && T[x] > max_H) { max_H = T[x]; max_t = en1 + x; }
+	if (en0 == tlen - 1 && A > b->mte) { b->mte = A; b->mte_q = r - ((en0 + 16) / 16 * 16 - 1); }   /* the reference's padded `en` */
+	if (r - st0 == qlen - 1 && S > b->mqe) { b->mqe = S; b->mqe_t = st0; }
+	if (max_H > b->max) { b->max = max_H; b->max_t = max_t; b->max_q = r - max_t; }
+	else if (max_t >= b->max_t && r - max_t >= b->max_q) {
+		if (zdrop >= 0 && b->max - max_H > zdrop) { b->dropped = 1; return 1; }
+	}
+	if (r == qlen + tlen - 2 && en0 == tlen - 1) b->score = A;
+	b->rows = r + 1;
+	return 0;
+}
+
+/* ksw_backtrack with is_rot = 1 (ksw2.h:129-161) on the diagonal-major direction bytes tb[r*ncol + i - st0(r)]:
+ * writes the CIGAR in walk order (end -> start), returns the op count.  State 3 is an intron (N) when long_thres > 0. */
+K2A_FN int k2a_dm_trace(const uint8_t *tb, int ncol, int i, int j, uint32_t *out, int qlen, int long_thres)
+{
+	int n = 0, state = 0;
+	uint32_t last_op = 0xffffffffu, run = 0;
+	while (i >= 0 && j >= 0) {
+		const int r = i + j, st0 = k2a_max(0, r - qlen + 1);
+		const uint32_t d = tb[(size_t)r * ncol + (i - st0)];
+		if (state == 0) state = d & 7;
+		else if (!((d >> (state + 2)) & 1)) state = 0;
+		if (state == 0) state = d & 7;
+		uint32_t op;
+		if (state == 0) { op = 0; --i; --j; }
+		else if (state == 1 || (state == 3 && long_thres <= 0)) { op = 2; --i; }
+		else if (state == 3) { op = 3; --i; }
+		else { op = 1; --j; }
+		if (op == last_op) ++run;
+		else { if (run) out[n++] = run << 4 | last_op; last_op = op; run = 1; }
+	}
+	if (i >= 0) {                                     /* leading deletion / intron */
+		const uint32_t op = long_thres > 0 && i >= long_thres ? 3u : 2u;
+		if (last_op == op) run += i + 1;
+		else { if (run) out[n++] = run << 4 | last_op; last_op = op; run = i + 1; }
+	}
+	if (j >= 0) {                                     /* leading insertion */
+		if (last_op == 1) run += j + 1;
+		else { if (run) out[n++] = run << 4 | last_op; last_op = 1; run = j + 1; }
+	}
+	if (run) out[n++] = run << 4 | last_op;
+	return n;
+}
+
+#endif

@@ -70,6 +70,15 @@ int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, const K2aS
 int k2a_shim_launch_trace_pk(int cfg, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb,
                              K2aResult *res, uint32_t *cig, void *stream);
 
+/* Splice-aware extension (ksw2_lane_dm.h): one alignment per wavefront, diagonal-major.  pairs[i].bnd_off = dword offset
+ * (in seq) of the alignment's packed per-target-position constants, tb_off = its direction bytes ((qlen+tlen-1) rows of
+ * min(qlen,tlen) bytes), w / end_bonus set so that k2a_finish applies the plain start-cell rule.  The trace launch walks
+ * them with the intron state.  order[t] = index into pairs / res, as for the fill kernels. */
+int k2a_shim_launch_exts(int mode, const K2aSplice *sp, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
+                         uint8_t *tb, K2aResult *res, void *stream);
+int k2a_shim_launch_exts_trace(const K2aSplice *sp, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb,
+                               K2aResult *res, uint32_t *cig, void *stream);
+
 /* Compaction: pool[pos[i] .. pos[i]+res[i].n_cigar) = cig[pairs[i].cig_off ..) for the n pairs of a plan
  * (pos = exclusive prefix sum of n_cigar, computed by the host), so that one D2H brings every CIGAR back. */
 int k2a_shim_launch_compact(const K2aPair *pairs, const K2aResult *res, const uint32_t *pos, int n, const uint32_t *cig,

@@ -13,6 +13,7 @@
 #include "ksw2_shim.h"
 #include "ksw2_lane.h"
 #include "ksw2_lane_pk.h"
+#include "ksw2_lane_dm.h"
 
 #define K2A_WPB 4          /* wavefronts per workgroup; waves never synchronise with each other */
 #define K2A_TRACE_PPW 8    /* alignments walked per wavefront by the traceback kernel */
@@ -441,6 +442,129 @@ k2a_trace_pk_kernel(const K2aPair *__restrict__ pairs, const uint32_t *__restric
 	res[pi].n_cigar = n;
 }
 
+/* ---------------------------------------------------------------- splice-aware extension, diagonal-major (ksw2_lane_dm.h) */
+
+/* lane l <- lane l-1 across the whole wavefront, lane 0 <- `carry` (the previous slot's lane 63) */
+__device__ __forceinline__ int k2a_shr1_carry(int v, int carry)
+{
+	return __builtin_amdgcn_update_dpp(carry, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
+/* maximum of a 64-bit key over the wavefront (butterfly, two 32-bit shuffles per level) */
+__device__ __forceinline__ uint64_t k2a_wave_max_u64(uint64_t k)
+{
+#pragma unroll
+	for (int m = 32; m >= 1; m >>= 1) {
+		const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)k, m, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(k >> 32), m, 64);
+		const uint64_t o = ((uint64_t)hi << 32) | lo;
+		k = o > k ? o : k;
+	}
+	return k;
+}
+
+template<int MODE>
+__global__ void __launch_bounds__(64 * K2A_WPB)
+k2a_exts_kernel(const K2aSplice sp, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
+                const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, K2aResult *__restrict__ res)
+{
+	enum { K = K2A_DM_SLOTS };
+	__shared__ int8_t mtab[K2A_MAXM * K2A_MAXM];
+	for (int x = threadIdx.x; x < sp.m * sp.m; x += blockDim.x) mtab[x] = sp.mat[x];
+	__syncthreads();
+
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int task = blockIdx.x * K2A_WPB + wave;
+	if (task >= ntasks) return;                       /* whole wavefronts leave; nobody synchronises below */
+	const uint32_t pi = order[task];
+	const K2aPair pr = pairs[pi];
+	const int qlen = pr.qlen, tlen = pr.tlen_full, ncol = min(qlen, tlen);
+	const uint8_t *qry = seq + pr.qoff;
+	const uint32_t *cst = (const uint32_t*)seq + pr.bnd_off;
+	uint8_t *tbp = tb + pr.tb_off;
+
+	int H1[K], H2[K], En[K], E2n[K], Fn[K];
+	uint32_t Q[K], Cst[K];
+#pragma unroll
+	for (int s = 0; s < K; ++s) {
+		H1[s] = H2[s] = En[s] = E2n[s] = Fn[s] = K2A_NEG; Q[s] = 0;
+		Cst[s] = cst[min(s * 64 + lane, tlen - 1)];
+	}
+	int base = 0;
+	K2aBook book;
+	k2a_book_reset(&book);
+	uint32_t qnext = qry[0];
+
+	for (int r = 0; r < qlen + tlen - 1; ++r) {
+		const int st0 = max(0, r - qlen + 1), en0 = min(tlen - 1, r), en1 = st0 + (en0 - st0) / 4 * 4;
+		while (st0 >= 1 && (st0 - 1) / 64 > base) {                        /* slide the window: slot s <- slot s+1 */
+#pragma unroll
+			for (int s = 0; s + 1 < K; ++s) {
+				H1[s] = H1[s + 1]; H2[s] = H2[s + 1]; En[s] = En[s + 1]; E2n[s] = E2n[s + 1]; Fn[s] = Fn[s + 1]; Q[s] = Q[s + 1]; Cst[s] = Cst[s + 1];
+			}
+			++base;
+			H1[K - 1] = H2[K - 1] = En[K - 1] = E2n[K - 1] = Fn[K - 1] = K2A_NEG; Q[K - 1] = 0;
+			Cst[K - 1] = cst[min((base + K - 1) * 64 + lane, tlen - 1)];
+		}
+		const uint32_t qcur = qnext;
+		qnext = qry[min(r + 1, qlen - 1)];                               /* used one diagonal later */
+		int cH2 = K2A_NEG, cEn = K2A_NEG, cE2n = K2A_NEG, cQ = 0;
+		int A = K2A_NEG, S = K2A_NEG, T[3] = { K2A_NEG, K2A_NEG, K2A_NEG };
+		int bH = K2A_NEG, bT = -1;
+#pragma unroll
+		for (int s = 0; s < K; ++s) {
+			const int h2s = k2a_shr1_carry(H2[s], cH2), ens = k2a_shr1_carry(En[s], cEn), e2ns = k2a_shr1_carry(E2n[s], cE2n);
+			const uint32_t qs = (uint32_t)k2a_shr1_carry((int)Q[s], cQ);
+			cH2 = __builtin_amdgcn_readlane(H2[s], 63); cEn = __builtin_amdgcn_readlane(En[s], 63);
+			cE2n = __builtin_amdgcn_readlane(E2n[s], 63); cQ = __builtin_amdgcn_readlane((int)Q[s], 63);
+			const int t0 = (base + s) * 64, t = t0 + lane;
+			Q[s] = t == 0 ? qcur : qs;
+			if (t0 <= en0 && t0 + 63 >= st0) {                              /* wave-uniform: the slot holds cells of this diagonal */
+				const bool active = t >= st0 && t <= en0, first_row = t == 0, first_col = t == r;
+				const int diag = first_row ? k2a_dm_border(sp, r) : first_col ? k2a_dm_border(sp, t) : h2s;
+				const int ein = first_row ? k2a_dm_border(sp, r + 1) - sp.q - sp.e : ens;
+				const int e2in = first_row ? k2a_dm_border(sp, r + 1) - sp.q2 : e2ns;
+				const int fin = first_col ? k2a_dm_border(sp, t + 1) - sp.q - sp.e : Fn[s];
+				const uint32_t c = Cst[s];
+				const int sc = (int)mtab[(c & 0xffu) * (uint32_t)sp.m + (Q[s] & 0xffu)];
+				int z, en, e2n, fn;
+				uint32_t dir;
+				k2a_dm_cell<MODE>(sp, diag, ein, e2in, fin, sc, c, z, en, e2n, fn, dir);
+				if (active) {
+					H2[s] = H1[s]; H1[s] = z; En[s] = en; E2n[s] = e2n; Fn[s] = fn;
+					if (MODE != K2A_MODE_SCORE) tbp[(size_t)r * ncol + (t - st0)] = (uint8_t)dir;
+					if (t < en1 && z > bH) { bH = z; bT = t; }
+				}
+				/* the cells the bookkeeping reads by position: the diagonal's last and first cell, the (<= 3) tail cells */
+				if (en0 >= t0 && en0 < t0 + 64) A = __builtin_amdgcn_readlane(H1[s], en0 & 63);
+				if (st0 >= t0 && st0 < t0 + 64) S = __builtin_amdgcn_readlane(H1[s], st0 & 63);
+#pragma unroll
+				for (int x = 0; x < 3; ++x) {
+					const int tt = en1 + x;
+					if (tt < en0 && tt >= t0 && tt < t0 + 64) T[x] = __builtin_amdgcn_readlane(H1[s], tt & 63);
+				}
+			}
+		}
+		const uint64_t Bkey = k2a_wave_max_u64(bT >= 0 ? k2a_dm_key(bH, bT, st0) : 0ull);
+		if (k2a_dm_book(&book, r, st0, en0, qlen, tlen, pr.zdrop, A, Bkey, T, S)) break;
+	}
+	if (lane == 0) k2a_finish(pr, book, &res[pi]);
+}
+
+__global__ void __launch_bounds__(64)
+k2a_exts_trace_kernel(const K2aSplice sp, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
+                      const uint8_t *__restrict__ tb, K2aResult *__restrict__ res, uint32_t *__restrict__ cig)
+{
+	if (threadIdx.x >= K2A_TRACE_PPW) return;
+	const int t = blockIdx.x * K2A_TRACE_PPW + threadIdx.x;
+	if (t >= ntasks) return;
+	const uint32_t pi = order[t];
+	const K2aPair pr = pairs[pi];
+	const int ti = res[pi].ti, tj = res[pi].tj;
+	int n = 0;
+	if (ti >= 0 && tj >= 0) n = k2a_dm_trace(tb + pr.tb_off, min(pr.qlen, pr.tlen_full), ti, tj, cig + pr.cig_off, pr.qlen, sp.long_thres);
+	res[pi].n_cigar = n;
+}
+
 typedef void (*fill_pk_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*);
 #define PK_ROW(G, C, RB) { { k2a_fill_pk_kernel<G, C, false, 0, RB>, k2a_fill_pk_kernel<G, C, false, 1, RB>, k2a_fill_pk_kernel<G, C, false, 2, RB> }, \
                            { k2a_fill_pk_kernel<G, C, true, 0, RB>,  k2a_fill_pk_kernel<G, C, true, 1, RB>,  k2a_fill_pk_kernel<G, C, true, 2, RB> } }
@@ -581,6 +705,29 @@ int k2a_shim_launch_trace_pk(int cfg, const K2aPair *pairs, const uint32_t *orde
 	if (cfg < 0 || cfg >= K2A_NPKCFG) { snprintf(g_err, sizeof(g_err), "bad packed kernel class"); return -1; }
 	hipLaunchKernelGGL(g_trace_pk[cfg], dim3((2 * ntasks + K2A_TRACE_PPW - 1) / K2A_TRACE_PPW), dim3(64), 0, (hipStream_t)stream,
 	                   pairs, order2, ntasks, tb, res, cig);
+	CHECK(hipGetLastError());
+	return 0;
+}
+
+int k2a_shim_launch_exts(int mode, const K2aSplice *sp, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
+                         uint8_t *tb, K2aResult *res, void *stream)
+{
+	if (ntasks <= 0) return 0;
+	const dim3 grid((ntasks + K2A_WPB - 1) / K2A_WPB), block(64 * K2A_WPB);
+	if (mode == K2A_MODE_SCORE) hipLaunchKernelGGL(k2a_exts_kernel<K2A_MODE_SCORE>, grid, block, 0, (hipStream_t)stream, *sp, pairs, order, ntasks, seq, tb, res);
+	else if (mode == K2A_MODE_LEFT) hipLaunchKernelGGL(k2a_exts_kernel<K2A_MODE_LEFT>, grid, block, 0, (hipStream_t)stream, *sp, pairs, order, ntasks, seq, tb, res);
+	else if (mode == K2A_MODE_RIGHT) hipLaunchKernelGGL(k2a_exts_kernel<K2A_MODE_RIGHT>, grid, block, 0, (hipStream_t)stream, *sp, pairs, order, ntasks, seq, tb, res);
+	else { snprintf(g_err, sizeof(g_err), "bad mode"); return -1; }
+	CHECK(hipGetLastError());
+	return 0;
+}
+
+int k2a_shim_launch_exts_trace(const K2aSplice *sp, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb,
+                               K2aResult *res, uint32_t *cig, void *stream)
+{
+	if (ntasks <= 0) return 0;
+	hipLaunchKernelGGL(k2a_exts_trace_kernel, dim3((ntasks + K2A_TRACE_PPW - 1) / K2A_TRACE_PPW), dim3(64), 0, (hipStream_t)stream,
+	                   *sp, pairs, order, ntasks, tb, res, cig);
 	CHECK(hipGetLastError());
 	return 0;
 }

@@ -31,6 +31,13 @@ typedef struct K2aScoring {
 	const int8_t *mat;           /* device copy of the effective m x m matrix, mat[target*m + query]       */
 } K2aScoring;
 
+/* batch-uniform parameters of the splice-aware extension (ksw2_lane_dm.h), passed by value */
+typedef struct K2aSplice {
+	int32_t q, e, q2, long_thres;
+	int32_t m;
+	const int8_t *mat;           /* device copy of the effective m x m matrix, mat[target*m + query] */
+} K2aSplice;
+
 /* one alignment, device-resident */
 typedef struct K2aPair {
 	uint32_t qoff, toff;         /* byte offsets of query / target in the sequence arena                  */

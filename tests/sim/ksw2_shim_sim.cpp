@@ -12,6 +12,7 @@
 #include <cstring>
 #include "../../ksw2_amd/csrc/ksw2_shim.h"
 #include "../../ksw2_amd/csrc/ksw2_lane.h"
+#include "../../ksw2_amd/csrc/ksw2_lane_dm.h"
 #include "../../ksw2_amd/csrc/ksw2_lane_pk.h"
 
 static char g_err[256] = "";
@@ -341,6 +342,104 @@ static const fill_pk_fn g_fill_pk[2][K2A_NPKCFG][2][3] = { { PK_ROW(8, 18, false
                                                           { PK_ROW(8, 18, true),  PK_ROW(16, 8, true),  PK_ROW(64, 8, true),  PK_ROW(64, 16, true) } };
 static const trace_fn g_trace_pk[K2A_NPKCFG] = { sim_trace_pk<8, 18>, sim_trace_pk<16, 8>, sim_trace_pk<64, 8>, sim_trace_pk<64, 16> };
 
+
+/* mirrors k2a_exts_kernel: one alignment per wavefront, diagonal-major, K2A_DM_SLOTS slots of 64 target positions */
+template<int MODE>
+static void sim_exts(const K2aSplice sp, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res)
+{
+	enum { K = K2A_DM_SLOTS };
+	for (int task = 0; task < ntasks; ++task) {
+		const uint32_t pi = order[task];
+		const K2aPair pr = pairs[pi];
+		const int qlen = pr.qlen, tlen = pr.tlen_full;
+		const uint8_t *qry = seq + pr.qoff;
+		const uint32_t *cst = (const uint32_t*)seq + pr.bnd_off;
+		uint8_t *tbp = tb + pr.tb_off;
+		const int ncol = k2a_min(qlen, tlen);
+		static int H1[K][64], H2[K][64], En[K][64], E2n[K][64], Fn[K][64];
+		static uint32_t Q[K][64], Cst[K][64];
+		int base = 0;
+		K2aBook book;
+		k2a_book_reset(&book);
+		for (int s = 0; s < K; ++s)
+			for (int l = 0; l < 64; ++l) {
+				const int t = s * 64 + l;
+				H1[s][l] = H2[s][l] = En[s][l] = E2n[s][l] = Fn[s][l] = K2A_NEG; Q[s][l] = 0;
+				Cst[s][l] = cst[k2a_min(t, tlen - 1)];
+			}
+		for (int r = 0; r < qlen + tlen - 1; ++r) {
+			const int st0 = k2a_max(0, r - qlen + 1), en0 = k2a_min(tlen - 1, r), en1 = st0 + (en0 - st0) / 4 * 4;
+			while (st0 >= 1 && (st0 - 1) / 64 > base) {                    /* slide the window: slot s <- slot s+1 */
+				for (int s = 0; s + 1 < K; ++s)
+					for (int l = 0; l < 64; ++l) {
+						H1[s][l] = H1[s + 1][l]; H2[s][l] = H2[s + 1][l]; En[s][l] = En[s + 1][l]; E2n[s][l] = E2n[s + 1][l];
+						Fn[s][l] = Fn[s + 1][l]; Q[s][l] = Q[s + 1][l]; Cst[s][l] = Cst[s + 1][l];
+					}
+				++base;
+				for (int l = 0; l < 64; ++l) {
+					const int t = (base + K - 1) * 64 + l;
+					H1[K - 1][l] = H2[K - 1][l] = En[K - 1][l] = E2n[K - 1][l] = Fn[K - 1][l] = K2A_NEG; Q[K - 1][l] = 0;
+					Cst[K - 1][l] = cst[k2a_min(t, tlen - 1)];
+				}
+			}
+			const uint32_t qcur = qry[k2a_min(r, qlen - 1)];
+			int cH2 = K2A_NEG, cEn = K2A_NEG, cE2n = K2A_NEG;
+			uint32_t cQ = 0;
+			int A = K2A_NEG, S = K2A_NEG, T[3] = { K2A_NEG, K2A_NEG, K2A_NEG };
+			int bH[64], bT[64];
+			for (int l = 0; l < 64; ++l) { bH[l] = K2A_NEG; bT[l] = -1; }
+			for (int s = 0; s < K; ++s) {
+				int h2s[64], ens[64], e2ns[64];
+				uint32_t qs[64];
+				for (int l = 0; l < 64; ++l) {                             /* one-lane shift with the previous slot's lane 63 carried in */
+					h2s[l] = l ? H2[s][l - 1] : cH2; ens[l] = l ? En[s][l - 1] : cEn; e2ns[l] = l ? E2n[s][l - 1] : cE2n;
+					qs[l] = l ? Q[s][l - 1] : cQ;
+				}
+				cH2 = H2[s][63]; cEn = En[s][63]; cE2n = E2n[s][63]; cQ = Q[s][63];
+				const int t0 = (base + s) * 64;
+				const bool slot_live = t0 <= en0 && t0 + 63 >= st0;
+				for (int l = 0; l < 64; ++l) {
+					const int t = t0 + l;
+					Q[s][l] = t == 0 ? qcur : qs[l];
+					if (!slot_live) continue;
+					const bool active = t >= st0 && t <= en0, first_row = t == 0, first_col = t == r;
+					const int diag = first_row ? k2a_dm_border(sp, r) : first_col ? k2a_dm_border(sp, t) : h2s[l];
+					const int ein = first_row ? k2a_dm_border(sp, r + 1) - sp.q - sp.e : ens[l];
+					const int e2in = first_row ? k2a_dm_border(sp, r + 1) - sp.q2 : e2ns[l];
+					const int fin = first_col ? k2a_dm_border(sp, t + 1) - sp.q - sp.e : Fn[s][l];
+					const uint32_t c = Cst[s][l];
+					const int sc = (int)sp.mat[(c & 0xffu) * (uint32_t)sp.m + (Q[s][l] & 0xffu)];
+					int z, en, e2n, fn;
+					uint32_t dir;
+					k2a_dm_cell<MODE>(sp, diag, ein, e2in, fin, sc, c, z, en, e2n, fn, dir);
+					if (!active) continue;
+					H2[s][l] = H1[s][l]; H1[s][l] = z; En[s][l] = en; E2n[s][l] = e2n; Fn[s][l] = fn;
+					if (MODE != K2A_MODE_SCORE) tbp[(size_t)r * ncol + (t - st0)] = (uint8_t)dir;
+					if (t == en0) A = z;
+					if (t == st0) S = z;
+					if (t >= en1 && t < en0) T[t - en1] = z;
+					if (t < en1 && z > bH[l]) { bH[l] = z; bT[l] = t; }
+				}
+			}
+			uint64_t Bkey = 0;
+			for (int l = 0; l < 64; ++l)
+				if (bT[l] >= 0) { const uint64_t k = k2a_dm_key(bH[l], bT[l], st0); if (k > Bkey) Bkey = k; }
+			if (k2a_dm_book(&book, r, st0, en0, qlen, tlen, pr.zdrop, A, Bkey, T, S)) break;
+		}
+		k2a_finish(pr, book, &res[pi]);
+	}
+}
+
+static void sim_exts_trace(const K2aSplice sp, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb, K2aResult *res, uint32_t *cig)
+{
+	for (int task = 0; task < ntasks; ++task) {
+		const K2aPair pr = pairs[order[task]];
+		K2aResult &r = res[order[task]];
+		r.n_cigar = r.ti >= 0 ? k2a_dm_trace(tb + pr.tb_off, k2a_min(pr.qlen, pr.tlen_full), r.ti, r.tj, cig + pr.cig_off, pr.qlen, sp.long_thres) : 0;
+	}
+}
+
+
 extern "C" {
 
 const char *k2a_shim_backend(void) { return "sim"; }
@@ -399,6 +498,22 @@ int k2a_shim_launch_compact(const K2aPair *pairs, const K2aResult *res, const ui
 {
 	for (int i = 0; i < n; ++i)
 		for (int k = 0; k < res[i].n_cigar; ++k) pool[pos[i] + k] = cig[pairs[i].cig_off + k];
+	return 0;
+}
+
+int k2a_shim_launch_exts(int mode, const K2aSplice *sp, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, uint8_t *tb,
+                         K2aResult *res, void *)
+{
+	if (ntasks <= 0) return 0;
+	if (mode == K2A_MODE_SCORE) sim_exts<K2A_MODE_SCORE>(*sp, pairs, order, ntasks, seq, tb, res);
+	else if (mode == K2A_MODE_LEFT) sim_exts<K2A_MODE_LEFT>(*sp, pairs, order, ntasks, seq, tb, res);
+	else sim_exts<K2A_MODE_RIGHT>(*sp, pairs, order, ntasks, seq, tb, res);
+	return 0;
+}
+int k2a_shim_launch_exts_trace(const K2aSplice *sp, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb, K2aResult *res,
+                               uint32_t *cig, void *)
+{
+	if (ntasks > 0) sim_exts_trace(*sp, pairs, order, ntasks, tb, res, cig);
 	return 0;
 }
 

@@ -408,3 +408,40 @@ def test_cli_matches_reference_cli(lib):
     a = subprocess.run([ours, "-t", "extz2_sse", "-b", t1, q1], capture_output=True, text=True)
     b = subprocess.run([ours, "-t", "extz2_sse", t1, q1], capture_output=True, text=True)
     assert a.returncode == 0 and a.stdout == b.stdout and a.stdout.count("\n") == 5
+
+
+def test_splice_aware_golden(lib):
+    """All 1200 ksw_exts2_sse cases produced by the compiled reference (tests/golden/exts_cases.npz), batched by scoring."""
+    ec = gu.ExtsCases()
+    groups = {}
+    for k in range(ec.n):
+        c = ec.case(k)
+        groups.setdefault((c["mat"].tobytes(), c["gq"], c["ge"], c["gq2"], c["noncan"], c["junc_bonus"]), []).append(c)
+    n = 0
+    for (_, gq, ge, gq2, noncan, jb), cs in groups.items():
+        res = lib.exts_batch([c["q"] for c in cs], [c["t"] for c in cs], cs[0]["mat"], gq, ge, gq2, noncan, zdrop=np.array([c["zdrop"] for c in cs]),
+                             junc_bonus=jb, flag=np.array([c["flag"] for c in cs]), juncs=[c["junc"] for c in cs])
+        for c, r in zip(cs, res):
+            assert not diff(c["expect"], r, gu.FIELDS + ["cigar"]), (hex(c["flag"]), c["zdrop"], len(c["q"]), len(c["t"]))
+            n += 1
+    assert n == ec.n
+
+
+def test_splice_aware_random_and_long(lib):
+    from tests.test_sim_parity import _exts_cases, _intron_pair, check_exts_batch
+    rng = np.random.Generator(np.random.PCG64(77))
+    for rnd in range(30):
+        check_exts_batch(lib, *_exts_cases(rng, rnd, 1400))
+    mat = synth.simple_mat(5, 1, 2, 0)
+    qs, ts = [], []
+    for rnd in range(24):
+        q, t = _intron_pair(rng, int(rng.integers(1500, 12000)))
+        if rnd % 3 == 1:
+            q, t = t, q
+        qs.append(q)
+        ts.append(t)
+    flag = np.array([int(rng.choice([0, po.RIGHT, po.SCORE_ONLY, po.EXTZ_ONLY])) | po.SPLICE_FOR for _ in qs])
+    zd = rng.choice([-1, 200, 1000], size=len(qs))
+    check_exts_batch(lib, qs, ts, [None] * len(qs), mat, 2, 1, 32, 4, 0, flag, zd)
+    r = lib.exts2(qs[0], ts[0], mat, 2, 1, 32, 4, flag=po.SPLICE_FOR)
+    assert not diff(po.exts2("oracle", qs[0], ts[0], mat, 2, 1, 32, 4, flag=po.SPLICE_FOR), r, gu.FIELDS + ["cigar"])

@@ -249,3 +249,76 @@ def test_sim_packed_range_guard(sim):
     assert p.packed_pairs() == 0
     p.close()
     check_batch(sim, False, q, t, m2, 4, 2, 0, 0, w=64, flag=po.SCORE_ONLY | po.GENERIC_SC)
+
+
+def _exts_cases(rng, rnd, big_limit):
+    from oracle.gen_golden_exts import spliced_pair
+    n = int(rng.integers(1, 8))
+    qs, ts, js = [], [], []
+    for _ in range(n):
+        q, t = spliced_pair(rng, int(rng.integers(1, big_limit if rnd % 7 == 0 else 400)), low_complexity=(rnd % 5 == 2))
+        qs.append(q)
+        ts.append(t)
+        js.append((rng.integers(0, 16, len(t), dtype=np.uint8) * (rng.random(len(t)) < 0.05)).astype(np.uint8) if rnd % 3 == 0 else None)
+    a, b, scn, q_, e_, q2, nc = [(1, 2, 0, 2, 1, 32, 4), (2, 4, -1, 4, 2, 24, 5), (1, 3, 0, 2, 1, 20, 9)][rnd % 3]
+    flag = np.array([int(rng.choice([0, po.SCORE_ONLY, po.RIGHT, po.EXTZ_ONLY, po.REV_CIGAR, po.GENERIC_SC, po.RIGHT | po.REV_CIGAR])) |
+                     int(rng.choice([0, po.SPLICE_FOR, po.SPLICE_REV, po.SPLICE_FOR | po.SPLICE_FLANK, po.SPLICE_FOR | po.SPLICE_REV])) for _ in range(n)])
+    zd = rng.choice([-1, 20, 100, 400], size=n)
+    return qs, ts, js, synth.simple_mat(5, a, b, scn), q_, e_, q2, nc, (3 if rnd % 3 == 0 else 0), flag, zd
+
+
+def check_exts_batch(lib, qs, ts, js, mat, q, e, q2, nc, jb, flag, zd):
+    res = lib.exts_batch(qs, ts, mat, q, e, q2, nc, zdrop=zd, junc_bonus=jb, flag=flag, juncs=js)
+    for i in range(len(qs)):
+        exp = po.exts2("oracle", qs[i], ts[i], mat, q, e, q2, nc, zdrop=int(zd[i]), junc_bonus=jb, flag=int(flag[i]), junc=js[i])
+        d = diff(exp, res[i], gu.FIELDS + ["cigar"])
+        assert not d, (i, len(qs[i]), len(ts[i]), hex(int(flag[i])), int(zd[i]), {k: (exp[k], res[i][k]) for k in d if k != "cigar"})
+
+
+def _intron_pair(rng, tl):
+    """A long target with one GT..AG intron and a query made of the two exons around it."""
+    t = rng.integers(0, 4, tl, dtype=np.uint8)
+    a = int(rng.integers(50, tl // 3))
+    ex1, intr, ex2 = int(rng.integers(40, 500)), int(rng.integers(100, tl // 2)), int(rng.integers(40, 700))
+    b = min(tl - 5, a + ex1 + intr)
+    t[a + ex1], t[a + ex1 + 1], t[b - 2], t[b - 1] = 2, 3, 0, 2
+    q = np.concatenate([t[a:a + ex1], t[b:min(tl, b + ex2)]]).copy()
+    mm = rng.random(len(q)) < 0.04
+    q[mm] = rng.integers(0, 4, int(mm.sum()), dtype=np.uint8)
+    return q, t
+
+
+def test_sim_splice_aware(sim):
+    """ksw_exts2_sse semantics through the diagonal-major kernel (ksw2_lane_dm.h): random spliced pairs with junction
+    annotation, every flag combination, tie-heavy two-letter sequences, and diagonals longer than one register slot."""
+    rng = np.random.Generator(np.random.PCG64(21))
+    for rnd in range(22):
+        check_exts_batch(sim, *_exts_cases(rng, rnd, 1400))
+
+
+def test_sim_splice_aware_sliding_window(sim):
+    rng = np.random.Generator(np.random.PCG64(4))
+    mat = synth.simple_mat(5, 1, 2, 0)
+    for rnd in range(8):
+        q, t = _intron_pair(rng, int(rng.integers(1500, 6000)))
+        if rnd % 2:
+            q, t = t, q                              # long query, short target
+        flag = int(rng.choice([0, po.RIGHT, po.SCORE_ONLY, po.EXTZ_ONLY])) | po.SPLICE_FOR
+        zd = int(rng.choice([-1, 200, 1000]))
+        exp = po.exts2("oracle", q, t, mat, 2, 1, 32, 4, zdrop=zd, flag=flag)
+        res = sim.exts2(q, t, mat, 2, 1, 32, 4, zdrop=zd, flag=flag)
+        assert not diff(exp, res, gu.FIELDS + ["cigar"]), (rnd, len(q), len(t))
+        if flag == po.SPLICE_FOR and zd == -1 and not rnd % 2:
+            assert any((c & 0xf) == 3 and (c >> 4) > 50 for c in res["cigar"])       # the intron comes back as N
+    # a diagonal that does not fit the register window is refused loudly
+    with pytest.raises(ka.Ksw2Error):
+        sim.exts_batch([np.zeros(1600, np.uint8)], [np.zeros(1600, np.uint8)], mat, 2, 1, 32, 4)
+
+
+def test_sim_splice_aware_golden_subset(sim):
+    ec = gu.ExtsCases()
+    for k in range(0, ec.n, 5):
+        c = ec.case(k)
+        res = sim.exts2(c["q"], c["t"], c["mat"], c["gq"], c["ge"], c["gq2"], c["noncan"], zdrop=c["zdrop"], junc_bonus=c["junc_bonus"],
+                        flag=c["flag"], junc=c["junc"])
+        assert not diff(c["expect"], res, gu.FIELDS + ["cigar"]), (k, hex(c["flag"]))
