@@ -26,7 +26,8 @@ from ksw2_amd import synth           # noqa: E402
 
 # algorithmic integer ops per cell and VALU peak (256 CU x 4 SIMD x 32 lanes x 2.4 GHz x 2 for
 # packed int16; gfx950 has no packed int8 add/max).  The int32 lane-op peak is half of that.
-OPS_PER_CELL = {("extz", True): 15, ("extz", False): 22, ("extd", True): 28, ("extd", False): 42}
+OPS_PER_CELL = {("extz", True): 15, ("extz", False): 22, ("extd", True): 28, ("extd", False): 42,
+                ("exts", True): 21, ("exts", False): 31}     # extz + the long-gap state: 3 more values per cell, 3 more decisions
 VALU_PEAK_PK16 = 157.3e12
 HBM_PEAK = 8.0e12
 
@@ -45,8 +46,12 @@ WORKLOADS = {
     # config 5: ONT-like mix, target length uniform in [300, 20000] (64 length buckets), 3 % substitutions + 15 % indels, band 500,
     # extd2 with Z-drop 400 and CIGAR; 16384 pairs per GPU here (the full config shards 1 M pairs over 8 GPUs)
     "cfg5": dict(idx=5, n=16384, qlen=0, tlen=0, w=500, zdrop=400, dual=True, flag=0, sub=0.03, ind=0.15, ragged=True),
+    # splice-aware extension: 16384 spliced pairs per GPU, 400-base query = two exons around a 1000-base GT..AG
+    # intron of a 1500-base target, unbanded, forward signals, CIGAR with N; the reference CLI's splice scoring
+    "exts": dict(idx=7, n=16384, qlen=400, tlen=1500, w=-1, zdrop=-1, dual=False, flag=0, sub=0.03, ind=0.0, splice=True),
 }
 SCORING = dict(a=2, b=4, sc_n=-1, q=4, e=2, q2=24, e2=1)
+SPLICE_SCORING = dict(a=1, b=2, sc_n=0, q=2, e=1, q2=32, noncan=4)
 
 
 def make_ragged(wl, rank, n):
@@ -66,8 +71,24 @@ def make_ragged(wl, rank, n):
     return qs, ts
 
 
+def make_spliced(wl, rank, n):
+    """Fixed-shape spliced pairs: target = exon | GT intron AG | exon with flanks, query = the two exons with substitutions."""
+    rng = synth.rng_for(wl["idx"], rank)
+    tl, ql = wl["tlen"], wl["qlen"]
+    t = rng.integers(0, 4, size=(n, tl), dtype=np.uint8)
+    ex1 = ql // 2
+    a, b = 50, tl - 50 - (ql - ex1)                    # exon 1 = [a, a+ex1), exon 2 = [b, b+ql-ex1)
+    t[:, a + ex1], t[:, a + ex1 + 1], t[:, b - 2], t[:, b - 1] = 2, 3, 0, 2
+    q = np.concatenate([t[:, a:a + ex1], t[:, b:b + ql - ex1]], axis=1).copy()
+    mism = rng.random(q.shape) < wl["sub"]
+    q[mism] = (q[mism] + rng.integers(1, 4, size=int(mism.sum()), dtype=np.uint8)) & 3
+    return q, t
+
+
 def make_batch(wl, rank, n_override=None):
     n = n_override or wl["n"]
+    if wl.get("splice"):
+        return make_spliced(wl, rank, n)
     if wl.get("ragged"):
         return make_ragged(wl, rank, n)
     if wl.get("mt"):
@@ -88,6 +109,9 @@ def cpu_baseline(wl, q, t, mat, seconds=10.0):
     ref = po.ref_lib()
     kind = "reference" if ref is not None else "port"
     name = ("ksw_extd2_sse" if wl["dual"] else "ksw_extz2_sse") if ref is not None else ("kso_extd2_km" if wl["dual"] else "kso_extz2_km")
+    if wl.get("splice"):
+        name = "ksw_exts2_sse" if ref is not None and hasattr(ref, "ksw_exts2_sse") else "kso_exts2_km"
+        kind = "reference" if name.startswith("ksw_") else "port"
     fn = ctypes.cast(getattr(ref if ref is not None else olib, name), ctypes.c_void_p)
     olib.kso_cpu_bench.restype = ctypes.c_long
     olib.kso_cpu_bench.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -97,12 +121,15 @@ def cpu_baseline(wl, q, t, mat, seconds=10.0):
         return {"value": None, "unit": "GCUPS", "cores": 0, "kind": "skipped", "sample": "ragged workload: CPU baseline loop needs fixed shapes"}
     cells_pair = synth.band_cells(wl["qlen"], wl["tlen"], wl["w"])
     S = SCORING
+    mode = 2 if wl.get("splice") else int(wl["dual"])
+    if wl.get("splice"):
+        S = dict(q=SPLICE_SCORING["q"], e=SPLICE_SCORING["e"], q2=SPLICE_SCORING["q2"], e2=SPLICE_SCORING["noncan"])
     qa, ta = np.ascontiguousarray(q), np.ascontiguousarray(t)
     ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     out = {}
     for threads in sorted({1, ncores}):
         el = ctypes.c_double(0)
-        done = olib.kso_cpu_bench(fn, int(wl["dual"]), threads, seconds, len(qa), wl["qlen"], wl["tlen"], qa.ctypes.data, ta.ctypes.data,
+        done = olib.kso_cpu_bench(fn, mode, threads, seconds, len(qa), wl["qlen"], wl["tlen"], qa.ctypes.data, ta.ctypes.data,
                                   5, mat.ctypes.data, S["q"], S["e"], S["q2"], S["e2"], wl["w"], wl["zdrop"], wl["flag"], ctypes.byref(el))
         out[threads] = (done, el.value, done * cells_pair / el.value / 1e9)
     n1, dt1, g1 = out[1]
@@ -160,11 +187,18 @@ def main():
     lib.set_device(dev)
     wl = WORKLOADS[args.workload]
     S = SCORING
-    mat = synth.simple_mat(5, S["a"], S["b"], 0 if wl.get("mt") else S["sc_n"])
     q, t = make_batch(wl, rank, args.pairs or None)
     n = len(q)
-    batch = lib.make_batch(q, t, mat, S["q"], S["e"], S["q2"], S["e2"], w=wl["w"], zdrop=wl["zdrop"], end_bonus=0, flag=wl["flag"])
-    plan = batch.plan(wl["dual"])                     # packs and uploads: inputs resident in HBM from here on
+    if wl.get("splice"):
+        P = SPLICE_SCORING
+        mat = synth.simple_mat(5, P["a"], P["b"], P["sc_n"])
+        wl = dict(wl, flag=wl["flag"] | ksw2_amd.KSW_EZ_SPLICE_FOR)
+        batch = lib.make_splice_batch(list(q), list(t), mat, P["q"], P["e"], P["q2"], P["noncan"], zdrop=wl["zdrop"], flag=wl["flag"])
+        plan = batch.plan()
+    else:
+        mat = synth.simple_mat(5, S["a"], S["b"], 0 if wl.get("mt") else S["sc_n"])
+        batch = lib.make_batch(q, t, mat, S["q"], S["e"], S["q2"], S["e2"], w=wl["w"], zdrop=wl["zdrop"], end_bonus=0, flag=wl["flag"])
+        plan = batch.plan(wl["dual"])                 # packs and uploads: inputs resident in HBM from here on
     cells = plan.cells()
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -200,7 +234,7 @@ def main():
 
     if rank == 0:
         score_only = bool(wl["flag"] & ksw2_amd.KSW_EZ_SCORE_ONLY)
-        ops = OPS_PER_CELL[("extd" if wl["dual"] else "extz", score_only)]
+        ops = OPS_PER_CELL[("exts" if wl.get("splice") else "extd" if wl["dual"] else "extz", score_only)]
         kern_ms = float(np.mean(total_ms))
         fill_only_ms = float(np.mean(fill_ms))
         achieved = cells * ops / (kern_ms * 1e-3)
@@ -209,6 +243,7 @@ def main():
         traffic, traffic_src = recorded_traffic(args.workload) if not args.pairs else (None, None)
         npk = plan.packed_pairs()
         dtype = "int16x2 (packed, two alignments per lane)" if npk == n else "int32" if npk == 0 else "int16x2 + int32"
+        func = "exts2 splice-aware" if wl.get("splice") else "extd2 dual-gap" if wl["dual"] else "extz2 affine"
         out = {
             "metric": "GCUPS (DP cells/s) + pairs/s at fixed (qlen,tlen,band)",
             "value": round(cells_all * args.steps / dt / 1e9, 3), "unit": "GCUPS",
@@ -216,7 +251,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "%s: %d pairs/GPU, qlen=%d tlen=%d band=%d zdrop=%d %s %s" % (
-                args.workload, n, wl["qlen"], wl["tlen"], wl["w"], wl["zdrop"], "extd2 dual-gap" if wl["dual"] else "extz2 affine",
+                args.workload, n, wl["qlen"], wl["tlen"], wl["w"], wl["zdrop"], func,
                 "score-only" if score_only else "CIGAR"), "cells_per_gpu": cells, "parallelism": "pairs sharded over %d GPU(s), no collective" % world},
             "roofline": {"bound": "valu", "achieved": round(achieved / 1e12, 4), "peak": VALU_PEAK_PK16 / 1e12, "unit": "Tiop/s",
                          "frac": round(achieved / VALU_PEAK_PK16, 5), "traffic": traffic, "traffic_source": traffic_src,

@@ -174,6 +174,8 @@ int64_t ksw2amd_plan_cells(const ksw2amd_plan_t *plan);
 int64_t ksw2amd_plan_device_bytes(const ksw2amd_plan_t *plan);
 /* alignments routed to the packed-int16 kernels (two same-shape alignments per lane group) */
 int64_t ksw2amd_plan_packed_pairs(const ksw2amd_plan_t *plan);
+/* a resident plan of splice-aware extensions; run / fetch / timing / cells / destroy as above */
+ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, const ksw2amd_spair_t *pairs);
 /* raw device results without the host-side ez[] assembly: 16 int32 per pair
  * {max, zdropped, max_q, max_t, mqe, mqe_t, mte, mte_q, score, reach_end, n_cigar, rows_done, ti, tj, 0, 0} */
 int  ksw2amd_plan_fetch_raw(ksw2amd_plan_t *plan, int32_t *out16);

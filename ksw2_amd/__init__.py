@@ -60,7 +60,7 @@ EXPORTS = ["ksw_extz2_sse", "ksw_extd2_sse", "ksw_gg2", "ksw_gg2_sse", "ksw_extz
            "ksw2amd_last_error", "ksw2amd_backend", "ksw2amd_device_count", "ksw2amd_set_device", "ksw2amd_release_cache",
            "ksw2amd_extz_batch", "ksw2amd_extd_batch", "ksw2amd_plan_create", "ksw2amd_plan_run", "ksw2amd_plan_fetch",
            "ksw2amd_plan_destroy", "ksw2amd_plan_timing", "ksw2amd_plan_cells", "ksw2amd_plan_device_bytes", "ksw2amd_plan_packed_pairs",
-           "ksw2amd_plan_fetch_raw", "ksw_exts2_sse", "ksw_exts2_sse41", "ksw_exts2_sse2", "ksw2amd_exts_batch"]
+           "ksw2amd_plan_fetch_raw", "ksw_exts2_sse", "ksw_exts2_sse41", "ksw_exts2_sse2", "ksw2amd_exts_batch", "ksw2amd_exts_plan_create"]
 KSW_EZ_SPLICE_FOR, KSW_EZ_SPLICE_REV, KSW_EZ_SPLICE_FLANK = 0x100, 0x200, 0x400
 
 
@@ -115,6 +115,8 @@ class Library:
             getattr(L, name).argtypes = s2
             getattr(L, name).restype = None
         L.ksw2amd_exts_batch.argtypes = [km, ctypes.POINTER(SpliceScoring), _int, ctypes.POINTER(SplicePair), ezp]
+        L.ksw2amd_exts_plan_create.argtypes = [ctypes.POINTER(SpliceScoring), _int, ctypes.POINTER(SplicePair)]
+        L.ksw2amd_exts_plan_create.restype = ctypes.c_void_p
         L.ksw2amd_last_error.restype = ctypes.c_char_p
         L.ksw2amd_backend.restype = ctypes.c_char_p
         L.ksw2amd_set_device.argtypes = [_int]
@@ -191,24 +193,12 @@ class Library:
         self.lib.ksw_exts2_sse(None, len(qa), qp, len(ta), tp, m, mat.ctypes.data_as(_i8p), q, e, q2, noncan, zdrop, junc_bonus, flag, jp, ez)
         return ez_to_dict(ez, free_cigar=True)
 
-    def exts_batch(self, queries, targets, mat, q, e, q2, noncan, zdrop=-1, junc_bonus=0, flag=0, juncs=None, m=None):
+    def make_splice_batch(self, queries, targets, mat, q, e, q2, noncan, zdrop=-1, junc_bonus=0, flag=0, juncs=None, m=None):
+        return SpliceBatch(self, queries, targets, mat, q, e, q2, noncan, zdrop, junc_bonus, flag, juncs, m)
+
+    def exts_batch(self, queries, targets, mat, q, e, q2, noncan, **kw):
         """ksw2amd_exts_batch: n independent splice-aware extensions -> list of dicts."""
-        n = len(queries)
-        mat = np.ascontiguousarray(mat, dtype=np.int8)
-        m = int(round(len(mat) ** 0.5)) if m is None else m
-        qs = [np.ascontiguousarray(x, dtype=np.uint8) for x in queries]
-        ts = [np.ascontiguousarray(x, dtype=np.uint8) for x in targets]
-        js = [None if (juncs is None or juncs[i] is None) else np.ascontiguousarray(juncs[i], dtype=np.uint8) for i in range(n)]
-        bc = lambda v: np.full(n, v) if np.ndim(v) == 0 else np.asarray(v)      # noqa: E731
-        zdrop, flag = bc(zdrop), bc(flag)
-        sc = SpliceScoring(m, mat.ctypes.data_as(_i8p), q, e, q2, noncan, junc_bonus)
-        pairs = (SplicePair * max(n, 1))()
-        for i in range(n):
-            pairs[i] = SplicePair(qs[i].ctypes.data, ts[i].ctypes.data, None if js[i] is None else js[i].ctypes.data, len(qs[i]), len(ts[i]),
-                                  int(zdrop[i]), int(flag[i]))
-        ez = (KswExtz * max(n, 1))()
-        self._check(self.lib.ksw2amd_exts_batch(None, ctypes.byref(sc), n, pairs, ez))
-        return [ez_to_dict(ez[i], free_cigar=True) for i in range(n)]
+        return self.make_splice_batch(queries, targets, mat, q, e, q2, noncan, **kw).run_oneshot()
 
     def extz(self, query, target, mat, q, e, w=-1, zdrop=-1, flag=0, m=None):
         qa, qp = self._seq(query)
@@ -316,12 +306,40 @@ class Batch:
         return Plan(self, dual)
 
 
+class SpliceBatch:
+    """Arguments of n ksw_exts2_sse calls with shared scoring, kept alive for the C side."""
+
+    def __init__(self, L, queries, targets, mat, q, e, q2, noncan, zdrop, junc_bonus, flag, juncs, m):
+        self.L = L
+        self.n = n = len(queries)
+        self.mat = np.ascontiguousarray(mat, dtype=np.int8)
+        m = int(round(len(self.mat) ** 0.5)) if m is None else m
+        self.qs = [np.ascontiguousarray(x, dtype=np.uint8) for x in queries]
+        self.ts = [np.ascontiguousarray(x, dtype=np.uint8) for x in targets]
+        self.js = [None if (juncs is None or juncs[i] is None) else np.ascontiguousarray(juncs[i], dtype=np.uint8) for i in range(n)]
+        bc = lambda v: np.full(n, v) if np.ndim(v) == 0 else np.asarray(v)      # noqa: E731
+        zdrop, flag = bc(zdrop), bc(flag)
+        self.sc = SpliceScoring(m, self.mat.ctypes.data_as(_i8p), q, e, q2, noncan, junc_bonus)
+        self.pairs = (SplicePair * max(n, 1))()
+        for i in range(n):
+            self.pairs[i] = SplicePair(self.qs[i].ctypes.data, self.ts[i].ctypes.data, None if self.js[i] is None else self.js[i].ctypes.data,
+                                       len(self.qs[i]), len(self.ts[i]), int(zdrop[i]), int(flag[i]))
+
+    def run_oneshot(self):
+        ez = (KswExtz * max(self.n, 1))()
+        self.L._check(self.L.lib.ksw2amd_exts_batch(None, ctypes.byref(self.sc), self.n, self.pairs, ez))
+        return [ez_to_dict(ez[i], free_cigar=True) for i in range(self.n)]
+
+    def plan(self):
+        return Plan(self, False, handle=self.L.lib.ksw2amd_exts_plan_create(ctypes.byref(self.sc), self.n, self.pairs))
+
+
 class Plan:
     """ksw2amd_plan_*: batch resident in HBM; run() enqueues kernels only."""
 
-    def __init__(self, batch, dual):
+    def __init__(self, batch, dual, handle=None):
         self.b, self.L = batch, batch.L
-        self.h = self.L.lib.ksw2amd_plan_create(1 if dual else 0, ctypes.byref(batch.sc), batch.n, batch.pairs)
+        self.h = handle if handle is not None else self.L.lib.ksw2amd_plan_create(1 if dual else 0, ctypes.byref(batch.sc), batch.n, batch.pairs)
         if not self.h:
             raise Ksw2Error("plan_create failed: " + self.L.last_error())
 

@@ -170,7 +170,7 @@ struct ksw2amd_plan_s {
 	void *stream;
 	int stream_used;
 	int64_t cells;
-	/* splice-aware plans (exts_plan_create): tasks of h_order grouped by kernel mode x matrix variant */
+	/* splice-aware plans (ksw2amd_exts_plan_create): tasks of h_order grouped by kernel mode x matrix variant */
 	int splice, s_first[3][2], s_count[3][2];
 	K2aSplice s_par[2];
 };
@@ -944,7 +944,7 @@ static int exts_long_thres(int q, int e, int q2)           /* ksw2_exts2_sse.c:1
 	return lt;
 }
 
-static ksw2amd_plan_t *exts_plan_create(const ksw2amd_splice_t *sc, int n, const ksw2amd_spair_t *pairs)
+ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, const ksw2amd_spair_t *pairs)
 {
 	ksw2amd_plan_t *p;
 	const int m = sc ? sc->m : 0;
@@ -1101,7 +1101,7 @@ int ksw2amd_exts_batch(void *km, const ksw2amd_splice_t *sc, int n, const ksw2am
 			if (end > beg && (acc + b > budget || seq + ql + 4 * tl > 3000000000u || end - beg >= (1 << 22))) break;
 			acc += b; seq += ql + 4 * tl + 16;
 		}
-		p = exts_plan_create(sc, end - beg, pairs + beg);
+		p = ksw2amd_exts_plan_create(sc, end - beg, pairs + beg);
 		if (!p) return strstr(g_err, "alloc") ? KSW2AMD_E_NOMEM : strstr(g_err, "device") ? KSW2AMD_E_NODEVICE : KSW2AMD_E_PARAM;
 		rc = ksw2amd_plan_run(p, thread_stream());
 		if (rc == KSW2AMD_OK) rc = ksw2amd_plan_fetch(p, km, ez + beg);

@@ -18,8 +18,11 @@ typedef void (*extz2_fn)(void *km, int qlen, const uint8_t *query, int tlen, con
 typedef void (*extd2_fn)(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
                          int8_t q, int8_t e, int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, kso_extz_t *ez);
 
+typedef void (*exts2_fn)(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                         int8_t q, int8_t e, int8_t q2, int8_t noncan, int zdrop, int8_t junc_bonus, int flag, const uint8_t *junc, kso_extz_t *ez);
+
 typedef struct {
-	void *fn; int dual, with_km;
+	void *fn; int dual, with_km;                   /* dual: 0 extz2, 1 extd2, 2 exts2 (gq2 = long-gap open, ge2 = noncan) */
 	const uint8_t *q, *t; int n, qlen, tlen;       /* n fixed-shape pairs, row-major */
 	int8_t m; const int8_t *mat; int8_t gq, ge, gq2, ge2; int w, zdrop, flag;
 	double seconds;
@@ -40,7 +43,8 @@ static void *worker(void *arg)
 	while (now() - t0 < J->seconds) {
 		long i = __sync_fetch_and_add(&J->next, 1) % J->n;
 		const uint8_t *q = J->q + (size_t)i * J->qlen, *t = J->t + (size_t)i * J->tlen;
-		if (J->dual) ((extd2_fn)J->fn)(0, J->qlen, q, J->tlen, t, J->m, J->mat, J->gq, J->ge, J->gq2, J->ge2, J->w, J->zdrop, 0, J->flag, &ez);
+		if (J->dual == 2) ((exts2_fn)J->fn)(0, J->qlen, q, J->tlen, t, J->m, J->mat, J->gq, J->ge, J->gq2, J->ge2, J->zdrop, 0, J->flag, 0, &ez);
+		else if (J->dual) ((extd2_fn)J->fn)(0, J->qlen, q, J->tlen, t, J->m, J->mat, J->gq, J->ge, J->gq2, J->ge2, J->w, J->zdrop, 0, J->flag, &ez);
 		else ((extz2_fn)J->fn)(0, J->qlen, q, J->tlen, t, J->m, J->mat, J->gq, J->ge, J->w, J->zdrop, 0, J->flag, &ez);
 		++mine;
 	}
@@ -76,3 +80,6 @@ void kso_extz2_km(void *km, int qlen, const uint8_t *query, int tlen, const uint
 void kso_extd2_km(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
                   int8_t q, int8_t e, int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, kso_extz_t *ez)
 { (void)km; kso_extd2(qlen, query, tlen, target, m, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez); }
+void kso_exts2_km(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                  int8_t q, int8_t e, int8_t q2, int8_t noncan, int zdrop, int8_t junc_bonus, int flag, const uint8_t *junc, kso_extz_t *ez)
+{ (void)km; kso_exts2(qlen, query, tlen, target, m, mat, q, e, q2, noncan, zdrop, junc_bonus, flag, junc, ez); }

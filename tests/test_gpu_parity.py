@@ -398,6 +398,7 @@ def test_cli_matches_reference_cli(lib):
     t1, q1, mh, mo = (os.path.join(d, f) for f in ("t1.fa", "q1.fa", "MT-human.fa", "MT-orang.fa"))
     runs = [(["-t", "extz"], t1, q1), (["-t", "extd"], t1, q1), (["-t", "extz", "-r"], t1, q1), (["-t", "extd", "-s"], t1, q1),
             (["-t", "gg"], t1, q1), (["-t", "gg2"], t1, q1), (["-t", "extz", "-A1", "-B3", "-O5", "-E1"], t1, q1), (["-t", "extd", "-a"], t1, q1),
+            (["-t", "exts2_sse"], t1, q1), (["-t", "exts2_sse", "-r"], t1, q1), (["-t", "exts2_sse", "-z", "100"], t1, q1),
             (["-t", "extz", "-w", "500"], mh, mo), (["-t", "extd", "-w", "500", "-r"], mh, mo), (["-t", "extz"], mh, mo), (["-t", "gg2", "-s"], mh, mo)]
     for opts, t, q in runs:
         a = subprocess.run([ours] + opts + [t, q], capture_output=True, text=True)
