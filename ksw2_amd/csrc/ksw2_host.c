@@ -171,7 +171,7 @@ struct ksw2amd_plan_s {
 	int stream_used;
 	int64_t cells;
 	/* splice-aware plans (ksw2amd_exts_plan_create): tasks of h_order grouped by kernel mode x matrix variant */
-	int splice, s_first[3][2], s_count[3][2];
+	int splice, s_first[3][2][3], s_count[3][2][3];   /* [mode][matrix variant][window class] */
 	K2aSplice s_par[2];
 };
 
@@ -951,7 +951,8 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 	int i, k, g, lo;
 	size_t off, mat_off;
 	void *up;
-	uint32_t fill[3][2];
+	uint32_t fill[3][2][3];
+	int wn;
 
 	g_err[0] = 0;
 	if (n < 0 || (n > 0 && !pairs) || !sc) { fail(KSW2AMD_E_PARAM, "exts: bad arguments%s", 0); return 0; }
@@ -983,14 +984,15 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 		int mode, generic;
 		if (a->qlen <= 0 || a->tlen <= 0) continue;
 		if (!a->query || !a->target) { fail(KSW2AMD_E_PARAM, "exts: NULL sequence%s", 0); goto err; }
-		if (imin(a->qlen, a->tlen) > 24 * 64 - 64) {
+		if (imin(a->qlen, a->tlen) > K2A_DM_DIAG(K2A_DM_SLOTS)) {
 			fail(KSW2AMD_E_PARAM, "exts: min(qlen, tlen) > 1472 is not supported by this release%s", 0);
 			goto err;
 		}
 		mode = (a->flag & KSW_EZ_SCORE_ONLY) ? K2A_MODE_SCORE : (a->flag & KSW_EZ_RIGHT) ? K2A_MODE_RIGHT : K2A_MODE_LEFT;
 		generic = (a->flag & KSW_EZ_GENERIC_SC) ? 1 : 0;
-		p->h_cls[i] = (int8_t)(mode * 2 + generic);
-		++p->s_count[mode][generic];
+		wn = imin(a->qlen, a->tlen) <= K2A_DM_DIAG(K2A_DM_SLOTS_S) ? 0 : imin(a->qlen, a->tlen) <= K2A_DM_DIAG(K2A_DM_SLOTS_M) ? 1 : 2;
+		p->h_cls[i] = (int8_t)((mode * 2 + generic) * 3 + wn);
+		++p->s_count[mode][generic][wn];
 		d->qlen = a->qlen; d->tlen = d->tlen_full = a->tlen;
 		d->w = imax(a->qlen, a->tlen);                 /* no band: k2a_finish must never see an unreachable corner */
 		d->zdrop = a->zdrop; d->end_bonus = K2A_NEG;   /* no end bonus in this function */
@@ -1013,14 +1015,15 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 	p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, p->seq_bytes, &p->cap[BUF_HSEQ]);
 	if (!p->h_seq) { fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
 	for (k = 0, i = 0; i < 3; ++i)
-		for (g = 0; g < 2; ++g) { p->s_first[i][g] = k; fill[i][g] = (uint32_t)k; k += p->s_count[i][g]; }
+		for (g = 0; g < 2; ++g)
+			for (wn = 0; wn < 3; ++wn) { p->s_first[i][g][wn] = k; fill[i][g][wn] = (uint32_t)k; k += p->s_count[i][g][wn]; }
 	p->ntasks = p->norder = k;
 	for (i = 0; i < n; ++i) {
 		const ksw2amd_spair_t *a = &pairs[i];
 		if (p->h_cls[i] < 0) continue;
 		memcpy(p->h_seq + p->h_pairs[i].qoff, a->query, (size_t)a->qlen);
 		splice_constants(sc, a, (uint32_t*)p->h_seq + p->h_pairs[i].bnd_off);
-		p->h_order[fill[p->h_cls[i] / 2][p->h_cls[i] & 1]++] = (uint32_t)i;
+		p->h_order[fill[p->h_cls[i] / 6][(p->h_cls[i] / 3) & 1][p->h_cls[i] % 3]++] = (uint32_t)i;
 	}
 	build_eff(0, m, sc->mat, sc->e, 0, 0, (int8_t*)p->h_seq + mat_off);
 	build_eff(0, m, sc->mat, sc->e, 0, 1, (int8_t*)p->h_seq + mat_off + (size_t)m * m);
@@ -1057,21 +1060,23 @@ err:
 
 static int exts_plan_run(ksw2amd_plan_t *p, void *stream)
 {
-	int mode, g;
+	int mode, g, wn;
 	p->stream = stream; p->ran = 1; p->stream_used = 1;
 	if (p->reject_all || p->ntasks == 0) return KSW2AMD_OK;
 	if (k2a_shim_event_record(p->ev[0], stream)) goto err;
 	for (mode = 0; mode < 3; ++mode)
 		for (g = 0; g < 2; ++g)
-			if (p->s_count[mode][g] &&
-			    k2a_shim_launch_exts(mode, &p->s_par[g], p->d_pairs, p->d_order + p->s_first[mode][g], p->s_count[mode][g], p->d_seq, p->d_tb,
-			                         p->d_res, stream)) goto err;
+			for (wn = 0; wn < 3; ++wn)
+				if (p->s_count[mode][g][wn] &&
+				    k2a_shim_launch_exts(mode, wn, &p->s_par[g], p->d_pairs, p->d_order + p->s_first[mode][g][wn], p->s_count[mode][g][wn], p->d_seq,
+				                         p->d_tb, p->d_res, stream)) goto err;
 	if (k2a_shim_event_record(p->ev[1], stream)) goto err;
 	for (mode = 1; mode < 3; ++mode)
 		for (g = 0; g < 2; ++g)
-			if (p->s_count[mode][g] &&
-			    k2a_shim_launch_exts_trace(&p->s_par[g], p->d_pairs, p->d_order + p->s_first[mode][g], p->s_count[mode][g], p->d_tb, p->d_res,
-			                               p->d_cig, stream)) goto err;
+			for (wn = 0; wn < 3; ++wn)
+				if (p->s_count[mode][g][wn] &&
+				    k2a_shim_launch_exts_trace(&p->s_par[g], p->d_pairs, p->d_order + p->s_first[mode][g][wn], p->s_count[mode][g][wn], p->d_tb,
+				                               p->d_res, p->d_cig, stream)) goto err;
 	if (k2a_shim_event_record(p->ev[2], stream)) goto err;
 	return KSW2AMD_OK;
 err:

@@ -22,8 +22,7 @@
 
 #include "ksw2_lane.h"
 
-#define K2A_DM_SLOTS 24                                  /* 64 target positions each: diagonals up to 24*64 - 64 cells */
-#define K2A_DM_MAXDIAG (K2A_DM_SLOTS * 64 - 64)
+#define K2A_DM_MAXDIAG K2A_DM_DIAG(K2A_DM_SLOTS)         /* ksw2_types.h: window classes of 8 / 16 / 24 slots */
 
 /* virtual row -1 / column -1 at distance k from the origin */
 K2A_FN int k2a_dm_border(const K2aSplice &sp, int k)
@@ -81,14 +80,15 @@ K2A_FN int k2a_dm_key_H(uint64_t key) { return (int)((uint32_t)(key >> 32) ^ 0x8
 K2A_FN int k2a_dm_key_t(uint64_t key) { return (int)((0xffffffffu - (uint32_t)key) & 0x0fffffffu); }
 
 /* per-diagonal bookkeeping on uniform values (ksw2_exts2_sse.c:371-377, ksw_apply_zdrop with is_rot = 1 and e = 0):
- * A = H at en0, Bkey = region winner (0 = empty region), T[x] = H at en1 + x, S = H at st0.  Returns 1 on a Z-drop. */
-K2A_FN int k2a_dm_book(K2aBook *b, int r, int st0, int en0, int qlen, int tlen, int zdrop, int A, uint64_t Bkey, const int *T, int S)
+ * A = H at en0, Bkey = region winner (0 = empty region), T0..T2 = H at en1 + 0..2, S = H at st0.  Returns 1 on a Z-drop. */
+K2A_FN int k2a_dm_book(K2aBook *b, int r, int st0, int en0, int qlen, int tlen, int zdrop, int A, uint64_t Bkey, int T0, int T1, int T2, int S)
 {
 	const int en1 = st0 + (en0 - st0) / 4 * 4;
 	int max_H = A, max_t = en0;
 	if (Bkey != 0 && k2a_dm_key_H(Bkey) > max_H) { max_H = k2a_dm_key_H(Bkey); max_t = k2a_dm_key_t(Bkey); }
-	for (int x = 0; x < 3; ++x)
-		if (en1 + x < en0 && T[x] > max_H) { max_H = T[x]; max_t = en1 + x; }
+	if (en1 < en0 && T0 > max_H) { max_H = T0; max_t = en1; }
+	if (en1 + 1 < en0 && T1 > max_H) { max_H = T1; max_t = en1 + 1; }
+	if (en1 + 2 < en0 && T2 > max_H) { max_H = T2; max_t = en1 + 2; }
 	if (en0 == tlen - 1 && A > b->mte) { b->mte = A; b->mte_q = r - ((en0 + 16) / 16 * 16 - 1); }   /* the reference's padded `en` */
 	if (r - st0 == qlen - 1 && S > b->mqe) { b->mqe = S; b->mqe_t = st0; }
 	if (max_H > b->max) { b->max = max_H; b->max_t = max_t; b->max_q = r - max_t; }

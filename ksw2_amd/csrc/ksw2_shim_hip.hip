@@ -450,24 +450,37 @@ __device__ __forceinline__ int k2a_shr1_carry(int v, int carry)
 	return __builtin_amdgcn_update_dpp(carry, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
 
-/* maximum of a 64-bit key over the wavefront (butterfly, two 32-bit shuffles per level) */
+/* maximum of a 64-bit key over the wavefront, uniform result: four row_ror steps leave every 16-lane row's maximum in all
+ * of its lanes, the four row results meet on the scalar side */
+template<int CTRL>
+__device__ __forceinline__ uint64_t k2a_dpp_max_u64(uint64_t k)
+{
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)k, CTRL, 0xf, 0xf, false);
+	const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(k >> 32), CTRL, 0xf, 0xf, false);
+	const uint64_t o = ((uint64_t)hi << 32) | lo;
+	return o > k ? o : k;
+}
 __device__ __forceinline__ uint64_t k2a_wave_max_u64(uint64_t k)
 {
+	k = k2a_dpp_max_u64<0x121>(k);                    /* row_ror:1 */
+	k = k2a_dpp_max_u64<0x122>(k);                    /* row_ror:2 */
+	k = k2a_dpp_max_u64<0x124>(k);                    /* row_ror:4 */
+	k = k2a_dpp_max_u64<0x128>(k);                    /* row_ror:8 */
+	uint64_t best = 0;
 #pragma unroll
-	for (int m = 32; m >= 1; m >>= 1) {
-		const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)k, m, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(k >> 32), m, 64);
-		const uint64_t o = ((uint64_t)hi << 32) | lo;
-		k = o > k ? o : k;
+	for (int row = 0; row < 4; ++row) {
+		const uint64_t v = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k >> 32), row * 16) << 32) |
+		                   (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k, row * 16);
+		best = v > best ? v : best;
 	}
-	return k;
+	return best;
 }
 
-template<int MODE>
+template<int MODE, int K>
 __global__ void __launch_bounds__(64 * K2A_WPB)
 k2a_exts_kernel(const K2aSplice sp, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
                 const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, K2aResult *__restrict__ res)
 {
-	enum { K = K2A_DM_SLOTS };
 	__shared__ int8_t mtab[K2A_MAXM * K2A_MAXM];
 	for (int x = threadIdx.x; x < sp.m * sp.m; x += blockDim.x) mtab[x] = sp.mat[x];
 	__syncthreads();
@@ -496,7 +509,7 @@ k2a_exts_kernel(const K2aSplice sp, const K2aPair *__restrict__ pairs, const uin
 
 	for (int r = 0; r < qlen + tlen - 1; ++r) {
 		const int st0 = max(0, r - qlen + 1), en0 = min(tlen - 1, r), en1 = st0 + (en0 - st0) / 4 * 4;
-		while (st0 >= 1 && (st0 - 1) / 64 > base) {                        /* slide the window: slot s <- slot s+1 */
+		if (st0 >= 1 && (st0 - 1) / 64 > base) {                           /* slide the window (st0 grows by at most 1 per diagonal): slot s <- slot s+1 */
 #pragma unroll
 			for (int s = 0; s + 1 < K; ++s) {
 				H1[s] = H1[s + 1]; H2[s] = H2[s + 1]; En[s] = En[s + 1]; E2n[s] = E2n[s + 1]; Fn[s] = Fn[s + 1]; Q[s] = Q[s + 1]; Cst[s] = Cst[s + 1];
@@ -508,17 +521,20 @@ k2a_exts_kernel(const K2aSplice sp, const K2aPair *__restrict__ pairs, const uin
 		const uint32_t qcur = qnext;
 		qnext = qry[min(r + 1, qlen - 1)];                               /* used one diagonal later */
 		int cH2 = K2A_NEG, cEn = K2A_NEG, cE2n = K2A_NEG, cQ = 0;
-		int A = K2A_NEG, S = K2A_NEG, T[3] = { K2A_NEG, K2A_NEG, K2A_NEG };
+		int A = K2A_NEG, S = K2A_NEG, T0 = K2A_NEG, T1 = K2A_NEG, T2 = K2A_NEG;
 		int bH = K2A_NEG, bT = -1;
 #pragma unroll
 		for (int s = 0; s < K; ++s) {
+			const int t0 = (base + s) * 64, t = t0 + lane;
+			/* wave-uniform: slots below the diagonal's first cell are finished, slots above its last cell (+1: the query code
+			 * that shifts into next diagonal's new cell) hold nothing yet */
+			if (t0 > en0 + 1 || t0 + 63 < st0 - 1) continue;
 			const int h2s = k2a_shr1_carry(H2[s], cH2), ens = k2a_shr1_carry(En[s], cEn), e2ns = k2a_shr1_carry(E2n[s], cE2n);
 			const uint32_t qs = (uint32_t)k2a_shr1_carry((int)Q[s], cQ);
 			cH2 = __builtin_amdgcn_readlane(H2[s], 63); cEn = __builtin_amdgcn_readlane(En[s], 63);
 			cE2n = __builtin_amdgcn_readlane(E2n[s], 63); cQ = __builtin_amdgcn_readlane((int)Q[s], 63);
-			const int t0 = (base + s) * 64, t = t0 + lane;
 			Q[s] = t == 0 ? qcur : qs;
-			if (t0 <= en0 && t0 + 63 >= st0) {                              /* wave-uniform: the slot holds cells of this diagonal */
+			if (t0 <= en0 && t0 + 63 >= st0) {                              /* the slot holds cells of this diagonal */
 				const bool active = t >= st0 && t <= en0, first_row = t == 0, first_col = t == r;
 				const int diag = first_row ? k2a_dm_border(sp, r) : first_col ? k2a_dm_border(sp, t) : h2s;
 				const int ein = first_row ? k2a_dm_border(sp, r + 1) - sp.q - sp.e : ens;
@@ -537,15 +553,13 @@ k2a_exts_kernel(const K2aSplice sp, const K2aPair *__restrict__ pairs, const uin
 				/* the cells the bookkeeping reads by position: the diagonal's last and first cell, the (<= 3) tail cells */
 				if (en0 >= t0 && en0 < t0 + 64) A = __builtin_amdgcn_readlane(H1[s], en0 & 63);
 				if (st0 >= t0 && st0 < t0 + 64) S = __builtin_amdgcn_readlane(H1[s], st0 & 63);
-#pragma unroll
-				for (int x = 0; x < 3; ++x) {
-					const int tt = en1 + x;
-					if (tt < en0 && tt >= t0 && tt < t0 + 64) T[x] = __builtin_amdgcn_readlane(H1[s], tt & 63);
-				}
+				if (en1 < en0 && en1 >= t0 && en1 < t0 + 64) T0 = __builtin_amdgcn_readlane(H1[s], en1 & 63);
+				if (en1 + 1 < en0 && en1 + 1 >= t0 && en1 + 1 < t0 + 64) T1 = __builtin_amdgcn_readlane(H1[s], (en1 + 1) & 63);
+				if (en1 + 2 < en0 && en1 + 2 >= t0 && en1 + 2 < t0 + 64) T2 = __builtin_amdgcn_readlane(H1[s], (en1 + 2) & 63);
 			}
 		}
 		const uint64_t Bkey = k2a_wave_max_u64(bT >= 0 ? k2a_dm_key(bH, bT, st0) : 0ull);
-		if (k2a_dm_book(&book, r, st0, en0, qlen, tlen, pr.zdrop, A, Bkey, T, S)) break;
+		if (k2a_dm_book(&book, r, st0, en0, qlen, tlen, pr.zdrop, A, Bkey, T0, T1, T2, S)) break;
 	}
 	if (lane == 0) k2a_finish(pr, book, &res[pi]);
 }
@@ -709,15 +723,18 @@ int k2a_shim_launch_trace_pk(int cfg, const K2aPair *pairs, const uint32_t *orde
 	return 0;
 }
 
-int k2a_shim_launch_exts(int mode, const K2aSplice *sp, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
+int k2a_shim_launch_exts(int mode, int win, const K2aSplice *sp, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
                          uint8_t *tb, K2aResult *res, void *stream)
 {
 	if (ntasks <= 0) return 0;
 	const dim3 grid((ntasks + K2A_WPB - 1) / K2A_WPB), block(64 * K2A_WPB);
-	if (mode == K2A_MODE_SCORE) hipLaunchKernelGGL(k2a_exts_kernel<K2A_MODE_SCORE>, grid, block, 0, (hipStream_t)stream, *sp, pairs, order, ntasks, seq, tb, res);
-	else if (mode == K2A_MODE_LEFT) hipLaunchKernelGGL(k2a_exts_kernel<K2A_MODE_LEFT>, grid, block, 0, (hipStream_t)stream, *sp, pairs, order, ntasks, seq, tb, res);
-	else if (mode == K2A_MODE_RIGHT) hipLaunchKernelGGL(k2a_exts_kernel<K2A_MODE_RIGHT>, grid, block, 0, (hipStream_t)stream, *sp, pairs, order, ntasks, seq, tb, res);
-	else { snprintf(g_err, sizeof(g_err), "bad mode"); return -1; }
+	typedef void (*exts_fn)(const K2aSplice, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*);
+	static const exts_fn fn[3][3] = {
+		{ k2a_exts_kernel<0, K2A_DM_SLOTS_S>, k2a_exts_kernel<0, K2A_DM_SLOTS_M>, k2a_exts_kernel<0, K2A_DM_SLOTS> },
+		{ k2a_exts_kernel<1, K2A_DM_SLOTS_S>, k2a_exts_kernel<1, K2A_DM_SLOTS_M>, k2a_exts_kernel<1, K2A_DM_SLOTS> },
+		{ k2a_exts_kernel<2, K2A_DM_SLOTS_S>, k2a_exts_kernel<2, K2A_DM_SLOTS_M>, k2a_exts_kernel<2, K2A_DM_SLOTS> } };
+	if (mode < 0 || mode > 2 || win < 0 || win > 2) { snprintf(g_err, sizeof(g_err), "bad splice kernel class"); return -1; }
+	hipLaunchKernelGGL(fn[mode][win], grid, block, 0, (hipStream_t)stream, *sp, pairs, order, ntasks, seq, tb, res);
 	CHECK(hipGetLastError());
 	return 0;
 }

@@ -31,6 +31,13 @@ typedef struct K2aScoring {
 	const int8_t *mat;           /* device copy of the effective m x m matrix, mat[target*m + query]       */
 } K2aScoring;
 
+/* register window classes of the diagonal-major kernel: K slots of 64 target positions hold diagonals of up to
+ * K*64 - 64 cells (the window starts one cell below the diagonal and is 64-aligned) */
+#define K2A_DM_SLOTS_S 8
+#define K2A_DM_SLOTS_M 16
+#define K2A_DM_SLOTS   24
+#define K2A_DM_DIAG(K) ((K) * 64 - 64)
+
 /* batch-uniform parameters of the splice-aware extension (ksw2_lane_dm.h), passed by value */
 typedef struct K2aSplice {
 	int32_t q, e, q2, long_thres;

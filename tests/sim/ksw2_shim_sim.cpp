@@ -344,10 +344,9 @@ static const trace_fn g_trace_pk[K2A_NPKCFG] = { sim_trace_pk<8, 18>, sim_trace_
 
 
 /* mirrors k2a_exts_kernel: one alignment per wavefront, diagonal-major, K2A_DM_SLOTS slots of 64 target positions */
-template<int MODE>
+template<int MODE, int K>
 static void sim_exts(const K2aSplice sp, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res)
 {
-	enum { K = K2A_DM_SLOTS };
 	for (int task = 0; task < ntasks; ++task) {
 		const uint32_t pi = order[task];
 		const K2aPair pr = pairs[pi];
@@ -391,6 +390,7 @@ static void sim_exts(const K2aSplice sp, const K2aPair *pairs, const uint32_t *o
 			for (int s = 0; s < K; ++s) {
 				int h2s[64], ens[64], e2ns[64];
 				uint32_t qs[64];
+				if ((base + s) * 64 > en0 + 1 || (base + s) * 64 + 63 < st0 - 1) continue;   /* finished / not yet reached */
 				for (int l = 0; l < 64; ++l) {                             /* one-lane shift with the previous slot's lane 63 carried in */
 					h2s[l] = l ? H2[s][l - 1] : cH2; ens[l] = l ? En[s][l - 1] : cEn; e2ns[l] = l ? E2n[s][l - 1] : cE2n;
 					qs[l] = l ? Q[s][l - 1] : cQ;
@@ -424,7 +424,7 @@ static void sim_exts(const K2aSplice sp, const K2aPair *pairs, const uint32_t *o
 			uint64_t Bkey = 0;
 			for (int l = 0; l < 64; ++l)
 				if (bT[l] >= 0) { const uint64_t k = k2a_dm_key(bH[l], bT[l], st0); if (k > Bkey) Bkey = k; }
-			if (k2a_dm_book(&book, r, st0, en0, qlen, tlen, pr.zdrop, A, Bkey, T, S)) break;
+			if (k2a_dm_book(&book, r, st0, en0, qlen, tlen, pr.zdrop, A, Bkey, T[0], T[1], T[2], S)) break;
 		}
 		k2a_finish(pr, book, &res[pi]);
 	}
@@ -501,13 +501,15 @@ int k2a_shim_launch_compact(const K2aPair *pairs, const K2aResult *res, const ui
 	return 0;
 }
 
-int k2a_shim_launch_exts(int mode, const K2aSplice *sp, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, uint8_t *tb,
-                         K2aResult *res, void *)
+int k2a_shim_launch_exts(int mode, int win, const K2aSplice *sp, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
+                         uint8_t *tb, K2aResult *res, void *)
 {
-	if (ntasks <= 0) return 0;
-	if (mode == K2A_MODE_SCORE) sim_exts<K2A_MODE_SCORE>(*sp, pairs, order, ntasks, seq, tb, res);
-	else if (mode == K2A_MODE_LEFT) sim_exts<K2A_MODE_LEFT>(*sp, pairs, order, ntasks, seq, tb, res);
-	else sim_exts<K2A_MODE_RIGHT>(*sp, pairs, order, ntasks, seq, tb, res);
+	typedef void (*exts_fn)(const K2aSplice, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*);
+	static const exts_fn fn[3][3] = {
+		{ sim_exts<0, K2A_DM_SLOTS_S>, sim_exts<0, K2A_DM_SLOTS_M>, sim_exts<0, K2A_DM_SLOTS> },
+		{ sim_exts<1, K2A_DM_SLOTS_S>, sim_exts<1, K2A_DM_SLOTS_M>, sim_exts<1, K2A_DM_SLOTS> },
+		{ sim_exts<2, K2A_DM_SLOTS_S>, sim_exts<2, K2A_DM_SLOTS_M>, sim_exts<2, K2A_DM_SLOTS> } };
+	if (ntasks > 0) fn[mode][win](*sp, pairs, order, ntasks, seq, tb, res);
 	return 0;
 }
 int k2a_shim_launch_exts_trace(const K2aSplice *sp, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb, K2aResult *res,
