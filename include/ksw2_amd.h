@@ -103,7 +103,7 @@ void ksw_extd2_sse2(void *km, int qlen, const uint8_t *query, int tlen, const ui
  * acceptor sites (flag KSW_EZ_SPLICE_FOR / _REV / _FLANK), junc[t] bits 1/2 (forward donor/acceptor), 8/4 (reverse)
  * rewarded with junc_bonus.  Unbanded; Z-drop, max and mqe / mte per anti-diagonal exactly like the reference,
  * CIGAR with N for introns.  Bit-exact against the reference's SSE kernel in exact-max mode.
- * This release handles min(qlen, tlen) <= 1472 (one diagonal must fit a wavefront's register window); longer ones abort. */
+ * Diagonals of up to 1472 cells (min(qlen, tlen)) run from registers, longer ones from an HBM-resident state (slower). */
 void ksw_exts2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
                    int8_t gapo, int8_t gape, int8_t gapo2, int8_t noncan, int zdrop, int8_t junc_bonus, int flag, const uint8_t *junc, ksw_extz_t *ez);
 void ksw_exts2_sse41(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,

@@ -171,7 +171,7 @@ struct ksw2amd_plan_s {
 	int stream_used;
 	int64_t cells;
 	/* splice-aware plans (ksw2amd_exts_plan_create): tasks of h_order grouped by kernel mode x matrix variant */
-	int splice, s_first[3][2][3], s_count[3][2][3];   /* [mode][matrix variant][window class] */
+	int splice, s_first[3][2][3], s_count[3][2][3];   /* [mode][matrix variant][window class: 8 slots, 16 slots, state in HBM] */
 	K2aSplice s_par[2];
 };
 
@@ -984,13 +984,19 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 		int mode, generic;
 		if (a->qlen <= 0 || a->tlen <= 0) continue;
 		if (!a->query || !a->target) { fail(KSW2AMD_E_PARAM, "exts: NULL sequence%s", 0); goto err; }
-		if (imin(a->qlen, a->tlen) > K2A_DM_DIAG(K2A_DM_SLOTS)) {
-			fail(KSW2AMD_E_PARAM, "exts: min(qlen, tlen) > 1472 is not supported by this release%s", 0);
-			goto err;
-		}
 		mode = (a->flag & KSW_EZ_SCORE_ONLY) ? K2A_MODE_SCORE : (a->flag & KSW_EZ_RIGHT) ? K2A_MODE_RIGHT : K2A_MODE_LEFT;
 		generic = (a->flag & KSW_EZ_GENERIC_SC) ? 1 : 0;
-		wn = imin(a->qlen, a->tlen) <= K2A_DM_DIAG(K2A_DM_SLOTS_S) ? 0 : imin(a->qlen, a->tlen) <= K2A_DM_DIAG(K2A_DM_SLOTS_M) ? 1 : 2;
+		/* register windows where they are the faster kernel (tools/scripts/exts_classes.py): 8 slots always, 16 slots without
+		 * traceback (with it that kernel is down to one wavefront per SIMD) */
+		wn = imin(a->qlen, a->tlen) <= K2A_DM_DIAG(K2A_DM_SLOTS_S) ? 0 :
+		     (imin(a->qlen, a->tlen) <= K2A_DM_DIAG(K2A_DM_SLOTS) && mode == K2A_MODE_SCORE) ? 1 : 2;
+		if (getenv("KSW2AMD_EXTS_BIG")) wn = 2;        /* tests: every pair through the HBM-state kernel */
+		else if (getenv("KSW2AMD_EXTS_REG") && imin(a->qlen, a->tlen) <= K2A_DM_DIAG(K2A_DM_SLOTS)) wn = imin(wn, 1);   /* tests: 16 slots with traceback */
+		if (wn == 2) {                                 /* 9 ints of state per target position, 16-byte granules */
+			d->pad = (uint32_t)(p->bnd_words / 4);
+			p->bnd_words += align_up(9 * (size_t)a->tlen, 4);
+			if (p->bnd_words / 4 > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "exts: state scratch over 64 GiB in one plan%s", 0); goto err; }
+		}
 		p->h_cls[i] = (int8_t)((mode * 2 + generic) * 3 + wn);
 		++p->s_count[mode][generic][wn];
 		d->qlen = a->qlen; d->tlen = d->tlen_full = a->tlen;
@@ -1034,7 +1040,9 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 	p->d_order = (uint32_t*)cache_get(BUF_ORDER, sizeof(uint32_t) * ((size_t)p->norder + 1), &p->cap[BUF_ORDER]);
 	p->d_tb = p->tb_bytes ? (uint8_t*)cache_get(BUF_TB, p->tb_bytes, &p->cap[BUF_TB]) : 0;
 	p->d_cig = p->cig_words ? (uint32_t*)cache_get(BUF_CIG, p->cig_words * 4, &p->cap[BUF_CIG]) : 0;
-	if (!p->d_seq || !p->d_pairs || !p->d_res || !p->d_order || (p->tb_bytes && !p->d_tb) || (p->cig_words && !p->d_cig)) {
+	p->d_bnd = p->bnd_words ? (int32_t*)cache_get(BUF_BND, p->bnd_words * 4, &p->cap[BUF_BND]) : 0;
+	if (!p->d_seq || !p->d_pairs || !p->d_res || !p->d_order || (p->tb_bytes && !p->d_tb) || (p->cig_words && !p->d_cig) ||
+	    (p->bnd_words && !p->d_bnd)) {
 		fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error());
 		goto err;
 	}
@@ -1069,7 +1077,7 @@ static int exts_plan_run(ksw2amd_plan_t *p, void *stream)
 			for (wn = 0; wn < 3; ++wn)
 				if (p->s_count[mode][g][wn] &&
 				    k2a_shim_launch_exts(mode, wn, &p->s_par[g], p->d_pairs, p->d_order + p->s_first[mode][g][wn], p->s_count[mode][g][wn], p->d_seq,
-				                         p->d_tb, p->d_res, stream)) goto err;
+				                         p->d_tb, p->d_bnd, p->d_res, stream)) goto err;
 	if (k2a_shim_event_record(p->ev[1], stream)) goto err;
 	for (mode = 1; mode < 3; ++mode)
 		for (g = 0; g < 2; ++g)

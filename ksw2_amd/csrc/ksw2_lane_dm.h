@@ -4,8 +4,8 @@
  * Unlike the banded kernels (ksw2_lane.h) this function is unbanded and does its bookkeeping -- running maximum,
  * Z-drop, mqe / mte -- once per ANTI-DIAGONAL r = i + j on the diagonal's best cell (ksw2_exts2_sse.c:345-384), with
  * ties inside a diagonal resolved by the reference's own scan order.  So the kernel is diagonal-major like the
- * reference: one alignment per wavefront, lane <-> target position t (64 per register "slot", K2A_DM_SLOTS slots in a
- * window that slides with the diagonal), one step per diagonal.  A lane keeps H of the last two diagonals and the gap
+ * reference: one alignment per wavefront, lane <-> target position t (64 per register "slot", 8 or 16 slots in a
+ * window that slides with the diagonal; longer diagonals keep the same state in a scratch array), one step per diagonal.  A lane keeps H of the last two diagonals and the gap
  * states leaving its cell; the values a cell needs from row t-1 arrive by a one-lane shift (DPP wave_shr:1 with the
  * previous slot's last lane carried in).  Everything is int32 absolute scores (the reference's int8 differences, summed).
  *
@@ -22,7 +22,6 @@
 
 #include "ksw2_lane.h"
 
-#define K2A_DM_MAXDIAG K2A_DM_DIAG(K2A_DM_SLOTS)         /* ksw2_types.h: window classes of 8 / 16 / 24 slots */
 
 /* virtual row -1 / column -1 at distance k from the origin */
 K2A_FN int k2a_dm_border(const K2aSplice &sp, int k)

@@ -74,9 +74,10 @@ int k2a_shim_launch_trace_pk(int cfg, const K2aPair *pairs, const uint32_t *orde
  * (in seq) of the alignment's packed per-target-position constants, tb_off = its direction bytes ((qlen+tlen-1) rows of
  * min(qlen,tlen) bytes), w / end_bonus set so that k2a_finish applies the plain start-cell rule.  The trace launch walks
  * them with the intron state.  order[t] = index into pairs / res, as for the fill kernels.
- * win = register window class 0 / 1 / 2: diagonals up to K2A_DM_DIAG(K2A_DM_SLOTS_S / _M / K2A_DM_SLOTS) cells. */
+ * win = register window class 0 / 1: diagonals up to K2A_DM_DIAG(K2A_DM_SLOTS_S / K2A_DM_SLOTS) cells; win = 2: any length,
+ * state in `scratch` (9 * tlen ints per alignment at 4 * pairs[i].pad). */
 int k2a_shim_launch_exts(int mode, int win, const K2aSplice *sp, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
-                         uint8_t *tb, K2aResult *res, void *stream);
+                         uint8_t *tb, int32_t *scratch, K2aResult *res, void *stream);
 int k2a_shim_launch_exts_trace(const K2aSplice *sp, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb,
                                K2aResult *res, uint32_t *cig, void *stream);
 

@@ -564,6 +564,76 @@ k2a_exts_kernel(const K2aSplice sp, const K2aPair *__restrict__ pairs, const uin
 	if (lane == 0) k2a_finish(pr, book, &res[pi]);
 }
 
+/* The same function for diagonals of any length: the per-position state lives in a scratch array in HBM (L2-resident:
+ * 9 ints per target position) instead of registers, double-buffered by diagonal parity (H: three diagonals), so the value
+ * of position t-1 is simply read at t-1.  Writer and reader are lanes of the same wavefront, so workgroup scope is enough:
+ * one release / acquire pair per diagonal orders a diagonal's stores before the next diagonal's loads (the CU's L1 is
+ * write-through and shared by the wavefront).  Slower than the register
+ * kernel (about 44 bytes of L2 traffic per cell), it exists so that no input size is refused. */
+template<int MODE>
+__global__ void __launch_bounds__(64 * K2A_WPB)
+k2a_exts_big_kernel(const K2aSplice sp, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
+                    const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, int32_t *scratch, K2aResult *__restrict__ res)
+{
+	__shared__ int8_t mtab[K2A_MAXM * K2A_MAXM];
+	for (int x = threadIdx.x; x < sp.m * sp.m; x += blockDim.x) mtab[x] = sp.mat[x];
+	__syncthreads();
+
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int task = blockIdx.x * K2A_WPB + wave;
+	if (task >= ntasks) return;
+	const uint32_t pi = order[task];
+	const K2aPair pr = pairs[pi];
+	const int qlen = pr.qlen, tlen = pr.tlen_full, ncol = min(qlen, tlen);
+	const uint8_t *qry = seq + pr.qoff;
+	const uint32_t *cst = (const uint32_t*)seq + pr.bnd_off;
+	uint8_t *tbp = tb + pr.tb_off;
+	int32_t *W = scratch + (size_t)pr.pad * 4;         /* pad = scratch offset in units of 4 ints */
+	K2aBook book;
+	k2a_book_reset(&book);
+
+	for (int r = 0; r < qlen + tlen - 1; ++r) {
+		const int st0 = max(0, r - qlen + 1), en0 = min(tlen - 1, r), en1 = st0 + (en0 - st0) / 4 * 4;
+		int32_t *Hc = W + (size_t)(r % 3) * tlen;
+		const int32_t *H2 = W + (size_t)((r + 1) % 3) * tlen;                         /* diagonal r - 2 */
+		int32_t *Ec = W + (size_t)(3 + (r & 1)) * tlen, *E2c = W + (size_t)(5 + (r & 1)) * tlen, *Fc = W + (size_t)(7 + (r & 1)) * tlen;
+		const int32_t *Ep = W + (size_t)(3 + ((r + 1) & 1)) * tlen, *E2p = W + (size_t)(5 + ((r + 1) & 1)) * tlen, *Fp = W + (size_t)(7 + ((r + 1) & 1)) * tlen;
+		int A = K2A_NEG, S = K2A_NEG, T0 = K2A_NEG, T1 = K2A_NEG, T2 = K2A_NEG;
+		int bH = K2A_NEG, bT = -1;
+		for (int t0 = st0 & ~63; t0 <= en0; t0 += 64) {
+			const int t = t0 + lane;
+			const bool active = t >= st0 && t <= en0;
+			int z = K2A_NEG;
+			if (active) {
+				const bool first_row = t == 0, first_col = t == r;
+				const int diag = first_row ? k2a_dm_border(sp, r) : first_col ? k2a_dm_border(sp, t)
+				                 : __hip_atomic_load(&H2[t - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				const int ein = first_row ? k2a_dm_border(sp, r + 1) - sp.q - sp.e : __hip_atomic_load(&Ep[t - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				const int e2in = first_row ? k2a_dm_border(sp, r + 1) - sp.q2 : __hip_atomic_load(&E2p[t - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				const int fin = first_col ? k2a_dm_border(sp, t + 1) - sp.q - sp.e : __hip_atomic_load(&Fp[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				const uint32_t c = cst[t];
+				const int sc = (int)mtab[(c & 0xffu) * (uint32_t)sp.m + qry[r - t]];
+				int en, e2n, fn;
+				uint32_t dir;
+				k2a_dm_cell<MODE>(sp, diag, ein, e2in, fin, sc, c, z, en, e2n, fn, dir);
+				Hc[t] = z; Ec[t] = en; E2c[t] = e2n; Fc[t] = fn;
+				if (MODE != K2A_MODE_SCORE) tbp[(size_t)r * ncol + (t - st0)] = (uint8_t)dir;
+				if (t < en1 && z > bH) { bH = z; bT = t; }
+			}
+			if (en0 >= t0 && en0 < t0 + 64) A = __builtin_amdgcn_readlane(z, en0 & 63);
+			if (st0 >= t0 && st0 < t0 + 64) S = __builtin_amdgcn_readlane(z, st0 & 63);
+			if (en1 < en0 && en1 >= t0 && en1 < t0 + 64) T0 = __builtin_amdgcn_readlane(z, en1 & 63);
+			if (en1 + 1 < en0 && en1 + 1 >= t0 && en1 + 1 < t0 + 64) T1 = __builtin_amdgcn_readlane(z, (en1 + 1) & 63);
+			if (en1 + 2 < en0 && en1 + 2 >= t0 && en1 + 2 < t0 + 64) T2 = __builtin_amdgcn_readlane(z, (en1 + 2) & 63);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                /* this diagonal's state is written ... */
+		const uint64_t Bkey = k2a_wave_max_u64(bT >= 0 ? k2a_dm_key(bH, bT, st0) : 0ull);
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                /* ... before anybody reads it on the next one */
+		if (k2a_dm_book(&book, r, st0, en0, qlen, tlen, pr.zdrop, A, Bkey, T0, T1, T2, S)) break;
+	}
+	if (lane == 0) k2a_finish(pr, book, &res[pi]);
+}
+
 __global__ void __launch_bounds__(64)
 k2a_exts_trace_kernel(const K2aSplice sp, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
                       const uint8_t *__restrict__ tb, K2aResult *__restrict__ res, uint32_t *__restrict__ cig)
@@ -724,17 +794,21 @@ int k2a_shim_launch_trace_pk(int cfg, const K2aPair *pairs, const uint32_t *orde
 }
 
 int k2a_shim_launch_exts(int mode, int win, const K2aSplice *sp, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
-                         uint8_t *tb, K2aResult *res, void *stream)
+                         uint8_t *tb, int32_t *scratch, K2aResult *res, void *stream)
 {
 	if (ntasks <= 0) return 0;
 	const dim3 grid((ntasks + K2A_WPB - 1) / K2A_WPB), block(64 * K2A_WPB);
 	typedef void (*exts_fn)(const K2aSplice, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*);
-	static const exts_fn fn[3][3] = {
-		{ k2a_exts_kernel<0, K2A_DM_SLOTS_S>, k2a_exts_kernel<0, K2A_DM_SLOTS_M>, k2a_exts_kernel<0, K2A_DM_SLOTS> },
-		{ k2a_exts_kernel<1, K2A_DM_SLOTS_S>, k2a_exts_kernel<1, K2A_DM_SLOTS_M>, k2a_exts_kernel<1, K2A_DM_SLOTS> },
-		{ k2a_exts_kernel<2, K2A_DM_SLOTS_S>, k2a_exts_kernel<2, K2A_DM_SLOTS_M>, k2a_exts_kernel<2, K2A_DM_SLOTS> } };
+	static const exts_fn fn[3][2] = {
+		{ k2a_exts_kernel<0, K2A_DM_SLOTS_S>, k2a_exts_kernel<0, K2A_DM_SLOTS> },
+		{ k2a_exts_kernel<1, K2A_DM_SLOTS_S>, k2a_exts_kernel<1, K2A_DM_SLOTS> },
+		{ k2a_exts_kernel<2, K2A_DM_SLOTS_S>, k2a_exts_kernel<2, K2A_DM_SLOTS> } };
 	if (mode < 0 || mode > 2 || win < 0 || win > 2) { snprintf(g_err, sizeof(g_err), "bad splice kernel class"); return -1; }
-	hipLaunchKernelGGL(fn[mode][win], grid, block, 0, (hipStream_t)stream, *sp, pairs, order, ntasks, seq, tb, res);
+	if (win == 2) {
+		if (mode == 0) hipLaunchKernelGGL(k2a_exts_big_kernel<0>, grid, block, 0, (hipStream_t)stream, *sp, pairs, order, ntasks, seq, tb, scratch, res);
+		else if (mode == 1) hipLaunchKernelGGL(k2a_exts_big_kernel<1>, grid, block, 0, (hipStream_t)stream, *sp, pairs, order, ntasks, seq, tb, scratch, res);
+		else hipLaunchKernelGGL(k2a_exts_big_kernel<2>, grid, block, 0, (hipStream_t)stream, *sp, pairs, order, ntasks, seq, tb, scratch, res);
+	} else hipLaunchKernelGGL(fn[mode][win], grid, block, 0, (hipStream_t)stream, *sp, pairs, order, ntasks, seq, tb, res);
 	CHECK(hipGetLastError());
 	return 0;
 }

@@ -430,6 +430,57 @@ static void sim_exts(const K2aSplice sp, const K2aPair *pairs, const uint32_t *o
 	}
 }
 
+/* mirrors k2a_exts_big_kernel: state in a scratch array, double-buffered by diagonal parity */
+template<int MODE>
+static void sim_exts_big(const K2aSplice sp, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, uint8_t *tb,
+                         int32_t *scratch, K2aResult *res)
+{
+	for (int task = 0; task < ntasks; ++task) {
+		const uint32_t pi = order[task];
+		const K2aPair pr = pairs[pi];
+		const int qlen = pr.qlen, tlen = pr.tlen_full, ncol = k2a_min(qlen, tlen);
+		const uint8_t *qry = seq + pr.qoff;
+		const uint32_t *cst = (const uint32_t*)seq + pr.bnd_off;
+		uint8_t *tbp = tb + pr.tb_off;
+		int32_t *W = scratch + (size_t)pr.pad * 4;
+		K2aBook book;
+		k2a_book_reset(&book);
+		for (int r = 0; r < qlen + tlen - 1; ++r) {
+			const int st0 = k2a_max(0, r - qlen + 1), en0 = k2a_min(tlen - 1, r), en1 = st0 + (en0 - st0) / 4 * 4;
+			int32_t *Hc = W + (size_t)(r % 3) * tlen;
+			const int32_t *H2 = W + (size_t)((r + 1) % 3) * tlen;
+			int32_t *Ec = W + (size_t)(3 + (r & 1)) * tlen, *E2c = W + (size_t)(5 + (r & 1)) * tlen, *Fc = W + (size_t)(7 + (r & 1)) * tlen;
+			const int32_t *Ep = W + (size_t)(3 + ((r + 1) & 1)) * tlen, *E2p = W + (size_t)(5 + ((r + 1) & 1)) * tlen, *Fp = W + (size_t)(7 + ((r + 1) & 1)) * tlen;
+			int A = K2A_NEG, S = K2A_NEG, T[3] = { K2A_NEG, K2A_NEG, K2A_NEG };
+			int bH[64], bT[64];
+			for (int l = 0; l < 64; ++l) { bH[l] = K2A_NEG; bT[l] = -1; }
+			for (int t = st0; t <= en0; ++t) {
+				const bool first_row = t == 0, first_col = t == r;
+				const int diag = first_row ? k2a_dm_border(sp, r) : first_col ? k2a_dm_border(sp, t) : H2[t - 1];
+				const int ein = first_row ? k2a_dm_border(sp, r + 1) - sp.q - sp.e : Ep[t - 1];
+				const int e2in = first_row ? k2a_dm_border(sp, r + 1) - sp.q2 : E2p[t - 1];
+				const int fin = first_col ? k2a_dm_border(sp, t + 1) - sp.q - sp.e : Fp[t];
+				const uint32_t c = cst[t];
+				const int sc = (int)sp.mat[(c & 0xffu) * (uint32_t)sp.m + qry[r - t]];
+				int z, en, e2n, fn;
+				uint32_t dir;
+				k2a_dm_cell<MODE>(sp, diag, ein, e2in, fin, sc, c, z, en, e2n, fn, dir);
+				Hc[t] = z; Ec[t] = en; E2c[t] = e2n; Fc[t] = fn;
+				if (MODE != K2A_MODE_SCORE) tbp[(size_t)r * ncol + (t - st0)] = (uint8_t)dir;
+				if (t == en0) A = z;
+				if (t == st0) S = z;
+				if (t >= en1 && t < en0) T[t - en1] = z;
+				if (t < en1 && z > bH[t & 63]) { bH[t & 63] = z; bT[t & 63] = t; }
+			}
+			uint64_t Bkey = 0;
+			for (int l = 0; l < 64; ++l)
+				if (bT[l] >= 0) { const uint64_t k = k2a_dm_key(bH[l], bT[l], st0); if (k > Bkey) Bkey = k; }
+			if (k2a_dm_book(&book, r, st0, en0, qlen, tlen, pr.zdrop, A, Bkey, T[0], T[1], T[2], S)) break;
+		}
+		k2a_finish(pr, book, &res[pi]);
+	}
+}
+
 static void sim_exts_trace(const K2aSplice sp, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb, K2aResult *res, uint32_t *cig)
 {
 	for (int task = 0; task < ntasks; ++task) {
@@ -502,13 +553,19 @@ int k2a_shim_launch_compact(const K2aPair *pairs, const K2aResult *res, const ui
 }
 
 int k2a_shim_launch_exts(int mode, int win, const K2aSplice *sp, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
-                         uint8_t *tb, K2aResult *res, void *)
+                         uint8_t *tb, int32_t *scratch, K2aResult *res, void *)
 {
+	if (win == 2 && ntasks > 0) {
+		if (mode == 0) sim_exts_big<0>(*sp, pairs, order, ntasks, seq, tb, scratch, res);
+		else if (mode == 1) sim_exts_big<1>(*sp, pairs, order, ntasks, seq, tb, scratch, res);
+		else sim_exts_big<2>(*sp, pairs, order, ntasks, seq, tb, scratch, res);
+		return 0;
+	}
 	typedef void (*exts_fn)(const K2aSplice, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*);
-	static const exts_fn fn[3][3] = {
-		{ sim_exts<0, K2A_DM_SLOTS_S>, sim_exts<0, K2A_DM_SLOTS_M>, sim_exts<0, K2A_DM_SLOTS> },
-		{ sim_exts<1, K2A_DM_SLOTS_S>, sim_exts<1, K2A_DM_SLOTS_M>, sim_exts<1, K2A_DM_SLOTS> },
-		{ sim_exts<2, K2A_DM_SLOTS_S>, sim_exts<2, K2A_DM_SLOTS_M>, sim_exts<2, K2A_DM_SLOTS> } };
+	static const exts_fn fn[3][2] = {
+		{ sim_exts<0, K2A_DM_SLOTS_S>, sim_exts<0, K2A_DM_SLOTS> },
+		{ sim_exts<1, K2A_DM_SLOTS_S>, sim_exts<1, K2A_DM_SLOTS> },
+		{ sim_exts<2, K2A_DM_SLOTS_S>, sim_exts<2, K2A_DM_SLOTS> } };
 	if (ntasks > 0) fn[mode][win](*sp, pairs, order, ntasks, seq, tb, res);
 	return 0;
 }

@@ -411,8 +411,12 @@ def test_cli_matches_reference_cli(lib):
     assert a.returncode == 0 and a.stdout == b.stdout and a.stdout.count("\n") == 5
 
 
-def test_splice_aware_golden(lib):
-    """All 1200 ksw_exts2_sse cases produced by the compiled reference (tests/golden/exts_cases.npz), batched by scoring."""
+@pytest.mark.parametrize("big", [False, True])
+def test_splice_aware_golden(lib, big, monkeypatch):
+    """All 1200 ksw_exts2_sse cases produced by the compiled reference (tests/golden/exts_cases.npz), batched by scoring;
+    once through the register-window kernels, once through the scratch-array kernel that takes diagonals of any length."""
+    if big:
+        monkeypatch.setenv("KSW2AMD_EXTS_BIG", "1")
     ec = gu.ExtsCases()
     groups = {}
     for k in range(ec.n):
@@ -446,3 +450,11 @@ def test_splice_aware_random_and_long(lib):
     check_exts_batch(lib, qs, ts, [None] * len(qs), mat, 2, 1, 32, 4, 0, flag, zd)
     r = lib.exts2(qs[0], ts[0], mat, 2, 1, 32, 4, flag=po.SPLICE_FOR)
     assert not diff(po.exts2("oracle", qs[0], ts[0], mat, 2, 1, 32, 4, flag=po.SPLICE_FOR), r, gu.FIELDS + ["cigar"])
+    # diagonals beyond the largest register window (1472 cells): state in HBM
+    big_q, big_t = [], []
+    for tl in (2600, 4000, 3000):
+        q, t = _intron_pair(rng, tl)
+        big_q.append(np.concatenate([q, t[-2000:]])[:int(rng.integers(1600, 2400))])
+        big_t.append(t)
+    check_exts_batch(lib, big_q, big_t, [None] * 3, mat, 2, 1, 32, 4, 0, np.array([po.SPLICE_FOR, po.SPLICE_FOR | po.RIGHT, po.SCORE_ONLY]),
+                     np.array([-1, 500, 200]))

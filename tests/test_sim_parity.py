@@ -288,6 +288,14 @@ def _intron_pair(rng, tl):
     return q, t
 
 
+def test_sim_splice_aware_16_slots_with_traceback(sim, monkeypatch):
+    """The 16-slot register window is only chosen for score-only launches; KSW2AMD_EXTS_REG forces it with traceback."""
+    monkeypatch.setenv("KSW2AMD_EXTS_REG", "1")
+    rng = np.random.Generator(np.random.PCG64(31))
+    for rnd in (0, 7, 14):
+        check_exts_batch(sim, *_exts_cases(rng, rnd, 950))
+
+
 def test_sim_splice_aware(sim):
     """ksw_exts2_sse semantics through the diagonal-major kernel (ksw2_lane_dm.h): random spliced pairs with junction
     annotation, every flag combination, tie-heavy two-letter sequences, and diagonals longer than one register slot."""
@@ -310,14 +318,20 @@ def test_sim_splice_aware_sliding_window(sim):
         assert not diff(exp, res, gu.FIELDS + ["cigar"]), (rnd, len(q), len(t))
         if flag == po.SPLICE_FOR and zd == -1 and not rnd % 2:
             assert any((c & 0xf) == 3 and (c >> 4) > 50 for c in res["cigar"])       # the intron comes back as N
-    # a diagonal that does not fit the register window is refused loudly
-    with pytest.raises(ka.Ksw2Error):
-        sim.exts_batch([np.zeros(1600, np.uint8)], [np.zeros(1600, np.uint8)], mat, 2, 1, 32, 4)
+    # a diagonal that does not fit the largest register window: state in the scratch array (k2a_exts_big_kernel)
+    q, t = _intron_pair(rng, 2600)
+    q = np.concatenate([q, t[-1500:]])[:1700]
+    for flag in (po.SPLICE_FOR, po.SPLICE_FOR | po.SCORE_ONLY):
+        exp = po.exts2("oracle", q, t, mat, 2, 1, 32, 4, zdrop=500, flag=flag)
+        assert not diff(exp, sim.exts2(q, t, mat, 2, 1, 32, 4, zdrop=500, flag=flag), gu.FIELDS + ["cigar"])
 
 
-def test_sim_splice_aware_golden_subset(sim):
+@pytest.mark.parametrize("big", [False, True])
+def test_sim_splice_aware_golden_subset(sim, big, monkeypatch):
+    if big:
+        monkeypatch.setenv("KSW2AMD_EXTS_BIG", "1")      # every case through the scratch-array kernel
     ec = gu.ExtsCases()
-    for k in range(0, ec.n, 5):
+    for k in range(1 if big else 0, ec.n, 5):
         c = ec.case(k)
         res = sim.exts2(c["q"], c["t"], c["mat"], c["gq"], c["ge"], c["gq2"], c["noncan"], zdrop=c["zdrop"], junc_bonus=c["junc_bonus"],
                         flag=c["flag"], junc=c["junc"])
