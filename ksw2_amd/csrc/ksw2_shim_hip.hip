@@ -16,7 +16,16 @@
 #include "ksw2_lane_dm.h"
 
 #define K2A_WPB 4          /* wavefronts per workgroup; waves never synchronise with each other */
-#define K2A_TRACE_PPW 8    /* alignments walked per wavefront by the traceback kernel */
+/* The traceback walk is a chain of dependent loads and a few dozen instructions per step on ONE lane; what it needs is many
+ * wavefronts in flight, not many lanes per wavefront.  Walks per wavefront (1..8) so that a launch has about four wavefronts
+ * per SIMD: measured on 10 k x 10 k CIGARs, 4096 walks: 8 per wavefront 6.7 ms, 1 per wavefront 5.7 ms; 16384 walks of
+ * config 3: 8 -> 1.6 ms, 1 -> 3.3 ms. */
+static int k2a_trace_ppw(int nwalks)
+{
+	const int target_waves = 4096;
+	int ppw = (nwalks + target_waves - 1) / target_waves;
+	return ppw < 1 ? 1 : ppw > 8 ? 8 : ppw;
+}
 
 static thread_local char g_err[512] = "";
 
@@ -380,12 +389,12 @@ k2a_fill_mp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 template<int G, int C, bool DUAL, bool MP>
 __global__ void __launch_bounds__(64)
 k2a_trace_kernel(const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
-                 const uint8_t *__restrict__ tb, K2aResult *__restrict__ res, uint32_t *__restrict__ cig)
+                 const uint8_t *__restrict__ tb, K2aResult *__restrict__ res, uint32_t *__restrict__ cig, int ppw)
 {
 	/* the walk is a chain of dependent, scattered byte loads: a few walks per wavefront on many wavefronts beats
 	 * 64 walks whose loads serialise in one texture-address unit */
-	if (threadIdx.x >= K2A_TRACE_PPW) return;
-	const int t = blockIdx.x * K2A_TRACE_PPW + threadIdx.x;
+	if ((int)threadIdx.x >= ppw) return;
+	const int t = blockIdx.x * ppw + threadIdx.x;
 	if (t >= ntasks) return;
 	const uint32_t pi = order[t];
 	const K2aPair pr = pairs[pi];
@@ -410,7 +419,7 @@ k2a_compact_kernel(const K2aPair *__restrict__ pairs, const K2aResult *__restric
 /* ---------------------------------------------------------------- dispatch tables */
 
 typedef void (*fill_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*);
-typedef void (*trace_fn)(const K2aPair*, const uint32_t*, int, const uint8_t*, K2aResult*, uint32_t*);
+typedef void (*trace_fn)(const K2aPair*, const uint32_t*, int, const uint8_t*, K2aResult*, uint32_t*, int);
 
 #define FILL_ROW(G, C) { { k2a_fill_kernel<G, C, false, 0>, k2a_fill_kernel<G, C, false, 1>, k2a_fill_kernel<G, C, false, 2> }, \
                          { k2a_fill_kernel<G, C, true, 0>,  k2a_fill_kernel<G, C, true, 1>,  k2a_fill_kernel<G, C, true, 2> } }
@@ -427,10 +436,10 @@ static const trace_fn g_trace[K2A_NCFG][2] = { TRACE_ROW(16, 8, false), TRACE_RO
 template<int G, int C>
 __global__ void __launch_bounds__(64)
 k2a_trace_pk_kernel(const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
-                    const uint8_t *__restrict__ tb, K2aResult *__restrict__ res, uint32_t *__restrict__ cig)
+                    const uint8_t *__restrict__ tb, K2aResult *__restrict__ res, uint32_t *__restrict__ cig, int ppw)
 {
-	if (threadIdx.x >= K2A_TRACE_PPW) return;
-	const int t = blockIdx.x * K2A_TRACE_PPW + threadIdx.x;
+	if ((int)threadIdx.x >= ppw) return;
+	const int t = blockIdx.x * ppw + threadIdx.x;
 	if (t >= 2 * ntasks) return;
 	const int half = t & 1;
 	const uint32_t piA = order2[t & ~1], pi = order2[t];
@@ -636,10 +645,10 @@ k2a_exts_big_kernel(const K2aSplice sp, const K2aPair *__restrict__ pairs, const
 
 __global__ void __launch_bounds__(64)
 k2a_exts_trace_kernel(const K2aSplice sp, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
-                      const uint8_t *__restrict__ tb, K2aResult *__restrict__ res, uint32_t *__restrict__ cig)
+                      const uint8_t *__restrict__ tb, K2aResult *__restrict__ res, uint32_t *__restrict__ cig, int ppw)
 {
-	if (threadIdx.x >= K2A_TRACE_PPW) return;
-	const int t = blockIdx.x * K2A_TRACE_PPW + threadIdx.x;
+	if ((int)threadIdx.x >= ppw) return;
+	const int t = blockIdx.x * ppw + threadIdx.x;
 	if (t >= ntasks) return;
 	const uint32_t pi = order[t];
 	const K2aPair pr = pairs[pi];
@@ -763,8 +772,9 @@ int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_
 {
 	if (ntasks <= 0) return 0;
 	if (cfg < 0 || cfg >= K2A_NCFG) { snprintf(g_err, sizeof(g_err), "bad kernel class"); return -1; }
-	hipLaunchKernelGGL(g_trace[cfg][dual ? 1 : 0], dim3((ntasks + K2A_TRACE_PPW - 1) / K2A_TRACE_PPW), dim3(64), 0, (hipStream_t)stream,
-	                   pairs, order, ntasks, tb, res, cig);
+	const int ppw = k2a_trace_ppw(ntasks);
+	hipLaunchKernelGGL(g_trace[cfg][dual ? 1 : 0], dim3((ntasks + ppw - 1) / ppw), dim3(64), 0, (hipStream_t)stream,
+	                   pairs, order, ntasks, tb, res, cig, ppw);
 	CHECK(hipGetLastError());
 	return 0;
 }
@@ -787,8 +797,9 @@ int k2a_shim_launch_trace_pk(int cfg, const K2aPair *pairs, const uint32_t *orde
 {
 	if (ntasks <= 0) return 0;
 	if (cfg < 0 || cfg >= K2A_NPKCFG) { snprintf(g_err, sizeof(g_err), "bad packed kernel class"); return -1; }
-	hipLaunchKernelGGL(g_trace_pk[cfg], dim3((2 * ntasks + K2A_TRACE_PPW - 1) / K2A_TRACE_PPW), dim3(64), 0, (hipStream_t)stream,
-	                   pairs, order2, ntasks, tb, res, cig);
+	const int ppw = k2a_trace_ppw(2 * ntasks);
+	hipLaunchKernelGGL(g_trace_pk[cfg], dim3((2 * ntasks + ppw - 1) / ppw), dim3(64), 0, (hipStream_t)stream,
+	                   pairs, order2, ntasks, tb, res, cig, ppw);
 	CHECK(hipGetLastError());
 	return 0;
 }
@@ -817,8 +828,9 @@ int k2a_shim_launch_exts_trace(const K2aSplice *sp, const K2aPair *pairs, const 
                                K2aResult *res, uint32_t *cig, void *stream)
 {
 	if (ntasks <= 0) return 0;
-	hipLaunchKernelGGL(k2a_exts_trace_kernel, dim3((ntasks + K2A_TRACE_PPW - 1) / K2A_TRACE_PPW), dim3(64), 0, (hipStream_t)stream,
-	                   *sp, pairs, order, ntasks, tb, res, cig);
+	const int ppw = k2a_trace_ppw(ntasks);
+	hipLaunchKernelGGL(k2a_exts_trace_kernel, dim3((ntasks + ppw - 1) / ppw), dim3(64), 0, (hipStream_t)stream,
+	                   *sp, pairs, order, ntasks, tb, res, cig, ppw);
 	CHECK(hipGetLastError());
 	return 0;
 }
