@@ -418,13 +418,19 @@ struct K2aWalk {
 		}
 	}
 
-	/* direction code of the current cell in the reference's byte layout (ksw2.h:125-128) */
-	K2A_FN uint32_t code() const
+	/* raw byte holding the code of the cell k diagonal moves ahead of the current one inside this strip (valid for k <= c) */
+	K2A_FN uint32_t raw(int k) const
 	{
-		if (LAYOUT == 2) return p[2 * c + half];
-		if (LAYOUT == 1) return p[c];
-		const uint32_t raw = (p[c >> 1] >> ((c & 1) * 4)) & 0xfu;
-		return (raw & 3u) | ((raw & 4u) << 1) | ((raw & 8u) << 1);
+		const uint8_t *pk = p - (size_t)k * WB;
+		const int ck = c - k;
+		return LAYOUT == 2 ? pk[2 * ck + half] : LAYOUT == 1 ? pk[ck] : pk[ck >> 1];
+	}
+	/* direction code in the reference's byte layout (ksw2.h:125-128) from that byte; ck = row of the cell in the strip */
+	K2A_FN uint32_t decode(uint32_t b, int ck) const
+	{
+		if (LAYOUT != 0) return b;
+		const uint32_t r4 = (b >> ((ck & 1) * 4)) & 0xfu;
+		return (r4 & 3u) | ((r4 & 4u) << 1) | ((r4 & 8u) << 1);
 	}
 };
 
@@ -437,18 +443,31 @@ K2A_FN int k2a_trace_walk(const uint8_t *tb, int half, int i, int j, uint32_t *o
 	uint32_t last_op = 0xffffffffu, run = 0;
 	W.init(tb, qlen, tlen, w, half);
 	if (i >= 0 && j >= 0) W.locate(i, j);
+	/* The walk is a chain of dependent loads, and most moves are diagonal: the bytes of the next AHEAD cells on the diagonal
+	 * (clamped to the part that stays inside the strip and the matrix, so every load is valid and none is conditional) are
+	 * requested together and consumed while the path really is diagonal; the first gap move throws the rest away. */
+	enum { AHEAD = 8 };
 	while (i >= 0 && j >= 0) {
-		const uint32_t d = W.code();
-		if (state == 0) state = d & 7;
-		else if (!((d >> (state + 2)) & 1)) state = 0;
-		if (state == 0) state = d & 7;
-		uint32_t op;
-		if (state == 0) { op = 0; --i; --j; --W.c; W.p -= W.WB; }                  /* M: previous row, previous lane-step */
-		else if (state == 1 || state == 3) { op = 2; --i; --W.c; }                 /* D: previous row, same lane-step */
-		else { op = 1; --j; W.p -= W.WB; }                                         /* I: same row, previous lane-step */
+		const int nq = k2a_min(k2a_min(AHEAD, W.c + 1), k2a_min(i, j) + 1);
+		uint32_t bq[AHEAD];
+#pragma unroll
+		for (int k = 0; k < AHEAD; ++k) bq[k] = W.raw(k2a_min(k, nq - 1));
+		bool diagonal = true;
+#pragma unroll
+		for (int k = 0; k < AHEAD; ++k) {
+			if (k >= nq || !diagonal) break;
+			const uint32_t d = W.decode(bq[k], W.c);
+			if (state == 0) state = d & 7;
+			else if (!((d >> (state + 2)) & 1)) state = 0;
+			if (state == 0) state = d & 7;
+			uint32_t op;
+			if (state == 0) { op = 0; --i; --j; --W.c; W.p -= W.WB; }              /* M: previous row, previous lane-step */
+			else if (state == 1 || state == 3) { op = 2; --i; --W.c; diagonal = false; }   /* D: previous row, same lane-step */
+			else { op = 1; --j; W.p -= W.WB; diagonal = false; }                   /* I: same row, previous lane-step */
+			if (op == last_op) ++run;
+			else { if (run) out[n++] = run << 4 | last_op; last_op = op; run = 1; }
+		}
 		if (W.c < 0 && i >= 0 && j >= 0) W.locate(i, j);                           /* crossed into the strip above */
-		if (op == last_op) ++run;
-		else { if (run) out[n++] = run << 4 | last_op; last_op = op; run = 1; }
 	}
 	if (i >= 0) {                                     /* leading deletion */
 		if (last_op == 2) run += i + 1;
