@@ -258,9 +258,10 @@ def main():
                          "ops_per_cell": ops, "kernel_ms": round(kern_ms, 4), "fill_kernel_ms": round(fill_only_ms, 4),
                          "kernel_gcups": round(cells / (kern_ms * 1e-3) / 1e9, 2),
                          "algorithmic_bytes": alg_bytes, "hbm_algorithmic_GBps": round(alg_bytes / (kern_ms * 1e-3) / 1e9, 2), "hbm_peak_GBps": HBM_PEAK / 1e9,
-                         "note": "integer-VALU bound (no dense contraction, SURVEY 8d); peak = packed-int16 rate 256CU x 4SIMD x 32 lanes x 2.4GHz x 2; "
-                                 "measured issue rate of integer VALU ops (incl. v_pk_*_i16) on gfx950 is one wave64 instruction per 4 cycles per SIMD "
-                                 "(SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles, profiles/), i.e. 39.3 T lane-instr/s, which this kernel saturates"},
+                         "note": "integer-VALU bound (no dense contraction, SURVEY 8d); peak = the guide's vector peak 256CU x 4SIMD x 32 lanes x 2.4GHz x 2 "
+                                 "(packed int16); measured with tools/probe/valu_rate.hip (profiles/r1d_valu_rate.txt): v_pk_*_i16, v_max_i32, v_bfi issue one "
+                                 "wave64 instruction per 4 cycles per SIMD (add/sub/xor/bitop3: 2), so the attainable rate for this recurrence is 39.3 T "
+                                 "lane-instr/s; the fill kernels run at 4.35-4.45 cycles per instruction"},
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(wl, q, t, mat, seconds=args.cpu_seconds)
