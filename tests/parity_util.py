@@ -35,3 +35,24 @@ def check_batch(lib, dual, qs, ts, mat, q, e, q2, e2, w=-1, zdrop=-1, end_bonus=
         assert not d, ("pair %d dual=%s w=%d zdrop=%d flag=%d qlen=%d tlen=%d" % (i, dual, w[i], zdrop[i], flag[i], len(qs[i]), len(ts[i])),
                        {k: (exp[k], res[i][k]) for k in d if k != "cigar"})
     return len(list(idx)), res
+
+
+def cigar_score(cigar, q, t, mat, m, gq, ge, gq2=None, ge2=None):
+    """Score of a CIGAR (M/I/D runs, start of both sequences) under the (two-piece) affine model; returns (score, qlen used, tlen used)."""
+    x = y = 0
+    sc = 0
+    mat = np.asarray(mat, dtype=np.int64).reshape(m, m)
+    for c in cigar:
+        op, ln = c & 0xf, c >> 4
+        if op == 0:
+            sc += int(mat[t[x:x + ln], q[y:y + ln]].sum())
+            x += ln
+            y += ln
+        else:
+            cost = gq + ln * ge if gq2 is None else min(gq + ln * ge, gq2 + ln * ge2)
+            sc -= cost
+            if op == 2:
+                x += ln
+            else:
+                y += ln
+    return sc, y, x

@@ -8,7 +8,7 @@ import ksw2_amd as ka
 from ksw2_amd import synth
 from oracle import pyoracle as po
 from tests import golden_util as gu
-from tests.parity_util import check_batch, diff, CMP_FIELDS
+from tests.parity_util import check_batch, cigar_score, diff, CMP_FIELDS
 
 pytestmark = pytest.mark.gpu
 
@@ -124,6 +124,52 @@ def test_cfg3_shape_subset(lib):
     k, res = check_batch(lib, True, q, t, mat, 4, 2, 24, 1, w=256, zdrop=400, flag=0)
     assert k == n
     assert sum(r["zdropped"] for r in res) > 0          # the Z-drop path is exercised
+
+
+def test_cfg2_full_size_properties(lib, monkeypatch):
+    """BASELINE config 2 at its full size (65 536 pairs) through properties that do not need the oracle on every pair:
+    the packed-int16 and the int32 kernels agree on every field of every pair, results do not depend on the position of a
+    pair in the batch (reversed batch), and every 64th pair equals the oracle."""
+    n = 65536
+    q, t = synth.fixed_batch(2, n, 512, 512, sub=0.05, ind=0.06)
+    mat = synth.simple_mat(5, 2, 4, -1)
+    b = lib.make_batch(q, t, mat, 4, 2, 24, 1, w=64, zdrop=-1, flag=po.SCORE_ONLY)
+    p = b.plan(False); assert p.packed_pairs() == n; p.run(); r1 = p.fetch_raw().copy(); p.close()
+    b2 = lib.make_batch(q[::-1], t[::-1], mat, 4, 2, 24, 1, w=64, zdrop=-1, flag=po.SCORE_ONLY)
+    p = b2.plan(False); p.run(); r2 = p.fetch_raw().copy(); p.close()
+    assert (r2[::-1] == r1).all()
+    monkeypatch.setenv("KSW2AMD_NO_PK", "1")
+    p = b.plan(False); assert p.packed_pairs() == 0; p.run(); r0 = p.fetch_raw().copy(); p.close()
+    assert (r0 == r1).all()
+    for i in range(0, n, 64):
+        exp = po.align("oracle", "extz2", q[i], t[i], mat, 4, 2, w=64, zdrop=-1, flag=po.SCORE_ONLY)
+        assert (exp["score"], exp["max"], exp["max_t"], exp["max_q"], exp["mqe"], exp["mte"]) == (r1[i][8], r1[i][0], r1[i][3], r1[i][2], r1[i][4], r1[i][6])
+
+
+def test_cfg3_full_size_properties(lib, monkeypatch):
+    """BASELINE config 3 at its full size (16 384 pairs, extd2, Z-drop, CIGAR): packed and int32 kernels agree on every pair
+    (fields and CIGARs), every CIGAR spans exactly the aligned prefixes and re-scores to the reported score / maximum, Z-drop
+    fires on the pairs with a random tail, and every 64th pair equals the oracle."""
+    n = 16384
+    q, t = synth.fixed_batch(3, n, 2048, 2048, sub=0.05, ind=0.10, tail_random_frac=0.25, tail_pairs=0.10)
+    mat = synth.simple_mat(5, 2, 4, -1)
+    res = lib.extd_batch(q, t, mat, 4, 2, 24, 1, w=256, zdrop=400, flag=0)
+    monkeypatch.setenv("KSW2AMD_NO_PK", "1")
+    res0 = lib.extd_batch(q, t, mat, 4, 2, 24, 1, w=256, zdrop=400, flag=0)
+    ndrop = 0
+    for i in range(n):
+        r = res[i]
+        assert r == res0[i], i
+        sc, ql, tl = cigar_score(r["cigar"], q[i], t[i], mat, 5, 4, 2, 24, 1)
+        if r["zdropped"]:
+            ndrop += 1
+            assert (ql, tl) == (r["max_q"] + 1, r["max_t"] + 1) and sc == r["max"], i
+        else:
+            assert (ql, tl) == (2048, 2048) and sc == r["score"], i
+    assert 100 < ndrop < 0.2 * n, ndrop          # the pairs with a random tail: Z-drop fires on a few hundred of them
+    for i in range(0, n, 64):
+        exp = po.align("oracle", "extd2", q[i], t[i], mat, 4, 2, 24, 1, w=256, zdrop=400, flag=0)
+        assert not diff(exp, res[i], CMP_FIELDS), i
 
 
 def test_10k_banded(lib):
