@@ -181,6 +181,20 @@ def test_10k_banded(lib):
     check_batch(lib, False, q, t, mat, 4, 2, 0, 0, w=500, zdrop=400, flag=0)
 
 
+def test_very_long_reads(lib):
+    """Sizes beyond the packed kernels' 16-bit column index (32 000): 150 k x 150 k banded through the int32 resident class, and
+    25 k x 25 k unbanded through the generation-serial class; score-only and CIGAR."""
+    mat = synth.simple_mat(5, 2, 4, -1)
+    q, t = synth.fixed_batch(9, 2, 150000, 150000, sub=0.04, ind=0.05)
+    p = lib.make_batch(q, t, mat, 4, 2, 24, 1, w=500, zdrop=400, flag=po.SCORE_ONLY).plan(False)
+    assert p.packed_pairs() == 0
+    p.close()
+    check_batch(lib, False, q, t, mat, 4, 2, 0, 0, w=500, zdrop=400, flag=po.SCORE_ONLY)
+    check_batch(lib, True, q, t, mat, 4, 2, 24, 1, w=500, zdrop=400, flag=0)
+    q, t = synth.fixed_batch(10, 1, 25000, 25300, sub=0.04, ind=0.05)
+    check_batch(lib, False, q, t, mat, 4, 2, 0, 0, w=-1, zdrop=-1, flag=po.RIGHT)
+
+
 def test_edge_cases(lib):
     mat = synth.simple_mat(5, 2, 4, -1)
     one = np.array([1], dtype=np.uint8)
