@@ -32,8 +32,8 @@ extern "C" {
 #define KSW_EZ_SCORE_ONLY  0x01                   /* (ksw2.h:8)  no CIGAR */
 #define KSW_EZ_RIGHT       0x02                   /* (ksw2.h:9)  right-align gaps */
 #define KSW_EZ_GENERIC_SC  0x04                   /* (ksw2.h:10) use mat[] for every residue pair */
-#define KSW_EZ_APPROX_MAX  0x08                   /* (ksw2.h:11) accepted; computed exactly */
-#define KSW_EZ_APPROX_DROP 0x10                   /* (ksw2.h:12) accepted; computed exactly */
+#define KSW_EZ_APPROX_MAX  0x08                   /* (ksw2.h:11) alone: like the reference only score + corner CIGAR are returned */
+#define KSW_EZ_APPROX_DROP 0x10                   /* (ksw2.h:12) with APPROX_MAX: computed exactly (the reference's drop heuristic is band-padding dependent) */
 #define KSW_EZ_EXTZ_ONLY   0x40                   /* (ksw2.h:13) extension only */
 #define KSW_EZ_REV_CIGAR   0x80                   /* (ksw2.h:14) CIGAR in end->start order */
 #define KSW_EZ_SPLICE_FOR   0x100                  /* (ksw2.h:15) exts2: GT..AG signals (forward transcript strand) */

@@ -140,6 +140,16 @@ static void ez_reserve(void *km, ksw_extz_t *ez, int n)   /* capacity sequence o
 	ez->m_cigar = m;
 }
 
+/* KSW_EZ_APPROX_MAX without KSW_EZ_APPROX_DROP on the "...2_sse" entry points: the reference then tracks one cell per
+ * diagonal only to deliver the final score (ksw2_extz2_sse.c:270-286, ksw2_extd2_sse.c:366-382, ksw2_exts2_sse.c:386-404) -- no
+ * max / mqe / mte, no Z-drop -- and returns { score, CIGAR from the corner unless EXTZ_ONLY }, everything else left reset.
+ * Reproduced as such; with APPROX_DROP the reference's drop heuristic depends on its padded band and the exact
+ * computation is returned instead. */
+static int is_approx(int flag)
+{
+	return !(flag & F_SCALAR_CONTRACT) && (flag & KSW_EZ_APPROX_MAX) && !(flag & KSW_EZ_APPROX_DROP);
+}
+
 /* ---------------------------------------------------------------- plan */
 
 typedef struct {
@@ -418,8 +428,12 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 		d->zdrop = a->zdrop;
 		d->end_bonus = (a->flag & F_SCALAR_CONTRACT) ? K2A_NEG : a->end_bonus;
 		d->flag = a->flag & (KSW_EZ_EXTZ_ONLY | KSW_EZ_REV_CIGAR | KSW_EZ_SCORE_ONLY);
+		if (is_approx(a->flag)) {                              /* only the score and the corner CIGAR exist in this mode */
+			d->zdrop = -1;
+			if (a->flag & KSW_EZ_EXTZ_ONLY) d->flag |= KSW_EZ_SCORE_ONLY;
+		}
 		for (cfg = 0; cfg < K2A_NCFG; ++cfg) if (cfg_fits(cfg, d->tlen, w)) break;
-		mode = (a->flag & KSW_EZ_SCORE_ONLY) ? K2A_MODE_SCORE : (a->flag & KSW_EZ_RIGHT) ? K2A_MODE_RIGHT : K2A_MODE_LEFT;
+		mode = (d->flag & KSW_EZ_SCORE_ONLY) ? K2A_MODE_SCORE : (a->flag & KSW_EZ_RIGHT) ? K2A_MODE_RIGHT : K2A_MODE_LEFT;
 		generic = (a->flag & (KSW_EZ_GENERIC_SC | F_SCALAR_CONTRACT)) ? 1 : 0;
 		ci = (cfg * 3 + mode) * 2 + generic;
 		p->h_cls[i] = (int8_t)ci;
@@ -726,6 +740,10 @@ int ksw2amd_plan_fetch(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez)
 		z->max = (uint32_t)r->max; z->zdropped = (uint32_t)r->zdropped;
 		z->max_q = r->max_q; z->max_t = r->max_t; z->mqe = r->mqe; z->mqe_t = r->mqe_t;
 		z->mte = r->mte; z->mte_q = r->mte_q; z->score = r->score; z->reach_end = r->reach_end;
+		if (is_approx(p->h_flag[i])) {
+			z->max = 0; z->max_q = z->max_t = z->mqe_t = z->mte_q = -1; z->mqe = z->mte = KSW_NEG_INF; z->reach_end = 0;
+			if (r->zdropped || (p->h_flag[i] & KSW_EZ_EXTZ_ONLY)) continue;    /* no start cell without a maximum */
+		}
 		if (r->n_cigar > 0) {
 			const uint32_t *src = pool + pos[i];
 			int k, nc = r->n_cigar;
@@ -985,6 +1003,7 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 		if (a->qlen <= 0 || a->tlen <= 0) continue;
 		if (!a->query || !a->target) { fail(KSW2AMD_E_PARAM, "exts: NULL sequence%s", 0); goto err; }
 		mode = (a->flag & KSW_EZ_SCORE_ONLY) ? K2A_MODE_SCORE : (a->flag & KSW_EZ_RIGHT) ? K2A_MODE_RIGHT : K2A_MODE_LEFT;
+		if (is_approx(a->flag) && (a->flag & KSW_EZ_EXTZ_ONLY)) mode = K2A_MODE_SCORE;      /* no start cell in that mode: no CIGAR */
 		generic = (a->flag & KSW_EZ_GENERIC_SC) ? 1 : 0;
 		/* register windows where they are the faster kernel (tools/scripts/exts_classes.py): 8 slots always, 16 slots without
 		 * traceback (with it that kernel is down to one wavefront per SIMD) */
@@ -1003,6 +1022,10 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 		d->w = imax(a->qlen, a->tlen);                 /* no band: k2a_finish must never see an unreachable corner */
 		d->zdrop = a->zdrop; d->end_bonus = K2A_NEG;   /* no end bonus in this function */
 		d->flag = a->flag & (KSW_EZ_EXTZ_ONLY | KSW_EZ_REV_CIGAR | KSW_EZ_SCORE_ONLY);
+		if (is_approx(a->flag)) {
+			d->zdrop = -1;
+			if (a->flag & KSW_EZ_EXTZ_ONLY) d->flag |= KSW_EZ_SCORE_ONLY;
+		}
 		off = align_up(off, 4); d->qoff = (uint32_t)off; off += (size_t)a->qlen;
 		off = align_up(off, 4); d->bnd_off = (uint32_t)(off / 4); off += 4 * (size_t)a->tlen;
 		if (off > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "exts: more than 4 GiB of sequence in one plan%s", 0); goto err; }

@@ -259,8 +259,14 @@ static void run_ext(contract_t ct, int qlen, const uint8_t *query, int tlen, con
 	fill_t F;
 	cig_t c;
 	int8_t *eff = 0;
+	/* KSW_EZ_APPROX_MAX without KSW_EZ_APPROX_DROP (ksw2_extz2_sse.c:270-286, ksw2_extd2_sse.c:366-382): the SSE kernels then
+	 * track one cell per diagonal only to deliver the final score -- no max / mqe / mte, no Z-drop at all -- so the result is
+	 * { score, CIGAR from the corner unless EXTZ_ONLY } with every other field left reset.  (With APPROX_DROP the reference's
+	 * heuristic drop test depends on its padded band; that mode is computed exactly here.) */
+	const int approx = ct == CONTRACT_SSE_SIG && (flag & KSO_APPROX_MAX) && !(flag & KSO_APPROX_DROP);
 
 	ez_reset(ez);
+	if (approx) zdrop = -1;
 	if (ct == CONTRACT_SSE_SIG) {
 		int k, lo;
 		/* ksw2_extz2_sse.c:57, ksw2_extd2_sse.c:76 */
@@ -296,6 +302,9 @@ static void run_ext(contract_t ct, int qlen, const uint8_t *query, int tlen, con
 	 * with zdropped=1 when a diagonal has no in-band cell (ksw2_extz2_sse.c:111-114).  The scalar
 	 * reference is undefined there, so this is outside the scalar parity contract. */
 	if (!ez->zdropped && (F.band_empty || (tlen - 1) + w < qlen - 1)) ez->zdropped = 1;
+	if (approx) {
+		ez->max = 0; ez->max_t = ez->max_q = ez->mqe_t = ez->mte_q = -1; ez->mqe = ez->mte = NEG;
+	}
 
 	if (J.want_tb) {
 		int rev = !!(flag & KSO_REV_CIGAR), si = -1, sj = -1;

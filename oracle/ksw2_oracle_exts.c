@@ -130,6 +130,8 @@ void kso_exts2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, 
                kso_extz_t *ez)
 {
 	const int with_cigar = !(flag & KSO_SCORE_ONLY), right = !!(flag & KSO_RIGHT);
+	/* approximate-max mode without APPROX_DROP (ksw2_exts2_sse.c:386-404): only the final score is tracked */
+	const int approx = (flag & KSO_APPROX_MAX) && !(flag & KSO_APPROX_DROP);
 	int i, j, r, k, min_sc, long_thres, scN;
 	int32_t *H, *En, *E2n, *Hd;
 	uint8_t *dir = 0;
@@ -193,8 +195,9 @@ void kso_exts2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, 
 	}
 #undef HB
 
-	/* bookkeeping per anti-diagonal (exact-max mode; KSO_APPROX_* are accepted and computed exactly) */
-	for (r = 0; r < qlen + tlen - 1; ++r) {
+	/* bookkeeping per anti-diagonal (exact-max mode; APPROX_MAX | APPROX_DROP is computed exactly as well) */
+	if (approx) ez->score = H[(size_t)(tlen - 1) * qlen + qlen - 1];
+	for (r = 0; !approx && r < qlen + tlen - 1; ++r) {
 		int st0 = 0, en0 = tlen - 1, t, max_t;
 		int32_t max_H;
 		if (st0 < r - qlen + 1) st0 = r - qlen + 1;

@@ -518,3 +518,11 @@ def test_splice_aware_random_and_long(lib):
         big_t.append(t)
     check_exts_batch(lib, big_q, big_t, [None] * 3, mat, 2, 1, 32, 4, 0, np.array([po.SPLICE_FOR, po.SPLICE_FOR | po.RIGHT, po.SCORE_ONLY]),
                      np.array([-1, 500, 200]))
+
+
+def test_approx_max_mode_golden(lib):
+    """KSW_EZ_APPROX_MAX alone on the three "...2_sse" functions: outputs of the compiled reference."""
+    ac = gu.ApproxCases()
+    for k in range(ac.n):
+        c = ac.case(k)
+        assert not diff(c["expect"], gu.ApproxCases.run(lib, c), gu.FIELDS + ["cigar"]), (k, c["func"], hex(c["flag"]))

@@ -123,3 +123,14 @@ def test_band_cells():
     assert po.band_cells(2048, 2048, 256) == 984832
     assert po.band_cells(10000, 10000, 500) == 9759500
     assert po.band_cells(16499, 16569, -1) == 16499 * 16569
+
+
+def test_approx_max_mode_matches_reference_golden():
+    """KSW_EZ_APPROX_MAX alone: the reference returns only the score and the corner CIGAR (tests/golden/approx_cases.npz)."""
+    ac = gu.ApproxCases()
+    assert ac.n >= 400
+    for k in range(ac.n):
+        c = ac.case(k)
+        r = gu.ApproxCases.run("oracle", c)
+        for f in gu.FIELDS + ["cigar"]:
+            assert r[f] == c["expect"][f], (k, c["func"], hex(c["flag"]), f, r[f], c["expect"][f])

@@ -336,3 +336,10 @@ def test_sim_splice_aware_golden_subset(sim, big, monkeypatch):
         res = sim.exts2(c["q"], c["t"], c["mat"], c["gq"], c["ge"], c["gq2"], c["noncan"], zdrop=c["zdrop"], junc_bonus=c["junc_bonus"],
                         flag=c["flag"], junc=c["junc"])
         assert not diff(c["expect"], res, gu.FIELDS + ["cigar"]), (k, hex(c["flag"]))
+
+
+def test_sim_approx_max_mode(sim):
+    ac = gu.ApproxCases()
+    for k in range(0, ac.n, 2):
+        c = ac.case(k)
+        assert not diff(c["expect"], gu.ApproxCases.run(sim, c), gu.FIELDS + ["cigar"]), (k, c["func"], hex(c["flag"]))
