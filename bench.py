@@ -162,6 +162,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=0, help="override pairs per GPU (parity/debug only)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--approx", action="store_true", help="OR KSW_EZ_APPROX_MAX into the flags (score + corner CIGAR only, as in the reference)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -186,6 +187,8 @@ def main():
     lib = ksw2_amd.library()
     lib.set_device(dev)
     wl = WORKLOADS[args.workload]
+    if args.approx:
+        wl = dict(wl, flag=wl["flag"] | 0x08)
     S = SCORING
     q, t = make_batch(wl, rank, args.pairs or None)
     n = len(q)
@@ -252,7 +255,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "%s: %d pairs/GPU, qlen=%d tlen=%d band=%d zdrop=%d %s %s" % (
                 args.workload, n, wl["qlen"], wl["tlen"], wl["w"], wl["zdrop"], func,
-                "score-only" if score_only else "CIGAR"), "cells_per_gpu": cells, "parallelism": "pairs sharded over %d GPU(s), no collective" % world},
+                ("score-only" if score_only else "CIGAR") + (" APPROX_MAX" if args.approx else "")), "cells_per_gpu": cells, "parallelism": "pairs sharded over %d GPU(s), no collective" % world},
             "roofline": {"bound": "valu", "achieved": round(achieved / 1e12, 4), "peak": VALU_PEAK_PK16 / 1e12, "unit": "Tiop/s",
                          "frac": round(achieved / VALU_PEAK_PK16, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "ops_per_cell": ops, "kernel_ms": round(kern_ms, 4), "fill_kernel_ms": round(fill_only_ms, 4),

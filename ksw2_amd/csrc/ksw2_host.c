@@ -19,7 +19,7 @@
 
 #define F_SCALAR_CONTRACT 0x40000000   /* internal: call came through ksw_extz / ksw_extd / ksw_gg* */
 #define NCLS_MAX (K2A_NCFG * 3 * 2)
-#define NPASS (1 + 2 * K2A_NPKCFG)     /* per class: one alignment per lane group | packed class pc | re-based packed class pc */
+#define NPASS (1 + 4 * K2A_NPKCFG)     /* per class: one alignment per lane group | packed class pc (x re-based) (x no maximum tracking) */
 #define NCLS_ENTRIES (NCLS_MAX * NPASS)
 
 static __thread char g_err[512];
@@ -153,7 +153,8 @@ static int is_approx(int flag)
 /* ---------------------------------------------------------------- plan */
 
 typedef struct {
-	int cfg, mode, generic, pk, rb, first, count;   /* pk: packed-int16 tasks, two h_order entries per task; rb: per-strip bases */
+	int cfg, mode, generic, pk, rb, nomax, first, count;   /* pk: packed-int16 tasks, two h_order entries per task; rb: per-strip bases;
+	                                                        * nomax: KSW_EZ_APPROX_MAX launches without row maxima */
 	K2aScoring sc;
 } cls_t;
 
@@ -448,7 +449,7 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 			for (pc = (mode == K2A_MODE_SCORE ? 0 : 1); pc < K2A_NPKCFG; ++pc)
 				if (geom_fits(k2a_pkcfg_G[pc], k2a_pkcfg_C[pc], d->tlen, w) &&
 				    (plain || (use_rb && pk_window_ok(&pkinfo[generic], a->qlen, d->tlen, w, k2a_pkcfg_C[pc])))) break;
-			if (pc < K2A_NPKCFG) pk_ok[i] = (uint8_t)(1 + pc + (plain ? 0 : K2A_NPKCFG));
+			if (pc < K2A_NPKCFG) pk_ok[i] = (uint8_t)(1 + pc + (plain ? 0 : K2A_NPKCFG) + (is_approx(a->flag) ? 2 * K2A_NPKCFG : 0));
 		}
 		if (cfg == K2A_CFG_MP) {                              /* boundary rows H, E, E~ between generations */
 			d->bnd_off = (uint32_t)p->bnd_words;
@@ -518,7 +519,7 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 			ci = b / NPASS;
 			qsort(g, (size_t)cnt, sizeof(sort_t), cmp_cost_desc);
 			c = &p->cls[p->ncls++];
-			c->cfg = pass ? (pass - 1) % K2A_NPKCFG : ci / 6; c->rb = pass > K2A_NPKCFG; c->mode = (ci / 2) % 3; c->generic = ci & 1; c->pk = pass != 0; c->first = k;
+			c->cfg = pass ? (pass - 1) % K2A_NPKCFG : ci / 6; c->rb = pass ? ((pass - 1) / K2A_NPKCFG) & 1 : 0; c->nomax = pass > 2 * K2A_NPKCFG; c->mode = (ci / 2) % 3; c->generic = ci & 1; c->pk = pass != 0; c->first = k;
 			build_scoring(dual, m, sc->mat, q, e, q2, e2, c->generic, &c->sc);
 			c->sc.pk_a = pkinfo[c->generic].a; c->sc.pk_b = pkinfo[c->generic].b; c->sc.pk_n = pkinfo[c->generic].n;
 			if (!pass) {
@@ -605,7 +606,7 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 	for (c = 0; c < p->ncls; ++c) {
 		const cls_t *k = &p->cls[c];
 		if (k->pk) {
-			if (k2a_shim_launch_fill_pk(k->cfg, p->dual, k->mode, k->rb, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
+			if (k2a_shim_launch_fill_pk(k->cfg, p->dual, k->mode, k->rb, k->nomax, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
 			                            p->d_res, stream)) goto err;
 		} else if (k2a_shim_launch_fill(k->cfg, p->dual, k->mode, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
 		                                p->d_bnd, p->d_res, stream)) goto err;

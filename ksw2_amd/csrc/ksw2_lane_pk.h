@@ -129,7 +129,9 @@ K2A_FN uint32_t k2a_pack_dirs(k2a_pk d0, k2a_pk d1)
 /* packed traceback: one byte per cell and alignment in the reference's own layout (ksw2.h:125-128): bits 0-2 winner
  * {0 diag, 1 E, 2 F, 3 E~, 4 F~}, 0x08/0x10/0x20/0x40 = the E/F/E~/F~ gap leaving the cell is an extension.
  * A lane-step word holds C cells x 2 alignments: byte 2c = alignment A, byte 2c+1 = alignment B. */
-template<int G, int C, bool DUAL, int MODE = K2A_MODE_SCORE, bool RB = false>
+/* NOMAX: KSW_EZ_APPROX_MAX launches (ksw2_host.c::is_approx) need the final score and the direction bytes only: no row
+ * maximum, no arg-max, no Z-drop -- four instructions per row and two registers per row less. */
+template<int G, int C, bool DUAL, int MODE = K2A_MODE_SCORE, bool RB = false, bool NOMAX = false>
 struct K2aLanePk {
 	enum { TBWORDS = C / 2 };
 	/* group-uniform (both alignments share the shape) */
@@ -146,7 +148,7 @@ struct K2aLanePk {
 	/* rows */
 	/* target codes as bit planes x D: one register more per row, so only where the kernel keeps its occupancy */
 	enum { PLANES = MODE == K2A_MODE_SCORE && (!DUAL || C <= 16) };
-	k2a_pk hl[C], f[C], f2[DUAL ? C : 1], rmax[C], rmj[C];       /* hl, f, f2, rmax and the ports above: offset form */
+	k2a_pk hl[C], f[C], f2[DUAL ? C : 1], rmax[NOMAX ? 1 : C], rmj[NOMAX ? 1 : C];       /* hl, f, f2, rmax and the ports above: offset form */
 	k2a_pk tc[C], tc1[PLANES ? C : 1];                           /* target codes {A, B}; PLANES: bit 0 / bit 1 of the codes, times D */
 
 	K2A_FN static int first_col(int S_, int w_) { return k2a_max(0, S_ * C - w_); }
@@ -171,7 +173,8 @@ struct K2aLanePk {
 		baseA = baseB = 0; delta = 0;
 		local_reset();
 #pragma unroll
-		for (int c = 0; c < C; ++c) { hl[c] = f[c] = rmax[c] = neg; rmj[c] = 0; tc[c] = 0; if (PLANES) tc1[c] = 0; if (DUAL) f2[c] = neg; }
+		for (int c = 0; c < C; ++c) { hl[c] = f[c] = neg; tc[c] = 0; if (!NOMAX) { rmax[c] = neg; rmj[c] = 0; } if (PLANES) tc1[c] = 0; if (DUAL) f2[c] = neg; }
+		if (NOMAX) { rmax[0] = neg; rmj[0] = 0; }
 		if (!DUAL) f2[0] = 0;
 		if (!PLANES) tc1[0] = 0;
 	}
@@ -211,7 +214,7 @@ struct K2aLanePk {
 #pragma unroll
 		for (int c = 0; c < C; ++c) {
 			hl[c] = neg; f[c] = neg; if (DUAL) f2[c] = neg;
-			rmax[c] = neg; rmj[c] = 0;
+			if (!NOMAX) { rmax[c] = neg; rmj[c] = 0; }
 		}
 		const int hcorner = k2a_border<DUAL>(sc, i0) + sc.e * (i0 - 1);   /* H(i0-1,-1), carrying the bias of row i0-1 */
 		if (RB) {
@@ -312,9 +315,11 @@ struct K2aLanePk {
 			h = k2a_pk_sel(k2a_bit_mask(live, c), h, neg);
 			/* running row maximum: ties to the last column (keep the old arg-max only where h < max), except
 			 * extz + RIGHT + CIGAR where the first column wins (take the new one only where max < h); SURVEY 8a rule 3 */
-			if (!DUAL && MODE == K2A_MODE_RIGHT) rmj[c] = k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(rmax[c], h)), jjpk, rmj[c]);
-			else rmj[c] = k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(h, rmax[c])), rmj[c], jjpk);
-			rmax[c] = k2a_pk_maxu(rmax[c], h);
+			if (!NOMAX) {
+				if (!DUAL && MODE == K2A_MODE_RIGHT) rmj[c] = k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(rmax[c], h)), jjpk, rmj[c]);
+				else rmj[c] = k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(h, rmax[c])), rmj[c], jjpk);
+				rmax[c] = k2a_pk_maxu(rmax[c], h);
+			}
 			/* gaps leaving the cell, all in row-biased form: opening = H' - q; the extension cost cancels against the bias
 			 * for E (next row), stays e for F (same row), becomes e2 - e for E~ and stays e2 for F~.  "extension beats
 			 * opening" (ksw2_extz.c:79-86 / 105-112) compares the gap state with the opening value directly. */
@@ -365,7 +370,7 @@ struct K2aLanePk {
 	K2A_FN void stage_rows(uint32_t *rowbuf) const
 	{
 #pragma unroll
-		for (int c = 0; c < C; ++c) { rowbuf[c] = hl[c] ^ K2A_OFS; rowbuf[C + c] = rmax[c] ^ K2A_OFS; rowbuf[2 * C + c] = rmj[c]; }   /* plain int16 halves */
+		for (int c = 0; c < C; ++c) { rowbuf[c] = hl[c] ^ K2A_OFS; rowbuf[C + c] = rmax[NOMAX ? 0 : c] ^ K2A_OFS; rowbuf[2 * C + c] = rmj[NOMAX ? 0 : c]; }   /* plain int16 halves */
 		rowbuf[3 * C] = (uint32_t)i0;
 		if (RB) { rowbuf[3 * C + 1] = (uint32_t)baseA; rowbuf[3 * C + 2] = (uint32_t)baseB; }
 	}
@@ -420,7 +425,7 @@ struct K2aLanePk {
 		/* rows compare without their bias: v_c = rmax[c] - e*c = H(row) + (e*i0 - base) */
 		k2a_pk m = rmax[0] ^ K2A_OFS, mn = m, arg = 0, argj = rmj[0];
 #pragma unroll
-		for (int c = 1; c < C; ++c) {
+		for (int c = 1; c < (NOMAX ? 1 : C); ++c) {
 			const k2a_pk v = k2a_pk_sub(rmax[c] ^ K2A_OFS, k2a_pk2(sc.e * c));
 			const k2a_pk gt = k2a_pk_sign(k2a_pk_sub(m, v));                        /* strictly larger: first row keeps a tie */
 			arg = k2a_pk_sel(gt, k2a_pk2(c), arg);
@@ -485,6 +490,21 @@ struct K2aLanePk {
 		}
 	}
 	K2A_FN void end_strip() { S = -1; je = -1; kfin = K2A_KNONE; rows_m1 = -1; }
+
+	/* NOMAX epilogue: the only thing a finished strip contributes is H(tlen-1, qlen-1), if it holds the last target row and
+	 * that row reaches the last column (ksw2_extz2_sse.c:284-285) */
+	K2A_FN void fin_score_only(const K2aScoring &sc, K2aBook *bA, K2aBook *bB)
+	{
+		const int last = tlen_full - 1;
+		if (tlen == tlen_full && last >= i0 && last < i0 + C && last + w >= qlen - 1) {
+			k2a_pk v = 0;
+#pragma unroll
+			for (int c = 0; c < C; ++c) if (i0 + c == last) v = hl[c] ^ K2A_OFS;
+			bA->score = k2a_pk_lo(v) + (RB ? baseA : 0) - sc.e * last;
+			bB->score = k2a_pk_hi(v) + (RB ? baseB : 0) - sc.e * last;
+		}
+		end_strip();
+	}
 };
 
 /* Traceback walk for one alignment (half = 0/1) of a packed task: direction bytes in the reference layout at byte

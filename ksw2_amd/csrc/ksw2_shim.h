@@ -64,8 +64,9 @@ int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_
  * for an unpaired leftover); both K2aPair entries point at the task's byte-interleaved sequences and, with
  * mode != SCORE, at the task's shared traceback block (2*C bytes per lane-step).  cfg indexes the k2a_pkcfg_* table.
  * rebased: per-strip score bases (reads of any length whose band window fits 16 bits).
+ * nomax: final score and direction bytes only (KSW_EZ_APPROX_MAX launches).
  * The packed trace kernel walks 2*ntasks alignments of such a launch. */
-int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2,
+int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2,
                             int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, void *stream);
 int k2a_shim_launch_trace_pk(int cfg, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb,
                              K2aResult *res, uint32_t *cig, void *stream);

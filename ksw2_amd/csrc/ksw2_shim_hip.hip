@@ -144,13 +144,13 @@ k2a_fill_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const ui
 }
 
 /* Packed-int16 resident fill: two same-shape alignments per lane group (ksw2_lane_pk.h). */
-template<int G, int C, bool DUAL, int MODE, bool RB>
+template<int G, int C, bool DUAL, int MODE, bool RB, bool NOMAX>
 __global__ void __launch_bounds__(64 * K2A_WPB)      /* no occupancy floor: capping at 168 VGPRs spills and is 18 % slower */
 k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
                    const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, K2aResult *__restrict__ res)
 {
 	constexpr int NG = 64 / G;
-	typedef K2aLanePk<G, C, DUAL, MODE, RB> Lane;
+	typedef K2aLanePk<G, C, DUAL, MODE, RB, NOMAX> Lane;
 	__shared__ K2aBook book[K2A_WPB][NG][2];
 	__shared__ uint32_t stage[K2A_WPB][(NG * K2A_PK_STAGE(C) > 64 * 5) ? NG * K2A_PK_STAGE(C) : 64 * 5];   /* row buffers / final lane records */
 
@@ -162,7 +162,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	const K2aPair prA = pairs[piA], prB = pairs[piB];
 	const int zdropA = prA.zdrop, zdropB = prB.zdrop;
 	/* a Z-drop test anywhere in the wavefront selects the sequential strip epilogue for all of it */
-	const bool zseq = RB || __builtin_amdgcn_ballot_w64(valid && (zdropA >= 0 || zdropB >= 0)) != 0;
+	const bool zseq = NOMAX || RB || __builtin_amdgcn_ballot_w64(valid && (zdropA >= 0 || zdropB >= 0)) != 0;   /* NOMAX: books only */
 
 	Lane L;
 	L.setup(prA, prB, seq, gl, valid);
@@ -216,7 +216,9 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 		const uint64_t finmask = __builtin_amdgcn_ballot_w64(nfin);
 		if (finmask != 0) {
 			uint32_t *rowbuf = &stage[wave][grp * K2A_PK_STAGE(C)];
-			if (zseq) {
+			if (NOMAX) {
+				if (nfin) L.fin_score_only(sc, bkA, bkB);
+			} else if (zseq) {
 				/* most strips fold into the books from registers; the rest take the row-by-row scan */
 				const bool slow = nfin && !L.fin_fast(sc, bkA, bkB, zdropA, zdropB);
 				if (__builtin_amdgcn_ballot_w64(slow) != 0) {
@@ -659,10 +661,11 @@ k2a_exts_trace_kernel(const K2aSplice sp, const K2aPair *__restrict__ pairs, con
 }
 
 typedef void (*fill_pk_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*);
-#define PK_ROW(G, C, RB) { { k2a_fill_pk_kernel<G, C, false, 0, RB>, k2a_fill_pk_kernel<G, C, false, 1, RB>, k2a_fill_pk_kernel<G, C, false, 2, RB> }, \
-                           { k2a_fill_pk_kernel<G, C, true, 0, RB>,  k2a_fill_pk_kernel<G, C, true, 1, RB>,  k2a_fill_pk_kernel<G, C, true, 2, RB> } }
-static const fill_pk_fn g_fill_pk[2][K2A_NPKCFG][2][3] = { { PK_ROW(8, 18, false), PK_ROW(16, 8, false), PK_ROW(64, 8, false), PK_ROW(64, 16, false) },
-                                                          { PK_ROW(8, 18, true),  PK_ROW(16, 8, true),  PK_ROW(64, 8, true),  PK_ROW(64, 16, true) } };
+#define PK_ROW(G, C, RB, NM) { { k2a_fill_pk_kernel<G, C, false, 0, RB, NM>, k2a_fill_pk_kernel<G, C, false, 1, RB, NM>, k2a_fill_pk_kernel<G, C, false, 2, RB, NM> }, \
+                               { k2a_fill_pk_kernel<G, C, true, 0, RB, NM>,  k2a_fill_pk_kernel<G, C, true, 1, RB, NM>,  k2a_fill_pk_kernel<G, C, true, 2, RB, NM> } }
+#define PK_SET(NM) { { PK_ROW(8, 18, false, NM), PK_ROW(16, 8, false, NM), PK_ROW(64, 8, false, NM), PK_ROW(64, 16, false, NM) }, \
+                     { PK_ROW(8, 18, true, NM),  PK_ROW(16, 8, true, NM),  PK_ROW(64, 8, true, NM),  PK_ROW(64, 16, true, NM) } }
+static const fill_pk_fn g_fill_pk[2][2][K2A_NPKCFG][2][3] = { PK_SET(false), PK_SET(true) };     /* [nomax][rebased][cfg][dual][mode] */
 static const trace_fn g_trace_pk[K2A_NPKCFG] = { k2a_trace_pk_kernel<8, 18>, k2a_trace_pk_kernel<16, 8>, k2a_trace_pk_kernel<64, 8>,
                                                  k2a_trace_pk_kernel<64, 16> };
 
@@ -779,14 +782,14 @@ int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_
 	return 0;
 }
 
-int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2,
+int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2,
                             int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, void *stream)
 {
 	if (ntasks <= 0) return 0;
 	if (cfg < 0 || cfg >= K2A_NPKCFG || mode < 0 || mode > 2) { snprintf(g_err, sizeof(g_err), "bad packed kernel class"); return -1; }
 	const int per_block = K2A_WPB * (64 / k2a_pkcfg_G[cfg]);
 	const int blocks = (ntasks + per_block - 1) / per_block;
-	hipLaunchKernelGGL(g_fill_pk[rebased ? 1 : 0][cfg][dual ? 1 : 0][mode], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
+	hipLaunchKernelGGL(g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
 	                   *sc, pairs, order2, ntasks, seq, tb, res);
 	CHECK(hipGetLastError());
 	return 0;

@@ -100,12 +100,12 @@ static void sim_fill(const K2aScoring sc, const K2aPair *pairs, const uint32_t *
 }
 
 /* mirrors k2a_fill_pk_kernel */
-template<int G, int C, bool DUAL, int MODE, bool RB>
+template<int G, int C, bool DUAL, int MODE, bool RB, bool NOMAX>
 static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *seq, uint8_t *tb,
                         K2aResult *res)
 {
 	constexpr int NG = 64 / G;
-	typedef K2aLanePk<G, C, DUAL, MODE, RB> Lane;
+	typedef K2aLanePk<G, C, DUAL, MODE, RB, NOMAX> Lane;
 	const int nwaves = (ntasks + NG - 1) / NG;
 	for (int wv = 0; wv < nwaves; ++wv) {
 		static Lane L[64];
@@ -113,7 +113,7 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 		K2aPair prA[64];
 		uint32_t piA[64], piB[64], stage[(NG * K2A_PK_STAGE(C) > 64 * 5) ? NG * K2A_PK_STAGE(C) : 64 * 5];
 		int zdA[64], zdB[64], klast[64], kmax = -1, ktop = -1;
-		bool valid[64], gdone[64], zseq = RB;
+		bool valid[64], gdone[64], zseq = RB || NOMAX;
 		for (int lane = 0; lane < 64; ++lane) {
 			const int grp = lane / G, gl = lane % G, task = wv * NG + grp;
 			valid[lane] = task < ntasks;
@@ -171,7 +171,8 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 					uint32_t *rowbuf = &stage[(lane / G) * K2A_PK_STAGE(C)];
 					assert(!gfin[lane / G]);                          /* one strip per group and step */
 					gfin[lane / G] = true;
-					if (zseq) {
+					if (NOMAX) L[lane].fin_score_only(sc, &book[lane / G][0], &book[lane / G][1]);
+					else if (zseq) {
 						if (!L[lane].fin_fast(sc, &book[lane / G][0], &book[lane / G][1], zdA[lane], zdB[lane])) {
 							L[lane].stage_rows(rowbuf);
 							L[lane].do_fin_seq(sc, &book[lane / G][0], &book[lane / G][1], zdA[lane], zdB[lane], rowbuf);
@@ -336,10 +337,11 @@ static void sim_trace_pk(const K2aPair *pairs, const uint32_t *order2, int ntask
 }
 
 typedef void (*fill_pk_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*);
-#define PK_ROW(G, C, RB) { { sim_fill_pk<G, C, false, 0, RB>, sim_fill_pk<G, C, false, 1, RB>, sim_fill_pk<G, C, false, 2, RB> }, \
-                           { sim_fill_pk<G, C, true, 0, RB>,  sim_fill_pk<G, C, true, 1, RB>,  sim_fill_pk<G, C, true, 2, RB> } }
-static const fill_pk_fn g_fill_pk[2][K2A_NPKCFG][2][3] = { { PK_ROW(8, 18, false), PK_ROW(16, 8, false), PK_ROW(64, 8, false), PK_ROW(64, 16, false) },
-                                                          { PK_ROW(8, 18, true),  PK_ROW(16, 8, true),  PK_ROW(64, 8, true),  PK_ROW(64, 16, true) } };
+#define PK_ROW(G, C, RB, NM) { { sim_fill_pk<G, C, false, 0, RB, NM>, sim_fill_pk<G, C, false, 1, RB, NM>, sim_fill_pk<G, C, false, 2, RB, NM> }, \
+                               { sim_fill_pk<G, C, true, 0, RB, NM>,  sim_fill_pk<G, C, true, 1, RB, NM>,  sim_fill_pk<G, C, true, 2, RB, NM> } }
+#define PK_SET(NM) { { PK_ROW(8, 18, false, NM), PK_ROW(16, 8, false, NM), PK_ROW(64, 8, false, NM), PK_ROW(64, 16, false, NM) }, \
+                     { PK_ROW(8, 18, true, NM),  PK_ROW(16, 8, true, NM),  PK_ROW(64, 8, true, NM),  PK_ROW(64, 16, true, NM) } }
+static const fill_pk_fn g_fill_pk[2][2][K2A_NPKCFG][2][3] = { PK_SET(false), PK_SET(true) };
 static const trace_fn g_trace_pk[K2A_NPKCFG] = { sim_trace_pk<8, 18>, sim_trace_pk<16, 8>, sim_trace_pk<64, 8>, sim_trace_pk<64, 16> };
 
 
@@ -526,10 +528,10 @@ int k2a_shim_launch_fill(int cfg, int dual, int mode, const K2aScoring *sc, cons
 	else g_fill[cfg][dual ? 1 : 0][mode](*sc, pairs, order, ntasks, seq, tb, res);
 	return 0;
 }
-int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2,
+int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2,
                             int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, void *)
 {
-	if (ntasks > 0) g_fill_pk[rebased ? 1 : 0][cfg][dual ? 1 : 0][mode](*sc, pairs, order2, ntasks, seq, tb, res);
+	if (ntasks > 0) g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode](*sc, pairs, order2, ntasks, seq, tb, res);
 	return 0;
 }
 int k2a_shim_launch_trace_pk(int cfg, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb,

@@ -526,3 +526,12 @@ def test_approx_max_mode_golden(lib):
     for k in range(ac.n):
         c = ac.case(k)
         assert not diff(c["expect"], gu.ApproxCases.run(lib, c), gu.FIELDS + ["cigar"]), (k, c["func"], hex(c["flag"]))
+
+
+def test_approx_max_packed_classes(lib):
+    from tests.test_sim_parity import _approx_batches
+    rng = np.random.Generator(np.random.PCG64(67))
+    for rnd in range(18):
+        mat, q, e, q2, e2, qs, ts, w, zd, eb, fl = _approx_batches(rng, rnd)
+        for dual in (False, True):
+            check_batch(lib, dual, qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl)

@@ -343,3 +343,29 @@ def test_sim_approx_max_mode(sim):
     for k in range(0, ac.n, 2):
         c = ac.case(k)
         assert not diff(c["expect"], gu.ApproxCases.run(sim, c), gu.FIELDS + ["cigar"]), (k, c["func"], hex(c["flag"]))
+
+
+def _approx_batches(rng, rnd):
+    mat, q, e, q2, e2 = [(synth.simple_mat(5, 2, 4, -1), 4, 2, 24, 1), (synth.simple_mat(5, 1, 3, 0), 5, 1, 20, 1)][rnd % 2]
+    n = int(rng.integers(3, 14))
+    long_reads = rnd % 3 == 2
+    ql = int(rng.integers(2500, 6000)) if long_reads else int(rng.integers(40, 800))
+    tl = max(1, ql + int(rng.integers(-30, 30)))
+    w = int(rng.choice([20, 64, 100, 150])) if long_reads else int(rng.choice([20, 64, 68, 100, 284, 400, -1]))
+    qs, ts = synth.fixed_batch(4000 + rnd, n, ql, tl, sub=0.05, ind=0.08, tail_random_frac=0.3, tail_pairs=0.3)
+    fl = np.array([0x08 | int(rng.choice([0, po.RIGHT, po.SCORE_ONLY, po.EXTZ_ONLY, po.REV_CIGAR])) for _ in range(n)])
+    return mat, q, e, q2, e2, qs, ts, w, rng.choice([-1, 100, 400], size=n), rng.choice([0, 50], size=n), fl
+
+
+def test_sim_approx_max_packed_classes(sim):
+    """KSW_EZ_APPROX_MAX batches run the packed kernels without row-maximum tracking (NOMAX), plain and re-based."""
+    rng = np.random.Generator(np.random.PCG64(66))
+    npk = ntot = 0
+    for rnd in range(15):
+        mat, q, e, q2, e2, qs, ts, w, zd, eb, fl = _approx_batches(rng, rnd)
+        for dual in (False, True):
+            p = sim.make_batch(qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl).plan(dual)
+            npk += p.packed_pairs(); ntot += len(qs)
+            p.close()
+            check_batch(sim, dual, qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl)
+    assert npk > ntot // 2
