@@ -147,7 +147,7 @@ struct K2aLanePk {
 	uint32_t qb;                        /* { query code A, query code B } of this step's column */
 	/* rows */
 	/* target codes as bit planes x D: one register more per row, so only where the kernel keeps its occupancy */
-	enum { PLANES = MODE == K2A_MODE_SCORE && (!DUAL || C <= 16) };
+	enum { PLANES = (MODE == K2A_MODE_SCORE && (!DUAL || C <= 16)) || C <= 8 };
 	k2a_pk hl[C], f[C], f2[DUAL ? C : 1], rmax[NOMAX ? 1 : C], rmj[NOMAX ? 1 : C];       /* hl, f, f2, rmax and the ports above: offset form */
 	k2a_pk tc[C], tc1[PLANES ? C : 1];                           /* target codes {A, B}; PLANES: bit 0 / bit 1 of the codes, times D */
 
