@@ -15,11 +15,15 @@ REF = "/root/reference"
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF, "ksw2.h")), reason="reference header not present")
-def test_caller_built_against_reference_header(tmp_path):
+@pytest.mark.parametrize("kalloc", [False, True])
+def test_caller_built_against_reference_header(tmp_path, kalloc):
+    """kalloc=True: the caller is built with -DHAVE_KALLOC plus the reference's kalloc.c (compiled where it lies) and passes
+    its pool as `km`; the library finds the process's krealloc (executable linked with -rdynamic) and grows the CIGAR there."""
     sim_dir = os.path.join(ROOT, "tests", "sim")
     subprocess.run(["make", "-C", sim_dir], check=True, capture_output=True)
     exe = str(tmp_path / "caller")
-    subprocess.run(["gcc", "-O1", "-Wall", "-I" + REF, os.path.join(ROOT, "tests", "dropin", "caller.c"), "-o", exe,
+    extra = ["-DHAVE_KALLOC", os.path.join(REF, "kalloc.c"), "-rdynamic"] if kalloc else []
+    subprocess.run(["gcc", "-O1", "-Wall", "-I" + REF, os.path.join(ROOT, "tests", "dropin", "caller.c")] + extra + ["-o", exe,
                     "-L" + sim_dir, "-lksw2_amd_sim", "-Wl,-rpath," + sim_dir], check=True, capture_output=True)
     rng = np.random.Generator(np.random.PCG64(12))
     mat = synth.simple_mat(5, 2, 4, -1)
