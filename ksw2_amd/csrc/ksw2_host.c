@@ -299,7 +299,7 @@ static int pk_eligible(const pkinfo_t *k, int qlen, int tlen, int w)
 {
 	const int64_t L = imin(qlen, tlen);
 	int64_t hmax, hmin;
-	if (k->ok <= 0 || qlen > 32000 || tlen > 32000) return 0;
+	if (k->ok <= 0 || qlen > 32000 || tlen > 32000) return 0;   /* (the score bound below is far tighter) */
 	hmax = (int64_t)imax(k->smax, 0) * L + (int64_t)k->e * tlen;     /* + row bias e*i carried by the packed kernels */
 	hmin = -((int64_t)k->q + (int64_t)k->e * (w + 1)) + (int64_t)imin(k->smin, 0) * L;
 	return hmax < 16383 - 2 * k->qemax - 8 && hmin > -16384 + 2 * k->qemax + 8;
@@ -314,7 +314,7 @@ static int pk_eligible(const pkinfo_t *k, int qlen, int tlen, int w)
 static int pk_window_ok(const pkinfo_t *k, int qlen, int tlen, int w, int C)
 {
 	const int64_t D = imax(imax(k->smax, 0) + k->qemin, -k->smin) + k->e;
-	if (k->ok <= 0 || qlen > 32000 || tlen > 32000) return 0;
+	if (k->ok <= 0 || qlen > 65000 || tlen > 65000) return 0;          /* column / row indices travel as unsigned 16-bit halves */
 	return ((int64_t)2 * w + 2 * C + 2) * D + 2 * k->qemax + (int64_t)4 * C * D + 64 <= 12000;
 }
 
@@ -440,7 +440,7 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 		p->h_cls[i] = (int8_t)ci;
 		p->cells += band_cells(a->qlen, a->tlen, w);
 		if (pkinfo[generic].ok < 0) pk_scoring(dual, m, sc->mat, q, e, q2, e2, generic, &pkinfo[generic]);
-		if (use_pk && pkinfo[generic].ok > 0 && a->qlen <= 32000 && a->tlen <= 32000 && !wild) {
+		if (use_pk && pkinfo[generic].ok > 0 && a->qlen <= 65000 && a->tlen <= 65000 && !wild) {
 			/* packed class: first geometry that holds the band, 1-based; scores that fit 16 bits outright use the plain
 			 * kernels, longer reads the re-based ones as long as the band window fits */
 			const int plain = pk_eligible(&pkinfo[generic], a->qlen, d->tlen, w);

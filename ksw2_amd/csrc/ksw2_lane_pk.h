@@ -394,7 +394,7 @@ struct K2aLanePk {
 					const bool reach = i + w >= qlen - 1;
 					const int unb = (half ? baseB : baseA) - sc.e * i;                                       /* plus base, minus row bias */
 					const int hend = (int)(int16_t)(rowbuf[c] >> sh) + unb, H = (int)(int16_t)(rowbuf[C + c] >> sh) + unb;
-					const int j = (int)(int16_t)(rowbuf[2 * C + c] >> sh);
+					const int j = (int)(uint16_t)(rowbuf[2 * C + c] >> sh);             /* column index: unsigned, reads up to 65 000 */
 					if (reach && hend > bmqe) { bmqe = hend; bmqe_t = i; }
 					if (i == tlen_full - 1) { bmte = H; bmte_q = j; }
 					if (H > bmax) { bmax = H; bmax_t = i; bmax_q = j; }
@@ -440,11 +440,11 @@ struct K2aLanePk {
 		if (!deadA && zdropA >= 0 && k2a_max(bmA, MA) - mA > zdropA) return false;
 		if (!deadB && zdropB >= 0 && k2a_max(bmB, MB) - mB > zdropB) return false;
 		if (!deadA) {
-			if (MA > bmA) { bA->max = MA; bA->max_t = i0 + k2a_pk_lo(arg); bA->max_q = k2a_pk_lo(argj); }
+			if (MA > bmA) { bA->max = MA; bA->max_t = i0 + k2a_pk_lo(arg); bA->max_q = (int)(argj & 0xffffu); }
 			bA->rows = i0 + C;
 		}
 		if (!deadB) {
-			if (MB > bmB) { bB->max = MB; bB->max_t = i0 + k2a_pk_hi(arg); bB->max_q = k2a_pk_hi(argj); }
+			if (MB > bmB) { bB->max = MB; bB->max_t = i0 + k2a_pk_hi(arg); bB->max_q = (int)(argj >> 16); }
 			bB->rows = i0 + C;
 		}
 		end_strip();

@@ -193,6 +193,13 @@ def test_very_long_reads(lib):
     check_batch(lib, True, q, t, mat, 4, 2, 24, 1, w=500, zdrop=400, flag=0)
     q, t = synth.fixed_batch(10, 1, 25000, 25300, sub=0.04, ind=0.05)
     check_batch(lib, False, q, t, mat, 4, 2, 0, 0, w=-1, zdrop=-1, flag=po.RIGHT)
+    # 50 k reads still fit the packed kernels (unsigned 16-bit column index, per-strip score bases)
+    q, t = synth.fixed_batch(11, 4, 50000, 50011, sub=0.04, ind=0.05, tail_random_frac=0.2, tail_pairs=0.5)
+    p = lib.make_batch(q, t, mat, 4, 2, 24, 1, w=100, zdrop=300, flag=0).plan(True)
+    assert p.packed_pairs() == 4
+    p.close()
+    check_batch(lib, True, q, t, mat, 4, 2, 24, 1, w=100, zdrop=300, flag=0)
+    check_batch(lib, False, q, t, mat, 4, 2, 0, 0, w=100, zdrop=300, flag=po.SCORE_ONLY)
 
 
 def test_edge_cases(lib):
