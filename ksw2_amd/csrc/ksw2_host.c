@@ -75,6 +75,19 @@ static void thread_owns_cache(void)
 	if (!pthread_getspecific(g_exit_key)) pthread_setspecific(g_exit_key, (void*)1);
 }
 static void *thread_stream(void) { if (!g_stream) { thread_owns_cache(); g_stream = k2a_shim_stream_create(); } return g_stream; }
+/* side streams + events for plans with several kernel classes: the classes are independent, and a class of a few long
+ * alignments would otherwise hold the whole device for the duration of one alignment while the next class waits */
+#define NSIDE 3
+static __thread void *g_side[NSIDE], *g_side_ev[NSIDE + 1];
+static int side_streams(void)
+{
+	int i;
+	if (g_side[0]) return 0;
+	thread_owns_cache();
+	for (i = 0; i < NSIDE; ++i) { g_side[i] = k2a_shim_stream_create(); if (!g_side[i]) return -1; }
+	for (i = 0; i <= NSIDE; ++i) { g_side_ev[i] = k2a_shim_event_create(); if (!g_side_ev[i]) return -1; }
+	return 0;
+}
 
 static void cache_free_raw(int kind, void *p) { if (kind == BUF_HSEQ) k2a_shim_host_free(p); else k2a_shim_free(p); }
 
@@ -106,6 +119,8 @@ void ksw2amd_release_cache(void)
 	for (k = 0; k < BUF_KINDS; ++k) { if (g_cache[k].p) cache_free_raw(k, g_cache[k].p); g_cache[k].p = 0; g_cache[k].cap = 0; }
 	for (k = 0; k < 3; ++k) { if (g_ev_cache[k]) k2a_shim_event_destroy(g_ev_cache[k]); g_ev_cache[k] = 0; }
 	if (g_stream) { k2a_shim_stream_sync(g_stream); k2a_shim_stream_destroy(g_stream); g_stream = 0; }
+	for (k = 0; k < NSIDE; ++k) if (g_side[k]) { k2a_shim_stream_sync(g_side[k]); k2a_shim_stream_destroy(g_side[k]); g_side[k] = 0; }
+	for (k = 0; k <= NSIDE; ++k) if (g_side_ev[k]) { k2a_shim_event_destroy(g_side_ev[k]); g_side_ev[k] = 0; }
 }
 
 /* ---------------------------------------------------------------- CIGAR memory */
@@ -458,6 +473,33 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 		}
 	}
 
+	/* Alignments without a partner of identical shape would be paired with themselves.  With traceback on a
+	 * one-alignment-per-wavefront geometry that is slower than the int32 kernel (tools/scripts/ragged_probe.py: 10 k reads of
+	 * unique lengths, CIGAR: 707 vs 825 GCUPS) and writes twice the direction bytes, so the odd one of every shape goes back.
+	 * Parity of every (class, shape) key in one pass over an open-addressing table. */
+	if (n > 0 && !getenv("KSW2AMD_KEEP_LEFTOVERS")) {
+		size_t cap = 16, h;
+		struct slot { uint64_t k1, k2; int32_t last, odd; } *tab;
+		int any = 0;
+		for (i = 0; i < n; ++i)
+			if (p->h_cls[i] >= 0 && pk_ok[i] && (p->h_cls[i] / 2) % 3 != K2A_MODE_SCORE && k2a_pkcfg_G[(pk_ok[i] - 1) % K2A_NPKCFG] == 64) ++any;
+		if (any) {
+			while (cap < 2 * (size_t)any) cap <<= 1;
+			tab = (struct slot*)calloc(cap, sizeof(*tab));
+			for (i = 0; i < n; ++i) {
+				uint64_t k1, k2;
+				if (!(p->h_cls[i] >= 0 && pk_ok[i] && (p->h_cls[i] / 2) % 3 != K2A_MODE_SCORE && k2a_pkcfg_G[(pk_ok[i] - 1) % K2A_NPKCFG] == 64)) continue;
+				k1 = ((uint64_t)(uint32_t)p->h_pairs[i].qlen << 32) | (uint32_t)p->h_pairs[i].tlen;
+				k2 = ((uint64_t)(uint32_t)p->h_pairs[i].w << 32) | ((uint32_t)p->h_cls[i] << 8) | pk_ok[i] | 0x80000000u;     /* never 0 */
+				for (h = (size_t)((k1 * 0x9E3779B97F4A7C15ull ^ k2 * 0xC2B2AE3D27D4EB4Full) >> 20) & (cap - 1); tab[h].k2 && (tab[h].k1 != k1 || tab[h].k2 != k2);
+				     h = (h + 1) & (cap - 1)) {}
+				tab[h].k1 = k1; tab[h].k2 = k2; tab[h].last = i; tab[h].odd ^= 1;
+			}
+			for (h = 0; h < cap; ++h) if (tab[h].k2 && tab[h].odd) pk_ok[tab[h].last] = 0;
+			free(tab);
+		}
+	}
+
 	/* A packed launch has half the wavefronts of the int32 launch of the same pairs.  When that leaves SIMDs without a
 	 * wavefront (a few hundred long reads), the wider int32 launch finishes earlier: measured on MI355X, 1024 pairs of
 	 * 10k x 10k, w = 500: 512 packed wavefronts 11.5 ms, 1024 int32 wavefronts 8.8 ms.  Below 0.6 wavefronts per SIMD the
@@ -603,6 +645,40 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 	p->stream = stream; p->ran = 1; p->stream_used = 1;
 	if (p->reject_all || p->ntasks == 0) return KSW2AMD_OK;
 	if (k2a_shim_event_record(p->ev[0], stream)) goto err;
+	if (p->ncls > 1 && !getenv("KSW2AMD_SERIAL") && side_streams() == 0) {
+		/* several classes: fork them over the caller's stream and the side streams (fill, then that class's traceback, in
+		 * stream order), join on the caller's stream.  The fill / traceback split of plan_timing is then meaningless:
+		 * both report the whole run (KSW2AMD_SERIAL=1 restores the two-phase order for profiling). */
+		int used = 0, ord[NCLS_ENTRIES], x, y;
+		/* small classes first: their few wavefronts get their slots at once and run beside the big launches instead of after them */
+		for (c = 0; c < p->ncls; ++c) ord[c] = c;
+		for (x = 1; x < p->ncls; ++x)
+			for (y = x; y > 0 && p->cls[ord[y]].count < p->cls[ord[y - 1]].count; --y) { const int t = ord[y]; ord[y] = ord[y - 1]; ord[y - 1] = t; }
+		if (k2a_shim_event_record(g_side_ev[NSIDE], stream)) goto err;
+		for (x = 0; x < p->ncls; ++x) {
+			const cls_t *k = &p->cls[ord[x]];
+			const int lane = x % (NSIDE + 1);
+			void *s = lane == 0 ? stream : g_side[lane - 1];
+			if (lane > 0 && !(used & (1 << lane))) { if (k2a_shim_stream_wait_event(s, g_side_ev[NSIDE])) goto err; used |= 1 << lane; }
+			if (k->pk) {
+				if (k2a_shim_launch_fill_pk(k->cfg, p->dual, k->mode, k->rb, k->nomax, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq,
+				                            p->d_tb, p->d_res, s)) goto err;
+				if (k->mode != K2A_MODE_SCORE &&
+				    k2a_shim_launch_trace_pk(k->cfg, p->d_pairs, p->d_order + k->first, k->count, p->d_tb, p->d_res, p->d_cig, s)) goto err;
+			} else {
+				if (k2a_shim_launch_fill(k->cfg, p->dual, k->mode, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
+				                         p->d_bnd, p->d_res, s)) goto err;
+				if (k->mode != K2A_MODE_SCORE &&
+				    k2a_shim_launch_trace(k->cfg, p->dual, p->d_pairs, p->d_order + k->first, k->count, p->d_tb, p->d_res, p->d_cig, s)) goto err;
+			}
+		}
+		for (c = 1; c <= NSIDE; ++c)
+			if (used & (1 << c)) {
+				if (k2a_shim_event_record(g_side_ev[c - 1], g_side[c - 1]) || k2a_shim_stream_wait_event(stream, g_side_ev[c - 1])) goto err;
+			}
+		if (k2a_shim_event_record(p->ev[1], stream) || k2a_shim_event_record(p->ev[2], stream)) goto err;
+		return KSW2AMD_OK;
+	}
 	for (c = 0; c < p->ncls; ++c) {
 		const cls_t *k = &p->cls[c];
 		if (k->pk) {

@@ -47,6 +47,7 @@ int   k2a_shim_stream_sync(void *stream);
 void *k2a_shim_event_create(void);
 void  k2a_shim_event_destroy(void *ev);
 int   k2a_shim_event_record(void *ev, void *stream);
+int   k2a_shim_stream_wait_event(void *stream, void *ev);   /* later work on `stream` waits for `ev` */
 float k2a_shim_event_ms(void *start, void *stop);  /* blocks on `stop` */
 
 /*

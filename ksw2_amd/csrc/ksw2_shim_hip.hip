@@ -745,6 +745,7 @@ void *k2a_shim_event_create(void)
 }
 void k2a_shim_event_destroy(void *ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
 int k2a_shim_event_record(void *ev, void *stream) { CHECK(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream)); return 0; }
+int k2a_shim_stream_wait_event(void *stream, void *ev) { CHECK(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0)); return 0; }
 float k2a_shim_event_ms(void *start, void *stop)
 {
 	float ms = -1.0f;

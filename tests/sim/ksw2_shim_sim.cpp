@@ -513,6 +513,7 @@ void k2a_shim_stream_destroy(void *) {}
 int k2a_shim_stream_sync(void *) { return 0; }
 void *k2a_shim_event_create(void) { return calloc(1, sizeof(double)); }
 void k2a_shim_event_destroy(void *ev) { free(ev); }
+int k2a_shim_stream_wait_event(void *, void *) { return 0; }
 int k2a_shim_event_record(void *ev, void *)
 {
 	*(double*)ev = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
