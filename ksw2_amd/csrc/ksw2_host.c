@@ -19,7 +19,8 @@
 
 #define F_SCALAR_CONTRACT 0x40000000   /* internal: call came through ksw_extz / ksw_extd / ksw_gg* */
 #define NCLS_MAX (K2A_NCFG * 3 * 2)
-#define NPASS (1 + 4 * K2A_NPKCFG)     /* per class: one alignment per lane group | packed class pc (x re-based) (x no maximum tracking) */
+#define NPASS (2 + 4 * K2A_NPKCFG)     /* per class: one alignment per lane group | packed class pc (x re-based) (x no maximum tracking) | solo */
+#define PASS_SOLO (NPASS - 1)           /* both halves of the packed registers for one alignment (ksw2_lane_solo.h) */
 #define NCLS_ENTRIES (NCLS_MAX * NPASS)
 
 static __thread char g_err[512];
@@ -168,7 +169,7 @@ static int is_approx(int flag)
 /* ---------------------------------------------------------------- plan */
 
 typedef struct {
-	int cfg, mode, generic, pk, rb, nomax, first, count;   /* pk: packed-int16 tasks, two h_order entries per task; rb: per-strip bases;
+	int cfg, mode, generic, pk, rb, nomax, solo, first, count;   /* pk: packed-int16 tasks, two h_order entries per task; rb: per-strip bases;
 	                                                        * nomax: KSW_EZ_APPROX_MAX launches without row maxima */
 	K2aScoring sc;
 } cls_t;
@@ -379,7 +380,11 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 	void *up;
 	sort_t *srt = 0;
 	pkinfo_t pkinfo[2];
-	uint8_t *pk_ok = 0;
+	uint8_t *pk_ok = 0, *solo_ok = 0;
+	/* KSW2AMD_SOLO: unset = alignments without a partner of identical shape take the solo kernel when there are enough of them
+	 * to keep four wavefronts on every SIMD, 1 = always, all = every eligible alignment (tests), 0 = never */
+	const char *solo_env = getenv("KSW2AMD_SOLO");
+	const int solo_mode = !solo_env ? 3 : !strcmp(solo_env, "0") ? 0 : !strcmp(solo_env, "all") ? 2 : 1;
 	const int use_pk = !getenv("KSW2AMD_NO_PK"), use_rb = !getenv("KSW2AMD_NO_RB");
 
 	g_err[0] = 0;
@@ -429,6 +434,7 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 	/* pass 1: copy the codes; geometry class, traceback / CIGAR / boundary space, packed-int16 eligibility per pair */
 	pkinfo[0].ok = pkinfo[1].ok = -1;
 	pk_ok = (uint8_t*)calloc((size_t)n + 1, 1);
+	solo_ok = (uint8_t*)calloc((size_t)n + 1, 1);
 	for (i = 0; i < n; ++i) {
 		const ksw2amd_pair_t *a = &pairs[i];
 		K2aPair *d = &p->h_pairs[i];
@@ -465,6 +471,12 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 				if (geom_fits(k2a_pkcfg_G[pc], k2a_pkcfg_C[pc], d->tlen, w) &&
 				    (plain || (use_rb && pk_window_ok(&pkinfo[generic], a->qlen, d->tlen, w, k2a_pkcfg_C[pc])))) break;
 			if (pc < K2A_NPKCFG) pk_ok[i] = (uint8_t)(1 + pc + (plain ? 0 : K2A_NPKCFG) + (is_approx(a->flag) ? 2 * K2A_NPKCFG : 0));
+			/* solo kernel: 2 * K2A_SOLO_C rows per lane share one base; a lane must finish a double strip before its next one starts */
+			if (solo_mode && !is_approx(a->flag) && pk_window_ok(&pkinfo[generic], a->qlen, d->tlen, w, 2 * K2A_SOLO_C) &&
+			    ((d->tlen + 2 * K2A_SOLO_C - 1) / (2 * K2A_SOLO_C) <= 64 || w < 64 * (K2A_SOLO_C + 1) - K2A_SOLO_C)) {
+				solo_ok[i] = 1;
+				if (solo_mode == 2) pk_ok[i] = PASS_SOLO;
+			}
 		}
 		if (cfg == K2A_CFG_MP) {                              /* boundary rows H, E, E~ between generations */
 			d->bnd_off = (uint32_t)p->bnd_words;
@@ -482,20 +494,20 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 		struct slot { uint64_t k1, k2; int32_t last, odd; } *tab;
 		int any = 0;
 		for (i = 0; i < n; ++i)
-			if (p->h_cls[i] >= 0 && pk_ok[i] && (p->h_cls[i] / 2) % 3 != K2A_MODE_SCORE && k2a_pkcfg_G[(pk_ok[i] - 1) % K2A_NPKCFG] == 64) ++any;
+			if (p->h_cls[i] >= 0 && pk_ok[i] && pk_ok[i] != PASS_SOLO && ((p->h_cls[i] / 2) % 3 != K2A_MODE_SCORE || (solo_mode && solo_ok[i])) && k2a_pkcfg_G[(pk_ok[i] - 1) % K2A_NPKCFG] == 64) ++any;
 		if (any) {
 			while (cap < 2 * (size_t)any) cap <<= 1;
 			tab = (struct slot*)calloc(cap, sizeof(*tab));
 			for (i = 0; i < n; ++i) {
 				uint64_t k1, k2;
-				if (!(p->h_cls[i] >= 0 && pk_ok[i] && (p->h_cls[i] / 2) % 3 != K2A_MODE_SCORE && k2a_pkcfg_G[(pk_ok[i] - 1) % K2A_NPKCFG] == 64)) continue;
+				if (!(p->h_cls[i] >= 0 && pk_ok[i] && pk_ok[i] != PASS_SOLO && ((p->h_cls[i] / 2) % 3 != K2A_MODE_SCORE || (solo_mode && solo_ok[i])) && k2a_pkcfg_G[(pk_ok[i] - 1) % K2A_NPKCFG] == 64)) continue;
 				k1 = ((uint64_t)(uint32_t)p->h_pairs[i].qlen << 32) | (uint32_t)p->h_pairs[i].tlen;
 				k2 = ((uint64_t)(uint32_t)p->h_pairs[i].w << 32) | ((uint32_t)p->h_cls[i] << 8) | pk_ok[i] | 0x80000000u;     /* never 0 */
 				for (h = (size_t)((k1 * 0x9E3779B97F4A7C15ull ^ k2 * 0xC2B2AE3D27D4EB4Full) >> 20) & (cap - 1); tab[h].k2 && (tab[h].k1 != k1 || tab[h].k2 != k2);
 				     h = (h + 1) & (cap - 1)) {}
 				tab[h].k1 = k1; tab[h].k2 = k2; tab[h].last = i; tab[h].odd ^= 1;
 			}
-			for (h = 0; h < cap; ++h) if (tab[h].k2 && tab[h].odd) pk_ok[tab[h].last] = 0;
+			for (h = 0; h < cap; ++h) if (tab[h].k2 && tab[h].odd) pk_ok[tab[h].last] = (uint8_t)(solo_mode && solo_ok[tab[h].last] ? PASS_SOLO : 0);
 			free(tab);
 		}
 	}
@@ -511,7 +523,7 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 		if (simds > 0) {
 			int cnt[NCLS_MAX * NPASS], b;
 			memset(cnt, 0, sizeof(cnt));
-			for (i = 0; i < n; ++i) if (p->h_cls[i] >= 0 && pk_ok[i]) ++cnt[p->h_cls[i] * NPASS + pk_ok[i]];
+			for (i = 0; i < n; ++i) if (p->h_cls[i] >= 0 && pk_ok[i] && pk_ok[i] != PASS_SOLO) ++cnt[p->h_cls[i] * NPASS + pk_ok[i]];
 			for (b = 0; b < NCLS_MAX * NPASS; ++b)
 				if (cnt[b]) {
 					const int G = k2a_pkcfg_G[(b % NPASS - 1) % K2A_NPKCFG];
@@ -520,8 +532,20 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 					 * fraction of a millisecond per call and costs 2-3 x the SIMD time, which concurrent callers would rather keep */
 					cnt[b] = G == 64 && waves * 10 < (int64_t)simds * 6;        /* 1 = demote */
 				}
-			for (i = 0; i < n; ++i) if (p->h_cls[i] >= 0 && pk_ok[i] && cnt[p->h_cls[i] * NPASS + pk_ok[i]]) pk_ok[i] = 0;
+			for (i = 0; i < n; ++i) if (p->h_cls[i] >= 0 && pk_ok[i] && pk_ok[i] != PASS_SOLO && cnt[p->h_cls[i] * NPASS + pk_ok[i]]) pk_ok[i] = 0;
 		}
+	}
+
+	/* The solo kernel has fewer instructions per cell than the int32 kernel but most of them at half the issue rate; it is
+	 * ahead only with enough wavefronts per SIMD to hide that (tools/scripts/ragged_probe.py, 10 k reads of unique lengths,
+	 * score only: 2048 reads 1212 vs 1422 GCUPS, 6144 reads 2077 vs 1822).  Below four per SIMD they go back to int32. */
+	if (solo_mode == 3) {
+		const char *ev = getenv("KSW2AMD_SIMDS");
+		const int simds = ev ? atoi(ev) : k2a_shim_simd_count();
+		int cnt[NCLS_MAX];
+		memset(cnt, 0, sizeof(cnt));
+		for (i = 0; i < n; ++i) if (p->h_cls[i] >= 0 && pk_ok[i] == PASS_SOLO) ++cnt[p->h_cls[i]];
+		for (i = 0; i < n; ++i) if (p->h_cls[i] >= 0 && pk_ok[i] == PASS_SOLO && (simds <= 0 || cnt[p->h_cls[i]] < 4 * simds)) pk_ok[i] = 0;
 	}
 
 	/* the sequence arena goes up while the host sorts out the task lists (pinned staging: the copy is asynchronous) */
@@ -561,10 +585,12 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 			ci = b / NPASS;
 			qsort(g, (size_t)cnt, sizeof(sort_t), cmp_cost_desc);
 			c = &p->cls[p->ncls++];
-			c->cfg = pass ? (pass - 1) % K2A_NPKCFG : ci / 6; c->rb = pass ? ((pass - 1) / K2A_NPKCFG) & 1 : 0; c->nomax = pass > 2 * K2A_NPKCFG; c->mode = (ci / 2) % 3; c->generic = ci & 1; c->pk = pass != 0; c->first = k;
+			c->solo = pass == PASS_SOLO;
+			c->cfg = c->solo ? 0 : pass ? (pass - 1) % K2A_NPKCFG : ci / 6; c->rb = pass && !c->solo ? ((pass - 1) / K2A_NPKCFG) & 1 : 0;
+			c->nomax = !c->solo && pass > 2 * K2A_NPKCFG; c->mode = (ci / 2) % 3; c->generic = ci & 1; c->pk = pass != 0 && !c->solo; c->first = k;
 			build_scoring(dual, m, sc->mat, q, e, q2, e2, c->generic, &c->sc);
 			c->sc.pk_a = pkinfo[c->generic].a; c->sc.pk_b = pkinfo[c->generic].b; c->sc.pk_n = pkinfo[c->generic].n;
-			if (!pass) {
+			if (!pass || c->solo) {
 				for (i = 0; i < cnt; ++i) p->h_order[k++] = g[i].idx;
 				ntask = cnt;
 			} else {
@@ -594,8 +620,12 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 			const int nstrips = (da->tlen + C - 1) / C;
 			size_t steps = (size_t)(nstrips - 1) + (size_t)imin(da->qlen - 1, da->tlen - 1 + da->w) + 1;
 			const size_t wb = c->pk ? 2 * (size_t)C : (size_t)C * (dual ? 8 : 4) / 8;
-			if (!c->pk && c->cfg == K2A_CFG_MP) steps = mp_total_steps(G, C, da->qlen, da->tlen, da->w);
+			if (!c->pk && !c->solo && c->cfg == K2A_CFG_MP) steps = mp_total_steps(G, C, da->qlen, da->tlen, da->w);
 			da->tb_off = db->tb_off = p->tb_bytes;
+			if (c->solo) {        /* k2a_solo_steps: 2 * (double strips - 1) + 2 + last column; 64 lanes x 2 * K2A_SOLO_C bytes per step */
+				const int nds = (da->tlen + 2 * K2A_SOLO_C - 1) / (2 * K2A_SOLO_C);
+				p->tb_bytes += align_up(((size_t)(2 * (nds - 1) + 2) + (size_t)imin(da->qlen - 1, da->tlen - 1 + da->w)) * 64 * 2 * K2A_SOLO_C, 256);
+			} else
 			p->tb_bytes += align_up(steps * G * wb, 256);
 			da->cig_off = (uint32_t)p->cig_words;
 			p->cig_words += (size_t)da->qlen + da->tlen_full + 2;
@@ -627,10 +657,10 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 	}
 	if (m > 5) for (k = 0; k < p->ncls; ++k) p->cls[k].sc.mat = (const int8_t*)p->d_seq + mat_off + (p->cls[k].generic ? (size_t)m * m : 0);
 	for (i = 0; i < 3; ++i) { p->ev[i] = g_ev_cache[i] ? g_ev_cache[i] : k2a_shim_event_create(); g_ev_cache[i] = 0; }
-	free(pk_ok);
+	free(pk_ok); free(solo_ok);
 	return p;
 err:
-	free(srt); free(pk_ok);
+	free(srt); free(pk_ok); free(solo_ok);
 	ksw2amd_plan_destroy(p);
 	return 0;
 }
@@ -660,7 +690,11 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 			const int lane = x % (NSIDE + 1);
 			void *s = lane == 0 ? stream : g_side[lane - 1];
 			if (lane > 0 && !(used & (1 << lane))) { if (k2a_shim_stream_wait_event(s, g_side_ev[NSIDE])) goto err; used |= 1 << lane; }
-			if (k->pk) {
+			if (k->solo) {
+				if (k2a_shim_launch_fill_solo(p->dual, k->mode, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb, p->d_res, s)) goto err;
+				if (k->mode != K2A_MODE_SCORE &&
+				    k2a_shim_launch_trace_solo(p->d_pairs, p->d_order + k->first, k->count, p->d_tb, p->d_res, p->d_cig, s)) goto err;
+			} else if (k->pk) {
 				if (k2a_shim_launch_fill_pk(k->cfg, p->dual, k->mode, k->rb, k->nomax, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq,
 				                            p->d_tb, p->d_res, s)) goto err;
 				if (k->mode != K2A_MODE_SCORE &&
@@ -681,7 +715,9 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 	}
 	for (c = 0; c < p->ncls; ++c) {
 		const cls_t *k = &p->cls[c];
-		if (k->pk) {
+		if (k->solo) {
+			if (k2a_shim_launch_fill_solo(p->dual, k->mode, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb, p->d_res, stream)) goto err;
+		} else if (k->pk) {
 			if (k2a_shim_launch_fill_pk(k->cfg, p->dual, k->mode, k->rb, k->nomax, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
 			                            p->d_res, stream)) goto err;
 		} else if (k2a_shim_launch_fill(k->cfg, p->dual, k->mode, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
@@ -691,7 +727,9 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 	for (c = 0; c < p->ncls; ++c) {
 		const cls_t *k = &p->cls[c];
 		if (k->mode == K2A_MODE_SCORE) continue;
-		if (k->pk) {
+		if (k->solo) {
+			if (k2a_shim_launch_trace_solo(p->d_pairs, p->d_order + k->first, k->count, p->d_tb, p->d_res, p->d_cig, stream)) goto err;
+		} else if (k->pk) {
 			if (k2a_shim_launch_trace_pk(k->cfg, p->d_pairs, p->d_order + k->first, k->count, p->d_tb, p->d_res, p->d_cig, stream)) goto err;
 		} else if (k2a_shim_launch_trace(k->cfg, p->dual, p->d_pairs, p->d_order + k->first, k->count, p->d_tb, p->d_res, p->d_cig, stream)) goto err;
 	}
@@ -720,6 +758,7 @@ int64_t ksw2amd_plan_packed_pairs(const ksw2amd_plan_t *p)
 		if (p->cls[c].pk)
 			for (i = 0; i < p->cls[c].count; ++i)
 				n += p->h_order[p->cls[c].first + 2 * i] == p->h_order[p->cls[c].first + 2 * i + 1] ? 1 : 2;
+		else if (p->cls[c].solo) n += p->cls[c].count;
 	return n;
 }
 int64_t ksw2amd_plan_device_bytes(const ksw2amd_plan_t *p)

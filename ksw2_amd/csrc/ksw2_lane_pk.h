@@ -92,6 +92,10 @@ K2A_FN k2a_pk k2a_pk_selv(k2a_pk m, k2a_pk a, k2a_pk b)   /* k2a_pk_sel on three
 	asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe4" : "=v"(d) : "v"(a), "v"(b), "v"(m));
 	return d;
 }
+K2A_FN k2a_pk k2a_pk_shl(k2a_pk a, int n)   /* per half, n a compile-time constant */
+{
+	return n == 0 ? a : __builtin_bit_cast(k2a_pk, (k2a_u2)(__builtin_bit_cast(k2a_u2, a) << (k2a_u2)(unsigned short)n));
+}
 K2A_FN k2a_pk k2a_bit_mask(uint32_t bits, int c) { return (k2a_pk)__builtin_amdgcn_sbfe((int)bits, c, 1); }
 K2A_FN uint32_t k2a_pack_dirs(k2a_pk d0, k2a_pk d1)   /* low bytes of the four halves -> one word */
 {
@@ -119,6 +123,7 @@ K2A_FN k2a_pk k2a_pk_minu(k2a_pk a, k2a_pk b)
 K2A_FN k2a_pk k2a_pk_mad(k2a_pk a, k2a_pk b, k2a_pk c) { return k2a_pk_mk(k2a_pk_lo(a) * k2a_pk_lo(b) + k2a_pk_lo(c), k2a_pk_hi(a) * k2a_pk_hi(b) + k2a_pk_hi(c)); }
 K2A_FN k2a_pk k2a_pk_sign(k2a_pk a) { return ((a & 0x8000u) ? 0xffffu : 0u) | ((a & 0x80000000u) ? 0xffff0000u : 0u); }
 K2A_FN k2a_pk k2a_pk_selv(k2a_pk m, k2a_pk a, k2a_pk b) { return k2a_pk_sel(m, a, b); }
+K2A_FN k2a_pk k2a_pk_shl(k2a_pk a, int n) { return (((a & 0xffffu) << n) & 0xffffu) | ((((a >> 16) << n) & 0xffffu) << 16); }
 K2A_FN k2a_pk k2a_bit_mask(uint32_t bits, int c) { return ((bits >> c) & 1u) ? 0xffffffffu : 0u; }
 K2A_FN uint32_t k2a_pack_dirs(k2a_pk d0, k2a_pk d1)
 {

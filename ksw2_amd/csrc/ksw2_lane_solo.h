@@ -1,0 +1,383 @@
+/*
+ * ksw2_lane_solo.h -- packed-int16 per-lane code for ONE alignment per 64-lane wavefront that uses BOTH 16-bit halves of
+ * every register: the low half carries rows [i0, i0+C) of a "double strip" at query column jj, the high half rows
+ * [i0+C, i0+2C) at column jj-1.  The two halves are two consecutive strips of the schedule of ksw2_lane.h (strip 2D and
+ * 2D+1, one step apart), so the low half's bottom row reaches the high half inside the lane one step later, and the high
+ * half's bottom row reaches the next lane's low half through the usual one-lane rotate.  Same cell update and number
+ * format as K2aLanePk (offset form, row bias, per-strip score base = re-based variant; one base per double strip), but no
+ * partner alignment of identical shape is needed: this is the kernel for reads whose shape is unique in their batch.
+ *
+ * Differences to K2aLanePk worth knowing when reading step(): the live-row mask, the "cell above is outside the band" test
+ * and the column index differ between the halves; the strip epilogue runs once per double strip, over 2C rows, after the
+ * high half has finished (the low half's last-column H values are saved when the low half finishes, C+1 steps earlier).
+ * Replaces the same reference loops as ksw2_lane_pk.h with the scalar ksw_extz / ksw_extd semantics.
+ */
+#ifndef KSW2_LANE_SOLO_H_
+#define KSW2_LANE_SOLO_H_
+
+#include "ksw2_lane_pk.h"
+
+#define K2A_SOLO_STAGE(C) (6 * (C) + 4)   /* LDS words of a staged double strip: H, row max, arg-max of 2C rows; first row, base */
+
+/* steps of a solo task (also the step dimension of its traceback block): the high half of the last double strip ends at
+ * 2*(nds-1) + 1 + last column */
+template<int C>
+K2A_FN size_t k2a_solo_steps(int qlen, int tlen, int w)
+{
+	const int nds = (tlen + 2 * C - 1) / (2 * C);
+	return nds > 0 ? (size_t)(2 * (nds - 1) + 2 + k2a_min(qlen - 1, tlen - 1 + w)) : 0;
+}
+
+template<int C, bool DUAL, int MODE = K2A_MODE_SCORE>
+struct K2aLaneSolo {
+	enum { G = 64, TBWORDS = C / 2 };
+	int qlen, tlen, tlen_full, w, nds;      /* nds = double strips */
+	const uint8_t *qa, *ta;
+	int gl, D, i0, koff, Dnext, knext, koff_next;
+	int kfin, kfinA, kd, kB0, rowsA_m1, rowsB_m1, wupA;   /* kB0: first step of the high half (its first in-band column) */
+	k2a_pk hout, eout, e2out, hd0, hu_prev;
+	int base;                              /* absolute (row-biased) score the double strip's values are relative to */
+	k2a_pk delta;                           /* low half: base of the double strip above minus this one; high half 0 */
+	bool bfirst;
+	uint32_t qb;                            /* { query code at column jj, at column jj-1 } */
+	k2a_pk hl[C], f[C], f2[DUAL ? C : 1], rmax[C], rmj[C], tc[C], tc1[C], hsave[C];
+
+	K2A_FN static int first_col(int D_, int w_) { return k2a_max(0, D_ * 2 * C - w_); }
+	K2A_FN void schedule_next()
+	{
+		koff_next = 2 * Dnext;
+		knext = Dnext < nds ? koff_next + first_col(Dnext, w) : K2A_KNONE;
+	}
+
+	K2A_FN void setup(const K2aPair &pr, const uint8_t *seq, int lane, bool valid)
+	{
+		qlen = pr.qlen; tlen = pr.tlen; tlen_full = pr.tlen_full; w = pr.w;
+		qa = seq + pr.qoff; ta = seq + pr.toff;
+		nds = valid ? (tlen + 2 * C - 1) / (2 * C) : 0;
+		gl = lane;
+		D = -1; i0 = 0; koff = 0; kfin = kfinA = K2A_KNONE; kd = 0; kB0 = 0; rowsA_m1 = rowsB_m1 = -1; wupA = w;
+		Dnext = gl;
+		schedule_next();
+		const k2a_pk neg = k2a_pku(K2A_NEG16);
+		hout = eout = e2out = hd0 = hu_prev = neg; qb = 0; base = 0; delta = 0; bfirst = false;
+#pragma unroll
+		for (int c = 0; c < C; ++c) { hl[c] = f[c] = rmax[c] = hsave[c] = neg; rmj[c] = 0; tc[c] = tc1[c] = 0; if (DUAL) f2[c] = neg; }
+		if (!DUAL) f2[0] = 0;
+	}
+
+	/* last step of the alignment: the high half of the last double strip (or its low half when the high half is empty) */
+	K2A_FN int last_step() const
+	{
+		if (nds <= 0) return -1;
+		const int Dl = nds - 1, rB = tlen - 1 - (Dl * 2 * C + C);
+		return rB >= 0 ? 2 * Dl + 1 + k2a_min(qlen - 1, tlen - 1 + w) : 2 * Dl + k2a_min(qlen - 1, tlen - 1 + w);
+	}
+	K2A_FN bool need_init(int k) const { return k == knext; }
+	K2A_FN bool need_fin(int k) const { return k == kfin; }
+	K2A_FN bool need_save(int k) const { return k == kfinA; }
+
+	/* bs = base of the double strip above (rotated in by the kernel) */
+	K2A_FN void do_init(const K2aScoring &sc, int bs)
+	{
+		D = Dnext; i0 = D * 2 * C; koff = koff_next;
+		const int i0b = i0 + C;
+		rowsA_m1 = k2a_min(C - 1, tlen - 1 - i0);
+		rowsB_m1 = k2a_max(-1, k2a_min(C - 1, tlen - 1 - i0b));
+		const int jeA = k2a_min(qlen - 1, k2a_min(i0 + C - 1, tlen - 1) + w);
+		const int jeB = k2a_min(qlen - 1, k2a_min(i0b + C - 1, tlen - 1) + w);
+		kfinA = koff + jeA;
+		kfin = rowsB_m1 >= 0 ? koff + 1 + jeB : kfinA;
+		kd = koff + i0;
+		kB0 = koff + 1 + k2a_max(0, i0b - w);
+		wupA = w + (D == 0 ? 1 : 0);
+		const int js = k2a_max(0, i0 - w);
+		const k2a_pk neg = k2a_pku(K2A_NEG16);
+		const uint32_t dmis = (uint32_t)(sc.pk_a - sc.pk_b);
+		/* target codes of the 2C rows as bit planes x D (ksw2_lane_pk.h), low half = rows i0.., high half = rows i0+C.. */
+		const uint16_t *tpa = (const uint16_t*)(ta + (size_t)i0), *tpb = (const uint16_t*)(ta + (size_t)i0b);
+#pragma unroll
+		for (int c = 0; c < C; c += 2) {
+			const uint32_t ua = tpa[c >> 1], ub = tpb[c >> 1];
+			const k2a_pk c0 = k2a_pair16(ua & 0xffu, ub & 0xffu), c1 = k2a_pair16(ua >> 8, ub >> 8);
+			tc[c] = (c0 & 0x00010001u) * dmis; tc1[c] = ((c0 >> 1) & 0x00010001u) * dmis;
+			if (c + 1 < C) { tc[c + 1] = (c1 & 0x00010001u) * dmis; tc1[c + 1] = ((c1 >> 1) & 0x00010001u) * dmis; }
+		}
+#pragma unroll
+		for (int c = 0; c < C; ++c) { hl[c] = neg; f[c] = neg; if (DUAL) f2[c] = neg; rmax[c] = neg; rmj[c] = 0; }
+		/* base = the diagonal input of the low half's first cell */
+		const int hcorner = k2a_border<DUAL>(sc, i0) + sc.e * (i0 - 1);
+		const int nb = js == 0 ? hcorner : bs + k2a_pk_hi(hu_prev ^ K2A_OFS);          /* what arrived: the high half of the lane above */
+		delta = D == 0 ? 0u : ((uint32_t)(bs - nb) & 0xffffu);
+		base = nb;
+		if (i0 <= w) {                                          /* rows starting at column 0: virtual column -1 (ksw2_extz.c:43-44) */
+#pragma unroll
+			for (int c = 0; c < C; ++c) {
+				const int ha = k2a_border<DUAL>(sc, i0 + c + 1) + sc.e * (i0 + c);
+				const uint32_t va = i0 + c <= w ? ((uint32_t)(ha - base) & 0xffffu) ^ 0x8000u : (K2A_NEG16 + 0x8000) & 0xffffu;
+				hl[c] = k2a_pair16(va, neg >> 16);
+				const k2a_pk fl = k2a_pk_sub(hl[c], k2a_pk2(sc.q + sc.e));
+				f[c] = k2a_pair16(i0 + c <= w ? fl & 0xffffu : neg & 0xffffu, neg >> 16);
+				if (DUAL) {
+					const k2a_pk fl2 = k2a_pk_sub(hl[c], k2a_pk2(sc.q2 + sc.e2));
+					f2[c] = k2a_pair16(i0 + c <= w ? fl2 & 0xffffu : neg & 0xffffu, neg >> 16);
+				}
+			}
+		}
+		/* diagonal input of the low half's first cell: 0 by construction of the base.  The high half takes the low half's bottom
+		 * row one step later; when its rows start at column 0 init_high() loads its virtual column -1 just before that step
+		 * (the step in between runs the high half dead and would wipe it). */
+		hd0 = k2a_pair16(0x8000u, neg >> 16);
+		bfirst = i0b <= w && rowsB_m1 >= 0;
+		Dnext += G;
+		schedule_next();
+	}
+
+	K2A_FN bool need_init_high(int k) const { return bfirst && k == kB0; }
+
+	/* high half, rows starting at column 0: H / F / F~ of the virtual column -1 and the first diagonal input */
+	K2A_FN void init_high(const K2aScoring &sc)
+	{
+		const int i0b = i0 + C;
+		const uint32_t negh = (uint32_t)(K2A_NEG16 + 0x8000) & 0xffffu;
+#pragma unroll
+		for (int c = 0; c < C; ++c) {
+			const bool in = i0b + c <= w;
+			const int hb = k2a_border<DUAL>(sc, i0b + c + 1) + sc.e * (i0b + c) - base;
+			const uint32_t vb = in ? ((uint32_t)hb & 0xffffu) ^ 0x8000u : negh;
+			const uint32_t fb = in ? ((uint32_t)(hb - (sc.q + sc.e)) & 0xffffu) ^ 0x8000u : negh;
+			hl[c] = (hl[c] & 0xffffu) | (vb << 16);
+			f[c] = (f[c] & 0xffffu) | (fb << 16);
+			if (DUAL) {
+				const uint32_t fb2 = in ? ((uint32_t)(hb - (sc.q2 + sc.e2)) & 0xffffu) ^ 0x8000u : negh;
+				f2[c] = (f2[c] & 0xffffu) | (fb2 << 16);
+			}
+		}
+		const uint32_t d0 = ((uint32_t)(k2a_border<DUAL>(sc, i0b) + sc.e * (i0b - 1) - base) & 0xffffu) ^ 0x8000u;
+		hd0 = (hd0 & 0xffffu) | (d0 << 16);
+		bfirst = false;
+	}
+
+	/* double strip 0, low half only: the cells above row 0 are the virtual row -1 (ksw2_extz.c:32-35) */
+	K2A_FN void top_inputs(const K2aScoring &sc, int k, k2a_pk &hin, k2a_pk &ein, k2a_pk &e2in) const
+	{
+		if (D == 0) {
+			const int hb = k2a_border<DUAL>(sc, k - koff + 1) - base;
+			const uint32_t h0 = ((uint32_t)(hb - sc.e) & 0xffffu) ^ 0x8000u, e0 = ((uint32_t)(hb - (sc.q + sc.e)) & 0xffffu) ^ 0x8000u;
+			const uint32_t e20 = ((uint32_t)(hb - (sc.q2 + sc.e2)) & 0xffffu) ^ 0x8000u;
+			hin = (hin & 0xffff0000u) | h0; ein = (ein & 0xffff0000u) | e0; e2in = (e2in & 0xffff0000u) | e20;
+		}
+	}
+
+	/* One step: column jj = k - koff for the low half's rows, jj - 1 for the high half's.  hin / ein / e2in: low half = bottom
+	 * row of the lane above's high half (already shifted by delta), high half = this lane's own low-half bottom row of the
+	 * previous step. */
+	K2A_FN bool step(const K2aScoring &sc, int k, k2a_pk hin, k2a_pk ein, k2a_pk e2in, uint32_t *tbw)
+	{
+		const int ddA = k - kd, ddB = ddA - C - 1;
+		const k2a_pk neg = k2a_pku(K2A_NEG16);
+		const k2a_pk gq = k2a_pk2(sc.q), ge = k2a_pk2(sc.e), gq2 = k2a_pk2(sc.q2), ge2 = k2a_pk2(sc.e2), de2 = k2a_pk2(sc.e2 - sc.e);
+		const k2a_pk mat_a = k2a_pk2(sc.pk_a + sc.e);
+		/* the cell above is outside the band: per half */
+		const k2a_pk cut = k2a_pair16(ddA >= wupA ? 0xffffu : 0u, ddB >= w ? 0xffffu : 0u);
+		k2a_pk e = k2a_pk_sel(cut, neg, ein), e2 = k2a_pk_sel(cut, neg, e2in);
+		/* the low half keeps stepping after its last column while the high half finishes, the high half is carried along before
+		 * its first column: no live rows there */
+		const int loA = k2a_max(0, ddA - w), hiA = k2a_min(rowsA_m1, ddA + w), cntA = k <= kfinA ? k2a_max(hiA - loA + 1, 0) : 0;
+		const int loB = k2a_max(0, ddB - w), hiB = k2a_min(rowsB_m1, ddB + w), cntB = k >= kB0 ? k2a_max(hiB - loB + 1, 0) : 0;
+		const uint32_t liveA = ((1u << cntA) - 1u) << loA, liveB = ((1u << cntB) - 1u) << loB;
+		k2a_pk lv = k2a_pair16(liveA << (15 - (C - 1)), liveB << (15 - (C - 1)));      /* bit C-1 of each half at bit 15; row c at bit 15 - (C-1-c) */
+		const k2a_pk qcode = qb;
+		const k2a_pk jjpk = k2a_pair16((uint32_t)(k - koff) & 0xffffu, (uint32_t)(k - koff - 1) & 0xffffu);
+		const uint32_t dmis = (uint32_t)(sc.pk_a - sc.pk_b);
+		const k2a_pk q0 = (qcode & 0x00010001u) * dmis, q1 = ((qcode >> 1) & 0x00010001u) * dmis;
+		k2a_pk cand[C];
+#pragma unroll
+		for (int c = 0; c < C; ++c)
+			cand[c] = k2a_sub32(k2a_add32(c == 0 ? hd0 : hl[c - 1], mat_a), k2a_or_xor(tc[c] ^ q0, tc1[c], q1));
+		k2a_pk dprev = 0;
+#pragma unroll
+		for (int c = 0; c < C; ++c) {
+			const k2a_pk fc = f[c];
+			k2a_pk h = cand[c], d = 0;
+			if (MODE == K2A_MODE_SCORE) {
+				h = k2a_pk_maxu(k2a_pk_maxu(h, e), fc);
+				if (DUAL) h = k2a_pk_maxu(k2a_pk_maxu(h, e2), f2[c]);
+			} else if (MODE == K2A_MODE_LEFT) {
+				d = k2a_pk_sign(k2a_pk_sub(h, e)) & 0x00010001u;                     h = k2a_pk_maxu(h, e);
+				d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, fc)), 0x00020002u, d);      h = k2a_pk_maxu(h, fc);
+				if (DUAL) {
+					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, e2)), 0x00030003u, d);    h = k2a_pk_maxu(h, e2);
+					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, f2[c])), 0x00040004u, d); h = k2a_pk_maxu(h, f2[c]);
+				}
+			} else {
+				d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e, h)), 0u, 0x00010001u);      h = k2a_pk_maxu(h, e);
+				d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(fc, h)), d, 0x00020002u);      h = k2a_pk_maxu(h, fc);
+				if (DUAL) {
+					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e2, h)), d, 0x00030003u);    h = k2a_pk_maxu(h, e2);
+					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(f2[c], h)), d, 0x00040004u); h = k2a_pk_maxu(h, f2[c]);
+				}
+			}
+			/* live mask of row c, per half: the row's bit sits at bit 15 - (C-1-c) of lv's halves */
+			h = k2a_pk_sel(k2a_pk_sign(k2a_pk_shl(lv, C - 1 - c)), h, neg);
+			if (!DUAL && MODE == K2A_MODE_RIGHT) rmj[c] = k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(rmax[c], h)), jjpk, rmj[c]);
+			else rmj[c] = k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(h, rmax[c])), rmj[c], jjpk);
+			rmax[c] = k2a_pk_maxu(rmax[c], h);
+			const k2a_pk t = k2a_sub32(h, gq);
+			if (MODE == K2A_MODE_LEFT) {
+				d |= k2a_pk_sign(k2a_pk_sub(t, e)) & 0x00080008u;
+				d |= k2a_pk_sign(k2a_pk_sub(t, fc)) & 0x00100010u;
+			} else if (MODE == K2A_MODE_RIGHT) {
+				d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e, t)), 0u, 0x00080008u);
+				d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(fc, t)), 0u, 0x00100010u);
+			}
+			e = k2a_pk_maxu(e, t);
+			f[c] = k2a_sub32(k2a_pk_maxu(fc, t), ge);
+			if (DUAL) {
+				const k2a_pk t2 = k2a_sub32(h, gq2);
+				if (MODE == K2A_MODE_LEFT) {
+					d |= k2a_pk_sign(k2a_pk_sub(t2, e2)) & 0x00200020u;
+					d |= k2a_pk_sign(k2a_pk_sub(t2, f2[c])) & 0x00400040u;
+				} else if (MODE == K2A_MODE_RIGHT) {
+					d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e2, t2)), 0u, 0x00200020u);
+					d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(f2[c], t2)), 0u, 0x00400040u);
+				}
+				e2 = k2a_pk_sub(k2a_pk_maxu(e2, t2), de2);
+				f2[c] = k2a_sub32(k2a_pk_maxu(f2[c], t2), ge2);
+			}
+			if (MODE != K2A_MODE_SCORE) {
+				if (c & 1) tbw[c >> 1] = k2a_pack_dirs(dprev, d);
+				else dprev = d;
+			}
+			hl[c] = h;
+		}
+		hd0 = hin;
+		hout = hl[C - 1]; eout = e; e2out = e2;
+		return (liveA | liveB) != 0;
+	}
+
+	/* query codes for step k+1: columns jj and jj-1 */
+	K2A_FN uint32_t next_query_codes(int k) const
+	{
+		const int j = k + 1 - ((k + 1 == knext) ? koff_next : koff);
+		const int ja = k2a_min(k2a_max(j, 0), qlen - 1), jb = k2a_min(k2a_max(j - 1, 0), qlen - 1);
+		return k2a_pair16(qa[ja], qa[jb]);
+	}
+
+	/* the low half is done C+1 steps before the high half and keeps stepping over dead cells: keep its last-column H */
+	K2A_FN void save_low() {
+#pragma unroll
+		for (int c = 0; c < C; ++c) hsave[c] = hl[c];
+	}
+
+	/* rows of the finished double strip in row order into LDS: [0,2C) H(i, last column), [2C,4C) row max, [4C,6C) arg-max */
+	K2A_FN void stage_rows(uint32_t *rowbuf) const
+	{
+#pragma unroll
+		for (int c = 0; c < C; ++c) {
+			const k2a_pk hA = (rowsB_m1 >= 0 ? hsave[c] : hl[c]) ^ K2A_OFS, hB = hl[c] ^ K2A_OFS, m = rmax[c] ^ K2A_OFS;
+			rowbuf[c] = hA & 0xffffu; rowbuf[C + c] = hB >> 16;
+			rowbuf[2 * C + c] = m & 0xffffu; rowbuf[3 * C + c] = m >> 16;
+			rowbuf[4 * C + c] = rmj[c] & 0xffffu; rowbuf[5 * C + c] = rmj[c] >> 16;
+		}
+	}
+
+	/* the scalar reference's per-row epilogue over the 2C rows (K2aLane::do_fin) */
+	K2A_FN void do_fin_seq(const K2aScoring &sc, K2aBook *b, int zdrop, const uint32_t *rowbuf)
+	{
+		const int zslope = DUAL ? sc.e2 : sc.e;
+		int bmax = b->max, bmax_t = b->max_t, bmax_q = b->max_q, bmqe = b->mqe, bmqe_t = b->mqe_t;
+		int bmte = b->mte, bmte_q = b->mte_q, bscore = b->score, bdrop = b->dropped, brows = b->rows;
+#pragma nounroll
+		for (int c = 0; c < 2 * C; ++c) {
+			const int i = i0 + c;
+			if (i < tlen && !bdrop) {
+				const bool reach = i + w >= qlen - 1;
+				const int unb = base - sc.e * i;
+				const int hend = (int)(int16_t)rowbuf[c] + unb, H = (int)(int16_t)rowbuf[2 * C + c] + unb;
+				const int j = (int)(uint16_t)rowbuf[4 * C + c];
+				if (reach && hend > bmqe) { bmqe = hend; bmqe_t = i; }
+				if (i == tlen_full - 1) { bmte = H; bmte_q = j; }
+				if (H > bmax) { bmax = H; bmax_t = i; bmax_q = j; }
+				else if (i >= bmax_t && j >= bmax_q) {
+					const int dt = i - bmax_t, dq = j - bmax_q;
+					const int skew = dt > dq ? dt - dq : dq - dt;
+					if (zdrop >= 0 && bmax - H > zdrop + skew * zslope) bdrop = 1;
+				}
+				if (!bdrop && i == tlen_full - 1 && reach) bscore = hend;
+				brows = i + 1;
+			}
+		}
+		b->max = bmax; b->max_t = bmax_t; b->max_q = bmax_q; b->mqe = bmqe; b->mqe_t = bmqe_t;
+		b->mte = bmte; b->mte_q = bmte_q; b->score = bscore; b->dropped = bdrop; b->rows = brows;
+		end_strip();
+	}
+
+	/* shortcut of K2aLanePk::fin_fast over the 2C rows of the double strip (low-half rows come first) */
+	K2A_FN bool fin_fast(const K2aScoring &sc, K2aBook *b, int zdrop)
+	{
+		if (i0 + 2 * C >= tlen || i0 + 2 * C - 1 + w >= qlen - 1) return false;
+		/* rows compare without their bias: low half v_c = rmax[c] - e*c, high half rmax[c] - e*(C+c) */
+		const k2a_pk hb = k2a_pair16(0u, (uint32_t)(sc.e * C) & 0xffffu);
+		k2a_pk m = k2a_pk_sub(rmax[0] ^ K2A_OFS, hb), mn = m, arg = 0, argj = rmj[0];
+#pragma unroll
+		for (int c = 1; c < C; ++c) {
+			const k2a_pk v = k2a_pk_sub(k2a_pk_sub(rmax[c] ^ K2A_OFS, hb), k2a_pk2(sc.e * c));
+			const k2a_pk gt = k2a_pk_sign(k2a_pk_sub(m, v));
+			arg = k2a_pk_sel(gt, k2a_pk2(c), arg);
+			argj = k2a_pk_sel(gt, rmj[c], argj);
+			m = k2a_pk_max(m, v);
+			mn = k2a_pk_min(mn, v);
+		}
+		const int off = base - sc.e * i0;
+		const int MA = k2a_pk_lo(m) + off, MB = k2a_pk_hi(m) + off;
+		const int mnn = k2a_min(k2a_pk_lo(mn), k2a_pk_hi(mn)) + off;
+		const int M = k2a_max(MA, MB), bm = b->max;
+		if (b->dropped) { end_strip(); return true; }
+		if (zdrop >= 0 && k2a_max(bm, M) - mnn > zdrop) return false;
+		if (M > bm) {
+			if (MB > MA) { b->max = MB; b->max_t = i0 + C + k2a_pk_hi(arg); b->max_q = (int)(argj >> 16); }
+			else { b->max = MA; b->max_t = i0 + k2a_pk_lo(arg); b->max_q = (int)(argj & 0xffffu); }
+		}
+		b->rows = i0 + 2 * C;
+		end_strip();
+		return true;
+	}
+
+	K2A_FN void end_strip() { D = -1; kfin = kfinA = K2A_KNONE; rowsA_m1 = rowsB_m1 = -1; }
+};
+
+/* Traceback walk over a solo task's direction bytes: cell (i, j) is byte 2c + half of the word written at step
+ * j + 2D + half by lane D mod 64, with D = i / 2C, half = (i mod 2C) / C, c = i mod C (lane-major block as everywhere). */
+template<int C>
+K2A_FN int k2a_trace_solo(const uint8_t *tb, int i, int j, uint32_t *out, int qlen, int tlen, int w)
+{
+	enum { WB = 2 * C };
+	int n = 0, state = 0;
+	uint32_t last_op = 0xffffffffu, run = 0;
+	const size_t nsteps = k2a_solo_steps<C>(qlen, tlen, w);
+	while (i >= 0 && j >= 0) {
+		const int D = i / (2 * C), r = i - D * 2 * C, half = r >= C ? 1 : 0, c = r - half * C;
+		const uint32_t d = tb[k2a_tb_word((size_t)(j + 2 * D + half), D % 64, nsteps, 64, WB) + 2 * c + half];
+		if (state == 0) state = d & 7;
+		else if (!((d >> (state + 2)) & 1)) state = 0;
+		if (state == 0) state = d & 7;
+		uint32_t op;
+		if (state == 0) { op = 0; --i; --j; }
+		else if (state == 1 || state == 3) { op = 2; --i; }
+		else { op = 1; --j; }
+		if (op == last_op) ++run;
+		else { if (run) out[n++] = run << 4 | last_op; last_op = op; run = 1; }
+	}
+	if (i >= 0) {
+		if (last_op == 2) run += i + 1;
+		else { if (run) out[n++] = run << 4 | last_op; last_op = 2; run = i + 1; }
+	}
+	if (j >= 0) {
+		if (last_op == 1) run += j + 1;
+		else { if (run) out[n++] = run << 4 | last_op; last_op = 1; run = j + 1; }
+	}
+	if (run) out[n++] = run << 4 | last_op;
+	return n;
+}
+
+#endif

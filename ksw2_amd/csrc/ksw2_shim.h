@@ -72,6 +72,14 @@ int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax,
 int k2a_shim_launch_trace_pk(int cfg, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb,
                              K2aResult *res, uint32_t *cig, void *stream);
 
+/* Solo packed fill (ksw2_lane_solo.h): ONE alignment per wavefront using both 16-bit halves (rows [i0,i0+C) and [i0+C,i0+2C) of
+ * a double strip), for alignments without a partner of identical shape.  K2A_SOLO_C rows per half; order[t] = pair index. */
+#define K2A_SOLO_C 8
+int k2a_shim_launch_fill_solo(int dual, int mode, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order, int ntasks,
+                              const uint8_t *seq, uint8_t *tb, K2aResult *res, void *stream);
+int k2a_shim_launch_trace_solo(const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb, K2aResult *res,
+                               uint32_t *cig, void *stream);
+
 /* Splice-aware extension (ksw2_lane_dm.h): one alignment per wavefront, diagonal-major.  pairs[i].bnd_off = dword offset
  * (in seq) of the alignment's packed per-target-position constants, tb_off = its direction bytes ((qlen+tlen-1) rows of
  * min(qlen,tlen) bytes), w / end_bonus set so that k2a_finish applies the plain start-cell rule.  The trace launch walks

@@ -13,6 +13,7 @@
 #include "ksw2_shim.h"
 #include "ksw2_lane.h"
 #include "ksw2_lane_pk.h"
+#include "ksw2_lane_solo.h"
 #include "ksw2_lane_dm.h"
 
 #define K2A_WPB 4          /* wavefronts per workgroup; waves never synchronise with each other */
@@ -267,6 +268,105 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	}
 }
 
+/* Packed-int16 fill of ONE alignment per wavefront on both register halves (ksw2_lane_solo.h): reads without a partner of
+ * identical shape.  The high half's bottom row goes to the next lane's low half (wave_ror:1 + v_alignbit), the low half's
+ * bottom row to the lane's own high half one step later. */
+template<int C, bool DUAL, int MODE>
+__global__ void __launch_bounds__(64 * K2A_WPB)
+k2a_fill_solo_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
+                     const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, K2aResult *__restrict__ res)
+{
+	typedef K2aLaneSolo<C, DUAL, MODE> Lane;
+	__shared__ K2aBook book[K2A_WPB];
+	__shared__ uint32_t stage[K2A_WPB][K2A_SOLO_STAGE(C)];
+
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int task = blockIdx.x * K2A_WPB + wave;
+	const bool valid = task < ntasks;
+	const uint32_t pi = order[valid ? task : 0];
+	const K2aPair pr = pairs[pi];
+
+	Lane L;
+	L.setup(pr, seq, lane, valid);
+	K2aBook *bk = &book[wave];
+	if (lane == 0) k2a_book_reset(bk);
+	__builtin_amdgcn_wave_barrier();
+
+	const int klast = __builtin_amdgcn_readfirstlane(L.last_step());
+	const int ktop = valid ? min(pr.qlen - 1, min(C - 1, pr.tlen - 1) + pr.w) : -1;
+	const size_t tbsteps = k2a_solo_steps<C>(pr.qlen, pr.tlen, pr.w);
+	uint8_t *tbp = tb + pr.tb_off;
+	L.qb = L.next_query_codes(-1);
+
+	for (int k = 0; k <= klast; ++k) {
+		const k2a_pk rh = (k2a_pk)k2a_rot1<64>((int)L.hout);
+		k2a_pk hin = __builtin_amdgcn_alignbit(L.hout, rh, 16);                                   /* { lane above's high half, own low half } */
+		k2a_pk ein = __builtin_amdgcn_alignbit(L.eout, (k2a_pk)k2a_rot1<64>((int)L.eout), 16);
+		k2a_pk e2in = DUAL ? __builtin_amdgcn_alignbit(L.e2out, (k2a_pk)k2a_rot1<64>((int)L.e2out), 16) : 0u;
+
+		const bool ninit = L.need_init(k);
+		if (__builtin_amdgcn_ballot_w64(ninit) != 0) {
+			const int bs = k2a_rot1<64>(L.base);
+			if (ninit) L.do_init(sc, bs);                      /* uses hu_prev = what arrived one step ago */
+		}
+		const bool nhigh = L.need_init_high(k);
+		if (__builtin_amdgcn_ballot_w64(nhigh) != 0) {
+			if (nhigh) L.init_high(sc);
+		}
+		L.hu_prev = rh;
+		hin = k2a_pk_add(hin, L.delta); ein = k2a_pk_add(ein, L.delta); if (DUAL) e2in = k2a_pk_add(e2in, L.delta);
+		const uint32_t qnext = L.next_query_codes(k);
+		if (k <= ktop) L.top_inputs(sc, k, hin, ein, e2in);
+
+		uint32_t tw[Lane::TBWORDS];
+		const bool live = L.step(sc, k, hin, ein, e2in, tw);
+		if (MODE != K2A_MODE_SCORE) {
+			if (live) {
+				uint32_t *dst = (uint32_t*)(tbp + k2a_tb_word((size_t)k, lane, tbsteps, 64, Lane::TBWORDS * 4));
+#pragma unroll
+				for (int x = 0; x + 3 < Lane::TBWORDS; x += 4) *(uint4*)(dst + x) = make_uint4(tw[x], tw[x + 1], tw[x + 2], tw[x + 3]);
+				if (Lane::TBWORDS & 2) *(uint2*)(dst + (Lane::TBWORDS & ~3)) = make_uint2(tw[Lane::TBWORDS & ~3], tw[(Lane::TBWORDS & ~3) + 1]);
+			}
+		}
+		const bool nsave = L.need_save(k);
+		if (__builtin_amdgcn_ballot_w64(nsave) != 0) {
+			if (nsave) L.save_low();
+		}
+		const bool nfin = L.need_fin(k);
+		if (__builtin_amdgcn_ballot_w64(nfin) != 0) {
+			/* one double strip ends per step at most; most fold into the book from registers, the rest take the row scan */
+			const bool slow = nfin && !L.fin_fast(sc, bk, pr.zdrop);
+			if (__builtin_amdgcn_ballot_w64(slow) != 0) {
+				if (slow) { L.stage_rows(stage[wave]); L.do_fin_seq(sc, bk, pr.zdrop, stage[wave]); }
+				__builtin_amdgcn_wave_barrier();
+				if (bk->dropped) break;
+			}
+		}
+		L.qb = qnext;
+	}
+	__builtin_amdgcn_wave_barrier();
+	if (valid && lane == 0) {
+		const K2aBook b = *bk;
+		k2a_finish(pr, b, &res[pi]);
+	}
+}
+
+template<int C>
+__global__ void __launch_bounds__(64)
+k2a_trace_solo_kernel(const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
+                      const uint8_t *__restrict__ tb, K2aResult *__restrict__ res, uint32_t *__restrict__ cig, int ppw)
+{
+	if ((int)threadIdx.x >= ppw) return;
+	const int t = blockIdx.x * ppw + threadIdx.x;
+	if (t >= ntasks) return;
+	const uint32_t pi = order[t];
+	const K2aPair pr = pairs[pi];
+	const int ti = res[pi].ti, tj = res[pi].tj;
+	int n = 0;
+	if (ti >= 0 && tj >= 0) n = k2a_trace_solo<C>(tb + pr.tb_off, ti, tj, cig + pr.cig_off, pr.qlen, pr.tlen, pr.w);
+	res[pi].n_cigar = n;
+}
+
 /* Generation-serial fill (class K2A_CFG_MP): bands too wide to keep resident.  One alignment per wavefront;
  * generation g = rows g*G*C .. (g+1)*G*C-1 over all their in-band columns.  Lane G-1 streams its bottom row
  * (H, E[, E~]) to the boundary buffer, lane 0 of the next generation streams it back in (L1-bypassing loads,
@@ -433,6 +533,10 @@ static const fill_mp_fn g_fill_mp[2][3] = {
 #define TRACE_ROW(G, C, MP) { k2a_trace_kernel<G, C, false, MP>, k2a_trace_kernel<G, C, true, MP> }
 static const trace_fn g_trace[K2A_NCFG][2] = { TRACE_ROW(16, 8, false), TRACE_ROW(64, 8, false), TRACE_ROW(64, 16, false),
                                                TRACE_ROW(64, 32, false), TRACE_ROW(64, 16, true) };
+
+static const fill_fn g_fill_solo[2][3] = {
+	{ k2a_fill_solo_kernel<K2A_SOLO_C, false, 0>, k2a_fill_solo_kernel<K2A_SOLO_C, false, 1>, k2a_fill_solo_kernel<K2A_SOLO_C, false, 2> },
+	{ k2a_fill_solo_kernel<K2A_SOLO_C, true, 0>,  k2a_fill_solo_kernel<K2A_SOLO_C, true, 1>,  k2a_fill_solo_kernel<K2A_SOLO_C, true, 2> } };
 
 /* packed walk: thread t = alignment (t & 1) of task (t >> 1) */
 template<int G, int C>
@@ -804,6 +908,27 @@ int k2a_shim_launch_trace_pk(int cfg, const K2aPair *pairs, const uint32_t *orde
 	const int ppw = k2a_trace_ppw(2 * ntasks);
 	hipLaunchKernelGGL(g_trace_pk[cfg], dim3((2 * ntasks + ppw - 1) / ppw), dim3(64), 0, (hipStream_t)stream,
 	                   pairs, order2, ntasks, tb, res, cig, ppw);
+	CHECK(hipGetLastError());
+	return 0;
+}
+
+int k2a_shim_launch_fill_solo(int dual, int mode, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order, int ntasks,
+                              const uint8_t *seq, uint8_t *tb, K2aResult *res, void *stream)
+{
+	if (ntasks <= 0) return 0;
+	if (mode < 0 || mode > 2) { snprintf(g_err, sizeof(g_err), "bad kernel class"); return -1; }
+	hipLaunchKernelGGL(g_fill_solo[dual ? 1 : 0][mode], dim3((ntasks + K2A_WPB - 1) / K2A_WPB), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
+	                   *sc, pairs, order, ntasks, seq, tb, res);
+	CHECK(hipGetLastError());
+	return 0;
+}
+
+int k2a_shim_launch_trace_solo(const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb, K2aResult *res, uint32_t *cig, void *stream)
+{
+	if (ntasks <= 0) return 0;
+	const int ppw = k2a_trace_ppw(ntasks);
+	hipLaunchKernelGGL(k2a_trace_solo_kernel<K2A_SOLO_C>, dim3((ntasks + ppw - 1) / ppw), dim3(64), 0, (hipStream_t)stream,
+	                   pairs, order, ntasks, tb, res, cig, ppw);
 	CHECK(hipGetLastError());
 	return 0;
 }

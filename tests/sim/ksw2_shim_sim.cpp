@@ -13,6 +13,7 @@
 #include "../../ksw2_amd/csrc/ksw2_shim.h"
 #include "../../ksw2_amd/csrc/ksw2_lane.h"
 #include "../../ksw2_amd/csrc/ksw2_lane_dm.h"
+#include "../../ksw2_amd/csrc/ksw2_lane_solo.h"
 #include "../../ksw2_amd/csrc/ksw2_lane_pk.h"
 
 static char g_err[256] = "";
@@ -493,6 +494,72 @@ static void sim_exts_trace(const K2aSplice sp, const K2aPair *pairs, const uint3
 }
 
 
+
+/* mirrors k2a_fill_solo_kernel: one alignment per wavefront, both halves of every lane */
+template<int C, bool DUAL, int MODE>
+static void sim_fill_solo(const K2aScoring sc, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, uint8_t *tb,
+                          K2aResult *res)
+{
+	typedef K2aLaneSolo<C, DUAL, MODE> Lane;
+	for (int task = 0; task < ntasks; ++task) {
+		const uint32_t pi = order[task];
+		const K2aPair pr = pairs[pi];
+		static Lane L[64];
+		K2aBook book;
+		uint32_t rowbuf[K2A_SOLO_STAGE(C)];
+		k2a_book_reset(&book);
+		for (int l = 0; l < 64; ++l) { L[l].setup(pr, seq, l, true); }
+		const int klast = L[0].last_step();
+		const int ktop = k2a_min(pr.qlen - 1, k2a_min(C - 1, pr.tlen - 1) + pr.w);
+		const size_t tbsteps = k2a_solo_steps<C>(pr.qlen, pr.tlen, pr.w);
+		uint8_t *tbp = tb + pr.tb_off;
+		for (int l = 0; l < 64; ++l) L[l].qb = L[l].next_query_codes(-1);
+		bool done = false;
+		for (int k = 0; k <= klast && !done; ++k) {
+			k2a_pk rh[64], re[64], re2[64];
+			int rb[64];
+			for (int l = 0; l < 64; ++l) {
+				const int src = (l + 63) & 63;
+				rh[l] = L[src].hout; re[l] = L[src].eout; re2[l] = L[src].e2out; rb[l] = L[src].base;
+			}
+			k2a_pk oh[64], oe[64], oe2[64];
+			for (int l = 0; l < 64; ++l) { oh[l] = L[l].hout; oe[l] = L[l].eout; oe2[l] = L[l].e2out; }
+			uint32_t qnext[64];
+			for (int l = 0; l < 64; ++l) {
+				if (L[l].need_init(k)) L[l].do_init(sc, rb[l]);
+				if (L[l].need_init_high(k)) L[l].init_high(sc);
+				L[l].hu_prev = rh[l];
+				k2a_pk hin = (rh[l] >> 16) | (oh[l] << 16), ein = (re[l] >> 16) | (oe[l] << 16), e2in = DUAL ? (re2[l] >> 16) | (oe2[l] << 16) : 0u;
+				hin = k2a_pk_add(hin, L[l].delta); ein = k2a_pk_add(ein, L[l].delta); if (DUAL) e2in = k2a_pk_add(e2in, L[l].delta);
+				qnext[l] = L[l].next_query_codes(k);
+				if (k <= ktop) L[l].top_inputs(sc, k, hin, ein, e2in);
+				uint32_t tw[Lane::TBWORDS];
+				const bool live = L[l].step(sc, k, hin, ein, e2in, tw);
+				if (MODE != K2A_MODE_SCORE && live)
+					memcpy(tbp + k2a_tb_word((size_t)k, l, tbsteps, 64, Lane::TBWORDS * 4), tw, sizeof(tw));
+				if (L[l].need_save(k)) L[l].save_low();
+			}
+			for (int l = 0; l < 64; ++l) {
+				if (!L[l].need_fin(k)) continue;
+				if (!L[l].fin_fast(sc, &book, pr.zdrop)) { L[l].stage_rows(rowbuf); L[l].do_fin_seq(sc, &book, pr.zdrop, rowbuf); }
+				if (book.dropped) done = true;
+			}
+			for (int l = 0; l < 64; ++l) L[l].qb = qnext[l];
+		}
+		k2a_finish(pr, book, &res[pi]);
+	}
+}
+
+template<int C>
+static void sim_trace_solo(const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb, K2aResult *res, uint32_t *cig)
+{
+	for (int task = 0; task < ntasks; ++task) {
+		const K2aPair pr = pairs[order[task]];
+		K2aResult &r = res[order[task]];
+		r.n_cigar = r.ti >= 0 ? k2a_trace_solo<C>(tb + pr.tb_off, r.ti, r.tj, cig + pr.cig_off, pr.qlen, pr.tlen, pr.w) : 0;
+	}
+}
+
 extern "C" {
 
 const char *k2a_shim_backend(void) { return "sim"; }
@@ -576,6 +643,22 @@ int k2a_shim_launch_exts_trace(const K2aSplice *sp, const K2aPair *pairs, const 
                                uint32_t *cig, void *)
 {
 	if (ntasks > 0) sim_exts_trace(*sp, pairs, order, ntasks, tb, res, cig);
+	return 0;
+}
+
+
+int k2a_shim_launch_fill_solo(int dual, int mode, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order, int ntasks,
+                              const uint8_t *seq, uint8_t *tb, K2aResult *res, void *)
+{
+	typedef void (*fn_t)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*);
+	static const fn_t fn[2][3] = { { sim_fill_solo<K2A_SOLO_C, false, 0>, sim_fill_solo<K2A_SOLO_C, false, 1>, sim_fill_solo<K2A_SOLO_C, false, 2> },
+	                               { sim_fill_solo<K2A_SOLO_C, true, 0>, sim_fill_solo<K2A_SOLO_C, true, 1>, sim_fill_solo<K2A_SOLO_C, true, 2> } };
+	if (ntasks > 0) fn[dual ? 1 : 0][mode](*sc, pairs, order, ntasks, seq, tb, res);
+	return 0;
+}
+int k2a_shim_launch_trace_solo(const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb, K2aResult *res, uint32_t *cig, void *)
+{
+	if (ntasks > 0) sim_trace_solo<K2A_SOLO_C>(pairs, order, ntasks, tb, res, cig);
 	return 0;
 }
 

@@ -369,3 +369,53 @@ def test_sim_approx_max_packed_classes(sim):
             p.close()
             check_batch(sim, dual, qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl)
     assert npk > ntot // 2
+
+
+def _solo_cases(rng, rnd, n):
+    scs = [(synth.simple_mat(5, 2, 4, -1), 4, 2, 24, 1), (synth.simple_mat(5, 1, 3, 0), 4, 1, 24, 1),
+           (synth.simple_mat(5, 2, 4, -3), 4, 2, 13, 1), (synth.simple_mat(5, 2, 5, -1), 5, 3, 20, 2)]
+    mat, q, e, q2, e2 = scs[rnd % 4]
+    pairs = synth.ragged_pairs(rng, n, 1, [120, 700, 2200, 6000][rnd % 4], sub=0.05, ind=0.12)
+    for i in range(0, n, 5):              # very uneven shapes: long leading / trailing gaps through the long piece
+        pairs[i] = (rng.integers(0, 4, int(rng.integers(1, 300))).astype(np.uint8), rng.integers(0, 4, int(rng.integers(1, 300))).astype(np.uint8))
+    if rnd % 3 == 0:
+        pairs[1] = (np.full(39, 1, np.uint8), np.full(12, 2, np.uint8))
+    qs, ts = [p[0] for p in pairs], [p[1] for p in pairs]
+    w = rng.choice([-1, 0, 1, 5, 8, 9, 15, 16, 17, 20, 30, 64, 68, 100, 284, 500], size=n)
+    zd = rng.choice([-1, 50, 200, 400], size=n)
+    eb = rng.choice([0, 10, 50], size=n)
+    return mat, q, e, q2, e2, qs, ts, w, zd, eb
+
+
+@pytest.mark.parametrize("dual", [False, True])
+def test_sim_solo_kernel(sim, dual, monkeypatch):
+    """One alignment per wavefront on both register halves (ksw2_lane_solo.h): KSW2AMD_SOLO=all sends every eligible
+    alignment there.  Ragged shapes, every band regime of the double strips, Z-drop, all three modes."""
+    monkeypatch.setenv("KSW2AMD_SOLO", "all")
+    rng = np.random.Generator(np.random.PCG64(808 + dual))
+    nsolo = ntot = 0
+    for rnd in range(9):
+        n = 20
+        mat, q, e, q2, e2, qs, ts, w, zd, eb = _solo_cases(rng, rnd, n)
+        mode = [po.SCORE_ONLY, 0, po.RIGHT][rnd % 3]
+        fl = np.array([mode | (po.EXTZ_ONLY if rng.random() < 0.3 else 0) | (po.REV_CIGAR if rng.random() < 0.3 else 0) for _ in range(n)])
+        p = sim.make_batch(qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl).plan(dual)
+        nsolo += p.packed_pairs(); ntot += n
+        p.close()
+        check_batch(sim, dual, qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl)
+    assert nsolo > ntot * 3 // 4
+
+
+def test_sim_solo_takes_unpaired_leftovers(sim, monkeypatch):
+    """KSW2AMD_SOLO=1: same-shape pairs stay on the two-per-lane kernels, alignments without a partner go solo."""
+    monkeypatch.setenv("KSW2AMD_SOLO", "1")
+    mat = synth.simple_mat(5, 2, 4, -1)
+    qs, ts = synth.fixed_batch(31, 6, 900, 880, sub=0.05, ind=0.1)
+    rng = np.random.Generator(np.random.PCG64(12))
+    extra = synth.ragged_pairs(rng, 5, 500, 1500, sub=0.05, ind=0.1)
+    qs = [x for x in qs] + [p[0] for p in extra]; ts = [x for x in ts] + [p[1] for p in extra]
+    for flag in (0, po.SCORE_ONLY):
+        p = sim.make_batch(qs, ts, mat, 4, 2, 24, 1, w=64, zdrop=400, flag=flag).plan(True)
+        assert p.packed_pairs() == 11
+        p.close()
+        check_batch(sim, True, qs, ts, mat, 4, 2, 24, 1, w=64, zdrop=400, flag=flag)
