@@ -21,6 +21,7 @@
  *                 evaluated with the scalar cell semantics above: this is the contract the
  *                 MI355X kernels implement (SURVEY.md section 8a rules 1-10).
  *   kso_exts2  <- ksw_exts2_sse ksw2_exts2_sse.c:33-415 (splice-aware; ksw2_oracle_exts.c; the SSE code is the only definition)
+ *   kso_extf2  <- ksw_extf2_sse ksw2_extf2_sse.c:11-98 (gap-linear X-drop extension; ksw2_oracle_extf.c; follows the SSE memory image)
  *   helpers    <- ksw2.h:113-123 (CIGAR push), :129-161 (traceback state machine, row-major case),
  *                 :163-182 (EQX rewrite), :184-189 (reset), :191-207 (Z-drop test)
  */
@@ -75,6 +76,10 @@ void kso_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, 
                int8_t q, int8_t e, int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, kso_extz_t *ez);
 int  kso_gg2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
              int8_t q, int8_t e, int w, int *m_cigar, int *n_cigar, uint32_t **cigar);
+
+/* gap-linear X-drop extension, score only (ksw2_extf2_sse.c:11); mch / mis / e as in the reference's signature */
+void kso_extf2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t mch, int8_t mis, int8_t e, int w, int xdrop,
+               kso_extz_t *ez);
 
 /* number of DP cells inside the exact band |i-j|<=w (SURVEY.md section 8d metric definition) */
 int64_t kso_band_cells(int qlen, int tlen, int w);

@@ -71,6 +71,7 @@ def oracle_lib():
         lib.kso_band_cells.argtypes = [_int, _int, _int]
         lib.kso_band_cells.restype = ctypes.c_int64
         lib.kso_exts2.argtypes = [_int, _u8p, _int, _u8p, _i8, _i8p, _i8, _i8, _i8, _i8, _int, _i8, _int, _u8p, ctypes.POINTER(Ez)]
+        lib.kso_extf2.argtypes = [_int, _u8p, _int, _u8p, _i8, _i8, _i8, _int, _int, ctypes.POINTER(Ez)]
         lib.kso_long_thres.argtypes = [_int, _int, _int]
         lib.kso_long_thres.restype = _int
         _cache["o"] = lib
@@ -92,6 +93,8 @@ def ref_lib():
                   ctypes.POINTER(ctypes.POINTER(ctypes.c_uint32))]
             if hasattr(lib, "ksw_exts2_sse"):
                 lib.ksw_exts2_sse.argtypes = [km, _int, _u8p, _int, _u8p, _i8, _i8p, _i8, _i8, _i8, _i8, _int, _i8, _int, _u8p, ctypes.POINTER(Ez)]
+            if hasattr(lib, "ksw_extf2_sse"):
+                lib.ksw_extf2_sse.argtypes = [km, _int, _u8p, _int, _u8p, _i8, _i8, _i8, _int, _int, ctypes.POINTER(Ez)]
             for name in ("ksw_gg", "ksw_gg2", "ksw_gg2_sse"):
                 getattr(lib, name).argtypes = gg
                 getattr(lib, name).restype = _int
@@ -222,4 +225,19 @@ def exts2(which, query, target, mat, q, e, q2, noncan, zdrop=-1, junc_bonus=0, f
         if lib is None or not hasattr(lib, "ksw_exts2_sse"):
             raise RuntimeError("oracle/_ref/libksw2ref.so not built (make -C oracle ref)")
         lib.ksw_exts2_sse(None, len(query), _p8(query), len(target), _p8(target), m, matp, q, e, q2, noncan, zdrop, junc_bonus, flag, jp, ez)
+    return _ez_to_dict(ez)
+
+
+def extf2(which, query, target, mch, mis, e, w=-1, xdrop=-1):
+    """ksw_extf2_sse (which='ref') or its restatement kso_extf2 (which='oracle'); dict of ksw_extz_t fields."""
+    query = np.ascontiguousarray(query, dtype=np.uint8)
+    target = np.ascontiguousarray(target, dtype=np.uint8)
+    ez = Ez()
+    if which == "oracle":
+        oracle_lib().kso_extf2(len(query), _p8(query), len(target), _p8(target), mch, mis, e, w, xdrop, ez)
+    else:
+        lib = ref_lib()
+        if lib is None or not hasattr(lib, "ksw_extf2_sse"):
+            raise RuntimeError("oracle/_ref/libksw2ref.so not built (make -C oracle ref)")
+        lib.ksw_extf2_sse(None, len(query), _p8(query), len(target), _p8(target), mch, mis, e, w, xdrop, ez)
     return _ez_to_dict(ez)
