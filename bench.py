@@ -27,7 +27,8 @@ from ksw2_amd import synth           # noqa: E402
 # algorithmic integer ops per cell and VALU peak (256 CU x 4 SIMD x 32 lanes x 2.4 GHz x 2 for
 # packed int16; gfx950 has no packed int8 add/max).  The int32 lane-op peak is half of that.
 OPS_PER_CELL = {("extz", True): 15, ("extz", False): 22, ("extd", True): 28, ("extd", False): 42,
-                ("exts", True): 21, ("exts", False): 31}     # extz + the long-gap state: 3 more values per cell, 3 more decisions
+                ("exts", True): 21, ("exts", False): 31,     # extz + the long-gap state: 3 more values per cell, 3 more decisions
+                ("extf", True): 7}                            # score compare/select, add, two maxima, two subtractions
 VALU_PEAK_PK16 = 157.3e12
 HBM_PEAK = 8.0e12
 
@@ -49,8 +50,11 @@ WORKLOADS = {
     # splice-aware extension: 16384 spliced pairs per GPU, 400-base query = two exons around a 1000-base GT..AG
     # intron of a 1500-base target, unbanded, forward signals, CIGAR with N; the reference CLI's splice scoring
     "exts": dict(idx=7, n=16384, qlen=400, tlen=1500, w=-1, zdrop=-1, dual=False, flag=0, sub=0.03, ind=0.0, splice=True),
+    # gap-linear X-drop extension: 16384 pairs per GPU, 1000 x 1000, band 100, no drop (every anti-diagonal runs)
+    "extf": dict(idx=8, n=16384, qlen=1000, tlen=1000, w=100, zdrop=-1, dual=False, flag=ksw2_amd.KSW_EZ_SCORE_ONLY, sub=0.05, ind=0.01, linear=True),
 }
 SCORING = dict(a=2, b=4, sc_n=-1, q=4, e=2, q2=24, e2=1)
+LINEAR_SCORING = dict(mch=2, mis=-4, e=2)
 SPLICE_SCORING = dict(a=1, b=2, sc_n=0, q=2, e=1, q2=32, noncan=4)
 
 
@@ -112,7 +116,10 @@ def cpu_baseline(wl, q, t, mat, seconds=10.0):
     if wl.get("splice"):
         name = "ksw_exts2_sse" if ref is not None and hasattr(ref, "ksw_exts2_sse") else "kso_exts2_km"
         kind = "reference" if name.startswith("ksw_") else "port"
-    fn = ctypes.cast(getattr(ref if ref is not None else olib, name), ctypes.c_void_p)
+    if wl.get("linear"):
+        name = "ksw_extf2_sse" if ref is not None and hasattr(ref, "ksw_extf2_sse") else "kso_extf2_km"
+        kind = "reference" if name.startswith("ksw_") else "port"
+    fn = ctypes.cast(getattr(ref if name.startswith("ksw_") else olib, name), ctypes.c_void_p)
     olib.kso_cpu_bench.restype = ctypes.c_long
     olib.kso_cpu_bench.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int8, ctypes.c_void_p, ctypes.c_int8, ctypes.c_int8,
@@ -121,7 +128,9 @@ def cpu_baseline(wl, q, t, mat, seconds=10.0):
         return {"value": None, "unit": "GCUPS", "cores": 0, "kind": "skipped", "sample": "ragged workload: CPU baseline loop needs fixed shapes"}
     cells_pair = synth.band_cells(wl["qlen"], wl["tlen"], wl["w"])
     S = SCORING
-    mode = 2 if wl.get("splice") else int(wl["dual"])
+    mode = 3 if wl.get("linear") else 2 if wl.get("splice") else int(wl["dual"])
+    if wl.get("linear"):
+        S = dict(q=LINEAR_SCORING["mch"], e=LINEAR_SCORING["mis"], q2=LINEAR_SCORING["e"], e2=0)
     if wl.get("splice"):
         S = dict(q=SPLICE_SCORING["q"], e=SPLICE_SCORING["e"], q2=SPLICE_SCORING["q2"], e2=SPLICE_SCORING["noncan"])
     qa, ta = np.ascontiguousarray(q), np.ascontiguousarray(t)
@@ -198,6 +207,11 @@ def main():
         wl = dict(wl, flag=wl["flag"] | ksw2_amd.KSW_EZ_SPLICE_FOR)
         batch = lib.make_splice_batch(list(q), list(t), mat, P["q"], P["e"], P["q2"], P["noncan"], zdrop=wl["zdrop"], flag=wl["flag"])
         plan = batch.plan()
+    elif wl.get("linear"):
+        P = LINEAR_SCORING
+        mat = synth.simple_mat(5, P["mch"], -P["mis"], 0)          # for the CPU leg's signature only
+        batch = lib.make_linear_batch(list(q), list(t), P["mch"], P["mis"], P["e"], w=wl["w"], xdrop=wl["zdrop"])
+        plan = batch.plan()
     else:
         mat = synth.simple_mat(5, S["a"], S["b"], 0 if wl.get("mt") else S["sc_n"])
         batch = lib.make_batch(q, t, mat, S["q"], S["e"], S["q2"], S["e2"], w=wl["w"], zdrop=wl["zdrop"], end_bonus=0, flag=wl["flag"])
@@ -237,7 +251,7 @@ def main():
 
     if rank == 0:
         score_only = bool(wl["flag"] & ksw2_amd.KSW_EZ_SCORE_ONLY)
-        ops = OPS_PER_CELL[("exts" if wl.get("splice") else "extd" if wl["dual"] else "extz", score_only)]
+        ops = OPS_PER_CELL[("extf" if wl.get("linear") else "exts" if wl.get("splice") else "extd" if wl["dual"] else "extz", score_only)]
         kern_ms = float(np.mean(total_ms))
         fill_only_ms = float(np.mean(fill_ms))
         achieved = cells * ops / (kern_ms * 1e-3)
@@ -245,8 +259,8 @@ def main():
         alg_bytes = seq_bytes + 56 * n + (0 if score_only else cells // (1 if wl["dual"] else 2))
         traffic, traffic_src = recorded_traffic(args.workload) if not args.pairs else (None, None)
         npk = plan.packed_pairs()
-        dtype = "int16x2 (packed, two alignments per lane)" if npk == n else "int32" if npk == 0 else "int16x2 + int32"
-        func = "exts2 splice-aware" if wl.get("splice") else "extd2 dual-gap" if wl["dual"] else "extz2 affine"
+        dtype = "u8 (wrapping, one position per lane)" if wl.get("linear") else "int16x2 (packed, two alignments per lane)" if npk == n else "int32" if npk == 0 else "int16x2 + int32"
+        func = "extf2 gap-linear X-drop" if wl.get("linear") else "exts2 splice-aware" if wl.get("splice") else "extd2 dual-gap" if wl["dual"] else "extz2 affine"
         out = {
             "metric": "GCUPS (DP cells/s) + pairs/s at fixed (qlen,tlen,band)",
             "value": round(cells_all * args.steps / dt / 1e9, 3), "unit": "GCUPS",

@@ -111,6 +111,15 @@ void ksw_exts2_sse41(void *km, int qlen, const uint8_t *query, int tlen, const u
 void ksw_exts2_sse2(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
                     int8_t gapo, int8_t gape, int8_t gapo2, int8_t noncan, int zdrop, int8_t junc_bonus, int flag, const uint8_t *junc, ksw_extz_t *ez);
 
+/* (ksw2.h:76) gap-linear X-drop extension, score only; replaces ksw_extf2_sse (ksw2_extf2_sse.c:11-98): match `mch`,
+ * mismatch -|mis|, gap cost e per base, band w (< 0: none), X-drop on the one cell per anti-diagonal the reference follows.
+ * Fills ez->max, max_t, max_q, score (when every anti-diagonal ran) and zdropped; the other fields stay reset.  The
+ * reference's results depend on the 16-byte blocking of its SSE loops (cells outside the band are updated too and feed
+ * the band's edge); reproduced bit for bit for its SSE4.1 build.  Targets up to 21504 residues keep their state in LDS,
+ * longer ones in HBM (slower). */
+void ksw_extf2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t mch, int8_t mis, int8_t e, int w, int xdrop,
+                   ksw_extz_t *ez);
+
 /* ------------------------------------------------------------------ Part 2: batched front-end */
 
 /* scoring shared by every pair of a batch (the arguments m, mat, q, e[, q2, e2] of the calls above) */
@@ -159,6 +168,15 @@ typedef struct {
 } ksw2amd_spair_t;
 int ksw2amd_exts_batch(void *km, const ksw2amd_splice_t *sc, int n, const ksw2amd_spair_t *pairs, ksw_extz_t *ez);
 
+/* gap-linear X-drop batches: the arguments of ksw_extf2_sse, scoring shared by the batch.  ez[i] ends up exactly as after
+ *   ksw_extf2_sse(km, pairs[i].qlen, pairs[i].query, pairs[i].tlen, pairs[i].target, mch, mis, e, pairs[i].w, pairs[i].xdrop, &ez[i]) */
+typedef struct {
+	const uint8_t *query, *target;
+	int32_t qlen, tlen;
+	int32_t w, xdrop;
+} ksw2amd_fpair_t;
+int ksw2amd_extf_batch(void *km, int8_t mch, int8_t mis, int8_t e, int n, const ksw2amd_fpair_t *pairs, ksw_extz_t *ez);
+
 /* The same in three phases, for callers that keep batches resident in HBM (and for benchmarking the
  * device part alone): create = pack + upload, run = kernels only (asynchronous on `stream`, a hipStream_t
  * or NULL), fetch = wait + download + fill ez[]. */
@@ -176,6 +194,8 @@ int64_t ksw2amd_plan_device_bytes(const ksw2amd_plan_t *plan);
 int64_t ksw2amd_plan_packed_pairs(const ksw2amd_plan_t *plan);
 /* a resident plan of splice-aware extensions; run / fetch / timing / cells / destroy as above */
 ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, const ksw2amd_spair_t *pairs);
+/* a resident plan of gap-linear X-drop extensions; run / fetch / timing / cells / destroy as above */
+ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n, const ksw2amd_fpair_t *pairs);
 /* raw device results without the host-side ez[] assembly: 16 int32 per pair
  * {max, zdropped, max_q, max_t, mqe, mqe_t, mte, mte_q, score, reach_end, n_cigar, rows_done, ti, tj, 0, 0} */
 int  ksw2amd_plan_fetch_raw(ksw2amd_plan_t *plan, int32_t *out16);

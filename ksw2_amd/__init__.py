@@ -43,6 +43,12 @@ class SplicePair(ctypes.Structure):
                 ("tlen", ctypes.c_int32), ("zdrop", ctypes.c_int32), ("flag", ctypes.c_int32)]
 
 
+class LinearPair(ctypes.Structure):
+    """ksw2amd_fpair_t: the per-call arguments of ksw_extf2_sse."""
+    _fields_ = [("query", ctypes.c_void_p), ("target", ctypes.c_void_p), ("qlen", ctypes.c_int32), ("tlen", ctypes.c_int32),
+                ("w", ctypes.c_int32), ("xdrop", ctypes.c_int32)]
+
+
 class Pair(ctypes.Structure):
     _fields_ = [("query", ctypes.c_void_p), ("target", ctypes.c_void_p), ("qlen", ctypes.c_int32), ("tlen", ctypes.c_int32),
                 ("w", ctypes.c_int32), ("zdrop", ctypes.c_int32), ("end_bonus", ctypes.c_int32), ("flag", ctypes.c_int32)]
@@ -60,7 +66,8 @@ EXPORTS = ["ksw_extz2_sse", "ksw_extd2_sse", "ksw_gg2", "ksw_gg2_sse", "ksw_extz
            "ksw2amd_last_error", "ksw2amd_backend", "ksw2amd_device_count", "ksw2amd_set_device", "ksw2amd_release_cache",
            "ksw2amd_extz_batch", "ksw2amd_extd_batch", "ksw2amd_plan_create", "ksw2amd_plan_run", "ksw2amd_plan_fetch",
            "ksw2amd_plan_destroy", "ksw2amd_plan_timing", "ksw2amd_plan_cells", "ksw2amd_plan_device_bytes", "ksw2amd_plan_packed_pairs",
-           "ksw2amd_plan_fetch_raw", "ksw_exts2_sse", "ksw_exts2_sse41", "ksw_exts2_sse2", "ksw2amd_exts_batch", "ksw2amd_exts_plan_create"]
+           "ksw2amd_plan_fetch_raw", "ksw_exts2_sse", "ksw_exts2_sse41", "ksw_exts2_sse2", "ksw2amd_exts_batch", "ksw2amd_exts_plan_create",
+           "ksw_extf2_sse", "ksw2amd_extf_batch", "ksw2amd_extf_plan_create"]
 KSW_EZ_SPLICE_FOR, KSW_EZ_SPLICE_REV, KSW_EZ_SPLICE_FLANK = 0x100, 0x200, 0x400
 
 
@@ -117,6 +124,11 @@ class Library:
         L.ksw2amd_exts_batch.argtypes = [km, ctypes.POINTER(SpliceScoring), _int, ctypes.POINTER(SplicePair), ezp]
         L.ksw2amd_exts_plan_create.argtypes = [ctypes.POINTER(SpliceScoring), _int, ctypes.POINTER(SplicePair)]
         L.ksw2amd_exts_plan_create.restype = ctypes.c_void_p
+        L.ksw_extf2_sse.argtypes = [km, _int, _u8p, _int, _u8p, _i8, _i8, _i8, _int, _int, ezp]
+        L.ksw_extf2_sse.restype = None
+        L.ksw2amd_extf_batch.argtypes = [km, _i8, _i8, _i8, _int, ctypes.POINTER(LinearPair), ezp]
+        L.ksw2amd_extf_plan_create.argtypes = [_i8, _i8, _i8, _int, ctypes.POINTER(LinearPair)]
+        L.ksw2amd_extf_plan_create.restype = ctypes.c_void_p
         L.ksw2amd_last_error.restype = ctypes.c_char_p
         L.ksw2amd_backend.restype = ctypes.c_char_p
         L.ksw2amd_set_device.argtypes = [_int]
@@ -192,6 +204,21 @@ class Library:
         ez = KswExtz()
         self.lib.ksw_exts2_sse(None, len(qa), qp, len(ta), tp, m, mat.ctypes.data_as(_i8p), q, e, q2, noncan, zdrop, junc_bonus, flag, jp, ez)
         return ez_to_dict(ez, free_cigar=True)
+
+    def extf2(self, query, target, mch, mis, e, w=-1, xdrop=-1):
+        """ksw_extf2_sse(km=NULL, ...): gap-linear X-drop extension, score only -> dict of ksw_extz_t fields."""
+        qa, qp = self._seq(query)
+        ta, tp = self._seq(target)
+        ez = KswExtz()
+        self.lib.ksw_extf2_sse(None, len(qa), qp, len(ta), tp, mch, mis, e, w, xdrop, ez)
+        return ez_to_dict(ez, free_cigar=True)
+
+    def make_linear_batch(self, queries, targets, mch, mis, e, w=-1, xdrop=-1):
+        return LinearBatch(self, queries, targets, mch, mis, e, w, xdrop)
+
+    def extf_batch(self, queries, targets, mch, mis, e, **kw):
+        """ksw2amd_extf_batch: n independent gap-linear X-drop extensions -> list of dicts."""
+        return self.make_linear_batch(queries, targets, mch, mis, e, **kw).run_oneshot()
 
     def make_splice_batch(self, queries, targets, mat, q, e, q2, noncan, zdrop=-1, junc_bonus=0, flag=0, juncs=None, m=None):
         return SpliceBatch(self, queries, targets, mat, q, e, q2, noncan, zdrop, junc_bonus, flag, juncs, m)
@@ -304,6 +331,29 @@ class Batch:
 
     def plan(self, dual):
         return Plan(self, dual)
+
+
+class LinearBatch:
+    """Arguments of n ksw_extf2_sse calls with shared scoring, kept alive for the C side."""
+
+    def __init__(self, L, queries, targets, mch, mis, e, w, xdrop):
+        self.L = L
+        self.n = n = len(queries)
+        self.par = (mch, mis, e)
+        self.qs = [np.ascontiguousarray(x, dtype=np.uint8) for x in queries]
+        self.ts = [np.ascontiguousarray(x, dtype=np.uint8) for x in targets]
+        w, xdrop = _per_pair(w, n), _per_pair(xdrop, n)
+        self.pairs = (LinearPair * max(n, 1))()
+        for i in range(n):
+            self.pairs[i] = LinearPair(self.qs[i].ctypes.data, self.ts[i].ctypes.data, len(self.qs[i]), len(self.ts[i]), int(w[i]), int(xdrop[i]))
+
+    def run_oneshot(self):
+        ez = (KswExtz * max(self.n, 1))()
+        self.L._check(self.L.lib.ksw2amd_extf_batch(None, *self.par, self.n, self.pairs, ez))
+        return [ez_to_dict(ez[i], free_cigar=True) for i in range(self.n)]
+
+    def plan(self):
+        return Plan(self, False, handle=self.L.lib.ksw2amd_extf_plan_create(*self.par, self.n, self.pairs))
 
 
 class SpliceBatch:

@@ -200,6 +200,9 @@ struct ksw2amd_plan_s {
 	/* splice-aware plans (ksw2amd_exts_plan_create): tasks of h_order grouped by kernel mode x matrix variant */
 	int splice, s_first[3][2][3], s_count[3][2][3];   /* [mode][matrix variant][window class: 8 slots, 16 slots, state in HBM] */
 	K2aSplice s_par[2];
+	/* gap-linear X-drop plans (ksw2amd_extf_plan_create, splice == 2): tasks grouped by where the state arrays live */
+	int f_first[4], f_count[4];
+	K2aExtf f_par;
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -666,11 +669,13 @@ err:
 }
 
 static int exts_plan_run(ksw2amd_plan_t *p, void *stream);
+static int extf_plan_run(ksw2amd_plan_t *p, void *stream);
 
 int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 {
 	int c;
 	if (!p) return fail(KSW2AMD_E_PARAM, "plan_run: NULL plan%s", 0);
+	if (p->splice == 2) return extf_plan_run(p, stream);
 	if (p->splice) return exts_plan_run(p, stream);
 	p->stream = stream; p->ran = 1; p->stream_used = 1;
 	if (p->reject_all || p->ntasks == 0) return KSW2AMD_OK;
@@ -852,6 +857,11 @@ int ksw2amd_plan_fetch(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez)
 		ksw_extz_t *z = &ez[i];
 		const K2aResult *r = &p->h_res[i];
 		ez_reset(z);
+		if (p->splice == 2 && p->h_cls[i] < 0) {          /* an empty sequence: ksw2_extf2_sse.c:33 runs no anti-diagonal, :37 leaves at the first */
+			if (imax(p->h_pairs[i].qlen, 0) + imax(p->h_pairs[i].tlen, 0) == 1) z->score = 0;
+			else z->zdropped = 1;
+			continue;
+		}
 		if (p->reject_all || p->h_cls[i] < 0) continue;
 		z->max = (uint32_t)r->max; z->zdropped = (uint32_t)r->zdropped;
 		z->max_q = r->max_q; z->max_t = r->max_t; z->mqe = r->mqe; z->mqe_t = r->mqe_t;
@@ -1279,3 +1289,131 @@ void ksw_exts2_sse41(void *km, int qlen, const uint8_t *query, int tlen, const u
 void ksw_exts2_sse2(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
                     int8_t q, int8_t e, int8_t q2, int8_t noncan, int zdrop, int8_t junc_bonus, int flag, const uint8_t *junc, ksw_extz_t *ez)
 { ksw_exts2_sse(km, qlen, query, tlen, target, m, mat, q, e, q2, noncan, zdrop, junc_bonus, flag, junc, ez); }
+
+/* ---------------------------------------------------------------- gap-linear X-drop extension (ksw_extf2_sse) */
+
+#define EXTF_LDS_T0 1024
+#define EXTF_LDS_T1 4096
+#define EXTF_LDS_T2 21504          /* 3 x 21504 bytes = 63 KiB of LDS for one wavefront */
+
+ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n, const ksw2amd_fpair_t *pairs)
+{
+	ksw2amd_plan_t *p;
+	int i, c;
+	size_t off = 0;
+	uint32_t fill[4];
+	void *up;
+
+	g_err[0] = 0;
+	if (n < 0 || (n > 0 && !pairs)) { fail(KSW2AMD_E_PARAM, "extf: bad arguments%s", 0); return 0; }
+	if (k2a_shim_device_count() <= 0) { fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend()); return 0; }
+	p = (ksw2amd_plan_t*)calloc(1, sizeof(*p));
+	p->splice = 2; p->n = n;
+	p->h_cls = (int8_t*)malloc((size_t)n + 1);
+	p->h_half = (uint8_t*)calloc((size_t)n + 1, 1);
+	p->h_flag = (int32_t*)calloc((size_t)n + 1, sizeof(int32_t));
+	p->h_pairs = (K2aPair*)calloc((size_t)n + 1, sizeof(K2aPair));
+	p->h_res = (K2aResult*)calloc((size_t)n + 1, sizeof(K2aResult));
+	p->h_order = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n + 1));
+	p->f_par.mch = mch; p->f_par.mis = mis < 0 ? mis : -mis; p->f_par.e = e;      /* ksw2_extf2_sse.c:18-20 */
+	for (i = 0; i < n; ++i) {
+		const ksw2amd_fpair_t *a = &pairs[i];
+		K2aPair *d = &p->h_pairs[i];
+		p->h_cls[i] = -1;
+		d->qlen = a->qlen; d->tlen = d->tlen_full = a->tlen;
+		if (a->qlen <= 0 || a->tlen <= 0) continue;
+		if (!a->query || !a->target) { fail(KSW2AMD_E_PARAM, "extf: NULL sequence%s", 0); goto err; }
+		d->w = a->w < 0 ? imax(a->qlen, a->tlen) : a->w;                             /* ksw2_extf2_sse.c:23 */
+		d->zdrop = a->xdrop;
+		c = a->tlen <= EXTF_LDS_T0 ? 0 : a->tlen <= EXTF_LDS_T1 ? 1 : a->tlen <= EXTF_LDS_T2 ? 2 : 3;
+		if (getenv("KSW2AMD_EXTF_HBM")) c = 3;            /* tests: every pair through the HBM-state kernel */
+		if (c == 3) { d->tb_off = p->tb_bytes; p->tb_bytes += align_up(3 * align_up((size_t)a->tlen, 16), 256); }
+		p->h_cls[i] = (int8_t)c; ++p->f_count[c];
+		off = align_up(off, 4); d->qoff = (uint32_t)off; off += (size_t)a->qlen;
+		off = align_up(off, 4); d->toff = (uint32_t)off; off += (size_t)a->tlen;
+		if (off > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "extf: more than 4 GiB of sequence in one plan%s", 0); goto err; }
+		p->cells += band_cells(a->qlen, a->tlen, d->w);
+	}
+	for (c = 0, i = 0; c < 4; ++c) { p->f_first[c] = i; fill[c] = (uint32_t)i; i += p->f_count[c]; }
+	p->ntasks = p->norder = i;
+	if (p->ntasks == 0) return p;
+	p->seq_bytes = align_up(off + 256, 256);
+	p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, p->seq_bytes, &p->cap[BUF_HSEQ]);
+	if (!p->h_seq) { fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
+	for (i = 0; i < n; ++i) {
+		if (p->h_cls[i] < 0) continue;
+		memcpy(p->h_seq + p->h_pairs[i].qoff, pairs[i].query, (size_t)pairs[i].qlen);
+		memcpy(p->h_seq + p->h_pairs[i].toff, pairs[i].target, (size_t)pairs[i].tlen);
+		p->h_order[fill[p->h_cls[i]]++] = (uint32_t)i;
+	}
+	p->d_seq = (uint8_t*)cache_get(BUF_SEQ, p->seq_bytes, &p->cap[BUF_SEQ]);
+	p->d_pairs = (K2aPair*)cache_get(BUF_PAIRS, sizeof(K2aPair) * ((size_t)n + 1), &p->cap[BUF_PAIRS]);
+	p->d_res = (K2aResult*)cache_get(BUF_RES, sizeof(K2aResult) * ((size_t)n + 1), &p->cap[BUF_RES]);
+	p->d_order = (uint32_t*)cache_get(BUF_ORDER, sizeof(uint32_t) * ((size_t)p->norder + 1), &p->cap[BUF_ORDER]);
+	p->d_tb = p->tb_bytes ? (uint8_t*)cache_get(BUF_TB, p->tb_bytes, &p->cap[BUF_TB]) : 0;
+	if (!p->d_seq || !p->d_pairs || !p->d_res || !p->d_order || (p->tb_bytes && !p->d_tb)) {
+		fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error());
+		goto err;
+	}
+	up = thread_stream();
+	p->stream = up; p->stream_used = 1;
+	if (k2a_shim_h2d(p->d_seq, p->h_seq, p->seq_bytes, up) || k2a_shim_h2d(p->d_pairs, p->h_pairs, sizeof(K2aPair) * (size_t)n, up) ||
+	    k2a_shim_h2d(p->d_order, p->h_order, sizeof(uint32_t) * (size_t)p->norder, up) ||
+	    k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)n, up) || k2a_shim_stream_sync(up)) {
+		fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error());
+		goto err;
+	}
+	for (i = 0; i < 3; ++i) { p->ev[i] = g_ev_cache[i] ? g_ev_cache[i] : k2a_shim_event_create(); g_ev_cache[i] = 0; }
+	return p;
+err:
+	ksw2amd_plan_destroy(p);
+	return 0;
+}
+
+static int extf_plan_run(ksw2amd_plan_t *p, void *stream)
+{
+	int c;
+	p->stream = stream; p->ran = 1; p->stream_used = 1;
+	if (p->ntasks == 0) return KSW2AMD_OK;
+	if (k2a_shim_event_record(p->ev[0], stream)) goto err;
+	for (c = 3; c >= 0; --c)                           /* longest targets first */
+		if (p->f_count[c] && k2a_shim_launch_extf(c, &p->f_par, p->d_pairs, p->d_order + p->f_first[c], p->f_count[c], p->d_seq, p->d_tb, p->d_res, stream))
+			goto err;
+	if (k2a_shim_event_record(p->ev[1], stream) || k2a_shim_event_record(p->ev[2], stream)) goto err;
+	return KSW2AMD_OK;
+err:
+	return fail(KSW2AMD_E_NODEVICE, "extf run: %s", k2a_shim_last_error());
+}
+
+int ksw2amd_extf_batch(void *km, int8_t mch, int8_t mis, int8_t e, int n, const ksw2amd_fpair_t *pairs, ksw_extz_t *ez)
+{
+	int beg = 0;
+	if (n <= 0) return KSW2AMD_OK;
+	if (k2a_shim_device_count() <= 0) return fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend());
+	while (beg < n) {
+		ksw2amd_plan_t *p;
+		size_t seq = 0;
+		int end, rc;
+		for (end = beg; end < n; ++end) {
+			const size_t b = (size_t)imax(pairs[end].qlen, 0) + 4 * (size_t)imax(pairs[end].tlen, 0) + 64;
+			if (end > beg && (seq + b > 3000000000u || end - beg >= (1 << 22))) break;
+			seq += b;
+		}
+		p = ksw2amd_extf_plan_create(mch, mis, e, end - beg, pairs + beg);
+		if (!p) return strstr(g_err, "alloc") ? KSW2AMD_E_NOMEM : strstr(g_err, "device") ? KSW2AMD_E_NODEVICE : KSW2AMD_E_PARAM;
+		rc = ksw2amd_plan_run(p, thread_stream());
+		if (rc == KSW2AMD_OK) rc = ksw2amd_plan_fetch(p, km, ez + beg);
+		ksw2amd_plan_destroy(p);
+		if (rc) return rc;
+		beg = end;
+	}
+	return KSW2AMD_OK;
+}
+
+void ksw_extf2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t mch, int8_t mis, int8_t e, int w, int xdrop,
+                   ksw_extz_t *ez)
+{
+	ksw2amd_fpair_t pr;
+	pr.query = query; pr.target = target; pr.qlen = qlen; pr.tlen = tlen; pr.w = w; pr.xdrop = xdrop;
+	if (ksw2amd_extf_batch(km, mch, mis, e, 1, &pr, ez) != KSW2AMD_OK) die_loudly("ksw_extf2_sse");
+}

@@ -1,0 +1,80 @@
+/*
+ * ksw2_lane_extf.h -- per-position code of the gap-linear X-drop extension (replaces ksw_extf2_sse, ksw2_extf2_sse.c:11-98;
+ * SURVEY section 8f row N3), shared by the gfx950 kernel (ksw2_shim_hip.hip) and the lock-step simulator (tests/sim).
+ *
+ * The reference keeps three byte arrays over target positions -- U, V (difference encoding of the anti-diagonal DP, 8-bit
+ * wrapping arithmetic) and S (match / mismatch score on the current anti-diagonal) -- and updates them in 16-byte blocks
+ * around the in-band range [lo, hi] of anti-diagonal r.  Positions of those blocks outside [lo, hi] are updated as well,
+ * from whatever S holds there, and the band's edge cells read them on later anti-diagonals: the result depends on the
+ * blocking, so the kernel reproduces it position by position.  One alignment per wavefront, lane <-> target position,
+ * 64 positions per pass over [blo, bhi]; U, V, S live in LDS (HBM scratch for targets over 21 k); V's left neighbour comes
+ * through a one-lane shift with the previous pass's last V carried in.  The score follows one cell per anti-diagonal
+ * (ksw2_extf2_sse.c:80-92): wavefront-uniform work on two bytes.
+ */
+#ifndef KSW2_LANE_EXTF_H_
+#define KSW2_LANE_EXTF_H_
+
+#include "ksw2_lane.h"
+
+/* in-band target positions of anti-diagonal r (ksw2_extf2_sse.c:35-41), the 16-aligned block range around them (:42) and
+ * the end of the positions whose S is recomputed (:48-61: chunks of 16 from lo, clipped to the padded array) */
+struct K2aExtfDiag {
+	int lo, hi, blo, bhi, fresh_end;
+};
+K2A_FN bool k2a_extf_diag(int r, int qlen, int tlen, int w, int tpad, K2aExtfDiag &d)
+{
+	d.lo = k2a_max3(0, r - qlen + 1, (r - w + 1) >> 1);
+	d.hi = k2a_min(k2a_min(tlen - 1, r), (r + w) >> 1);
+	if (d.lo > d.hi) return false;
+	d.blo = d.lo & ~15; d.bhi = d.hi | 15;
+	d.fresh_end = k2a_min(tpad, d.lo + ((d.hi - d.lo) / 16 + 1) * 16);
+	return true;
+}
+
+/* S of position x on anti-diagonal r: codes read 0 past the target's end and outside the query (the reference's zeroed padding) */
+K2A_FN uint32_t k2a_extf_score(const K2aExtf &par, const uint8_t *qa, const uint8_t *ta, int qlen, int tlen, int r, int x)
+{
+	const int j = r - x;
+	const uint32_t tc = x < tlen ? ta[x] : 0u, qc = (j >= 0 && j < qlen) ? qa[j] : 0u;
+	return (uint32_t)(tc == qc ? par.mch : par.mis) & 0xffu;
+}
+
+/* one position (ksw2_extf2_sse.c:64-78, SSE4.1 build): a = V of the position below on the previous anti-diagonal, b = U */
+K2A_FN void k2a_extf_cell(uint32_t s, uint32_t a, uint32_t b, uint32_t two_e, uint32_t &u, uint32_t &v)
+{
+	uint32_t z = (s + two_e) & 0xffu;
+	if ((int8_t)z < (int8_t)a) z = a;
+	if (z < b) z = b;
+	u = (z - a) & 0xffu; v = (z - b) & 0xffu;
+}
+
+/* the followed cell (ksw2_extf2_sse.c:80-92); vf = V[follow], un = U[follow + 1] after the update.  Returns false on X-drop. */
+struct K2aExtfBook {
+	int32_t H0, follow, max, max_t, max_q;
+};
+K2A_FN void k2a_extf_book_reset(K2aExtfBook &b) { b.H0 = 0; b.follow = 0; b.max = 0; b.max_t = b.max_q = -1; }
+K2A_FN bool k2a_extf_follow(K2aExtfBook &b, const K2aExtfDiag &d, int r, int e, int xdrop, uint32_t vf, uint32_t un)
+{
+	if (r == 0) { b.H0 = (int)vf - e - e; b.follow = 0; return true; }          /* vf = V[0] */
+	const bool in0 = b.follow >= d.lo && b.follow <= d.hi, in1 = b.follow + 1 >= d.lo && b.follow + 1 <= d.hi;
+	if (in0 && in1) {
+		const int d0 = (int)vf - e, d1 = (int)un - e;
+		if (d0 > d1) b.H0 += d0;
+		else { b.H0 += d1; ++b.follow; }
+	} else if (in0) b.H0 += (int)vf - e;
+	else { ++b.follow; b.H0 += (int)un - e; }
+	if (b.H0 > b.max) { b.max = b.H0; b.max_t = b.follow; b.max_q = r - b.follow; }
+	else if (xdrop >= 0 && b.max - b.H0 > xdrop) return false;
+	return true;
+}
+
+K2A_FN void k2a_extf_finish(const K2aExtfBook &b, bool complete, K2aResult *r)
+{
+	r->max = b.max; r->max_t = b.max_t; r->max_q = b.max_q;
+	r->zdropped = complete ? 0 : 1;
+	r->score = complete ? b.H0 : K2A_NEG;
+	r->mqe = r->mte = K2A_NEG; r->mqe_t = r->mte_q = -1;
+	r->reach_end = 0; r->n_cigar = 0; r->rows_done = 0; r->ti = r->tj = -1;
+}
+
+#endif

@@ -91,6 +91,12 @@ int k2a_shim_launch_exts(int mode, int win, const K2aSplice *sp, const K2aPair *
 int k2a_shim_launch_exts_trace(const K2aSplice *sp, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb,
                                K2aResult *res, uint32_t *cig, void *stream);
 
+/* Gap-linear X-drop extension (ksw2_lane_extf.h): one alignment per wavefront; class 0..2 keep the three state arrays in LDS
+ * (targets up to 1024 / 4096 / 21504 residues), class 3 in `scratch` (3 x 16-padded target length bytes at pairs[i].tb_off).
+ * pairs[i].zdrop = the X-drop threshold, pairs[i].w the band resolved as in ksw2_extf2_sse.c:23. */
+int k2a_shim_launch_extf(int cls, const K2aExtf *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
+                         uint8_t *scratch, K2aResult *res, void *stream);
+
 /* Compaction: pool[pos[i] .. pos[i]+res[i].n_cigar) = cig[pairs[i].cig_off ..) for the n pairs of a plan
  * (pos = exclusive prefix sum of n_cigar, computed by the host), so that one D2H brings every CIGAR back. */
 int k2a_shim_launch_compact(const K2aPair *pairs, const K2aResult *res, const uint32_t *pos, int n, const uint32_t *cig,

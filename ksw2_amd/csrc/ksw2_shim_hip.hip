@@ -15,6 +15,7 @@
 #include "ksw2_lane_pk.h"
 #include "ksw2_lane_solo.h"
 #include "ksw2_lane_dm.h"
+#include "ksw2_lane_extf.h"
 
 #define K2A_WPB 4          /* wavefronts per workgroup; waves never synchronise with each other */
 /* The traceback walk is a chain of dependent loads and a few dozen instructions per step on ONE lane; what it needs is many
@@ -764,6 +765,65 @@ k2a_exts_trace_kernel(const K2aSplice sp, const K2aPair *__restrict__ pairs, con
 	res[pi].n_cigar = n;
 }
 
+/* ---------------------------------------------------------------- gap-linear X-drop extension (ksw2_lane_extf.h) */
+
+/* One alignment per wavefront (one wavefront per workgroup: the LDS a workgroup asks for decides how many share a CU).
+ * STATE_HBM = false: U, V, S (3 x padded target length bytes) in dynamic LDS; true: in `scratch` at pairs[i].tb_off. */
+template<bool STATE_HBM>
+__global__ void __launch_bounds__(64)
+k2a_extf_kernel(const K2aExtf par, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
+                const uint8_t *__restrict__ seq, uint8_t *__restrict__ scratch, K2aResult *__restrict__ res)
+{
+	extern __shared__ uint8_t k2a_extf_lds[];
+	const int lane = threadIdx.x;
+	const uint32_t pi = order[blockIdx.x];
+	const K2aPair pr = pairs[pi];
+	const int qlen = pr.qlen, tlen = pr.tlen, w = pr.w, xdrop = pr.zdrop;
+	const int tpad = (tlen + 15) & ~15;
+	const uint8_t *qa = seq + pr.qoff, *ta = seq + pr.toff;
+	uint8_t *U = STATE_HBM ? scratch + pr.tb_off : k2a_extf_lds, *V = U + tpad, *S = V + tpad;
+	const uint32_t two_e = (uint32_t)(par.e * 2) & 0xffu;
+
+	for (int x = lane * 4; x < 3 * tpad; x += 256) *(uint32_t*)(U + x) = 0u;      /* the reference's kcalloc (ksw2_extf2_sse.c:25) */
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+	K2aExtfBook bk;
+	k2a_extf_book_reset(bk);
+	int prev_lo = -1, prev_hi = -1, r;
+	const int nr = qlen + tlen - 1;
+	for (r = 0; r < nr; ++r) {
+		K2aExtfDiag d;
+		if (!k2a_extf_diag(r, qlen, tlen, w, tpad, d)) break;
+		int carry = (d.blo > 0 && d.blo - 1 >= prev_lo && d.blo - 1 <= prev_hi) ? __builtin_amdgcn_readfirstlane((int)V[d.blo - 1]) : 0;
+		const int last = k2a_max(d.bhi, d.fresh_end - 1);
+		const bool top0 = d.bhi >= r;                       /* ksw2_extf2_sse.c:46: U of the anti-diagonal's first-row cell reads 0 */
+		for (int base = d.blo; base <= last; base += 64) {
+			const int x = base + lane;
+			const bool act = x <= d.bhi, fresh = x >= d.lo && x < d.fresh_end;
+			uint32_t vold = 0, b = 0, sv = 0;
+			if (act) { vold = V[x]; b = U[x]; }
+			if (fresh) sv = k2a_extf_score(par, qa, ta, qlen, tlen, r, x);
+			else if (act) sv = S[x];
+			if (top0 && x == r) b = 0;
+			const uint32_t a = (uint32_t)k2a_shr1_carry((int)vold, carry);
+			carry = __builtin_amdgcn_readlane((int)vold, 63);
+			uint32_t u, v;
+			k2a_extf_cell(sv, a, b, two_e, u, v);
+			if (act) { U[x] = (uint8_t)u; V[x] = (uint8_t)v; }
+			if (fresh) S[x] = (uint8_t)sv;
+		}
+		/* positions move between lanes from one anti-diagonal to the next (blo moves in steps of 16) */
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		const uint32_t vf = (uint32_t)__builtin_amdgcn_readfirstlane((int)V[bk.follow]);
+		const uint32_t un = (uint32_t)__builtin_amdgcn_readfirstlane((int)U[bk.follow + 1]);
+		if (!k2a_extf_follow(bk, d, r, par.e, xdrop, vf, un)) break;
+		prev_lo = d.blo; prev_hi = d.bhi;
+	}
+	if (lane == 0) k2a_extf_finish(bk, r == nr, &res[pi]);
+}
+
 typedef void (*fill_pk_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*);
 #define PK_ROW(G, C, RB, NM) { { k2a_fill_pk_kernel<G, C, false, 0, RB, NM>, k2a_fill_pk_kernel<G, C, false, 1, RB, NM>, k2a_fill_pk_kernel<G, C, false, 2, RB, NM> }, \
                                { k2a_fill_pk_kernel<G, C, true, 0, RB, NM>,  k2a_fill_pk_kernel<G, C, true, 1, RB, NM>,  k2a_fill_pk_kernel<G, C, true, 2, RB, NM> } }
@@ -960,6 +1020,22 @@ int k2a_shim_launch_exts_trace(const K2aSplice *sp, const K2aPair *pairs, const 
 	const int ppw = k2a_trace_ppw(ntasks);
 	hipLaunchKernelGGL(k2a_exts_trace_kernel, dim3((ntasks + ppw - 1) / ppw), dim3(64), 0, (hipStream_t)stream,
 	                   *sp, pairs, order, ntasks, tb, res, cig, ppw);
+	CHECK(hipGetLastError());
+	return 0;
+}
+
+/* cls 0..2: state in LDS (targets up to 1024 / 4096 / 21504 residues), 3: state in `scratch` (3 x padded length bytes at
+ * pairs[i].tb_off) */
+int k2a_shim_launch_extf(int cls, const K2aExtf *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
+                         uint8_t *scratch, K2aResult *res, void *stream)
+{
+	static const int lds_bytes[4] = { 3 * 1024, 3 * 4096, 3 * 21504, 0 };
+	if (ntasks <= 0) return 0;
+	if (cls < 0 || cls > 3) { snprintf(g_err, sizeof(g_err), "bad kernel class"); return -1; }
+	if (cls == 3)
+		hipLaunchKernelGGL(k2a_extf_kernel<true>, dim3(ntasks), dim3(64), 0, (hipStream_t)stream, *par, pairs, order, ntasks, seq, scratch, res);
+	else
+		hipLaunchKernelGGL(k2a_extf_kernel<false>, dim3(ntasks), dim3(64), lds_bytes[cls], (hipStream_t)stream, *par, pairs, order, ntasks, seq, scratch, res);
 	CHECK(hipGetLastError());
 	return 0;
 }

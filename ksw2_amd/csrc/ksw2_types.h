@@ -46,6 +46,11 @@ typedef struct K2aSplice {
 	const int8_t *mat;           /* device copy of the effective m x m matrix, mat[target*m + query] */
 } K2aSplice;
 
+/* batch-uniform parameters of the gap-linear X-drop extension (ksw2_lane_extf.h), passed by value */
+typedef struct K2aExtf {
+	int32_t mch, mis, e;         /* mis <= 0 (ksw2_extf2_sse.c:20) */
+} K2aExtf;
+
 /* one alignment, device-resident */
 typedef struct K2aPair {
 	uint32_t qoff, toff;         /* byte offsets of query / target in the sequence arena                  */

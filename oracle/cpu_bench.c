@@ -31,6 +31,9 @@ typedef struct {
 	pthread_mutex_t mu;
 } job_t;
 
+typedef void (*extf2_fn)(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t mch, int8_t mis, int8_t e, int w,
+                         int xdrop, kso_extz_t *ez);
+
 static double now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
 
 static void *worker(void *arg)
@@ -43,7 +46,8 @@ static void *worker(void *arg)
 	while (now() - t0 < J->seconds) {
 		long i = __sync_fetch_and_add(&J->next, 1) % J->n;
 		const uint8_t *q = J->q + (size_t)i * J->qlen, *t = J->t + (size_t)i * J->tlen;
-		if (J->dual == 2) ((exts2_fn)J->fn)(0, J->qlen, q, J->tlen, t, J->m, J->mat, J->gq, J->ge, J->gq2, J->ge2, J->zdrop, 0, J->flag, 0, &ez);
+		if (J->dual == 3) ((extf2_fn)J->fn)(0, J->qlen, q, J->tlen, t, J->gq, J->ge, J->gq2, J->w, J->zdrop, &ez);      /* mch, mis, e */
+		else if (J->dual == 2) ((exts2_fn)J->fn)(0, J->qlen, q, J->tlen, t, J->m, J->mat, J->gq, J->ge, J->gq2, J->ge2, J->zdrop, 0, J->flag, 0, &ez);
 		else if (J->dual) ((extd2_fn)J->fn)(0, J->qlen, q, J->tlen, t, J->m, J->mat, J->gq, J->ge, J->gq2, J->ge2, J->w, J->zdrop, 0, J->flag, &ez);
 		else ((extz2_fn)J->fn)(0, J->qlen, q, J->tlen, t, J->m, J->mat, J->gq, J->ge, J->w, J->zdrop, 0, J->flag, &ez);
 		++mine;
@@ -83,3 +87,6 @@ void kso_extd2_km(void *km, int qlen, const uint8_t *query, int tlen, const uint
 void kso_exts2_km(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
                   int8_t q, int8_t e, int8_t q2, int8_t noncan, int zdrop, int8_t junc_bonus, int flag, const uint8_t *junc, kso_extz_t *ez)
 { (void)km; kso_exts2(qlen, query, tlen, target, m, mat, q, e, q2, noncan, zdrop, junc_bonus, flag, junc, ez); }
+void kso_extf2_km(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t mch, int8_t mis, int8_t e, int w, int xdrop,
+                  kso_extz_t *ez)
+{ (void)km; kso_extf2(qlen, query, tlen, target, mch, mis, e, w, xdrop, ez); }

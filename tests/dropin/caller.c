@@ -30,6 +30,7 @@ int main(void)
 		if (strcmp(algo, "extz2") == 0) ksw_extz2_sse(km, ql, q, tl, t, 5, mat, 4, 2, w, zdrop, 10, flag, &ez);
 		else if (strcmp(algo, "extd2") == 0) ksw_extd2_sse(km, ql, q, tl, t, 5, mat, 4, 2, 24, 1, w, zdrop, 10, flag, &ez);
 		else if (strcmp(algo, "exts2") == 0) ksw_exts2_sse(km, ql, q, tl, t, 5, mat, 4, 2, 32, 4, zdrop, 0, flag | KSW_EZ_SPLICE_FOR, 0, &ez);
+		else if (strcmp(algo, "extf2") == 0) ksw_extf2_sse(km, ql, q, tl, t, 2, -4, 2, w, zdrop, &ez);
 		else if (strcmp(algo, "gg2") == 0) {
 			ez.score = ksw_gg2_sse(km, ql, q, tl, t, 5, mat, 4, 2, w, &ez.m_cigar, &ez.n_cigar, &ez.cigar);
 			ez.max = 0; ez.zdropped = 0; ez.max_q = ez.max_t = ez.mqe_t = ez.mte_q = -1; ez.mqe = ez.mte = KSW_NEG_INF; ez.reach_end = 0;

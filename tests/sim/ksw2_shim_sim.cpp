@@ -7,6 +7,7 @@
  */
 #include <assert.h>
 #include <chrono>
+#include <vector>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -14,6 +15,7 @@
 #include "../../ksw2_amd/csrc/ksw2_lane.h"
 #include "../../ksw2_amd/csrc/ksw2_lane_dm.h"
 #include "../../ksw2_amd/csrc/ksw2_lane_solo.h"
+#include "../../ksw2_amd/csrc/ksw2_lane_extf.h"
 #include "../../ksw2_amd/csrc/ksw2_lane_pk.h"
 
 static char g_err[256] = "";
@@ -560,6 +562,53 @@ static void sim_trace_solo(const K2aPair *pairs, const uint32_t *order, int ntas
 	}
 }
 
+/* mirrors k2a_extf_kernel: one alignment per wavefront, passes of 64 target positions, V's neighbour through the lane shift */
+static void sim_extf(const K2aExtf par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, uint8_t *scratch,
+                     K2aResult *res, bool state_hbm)
+{
+	for (int task = 0; task < ntasks; ++task) {
+		const uint32_t pi = order[task];
+		const K2aPair pr = pairs[pi];
+		const int qlen = pr.qlen, tlen = pr.tlen, w = pr.w, xdrop = pr.zdrop, tpad = (tlen + 15) & ~15;
+		const uint8_t *qa = seq + pr.qoff, *ta = seq + pr.toff;
+		std::vector<uint8_t> lds((size_t)3 * tpad + 16);
+		uint8_t *U = state_hbm ? scratch + pr.tb_off : lds.data(), *V = U + tpad, *S = V + tpad;
+		const uint32_t two_e = (uint32_t)(par.e * 2) & 0xffu;
+		memset(U, 0, (size_t)3 * tpad);
+		K2aExtfBook bk;
+		k2a_extf_book_reset(bk);
+		int prev_lo = -1, prev_hi = -1, r;
+		const int nr = qlen + tlen - 1;
+		for (r = 0; r < nr; ++r) {
+			K2aExtfDiag d;
+			if (!k2a_extf_diag(r, qlen, tlen, w, tpad, d)) break;
+			uint32_t carry = (d.blo > 0 && d.blo - 1 >= prev_lo && d.blo - 1 <= prev_hi) ? V[d.blo - 1] : 0u;
+			const int last = k2a_max(d.bhi, d.fresh_end - 1);
+			const bool top0 = d.bhi >= r;
+			for (int base = d.blo; base <= last; base += 64) {
+				uint32_t vold[64], b[64], sv[64], u[64], v[64];
+				for (int lane = 0; lane < 64; ++lane) {         /* loads of the whole wavefront first, as on the GPU */
+					const int x = base + lane;
+					const bool act = x <= d.bhi, fresh = x >= d.lo && x < d.fresh_end;
+					vold[lane] = act ? V[x] : 0u; b[lane] = act ? U[x] : 0u;
+					sv[lane] = fresh ? k2a_extf_score(par, qa, ta, qlen, tlen, r, x) : act ? S[x] : 0u;
+					if (top0 && x == r) b[lane] = 0;
+				}
+				for (int lane = 0; lane < 64; ++lane) k2a_extf_cell(sv[lane], lane ? vold[lane - 1] : carry, b[lane], two_e, u[lane], v[lane]);
+				carry = vold[63];
+				for (int lane = 0; lane < 64; ++lane) {
+					const int x = base + lane;
+					if (x <= d.bhi) { U[x] = (uint8_t)u[lane]; V[x] = (uint8_t)v[lane]; }
+					if (x >= d.lo && x < d.fresh_end) S[x] = (uint8_t)sv[lane];
+				}
+			}
+			if (!k2a_extf_follow(bk, d, r, par.e, xdrop, V[bk.follow], U[bk.follow + 1])) break;
+			prev_lo = d.blo; prev_hi = d.bhi;
+		}
+		k2a_extf_finish(bk, r == nr, &res[pi]);
+	}
+}
+
 extern "C" {
 
 const char *k2a_shim_backend(void) { return "sim"; }
@@ -612,6 +661,12 @@ int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_
                           K2aResult *res, uint32_t *cig, void *)
 {
 	if (ntasks > 0) g_trace[cfg][dual ? 1 : 0](pairs, order, ntasks, tb, res, cig);
+	return 0;
+}
+int k2a_shim_launch_extf(int cls, const K2aExtf *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
+                         uint8_t *scratch, K2aResult *res, void *)
+{
+	if (ntasks > 0) sim_extf(*par, pairs, order, ntasks, seq, scratch, res, cls == 3);
 	return 0;
 }
 int k2a_shim_launch_compact(const K2aPair *pairs, const K2aResult *res, const uint32_t *pos, int n, const uint32_t *cig,

@@ -30,7 +30,7 @@ def test_caller_built_against_reference_header(tmp_path, kalloc):
     lines, expect = [], []
     for k in range(40):
         (q, t), = synth.ragged_pairs(rng, 1, 5, 400, sub=0.05, ind=0.1, n_rate=0.01 if k % 4 == 0 else 0.0)
-        algo = ["extz2", "extd2", "exts2", "gg2"][k % 4]
+        algo = ["extz2", "extd2", "exts2", "gg2", "extf2"][k % 5]
         w = int(rng.choice([-1, 50, 500])) if algo != "gg2" else -1
         zd = int(rng.choice([-1, 100])) if algo != "gg2" else -1
         flag = int(rng.choice([0, po.RIGHT, po.EXTZ_ONLY, po.REV_CIGAR])) if algo != "gg2" else 0
@@ -39,6 +39,8 @@ def test_caller_built_against_reference_header(tmp_path, kalloc):
             e = po.align("oracle", "extz2", q, t, mat, 4, 2, w=w, zdrop=zd, end_bonus=10, flag=flag)
         elif algo == "extd2":
             e = po.align("oracle", "extd2", q, t, mat, 4, 2, 24, 1, w=w, zdrop=zd, end_bonus=10, flag=flag)
+        elif algo == "extf2":
+            e = po.extf2("oracle", q, t, 2, -4, 2, w, zd)
         elif algo == "exts2":
             e = po.exts2("oracle", q, t, mat, 4, 2, 32, 4, zdrop=zd, flag=flag | po.SPLICE_FOR)
         else:

@@ -466,6 +466,7 @@ def test_cli_matches_reference_cli(lib):
     runs = [(["-t", "extz"], t1, q1), (["-t", "extd"], t1, q1), (["-t", "extz", "-r"], t1, q1), (["-t", "extd", "-s"], t1, q1),
             (["-t", "gg"], t1, q1), (["-t", "gg2"], t1, q1), (["-t", "extz", "-A1", "-B3", "-O5", "-E1"], t1, q1), (["-t", "extd", "-a"], t1, q1),
             (["-t", "exts2_sse"], t1, q1), (["-t", "exts2_sse", "-r"], t1, q1), (["-t", "exts2_sse", "-z", "100"], t1, q1),
+            (["-t", "extf2_sse"], t1, q1), (["-t", "extf2_sse", "-z", "30", "-w", "20"], t1, q1), (["-t", "extf2_sse", "-w", "500"], mh, mo),
             (["-t", "extz", "-w", "500"], mh, mo), (["-t", "extd", "-w", "500", "-r"], mh, mo), (["-t", "extz"], mh, mo), (["-t", "gg2", "-s"], mh, mo)]
     for opts, t, q in runs:
         a = subprocess.run([ours] + opts + [t, q], capture_output=True, text=True)
@@ -591,3 +592,45 @@ def test_solo_long_reads_and_leftovers(lib, monkeypatch):
         assert p.packed_pairs() == 20
         p.close()
         check_batch(lib, dual, qs, ts, mat, 4, 2, 24, 1, w=300, zdrop=400, flag=flag)
+
+
+@pytest.mark.parametrize("hbm", [False, True])
+def test_linear_xdrop_golden(lib, hbm, monkeypatch):
+    """All 2000 ksw_extf2_sse cases produced by the compiled reference (tests/golden/extf_cases.npz), batched by scoring;
+    hbm: the same through the kernel that keeps U, V, S in HBM scratch (targets over 21504 residues take it in production)."""
+    if hbm:
+        monkeypatch.setenv("KSW2AMD_EXTF_HBM", "1")
+    fc = gu.ExtfCases()
+    cases = [fc.case(k) for k in range(fc.n)]
+    ndrop = 0
+    for sc in sorted({(c["mch"], c["mis"], c["e"]) for c in cases}):
+        sub = [c for c in cases if (c["mch"], c["mis"], c["e"]) == sc]
+        res = lib.extf_batch([c["q"] for c in sub], [c["t"] for c in sub], *sc, w=[c["w"] for c in sub], xdrop=[c["xdrop"] for c in sub])
+        for r, c in zip(res, sub):
+            assert not diff(r, c["expect"], gu.FIELDS), (sc, len(c["q"]), len(c["t"]), c["w"], c["xdrop"])
+            ndrop += r["zdropped"]
+    assert ndrop > 200
+    c = cases[7]
+    assert not diff(lib.extf2(c["q"], c["t"], c["mch"], c["mis"], c["e"], c["w"], c["xdrop"]), c["expect"], gu.FIELDS)
+
+
+def test_linear_xdrop_long_and_empty(lib):
+    """Every state class against the oracle: targets of 1 k / 4 k / 20 k (LDS) and 30 k (HBM), banded and not, X-drop on and
+    off, a diverging tail that triggers the drop; empty sequences."""
+    rng = np.random.Generator(np.random.PCG64(606))
+    qs, ts, ws, xs = [], [], [], []
+    for tl, w, xd in ((1000, -1, -1), (1024, 100, 50), (1025, 33, -1), (4096, 500, 100), (5000, 64, -1), (20000, 200, 300), (21504, 16, -1),
+                      (21505, 100, -1), (30000, 300, 200), (30000, 50, -1)):
+        (q, t), = synth.ragged_pairs(rng, 1, tl, tl, sub=0.04, ind=0.02)
+        t = t[:tl] if len(t) >= tl else np.concatenate([t, rng.integers(0, 4, tl - len(t)).astype(np.uint8)])
+        if xd >= 0:
+            q = np.concatenate([q[: len(q) * 2 // 3], rng.integers(0, 4, len(q) // 3).astype(np.uint8)])
+        qs.append(q); ts.append(t); ws.append(w); xs.append(xd)
+    res = lib.extf_batch(qs, ts, 2, -4, 2, w=ws, xdrop=xs)
+    for i, r in enumerate(res):
+        exp = po.extf2("oracle", qs[i], ts[i], 2, -4, 2, ws[i], xs[i])
+        assert not diff(r, exp, gu.FIELDS), (i, len(qs[i]), len(ts[i]), ws[i], xs[i], {f: (r[f], exp[f]) for f in diff(r, exp, gu.FIELDS)})
+    assert sum(r["zdropped"] for r in res) >= 2 and sum(not r["zdropped"] for r in res) >= 2
+    e = np.zeros(0, np.uint8); one = np.array([2], np.uint8); five = (np.arange(5) % 4).astype(np.uint8)
+    for q, t in ((e, e), (one, e), (e, one), (five, e), (e, five), (one, one)):
+        assert not diff(lib.extf2(q, t, 2, -4, 2, -1, 50), po.extf2("oracle", q, t, 2, -4, 2, -1, 50), gu.FIELDS), (len(q), len(t))

@@ -419,3 +419,24 @@ def test_sim_solo_takes_unpaired_leftovers(sim, monkeypatch):
         assert p.packed_pairs() == 11
         p.close()
         check_batch(sim, True, qs, ts, mat, 4, 2, 24, 1, w=64, zdrop=400, flag=flag)
+
+
+def test_sim_linear_xdrop_golden_and_batches(sim, monkeypatch):
+    """ksw_extf2_sse through the simulator build: every 4th reference case one by one, the rest as one batch (LDS-state
+    classes), the same batch again with the state arrays in HBM scratch, empty sequences."""
+    fc = gu.ExtfCases()
+    cases = [fc.case(k) for k in range(fc.n)]
+    for c in cases[::4]:
+        r = sim.extf2(c["q"], c["t"], c["mch"], c["mis"], c["e"], c["w"], c["xdrop"])
+        assert not diff(r, c["expect"], gu.FIELDS), (len(c["q"]), len(c["t"]), c["w"], c["xdrop"])
+    for hbm in (False, True):
+        if hbm:
+            monkeypatch.setenv("KSW2AMD_EXTF_HBM", "1")
+        for sc in sorted({(c["mch"], c["mis"], c["e"]) for c in cases}):
+            sub = [c for c in cases if (c["mch"], c["mis"], c["e"]) == sc][:: 3 if hbm else 1]
+            res = sim.extf_batch([c["q"] for c in sub], [c["t"] for c in sub], *sc, w=[c["w"] for c in sub], xdrop=[c["xdrop"] for c in sub])
+            for r, c in zip(res, sub):
+                assert not diff(r, c["expect"], gu.FIELDS), (sc, len(c["q"]), len(c["t"]), c["w"], c["xdrop"])
+    e = np.zeros(0, np.uint8); one = np.array([2], np.uint8); five = np.arange(5, dtype=np.uint8) % 4
+    for q, t in ((e, e), (one, e), (e, one), (five, e), (e, five), (one, one)):
+        assert not diff(sim.extf2(q, t, 2, -4, 2, -1, 50), po.extf2("oracle", q, t, 2, -4, 2, -1, 50), gu.FIELDS), (len(q), len(t))

@@ -3,7 +3,7 @@
  * (cli.c:159-259: getopt "t:w:R:rsgz:A:B:O:E:Ka", output cli.c:134-145), running every algorithm through
  * libksw2_amd.so (MI355X).  Lets a user A/B the two implementations byte for byte on stdout:
  *
- *     ksw2-test-amd [-t extz|extz2_sse|extd|extd2_sse|exts2_sse|gg|gg2|gg2_sse] [-w band] [-z zdrop] [-r] [-s] [-g]
+ *     ksw2-test-amd [-t extz|extz2_sse|extd|extd2_sse|exts2_sse|extf2_sse|gg|gg2|gg2_sse] [-w band] [-z zdrop] [-r] [-s] [-g]
  *                   [-A match] [-B mismatch] [-O gapo[,gapo2]] [-E gape[,gape2]] [-R rep] [-a] [-b] <target.fa> <query.fa>
  *
  * Own code: plain FASTA/FASTQ-less reader (one record per '>' header; .gz is not supported), ACGT -> 0..3, other -> 4
@@ -121,7 +121,7 @@ int main(int argc, char *argv[])
 	}
 	if (argc - optind < 2) {
 		fprintf(stderr, "Usage: ksw2-test-amd [-t algo] [-w band] [-z zdrop] [-rsgab] [-A a] [-B b] [-O o1[,o2]] [-E e1[,e2]] [-R rep] <target.fa> <query.fa>\n");
-		fprintf(stderr, "  algorithms: extz extz2_sse extd extd2_sse exts2_sse gg gg2 gg2_sse (all evaluated on the GPU by libksw2_amd, backend %s)\n", ksw2amd_backend());
+		fprintf(stderr, "  algorithms: extz extz2_sse extd extd2_sse exts2_sse extf2_sse gg gg2 gg2_sse (all evaluated on the GPU by libksw2_amd, backend %s)\n", ksw2amd_backend());
 		return 1;
 	}
 	gen_simple_mat(5, mat, a, b);
@@ -183,6 +183,7 @@ int main(int argc, char *argv[])
 					for (y = 0; y < 5; ++y) smat[x * 5 + y] = (int8_t)((x == 4 || y == 4) ? 0 : x == y ? 1 : -2);
 				ksw_exts2_sse(0, ql, qs, tl, ts, 5, smat, 2, 1, 32, 4, zdrop, 0, flag | KSW_EZ_SPLICE_FOR, 0, &ez);
 			}
+			else if (strcmp(algo, "extf2_sse") == 0) ksw_extf2_sse(0, ql, qs, tl, ts, mat[0], mat[1], e, w, zdrop, &ez);     /* cli.c:78 */
 			else { fprintf(stderr, "ERROR: can't find algorithm '%s'\n", algo); return 1; }
 		}
 		print_aln(tr->name, qr->name, &ez);
