@@ -201,7 +201,7 @@ struct ksw2amd_plan_s {
 	int splice, s_first[3][2][3], s_count[3][2][3];   /* [mode][matrix variant][window class: 8 slots, 16 slots, state in HBM] */
 	K2aSplice s_par[2];
 	/* gap-linear X-drop plans (ksw2amd_extf_plan_create, splice == 2): tasks grouped by where the state arrays live */
-	int f_first[4], f_count[4];
+	int f_first[6], f_count[6];
 	K2aExtf f_par;
 };
 
@@ -1299,9 +1299,9 @@ void ksw_exts2_sse2(void *km, int qlen, const uint8_t *query, int tlen, const ui
 ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n, const ksw2amd_fpair_t *pairs)
 {
 	ksw2amd_plan_t *p;
-	int i, c;
+	int i, c, span;
 	size_t off = 0;
-	uint32_t fill[4];
+	uint32_t fill[6];
 	void *up;
 
 	g_err[0] = 0;
@@ -1326,6 +1326,9 @@ ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n
 		d->w = a->w < 0 ? imax(a->qlen, a->tlen) : a->w;                             /* ksw2_extf2_sse.c:23 */
 		d->zdrop = a->xdrop;
 		c = a->tlen <= EXTF_LDS_T0 ? 0 : a->tlen <= EXTF_LDS_T1 ? 1 : a->tlen <= EXTF_LDS_T2 ? 2 : 3;
+		/* narrow bands run from registers: at most min(w + 1, qlen, tlen) positions of an anti-diagonal are inside the band */
+		span = imin(imin(a->qlen, a->tlen), d->w < 0x7ffffff0 ? d->w + 1 : d->w);
+		if (!getenv("KSW2AMD_EXTF_LDS")) c = span <= K2A_EXTF_WIN_SPAN(4) ? 4 : span <= K2A_EXTF_WIN_SPAN(8) ? 5 : c;
 		if (getenv("KSW2AMD_EXTF_HBM")) c = 3;            /* tests: every pair through the HBM-state kernel */
 		if (c == 3) { d->tb_off = p->tb_bytes; p->tb_bytes += align_up(3 * align_up((size_t)a->tlen, 16), 256); }
 		p->h_cls[i] = (int8_t)c; ++p->f_count[c];
@@ -1334,7 +1337,7 @@ ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n
 		if (off > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "extf: more than 4 GiB of sequence in one plan%s", 0); goto err; }
 		p->cells += band_cells(a->qlen, a->tlen, d->w);
 	}
-	for (c = 0, i = 0; c < 4; ++c) { p->f_first[c] = i; fill[c] = (uint32_t)i; i += p->f_count[c]; }
+	for (c = 0, i = 0; c < 6; ++c) { p->f_first[c] = i; fill[c] = (uint32_t)i; i += p->f_count[c]; }
 	p->ntasks = p->norder = i;
 	if (p->ntasks == 0) return p;
 	p->seq_bytes = align_up(off + 256, 256);
@@ -1376,7 +1379,7 @@ static int extf_plan_run(ksw2amd_plan_t *p, void *stream)
 	p->stream = stream; p->ran = 1; p->stream_used = 1;
 	if (p->ntasks == 0) return KSW2AMD_OK;
 	if (k2a_shim_event_record(p->ev[0], stream)) goto err;
-	for (c = 3; c >= 0; --c)                           /* longest targets first */
+	for (c = 5; c >= 0; --c)
 		if (p->f_count[c] && k2a_shim_launch_extf(c, &p->f_par, p->d_pairs, p->d_order + p->f_first[c], p->f_count[c], p->d_seq, p->d_tb, p->d_res, stream))
 			goto err;
 	if (k2a_shim_event_record(p->ev[1], stream) || k2a_shim_event_record(p->ev[2], stream)) goto err;

@@ -68,6 +68,31 @@ K2A_FN bool k2a_extf_follow(K2aExtfBook &b, const K2aExtfDiag &d, int r, int e, 
 	return true;
 }
 
+
+/* ---- register window (k2a_extf_win_kernel<K>): K slots of 64 positions per wavefront, position x in lane x & 63 of slot
+ * (x >> 6) & (K - 1).  The window starts at the 64-block of blo - 16 (the followed cell may sit one position below lo, the
+ * carry into blo one below blo) and must reach hi + 15 (the padded block and the S refresh): 64 K >= in-band span + 109 (K2A_EXTF_WIN_SPAN, ksw2_types.h). */
+K2A_FN int k2a_extf_win_base(const K2aExtfDiag &d) { return k2a_max(0, d.blo - 16) >> 6; }
+/* block held by slot s when the window starts at block wb */
+template<int K> K2A_FN int k2a_extf_win_block(int wb, int s) { return wb + ((s - wb) & (K - 1)); }
+
+/* one position of one slot: vshift = old V of position x - 1 (what the lane shift delivers), qc = query code of (r, x).
+ * tcode reads 0 past the target's end, qc 0 outside the query (the caller's job).  Updates u / v / sreg in place where the
+ * reference would write them. */
+K2A_FN void k2a_extf_win_cell(const K2aExtf &par, const K2aExtfDiag &d, int r, int x, uint32_t two_e, bool carry_ok,
+                              uint32_t tcode, uint32_t qc, uint32_t vshift, uint32_t &u, uint32_t &v, uint32_t &sreg)
+{
+	/* unsigned range tests: x - lo < n  <=>  lo <= x < lo + n */
+	const bool act = (uint32_t)(x - d.blo) <= (uint32_t)(d.bhi - d.blo), fresh = (uint32_t)(x - d.lo) < (uint32_t)(d.fresh_end - d.lo);
+	const uint32_t sv = fresh ? ((uint32_t)(tcode == qc ? par.mch : par.mis) & 0xffu) : sreg;
+	const uint32_t a = (x == d.blo && !carry_ok) ? 0u : vshift;
+	const uint32_t b = (d.bhi >= r && x == r) ? 0u : u;
+	uint32_t nu, nv;
+	k2a_extf_cell(sv, a, b, two_e, nu, nv);
+	if (act) { u = nu; v = nv; }
+	sreg = sv;
+}
+
 K2A_FN void k2a_extf_finish(const K2aExtfBook &b, bool complete, K2aResult *r)
 {
 	r->max = b.max; r->max_t = b.max_t; r->max_q = b.max_q;

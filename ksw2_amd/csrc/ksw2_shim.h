@@ -93,6 +93,7 @@ int k2a_shim_launch_exts_trace(const K2aSplice *sp, const K2aPair *pairs, const 
 
 /* Gap-linear X-drop extension (ksw2_lane_extf.h): one alignment per wavefront; class 0..2 keep the three state arrays in LDS
  * (targets up to 1024 / 4096 / 21504 residues), class 3 in `scratch` (3 x 16-padded target length bytes at pairs[i].tb_off).
+ * Class 4 / 5: register window of 4 / 8 slots, for alignments whose band never holds more than K2A_EXTF_WIN_SPAN(K) positions.
  * pairs[i].zdrop = the X-drop threshold, pairs[i].w the band resolved as in ksw2_extf2_sse.c:23. */
 int k2a_shim_launch_extf(int cls, const K2aExtf *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
                          uint8_t *scratch, K2aResult *res, void *stream);

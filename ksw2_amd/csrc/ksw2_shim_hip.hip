@@ -39,6 +39,18 @@ static int set_err(hipError_t e, const char *what)
 }
 #define CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return set_err(e_, #call); } while (0)
 
+/* The wavefront index, optionally as a scalar.  With one alignment per wavefront the compiler can then keep everything
+ * derived from the task (lengths, band, pointers, strip schedule) in SGPRs: 25-40 fewer VGPRs, often one more resident
+ * wavefront -- but the work moves to the scalar unit, which the four SIMDs of a CU share, and its latency sits in front
+ * of every step.  Measured per kernel on one box, back to back (tools/scripts/ab_variants.sh): splice-aware kernels +23 %,
+ * int32 strips of config 3's shape +12 % (2 -> 3 wavefronts), packed (64, 8) +4 %, generation-serial +2 %, solo neutral;
+ * packed (64, 16) -1 % (score only) to -4 % (two-piece with traceback), X-drop register window -14 %: those stay vector. */
+template<bool UNIFORM>
+__device__ __forceinline__ int k2a_wave_id()
+{
+	return UNIFORM ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
+}
+
 template<int G>
 __device__ __forceinline__ int k2a_rot1(int v)
 {
@@ -69,7 +81,7 @@ k2a_fill_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const ui
 	if (sc.m > 5) for (int x = threadIdx.x; x < sc.m * sc.m; x += blockDim.x) mtab[x] = sc.mat[x];
 	__syncthreads();
 
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63, wave = k2a_wave_id<true>();
 	const int grp = lane / G, gl = lane % G;
 	const int task = (blockIdx.x * K2A_WPB + wave) * NG + grp;
 	const bool valid = task < ntasks;
@@ -156,7 +168,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	__shared__ K2aBook book[K2A_WPB][NG][2];
 	__shared__ uint32_t stage[K2A_WPB][(NG * K2A_PK_STAGE(C) > 64 * 5) ? NG * K2A_PK_STAGE(C) : 64 * 5];   /* row buffers / final lane records */
 
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63, wave = k2a_wave_id<(C <= 8)>();
 	const int grp = lane / G, gl = lane % G;
 	const int task = (blockIdx.x * K2A_WPB + wave) * NG + grp;
 	const bool valid = task < ntasks;
@@ -281,7 +293,7 @@ k2a_fill_solo_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 	__shared__ K2aBook book[K2A_WPB];
 	__shared__ uint32_t stage[K2A_WPB][K2A_SOLO_STAGE(C)];
 
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63, wave = k2a_wave_id<true>();
 	const int task = blockIdx.x * K2A_WPB + wave;
 	const bool valid = task < ntasks;
 	const uint32_t pi = order[valid ? task : 0];
@@ -387,7 +399,7 @@ k2a_fill_mp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	if (sc.m > 5) for (int x = threadIdx.x; x < sc.m * sc.m; x += blockDim.x) mtab[x] = sc.mat[x];
 	__syncthreads();
 
-	const int gl = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int gl = threadIdx.x & 63, wave = k2a_wave_id<true>();
 	const int task = blockIdx.x * K2A_WPB + wave;
 	const bool valid = task < ntasks;
 	const uint32_t pi = order[valid ? task : 0];
@@ -601,7 +613,7 @@ k2a_exts_kernel(const K2aSplice sp, const K2aPair *__restrict__ pairs, const uin
 	for (int x = threadIdx.x; x < sp.m * sp.m; x += blockDim.x) mtab[x] = sp.mat[x];
 	__syncthreads();
 
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63, wave = k2a_wave_id<true>();
 	const int task = blockIdx.x * K2A_WPB + wave;
 	if (task >= ntasks) return;                       /* whole wavefronts leave; nobody synchronises below */
 	const uint32_t pi = order[task];
@@ -695,7 +707,7 @@ k2a_exts_big_kernel(const K2aSplice sp, const K2aPair *__restrict__ pairs, const
 	for (int x = threadIdx.x; x < sp.m * sp.m; x += blockDim.x) mtab[x] = sp.mat[x];
 	__syncthreads();
 
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63, wave = k2a_wave_id<true>();
 	const int task = blockIdx.x * K2A_WPB + wave;
 	if (task >= ntasks) return;
 	const uint32_t pi = order[task];
@@ -818,6 +830,78 @@ k2a_extf_kernel(const K2aExtf par, const K2aPair *__restrict__ pairs, const uint
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 		const uint32_t vf = (uint32_t)__builtin_amdgcn_readfirstlane((int)V[bk.follow]);
 		const uint32_t un = (uint32_t)__builtin_amdgcn_readfirstlane((int)U[bk.follow + 1]);
+		if (!k2a_extf_follow(bk, d, r, par.e, xdrop, vf, un)) break;
+		prev_lo = d.blo; prev_hi = d.bhi;
+	}
+	if (lane == 0) k2a_extf_finish(bk, r == nr, &res[pi]);
+}
+
+/* Register-window form: bands up to K2A_EXTF_WIN_SPAN(K) positions wide.  U, V, S and the target code of K x 64 positions
+ * stay in registers; the window slides up a 64-block at a time (a block entering it is all zero, like the reference's
+ * fresh allocation); no LDS, no fences.  Slots are visited in a fixed order: every slot's old V of lane 63 is taken first,
+ * so slot s finds its left neighbour in slot s - 1 whatever block that holds. */
+template<int K>
+__global__ void __launch_bounds__(64 * K2A_WPB)
+k2a_extf_win_kernel(const K2aExtf par, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
+                    const uint8_t *__restrict__ seq, K2aResult *__restrict__ res)
+{
+	const int lane = threadIdx.x & 63, wave = k2a_wave_id<false>();
+	const int task = blockIdx.x * K2A_WPB + wave;
+	if (task >= ntasks) return;
+	const uint32_t pi = order[task];
+	const K2aPair pr = pairs[pi];
+	const int qlen = pr.qlen, tlen = pr.tlen, w = pr.w, xdrop = pr.zdrop;
+	const int tpad = (tlen + 15) & ~15;
+	const uint8_t *qa = seq + pr.qoff, *ta = seq + pr.toff;
+	const uint32_t two_e = (uint32_t)(par.e * 2) & 0xffu;
+
+	uint32_t U[K], V[K], S[K], T[K];
+	int wb_cur = 0;
+#pragma unroll
+	for (int s = 0; s < K; ++s) { U[s] = V[s] = S[s] = 0u; T[s] = 64 * s + lane < tlen ? ta[64 * s + lane] : 0u; }
+
+	K2aExtfBook bk;
+	k2a_extf_book_reset(bk);
+	int prev_lo = -1, prev_hi = -1, r;
+	const int nr = qlen + tlen - 1;
+	for (r = 0; r < nr; ++r) {
+		K2aExtfDiag d;
+		if (!k2a_extf_diag(r, qlen, tlen, w, tpad, d)) break;
+		const int wb = __builtin_amdgcn_readfirstlane(k2a_extf_win_base(d));
+		const bool carry_ok = d.blo > 0 && d.blo - 1 >= prev_lo && d.blo - 1 <= prev_hi;
+		const int last = k2a_max(d.bhi, d.fresh_end - 1);
+		if (wb != wb_cur) {                                   /* a block left the window: its slot takes the next one above */
+#pragma unroll
+			for (int s = 0; s < K; ++s) {
+				const int nb = k2a_extf_win_block<K>(wb, s);
+				if (nb != k2a_extf_win_block<K>(wb_cur, s)) {
+					U[s] = V[s] = S[s] = 0u;
+					T[s] = 64 * nb + lane < tlen ? ta[64 * nb + lane] : 0u;
+				}
+			}
+			wb_cur = wb;
+		}
+		int c63[K];
+#pragma unroll
+		for (int s = 0; s < K; ++s) c63[s] = __builtin_amdgcn_readlane((int)V[s], 63);
+		const int jl = r - lane;                               /* query index of the lane's position in block 0 */
+#pragma unroll
+		for (int s = 0; s < K; ++s) {
+			const int base = 64 * k2a_extf_win_block<K>(wb, s);
+			if (base > last || base + 63 < d.blo) continue;
+			const int x = base + lane, j = jl - base;
+			const uint32_t jc = (uint32_t)j < (uint32_t)qlen ? (uint32_t)j : 0u;
+			const uint32_t qc = (uint32_t)j < (uint32_t)qlen ? (uint32_t)qa[jc] : 0u;
+			const uint32_t vshift = (uint32_t)k2a_shr1_carry((int)V[s], c63[(s + K - 1) & (K - 1)]);
+			k2a_extf_win_cell(par, d, r, x, two_e, carry_ok, T[s], qc, vshift, U[s], V[s], S[s]);
+		}
+		/* the followed cell: V[follow], U[follow + 1] out of their slots (follow >= lo - 1, inside the window) */
+		const int fs = (bk.follow >> 6) & (K - 1), gs = ((bk.follow + 1) >> 6) & (K - 1);
+		uint32_t vsel = V[0], usel = U[0];
+#pragma unroll
+		for (int s = 1; s < K; ++s) { if (fs == s) vsel = V[s]; if (gs == s) usel = U[s]; }
+		const uint32_t vf = (uint32_t)__builtin_amdgcn_readlane((int)vsel, bk.follow & 63);
+		const uint32_t un = (uint32_t)__builtin_amdgcn_readlane((int)usel, (bk.follow + 1) & 63);
 		if (!k2a_extf_follow(bk, d, r, par.e, xdrop, vf, un)) break;
 		prev_lo = d.blo; prev_hi = d.bhi;
 	}
@@ -1025,14 +1109,18 @@ int k2a_shim_launch_exts_trace(const K2aSplice *sp, const K2aPair *pairs, const 
 }
 
 /* cls 0..2: state in LDS (targets up to 1024 / 4096 / 21504 residues), 3: state in `scratch` (3 x padded length bytes at
- * pairs[i].tb_off) */
+ * pairs[i].tb_off), 4 / 5: state in registers (bands up to K2A_EXTF_WIN_SPAN(4 / 8) positions) */
 int k2a_shim_launch_extf(int cls, const K2aExtf *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
                          uint8_t *scratch, K2aResult *res, void *stream)
 {
 	static const int lds_bytes[4] = { 3 * 1024, 3 * 4096, 3 * 21504, 0 };
 	if (ntasks <= 0) return 0;
-	if (cls < 0 || cls > 3) { snprintf(g_err, sizeof(g_err), "bad kernel class"); return -1; }
-	if (cls == 3)
+	if (cls < 0 || cls > 5) { snprintf(g_err, sizeof(g_err), "bad kernel class"); return -1; }
+	if (cls >= 4) {
+		const int blocks = (ntasks + K2A_WPB - 1) / K2A_WPB;
+		if (cls == 4) hipLaunchKernelGGL(k2a_extf_win_kernel<4>, dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream, *par, pairs, order, ntasks, seq, res);
+		else hipLaunchKernelGGL(k2a_extf_win_kernel<8>, dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream, *par, pairs, order, ntasks, seq, res);
+	} else if (cls == 3)
 		hipLaunchKernelGGL(k2a_extf_kernel<true>, dim3(ntasks), dim3(64), 0, (hipStream_t)stream, *par, pairs, order, ntasks, seq, scratch, res);
 	else
 		hipLaunchKernelGGL(k2a_extf_kernel<false>, dim3(ntasks), dim3(64), lds_bytes[cls], (hipStream_t)stream, *par, pairs, order, ntasks, seq, scratch, res);

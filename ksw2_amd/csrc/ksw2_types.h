@@ -51,6 +51,9 @@ typedef struct K2aExtf {
 	int32_t mch, mis, e;         /* mis <= 0 (ksw2_extf2_sse.c:20) */
 } K2aExtf;
 
+/* widest band (positions on one anti-diagonal) the K-slot register window of the X-drop kernel holds */
+#define K2A_EXTF_WIN_SPAN(K) (64 * (K) - 109)
+
 /* one alignment, device-resident */
 typedef struct K2aPair {
 	uint32_t qoff, toff;         /* byte offsets of query / target in the sequence arena                  */

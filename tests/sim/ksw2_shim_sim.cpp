@@ -609,6 +609,64 @@ static void sim_extf(const K2aExtf par, const K2aPair *pairs, const uint32_t *or
 	}
 }
 
+/* mirrors k2a_extf_win_kernel<K>: the register window, lanes in lock step */
+template<int K>
+static void sim_extf_win(const K2aExtf par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, K2aResult *res)
+{
+	for (int task = 0; task < ntasks; ++task) {
+		const uint32_t pi = order[task];
+		const K2aPair pr = pairs[pi];
+		const int qlen = pr.qlen, tlen = pr.tlen, w = pr.w, xdrop = pr.zdrop, tpad = (tlen + 15) & ~15;
+		const uint8_t *qa = seq + pr.qoff, *ta = seq + pr.toff;
+		const uint32_t two_e = (uint32_t)(par.e * 2) & 0xffu;
+		static uint32_t U[K][64], V[K][64], S[K][64], T[K][64];
+		int blk[K];
+		for (int s = 0; s < K; ++s) {
+			blk[s] = s;
+			for (int lane = 0; lane < 64; ++lane) { U[s][lane] = V[s][lane] = S[s][lane] = 0u; T[s][lane] = 64 * s + lane < tlen ? ta[64 * s + lane] : 0u; }
+		}
+		K2aExtfBook bk;
+		k2a_extf_book_reset(bk);
+		int prev_lo = -1, prev_hi = -1, r;
+		const int nr = qlen + tlen - 1;
+		for (r = 0; r < nr; ++r) {
+			K2aExtfDiag d;
+			if (!k2a_extf_diag(r, qlen, tlen, w, tpad, d)) break;
+			const int wb = k2a_extf_win_base(d);
+			const bool carry_ok = d.blo > 0 && d.blo - 1 >= prev_lo && d.blo - 1 <= prev_hi;
+			const int last = k2a_max(d.bhi, d.fresh_end - 1);
+			assert(64 * (wb + K) - 1 >= last);
+			uint32_t c63[K];
+			for (int s = 0; s < K; ++s) {
+				const int nb = k2a_extf_win_block<K>(wb, s);
+				if (nb != blk[s]) {
+					assert(nb > blk[s]);
+					blk[s] = nb;
+					for (int lane = 0; lane < 64; ++lane) { U[s][lane] = V[s][lane] = S[s][lane] = 0u; T[s][lane] = 64 * nb + lane < tlen ? ta[64 * nb + lane] : 0u; }
+				}
+				c63[s] = V[s][63];
+			}
+			for (int s = 0; s < K; ++s) {
+				const int base = 64 * blk[s];
+				if (base > last || base + 63 < d.blo) continue;
+				uint32_t vold[64];
+				for (int lane = 0; lane < 64; ++lane) vold[lane] = V[s][lane];
+				for (int lane = 0; lane < 64; ++lane) {
+					const int x = base + lane, j = r - x;
+					const uint32_t qc = (uint32_t)j < (uint32_t)qlen ? (uint32_t)qa[j] : 0u;
+					k2a_extf_win_cell(par, d, r, x, two_e, carry_ok, T[s][lane], qc, lane ? vold[lane - 1] : c63[(s + K - 1) & (K - 1)],
+					                  U[s][lane], V[s][lane], S[s][lane]);
+				}
+			}
+			assert(bk.follow >= 64 * wb && bk.follow + 1 <= 64 * (wb + K) - 1);
+			const uint32_t vf = V[(bk.follow >> 6) & (K - 1)][bk.follow & 63], un = U[((bk.follow + 1) >> 6) & (K - 1)][(bk.follow + 1) & 63];
+			if (!k2a_extf_follow(bk, d, r, par.e, xdrop, vf, un)) break;
+			prev_lo = d.blo; prev_hi = d.bhi;
+		}
+		k2a_extf_finish(bk, r == nr, &res[pi]);
+	}
+}
+
 extern "C" {
 
 const char *k2a_shim_backend(void) { return "sim"; }
@@ -666,7 +724,9 @@ int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_
 int k2a_shim_launch_extf(int cls, const K2aExtf *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
                          uint8_t *scratch, K2aResult *res, void *)
 {
-	if (ntasks > 0) sim_extf(*par, pairs, order, ntasks, seq, scratch, res, cls == 3);
+	if (ntasks > 0 && cls == 4) sim_extf_win<4>(*par, pairs, order, ntasks, seq, res);
+	else if (ntasks > 0 && cls == 5) sim_extf_win<8>(*par, pairs, order, ntasks, seq, res);
+	else if (ntasks > 0) sim_extf(*par, pairs, order, ntasks, seq, scratch, res, cls == 3);
 	return 0;
 }
 int k2a_shim_launch_compact(const K2aPair *pairs, const K2aResult *res, const uint32_t *pos, int n, const uint32_t *cig,

@@ -594,12 +594,15 @@ def test_solo_long_reads_and_leftovers(lib, monkeypatch):
         check_batch(lib, dual, qs, ts, mat, 4, 2, 24, 1, w=300, zdrop=400, flag=flag)
 
 
-@pytest.mark.parametrize("hbm", [False, True])
-def test_linear_xdrop_golden(lib, hbm, monkeypatch):
-    """All 2000 ksw_extf2_sse cases produced by the compiled reference (tests/golden/extf_cases.npz), batched by scoring;
-    hbm: the same through the kernel that keeps U, V, S in HBM scratch (targets over 21504 residues take it in production)."""
-    if hbm:
+@pytest.mark.parametrize("state", ["auto", "lds", "hbm"])
+def test_linear_xdrop_golden(lib, state, monkeypatch):
+    """All 2000 ksw_extf2_sse cases produced by the compiled reference (tests/golden/extf_cases.npz), batched by scoring.
+    auto: narrow bands from the register window, the rest from LDS; lds: every case through the LDS-state kernel; hbm: through
+    the kernel that keeps U, V, S in HBM scratch (wide bands on targets over 21504 residues take it in production)."""
+    if state == "hbm":
         monkeypatch.setenv("KSW2AMD_EXTF_HBM", "1")
+    if state == "lds":
+        monkeypatch.setenv("KSW2AMD_EXTF_LDS", "1")
     fc = gu.ExtfCases()
     cases = [fc.case(k) for k in range(fc.n)]
     ndrop = 0
@@ -620,7 +623,8 @@ def test_linear_xdrop_long_and_empty(lib):
     rng = np.random.Generator(np.random.PCG64(606))
     qs, ts, ws, xs = [], [], [], []
     for tl, w, xd in ((1000, -1, -1), (1024, 100, 50), (1025, 33, -1), (4096, 500, 100), (5000, 64, -1), (20000, 200, 300), (21504, 16, -1),
-                      (21505, 100, -1), (30000, 300, 200), (30000, 50, -1)):
+                      (21505, 100, -1), (30000, 300, 200), (30000, 50, -1), (3000, 146, -1), (3000, 147, -1), (6000, 402, 400), (6000, 403, -1),
+                      (30000, 403, -1), (22000, 1000, 300)):
         (q, t), = synth.ragged_pairs(rng, 1, tl, tl, sub=0.04, ind=0.02)
         t = t[:tl] if len(t) >= tl else np.concatenate([t, rng.integers(0, 4, tl - len(t)).astype(np.uint8)])
         if xd >= 0:

@@ -429,6 +429,18 @@ def test_sim_linear_xdrop_golden_and_batches(sim, monkeypatch):
     for c in cases[::4]:
         r = sim.extf2(c["q"], c["t"], c["mch"], c["mis"], c["e"], c["w"], c["xdrop"])
         assert not diff(r, c["expect"], gu.FIELDS), (len(c["q"]), len(c["t"]), c["w"], c["xdrop"])
+    for c in cases[1::4]:                             # LDS-state kernel for every band width
+        monkeypatch.setenv("KSW2AMD_EXTF_LDS", "1")
+        r = sim.extf2(c["q"], c["t"], c["mch"], c["mis"], c["e"], c["w"], c["xdrop"])
+        assert not diff(r, c["expect"], gu.FIELDS), (len(c["q"]), len(c["t"]), c["w"], c["xdrop"])
+    monkeypatch.delenv("KSW2AMD_EXTF_LDS")
+    rng = np.random.Generator(np.random.PCG64(99))     # both register windows at their limits, windows sliding over long targets
+    from oracle.gen_golden_extf import noisy_pair
+    for it in range(60):
+        q, t = noisy_pair(rng, int(rng.integers(300, 3000)), it % 3)
+        w = int(rng.choice([100, 145, 146, 147, 300, 401, 402, 403]))
+        xd = int(rng.choice([-1, 200]))
+        assert not diff(sim.extf2(q, t, 2, -4, 2, w, xd), po.extf2("oracle", q, t, 2, -4, 2, w, xd), gu.FIELDS), (len(q), len(t), w, xd)
     for hbm in (False, True):
         if hbm:
             monkeypatch.setenv("KSW2AMD_EXTF_HBM", "1")
