@@ -1131,10 +1131,9 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 		mode = (a->flag & KSW_EZ_SCORE_ONLY) ? K2A_MODE_SCORE : (a->flag & KSW_EZ_RIGHT) ? K2A_MODE_RIGHT : K2A_MODE_LEFT;
 		if (is_approx(a->flag) && (a->flag & KSW_EZ_EXTZ_ONLY)) mode = K2A_MODE_SCORE;      /* no start cell in that mode: no CIGAR */
 		generic = (a->flag & KSW_EZ_GENERIC_SC) ? 1 : 0;
-		/* register windows where they are the faster kernel (tools/scripts/exts_classes.py): 8 slots always, 16 slots without
-		 * traceback (with it that kernel is down to one wavefront per SIMD) */
-		wn = imin(a->qlen, a->tlen) <= K2A_DM_DIAG(K2A_DM_SLOTS_S) ? 0 :
-		     (imin(a->qlen, a->tlen) <= K2A_DM_DIAG(K2A_DM_SLOTS) && mode == K2A_MODE_SCORE) ? 1 : 2;
+		/* register windows wherever the diagonal fits one: faster than the HBM-state kernel in every mode
+		 * (tools/scripts/exts_classes.py) */
+		wn = imin(a->qlen, a->tlen) <= K2A_DM_DIAG(K2A_DM_SLOTS_S) ? 0 : imin(a->qlen, a->tlen) <= K2A_DM_DIAG(K2A_DM_SLOTS) ? 1 : 2;
 		if (getenv("KSW2AMD_EXTS_BIG")) wn = 2;        /* tests: every pair through the HBM-state kernel */
 		else if (getenv("KSW2AMD_EXTS_REG") && imin(a->qlen, a->tlen) <= K2A_DM_DIAG(K2A_DM_SLOTS)) wn = imin(wn, 1);   /* tests: 16 slots with traceback */
 		if (wn == 2) {                                 /* 9 ints of state per target position, 16-byte granules */
@@ -1328,7 +1327,10 @@ ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n
 		c = a->tlen <= EXTF_LDS_T0 ? 0 : a->tlen <= EXTF_LDS_T1 ? 1 : a->tlen <= EXTF_LDS_T2 ? 2 : 3;
 		/* narrow bands run from registers: at most min(w + 1, qlen, tlen) positions of an anti-diagonal are inside the band */
 		span = imin(imin(a->qlen, a->tlen), d->w < 0x7ffffff0 ? d->w + 1 : d->w);
-		if (!getenv("KSW2AMD_EXTF_LDS")) c = span <= K2A_EXTF_WIN_SPAN(4) ? 4 : span <= K2A_EXTF_WIN_SPAN(8) ? 5 : c;
+		/* (tools/scripts/extf_classes.py: equal to the LDS form up to ~128 positions on short targets -- both are bound by
+		 * the per-anti-diagonal bookkeeping -- and 1.5-1.8 x faster on wider bands and wherever the LDS form needs 12 KiB or more) */
+		if (!getenv("KSW2AMD_EXTF_LDS") && (span > 128 || c > 0)) c = span <= K2A_EXTF_WIN_SPAN(4) ? 4 : span <= K2A_EXTF_WIN_SPAN(8) ? 5 : c;
+		if (getenv("KSW2AMD_EXTF_WIN")) c = span <= K2A_EXTF_WIN_SPAN(4) ? 4 : span <= K2A_EXTF_WIN_SPAN(8) ? 5 : c;   /* tests: the window wherever it fits */
 		if (getenv("KSW2AMD_EXTF_HBM")) c = 3;            /* tests: every pair through the HBM-state kernel */
 		if (c == 3) { d->tb_off = p->tb_bytes; p->tb_bytes += align_up(3 * align_up((size_t)a->tlen, 16), 256); }
 		p->h_cls[i] = (int8_t)c; ++p->f_count[c];

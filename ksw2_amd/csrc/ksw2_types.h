@@ -33,8 +33,7 @@ typedef struct K2aScoring {
 
 /* register window classes of the diagonal-major kernel: K slots of 64 target positions hold diagonals of up to
  * K*64 - 64 cells (the window starts one cell below the diagonal and is 64-aligned).  A 24-slot class (1 wavefront per
- * SIMD, spills) measured slower than the scratch-array kernel and was dropped; the 16-slot class is used for score-only
- * launches only (with traceback it has one wavefront per SIMD: 113 vs 151 GCUPS for the scratch-array kernel). */
+ * SIMD, spills) measured slower than the HBM-state kernel and was dropped. */
 #define K2A_DM_SLOTS_S 8
 #define K2A_DM_SLOTS   16
 #define K2A_DM_DIAG(K) ((K) * 64 - 64)

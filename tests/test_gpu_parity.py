@@ -594,15 +594,17 @@ def test_solo_long_reads_and_leftovers(lib, monkeypatch):
         check_batch(lib, dual, qs, ts, mat, 4, 2, 24, 1, w=300, zdrop=400, flag=flag)
 
 
-@pytest.mark.parametrize("state", ["auto", "lds", "hbm"])
+@pytest.mark.parametrize("state", ["auto", "win", "lds", "hbm"])
 def test_linear_xdrop_golden(lib, state, monkeypatch):
     """All 2000 ksw_extf2_sse cases produced by the compiled reference (tests/golden/extf_cases.npz), batched by scoring.
-    auto: narrow bands from the register window, the rest from LDS; lds: every case through the LDS-state kernel; hbm: through
+    auto: the host's choice between register window and LDS; win: the register window wherever the band fits it; lds: every case through the LDS-state kernel; hbm: through
     the kernel that keeps U, V, S in HBM scratch (wide bands on targets over 21504 residues take it in production)."""
     if state == "hbm":
         monkeypatch.setenv("KSW2AMD_EXTF_HBM", "1")
     if state == "lds":
         monkeypatch.setenv("KSW2AMD_EXTF_LDS", "1")
+    if state == "win":
+        monkeypatch.setenv("KSW2AMD_EXTF_WIN", "1")
     fc = gu.ExtfCases()
     cases = [fc.case(k) for k in range(fc.n)]
     ndrop = 0

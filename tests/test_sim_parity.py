@@ -434,6 +434,11 @@ def test_sim_linear_xdrop_golden_and_batches(sim, monkeypatch):
         r = sim.extf2(c["q"], c["t"], c["mch"], c["mis"], c["e"], c["w"], c["xdrop"])
         assert not diff(r, c["expect"], gu.FIELDS), (len(c["q"]), len(c["t"]), c["w"], c["xdrop"])
     monkeypatch.delenv("KSW2AMD_EXTF_LDS")
+    monkeypatch.setenv("KSW2AMD_EXTF_WIN", "1")        # the register window wherever the band fits it
+    for c in cases[2::4]:
+        r = sim.extf2(c["q"], c["t"], c["mch"], c["mis"], c["e"], c["w"], c["xdrop"])
+        assert not diff(r, c["expect"], gu.FIELDS), (len(c["q"]), len(c["t"]), c["w"], c["xdrop"])
+    monkeypatch.delenv("KSW2AMD_EXTF_WIN")
     rng = np.random.Generator(np.random.PCG64(99))     # both register windows at their limits, windows sliding over long targets
     from oracle.gen_golden_extf import noisy_pair
     for it in range(60):

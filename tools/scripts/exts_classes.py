@@ -21,11 +21,12 @@ for ql, tl, n in ((400, 1500, 8192), (900, 2500, 4096), (1400, 3000, 2048), (240
     q = np.concatenate([t[:, a:a + ex1], t[:, b:b + ql - ex1]], axis=1).copy()
     mm = rng.random(q.shape) < 0.03
     q[mm] = (q[mm] + 1) & 3
-    for big in (0, 1):
-        if big:
+    for big in (0, 1, 2):                      # 0: the host's choice, 1: HBM state for everything, 2: 16 register slots also with traceback
+        os.environ.pop("KSW2AMD_EXTS_BIG", None); os.environ.pop("KSW2AMD_EXTS_REG", None)
+        if big == 1:
             os.environ["KSW2AMD_EXTS_BIG"] = "1"
-        else:
-            os.environ.pop("KSW2AMD_EXTS_BIG", None)
+        if big == 2:
+            os.environ["KSW2AMD_EXTS_REG"] = "1"
         for flag, name in ((ka.KSW_EZ_SCORE_ONLY | 0x100, "score"), (0x100, "cigar")):
             p = lib.make_splice_batch(list(q), list(t), mat, 2, 1, 32, 4, zdrop=-1, flag=flag).plan()
             p.run(); p.timing()
@@ -34,4 +35,4 @@ for ql, tl, n in ((400, 1500, 8192), (900, 2500, 4096), (1400, 3000, 2048), (240
                 p.run(); ms.append(p.timing()[1])
             cells = p.cells()
             p.close()
-            print("q=%d t=%d n=%d %-5s %-8s %8.2f ms  %7.1f GCUPS" % (ql, tl, n, name, "scratch" if big else "register", np.mean(ms), cells / np.mean(ms) / 1e6))
+            print("q=%d t=%d n=%d %-5s %-8s %8.2f ms  %7.1f GCUPS" % (ql, tl, n, name, ["auto", "scratch", "reg16"][big], np.mean(ms), cells / np.mean(ms) / 1e6))
