@@ -136,6 +136,13 @@ K2A_FN uint32_t k2a_pack_dirs(k2a_pk d0, k2a_pk d1)
  * A lane-step word holds C cells x 2 alignments: byte 2c = alignment A, byte 2c+1 = alignment B. */
 /* NOMAX: KSW_EZ_APPROX_MAX launches (ksw2_host.c::is_approx) need the final score and the direction bytes only: no row
  * maximum, no arg-max, no Z-drop -- four instructions per row and two registers per row less. */
+/* Classes whose per-row maxima, arg-max columns and target codes live in LDS instead of registers (3 x C dwords per
+ * lane, [array][row][lane]): the two-piece traceback kernels of the 16-row geometry, which otherwise need 290-330
+ * registers and run one wavefront per SIMD.  The values are touched once per row and step, so the LDS traffic is a few
+ * per cent of the step; the kernel then fits two wavefronts. */
+#define K2A_PK_LDSROWS(G, C, DUAL, MODE, NOMAX) ((G) == 64 && (C) == 16 && (DUAL) && (MODE) != K2A_MODE_SCORE && !(NOMAX))
+#define K2A_PK_LDSROW_WORDS(C) (3 * (C) * 64)        /* per wavefront */
+
 template<int G, int C, bool DUAL, int MODE = K2A_MODE_SCORE, bool RB = false, bool NOMAX = false>
 struct K2aLanePk {
 	enum { TBWORDS = C / 2 };
@@ -153,8 +160,16 @@ struct K2aLanePk {
 	/* rows */
 	/* target codes as bit planes x D: one register more per row, so only where the kernel keeps its occupancy */
 	enum { PLANES = (MODE == K2A_MODE_SCORE && (!DUAL || C <= 16)) || C <= 8 };
-	k2a_pk hl[C], f[C], f2[DUAL ? C : 1], rmax[NOMAX ? 1 : C], rmj[NOMAX ? 1 : C];       /* hl, f, f2, rmax and the ports above: offset form */
-	k2a_pk tc[C], tc1[PLANES ? C : 1];                           /* target codes {A, B}; PLANES: bit 0 / bit 1 of the codes, times D */
+	enum { LDSROW = K2A_PK_LDSROWS(G, C, DUAL, MODE, NOMAX) };
+	k2a_pk hl[C], f[C], f2[DUAL ? C : 1], rmax_[(NOMAX || LDSROW) ? 1 : C], rmj_[(NOMAX || LDSROW) ? 1 : C];       /* hl, f, f2, rmax and the ports above: offset form */
+	k2a_pk tc_[LDSROW ? 1 : C], tc1[PLANES ? C : 1];             /* target codes {A, B}; PLANES: bit 0 / bit 1 of the codes, times D */
+	uint32_t *lrow;                                              /* LDSROW: this lane's column of the wavefront's [3][C][64] block */
+	K2A_FN k2a_pk rmax(int c) const { return LDSROW ? lrow[(0 * C + c) * 64] : rmax_[(NOMAX || LDSROW) ? 0 : c]; }
+	K2A_FN k2a_pk rmj(int c) const { return LDSROW ? lrow[(1 * C + c) * 64] : rmj_[(NOMAX || LDSROW) ? 0 : c]; }
+	K2A_FN k2a_pk tc(int c) const { return LDSROW ? lrow[(2 * C + c) * 64] : tc_[LDSROW ? 0 : c]; }
+	K2A_FN void set_rmax(int c, k2a_pk v) { if (LDSROW) lrow[(0 * C + c) * 64] = v; else rmax_[(NOMAX || LDSROW) ? 0 : c] = v; }
+	K2A_FN void set_rmj(int c, k2a_pk v) { if (LDSROW) lrow[(1 * C + c) * 64] = v; else rmj_[(NOMAX || LDSROW) ? 0 : c] = v; }
+	K2A_FN void set_tc(int c, k2a_pk v) { if (LDSROW) lrow[(2 * C + c) * 64] = v; else tc_[LDSROW ? 0 : c] = v; }
 
 	K2A_FN static int first_col(int S_, int w_) { return k2a_max(0, S_ * C - w_); }
 
@@ -178,8 +193,9 @@ struct K2aLanePk {
 		baseA = baseB = 0; delta = 0;
 		local_reset();
 #pragma unroll
-		for (int c = 0; c < C; ++c) { hl[c] = f[c] = neg; tc[c] = 0; if (!NOMAX) { rmax[c] = neg; rmj[c] = 0; } if (PLANES) tc1[c] = 0; if (DUAL) f2[c] = neg; }
-		if (NOMAX) { rmax[0] = neg; rmj[0] = 0; }
+		for (int c = 0; c < C; ++c) { hl[c] = f[c] = neg; set_tc(c, 0); if (!NOMAX) { set_rmax(c, neg); set_rmj(c, 0); } if (PLANES) tc1[c] = 0; if (DUAL) f2[c] = neg; }
+		if (NOMAX || LDSROW) { rmax_[0] = neg; rmj_[0] = 0; }
+		if (LDSROW) tc_[0] = 0;
 		if (!DUAL) f2[0] = 0;
 		if (!PLANES) tc1[0] = 0;
 	}
@@ -209,17 +225,17 @@ struct K2aLanePk {
 			const uint32_t ua = tpa[c >> 1], ub = tpb[c >> 1];
 			const k2a_pk c0 = k2a_pair16(ua & 0xffu, ub & 0xffu), c1 = k2a_pair16(ua >> 8, ub >> 8);
 			if (PLANES) {
-				tc[c] = (c0 & 0x00010001u) * dmis; tc1[c] = ((c0 >> 1) & 0x00010001u) * dmis;
-				if (c + 1 < C) { tc[c + 1] = (c1 & 0x00010001u) * dmis; tc1[c + 1] = ((c1 >> 1) & 0x00010001u) * dmis; }
+				set_tc(c, (c0 & 0x00010001u) * dmis); tc1[c] = ((c0 >> 1) & 0x00010001u) * dmis;
+				if (c + 1 < C) { set_tc(c + 1, (c1 & 0x00010001u) * dmis); tc1[c + 1] = ((c1 >> 1) & 0x00010001u) * dmis; }
 			} else {
-				tc[c] = c0;
-				if (c + 1 < C) tc[c + 1] = c1;
+				set_tc(c, c0);
+				if (c + 1 < C) set_tc(c + 1, c1);
 			}
 		}
 #pragma unroll
 		for (int c = 0; c < C; ++c) {
 			hl[c] = neg; f[c] = neg; if (DUAL) f2[c] = neg;
-			if (!NOMAX) { rmax[c] = neg; rmj[c] = 0; }
+			if (!NOMAX) { set_rmax(c, neg); set_rmj(c, 0); }
 		}
 		const int hcorner = k2a_border<DUAL>(sc, i0) + sc.e * (i0 - 1);   /* H(i0-1,-1), carrying the bias of row i0-1 */
 		if (RB) {
@@ -285,12 +301,12 @@ struct K2aLanePk {
 			const k2a_pk q0 = (qcode & 0x00010001u) * dmis, q1 = ((qcode >> 1) & 0x00010001u) * dmis;
 #pragma unroll
 			for (int c = 0; c < C; ++c)
-				cand[c] = k2a_sub32(k2a_add32(c == 0 ? hd0 : hl[c - 1], mat_a), k2a_or_xor(tc[c] ^ q0, tc1[c], q1));
+				cand[c] = k2a_sub32(k2a_add32(c == 0 ? hd0 : hl[c - 1], mat_a), k2a_or_xor(tc(c) ^ q0, tc1[c], q1));
 		} else {
 #pragma unroll
 			for (int c = 0; c < C; ++c) {
 				/* score: a on equal codes, b otherwise (no wildcards in this class) */
-				const k2a_pk ne01 = k2a_pk_minu(tc[c] ^ qcode, 0x00010001u);
+				const k2a_pk ne01 = k2a_pk_minu(tc(c) ^ qcode, 0x00010001u);
 				cand[c] = k2a_pk_add(c == 0 ? hd0 : hl[c - 1], k2a_pk_mad(ne01, mat_bma, mat_a));
 			}
 		}
@@ -321,9 +337,10 @@ struct K2aLanePk {
 			/* running row maximum: ties to the last column (keep the old arg-max only where h < max), except
 			 * extz + RIGHT + CIGAR where the first column wins (take the new one only where max < h); SURVEY 8a rule 3 */
 			if (!NOMAX) {
-				if (!DUAL && MODE == K2A_MODE_RIGHT) rmj[c] = k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(rmax[c], h)), jjpk, rmj[c]);
-				else rmj[c] = k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(h, rmax[c])), rmj[c], jjpk);
-				rmax[c] = k2a_pk_maxu(rmax[c], h);
+				const k2a_pk rm = rmax(c), rj = rmj(c);
+				if (!DUAL && MODE == K2A_MODE_RIGHT) set_rmj(c, k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(rm, h)), jjpk, rj));
+				else set_rmj(c, k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(h, rm)), rj, jjpk));
+				set_rmax(c, k2a_pk_maxu(rm, h));
 			}
 			/* gaps leaving the cell, all in row-biased form: opening = H' - q; the extension cost cancels against the bias
 			 * for E (next row), stays e for F (same row), becomes e2 - e for E~ and stays e2 for F~.  "extension beats
@@ -375,7 +392,7 @@ struct K2aLanePk {
 	K2A_FN void stage_rows(uint32_t *rowbuf) const
 	{
 #pragma unroll
-		for (int c = 0; c < C; ++c) { rowbuf[c] = hl[c] ^ K2A_OFS; rowbuf[C + c] = rmax[NOMAX ? 0 : c] ^ K2A_OFS; rowbuf[2 * C + c] = rmj[NOMAX ? 0 : c]; }   /* plain int16 halves */
+		for (int c = 0; c < C; ++c) { rowbuf[c] = hl[c] ^ K2A_OFS; rowbuf[C + c] = rmax(c) ^ K2A_OFS; rowbuf[2 * C + c] = rmj(c); }   /* plain int16 halves */
 		rowbuf[3 * C] = (uint32_t)i0;
 		if (RB) { rowbuf[3 * C + 1] = (uint32_t)baseA; rowbuf[3 * C + 2] = (uint32_t)baseB; }
 	}
@@ -428,13 +445,13 @@ struct K2aLanePk {
 	{
 		if (i0 + C >= tlen || i0 + C - 1 + w >= qlen - 1) return false;
 		/* rows compare without their bias: v_c = rmax[c] - e*c = H(row) + (e*i0 - base) */
-		k2a_pk m = rmax[0] ^ K2A_OFS, mn = m, arg = 0, argj = rmj[0];
+		k2a_pk m = rmax(0) ^ K2A_OFS, mn = m, arg = 0, argj = rmj(0);
 #pragma unroll
 		for (int c = 1; c < (NOMAX ? 1 : C); ++c) {
-			const k2a_pk v = k2a_pk_sub(rmax[c] ^ K2A_OFS, k2a_pk2(sc.e * c));
+			const k2a_pk v = k2a_pk_sub(rmax(c) ^ K2A_OFS, k2a_pk2(sc.e * c));
 			const k2a_pk gt = k2a_pk_sign(k2a_pk_sub(m, v));                        /* strictly larger: first row keeps a tie */
 			arg = k2a_pk_sel(gt, k2a_pk2(c), arg);
-			argj = k2a_pk_sel(gt, rmj[c], argj);
+			argj = k2a_pk_sel(gt, rmj(c), argj);
 			m = k2a_pk_max(m, v);
 			mn = k2a_pk_min(mn, v);
 		}

@@ -159,7 +159,7 @@ k2a_fill_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const ui
 
 /* Packed-int16 resident fill: two same-shape alignments per lane group (ksw2_lane_pk.h). */
 template<int G, int C, bool DUAL, int MODE, bool RB, bool NOMAX>
-__global__ void __launch_bounds__(64 * K2A_WPB)      /* no occupancy floor: capping at 168 VGPRs spills and is 18 % slower */
+__global__ void __launch_bounds__(64 * K2A_WPB, K2A_PK_LDSROWS(G, C, DUAL, MODE, NOMAX) ? 2 : 1)      /* no floor elsewhere: capping the score-only kernels at 168 VGPRs spills and is 18 % slower */
 k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
                    const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, K2aResult *__restrict__ res)
 {
@@ -168,7 +168,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	__shared__ K2aBook book[K2A_WPB][NG][2];
 	__shared__ uint32_t stage[K2A_WPB][(NG * K2A_PK_STAGE(C) > 64 * 5) ? NG * K2A_PK_STAGE(C) : 64 * 5];   /* row buffers / final lane records */
 
-	const int lane = threadIdx.x & 63, wave = k2a_wave_id<(C <= 8)>();
+	const int lane = threadIdx.x & 63, wave = k2a_wave_id<(C <= 8 || (DUAL && MODE != K2A_MODE_SCORE))>();   /* 16 rows, two-piece, traceback: what gets those kernels to two wavefronts */
 	const int grp = lane / G, gl = lane % G;
 	const int task = (blockIdx.x * K2A_WPB + wave) * NG + grp;
 	const bool valid = task < ntasks;
@@ -178,7 +178,9 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	/* a Z-drop test anywhere in the wavefront selects the sequential strip epilogue for all of it */
 	const bool zseq = NOMAX || RB || __builtin_amdgcn_ballot_w64(valid && (zdropA >= 0 || zdropB >= 0)) != 0;   /* NOMAX: books only */
 
+	__shared__ uint32_t lrows[Lane::LDSROW ? K2A_WPB * K2A_PK_LDSROW_WORDS(C) : 1];   /* per-row maxima / arg-max / target codes of the LDSROW classes */
 	Lane L;
+	L.lrow = &lrows[Lane::LDSROW ? wave * K2A_PK_LDSROW_WORDS(C) + lane : 0];
 	L.setup(prA, prB, seq, gl, valid);
 	K2aBook *bkA = &book[wave][grp][0], *bkB = &book[wave][grp][1];
 	if (gl == 0) { k2a_book_reset(bkA); k2a_book_reset(bkB); }

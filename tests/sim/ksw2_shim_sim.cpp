@@ -112,6 +112,7 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 	const int nwaves = (ntasks + NG - 1) / NG;
 	for (int wv = 0; wv < nwaves; ++wv) {
 		static Lane L[64];
+		static uint32_t lrows[K2A_PK_LDSROW_WORDS(C)];
 		K2aBook book[NG][2];
 		K2aPair prA[64];
 		uint32_t piA[64], piB[64], stage[(NG * K2A_PK_STAGE(C) > 64 * 5) ? NG * K2A_PK_STAGE(C) : 64 * 5];
@@ -123,6 +124,7 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 			piA[lane] = order2[valid[lane] ? 2 * task : 0]; piB[lane] = order2[valid[lane] ? 2 * task + 1 : 0];
 			prA[lane] = pairs[piA[lane]];
 			zdA[lane] = prA[lane].zdrop; zdB[lane] = pairs[piB[lane]].zdrop;
+			L[lane].lrow = lrows + lane;
 			L[lane].setup(prA[lane], pairs[piB[lane]], seq, gl, valid[lane]);
 			if (gl == 0) { k2a_book_reset(&book[grp][0]); k2a_book_reset(&book[grp][1]); }
 			klast[lane] = L[lane].last_step();
