@@ -57,7 +57,11 @@ K2A_FN void k2a_book_reset(K2aBook *b)
  *   dual gap   (8 bits): bits 0-2 winner {0..4}, bits 3-6 E / F / E~ / F~ continue   (as ksw2.h:125-128) */
 template<bool DUAL> struct K2aTb { enum { BITS = DUAL ? 8 : 4 }; };
 
-template<int G, int C, bool DUAL, int MODE>
+/* LROW: the per-row maxima and arg-max columns live in LDS ([2][C][64] dwords per wavefront, `lrow` = this lane's column)
+ * instead of registers -- for kernels that are a few registers over an occupancy step (ksw2_shim_hip.hip) */
+#define K2A_LROW_WORDS(C) (2 * (C) * 64)
+
+template<int G, int C, bool DUAL, int MODE, bool LROW = false>
 struct K2aLane {
 	enum { TBBITS = K2aTb<DUAL>::BITS, TBWORDS = (C * TBBITS + 31) / 32 };
 
@@ -73,7 +77,10 @@ struct K2aLane {
 	int hu_prev;                  /* H(i0-1, jj-1) candidate received last step */
 	int qb;                       /* query code for this step's column */
 	/* rows */
-	int hl[C], f[C], f2[DUAL ? C : 1], rmax[C], rmj[C];
+	int hl[C], f[C], f2[DUAL ? C : 1], rmax_[LROW ? 1 : C], rmj_[LROW ? 1 : C];
+	int *lrow;
+	K2A_FN int &rmaxr(int c) { return LROW ? lrow[(0 * C + c) * 64] : rmax_[LROW ? 0 : c]; }
+	K2A_FN int &rmjr(int c) { return LROW ? lrow[(1 * C + c) * 64] : rmj_[LROW ? 0 : c]; }
 	uint32_t P[C];
 	uint32_t tbp[(C + 3) / 4];    /* packed target codes (only needed against the query wildcard) */
 	uint32_t tnext[(C + 3) / 4];  /* prefetched target codes of strip Snext */
@@ -108,7 +115,7 @@ struct K2aLane {
 		schedule_next_resident();
 		hout = eout = e2out = K2A_NEG; hd0 = K2A_NEG; hu_prev = K2A_NEG; qb = 0;
 #pragma unroll
-		for (int c = 0; c < C; ++c) { hl[c] = f[c] = K2A_NEG; rmax[c] = K2A_NEG; rmj[c] = 0; P[c] = 0; if (DUAL) f2[c] = K2A_NEG; }
+		for (int c = 0; c < C; ++c) { hl[c] = f[c] = K2A_NEG; rmaxr(c) = K2A_NEG; rmjr(c) = 0; P[c] = 0; if (DUAL) f2[c] = K2A_NEG; }
 		if (!DUAL) f2[0] = 0;
 #pragma unroll
 		for (int x = 0; x < (C + 3) / 4; ++x) tbp[x] = tnext[x] = 0;
@@ -155,7 +162,7 @@ struct K2aLane {
 			const uint32_t tb = (tbp[c >> 2] >> (8 * (c & 3))) & 0xff;
 			P[c] = ptab[tb < 4 ? tb : 4];                     /* score profile of this row's target code (LDS table) */
 			hl[c] = K2A_NEG; f[c] = K2A_NEG; if (DUAL) f2[c] = K2A_NEG;
-			rmax[c] = K2A_NEG; rmj[c] = 0;
+			rmaxr(c) = K2A_NEG; rmjr(c) = 0;
 		}
 		if (i0 <= w) {                                      /* some rows start at column 0: virtual column -1 */
 #pragma unroll
@@ -257,9 +264,10 @@ struct K2aLane {
 			const bool lv = (live >> c) & 1u;
 			h = lv ? h : K2A_NEG;
 			/* running row maximum; ties to the last column unless extz + RIGHT + CIGAR (SURVEY 8a rule 3) */
-			const bool upd = (!DUAL && MODE == K2A_MODE_RIGHT) ? (h > rmax[c]) : (h >= rmax[c]);
-			rmj[c] = upd ? jj : rmj[c];
-			rmax[c] = k2a_max(rmax[c], h);
+			const int rm = rmaxr(c), rj = rmjr(c);            /* read once: with LROW these are LDS loads the scheduler can issue early */
+			const bool upd = (!DUAL && MODE == K2A_MODE_RIGHT) ? (h > rm) : (h >= rm);
+			rmjr(c) = upd ? jj : rj;
+			rmaxr(c) = k2a_max(rm, h);
 			/* gaps leaving this cell */
 			const int t = h - qe;
 			const int ex = e - sc.e, fx = fc - sc.e;
@@ -310,7 +318,7 @@ struct K2aLane {
 	{
 		const int zslope = DUAL ? sc.e2 : sc.e;
 #pragma unroll
-		for (int c = 0; c < C; ++c) { rowbuf[c] = hl[c]; rowbuf[C + c] = rmax[c]; rowbuf[2 * C + c] = rmj[c]; }
+		for (int c = 0; c < C; ++c) { rowbuf[c] = hl[c]; rowbuf[C + c] = rmaxr(c); rowbuf[2 * C + c] = rmjr(c); }
 		int bmax = b->max, bmax_t = b->max_t, bmax_q = b->max_q, bmqe = b->mqe, bmqe_t = b->mqe_t;
 		int bmte = b->mte, bmte_q = b->mte_q, bscore = b->score, bdrop = b->dropped, brows = b->rows;
 #pragma nounroll

@@ -139,11 +139,12 @@ K2A_FN uint32_t k2a_pack_dirs(k2a_pk d0, k2a_pk d1)
 /* Classes whose per-row maxima, arg-max columns and target codes live in LDS instead of registers (3 x C dwords per
  * lane, [array][row][lane]): the two-piece traceback kernels of the 16-row geometry, which otherwise need 290-330
  * registers and run one wavefront per SIMD.  The values are touched once per row and step, so the LDS traffic is a few
- * per cent of the step; the kernel then fits two wavefronts. */
+ * per cent of the step; the kernel then fits two wavefronts.  With a single wavefront on a SIMD the loads' latency is
+ * exposed and the register form is faster, so both are built and the launcher picks by the number of tasks. */
 #define K2A_PK_LDSROWS(G, C, DUAL, MODE, NOMAX) ((G) == 64 && (C) == 16 && (DUAL) && (MODE) != K2A_MODE_SCORE && !(NOMAX))
 #define K2A_PK_LDSROW_WORDS(C) (3 * (C) * 64)        /* per wavefront */
 
-template<int G, int C, bool DUAL, int MODE = K2A_MODE_SCORE, bool RB = false, bool NOMAX = false>
+template<int G, int C, bool DUAL, int MODE = K2A_MODE_SCORE, bool RB = false, bool NOMAX = false, bool LDSROW_ = false>
 struct K2aLanePk {
 	enum { TBWORDS = C / 2 };
 	/* group-uniform (both alignments share the shape) */
@@ -160,7 +161,7 @@ struct K2aLanePk {
 	/* rows */
 	/* target codes as bit planes x D: one register more per row, so only where the kernel keeps its occupancy */
 	enum { PLANES = (MODE == K2A_MODE_SCORE && (!DUAL || C <= 16)) || C <= 8 };
-	enum { LDSROW = K2A_PK_LDSROWS(G, C, DUAL, MODE, NOMAX) };
+	enum { LDSROW = LDSROW_ };
 	k2a_pk hl[C], f[C], f2[DUAL ? C : 1], rmax_[(NOMAX || LDSROW) ? 1 : C], rmj_[(NOMAX || LDSROW) ? 1 : C];       /* hl, f, f2, rmax and the ports above: offset form */
 	k2a_pk tc_[LDSROW ? 1 : C], tc1[PLANES ? C : 1];             /* target codes {A, B}; PLANES: bit 0 / bit 1 of the codes, times D */
 	uint32_t *lrow;                                              /* LDSROW: this lane's column of the wavefront's [3][C][64] block */

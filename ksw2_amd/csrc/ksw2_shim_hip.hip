@@ -158,17 +158,17 @@ k2a_fill_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const ui
 }
 
 /* Packed-int16 resident fill: two same-shape alignments per lane group (ksw2_lane_pk.h). */
-template<int G, int C, bool DUAL, int MODE, bool RB, bool NOMAX>
-__global__ void __launch_bounds__(64 * K2A_WPB, K2A_PK_LDSROWS(G, C, DUAL, MODE, NOMAX) ? 2 : 1)      /* no floor elsewhere: capping the score-only kernels at 168 VGPRs spills and is 18 % slower */
+template<int G, int C, bool DUAL, int MODE, bool RB, bool NOMAX, bool LDSROW = false>
+__global__ void __launch_bounds__(64 * K2A_WPB, LDSROW ? 2 : 1)      /* no floor elsewhere: capping the score-only kernels at 168 VGPRs spills and is 18 % slower */
 k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
                    const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, K2aResult *__restrict__ res)
 {
 	constexpr int NG = 64 / G;
-	typedef K2aLanePk<G, C, DUAL, MODE, RB, NOMAX> Lane;
+	typedef K2aLanePk<G, C, DUAL, MODE, RB, NOMAX, LDSROW> Lane;
 	__shared__ K2aBook book[K2A_WPB][NG][2];
 	__shared__ uint32_t stage[K2A_WPB][(NG * K2A_PK_STAGE(C) > 64 * 5) ? NG * K2A_PK_STAGE(C) : 64 * 5];   /* row buffers / final lane records */
 
-	const int lane = threadIdx.x & 63, wave = k2a_wave_id<(C <= 8 || (DUAL && MODE != K2A_MODE_SCORE))>();   /* 16 rows, two-piece, traceback: what gets those kernels to two wavefronts */
+	const int lane = threadIdx.x & 63, wave = k2a_wave_id<(C <= 8 || LDSROW || (NOMAX && DUAL && MODE != K2A_MODE_SCORE))>();   /* 16 rows, two-piece, traceback: part of what gets those kernels to two wavefronts */
 	const int grp = lane / G, gl = lane % G;
 	const int task = (blockIdx.x * K2A_WPB + wave) * NG + grp;
 	const bool valid = task < ntasks;
@@ -178,9 +178,9 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	/* a Z-drop test anywhere in the wavefront selects the sequential strip epilogue for all of it */
 	const bool zseq = NOMAX || RB || __builtin_amdgcn_ballot_w64(valid && (zdropA >= 0 || zdropB >= 0)) != 0;   /* NOMAX: books only */
 
-	__shared__ uint32_t lrows[Lane::LDSROW ? K2A_WPB * K2A_PK_LDSROW_WORDS(C) : 1];   /* per-row maxima / arg-max / target codes of the LDSROW classes */
+	__shared__ uint32_t lrows[LDSROW ? K2A_WPB * K2A_PK_LDSROW_WORDS(C) : 1];   /* per-row maxima / arg-max / target codes of the LDSROW classes */
 	Lane L;
-	L.lrow = &lrows[Lane::LDSROW ? wave * K2A_PK_LDSROW_WORDS(C) + lane : 0];
+	L.lrow = &lrows[LDSROW ? wave * K2A_PK_LDSROW_WORDS(C) + lane : 0];
 	L.setup(prA, prB, seq, gl, valid);
 	K2aBook *bkA = &book[wave][grp][0], *bkB = &book[wave][grp][1];
 	if (gl == 0) { k2a_book_reset(bkA); k2a_book_reset(bkB); }
@@ -386,15 +386,18 @@ k2a_trace_solo_kernel(const K2aPair *__restrict__ pairs, const uint32_t *__restr
  * generation g = rows g*G*C .. (g+1)*G*C-1 over all their in-band columns.  Lane G-1 streams its bottom row
  * (H, E[, E~]) to the boundary buffer, lane 0 of the next generation streams it back in (L1-bypassing loads,
  * the producer wrote them thousands of steps earlier from this same wavefront). */
-template<int G, int C, bool DUAL, int MODE>
-__global__ void __launch_bounds__(64 * K2A_WPB)
+template<int G, int C, bool DUAL, int MODE, bool LROW = false>
+__global__ void __launch_bounds__(64 * K2A_WPB, LROW ? 2 : 1)
 k2a_fill_mp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
                    const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, int32_t *bnd, K2aResult *__restrict__ res)
 {
 	static_assert(G == 64, "one alignment per wavefront");
-	typedef K2aLane<G, C, DUAL, MODE> Lane;
+	/* LROW (single-gap traceback): 264 registers with the row maxima in VGPRs (one wavefront per SIMD), 8 KiB of LDS per
+	 * wavefront for them instead makes it two; chosen by the launcher like the packed kernels' LDS form */
+	typedef K2aLane<G, C, DUAL, MODE, LROW> Lane;
 	__shared__ K2aBook book[K2A_WPB];
 	__shared__ int rowbuf[K2A_WPB][3 * C];
+	__shared__ int lrows[LROW ? K2A_WPB * K2A_LROW_WORDS(C) : 1];
 	__shared__ uint32_t tabs[16];
 	__shared__ int8_t mtab[K2A_MAXM * K2A_MAXM];      /* m > 5: the whole matrix, one byte per residue pair */
 	if (threadIdx.x < 5) { tabs[threadIdx.x] = sc.prof[threadIdx.x]; tabs[8 + threadIdx.x] = (uint32_t)sc.colw[threadIdx.x]; }
@@ -408,6 +411,7 @@ k2a_fill_mp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	const K2aPair pr = pairs[pi];
 
 	Lane L;
+	L.lrow = &lrows[LROW ? wave * K2A_LROW_WORDS(C) + gl : 0];
 	L.setup(pr, seq, gl, valid);
 	K2aBook *bk = &book[wave];
 	if (gl == 0) k2a_book_reset(bk);
@@ -545,6 +549,7 @@ typedef void (*fill_mp_fn)(const K2aScoring, const K2aPair*, const uint32_t*, in
 static const fill_mp_fn g_fill_mp[2][3] = {
 	{ k2a_fill_mp_kernel<64, 16, false, 0>, k2a_fill_mp_kernel<64, 16, false, 1>, k2a_fill_mp_kernel<64, 16, false, 2> },
 	{ k2a_fill_mp_kernel<64, 16, true, 0>,  k2a_fill_mp_kernel<64, 16, true, 1>,  k2a_fill_mp_kernel<64, 16, true, 2> } };
+static const fill_mp_fn g_fill_mp_lds[2] = { k2a_fill_mp_kernel<64, 16, false, 1, true>, k2a_fill_mp_kernel<64, 16, false, 2, true> };   /* [mode - 1] */
 #define TRACE_ROW(G, C, MP) { k2a_trace_kernel<G, C, false, MP>, k2a_trace_kernel<G, C, true, MP> }
 static const trace_fn g_trace[K2A_NCFG][2] = { TRACE_ROW(16, 8, false), TRACE_ROW(64, 8, false), TRACE_ROW(64, 16, false),
                                                TRACE_ROW(64, 32, false), TRACE_ROW(64, 16, true) };
@@ -916,6 +921,20 @@ typedef void (*fill_pk_fn)(const K2aScoring, const K2aPair*, const uint32_t*, in
 #define PK_SET(NM) { { PK_ROW(8, 18, false, NM), PK_ROW(16, 8, false, NM), PK_ROW(64, 8, false, NM), PK_ROW(64, 16, false, NM) }, \
                      { PK_ROW(8, 18, true, NM),  PK_ROW(16, 8, true, NM),  PK_ROW(64, 8, true, NM),  PK_ROW(64, 16, true, NM) } }
 static const fill_pk_fn g_fill_pk[2][2][K2A_NPKCFG][2][3] = { PK_SET(false), PK_SET(true) };     /* [nomax][rebased][cfg][dual][mode] */
+/* the K2A_PK_LDSROWS classes with their row state in LDS: [rebased][mode - 1] */
+static const fill_pk_fn g_fill_pk_lds[2][2] = {
+	{ k2a_fill_pk_kernel<64, 16, true, 1, false, false, true>, k2a_fill_pk_kernel<64, 16, true, 2, false, false, true> },
+	{ k2a_fill_pk_kernel<64, 16, true, 1, true, false, true>,  k2a_fill_pk_kernel<64, 16, true, 2, true, false, true> } };
+
+/* Row state in LDS (two wavefronts per SIMD) or in registers (one): the LDS form wins as soon as SIMDs hold two
+ * wavefronts, the register form when they hold one (measured: config 5, 8 per SIMD, 836 -> 1035 GCUPS; config 4, one per
+ * SIMD, 757 -> 640).  KSW2AMD_LDSROWS=0 / 1 forces the choice. */
+static bool k2a_use_ldsrows(int waves)
+{
+	const char *ev = getenv("KSW2AMD_LDSROWS");
+	if (ev) return atoi(ev) != 0;
+	return 2 * (long)waves >= 3 * (long)k2a_shim_simd_count();
+}
 static const trace_fn g_trace_pk[K2A_NPKCFG] = { k2a_trace_pk_kernel<8, 18>, k2a_trace_pk_kernel<16, 8>, k2a_trace_pk_kernel<64, 8>,
                                                  k2a_trace_pk_kernel<64, 16> };
 
@@ -1012,8 +1031,8 @@ int k2a_shim_launch_fill(int cfg, int dual, int mode, const K2aScoring *sc, cons
 	const int per_block = K2A_WPB * (64 / k2a_cfg_G[cfg]);
 	const int blocks = (ntasks + per_block - 1) / per_block;
 	if (cfg == K2A_CFG_MP)
-		hipLaunchKernelGGL(g_fill_mp[dual ? 1 : 0][mode], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
-		                   *sc, pairs, order, ntasks, seq, tb, bnd, res);
+		hipLaunchKernelGGL((!dual && mode != K2A_MODE_SCORE && k2a_use_ldsrows(ntasks)) ? g_fill_mp_lds[mode - 1] : g_fill_mp[dual ? 1 : 0][mode],
+		                   dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream, *sc, pairs, order, ntasks, seq, tb, bnd, res);
 	else
 		hipLaunchKernelGGL(g_fill[cfg][dual ? 1 : 0][mode], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
 		                   *sc, pairs, order, ntasks, seq, tb, res);
@@ -1040,7 +1059,8 @@ int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax,
 	if (cfg < 0 || cfg >= K2A_NPKCFG || mode < 0 || mode > 2) { snprintf(g_err, sizeof(g_err), "bad packed kernel class"); return -1; }
 	const int per_block = K2A_WPB * (64 / k2a_pkcfg_G[cfg]);
 	const int blocks = (ntasks + per_block - 1) / per_block;
-	hipLaunchKernelGGL(g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
+	const bool lds = K2A_PK_LDSROWS(k2a_pkcfg_G[cfg], k2a_pkcfg_C[cfg], dual, mode, nomax) && k2a_use_ldsrows(ntasks);
+	hipLaunchKernelGGL(lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
 	                   *sc, pairs, order2, ntasks, seq, tb, res);
 	CHECK(hipGetLastError());
 	return 0;

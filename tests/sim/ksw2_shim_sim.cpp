@@ -103,12 +103,12 @@ static void sim_fill(const K2aScoring sc, const K2aPair *pairs, const uint32_t *
 }
 
 /* mirrors k2a_fill_pk_kernel */
-template<int G, int C, bool DUAL, int MODE, bool RB, bool NOMAX>
+template<int G, int C, bool DUAL, int MODE, bool RB, bool NOMAX, bool LDSROW = false>
 static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *seq, uint8_t *tb,
                         K2aResult *res)
 {
 	constexpr int NG = 64 / G;
-	typedef K2aLanePk<G, C, DUAL, MODE, RB, NOMAX> Lane;
+	typedef K2aLanePk<G, C, DUAL, MODE, RB, NOMAX, LDSROW> Lane;
 	const int nwaves = (ntasks + NG - 1) / NG;
 	for (int wv = 0; wv < nwaves; ++wv) {
 		static Lane L[64];
@@ -230,20 +230,21 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 }
 
 /* mirrors k2a_fill_mp_kernel */
-template<int G, int C, bool DUAL, int MODE>
+template<int G, int C, bool DUAL, int MODE, bool LROW = false>
 static void sim_fill_mp(const K2aScoring sc, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, uint8_t *tb,
                         int32_t *bnd, K2aResult *res)
 {
-	typedef K2aLane<G, C, DUAL, MODE> Lane;
+	typedef K2aLane<G, C, DUAL, MODE, LROW> Lane;
 	for (int task = 0; task < ntasks; ++task) {
 		static Lane L[64];
+		static int lrows[K2A_LROW_WORDS(C)];
 		K2aBook book;
 		int rowbuf[3 * C];
 		const uint32_t pi = order[task];
 		const K2aPair pr = pairs[pi];
 		uint32_t tabs[16] = {0};
 		make_tabs(sc, tabs);
-		for (int gl = 0; gl < 64; ++gl) L[gl].setup(pr, seq, gl, true);
+		for (int gl = 0; gl < 64; ++gl) { L[gl].lrow = lrows + gl; L[gl].setup(pr, seq, gl, true); }
 		k2a_book_reset(&book);
 		int32_t *Bh = bnd + pr.bnd_off, *Be = Bh + pr.qlen, *Be2 = Be + pr.qlen;
 		const int R = G * C, ngen = (pr.tlen + R - 1) / R;
@@ -322,6 +323,7 @@ typedef void (*fill_mp_fn)(const K2aScoring, const K2aPair*, const uint32_t*, in
 static const fill_mp_fn g_fill_mp[2][3] = {
 	{ sim_fill_mp<64, 16, false, 0>, sim_fill_mp<64, 16, false, 1>, sim_fill_mp<64, 16, false, 2> },
 	{ sim_fill_mp<64, 16, true, 0>,  sim_fill_mp<64, 16, true, 1>,  sim_fill_mp<64, 16, true, 2> } };
+static const fill_mp_fn g_fill_mp_lds[2] = { sim_fill_mp<64, 16, false, 1, true>, sim_fill_mp<64, 16, false, 2, true> };
 #define TRACE_ROW(G, C, MP) { sim_trace<G, C, false, MP>, sim_trace<G, C, true, MP> }
 static const trace_fn g_trace[K2A_NCFG][2] = { TRACE_ROW(16, 8, false), TRACE_ROW(64, 8, false), TRACE_ROW(64, 16, false),
                                                TRACE_ROW(64, 32, false), TRACE_ROW(64, 16, true) };
@@ -347,6 +349,11 @@ typedef void (*fill_pk_fn)(const K2aScoring, const K2aPair*, const uint32_t*, in
 #define PK_SET(NM) { { PK_ROW(8, 18, false, NM), PK_ROW(16, 8, false, NM), PK_ROW(64, 8, false, NM), PK_ROW(64, 16, false, NM) }, \
                      { PK_ROW(8, 18, true, NM),  PK_ROW(16, 8, true, NM),  PK_ROW(64, 8, true, NM),  PK_ROW(64, 16, true, NM) } }
 static const fill_pk_fn g_fill_pk[2][2][K2A_NPKCFG][2][3] = { PK_SET(false), PK_SET(true) };
+static const fill_pk_fn g_fill_pk_lds[2][2] = {
+	{ sim_fill_pk<64, 16, true, 1, false, false, true>, sim_fill_pk<64, 16, true, 2, false, false, true> },
+	{ sim_fill_pk<64, 16, true, 1, true, false, true>,  sim_fill_pk<64, 16, true, 2, true, false, true> } };
+/* the simulator takes the LDS form of the row state unless KSW2AMD_LDSROWS=0 (the GPU launcher decides by the number of tasks) */
+static bool sim_use_ldsrows(void) { const char *ev = getenv("KSW2AMD_LDSROWS"); return !ev || atoi(ev) != 0; }
 static const trace_fn g_trace_pk[K2A_NPKCFG] = { sim_trace_pk<8, 18>, sim_trace_pk<16, 8>, sim_trace_pk<64, 8>, sim_trace_pk<64, 16> };
 
 
@@ -701,14 +708,15 @@ int k2a_shim_launch_fill(int cfg, int dual, int mode, const K2aScoring *sc, cons
                          int ntasks, const uint8_t *seq, uint8_t *tb, int32_t *bnd, K2aResult *res, void *)
 {
 	if (ntasks <= 0) return 0;
-	if (cfg == K2A_CFG_MP) g_fill_mp[dual ? 1 : 0][mode](*sc, pairs, order, ntasks, seq, tb, bnd, res);
+	if (cfg == K2A_CFG_MP) ((!dual && mode != K2A_MODE_SCORE && sim_use_ldsrows()) ? g_fill_mp_lds[mode - 1] : g_fill_mp[dual ? 1 : 0][mode])(*sc, pairs, order, ntasks, seq, tb, bnd, res);
 	else g_fill[cfg][dual ? 1 : 0][mode](*sc, pairs, order, ntasks, seq, tb, res);
 	return 0;
 }
 int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2,
                             int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, void *)
 {
-	if (ntasks > 0) g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode](*sc, pairs, order2, ntasks, seq, tb, res);
+	const bool lds = K2A_PK_LDSROWS(k2a_pkcfg_G[cfg], k2a_pkcfg_C[cfg], dual, mode, nomax) && sim_use_ldsrows();
+	if (ntasks > 0) (lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode])(*sc, pairs, order2, ntasks, seq, tb, res);
 	return 0;
 }
 int k2a_shim_launch_trace_pk(int cfg, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb,

@@ -640,3 +640,27 @@ def test_linear_xdrop_long_and_empty(lib):
     e = np.zeros(0, np.uint8); one = np.array([2], np.uint8); five = (np.arange(5) % 4).astype(np.uint8)
     for q, t in ((e, e), (one, e), (e, one), (five, e), (e, five), (one, one)):
         assert not diff(lib.extf2(q, t, 2, -4, 2, -1, 50), po.extf2("oracle", q, t, 2, -4, 2, -1, 50), gu.FIELDS), (len(q), len(t))
+
+
+@pytest.mark.parametrize("lds", ["0", "1"])
+def test_row_state_in_registers_and_in_lds(lib, lds, monkeypatch):
+    """Packed (64, 16) two-piece traceback and generation-serial single-gap traceback kernels with their per-row maxima in
+    registers (KSW2AMD_LDSROWS=0) and in LDS (=1); the launcher's own choice depends on the number of tasks."""
+    monkeypatch.setenv("KSW2AMD_LDSROWS", lds)
+    rng = np.random.Generator(np.random.PCG64(2025))
+    mat, q, e, q2, e2 = synth.simple_mat(5, 2, 4, -1), 4, 2, 24, 1
+    npk = 0
+    for rnd, (ql, w) in enumerate(((2500, 400), (9000, 500), (15000, 330))):
+        qs, ts = synth.fixed_batch(800 + rnd, 6, ql, ql - 20, sub=0.05, ind=0.1, tail_random_frac=0.3, tail_pairs=0.3)
+        zd = rng.choice([-1, 400, 2000], size=6)
+        for mode in (0, po.RIGHT):
+            fl = np.array([mode | (po.REV_CIGAR if rng.random() < 0.3 else 0) for _ in range(6)])
+            p = lib.make_batch(qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, flag=fl).plan(True)
+            npk += p.packed_pairs()
+            p.close()
+            check_batch(lib, True, qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, flag=fl)
+    assert npk >= 24
+    pairs = synth.ragged_pairs(rng, 4, 2100, 5000, sub=0.05, ind=0.12, indel_mean=4.0)
+    qs, ts = [p[0] for p in pairs], [p[1] for p in pairs]
+    for flag in (0, po.RIGHT):
+        check_batch(lib, False, qs, ts, mat, q, e, q2, e2, w=np.array([-1, 1500, 2000, -1]), zdrop=np.array([-1, 400, -1, 1000]), flag=flag)

@@ -457,3 +457,27 @@ def test_sim_linear_xdrop_golden_and_batches(sim, monkeypatch):
     e = np.zeros(0, np.uint8); one = np.array([2], np.uint8); five = np.arange(5, dtype=np.uint8) % 4
     for q, t in ((e, e), (one, e), (e, one), (five, e), (e, five), (one, one)):
         assert not diff(sim.extf2(q, t, 2, -4, 2, -1, 50), po.extf2("oracle", q, t, 2, -4, 2, -1, 50), gu.FIELDS), (len(q), len(t))
+
+
+@pytest.mark.parametrize("lds", ["0", "1"])
+def test_sim_row_state_in_registers_and_in_lds(sim, lds, monkeypatch):
+    """The classes that can keep row maxima / arg-max columns (and, packed, target codes) in LDS -- packed (64, 16) two-piece
+    with traceback, generation-serial single-gap with traceback -- in both forms (KSW2AMD_LDSROWS)."""
+    monkeypatch.setenv("KSW2AMD_LDSROWS", lds)
+    rng = np.random.Generator(np.random.PCG64(2024))
+    mat, q, e, q2, e2 = synth.simple_mat(5, 2, 4, -1), 4, 2, 24, 1
+    npk = 0
+    for rnd, (ql, w) in enumerate(((2500, 400), (5200, 500), (1800, 330))):      # w > 284: the 16-row geometry
+        qs, ts = synth.fixed_batch(700 + rnd, 4, ql, ql - 20, sub=0.05, ind=0.1, tail_random_frac=0.3, tail_pairs=0.3)
+        zd = rng.choice([-1, 400, 2000], size=4)
+        for mode in (0, po.RIGHT):
+            fl = np.array([mode | (po.REV_CIGAR if rng.random() < 0.3 else 0) for _ in range(4)])
+            p = sim.make_batch(qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, flag=fl).plan(True)
+            npk += p.packed_pairs()
+            p.close()
+            check_batch(sim, True, qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, flag=fl)
+    assert npk >= 16
+    pairs = synth.ragged_pairs(rng, 3, 2100, 3000, sub=0.05, ind=0.12, indel_mean=4.0)
+    qs, ts = [p[0] for p in pairs], [p[1] for p in pairs]
+    for flag in (0, po.RIGHT):
+        check_batch(sim, False, qs, ts, mat, q, e, q2, e2, w=np.array([-1, 1500, 2000]), zdrop=np.array([-1, 400, -1]), flag=flag)
