@@ -212,7 +212,7 @@ struct K2aLane {
 		const int lo = k2a_max(0, dd - w);
 		const int hi = k2a_min(rows_m1, dd + w);
 		const int cnt = k2a_max(hi - lo + 1, 0);
-		const uint32_t live = cnt >= 32 ? 0xffffffffu : ((1u << cnt) - 1u) << lo;
+		const uint32_t live = cnt >= 32 ? 0xffffffffu : ((1u << cnt) - 1u) << (lo & 31);      /* lo >= 32 only with cnt = 0 */
 		/* query code of this column; wildcard columns take the slow score path */
 		const int qcode = qb;
 		const int qsh = (qcode & 3) * 8;

@@ -292,7 +292,7 @@ struct K2aLanePk {
 		const int lo = k2a_max(0, dd - w);
 		const int hi = k2a_min(rows_m1, dd + w);
 		const int cnt = k2a_max(hi - lo + 1, 0);
-		const uint32_t live = ((1u << cnt) - 1u) << lo;
+		const uint32_t live = ((1u << cnt) - 1u) << (lo & 31);       /* lo >= 32 only with cnt = 0 */
 		const k2a_pk qcode = qb;
 		const k2a_pk jjpk = k2a_pk2(k - koff);
 		k2a_pk cand[C];

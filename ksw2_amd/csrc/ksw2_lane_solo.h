@@ -184,7 +184,7 @@ struct K2aLaneSolo {
 		 * its first column: no live rows there */
 		const int loA = k2a_max(0, ddA - w), hiA = k2a_min(rowsA_m1, ddA + w), cntA = k <= kfinA ? k2a_max(hiA - loA + 1, 0) : 0;
 		const int loB = k2a_max(0, ddB - w), hiB = k2a_min(rowsB_m1, ddB + w), cntB = k >= kB0 ? k2a_max(hiB - loB + 1, 0) : 0;
-		const uint32_t liveA = ((1u << cntA) - 1u) << loA, liveB = ((1u << cntB) - 1u) << loB;
+		const uint32_t liveA = ((1u << cntA) - 1u) << (loA & 31), liveB = ((1u << cntB) - 1u) << (loB & 31);   /* lo >= 32 only with cnt = 0 */
 		k2a_pk lv = k2a_pair16(liveA << (15 - (C - 1)), liveB << (15 - (C - 1)));      /* bit C-1 of each half at bit 15; row c at bit 15 - (C-1-c) */
 		const k2a_pk qcode = qb;
 		const k2a_pk jjpk = k2a_pair16((uint32_t)(k - koff) & 0xffffu, (uint32_t)(k - koff - 1) & 0xffffu);
