@@ -389,6 +389,7 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 	const char *solo_env = getenv("KSW2AMD_SOLO");
 	const int solo_mode = !solo_env ? 3 : !strcmp(solo_env, "0") ? 0 : !strcmp(solo_env, "all") ? 2 : 1;
 	const int use_pk = !getenv("KSW2AMD_NO_PK"), use_rb = !getenv("KSW2AMD_NO_RB");
+	const int pk_first = getenv("KSW2AMD_PK_FIRST") ? atoi(getenv("KSW2AMD_PK_FIRST")) : 0;   /* A/B runs: skip the smaller packed geometries */
 
 	g_err[0] = 0;
 	if (n < 0 || (n > 0 && !pairs) || !sc) { fail(KSW2AMD_E_PARAM, "plan_create: bad arguments%s", 0); return 0; }
@@ -470,7 +471,7 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 			const int plain = pk_eligible(&pkinfo[generic], a->qlen, d->tlen, w);
 			int pc;
 			/* (8 lanes x 18 rows) needs every register with traceback on: score-only pairs only */
-			for (pc = (mode == K2A_MODE_SCORE ? 0 : 1); pc < K2A_NPKCFG; ++pc)
+			for (pc = imax(mode == K2A_MODE_SCORE ? 0 : 1, pk_first); pc < K2A_NPKCFG; ++pc)
 				if (geom_fits(k2a_pkcfg_G[pc], k2a_pkcfg_C[pc], d->tlen, w) &&
 				    (plain || (use_rb && pk_window_ok(&pkinfo[generic], a->qlen, d->tlen, w, k2a_pkcfg_C[pc])))) break;
 			if (pc < K2A_NPKCFG) pk_ok[i] = (uint8_t)(1 + pc + (plain ? 0 : K2A_NPKCFG) + (is_approx(a->flag) ? 2 * K2A_NPKCFG : 0));
