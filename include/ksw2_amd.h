@@ -190,7 +190,7 @@ int  ksw2amd_plan_timing(ksw2amd_plan_t *plan, float *fill_ms, float *total_ms);
 /* in-band DP cells of the plan (exact band, all rows counted even if Z-drop stops early) and device bytes held */
 int64_t ksw2amd_plan_cells(const ksw2amd_plan_t *plan);
 int64_t ksw2amd_plan_device_bytes(const ksw2amd_plan_t *plan);
-/* alignments routed to the packed-int16 kernels (two same-shape alignments per lane group; DESIGN.md section 3.5) */
+/* alignments routed to the packed-int16 kernels (two same-shape alignments per lane group; DESIGN.md section 3.2b) */
 int64_t ksw2amd_plan_packed_pairs(const ksw2amd_plan_t *plan);
 /* a resident plan of splice-aware extensions; run / fetch / timing / cells / destroy as above */
 ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, const ksw2amd_spair_t *pairs);
