@@ -1,0 +1,77 @@
+"""Randomised GPU-vs-oracle soak (GPU box):  python tools/scripts/fuzz_gpu.py [seconds] [seed]
+Ragged batches of every function on the path under the kernel-selection switches; stops at the first difference."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, '.')
+import ksw2_amd as ka                    # noqa: E402
+from ksw2_amd import synth               # noqa: E402
+from oracle import pyoracle as po        # noqa: E402
+from oracle.gen_golden_extf import noisy_pair          # noqa: E402
+from oracle.gen_golden_exts import spliced_pair        # noqa: E402
+from tests.parity_util import check_batch, diff        # noqa: E402
+from tests import golden_util as gu                    # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.Generator(np.random.PCG64(seed))
+lib = ka.library()
+ENVS = [{}, {"KSW2AMD_SOLO": "1"}, {"KSW2AMD_SOLO": "all"}, {"KSW2AMD_LDSROWS": "0"}, {"KSW2AMD_LDSROWS": "1"}, {"KSW2AMD_NO_PK": "1"},
+        {"KSW2AMD_SIMDS": "0"}, {"KSW2AMD_EXTF_WIN": "1"}, {"KSW2AMD_EXTF_LDS": "1"}, {"KSW2AMD_EXTS_REG": "1"}]
+KEYS = sorted({k for e in ENVS for k in e})
+t0 = time.time()
+rounds = pairs = 0
+while time.time() - t0 < budget:
+    env = ENVS[rounds % len(ENVS)]
+    for k in KEYS:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    kind = rounds % 4
+    if kind < 2:                                                          # extz2 / extd2
+        dual = bool(kind)
+        a, b, q, e, q2, e2 = [(2, 4, 4, 2, 24, 1), (1, 3, 4, 1, 24, 1), (2, 4, 4, 2, 13, 1), (2, 5, 5, 3, 20, 2)][int(rng.integers(4))]
+        mat = synth.simple_mat(5, a, b, int(rng.choice([0, -1, -3])))
+        n = int(rng.integers(4, 40))
+        hi = int(rng.choice([150, 700, 2500, 7000]))
+        if rng.random() < 0.5:                                             # same-shape batch: the packed pairs
+            ql = int(rng.integers(20, hi)); tl = max(1, ql + int(rng.integers(-40, 40)))
+            qs, ts = synth.fixed_batch(int(rng.integers(1 << 30)), n, ql, tl, sub=0.05, ind=0.1, tail_random_frac=0.3, tail_pairs=0.3)
+            qs, ts = list(qs), list(ts)
+        else:
+            pr = synth.ragged_pairs(rng, n, 1, hi, sub=0.05, ind=0.12, n_rate=0.01 if rng.random() < 0.2 else 0.0)
+            qs, ts = [p[0] for p in pr], [p[1] for p in pr]
+        w = rng.choice([-1, 0, 1, 5, 16, 20, 64, 68, 100, 284, 285, 330, 500, 536, 537, 1040, 1041], size=n)
+        zd = rng.choice([-1, 50, 200, 400, 2000], size=n)
+        eb = rng.choice([0, 10, 50], size=n)
+        mode = int(rng.choice([po.SCORE_ONLY, 0, po.RIGHT]))
+        fl = np.array([mode | (po.EXTZ_ONLY if rng.random() < 0.3 else 0) | (po.REV_CIGAR if rng.random() < 0.3 else 0) |
+                       (po.GENERIC_SC if rng.random() < 0.2 else 0) for _ in range(n)])
+        check_batch(lib, dual, qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl)
+        pairs += n
+    elif kind == 2:                                                       # extf2
+        n = int(rng.integers(4, 40))
+        prs = [noisy_pair(rng, int(rng.integers(1, int(rng.choice([200, 1500, 6000])))), int(rng.integers(7))) for _ in range(n)]
+        w = rng.choice([-1, 0, 3, 16, 33, 100, 146, 147, 300, 402, 403, 900], size=n)
+        xd = rng.choice([-1, 10, 60, 500], size=n)
+        mch, mis, e = [(1, -2, 1), (2, -4, 2), (4, -6, 3)][int(rng.integers(3))]
+        res = lib.extf_batch([p[0] for p in prs], [p[1] for p in prs], mch, mis, e, w=w, xdrop=xd)
+        for i, r in enumerate(res):
+            exp = po.extf2("oracle", prs[i][0], prs[i][1], mch, mis, e, int(w[i]), int(xd[i]))
+            assert not diff(r, exp, gu.FIELDS), ("extf", env, len(prs[i][0]), len(prs[i][1]), int(w[i]), int(xd[i]))
+        pairs += n
+    else:                                                                 # exts2
+        n = int(rng.integers(4, 24))
+        prs = [spliced_pair(rng, int(rng.integers(1, int(rng.choice([300, 1200])))), low_complexity=rng.random() < 0.15) for _ in range(n)]
+        mat = po.simple_mat(5, 1, 2, 0)
+        fl = [int(rng.choice([0, po.SPLICE_FOR, po.SPLICE_REV | po.RIGHT, po.SPLICE_FOR | po.EXTZ_ONLY, po.SCORE_ONLY | po.SPLICE_FOR])) for _ in range(n)]
+        zd = [int(rng.choice([-1, 30, 200])) for _ in range(n)]
+        res = lib.exts_batch([p[0] for p in prs], [p[1] for p in prs], mat, 2, 1, 32, 4, zdrop=zd, flag=fl)
+        for i, r in enumerate(res):
+            exp = po.exts2("oracle", prs[i][0], prs[i][1], mat, 2, 1, 32, 4, zdrop=zd[i], flag=fl[i])
+            assert not diff(r, exp), ("exts", env, len(prs[i][0]), len(prs[i][1]), hex(fl[i]), zd[i])
+        pairs += n
+    rounds += 1
+print("fuzz ok: %d rounds, %d alignments, %.0f s, seed %d" % (rounds, pairs, time.time() - t0, seed))
