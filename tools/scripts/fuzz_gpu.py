@@ -1,4 +1,5 @@
-"""Randomised GPU-vs-oracle soak (GPU box):  python tools/scripts/fuzz_gpu.py [seconds] [seed]
+"""Randomised GPU-vs-oracle soak (GPU box):  python tools/scripts/fuzz_gpu.py [seconds] [seed] [long]
+("long": few long reads per batch -- re-based, LDS-row, solo and generation-serial classes on 5-20 k sequences.)
 Ragged batches of every function on the path under the kernel-selection switches; stops at the first difference."""
 import os
 import sys
@@ -17,6 +18,7 @@ from tests import golden_util as gu                    # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+LONG = len(sys.argv) > 3
 rng = np.random.Generator(np.random.PCG64(seed))
 lib = ka.library()
 ENVS = [{}, {"KSW2AMD_SOLO": "1"}, {"KSW2AMD_SOLO": "all"}, {"KSW2AMD_LDSROWS": "0"}, {"KSW2AMD_LDSROWS": "1"}, {"KSW2AMD_NO_PK": "1"},
@@ -29,21 +31,22 @@ while time.time() - t0 < budget:
     for k in KEYS:
         os.environ.pop(k, None)
     os.environ.update(env)
-    kind = rounds % 4
+    kind = rounds % 2 if LONG else rounds % 4
     if kind < 2:                                                          # extz2 / extd2
         dual = bool(kind)
         a, b, q, e, q2, e2 = [(2, 4, 4, 2, 24, 1), (1, 3, 4, 1, 24, 1), (2, 4, 4, 2, 13, 1), (2, 5, 5, 3, 20, 2)][int(rng.integers(4))]
         mat = synth.simple_mat(5, a, b, int(rng.choice([0, -1, -3])))
-        n = int(rng.integers(4, 40))
-        hi = int(rng.choice([150, 700, 2500, 7000]))
+        n = int(rng.integers(2, 9)) if LONG else int(rng.integers(4, 40))
+        hi = int(rng.choice([5000, 9000, 14000, 20000])) if LONG else int(rng.choice([150, 700, 2500, 7000]))
         if rng.random() < 0.5:                                             # same-shape batch: the packed pairs
-            ql = int(rng.integers(20, hi)); tl = max(1, ql + int(rng.integers(-40, 40)))
+            ql = int(rng.integers(hi // 2 if LONG else 20, hi)); tl = max(1, ql + int(rng.integers(-40, 40)))
             qs, ts = synth.fixed_batch(int(rng.integers(1 << 30)), n, ql, tl, sub=0.05, ind=0.1, tail_random_frac=0.3, tail_pairs=0.3)
             qs, ts = list(qs), list(ts)
         else:
-            pr = synth.ragged_pairs(rng, n, 1, hi, sub=0.05, ind=0.12, n_rate=0.01 if rng.random() < 0.2 else 0.0)
+            pr = synth.ragged_pairs(rng, n, hi // 3 if LONG else 1, hi, sub=0.05, ind=0.12, n_rate=0.01 if rng.random() < 0.2 else 0.0)
             qs, ts = [p[0] for p in pr], [p[1] for p in pr]
-        w = rng.choice([-1, 0, 1, 5, 16, 20, 64, 68, 100, 284, 285, 330, 500, 536, 537, 1040, 1041], size=n)
+        w = rng.choice([100, 284, 285, 330, 500, 536, 537, 800, 1040, 1041, 3000] + ([-1] if hi <= 9000 else []), size=n) if LONG else \
+            rng.choice([-1, 0, 1, 5, 16, 20, 64, 68, 100, 284, 285, 330, 500, 536, 537, 1040, 1041], size=n)
         zd = rng.choice([-1, 50, 200, 400, 2000], size=n)
         eb = rng.choice([0, 10, 50], size=n)
         mode = int(rng.choice([po.SCORE_ONLY, 0, po.RIGHT]))
