@@ -664,3 +664,23 @@ def test_row_state_in_registers_and_in_lds(lib, lds, monkeypatch):
     qs, ts = [p[0] for p in pairs], [p[1] for p in pairs]
     for flag in (0, po.RIGHT):
         check_batch(lib, False, qs, ts, mat, q, e, q2, e2, w=np.array([-1, 1500, 2000, -1]), zdrop=np.array([-1, 400, -1, 1000]), flag=flag)
+
+
+def test_automatic_kernel_choices_at_scale(lib, monkeypatch):
+    """The host's and launcher's own choices, which need thousands of wavefronts to trigger: unique-shape long reads go to the
+    solo kernel (>= 4 wavefronts per SIMD), a big two-piece traceback class takes the LDS row form (>= 1.5 per SIMD).
+    A sample of each batch against the oracle."""
+    monkeypatch.delenv("KSW2AMD_SIMDS", raising=False)          # the occupancy rules as in production
+    rng = np.random.Generator(np.random.PCG64(4242))
+    mat, q, e, q2, e2 = synth.simple_mat(5, 2, 4, -1), 4, 2, 24, 1
+    n = 6144
+    pairs = synth.ragged_pairs(rng, n, 3000, 5000, sub=0.05, ind=0.06)
+    qs, ts = [p[0] for p in pairs], [p[1] for p in pairs]
+    p = lib.make_batch(qs, ts, mat, q, e, q2, e2, w=300, zdrop=400, flag=po.SCORE_ONLY).plan(False)
+    assert p.packed_pairs() > n * 9 // 10                      # solo tasks count as packed
+    p.close()
+    check_batch(lib, False, qs, ts, mat, q, e, q2, e2, w=300, zdrop=400, flag=po.SCORE_ONLY, sample=list(range(0, n, 211)))
+    n = 3200
+    qs, ts = synth.fixed_batch(903, n, 2000, 1990, sub=0.05, ind=0.1, tail_random_frac=0.3, tail_pairs=0.3)
+    zd = rng.choice([-1, 400, 2000], size=n)
+    check_batch(lib, True, qs, ts, mat, q, e, q2, e2, w=330, zdrop=zd, flag=0, sample=list(range(0, n, 97)))
