@@ -367,11 +367,12 @@ void ksw2amd_plan_destroy(ksw2amd_plan_t *p)
 	free(p);
 }
 
-typedef struct { int64_t cost; uint32_t idx; } sort_t;
+typedef struct { int64_t cost; uint32_t idx, tf; } sort_t;      /* tf = true target length: part of a packed pair's shape */
 static int cmp_cost_desc(const void *a, const void *b)
 {
 	const sort_t *x = (const sort_t*)a, *y = (const sort_t*)b;
 	if (x->cost != y->cost) return x->cost > y->cost ? -1 : 1;
+	if (x->tf != y->tf) return x->tf > y->tf ? -1 : 1;
 	return x->idx < y->idx ? -1 : x->idx > y->idx;
 }
 
@@ -505,7 +506,7 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 			for (i = 0; i < n; ++i) {
 				uint64_t k1, k2;
 				if (!(p->h_cls[i] >= 0 && pk_ok[i] && pk_ok[i] != PASS_SOLO && ((p->h_cls[i] / 2) % 3 != K2A_MODE_SCORE || (solo_mode && solo_ok[i])) && k2a_pkcfg_G[(pk_ok[i] - 1) % K2A_NPKCFG] == 64)) continue;
-				k1 = ((uint64_t)(uint32_t)p->h_pairs[i].qlen << 32) | (uint32_t)p->h_pairs[i].tlen;
+				k1 = ((uint64_t)(uint32_t)p->h_pairs[i].qlen << 32) | (uint32_t)p->h_pairs[i].tlen_full;      /* with w this fixes the rows too */
 				k2 = ((uint64_t)(uint32_t)p->h_pairs[i].w << 32) | ((uint32_t)p->h_cls[i] << 8) | pk_ok[i] | 0x80000000u;     /* never 0 */
 				for (h = (size_t)((k1 * 0x9E3779B97F4A7C15ull ^ k2 * 0xC2B2AE3D27D4EB4Full) >> 20) & (cap - 1); tab[h].k2 && (tab[h].k1 != k1 || tab[h].k2 != k2);
 				     h = (h + 1) & (cap - 1)) {}
@@ -564,7 +565,8 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 	if (k2a_shim_h2d(p->d_seq, p->h_seq, p->seq_bytes, up)) { fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error()); goto err; }
 
 	/* pass 2: task lists per class, most expensive first (similar shapes end up in the same wavefront).  Packed-int16
-	 * candidates of a class are paired up with a neighbour of identical (qlen, tlen, w); a leftover is paired with itself. */
+	 * candidates of a class are paired up with a neighbour of identical (qlen, tlen, rows inside the band, w); a leftover is
+	 * paired with itself. */
 	{
 		enum { NB = NCLS_MAX * NPASS };
 		int bcnt[NB], bpos[NB], b;
@@ -579,6 +581,7 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 				sort_t *e_ = &srt[bpos[p->h_cls[i] * NPASS + pk_ok[i]]++];
 				e_->idx = (uint32_t)i;
 				e_->cost = ((int64_t)p->h_pairs[i].qlen << 40) + ((int64_t)p->h_pairs[i].tlen << 16) + p->h_pairs[i].w;
+				e_->tf = (uint32_t)p->h_pairs[i].tlen_full;
 			}
 		for (b = 0, k = 0; b < NB; ++b) {
 			const int cnt = bcnt[b], pass = b % NPASS;   /* 0: one alignment per lane group, 1 + pc (+ NPKCFG): packed class pc */
@@ -601,7 +604,8 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 				for (i = 0; i < cnt; ++ntask) {
 					const uint32_t ia = g[i].idx;
 					uint32_t ib = ia;
-					if (i + 1 < cnt && g[i + 1].cost == g[i].cost) { ib = g[i + 1].idx; i += 2; } else i += 1;
+					/* same (qlen, rows, w) AND same true target length: a target cut off by the band (rows < tlen) has no last row */
+					if (i + 1 < cnt && g[i + 1].cost == g[i].cost && g[i + 1].tf == g[i].tf) { ib = g[i + 1].idx; i += 2; } else i += 1;
 					p->h_order[k++] = ia; p->h_order[k++] = ib;
 				}
 			}

@@ -684,3 +684,17 @@ def test_automatic_kernel_choices_at_scale(lib, monkeypatch):
     qs, ts = synth.fixed_batch(903, n, 2000, 1990, sub=0.05, ind=0.1, tail_random_frac=0.3, tail_pairs=0.3)
     zd = rng.choice([-1, 400, 2000], size=n)
     check_batch(lib, True, qs, ts, mat, q, e, q2, e2, w=330, zdrop=zd, flag=0, sample=list(range(0, n, 97)))
+
+
+def test_pairs_share_the_true_target_length(lib):
+    """Found by tools/scripts/fuzz_gpu.py: two alignments with the same query length, band and rows inside the band but
+    different true target lengths (one target cut off by the band, so it has no last row: mte / score stay unset) must not
+    share a packed task."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    mat = synth.simple_mat(5, 2, 4, -1)
+    q = rng.integers(0, 4, 519).astype(np.uint8)
+    t = np.concatenate([q, rng.integers(0, 4, 10).astype(np.uint8)])
+    qs, ts = [q, q, q, q], [t[:524], t[:529], t[:524], t[:531]]
+    for dual in (False, True):
+        for flag in (po.SCORE_ONLY, 0):
+            check_batch(lib, dual, qs, ts, mat, 4, 2, 13, 1, w=5, zdrop=-1, end_bonus=10, flag=flag)

@@ -481,3 +481,17 @@ def test_sim_row_state_in_registers_and_in_lds(sim, lds, monkeypatch):
     qs, ts = [p[0] for p in pairs], [p[1] for p in pairs]
     for flag in (0, po.RIGHT):
         check_batch(sim, False, qs, ts, mat, q, e, q2, e2, w=np.array([-1, 1500, 2000]), zdrop=np.array([-1, 400, -1]), flag=flag)
+
+
+def test_sim_pairs_share_the_true_target_length(sim):
+    """Found by tools/scripts/fuzz_gpu.py: two alignments with the same query length, band and rows inside the band but
+    different true target lengths (one target cut off by the band, so it has no last row: mte / score stay unset) must not
+    share a packed task."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    mat = synth.simple_mat(5, 2, 4, -1)
+    q = rng.integers(0, 4, 519).astype(np.uint8)
+    t = np.concatenate([q, rng.integers(0, 4, 10).astype(np.uint8)])
+    qs, ts = [q, q, q, q], [t[:524], t[:529], t[:524], t[:531]]
+    for dual in (False, True):
+        for flag in (po.SCORE_ONLY, 0):
+            check_batch(sim, dual, qs, ts, mat, 4, 2, 13, 1, w=5, zdrop=-1, end_bonus=10, flag=flag)

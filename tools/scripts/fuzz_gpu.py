@@ -20,7 +20,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 LONG = len(sys.argv) > 3
 rng = np.random.Generator(np.random.PCG64(seed))
-lib = ka.library()
+lib = ka.Library(os.environ["KSW2AMD_FUZZ_LIB"]) if os.environ.get("KSW2AMD_FUZZ_LIB") else ka.library()      # the simulator build, for reproducing on the CPU
 ENVS = [{}, {"KSW2AMD_SOLO": "1"}, {"KSW2AMD_SOLO": "all"}, {"KSW2AMD_LDSROWS": "0"}, {"KSW2AMD_LDSROWS": "1"}, {"KSW2AMD_NO_PK": "1"},
         {"KSW2AMD_SIMDS": "0"}, {"KSW2AMD_EXTF_WIN": "1"}, {"KSW2AMD_EXTF_LDS": "1"}, {"KSW2AMD_EXTS_REG": "1"}]
 KEYS = sorted({k for e in ENVS for k in e})
@@ -52,7 +52,13 @@ while time.time() - t0 < budget:
         mode = int(rng.choice([po.SCORE_ONLY, 0, po.RIGHT]))
         fl = np.array([mode | (po.EXTZ_ONLY if rng.random() < 0.3 else 0) | (po.REV_CIGAR if rng.random() < 0.3 else 0) |
                        (po.GENERIC_SC if rng.random() < 0.2 else 0) for _ in range(n)])
-        check_batch(lib, dual, qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl)
+        try:
+            check_batch(lib, dual, qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl)
+        except AssertionError:
+            print("failing round", rounds, "env", env, "dual", dual, "scoring", (a, b, q, e, q2, e2))
+            import pickle
+            pickle.dump(dict(qs=qs, ts=ts, mat=mat, sc=(q, e, q2, e2), w=w, zd=zd, eb=eb, fl=fl, dual=dual), open("/tmp/fuzz_fail.pkl", "wb"))
+            raise
         pairs += n
     elif kind == 2:                                                       # extf2
         n = int(rng.integers(4, 40))
