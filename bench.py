@@ -1,18 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- GCUPS of the banded extension hot path on N MI355X (one process per GPU).
 
-A "step" = one pass of the fill (+ traceback) kernels over one resident batch of synthetic pairs.
-Default workload = BASELINE.json configs[1]: 65 536 pairs, qlen = tlen = 512, band 64, extz2 affine,
-score-only.  Inputs are resident in HBM before the timed region (ksw2amd_plan_create uploads them);
-`value` is whole-job GCUPS = exact-band DP cells of all ranks / max-over-ranks wall time.
+Headline workload (north_star): 10 000 x 10 000 extensions, band 500, Z-drop 400, ksw_extz2_sse semantics, score only.
+
+A "step" = ONE call of the drop-in batch entry point (ksw2amd_extz_batch / ksw2amd_extd_batch) on one batch of synthetic
+pairs that sit in ordinary host memory: pack into pinned staging, H2D, fill (+ traceback) kernels, D2H, ksw_extz_t assembly.
+`value` is therefore transfer-inclusive ("wall seconds incl. H2D/D2H"); the library overlaps the phases
+of successive chunks of the batch on its worker threads / streams.  The HBM-resident kernel rate of the same batch
+(ksw2amd_plan_run only, HIP events on the launch stream) is reported next to it as `value_hbm_resident` and prices the
+roofline.  The batch is sized so that the K = 20 steps of the driver's run take a few seconds.
+
+The other configurations of BASELINE.json (config 2, 3, 4 at 4 096 replicas, 5 with channel-derived target lengths) and the
+10 k case with CIGAR / at the n = 1 024 of SURVEY 8d run in the same process and are reported in the `also` array.
 
 Launch:  python bench.py [--gpus 1 --steps K --warmup W]
+         python bench.py --gpus N            (starts its own N ranks through torch.distributed.run)
          python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,48 +41,31 @@ OPS_PER_CELL = {("extz", True): 15, ("extz", False): 22, ("extd", True): 28, ("e
                 ("extf", True): 7}                            # score compare/select, add, two maxima, two subtractions
 VALU_PEAK_PK16 = 157.3e12
 HBM_PEAK = 8.0e12
+SO = ksw2_amd.KSW_EZ_SCORE_ONLY
 
 WORKLOADS = {
-    # name: (config index, n pairs, qlen, tlen, w, zdrop, dual, flag, sub, ind, tail_frac, tail_pairs)
-    "cfg2": dict(idx=2, n=65536, qlen=512, tlen=512, w=64, zdrop=-1, dual=False, flag=ksw2_amd.KSW_EZ_SCORE_ONLY, sub=0.05, ind=0.06),
-    "cfg3": dict(idx=3, n=16384, qlen=2048, tlen=2048, w=256, zdrop=400, dual=True, flag=0, sub=0.05, ind=0.10, tail_frac=0.25, tail_pairs=0.10),
-    # north_star's 10k x 10k banded extension.  4096 pairs per GPU: one alignment (or packed pair) per wavefront, and
-    # 1024 SIMDs need a few wavefronts each (1024 pairs leave half of them empty; the host then picks the int32 kernels)
-    "10k": dict(idx=6, n=4096, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=ksw2_amd.KSW_EZ_SCORE_ONLY, sub=0.05, ind=0.06),
+    # north_star's 10k x 10k banded extension.  49 152 pairs per step (0.96 GB of sequence, 4.8e11 cells): ~0.16 s per step.
+    "10k": dict(idx=6, n=49152, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=SO, sub=0.05, ind=0.06),
+    # the same at the n = 1 024 SURVEY 8d names: 512 packed wavefronts cannot fill 1 024 SIMDs, the host takes the int32 kernels
+    "10k-n1024": dict(idx=6, n=1024, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=SO, sub=0.05, ind=0.06),
     "10k-cigar": dict(idx=6, n=4096, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=0, sub=0.05, ind=0.06),
-    # config 4: MT-human x MT-orang (tests/golden/data), full global extz2 with CIGAR, replicated; 1024 replicas per GPU here:
-    # 147 GB of traceback (144 MB per pair at 4 bits per cell), one wavefront per SIMD.  4096 replicas do not fit one GPU at
-    # once; the batch entry points split such batches.
-    "cfg4": dict(idx=4, n=1024, qlen=16499, tlen=16569, w=-1, zdrop=-1, dual=False, flag=0, mt=True),
-    # config 5: ONT-like mix, target length uniform in [300, 20000] (64 length buckets), 3 % substitutions + 15 % indels, band 500,
-    # extd2 with Z-drop 400 and CIGAR; 16384 pairs per GPU here (the full config shards 1 M pairs over 8 GPUs)
+    "cfg2": dict(idx=2, n=65536, qlen=512, tlen=512, w=64, zdrop=-1, dual=False, flag=SO, sub=0.05, ind=0.06),
+    "cfg3": dict(idx=3, n=16384, qlen=2048, tlen=2048, w=256, zdrop=400, dual=True, flag=0, sub=0.05, ind=0.10, tail_frac=0.25, tail_pairs=0.10),
+    # config 4: MT-human x MT-orang (tests/golden/data), full global extz2 with CIGAR, 4 096 replicas: 590 GB of direction
+    # bits, so the batch entry point runs it as several plans (no single resident plan: transfer-inclusive figure only)
+    "cfg4": dict(idx=4, n=4096, qlen=16499, tlen=16569, w=-1, zdrop=-1, dual=False, flag=0, mt=True, resident_n=1024),
+    # config 5: ONT-like mix, query length uniform in [300, 20000], 3 % substitutions + 15 % indels, target length from the
+    # channel (|tlen - qlen| <= 450), band 500, extd2 with Z-drop 400 and CIGAR; 16 384 pairs = one eighth of the per-GPU share
+    # of the 1 M pair config (which shards over 8 GPUs)
     "cfg5": dict(idx=5, n=16384, qlen=0, tlen=0, w=500, zdrop=400, dual=True, flag=0, sub=0.03, ind=0.15, ragged=True),
-    # splice-aware extension: 16384 spliced pairs per GPU, 400-base query = two exons around a 1000-base GT..AG
-    # intron of a 1500-base target, unbanded, forward signals, CIGAR with N; the reference CLI's splice scoring
+    # splice-aware extension and gap-linear X-drop extension (N3): see DESIGN.md sections 3.6 / 3.7
     "exts": dict(idx=7, n=16384, qlen=400, tlen=1500, w=-1, zdrop=-1, dual=False, flag=0, sub=0.03, ind=0.0, splice=True),
-    # gap-linear X-drop extension: 16384 pairs per GPU, 1000 x 1000, band 100, no drop (every anti-diagonal runs)
-    "extf": dict(idx=8, n=16384, qlen=1000, tlen=1000, w=100, zdrop=-1, dual=False, flag=ksw2_amd.KSW_EZ_SCORE_ONLY, sub=0.05, ind=0.01, linear=True),
+    "extf": dict(idx=8, n=16384, qlen=1000, tlen=1000, w=100, zdrop=-1, dual=False, flag=SO, sub=0.05, ind=0.01, linear=True),
 }
+ALSO_DEFAULT = ["10k-n1024", "10k-cigar", "cfg2", "cfg3", "cfg5", "cfg4"]
 SCORING = dict(a=2, b=4, sc_n=-1, q=4, e=2, q2=24, e2=1)
 LINEAR_SCORING = dict(mch=2, mis=-4, e=2)
 SPLICE_SCORING = dict(a=1, b=2, sc_n=0, q=2, e=1, q2=32, noncan=4)
-
-
-def make_ragged(wl, rank, n):
-    """Length-bucketed ragged batch: every bucket is a fixed-shape batch from the vectorised channel; the query keeps the
-    length the channel produced on average (tlen * (1 + ind/2 * (mean_ins - mean_del)) ~ tlen), so |tlen - qlen| << band."""
-    rng = synth.rng_for(wl["idx"], 1000 + rank)
-    nb = 64
-    lens = np.sort(rng.integers(300, 20001, size=nb))
-    per = [n // nb + (1 if b < n % nb else 0) for b in range(nb)]
-    qs, ts = [], []
-    for b in range(nb):
-        if per[b] == 0:
-            continue
-        q, t = synth.fixed_batch(wl["idx"], per[b], int(lens[b]), int(lens[b]), sub=wl["sub"], ind=wl["ind"], stream=rank * 100 + b)
-        qs += list(q)
-        ts += list(t)
-    return qs, ts
 
 
 def make_spliced(wl, rank, n):
@@ -89,20 +82,33 @@ def make_spliced(wl, rank, n):
     return q, t
 
 
-def make_batch(wl, rank, n_override=None):
-    n = n_override or wl["n"]
+def make_batch(wl, rank, n):
+    """Synthetic pairs of the workload (tools/synth: one xorshift64* stream per pair, seed 20260001 + config index); rank r
+    takes pairs [r * n, (r + 1) * n) of the stream, so every rank aligns different data."""
     if wl.get("splice"):
         return make_spliced(wl, rank, n)
     if wl.get("ragged"):
-        return make_ragged(wl, rank, n)
+        return synth.fast_ragged(wl["idx"], n, 300, 20000, sub=wl["sub"], ind=wl["ind"], maxdiff=450, first=rank * n)
     if wl.get("mt"):
         from tests import golden_util as gu
         _, ts = gu.read_fasta("MT-human.fa")
         _, qs = gu.read_fasta("MT-orang.fa")
-        return np.repeat(qs[0][None, :], n, axis=0), np.repeat(ts[0][None, :], n, axis=0)
-    q, t = synth.fixed_batch(wl["idx"], n, wl["qlen"], wl["tlen"], sub=wl["sub"], ind=wl["ind"],
-                             tail_random_frac=wl.get("tail_frac", 0.0), tail_pairs=wl.get("tail_pairs", 0.0), stream=rank)
-    return q, t
+        q1, t1 = np.ascontiguousarray(qs[0]), np.ascontiguousarray(ts[0])
+        return [q1] * n, [t1] * n                        # same bytes; every replica is still packed, uploaded and computed
+    return synth.fast_fixed(wl["idx"], n, wl["qlen"], wl["tlen"], sub=wl["sub"], ind=wl["ind"],
+                            tail_random_frac=wl.get("tail_frac", 0.0), tail_pairs=wl.get("tail_pairs", 0.0), first=rank * n)
+
+
+def cells_of_rows(qlen, rows, w):
+    """In-band cells of target rows [0, rows) for arrays of (qlen, rows, w): the closed form of ksw2_host.c::band_cells."""
+    qlen, rows, w = (np.asarray(x, dtype=np.int64) for x in (qlen, rows, w))
+    T = np.minimum(qlen + w, rows)
+    a = qlen - 1 - w
+    na = np.where(a < 0, 0, np.minimum(a + 1, T))
+    nb = np.minimum(w + 1, T)
+    sum_en = na * (na - 1) // 2 + na * w + (T - na) * (qlen - 1)
+    sum_st = (T - nb) * (T - 1 + nb) // 2 - (T - nb) * w
+    return np.where(T <= 0, 0, sum_en - sum_st + T)
 
 
 def cpu_baseline(wl, q, t, mat, seconds=10.0):
@@ -121,26 +127,35 @@ def cpu_baseline(wl, q, t, mat, seconds=10.0):
         kind = "reference" if name.startswith("ksw_") else "port"
     fn = ctypes.cast(getattr(ref if name.startswith("ksw_") else olib, name), ctypes.c_void_p)
     olib.kso_cpu_bench.restype = ctypes.c_long
-    olib.kso_cpu_bench.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int8, ctypes.c_void_p, ctypes.c_int8, ctypes.c_int8,
+    olib.kso_cpu_bench.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int8, ctypes.c_void_p, ctypes.c_int8, ctypes.c_int8,
                                    ctypes.c_int8, ctypes.c_int8, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
-    if wl.get("ragged"):
-        return {"value": None, "unit": "GCUPS", "cores": 0, "kind": "skipped", "sample": "ragged workload: CPU baseline loop needs fixed shapes"}
-    cells_pair = synth.band_cells(wl["qlen"], wl["tlen"], wl["w"])
     S = SCORING
     mode = 3 if wl.get("linear") else 2 if wl.get("splice") else int(wl["dual"])
     if wl.get("linear"):
         S = dict(q=LINEAR_SCORING["mch"], e=LINEAR_SCORING["mis"], q2=LINEAR_SCORING["e"], e2=0)
     if wl.get("splice"):
         S = dict(q=SPLICE_SCORING["q"], e=SPLICE_SCORING["e"], q2=SPLICE_SCORING["q2"], e2=SPLICE_SCORING["noncan"])
-    qa, ta = np.ascontiguousarray(q), np.ascontiguousarray(t)
+    # a bounded sample: the first pairs of the batch (the loop wraps around if the CPU gets through them)
+    ns = min(len(q), 4096)
+    qa = [np.ascontiguousarray(q[i]) for i in range(ns)]
+    ta = [np.ascontiguousarray(t[i]) for i in range(ns)]
+    qp = np.array([x.ctypes.data for x in qa], dtype=np.int64)
+    tp = np.array([x.ctypes.data for x in ta], dtype=np.int64)
+    ql = np.array([len(x) for x in qa], dtype=np.int32)
+    tl = np.array([len(x) for x in ta], dtype=np.int32)
+    wv = np.where(wl["w"] < 0, np.maximum(ql, tl), wl["w"]).astype(np.int64)
+    cells = cells_of_rows(ql, tl, np.minimum(wv, np.maximum(ql, tl))).astype(np.float64)
     ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     out = {}
     for threads in sorted({1, ncores}):
         el = ctypes.c_double(0)
-        done = olib.kso_cpu_bench(fn, mode, threads, seconds, len(qa), wl["qlen"], wl["tlen"], qa.ctypes.data, ta.ctypes.data,
+        done = olib.kso_cpu_bench(fn, mode, threads, seconds, ns, qp.ctypes.data, tp.ctypes.data, ql.ctypes.data, tl.ctypes.data, None,
                                   5, mat.ctypes.data, S["q"], S["e"], S["q2"], S["e2"], wl["w"], wl["zdrop"], wl["flag"], ctypes.byref(el))
-        out[threads] = (done, el.value, done * cells_pair / el.value / 1e9)
+        # pairs are taken in order (index mod ns): cells of the pairs actually aligned
+        full, rem = divmod(int(done), ns)
+        c = full * cells.sum() + cells[:rem].sum()
+        out[threads] = (done, el.value, c / el.value / 1e9)
     n1, dt1, g1 = out[1]
     what = "reference %s, gcc -O2 -msse4.1, exact-max mode" % name if kind == "reference" else "oracle int32 scalar port (reference artefact absent: not comparable)"
     res = {"value": round(g1, 4), "unit": "GCUPS", "cores": 1, "kind": kind,
@@ -159,7 +174,139 @@ def recorded_traffic(workload):
     if not cand:
         return None, None
     d = json.load(open(cand[-1]))
-    return d["derived"]["hbm_bytes_gfx950_corrected"], os.path.relpath(cand[-1], ROOT)
+    return d["derived"].get("hbm_bytes_gfx950_corrected"), os.path.relpath(cand[-1], ROOT)
+
+
+class Job:
+    """One workload on this rank: host batch, the library's batch object, and the two measurements."""
+
+    def __init__(self, lib, name, wl, rank, n_override=None, approx=False):
+        self.lib, self.name, self.rank = lib, name, rank
+        if approx:
+            wl = dict(wl, flag=wl["flag"] | 0x08)
+        self.wl = wl
+        self.n = n_override or wl["n"]
+        t0 = time.perf_counter()
+        self.q, self.t = make_batch(wl, rank, self.n)
+        self.gen_s = time.perf_counter() - t0
+        S = SCORING
+        if wl.get("splice"):
+            P = SPLICE_SCORING
+            self.mat = synth.simple_mat(5, P["a"], P["b"], P["sc_n"])
+            self.wl = wl = dict(wl, flag=wl["flag"] | ksw2_amd.KSW_EZ_SPLICE_FOR)
+            self.batch = lib.make_splice_batch(list(self.q), list(self.t), self.mat, P["q"], P["e"], P["q2"], P["noncan"], zdrop=wl["zdrop"], flag=wl["flag"])
+            self.kind = "exts"
+        elif wl.get("linear"):
+            P = LINEAR_SCORING
+            self.mat = synth.simple_mat(5, P["mch"], -P["mis"], 0)          # for the CPU leg's signature only
+            self.batch = lib.make_linear_batch(list(self.q), list(self.t), P["mch"], P["mis"], P["e"], w=wl["w"], xdrop=wl["zdrop"])
+            self.kind = "extf"
+        else:
+            self.mat = synth.simple_mat(5, S["a"], S["b"], 0 if wl.get("mt") else S["sc_n"])
+            self.batch = lib.make_batch(self.q, self.t, self.mat, S["q"], S["e"], S["q2"], S["e2"], w=wl["w"], zdrop=wl["zdrop"], end_bonus=0, flag=wl["flag"])
+            self.kind = "extd" if wl["dual"] else "extz"
+        self.score_only = bool(wl["flag"] & SO)
+        ql, tl = np.asarray(self.batch.qlen if hasattr(self.batch, "qlen") else [len(x) for x in self.q]), \
+            np.asarray(self.batch.tlen if hasattr(self.batch, "tlen") else [len(x) for x in self.t])
+        self.qlen, self.tlen = ql.astype(np.int64), tl.astype(np.int64)
+        mx = np.maximum(self.qlen, self.tlen)
+        self.weff = np.where((wl["w"] < 0) | (wl["w"] > mx), mx, wl["w"]) if self.kind in ("extz", "extd", "extf") else mx
+        self.cells = int(cells_of_rows(self.qlen, self.tlen, self.weff).sum()) if self.kind != "exts" else int((self.qlen * self.tlen).sum())
+        self.ez = None
+
+    # ---- transfer-inclusive: one call of the batch entry point per step
+    def e2e_step(self):
+        b, L = self.batch, self.lib
+        if self.ez is None:
+            self.ez = (ksw2_amd.KswExtz * max(self.n, 1))()     # reused across steps like a caller would: CIGAR buffers are recycled
+        if self.kind == "exts":
+            L._check(L.lib.ksw2amd_exts_batch(None, ctypes.byref(b.sc), b.n, b.pairs, self.ez))
+        elif self.kind == "extf":
+            L._check(L.lib.ksw2amd_extf_batch(None, *b.par, b.n, b.pairs, self.ez))
+        else:
+            f = L.lib.ksw2amd_extd_batch if self.kind == "extd" else L.lib.ksw2amd_extz_batch
+            L._check(f(None, ctypes.byref(b.sc), b.n, b.pairs, self.ez))
+
+    def free_ez(self):
+        if self.ez is not None:
+            for i in range(self.n):
+                if self.ez[i].cigar:
+                    ksw2_amd._libc.free(ctypes.cast(self.ez[i].cigar, ctypes.c_void_p))
+            self.ez = None
+
+    # ---- HBM-resident: plan_run only, HIP events on the launch stream
+    def resident(self, steps, warmup, stream, min_seconds=0.0):
+        wl = self.wl
+        nres = wl.get("resident_n")
+        b = self.batch
+        if nres and nres < self.n:          # a plan of the whole batch does not fit one device: a slice of it
+            S = SCORING
+            b = self.lib.make_batch(self.q[:nres], self.t[:nres], self.mat, S["q"], S["e"], S["q2"], S["e2"], w=wl["w"], zdrop=wl["zdrop"], end_bonus=0, flag=wl["flag"])
+        plan = b.plan() if self.kind in ("exts", "extf") else b.plan(wl["dual"])
+        cells = plan.cells()
+        for _ in range(warmup):
+            plan.run(stream)
+        plan.timing()
+        fill_ms, total_ms = [], []
+        t0 = time.perf_counter()
+        k = 0
+        while k < steps or time.perf_counter() - t0 < min_seconds:
+            plan.run(stream)
+            f, tot = plan.timing()              # blocks on the step's last event
+            fill_ms.append(f)
+            total_ms.append(tot)
+            k += 1
+        wall = time.perf_counter() - t0
+        raw = plan.fetch_raw()
+        rows = raw[:, 11].astype(np.int64)
+        nn = b.n
+        if self.kind == "exts":
+            done = cells
+        else:
+            done = int(cells_of_rows(self.qlen[:nn], np.minimum(rows, self.tlen[:nn]), self.weff[:nn]).sum())
+        res = dict(n=nn, cells=cells, steps=k, wall_s=wall, kernel_ms=float(np.mean(total_ms)), fill_ms=float(np.mean(fill_ms)),
+                   cells_done=done, zdropped=int(raw[:, 1].sum()), packed_pairs=plan.packed_pairs(), device_bytes=plan.device_bytes())
+        plan.close()
+        return res
+
+
+def describe(job, world):
+    wl = job.wl
+    func = {"extf": "extf2 gap-linear X-drop", "exts": "exts2 splice-aware", "extd": "extd2 dual-gap", "extz": "extz2 affine"}[job.kind]
+    shape = "qlen in [300,20000] tlen from the channel" if wl.get("ragged") else "qlen=%d tlen=%d" % (wl["qlen"], wl["tlen"])
+    return "%s: %d pairs/step/GPU, %s band=%d zdrop=%d %s %s" % (job.name, job.n, shape, wl["w"], wl["zdrop"], func,
+                                                                 ("score-only" if job.score_only else "CIGAR") + (" APPROX_MAX" if wl["flag"] & 0x08 else ""))
+
+
+def roofline_of(job, res, workload_key):
+    ops = OPS_PER_CELL[(job.kind, job.score_only)]
+    kern_s = res["kernel_ms"] * 1e-3
+    achieved = res["cells"] * ops / kern_s
+    seq_bytes = int(job.qlen[:res["n"]].sum() + job.tlen[:res["n"]].sum())
+    alg_bytes = seq_bytes + 56 * res["n"] + (0 if job.score_only else res["cells"] // (1 if job.kind == "extd" else 2))
+    traffic, src = recorded_traffic(workload_key)
+    return {"bound": "valu", "achieved": round(achieved / 1e12, 4), "peak": VALU_PEAK_PK16 / 1e12, "unit": "Tiop/s",
+            "frac": round(achieved / VALU_PEAK_PK16, 5), "traffic": traffic, "traffic_source": src,
+            "ops_per_cell": ops, "kernel_ms": round(res["kernel_ms"], 4), "fill_kernel_ms": round(res["fill_ms"], 4),
+            "kernel_gcups": round(res["cells"] / kern_s / 1e9, 2), "pairs_per_launch": res["n"], "cells_per_launch": res["cells"],
+            "kernel_gcups_cells_filled": round(res["cells_done"] / kern_s / 1e9, 2),
+            "early_stop_fraction": round(1.0 - res["cells_done"] / max(res["cells"], 1), 5), "zdropped_pairs": res["zdropped"],
+            "algorithmic_bytes": alg_bytes, "hbm_algorithmic_GBps": round(alg_bytes / kern_s / 1e9, 2), "hbm_peak_GBps": HBM_PEAK / 1e9}
+
+
+def dtype_of(job, res):
+    if job.kind == "extf":
+        return "u8 (wrapping, one position per lane)"
+    npk = res["packed_pairs"]
+    return "int16x2 (packed, two alignments per lane)" if npk == res["n"] else "int32" if npk == 0 else "int16x2 + int32"
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
@@ -167,12 +314,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--pairs", type=int, default=0, help="override pairs per GPU (parity/debug only)")
+    ap.add_argument("--workload", default="10k", choices=sorted(WORKLOADS))
+    ap.add_argument("--pairs", type=int, default=0, help="override pairs per step and GPU (parity/debug only)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--also", default=None, help="comma-separated workloads for the `also` array ('' = none; default: the other configs at N = 1)")
+    ap.add_argument("--no-also", action="store_true")
+    ap.add_argument("--resident-only", action="store_true", help="profiling: only the HBM-resident kernel loop (what rocprofv3 should see)")
     ap.add_argument("--approx", action="store_true", help="OR KSW_EZ_APPROX_MAX into the flags (score + corner CIGAR only, as in the reference)")
     args = ap.parse_args()
+
+    # N > 1 without a launcher: start our own ranks BEFORE anything touches a GPU (a process that has initialised HIP is never
+    # re-exec'ed); the child ranks print the JSON line, we pass their exit code on
+    if args.gpus > 1 and "RANK" not in os.environ:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -195,28 +352,6 @@ def main():
 
     lib = ksw2_amd.library()
     lib.set_device(dev)
-    wl = WORKLOADS[args.workload]
-    if args.approx:
-        wl = dict(wl, flag=wl["flag"] | 0x08)
-    S = SCORING
-    q, t = make_batch(wl, rank, args.pairs or None)
-    n = len(q)
-    if wl.get("splice"):
-        P = SPLICE_SCORING
-        mat = synth.simple_mat(5, P["a"], P["b"], P["sc_n"])
-        wl = dict(wl, flag=wl["flag"] | ksw2_amd.KSW_EZ_SPLICE_FOR)
-        batch = lib.make_splice_batch(list(q), list(t), mat, P["q"], P["e"], P["q2"], P["noncan"], zdrop=wl["zdrop"], flag=wl["flag"])
-        plan = batch.plan()
-    elif wl.get("linear"):
-        P = LINEAR_SCORING
-        mat = synth.simple_mat(5, P["mch"], -P["mis"], 0)          # for the CPU leg's signature only
-        batch = lib.make_linear_batch(list(q), list(t), P["mch"], P["mis"], P["e"], w=wl["w"], xdrop=wl["zdrop"])
-        plan = batch.plan()
-    else:
-        mat = synth.simple_mat(5, S["a"], S["b"], 0 if wl.get("mt") else S["sc_n"])
-        batch = lib.make_batch(q, t, mat, S["q"], S["e"], S["q2"], S["e2"], w=wl["w"], zdrop=wl["zdrop"], end_bonus=0, flag=wl["flag"])
-        plan = batch.plan(wl["dual"])                 # packs and uploads: inputs resident in HBM from here on
-    cells = plan.cells()
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
@@ -225,67 +360,100 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ------------------------------------------------------------------ headline
+    job = Job(lib, args.workload, WORKLOADS[args.workload], rank, args.pairs or None, approx=args.approx)
+    if args.resident_only:
+        res = job.resident(args.steps, args.warmup, stream)
+        if rank == 0:
+            print(json.dumps({"resident_only": True, "workload": describe(job, world), "roofline": roofline_of(job, res, args.workload)}))
+        return
     for _ in range(args.warmup):
-        plan.run(stream)
+        job.e2e_step()
+    stats0 = lib.host_stats()
     barrier()
-    fill_ms, total_ms = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        plan.run(stream)
-        # per-launch device time from HIP events recorded on this stream by the library (blocks on the step's last event)
-        f, tot = plan.timing()
-        fill_ms.append(f)
-        total_ms.append(tot)
+        job.e2e_step()
     barrier()
     dt = time.perf_counter() - t0
+    stats1 = lib.host_stats()
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        cc = torch.tensor([cells], dtype=torch.float64, device=red_dev)
+        cc = torch.tensor([float(job.cells)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(cc, op=dist.ReduceOp.SUM)
         cells_all = float(cc.item())
-        pairs_all = n * world
+        pairs_all = job.n * world
     else:
-        cells_all, pairs_all = float(cells), n
+        cells_all, pairs_all = float(job.cells), job.n
+    job.free_ez()
+    lib.release_cache()
+    barrier()
+    res = job.resident(args.steps, max(1, min(args.warmup, 3)), stream)
+    lib.release_cache()
 
+    out = None
     if rank == 0:
-        score_only = bool(wl["flag"] & ksw2_amd.KSW_EZ_SCORE_ONLY)
-        ops = OPS_PER_CELL[("extf" if wl.get("linear") else "exts" if wl.get("splice") else "extd" if wl["dual"] else "extz", score_only)]
-        kern_ms = float(np.mean(total_ms))
-        fill_only_ms = float(np.mean(fill_ms))
-        achieved = cells * ops / (kern_ms * 1e-3)
-        seq_bytes = sum(len(x) for x in q) + sum(len(x) for x in t) if wl.get("ragged") else n * (wl["qlen"] + wl["tlen"])
-        alg_bytes = seq_bytes + 56 * n + (0 if score_only else cells // (1 if wl["dual"] else 2))
-        traffic, traffic_src = recorded_traffic(args.workload) if not args.pairs else (None, None)
-        npk = plan.packed_pairs()
-        dtype = "u8 (wrapping, one position per lane)" if wl.get("linear") else "int16x2 (packed, two alignments per lane)" if npk == n else "int32" if npk == 0 else "int16x2 + int32"
-        func = "extf2 gap-linear X-drop" if wl.get("linear") else "exts2 splice-aware" if wl.get("splice") else "extd2 dual-gap" if wl["dual"] else "extz2 affine"
+        rl = roofline_of(job, res, args.workload)
+        rl["note"] = ("integer-VALU bound (no dense contraction, SURVEY 8d); peak = the guide's vector peak 256CU x 4SIMD x 32 lanes x 2.4GHz x 2 "
+                      "(packed int16); measured with tools/probe/valu_rate.hip (profiles/r1d_valu_rate.txt): v_pk_*_i16, v_max_i32, v_bfi issue one "
+                      "wave64 instruction per 4 cycles per SIMD (add/sub/xor/bitop3: 2), i.e. 39.3 T lane-instr/s = 78.6 T 16-bit ops/s, half of `peak`")
+        value = cells_all * args.steps / dt / 1e9
         out = {
             "metric": "GCUPS (DP cells/s) + pairs/s at fixed (qlen,tlen,band)",
-            "value": round(cells_all * args.steps / dt / 1e9, 3), "unit": "GCUPS",
+            "value": round(value, 3), "unit": "GCUPS",
+            "value_definition": "exact-band cells of all pairs / wall time of `steps` calls of the batch entry point on host-memory inputs: "
+                                "pack + H2D + kernels + D2H + ksw_extz_t assembly (SURVEY 8d)",
+            "value_hbm_resident": rl["kernel_gcups"],
             "pairs_per_s": round(pairs_all * args.steps / dt, 1),
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": "%s: %d pairs/GPU, qlen=%d tlen=%d band=%d zdrop=%d %s %s" % (
-                args.workload, n, wl["qlen"], wl["tlen"], wl["w"], wl["zdrop"], func,
-                ("score-only" if score_only else "CIGAR") + (" APPROX_MAX" if args.approx else "")), "cells_per_gpu": cells, "parallelism": "pairs sharded over %d GPU(s), no collective" % world},
-            "roofline": {"bound": "valu", "achieved": round(achieved / 1e12, 4), "peak": VALU_PEAK_PK16 / 1e12, "unit": "Tiop/s",
-                         "frac": round(achieved / VALU_PEAK_PK16, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "ops_per_cell": ops, "kernel_ms": round(kern_ms, 4), "fill_kernel_ms": round(fill_only_ms, 4),
-                         "kernel_gcups": round(cells / (kern_ms * 1e-3) / 1e9, 2),
-                         "algorithmic_bytes": alg_bytes, "hbm_algorithmic_GBps": round(alg_bytes / (kern_ms * 1e-3) / 1e9, 2), "hbm_peak_GBps": HBM_PEAK / 1e9,
-                         "note": "integer-VALU bound (no dense contraction, SURVEY 8d); peak = the guide's vector peak 256CU x 4SIMD x 32 lanes x 2.4GHz x 2 "
-                                 "(packed int16); measured with tools/probe/valu_rate.hip (profiles/r1d_valu_rate.txt): v_pk_*_i16, v_max_i32, v_bfi issue one "
-                                 "wave64 instruction per 4 cycles per SIMD (add/sub/xor/bitop3: 2), so the attainable rate for this recurrence is 39.3 T "
-                                 "lane-instr/s; the fill kernels run at 4.35-4.45 cycles per instruction"},
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "timed_region_s": round(dt, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_of(job, res), "data": "synthetic",
+            "config": {"workload": describe(job, world), "cells_per_step_per_gpu": job.cells,
+                       "host_pipeline": {k: stats1[k] - stats0[k] for k in stats1},
+                       "parallelism": "pairs sharded over %d GPU(s), one process per GPU, no collective in the data path" % world},
+            "roofline": rl,
         }
+    # ------------------------------------------------------------------ the other configurations (N = 1: one run covers them all)
+    names = ALSO_DEFAULT if args.also is None else [x for x in args.also.split(",") if x]
+    if args.no_also or world > 1 or args.pairs or args.approx or args.workload != "10k":
+        names = [] if args.also is None else names
+    also = []
+    for name in names:
+        if name == args.workload:
+            continue
+        try:
+            j = Job(lib, name, WORKLOADS[name], rank)
+            j.e2e_step()                                         # warm-up: buffers, streams, worker threads
+            t0 = time.perf_counter()
+            k = 0
+            while k < 3 or time.perf_counter() - t0 < 1.5:
+                j.e2e_step()
+                k += 1
+            edt = time.perf_counter() - t0
+            j.free_ez()
+            lib.release_cache()
+            r = j.resident(3, 1, stream, min_seconds=1.0)
+            lib.release_cache()
+            rr = roofline_of(j, r, name)
+            also.append({"workload": describe(j, world), "value": round(j.cells * k / edt / 1e9, 2), "value_hbm_resident": rr["kernel_gcups"],
+                         "unit": "GCUPS", "pairs_per_s": round(j.n * k / edt, 1), "steps": k, "ms_per_step": round(edt / k * 1e3, 3),
+                         "dtype": dtype_of(j, r), "roofline": {x: rr[x] for x in ("frac", "kernel_ms", "fill_kernel_ms", "ops_per_cell", "pairs_per_launch",
+                                                                                   "kernel_gcups_cells_filled", "early_stop_fraction", "zdropped_pairs", "traffic", "traffic_source")}})
+            del j
+        except Exception as exc:                                  # one workload must not take the headline with it
+            also.append({"workload": name, "error": "%s: %s" % (type(exc).__name__, exc)})
+            lib.release_cache()
+    if rank == 0:
+        if also:
+            out["also"] = also
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(wl, q, t, mat, seconds=args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(job.wl, job.q, job.t, job.mat, seconds=args.cpu_seconds)
             if out["cpu_baseline"]["value"]:
                 out["gpu_over_cpu_1thread"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+                if "all_cores" in out["cpu_baseline"]:
+                    out["gpu_over_cpu_all_cores"] = round(out["value"] / out["cpu_baseline"]["all_cores"]["value"], 1)
         print(json.dumps(out))
-    plan.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -145,8 +145,23 @@ const char *ksw2amd_last_error(void);  /* message of the calling thread's last f
 const char *ksw2amd_backend(void);     /* "hip:gfx950" */
 int ksw2amd_device_count(void);
 int ksw2amd_set_device(int device);    /* device used by the calling thread's subsequent calls */
-/* each thread keeps the device / pinned buffers of its last batch for reuse (allocation costs milliseconds); this returns them */
+/* each thread keeps the device / pinned buffers of its last batch for reuse (allocation costs milliseconds); this returns the
+ * calling thread's and those of the library's worker threads */
 void ksw2amd_release_cache(void);
+/* Devices the batch entry points below shard their work over (process-wide; pairs are independent, so this is host-side
+ * sharding without any collective: the library's worker threads -- KSW2AMD_THREADS per device, default 4 -- pull chunks of
+ * the batch from a shared counter).  n = 0 (the default): the calling thread's current device only.
+ * Replaces nothing in the reference (ksw2.h has no device notion); SURVEY.md section 8b "device selection / multi-GPU inside". */
+int ksw2amd_set_devices(int n, const int *devices);
+/* The ksw2-named functions return void (ksw2.h:61-76), so a device failure has no return channel.  Default: message on
+ * stderr and abort() -- there is no CPU fallback to hide behind.  With a handler installed the failing call invokes it
+ * (function name, KSW2AMD_E_* code, message) and returns with *ez reset (ksw2.h:184-189: score = KSW_NEG_INF, no CIGAR). */
+typedef void (*ksw2amd_error_fn)(const char *func, int code, const char *msg, void *user);
+void ksw2amd_set_error_handler(ksw2amd_error_fn fn, void *user);
+long ksw2amd_error_count(void);        /* failed ksw2-named calls so far */
+/* diagnostics: { batches run on the worker pool, chunks they were cut into, single-pair calls that were coalesced with other
+ * threads' calls, device batches those formed } since the library was loaded */
+void ksw2amd_host_stats(int64_t out[4]);
 
 /* n independent alignments; ez[i] ends up exactly as after
  *   ksw_extz2_sse(km, pairs[i].qlen, pairs[i].query, ..., sc->m, sc->mat, sc->q, sc->e, w, zdrop, end_bonus, flag, &ez[i])

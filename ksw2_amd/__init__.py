@@ -67,7 +67,9 @@ EXPORTS = ["ksw_extz2_sse", "ksw_extd2_sse", "ksw_gg2", "ksw_gg2_sse", "ksw_extz
            "ksw2amd_extz_batch", "ksw2amd_extd_batch", "ksw2amd_plan_create", "ksw2amd_plan_run", "ksw2amd_plan_fetch",
            "ksw2amd_plan_destroy", "ksw2amd_plan_timing", "ksw2amd_plan_cells", "ksw2amd_plan_device_bytes", "ksw2amd_plan_packed_pairs",
            "ksw2amd_plan_fetch_raw", "ksw_exts2_sse", "ksw_exts2_sse41", "ksw_exts2_sse2", "ksw2amd_exts_batch", "ksw2amd_exts_plan_create",
-           "ksw_extf2_sse", "ksw2amd_extf_batch", "ksw2amd_extf_plan_create"]
+           "ksw_extf2_sse", "ksw2amd_extf_batch", "ksw2amd_extf_plan_create",
+           "ksw2amd_set_devices", "ksw2amd_set_error_handler", "ksw2amd_error_count", "ksw2amd_host_stats"]
+ERROR_FN = ctypes.CFUNCTYPE(None, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_void_p)
 KSW_EZ_SPLICE_FOR, KSW_EZ_SPLICE_REV, KSW_EZ_SPLICE_FLANK = 0x100, 0x200, 0x400
 
 
@@ -149,6 +151,13 @@ class Library:
         L.ksw2amd_plan_packed_pairs.argtypes = [ctypes.c_void_p]
         L.ksw2amd_plan_packed_pairs.restype = ctypes.c_int64
         L.ksw2amd_plan_fetch_raw.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]
+        L.ksw2amd_set_devices.argtypes = [_int, ctypes.POINTER(_int)]
+        L.ksw2amd_set_error_handler.argtypes = [ERROR_FN, ctypes.c_void_p]
+        L.ksw2amd_set_error_handler.restype = None
+        L.ksw2amd_error_count.restype = ctypes.c_long
+        L.ksw2amd_release_cache.restype = None
+        L.ksw2amd_host_stats.argtypes = [ctypes.POINTER(ctypes.c_int64)]
+        L.ksw2amd_host_stats.restype = None
 
     # ---- info
     def backend(self):
@@ -162,6 +171,28 @@ class Library:
 
     def last_error(self):
         return self.lib.ksw2amd_last_error().decode()
+
+    def set_devices(self, devices):
+        """ksw2amd_set_devices: the batch entry points shard over these devices ([] = the calling thread's device)."""
+        arr = (_int * max(len(devices), 1))(*devices)
+        self._check(self.lib.ksw2amd_set_devices(len(devices), arr))
+
+    def set_error_handler(self, fn):
+        """ksw2amd_set_error_handler: fn(func_name, code, message) instead of abort() when a ksw2-named call fails; None restores abort."""
+        self._err_cb = ERROR_FN(lambda f, c, m, u: fn(f.decode(), c, m.decode())) if fn else ctypes.cast(None, ERROR_FN)
+        self.lib.ksw2amd_set_error_handler(self._err_cb, None)
+
+    def error_count(self):
+        return int(self.lib.ksw2amd_error_count())
+
+    def release_cache(self):
+        self.lib.ksw2amd_release_cache()
+
+    def host_stats(self):
+        """ksw2amd_host_stats -> dict(pool_batches, pool_chunks, coalesced_calls, coalesced_batches)."""
+        out = (ctypes.c_int64 * 4)()
+        self.lib.ksw2amd_host_stats(out)
+        return dict(zip(("pool_batches", "pool_chunks", "coalesced_calls", "coalesced_batches"), (int(x) for x in out)))
 
     def _check(self, rc):
         if rc != 0:

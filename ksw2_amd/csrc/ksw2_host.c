@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <pthread.h>
 #include <string.h>
+#include <time.h>
 #include "../../include/ksw2_amd.h"
 #include "ksw2_shim.h"
 
@@ -36,10 +37,11 @@ static int fail(int code, const char *fmt, const char *detail)
 }
 
 void ksw2amd_release_cache(void);
+static void release_thread_cache(void);
 
 int ksw2amd_set_device(int device)
 {
-	ksw2amd_release_cache();                                /* cached buffers belong to the previous device */
+	release_thread_cache();                                 /* cached buffers belong to the previous device */
 	if (k2a_shim_set_device(device)) return fail(KSW2AMD_E_NODEVICE, "set_device: %s", k2a_shim_last_error());
 	return KSW2AMD_OK;
 }
@@ -48,7 +50,7 @@ int ksw2amd_set_device(int device)
  * Device allocations and page-locking cost milliseconds; a minimap2-style caller issues many batches (or single-pair
  * calls) from the same thread.  Each thread therefore keeps the buffers of its last plan (one per kind) and hands them to
  * the next plan when they are large enough.  ksw2amd_release_cache() returns them; switching device flushes them. */
-enum { BUF_HSEQ, BUF_SEQ, BUF_PAIRS, BUF_RES, BUF_ORDER, BUF_TB, BUF_CIG, BUF_BND, BUF_KINDS };
+enum { BUF_HSEQ, BUF_SEQ, BUF_PAIRS, BUF_RES, BUF_ORDER, BUF_TB, BUF_CIG, BUF_BND, BUF_POS, BUF_POOL, BUF_KINDS };
 static __thread struct { void *p; size_t cap; } g_cache[BUF_KINDS];
 static __thread void *g_ev_cache[3];
 /* Every host thread uploads and (in the one-shot entry points) computes on a stream of its own, so concurrent callers --
@@ -66,7 +68,7 @@ static void thread_exit_cb(void *unused)
 {
 	(void)unused;
 	pthread_mutex_lock(&g_exit_mu);
-	if (!g_exiting) ksw2amd_release_cache();
+	if (!g_exiting) release_thread_cache();
 	pthread_mutex_unlock(&g_exit_mu);
 }
 static void thread_exit_init(void) { pthread_key_create(&g_exit_key, thread_exit_cb); atexit(process_exit_cb); }
@@ -114,7 +116,7 @@ static void cache_put(int kind, void *p, size_t cap)
 	} else cache_free_raw(kind, p);
 }
 
-void ksw2amd_release_cache(void)
+static void release_thread_cache(void)
 {
 	int k;
 	for (k = 0; k < BUF_KINDS; ++k) { if (g_cache[k].p) cache_free_raw(k, g_cache[k].p); g_cache[k].p = 0; g_cache[k].cap = 0; }
@@ -376,7 +378,9 @@ static int cmp_cost_desc(const void *a, const void *b)
 	return x->idx < y->idx ? -1 : x->idx > y->idx;
 }
 
-ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs)
+/* `scalar`: the call came through ksw_extz / ksw_extd / ksw_gg* (matrix used as given, no end bonus, no mismatch-vs-gap
+ * reject, gap pieces kept in the caller's order).  Decided by the entry point, never by a bit in the caller's flags. */
+static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs)
 {
 	ksw2amd_plan_t *p;
 	int i, k, q, e, q2, e2, m, lo, ci;
@@ -396,6 +400,7 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 	if (n < 0 || (n > 0 && !pairs) || !sc) { fail(KSW2AMD_E_PARAM, "plan_create: bad arguments%s", 0); return 0; }
 	if (k2a_shim_device_count() <= 0) { fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend()); return 0; }
 	p = (ksw2amd_plan_t*)calloc(1, sizeof(*p));
+	if (!p) { fail(KSW2AMD_E_NOMEM, "plan_create: host allocation failed%s", 0); return 0; }
 	p->dual = !!dual; p->n = n; p->m = m = sc->m;
 	q = sc->q; e = sc->e; q2 = sc->q2; e2 = sc->e2;
 	p->h_cls = (int8_t*)malloc((size_t)n + 1);
@@ -403,12 +408,12 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 	p->h_flag = (int32_t*)malloc(sizeof(int32_t) * ((size_t)n + 1));
 	p->h_pairs = (K2aPair*)calloc((size_t)n + 1, sizeof(K2aPair));
 	p->h_res = (K2aResult*)calloc((size_t)n + 1, sizeof(K2aResult));
-	for (i = 0; i < n; ++i) { p->h_cls[i] = -1; p->h_flag[i] = pairs[i].flag; }
+	if (!p->h_cls || !p->h_half || !p->h_flag || !p->h_pairs || !p->h_res) { fail(KSW2AMD_E_NOMEM, "plan_create: host allocation failed%s", 0); goto err; }
+	for (i = 0; i < n; ++i) { p->h_cls[i] = -1; p->h_flag[i] = (pairs[i].flag & ~F_SCALAR_CONTRACT) | (scalar ? F_SCALAR_CONTRACT : 0); }
 
 	/* batch-level early rejects of the "...2_sse" signatures; the scalar-contract entry points skip the
 	 * mismatch-vs-gap test (ksw_extz has none) but still need a usable matrix */
 	{
-		int scalar = n > 0 && (pairs[0].flag & F_SCALAR_CONTRACT);
 		if (m <= 0 || (dual && m <= 1) || !sc->mat) p->reject_all = 1;
 		else if (m > K2A_MAXM) { fail(KSW2AMD_E_PARAM, "more than 127 residue types (int8_t m, ksw2.h:61)%s", 0); goto err; }
 		else {
@@ -440,9 +445,11 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 	pkinfo[0].ok = pkinfo[1].ok = -1;
 	pk_ok = (uint8_t*)calloc((size_t)n + 1, 1);
 	solo_ok = (uint8_t*)calloc((size_t)n + 1, 1);
+	if (!pk_ok || !solo_ok) { fail(KSW2AMD_E_NOMEM, "plan_create: host allocation failed%s", 0); goto err; }
 	for (i = 0; i < n; ++i) {
 		const ksw2amd_pair_t *a = &pairs[i];
 		K2aPair *d = &p->h_pairs[i];
+		const int fl = p->h_flag[i];
 		int w = a->w, cfg, mode, generic, mx, wild;
 		if (a->qlen <= 0 || a->tlen <= 0) continue;
 		wild = copy_scan(p->h_seq + d->qoff, a->query, a->qlen);
@@ -453,15 +460,15 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 		d->qlen = a->qlen; d->tlen_full = a->tlen; d->w = w;
 		d->tlen = (int64_t)a->qlen + w < a->tlen ? a->qlen + w : a->tlen;      /* rows i with i-w <= qlen-1 */
 		d->zdrop = a->zdrop;
-		d->end_bonus = (a->flag & F_SCALAR_CONTRACT) ? K2A_NEG : a->end_bonus;
-		d->flag = a->flag & (KSW_EZ_EXTZ_ONLY | KSW_EZ_REV_CIGAR | KSW_EZ_SCORE_ONLY);
-		if (is_approx(a->flag)) {                              /* only the score and the corner CIGAR exist in this mode */
+		d->end_bonus = scalar ? K2A_NEG : a->end_bonus;
+		d->flag = fl & (KSW_EZ_EXTZ_ONLY | KSW_EZ_REV_CIGAR | KSW_EZ_SCORE_ONLY);
+		if (is_approx(fl)) {                                   /* only the score and the corner CIGAR exist in this mode */
 			d->zdrop = -1;
-			if (a->flag & KSW_EZ_EXTZ_ONLY) d->flag |= KSW_EZ_SCORE_ONLY;
+			if (fl & KSW_EZ_EXTZ_ONLY) d->flag |= KSW_EZ_SCORE_ONLY;
 		}
 		for (cfg = 0; cfg < K2A_NCFG; ++cfg) if (cfg_fits(cfg, d->tlen, w)) break;
-		mode = (d->flag & KSW_EZ_SCORE_ONLY) ? K2A_MODE_SCORE : (a->flag & KSW_EZ_RIGHT) ? K2A_MODE_RIGHT : K2A_MODE_LEFT;
-		generic = (a->flag & (KSW_EZ_GENERIC_SC | F_SCALAR_CONTRACT)) ? 1 : 0;
+		mode = (d->flag & KSW_EZ_SCORE_ONLY) ? K2A_MODE_SCORE : (fl & KSW_EZ_RIGHT) ? K2A_MODE_RIGHT : K2A_MODE_LEFT;
+		generic = (fl & (KSW_EZ_GENERIC_SC | F_SCALAR_CONTRACT)) ? 1 : 0;
 		ci = (cfg * 3 + mode) * 2 + generic;
 		p->h_cls[i] = (int8_t)ci;
 		p->cells += band_cells(a->qlen, a->tlen, w);
@@ -475,9 +482,9 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 			for (pc = imax(mode == K2A_MODE_SCORE ? 0 : 1, pk_first); pc < K2A_NPKCFG; ++pc)
 				if (geom_fits(k2a_pkcfg_G[pc], k2a_pkcfg_C[pc], d->tlen, w) &&
 				    (plain || (use_rb && pk_window_ok(&pkinfo[generic], a->qlen, d->tlen, w, k2a_pkcfg_C[pc])))) break;
-			if (pc < K2A_NPKCFG) pk_ok[i] = (uint8_t)(1 + pc + (plain ? 0 : K2A_NPKCFG) + (is_approx(a->flag) ? 2 * K2A_NPKCFG : 0));
+			if (pc < K2A_NPKCFG) pk_ok[i] = (uint8_t)(1 + pc + (plain ? 0 : K2A_NPKCFG) + (is_approx(fl) ? 2 * K2A_NPKCFG : 0));
 			/* solo kernel: 2 * K2A_SOLO_C rows per lane share one base; a lane must finish a double strip before its next one starts */
-			if (solo_mode && !is_approx(a->flag) && pk_window_ok(&pkinfo[generic], a->qlen, d->tlen, w, 2 * K2A_SOLO_C) &&
+			if (solo_mode && !is_approx(fl) && pk_window_ok(&pkinfo[generic], a->qlen, d->tlen, w, 2 * K2A_SOLO_C) &&
 			    ((d->tlen + 2 * K2A_SOLO_C - 1) / (2 * K2A_SOLO_C) <= 64 || w < 64 * (K2A_SOLO_C + 1) - K2A_SOLO_C)) {
 				solo_ok[i] = 1;
 				if (solo_mode == 2) pk_ok[i] = PASS_SOLO;
@@ -503,6 +510,7 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 		if (any) {
 			while (cap < 2 * (size_t)any) cap <<= 1;
 			tab = (struct slot*)calloc(cap, sizeof(*tab));
+			if (!tab) { fail(KSW2AMD_E_NOMEM, "plan_create: host allocation failed%s", 0); goto err; }
 			for (i = 0; i < n; ++i) {
 				uint64_t k1, k2;
 				if (!(p->h_cls[i] >= 0 && pk_ok[i] && pk_ok[i] != PASS_SOLO && ((p->h_cls[i] / 2) % 3 != K2A_MODE_SCORE || (solo_mode && solo_ok[i])) && k2a_pkcfg_G[(pk_ok[i] - 1) % K2A_NPKCFG] == 64)) continue;
@@ -573,6 +581,7 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 		p->ncls = 0; p->ntasks = 0;
 		p->h_order = (uint32_t*)malloc(sizeof(uint32_t) * (2 * (size_t)n + 2));
 		srt = (sort_t*)malloc(sizeof(sort_t) * ((size_t)n + 1));
+		if (!p->h_order || !srt) { fail(KSW2AMD_E_NOMEM, "plan_create: host allocation failed%s", 0); goto err; }
 		memset(bcnt, 0, sizeof(bcnt));
 		for (i = 0; i < n; ++i) if (p->h_cls[i] >= 0) ++bcnt[p->h_cls[i] * NPASS + pk_ok[i]];
 		for (b = 0, k = 0; b < NB; ++b) { bpos[b] = k; k += bcnt[b]; }
@@ -666,11 +675,19 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 	if (m > 5) for (k = 0; k < p->ncls; ++k) p->cls[k].sc.mat = (const int8_t*)p->d_seq + mat_off + (p->cls[k].generic ? (size_t)m * m : 0);
 	for (i = 0; i < 3; ++i) { p->ev[i] = g_ev_cache[i] ? g_ev_cache[i] : k2a_shim_event_create(); g_ev_cache[i] = 0; }
 	free(pk_ok); free(solo_ok);
+	/* the uploads are complete: the plan no longer refers to the creating thread's stream (which may be gone -- thread exit,
+	 * ksw2amd_release_cache, ksw2amd_set_device -- before the plan runs or is destroyed) */
+	p->stream = 0; p->stream_used = 0;
 	return p;
 err:
 	free(srt); free(pk_ok); free(solo_ok);
 	ksw2amd_plan_destroy(p);
 	return 0;
+}
+
+ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs)
+{
+	return plan_create_ex(dual, 0, sc, n, pairs);
 }
 
 static int exts_plan_run(ksw2amd_plan_t *p, void *stream);
@@ -829,7 +846,11 @@ static void eqx_rewrite(void *km, const uint8_t *query, const uint8_t *target, i
 	free(old);
 }
 
-int ksw2amd_plan_fetch(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez)
+/* a kalloc pool has no locks (kalloc.c:24-28): the batch entry points' worker threads take this around every use of `km` */
+static pthread_mutex_t g_km_mu = PTHREAD_MUTEX_INITIALIZER;
+
+/* results into ez[i] with CIGAR memory from `km`, or -- the coalesced single calls -- into *ezp[i] with memory from kmp[i] */
+static int plan_fetch_ex(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez, ksw_extz_t **ezp, void **kmp)
 {
 	int i, rc = fetch_results(p);
 	uint32_t *pool = 0;
@@ -838,29 +859,36 @@ int ksw2amd_plan_fetch(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez)
 	if (!p->reject_all && p->cig_words) {
 		/* bring every CIGAR back with one D2H: prefix-sum the counts, compact on the device, download the pool */
 		uint32_t *hpos = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)p->n + 1)), *d_pos = 0, *d_pool = 0;
+		size_t cap_pos = 0, cap_pool = 0;
 		int bad = 0;
 		pos = (size_t*)malloc(sizeof(size_t) * ((size_t)p->n + 1));
+		if (!hpos || !pos) { free(hpos); free(pos); return fail(KSW2AMD_E_NOMEM, "plan_fetch: host allocation failed%s", 0); }
 		for (i = 0; i < p->n; ++i) {
 			if (p->h_cls[i] < 0) p->h_res[i].n_cigar = 0;
 			pos[i] = total; hpos[i] = (uint32_t)total;
 			total += (size_t)p->h_res[i].n_cigar;
 		}
 		pool = (uint32_t*)malloc(sizeof(uint32_t) * (total + 1));
+		if (!pool) { free(hpos); free(pos); return fail(KSW2AMD_E_NOMEM, "plan_fetch: host allocation failed%s", 0); }
 		if (total > 0) {
-			d_pos = (uint32_t*)k2a_shim_malloc(sizeof(uint32_t) * (size_t)p->n);
-			d_pool = (uint32_t*)k2a_shim_malloc(sizeof(uint32_t) * total);
+			/* device scratch from the thread's buffer cache: an allocation costs milliseconds and synchronises the device */
+			d_pos = (uint32_t*)cache_get(BUF_POS, sizeof(uint32_t) * (size_t)p->n, &cap_pos);
+			d_pool = (uint32_t*)cache_get(BUF_POOL, sizeof(uint32_t) * total, &cap_pool);
 			bad = !d_pos || !d_pool || total > 0xfff00000u ||
 			      k2a_shim_h2d(d_pos, hpos, sizeof(uint32_t) * (size_t)p->n, p->stream) ||
 			      k2a_shim_launch_compact(p->d_pairs, p->d_res, d_pos, p->n, p->d_cig, d_pool, p->stream) ||
 			      k2a_shim_d2h(pool, d_pool, sizeof(uint32_t) * total, p->stream) || k2a_shim_stream_sync(p->stream);
-			k2a_shim_free(d_pos); k2a_shim_free(d_pool);
+			if (bad) k2a_shim_stream_sync(p->stream);
+			cache_put(BUF_POS, d_pos, cap_pos); cache_put(BUF_POOL, d_pool, cap_pool);
 		}
 		free(hpos);
 		if (bad) { free(pos); free(pool); return fail(KSW2AMD_E_NODEVICE, "plan_fetch: %s", k2a_shim_last_error()); }
 	}
+	if (km || kmp) pthread_mutex_lock(&g_km_mu);
 	for (i = 0; i < p->n; ++i) {
-		ksw_extz_t *z = &ez[i];
+		ksw_extz_t *z = ezp ? ezp[i] : &ez[i];
 		const K2aResult *r = &p->h_res[i];
+		if (kmp) km = kmp[i];
 		ez_reset(z);
 		if (p->splice == 2 && p->h_cls[i] < 0) {          /* an empty sequence: ksw2_extf2_sse.c:33 runs no anti-diagonal, :37 leaves at the first */
 			if (imax(p->h_pairs[i].qlen, 0) + imax(p->h_pairs[i].tlen, 0) == 1) z->score = 0;
@@ -886,8 +914,14 @@ int ksw2amd_plan_fetch(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez)
 				eqx_rewrite(km, p->h_seq + p->h_pairs[i].qoff, p->h_seq + p->h_pairs[i].toff, 1, z);
 		}
 	}
+	if (km || kmp) pthread_mutex_unlock(&g_km_mu);
 	free(pos); free(pool);
 	return KSW2AMD_OK;
+}
+
+int ksw2amd_plan_fetch(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez)
+{
+	return plan_fetch_ex(p, km, ez, 0, 0);
 }
 
 /* ---------------------------------------------------------------- batch entry points */
@@ -910,13 +944,15 @@ static size_t pair_device_bytes(int dual, const ksw2amd_pair_t *a)
 	return b;
 }
 
-static int run_batch(int dual, void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez)
+/* One slice of a batch on the calling thread: plan(s) sized to `1 / share` of the device's free memory (share = threads that
+ * work on this device at the same time), each created, run on the thread's own stream, fetched and destroyed. */
+static int run_serial(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez, int share)
 {
 	size_t budget, free_b = 0, total_b = 0, acc;
 	const char *env = getenv("KSW2AMD_MAX_BYTES");
 	int beg = 0, end;
 	if (n <= 0) return KSW2AMD_OK;
-	if (k2a_shim_device_count() <= 0) return fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend());
+	if (share < 1) share = 1;
 	if (env && atoll(env) > 0) budget = (size_t)atoll(env);
 	else {
 		/* small batches (the single-pair entry points above all) skip the free-memory query: it costs ~0.1 ms */
@@ -924,7 +960,7 @@ static int run_batch(int dual, void *km, const ksw2amd_scoring_t *sc, int n, con
 		if (acc <= ((size_t)256 << 20)) budget = (size_t)1 << 30;
 		else {
 			if (k2a_shim_mem_info(&free_b, &total_b)) return fail(KSW2AMD_E_NODEVICE, "mem_info: %s", k2a_shim_last_error());
-			budget = free_b / 10 * 7;
+			budget = free_b / 10 * 7 / (size_t)share;
 		}
 	}
 	while (beg < n) {
@@ -942,10 +978,10 @@ static int run_batch(int dual, void *km, const ksw2amd_scoring_t *sc, int n, con
 		/* the footprint estimate is an upper bound in practice; should the device still run out, retry with half the pairs */
 		for (p = 0; p == 0; ) {
 			if (end - beg > limit) end = beg + limit;
-			p = ksw2amd_plan_create(dual, sc, end - beg, pairs + beg);
+			p = plan_create_ex(dual, scalar, sc, end - beg, pairs + beg);
 			if (p) break;
 			if (!strstr(g_err, "alloc") || end - beg <= 1) return strstr(g_err, "alloc") ? KSW2AMD_E_NOMEM : g_err[0] && strstr(g_err, "device") ? KSW2AMD_E_NODEVICE : KSW2AMD_E_PARAM;
-			ksw2amd_release_cache();
+			release_thread_cache();
 			limit = (end - beg) / 2;
 		}
 		rc = ksw2amd_plan_run(p, thread_stream());
@@ -957,46 +993,317 @@ static int run_batch(int dual, void *km, const ksw2amd_scoring_t *sc, int n, con
 	return KSW2AMD_OK;
 }
 
+/* ---------------------------------------------------------------- worker pool: chunked, pipelined, multi-device batches
+ * A large batch handed to one ksw2amd_ext?_batch call is cut into chunks of consecutive pairs that a few persistent worker
+ * threads pull from a shared counter.  Every worker packs, uploads, computes and fetches on a stream (and with pinned staging
+ * and device buffers) of its own, so chunk i+1 is packed and uploaded while chunk i computes and chunk i-1's results come
+ * back: one calling thread gets the device-bound rate instead of the sum of the phases.  With ksw2amd_set_devices() the
+ * workers belong to several GPUs and the same counter shards the batch over them (pairs are independent: no collective). */
+#define POOL_MAXW 64
+#define POOL_MAXDEV 16
+typedef int (*chunk_fn)(void *ctx, int beg, int end, int share);
+typedef struct {
+	chunk_fn fn; void *ctx;
+	int nchunks; const int *cbeg;               /* chunk c = pairs [cbeg[c], cbeg[c + 1]) */
+	int next;                                   /* next chunk, atomic */
+	int ndev, dev[POOL_MAXDEV], share;          /* devices of the job, worker threads per device */
+	int flush;                                  /* instead of chunks: every worker returns its cached buffers */
+	int rc; char err[512];                      /* first failure */
+	int pending;                                /* participating workers still busy */
+} job_t;
+static struct {
+	pthread_mutex_t mu, submit;
+	pthread_cond_t work, done;
+	int nw, gen;
+	int dev[POOL_MAXW];
+	job_t *job;
+} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, 0, 0, {0}, 0 };
+static int64_t g_stat[4];                          /* pooled batches, their chunks, coalesced single calls, the batches they formed */
+static int g_ndev_set, g_dev_set[POOL_MAXDEV];     /* ksw2amd_set_devices(); 0 = the calling thread's device */
+static __thread int g_is_worker;
+
+static int job_has_dev(const job_t *j, int dev)
+{
+	int i;
+	for (i = 0; i < j->ndev; ++i) if (j->dev[i] == dev) return 1;
+	return 0;
+}
+
+typedef struct { int idx, dev, seen; } worker_arg_t;
+
+static void *pool_worker(void *arg_)
+{
+	worker_arg_t *arg = (worker_arg_t*)arg_;
+	const int dev = arg->dev;
+	int seen = arg->seen;
+	free(arg);
+	g_is_worker = 1;
+	k2a_shim_set_device(dev);
+	pthread_mutex_lock(&g_pool.mu);
+	for (;;) {
+		job_t *j;
+		while (g_pool.gen == seen) pthread_cond_wait(&g_pool.work, &g_pool.mu);
+		seen = g_pool.gen; j = g_pool.job;
+		if (!j || !job_has_dev(j, dev)) continue;
+		pthread_mutex_unlock(&g_pool.mu);
+		if (j->flush) release_thread_cache();
+		else for (;;) {
+			const int c = __sync_fetch_and_add(&j->next, 1);
+			int rc;
+			if (c >= j->nchunks || j->rc) break;
+			rc = j->fn(j->ctx, j->cbeg[c], j->cbeg[c + 1], j->share);
+			if (rc) {
+				pthread_mutex_lock(&g_pool.mu);
+				if (!j->rc) { j->rc = rc; snprintf(j->err, sizeof(j->err), "%s", g_err); }
+				pthread_mutex_unlock(&g_pool.mu);
+			}
+		}
+		pthread_mutex_lock(&g_pool.mu);
+		if (--j->pending == 0) pthread_cond_broadcast(&g_pool.done);
+	}
+	return 0;
+}
+
+static int pool_threads_per_device(void)
+{
+	const char *e = getenv("KSW2AMD_THREADS");
+	int t = e ? atoi(e) : 4;
+	return t < 0 ? 0 : t > 16 ? 16 : t;
+}
+
+/* run `j` on the pool (workers for its devices are created on first use); returns -1 if the pool cannot take it now */
+static int pool_run(job_t *j)
+{
+	int i, d, have;
+	if (g_is_worker || pthread_mutex_trylock(&g_pool.submit)) return -1;      /* busy with another caller's batch: that caller runs inline */
+	pthread_mutex_lock(&g_pool.mu);
+	for (d = 0; d < j->ndev; ++d) {
+		for (i = 0, have = 0; i < g_pool.nw; ++i) have += g_pool.dev[i] == j->dev[d];
+		for (; have < j->share && g_pool.nw < POOL_MAXW; ++have) {
+			pthread_t th;
+			pthread_attr_t at;
+			worker_arg_t *wa = (worker_arg_t*)malloc(sizeof(*wa));
+			if (!wa) break;
+			wa->idx = g_pool.nw; wa->dev = j->dev[d]; wa->seen = g_pool.gen;
+			pthread_attr_init(&at);
+			pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
+			if (pthread_create(&th, &at, pool_worker, wa)) { free(wa); pthread_attr_destroy(&at); break; }
+			pthread_attr_destroy(&at);
+			g_pool.dev[g_pool.nw++] = j->dev[d];
+		}
+	}
+	for (i = 0, j->pending = 0; i < g_pool.nw; ++i) j->pending += job_has_dev(j, g_pool.dev[i]);
+	if (j->pending == 0) { pthread_mutex_unlock(&g_pool.mu); pthread_mutex_unlock(&g_pool.submit); return -1; }
+	g_pool.job = j; ++g_pool.gen;
+	if (!j->flush) { g_stat[0] += 1; g_stat[1] += j->nchunks; }
+	pthread_cond_broadcast(&g_pool.work);
+	while (j->pending > 0) pthread_cond_wait(&g_pool.done, &g_pool.mu);
+	g_pool.job = 0;
+	pthread_mutex_unlock(&g_pool.mu);
+	pthread_mutex_unlock(&g_pool.submit);
+	return 0;
+}
+
+void ksw2amd_host_stats(int64_t out[4])
+{
+	int i;
+	for (i = 0; i < 4; ++i) out[i] = g_stat[i];
+}
+
+int ksw2amd_set_devices(int n, const int *devices)
+{
+	int i;
+	if (n < 0 || n > POOL_MAXDEV || (n > 0 && !devices)) return fail(KSW2AMD_E_PARAM, "set_devices: bad arguments%s", 0);
+	for (i = 0; i < n; ++i)
+		if (devices[i] < 0 || devices[i] >= k2a_shim_device_count()) return fail(KSW2AMD_E_NODEVICE, "set_devices: no such device%s", 0);
+	pthread_mutex_lock(&g_pool.submit);
+	for (i = 0; i < n; ++i) g_dev_set[i] = devices[i];
+	g_ndev_set = n;
+	pthread_mutex_unlock(&g_pool.submit);
+	return KSW2AMD_OK;
+}
+
+void ksw2amd_release_cache(void)
+{
+	release_thread_cache();
+	if (!g_is_worker && g_pool.nw > 0) {       /* and the pool's threads */
+		job_t j;
+		int i;
+		memset(&j, 0, sizeof(j));
+		j.flush = 1;
+		pthread_mutex_lock(&g_pool.mu);
+		for (i = 0; i < g_pool.nw && j.ndev < POOL_MAXDEV; ++i) if (!job_has_dev(&j, g_pool.dev[i])) j.dev[j.ndev++] = g_pool.dev[i];
+		pthread_mutex_unlock(&g_pool.mu);
+		j.share = 0;
+		pool_run(&j);
+	}
+}
+
+/* cut [0, n) into chunks of consecutive pairs of about equal cost; cost[i] >= 1.  Returns the number of chunks, cbeg[0..nchunks] */
+static int make_chunks(int n, const double *cost, double total, int nchunks, int *cbeg)
+{
+	int i, c = 0;
+	double acc = 0;
+	cbeg[0] = 0;
+	for (i = 0; i < n; ++i) {
+		acc += cost[i];
+		if (c + 1 < nchunks && acc >= total * (c + 1) / nchunks && i + 1 < n) cbeg[++c] = i + 1;
+	}
+	cbeg[++c] = n;
+	return c;
+}
+
+/* decide how a batch of `n` items with the given sequence bytes / DP cells is run: 0 = inline on the caller, else the number
+ * of chunks.  Small batches are not worth the hand-off; beyond that there is at least one chunk per worker (packing is the
+ * bottleneck of short alignments), and no chunk holds more than KSW2AMD_CHUNK_MB of sequence or KSW2AMD_CHUNK_GCELLS * 1e9
+ * cells, so that uploads, kernels and downloads of different chunks overlap. */
+static int pool_min_pairs(void)
+{
+	const char *e = getenv("KSW2AMD_POOL_MIN");           /* tests: pool batches of this many pairs or more, whatever their size */
+	return e && atoi(e) > 0 ? atoi(e) : 0;
+}
+
+static int plan_chunks(int n, double bytes, double cells, int workers, int ndev)
+{
+	const char *e1 = getenv("KSW2AMD_CHUNK_MB"), *e2 = getenv("KSW2AMD_CHUNK_GCELLS");
+	const double cap_b = (e1 && atof(e1) > 0 ? atof(e1) : 64.0) * 1048576.0, cap_c = (e2 && atof(e2) > 0 ? atof(e2) : 40.0) * 1e9;
+	const int forced = pool_min_pairs(), min_chunk = forced ? imax(forced / 4, 1) : 256;
+	double k;
+	if (workers <= 0) return 0;
+	if (forced) { if (n < forced) return 0; k = workers; }
+	else {
+		if (n < 512 || (bytes < 4.0 * 1048576.0 && cells < 2e9)) return 0;
+		k = bytes / (2.0 * 1048576.0);
+		if (k > workers) k = workers;
+	}
+	if (bytes / cap_b > k) k = bytes / cap_b;
+	if (cells / cap_c > k) k = cells / cap_c;
+	if (ndev > 1 && k < 3 * workers) k = 3 * workers;      /* several devices: finer grains balance them */
+	if (k > n / min_chunk) k = n / min_chunk;
+	return k < 2 ? 0 : (int)(k + 0.999);
+}
+
+typedef struct { int dual, scalar; void *km; const ksw2amd_scoring_t *sc; const ksw2amd_pair_t *pairs; ksw_extz_t *ez; } ext_ctx_t;
+static int ext_chunk(void *ctx_, int beg, int end, int share)
+{
+	ext_ctx_t *c = (ext_ctx_t*)ctx_;
+	return run_serial(c->dual, c->scalar, c->km, c->sc, end - beg, c->pairs + beg, c->ez + beg, share);
+}
+
+/* devices of a pooled job: ksw2amd_set_devices() or the calling thread's current device */
+static void job_devices(job_t *j)
+{
+	int i;
+	if (g_ndev_set > 0) { j->ndev = g_ndev_set; for (i = 0; i < g_ndev_set; ++i) j->dev[i] = g_dev_set[i]; }
+	else { j->ndev = 1; j->dev[0] = k2a_shim_get_device(); if (j->dev[0] < 0) j->dev[0] = 0; }
+}
+
+/* run the chunks of a batch on the pool; 1 = done (rc in *rc), 0 = the caller must run the batch inline */
+static int run_pooled(chunk_fn fn, void *ctx, int n, const double *cost, double total, int nchunks, int *rc)
+{
+	job_t j;
+	int *cbeg = (int*)malloc(sizeof(int) * ((size_t)nchunks + 2));
+	if (!cbeg) return 0;
+	memset(&j, 0, sizeof(j));
+	j.fn = fn; j.ctx = ctx; j.cbeg = cbeg;
+	j.nchunks = make_chunks(n, cost, total, nchunks, cbeg);
+	j.share = pool_threads_per_device();
+	job_devices(&j);
+	if (pool_run(&j)) { free(cbeg); return 0; }
+	free(cbeg);
+	if (j.rc) snprintf(g_err, sizeof(g_err), "%s", j.err);
+	*rc = j.rc;
+	return 1;
+}
+
+static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez)
+{
+	const int tpd = pool_threads_per_device();
+	if (n <= 0) return KSW2AMD_OK;
+	if (k2a_shim_device_count() <= 0) return fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend());
+	if (n >= (pool_min_pairs() ? pool_min_pairs() : 512) && tpd > 0 && !g_is_worker) {
+		const int workers = tpd * (g_ndev_set > 0 ? g_ndev_set : 1);
+		double *cost = (double*)malloc(sizeof(double) * (size_t)n), bytes = 0, cells = 0, total = 0;
+		int i, nchunks, rc = 0;
+		if (cost) {
+			for (i = 0; i < n; ++i) {
+				const int ql = imax(pairs[i].qlen, 0), tl = imax(pairs[i].tlen, 0), mx = imax(ql, tl);
+				const double b = (double)ql + tl, c = ql && tl ? (double)band_cells(ql, tl, (pairs[i].w < 0 || pairs[i].w > mx) ? mx : pairs[i].w) : 0;
+				bytes += b; cells += c;
+				cost[i] = 1.0 + c + 64.0 * b;              /* a byte costs the host about as much as 64 cells cost the device */
+				total += cost[i];
+			}
+			nchunks = plan_chunks(n, bytes, cells, workers, g_ndev_set);
+			if (nchunks >= 2) {
+				ext_ctx_t ctx;
+				ctx.dual = dual; ctx.scalar = scalar; ctx.km = km; ctx.sc = sc; ctx.pairs = pairs; ctx.ez = ez;
+				if (run_pooled(ext_chunk, &ctx, n, cost, total, nchunks, &rc)) { free(cost); return rc; }
+			}
+			free(cost);
+		}
+	}
+	return run_serial(dual, scalar, km, sc, n, pairs, ez, 1);
+}
+
 int ksw2amd_extz_batch(void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez)
 {
-	return run_batch(0, km, sc, n, pairs, ez);
+	return run_batch(0, 0, km, sc, n, pairs, ez);
 }
 
 int ksw2amd_extd_batch(void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez)
 {
-	return run_batch(1, km, sc, n, pairs, ez);
+	return run_batch(1, 0, km, sc, n, pairs, ez);
 }
 
 /* ---------------------------------------------------------------- the ksw2-named single-pair calls */
 
-static void die_loudly(const char *fn)
+/* The ksw2 signatures return void: a HIP failure (no device, out of memory) has no channel.  There is no CPU fallback, so by
+ * default the library reports on stderr and aborts.  A caller that must survive installs a handler: it is called with the
+ * function name, the KSW2AMD_E_* code and the message, and the call then returns with `ez` reset (score = KSW_NEG_INF,
+ * no CIGAR) -- never with a made-up result.  ksw2amd_error_count() tells how often that happened. */
+static ksw2amd_error_fn g_err_fn;
+static void *g_err_user;
+static long g_err_count;
+
+void ksw2amd_set_error_handler(ksw2amd_error_fn fn, void *user) { g_err_fn = fn; g_err_user = user; }
+long ksw2amd_error_count(void) { return g_err_count; }
+
+static void call_failed(const char *fn, int code, ksw_extz_t *ez)
 {
-	fprintf(stderr, "[ksw2_amd] %s: %s -- libksw2_amd has no CPU fallback, aborting\n", fn, g_err);
+	__sync_fetch_and_add(&g_err_count, 1);
+	if (ez) ez_reset(ez);
+	if (g_err_fn) { g_err_fn(fn, code, g_err, g_err_user); return; }
+	fprintf(stderr, "[ksw2_amd] %s: %s -- libksw2_amd has no CPU fallback (install ksw2amd_set_error_handler() to survive), aborting\n", fn, g_err);
 	abort();
 }
 
-static void one_pair(const char *fn, int dual, void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m,
+static int queue_one(const char *fn, int dual, void *km, const ksw2amd_scoring_t *sc, const ksw2amd_pair_t *pr, ksw_extz_t *ez);
+
+static void one_pair(const char *fn, int dual, int scalar, void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m,
                      const int8_t *mat, int8_t q, int8_t e, int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag,
                      ksw_extz_t *ez)
 {
 	ksw2amd_scoring_t sc;
 	ksw2amd_pair_t pr;
+	int rc;
 	sc.m = m; sc.mat = mat; sc.q = q; sc.e = e; sc.q2 = q2; sc.e2 = e2;
 	pr.query = query; pr.target = target; pr.qlen = qlen; pr.tlen = tlen;
-	pr.w = w; pr.zdrop = zdrop; pr.end_bonus = end_bonus; pr.flag = flag;
-	if (run_batch(dual, km, &sc, 1, &pr, ez) != KSW2AMD_OK) die_loudly(fn);
+	pr.w = w; pr.zdrop = zdrop; pr.end_bonus = end_bonus; pr.flag = flag & ~F_SCALAR_CONTRACT;
+	if (!scalar && queue_one(fn, dual, km, &sc, &pr, ez)) return;     /* coalesced with other threads' calls */
+	rc = run_serial(dual, scalar, km, &sc, 1, &pr, ez, 1);
+	if (rc != KSW2AMD_OK) call_failed(fn, rc, ez);
 }
 
 void ksw_extz2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
                    int8_t q, int8_t e, int w, int zdrop, int end_bonus, int flag, ksw_extz_t *ez)
 {
-	one_pair("ksw_extz2_sse", 0, km, qlen, query, tlen, target, m, mat, q, e, 0, 0, w, zdrop, end_bonus, flag & ~F_SCALAR_CONTRACT, ez);
+	one_pair("ksw_extz2_sse", 0, 0, km, qlen, query, tlen, target, m, mat, q, e, 0, 0, w, zdrop, end_bonus, flag, ez);
 }
 
 void ksw_extd2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
                    int8_t q, int8_t e, int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, ksw_extz_t *ez)
 {
-	one_pair("ksw_extd2_sse", 1, km, qlen, query, tlen, target, m, mat, q, e, q2, e2, w, zdrop, end_bonus, flag & ~F_SCALAR_CONTRACT, ez);
+	one_pair("ksw_extd2_sse", 1, 0, km, qlen, query, tlen, target, m, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
 }
 
 void ksw_extz2_sse41(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
@@ -1016,13 +1323,13 @@ void ksw_extd2_sse2(void *km, int qlen, const uint8_t *query, int tlen, const ui
 void ksw_extz(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
               int8_t q, int8_t e, int w, int zdrop, int flag, ksw_extz_t *ez)
 {
-	one_pair("ksw_extz", 0, km, qlen, query, tlen, target, m, mat, q, e, 0, 0, w, zdrop, 0, flag | F_SCALAR_CONTRACT, ez);
+	one_pair("ksw_extz", 0, 1, km, qlen, query, tlen, target, m, mat, q, e, 0, 0, w, zdrop, 0, flag, ez);
 }
 
 void ksw_extd(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
               int8_t q, int8_t e, int8_t q2, int8_t e2, int w, int zdrop, int flag, ksw_extz_t *ez)
 {
-	one_pair("ksw_extd", 1, km, qlen, query, tlen, target, m, mat, q, e, q2, e2, w, zdrop, 0, flag | F_SCALAR_CONTRACT, ez);
+	one_pair("ksw_extd", 1, 1, km, qlen, query, tlen, target, m, mat, q, e, q2, e2, w, zdrop, 0, flag, ez);
 }
 
 static int global_align(const char *fn, void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m,
@@ -1033,8 +1340,7 @@ static int global_align(const char *fn, void *km, int qlen, const uint8_t *query
 	const int with_cigar = m_cigar_ && n_cigar_ && cigar_;
 	memset(&ez, 0, sizeof(ez));
 	if (with_cigar) { ez.cigar = *cigar_; ez.m_cigar = *m_cigar_; *n_cigar_ = 0; }
-	one_pair(fn, 0, km, qlen, query, tlen, target, m, mat, q, e, 0, 0, w, -1, 0,
-	         (with_cigar ? 0 : KSW_EZ_SCORE_ONLY) | F_SCALAR_CONTRACT, &ez);
+	one_pair(fn, 0, 1, km, qlen, query, tlen, target, m, mat, q, e, 0, 0, w, -1, 0, with_cigar ? 0 : KSW_EZ_SCORE_ONLY, &ez);
 	if (with_cigar) {
 		*cigar_ = ez.cigar; *m_cigar_ = ez.m_cigar;
 		*n_cigar_ = ez.zdropped ? 0 : ez.n_cigar;
@@ -1051,6 +1357,115 @@ int ksw_gg2(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *t
 int ksw_gg2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
                 int8_t q, int8_t e, int w, int *m_cigar_, int *n_cigar_, uint32_t **cigar_)
 { return global_align("ksw_gg2_sse", km, qlen, query, tlen, target, m, mat, q, e, w, m_cigar_, n_cigar_, cigar_); }
+
+/* ---------------------------------------------------------------- coalescing of concurrent single-pair calls
+ * A minimap2-style caller runs a pool of host threads that each call ksw_extz2_sse / ksw_extd2_sse for one pair at a time.
+ * One pair is far too little work for a launch: the call costs ~0.45 ms of fixed latency, and the runtime serialises the
+ * threads' API calls.  So at most KSW2AMD_COALESCE_SLOTS (default 4, 0 = off) device batches of single-pair calls are in
+ * flight at a time.  A call that finds a free slot runs at once, alone, exactly as before.  A call that finds none queues
+ * up; the first one in the queue becomes the leader, waits for a slot -- while every other arriving call joins the queue --
+ * and then runs everybody's pairs as ONE batch per (function, scoring) group, each result into the caller's own ksw_extz_t
+ * with CIGAR memory from the caller's own km.  Few threads: no added latency.  Many threads: batches of about half the
+ * thread count alternate on the device.  Results are identical either way. */
+#define COAL_MAXQ 512
+typedef struct creq_s {
+	struct creq_s *next;
+	int dual, done, rc, taken;
+	const ksw2amd_scoring_t *sc;
+	const ksw2amd_pair_t *pr;
+	void *km;
+	ksw_extz_t *ez;
+	char err[200];
+} creq_t;
+static struct {
+	pthread_mutex_t mu;
+	pthread_cond_t arrive, finished;
+	creq_t *head, *tail;
+	int count, leader, busy;
+} g_coal = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, 0, 0, 0, 0, 0 };
+
+static int same_scoring(const creq_t *a, const creq_t *b)
+{
+	const ksw2amd_scoring_t *x = a->sc, *y = b->sc;
+	if (a->dual != b->dual || x->m != y->m || x->q != y->q || x->e != y->e || (a->dual && (x->q2 != y->q2 || x->e2 != y->e2))) return 0;
+	if (x->mat == y->mat) return 1;
+	if (!x->mat || !y->mat || x->m <= 0) return 0;
+	return memcmp(x->mat, y->mat, (size_t)x->m * x->m) == 0;
+}
+
+static void coal_process(creq_t *list)
+{
+	creq_t *r, *g;
+	for (g = list; g; g = g->next) {
+		ksw2amd_pair_t pairs[COAL_MAXQ];
+		ksw_extz_t *ezp[COAL_MAXQ];
+		void *kmp[COAL_MAXQ];
+		creq_t *mem[COAL_MAXQ];
+		ksw2amd_plan_t *p;
+		size_t bytes = 0;
+		int n = 0, rc = KSW2AMD_OK, i;
+		if (g->taken) continue;
+		for (r = g; r && n < COAL_MAXQ; r = r->next) {
+			size_t b;
+			if (r->taken || !same_scoring(g, r)) continue;
+			b = pair_device_bytes(g->dual, r->pr);
+			if (n > 0 && bytes + b > ((size_t)8 << 30)) continue;       /* stays for a later group */
+			bytes += b;
+			r->taken = 1; mem[n] = r; pairs[n] = *r->pr; ezp[n] = r->ez; kmp[n] = r->km; ++n;
+		}
+		__sync_fetch_and_add(&g_stat[2], n); __sync_fetch_and_add(&g_stat[3], 1);
+		p = plan_create_ex(g->dual, 0, g->sc, n, pairs);
+		if (!p) rc = strstr(g_err, "alloc") ? KSW2AMD_E_NOMEM : strstr(g_err, "device") ? KSW2AMD_E_NODEVICE : KSW2AMD_E_PARAM;
+		else {
+			rc = ksw2amd_plan_run(p, thread_stream());
+			if (rc == KSW2AMD_OK) rc = plan_fetch_ex(p, 0, 0, ezp, kmp);
+			ksw2amd_plan_destroy(p);
+		}
+		for (i = 0; i < n; ++i) { mem[i]->rc = rc; if (rc) snprintf(mem[i]->err, sizeof(mem[i]->err), "%.190s", g_err); }
+	}
+}
+
+/* 1 = handled (result or failure delivered), 0 = coalescing is off: the caller runs the pair itself */
+static int queue_one(const char *fn, int dual, void *km, const ksw2amd_scoring_t *sc, const ksw2amd_pair_t *pr, ksw_extz_t *ez)
+{
+	static int slots = -1;
+	creq_t me;
+	if (slots < 0) { const char *e = getenv("KSW2AMD_COALESCE_SLOTS"); slots = e ? atoi(e) : 4; if (slots < 0) slots = 0; }
+	if (slots == 0 || g_is_worker) return 0;
+	memset(&me, 0, sizeof(me));
+	me.dual = dual; me.sc = sc; me.pr = pr; me.km = km; me.ez = ez;
+	pthread_mutex_lock(&g_coal.mu);
+	if (g_coal.busy < slots && g_coal.count == 0) {        /* a free slot and nobody waiting: run alone, now */
+		++g_coal.busy;
+		pthread_mutex_unlock(&g_coal.mu);
+		me.rc = run_serial(dual, 0, km, sc, 1, pr, ez, 1);
+		if (me.rc) snprintf(me.err, sizeof(me.err), "%.190s", g_err);
+		pthread_mutex_lock(&g_coal.mu);
+		--g_coal.busy;
+		pthread_cond_signal(&g_coal.arrive);                 /* a slot is free: wakes a waiting leader */
+	} else {
+		if (g_coal.tail) g_coal.tail->next = &me; else g_coal.head = &me;
+		g_coal.tail = &me; ++g_coal.count;
+		if (!g_coal.leader) {
+			creq_t *list, *r, *nx;
+			g_coal.leader = 1;
+			while (g_coal.busy >= slots) pthread_cond_wait(&g_coal.arrive, &g_coal.mu);    /* others keep joining the queue meanwhile */
+			list = g_coal.head;
+			g_coal.head = g_coal.tail = 0; g_coal.count = 0; g_coal.leader = 0;
+			++g_coal.busy;
+			pthread_mutex_unlock(&g_coal.mu);
+			coal_process(list);
+			pthread_mutex_lock(&g_coal.mu);
+			--g_coal.busy;
+			for (r = list; r; r = nx) { nx = r->next; r->done = 1; }      /* `me` included; a follower's record dies when it returns */
+			pthread_cond_broadcast(&g_coal.finished);
+			pthread_cond_signal(&g_coal.arrive);
+		} else while (!me.done) pthread_cond_wait(&g_coal.finished, &g_coal.mu);
+	}
+	pthread_mutex_unlock(&g_coal.mu);
+	if (me.rc) { snprintf(g_err, sizeof(g_err), "%s", me.err); call_failed(fn, me.rc, ez); }
+	return 1;
+}
 
 /* ---------------------------------------------------------------- splice-aware extension (ksw_exts2_sse) */
 
@@ -1107,6 +1522,7 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 	if (n < 0 || (n > 0 && !pairs) || !sc) { fail(KSW2AMD_E_PARAM, "exts: bad arguments%s", 0); return 0; }
 	if (k2a_shim_device_count() <= 0) { fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend()); return 0; }
 	p = (ksw2amd_plan_t*)calloc(1, sizeof(*p));
+	if (!p) { fail(KSW2AMD_E_NOMEM, "exts: host allocation failed%s", 0); return 0; }
 	p->splice = 1; p->n = n; p->m = m;
 	p->h_cls = (int8_t*)malloc((size_t)n + 1);
 	p->h_half = (uint8_t*)calloc((size_t)n + 1, 1);
@@ -1114,7 +1530,8 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 	p->h_pairs = (K2aPair*)calloc((size_t)n + 1, sizeof(K2aPair));
 	p->h_res = (K2aResult*)calloc((size_t)n + 1, sizeof(K2aResult));
 	p->h_order = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n + 1));
-	for (i = 0; i < n; ++i) { p->h_cls[i] = -1; p->h_flag[i] = pairs[i].flag; }
+	if (!p->h_cls || !p->h_half || !p->h_flag || !p->h_pairs || !p->h_res || !p->h_order) { fail(KSW2AMD_E_NOMEM, "exts: host allocation failed%s", 0); goto err; }
+	for (i = 0; i < n; ++i) { p->h_cls[i] = -1; p->h_flag[i] = pairs[i].flag & ~F_SCALAR_CONTRACT; }
 	/* ksw2_exts2_sse.c:74,91: unusable model or a mismatch no gap pair could undercut -> results stay reset */
 	if (m <= 1 || !sc->mat || sc->q2 <= sc->q + sc->e) p->reject_all = 1;
 	else if (m > K2A_MAXM || sc->e <= 0) { fail(KSW2AMD_E_PARAM, "exts: m > 127 or gap extension <= 0%s", 0); goto err; }
@@ -1130,12 +1547,13 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 	for (i = 0; i < n; ++i) {
 		const ksw2amd_spair_t *a = &pairs[i];
 		K2aPair *d = &p->h_pairs[i];
+		const int fl = p->h_flag[i];
 		int mode, generic;
 		if (a->qlen <= 0 || a->tlen <= 0) continue;
 		if (!a->query || !a->target) { fail(KSW2AMD_E_PARAM, "exts: NULL sequence%s", 0); goto err; }
-		mode = (a->flag & KSW_EZ_SCORE_ONLY) ? K2A_MODE_SCORE : (a->flag & KSW_EZ_RIGHT) ? K2A_MODE_RIGHT : K2A_MODE_LEFT;
-		if (is_approx(a->flag) && (a->flag & KSW_EZ_EXTZ_ONLY)) mode = K2A_MODE_SCORE;      /* no start cell in that mode: no CIGAR */
-		generic = (a->flag & KSW_EZ_GENERIC_SC) ? 1 : 0;
+		mode = (fl & KSW_EZ_SCORE_ONLY) ? K2A_MODE_SCORE : (fl & KSW_EZ_RIGHT) ? K2A_MODE_RIGHT : K2A_MODE_LEFT;
+		if (is_approx(fl) && (fl & KSW_EZ_EXTZ_ONLY)) mode = K2A_MODE_SCORE;      /* no start cell in that mode: no CIGAR */
+		generic = (fl & KSW_EZ_GENERIC_SC) ? 1 : 0;
 		/* register windows wherever the diagonal fits one: faster than the HBM-state kernel in every mode
 		 * (tools/scripts/exts_classes.py) */
 		wn = imin(a->qlen, a->tlen) <= K2A_DM_DIAG(K2A_DM_SLOTS_S) ? 0 : imin(a->qlen, a->tlen) <= K2A_DM_DIAG(K2A_DM_SLOTS) ? 1 : 2;
@@ -1151,10 +1569,10 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 		d->qlen = a->qlen; d->tlen = d->tlen_full = a->tlen;
 		d->w = imax(a->qlen, a->tlen);                 /* no band: k2a_finish must never see an unreachable corner */
 		d->zdrop = a->zdrop; d->end_bonus = K2A_NEG;   /* no end bonus in this function */
-		d->flag = a->flag & (KSW_EZ_EXTZ_ONLY | KSW_EZ_REV_CIGAR | KSW_EZ_SCORE_ONLY);
-		if (is_approx(a->flag)) {
+		d->flag = fl & (KSW_EZ_EXTZ_ONLY | KSW_EZ_REV_CIGAR | KSW_EZ_SCORE_ONLY);
+		if (is_approx(fl)) {
 			d->zdrop = -1;
-			if (a->flag & KSW_EZ_EXTZ_ONLY) d->flag |= KSW_EZ_SCORE_ONLY;
+			if (fl & KSW_EZ_EXTZ_ONLY) d->flag |= KSW_EZ_SCORE_ONLY;
 		}
 		off = align_up(off, 4); d->qoff = (uint32_t)off; off += (size_t)a->qlen;
 		off = align_up(off, 4); d->bnd_off = (uint32_t)(off / 4); off += 4 * (size_t)a->tlen;
@@ -1213,6 +1631,7 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 		p->s_par[g].mat = (const int8_t*)p->d_seq + mat_off + (g ? (size_t)m * m : 0);
 	}
 	for (i = 0; i < 3; ++i) { p->ev[i] = g_ev_cache[i] ? g_ev_cache[i] : k2a_shim_event_create(); g_ev_cache[i] = 0; }
+	p->stream = 0; p->stream_used = 0;             /* uploads complete, see plan_create_ex */
 	return p;
 err:
 	ksw2amd_plan_destroy(p);
@@ -1285,7 +1704,10 @@ void ksw_exts2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uin
 	ksw2amd_spair_t pr;
 	sc.m = m; sc.mat = mat; sc.q = q; sc.e = e; sc.q2 = q2; sc.noncan = noncan; sc.junc_bonus = junc_bonus;
 	pr.query = query; pr.target = target; pr.junc = junc; pr.qlen = qlen; pr.tlen = tlen; pr.zdrop = zdrop; pr.flag = flag;
-	if (ksw2amd_exts_batch(km, &sc, 1, &pr, ez) != KSW2AMD_OK) die_loudly("ksw_exts2_sse");
+	{
+		const int rc = ksw2amd_exts_batch(km, &sc, 1, &pr, ez);
+		if (rc != KSW2AMD_OK) call_failed("ksw_exts2_sse", rc, ez);
+	}
 }
 void ksw_exts2_sse41(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
                      int8_t q, int8_t e, int8_t q2, int8_t noncan, int zdrop, int8_t junc_bonus, int flag, const uint8_t *junc, ksw_extz_t *ez)
@@ -1312,6 +1734,7 @@ ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n
 	if (n < 0 || (n > 0 && !pairs)) { fail(KSW2AMD_E_PARAM, "extf: bad arguments%s", 0); return 0; }
 	if (k2a_shim_device_count() <= 0) { fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend()); return 0; }
 	p = (ksw2amd_plan_t*)calloc(1, sizeof(*p));
+	if (!p) { fail(KSW2AMD_E_NOMEM, "extf: host allocation failed%s", 0); return 0; }
 	p->splice = 2; p->n = n;
 	p->h_cls = (int8_t*)malloc((size_t)n + 1);
 	p->h_half = (uint8_t*)calloc((size_t)n + 1, 1);
@@ -1319,6 +1742,7 @@ ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n
 	p->h_pairs = (K2aPair*)calloc((size_t)n + 1, sizeof(K2aPair));
 	p->h_res = (K2aResult*)calloc((size_t)n + 1, sizeof(K2aResult));
 	p->h_order = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n + 1));
+	if (!p->h_cls || !p->h_half || !p->h_flag || !p->h_pairs || !p->h_res || !p->h_order) { fail(KSW2AMD_E_NOMEM, "extf: host allocation failed%s", 0); goto err; }
 	p->f_par.mch = mch; p->f_par.mis = mis < 0 ? mis : -mis; p->f_par.e = e;      /* ksw2_extf2_sse.c:18-20 */
 	for (i = 0; i < n; ++i) {
 		const ksw2amd_fpair_t *a = &pairs[i];
@@ -1374,6 +1798,7 @@ ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n
 		goto err;
 	}
 	for (i = 0; i < 3; ++i) { p->ev[i] = g_ev_cache[i] ? g_ev_cache[i] : k2a_shim_event_create(); g_ev_cache[i] = 0; }
+	p->stream = 0; p->stream_used = 0;             /* uploads complete, see plan_create_ex */
 	return p;
 err:
 	ksw2amd_plan_destroy(p);
@@ -1425,5 +1850,8 @@ void ksw_extf2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uin
 {
 	ksw2amd_fpair_t pr;
 	pr.query = query; pr.target = target; pr.qlen = qlen; pr.tlen = tlen; pr.w = w; pr.xdrop = xdrop;
-	if (ksw2amd_extf_batch(km, mch, mis, e, 1, &pr, ez) != KSW2AMD_OK) die_loudly("ksw_extf2_sse");
+	{
+		const int rc = ksw2amd_extf_batch(km, mch, mis, e, 1, &pr, ez);
+		if (rc != KSW2AMD_OK) call_failed("ksw_extf2_sse", rc, ez);
+	}
 }

@@ -31,6 +31,7 @@ const char *k2a_shim_last_error(void);
 int   k2a_shim_device_count(void);
 int   k2a_shim_simd_count(void);               /* SIMDs (wavefront slots side by side) of the current device; 0 = unknown */
 int   k2a_shim_set_device(int dev);
+int   k2a_shim_get_device(void);             /* device of the calling thread; -1 = none */
 int   k2a_shim_mem_info(size_t *free_b, size_t *total_b);
 
 void *k2a_shim_malloc(size_t bytes);               /* device memory */

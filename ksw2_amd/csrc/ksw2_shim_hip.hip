@@ -962,6 +962,7 @@ int k2a_shim_simd_count(void)
 }
 
 int k2a_shim_set_device(int dev) { CHECK(hipSetDevice(dev)); return 0; }
+int k2a_shim_get_device(void) { int dev = -1; return hipGetDevice(&dev) == hipSuccess ? dev : -1; }
 
 int k2a_shim_mem_info(size_t *free_b, size_t *total_b) { CHECK(hipMemGetInfo(free_b, total_b)); return 0; }
 

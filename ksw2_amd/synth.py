@@ -133,3 +133,68 @@ def band_cells(qlen, tlen, w):
     st = np.maximum(0, i - w)
     en = np.minimum(qlen - 1, i + w)
     return int(np.maximum(en - st + 1, 0).sum())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Fast generator (tools/synth/ksw2_synth.c -> tools/libksw2_synth.so): the same channel with one xorshift64* stream per
+# pair, multi-threaded.  bench.py's batches (up to a GB of sequence) come from here; the numpy functions above stay for the
+# tests whose inputs they have always produced.
+
+_fast = None
+
+
+def _fast_lib():
+    global _fast
+    if _fast is None:
+        import ctypes
+        import os
+        import subprocess
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        so = os.path.join(root, "tools", "libksw2_synth.so")
+        if not os.path.exists(so):
+            subprocess.run(["make", "-C", os.path.join(root, "tools"), "libksw2_synth.so"], check=True, capture_output=True)
+        L = ctypes.CDLL(so)
+        vp, i64, dbl, c_int = ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_int
+        L.k2s_fixed.argtypes = [ctypes.c_uint64, i64, c_int, c_int, c_int, dbl, dbl, dbl, dbl, vp, vp, c_int]
+        L.k2s_fixed.restype = None
+        L.k2s_ragged_lengths.argtypes = [ctypes.c_uint64, i64, c_int, c_int, c_int, dbl, dbl, c_int, vp, vp, c_int]
+        L.k2s_ragged_lengths.restype = None
+        L.k2s_ragged_fill.argtypes = [ctypes.c_uint64, i64, c_int, c_int, c_int, dbl, dbl, c_int, vp, vp, vp, vp, c_int]
+        L.k2s_ragged_fill.restype = None
+        _fast = L
+    return _fast
+
+
+def _threads():
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(32, n))
+
+
+def fast_fixed(config_index, n, qlen, tlen, sub=0.05, ind=0.06, tail_random_frac=0.0, tail_pairs=0.0, first=0):
+    """[n, qlen] queries and [n, tlen] targets; pair i is a function of (config_index, first + i) only."""
+    q = np.empty((n, qlen), dtype=np.uint8)
+    t = np.empty((n, tlen), dtype=np.uint8)
+    _fast_lib().k2s_fixed(BASE_SEED + int(config_index), int(first), n, qlen, tlen, sub, ind, tail_pairs, tail_random_frac,
+                          q.ctypes.data, t.ctypes.data, _threads())
+    return q, t
+
+
+def fast_ragged(config_index, n, lo, hi, sub=0.03, ind=0.15, maxdiff=450, first=0):
+    """Config 5's mix: query length uniform in [lo, hi], target = the query through the channel (its natural length; redrawn
+    while |tlen - qlen| > maxdiff).  Returns two lists of uint8 views into two flat arrays (kept alive by the views)."""
+    L = _fast_lib()
+    ql = np.empty(n, dtype=np.int32)
+    tl = np.empty(n, dtype=np.int32)
+    seed = BASE_SEED + int(config_index)
+    L.k2s_ragged_lengths(seed, int(first), n, lo, hi, sub, ind, maxdiff, ql.ctypes.data, tl.ctypes.data, _threads())
+    qoff = np.zeros(n + 1, dtype=np.int64)
+    toff = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(ql, out=qoff[1:])
+    np.cumsum(tl, out=toff[1:])
+    qbuf = np.empty(int(qoff[-1]), dtype=np.uint8)
+    tbuf = np.empty(int(toff[-1]), dtype=np.uint8)
+    L.k2s_ragged_fill(seed, int(first), n, lo, hi, sub, ind, maxdiff, qoff.ctypes.data, toff.ctypes.data, qbuf.ctypes.data, tbuf.ctypes.data, _threads())
+    qs = [qbuf[qoff[i]:qoff[i + 1]] for i in range(n)]
+    ts = [tbuf[toff[i]:toff[i + 1]] for i in range(n)]
+    return qs, ts

@@ -23,7 +23,7 @@ typedef void (*exts2_fn)(void *km, int qlen, const uint8_t *query, int tlen, con
 
 typedef struct {
 	void *fn; int dual, with_km;                   /* dual: 0 extz2, 1 extd2, 2 exts2 (gq2 = long-gap open, ge2 = noncan) */
-	const uint8_t *q, *t; int n, qlen, tlen;       /* n fixed-shape pairs, row-major */
+	const uint8_t *const *q, *const *t; const int32_t *qlen, *tlen; int n;       /* n pairs of any shapes; index i mod n is aligned next */
 	int8_t m; const int8_t *mat; int8_t gq, ge, gq2, ge2; int w, zdrop, flag;
 	double seconds;
 	volatile long next;
@@ -45,11 +45,12 @@ static void *worker(void *arg)
 	memset(&ez, 0, sizeof(ez));
 	while (now() - t0 < J->seconds) {
 		long i = __sync_fetch_and_add(&J->next, 1) % J->n;
-		const uint8_t *q = J->q + (size_t)i * J->qlen, *t = J->t + (size_t)i * J->tlen;
-		if (J->dual == 3) ((extf2_fn)J->fn)(0, J->qlen, q, J->tlen, t, J->gq, J->ge, J->gq2, J->w, J->zdrop, &ez);      /* mch, mis, e */
-		else if (J->dual == 2) ((exts2_fn)J->fn)(0, J->qlen, q, J->tlen, t, J->m, J->mat, J->gq, J->ge, J->gq2, J->ge2, J->zdrop, 0, J->flag, 0, &ez);
-		else if (J->dual) ((extd2_fn)J->fn)(0, J->qlen, q, J->tlen, t, J->m, J->mat, J->gq, J->ge, J->gq2, J->ge2, J->w, J->zdrop, 0, J->flag, &ez);
-		else ((extz2_fn)J->fn)(0, J->qlen, q, J->tlen, t, J->m, J->mat, J->gq, J->ge, J->w, J->zdrop, 0, J->flag, &ez);
+		const uint8_t *q = J->q[i], *t = J->t[i];
+		const int ql = J->qlen[i], tl = J->tlen[i];
+		if (J->dual == 3) ((extf2_fn)J->fn)(0, ql, q, tl, t, J->gq, J->ge, J->gq2, J->w, J->zdrop, &ez);      /* mch, mis, e */
+		else if (J->dual == 2) ((exts2_fn)J->fn)(0, ql, q, tl, t, J->m, J->mat, J->gq, J->ge, J->gq2, J->ge2, J->zdrop, 0, J->flag, 0, &ez);
+		else if (J->dual) ((extd2_fn)J->fn)(0, ql, q, tl, t, J->m, J->mat, J->gq, J->ge, J->gq2, J->ge2, J->w, J->zdrop, 0, J->flag, &ez);
+		else ((extz2_fn)J->fn)(0, ql, q, tl, t, J->m, J->mat, J->gq, J->ge, J->w, J->zdrop, 0, J->flag, &ez);
 		++mine;
 	}
 	free(ez.cigar);
@@ -57,14 +58,15 @@ static void *worker(void *arg)
 	return 0;
 }
 
-/* returns pairs completed; *elapsed = wall seconds */
-long kso_cpu_bench(void *fn, int dual, int threads, double seconds, int n, int qlen, int tlen, const uint8_t *q, const uint8_t *t,
-                   int8_t m, const int8_t *mat, int8_t gq, int8_t ge, int8_t gq2, int8_t ge2, int w, int zdrop, int flag, double *elapsed)
+/* returns pairs completed (indices 0, 1, ... mod n, each one finished); *elapsed = wall seconds.  `reserved` must be NULL. */
+long kso_cpu_bench(void *fn, int dual, int threads, double seconds, int n, const uint8_t *const *q, const uint8_t *const *t,
+                   const int32_t *qlen, const int32_t *tlen, const void *reserved, int8_t m, const int8_t *mat, int8_t gq, int8_t ge, int8_t gq2, int8_t ge2, int w, int zdrop, int flag, double *elapsed)
 {
 	job_t J;
 	pthread_t *th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
 	int i;
 	double t0;
+	(void)reserved;
 	memset(&J, 0, sizeof(J));
 	J.fn = fn; J.dual = dual; J.q = q; J.t = t; J.n = n; J.qlen = qlen; J.tlen = tlen; J.m = m; J.mat = mat;
 	J.gq = gq; J.ge = ge; J.gq2 = gq2; J.ge2 = ge2; J.w = w; J.zdrop = zdrop; J.flag = flag; J.seconds = seconds;

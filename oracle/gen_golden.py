@@ -61,7 +61,7 @@ def known_answers():
     for f in ("t1.fa", "q1.fa", "MT-human.fa", "MT-orang.fa"):
         shutil.copy(os.path.join(REF, "test", f), os.path.join(GOLD, "data", f))
     with open(os.path.join(GOLD, "data", "NOTICE"), "w") as fh:
-        fh.write("t1.fa q1.fa MT-human.fa MT-orang.fa: test inputs distributed with lh3/ksw2 (test/), MIT licence,\n"
+        fh.write("t1.fa q1.fa MT-human.fa MT-orang.fa t2.fa.gz q2.fa.gz: test inputs distributed with lh3/ksw2 (test/), MIT licence,\n"
                  "Copyright (c) 2018- Dana-Farber Cancer Institute, 2017-2018 Broad Institute, Inc.  Data only.\n")
     out = {"scoring": {"a": 2, "b": 4, "q": 4, "e": 2, "q2": 13, "e2": 1, "sc_n": 0},
            "note": "ksw2-test defaults (cli.c:162): mat = 5x5 a=2 b=-4 N=0; -O4,13 -E2,1; w=-1 zdrop=-1",
@@ -99,6 +99,45 @@ def known_answers():
     out["mt"].append({"func": "ksw_gg", "w": -1, "score": sc, "cigar": po.cigar_string(cg),
                       "cigar_md5_12": hashlib.md5((po.cigar_string(cg) + "\n").encode()).hexdigest()[:12]})
     json.dump(out, open(os.path.join(GOLD, "known_answers.json"), "w"), indent=1)
+
+
+def read_fasta_gz(path):
+    import gzip
+    seqs, cur = [], []
+    for line in gzip.open(path, "rt"):
+        line = line.strip()
+        if line.startswith(">"):
+            if cur:
+                seqs.append("".join(cur))
+                cur = []
+        elif line:
+            cur.append(line)
+    seqs.append("".join(cur))
+    return seqs
+
+
+def t2q2_anchor():
+    """The README's 50 000 x 50 000 data set (test/t2.fa.gz x test/q2.fa.gz, README.md:96-107; SURVEY 4.2: 69932 / 70010 / 49962 /
+    49999): the two gzip files are copied as data, the reference's answers go into known_answers.json["t2q2_50k"]."""
+    for f in ("t2.fa.gz", "q2.fa.gz"):
+        shutil.copy(os.path.join(REF, "test", f), os.path.join(GOLD, "data", f))
+        os.chmod(os.path.join(GOLD, "data", f), 0o644)
+    t = encode(read_fasta_gz(os.path.join(REF, "test", "t2.fa.gz"))[0])
+    q = encode(read_fasta_gz(os.path.join(REF, "test", "q2.fa.gz"))[0])
+    mat = po.simple_mat(5, 2, 4, 0)
+    out = []
+    for func, flag, w, zd in [("extz", po.SCORE_ONLY, -1, -1), ("extz2", po.SCORE_ONLY, -1, -1), ("extz2", 0, -1, -1), ("extd2", po.SCORE_ONLY, -1, -1),
+                              ("extz2", po.SCORE_ONLY, 500, 400)]:
+        r = pack(po.align("ref", func, q, t, mat, 4, 2, 13, 1, w=w, zdrop=zd, flag=flag))
+        if len(r["cigar"]) > 2000:
+            r["cigar_len"] = len(r["cigar"])
+            r["cigar"] = None                       # the md5 pins it
+        r.update({"func": {"extz": "ksw_extz", "extz2": "ksw_extz2_sse", "extd2": "ksw_extd2_sse"}[func], "flag": flag, "w": w, "zdrop": zd})
+        out.append(r)
+        print("50k", func, flag, w, zd, r["score"], r["max"], r["max_t"], r["max_q"], r["n_cigar"], r["cigar_md5_12"])
+    ka = json.load(open(os.path.join(GOLD, "known_answers.json")))
+    ka["t2q2_50k"] = out
+    json.dump(ka, open(os.path.join(GOLD, "known_answers.json"), "w"), indent=1)
 
 
 MATS = [  # (a, b, sc_n, q, e, q2, e2)
@@ -163,4 +202,5 @@ if __name__ == "__main__":
     if po.ref_lib() is None and not po.build_ref(REF):
         sys.exit("reference sources not available: golden vectors can only be regenerated in the build container")
     known_answers()
+    t2q2_anchor()
     random_cases()

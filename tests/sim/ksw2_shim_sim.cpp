@@ -18,7 +18,7 @@
 #include "../../ksw2_amd/csrc/ksw2_lane_extf.h"
 #include "../../ksw2_amd/csrc/ksw2_lane_pk.h"
 
-static char g_err[256] = "";
+static thread_local char g_err[256] = "";
 
 static void make_tabs(const K2aScoring &sc, uint32_t *tabs)
 {
@@ -35,7 +35,7 @@ static void sim_fill(const K2aScoring sc, const K2aPair *pairs, const uint32_t *
 	uint32_t tabs[16] = {0};
 	make_tabs(sc, tabs);
 	for (int wv = 0; wv < nwaves; ++wv) {
-		static Lane L[64];
+		static thread_local Lane L[64];
 		K2aBook book[NG];
 		int rowbuf[NG][3 * C];
 		K2aPair pr[64];
@@ -111,8 +111,8 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 	typedef K2aLanePk<G, C, DUAL, MODE, RB, NOMAX, LDSROW> Lane;
 	const int nwaves = (ntasks + NG - 1) / NG;
 	for (int wv = 0; wv < nwaves; ++wv) {
-		static Lane L[64];
-		static uint32_t lrows[K2A_PK_LDSROW_WORDS(C)];
+		static thread_local Lane L[64];
+		static thread_local uint32_t lrows[K2A_PK_LDSROW_WORDS(C)];
 		K2aBook book[NG][2];
 		K2aPair prA[64];
 		uint32_t piA[64], piB[64], stage[(NG * K2A_PK_STAGE(C) > 64 * 5) ? NG * K2A_PK_STAGE(C) : 64 * 5];
@@ -236,8 +236,8 @@ static void sim_fill_mp(const K2aScoring sc, const K2aPair *pairs, const uint32_
 {
 	typedef K2aLane<G, C, DUAL, MODE, LROW> Lane;
 	for (int task = 0; task < ntasks; ++task) {
-		static Lane L[64];
-		static int lrows[K2A_LROW_WORDS(C)];
+		static thread_local Lane L[64];
+		static thread_local int lrows[K2A_LROW_WORDS(C)];
 		K2aBook book;
 		int rowbuf[3 * C];
 		const uint32_t pi = order[task];
@@ -369,8 +369,8 @@ static void sim_exts(const K2aSplice sp, const K2aPair *pairs, const uint32_t *o
 		const uint32_t *cst = (const uint32_t*)seq + pr.bnd_off;
 		uint8_t *tbp = tb + pr.tb_off;
 		const int ncol = k2a_min(qlen, tlen);
-		static int H1[K][64], H2[K][64], En[K][64], E2n[K][64], Fn[K][64];
-		static uint32_t Q[K][64], Cst[K][64];
+		static thread_local int H1[K][64], H2[K][64], En[K][64], E2n[K][64], Fn[K][64];
+		static thread_local uint32_t Q[K][64], Cst[K][64];
 		int base = 0;
 		K2aBook book;
 		k2a_book_reset(&book);
@@ -515,7 +515,7 @@ static void sim_fill_solo(const K2aScoring sc, const K2aPair *pairs, const uint3
 	for (int task = 0; task < ntasks; ++task) {
 		const uint32_t pi = order[task];
 		const K2aPair pr = pairs[pi];
-		static Lane L[64];
+		static thread_local Lane L[64];
 		K2aBook book;
 		uint32_t rowbuf[K2A_SOLO_STAGE(C)];
 		k2a_book_reset(&book);
@@ -628,7 +628,7 @@ static void sim_extf_win(const K2aExtf par, const K2aPair *pairs, const uint32_t
 		const int qlen = pr.qlen, tlen = pr.tlen, w = pr.w, xdrop = pr.zdrop, tpad = (tlen + 15) & ~15;
 		const uint8_t *qa = seq + pr.qoff, *ta = seq + pr.toff;
 		const uint32_t two_e = (uint32_t)(par.e * 2) & 0xffu;
-		static uint32_t U[K][64], V[K][64], S[K][64], T[K][64];
+		static thread_local uint32_t U[K][64], V[K][64], S[K][64], T[K][64];
 		int blk[K];
 		for (int s = 0; s < K; ++s) {
 			blk[s] = s;
@@ -680,9 +680,13 @@ extern "C" {
 
 const char *k2a_shim_backend(void) { return "sim"; }
 const char *k2a_shim_last_error(void) { return g_err; }
-int k2a_shim_device_count(void) { return 1; }
+/* KSW2AMD_SIM_DEVICES=N pretends to have N devices (all the same host memory) so that the host's multi-device worker
+ * pool can be exercised without hardware */
+static thread_local int g_sim_dev = 0;
+int k2a_shim_device_count(void) { const char *e = getenv("KSW2AMD_SIM_DEVICES"); const int n = e ? atoi(e) : 1; return n > 0 ? n : 1; }
 int k2a_shim_simd_count(void) { return 0; }
-int k2a_shim_set_device(int dev) { return dev == 0 ? 0 : -1; }
+int k2a_shim_set_device(int dev) { if (dev < 0 || dev >= k2a_shim_device_count()) return -1; g_sim_dev = dev; return 0; }
+int k2a_shim_get_device(void) { return g_sim_dev; }
 int k2a_shim_mem_info(size_t *free_b, size_t *total_b) { *free_b = (size_t)8 << 30; *total_b = (size_t)8 << 30; return 0; }
 void *k2a_shim_malloc(size_t bytes) { return calloc(bytes ? bytes : 16, 1); }
 void k2a_shim_free(void *p) { free(p); }

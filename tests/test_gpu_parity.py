@@ -1,4 +1,5 @@
 """GPU: the HIP path through the C-ABI (libksw2_amd.so) against the oracle and the golden vectors. Bit-exact."""
+import ctypes
 import hashlib
 
 import numpy as np
@@ -698,3 +699,87 @@ def test_pairs_share_the_true_target_length(lib):
     for dual in (False, True):
         for flag in (po.SCORE_ONLY, 0):
             check_batch(lib, dual, qs, ts, mat, 4, 2, 13, 1, w=5, zdrop=-1, end_bonus=10, flag=flag)
+
+
+def test_eqx_golden(lib):
+    """KSW_EZ_EQX (ksw2_extd2_sse.c:399-406): all committed runs of the reference, batched per scoring; plus single calls that
+    reuse one ksw_extz_t (the =/X list is longer than the M list it replaces: the buffer must grow by the reference's rule)."""
+    ec = gu.EqxCases()
+    groups = {}
+    for k in range(ec.n):
+        c = ec.case(k)
+        groups.setdefault((c["mat"].tobytes(), c["gq"], c["ge"], c["gq2"], c["ge2"]), []).append(c)
+    n = 0
+    for (_, gq, ge, gq2, ge2), cs in groups.items():
+        res = lib.extd_batch([c["q"] for c in cs], [c["t"] for c in cs], cs[0]["mat"], gq, ge, gq2, ge2, w=np.array([c["w"] for c in cs]), zdrop=-1,
+                             end_bonus=np.array([c["end_bonus"] for c in cs]), flag=np.array([c["flag"] for c in cs]))
+        for c, r in zip(cs, res):
+            bad, same = gu.EqxCases.check(c, r)
+            assert not bad and same, (bad, c["flag"])
+            n += 1
+    assert n == ec.n >= 300
+    ez = ka.KswExtz()
+    for k in range(0, ec.n, 9):
+        c = ec.case(k)
+        r = lib.extd2(c["q"], c["t"], c["mat"], c["gq"], c["ge"], c["gq2"], c["ge2"], w=c["w"], zdrop=-1, end_bonus=c["end_bonus"], flag=c["flag"], ez=ez)
+        bad, _ = gu.EqxCases.check(c, r)
+        assert not bad, (k, bad)
+        assert r["m_cigar"] >= r["n_cigar"] and (r["m_cigar"] & (r["m_cigar"] - 1)) == 0
+    ka._libc.free(ctypes.cast(ez.cigar, ctypes.c_void_p))
+
+
+def test_50k_anchor(lib):
+    """The README's 50 000 x 50 000 pair through the generation-serial kernels (unbanded: 49 generations of 1 024 rows) and the
+    re-based packed kernels (band 500): the reference's answers, CIGAR by md5 (3 995 operations)."""
+    ka_ = gu.known_answers()["t2q2_50k"]
+    _, ts = gu.read_fasta("t2.fa.gz")
+    _, qs = gu.read_fasta("q2.fa.gz")
+    q, t = qs[0], ts[0]
+    mat = gu.simple_mat(5, 2, 4, 0)
+    for exp in ka_:
+        if exp["func"] == "ksw_extz":
+            res = lib.extz(q, t, mat, 4, 2, w=exp["w"], zdrop=exp["zdrop"], flag=exp["flag"])
+            assert not diff(exp, res, gu.FIELDS), exp["func"]
+            assert (res["score"], res["max"], res["max_t"], res["max_q"]) == (69932, 70010, 49962, 49999)
+        elif exp["func"] == "ksw_extz2_sse":
+            res = lib.extz2(q, t, mat, 4, 2, w=exp["w"], zdrop=exp["zdrop"], flag=exp["flag"])
+            assert not diff(exp, res, gu.SSE_LOOSE_FIELDS), (exp["w"], exp["flag"])
+            if not (exp["flag"] & po.SCORE_ONLY):
+                assert hashlib.md5((gu.cigar_string(res["cigar"]) + "\n").encode()).hexdigest()[:12] == exp["cigar_md5_12"]
+        else:
+            res = lib.extd2(q, t, mat, 4, 2, 13, 1, w=exp["w"], zdrop=exp["zdrop"], flag=exp["flag"])
+            assert not diff(exp, res, gu.SSE_LOOSE_FIELDS)
+
+
+@pytest.mark.parametrize("mode", ["short", "long"])
+def test_fuzz_slice(mode):
+    """A time-boxed slice of tools/scripts/fuzz_gpu.py (the soak that found round 1's pairing bug): ragged and same-shape batches of
+    all four functions against the oracle under every kernel-selection switch -- including none at all, i.e. the production
+    occupancy rules (the script's environment does not carry this module's KSW2AMD_SIMDS=0) -- and through the worker pool."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("KSW2AMD_")}
+    args = ["40", "20260002"] if mode == "short" else ["25", "20260003", "long"]
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "scripts", "fuzz_gpu.py")] + args, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "fuzz ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("cigar", [0, 1])
+def test_unchanged_threaded_caller_is_coalesced(cigar):
+    """tools/coalesce-bench: 64 host threads calling ksw_extz2_sse / ksw_extd2_sse one pair at a time (the minimap2 pattern).  The
+    library batches concurrent calls behind the unchanged symbols; every call returns exactly what the batch entry point returns."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "coalesce-bench")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(root, "tools"), "coalesce-bench"], check=True, capture_output=True)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("KSW2AMD_")}
+    r = subprocess.run([exe, "64", "300", "512", "64", str(cigar)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-1000:])
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["mismatches"] == 0 and d["calls"] == 64 * 300
+    assert d["coalesced_calls"] > d["coalesced_batches"] > 0

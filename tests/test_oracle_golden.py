@@ -134,3 +134,38 @@ def test_approx_max_mode_matches_reference_golden():
         r = gu.ApproxCases.run("oracle", c)
         for f in gu.FIELDS + ["cigar"]:
             assert r[f] == c["expect"][f], (k, c["func"], hex(c["flag"]), f, r[f], c["expect"][f])
+
+
+def test_eqx_cases_pin_the_oracle():
+    """KSW_EZ_EQX: all 400 committed runs of the reference's ksw_extd2_sse (buffers pre-sized so that its ksw_cigar2eqx never
+    reallocates; oracle/gen_golden_eqx.py), =/X CIGARs word for word."""
+    ec = gu.EqxCases()
+    assert ec.n >= 300
+    nx = 0
+    for k in range(ec.n):
+        c = ec.case(k)
+        r = po.align("oracle", "extd2", c["q"], c["t"], c["mat"], c["gq"], c["ge"], c["gq2"], c["ge2"], w=c["w"], zdrop=-1, end_bonus=c["end_bonus"],
+                     flag=c["flag"])
+        bad, same = gu.EqxCases.check(c, r)
+        assert not bad, (k, bad, c["flag"])
+        assert same
+        nx += sum(1 for x in r["cigar"] if (x & 0xf) == 8)
+        assert all((x & 0xf) != 0 for x in r["cigar"])           # no M left
+    assert nx > 1000
+
+
+def test_50k_anchor():
+    """The README's 50 000 x 50 000 pair (test/t2.fa.gz x test/q2.fa.gz; SURVEY 4.2: 69932 / 70010 / 49962 / 49999), unbanded score-only
+    through the scalar contract and banded through the SSE signature."""
+    ka = gu.known_answers()["t2q2_50k"]
+    _, ts = gu.read_fasta("t2.fa.gz")
+    _, qs = gu.read_fasta("q2.fa.gz")
+    assert len(ts[0]) == len(qs[0]) == 50000
+    mat = gu.simple_mat(5, 2, 4, 0)
+    exp = [r for r in ka if r["func"] == "ksw_extz"][0]
+    assert (exp["score"], exp["max"], exp["max_t"], exp["max_q"]) == (69932, 70010, 49962, 49999)
+    res = po.align("oracle", "extz", qs[0], ts[0], mat, 4, 2, w=-1, flag=po.SCORE_ONLY)
+    _check(res, exp, gu.FIELDS)
+    exp = [r for r in ka if r["func"] == "ksw_extz2_sse" and r["w"] == 500][0]
+    res = po.align("oracle", "extz2", qs[0], ts[0], mat, 4, 2, w=500, zdrop=400, flag=po.SCORE_ONLY)
+    _check(res, exp, gu.SSE_LOOSE_FIELDS)

@@ -495,3 +495,30 @@ def test_sim_pairs_share_the_true_target_length(sim):
     for dual in (False, True):
         for flag in (po.SCORE_ONLY, 0):
             check_batch(sim, dual, qs, ts, mat, 4, 2, 13, 1, w=5, zdrop=-1, end_bonus=10, flag=flag)
+
+
+def test_sim_eqx_golden_subset(sim):
+    """Every 4th committed KSW_EZ_EQX case of the reference through the simulator build: single calls and one batch."""
+    ec = gu.EqxCases()
+    cs = [ec.case(k) for k in range(0, ec.n, 4)]
+    for c in cs:
+        r = sim.extd2(c["q"], c["t"], c["mat"], c["gq"], c["ge"], c["gq2"], c["ge2"], w=c["w"], zdrop=-1, end_bonus=c["end_bonus"], flag=c["flag"])
+        bad, _ = gu.EqxCases.check(c, r)
+        assert not bad, (bad, c["flag"])
+    g = [c for c in cs if (c["gq"], c["ge2"]) == (4, 1) and c["mat"][0] == 2 and c["mat"][24] == -1]
+    assert len(g) >= 20
+    res = sim.extd_batch([c["q"] for c in g], [c["t"] for c in g], g[0]["mat"], 4, 2, 24, 1, w=np.array([c["w"] for c in g]), zdrop=-1,
+                         end_bonus=np.array([c["end_bonus"] for c in g]), flag=np.array([c["flag"] for c in g]))
+    for c, r in zip(g, res):
+        bad, _ = gu.EqxCases.check(c, r)
+        assert not bad, (bad, c["flag"])
+
+
+def test_sim_fuzz_script_runs(sim):
+    """The soak script itself (tools/scripts/fuzz_gpu.py, a -m gpu test on the box) for a few seconds against the simulator build."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("KSW2AMD_")}
+    env["KSW2AMD_FUZZ_LIB"] = os.path.join(SIM_DIR, "libksw2_amd_sim.so")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "scripts", "fuzz_gpu.py"), "8", "7"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fuzz ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

@@ -22,7 +22,8 @@ LONG = len(sys.argv) > 3
 rng = np.random.Generator(np.random.PCG64(seed))
 lib = ka.Library(os.environ["KSW2AMD_FUZZ_LIB"]) if os.environ.get("KSW2AMD_FUZZ_LIB") else ka.library()      # the simulator build, for reproducing on the CPU
 ENVS = [{}, {"KSW2AMD_SOLO": "1"}, {"KSW2AMD_SOLO": "all"}, {"KSW2AMD_LDSROWS": "0"}, {"KSW2AMD_LDSROWS": "1"}, {"KSW2AMD_NO_PK": "1"},
-        {"KSW2AMD_SIMDS": "0"}, {"KSW2AMD_EXTF_WIN": "1"}, {"KSW2AMD_EXTF_LDS": "1"}, {"KSW2AMD_EXTS_REG": "1"}]
+        {"KSW2AMD_SIMDS": "0"}, {"KSW2AMD_EXTF_WIN": "1"}, {"KSW2AMD_EXTF_LDS": "1"}, {"KSW2AMD_EXTS_REG": "1"},
+        {"KSW2AMD_POOL_MIN": "8", "KSW2AMD_THREADS": "3"}, {"KSW2AMD_POOL_MIN": "4", "KSW2AMD_SIMDS": "0"}]
 KEYS = sorted({k for e in ENVS for k in e})
 t0 = time.time()
 rounds = pairs = 0
@@ -51,7 +52,7 @@ while time.time() - t0 < budget:
         eb = rng.choice([0, 10, 50], size=n)
         mode = int(rng.choice([po.SCORE_ONLY, 0, po.RIGHT]))
         fl = np.array([mode | (po.EXTZ_ONLY if rng.random() < 0.3 else 0) | (po.REV_CIGAR if rng.random() < 0.3 else 0) |
-                       (po.GENERIC_SC if rng.random() < 0.2 else 0) for _ in range(n)])
+                       (po.GENERIC_SC if rng.random() < 0.2 else 0) | (po.EQX if dual and rng.random() < 0.2 else 0) for _ in range(n)])
         try:
             check_batch(lib, dual, qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl)
         except AssertionError:
