@@ -246,7 +246,8 @@ class Job:
         cells = plan.cells()
         for _ in range(warmup):
             plan.run(stream)
-        plan.timing()
+        if warmup:
+            plan.timing()
         fill_ms, total_ms = [], []
         t0 = time.perf_counter()
         k = 0

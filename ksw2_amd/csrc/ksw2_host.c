@@ -56,6 +56,8 @@ static __thread void *g_ev_cache[3];
 /* Every host thread uploads and (in the one-shot entry points) computes on a stream of its own, so concurrent callers --
  * a minimap2-style thread pool -- overlap their copies and kernels instead of queueing on the device's default stream. */
 static __thread void *g_stream;
+/* ... and uploads on a second one: a plan is packed and uploaded while the thread's previous plan still computes */
+static __thread void *g_up_stream;
 /* a worker thread that exits gives its cached buffers and stream back (pthread key destructor) */
 static pthread_key_t g_exit_key;
 static pthread_once_t g_exit_once = PTHREAD_ONCE_INIT;
@@ -78,6 +80,7 @@ static void thread_owns_cache(void)
 	if (!pthread_getspecific(g_exit_key)) pthread_setspecific(g_exit_key, (void*)1);
 }
 static void *thread_stream(void) { if (!g_stream) { thread_owns_cache(); g_stream = k2a_shim_stream_create(); } return g_stream; }
+static void *thread_upload_stream(void) { if (!g_up_stream) { thread_owns_cache(); g_up_stream = k2a_shim_stream_create(); } return g_up_stream; }
 /* side streams + events for plans with several kernel classes: the classes are independent, and a class of a few long
  * alignments would otherwise hold the whole device for the duration of one alignment while the next class waits */
 #define NSIDE 3
@@ -122,6 +125,7 @@ static void release_thread_cache(void)
 	for (k = 0; k < BUF_KINDS; ++k) { if (g_cache[k].p) cache_free_raw(k, g_cache[k].p); g_cache[k].p = 0; g_cache[k].cap = 0; }
 	for (k = 0; k < 3; ++k) { if (g_ev_cache[k]) k2a_shim_event_destroy(g_ev_cache[k]); g_ev_cache[k] = 0; }
 	if (g_stream) { k2a_shim_stream_sync(g_stream); k2a_shim_stream_destroy(g_stream); g_stream = 0; }
+	if (g_up_stream) { k2a_shim_stream_sync(g_up_stream); k2a_shim_stream_destroy(g_up_stream); g_up_stream = 0; }
 	for (k = 0; k < NSIDE; ++k) if (g_side[k]) { k2a_shim_stream_sync(g_side[k]); k2a_shim_stream_destroy(g_side[k]); g_side[k] = 0; }
 	for (k = 0; k <= NSIDE; ++k) if (g_side_ev[k]) { k2a_shim_event_destroy(g_side_ev[k]); g_side_ev[k] = 0; }
 }
@@ -568,7 +572,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	}
 	p->d_seq = (uint8_t*)cache_get(BUF_SEQ, p->seq_bytes, &p->cap[BUF_SEQ]);
 	if (!p->d_seq) { fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error()); goto err; }
-	up = thread_stream();
+	up = thread_upload_stream();
 	p->stream = up; p->stream_used = 1;              /* plan_destroy waits for it before the buffers are recycled */
 	if (k2a_shim_h2d(p->d_seq, p->h_seq, p->seq_bytes, up)) { fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error()); goto err; }
 
@@ -1001,7 +1005,8 @@ static int run_serial(int dual, int scalar, void *km, const ksw2amd_scoring_t *s
  * workers belong to several GPUs and the same counter shards the batch over them (pairs are independent: no collective). */
 #define POOL_MAXW 64
 #define POOL_MAXDEV 16
-typedef int (*chunk_fn)(void *ctx, int beg, int end, int share);
+typedef struct { ksw2amd_plan_t *p; int beg; } pend_t;      /* a worker's plan that is computing while the worker packs the next chunk */
+typedef int (*chunk_fn)(void *ctx, int beg, int end, int share, pend_t *pd);   /* beg < 0: finish what is pending */
 typedef struct {
 	chunk_fn fn; void *ctx;
 	int nchunks; const int *cbeg;               /* chunk c = pairs [cbeg[c], cbeg[c + 1]) */
@@ -1047,15 +1052,18 @@ static void *pool_worker(void *arg_)
 		if (!j || !job_has_dev(j, dev)) continue;
 		pthread_mutex_unlock(&g_pool.mu);
 		if (j->flush) release_thread_cache();
-		else for (;;) {
-			const int c = __sync_fetch_and_add(&j->next, 1);
-			int rc;
-			if (c >= j->nchunks || j->rc) break;
-			rc = j->fn(j->ctx, j->cbeg[c], j->cbeg[c + 1], j->share);
-			if (rc) {
-				pthread_mutex_lock(&g_pool.mu);
-				if (!j->rc) { j->rc = rc; snprintf(j->err, sizeof(j->err), "%s", g_err); }
-				pthread_mutex_unlock(&g_pool.mu);
+		else {
+			pend_t pd = { 0, 0 };
+			for (;;) {
+				const int c = __sync_fetch_and_add(&j->next, 1);
+				const int last = c >= j->nchunks || j->rc;
+				const int rc = last ? j->fn(j->ctx, -1, -1, j->share, &pd) : j->fn(j->ctx, j->cbeg[c], j->cbeg[c + 1], j->share, &pd);
+				if (rc) {
+					pthread_mutex_lock(&g_pool.mu);
+					if (!j->rc) { j->rc = rc; snprintf(j->err, sizeof(j->err), "%s", g_err); }
+					pthread_mutex_unlock(&g_pool.mu);
+				}
+				if (last) break;
 			}
 		}
 		pthread_mutex_lock(&g_pool.mu);
@@ -1139,24 +1147,28 @@ void ksw2amd_release_cache(void)
 	}
 }
 
-/* cut [0, n) into chunks of consecutive pairs of about equal cost; cost[i] >= 1.  Returns the number of chunks, cbeg[0..nchunks] */
-static int make_chunks(int n, const double *cost, double total, int nchunks, int *cbeg)
+/* cut [0, n) into at most `nchunks` (+ 2 * workers) chunks of consecutive pairs; cost[i] >= 1.  With enough chunks the first
+ * ones are small (the device gets its first kernels after a quarter of a chunk's packing time, not a whole one) and so are the
+ * last ones (the results of the final chunks come back quickly): weights 1/4, 1/2, 1 ... 1, 1/2.  Returns the chunk count, cbeg[0..count] */
+static int make_chunks(int n, const double *cost, double total, int nchunks, int workers, int *cbeg)
 {
+	const int ramp = nchunks >= 3 * workers && workers > 0, nc = ramp ? nchunks + 2 * workers : nchunks;
+	double wsum = 0, acc = 0, edge = 0;
 	int i, c = 0;
-	double acc = 0;
+	for (i = 0; i < nc; ++i) wsum += !ramp ? 1.0 : i < workers ? 0.25 : (i < 2 * workers || i >= nc - workers) ? 0.5 : 1.0;
 	cbeg[0] = 0;
+	edge = (!ramp ? 1.0 : 0.25) / wsum * total;
 	for (i = 0; i < n; ++i) {
 		acc += cost[i];
-		if (c + 1 < nchunks && acc >= total * (c + 1) / nchunks && i + 1 < n) cbeg[++c] = i + 1;
+		if (c + 1 < nc && acc >= edge && i + 1 < n) {
+			cbeg[++c] = i + 1;
+			edge += (!ramp ? 1.0 : c < workers ? 0.25 : (c < 2 * workers || c >= nc - workers) ? 0.5 : 1.0) / wsum * total;
+		}
 	}
 	cbeg[++c] = n;
 	return c;
 }
 
-/* decide how a batch of `n` items with the given sequence bytes / DP cells is run: 0 = inline on the caller, else the number
- * of chunks.  Small batches are not worth the hand-off; beyond that there is at least one chunk per worker (packing is the
- * bottleneck of short alignments), and no chunk holds more than KSW2AMD_CHUNK_MB of sequence or KSW2AMD_CHUNK_GCELLS * 1e9
- * cells, so that uploads, kernels and downloads of different chunks overlap. */
 static int pool_min_pairs(void)
 {
 	const char *e = getenv("KSW2AMD_POOL_MIN");           /* tests: pool batches of this many pairs or more, whatever their size */
@@ -1184,10 +1196,59 @@ static int plan_chunks(int n, double bytes, double cells, int workers, int ndev)
 }
 
 typedef struct { int dual, scalar; void *km; const ksw2amd_scoring_t *sc; const ksw2amd_pair_t *pairs; ksw_extz_t *ez; } ext_ctx_t;
-static int ext_chunk(void *ctx_, int beg, int end, int share)
+static double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+static int trace_on(void) { static int t = -1; if (t < 0) t = getenv("KSW2AMD_TRACE") != 0; return t; }
+
+static int ext_finish(ext_ctx_t *c, pend_t *pd)
+{
+	int rc = KSW2AMD_OK;
+	if (pd->p) {
+		const double t0 = now_ms();
+		rc = ksw2amd_plan_fetch(pd->p, c->km, c->ez + pd->beg);
+		if (trace_on()) fprintf(stderr, "[ksw2_amd] chunk @%d n=%d: wait+fetch %.2f ms\n", pd->beg, pd->p->n, now_ms() - t0);
+		ksw2amd_plan_destroy(pd->p);
+		pd->p = 0;
+	}
+	return rc;
+}
+
+/* One chunk on a pool worker, double-buffered: the chunk is packed and uploaded and its kernels are queued on the worker's
+ * stream BEFORE the worker waits for the previous chunk's results, so the device always has the next chunk's kernels behind
+ * the ones it is running.  A chunk that does not fit one plan (traceback memory) takes the serial path. */
+static int ext_chunk(void *ctx_, int beg, int end, int share, pend_t *pd)
 {
 	ext_ctx_t *c = (ext_ctx_t*)ctx_;
-	return run_serial(c->dual, c->scalar, c->km, c->sc, end - beg, c->pairs + beg, c->ez + beg, share);
+	size_t bytes = 0, free_b = 0, total_b = 0, budget = (size_t)1 << 30;
+	const char *env = getenv("KSW2AMD_MAX_BYTES");
+	ksw2amd_plan_t *p;
+	double t0, t1;
+	int i, rc, rc2;
+	if (beg < 0) return ext_finish(c, pd);
+	for (i = beg; i < end; ++i) bytes += pair_device_bytes(c->dual, &c->pairs[i]);
+	if (env && atoll(env) > 0) budget = (size_t)atoll(env);
+	else if (bytes > ((size_t)256 << 20)) {
+		if (k2a_shim_mem_info(&free_b, &total_b)) return fail(KSW2AMD_E_NODEVICE, "mem_info: %s", k2a_shim_last_error());
+		/* what is free now, plus what this worker's pending plan and cache will hand back, over two plans per worker */
+		budget = free_b / 10 * 7 / (size_t)(share > 0 ? share : 1);
+	}
+	if (bytes > budget) {
+		rc = ext_finish(c, pd);
+		return rc ? rc : run_serial(c->dual, c->scalar, c->km, c->sc, end - beg, c->pairs + beg, c->ez + beg, share);
+	}
+	t0 = now_ms();
+	p = plan_create_ex(c->dual, c->scalar, c->sc, end - beg, c->pairs + beg);
+	if (!p) {                                       /* out of device memory with two plans alive: finish the old one, go serial */
+		if (!strstr(g_err, "alloc")) return strstr(g_err, "device") ? KSW2AMD_E_NODEVICE : KSW2AMD_E_PARAM;
+		rc = ext_finish(c, pd);
+		return rc ? rc : run_serial(c->dual, c->scalar, c->km, c->sc, end - beg, c->pairs + beg, c->ez + beg, share);
+	}
+	t1 = now_ms();
+	rc = ksw2amd_plan_run(p, thread_stream());
+	if (trace_on()) fprintf(stderr, "[ksw2_amd] chunk @%d n=%d: pack+upload %.2f ms, launch %.2f ms, %zu device bytes\n", beg, end - beg, t1 - t0, now_ms() - t1, bytes);
+	rc2 = ext_finish(c, pd);
+	if (rc) { ksw2amd_plan_destroy(p); return rc; }
+	pd->p = p; pd->beg = beg;
+	return rc2;
 }
 
 /* devices of a pooled job: ksw2amd_set_devices() or the calling thread's current device */
@@ -1202,12 +1263,13 @@ static void job_devices(job_t *j)
 static int run_pooled(chunk_fn fn, void *ctx, int n, const double *cost, double total, int nchunks, int *rc)
 {
 	job_t j;
-	int *cbeg = (int*)malloc(sizeof(int) * ((size_t)nchunks + 2));
+	const int tpd = pool_threads_per_device(), workers = tpd * (g_ndev_set > 0 ? g_ndev_set : 1);
+	int *cbeg = (int*)malloc(sizeof(int) * ((size_t)nchunks + 2 * (size_t)workers + 2));
 	if (!cbeg) return 0;
 	memset(&j, 0, sizeof(j));
 	j.fn = fn; j.ctx = ctx; j.cbeg = cbeg;
-	j.nchunks = make_chunks(n, cost, total, nchunks, cbeg);
-	j.share = pool_threads_per_device();
+	j.nchunks = make_chunks(n, cost, total, nchunks, workers, cbeg);
+	j.share = tpd;
 	job_devices(&j);
 	if (pool_run(&j)) { free(cbeg); return 0; }
 	free(cbeg);
@@ -1617,7 +1679,7 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 		fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error());
 		goto err;
 	}
-	up = thread_stream();
+	up = thread_upload_stream();
 	p->stream = up; p->stream_used = 1;
 	if (k2a_shim_h2d(p->d_seq, p->h_seq, p->seq_bytes, up) || k2a_shim_h2d(p->d_pairs, p->h_pairs, sizeof(K2aPair) * (size_t)n, up) ||
 	    k2a_shim_h2d(p->d_order, p->h_order, sizeof(uint32_t) * (size_t)p->norder, up) ||
@@ -1789,7 +1851,7 @@ ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n
 		fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error());
 		goto err;
 	}
-	up = thread_stream();
+	up = thread_upload_stream();
 	p->stream = up; p->stream_used = 1;
 	if (k2a_shim_h2d(p->d_seq, p->h_seq, p->seq_bytes, up) || k2a_shim_h2d(p->d_pairs, p->h_pairs, sizeof(K2aPair) * (size_t)n, up) ||
 	    k2a_shim_h2d(p->d_order, p->h_order, sizeof(uint32_t) * (size_t)p->norder, up) ||
