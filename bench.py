@@ -302,6 +302,40 @@ def dtype_of(job, res):
     return "int16x2 (packed, two alignments per lane)" if npk == res["n"] else "int32" if npk == 0 else "int16x2 + int32"
 
 
+def scatter_gather_leg(lib, job, rank, world, barrier, red_dev, steps=3):
+    """ksw2_amd/parallel.py::sharded on the headline workload: rank 0 owns `world` x n pairs in host memory; one step = LPT
+    partition + point-to-point scatter (RCCL) + every rank's batch call + gather of records and CIGARs back to rank 0."""
+    import torch
+    import torch.distributed as dist
+    from ksw2_amd import parallel
+    wl = job.wl
+    n = min(job.n, 8192)
+    q = t = None
+    if rank == 0:
+        q, t = make_batch(wl, 0, n * world)
+    S = SCORING
+    sc = dict(mat=job.mat, q=S["q"], e=S["e"], q2=S["q2"], e2=S["e2"])
+    kw = dict(w=wl["w"], zdrop=wl["zdrop"], end_bonus=0, flag=wl["flag"], raw=True)
+    parallel.sharded(lib, job.kind, q, t, sc, **kw)                  # warm-up
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = parallel.sharded(lib, job.kind, q, t, sc, **kw)
+    barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    if rank != 0:
+        return None
+    ql = np.full(n * world, wl["qlen"]) if not wl.get("ragged") else np.array([len(x) for x in q])
+    tl = np.full(n * world, wl["tlen"]) if not wl.get("ragged") else np.array([len(x) for x in t])
+    cells = float(parallel.band_cells(ql, tl, np.full(len(ql), wl["w"])).sum())
+    return {"value": round(cells * steps / dt / 1e9, 2), "unit": "GCUPS", "pairs_per_step": n * world, "steps": steps,
+            "ms_per_step": round(dt / steps * 1e3, 3), "records_checked": int(out[0].shape[0]),
+            "what": "rank 0 holds the batch: LPT partition, torch.distributed point-to-point scatter, per-rank batch call, gather to rank 0"}
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -391,6 +425,9 @@ def main():
     job.free_ez()
     lib.release_cache()
     barrier()
+    # north_star's form of the multi-GPU path, next to the host-side sharding above ("report both"): rank 0 holds
+    # the whole batch, LPT-partitions it, scatters sequences + parameters and gathers records + CIGARs over RCCL
+    sg = scatter_gather_leg(lib, job, rank, world, barrier, red_dev) if world > 1 and job.kind in ("extz", "extd") else None
     res = job.resident(args.steps, max(1, min(args.warmup, 3)), stream)
     lib.release_cache()
 
@@ -415,6 +452,8 @@ def main():
                        "parallelism": "pairs sharded over %d GPU(s), one process per GPU, no collective in the data path" % world},
             "roofline": rl,
         }
+        if sg:
+            out["config"]["rank0_scatter_gather"] = sg
     # ------------------------------------------------------------------ the other configurations (N = 1: one run covers them all)
     names = ALSO_DEFAULT if args.also is None else [x for x in args.also.split(",") if x]
     if args.no_also or world > 1 or args.pairs or args.approx or args.workload != "10k":

@@ -645,9 +645,9 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 			da->tb_off = db->tb_off = p->tb_bytes;
 			if (c->solo) {        /* k2a_solo_steps: 2 * (double strips - 1) + 2 + last column; 64 lanes x 2 * K2A_SOLO_C bytes per step */
 				const int nds = (da->tlen + 2 * K2A_SOLO_C - 1) / (2 * K2A_SOLO_C);
-				p->tb_bytes += align_up(((size_t)(2 * (nds - 1) + 2) + (size_t)imin(da->qlen - 1, da->tlen - 1 + da->w)) * 64 * 2 * K2A_SOLO_C, 256);
+				p->tb_bytes += align_up(K2A_TB_PADDED((size_t)(2 * (nds - 1) + 2) + (size_t)imin(da->qlen - 1, da->tlen - 1 + da->w)) * 64 * 2 * K2A_SOLO_C, 256);
 			} else
-			p->tb_bytes += align_up(steps * G * wb, 256);
+			p->tb_bytes += align_up(K2A_TB_PADDED(steps) * G * wb, 256);          /* lane runs padded: k2a_tb_word */
 			da->cig_off = (uint32_t)p->cig_words;
 			p->cig_words += (size_t)da->qlen + da->tlen_full + 2;
 			if (ib != ia) { db->cig_off = (uint32_t)p->cig_words; p->cig_words += (size_t)db->qlen + db->tlen_full + 2; }
@@ -936,13 +936,13 @@ static size_t pair_device_bytes(int dual, const ksw2amd_pair_t *a)
 	size_t b = (size_t)imax(a->qlen, 0) + (size_t)imax(a->tlen, 0) + 96 + sizeof(K2aPair) + sizeof(K2aResult) + 4;
 	if (a->qlen > 0 && a->tlen > 0 && !(a->flag & KSW_EZ_SCORE_ONLY)) {
 		int mx = imax(a->qlen, a->tlen), w = (a->w < 0 || a->w > mx) ? mx : a->w;
-		size_t steps = (size_t)a->qlen + (size_t)a->tlen / 8 + 2;
+		size_t steps = (size_t)a->qlen + (size_t)a->tlen / 8 + 2 + K2A_TB_PAD;      /* lane runs are padded */
 		size_t lanes = (size_t)imin(64, (2 * w + 16) / 9 + 2);
 		(void)lanes;
 		if (w <= 1040 || a->tlen <= 2048)
 			b += steps * 64 * (dual ? 32 : 16) / (w <= 68 ? 8 : w <= 284 ? 4 : w <= 536 ? 2 : 1) + 256;
 		else   /* generation-serial: one (qlen + 63)-step sweep per 1024 rows, 64 lanes x 16 rows per step */
-			b += ((size_t)a->tlen / 1024 + 1) * ((size_t)a->qlen + 64) * 64 * (dual ? 16 : 8) + 12 * (size_t)a->qlen + 320;
+			b += (((size_t)a->tlen / 1024 + 1) * ((size_t)a->qlen + 64) + K2A_TB_PAD) * 64 * (dual ? 16 : 8) + 12 * (size_t)a->qlen + 320;
 		b += ((size_t)a->qlen + a->tlen + 2) * 4;
 	}
 	return b;
@@ -1147,12 +1147,13 @@ void ksw2amd_release_cache(void)
 	}
 }
 
+static int env_flag(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) != 0 : dflt; }
 /* cut [0, n) into at most `nchunks` (+ 2 * workers) chunks of consecutive pairs; cost[i] >= 1.  With enough chunks the first
  * ones are small (the device gets its first kernels after a quarter of a chunk's packing time, not a whole one) and so are the
  * last ones (the results of the final chunks come back quickly): weights 1/4, 1/2, 1 ... 1, 1/2.  Returns the chunk count, cbeg[0..count] */
 static int make_chunks(int n, const double *cost, double total, int nchunks, int workers, int *cbeg)
 {
-	const int ramp = nchunks >= 3 * workers && workers > 0, nc = ramp ? nchunks + 2 * workers : nchunks;
+	const int ramp = nchunks >= 3 * workers && workers > 0 && env_flag("KSW2AMD_RAMP", 1), nc = ramp ? nchunks + 2 * workers : nchunks;
 	double wsum = 0, acc = 0, edge = 0;
 	int i, c = 0;
 	for (i = 0; i < nc; ++i) wsum += !ramp ? 1.0 : i < workers ? 0.25 : (i < 2 * workers || i >= nc - workers) ? 0.5 : 1.0;
@@ -1248,6 +1249,7 @@ static int ext_chunk(void *ctx_, int beg, int end, int share, pend_t *pd)
 	rc2 = ext_finish(c, pd);
 	if (rc) { ksw2amd_plan_destroy(p); return rc; }
 	pd->p = p; pd->beg = beg;
+	if (!env_flag("KSW2AMD_DBUF", 1)) { rc = ext_finish(c, pd); if (!rc2) rc2 = rc; }    /* A/B: no double buffering */
 	return rc2;
 }
 

@@ -370,7 +370,7 @@ K2A_FN void k2a_gen_cols(int g, int qlen, int tlen, int w, int *jlo, int *nsteps
 K2A_FN size_t k2a_tb_word(size_t step, int lane, size_t nsteps, int G, int WB)
 {
 	(void)G;
-	return ((size_t)lane * nsteps + step) * (size_t)WB;
+	return ((size_t)lane * K2A_TB_PADDED(nsteps) + step) * (size_t)WB;      /* padded runs: ksw2_types.h */
 }
 
 template<int G, int C, bool MP>

@@ -157,6 +157,59 @@ k2a_fill_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const ui
 	}
 }
 
+/* Traceback words leave the wavefront as whole cache lines.  A lane's words of consecutive steps are contiguous in the
+ * lane-major block (k2a_tb_word), but written one 16 / 32-byte store per lane and step they reach HBM as partial-line
+ * writes: config 3 moved 1.9 x its algorithmic bytes that way (profiles/r1g_cfg3_pmc.json).  Instead every lane parks its
+ * WB-byte word of a step in LDS ([slot][lane], lane index swizzled by the slot so that the transposed read spreads over the
+ * banks), and every NS steps the wavefront writes out each lane's NS * WB contiguous bytes with 16-byte pieces of 64 lanes
+ * side by side: every store instruction covers whole 64- or 128-byte segments.  Lane runs are padded to K2A_TB_PAD steps
+ * (ksw2_types.h), so a block never crosses into the next lane's run; slots of steps that were not executed hold stale
+ * words that no walk ever visits.  Lanes that were idle for the whole block are skipped (`livemask`). */
+template<int WB, int NS>
+struct K2aTbStage {
+	enum { PIECES = WB / 16, BLOCK = NS * WB, CPB = BLOCK / 16, NI = NS * PIECES, WORDS = NS * 64 * PIECES };   /* uint4 per wavefront */
+	static_assert(WB == 16 || WB == 32, "16- or 32-byte lane-step words");
+	static_assert(K2A_TB_PAD % NS == 0 && 64 % CPB == 0, "blocks tile the padded runs");
+	uint4 *buf;                       /* this wavefront's [NS][64][PIECES] */
+	unsigned long long *gbase;        /* per lane: global address of its run (byte address of word (lane, 0)) */
+	uint64_t livemask;
+	int lane;
+
+	__device__ __forceinline__ void init(uint4 *buf_, unsigned long long *gb, int lane_, uint8_t *run)
+	{
+		buf = buf_; gbase = gb; lane = lane_; livemask = 0;
+		gbase[lane] = (unsigned long long)run;
+		__builtin_amdgcn_wave_barrier();
+	}
+	__device__ __forceinline__ void put(int k, const uint32_t *tw, bool live)
+	{
+		const int s = k & (NS - 1);
+		uint4 *d = buf + (s * 64 + (lane ^ s)) * PIECES;
+#pragma unroll
+		for (int x = 0; x < PIECES; ++x) d[x] = make_uint4(tw[4 * x], tw[4 * x + 1], tw[4 * x + 2], tw[4 * x + 3]);
+		livemask |= __builtin_amdgcn_ballot_w64(live);
+	}
+	/* write out the block of steps [k0, k0 + NS) */
+	__device__ __forceinline__ void flush(int k0)
+	{
+		__builtin_amdgcn_wave_barrier();
+		if (livemask != 0) {
+#pragma unroll
+			for (int x = 0; x < NI; ++x) {
+				const int id = x * 64 + lane, L = id / CPB, c = id % CPB;      /* source lane, 16-byte piece of its block */
+				const int s = c / PIECES, piece = c % PIECES;
+				const uint4 v = buf[(s * 64 + (L ^ s)) * PIECES + piece];
+				if ((livemask >> L) & 1) *(uint4*)(gbase[L] + (size_t)k0 * WB + (size_t)c * 16) = v;
+			}
+		}
+		livemask = 0;
+		__builtin_amdgcn_wave_barrier();
+	}
+	__device__ __forceinline__ void step_done(int k) { if ((k & (NS - 1)) == NS - 1) flush(k - (NS - 1)); }
+	__device__ __forceinline__ void finish(int kdone) { if (kdone >= 0 && (kdone & (NS - 1)) != NS - 1) flush(kdone & ~(NS - 1)); }   /* kdone = last executed step */
+};
+#define K2A_PK_TB_NS(WB, LDSROW) ((WB) == 32 && (LDSROW) ? 2 : 8)      /* row state in LDS: two wavefronts per SIMD need the room */
+
 /* Packed-int16 resident fill: two same-shape alignments per lane group (ksw2_lane_pk.h). */
 template<int G, int C, bool DUAL, int MODE, bool RB, bool NOMAX, bool LDSROW = false>
 __global__ void __launch_bounds__(64 * K2A_WPB, LDSROW ? 2 : 1)      /* no floor elsewhere: capping the score-only kernels at 168 VGPRs spills and is 18 % slower */
@@ -201,6 +254,14 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	L.qb = L.next_query_codes(-1);
 	const size_t tbsteps = (size_t)(klast + 1);
 	uint8_t *tbp = tb + prA.tb_off;
+	constexpr int WB = Lane::TBWORDS * 4;
+	constexpr bool STAGED = MODE != K2A_MODE_SCORE && (WB == 16 || WB == 32);
+	typedef K2aTbStage<STAGED ? WB : 16, K2A_PK_TB_NS(WB, LDSROW)> Stage;
+	__shared__ uint4 tbstage[STAGED ? K2A_WPB * Stage::WORDS : 1];
+	__shared__ unsigned long long tbruns[STAGED ? K2A_WPB * 64 : 1];
+	Stage ST;
+	if (STAGED) ST.init(&tbstage[wave * Stage::WORDS], &tbruns[wave * 64], lane, tbp + k2a_tb_word(0, gl, tbsteps, G, WB));
+	int kdone = -1;
 
 	for (int k = 0; k <= kmax; ++k) {
 		k2a_pk hin = (k2a_pk)k2a_rot1<G>((int)L.hout);
@@ -219,7 +280,8 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 
 		uint32_t tw[Lane::TBWORDS];
 		const bool live = L.step(sc, k, hin, ein, e2in, tw);
-		if (MODE != K2A_MODE_SCORE) {
+		if (STAGED) { ST.put(k, tw, live); ST.step_done(k); kdone = k; }
+		else if (MODE != K2A_MODE_SCORE) {
 			if (live) {
 				uint32_t *dst = (uint32_t*)(tbp + k2a_tb_word((size_t)k, gl, tbsteps, G, Lane::TBWORDS * 4));
 #pragma unroll
@@ -255,6 +317,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 		L.qb = qnext;
 		if (zseq && __builtin_amdgcn_ballot_w64(!(gdone || k >= klast)) == 0) break;   /* only a Z-drop ends a group early */
 	}
+	if (STAGED) ST.finish(kdone);
 	__builtin_amdgcn_wave_barrier();
 	if (!zseq) {
 		/* merge the lane-local bests of each group; the lane that finished the last target row adds mte / score */

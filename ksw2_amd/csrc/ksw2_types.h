@@ -21,6 +21,11 @@
 #define K2A_MODE_LEFT  1     /* traceback bits, gaps left-aligned  (default)       */
 #define K2A_MODE_RIGHT 2     /* traceback bits, gaps right-aligned (KSW_EZ_RIGHT)  */
 
+/* traceback blocks: every lane's run of lane-step words is padded to a multiple of K2A_TB_PAD steps, so that the fill
+ * kernels can hand whole 128-byte lines to the memory system (staged through LDS, ksw2_shim_hip.hip) */
+#define K2A_TB_PAD 32
+#define K2A_TB_PADDED(steps) (((steps) + (K2A_TB_PAD - 1)) / K2A_TB_PAD * K2A_TB_PAD)
+
 /* batch-uniform scoring, passed by value to the kernel */
 typedef struct K2aScoring {
 	int32_t q, e, q2, e2;        /* gap open / extend; (q2,e2) only for the two-piece model, q+e <= q2+e2 */

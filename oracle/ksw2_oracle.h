@@ -22,6 +22,8 @@
  *                 MI355X kernels implement (SURVEY.md section 8a rules 1-10).
  *   kso_exts2  <- ksw_exts2_sse ksw2_exts2_sse.c:33-415 (splice-aware; ksw2_oracle_exts.c; the SSE code is the only definition)
  *   kso_extf2  <- ksw_extf2_sse ksw2_extf2_sse.c:11-98 (gap-linear X-drop extension; ksw2_oracle_extf.c; follows the SSE memory image)
+ *   kso_extz2_sse / kso_extd2_sse <- ksw_extz2_sse / ksw_extd2_sse as they are (ksw2_extz2_sse.c:23-304, ksw2_extd2_sse.c:34-409):
+ *                 the SSE memory image, for the opt-in SSE-compatible mode of the product (ksw2_oracle_sse.c)
  *   helpers    <- ksw2.h:113-123 (CIGAR push), :129-161 (traceback state machine, row-major case),
  *                 :163-182 (EQX rewrite), :184-189 (reset), :191-207 (Z-drop test)
  */
@@ -76,6 +78,13 @@ void kso_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, 
                int8_t q, int8_t e, int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, kso_extz_t *ez);
 int  kso_gg2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
              int8_t q, int8_t e, int w, int *m_cigar, int *n_cigar, uint32_t **cigar);
+
+/* what ksw_extz2_sse / ksw_extd2_sse themselves return -- 16-position blocks ("leaky band"), anti-diagonal Z-drop, padded mte_q,
+ * KSW_EZ_APPROX_MAX / APPROX_DROP heuristics (ksw2_oracle_sse.c; follows the SSE memory image) */
+void kso_extz2_sse(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                   int8_t q, int8_t e, int w, int zdrop, int end_bonus, int flag, kso_extz_t *ez);
+void kso_extd2_sse(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
+                   int8_t q, int8_t e, int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, kso_extz_t *ez);
 
 /* gap-linear X-drop extension, score only (ksw2_extf2_sse.c:11); mch / mis / e as in the reference's signature */
 void kso_extf2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t mch, int8_t mis, int8_t e, int w, int xdrop,

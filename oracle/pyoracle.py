@@ -62,6 +62,8 @@ def oracle_lib():
         lib.kso_extd.argtypes = [_int, _u8p, _int, _u8p, _i8, _i8p, _i8, _i8, _i8, _i8, _int, _int, _int, ctypes.POINTER(Ez)]
         lib.kso_extz2.argtypes = [_int, _u8p, _int, _u8p, _i8, _i8p, _i8, _i8, _int, _int, _int, _int, ctypes.POINTER(Ez)]
         lib.kso_extd2.argtypes = [_int, _u8p, _int, _u8p, _i8, _i8p, _i8, _i8, _i8, _i8, _int, _int, _int, _int, ctypes.POINTER(Ez)]
+        lib.kso_extz2_sse.argtypes = lib.kso_extz2.argtypes
+        lib.kso_extd2_sse.argtypes = lib.kso_extd2.argtypes
         gg = [_int, _u8p, _int, _u8p, _i8, _i8p, _i8, _i8, _int, ctypes.POINTER(_int), ctypes.POINTER(_int),
               ctypes.POINTER(ctypes.POINTER(ctypes.c_uint32))]
         lib.kso_gg.argtypes = gg
@@ -149,6 +151,10 @@ def align(which, func, query, target, mat, q, e, q2=None, e2=None, w=-1, zdrop=-
             lib.kso_extz2(len(query), _p8(query), len(target), _p8(target), m, matp, q, e, w, zdrop, end_bonus, flag, ez)
         elif func == "extd2":
             lib.kso_extd2(len(query), _p8(query), len(target), _p8(target), m, matp, q, e, q2, e2, w, zdrop, end_bonus, flag, ez)
+        elif func == "extz2_sse":                    # the SSE kernels as they are (leaky band, anti-diagonal Z-drop, APPROX modes)
+            lib.kso_extz2_sse(len(query), _p8(query), len(target), _p8(target), m, matp, q, e, w, zdrop, end_bonus, flag, ez)
+        elif func == "extd2_sse":
+            lib.kso_extd2_sse(len(query), _p8(query), len(target), _p8(target), m, matp, q, e, q2, e2, w, zdrop, end_bonus, flag, ez)
         else:
             raise ValueError(func)
     else:
@@ -159,9 +165,9 @@ def align(which, func, query, target, mat, q, e, q2=None, e2=None, w=-1, zdrop=-
             lib.ksw_extz(None, len(query), _p8(query), len(target), _p8(target), m, matp, q, e, w, zdrop, flag, ez)
         elif func == "extd":
             lib.ksw_extd(None, len(query), _p8(query), len(target), _p8(target), m, matp, q, e, q2, e2, w, zdrop, flag, ez)
-        elif func == "extz2":
+        elif func in ("extz2", "extz2_sse"):
             lib.ksw_extz2_sse(None, len(query), _p8(query), len(target), _p8(target), m, matp, q, e, w, zdrop, end_bonus, flag, ez)
-        elif func == "extd2":
+        elif func in ("extd2", "extd2_sse"):
             lib.ksw_extd2_sse(None, len(query), _p8(query), len(target), _p8(target), m, matp, q, e, q2, e2, w, zdrop, end_bonus, flag, ez)
         else:
             raise ValueError(func)

@@ -474,6 +474,23 @@ def test_cli_matches_reference_cli(lib):
         b = subprocess.run([ref] + opts + [t, q], capture_output=True, text=True)
         assert a.returncode == 0, a.stderr
         assert a.stdout == b.stdout, (opts, a.stdout[:300], b.stdout[:300])
+    # -K (results from the caller's pool, cli.c:177,206) and gzip-compressed input (cli.c:210-211)
+    import gzip
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        gz = []
+        for f in (t1, q1):
+            gz.append(os.path.join(tmp, os.path.basename(f) + ".gz"))
+            with open(f, "rb") as src, gzip.open(gz[-1], "wb") as dst:
+                dst.write(src.read())
+        for opts in (["-t", "extz", "-K"], ["-t", "extd2_sse", "-K"], ["-t", "exts2_sse", "-K"]):
+            a = subprocess.run([ours] + opts + gz, capture_output=True, text=True, env=dict(os.environ, KSW2_TEST_POOL_STATS="1"))
+            b = subprocess.run([ours] + opts[:2] + [t1, q1], capture_output=True, text=True)
+            assert a.returncode == 0 and a.stdout == b.stdout and a.stdout.count("\n") == 5, (opts, a.stderr)
+            assert "pool: " in a.stderr and " 0 krealloc" not in a.stderr, a.stderr       # the CIGARs really came from the pool
+        a = subprocess.run([ours, "-t", "extz", "-K"] + gz, capture_output=True, text=True)
+        b = subprocess.run([ref, "-t", "extz", "-K"] + gz, capture_output=True, text=True)
+        assert a.stdout == b.stdout, (a.stdout[:300], b.stdout[:300])
     # batched mode prints the same lines as the per-pair mode
     a = subprocess.run([ours, "-t", "extz2_sse", "-b", t1, q1], capture_output=True, text=True)
     b = subprocess.run([ours, "-t", "extz2_sse", t1, q1], capture_output=True, text=True)

@@ -37,6 +37,29 @@ for dual in (False, True):
                 ok &= exp[k] == res[i][k]
     else:
         assert res is None
+# splice-aware and gap-linear X-drop batches shard the same way; fixed-length batches as 2-D arrays
+qs = ts = js = zd = fl = None
+if rank == 0:
+    from oracle.gen_golden_exts import spliced_pair
+    rng = np.random.Generator(np.random.PCG64(5))
+    cases = [spliced_pair(rng, 200) for _ in range(9)]
+    qs, ts = [c[0] for c in cases], [c[1] for c in cases]
+    js = [None if i %% 3 else rng.integers(0, 4, len(ts[i])).astype(np.uint8) for i in range(9)]
+    zd = rng.choice([-1, 60], size=9); fl = rng.choice([ka.KSW_EZ_SPLICE_FOR, ka.KSW_EZ_SPLICE_REV, ka.KSW_EZ_SPLICE_FOR | po.SCORE_ONLY], size=9)
+smat = synth.simple_mat(5, 1, 2, 0)
+res = parallel.sharded(lib, "exts", qs, ts, dict(mat=smat, q=2, e=1, q2=32, noncan=4, junc_bonus=3), zdrop=zd, flag=fl, juncs=js)
+if rank == 0:
+    for i in range(9):
+        exp = po.exts2("oracle", qs[i], ts[i], smat, 2, 1, 32, 4, zdrop=int(zd[i]), junc_bonus=3, flag=int(fl[i]), junc=js[i])
+        ok &= all(exp[k] == res[i][k] for k in ka.FIELDS + ["cigar"])
+q2d = t2d = None
+if rank == 0:
+    q2d, t2d = synth.fixed_batch(4, 11, 150, 160, sub=0.05, ind=0.03)
+res = parallel.sharded(lib, "extf", q2d, t2d, dict(mch=2, mis=-4, e=2), w=25, zdrop=30)
+if rank == 0:
+    for i in range(11):
+        exp = po.extf2("oracle", q2d[i], t2d[i], 2, -4, 2, 25, 30)
+        ok &= all(exp[k] == res[i][k] for k in ka.FIELDS)
 # an empty shard (more ranks than pairs) must work too
 res = parallel.sharded_align(lib, False, [np.array([1, 2], np.uint8)] if rank == 0 else None, [np.array([1, 2], np.uint8)] if rank == 0 else None, mat, q, e)
 if rank == 0:

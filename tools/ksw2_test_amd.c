@@ -6,16 +6,26 @@
  *     ksw2-test-amd [-t extz|extz2_sse|extd|extd2_sse|exts2_sse|extf2_sse|gg|gg2|gg2_sse] [-w band] [-z zdrop] [-r] [-s] [-g]
  *                   [-A match] [-B mismatch] [-O gapo[,gapo2]] [-E gape[,gape2]] [-R rep] [-a] [-b] <target.fa> <query.fa>
  *
- * Own code: plain FASTA/FASTQ-less reader (one record per '>' header; .gz is not supported), ACGT -> 0..3, other -> 4
- * (cli.c:17-34,58-65).  If a file cannot be opened the argument itself is taken as the sequence (cli.c:212-215).
+ * Own code: FASTA reader on zlib's gzFile (plain or .gz input, as cli.c:210-211 through kseq.h; one record per '>' header),
+ * ACGT -> 0..3, other -> 4 (cli.c:17-34,58-65).  If a file cannot be opened the argument itself is taken as the sequence
+ * (cli.c:212-215).
  * -b (new): align all pairs in one batched call (ksw2amd_ext?_batch) instead of one call per pair.
- * -K is accepted and ignored (no kalloc here).
+ * -K (cli.c:177,206): results are allocated from a caller-side pool passed as `km`.  The reference's kalloc is out of scope
+ * (SURVEY section 2), so the pool here is this program's own: it exports krealloc / kfree (kalloc.h:12-15), and the library
+ * finds them exactly as it finds the real kalloc's in a minimap2-style caller.
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <zlib.h>
 #include "../include/ksw2_amd.h"
+
+/* the caller-side pool behind -K: a counting wrapper around the C allocator with the kalloc entry points' signatures */
+typedef struct { long n_realloc, n_free; } pool_t;
+void *krealloc(void *km, void *ptr, size_t size) { if (km) ++((pool_t*)km)->n_realloc; return realloc(ptr, size); }
+void *kmalloc(void *km, size_t size) { return krealloc(km, 0, size); }
+void kfree(void *km, void *ptr) { if (km) ++((pool_t*)km)->n_free; free(ptr); }
 
 typedef struct { char *name, *seq; int len; } rec_t;
 typedef struct { rec_t *a; int n, m; } recs_t;
@@ -42,15 +52,27 @@ static void push_rec(recs_t *r, const char *name, const char *seq, int len)
 	++r->n;
 }
 
+/* one line of any length from a gzFile (plain files pass through zlib unchanged); returns the length or -1 at the end */
+static ssize_t gz_getline(gzFile fp, char **line, size_t *cap)
+{
+	size_t n = 0;
+	for (;;) {
+		if (*cap < n + 4096) { *cap = (n + 4096) * 2; *line = (char*)realloc(*line, *cap); }
+		if (!gzgets(fp, *line + n, (int)(*cap - n))) return n ? (ssize_t)n : -1;
+		n += strlen(*line + n);
+		if (n && (*line)[n - 1] == '\n') return (ssize_t)n;
+	}
+}
+
 static int read_fasta(const char *fn, recs_t *out)
 {
-	FILE *fp = fopen(fn, "r");
+	gzFile fp = gzopen(fn, "r");
 	char *line = 0, *seq = 0, name[1024] = "";
 	size_t cap = 0, scap = 0;
 	ssize_t got;
 	int slen = 0, have = 0;
 	if (!fp) return -1;
-	while ((got = getline(&line, &cap, fp)) >= 0) {
+	while ((got = gz_getline(fp, &line, &cap)) >= 0) {
 		while (got > 0 && (line[got - 1] == '\n' || line[got - 1] == '\r')) line[--got] = 0;
 		if (line[0] == '>') {
 			if (have) push_rec(out, name, seq ? seq : "", slen);
@@ -63,7 +85,7 @@ static int read_fasta(const char *fn, recs_t *out)
 		}
 	}
 	if (have) push_rec(out, name, seq ? seq : "", slen);
-	free(line); free(seq); fclose(fp);
+	free(line); free(seq); gzclose(fp);
 	return 0;
 }
 
@@ -103,6 +125,8 @@ int main(int argc, char *argv[])
 	char *s;
 	recs_t T = {0, 0, 0}, Q = {0, 0, 0};
 	ksw_extz_t ez;
+	pool_t pool = {0, 0};
+	void *km = 0;
 
 	while ((c = getopt(argc, argv, "t:w:R:rsgz:A:B:O:E:Kab")) >= 0) {
 		if (c == 't') algo = optarg;
@@ -114,6 +138,7 @@ int main(int argc, char *argv[])
 		else if (c == 'g') flag |= KSW_EZ_APPROX_MAX | KSW_EZ_APPROX_DROP;
 		else if (c == 'a') pair = 0;
 		else if (c == 'b') batch = 1;
+		else if (c == 'K') km = &pool;
 		else if (c == 'A') a = (int8_t)atoi(optarg);
 		else if (c == 'B') b = (int8_t)atoi(optarg);
 		else if (c == 'O') { q = q2 = (int8_t)strtol(optarg, &s, 10); if (*s == ',') q2 = (int8_t)strtol(s + 1, &s, 10); }
@@ -154,7 +179,7 @@ int main(int argc, char *argv[])
 		}
 		sc.m = 5; sc.mat = mat; sc.q = q; sc.e = e; sc.q2 = q2; sc.e2 = e2;
 		for (i = 0; i < rep && rc == 0; ++i)
-			rc = dual ? ksw2amd_extd_batch(0, &sc, n, p, res) : ksw2amd_extz_batch(0, &sc, n, p, res);
+			rc = dual ? ksw2amd_extd_batch(km, &sc, n, p, res) : ksw2amd_extz_batch(km, &sc, n, p, res);
 		if (rc) { fprintf(stderr, "ERROR: %s\n", ksw2amd_last_error()); return 1; }
 		for (k = 0; k < n; ++k) print_aln(T.a[jobs[2 * k]].name, Q.a[jobs[2 * k + 1]].name, &res[k]);
 		return 0;
@@ -170,25 +195,26 @@ int main(int argc, char *argv[])
 			if (strcmp(algo, "gg") == 0 || strcmp(algo, "gg2") == 0 || strcmp(algo, "gg2_sse") == 0) {
 				int (*f)(void*, int, const uint8_t*, int, const uint8_t*, int8_t, const int8_t*, int8_t, int8_t, int, int*, int*, uint32_t**) =
 					strcmp(algo, "gg") == 0 ? ksw_gg : strcmp(algo, "gg2") == 0 ? ksw_gg2 : ksw_gg2_sse;
-				if ((flag & KSW_EZ_SCORE_ONLY) && strcmp(algo, "gg2_sse") != 0) ez.score = f(0, ql, qs, tl, ts, 5, mat, q, e, w, 0, 0, 0);
-				else ez.score = f(0, ql, qs, tl, ts, 5, mat, q, e, w, &ez.m_cigar, &ez.n_cigar, &ez.cigar);
-			} else if (strcmp(algo, "extz") == 0) ksw_extz(0, ql, qs, tl, ts, 5, mat, q, e, w, zdrop, flag, &ez);
-			else if (strcmp(algo, "extz2_sse") == 0) ksw_extz2_sse(0, ql, qs, tl, ts, 5, mat, q, e, w, zdrop, 0, flag, &ez);
-			else if (strcmp(algo, "extd") == 0) ksw_extd(0, ql, qs, tl, ts, 5, mat, q, e, q2, e2, w, zdrop, flag, &ez);
-			else if (strcmp(algo, "extd2_sse") == 0) ksw_extd2_sse(0, ql, qs, tl, ts, 5, mat, q, e, q2, e2, w, zdrop, 0, flag, &ez);
+				if ((flag & KSW_EZ_SCORE_ONLY) && strcmp(algo, "gg2_sse") != 0) ez.score = f(km, ql, qs, tl, ts, 5, mat, q, e, w, 0, 0, 0);
+				else ez.score = f(km, ql, qs, tl, ts, 5, mat, q, e, w, &ez.m_cigar, &ez.n_cigar, &ez.cigar);
+			} else if (strcmp(algo, "extz") == 0) ksw_extz(km, ql, qs, tl, ts, 5, mat, q, e, w, zdrop, flag, &ez);
+			else if (strcmp(algo, "extz2_sse") == 0) ksw_extz2_sse(km, ql, qs, tl, ts, 5, mat, q, e, w, zdrop, 0, flag, &ez);
+			else if (strcmp(algo, "extd") == 0) ksw_extd(km, ql, qs, tl, ts, 5, mat, q, e, q2, e2, w, zdrop, flag, &ez);
+			else if (strcmp(algo, "extd2_sse") == 0) ksw_extd2_sse(km, ql, qs, tl, ts, 5, mat, q, e, q2, e2, w, zdrop, 0, flag, &ez);
 			else if (strcmp(algo, "exts2_sse") == 0) {     /* cli.c:79-83: its own 1 / -2 matrix, q=2 e=1 q2=32 noncan=4, forward signals */
 				int8_t smat[25];
 				int x, y;
 				for (x = 0; x < 5; ++x)
 					for (y = 0; y < 5; ++y) smat[x * 5 + y] = (int8_t)((x == 4 || y == 4) ? 0 : x == y ? 1 : -2);
-				ksw_exts2_sse(0, ql, qs, tl, ts, 5, smat, 2, 1, 32, 4, zdrop, 0, flag | KSW_EZ_SPLICE_FOR, 0, &ez);
+				ksw_exts2_sse(km, ql, qs, tl, ts, 5, smat, 2, 1, 32, 4, zdrop, 0, flag | KSW_EZ_SPLICE_FOR, 0, &ez);
 			}
-			else if (strcmp(algo, "extf2_sse") == 0) ksw_extf2_sse(0, ql, qs, tl, ts, mat[0], mat[1], e, w, zdrop, &ez);     /* cli.c:78 */
+			else if (strcmp(algo, "extf2_sse") == 0) ksw_extf2_sse(km, ql, qs, tl, ts, mat[0], mat[1], e, w, zdrop, &ez);     /* cli.c:78 */
 			else { fprintf(stderr, "ERROR: can't find algorithm '%s'\n", algo); return 1; }
 		}
 		print_aln(tr->name, qr->name, &ez);
 		free(qs); free(ts);
 	}
-	free(ez.cigar);
+	kfree(km, ez.cigar);
+	if (km && getenv("KSW2_TEST_POOL_STATS")) fprintf(stderr, "[ksw2-test-amd] pool: %ld krealloc, %ld kfree\n", pool.n_realloc, pool.n_free);
 	return 0;
 }

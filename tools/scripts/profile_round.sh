@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_${TAG}_${WL}
 rm -rf "$OUT"; mkdir -p "$OUT" "$ROOT/gpurun_out/profiles"
-BENCH="python3 $ROOT/bench.py --workload $WL --steps $STEPS --warmup 2 --no-cpu"
+BENCH="python3 $ROOT/bench.py --workload $WL --steps $STEPS --warmup 2 --no-cpu --resident-only"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- $BENCH > "$OUT/kt.log" 2>&1
 P=0
