@@ -170,6 +170,18 @@ void ksw2amd_host_stats(int64_t out[4]);
 int ksw2amd_extz_batch(void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez);
 int ksw2amd_extd_batch(void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez);
 
+/* SSE-compatible mode (opt-in).  By default the "...2_sse" functions above return the exact-band, row-wise results of the
+ * scalar ksw_extz / ksw_extd (the contract).  The reference's SSE kernels differ from that where their
+ * 16-position blocks leak across the band edge, in their anti-diagonal Z-drop, in mte_q, in tie order.  A
+ * caller that must reproduce an SSE build's output bit for bit -- every ksw_extz_t field and the CIGAR -- asks for it
+ *   per pair:      KSW2AMD_EZ_SSE_COMPAT or-ed into the flags of the single calls / of ksw2amd_pair_t, or
+ *   process-wide:  ksw2amd_set_sse_compat(1), or KSW2AMD_SSE_COMPAT=1 in the environment of an unchanged caller.
+ * Those pairs run through kernels that keep the SSE data flow (ksw2_extz2_sse.c:101-301, ksw2_extd2_sse.c:131-398; one
+ * alignment per wavefront, slower than the default path).  KSW_EZ_APPROX_MAX | KSW_EZ_APPROX_DROP always takes this path:
+ * that heuristic is defined by the SSE data flow (KSW2AMD_APPROX_DROP_EXACT=1 computes exactly instead). */
+#define KSW2AMD_EZ_SSE_COMPAT 0x20000000
+void ksw2amd_set_sse_compat(int on);
+
 /* splice-aware batches: the arguments of ksw_exts2_sse, scoring shared by the batch */
 typedef struct {
 	int32_t m;
@@ -207,6 +219,8 @@ int64_t ksw2amd_plan_cells(const ksw2amd_plan_t *plan);
 int64_t ksw2amd_plan_device_bytes(const ksw2amd_plan_t *plan);
 /* alignments routed to the packed-int16 kernels (two same-shape alignments per lane group) */
 int64_t ksw2amd_plan_packed_pairs(const ksw2amd_plan_t *plan);
+/* a resident plan of SSE-compatible alignments (every pair, whatever its flags); run / fetch / timing / cells / destroy as above */
+ksw2amd_plan_t *ksw2amd_sse_plan_create(int dual, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs);
 /* a resident plan of splice-aware extensions; run / fetch / timing / cells / destroy as above */
 ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, const ksw2amd_spair_t *pairs);
 /* a resident plan of gap-linear X-drop extensions; run / fetch / timing / cells / destroy as above */

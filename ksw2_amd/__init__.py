@@ -16,6 +16,7 @@ DEFAULT_SO = os.path.join(HERE, "libksw2_amd.so")
 KSW_NEG_INF = -0x40000000
 KSW_EZ_SCORE_ONLY, KSW_EZ_RIGHT, KSW_EZ_GENERIC_SC, KSW_EZ_APPROX_MAX, KSW_EZ_APPROX_DROP = 0x01, 0x02, 0x04, 0x08, 0x10
 KSW_EZ_EXTZ_ONLY, KSW_EZ_REV_CIGAR, KSW_EZ_EQX = 0x40, 0x80, 0x800
+KSW2AMD_EZ_SSE_COMPAT = 0x20000000      # per-pair opt-in: the SSE kernels' own results (include/ksw2_amd.h)
 
 FIELDS = ["score", "max", "max_t", "max_q", "mqe", "mqe_t", "mte", "mte_q", "zdropped", "reach_end", "n_cigar"]
 
@@ -68,7 +69,8 @@ EXPORTS = ["ksw_extz2_sse", "ksw_extd2_sse", "ksw_gg2", "ksw_gg2_sse", "ksw_extz
            "ksw2amd_plan_destroy", "ksw2amd_plan_timing", "ksw2amd_plan_cells", "ksw2amd_plan_device_bytes", "ksw2amd_plan_packed_pairs",
            "ksw2amd_plan_fetch_raw", "ksw_exts2_sse", "ksw_exts2_sse41", "ksw_exts2_sse2", "ksw2amd_exts_batch", "ksw2amd_exts_plan_create",
            "ksw_extf2_sse", "ksw2amd_extf_batch", "ksw2amd_extf_plan_create",
-           "ksw2amd_set_devices", "ksw2amd_set_error_handler", "ksw2amd_error_count", "ksw2amd_host_stats"]
+           "ksw2amd_set_devices", "ksw2amd_set_error_handler", "ksw2amd_error_count", "ksw2amd_host_stats",
+           "ksw2amd_set_sse_compat", "ksw2amd_sse_plan_create"]
 ERROR_FN = ctypes.CFUNCTYPE(None, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_void_p)
 KSW_EZ_SPLICE_FOR, KSW_EZ_SPLICE_REV, KSW_EZ_SPLICE_FLANK = 0x100, 0x200, 0x400
 
@@ -139,6 +141,10 @@ class Library:
         L.ksw2amd_extd_batch.argtypes = bt
         L.ksw2amd_plan_create.argtypes = [_int, ctypes.POINTER(Scoring), _int, ctypes.POINTER(Pair)]
         L.ksw2amd_plan_create.restype = ctypes.c_void_p
+        L.ksw2amd_sse_plan_create.argtypes = [_int, ctypes.POINTER(Scoring), _int, ctypes.POINTER(Pair)]
+        L.ksw2amd_sse_plan_create.restype = ctypes.c_void_p
+        L.ksw2amd_set_sse_compat.argtypes = [_int]
+        L.ksw2amd_set_sse_compat.restype = None
         L.ksw2amd_plan_run.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.ksw2amd_plan_fetch.argtypes = [ctypes.c_void_p, km, ezp]
         L.ksw2amd_plan_destroy.argtypes = [ctypes.c_void_p]
@@ -187,6 +193,10 @@ class Library:
 
     def release_cache(self):
         self.lib.ksw2amd_release_cache()
+
+    def set_sse_compat(self, on):
+        """ksw2amd_set_sse_compat: process-wide, every extz2 / extd2 call returns what the reference's SSE kernels return."""
+        self.lib.ksw2amd_set_sse_compat(1 if on else 0)
 
     def host_stats(self):
         """ksw2amd_host_stats -> dict(pool_batches, pool_chunks, coalesced_calls, coalesced_batches)."""
@@ -362,6 +372,10 @@ class Batch:
 
     def plan(self, dual):
         return Plan(self, dual)
+
+    def sse_plan(self, dual):
+        """ksw2amd_sse_plan_create: every pair through the SSE-compatible kernels."""
+        return Plan(self, dual, handle=self.L.lib.ksw2amd_sse_plan_create(1 if dual else 0, ctypes.byref(self.sc), self.n, self.pairs))
 
 
 class LinearBatch:

@@ -209,6 +209,8 @@ struct ksw2amd_plan_s {
 	/* gap-linear X-drop plans (ksw2amd_extf_plan_create, splice == 2): tasks grouped by where the state arrays live */
 	int f_first[6], f_count[6];
 	K2aExtf f_par;
+	/* SSE-compatible plans (ksw2amd_sse_plan_create, splice == 3): tasks grouped by kernel mode in s_first / s_count[mode][0][0] */
+	K2aSsec c_par;
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -696,11 +698,13 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 
 static int exts_plan_run(ksw2amd_plan_t *p, void *stream);
 static int extf_plan_run(ksw2amd_plan_t *p, void *stream);
+static int ssec_plan_run(ksw2amd_plan_t *p, void *stream);
 
 int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 {
 	int c;
 	if (!p) return fail(KSW2AMD_E_PARAM, "plan_run: NULL plan%s", 0);
+	if (p->splice == 3) return ssec_plan_run(p, stream);
 	if (p->splice == 2) return extf_plan_run(p, stream);
 	if (p->splice) return exts_plan_run(p, stream);
 	p->stream = stream; p->ran = 1; p->stream_used = 1;
@@ -903,7 +907,7 @@ static int plan_fetch_ex(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez, ksw_extz_t
 		z->max = (uint32_t)r->max; z->zdropped = (uint32_t)r->zdropped;
 		z->max_q = r->max_q; z->max_t = r->max_t; z->mqe = r->mqe; z->mqe_t = r->mqe_t;
 		z->mte = r->mte; z->mte_q = r->mte_q; z->score = r->score; z->reach_end = r->reach_end;
-		if (is_approx(p->h_flag[i])) {
+		if (p->splice != 3 && is_approx(p->h_flag[i])) {      /* (the SSE-compatible kernels produce that mode's fields themselves) */
 			z->max = 0; z->max_q = z->max_t = z->mqe_t = z->mte_q = -1; z->mqe = z->mte = KSW_NEG_INF; z->reach_end = 0;
 			if (r->zdropped || (p->h_flag[i] & KSW_EZ_EXTZ_ONLY)) continue;    /* no start cell without a maximum */
 		}
@@ -1075,7 +1079,7 @@ static void *pool_worker(void *arg_)
 static int pool_threads_per_device(void)
 {
 	const char *e = getenv("KSW2AMD_THREADS");
-	int t = e ? atoi(e) : 4;
+	int t = e ? atoi(e) : 6;
 	return t < 0 ? 0 : t > 16 ? 16 : t;
 }
 
@@ -1153,7 +1157,7 @@ static int env_flag(const char *name, int dflt) { const char *e = getenv(name); 
  * last ones (the results of the final chunks come back quickly): weights 1/4, 1/2, 1 ... 1, 1/2.  Returns the chunk count, cbeg[0..count] */
 static int make_chunks(int n, const double *cost, double total, int nchunks, int workers, int *cbeg)
 {
-	const int ramp = nchunks >= 3 * workers && workers > 0 && env_flag("KSW2AMD_RAMP", 1), nc = ramp ? nchunks + 2 * workers : nchunks;
+	const int ramp = nchunks >= 3 * workers && workers > 0 && env_flag("KSW2AMD_RAMP", 0), nc = ramp ? nchunks + 2 * workers : nchunks;
 	double wsum = 0, acc = 0, edge = 0;
 	int i, c = 0;
 	for (i = 0; i < nc; ++i) wsum += !ramp ? 1.0 : i < workers ? 0.25 : (i < 2 * workers || i >= nc - workers) ? 0.5 : 1.0;
@@ -1179,7 +1183,7 @@ static int pool_min_pairs(void)
 static int plan_chunks(int n, double bytes, double cells, int workers, int ndev)
 {
 	const char *e1 = getenv("KSW2AMD_CHUNK_MB"), *e2 = getenv("KSW2AMD_CHUNK_GCELLS");
-	const double cap_b = (e1 && atof(e1) > 0 ? atof(e1) : 64.0) * 1048576.0, cap_c = (e2 && atof(e2) > 0 ? atof(e2) : 40.0) * 1e9;
+	const double cap_b = (e1 && atof(e1) > 0 ? atof(e1) : 128.0) * 1048576.0, cap_c = (e2 && atof(e2) > 0 ? atof(e2) : 40.0) * 1e9;
 	const int forced = pool_min_pairs(), min_chunk = forced ? imax(forced / 4, 1) : 256;
 	double k;
 	if (workers <= 0) return 0;
@@ -1213,9 +1217,11 @@ static int ext_finish(ext_ctx_t *c, pend_t *pd)
 	return rc;
 }
 
-/* One chunk on a pool worker, double-buffered: the chunk is packed and uploaded and its kernels are queued on the worker's
- * stream BEFORE the worker waits for the previous chunk's results, so the device always has the next chunk's kernels behind
- * the ones it is running.  A chunk that does not fit one plan (traceback memory) takes the serial path. */
+/* One chunk on a pool worker.  Default: pack, upload, run, fetch -- the workers (KSW2AMD_THREADS per device, default 6) are
+ * what overlaps the phases of different chunks.  KSW2AMD_DBUF=1 lets a worker queue chunk k + 1 before it waits for chunk k
+ * (two plans per worker); measured on the 10 k headline (profiles/r2_chunk_grid.txt) that is slower -- 2 720 vs 3 100 GCUPS at
+ * 128 MB chunks: twice the plans in flight, each kernel filling less of the device -- so it is off.  A chunk that does not fit
+ * one plan (traceback memory) takes the serial path. */
 static int ext_chunk(void *ctx_, int beg, int end, int share, pend_t *pd)
 {
 	ext_ctx_t *c = (ext_ctx_t*)ctx_;
@@ -1249,7 +1255,7 @@ static int ext_chunk(void *ctx_, int beg, int end, int share, pend_t *pd)
 	rc2 = ext_finish(c, pd);
 	if (rc) { ksw2amd_plan_destroy(p); return rc; }
 	pd->p = p; pd->beg = beg;
-	if (!env_flag("KSW2AMD_DBUF", 1)) { rc = ext_finish(c, pd); if (!rc2) rc2 = rc; }    /* A/B: no double buffering */
+	if (!env_flag("KSW2AMD_DBUF", 0)) { rc = ext_finish(c, pd); if (!rc2) rc2 = rc; }    /* default: finish this chunk before taking the next */
 	return rc2;
 }
 
@@ -1309,14 +1315,39 @@ static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc
 	return run_serial(dual, scalar, km, sc, n, pairs, ez, 1);
 }
 
+static int wants_ssec(int flag);
+static int ssec_run(int dual, void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez);
+
+/* pairs that ask for the SSE kernels' own results (wants_ssec) run through the SSE-compatible plans, the others through the
+ * exact-contract kernels; a mixed batch is split and its results put back in place */
+static int route_batch(int dual, void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez)
+{
+	int i, nc = 0, rc = KSW2AMD_OK, part;
+	for (i = 0; i < n; ++i) nc += wants_ssec(pairs[i].flag);
+	if (nc == 0) return run_batch(dual, 0, km, sc, n, pairs, ez);
+	if (nc == n) return ssec_run(dual, km, sc, n, pairs, ez);
+	for (part = 0; part < 2 && rc == KSW2AMD_OK; ++part) {
+		const int cnt = part ? nc : n - nc;
+		ksw2amd_pair_t *pp = (ksw2amd_pair_t*)malloc(sizeof(*pp) * (size_t)cnt);
+		ksw_extz_t *zz = (ksw_extz_t*)malloc(sizeof(*zz) * (size_t)cnt);
+		int k = 0;
+		if (!pp || !zz) { free(pp); free(zz); return fail(KSW2AMD_E_NOMEM, "batch: host allocation failed%s", 0); }
+		for (i = 0; i < n; ++i) if (wants_ssec(pairs[i].flag) == part) { pp[k] = pairs[i]; zz[k] = ez[i]; ++k; }
+		rc = part ? ssec_run(dual, km, sc, cnt, pp, zz) : run_batch(dual, 0, km, sc, cnt, pp, zz);
+		for (i = 0, k = 0; i < n; ++i) if (wants_ssec(pairs[i].flag) == part) ez[i] = zz[k++];      /* CIGAR buffers may have moved: always copy back */
+		free(pp); free(zz);
+	}
+	return rc;
+}
+
 int ksw2amd_extz_batch(void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez)
 {
-	return run_batch(0, 0, km, sc, n, pairs, ez);
+	return route_batch(0, km, sc, n, pairs, ez);
 }
 
 int ksw2amd_extd_batch(void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez)
 {
-	return run_batch(1, 0, km, sc, n, pairs, ez);
+	return route_batch(1, km, sc, n, pairs, ez);
 }
 
 /* ---------------------------------------------------------------- the ksw2-named single-pair calls */
@@ -1353,6 +1384,11 @@ static void one_pair(const char *fn, int dual, int scalar, void *km, int qlen, c
 	sc.m = m; sc.mat = mat; sc.q = q; sc.e = e; sc.q2 = q2; sc.e2 = e2;
 	pr.query = query; pr.target = target; pr.qlen = qlen; pr.tlen = tlen;
 	pr.w = w; pr.zdrop = zdrop; pr.end_bonus = end_bonus; pr.flag = flag & ~F_SCALAR_CONTRACT;
+	if (!scalar && wants_ssec(pr.flag)) {                             /* the SSE kernels' own results (ksw2_lane_ssec.h) */
+		rc = ssec_run(dual, km, &sc, 1, &pr, ez);
+		if (rc != KSW2AMD_OK) call_failed(fn, rc, ez);
+		return;
+	}
 	if (!scalar && queue_one(fn, dual, km, &sc, &pr, ez)) return;     /* coalesced with other threads' calls */
 	rc = run_serial(dual, scalar, km, &sc, 1, &pr, ez, 1);
 	if (rc != KSW2AMD_OK) call_failed(fn, rc, ez);
@@ -1882,6 +1918,214 @@ static int extf_plan_run(ksw2amd_plan_t *p, void *stream)
 	return KSW2AMD_OK;
 err:
 	return fail(KSW2AMD_E_NODEVICE, "extf run: %s", k2a_shim_last_error());
+}
+
+
+/* ---------------------------------------------------------------- SSE-compatible mode (ksw2_lane_ssec.h) */
+
+/* Process-wide default (ksw2amd_set_sse_compat, KSW2AMD_SSE_COMPAT=1 at load): every ksw_extz2_sse / ksw_extd2_sse call and
+ * batch returns what the reference's SSE kernels return.  Per pair: KSW2AMD_EZ_SSE_COMPAT in the flags.  Independent of
+ * both, KSW_EZ_APPROX_MAX | KSW_EZ_APPROX_DROP takes this path, because that heuristic follows one cell through the SSE
+ * kernels' padded blocks and has no meaning outside them (KSW2AMD_APPROX_DROP_EXACT=1: the exact computation instead). */
+static int g_sse_compat = -1;
+void ksw2amd_set_sse_compat(int on) { g_sse_compat = on ? 1 : 0; }
+static int wants_ssec(int flag)
+{
+	static int drop_exact = -1;
+	if (g_sse_compat < 0) g_sse_compat = env_flag("KSW2AMD_SSE_COMPAT", 0);
+	if (drop_exact < 0) drop_exact = env_flag("KSW2AMD_APPROX_DROP_EXACT", 0);
+	if (g_sse_compat || (flag & KSW2AMD_EZ_SSE_COMPAT)) return 1;
+	return (flag & KSW_EZ_APPROX_MAX) && (flag & KSW_EZ_APPROX_DROP) && !drop_exact;
+}
+
+static int ssec_ncol(int qlen, int tlen, int w)            /* = k2a_ssec_ncol (ksw2_lane_ssec.h) */
+{
+	const int n = imin(imin(qlen, tlen), w + 1);
+	return ((n + 15) / 16 + 1) * 16;
+}
+
+static size_t ssec_pair_bytes(int dual, const ksw2amd_pair_t *a)
+{
+	const size_t ql = (size_t)imax(a->qlen, 0), tl = (size_t)imax(a->tlen, 0);
+	const int mx = imax(a->qlen, a->tlen), w = (a->w < 0 || a->w > mx) ? mx : a->w;
+	size_t b = ql + tl + 64 + (size_t)(dual ? 11 : 9) * (tl + 16) + sizeof(K2aPair) + sizeof(K2aResult);
+	if (ql && tl && !(a->flag & KSW_EZ_SCORE_ONLY)) b += (ql + tl) * (size_t)ssec_ncol(a->qlen, a->tlen, w) + 4 * (ql + tl) + 512;
+	return b;
+}
+
+ksw2amd_plan_t *ksw2amd_sse_plan_create(int dual, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs)
+{
+	ksw2amd_plan_t *p;
+	int i, k, mode, m, q, e, q2, e2, lo;
+	size_t off, mat_off;
+	void *up;
+	uint32_t fill[3];
+
+	g_err[0] = 0;
+	if (n < 0 || (n > 0 && !pairs) || !sc) { fail(KSW2AMD_E_PARAM, "sse plan: bad arguments%s", 0); return 0; }
+	if (k2a_shim_device_count() <= 0) { fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend()); return 0; }
+	p = (ksw2amd_plan_t*)calloc(1, sizeof(*p));
+	if (!p) { fail(KSW2AMD_E_NOMEM, "sse plan: host allocation failed%s", 0); return 0; }
+	p->splice = 3; p->dual = !!dual; p->n = n; p->m = m = sc->m;
+	q = sc->q; e = sc->e; q2 = dual ? sc->q2 : 0; e2 = dual ? sc->e2 : 0;
+	p->h_cls = (int8_t*)malloc((size_t)n + 1);
+	p->h_half = (uint8_t*)calloc((size_t)n + 1, 1);
+	p->h_flag = (int32_t*)malloc(sizeof(int32_t) * ((size_t)n + 1));
+	p->h_pairs = (K2aPair*)calloc((size_t)n + 1, sizeof(K2aPair));
+	p->h_res = (K2aResult*)calloc((size_t)n + 1, sizeof(K2aResult));
+	p->h_order = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n + 1));
+	if (!p->h_cls || !p->h_half || !p->h_flag || !p->h_pairs || !p->h_res || !p->h_order) { fail(KSW2AMD_E_NOMEM, "sse plan: host allocation failed%s", 0); goto err; }
+	for (i = 0; i < n; ++i) { p->h_cls[i] = -1; p->h_flag[i] = pairs[i].flag & ~F_SCALAR_CONTRACT; }
+	/* ksw2_extz2_sse.c:57,78-82 / ksw2_extd2_sse.c:76,96-100 */
+	if (m <= (dual ? 1 : 0) || !sc->mat) p->reject_all = 1;
+	else if (m > K2A_MAXM) { fail(KSW2AMD_E_PARAM, "more than 127 residue types (int8_t m, ksw2.h:61)%s", 0); goto err; }
+	else {
+		p->c_par.qe_first = q + e;
+		if (dual && q2 + e2 < q + e) { int t = q; q = q2; q2 = t; t = e; e = e2; e2 = t; }
+		for (k = 1, lo = sc->mat[m * m > 1 ? 1 : 0]; k < m * m; ++k) lo = imin(lo, sc->mat[k]);
+		if (-lo > 2 * (q + e)) p->reject_all = 1;
+	}
+	if (p->reject_all || n == 0) return p;
+
+	memset(p->s_count, 0, sizeof(p->s_count));
+	off = 0;
+	for (i = 0; i < n; ++i) {
+		const ksw2amd_pair_t *a = &pairs[i];
+		K2aPair *d = &p->h_pairs[i];
+		const int fl = p->h_flag[i];
+		int w = a->w, mx, T16;
+		if (a->qlen <= 0 || a->tlen <= 0) continue;
+		if (!a->query || !a->target) { fail(KSW2AMD_E_PARAM, "sse plan: NULL sequence%s", 0); goto err; }
+		mx = imax(a->qlen, a->tlen);
+		if (w < 0 || w > mx) w = mx;                                       /* a wider band than the sequences changes nothing (ksw2_extz2_sse.c:72) */
+		mode = (fl & KSW_EZ_SCORE_ONLY) ? K2A_MODE_SCORE : (fl & KSW_EZ_RIGHT) ? K2A_MODE_RIGHT : K2A_MODE_LEFT;
+		p->h_cls[i] = (int8_t)mode;
+		++p->s_count[mode][0][0];
+		d->qlen = a->qlen; d->tlen = d->tlen_full = a->tlen; d->w = w;
+		d->zdrop = a->zdrop; d->end_bonus = a->end_bonus;
+		d->flag = fl & (KSW_EZ_EXTZ_ONLY | KSW_EZ_REV_CIGAR | KSW_EZ_SCORE_ONLY);
+		d->pad = ((fl & KSW_EZ_APPROX_MAX) ? K2A_SSEC_APPROX : 0) | (((fl & KSW_EZ_APPROX_MAX) && (fl & KSW_EZ_APPROX_DROP)) ? K2A_SSEC_APPROX_DROP : 0) |
+		         ((fl & KSW_EZ_GENERIC_SC) ? K2A_SSEC_GENERIC : 0);
+		off = align_up(off, 4); d->qoff = (uint32_t)off; off += (size_t)a->qlen;
+		off = align_up(off, 4); d->toff = (uint32_t)off; off += (size_t)a->tlen;
+		if (off > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "sse plan: more than 4 GiB of sequence in one plan%s", 0); goto err; }
+		T16 = (a->tlen + 15) / 16 * 16;
+		d->bnd_off = (uint32_t)(p->bnd_words / 4);                           /* 16-byte units */
+		p->bnd_words += (size_t)(dual ? 11 : 9) * (size_t)T16 / 4;
+		if (p->bnd_words / 4 > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "sse plan: state scratch over 64 GiB in one plan%s", 0); goto err; }
+		p->cells += band_cells(a->qlen, a->tlen, w);
+		if (mode != K2A_MODE_SCORE) {
+			d->tb_off = p->tb_bytes;
+			p->tb_bytes += align_up((size_t)(a->qlen + a->tlen - 1) * (size_t)ssec_ncol(a->qlen, a->tlen, w), 256);
+			d->cig_off = (uint32_t)p->cig_words;
+			p->cig_words += (size_t)a->qlen + a->tlen + 2;
+			if (p->cig_words > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "sse plan: CIGAR scratch over 16 GiB in one plan%s", 0); goto err; }
+		}
+	}
+	off = align_up(off + 256, 256);
+	mat_off = off; off = align_up(off + (size_t)m * m, 256);
+	p->seq_bytes = off;
+	p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, p->seq_bytes, &p->cap[BUF_HSEQ]);
+	if (!p->h_seq) { fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
+	for (k = 0, mode = 0; mode < 3; ++mode) { p->s_first[mode][0][0] = k; fill[mode] = (uint32_t)k; k += p->s_count[mode][0][0]; }
+	p->ntasks = p->norder = k;
+	for (i = 0; i < n; ++i) {
+		if (p->h_cls[i] < 0) continue;
+		memcpy(p->h_seq + p->h_pairs[i].qoff, pairs[i].query, (size_t)pairs[i].qlen);
+		memcpy(p->h_seq + p->h_pairs[i].toff, pairs[i].target, (size_t)pairs[i].tlen);
+		p->h_order[fill[p->h_cls[i]]++] = (uint32_t)i;
+	}
+	memcpy(p->h_seq + mat_off, sc->mat, (size_t)m * m);
+
+	p->d_seq = (uint8_t*)cache_get(BUF_SEQ, p->seq_bytes, &p->cap[BUF_SEQ]);
+	p->d_pairs = (K2aPair*)cache_get(BUF_PAIRS, sizeof(K2aPair) * ((size_t)n + 1), &p->cap[BUF_PAIRS]);
+	p->d_res = (K2aResult*)cache_get(BUF_RES, sizeof(K2aResult) * ((size_t)n + 1), &p->cap[BUF_RES]);
+	p->d_order = (uint32_t*)cache_get(BUF_ORDER, sizeof(uint32_t) * ((size_t)p->norder + 1), &p->cap[BUF_ORDER]);
+	p->d_tb = p->tb_bytes ? (uint8_t*)cache_get(BUF_TB, p->tb_bytes, &p->cap[BUF_TB]) : 0;
+	p->d_cig = p->cig_words ? (uint32_t*)cache_get(BUF_CIG, p->cig_words * 4, &p->cap[BUF_CIG]) : 0;
+	p->d_bnd = p->bnd_words ? (int32_t*)cache_get(BUF_BND, p->bnd_words * 4, &p->cap[BUF_BND]) : 0;
+	if (!p->d_seq || !p->d_pairs || !p->d_res || !p->d_order || (p->tb_bytes && !p->d_tb) || (p->cig_words && !p->d_cig) ||
+	    (p->bnd_words && !p->d_bnd)) {
+		fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error());
+		goto err;
+	}
+	up = thread_upload_stream();
+	p->stream = up; p->stream_used = 1;
+	if (k2a_shim_h2d(p->d_seq, p->h_seq, p->seq_bytes, up) || k2a_shim_h2d(p->d_pairs, p->h_pairs, sizeof(K2aPair) * (size_t)n, up) ||
+	    k2a_shim_h2d(p->d_order, p->h_order, sizeof(uint32_t) * (size_t)p->norder, up) ||
+	    k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)n, up) || k2a_shim_stream_sync(up)) {
+		fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error());
+		goto err;
+	}
+	p->c_par.q = q; p->c_par.e = e; p->c_par.q2 = q2; p->c_par.e2 = e2; p->c_par.m = m;
+	p->c_par.sc_mch = sc->mat[0]; p->c_par.sc_mis = sc->mat[m * m > 1 ? 1 : 0];
+	p->c_par.sc_N = sc->mat[m * m - 1] == 0 ? -(dual ? e2 : e) : sc->mat[m * m - 1];     /* ksw2_extz2_sse.c:68, ksw2_extd2_sse.c:87 */
+	if (dual) {                                                                             /* ksw2_extd2_sse.c:102-105 */
+		int lt = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+		if (q2 + e2 + lt * e2 > q + e + lt * e) ++lt;
+		p->c_par.long_thres = lt; p->c_par.long_diff = lt * (e - e2) - (q2 - q) - e2;
+	}
+	p->c_par.mat = (const int8_t*)p->d_seq + mat_off;
+	for (i = 0; i < 3; ++i) { p->ev[i] = g_ev_cache[i] ? g_ev_cache[i] : k2a_shim_event_create(); g_ev_cache[i] = 0; }
+	p->stream = 0; p->stream_used = 0;             /* uploads complete, see plan_create_ex */
+	return p;
+err:
+	ksw2amd_plan_destroy(p);
+	return 0;
+}
+
+static int ssec_plan_run(ksw2amd_plan_t *p, void *stream)
+{
+	int mode;
+	p->stream = stream; p->ran = 1; p->stream_used = 1;
+	if (p->reject_all || p->ntasks == 0) return KSW2AMD_OK;
+	if (k2a_shim_event_record(p->ev[0], stream)) goto err;
+	for (mode = 0; mode < 3; ++mode)
+		if (p->s_count[mode][0][0] &&
+		    k2a_shim_launch_ssec(p->dual, mode, &p->c_par, p->d_pairs, p->d_order + p->s_first[mode][0][0], p->s_count[mode][0][0], p->d_seq, p->d_tb,
+		                         (uint8_t*)p->d_bnd, p->d_res, stream)) goto err;
+	if (k2a_shim_event_record(p->ev[1], stream)) goto err;
+	for (mode = 1; mode < 3; ++mode)
+		if (p->s_count[mode][0][0] &&
+		    k2a_shim_launch_ssec_trace(p->d_pairs, p->d_order + p->s_first[mode][0][0], p->s_count[mode][0][0], p->d_tb, p->d_res, p->d_cig, stream)) goto err;
+	if (k2a_shim_event_record(p->ev[2], stream)) goto err;
+	return KSW2AMD_OK;
+err:
+	return fail(KSW2AMD_E_NODEVICE, "sse-compatible run: %s", k2a_shim_last_error());
+}
+
+/* n pairs through SSE-compatible plans sized to the device's free memory */
+static int ssec_run(int dual, void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez)
+{
+	int beg = 0;
+	size_t budget, free_b = 0, total_b = 0;
+	const char *env = getenv("KSW2AMD_MAX_BYTES");
+	if (n <= 0) return KSW2AMD_OK;
+	if (k2a_shim_device_count() <= 0) return fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend());
+	if (env && atoll(env) > 0) budget = (size_t)atoll(env);
+	else if (n == 1) budget = (size_t)1 << 36;
+	else {
+		if (k2a_shim_mem_info(&free_b, &total_b)) return fail(KSW2AMD_E_NODEVICE, "mem_info: %s", k2a_shim_last_error());
+		budget = free_b / 10 * 7;
+	}
+	while (beg < n) {
+		ksw2amd_plan_t *p;
+		size_t acc = 0, seq = 0;
+		int end, rc;
+		for (end = beg; end < n; ++end) {
+			const size_t b = ssec_pair_bytes(dual, &pairs[end]), sq = (size_t)imax(pairs[end].qlen, 0) + (size_t)imax(pairs[end].tlen, 0) + 8;
+			if (end > beg && (acc + b > budget || seq + sq > 3000000000u || end - beg >= (1 << 22))) break;
+			acc += b; seq += sq;
+		}
+		p = ksw2amd_sse_plan_create(dual, sc, end - beg, pairs + beg);
+		if (!p) return strstr(g_err, "alloc") ? KSW2AMD_E_NOMEM : strstr(g_err, "device") ? KSW2AMD_E_NODEVICE : KSW2AMD_E_PARAM;
+		rc = ksw2amd_plan_run(p, thread_stream());
+		if (rc == KSW2AMD_OK) rc = ksw2amd_plan_fetch(p, km, ez + beg);
+		ksw2amd_plan_destroy(p);
+		if (rc) return rc;
+		beg = end;
+	}
+	return KSW2AMD_OK;
 }
 
 int ksw2amd_extf_batch(void *km, int8_t mch, int8_t mis, int8_t e, int n, const ksw2amd_fpair_t *pairs, ksw_extz_t *ez)

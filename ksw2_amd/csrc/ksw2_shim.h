@@ -99,6 +99,14 @@ int k2a_shim_launch_exts_trace(const K2aSplice *sp, const K2aPair *pairs, const 
 int k2a_shim_launch_extf(int cls, const K2aExtf *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
                          uint8_t *scratch, K2aResult *res, void *stream);
 
+/* SSE-compatible mode (ksw2_lane_ssec.h): ksw_extz2_sse / ksw_extd2_sse as the reference's SSE kernels return them.  One
+ * alignment per wavefront; pairs[i].bnd_off = offset of its state arrays in `scratch` in 16-byte units ((5 or 7) + 4 bytes per
+ * 16-padded target position), tb_off = its direction matrix ((qlen + tlen - 1) * k2a_ssec_ncol bytes), pad = K2A_SSEC_* bits,
+ * tlen = tlen_full, w = the band resolved as in ksw2_extz2_sse.c:72. */
+int k2a_shim_launch_ssec(int dual, int mode, const K2aSsec *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
+                         uint8_t *tb, uint8_t *scratch, K2aResult *res, void *stream);
+int k2a_shim_launch_ssec_trace(const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb, K2aResult *res, uint32_t *cig, void *stream);
+
 /* Compaction: pool[pos[i] .. pos[i]+res[i].n_cigar) = cig[pairs[i].cig_off ..) for the n pairs of a plan
  * (pos = exclusive prefix sum of n_cigar, computed by the host), so that one D2H brings every CIGAR back. */
 int k2a_shim_launch_compact(const K2aPair *pairs, const K2aResult *res, const uint32_t *pos, int n, const uint32_t *cig,

@@ -16,6 +16,7 @@
 #include "ksw2_lane_solo.h"
 #include "ksw2_lane_dm.h"
 #include "ksw2_lane_extf.h"
+#include "ksw2_lane_ssec.h"
 
 #define K2A_WPB 4          /* wavefronts per workgroup; waves never synchronise with each other */
 /* The traceback walk is a chain of dependent loads and a few dozen instructions per step on ONE lane; what it needs is many
@@ -847,6 +848,147 @@ k2a_exts_trace_kernel(const K2aSplice sp, const K2aPair *__restrict__ pairs, con
 	res[pi].n_cigar = n;
 }
 
+/* ---------------------------------------------------------------- SSE-compatible mode (ksw2_lane_ssec.h) */
+
+/* One alignment per wavefront, lane <-> target position, one step per anti-diagonal; the reference's byte arrays u v x y
+ * [x~ y~] s and its int32 H live in `scratch` (16 * pairs[i].bnd_off bytes in; (5 or 7) + 4 bytes per padded target position,
+ * L2-resident).  Positions move between lanes from one anti-diagonal to the next and the phases of an anti-diagonal read what
+ * other lanes wrote in the phase before, so workgroup-scope release / acquire pairs separate them (writer and reader are
+ * lanes of one wavefront; the CU's L1 is write-through). */
+#define K2A_SSEC_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+template<bool DUAL, int MODE>
+__global__ void __launch_bounds__(64 * K2A_WPB)
+k2a_ssec_kernel(const K2aSsec P, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
+                const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, uint8_t *scratch, K2aResult *__restrict__ res)
+{
+	const int lane = threadIdx.x & 63, wave = k2a_wave_id<true>();
+	const int task = blockIdx.x * K2A_WPB + wave;
+	if (task >= ntasks) return;                       /* whole wavefronts leave; nobody synchronises below */
+	const uint32_t pi = order[task];
+	const K2aPair pr = pairs[pi];
+	const int qlen = pr.qlen, tlen = pr.tlen_full, w = pr.w, T16 = (tlen + 15) / 16 * 16, ncol = k2a_ssec_ncol(qlen, tlen, w);
+	const bool approx = (pr.pad & K2A_SSEC_APPROX) != 0, adrop = (pr.pad & K2A_SSEC_APPROX_DROP) != 0, generic = (pr.pad & K2A_SSEC_GENERIC) != 0;
+	const uint8_t *qry = seq + pr.qoff, *tgt = seq + pr.toff;
+	uint8_t *tbp = tb + pr.tb_off;
+	uint8_t *U = scratch + (size_t)pr.bnd_off * 16, *V = U + T16, *X = V + T16, *Y = X + T16;
+	uint8_t *X2 = DUAL ? Y + T16 : Y, *Y2 = DUAL ? X2 + T16 : Y, *S = (DUAL ? Y2 : Y) + T16;
+	int32_t *H = (int32_t*)(S + T16);
+	const int slope = DUAL ? P.e2 : P.e;
+
+	/* the reference's allocation: zeros (ksw2_extz2_sse.c:84) or the gap-open differences (ksw2_extd2_sse.c:111-116), H = -inf */
+	for (int x = lane; x < T16; x += 64) {
+		const uint8_t g1 = DUAL ? (uint8_t)(-P.q - P.e) : 0, g2 = (uint8_t)(-P.q2 - P.e2);
+		U[x] = g1; V[x] = g1; X[x] = g1; Y[x] = g1; S[x] = 0;
+		if (DUAL) { X2[x] = g2; Y2[x] = g2; }
+		H[x] = K2A_NEG;
+	}
+	K2A_SSEC_SYNC();
+
+	K2aBook book;
+	k2a_book_reset(&book);
+	K2aSsecFollow fol = { 0, 0 };
+	int last_st = -1, last_en = -1;
+	for (int r = 0; r < qlen + tlen - 1; ++r) {
+		int st0, en0, st, en;
+		if (!k2a_ssec_bounds(r, qlen, tlen, w, st0, en0, st, en)) { book.dropped = 1; break; }      /* ksw2_extz2_sse.c:111-114 */
+		/* what the first position of the blocks reads to its left (uniform loads), the first-column cell */
+		int cx, cv, cx2 = 0;
+		const bool prev_ok = st > 0 && st - 1 >= last_st && st - 1 <= last_en;
+		if (!DUAL) {
+			cx = prev_ok ? k2a_s8(__builtin_amdgcn_readfirstlane((int)X[st - 1])) : 0;
+			cv = st > 0 ? (prev_ok ? k2a_s8(__builtin_amdgcn_readfirstlane((int)V[st - 1])) : 0) : (r ? P.q : 0);
+			if (en >= r && lane == 0) { Y[r] = 0; U[r] = (uint8_t)(r ? P.q : 0); }
+		} else {
+			const int edge = k2a_ssec_edge(P, r);
+			cx = prev_ok ? k2a_s8(__builtin_amdgcn_readfirstlane((int)X[st - 1])) : -P.q - P.e;
+			cx2 = prev_ok ? k2a_s8(__builtin_amdgcn_readfirstlane((int)X2[st - 1])) : -P.q2 - P.e2;
+			cv = st > 0 ? (prev_ok ? k2a_s8(__builtin_amdgcn_readfirstlane((int)V[st - 1])) : -P.q - P.e) : edge;
+			if (en >= r && lane == 0) { Y[r] = (uint8_t)(-P.q - P.e); Y2[r] = (uint8_t)(-P.q2 - P.e2); U[r] = (uint8_t)edge; }
+		}
+		/* scores in runs of 16 from st0 (:125-140); bytes past the padded target length would land in the reference's target copy
+		 * at positions no later anti-diagonal reads (below st0), so they are dropped */
+		{
+			const int pend = generic ? en0 + 1 : st0 + ((en0 - st0) / 16 + 1) * 16;
+			for (int p = st0 + lane; p < pend; p += 64)
+				if (p < T16) S[p] = (uint8_t)k2a_ssec_score(P, generic, k2a_ssec_tcode(tgt, qry, tlen, qlen, T16, p), k2a_ssec_qcode(qry, r, p));
+		}
+		K2A_SSEC_SYNC();
+		for (int base = st; base <= en; base += 64) {
+			const int p = base + lane;
+			const bool act = p <= en;
+			int xo = 0, vo = 0, x2o = 0, uo = 0, yo = 0, y2o = 0, so = 0;
+			if (act) { xo = k2a_s8(X[p]); vo = k2a_s8(V[p]); uo = k2a_s8(U[p]); yo = k2a_s8(Y[p]); so = k2a_s8(S[p]); if (DUAL) { x2o = k2a_s8(X2[p]); y2o = k2a_s8(Y2[p]); } }
+			const int xt1 = k2a_shr1_carry(xo, cx), vt1 = k2a_shr1_carry(vo, cv), x2t1 = DUAL ? k2a_shr1_carry(x2o, cx2) : 0;
+			cx = __builtin_amdgcn_readlane(xo, 63); cv = __builtin_amdgcn_readlane(vo, 63);
+			if (DUAL) cx2 = __builtin_amdgcn_readlane(x2o, 63);
+			int un, vn, xn, yn, x2n, y2n;
+			uint32_t dir;
+			k2a_ssec_cell<DUAL, MODE>(P, so, xt1, vt1, x2t1, uo, yo, y2o, un, vn, xn, yn, x2n, y2n, dir);
+			if (act) {
+				U[p] = (uint8_t)un; V[p] = (uint8_t)vn; X[p] = (uint8_t)xn; Y[p] = (uint8_t)yn;
+				if (DUAL) { X2[p] = (uint8_t)x2n; Y2[p] = (uint8_t)y2n; }
+				if (MODE != K2A_MODE_SCORE) tbp[(size_t)r * ncol + (p - st)] = (uint8_t)dir;
+			}
+		}
+		K2A_SSEC_SYNC();
+		int stop;
+		if (!approx) {
+			int A, Sv, T0 = K2A_NEG, T1 = K2A_NEG, T2 = K2A_NEG, bH = K2A_NEG, bT = -1;
+			const int en1 = st0 + (en0 - st0) / 4 * 4;
+			if (r > 0) {
+				/* H of the last in-band position first, from its neighbour's value of the previous anti-diagonal (:229) */
+				const int hprev = __builtin_amdgcn_readfirstlane(en0 > 0 ? H[en0 - 1] : H[en0]);
+				const int dl = __builtin_amdgcn_readfirstlane((int)(en0 > 0 ? U[en0] : V[en0]));
+				A = hprev + k2a_ssec_dh<DUAL>(P, dl);
+				Sv = A;
+				for (int t0 = st0; t0 < en0; t0 += 64) {
+					const int t = t0 + lane;
+					int h = K2A_NEG;
+					if (t < en0) {
+						h = H[t] + k2a_ssec_dh<DUAL>(P, (int)V[t]);
+						H[t] = h;
+						if (t < en1 && h > bH) { bH = h; bT = t; }
+					}
+					if (t0 == st0) Sv = __builtin_amdgcn_readlane(h, 0);
+					if (en1 < en0 && en1 >= t0 && en1 < t0 + 64) T0 = __builtin_amdgcn_readlane(h, (en1 - t0) & 63);
+					if (en1 + 1 < en0 && en1 + 1 >= t0 && en1 + 1 < t0 + 64) T1 = __builtin_amdgcn_readlane(h, (en1 + 1 - t0) & 63);
+					if (en1 + 2 < en0 && en1 + 2 >= t0 && en1 + 2 < t0 + 64) T2 = __builtin_amdgcn_readlane(h, (en1 + 2 - t0) & 63);
+				}
+				if (lane == 0) H[en0] = A;
+			} else {
+				A = Sv = k2a_ssec_dh<DUAL>(P, __builtin_amdgcn_readfirstlane((int)V[0])) - (DUAL ? P.qe_first : P.q + P.e);
+				if (lane == 0) H[0] = A;
+			}
+			const uint64_t Bkey = k2a_wave_max_u64(bT >= 0 ? k2a_dm_key(bH, bT, st0) : 0ull);
+			stop = k2a_ssec_book(&book, r, st0, en0, en, qlen, tlen, pr.zdrop, slope, A, Bkey, T0, T1, T2, Sv);
+		} else {
+			const int l0 = min(max(fol.last, 0), T16 - 1), l1 = min(max(fol.last + 1, 0), T16 - 1);
+			const int vl = __builtin_amdgcn_readfirstlane((int)V[l0]), un = __builtin_amdgcn_readfirstlane((int)U[l1]);
+			const int v0 = __builtin_amdgcn_readfirstlane((int)V[0]);
+			stop = k2a_ssec_follow<DUAL>(P, fol, &book, r, st0, en0, qlen, tlen, pr.zdrop, adrop, vl, un, v0);
+		}
+		K2A_SSEC_SYNC();
+		if (stop) break;
+		last_st = st; last_en = en;
+	}
+	if (lane == 0) k2a_finish(pr, book, &res[pi]);
+}
+
+__global__ void __launch_bounds__(64)
+k2a_ssec_trace_kernel(const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
+                      const uint8_t *__restrict__ tb, K2aResult *__restrict__ res, uint32_t *__restrict__ cig, int ppw)
+{
+	if ((int)threadIdx.x >= ppw) return;
+	const int t = blockIdx.x * ppw + threadIdx.x;
+	if (t >= ntasks) return;
+	const uint32_t pi = order[t];
+	const K2aPair pr = pairs[pi];
+	const int ti = res[pi].ti, tj = res[pi].tj;
+	int n = 0;
+	if (ti >= 0 && tj >= 0) n = k2a_ssec_trace(tb + pr.tb_off, k2a_ssec_ncol(pr.qlen, pr.tlen_full, pr.w), ti, tj, cig + pr.cig_off, pr.qlen, pr.tlen_full, pr.w);
+	res[pi].n_cigar = n;
+}
+
 /* ---------------------------------------------------------------- gap-linear X-drop extension (ksw2_lane_extf.h) */
 
 /* One alignment per wavefront (one wavefront per workgroup: the LDS a workgroup asks for decides how many share a CU).
@@ -1190,6 +1332,29 @@ int k2a_shim_launch_exts_trace(const K2aSplice *sp, const K2aPair *pairs, const 
 	const int ppw = k2a_trace_ppw(ntasks);
 	hipLaunchKernelGGL(k2a_exts_trace_kernel, dim3((ntasks + ppw - 1) / ppw), dim3(64), 0, (hipStream_t)stream,
 	                   *sp, pairs, order, ntasks, tb, res, cig, ppw);
+	CHECK(hipGetLastError());
+	return 0;
+}
+
+typedef void (*ssec_fn)(const K2aSsec, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, uint8_t*, K2aResult*);
+static const ssec_fn g_ssec[2][3] = { { k2a_ssec_kernel<false, 0>, k2a_ssec_kernel<false, 1>, k2a_ssec_kernel<false, 2> },
+                                      { k2a_ssec_kernel<true, 0>,  k2a_ssec_kernel<true, 1>,  k2a_ssec_kernel<true, 2> } };
+
+int k2a_shim_launch_ssec(int dual, int mode, const K2aSsec *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
+                         uint8_t *tb, uint8_t *scratch, K2aResult *res, void *stream)
+{
+	if (ntasks <= 0) return 0;
+	hipLaunchKernelGGL(g_ssec[dual ? 1 : 0][mode], dim3((ntasks + K2A_WPB - 1) / K2A_WPB), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
+	                   *par, pairs, order, ntasks, seq, tb, scratch, res);
+	CHECK(hipGetLastError());
+	return 0;
+}
+
+int k2a_shim_launch_ssec_trace(const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb, K2aResult *res, uint32_t *cig, void *stream)
+{
+	if (ntasks <= 0) return 0;
+	const int ppw = k2a_trace_ppw(ntasks);
+	hipLaunchKernelGGL(k2a_ssec_trace_kernel, dim3((ntasks + ppw - 1) / ppw), dim3(64), 0, (hipStream_t)stream, pairs, order, ntasks, tb, res, cig, ppw);
 	CHECK(hipGetLastError());
 	return 0;
 }

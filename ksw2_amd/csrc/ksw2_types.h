@@ -55,6 +55,18 @@ typedef struct K2aExtf {
 	int32_t mch, mis, e;         /* mis <= 0 (ksw2_extf2_sse.c:20) */
 } K2aExtf;
 
+/* batch-uniform parameters of the SSE-compatible mode (ksw2_lane_ssec.h), passed by value */
+typedef struct K2aSsec {
+	int32_t q, e, q2, e2;            /* extd2: pieces already ordered q + e <= q2 + e2 (ksw2_extd2_sse.c:78) */
+	int32_t qe_first;                /* extd2's scalar q + e from BEFORE that swap, used for the very first cell only (:67,:353,:377) */
+	int32_t long_thres, long_diff;   /* ksw2_extd2_sse.c:102-105 */
+	int32_t m, sc_mch, sc_mis, sc_N; /* residue types; match / mismatch / wildcard score of the simple scoring (:66-69 / :85-88) */
+	const int8_t *mat;               /* KSW_EZ_GENERIC_SC: device copy of the caller's matrix, mat[target * m + query] */
+} K2aSsec;
+#define K2A_SSEC_APPROX      1       /* bits of K2aPair.pad in that mode: KSW_EZ_APPROX_MAX ... */
+#define K2A_SSEC_APPROX_DROP 2       /* ... with KSW_EZ_APPROX_DROP */
+#define K2A_SSEC_GENERIC     4       /* KSW_EZ_GENERIC_SC */
+
 /* widest band (positions on one anti-diagonal) the K-slot register window of the X-drop kernel holds */
 #define K2A_EXTF_WIN_SPAN(K) (64 * (K) - 109)
 

@@ -17,6 +17,7 @@
 #include "../../ksw2_amd/csrc/ksw2_lane_solo.h"
 #include "../../ksw2_amd/csrc/ksw2_lane_extf.h"
 #include "../../ksw2_amd/csrc/ksw2_lane_pk.h"
+#include "../../ksw2_amd/csrc/ksw2_lane_ssec.h"
 
 static thread_local char g_err[256] = "";
 
@@ -506,6 +507,106 @@ static void sim_exts_trace(const K2aSplice sp, const K2aPair *pairs, const uint3
 
 
 
+/* mirrors k2a_ssec_kernel: one alignment per "wavefront", 64 positions per pass, the reference's byte arrays in `scratch` */
+template<bool DUAL, int MODE>
+static void sim_ssec(const K2aSsec P, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, uint8_t *tb, uint8_t *scratch,
+                     K2aResult *res)
+{
+	for (int task = 0; task < ntasks; ++task) {
+		const uint32_t pi = order[task];
+		const K2aPair pr = pairs[pi];
+		const int qlen = pr.qlen, tlen = pr.tlen_full, w = pr.w, T16 = (tlen + 15) / 16 * 16, ncol = k2a_ssec_ncol(qlen, tlen, w);
+		const bool approx = (pr.pad & K2A_SSEC_APPROX) != 0, adrop = (pr.pad & K2A_SSEC_APPROX_DROP) != 0, generic = (pr.pad & K2A_SSEC_GENERIC) != 0;
+		const uint8_t *qry = seq + pr.qoff, *tgt = seq + pr.toff;
+		uint8_t *tbp = tb + pr.tb_off;
+		uint8_t *U = scratch + (size_t)pr.bnd_off * 16, *V = U + T16, *X = V + T16, *Y = X + T16;
+		uint8_t *X2 = DUAL ? Y + T16 : Y, *Y2 = DUAL ? X2 + T16 : Y, *S = (DUAL ? Y2 : Y) + T16;
+		int32_t *H = (int32_t*)(S + T16);
+		const int slope = DUAL ? P.e2 : P.e;
+		for (int x = 0; x < T16; ++x) {
+			const uint8_t g1 = DUAL ? (uint8_t)(-P.q - P.e) : 0, g2 = (uint8_t)(-P.q2 - P.e2);
+			U[x] = g1; V[x] = g1; X[x] = g1; Y[x] = g1; S[x] = 0;
+			if (DUAL) { X2[x] = g2; Y2[x] = g2; }
+			H[x] = K2A_NEG;
+		}
+		K2aBook book;
+		k2a_book_reset(&book);
+		K2aSsecFollow fol = { 0, 0 };
+		int last_st = -1, last_en = -1;
+		for (int r = 0; r < qlen + tlen - 1; ++r) {
+			int st0, en0, st, en;
+			if (!k2a_ssec_bounds(r, qlen, tlen, w, st0, en0, st, en)) { book.dropped = 1; break; }
+			int cx, cv, cx2 = 0;
+			const bool prev_ok = st > 0 && st - 1 >= last_st && st - 1 <= last_en;
+			if (!DUAL) {
+				cx = prev_ok ? k2a_s8(X[st - 1]) : 0;
+				cv = st > 0 ? (prev_ok ? k2a_s8(V[st - 1]) : 0) : (r ? P.q : 0);
+				if (en >= r) { Y[r] = 0; U[r] = (uint8_t)(r ? P.q : 0); }
+			} else {
+				const int edge = k2a_ssec_edge(P, r);
+				cx = prev_ok ? k2a_s8(X[st - 1]) : -P.q - P.e;
+				cx2 = prev_ok ? k2a_s8(X2[st - 1]) : -P.q2 - P.e2;
+				cv = st > 0 ? (prev_ok ? k2a_s8(V[st - 1]) : -P.q - P.e) : edge;
+				if (en >= r) { Y[r] = (uint8_t)(-P.q - P.e); Y2[r] = (uint8_t)(-P.q2 - P.e2); U[r] = (uint8_t)edge; }
+			}
+			const int pend = generic ? en0 + 1 : st0 + ((en0 - st0) / 16 + 1) * 16;
+			for (int p = st0; p < pend; ++p)
+				if (p < T16) S[p] = (uint8_t)k2a_ssec_score(P, generic, k2a_ssec_tcode(tgt, qry, tlen, qlen, T16, p), k2a_ssec_qcode(qry, r, p));
+			for (int base = st; base <= en; base += 64) {
+				int xo[64], vo[64], x2o[64], uo[64], yo[64], y2o[64], so[64];
+				for (int l = 0; l < 64; ++l) {
+					const int p = base + l;
+					xo[l] = vo[l] = x2o[l] = uo[l] = yo[l] = y2o[l] = so[l] = 0;
+					if (p <= en) { xo[l] = k2a_s8(X[p]); vo[l] = k2a_s8(V[p]); uo[l] = k2a_s8(U[p]); yo[l] = k2a_s8(Y[p]); so[l] = k2a_s8(S[p]); if (DUAL) { x2o[l] = k2a_s8(X2[p]); y2o[l] = k2a_s8(Y2[p]); } }
+				}
+				for (int l = 0; l < 64; ++l) {
+					const int p = base + l;
+					const int xt1 = l ? xo[l - 1] : cx, vt1 = l ? vo[l - 1] : cv, x2t1 = DUAL ? (l ? x2o[l - 1] : cx2) : 0;
+					int un, vn, xn, yn, x2n, y2n;
+					uint32_t dir;
+					k2a_ssec_cell<DUAL, MODE>(P, so[l], xt1, vt1, x2t1, uo[l], yo[l], y2o[l], un, vn, xn, yn, x2n, y2n, dir);
+					if (p <= en) {
+						U[p] = (uint8_t)un; V[p] = (uint8_t)vn; X[p] = (uint8_t)xn; Y[p] = (uint8_t)yn;
+						if (DUAL) { X2[p] = (uint8_t)x2n; Y2[p] = (uint8_t)y2n; }
+						if (MODE != K2A_MODE_SCORE) tbp[(size_t)r * ncol + (p - st)] = (uint8_t)dir;
+					}
+				}
+				cx = xo[63]; cv = vo[63]; cx2 = x2o[63];
+			}
+			int stop;
+			if (!approx) {
+				int A, Sv, T[3] = { K2A_NEG, K2A_NEG, K2A_NEG };
+				const int en1 = st0 + (en0 - st0) / 4 * 4;
+				uint64_t Bkey = 0;
+				if (r > 0) {
+					const int hprev = en0 > 0 ? H[en0 - 1] : H[en0];
+					A = hprev + k2a_ssec_dh<DUAL>(P, en0 > 0 ? U[en0] : V[en0]);
+					Sv = A;
+					int bH[64], bT[64];
+					for (int l = 0; l < 64; ++l) { bH[l] = K2A_NEG; bT[l] = -1; }
+					for (int t = st0; t < en0; ++t) {
+						const int h = H[t] + k2a_ssec_dh<DUAL>(P, V[t]), l = (t - st0) & 63;
+						H[t] = h;
+						if (t < en1 && h > bH[l]) { bH[l] = h; bT[l] = t; }
+						if (t == st0) Sv = h;
+						if (t >= en1) T[t - en1] = h;
+					}
+					H[en0] = A;
+					for (int l = 0; l < 64; ++l)
+						if (bT[l] >= 0) { const uint64_t k = k2a_dm_key(bH[l], bT[l], st0); if (k > Bkey) Bkey = k; }
+				} else { A = Sv = k2a_ssec_dh<DUAL>(P, V[0]) - (DUAL ? P.qe_first : P.q + P.e); H[0] = A; }
+				stop = k2a_ssec_book(&book, r, st0, en0, en, qlen, tlen, pr.zdrop, slope, A, Bkey, T[0], T[1], T[2], Sv);
+			} else {
+				const int l0 = k2a_min(k2a_max(fol.last, 0), T16 - 1), l1 = k2a_min(k2a_max(fol.last + 1, 0), T16 - 1);
+				stop = k2a_ssec_follow<DUAL>(P, fol, &book, r, st0, en0, qlen, tlen, pr.zdrop, adrop, V[l0], U[l1], V[0]);
+			}
+			if (stop) break;
+			last_st = st; last_en = en;
+		}
+		k2a_finish(pr, book, &res[pi]);
+	}
+}
+
 /* mirrors k2a_fill_solo_kernel: one alignment per wavefront, both halves of every lane */
 template<int C, bool DUAL, int MODE>
 static void sim_fill_solo(const K2aScoring sc, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, uint8_t *tb,
@@ -776,6 +877,23 @@ int k2a_shim_launch_exts_trace(const K2aSplice *sp, const K2aPair *pairs, const 
 }
 
 
+int k2a_shim_launch_ssec(int dual, int mode, const K2aSsec *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
+                         uint8_t *tb, uint8_t *scratch, K2aResult *res, void *)
+{
+	typedef void (*fn)(const K2aSsec, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, uint8_t*, K2aResult*);
+	static const fn f[2][3] = { { sim_ssec<false, 0>, sim_ssec<false, 1>, sim_ssec<false, 2> }, { sim_ssec<true, 0>, sim_ssec<true, 1>, sim_ssec<true, 2> } };
+	f[dual ? 1 : 0][mode](*par, pairs, order, ntasks, seq, tb, scratch, res);
+	return 0;
+}
+int k2a_shim_launch_ssec_trace(const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb, K2aResult *res, uint32_t *cig, void *)
+{
+	for (int t = 0; t < ntasks; ++t) {
+		const K2aPair pr = pairs[order[t]];
+		K2aResult &r = res[order[t]];
+		r.n_cigar = r.ti >= 0 && r.tj >= 0 ? k2a_ssec_trace(tb + pr.tb_off, k2a_ssec_ncol(pr.qlen, pr.tlen_full, pr.w), r.ti, r.tj, cig + pr.cig_off, pr.qlen, pr.tlen_full, pr.w) : 0;
+	}
+	return 0;
+}
 int k2a_shim_launch_fill_solo(int dual, int mode, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order, int ntasks,
                               const uint8_t *seq, uint8_t *tb, K2aResult *res, void *)
 {

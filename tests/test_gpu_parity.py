@@ -800,3 +800,13 @@ def test_unchanged_threaded_caller_is_coalesced(cigar):
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["mismatches"] == 0 and d["calls"] == 64 * 300
     assert d["coalesced_calls"] > d["coalesced_batches"] > 0
+
+
+def test_sse_compatible_mode(lib):
+    """The opt-in SSE-compatible mode on the GPU (k2a_ssec_kernel): all 1500 golden cases of the unmodified ksw_extz2_sse /
+    ksw_extd2_sse -- narrow bands whose blocks leak, anti-diagonal Z-drop, padded mte_q, KSW_EZ_APPROX_MAX with and without
+    APPROX_DROP, swapped gap pieces -- every field and the CIGAR; mixed batches; the process-wide switch; long banded reads."""
+    from tests import sse_compat_util as su
+    assert su.check_golden(lib) >= 1500
+    su.check_routing(lib)
+    su.check_long(lib, n=6, length=6000, w=150)

@@ -522,3 +522,12 @@ def test_sim_fuzz_script_runs(sim):
     env["KSW2AMD_FUZZ_LIB"] = os.path.join(SIM_DIR, "libksw2_amd_sim.so")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "scripts", "fuzz_gpu.py"), "8", "7"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_sim_sse_compatible_mode(sim):
+    """ksw_extz2_sse / ksw_extd2_sse as the reference's SSE kernels return them (opt-in; ksw2_lane_ssec.h): a third of the golden
+    cases of the unmodified reference, the routing of mixed batches and of the process-wide switch, longer banded reads."""
+    from tests import sse_compat_util as su
+    assert su.check_golden(sim, step=3) >= 500
+    su.check_routing(sim)
+    su.check_long(sim, n=3, length=1500, w=60)
