@@ -464,7 +464,8 @@ def main():
             continue
         try:
             j = Job(lib, name, WORKLOADS[name], rank)
-            j.e2e_step()                                         # warm-up: buffers, streams, worker threads
+            j.e2e_step()                                         # warm-up: buffers, streams, worker threads (every worker's first
+            j.e2e_step()                                         # chunk allocates its device buffers)
             t0 = time.perf_counter()
             k = 0
             while k < 3 or time.perf_counter() - t0 < 1.5:

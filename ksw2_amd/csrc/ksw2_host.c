@@ -238,7 +238,8 @@ static size_t mp_total_steps(int G, int C, int qlen, int tlen, int w)
 	for (g = 0; g < ngen; ++g) {
 		const int lo = imax(0, g * R - w), hi = imin(qlen - 1, imin(g * R + R - 1, tlen - 1) + w);
 		const int nl = imin(G, (tlen - g * R + C - 1) / C);
-		if (hi >= lo) tot += (size_t)(hi - lo + 1) + (size_t)(nl - 1);
+		if (hi >= lo) tot += ((size_t)(hi - lo + 1) + (size_t)(nl - 1) + 7) & ~(size_t)7;      /* k2a_gen_pad */
+		(void)0;
 	}
 	return tot;
 }
@@ -345,6 +346,17 @@ static int pk_window_ok(const pkinfo_t *k, int qlen, int tlen, int w, int C)
 	return ((int64_t)2 * w + 2 * C + 2) * D + 2 * k->qemax + (int64_t)4 * C * D + 64 <= 12000;
 }
 
+/* Packed generation-serial class (ksw2_lane_pkmp.h): the base slides, so the read length does not matter; what must fit between
+ * the -inf sentinel's guard band (K2A_PKMP_DEAD = -8192) and +16383 is what a lane holds at one column (C rows) plus the drift
+ * of K2A_PKMP_T steps until the next re-base, each unit step changing H by at most D (as in pk_window_ok), E / F up to
+ * qemax + D below their H. */
+static int pk_slide_ok(const pkinfo_t *k, int qlen, int tlen)
+{
+	const int64_t D = imax(imax(k->smax, 0) + k->qemin, -k->smin) + k->e;
+	if (k->ok <= 0 || qlen > 65000 || tlen > 65000) return 0;
+	return (64 + 2 * 16 + 4) * D + 2 * k->qemax + 64 <= 6000;
+}
+
 /* copy a sequence into the staging arena and report whether it holds a residue code >= 4 (the wildcard of a 5-letter
  * alphabet): one pass over the bytes instead of a scan plus a memcpy */
 static int copy_scan(uint8_t *dst, const uint8_t *src, int n)
@@ -400,6 +412,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	const char *solo_env = getenv("KSW2AMD_SOLO");
 	const int solo_mode = !solo_env ? 3 : !strcmp(solo_env, "0") ? 0 : !strcmp(solo_env, "all") ? 2 : 1;
 	const int use_pk = !getenv("KSW2AMD_NO_PK"), use_rb = !getenv("KSW2AMD_NO_RB");
+	const int use_pkmp = !getenv("KSW2AMD_NO_PKMP");                          /* A/B runs and tests: wide bands through the int32 generation-serial kernels */
 	const int pk_first = getenv("KSW2AMD_PK_FIRST") ? atoi(getenv("KSW2AMD_PK_FIRST")) : 0;   /* A/B runs: skip the smaller packed geometries */
 
 	g_err[0] = 0;
@@ -485,10 +498,12 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 			const int plain = pk_eligible(&pkinfo[generic], a->qlen, d->tlen, w);
 			int pc;
 			/* (8 lanes x 18 rows) needs every register with traceback on: score-only pairs only */
-			for (pc = imax(mode == K2A_MODE_SCORE ? 0 : 1, pk_first); pc < K2A_NPKCFG; ++pc)
+			for (pc = imax(mode == K2A_MODE_SCORE ? 0 : 1, pk_first); pc < K2A_PKCFG_MP; ++pc)
 				if (geom_fits(k2a_pkcfg_G[pc], k2a_pkcfg_C[pc], d->tlen, w) &&
 				    (plain || (use_rb && pk_window_ok(&pkinfo[generic], a->qlen, d->tlen, w, k2a_pkcfg_C[pc])))) break;
-			if (pc < K2A_NPKCFG) pk_ok[i] = (uint8_t)(1 + pc + (plain ? 0 : K2A_NPKCFG) + (is_approx(fl) ? 2 * K2A_NPKCFG : 0));
+			/* no resident geometry holds the band: the packed generation-serial class (sliding base), exact modes only */
+			if (pc == K2A_PKCFG_MP && !(cfg == K2A_CFG_MP && use_rb && use_pkmp && !is_approx(fl) && pk_slide_ok(&pkinfo[generic], a->qlen, d->tlen))) pc = K2A_NPKCFG;
+			if (pc < K2A_NPKCFG) pk_ok[i] = (uint8_t)(1 + pc + ((plain && pc != K2A_PKCFG_MP) ? 0 : K2A_NPKCFG) + (is_approx(fl) ? 2 * K2A_NPKCFG : 0));
 			/* solo kernel: 2 * K2A_SOLO_C rows per lane share one base; a lane must finish a double strip before its next one starts */
 			if (solo_mode && !is_approx(fl) && pk_window_ok(&pkinfo[generic], a->qlen, d->tlen, w, 2 * K2A_SOLO_C) &&
 			    ((d->tlen + 2 * K2A_SOLO_C - 1) / (2 * K2A_SOLO_C) <= 64 || w < 64 * (K2A_SOLO_C + 1) - K2A_SOLO_C)) {
@@ -545,8 +560,8 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 			for (i = 0; i < n; ++i) if (p->h_cls[i] >= 0 && pk_ok[i] && pk_ok[i] != PASS_SOLO) ++cnt[p->h_cls[i] * NPASS + pk_ok[i]];
 			for (b = 0; b < NCLS_MAX * NPASS; ++b)
 				if (cnt[b]) {
-					const int G = k2a_pkcfg_G[(b % NPASS - 1) % K2A_NPKCFG];
-					const int64_t waves = ((int64_t)(cnt[b] + 1) / 2 * G + 63) / 64;
+					const int pcb = (b % NPASS - 1) % K2A_NPKCFG, G = k2a_pkcfg_G[pcb];
+					const int64_t waves = ((int64_t)(cnt[b] + 1) / 2 * G + 63) / 64 * (pcb == K2A_PKCFG_MP ? 4 : 1);     /* that class: four wavefronts per task */
 					/* one-alignment-per-wavefront classes only: for the short shapes of the multi-group geometries the gain is a
 					 * fraction of a millisecond per call and costs 2-3 x the SIMD time, which concurrent callers would rather keep */
 					cnt[b] = G == 64 && waves * 10 < (int64_t)simds * 6;        /* 1 = demote */
@@ -631,6 +646,19 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 		free(srt); srt = 0;
 	}
 
+	/* packed generation-serial tasks: boundary entries + the four wavefronts' row-maximum keys (ksw2_shim.h), shared by the two alignments */
+	for (k = 0; k < p->ncls; ++k) {
+		const cls_t *c = &p->cls[k];
+		if (!c->pk || c->cfg != K2A_PKCFG_MP) continue;
+		for (i = 0; i < c->count; ++i) {
+			K2aPair *da = &p->h_pairs[p->h_order[c->first + 2 * i]], *db = &p->h_pairs[p->h_order[c->first + 2 * i + 1]];
+			p->bnd_words = align_up(p->bnd_words, 4);
+			da->bnd_off = db->bnd_off = (uint32_t)p->bnd_words;
+			p->bnd_words += align_up((size_t)da->qlen * (dual ? 5 : 4) + 16, 4) + 4 * (size_t)(64 * 16 * 2 * 2);      /* K2A_PKMP_BND_WORDS + 4 x K2A_PKMP_SPILL_WORDS(16) */
+			if (p->bnd_words > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "plan_create: boundary rows over 16 GiB in one plan%s", 0); goto err; }
+		}
+	}
+
 	/* pass 3: traceback blocks (one per task: the two alignments of a packed task share theirs) and CIGAR scratch */
 	for (k = 0; k < p->ncls; ++k) {
 		const cls_t *c = &p->cls[k];
@@ -643,7 +671,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 			const int nstrips = (da->tlen + C - 1) / C;
 			size_t steps = (size_t)(nstrips - 1) + (size_t)imin(da->qlen - 1, da->tlen - 1 + da->w) + 1;
 			const size_t wb = c->pk ? 2 * (size_t)C : (size_t)C * (dual ? 8 : 4) / 8;
-			if (!c->pk && !c->solo && c->cfg == K2A_CFG_MP) steps = mp_total_steps(G, C, da->qlen, da->tlen, da->w);
+			if (!c->solo && (c->pk ? c->cfg == K2A_PKCFG_MP : c->cfg == K2A_CFG_MP)) steps = mp_total_steps(G, C, da->qlen, da->tlen, da->w);
 			da->tb_off = db->tb_off = p->tb_bytes;
 			if (c->solo) {        /* k2a_solo_steps: 2 * (double strips - 1) + 2 + last column; 64 lanes x 2 * K2A_SOLO_C bytes per step */
 				const int nds = (da->tlen + 2 * K2A_SOLO_C - 1) / (2 * K2A_SOLO_C);
@@ -730,7 +758,9 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 				if (k->mode != K2A_MODE_SCORE &&
 				    k2a_shim_launch_trace_solo(p->d_pairs, p->d_order + k->first, k->count, p->d_tb, p->d_res, p->d_cig, s)) goto err;
 			} else if (k->pk) {
-				if (k2a_shim_launch_fill_pk(k->cfg, p->dual, k->mode, k->rb, k->nomax, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq,
+				if (k->cfg == K2A_PKCFG_MP ? k2a_shim_launch_fill_pkmp(p->dual, k->mode, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
+				                                                     (uint32_t*)p->d_bnd, p->d_res, s)
+				    : k2a_shim_launch_fill_pk(k->cfg, p->dual, k->mode, k->rb, k->nomax, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq,
 				                            p->d_tb, p->d_res, s)) goto err;
 				if (k->mode != K2A_MODE_SCORE &&
 				    k2a_shim_launch_trace_pk(k->cfg, p->d_pairs, p->d_order + k->first, k->count, p->d_tb, p->d_res, p->d_cig, s)) goto err;
@@ -753,7 +783,9 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 		if (k->solo) {
 			if (k2a_shim_launch_fill_solo(p->dual, k->mode, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb, p->d_res, stream)) goto err;
 		} else if (k->pk) {
-			if (k2a_shim_launch_fill_pk(k->cfg, p->dual, k->mode, k->rb, k->nomax, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
+			if (k->cfg == K2A_PKCFG_MP ? k2a_shim_launch_fill_pkmp(p->dual, k->mode, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
+			                                                     (uint32_t*)p->d_bnd, p->d_res, stream)
+			    : k2a_shim_launch_fill_pk(k->cfg, p->dual, k->mode, k->rb, k->nomax, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
 			                            p->d_res, stream)) goto err;
 		} else if (k2a_shim_launch_fill(k->cfg, p->dual, k->mode, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
 		                                p->d_bnd, p->d_res, stream)) goto err;
@@ -946,7 +978,7 @@ static size_t pair_device_bytes(int dual, const ksw2amd_pair_t *a)
 		if (w <= 1040 || a->tlen <= 2048)
 			b += steps * 64 * (dual ? 32 : 16) / (w <= 68 ? 8 : w <= 284 ? 4 : w <= 536 ? 2 : 1) + 256;
 		else   /* generation-serial: one (qlen + 63)-step sweep per 1024 rows, 64 lanes x 16 rows per step */
-			b += (((size_t)a->tlen / 1024 + 1) * ((size_t)a->qlen + 64) + K2A_TB_PAD) * 64 * (dual ? 16 : 8) + 12 * (size_t)a->qlen + 320;
+			b += (((size_t)a->tlen / 1024 + 1) * ((size_t)a->qlen + 72) + K2A_TB_PAD) * 64 * 16 + 24 * (size_t)a->qlen + 320 + 131072;   /* packed class: 32 bytes per lane-step and two pairs */
 		b += ((size_t)a->qlen + a->tlen + 2) * 4;
 	}
 	return b;
@@ -1194,7 +1226,14 @@ static int plan_chunks(int n, double bytes, double cells, int workers, int ndev)
 		if (k > workers) k = workers;
 	}
 	if (bytes / cap_b > k) k = bytes / cap_b;
-	if (cells / cap_c > k) k = cells / cap_c;
+	/* the cell cap never cuts a chunk below 4096 pairs: 2048 packed wavefronts, two per SIMD -- kernels of fewer wavefronts leave
+	 * SIMDs idle (config 4 at 40 G cells per chunk was 146 pairs per kernel); what really limits such batches is traceback
+	 * memory, and ext_chunk splits by that */
+	{
+		double kc = cells / cap_c;
+		if (kc > (double)n / 4096.0) kc = (double)n / 4096.0;
+		if (kc > k) k = kc;
+	}
 	if (ndev > 1 && k < 3 * workers) k = 3 * workers;      /* several devices: finer grains balance them */
 	if (k > n / min_chunk) k = n / min_chunk;
 	return k < 2 ? 0 : (int)(k + 0.999);

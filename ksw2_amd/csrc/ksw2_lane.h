@@ -352,6 +352,10 @@ struct K2aLane {
  * ------------------------------------------------------------------------------------------------ */
 /* generation-serial layout: steps of generation g start at kbase(g); lane l of it sees column j at local
  * step j - jlo(g) + l.  These two helpers are the single definition used by the fill and by the walk. */
+/* a generation's steps are padded to a multiple of 8 in the traceback block, so that the 128-byte blocks the packed kernels
+ * write (K2aTbStage, ksw2_shim_hip.hip) never span two generations (which different wavefronts may be writing) */
+K2A_FN size_t k2a_gen_pad(int nsteps) { return (size_t)((nsteps + 7) & ~7); }
+
 template<int G, int C>
 K2A_FN void k2a_gen_cols(int g, int qlen, int tlen, int w, int *jlo, int *nsteps)
 {
@@ -379,7 +383,7 @@ K2A_FN size_t k2a_tb_steps(int qlen, int tlen, int w)
 	if (!MP) return (size_t)((tlen + C - 1) / C - 1) + (size_t)k2a_min(qlen - 1, tlen - 1 + w) + 1;
 	const int R = G * C, ngen = (tlen + R - 1) / R;
 	size_t tot = 0;
-	for (int g = 0; g < ngen; ++g) { int jlo, ns; k2a_gen_cols<G, C>(g, qlen, tlen, w, &jlo, &ns); tot += (size_t)ns; }
+	for (int g = 0; g < ngen; ++g) { int jlo, ns; k2a_gen_cols<G, C>(g, qlen, tlen, w, &jlo, &ns); tot += k2a_gen_pad(ns); }
 	return tot;
 }
 
@@ -414,9 +418,9 @@ struct K2aWalk {
 				int ns;
 				if (gcur < 0) {
 					gbase = 0;
-					for (int x = 0; x < g; ++x) { k2a_gen_cols<G, C>(x, qlen, tlen, w, &gjlo, &ns); gbase += (size_t)ns; }
+					for (int x = 0; x < g; ++x) { k2a_gen_cols<G, C>(x, qlen, tlen, w, &gjlo, &ns); gbase += k2a_gen_pad(ns); }
 				} else {
-					for (int x = gcur - 1; x >= g; --x) { k2a_gen_cols<G, C>(x, qlen, tlen, w, &gjlo, &ns); gbase -= (size_t)ns; }
+					for (int x = gcur - 1; x >= g; --x) { k2a_gen_cols<G, C>(x, qlen, tlen, w, &gjlo, &ns); gbase -= k2a_gen_pad(ns); }
 				}
 				k2a_gen_cols<G, C>(g, qlen, tlen, w, &gjlo, &ns);
 				gcur = g;

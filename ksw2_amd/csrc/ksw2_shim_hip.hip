@@ -13,6 +13,7 @@
 #include "ksw2_shim.h"
 #include "ksw2_lane.h"
 #include "ksw2_lane_pk.h"
+#include "ksw2_lane_pkmp.h"
 #include "ksw2_lane_solo.h"
 #include "ksw2_lane_dm.h"
 #include "ksw2_lane_extf.h"
@@ -562,7 +563,7 @@ k2a_fill_mp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 			L.qb = qnext;
 			if (dropped) break;
 		}
-		kbase += (size_t)nsteps;
+		kbase += k2a_gen_pad(nsteps);
 	}
 	__builtin_amdgcn_wave_barrier();
 	if (valid && gl == 0) {
@@ -623,7 +624,7 @@ static const fill_fn g_fill_solo[2][3] = {
 	{ k2a_fill_solo_kernel<K2A_SOLO_C, true, 0>,  k2a_fill_solo_kernel<K2A_SOLO_C, true, 1>,  k2a_fill_solo_kernel<K2A_SOLO_C, true, 2> } };
 
 /* packed walk: thread t = alignment (t & 1) of task (t >> 1) */
-template<int G, int C>
+template<int G, int C, bool MP = false>
 __global__ void __launch_bounds__(64)
 k2a_trace_pk_kernel(const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
                     const uint8_t *__restrict__ tb, K2aResult *__restrict__ res, uint32_t *__restrict__ cig, int ppw)
@@ -637,8 +638,180 @@ k2a_trace_pk_kernel(const K2aPair *__restrict__ pairs, const uint32_t *__restric
 	const K2aPair pr = pairs[pi];
 	const int ti = res[pi].ti, tj = res[pi].tj;
 	int n = 0;
-	if (ti >= 0 && tj >= 0) n = k2a_trace_pair_pk<G, C>(tb + pr.tb_off, half, ti, tj, cig + pr.cig_off, pr.qlen, pr.tlen, pr.w);
+	if (ti >= 0 && tj >= 0) n = k2a_trace_walk<G, C, 2, MP>(tb + pr.tb_off, half, ti, tj, cig + pr.cig_off, pr.qlen, pr.tlen, pr.w);
 	res[pi].n_cigar = n;
+}
+
+/* Packed-int16 generation-serial fill (ksw2_lane_pkmp.h): ONE pair of same-shape alignments per workgroup of K2A_PKMP_WAVES
+ * wavefronts; wavefront v runs generations v, v + 4, v + 8, ... (1024 target rows each), so up to four generations of a pair are
+ * in flight, each reading the boundary row its predecessor streams into HBM ({H, E, baseA, baseB} per column, L1-bypassing
+ * loads two columns ahead).  No spinning: the wavefronts advance in phases of K2A_PKMP_T steps with one workgroup barrier per
+ * phase, and generation g + 1 starts k2a_pkmp_lag phases after generation g -- late enough that every boundary column it reads
+ * was written in an earlier phase and that its strip epilogues (row order!) come after all of generation g's.  The schedule
+ * (start phase of every generation) is a function of the shape alone and is tabulated once per workgroup. */
+template<bool DUAL, int MODE>
+__global__ void __launch_bounds__(64 * K2A_PKMP_WAVES, 2)
+k2a_fill_pkmp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
+                     const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, uint32_t *bnd, K2aResult *__restrict__ res)
+{
+	constexpr int C = 16, G = 64, W = K2A_PKMP_WAVES, T = K2A_PKMP_T, R = G * C;
+	typedef K2aLanePkMp<C, DUAL, MODE> Lane;
+	constexpr int WB = Lane::TBWORDS * 4;
+	constexpr bool STAGED = MODE != K2A_MODE_SCORE;
+	typedef K2aTbStage<32, 8> Stage;
+	static_assert(WB == 32, "16 rows x 2 alignments");
+	__shared__ K2aBook book[2];
+	__shared__ uint32_t rowbuf[W][C];
+	__shared__ int pstart[64 + 1], pcount[64];            /* start phase / phases of every generation (at most 64: reads up to 65 000) */
+	__shared__ uint4 tbstage[STAGED ? W * Stage::WORDS : 1];
+	__shared__ unsigned long long tbruns[STAGED ? W * 64 : 1];
+
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int task = blockIdx.x;
+	if (task >= ntasks) return;
+	const uint32_t piA = order2[2 * task], piB = order2[2 * task + 1];
+	const K2aPair prA = pairs[piA], prB = pairs[piB];
+	const int qlen = prA.qlen, tlen = prA.tlen, w = prA.w;
+	const int ngen = (tlen + R - 1) / R;
+
+	Lane L;
+	/* the task's block of `bnd`: boundary entries, then one block of row-maximum keys per wavefront */
+	L.setup(prA, prB, seq, lane, true, (unsigned long long*)(bnd + prA.bnd_off + K2A_PKMP_BND_WORDS(qlen, DUAL)) + (size_t)wave * (K2A_PKMP_SPILL_WORDS(C) / 2));
+	K2aBook *bkA = &book[0], *bkB = &book[1];
+	if (threadIdx.x == 0) {
+		k2a_book_reset(bkA); k2a_book_reset(bkB);
+		int pend[W] = { 0, 0, 0, 0 }, prev_start = 0, prev_jlo = 0, total = 0;
+		for (int x = 0; x < ngen; ++x) {
+			int jlo, ns;
+			k2a_gen_cols<G, C>(x, qlen, tlen, w, &jlo, &ns);
+			int ps = x >= W ? pend[x % W] : 0;
+			if (x >= 1) ps = max(ps, prev_start + k2a_pkmp_lag(prev_jlo, jlo));
+			pstart[x] = ps; pcount[x] = (ns + T - 1) / T;
+			pend[x % W] = ps + pcount[x];
+			total = max(total, pend[x % W]);
+			prev_start = ps; prev_jlo = jlo;
+		}
+		pstart[64] = total;
+	}
+	__syncthreads();
+	const int total_phases = pstart[64];
+
+	uint4 *B1 = (uint4*)(bnd + prA.bnd_off);
+	uint32_t *B2 = (uint32_t*)(B1 + qlen);
+	uint8_t *tbp = tb + prA.tb_off;
+	const size_t tbsteps = STAGED ? k2a_tb_steps<G, C, true>(qlen, tlen, w) : 0;
+	Stage ST;
+	if (STAGED) ST.init(&tbstage[wave * Stage::WORDS], &tbruns[wave * 64], lane, tbp + k2a_tb_word(0, lane, tbsteps, G, WB));
+	const int zdropA = prA.zdrop, zdropB = prB.zdrop;
+	const int ktop = __builtin_amdgcn_readfirstlane(min(qlen - 1, min(C - 1, tlen - 1) + w));
+	const k2a_pk neg = k2a_pku(K2A_NEG16);
+
+	int g = wave;                                     /* the generation this wavefront runs next */
+	int jlo = 0, nsteps = 0, je_prev = -1, kdone = -1;
+	int kbase = 0, gk = 0;                            /* padded steps of the generations before g; generations counted into it */
+	bool feeder = false, drain = false;
+	/* lane 0 of generations > 0: boundary entries {H, E, baseA, baseB} (+ E~) of this step's column and of the next one */
+	uint4 cur = make_uint4(0, 0, 0, 0), nxt = cur;
+	uint32_t cur2 = 0, nxt2 = 0;
+	int bs0A = 0, bs0B = 0;                           /* bases of column jlo - 1 (the first cell's diagonal input) */
+	auto fetch = [&](int j, uint4 &v, uint32_t &v2) {
+		v = make_uint4(neg, neg, 0, 0); v2 = neg;     /* past what the generation above wrote: outside the band */
+		if (j <= je_prev) {
+			const uint32_t *e = (const uint32_t*)&B1[j];
+			v.x = __hip_atomic_load(&e[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v.y = __hip_atomic_load(&e[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			v.z = __hip_atomic_load(&e[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v.w = __hip_atomic_load(&e[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (DUAL) v2 = __hip_atomic_load(&B2[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	};
+
+	for (int phase = 0; phase < total_phases; ++phase) {
+		if (bkA->dropped && bkB->dropped) break;                       /* uniform: the books were last written before the barrier */
+		if (g < ngen && phase >= pstart[g]) {
+			if (phase == pstart[g]) {                                  /* begin the generation */
+				k2a_gen_cols<G, C>(g, qlen, tlen, w, &jlo, &nsteps);
+				for (; gk < g; ++gk) { int a, b; k2a_gen_cols<G, C>(gk, qlen, tlen, w, &a, &b); kbase += (int)k2a_gen_pad(b); }
+				L.begin_generation(g, jlo);
+				L.clear_spill();
+				feeder = lane == 0 && g > 0;
+				drain = lane == G - 1 && g + 1 < ngen;
+				je_prev = g > 0 ? min(qlen - 1, g * R - 1 + w) : -1;          /* last column the generation above wrote */
+				if (feeder) {
+					if (jlo > 0) {                                            /* H(i0 - 1, jlo - 1): the diagonal input of the first cell */
+						uint4 pv; uint32_t pv2;
+						fetch(jlo - 1, pv, pv2);
+						L.P.hu_prev = pv.x; bs0A = (int)pv.z; bs0B = (int)pv.w;
+					}
+					fetch(jlo, cur, cur2);
+					fetch(jlo + 1, nxt, nxt2);
+				}
+				L.P.qb = L.P.next_query_codes(-1);
+				kdone = -1;
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       /* the cleared keys are in place before any atomic on them */
+			}
+			const int k0 = (phase - pstart[g]) * T, k1 = min(nsteps, k0 + T);
+			for (int k = k0; k < k1; ++k) {
+				k2a_pk hin = (k2a_pk)k2a_rot1<G>((int)L.P.hout);
+				k2a_pk ein = (k2a_pk)k2a_rot1<G>((int)L.P.eout);
+				k2a_pk e2in = DUAL ? (k2a_pk)k2a_rot1<G>((int)L.P.e2out) : 0u;
+				const bool ninit = L.need_init(k);
+				if (__builtin_amdgcn_ballot_w64(ninit) != 0) {
+					int bsA = k2a_rot1<G>(L.P.baseA), bsB = k2a_rot1<G>(L.P.baseB);
+					if (feeder) { bsA = bs0A; bsB = bs0B; }
+					if (ninit) L.do_init(sc, bsA, bsB);                  /* uses hu_prev = what arrived one step ago */
+					bsA = k2a_rot1<G>(L.P.baseA); bsB = k2a_rot1<G>(L.P.baseB);
+					L.refresh_delta(bsA, bsB);                           /* a base changed: every lane re-reads its neighbour's */
+				}
+				if (feeder) {
+					hin = cur.x; ein = cur.y; e2in = cur2;
+					L.refresh_delta((int)cur.z, (int)cur.w);             /* every entry carries the bases it is relative to */
+					cur = nxt; cur2 = nxt2;
+					fetch(jlo + k + 2, nxt, nxt2);
+				}
+				L.P.hu_prev = hin;
+				hin = L.adopt(hin); ein = L.adopt(ein);
+				if (DUAL) e2in = L.adopt(e2in);
+				const uint32_t qnext = L.P.next_query_codes(k);
+				if (g == 0 && k <= ktop) L.P.top_inputs(sc, k, hin, ein, e2in);
+				uint32_t tw[Lane::TBWORDS];
+				const int jj = L.column(k);
+				const bool mine = L.P.S >= 0 && jj >= 0 && jj <= L.P.je;
+				const bool live = L.P.step(sc, k, hin, ein, e2in, tw);
+				if (STAGED) { ST.put(kbase + k, tw, live); ST.step_done(kbase + k); kdone = k; }
+				if (drain && mine) {
+					B1[jj] = make_uint4(L.P.hout, L.P.eout, (uint32_t)L.P.baseA, (uint32_t)L.P.baseB);
+					if (DUAL) B2[jj] = L.P.e2out;
+				}
+				const bool nfin = L.need_fin(k);
+				if (__builtin_amdgcn_ballot_w64(nfin) != 0) {
+					if (nfin) L.flush_rowmax();
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   /* the keys' atomics are done ... */
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   /* ... and no stale L1 line of them is read */
+					if (nfin) L.do_fin(sc, bkA, bkB, zdropA, zdropB, rowbuf[wave]);
+					__builtin_amdgcn_wave_barrier();
+				}
+				L.P.qb = qnext;
+				if ((k & (T - 1)) == T - 1) {
+					const k2a_pk d = L.rebase();
+					const k2a_pk da = (k2a_pk)k2a_rot1<G>((int)d);
+					const int bsA = k2a_rot1<G>(L.P.baseA), bsB = k2a_rot1<G>(L.P.baseB);
+					L.after_rebase(da, bsA, bsB);
+				}
+			}
+			if (k1 == nsteps) {                                         /* generation done: on to this wavefront's next one */
+				if (STAGED && kdone >= 0) ST.finish(kbase + kdone);
+				g += W;
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		__syncthreads();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		const K2aBook a = *bkA, b = *bkB;
+		k2a_finish(prA, a, &res[piA]);
+		if (piB != piA) k2a_finish(prB, b, &res[piB]);
+	}
 }
 
 /* ---------------------------------------------------------------- splice-aware extension, diagonal-major (ksw2_lane_dm.h) */
@@ -1141,7 +1314,7 @@ static bool k2a_use_ldsrows(int waves)
 	return 2 * (long)waves >= 3 * (long)k2a_shim_simd_count();
 }
 static const trace_fn g_trace_pk[K2A_NPKCFG] = { k2a_trace_pk_kernel<8, 18>, k2a_trace_pk_kernel<16, 8>, k2a_trace_pk_kernel<64, 8>,
-                                                 k2a_trace_pk_kernel<64, 16> };
+                                                 k2a_trace_pk_kernel<64, 16>, k2a_trace_pk_kernel<64, 16, true> };      /* last: generation-serial layout */
 
 
 extern "C" {
@@ -1280,6 +1453,20 @@ int k2a_shim_launch_trace_pk(int cfg, const K2aPair *pairs, const uint32_t *orde
 	const int ppw = k2a_trace_ppw(2 * ntasks);
 	hipLaunchKernelGGL(g_trace_pk[cfg], dim3((2 * ntasks + ppw - 1) / ppw), dim3(64), 0, (hipStream_t)stream,
 	                   pairs, order2, ntasks, tb, res, cig, ppw);
+	CHECK(hipGetLastError());
+	return 0;
+}
+
+typedef void (*fill_pkmp_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, uint32_t*, K2aResult*);
+static const fill_pkmp_fn g_fill_pkmp[2][3] = { { k2a_fill_pkmp_kernel<false, 0>, k2a_fill_pkmp_kernel<false, 1>, k2a_fill_pkmp_kernel<false, 2> },
+                                                { k2a_fill_pkmp_kernel<true, 0>,  k2a_fill_pkmp_kernel<true, 1>,  k2a_fill_pkmp_kernel<true, 2> } };
+
+int k2a_shim_launch_fill_pkmp(int dual, int mode, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2, int ntasks,
+                              const uint8_t *seq, uint8_t *tb, uint32_t *bnd, K2aResult *res, void *stream)
+{
+	if (ntasks <= 0) return 0;
+	hipLaunchKernelGGL(g_fill_pkmp[dual ? 1 : 0][mode], dim3(ntasks), dim3(64 * K2A_PKMP_WAVES), 0, (hipStream_t)stream,
+	                   *sc, pairs, order2, ntasks, seq, tb, bnd, res);
 	CHECK(hipGetLastError());
 	return 0;
 }

@@ -17,6 +17,7 @@
 #include "../../ksw2_amd/csrc/ksw2_lane_solo.h"
 #include "../../ksw2_amd/csrc/ksw2_lane_extf.h"
 #include "../../ksw2_amd/csrc/ksw2_lane_pk.h"
+#include "../../ksw2_amd/csrc/ksw2_lane_pkmp.h"
 #include "../../ksw2_amd/csrc/ksw2_lane_ssec.h"
 
 static thread_local char g_err[256] = "";
@@ -296,7 +297,7 @@ static void sim_fill_mp(const K2aScoring sc, const K2aPair *pairs, const uint32_
 				for (int gl = 0; gl < 64; ++gl) L[gl].qb = qnext[gl];
 				if (dropped) break;
 			}
-			kbase += (size_t)nsteps;
+			kbase += k2a_gen_pad(nsteps);
 		}
 		k2a_finish(pr, book, &res[pi]);
 	}
@@ -329,7 +330,7 @@ static const fill_mp_fn g_fill_mp_lds[2] = { sim_fill_mp<64, 16, false, 1, true>
 static const trace_fn g_trace[K2A_NCFG][2] = { TRACE_ROW(16, 8, false), TRACE_ROW(64, 8, false), TRACE_ROW(64, 16, false),
                                                TRACE_ROW(64, 32, false), TRACE_ROW(64, 16, true) };
 
-template<int G, int C>
+template<int G, int C, bool MP = false>
 static void sim_trace_pk(const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb, K2aResult *res, uint32_t *cig)
 {
 	for (int t = 0; t < 2 * ntasks; ++t) {
@@ -339,7 +340,7 @@ static void sim_trace_pk(const K2aPair *pairs, const uint32_t *order2, int ntask
 		const K2aPair pr = pairs[pi];
 		int n = 0;
 		if (res[pi].ti >= 0 && res[pi].tj >= 0)
-			n = k2a_trace_pair_pk<G, C>(tb + pr.tb_off, half, res[pi].ti, res[pi].tj, cig + pr.cig_off, pr.qlen, pr.tlen, pr.w);
+			n = k2a_trace_walk<G, C, 2, MP>(tb + pr.tb_off, half, res[pi].ti, res[pi].tj, cig + pr.cig_off, pr.qlen, pr.tlen, pr.w);
 		res[pi].n_cigar = n;
 	}
 }
@@ -355,7 +356,7 @@ static const fill_pk_fn g_fill_pk_lds[2][2] = {
 	{ sim_fill_pk<64, 16, true, 1, true, false, true>,  sim_fill_pk<64, 16, true, 2, true, false, true> } };
 /* the simulator takes the LDS form of the row state unless KSW2AMD_LDSROWS=0 (the GPU launcher decides by the number of tasks) */
 static bool sim_use_ldsrows(void) { const char *ev = getenv("KSW2AMD_LDSROWS"); return !ev || atoi(ev) != 0; }
-static const trace_fn g_trace_pk[K2A_NPKCFG] = { sim_trace_pk<8, 18>, sim_trace_pk<16, 8>, sim_trace_pk<64, 8>, sim_trace_pk<64, 16> };
+static const trace_fn g_trace_pk[K2A_NPKCFG] = { sim_trace_pk<8, 18>, sim_trace_pk<16, 8>, sim_trace_pk<64, 8>, sim_trace_pk<64, 16>, sim_trace_pk<64, 16, true> };
 
 
 /* mirrors k2a_exts_kernel: one alignment per wavefront, diagonal-major, K2A_DM_SLOTS slots of 64 target positions */
@@ -604,6 +605,107 @@ static void sim_ssec(const K2aSsec P, const K2aPair *pairs, const uint32_t *orde
 			last_st = st; last_en = en;
 		}
 		k2a_finish(pr, book, &res[pi]);
+	}
+}
+
+/* mirrors k2a_fill_pkmp_kernel.  The generations of a task run one after the other here (on the device four wavefronts pipeline
+ * them; the data flow -- boundary entries through `bnd`, row-maximum keys in the task's spill blocks, a re-base every
+ * K2A_PKMP_T steps -- is the same, and so is every value). */
+template<bool DUAL, int MODE>
+static void sim_fill_pkmp(const K2aScoring sc, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *seq, uint8_t *tb,
+                          uint32_t *bnd, K2aResult *res)
+{
+	constexpr int C = 16, G = 64, W = K2A_PKMP_WAVES, T = K2A_PKMP_T, R = G * C;
+	typedef K2aLanePkMp<C, DUAL, MODE> Lane;
+	constexpr int WB = Lane::TBWORDS * 4;
+	for (int task = 0; task < ntasks; ++task) {
+		static thread_local Lane L[64];
+		const uint32_t piA = order2[2 * task], piB = order2[2 * task + 1];
+		const K2aPair prA = pairs[piA], prB = pairs[piB];
+		const int qlen = prA.qlen, tlen = prA.tlen, w = prA.w, ngen = (tlen + R - 1) / R;
+		K2aBook bkA, bkB;
+		uint32_t rowbuf[C];
+		k2a_book_reset(&bkA); k2a_book_reset(&bkB);
+		uint32_t *B1 = bnd + prA.bnd_off, *B2 = B1 + 4 * (size_t)qlen;
+		unsigned long long *spill = (unsigned long long*)(bnd + prA.bnd_off + K2A_PKMP_BND_WORDS(qlen, DUAL));
+		const size_t tbsteps = MODE != K2A_MODE_SCORE ? k2a_tb_steps<G, C, true>(qlen, tlen, w) : 0;
+		const int ktop = k2a_min(qlen - 1, k2a_min(C - 1, tlen - 1) + w);
+		const k2a_pk neg = k2a_pku(K2A_NEG16);
+		size_t kbase = 0;
+		bool stop = false;
+		for (int g = 0; g < ngen && !stop; ++g) {
+			int jlo, nsteps;
+			k2a_gen_cols<G, C>(g, qlen, tlen, w, &jlo, &nsteps);
+			const int wave = g % W, je_prev = g > 0 ? k2a_min(qlen - 1, g * R - 1 + w) : -1;
+			/* (a wavefront's lane state does not survive begin_generation / do_init -- bases are re-derived at every init -- so
+			 * setting the lanes up afresh for every generation is equivalent to the device's wavefront g mod 4 carrying on) */
+			for (int l = 0; l < 64; ++l) {
+				L[l].setup(prA, prB, seq, l, true, spill + (size_t)wave * (K2A_PKMP_SPILL_WORDS(C) / 2));
+				L[l].begin_generation(g, jlo); L[l].clear_spill();
+			}
+			int bs0A = 0, bs0B = 0;
+			auto fetch = [&](int j, uint32_t v[4], uint32_t &v2) {
+				v[0] = v[1] = neg; v[2] = v[3] = 0; v2 = neg;
+				if (j <= je_prev) { for (int x = 0; x < 4; ++x) v[x] = B1[4 * (size_t)j + x]; if (DUAL) v2 = B2[j]; }
+			};
+			if (g > 0 && jlo > 0) { uint32_t pv[4], pv2; fetch(jlo - 1, pv, pv2); L[0].P.hu_prev = pv[0]; bs0A = (int)pv[2]; bs0B = (int)pv[3]; }
+			for (int l = 0; l < 64; ++l) L[l].P.qb = L[l].P.next_query_codes(-1);
+			for (int k = 0; k < nsteps && !stop; ++k) {
+				k2a_pk hin[64], ein[64], e2in[64];
+				uint32_t qnext[64];
+				for (int l = 0; l < 64; ++l) { const int src = (l + 63) % 64; hin[l] = L[src].P.hout; ein[l] = L[src].P.eout; e2in[l] = DUAL ? L[src].P.e2out : 0u; }
+				bool anyinit = false;
+				for (int l = 0; l < 64; ++l) anyinit |= L[l].need_init(k);
+				if (anyinit) {
+					int bsA[64], bsB[64];
+					for (int l = 0; l < 64; ++l) { bsA[l] = L[(l + 63) % 64].P.baseA; bsB[l] = L[(l + 63) % 64].P.baseB; }
+					if (g > 0) { bsA[0] = bs0A; bsB[0] = bs0B; }
+					for (int l = 0; l < 64; ++l) if (L[l].need_init(k)) L[l].do_init(sc, bsA[l], bsB[l]);
+					for (int l = 0; l < 64; ++l) { bsA[l] = L[(l + 63) % 64].P.baseA; bsB[l] = L[(l + 63) % 64].P.baseB; }
+					for (int l = 0; l < 64; ++l) L[l].refresh_delta(bsA[l], bsB[l]);
+				}
+				if (g > 0) {
+					uint32_t v[4], v2;
+					fetch(jlo + k, v, v2);
+					hin[0] = v[0]; ein[0] = v[1]; e2in[0] = v2;
+					L[0].refresh_delta((int)v[2], (int)v[3]);
+				}
+				bool nfin[64], anyfin = false;
+				for (int l = 0; l < 64; ++l) {
+					L[l].P.hu_prev = hin[l];
+					hin[l] = L[l].adopt(hin[l]); ein[l] = L[l].adopt(ein[l]);
+					if (DUAL) e2in[l] = L[l].adopt(e2in[l]);
+					qnext[l] = L[l].P.next_query_codes(k);
+					if (g == 0 && k <= ktop) L[l].P.top_inputs(sc, k, hin[l], ein[l], e2in[l]);
+					uint32_t tw[Lane::TBWORDS];
+					const int jj = L[l].column(k);
+					const bool mine = L[l].P.S >= 0 && jj >= 0 && jj <= L[l].P.je;
+					const bool live = L[l].P.step(sc, k, hin[l], ein[l], e2in[l], tw);
+					if (MODE != K2A_MODE_SCORE && live) memcpy(tb + prA.tb_off + k2a_tb_word(kbase + (size_t)k, l, tbsteps, G, WB), tw, sizeof(tw));
+					if (l == G - 1 && g + 1 < ngen && mine) {
+						B1[4 * (size_t)jj] = L[l].P.hout; B1[4 * (size_t)jj + 1] = L[l].P.eout; B1[4 * (size_t)jj + 2] = (uint32_t)L[l].P.baseA; B1[4 * (size_t)jj + 3] = (uint32_t)L[l].P.baseB;
+						if (DUAL) B2[jj] = L[l].P.e2out;
+					}
+					nfin[l] = L[l].need_fin(k);
+					anyfin |= nfin[l];
+				}
+				if (anyfin) {
+					for (int l = 0; l < 64; ++l) if (nfin[l]) { L[l].flush_rowmax(); L[l].do_fin(sc, &bkA, &bkB, prA.zdrop, prB.zdrop, rowbuf); }
+					if (bkA.dropped && bkB.dropped) stop = true;
+				}
+				for (int l = 0; l < 64; ++l) L[l].P.qb = qnext[l];
+				if ((k & (T - 1)) == T - 1) {
+					k2a_pk d[64];
+					for (int l = 0; l < 64; ++l) d[l] = L[l].rebase();
+					int bsA[64], bsB[64];
+					for (int l = 0; l < 64; ++l) { bsA[l] = L[(l + 63) % 64].P.baseA; bsB[l] = L[(l + 63) % 64].P.baseB; }
+					for (int l = 0; l < 64; ++l) L[l].after_rebase(d[(l + 63) % 64], bsA[l], bsB[l]);
+				}
+			}
+			kbase += k2a_gen_pad(nsteps);
+		}
+		k2a_finish(prA, bkA, &res[piA]);
+		if (piB != piA) k2a_finish(prB, bkB, &res[piB]);
 	}
 }
 
@@ -877,6 +979,15 @@ int k2a_shim_launch_exts_trace(const K2aSplice *sp, const K2aPair *pairs, const 
 }
 
 
+int k2a_shim_launch_fill_pkmp(int dual, int mode, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2, int ntasks,
+                              const uint8_t *seq, uint8_t *tb, uint32_t *bnd, K2aResult *res, void *)
+{
+	typedef void (*fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, uint32_t*, K2aResult*);
+	static const fn f[2][3] = { { sim_fill_pkmp<false, 0>, sim_fill_pkmp<false, 1>, sim_fill_pkmp<false, 2> },
+	                            { sim_fill_pkmp<true, 0>, sim_fill_pkmp<true, 1>, sim_fill_pkmp<true, 2> } };
+	if (ntasks > 0) f[dual ? 1 : 0][mode](*sc, pairs, order2, ntasks, seq, tb, bnd, res);
+	return 0;
+}
 int k2a_shim_launch_ssec(int dual, int mode, const K2aSsec *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
                          uint8_t *tb, uint8_t *scratch, K2aResult *res, void *)
 {

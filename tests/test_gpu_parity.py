@@ -810,3 +810,28 @@ def test_sse_compatible_mode(lib):
     assert su.check_golden(lib) >= 1500
     su.check_routing(lib)
     su.check_long(lib, n=6, length=6000, w=150)
+
+
+def test_packed_generation_serial(lib, monkeypatch):
+    """The packed generation-serial class on the GPU (k2a_fill_pkmp_kernel: four wavefronts pipeline a task's generations, one
+    workgroup barrier per 64 steps): same-shape batches whose band no resident geometry holds -- 2 to 25 generations, unbanded
+    and wide bands, both gap models, gap alignment modes, Z-drop with diverging tails, odd task counts -- against the oracle;
+    and against the int32 generation-serial kernels on a 25 k x 25 k pair."""
+    mat = synth.simple_mat(5, 2, 4, -1)
+    cases = [(2100, -1, False, 0, -1, 6), (2600, -1, False, po.SCORE_ONLY, -1, 10), (2200, 1100, True, 0, -1, 4), (2300, -1, True, po.RIGHT, 300, 6),
+             (3000, 1300, False, po.RIGHT, -1, 2), (4300, -1, False, po.EXTZ_ONLY, 400, 4), (5200, 1200, True, 0, 400, 4), (9000, -1, False, 0, -1, 2)]
+    for L, w, dual, flag, zd, n in cases:
+        q, t = synth.fixed_batch(9, n // 2, L, L + 37, sub=0.05, ind=0.08, tail_random_frac=0.3 if zd >= 0 else 0.0, tail_pairs=0.5 if zd >= 0 else 0.0)
+        qs, ts = [q[i // 2] for i in range(n)], [t[i // 2] for i in range(n)]
+        p = lib.make_batch(qs, ts, mat, 4, 2, 24, 1, w=w, zdrop=zd, flag=flag).plan(dual)
+        assert p.packed_pairs() == n
+        p.close()
+        check_batch(lib, dual, qs, ts, mat, 4, 2, 24, 1, w=w, zdrop=zd, flag=flag)
+    q, t = synth.fixed_batch(10, 1, 25000, 25300, sub=0.04, ind=0.05)
+    qs, ts = [q[0], q[0]], [t[0], t[0]]
+    for flag in (0, po.SCORE_ONLY):
+        a = lib.extz_batch(qs, ts, mat, 4, 2, w=-1, zdrop=-1, flag=flag)
+        monkeypatch.setenv("KSW2AMD_NO_PKMP", "1")
+        b = lib.extz_batch(qs, ts, mat, 4, 2, w=-1, zdrop=-1, flag=flag)
+        monkeypatch.delenv("KSW2AMD_NO_PKMP")
+        assert not diff(a[0], b[0], gu.FIELDS + ["cigar"]) and not diff(a[1], b[1], gu.FIELDS + ["cigar"])

@@ -531,3 +531,25 @@ def test_sim_sse_compatible_mode(sim):
     assert su.check_golden(sim, step=3) >= 500
     su.check_routing(sim)
     su.check_long(sim, n=3, length=1500, w=60)
+
+
+def test_sim_packed_generation_serial(sim, monkeypatch):
+    """Same-shape pairs whose band no resident geometry holds take the packed generation-serial class (ksw2_lane_pkmp.h: sliding
+    score base, row maxima merged as keys, boundary entries between generations): unbanded and wide bands, one to six
+    generations, both gap models, Z-drop; and the int32 generation-serial kernels still serve when it is switched off."""
+    monkeypatch.setenv("KSW2AMD_SIMDS", "0")
+    mat = synth.simple_mat(5, 2, 4, -1)
+    cases = [(900, -1, False, 0, -1), (2100, -1, False, po.RIGHT, -1), (2600, -1, False, po.SCORE_ONLY, -1), (2200, 1100, True, 0, -1),
+             (2300, -1, True, po.RIGHT, 300), (3300, -1, False, po.EXTZ_ONLY, 100), (5200, 1200, True, 0, 400)]
+    for L, w, dual, flag, zd in cases:
+        q, t = synth.fixed_batch(9, 2, L, L + 37, sub=0.05, ind=0.08, tail_random_frac=0.3 if zd >= 0 else 0.0, tail_pairs=0.5 if zd >= 0 else 0.0)
+        qs, ts = [q[0], q[0], q[1], q[1]], [t[0], t[0], t[1], t[1]]
+        p = sim.make_batch(qs, ts, mat, 4, 2, 24, 1, w=w, zdrop=zd, flag=flag).plan(dual)
+        assert p.packed_pairs() == 4          # 900 rows: all strips resident in the packed (64, 16) array; beyond 2 048 rows: this class
+        p.close()
+        check_batch(sim, dual, qs, ts, mat, 4, 2, 24, 1, w=w, zdrop=zd, flag=flag)
+    monkeypatch.setenv("KSW2AMD_NO_PKMP", "1")
+    q, t = synth.fixed_batch(9, 2, 2300, 2337, sub=0.05, ind=0.08)
+    p = sim.make_batch(q, t, mat, 4, 2, 24, 1, w=-1, zdrop=-1, flag=0).plan(False)
+    assert p.packed_pairs() == 0
+    p.close()
