@@ -670,7 +670,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 			const int G = c->pk ? k2a_pkcfg_G[c->cfg] : k2a_cfg_G[c->cfg], C = c->pk ? k2a_pkcfg_C[c->cfg] : k2a_cfg_C[c->cfg];
 			const int nstrips = (da->tlen + C - 1) / C;
 			size_t steps = (size_t)(nstrips - 1) + (size_t)imin(da->qlen - 1, da->tlen - 1 + da->w) + 1;
-			const size_t wb = c->pk ? 2 * (size_t)C : (size_t)C * (dual ? 8 : 4) / 8;
+			const size_t wb = c->pk ? (size_t)K2A_PK_TB_BYTES(C, dual) : (size_t)C * (dual ? 8 : 4) / 8;
 			if (!c->solo && (c->pk ? c->cfg == K2A_PKCFG_MP : c->cfg == K2A_CFG_MP)) steps = mp_total_steps(G, C, da->qlen, da->tlen, da->w);
 			da->tb_off = db->tb_off = p->tb_bytes;
 			if (c->solo) {        /* k2a_solo_steps: 2 * (double strips - 1) + 2 + last column; 64 lanes x 2 * K2A_SOLO_C bytes per step */
@@ -763,7 +763,7 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 				    : k2a_shim_launch_fill_pk(k->cfg, p->dual, k->mode, k->rb, k->nomax, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq,
 				                            p->d_tb, p->d_res, s)) goto err;
 				if (k->mode != K2A_MODE_SCORE &&
-				    k2a_shim_launch_trace_pk(k->cfg, p->d_pairs, p->d_order + k->first, k->count, p->d_tb, p->d_res, p->d_cig, s)) goto err;
+				    k2a_shim_launch_trace_pk(k->cfg, p->dual, p->d_pairs, p->d_order + k->first, k->count, p->d_tb, p->d_res, p->d_cig, s)) goto err;
 			} else {
 				if (k2a_shim_launch_fill(k->cfg, p->dual, k->mode, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
 				                         p->d_bnd, p->d_res, s)) goto err;
@@ -797,7 +797,7 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 		if (k->solo) {
 			if (k2a_shim_launch_trace_solo(p->d_pairs, p->d_order + k->first, k->count, p->d_tb, p->d_res, p->d_cig, stream)) goto err;
 		} else if (k->pk) {
-			if (k2a_shim_launch_trace_pk(k->cfg, p->d_pairs, p->d_order + k->first, k->count, p->d_tb, p->d_res, p->d_cig, stream)) goto err;
+			if (k2a_shim_launch_trace_pk(k->cfg, p->dual, p->d_pairs, p->d_order + k->first, k->count, p->d_tb, p->d_res, p->d_cig, stream)) goto err;
 		} else if (k2a_shim_launch_trace(k->cfg, p->dual, p->d_pairs, p->d_order + k->first, k->count, p->d_tb, p->d_res, p->d_cig, stream)) goto err;
 	}
 	if (k2a_shim_event_record(p->ev[2], stream)) goto err;
@@ -966,6 +966,22 @@ int ksw2amd_plan_fetch(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez)
 
 /* ---------------------------------------------------------------- batch entry points */
 
+/* Device memory one plan of a worker may take: its fair share of the device (70 % over the `share` workers of this device), but no
+ * more than it can get right now -- the free memory plus what its own buffer cache hands back.  (Free memory alone is the wrong
+ * measure: after the first batch the workers' caches hold most of it, and a chunk that fitted before would be cut into slivers.) */
+static size_t thread_cached_device_bytes(void)
+{
+	size_t b = 0;
+	int k;
+	for (k = 0; k < BUF_KINDS; ++k) if (k != BUF_HSEQ && g_cache[k].p) b += g_cache[k].cap;
+	return b;
+}
+static size_t device_budget(size_t free_b, size_t total_b, int share)
+{
+	const size_t fair = total_b / 10 * 7 / (size_t)(share > 0 ? share : 1), have = (free_b + thread_cached_device_bytes()) / 10 * 9;
+	return fair < have ? fair : have;
+}
+
 static size_t pair_device_bytes(int dual, const ksw2amd_pair_t *a)
 {
 	/* upper bound of what plan_create allocates for this pair */
@@ -1000,7 +1016,7 @@ static int run_serial(int dual, int scalar, void *km, const ksw2amd_scoring_t *s
 		if (acc <= ((size_t)256 << 20)) budget = (size_t)1 << 30;
 		else {
 			if (k2a_shim_mem_info(&free_b, &total_b)) return fail(KSW2AMD_E_NODEVICE, "mem_info: %s", k2a_shim_last_error());
-			budget = free_b / 10 * 7 / (size_t)share;
+			budget = device_budget(free_b, total_b, share);
 		}
 	}
 	while (beg < n) {
@@ -1212,7 +1228,7 @@ static int pool_min_pairs(void)
 	return e && atoi(e) > 0 ? atoi(e) : 0;
 }
 
-static int plan_chunks(int n, double bytes, double cells, int workers, int ndev)
+static int plan_chunks(int n, double bytes, double cells, int workers, int ndev, int with_cigar)
 {
 	const char *e1 = getenv("KSW2AMD_CHUNK_MB"), *e2 = getenv("KSW2AMD_CHUNK_GCELLS");
 	const double cap_b = (e1 && atof(e1) > 0 ? atof(e1) : 128.0) * 1048576.0, cap_c = (e2 && atof(e2) > 0 ? atof(e2) : 40.0) * 1e9;
@@ -1222,8 +1238,11 @@ static int plan_chunks(int n, double bytes, double cells, int workers, int ndev)
 	if (forced) { if (n < forced) return 0; k = workers; }
 	else {
 		if (n < 512 || (bytes < 4.0 * 1048576.0 && cells < 2e9)) return 0;
+		/* score-only batches: one chunk per worker (packing in parallel; fewer, larger kernels).  With CIGARs the download and the
+		 * ksw_extz_t assembly of a chunk cost as much as its kernels: three chunks per worker, so that while one worker fetches
+		 * the others' kernels keep the device busy (config 3: one chunk per worker left the device idle a third of the call) */
 		k = bytes / (2.0 * 1048576.0);
-		if (k > workers) k = workers;
+		if (k > (with_cigar ? 3 : 1) * workers) k = (with_cigar ? 3 : 1) * workers;
 	}
 	if (bytes / cap_b > k) k = bytes / cap_b;
 	/* the cell cap never cuts a chunk below 4096 pairs: 2048 packed wavefronts, two per SIMD -- kernels of fewer wavefronts leave
@@ -1275,7 +1294,7 @@ static int ext_chunk(void *ctx_, int beg, int end, int share, pend_t *pd)
 	else if (bytes > ((size_t)256 << 20)) {
 		if (k2a_shim_mem_info(&free_b, &total_b)) return fail(KSW2AMD_E_NODEVICE, "mem_info: %s", k2a_shim_last_error());
 		/* what is free now, plus what this worker's pending plan and cache will hand back, over two plans per worker */
-		budget = free_b / 10 * 7 / (size_t)(share > 0 ? share : 1);
+		budget = device_budget(free_b, total_b, share);
 	}
 	if (bytes > budget) {
 		rc = ext_finish(c, pd);
@@ -1342,7 +1361,7 @@ static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc
 				cost[i] = 1.0 + c + 64.0 * b;              /* a byte costs the host about as much as 64 cells cost the device */
 				total += cost[i];
 			}
-			nchunks = plan_chunks(n, bytes, cells, workers, g_ndev_set);
+			nchunks = plan_chunks(n, bytes, cells, workers, g_ndev_set, !(pairs[0].flag & KSW_EZ_SCORE_ONLY));
 			if (nchunks >= 2) {
 				ext_ctx_t ctx;
 				ctx.dual = dual; ctx.scalar = scalar; ctx.km = km; ctx.sc = sc; ctx.pairs = pairs; ctx.ez = ez;

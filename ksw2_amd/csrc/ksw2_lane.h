@@ -393,7 +393,7 @@ K2A_FN size_t k2a_tb_steps(int qlen, int tlen, int w)
  * tasks, byte 2c + half of a 2C-byte word. */
 template<int G, int C, int LAYOUT, bool MP>
 struct K2aWalk {
-	enum { WB = LAYOUT == 2 ? 2 * C : LAYOUT == 1 ? C : C / 2 };
+	enum { WB = LAYOUT == 2 ? 2 * C : (LAYOUT == 1 || LAYOUT == 3) ? C : C / 2 };
 	const uint8_t *tb, *p;          /* block, current word */
 	int qlen, tlen, w, half;
 	size_t nsteps, gbase;
@@ -435,13 +435,14 @@ struct K2aWalk {
 	{
 		const uint8_t *pk = p - (size_t)k * WB;
 		const int ck = c - k;
-		return LAYOUT == 2 ? pk[2 * ck + half] : LAYOUT == 1 ? pk[ck] : pk[ck >> 1];
+		/* LAYOUT 3 (packed single-gap, 4-bit codes): word ck / 4 of the lane-step, 16-bit half `half`, rows 4g..4g+3 from the top nibble down */
+		return LAYOUT == 3 ? pk[4 * (ck >> 2) + 2 * half + (1 - ((ck & 3) >> 1))] : LAYOUT == 2 ? pk[2 * ck + half] : LAYOUT == 1 ? pk[ck] : pk[ck >> 1];
 	}
 	/* direction code in the reference's byte layout (ksw2.h:125-128) from that byte; ck = row of the cell in the strip */
 	K2A_FN uint32_t decode(uint32_t b, int ck) const
 	{
-		if (LAYOUT != 0) return b;
-		const uint32_t r4 = (b >> ((ck & 1) * 4)) & 0xfu;
+		if (LAYOUT == 1 || LAYOUT == 2) return b;
+		const uint32_t r4 = LAYOUT == 3 ? ((ck & 1) ? b & 0xfu : b >> 4) : (b >> ((ck & 1) * 4)) & 0xfu;
 		return (r4 & 3u) | ((r4 & 4u) << 1) | ((r4 & 8u) << 1);
 	}
 };

@@ -146,7 +146,10 @@ K2A_FN uint32_t k2a_pack_dirs(k2a_pk d0, k2a_pk d1)
 
 template<int G, int C, bool DUAL, int MODE = K2A_MODE_SCORE, bool RB = false, bool NOMAX = false, bool LDSROW_ = false>
 struct K2aLanePk {
-	enum { TBWORDS = C / 2 };
+	enum { NIB = K2A_PK_NIBBLES(C, DUAL), TBWORDS = NIB ? C / 4 : C / 2 };
+	/* NIB (single gap, 16 rows): direction codes of 4 bits -- bits 0-1 winner {0 diag, 1 E, 2 F}, bit 2 / 3 = the E / F gap leaving the
+	 * cell is an extension -- four consecutive rows per 16-bit half (row 4g at bits 15-12 ... row 4g+3 at bits 3-0), word g of a
+	 * lane-step = { alignment A, alignment B }: half the traceback bytes of the byte layout, for one v_pk_mad per row */
 	/* group-uniform (both alignments share the shape) */
 	int qlen, tlen, tlen_full, w, nstrips;
 	const uint8_t *qa, *qbp, *ta, *tbq;   /* query / target codes of alignment A and of alignment B */
@@ -348,11 +351,11 @@ struct K2aLanePk {
 			 * opening" (ksw2_extz.c:79-86 / 105-112) compares the gap state with the opening value directly. */
 			const k2a_pk t = k2a_sub32(h, gq);
 			if (MODE == K2A_MODE_LEFT) {                   /* extension strictly better than opening */
-				d |= k2a_pk_sign(k2a_pk_sub(t, e)) & 0x00080008u;
-				d |= k2a_pk_sign(k2a_pk_sub(t, fc)) & 0x00100010u;
+				d |= k2a_pk_sign(k2a_pk_sub(t, e)) & (NIB ? 0x00040004u : 0x00080008u);
+				d |= k2a_pk_sign(k2a_pk_sub(t, fc)) & (NIB ? 0x00080008u : 0x00100010u);
 			} else if (MODE == K2A_MODE_RIGHT) {           /* extension at least as good as opening */
-				d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e, t)), 0u, 0x00080008u);
-				d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(fc, t)), 0u, 0x00100010u);
+				d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e, t)), 0u, NIB ? 0x00040004u : 0x00080008u);
+				d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(fc, t)), 0u, NIB ? 0x00080008u : 0x00100010u);
 			}
 			e = k2a_pk_maxu(e, t);
 			f[c] = k2a_sub32(k2a_pk_maxu(fc, t), ge);
@@ -369,7 +372,10 @@ struct K2aLanePk {
 				f2[c] = k2a_sub32(k2a_pk_maxu(f2[c], t2), ge2);
 			}
 			if (MODE != K2A_MODE_SCORE) {
-				if (c & 1) tbw[c >> 1] = k2a_pack_dirs(dprev, d);    /* bytes {A(c-1), B(c-1), A(c), B(c)} */
+				if (NIB) {
+					dprev = (c & 3) ? k2a_pk_mad(dprev, 0x00100010u, d) : d;      /* both halves: code << 4 | next row's code */
+					if ((c & 3) == 3) tbw[c >> 2] = dprev;
+				} else if (c & 1) tbw[c >> 1] = k2a_pack_dirs(dprev, d);    /* bytes {A(c-1), B(c-1), A(c), B(c)} */
 				else dprev = d;
 			}
 			hl[c] = h;
@@ -532,10 +538,10 @@ struct K2aLanePk {
 
 /* Traceback walk for one alignment (half = 0/1) of a packed task: direction bytes in the reference layout at byte
  * 2c + half of the (step, lane) word (K2aWalk layout 2). */
-template<int G, int C>
+template<int G, int C, bool DUAL = true, bool MP = false>
 K2A_FN int k2a_trace_pair_pk(const uint8_t *tb, int half, int i, int j, uint32_t *out, int qlen, int tlen, int w)
 {
-	return k2a_trace_walk<G, C, 2, false>(tb, half, i, j, out, qlen, tlen, w);
+	return k2a_trace_walk<G, C, K2A_PK_NIBBLES(C, DUAL) ? 3 : 2, MP>(tb, half, i, j, out, qlen, tlen, w);
 }
 
 /* merge the lane-local bests of one alignment (half = 0/1) of a lane group: loc[l*5 + {0..4}] = lane l's

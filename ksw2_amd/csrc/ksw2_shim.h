@@ -71,7 +71,7 @@ int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_
  * The packed trace kernel walks 2*ntasks alignments of such a launch. */
 int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2,
                             int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, void *stream);
-int k2a_shim_launch_trace_pk(int cfg, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb,
+int k2a_shim_launch_trace_pk(int cfg, int dual, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb,
                              K2aResult *res, uint32_t *cig, void *stream);
 
 /* Packed generation-serial fill (class K2A_PKCFG_MP): one task (two same-shape alignments) per workgroup of four wavefronts that

@@ -624,7 +624,7 @@ static const fill_fn g_fill_solo[2][3] = {
 	{ k2a_fill_solo_kernel<K2A_SOLO_C, true, 0>,  k2a_fill_solo_kernel<K2A_SOLO_C, true, 1>,  k2a_fill_solo_kernel<K2A_SOLO_C, true, 2> } };
 
 /* packed walk: thread t = alignment (t & 1) of task (t >> 1) */
-template<int G, int C, bool MP = false>
+template<int G, int C, bool DUAL, bool MP = false>
 __global__ void __launch_bounds__(64)
 k2a_trace_pk_kernel(const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
                     const uint8_t *__restrict__ tb, K2aResult *__restrict__ res, uint32_t *__restrict__ cig, int ppw)
@@ -638,7 +638,7 @@ k2a_trace_pk_kernel(const K2aPair *__restrict__ pairs, const uint32_t *__restric
 	const K2aPair pr = pairs[pi];
 	const int ti = res[pi].ti, tj = res[pi].tj;
 	int n = 0;
-	if (ti >= 0 && tj >= 0) n = k2a_trace_walk<G, C, 2, MP>(tb + pr.tb_off, half, ti, tj, cig + pr.cig_off, pr.qlen, pr.tlen, pr.w);
+	if (ti >= 0 && tj >= 0) n = k2a_trace_pair_pk<G, C, DUAL, MP>(tb + pr.tb_off, half, ti, tj, cig + pr.cig_off, pr.qlen, pr.tlen, pr.w);
 	res[pi].n_cigar = n;
 }
 
@@ -656,10 +656,9 @@ k2a_fill_pkmp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 {
 	constexpr int C = 16, G = 64, W = K2A_PKMP_WAVES, T = K2A_PKMP_T, R = G * C;
 	typedef K2aLanePkMp<C, DUAL, MODE> Lane;
-	constexpr int WB = Lane::TBWORDS * 4;
+	constexpr int WB = Lane::TBWORDS * 4;                 /* 16 bytes (single gap: 4-bit codes) or 32 per lane-step */
 	constexpr bool STAGED = MODE != K2A_MODE_SCORE;
-	typedef K2aTbStage<32, 8> Stage;
-	static_assert(WB == 32, "16 rows x 2 alignments");
+	typedef K2aTbStage<WB, 8> Stage;
 	__shared__ K2aBook book[2];
 	__shared__ uint32_t rowbuf[W][C];
 	__shared__ int pstart[64 + 1], pcount[64];            /* start phase / phases of every generation (at most 64: reads up to 65 000) */
@@ -1313,8 +1312,9 @@ static bool k2a_use_ldsrows(int waves)
 	if (ev) return atoi(ev) != 0;
 	return 2 * (long)waves >= 3 * (long)k2a_shim_simd_count();
 }
-static const trace_fn g_trace_pk[K2A_NPKCFG] = { k2a_trace_pk_kernel<8, 18>, k2a_trace_pk_kernel<16, 8>, k2a_trace_pk_kernel<64, 8>,
-                                                 k2a_trace_pk_kernel<64, 16>, k2a_trace_pk_kernel<64, 16, true> };      /* last: generation-serial layout */
+#define TRACE_PK_ROW(D) { k2a_trace_pk_kernel<8, 18, D>, k2a_trace_pk_kernel<16, 8, D>, k2a_trace_pk_kernel<64, 8, D>, k2a_trace_pk_kernel<64, 16, D>, \
+                          k2a_trace_pk_kernel<64, 16, D, true> }      /* last: generation-serial layout */
+static const trace_fn g_trace_pk[2][K2A_NPKCFG] = { TRACE_PK_ROW(false), TRACE_PK_ROW(true) };      /* [dual][cfg] */
 
 
 extern "C" {
@@ -1445,13 +1445,13 @@ int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax,
 	return 0;
 }
 
-int k2a_shim_launch_trace_pk(int cfg, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb,
+int k2a_shim_launch_trace_pk(int cfg, int dual, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb,
                              K2aResult *res, uint32_t *cig, void *stream)
 {
 	if (ntasks <= 0) return 0;
 	if (cfg < 0 || cfg >= K2A_NPKCFG) { snprintf(g_err, sizeof(g_err), "bad packed kernel class"); return -1; }
 	const int ppw = k2a_trace_ppw(2 * ntasks);
-	hipLaunchKernelGGL(g_trace_pk[cfg], dim3((2 * ntasks + ppw - 1) / ppw), dim3(64), 0, (hipStream_t)stream,
+	hipLaunchKernelGGL(g_trace_pk[dual ? 1 : 0][cfg], dim3((2 * ntasks + ppw - 1) / ppw), dim3(64), 0, (hipStream_t)stream,
 	                   pairs, order2, ntasks, tb, res, cig, ppw);
 	CHECK(hipGetLastError());
 	return 0;

@@ -26,6 +26,11 @@
 #define K2A_TB_PAD 32
 #define K2A_TB_PADDED(steps) (((steps) + (K2A_TB_PAD - 1)) / K2A_TB_PAD * K2A_TB_PAD)
 
+/* packed traceback words: single-gap kernels of the 16-row geometries write 4 bits per cell (2-bit winner + E / F continuation,
+ * the int32 kernels' code), everything else one byte per cell in the reference's layout (ksw2.h:125-128) */
+#define K2A_PK_NIBBLES(C, dual) (!(dual) && (C) == 16)
+#define K2A_PK_TB_BYTES(C, dual) (K2A_PK_NIBBLES(C, dual) ? (C) : 2 * (C))        /* per lane-step: C rows x 2 alignments */
+
 /* batch-uniform scoring, passed by value to the kernel */
 typedef struct K2aScoring {
 	int32_t q, e, q2, e2;        /* gap open / extend; (q2,e2) only for the two-piece model, q+e <= q2+e2 */

@@ -330,7 +330,7 @@ static const fill_mp_fn g_fill_mp_lds[2] = { sim_fill_mp<64, 16, false, 1, true>
 static const trace_fn g_trace[K2A_NCFG][2] = { TRACE_ROW(16, 8, false), TRACE_ROW(64, 8, false), TRACE_ROW(64, 16, false),
                                                TRACE_ROW(64, 32, false), TRACE_ROW(64, 16, true) };
 
-template<int G, int C, bool MP = false>
+template<int G, int C, bool DUAL, bool MP = false>
 static void sim_trace_pk(const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb, K2aResult *res, uint32_t *cig)
 {
 	for (int t = 0; t < 2 * ntasks; ++t) {
@@ -340,7 +340,7 @@ static void sim_trace_pk(const K2aPair *pairs, const uint32_t *order2, int ntask
 		const K2aPair pr = pairs[pi];
 		int n = 0;
 		if (res[pi].ti >= 0 && res[pi].tj >= 0)
-			n = k2a_trace_walk<G, C, 2, MP>(tb + pr.tb_off, half, res[pi].ti, res[pi].tj, cig + pr.cig_off, pr.qlen, pr.tlen, pr.w);
+			n = k2a_trace_pair_pk<G, C, DUAL, MP>(tb + pr.tb_off, half, res[pi].ti, res[pi].tj, cig + pr.cig_off, pr.qlen, pr.tlen, pr.w);
 		res[pi].n_cigar = n;
 	}
 }
@@ -356,7 +356,8 @@ static const fill_pk_fn g_fill_pk_lds[2][2] = {
 	{ sim_fill_pk<64, 16, true, 1, true, false, true>,  sim_fill_pk<64, 16, true, 2, true, false, true> } };
 /* the simulator takes the LDS form of the row state unless KSW2AMD_LDSROWS=0 (the GPU launcher decides by the number of tasks) */
 static bool sim_use_ldsrows(void) { const char *ev = getenv("KSW2AMD_LDSROWS"); return !ev || atoi(ev) != 0; }
-static const trace_fn g_trace_pk[K2A_NPKCFG] = { sim_trace_pk<8, 18>, sim_trace_pk<16, 8>, sim_trace_pk<64, 8>, sim_trace_pk<64, 16>, sim_trace_pk<64, 16, true> };
+#define TRACE_PK_ROW(D) { sim_trace_pk<8, 18, D>, sim_trace_pk<16, 8, D>, sim_trace_pk<64, 8, D>, sim_trace_pk<64, 16, D>, sim_trace_pk<64, 16, D, true> }
+static const trace_fn g_trace_pk[2][K2A_NPKCFG] = { TRACE_PK_ROW(false), TRACE_PK_ROW(true) };
 
 
 /* mirrors k2a_exts_kernel: one alignment per wavefront, diagonal-major, K2A_DM_SLOTS slots of 64 target positions */
@@ -926,10 +927,10 @@ int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax,
 	if (ntasks > 0) (lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode])(*sc, pairs, order2, ntasks, seq, tb, res);
 	return 0;
 }
-int k2a_shim_launch_trace_pk(int cfg, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb,
+int k2a_shim_launch_trace_pk(int cfg, int dual, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb,
                              K2aResult *res, uint32_t *cig, void *)
 {
-	if (ntasks > 0) g_trace_pk[cfg](pairs, order2, ntasks, tb, res, cig);
+	if (ntasks > 0) g_trace_pk[dual ? 1 : 0][cfg](pairs, order2, ntasks, tb, res, cig);
 	return 0;
 }
 int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb,
