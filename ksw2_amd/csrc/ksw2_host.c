@@ -1228,7 +1228,7 @@ static int pool_min_pairs(void)
 	return e && atoi(e) > 0 ? atoi(e) : 0;
 }
 
-static int plan_chunks(int n, double bytes, double cells, int workers, int ndev, int with_cigar)
+static int plan_chunks(int n, double bytes, double cells, int workers, int ndev, int with_cigar, double path_steps)
 {
 	const char *e1 = getenv("KSW2AMD_CHUNK_MB"), *e2 = getenv("KSW2AMD_CHUNK_GCELLS");
 	const double cap_b = (e1 && atof(e1) > 0 ? atof(e1) : 128.0) * 1048576.0, cap_c = (e2 && atof(e2) > 0 ? atof(e2) : 40.0) * 1e9;
@@ -1252,6 +1252,15 @@ static int plan_chunks(int n, double bytes, double cells, int workers, int ndev,
 		double kc = cells / cap_c;
 		if (kc > (double)n / 4096.0) kc = (double)n / 4096.0;
 		if (kc > k) k = kc;
+	}
+	/* A fill kernel lasts at least its longest alignment's step count (about 2.5 us per step, however few wavefronts it has), and
+	 * the workers' kernels run side by side: nchunks / workers rounds of that must not exceed what the device needs for the
+	 * whole batch's cells anyway (about 2e12 / 1e12 cells per second without / with CIGARs).  Cutting 4 096 reads of 10 k x 10 k
+	 * into 18 chunks made three rounds of 23 ms out of one. */
+	{
+		const double total_s = cells / (with_cigar ? 1e12 : 2e12), path_s = path_steps * 2.5e-6;
+		const double kmax = path_s > 0 ? (double)workers * (total_s / path_s > 1.0 ? total_s / path_s : 1.0) : k;
+		if (k > kmax) k = kmax;
 	}
 	if (ndev > 1 && k < 3 * workers) k = 3 * workers;      /* several devices: finer grains balance them */
 	if (k > n / min_chunk) k = n / min_chunk;
@@ -1351,17 +1360,22 @@ static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc
 	if (k2a_shim_device_count() <= 0) return fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend());
 	if (n >= (pool_min_pairs() ? pool_min_pairs() : 512) && tpd > 0 && !g_is_worker) {
 		const int workers = tpd * (g_ndev_set > 0 ? g_ndev_set : 1);
-		double *cost = (double*)malloc(sizeof(double) * (size_t)n), bytes = 0, cells = 0, total = 0;
+		double *cost = (double*)malloc(sizeof(double) * (size_t)n), bytes = 0, cells = 0, total = 0, path = 0;
 		int i, nchunks, rc = 0;
 		if (cost) {
 			for (i = 0; i < n; ++i) {
 				const int ql = imax(pairs[i].qlen, 0), tl = imax(pairs[i].tlen, 0), mx = imax(ql, tl);
 				const double b = (double)ql + tl, c = ql && tl ? (double)band_cells(ql, tl, (pairs[i].w < 0 || pairs[i].w > mx) ? mx : pairs[i].w) : 0;
 				bytes += b; cells += c;
+				{	/* steps of the pair's fill: columns + strips; wide bands on long targets run as generations of 1024 rows, four at a time */
+					const int wq = (pairs[i].w < 0 || pairs[i].w > mx) ? mx : pairs[i].w;
+					const double st = (wq > 1040 && tl > 2048) ? (double)((tl + 4095) / 4096) * (ql + 64) * 1.4 : (double)ql + tl / 8.0;
+					if (st > path) path = st;
+				}
 				cost[i] = 1.0 + c + 64.0 * b;              /* a byte costs the host about as much as 64 cells cost the device */
 				total += cost[i];
 			}
-			nchunks = plan_chunks(n, bytes, cells, workers, g_ndev_set, !(pairs[0].flag & KSW_EZ_SCORE_ONLY));
+			nchunks = plan_chunks(n, bytes, cells, workers, g_ndev_set, !(pairs[0].flag & KSW_EZ_SCORE_ONLY), path);
 			if (nchunks >= 2) {
 				ext_ctx_t ctx;
 				ctx.dual = dual; ctx.scalar = scalar; ctx.km = km; ctx.sc = sc; ctx.pairs = pairs; ctx.ez = ez;

@@ -29,15 +29,20 @@
 #define K2A_PKMP_DEAD (-8192)       /* relative values below this are -inf */
 #define K2A_PKMP_WAVES 4            /* wavefronts (generations in flight) per pair of alignments */
 #define K2A_PKMP_SPILL_WORDS(C) (64 * (C) * 2 * 2)     /* uint32 per wavefront: one 64-bit key per row, lane and alignment */
-#define K2A_PKMP_BND_WORDS(qlen, dual) ((size_t)(qlen) * ((dual) ? 5 : 4) + 16)   /* uint32 per task: {H, E, baseA, baseB}[qlen] (+ E~[qlen]) */
+#define K2A_PKMP_BND_WORDS(qlen, dual) ((((size_t)(qlen) * ((dual) ? 5 : 4) + 16) + 3) & ~(size_t)3)   /* uint32 per task: {H, E, baseA, baseB}[qlen] (+ E~[qlen]), rounded so that the 64-bit keys behind it stay aligned */
 
 #if defined(__HIP_DEVICE_COMPILE__)
 K2A_FN void k2a_key_max(unsigned long long *slot, unsigned long long key)
 {
 	__hip_atomic_fetch_max(slot, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      /* result unused: no-return atomic at L2 */
 }
+K2A_FN unsigned long long k2a_key_load(const unsigned long long *slot)       /* past the L1, where an older copy of the slot may sit */
+{
+	return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 #else
 K2A_FN void k2a_key_max(unsigned long long *slot, unsigned long long key) { if (key > *slot) *slot = key; }
+K2A_FN unsigned long long k2a_key_load(const unsigned long long *slot) { return *slot; }
 #endif
 
 template<int C, bool DUAL, int MODE>
@@ -155,7 +160,7 @@ struct K2aLanePkMp {
 				const int i = P.i0 + c;
 				if (i < P.tlen && !bdrop) {
 					const bool reach = i + P.w >= P.qlen - 1;
-					const unsigned long long key = spill[2 * c + half];
+					const unsigned long long key = k2a_key_load(&spill[2 * c + half]);
 					const int hend = (int)(int16_t)(rowbuf[c] >> sh) + base - sc.e * i;
 					const int H = (int)((uint32_t)(key >> 32) ^ 0x80000000u) - sc.e * i;
 					const int j = FIRSTJ ? 0xffff - (int)(key & 0xffffu) : (int)(key & 0xffffu);

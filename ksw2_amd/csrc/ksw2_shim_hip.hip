@@ -745,7 +745,7 @@ k2a_fill_pkmp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 				}
 				L.P.qb = L.P.next_query_codes(-1);
 				kdone = -1;
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       /* the cleared keys are in place before any atomic on them */
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   /* the cleared keys are in place before any atomic on them */
 			}
 			const int k0 = (phase - pstart[g]) * T, k1 = min(nsteps, k0 + T);
 			for (int k = k0; k < k1; ++k) {
@@ -783,8 +783,7 @@ k2a_fill_pkmp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 				const bool nfin = L.need_fin(k);
 				if (__builtin_amdgcn_ballot_w64(nfin) != 0) {
 					if (nfin) L.flush_rowmax();
-					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   /* the keys' atomics are done ... */
-					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   /* ... and no stale L1 line of them is read */
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   /* the keys' atomics (performed at L2) are done; do_fin reads them past L1 */
 					if (nfin) L.do_fin(sc, bkA, bkB, zdropA, zdropB, rowbuf[wave]);
 					__builtin_amdgcn_wave_barrier();
 				}
@@ -801,9 +800,12 @@ k2a_fill_pkmp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 				g += W;
 			}
 		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		/* producer and consumer of a boundary column are wavefronts of this workgroup: the stores only have to have left the CU's
+		 * write-through L1 (workgroup-scope release = wait for them), the consumer's loads bypass L1.  An agent-scope release here
+		 * would write back the whole L2 -- with the traceback stream in it -- every 64 steps. */
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		__syncthreads();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 	}
 	__syncthreads();
 	if (threadIdx.x == 0) {

@@ -819,9 +819,9 @@ def test_packed_generation_serial(lib, monkeypatch):
     and against the int32 generation-serial kernels on a 25 k x 25 k pair."""
     mat = synth.simple_mat(5, 2, 4, -1)
     cases = [(2100, -1, False, 0, -1, 6), (2600, -1, False, po.SCORE_ONLY, -1, 10), (2200, 1100, True, 0, -1, 4), (2300, -1, True, po.RIGHT, 300, 6),
-             (3000, 1300, False, po.RIGHT, -1, 2), (4300, -1, False, po.EXTZ_ONLY, 400, 4), (5200, 1200, True, 0, 400, 4), (9000, -1, False, 0, -1, 2)]
+             (3000, 1300, False, po.RIGHT, -1, 2), (2301, -1, True, po.SCORE_ONLY, -1, 3), (2403, 1500, True, po.SCORE_ONLY, 300, 1), (4300, -1, False, po.EXTZ_ONLY, 400, 4), (5200, 1200, True, 0, 400, 4), (9000, -1, False, 0, -1, 2)]
     for L, w, dual, flag, zd, n in cases:
-        q, t = synth.fixed_batch(9, n // 2, L, L + 37, sub=0.05, ind=0.08, tail_random_frac=0.3 if zd >= 0 else 0.0, tail_pairs=0.5 if zd >= 0 else 0.0)
+        q, t = synth.fixed_batch(9, (n + 1) // 2, L, L + 37, sub=0.05, ind=0.08, tail_random_frac=0.3 if zd >= 0 else 0.0, tail_pairs=0.5 if zd >= 0 else 0.0)
         qs, ts = [q[i // 2] for i in range(n)], [t[i // 2] for i in range(n)]
         p = lib.make_batch(qs, ts, mat, 4, 2, 24, 1, w=w, zdrop=zd, flag=flag).plan(dual)
         assert p.packed_pairs() == n
@@ -835,3 +835,43 @@ def test_packed_generation_serial(lib, monkeypatch):
         b = lib.extz_batch(qs, ts, mat, 4, 2, w=-1, zdrop=-1, flag=flag)
         monkeypatch.delenv("KSW2AMD_NO_PKMP")
         assert not diff(a[0], b[0], gu.FIELDS + ["cigar"]) and not diff(a[1], b[1], gu.FIELDS + ["cigar"])
+
+
+def test_two_rank_nccl_scatter_gather(lib):
+    """ksw2_amd/parallel.py over RCCL: two ranks on two GPUs, rank 0 scatters a ragged batch point to point and gathers records and
+    CIGARs.  Needs two devices (the 1-GPU test box skips it; the gloo twin in tests/test_sharding_gloo.py runs everywhere)."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+import ksw2_amd as ka
+from ksw2_amd import synth, parallel
+from oracle import pyoracle as po
+rank = int(os.environ["RANK"])
+torch.cuda.set_device(rank)
+dist.init_process_group("nccl", rank=rank, world_size=2, device_id=torch.device("cuda", rank))
+lib = ka.library(); lib.set_device(rank)
+mat = synth.simple_mat(5, 2, 4, -1)
+qs = ts = None
+if rank == 0:
+    rng = np.random.Generator(np.random.PCG64(3))
+    pairs = synth.ragged_pairs(rng, 41, 50, 900, sub=0.05, ind=0.1)
+    qs, ts = [p[0] for p in pairs], [p[1] for p in pairs]
+res = parallel.sharded(lib, "extd", qs, ts, dict(mat=mat, q=4, e=2, q2=24, e2=1), w=100, zdrop=200, flag=0)
+if rank == 0:
+    ok = all(all(po.align("oracle", "extd2", qs[i], ts[i], mat, 4, 2, 24, 1, w=100, zdrop=200)[k] == res[i][k] for k in ka.FIELDS + ["cigar"]) for i in range(41))
+    print("NCCL_SHARD_OK" if ok else "NCCL_SHARD_BAD")
+dist.destroy_process_group()
+''' % root
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, "-c", worker], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "NCCL_SHARD_OK" in outs[0][0], outs
