@@ -1239,10 +1239,10 @@ static int plan_chunks(int n, double bytes, double cells, int workers, int ndev,
 	else {
 		if (n < 512 || (bytes < 4.0 * 1048576.0 && cells < 2e9)) return 0;
 		/* score-only batches: one chunk per worker (packing in parallel; fewer, larger kernels).  With CIGARs the download and the
-		 * ksw_extz_t assembly of a chunk cost as much as its kernels: three chunks per worker, so that while one worker fetches
-		 * the others' kernels keep the device busy (config 3: one chunk per worker left the device idle a third of the call) */
+		 * ksw_extz_t assembly of a chunk cost as much as its kernels: two chunks per worker, double-buffered (ext_chunk), so
+		 * that while a worker fetches, kernels keep the device busy (config 3: one chunk per worker left it idle a third of the call) */
 		k = bytes / (2.0 * 1048576.0);
-		if (k > (with_cigar ? 3 : 1) * workers) k = (with_cigar ? 3 : 1) * workers;
+		if (k > (with_cigar ? 2 : 1) * workers) k = (with_cigar ? 2 : 1) * workers;
 	}
 	if (bytes / cap_b > k) k = bytes / cap_b;
 	/* the cell cap never cuts a chunk below 4096 pairs: 2048 packed wavefronts, two per SIMD -- kernels of fewer wavefronts leave
@@ -1253,21 +1253,22 @@ static int plan_chunks(int n, double bytes, double cells, int workers, int ndev,
 		if (kc > (double)n / 4096.0) kc = (double)n / 4096.0;
 		if (kc > k) k = kc;
 	}
-	/* A fill kernel lasts at least its longest alignment's step count (about 2.5 us per step, however few wavefronts it has), and
-	 * the workers' kernels run side by side: nchunks / workers rounds of that must not exceed what the device needs for the
-	 * whole batch's cells anyway (about 2e12 / 1e12 cells per second without / with CIGARs).  Cutting 4 096 reads of 10 k x 10 k
-	 * into 18 chunks made three rounds of 23 ms out of one. */
+	/* A fill kernel lasts at least its longest alignment's step count (2.5 / 4.5 us per step without / with traceback, however
+	 * few wavefronts it has), and kernels of long alignments do not really overlap: each has enough workgroups to hold every
+	 * SIMD, and its longest tasks are dispatched first (r2_pipeline_traces.txt: 18 chunks of config 5 = 18 x the 250 ms of a
+	 * 20 k read instead of 190 ms for everything).  So for long alignments the chunk count is what the batch's cells pay for:
+	 * nchunks x path <= cells / rate.  Short alignments (path below 10 ms) keep one (two with CIGARs) chunk per worker. */
 	{
-		const double total_s = cells / (with_cigar ? 1e12 : 2e12), path_s = path_steps * 2.5e-6;
-		const double kmax = path_s > 0 ? (double)workers * (total_s / path_s > 1.0 ? total_s / path_s : 1.0) : k;
-		if (k > kmax) k = kmax;
+		const double total_s = cells / (with_cigar ? 1e12 : 2e12), path_s = path_steps * (with_cigar ? 4.5e-6 : 2.5e-6);
+		if (path_s >= 0.010) { if (k > total_s / path_s) k = total_s / path_s; }
+		else if (k > (with_cigar ? 2 : 1) * workers && bytes / cap_b <= (with_cigar ? 2 : 1) * workers) k = (with_cigar ? 2 : 1) * workers;
 	}
 	if (ndev > 1 && k < 3 * workers) k = 3 * workers;      /* several devices: finer grains balance them */
 	if (k > n / min_chunk) k = n / min_chunk;
 	return k < 2 ? 0 : (int)(k + 0.999);
 }
 
-typedef struct { int dual, scalar; void *km; const ksw2amd_scoring_t *sc; const ksw2amd_pair_t *pairs; ksw_extz_t *ez; } ext_ctx_t;
+typedef struct { int dual, scalar, dbuf; void *km; const ksw2amd_scoring_t *sc; const ksw2amd_pair_t *pairs; ksw_extz_t *ez; } ext_ctx_t;
 static double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 static int trace_on(void) { static int t = -1; if (t < 0) t = getenv("KSW2AMD_TRACE") != 0; return t; }
 
@@ -1284,11 +1285,12 @@ static int ext_finish(ext_ctx_t *c, pend_t *pd)
 	return rc;
 }
 
-/* One chunk on a pool worker.  Default: pack, upload, run, fetch -- the workers (KSW2AMD_THREADS per device, default 6) are
- * what overlaps the phases of different chunks.  KSW2AMD_DBUF=1 lets a worker queue chunk k + 1 before it waits for chunk k
- * (two plans per worker); measured on the 10 k headline (profiles/r2_chunk_grid.txt) that is slower -- 2 720 vs 3 100 GCUPS at
- * 128 MB chunks: twice the plans in flight, each kernel filling less of the device -- so it is off.  A chunk that does not fit
- * one plan (traceback memory) takes the serial path. */
+/* One chunk on a pool worker: pack, upload, run, fetch.  Single-buffered, the workers are what overlaps the phases of
+ * different chunks; double-buffered (`dbuf`), a worker queues chunk k + 1 before it waits for chunk k, so the device always has
+ * kernels behind the ones it runs while the workers download and assemble CIGARs.  Measured (profiles/r2_chunk_grid.txt,
+ * r2_pipeline_traces.txt): score-only long reads lose with it (10 k headline 2 720 vs 3 100 GCUPS: twice the plans in flight, each
+ * kernel filling less of the device), short reads with CIGARs gain (config 3: 735 vs 540): run_batch decides (KSW2AMD_DBUF=0/1
+ * forces).  A chunk that does not fit one plan (traceback memory) takes the serial path. */
 static int ext_chunk(void *ctx_, int beg, int end, int share, pend_t *pd)
 {
 	ext_ctx_t *c = (ext_ctx_t*)ctx_;
@@ -1303,7 +1305,7 @@ static int ext_chunk(void *ctx_, int beg, int end, int share, pend_t *pd)
 	else if (bytes > ((size_t)256 << 20)) {
 		if (k2a_shim_mem_info(&free_b, &total_b)) return fail(KSW2AMD_E_NODEVICE, "mem_info: %s", k2a_shim_last_error());
 		/* what is free now, plus what this worker's pending plan and cache will hand back, over two plans per worker */
-		budget = device_budget(free_b, total_b, share);
+		budget = device_budget(free_b, total_b, share * (c->dbuf ? 2 : 1));
 	}
 	if (bytes > budget) {
 		rc = ext_finish(c, pd);
@@ -1322,7 +1324,7 @@ static int ext_chunk(void *ctx_, int beg, int end, int share, pend_t *pd)
 	rc2 = ext_finish(c, pd);
 	if (rc) { ksw2amd_plan_destroy(p); return rc; }
 	pd->p = p; pd->beg = beg;
-	if (!env_flag("KSW2AMD_DBUF", 0)) { rc = ext_finish(c, pd); if (!rc2) rc2 = rc; }    /* default: finish this chunk before taking the next */
+	if (!c->dbuf) { rc = ext_finish(c, pd); if (!rc2) rc2 = rc; }                       /* single-buffered: finish this chunk before taking the next */
 	return rc2;
 }
 
@@ -1344,8 +1346,8 @@ static int run_pooled(chunk_fn fn, void *ctx, int n, const double *cost, double 
 	memset(&j, 0, sizeof(j));
 	j.fn = fn; j.ctx = ctx; j.cbeg = cbeg;
 	j.nchunks = make_chunks(n, cost, total, nchunks, workers, cbeg);
-	j.share = tpd;
 	job_devices(&j);
+	j.share = imax(1, imin(tpd, (j.nchunks + j.ndev - 1) / j.ndev));      /* plans alive per device at a time: the memory budget's divisor */
 	if (pool_run(&j)) { free(cbeg); return 0; }
 	free(cbeg);
 	if (j.rc) snprintf(g_err, sizeof(g_err), "%s", j.err);
@@ -1379,6 +1381,10 @@ static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc
 			if (nchunks >= 2) {
 				ext_ctx_t ctx;
 				ctx.dual = dual; ctx.scalar = scalar; ctx.km = km; ctx.sc = sc; ctx.pairs = pairs; ctx.ez = ez;
+				{	/* double-buffer short reads with CIGARs (see ext_chunk) */
+					const char *ev = getenv("KSW2AMD_DBUF");
+					ctx.dbuf = ev && *ev ? atoi(ev) != 0 : (!(pairs[0].flag & KSW_EZ_SCORE_ONLY) && path * 4.5e-6 < 0.010);
+				}
 				if (run_pooled(ext_chunk, &ctx, n, cost, total, nchunks, &rc)) { free(cost); return rc; }
 			}
 			free(cost);

@@ -23,7 +23,8 @@ rng = np.random.Generator(np.random.PCG64(seed))
 lib = ka.Library(os.environ["KSW2AMD_FUZZ_LIB"]) if os.environ.get("KSW2AMD_FUZZ_LIB") else ka.library()      # the simulator build, for reproducing on the CPU
 ENVS = [{}, {"KSW2AMD_SOLO": "1"}, {"KSW2AMD_SOLO": "all"}, {"KSW2AMD_LDSROWS": "0"}, {"KSW2AMD_LDSROWS": "1"}, {"KSW2AMD_NO_PK": "1"},
         {"KSW2AMD_SIMDS": "0"}, {"KSW2AMD_EXTF_WIN": "1"}, {"KSW2AMD_EXTF_LDS": "1"}, {"KSW2AMD_EXTS_REG": "1"},
-        {"KSW2AMD_POOL_MIN": "8", "KSW2AMD_THREADS": "3"}, {"KSW2AMD_POOL_MIN": "4", "KSW2AMD_SIMDS": "0"}]
+        {"KSW2AMD_POOL_MIN": "8", "KSW2AMD_THREADS": "3"}, {"KSW2AMD_POOL_MIN": "4", "KSW2AMD_SIMDS": "0"}, {"KSW2AMD_NO_PKMP": "1"},
+        {"KSW2AMD_SIMDS": "0", "KSW2AMD_KEEP_LEFTOVERS": "1"}]
 KEYS = sorted({k for e in ENVS for k in e})
 t0 = time.time()
 rounds = pairs = 0
@@ -53,6 +54,19 @@ while time.time() - t0 < budget:
         mode = int(rng.choice([po.SCORE_ONLY, 0, po.RIGHT]))
         fl = np.array([mode | (po.EXTZ_ONLY if rng.random() < 0.3 else 0) | (po.REV_CIGAR if rng.random() < 0.3 else 0) |
                        (po.GENERIC_SC if rng.random() < 0.2 else 0) | (po.EQX if dual and rng.random() < 0.2 else 0) for _ in range(n)])
+        if not LONG and rng.random() < 0.3:                                 # the SSE kernels' own results: opt-in flag, or the APPROX_DROP route
+            wn = rng.choice([-1, 0, 1, 2, 5, 9, 16, 33, 64, 100, 300], size=n)
+            fl2 = np.array([int(f) & ~po.EQX | (po.EQX if dual and rng.random() < 0.1 and not (f & po.SCORE_ONLY) else 0) |
+                            int(rng.choice([ka.KSW2AMD_EZ_SSE_COMPAT, ka.KSW2AMD_EZ_SSE_COMPAT | po.APPROX_MAX, po.APPROX_MAX | po.APPROX_DROP])) for f in fl])
+            res = lib.extd_batch(qs, ts, mat, q, e, q2, e2, w=wn, zdrop=zd, end_bonus=eb, flag=fl2) if dual else \
+                lib.extz_batch(qs, ts, mat, q, e, w=wn, zdrop=zd, end_bonus=eb, flag=fl2)
+            for i, r in enumerate(res):
+                exp = po.align("oracle", "extd2_sse" if dual else "extz2_sse", qs[i], ts[i], mat, q, e, q2, e2, w=int(wn[i]), zdrop=int(zd[i]),
+                               end_bonus=int(eb[i]), flag=int(fl2[i]) & ~ka.KSW2AMD_EZ_SSE_COMPAT)
+                assert not diff(r, exp), ("sse-compatible", env, dual, len(qs[i]), len(ts[i]), int(wn[i]), int(zd[i]), hex(int(fl2[i])))
+            pairs += n
+            rounds += 1
+            continue
         try:
             check_batch(lib, dual, qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl)
         except AssertionError:
