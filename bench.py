@@ -180,10 +180,12 @@ def recorded_traffic(workload):
 class Job:
     """One workload on this rank: host batch, the library's batch object, and the two measurements."""
 
-    def __init__(self, lib, name, wl, rank, n_override=None, approx=False):
-        self.lib, self.name, self.rank = lib, name, rank
+    def __init__(self, lib, name, wl, rank, n_override=None, approx=False, sse=False):
+        self.lib, self.name, self.rank, self.sse = lib, name, rank, sse
         if approx:
             wl = dict(wl, flag=wl["flag"] | 0x08)
+        if sse:                                  # the SSE kernels' own results (DESIGN.md 3.9): every pair through k2a_ssec_kernel
+            wl = dict(wl, flag=wl["flag"] | ksw2_amd.KSW2AMD_EZ_SSE_COMPAT)
         self.wl = wl
         self.n = n_override or wl["n"]
         t0 = time.perf_counter()
@@ -242,7 +244,7 @@ class Job:
         if nres and nres < self.n:          # a plan of the whole batch does not fit one device: a slice of it
             S = SCORING
             b = self.lib.make_batch(self.q[:nres], self.t[:nres], self.mat, S["q"], S["e"], S["q2"], S["e2"], w=wl["w"], zdrop=wl["zdrop"], end_bonus=0, flag=wl["flag"])
-        plan = b.plan() if self.kind in ("exts", "extf") else b.plan(wl["dual"])
+        plan = b.plan() if self.kind in ("exts", "extf") else b.sse_plan(wl["dual"]) if self.sse else b.plan(wl["dual"])
         cells = plan.cells()
         for _ in range(warmup):
             plan.run(stream)
@@ -276,7 +278,8 @@ def describe(job, world):
     func = {"extf": "extf2 gap-linear X-drop", "exts": "exts2 splice-aware", "extd": "extd2 dual-gap", "extz": "extz2 affine"}[job.kind]
     shape = "qlen in [300,20000] tlen from the channel" if wl.get("ragged") else "qlen=%d tlen=%d" % (wl["qlen"], wl["tlen"])
     return "%s: %d pairs/step/GPU, %s band=%d zdrop=%d %s %s" % (job.name, job.n, shape, wl["w"], wl["zdrop"], func,
-                                                                 ("score-only" if job.score_only else "CIGAR") + (" APPROX_MAX" if wl["flag"] & 0x08 else ""))
+                                                                 ("score-only" if job.score_only else "CIGAR") + (" APPROX_MAX" if wl["flag"] & 0x08 else "") +
+                                                                 (" SSE-compatible mode" if getattr(job, "sse", False) else ""))
 
 
 def roofline_of(job, res, workload_key):
@@ -298,6 +301,8 @@ def roofline_of(job, res, workload_key):
 def dtype_of(job, res):
     if job.kind == "extf":
         return "u8 (wrapping, one position per lane)"
+    if getattr(job, "sse", False):
+        return "i8 differences + int32 H (the SSE kernels' data flow, one position per lane)"
     npk = res["packed_pairs"]
     return "int16x2 (packed, two alignments per lane)" if npk == res["n"] else "int32" if npk == 0 else "int16x2 + int32"
 
@@ -357,6 +362,7 @@ def main():
     ap.add_argument("--no-also", action="store_true")
     ap.add_argument("--resident-only", action="store_true", help="profiling: only the HBM-resident kernel loop (what rocprofv3 should see)")
     ap.add_argument("--approx", action="store_true", help="OR KSW_EZ_APPROX_MAX into the flags (score + corner CIGAR only, as in the reference)")
+    ap.add_argument("--sse-compat", action="store_true", help="OR KSW2AMD_EZ_SSE_COMPAT into the flags: the SSE kernels' own results through the SSE-compatible kernels")
     args = ap.parse_args()
 
     # N > 1 without a launcher: start our own ranks BEFORE anything touches a GPU (a process that has initialised HIP is never
@@ -396,7 +402,7 @@ def main():
         torch.cuda.synchronize()
 
     # ------------------------------------------------------------------ headline
-    job = Job(lib, args.workload, WORKLOADS[args.workload], rank, args.pairs or None, approx=args.approx)
+    job = Job(lib, args.workload, WORKLOADS[args.workload], rank, args.pairs or None, approx=args.approx, sse=args.sse_compat)
     if args.resident_only:
         res = job.resident(args.steps, args.warmup, stream)
         if rank == 0:
@@ -456,7 +462,7 @@ def main():
             out["config"]["rank0_scatter_gather"] = sg
     # ------------------------------------------------------------------ the other configurations (N = 1: one run covers them all)
     names = ALSO_DEFAULT if args.also is None else [x for x in args.also.split(",") if x]
-    if args.no_also or world > 1 or args.pairs or args.approx or args.workload != "10k":
+    if args.no_also or world > 1 or args.pairs or args.approx or args.sse_compat or args.workload != "10k":
         names = [] if args.also is None else names
     also = []
     for name in names:

@@ -1260,7 +1260,16 @@ static int plan_chunks(int n, double bytes, double cells, int workers, int ndev,
 	 * nchunks x path <= cells / rate.  Short alignments (path below 10 ms) keep one (two with CIGARs) chunk per worker. */
 	{
 		const double total_s = cells / (with_cigar ? 1e12 : 2e12), path_s = path_steps * (with_cigar ? 4.5e-6 : 2.5e-6);
-		if (path_s >= 0.010) { if (k > total_s / path_s) k = total_s / path_s; }
+		if (path_s >= 0.010) {
+			if (with_cigar) { if (k > total_s / path_s) k = total_s / path_s; }
+			else {
+				/* score only: a kernel of exactly two wavefronts per SIMD (4096 pairs, two per wavefront) has no tail, and such
+				 * kernels follow each other without a gap -- 12 chunks of 4096 pairs: 3 050 GCUPS, 9 of 5461: 2 675 */
+				const double units = (double)n / 4096.0;
+				if (k > units) k = units;
+				k = (double)(int)k;
+			}
+		}
 		else if (k > (with_cigar ? 2 : 1) * workers && bytes / cap_b <= (with_cigar ? 2 : 1) * workers) k = (with_cigar ? 2 : 1) * workers;
 	}
 	if (ndev > 1 && k < 3 * workers) k = 3 * workers;      /* several devices: finer grains balance them */
