@@ -207,7 +207,8 @@ struct ksw2amd_plan_s {
 	int splice, s_first[3][2][3], s_count[3][2][3];   /* [mode][matrix variant][window class: 8 slots, 16 slots, state in HBM] */
 	K2aSplice s_par[2];
 	/* gap-linear X-drop plans (ksw2amd_extf_plan_create, splice == 2): tasks grouped by where the state arrays live */
-	int f_first[6], f_count[6];
+	int f_first[7], f_count[7];          /* [6]: one extension per lane, groups of 64 with interleaved sequences (ksw2_lane_extf.h) */
+	size_t f_state_bytes;                /* that class: zeroed state rows at the start of d_tb, re-zeroed by every run */
 	K2aExtf f_par;
 	/* SSE-compatible plans (ksw2amd_sse_plan_create, splice == 3): tasks grouped by kernel mode in s_first / s_count[mode][0][0] */
 	K2aSsec c_par;
@@ -1912,10 +1913,11 @@ void ksw_exts2_sse2(void *km, int qlen, const uint8_t *query, int tlen, const ui
 ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n, const ksw2amd_fpair_t *pairs)
 {
 	ksw2amd_plan_t *p;
-	int i, c, span;
+	int i, c, span, nlane = 0, use_lane;
 	size_t off = 0;
-	uint32_t fill[6];
+	uint32_t fill[7];
 	void *up;
+	sort_t *srt = 0;
 
 	g_err[0] = 0;
 	if (n < 0 || (n > 0 && !pairs)) { fail(KSW2AMD_E_PARAM, "extf: bad arguments%s", 0); return 0; }
@@ -1931,6 +1933,14 @@ ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n
 	p->h_order = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n + 1));
 	if (!p->h_cls || !p->h_half || !p->h_flag || !p->h_pairs || !p->h_res || !p->h_order) { fail(KSW2AMD_E_NOMEM, "extf: host allocation failed%s", 0); goto err; }
 	p->f_par.mch = mch; p->f_par.mis = mis < 0 ? mis : -mis; p->f_par.e = e;      /* ksw2_extf2_sse.c:18-20 */
+	/* One extension per lane instead of per wavefront: an order of magnitude fewer instructions per cell, but a wavefront then
+	 * holds 64 extensions and every lane walks its band serially -- worth it from a few wavefronts per CU on
+	 * (KSW2AMD_EXTF_LANE=1 / 0 forces it on / off; profiles/r2_extf_lane.txt) */
+	{
+		const char *ev = getenv("KSW2AMD_EXTF_LANE");
+		use_lane = ev && *ev ? atoi(ev) != 0 : n >= 32768;
+		if (getenv("KSW2AMD_EXTF_LDS") || getenv("KSW2AMD_EXTF_WIN") || getenv("KSW2AMD_EXTF_HBM")) use_lane = ev && *ev ? atoi(ev) != 0 : 0;
+	}
 	for (i = 0; i < n; ++i) {
 		const ksw2amd_fpair_t *a = &pairs[i];
 		K2aPair *d = &p->h_pairs[i];
@@ -1948,25 +1958,70 @@ ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n
 		if (!getenv("KSW2AMD_EXTF_LDS") && (span > 128 || c > 0)) c = span <= K2A_EXTF_WIN_SPAN(4) ? 4 : span <= K2A_EXTF_WIN_SPAN(8) ? 5 : c;
 		if (getenv("KSW2AMD_EXTF_WIN")) c = span <= K2A_EXTF_WIN_SPAN(4) ? 4 : span <= K2A_EXTF_WIN_SPAN(8) ? 5 : c;   /* tests: the window wherever it fits */
 		if (getenv("KSW2AMD_EXTF_HBM")) c = 3;            /* tests: every pair through the HBM-state kernel */
+		p->cells += band_cells(a->qlen, a->tlen, d->w);
+		if (use_lane) { p->h_cls[i] = 6; ++p->f_count[6]; ++nlane; continue; }          /* sequences and state: grouped below */
 		if (c == 3) { d->tb_off = p->tb_bytes; p->tb_bytes += align_up(3 * align_up((size_t)a->tlen, 16), 256); }
 		p->h_cls[i] = (int8_t)c; ++p->f_count[c];
 		off = align_up(off, 4); d->qoff = (uint32_t)off; off += (size_t)a->qlen;
 		off = align_up(off, 4); d->toff = (uint32_t)off; off += (size_t)a->tlen;
 		if (off > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "extf: more than 4 GiB of sequence in one plan%s", 0); goto err; }
-		p->cells += band_cells(a->qlen, a->tlen, d->w);
 	}
-	for (c = 0, i = 0; c < 6; ++c) { p->f_first[c] = i; fill[c] = (uint32_t)i; i += p->f_count[c]; }
+	for (c = 0, i = 0; c < 7; ++c) { p->f_first[c] = i; fill[c] = (uint32_t)i; i += p->f_count[c]; }
+	if (nlane) {
+		/* groups of 64 pairs of similar shape (sorted by target, query, band); per group: target codes and the reversed query
+		 * interleaved by lane in the sequence arena, three state arrays of `rows` dwords per lane in the scratch block */
+		int k = 0, g;
+		srt = (sort_t*)malloc(sizeof(sort_t) * (size_t)nlane);
+		if (!srt) { fail(KSW2AMD_E_NOMEM, "extf: host allocation failed%s", 0); goto err; }
+		for (k = 0, c = 0; c < n; ++c)
+			if (p->h_cls[c] == 6) {
+				srt[k].idx = (uint32_t)c; srt[k].tf = (uint32_t)p->h_pairs[c].w;
+				srt[k].cost = ((int64_t)p->h_pairs[c].tlen << 32) + p->h_pairs[c].qlen; ++k;
+			}
+		qsort(srt, (size_t)nlane, sizeof(sort_t), cmp_cost_desc);
+		for (g = 0; g < nlane; g += 64) {
+			const int cnt = imin(64, nlane - g);
+			int tmax = 0, qmax = 0, j;
+			size_t trows, qrows, toff_g, qoff_g;
+			for (j = 0; j < cnt; ++j) { tmax = imax(tmax, p->h_pairs[srt[g + j].idx].tlen); qmax = imax(qmax, p->h_pairs[srt[g + j].idx].qlen); }
+			trows = (align_up((size_t)tmax, 16) + 16) / 4;            /* dwords per lane: the padded target + one block (the followed cell's neighbour) */
+			qrows = (align_up((size_t)qmax, 4) + 64) / 4;             /* the reversed query + the zeros the score runs read past it */
+			off = align_up(off, 256); toff_g = off; off += trows * 256;
+			qoff_g = off; off += qrows * 256;
+			if (off > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "extf: more than 4 GiB of sequence in one plan%s", 0); goto err; }
+			for (j = 0; j < cnt; ++j) {
+				K2aPair *d = &p->h_pairs[srt[g + j].idx];
+				d->toff = (uint32_t)toff_g; d->qoff = (uint32_t)qoff_g; d->pad = (uint32_t)trows;
+				d->tb_off = p->tb_bytes;
+				p->h_order[fill[6]++] = srt[g + j].idx;
+			}
+			p->tb_bytes += 3 * trows * 256;
+		}
+		p->f_state_bytes = p->tb_bytes;                       /* (class 3 blocks, if any, were laid out before: none when this class is on) */
+	}
 	p->ntasks = p->norder = i;
 	if (p->ntasks == 0) return p;
 	p->seq_bytes = align_up(off + 256, 256);
 	p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, p->seq_bytes, &p->cap[BUF_HSEQ]);
 	if (!p->h_seq) { fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
+	if (nlane) memset(p->h_seq, 0, p->seq_bytes);             /* the interleaved blocks read zero past every sequence's end */
 	for (i = 0; i < n; ++i) {
-		if (p->h_cls[i] < 0) continue;
+		if (p->h_cls[i] < 0 || p->h_cls[i] == 6) continue;
 		memcpy(p->h_seq + p->h_pairs[i].qoff, pairs[i].query, (size_t)pairs[i].qlen);
 		memcpy(p->h_seq + p->h_pairs[i].toff, pairs[i].target, (size_t)pairs[i].tlen);
 		p->h_order[fill[p->h_cls[i]]++] = (uint32_t)i;
 	}
+	for (i = 0; i < nlane; ++i) {                             /* lane = position in the class's task list, byte x of lane l at (x / 4 * 64 + l) * 4 + x % 4 */
+		const uint32_t pi = p->h_order[p->f_first[6] + i];
+		const K2aPair *d = &p->h_pairs[pi];
+		const int lane = i & 63, ql = d->qlen, tl = d->tlen;
+		uint8_t *T = p->h_seq + d->toff + 4 * lane, *Q = p->h_seq + d->qoff + 4 * lane;
+		const uint8_t *ts = pairs[pi].target, *qs = pairs[pi].query;
+		int x;
+		for (x = 0; x < tl; ++x) T[(size_t)(x >> 2) * 256 + (x & 3)] = ts[x];
+		for (x = 0; x < ql; ++x) Q[(size_t)(x >> 2) * 256 + (x & 3)] = qs[ql - 1 - x];      /* reversed, like ksw2_extf2_sse.c:31 */
+	}
+	free(srt); srt = 0;
 	p->d_seq = (uint8_t*)cache_get(BUF_SEQ, p->seq_bytes, &p->cap[BUF_SEQ]);
 	p->d_pairs = (K2aPair*)cache_get(BUF_PAIRS, sizeof(K2aPair) * ((size_t)n + 1), &p->cap[BUF_PAIRS]);
 	p->d_res = (K2aResult*)cache_get(BUF_RES, sizeof(K2aResult) * ((size_t)n + 1), &p->cap[BUF_RES]);
@@ -1988,6 +2043,7 @@ ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n
 	p->stream = 0; p->stream_used = 0;             /* uploads complete, see plan_create_ex */
 	return p;
 err:
+	free(srt);
 	ksw2amd_plan_destroy(p);
 	return 0;
 }
@@ -1998,7 +2054,8 @@ static int extf_plan_run(ksw2amd_plan_t *p, void *stream)
 	p->stream = stream; p->ran = 1; p->stream_used = 1;
 	if (p->ntasks == 0) return KSW2AMD_OK;
 	if (k2a_shim_event_record(p->ev[0], stream)) goto err;
-	for (c = 5; c >= 0; --c)
+	if (p->f_count[6] && k2a_shim_memset(p->d_tb, 0, p->f_state_bytes, stream)) goto err;     /* the reference's zeroed arrays (ksw2_extf2_sse.c:25) */
+	for (c = 6; c >= 0; --c)
 		if (p->f_count[c] && k2a_shim_launch_extf(c, &p->f_par, p->d_pairs, p->d_order + p->f_first[c], p->f_count[c], p->d_seq, p->d_tb, p->d_res, stream))
 			goto err;
 	if (k2a_shim_event_record(p->ev[1], stream) || k2a_shim_event_record(p->ev[2], stream)) goto err;

@@ -93,6 +93,66 @@ K2A_FN void k2a_extf_win_cell(const K2aExtf &par, const K2aExtfDiag &d, int r, i
 	sreg = sv;
 }
 
+/* ---- one extension per LANE (k2a_extf_lane_kernel): 64 extensions per wavefront, every lane runs the reference's loop over the
+ * padded blocks of its own pair.  The three byte arrays and the sequences of a group of 64 pairs are interleaved by lane, four
+ * positions per dword -- dword (x >> 2) * 64 + lane holds positions x .. x+3 of that lane's pair -- so a wavefront whose pairs
+ * have the same shape touches one 256-byte row per access.  The query is stored reversed and zero-padded like the reference's
+ * own copy (ksw2_extf2_sse.c:31), QR[k] = query[qlen - 1 - k]: the codes of positions x .. x+3 on anti-diagonal r are QR[k0 + x ..]
+ * with k0 = qlen - 1 - r, one funnel shift of two neighbouring dwords.  Per cell this costs about 25 instructions of ONE lane
+ * (2.7 wavefront instructions per cell in the position-per-lane kernels above, 0.4 here); it needs >= 64 extensions per
+ * wavefront, so the host takes it for large batches (ksw2_host.c). */
+struct K2aExtfLaneMem {
+	uint32_t *U4, *V4, *S4;            /* state, this lane's column: index (x >> 2) * 64 */
+	const uint32_t *TT, *QR;           /* target codes by position, reversed query by k: same layout, zero past the ends */
+};
+K2A_FN uint32_t k2a_funnel(uint32_t lo, uint32_t hi, int bytes) { return bytes == 0 ? lo : (lo >> (8 * bytes)) | (hi << (32 - 8 * bytes)); }
+
+/* anti-diagonal r of one lane's pair; false = the lane stops (band left the matrix or X-drop) */
+K2A_FN bool k2a_extf_lane_diag(const K2aExtf &par, int qlen, int tlen, int w, int tpad, int xdrop, int r, const K2aExtfLaneMem &m,
+                               int &prev_lo, int &prev_hi, K2aExtfBook &bk)
+{
+	K2aExtfDiag d;
+	if (!k2a_extf_diag(r, qlen, tlen, w, tpad, d)) return false;
+	const uint32_t two_e = (uint32_t)(par.e * 2) & 0xffu, mch = (uint32_t)par.mch & 0xffu, mis = (uint32_t)par.mis & 0xffu;
+	const bool top0 = d.bhi >= r;                                  /* ksw2_extf2_sse.c:46 */
+	const int last = k2a_max(d.bhi, d.fresh_end - 1), k0 = qlen - 1 - r;
+	uint32_t carry = 0;                                            /* V of position blo - 1 on the previous anti-diagonal (:45) */
+	if (d.blo > 0 && d.blo - 1 >= prev_lo && d.blo - 1 <= prev_hi) carry = (m.V4[(size_t)((d.blo - 1) >> 2) * 64] >> (8 * ((d.blo - 1) & 3))) & 0xffu;
+	for (int x4 = d.blo >> 2; x4 <= last >> 2; ++x4) {
+		const int x0 = x4 << 2;
+		const size_t row = (size_t)x4 * 64;
+		uint32_t u4 = m.U4[row], v4 = m.V4[row], s4 = m.S4[row];
+		const uint32_t t4 = m.TT[row];
+		/* QR[k0 + x0 .. +3]; k0 + x0 < 0 only where the dword starts below lo: positions of it at or above lo read QR[0..] */
+		const int k = k0 + x0, kc = k2a_max(k, 0);
+		uint32_t q4 = k2a_funnel(m.QR[(size_t)(kc >> 2) * 64], m.QR[(size_t)((kc >> 2) + 1) * 64], kc & 3);
+		if (k < 0) q4 = k > -4 ? q4 << (8 * -k) : 0u;
+		uint32_t nu4 = u4, nv4 = v4, ns4 = s4;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const int x = x0 + i, sh = 8 * i;
+			const bool act = x <= d.bhi, fresh = x >= d.lo && x < d.fresh_end;
+			const uint32_t tc = (t4 >> sh) & 0xffu, qc = (q4 >> sh) & 0xffu;
+			const uint32_t sv = fresh ? (tc == qc ? mch : mis) : (s4 >> sh) & 0xffu;
+			const uint32_t a = carry, vold = (v4 >> sh) & 0xffu;
+			const uint32_t b = (top0 && x == r) ? 0u : (u4 >> sh) & 0xffu;
+			uint32_t u, v;
+			k2a_extf_cell(sv, a, b, two_e, u, v);
+			carry = vold;
+			if (act) { nu4 = (nu4 & ~(0xffu << sh)) | (u << sh); nv4 = (nv4 & ~(0xffu << sh)) | (v << sh); }
+			if (fresh) ns4 = (ns4 & ~(0xffu << sh)) | (sv << sh);
+		}
+		m.U4[row] = nu4; m.V4[row] = nv4; m.S4[row] = ns4;
+	}
+	/* the followed cell reads the updated bytes (it may sit one position below lo: not touched on this anti-diagonal) */
+	const int f0 = bk.follow, f1 = bk.follow + 1;
+	const uint32_t vf = r == 0 ? (m.V4[0] & 0xffu) : (m.V4[(size_t)(f0 >> 2) * 64] >> (8 * (f0 & 3))) & 0xffu;
+	const uint32_t un = r == 0 ? 0u : (m.U4[(size_t)(f1 >> 2) * 64] >> (8 * (f1 & 3))) & 0xffu;
+	if (!k2a_extf_follow(bk, d, r, par.e, xdrop, vf, un)) return false;
+	prev_lo = d.blo; prev_hi = d.bhi;
+	return true;
+}
+
 K2A_FN void k2a_extf_finish(const K2aExtfBook &b, bool complete, K2aResult *r)
 {
 	r->max = b.max; r->max_t = b.max_t; r->max_q = b.max_q;

@@ -377,6 +377,15 @@ k2a_fill_solo_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 	const size_t tbsteps = k2a_solo_steps<C>(pr.qlen, pr.tlen, pr.w);
 	uint8_t *tbp = tb + pr.tb_off;
 	L.qb = L.next_query_codes(-1);
+	/* traceback words as whole cache lines (K2aTbStage, see the packed kernels): config 5's unique read shapes run here */
+	constexpr int WB = Lane::TBWORDS * 4;
+	constexpr bool STAGED = MODE != K2A_MODE_SCORE && (WB == 16 || WB == 32);
+	typedef K2aTbStage<STAGED ? WB : 16, 8> Stage;
+	__shared__ uint4 tbstage[STAGED ? K2A_WPB * Stage::WORDS : 1];
+	__shared__ unsigned long long tbruns[STAGED ? K2A_WPB * 64 : 1];
+	Stage ST;
+	if (STAGED) ST.init(&tbstage[wave * Stage::WORDS], &tbruns[wave * 64], lane, tbp + k2a_tb_word(0, lane, tbsteps, 64, WB));
+	int kdone = -1;
 
 	for (int k = 0; k <= klast; ++k) {
 		const k2a_pk rh = (k2a_pk)k2a_rot1<64>((int)L.hout);
@@ -400,7 +409,8 @@ k2a_fill_solo_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 
 		uint32_t tw[Lane::TBWORDS];
 		const bool live = L.step(sc, k, hin, ein, e2in, tw);
-		if (MODE != K2A_MODE_SCORE) {
+		if (STAGED) { ST.put(k, tw, live); ST.step_done(k); kdone = k; }
+		else if (MODE != K2A_MODE_SCORE) {
 			if (live) {
 				uint32_t *dst = (uint32_t*)(tbp + k2a_tb_word((size_t)k, lane, tbsteps, 64, Lane::TBWORDS * 4));
 #pragma unroll
@@ -424,6 +434,7 @@ k2a_fill_solo_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 		}
 		L.qb = qnext;
 	}
+	if (STAGED) ST.finish(kdone);
 	__builtin_amdgcn_wave_barrier();
 	if (valid && lane == 0) {
 		const K2aBook b = *bk;
@@ -1222,6 +1233,38 @@ k2a_extf_kernel(const K2aExtf par, const K2aPair *__restrict__ pairs, const uint
 	if (lane == 0) k2a_extf_finish(bk, r == nr, &res[pi]);
 }
 
+/* One extension per lane (ksw2_lane_extf.h, K2aExtfLaneMem): task t of the launch = lane t & 63 of wavefront t >> 6; the pairs of a
+ * wavefront share one group block -- pairs[i].toff / qoff = byte offsets of the group's interleaved target / reversed-query codes
+ * in `seq`, tb_off = its zeroed state rows in `scratch`, pad = rows (dwords per lane) of each state array.  Lanes run their own
+ * anti-diagonal loops; the wavefront iterates until its last lane is done. */
+__global__ void __launch_bounds__(64 * K2A_WPB)
+k2a_extf_lane_kernel(const K2aExtf par, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
+                     const uint8_t *__restrict__ seq, uint8_t *__restrict__ scratch, K2aResult *__restrict__ res)
+{
+	const int lane = threadIdx.x & 63, wave = k2a_wave_id<false>();
+	const int task = (blockIdx.x * K2A_WPB + wave) * 64 + lane;
+	const bool valid = task < ntasks;
+	const uint32_t pi = order[valid ? task : 0];
+	const K2aPair pr = pairs[pi];
+	const int qlen = pr.qlen, tlen = pr.tlen, w = pr.w, xdrop = pr.zdrop, tpad = (tlen + 15) & ~15;
+	const size_t rows = (size_t)pr.pad * 64;                    /* dwords per state array of the group */
+	K2aExtfLaneMem m;
+	m.U4 = (uint32_t*)(scratch + pr.tb_off) + lane; m.V4 = m.U4 + rows; m.S4 = m.V4 + rows;
+	m.TT = (const uint32_t*)(seq + pr.toff) + lane; m.QR = (const uint32_t*)(seq + pr.qoff) + lane;
+	K2aExtfBook bk;
+	k2a_extf_book_reset(bk);
+	int prev_lo = -1, prev_hi = -1, r = 0;
+	const int nr = qlen + tlen - 1;
+	bool go = valid;
+	while (__builtin_amdgcn_ballot_w64(go && r < nr) != 0) {
+		if (go && r < nr) {
+			if (k2a_extf_lane_diag(par, qlen, tlen, w, tpad, xdrop, r, m, prev_lo, prev_hi, bk)) ++r;
+			else go = false;
+		}
+	}
+	if (valid) k2a_extf_finish(bk, r == nr, &res[pi]);
+}
+
 /* Register-window form: bands up to K2A_EXTF_WIN_SPAN(K) positions wide.  U, V, S and the target code of K x 64 positions
  * stay in registers; the window slides up a 64-block at a time (a block entering it is all zero, like the reference's
  * fresh allocation); no LDS, no fences.  Slots are visited in a fixed order: every slot's old V of lane 63 is taken first,
@@ -1555,8 +1598,11 @@ int k2a_shim_launch_extf(int cls, const K2aExtf *par, const K2aPair *pairs, cons
 {
 	static const int lds_bytes[4] = { 3 * 1024, 3 * 4096, 3 * 21504, 0 };
 	if (ntasks <= 0) return 0;
-	if (cls < 0 || cls > 5) { snprintf(g_err, sizeof(g_err), "bad kernel class"); return -1; }
-	if (cls >= 4) {
+	if (cls < 0 || cls > 6) { snprintf(g_err, sizeof(g_err), "bad kernel class"); return -1; }
+	if (cls == 6) {                                   /* one extension per lane: 64 tasks per wavefront */
+		const int waves = (ntasks + 63) / 64;
+		hipLaunchKernelGGL(k2a_extf_lane_kernel, dim3((waves + K2A_WPB - 1) / K2A_WPB), dim3(64 * K2A_WPB), 0, (hipStream_t)stream, *par, pairs, order, ntasks, seq, scratch, res);
+	} else if (cls >= 4) {
 		const int blocks = (ntasks + K2A_WPB - 1) / K2A_WPB;
 		if (cls == 4) hipLaunchKernelGGL(k2a_extf_win_kernel<4>, dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream, *par, pairs, order, ntasks, seq, res);
 		else hipLaunchKernelGGL(k2a_extf_win_kernel<8>, dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream, *par, pairs, order, ntasks, seq, res);

@@ -939,10 +939,32 @@ int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_
 	if (ntasks > 0) g_trace[cfg][dual ? 1 : 0](pairs, order, ntasks, tb, res, cig);
 	return 0;
 }
+/* mirrors k2a_extf_lane_kernel: one extension per lane, the lanes of a wavefront one after the other (they do not interact) */
+static void sim_extf_lane(const K2aExtf par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, uint8_t *scratch, K2aResult *res)
+{
+	for (int task = 0; task < ntasks; ++task) {
+		const int lane = task & 63;
+		const uint32_t pi = order[task];
+		const K2aPair pr = pairs[pi];
+		const int qlen = pr.qlen, tlen = pr.tlen, w = pr.w, xdrop = pr.zdrop, tpad = (tlen + 15) & ~15;
+		const size_t rows = (size_t)pr.pad * 64;
+		K2aExtfLaneMem m;
+		m.U4 = (uint32_t*)(scratch + pr.tb_off) + lane; m.V4 = m.U4 + rows; m.S4 = m.V4 + rows;
+		m.TT = (const uint32_t*)(seq + pr.toff) + lane; m.QR = (const uint32_t*)(seq + pr.qoff) + lane;
+		K2aExtfBook bk;
+		k2a_extf_book_reset(bk);
+		int prev_lo = -1, prev_hi = -1, r = 0;
+		const int nr = qlen + tlen - 1;
+		while (r < nr && k2a_extf_lane_diag(par, qlen, tlen, w, tpad, xdrop, r, m, prev_lo, prev_hi, bk)) ++r;
+		k2a_extf_finish(bk, r == nr, &res[pi]);
+	}
+}
+
 int k2a_shim_launch_extf(int cls, const K2aExtf *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
                          uint8_t *scratch, K2aResult *res, void *)
 {
-	if (ntasks > 0 && cls == 4) sim_extf_win<4>(*par, pairs, order, ntasks, seq, res);
+	if (ntasks > 0 && cls == 6) sim_extf_lane(*par, pairs, order, ntasks, seq, scratch, res);
+	else if (ntasks > 0 && cls == 4) sim_extf_win<4>(*par, pairs, order, ntasks, seq, res);
 	else if (ntasks > 0 && cls == 5) sim_extf_win<8>(*par, pairs, order, ntasks, seq, res);
 	else if (ntasks > 0) sim_extf(*par, pairs, order, ntasks, seq, scratch, res, cls == 3);
 	return 0;
