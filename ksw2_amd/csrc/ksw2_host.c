@@ -1934,11 +1934,23 @@ ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n
 	if (!p->h_cls || !p->h_half || !p->h_flag || !p->h_pairs || !p->h_res || !p->h_order) { fail(KSW2AMD_E_NOMEM, "extf: host allocation failed%s", 0); goto err; }
 	p->f_par.mch = mch; p->f_par.mis = mis < 0 ? mis : -mis; p->f_par.e = e;      /* ksw2_extf2_sse.c:18-20 */
 	/* One extension per lane instead of per wavefront: an order of magnitude fewer instructions per cell, but a wavefront then
-	 * holds 64 extensions and every lane walks its band serially -- worth it from a few wavefronts per CU on
-	 * (KSW2AMD_EXTF_LANE=1 / 0 forces it on / off; profiles/r2_extf_lane.txt) */
+	 * holds 64 extensions and every lane walks its band serially: for big batches of narrow bands (KSW2AMD_EXTF_LANE=1 / 0 forces) */
 	{
+		/* measured (profiles/r2_extf_lane.txt): the lane form reaches ~600 GCUPS from 4 wavefronts per SIMD (262 144 extensions) and
+		 * scales down linearly below 131 072; the position-per-lane forms do 180 / 460 / 760 GCUPS at 30 / 100 / 300 positions in
+		 * the band whatever the batch size.  Take the lane form where it is ahead by 15 %. */
 		const char *ev = getenv("KSW2AMD_EXTF_LANE");
-		use_lane = ev && *ev ? atoi(ev) != 0 : n >= 32768;
+		double span_sum = 0, lane_rate, wave_rate;
+		int nv = 0;
+		for (i = 0; i < n; ++i)
+			if (pairs[i].qlen > 0 && pairs[i].tlen > 0) {
+				const int wq = pairs[i].w < 0 ? imax(pairs[i].qlen, pairs[i].tlen) : pairs[i].w;
+				span_sum += imin(imin(pairs[i].qlen, pairs[i].tlen), wq < 0x7ffffff0 ? wq + 1 : wq); ++nv;
+			}
+		lane_rate = 600.0 * (n >= 131072 ? 1.0 : (double)n / 131072.0);
+		wave_rate = nv ? 60.0 + 4.0 * span_sum / nv : 0.0;
+		if (wave_rate > 760.0) wave_rate = 760.0;
+		use_lane = ev && *ev ? atoi(ev) != 0 : lane_rate > 1.15 * wave_rate;
 		if (getenv("KSW2AMD_EXTF_LDS") || getenv("KSW2AMD_EXTF_WIN") || getenv("KSW2AMD_EXTF_HBM")) use_lane = ev && *ev ? atoi(ev) != 0 : 0;
 	}
 	for (i = 0; i < n; ++i) {

@@ -34,7 +34,10 @@
 #if defined(__HIP_DEVICE_COMPILE__)
 K2A_FN void k2a_key_max(unsigned long long *slot, unsigned long long key)
 {
-	__hip_atomic_fetch_max(slot, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      /* result unused: no-return atomic at L2 */
+	/* result unused: a no-return atomic performed in the XCD's L2.  Workgroup scope: every slot belongs to one lane of one
+	 * wavefront, and agent-scope atomics are carried out beyond the L2 on this part -- 5.4e9 of them per launch of config 4
+	 * showed up as 140 GB of extra HBM writes (profiles/r2_cfg4_pmc.json) */
+	__hip_atomic_fetch_max(slot, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 K2A_FN unsigned long long k2a_key_load(const unsigned long long *slot)       /* past the L1, where an older copy of the slot may sit */
 {

@@ -553,3 +553,20 @@ def test_sim_packed_generation_serial(sim, monkeypatch):
     p = sim.make_batch(q, t, mat, 4, 2, 24, 1, w=-1, zdrop=-1, flag=0).plan(False)
     assert p.packed_pairs() == 0
     p.close()
+
+
+def test_sim_linear_xdrop_one_extension_per_lane(sim, monkeypatch):
+    """The lane-per-extension form of ksw_extf2_sse (k2a_extf_lane_kernel: interleaved sequences and state, four positions per dword):
+    every reference case in batches of mixed shapes, so groups of 64 hold very different lengths and bands."""
+    monkeypatch.setenv("KSW2AMD_EXTF_LANE", "1")
+    fc = gu.ExtfCases()
+    cases = [fc.case(k) for k in range(fc.n)]
+    for sc in sorted({(c["mch"], c["mis"], c["e"]) for c in cases}):
+        sub = [c for c in cases if (c["mch"], c["mis"], c["e"]) == sc]
+        res = sim.extf_batch([c["q"] for c in sub], [c["t"] for c in sub], *sc, w=[c["w"] for c in sub], xdrop=[c["xdrop"] for c in sub])
+        for r, c in zip(res, sub):
+            assert not diff(r, c["expect"], gu.FIELDS), (sc, len(c["q"]), len(c["t"]), c["w"], c["xdrop"])
+    e = np.zeros(0, np.uint8); one = np.array([2], np.uint8)
+    res = sim.extf_batch([e, one, one, e], [e, e, one, one], 2, -4, 2, w=-1, xdrop=50)
+    for r, (q, t) in zip(res, ((e, e), (one, e), (one, one), (e, one))):
+        assert not diff(r, po.extf2("oracle", q, t, 2, -4, 2, -1, 50), gu.FIELDS)
