@@ -54,6 +54,8 @@ WORKLOADS = {
     # config 4: MT-human x MT-orang (tests/golden/data), full global extz2 with CIGAR, 4 096 replicas: 590 GB of direction
     # bits, so the batch entry point runs it as several plans (no single resident plan: transfer-inclusive figure only)
     "cfg4": dict(idx=4, n=4096, qlen=16499, tlen=16569, w=-1, zdrop=-1, dual=False, flag=0, mt=True, resident_n=1024),
+    # the same score-only (diagnostics: what the packed generation-serial kernel does without the traceback stream)
+    "cfg4-so": dict(idx=4, n=4096, qlen=16499, tlen=16569, w=-1, zdrop=-1, dual=False, flag=SO, mt=True, resident_n=1024),
     # config 5: ONT-like mix, query length uniform in [300, 20000], 3 % substitutions + 15 % indels, target length from the
     # channel (|tlen - qlen| <= 450), band 500, extd2 with Z-drop 400 and CIGAR; 16 384 pairs = one eighth of the per-GPU share
     # of the 1 M pair config (which shards over 8 GPUs)

@@ -9,9 +9,16 @@
  *
  * Result contract: every function evaluates the alignment on the GPU with the exact
  * band |i-j| <= w and the row-wise Z-drop of the reference's scalar ksw_extz / ksw_extd, and returns
- * bit-identical score / max / max_q / max_t / mqe / mqe_t / mte / mte_q / zdropped / reach_end / CIGAR.
+ * score / max / max_q / max_t / mqe / mqe_t / mte / mte_q / zdropped / reach_end / CIGAR bit-identical to THOSE.
+ * Where the reference's SSE functions differ from their scalar twins, the default results therefore differ from an SSE
+ * build's: mte_q (the SSE kernels report it from their 16-padded range: ~94 % of calls), scores at the edge of narrow
+ * bands (their 16-position blocks leak), Z-drop (theirs is per anti-diagonal), max_t / max_q on ties, ksw_gg2_sse on
+ * narrow bands; two reference bugs are not reproduced (ksw_extd2_sse with e == e2; its first cell when it swaps the
+ * gap pieces).  The SSE-compatible mode (KSW2AMD_EZ_SSE_COMPAT, below) returns the SSE functions' own results instead,
+ * every field and the CIGAR, and KSW_EZ_APPROX_MAX | KSW_EZ_APPROX_DROP always does.
  * There is no CPU fallback: without a usable gfx950 device the ksw2-named entry points print the error
- * to stderr and abort(); the ksw2amd_* entry points return a negative code (see ksw2amd_last_error()).
+ * to stderr and abort() (or report through ksw2amd_set_error_handler); the ksw2amd_* entry points return a negative
+ * code (see ksw2amd_last_error()).
  *
  * Reference interface each declaration replaces is cited as (ksw2.h:LINE).
  */
