@@ -1851,7 +1851,7 @@ err:
 	return fail(KSW2AMD_E_NODEVICE, "exts run: %s", k2a_shim_last_error());
 }
 
-int ksw2amd_exts_batch(void *km, const ksw2amd_splice_t *sc, int n, const ksw2amd_spair_t *pairs, ksw_extz_t *ez)
+static int exts_serial(void *km, const ksw2amd_splice_t *sc, int n, const ksw2amd_spair_t *pairs, ksw_extz_t *ez, int share)
 {
 	int beg = 0;
 	size_t budget, free_b = 0, total_b = 0;
@@ -1862,7 +1862,7 @@ int ksw2amd_exts_batch(void *km, const ksw2amd_splice_t *sc, int n, const ksw2am
 	else if (n == 1) budget = (size_t)1 << 34;
 	else {
 		if (k2a_shim_mem_info(&free_b, &total_b)) return fail(KSW2AMD_E_NODEVICE, "mem_info: %s", k2a_shim_last_error());
-		budget = free_b / 10 * 7;
+		budget = device_budget(free_b, total_b, share);
 	}
 	while (beg < n) {
 		ksw2amd_plan_t *p;
@@ -1883,6 +1883,36 @@ int ksw2amd_exts_batch(void *km, const ksw2amd_splice_t *sc, int n, const ksw2am
 		beg = end;
 	}
 	return KSW2AMD_OK;
+}
+
+/* the splice-aware and the X-drop batches through the same worker pool as the extz / extd batches (run_pooled): one chunk per
+ * worker, each packed, run and fetched on the worker's own streams -- the packing (per-position splice constants, interleaved
+ * lane blocks) is what bounds these functions end to end */
+typedef struct { void *km; const ksw2amd_splice_t *sc; const ksw2amd_spair_t *pairs; ksw_extz_t *ez; } exts_ctx_t;
+static int exts_chunk(void *ctx_, int beg, int end, int share, pend_t *pd)
+{
+	exts_ctx_t *c = (exts_ctx_t*)ctx_;
+	(void)pd;
+	if (beg < 0) return KSW2AMD_OK;
+	return exts_serial(c->km, c->sc, end - beg, c->pairs + beg, c->ez + beg, share);
+}
+
+int ksw2amd_exts_batch(void *km, const ksw2amd_splice_t *sc, int n, const ksw2amd_spair_t *pairs, ksw_extz_t *ez)
+{
+	const int tpd = pool_threads_per_device();
+	if (n >= (pool_min_pairs() ? pool_min_pairs() : 2048) && tpd > 0 && !g_is_worker && k2a_shim_device_count() > 0) {
+		const int workers = tpd * (g_ndev_set > 0 ? g_ndev_set : 1), nchunks = imin(workers, n / 256);
+		double *cost = (double*)malloc(sizeof(double) * (size_t)n), total = 0;
+		int i, rc = 0;
+		if (cost && nchunks >= 2) {
+			exts_ctx_t ctx;
+			for (i = 0; i < n; ++i) { cost[i] = 1.0 + (double)imax(pairs[i].qlen, 0) * imax(pairs[i].tlen, 0); total += cost[i]; }
+			ctx.km = km; ctx.sc = sc; ctx.pairs = pairs; ctx.ez = ez;
+			if (run_pooled(exts_chunk, &ctx, n, cost, total, nchunks, &rc)) { free(cost); return rc; }
+		}
+		free(cost);
+	}
+	return exts_serial(km, sc, n, pairs, ez, 1);
 }
 
 void ksw_exts2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
@@ -2284,7 +2314,7 @@ static int ssec_run(int dual, void *km, const ksw2amd_scoring_t *sc, int n, cons
 	return KSW2AMD_OK;
 }
 
-int ksw2amd_extf_batch(void *km, int8_t mch, int8_t mis, int8_t e, int n, const ksw2amd_fpair_t *pairs, ksw_extz_t *ez)
+static int extf_serial(void *km, int8_t mch, int8_t mis, int8_t e, int n, const ksw2amd_fpair_t *pairs, ksw_extz_t *ez)
 {
 	int beg = 0;
 	if (n <= 0) return KSW2AMD_OK;
@@ -2307,6 +2337,34 @@ int ksw2amd_extf_batch(void *km, int8_t mch, int8_t mis, int8_t e, int n, const 
 		beg = end;
 	}
 	return KSW2AMD_OK;
+}
+
+typedef struct { void *km; int8_t mch, mis, e; const ksw2amd_fpair_t *pairs; ksw_extz_t *ez; } extf_ctx_t;
+static int extf_chunk(void *ctx_, int beg, int end, int share, pend_t *pd)
+{
+	extf_ctx_t *c = (extf_ctx_t*)ctx_;
+	(void)pd; (void)share;
+	if (beg < 0) return KSW2AMD_OK;
+	return extf_serial(c->km, c->mch, c->mis, c->e, end - beg, c->pairs + beg, c->ez + beg);
+}
+
+int ksw2amd_extf_batch(void *km, int8_t mch, int8_t mis, int8_t e, int n, const ksw2amd_fpair_t *pairs, ksw_extz_t *ez)
+{
+	const int tpd = pool_threads_per_device();
+	/* (batches big enough for the one-extension-per-lane form stay whole: it needs every wavefront it can get) */
+	if (n >= (pool_min_pairs() ? pool_min_pairs() : 2048) && n < 131072 && tpd > 0 && !g_is_worker && k2a_shim_device_count() > 0) {
+		const int workers = tpd * (g_ndev_set > 0 ? g_ndev_set : 1), nchunks = imin(workers, n / 256);
+		double *cost = (double*)malloc(sizeof(double) * (size_t)n), total = 0;
+		int i, rc = 0;
+		if (cost && nchunks >= 2) {
+			extf_ctx_t ctx;
+			for (i = 0; i < n; ++i) { cost[i] = 1.0 + (double)imax(pairs[i].qlen, 0) + imax(pairs[i].tlen, 0); total += cost[i]; }
+			ctx.km = km; ctx.mch = mch; ctx.mis = mis; ctx.e = e; ctx.pairs = pairs; ctx.ez = ez;
+			if (run_pooled(extf_chunk, &ctx, n, cost, total, nchunks, &rc)) { free(cost); return rc; }
+		}
+		free(cost);
+	}
+	return extf_serial(km, mch, mis, e, n, pairs, ez);
 }
 
 void ksw_extf2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t mch, int8_t mis, int8_t e, int w, int xdrop,

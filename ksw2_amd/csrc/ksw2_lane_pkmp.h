@@ -27,6 +27,7 @@
 
 #define K2A_PKMP_T    64            /* steps between re-bases (a power of two) */
 #define K2A_PKMP_DEAD (-8192)       /* relative values below this are -inf */
+#define K2A_PKMP_RMAX_LIMIT 12000   /* a window's row maximum further above the base than this is merged into its key */
 #define K2A_PKMP_WAVES 4            /* wavefronts (generations in flight) per pair of alignments */
 #define K2A_PKMP_SPILL_WORDS(C) (64 * (C) * 2 * 2)     /* uint32 per wavefront: one 64-bit key per row, lane and alignment */
 #define K2A_PKMP_BND_WORDS(qlen, dual) ((((size_t)(qlen) * ((dual) ? 5 : 4) + 16) + 3) & ~(size_t)3)   /* uint32 per task: {H, E, baseA, baseB}[qlen] (+ E~[qlen]), rounded so that the 64-bit keys behind it stay aligned */
@@ -120,19 +121,29 @@ struct K2aLanePkMp {
 	}
 
 	/* Re-centre on the largest H of the lane's current column.  Returns the shift {dA, dB} (packed, plain halves); the caller
-	 * rotates it one lane down for `after_rebase`. */
+	 * rotates it one lane down for `after_rebase`.  The window's row maxima move with the base as long as they fit: a row's
+	 * maximum drifts away from the current values by a few units per column once the lane has passed the row's best cell, so
+	 * it is merged into its key (flush_rowmax: atomics that show up as HBM writes, r2 profiles) only when a half would leave
+	 * K2A_PKMP_RMAX_LIMIT -- once or twice per row of 16 k columns instead of every 64 steps. */
 	K2A_FN k2a_pk rebase()
 	{
-		flush_rowmax();
 		k2a_pk m = P.hl[0];
 #pragma unroll
 		for (int c = 1; c < C; ++c) m = k2a_pk_maxu(m, P.hl[c]);
 		m ^= K2A_OFS;
 		const k2a_pk dead = k2a_pk_sign(k2a_pk_sub(m, k2a_pk2(K2A_PKMP_DEAD)));
 		const k2a_pk d = k2a_pk_sel(dead, 0u, m);                                   /* no live row: stay */
+		/* would any row maximum overflow after the shift?  (offset form: plain value = stored ^ OFS) */
+		k2a_pk over = 0;
+#pragma unroll
+		for (int c = 0; c < C; ++c) over |= k2a_pk_sign(k2a_pk_sub(k2a_pk2(K2A_PKMP_RMAX_LIMIT), k2a_pk_sub(P.rmax(c) ^ K2A_OFS, d)));
+		if (over != 0) flush_rowmax();                                              /* with the bases the maxima are relative to */
 		P.baseA += k2a_pk_lo(d); P.baseB += k2a_pk_hi(d);
 #pragma unroll
-		for (int c = 0; c < C; ++c) { P.hl[c] = shift(P.hl[c], d); P.f[c] = shift(P.f[c], d); if (DUAL) P.f2[c] = shift(P.f2[c], d); }
+		for (int c = 0; c < C; ++c) {
+			P.hl[c] = shift(P.hl[c], d); P.f[c] = shift(P.f[c], d); if (DUAL) P.f2[c] = shift(P.f2[c], d);
+			P.set_rmax(c, shift(P.rmax(c), d));
+		}
 		P.hd0 = shift(P.hd0, d); P.hout = shift(P.hout, d); P.eout = shift(P.eout, d);
 		if (DUAL) P.e2out = shift(P.e2out, d);
 		return d;

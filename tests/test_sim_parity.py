@@ -548,6 +548,9 @@ def test_sim_packed_generation_serial(sim, monkeypatch):
         assert p.packed_pairs() == 4          # 900 rows: all strips resident in the packed (64, 16) array; beyond 2 048 rows: this class
         p.close()
         check_batch(sim, dual, qs, ts, mat, 4, 2, 24, 1, w=w, zdrop=zd, flag=flag)
+    # rows of 9 000 columns: a row's maximum drifts more than 12 000 units above the sliding base and is merged into its key mid-row
+    q, t = synth.fixed_batch(12, 1, 9000, 8800, sub=0.05, ind=0.08)
+    check_batch(sim, False, [q[0], q[0]], [t[0], t[0]], mat, 4, 2, 24, 1, w=-1, zdrop=-1, flag=po.SCORE_ONLY)
     monkeypatch.setenv("KSW2AMD_NO_PKMP", "1")
     q, t = synth.fixed_batch(9, 2, 2300, 2337, sub=0.05, ind=0.08)
     p = sim.make_batch(q, t, mat, 4, 2, 24, 1, w=-1, zdrop=-1, flag=0).plan(False)
