@@ -143,8 +143,13 @@ K2A_FN uint32_t k2a_pack_dirs(k2a_pk d0, k2a_pk d1)
  * exposed and the register form is faster, so both are built and the launcher picks by the number of tasks. */
 #define K2A_PK_LDSROWS(G, C, DUAL, MODE, NOMAX) ((G) == 64 && (C) == 16 && (DUAL) && (MODE) != K2A_MODE_SCORE && !(NOMAX))
 #define K2A_PK_LDSROW_WORDS(C) (3 * (C) * 64)        /* per wavefront */
+/* Codes only (LDSROW_ = 2): the exact score-only kernel of the 16-row geometry holds 178-190 registers, two wavefronts per
+ * SIMD; with the two code planes (32 registers) in LDS it fits three.  Nothing else changes: the planes are read-only
+ * between strip starts, two LDS loads per row and step. */
+#define K2A_PK_LDSCODES(G, C, DUAL, MODE, NOMAX) ((G) == 64 && (C) == 16 && !(DUAL) && (MODE) == K2A_MODE_SCORE && !(NOMAX))
+#define K2A_PK_LDSCODE_WORDS(C) (2 * (C) * 64)       /* per wavefront */
 
-template<int G, int C, bool DUAL, int MODE = K2A_MODE_SCORE, bool RB = false, bool NOMAX = false, bool LDSROW_ = false>
+template<int G, int C, bool DUAL, int MODE = K2A_MODE_SCORE, bool RB = false, bool NOMAX = false, int LDSROW_ = 0>
 struct K2aLanePk {
 	enum { NIB = K2A_PK_NIBBLES(C, DUAL), TBWORDS = NIB ? C / 4 : C / 2 };
 	/* NIB (single gap, 16 rows): direction codes of 4 bits -- bits 0-1 winner {0 diag, 1 E, 2 F}, bit 2 / 3 = the E / F gap leaving the
@@ -164,16 +169,20 @@ struct K2aLanePk {
 	/* rows */
 	/* target codes as bit planes x D: one register more per row, so only where the kernel keeps its occupancy */
 	enum { PLANES = (MODE == K2A_MODE_SCORE && (!DUAL || C <= 16)) || C <= 8 };
-	enum { LDSROW = LDSROW_ };
+	enum { LDSROW = LDSROW_ == 1,       /* row maxima, arg-max columns and target codes in LDS */
+	       LDSTC = LDSROW_ != 0 };      /* 2: only the target codes (both planes) */
 	k2a_pk hl[C], f[C], f2[DUAL ? C : 1], rmax_[(NOMAX || LDSROW) ? 1 : C], rmj_[(NOMAX || LDSROW) ? 1 : C];       /* hl, f, f2, rmax and the ports above: offset form */
-	k2a_pk tc_[LDSROW ? 1 : C], tc1[PLANES ? C : 1];             /* target codes {A, B}; PLANES: bit 0 / bit 1 of the codes, times D */
-	uint32_t *lrow;                                              /* LDSROW: this lane's column of the wavefront's [3][C][64] block */
+	k2a_pk tc_[LDSTC ? 1 : C], tc1_[(PLANES && !LDSTC) ? C : 1];   /* target codes {A, B}; PLANES: bit 0 / bit 1 of the codes, times D */
+	uint32_t *lrow;                                              /* LDSROW: this lane's column of the wavefront's [3][C][64] block; codes only: [2][C][64] */
+	enum { TCROW = LDSROW ? 2 : 0, TC1ROW = LDSROW ? 3 : 1 };
 	K2A_FN k2a_pk rmax(int c) const { return LDSROW ? lrow[(0 * C + c) * 64] : rmax_[(NOMAX || LDSROW) ? 0 : c]; }
 	K2A_FN k2a_pk rmj(int c) const { return LDSROW ? lrow[(1 * C + c) * 64] : rmj_[(NOMAX || LDSROW) ? 0 : c]; }
-	K2A_FN k2a_pk tc(int c) const { return LDSROW ? lrow[(2 * C + c) * 64] : tc_[LDSROW ? 0 : c]; }
+	K2A_FN k2a_pk tc(int c) const { return LDSTC ? lrow[(TCROW * C + c) * 64] : tc_[LDSTC ? 0 : c]; }
+	K2A_FN k2a_pk tc1(int c) const { return LDSTC ? lrow[(TC1ROW * C + c) * 64] : tc1_[(PLANES && !LDSTC) ? c : 0]; }
+	K2A_FN void set_tc1(int c, k2a_pk v) { if (LDSTC) lrow[(TC1ROW * C + c) * 64] = v; else tc1_[(PLANES && !LDSTC) ? c : 0] = v; }
 	K2A_FN void set_rmax(int c, k2a_pk v) { if (LDSROW) lrow[(0 * C + c) * 64] = v; else rmax_[(NOMAX || LDSROW) ? 0 : c] = v; }
 	K2A_FN void set_rmj(int c, k2a_pk v) { if (LDSROW) lrow[(1 * C + c) * 64] = v; else rmj_[(NOMAX || LDSROW) ? 0 : c] = v; }
-	K2A_FN void set_tc(int c, k2a_pk v) { if (LDSROW) lrow[(2 * C + c) * 64] = v; else tc_[LDSROW ? 0 : c] = v; }
+	K2A_FN void set_tc(int c, k2a_pk v) { if (LDSTC) lrow[(TCROW * C + c) * 64] = v; else tc_[LDSTC ? 0 : c] = v; }
 
 	K2A_FN static int first_col(int S_, int w_) { return k2a_max(0, S_ * C - w_); }
 
@@ -197,11 +206,11 @@ struct K2aLanePk {
 		baseA = baseB = 0; delta = 0;
 		local_reset();
 #pragma unroll
-		for (int c = 0; c < C; ++c) { hl[c] = f[c] = neg; set_tc(c, 0); if (!NOMAX) { set_rmax(c, neg); set_rmj(c, 0); } if (PLANES) tc1[c] = 0; if (DUAL) f2[c] = neg; }
+		for (int c = 0; c < C; ++c) { hl[c] = f[c] = neg; set_tc(c, 0); if (!NOMAX) { set_rmax(c, neg); set_rmj(c, 0); } if (PLANES) set_tc1(c, 0); if (DUAL) f2[c] = neg; }
 		if (NOMAX || LDSROW) { rmax_[0] = neg; rmj_[0] = 0; }
-		if (LDSROW) tc_[0] = 0;
+		if (LDSTC) tc_[0] = 0;
 		if (!DUAL) f2[0] = 0;
-		if (!PLANES) tc1[0] = 0;
+		if (!PLANES || LDSTC) tc1_[0] = 0;
 	}
 
 	K2A_FN int last_step() const { return nstrips > 0 ? (nstrips - 1) + k2a_min(qlen - 1, tlen - 1 + w) : -1; }
@@ -229,8 +238,8 @@ struct K2aLanePk {
 			const uint32_t ua = tpa[c >> 1], ub = tpb[c >> 1];
 			const k2a_pk c0 = k2a_pair16(ua & 0xffu, ub & 0xffu), c1 = k2a_pair16(ua >> 8, ub >> 8);
 			if (PLANES) {
-				set_tc(c, (c0 & 0x00010001u) * dmis); tc1[c] = ((c0 >> 1) & 0x00010001u) * dmis;
-				if (c + 1 < C) { set_tc(c + 1, (c1 & 0x00010001u) * dmis); tc1[c + 1] = ((c1 >> 1) & 0x00010001u) * dmis; }
+				set_tc(c, (c0 & 0x00010001u) * dmis); set_tc1(c, ((c0 >> 1) & 0x00010001u) * dmis);
+				if (c + 1 < C) { set_tc(c + 1, (c1 & 0x00010001u) * dmis); set_tc1(c + 1, ((c1 >> 1) & 0x00010001u) * dmis); }
 			} else {
 				set_tc(c, c0);
 				if (c + 1 < C) set_tc(c + 1, c1);
@@ -305,7 +314,7 @@ struct K2aLanePk {
 			const k2a_pk q0 = (qcode & 0x00010001u) * dmis, q1 = ((qcode >> 1) & 0x00010001u) * dmis;
 #pragma unroll
 			for (int c = 0; c < C; ++c)
-				cand[c] = k2a_sub32(k2a_add32(c == 0 ? hd0 : hl[c - 1], mat_a), k2a_or_xor(tc(c) ^ q0, tc1[c], q1));
+				cand[c] = k2a_sub32(k2a_add32(c == 0 ? hd0 : hl[c - 1], mat_a), k2a_or_xor(tc(c) ^ q0, tc1(c), q1));
 		} else {
 #pragma unroll
 			for (int c = 0; c < C; ++c) {

@@ -51,7 +51,7 @@ K2A_FN unsigned long long k2a_key_load(const unsigned long long *slot) { return 
 
 template<int C, bool DUAL, int MODE>
 struct K2aLanePkMp {
-	typedef K2aLanePk<64, C, DUAL, MODE, true, false, false> Pk;
+	typedef K2aLanePk<64, C, DUAL, MODE, true, false, 0> Pk;
 	enum { G = 64, TBWORDS = Pk::TBWORDS, FIRSTJ = (!DUAL && MODE == K2A_MODE_RIGHT) };    /* extz + RIGHT + CIGAR: ties to the first column */
 	Pk P;
 	unsigned long long *spill;          /* this lane's C x 2 keys: spill[c * 2 + half] (per-wavefront block, lane-major) */

@@ -210,11 +210,11 @@ struct K2aTbStage {
 	__device__ __forceinline__ void step_done(int k) { if ((k & (NS - 1)) == NS - 1) flush(k - (NS - 1)); }
 	__device__ __forceinline__ void finish(int kdone) { if (kdone >= 0 && (kdone & (NS - 1)) != NS - 1) flush(kdone & ~(NS - 1)); }   /* kdone = last executed step */
 };
-#define K2A_PK_TB_NS(WB, LDSROW) ((WB) == 32 && (LDSROW) ? 2 : 8)      /* row state in LDS: two wavefronts per SIMD need the room */
+#define K2A_PK_TB_NS(WB, LDSROW) ((WB) == 32 && (LDSROW) == 1 ? 2 : 8)      /* row state in LDS: two wavefronts per SIMD need the room */
 
 /* Packed-int16 resident fill: two same-shape alignments per lane group (ksw2_lane_pk.h). */
-template<int G, int C, bool DUAL, int MODE, bool RB, bool NOMAX, bool LDSROW = false>
-__global__ void __launch_bounds__(64 * K2A_WPB, LDSROW ? 2 : 1)      /* no floor elsewhere: capping the score-only kernels at 168 VGPRs spills and is 18 % slower */
+template<int G, int C, bool DUAL, int MODE, bool RB, bool NOMAX, int LDSROW = 0>      /* LDSROW: 1 = row state in LDS, 2 = only the target-code planes */
+__global__ void __launch_bounds__(64 * K2A_WPB, LDSROW == 2 ? 3 : LDSROW ? 2 : 1)      /* no floor elsewhere: capping the register form of the score-only kernels at 168 VGPRs spills and is 18 % slower */
 k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
                    const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, K2aResult *__restrict__ res)
 {
@@ -233,9 +233,10 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	/* a Z-drop test anywhere in the wavefront selects the sequential strip epilogue for all of it */
 	const bool zseq = NOMAX || RB || __builtin_amdgcn_ballot_w64(valid && (zdropA >= 0 || zdropB >= 0)) != 0;   /* NOMAX: books only */
 
-	__shared__ uint32_t lrows[LDSROW ? K2A_WPB * K2A_PK_LDSROW_WORDS(C) : 1];   /* per-row maxima / arg-max / target codes of the LDSROW classes */
+	constexpr int LROW_WORDS = LDSROW == 1 ? K2A_PK_LDSROW_WORDS(C) : LDSROW == 2 ? K2A_PK_LDSCODE_WORDS(C) : 0;
+	__shared__ uint32_t lrows[LDSROW ? K2A_WPB * LROW_WORDS : 1];   /* per-row maxima / arg-max / target codes of the LDSROW classes */
 	Lane L;
-	L.lrow = &lrows[LDSROW ? wave * K2A_PK_LDSROW_WORDS(C) + lane : 0];
+	L.lrow = &lrows[LDSROW ? wave * LROW_WORDS + lane : 0];
 	L.setup(prA, prB, seq, gl, valid);
 	K2aBook *bkA = &book[wave][grp][0], *bkB = &book[wave][grp][1];
 	if (gl == 0) { k2a_book_reset(bkA); k2a_book_reset(bkB); }
@@ -1345,8 +1346,18 @@ typedef void (*fill_pk_fn)(const K2aScoring, const K2aPair*, const uint32_t*, in
 static const fill_pk_fn g_fill_pk[2][2][K2A_NPKCFG][2][3] = { PK_SET(false), PK_SET(true) };     /* [nomax][rebased][cfg][dual][mode] */
 /* the K2A_PK_LDSROWS classes with their row state in LDS: [rebased][mode - 1] */
 static const fill_pk_fn g_fill_pk_lds[2][2] = {
-	{ k2a_fill_pk_kernel<64, 16, true, 1, false, false, true>, k2a_fill_pk_kernel<64, 16, true, 2, false, false, true> },
-	{ k2a_fill_pk_kernel<64, 16, true, 1, true, false, true>,  k2a_fill_pk_kernel<64, 16, true, 2, true, false, true> } };
+	{ k2a_fill_pk_kernel<64, 16, true, 1, false, false, 1>, k2a_fill_pk_kernel<64, 16, true, 2, false, false, 1> },
+	{ k2a_fill_pk_kernel<64, 16, true, 1, true, false, 1>,  k2a_fill_pk_kernel<64, 16, true, 2, true, false, 1> } };
+
+/* exact score-only kernels of the 16-row geometry with the code planes in LDS (three wavefronts per SIMD): [rebased] */
+static const fill_pk_fn g_fill_pk_ldscodes[2] = { k2a_fill_pk_kernel<64, 16, false, 0, false, false, 2>, k2a_fill_pk_kernel<64, 16, false, 0, true, false, 2> };
+/* worth it once SIMDs would hold a third wavefront; KSW2AMD_LDSCODES=0 / 1 forces the choice */
+static bool k2a_use_ldscodes(int waves)
+{
+	const char *ev = getenv("KSW2AMD_LDSCODES");
+	if (ev) return atoi(ev) != 0;
+	return (long)waves > 2 * (long)k2a_shim_simd_count();
+}
 
 /* Row state in LDS (two wavefronts per SIMD) or in registers (one): the LDS form wins as soon as SIMDs hold two
  * wavefronts, the register form when they hold one (measured: config 5, 8 per SIMD, 836 -> 1035 GCUPS; config 4, one per
@@ -1484,7 +1495,8 @@ int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax,
 	const int per_block = K2A_WPB * (64 / k2a_pkcfg_G[cfg]);
 	const int blocks = (ntasks + per_block - 1) / per_block;
 	const bool lds = K2A_PK_LDSROWS(k2a_pkcfg_G[cfg], k2a_pkcfg_C[cfg], dual, mode, nomax) && k2a_use_ldsrows(ntasks);
-	hipLaunchKernelGGL(lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
+	const bool ldc = K2A_PK_LDSCODES(k2a_pkcfg_G[cfg], k2a_pkcfg_C[cfg], dual, mode, nomax) && k2a_use_ldscodes(ntasks);
+	hipLaunchKernelGGL(lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1] : ldc ? g_fill_pk_ldscodes[rebased ? 1 : 0] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
 	                   *sc, pairs, order2, ntasks, seq, tb, res);
 	CHECK(hipGetLastError());
 	return 0;

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
+#include <cstdlib>
 
 #define REP 16            /* independent accumulators per lane */
 #define ITER 16384        /* loop trips, each issuing REP instructions */
@@ -23,6 +24,8 @@ __global__ void __launch_bounds__(256) probe(uint32_t *out, uint32_t seed, unsig
 	f2 d[REP], d2 = { (float)seed, 1.0f }, d3 = { 0.5f, (float)seed };
 #pragma unroll
 	for (int r = 0; r < REP; ++r) d[r] = f2{ (float)r, (float)threadIdx.x };
+	unsigned long long lm = 0x5555aaaa0f0ff0f0ull ^ seed, lm2[4] = { 0, 0, 0, 0 };
+	asm volatile("" : "+s"(lm));
 	const unsigned long long t0 = __builtin_readcyclecounter();
 	for (int i = 0; i < ITER; ++i) {
 #pragma unroll
@@ -77,22 +80,31 @@ __global__ void __launch_bounds__(256) probe(uint32_t *out, uint32_t seed, unsig
 			if (KIND == 47) asm volatile("v_msad_u8 %0, %0, %1, %2" : "+v"(a[r]) : "v"(b), "v"(c));
 			if (KIND == 48) asm volatile("v_dot2_i32_i16 %0, %0, %1, %2" : "+v"(a[r]) : "v"(b), "v"(c));
 			if (KIND == 49) asm volatile("v_dot4_i32_i8 %0, %0, %1, %2" : "+v"(a[r]) : "v"(b), "v"(c));
+			if (KIND == 50) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[r]) : "v"(b), "s"(lm));
+			if (KIND == 51) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[r]) : "v"(b));
+			if (KIND == 52) asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(a[r]) : "v"(b));
+			if (KIND == 53) asm volatile("v_cmp_lt_i32_e32 vcc, %0, %1" : : "v"(a[r]), "v"(b) : "vcc");
+			if (KIND == 54) asm volatile("v_cmp_lt_i32_e64 %0, %1, %2" : "=s"(lm2[r & 3]) : "v"(a[r]), "v"(b));
+			if (KIND == 55) asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(a[r]) : "v"(c), "v"(b), "s"(lm));
+			if (KIND == 56) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(a[r]) : "v"(c), "v"(b));
+			if (KIND == 57) asm volatile("v_pk_max_u16 %0, %0, %2\n\ts_mov_b64 %1, %3" : "+v"(a[r]), "=s"(lm2[r & 3]) : "v"(b), "s"(lm));
 		}
 	}
 	const unsigned long long t1 = __builtin_readcyclecounter();
 	uint32_t s = 0;
 #pragma unroll
-	for (int r = 0; r < REP; ++r) s ^= a[r] ^ (uint32_t)d[r].x ^ (uint32_t)d[r].y;
+	for (int r = 0; r < REP; ++r) s ^= a[r] ^ (uint32_t)d[r].x ^ (uint32_t)d[r].y ^ (uint32_t)lm2[r & 3];
 	out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 	if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
 typedef void (*kern_t)(uint32_t*, uint32_t, unsigned long long*);
 
-int main()
+int main(int argc, char **argv)
 {
-	const char *names[] = { "v_pk_max_i16", "v_pk_add_u16", "v_pk_sub_i16", "v_pk_mad_i16", "v_pk_min_u16", "v_pk_ashrrev_i16", "v_pk_lshlrev_b16", "v_max_i32", "v_min_i32", "v_max_u32", "v_max3_i32", "v_add_u32", "v_sub_u32", "v_add3_u32", "v_mad_u32_u24", "v_mad_i32_i24", "v_xor_b32", "v_and_b32", "v_or_b32", "v_or3_b32", "v_and_or_b32", "v_bfi_b32", "v_bitop3_b32", "v_bfe_i32", "v_perm_b32", "v_lshlrev_b32", "v_ashrrev_i32", "v_lshl_add_u32", "v_mov_b32", "v_cndmask_b32", "v_mov_dpp_ror", "v_fma_f32", "v_add_f32", "v_max_f32", "v_min_f32", "v_max3_f32", "v_pk_add_f16", "v_pk_max_f16", "v_pk_min_f16", "v_pk_fma_f16", "v_pk_mul_f16", "v_pk_add_f32", "v_pk_fma_f32", "v_max_i16", "v_add_u16", "v_max_f16", "v_sad_u16", "v_msad_u8", "v_dot2_i32_i16", "v_dot4_i32_i8" };
-	kern_t kern[] = { probe<0>, probe<1>, probe<2>, probe<3>, probe<4>, probe<5>, probe<6>, probe<7>, probe<8>, probe<9>, probe<10>, probe<11>, probe<12>, probe<13>, probe<14>, probe<15>, probe<16>, probe<17>, probe<18>, probe<19>, probe<20>, probe<21>, probe<22>, probe<23>, probe<24>, probe<25>, probe<26>, probe<27>, probe<28>, probe<29>, probe<30>, probe<31>, probe<32>, probe<33>, probe<34>, probe<35>, probe<36>, probe<37>, probe<38>, probe<39>, probe<40>, probe<41>, probe<42>, probe<43>, probe<44>, probe<45>, probe<46>, probe<47>, probe<48>, probe<49> };
+	const int kfirst = argc > 1 ? atoi(argv[1]) : 0;
+	const char *names[] = { "v_pk_max_i16", "v_pk_add_u16", "v_pk_sub_i16", "v_pk_mad_i16", "v_pk_min_u16", "v_pk_ashrrev_i16", "v_pk_lshlrev_b16", "v_max_i32", "v_min_i32", "v_max_u32", "v_max3_i32", "v_add_u32", "v_sub_u32", "v_add3_u32", "v_mad_u32_u24", "v_mad_i32_i24", "v_xor_b32", "v_and_b32", "v_or_b32", "v_or3_b32", "v_and_or_b32", "v_bfi_b32", "v_bitop3_b32", "v_bfe_i32", "v_perm_b32", "v_lshlrev_b32", "v_ashrrev_i32", "v_lshl_add_u32", "v_mov_b32", "v_cndmask_b32", "v_mov_dpp_ror", "v_fma_f32", "v_add_f32", "v_max_f32", "v_min_f32", "v_max3_f32", "v_pk_add_f16", "v_pk_max_f16", "v_pk_min_f16", "v_pk_fma_f16", "v_pk_mul_f16", "v_pk_add_f32", "v_pk_fma_f32", "v_max_i16", "v_add_u16", "v_max_f16", "v_sad_u16", "v_msad_u8", "v_dot2_i32_i16", "v_dot4_i32_i8", "v_cndmask_e64_sgpr", "v_mul_lo_u32", "v_pk_mul_lo_u16", "v_cmp_lt_i32_vcc", "v_cmp_lt_i32_sgpr", "v_cndmask_e64_nodep", "v_cndmask_vcc_nodep", "pk_max+s_mov_b64" };
+	kern_t kern[] = { probe<0>, probe<1>, probe<2>, probe<3>, probe<4>, probe<5>, probe<6>, probe<7>, probe<8>, probe<9>, probe<10>, probe<11>, probe<12>, probe<13>, probe<14>, probe<15>, probe<16>, probe<17>, probe<18>, probe<19>, probe<20>, probe<21>, probe<22>, probe<23>, probe<24>, probe<25>, probe<26>, probe<27>, probe<28>, probe<29>, probe<30>, probe<31>, probe<32>, probe<33>, probe<34>, probe<35>, probe<36>, probe<37>, probe<38>, probe<39>, probe<40>, probe<41>, probe<42>, probe<43>, probe<44>, probe<45>, probe<46>, probe<47>, probe<48>, probe<49>, probe<50>, probe<51>, probe<52>, probe<53>, probe<54>, probe<55>, probe<56>, probe<57> };
 	hipDeviceProp_t prop;
 	hipGetDeviceProperties(&prop, 0);
 	const int cus = prop.multiProcessorCount;
@@ -100,7 +112,7 @@ int main()
 	hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeClockRate, 0);
 	printf("device %s, %d CUs, clock attribute %d MHz\n", prop.gcnArchName, cus, clk_khz / 1000);
 	printf("%-18s %6s %12s %12s %10s\n", "instruction", "waves", "ms", "cyc/inst", "Tinst/s");
-	for (int k = 0; k < 50; ++k) {
+	for (int k = kfirst; k < 58; ++k) {
 		for (int wps = 2; wps <= 8; wps *= 4) {                   /* wavefronts per SIMD */
 			const int blocks = cus * wps;                          /* 256 threads = 4 waves = one per SIMD of a CU */
 			uint32_t *out;
