@@ -1204,8 +1204,14 @@ static int env_flag(const char *name, int dflt) { const char *e = getenv(name); 
 /* cut [0, n) into at most `nchunks` (+ 2 * workers) chunks of consecutive pairs; cost[i] >= 1.  With enough chunks the first
  * ones are small (the device gets its first kernels after a quarter of a chunk's packing time, not a whole one) and so are the
  * last ones (the results of the final chunks come back quickly): weights 1/4, 1/2, 1 ... 1, 1/2.  Returns the chunk count, cbeg[0..count] */
-static int make_chunks(int n, const double *cost, double total, int nchunks, int workers, int *cbeg)
+static int make_chunks(int n, const double *cost, double total, int nchunks, int workers, int chunk_pairs, int *cbeg)
 {
+	if (chunk_pairs > 0) {                                /* batches of one shape: whole device fills (uniform_chunks) */
+		int c = 0, b;
+		for (b = 0; b < n && c < nchunks; b += chunk_pairs) cbeg[c++] = b;
+		cbeg[c] = n;
+		return c;
+	}
 	const int ramp = nchunks >= 3 * workers && workers > 0 && env_flag("KSW2AMD_RAMP", 0), nc = ramp ? nchunks + 2 * workers : nchunks;
 	double wsum = 0, acc = 0, edge = 0;
 	int i, c = 0;
@@ -1227,6 +1233,52 @@ static int pool_min_pairs(void)
 {
 	const char *e = getenv("KSW2AMD_POOL_MIN");           /* tests: pool batches of this many pairs or more, whatever their size */
 	return e && atoi(e) > 0 ? atoi(e) : 0;
+}
+
+/* critical path of a fill (seconds) from which a batch counts as "long alignments" in plan_chunks; KSW2AMD_LONG_MS overrides */
+static double long_path_s(void)
+{
+	static double v = -1;
+	if (v < 0) { const char *e = getenv("KSW2AMD_LONG_MS"); v = e && atof(e) > 0 ? atof(e) * 1e-3 : 0.010; }
+	return v;
+}
+
+/* pairs that put one wavefront on every SIMD, for a batch of this pair's shape: the first packed geometry that holds the band
+ * (as the classification in plan_create_ex picks it) runs 2 x 64 / G alignments per wavefront.  0 = no resident geometry (the
+ * generation-serial classes) or no device figure: such batches keep the cost-balanced chunks. */
+static int unit_pairs(const ksw2amd_pair_t *a)
+{
+	const int simds = k2a_shim_simd_count(), tl = imax(a->tlen, 1), mx = imax(a->qlen, tl);
+	const int w = (a->w < 0 || a->w > mx) ? mx : a->w;
+	int pc;
+	if (simds <= 0) return 0;
+	for (pc = (a->flag & KSW_EZ_SCORE_ONLY) ? 0 : 1; pc < K2A_PKCFG_MP; ++pc)
+		if (geom_fits(k2a_pkcfg_G[pc], k2a_pkcfg_C[pc], tl, w)) return simds * 2 * (64 / k2a_pkcfg_G[pc]);
+	return 0;
+}
+
+/* Batches whose pairs all have one shape (the configurations of BASELINE.json; reads trimmed to one length): every wavefront of
+ * a fill lasts equally long, so a kernel takes as long as the SIMD that holds the most of them, and a chunk whose wavefronts do
+ * not tile the SIMDs wastes the difference (config 3, 16 384 pairs: 8 chunks of 2 048 pairs = 1 024 wavefronts 759 GCUPS end to
+ * end, 6 chunks of 2 731 485, 12 of 1 365 416; 10 k x 10 k with CIGAR, 4 096 pairs: 2 chunks 1 286, 3 chunks 585, one plan 1 075;
+ * config 2: 8 chunks of half a fill 1 118, 6 chunks 933; profiles/r2_chunk_units.txt).  `unit` = pairs of one wavefront per SIMD
+ * (unit_pairs).  Chunks are 2^j x the smallest useful size -- half a unit for short score-only reads, one unit with CIGARs, two
+ * units for long score-only reads (the 10 k headline: 12 chunks of 4 096 pairs 3 276, 24 of 2 048 3 211, 6 of 8 192 3 095) -- with
+ * at most two chunks per worker.  Returns the chunk count (0 = one plan on the calling thread) and the chunk size. */
+static int uniform_chunks(int n, int unit, double bytes, int workers, int ndev, int with_cigar, double path_steps, int *chunk_pairs)
+{
+	const char *e1 = getenv("KSW2AMD_CHUNK_MB");
+	const double cap_b = (e1 && atof(e1) > 0 ? atof(e1) : 128.0) * 1048576.0;
+	const double path_s = path_steps * (with_cigar ? 4.5e-6 : 2.5e-6);
+	double cu = with_cigar ? 1.0 : path_s >= long_path_s() ? 2.0 : 0.5, kmax = 2.0 * workers;
+	const double units = (double)n / unit;
+	int k;
+	if (ndev > 1) kmax = 3.0 * workers;
+	if (bytes / cap_b > kmax) kmax = bytes / cap_b;
+	while (units / cu > kmax) cu *= 2;
+	*chunk_pairs = (int)(cu * unit);
+	k = (n + *chunk_pairs - 1) / *chunk_pairs;
+	return k < 2 ? 0 : k;
 }
 
 static int plan_chunks(int n, double bytes, double cells, int workers, int ndev, int with_cigar, double path_steps)
@@ -1261,19 +1313,20 @@ static int plan_chunks(int n, double bytes, double cells, int workers, int ndev,
 	 * nchunks x path <= cells / rate.  Short alignments (path below 10 ms) keep one (two with CIGARs) chunk per worker. */
 	{
 		const double total_s = cells / (with_cigar ? 1e12 : 2e12), path_s = path_steps * (with_cigar ? 4.5e-6 : 2.5e-6);
-		if (path_s >= 0.010) {
+		if (path_s >= long_path_s()) {
 			if (with_cigar) { if (k > total_s / path_s) k = total_s / path_s; }
 			else {
 				/* score only: a kernel of exactly two wavefronts per SIMD (4096 pairs, two per wavefront) has no tail, and such
 				 * kernels follow each other without a gap -- 12 chunks of 4096 pairs: 3 050 GCUPS, 9 of 5461: 2 675 */
-				const double units = (double)n / 4096.0;
+				const double units = (double)(n / 4096);
+				k = (double)(int)(k + 0.999);              /* 11.99 chunks by the cell cap are 12, not 11 of 4 468 pairs */
 				if (k > units) k = units;
-				k = (double)(int)k;
 			}
 		}
 		else if (k > (with_cigar ? 2 : 1) * workers && bytes / cap_b <= (with_cigar ? 2 : 1) * workers) k = (with_cigar ? 2 : 1) * workers;
 	}
 	if (ndev > 1 && k < 3 * workers) k = 3 * workers;      /* several devices: finer grains balance them */
+	{ const char *e3 = getenv("KSW2AMD_CHUNKS"); if (e3 && atoi(e3) > 0) k = atoi(e3); }      /* experiments: this many chunks, whatever the batch */
 	if (k > n / min_chunk) k = n / min_chunk;
 	return k < 2 ? 0 : (int)(k + 0.999);
 }
@@ -1299,8 +1352,10 @@ static int ext_finish(ext_ctx_t *c, pend_t *pd)
  * different chunks; double-buffered (`dbuf`), a worker queues chunk k + 1 before it waits for chunk k, so the device always has
  * kernels behind the ones it runs while the workers download and assemble CIGARs.  Measured (profiles/r2_chunk_grid.txt,
  * r2_pipeline_traces.txt): score-only long reads lose with it (10 k headline 2 720 vs 3 100 GCUPS: twice the plans in flight, each
- * kernel filling less of the device), short reads with CIGARs gain (config 3: 735 vs 540): run_batch decides (KSW2AMD_DBUF=0/1
- * forces).  A chunk that does not fit one plan (traceback memory) takes the serial path. */
+ * kernel filling less of the device); short reads with CIGARs gained over chunks that did not tile the SIMDs (config 3: 735 vs
+ * 540) but lose against chunks that do (600-670 vs 745-765, r2_chunk_units.txt), and over many batches it degrades badly
+ * (config 3: 597 GCUPS over 10 batches, 42 over 30; not run down -- a worker's second live plan misses the one-deep buffer cache
+ * once per batch, i.e. a multi-GB hipMalloc + hipFree per worker and batch, which is the suspect): off unless KSW2AMD_DBUF=1.  A chunk that does not fit one plan (traceback memory) takes the serial path. */
 static int ext_chunk(void *ctx_, int beg, int end, int share, pend_t *pd)
 {
 	ext_ctx_t *c = (ext_ctx_t*)ctx_;
@@ -1347,7 +1402,7 @@ static void job_devices(job_t *j)
 }
 
 /* run the chunks of a batch on the pool; 1 = done (rc in *rc), 0 = the caller must run the batch inline */
-static int run_pooled(chunk_fn fn, void *ctx, int n, const double *cost, double total, int nchunks, int *rc)
+static int run_pooled(chunk_fn fn, void *ctx, int n, const double *cost, double total, int nchunks, int chunk_pairs, int *rc)
 {
 	job_t j;
 	const int tpd = pool_threads_per_device(), workers = tpd * (g_ndev_set > 0 ? g_ndev_set : 1);
@@ -1355,7 +1410,7 @@ static int run_pooled(chunk_fn fn, void *ctx, int n, const double *cost, double 
 	if (!cbeg) return 0;
 	memset(&j, 0, sizeof(j));
 	j.fn = fn; j.ctx = ctx; j.cbeg = cbeg;
-	j.nchunks = make_chunks(n, cost, total, nchunks, workers, cbeg);
+	j.nchunks = make_chunks(n, cost, total, nchunks, workers, chunk_pairs, cbeg);
 	job_devices(&j);
 	j.share = imax(1, imin(tpd, (j.nchunks + j.ndev - 1) / j.ndev));      /* plans alive per device at a time: the memory budget's divisor */
 	if (pool_run(&j)) { free(cbeg); return 0; }
@@ -1373,10 +1428,11 @@ static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc
 	if (n >= (pool_min_pairs() ? pool_min_pairs() : 512) && tpd > 0 && !g_is_worker) {
 		const int workers = tpd * (g_ndev_set > 0 ? g_ndev_set : 1);
 		double *cost = (double*)malloc(sizeof(double) * (size_t)n), bytes = 0, cells = 0, total = 0, path = 0;
-		int i, nchunks, rc = 0;
+		int i, nchunks, rc = 0, uniform = 1, chunk_pairs = 0;
 		if (cost) {
 			for (i = 0; i < n; ++i) {
 				const int ql = imax(pairs[i].qlen, 0), tl = imax(pairs[i].tlen, 0), mx = imax(ql, tl);
+				if (pairs[i].qlen != pairs[0].qlen || pairs[i].tlen != pairs[0].tlen || pairs[i].w != pairs[0].w || ((pairs[i].flag ^ pairs[0].flag) & KSW_EZ_SCORE_ONLY)) uniform = 0;
 				const double b = (double)ql + tl, c = ql && tl ? (double)band_cells(ql, tl, (pairs[i].w < 0 || pairs[i].w > mx) ? mx : pairs[i].w) : 0;
 				bytes += b; cells += c;
 				{	/* steps of the pair's fill: columns + strips; wide bands on long targets run as generations of 1024 rows, four at a time */
@@ -1387,15 +1443,19 @@ static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc
 				cost[i] = 1.0 + c + 64.0 * b;              /* a byte costs the host about as much as 64 cells cost the device */
 				total += cost[i];
 			}
-			nchunks = plan_chunks(n, bytes, cells, workers, g_ndev_set, !(pairs[0].flag & KSW_EZ_SCORE_ONLY), path);
+			{
+				const int unit = uniform && !pool_min_pairs() && !getenv("KSW2AMD_CHUNKS") && !getenv("KSW2AMD_NO_UNITS") ? unit_pairs(&pairs[0]) : 0;
+				if (unit > 0) nchunks = uniform_chunks(n, unit, bytes, workers, g_ndev_set, !(pairs[0].flag & KSW_EZ_SCORE_ONLY), path, &chunk_pairs);
+				else nchunks = plan_chunks(n, bytes, cells, workers, g_ndev_set, !(pairs[0].flag & KSW_EZ_SCORE_ONLY), path);
+			}
 			if (nchunks >= 2) {
 				ext_ctx_t ctx;
 				ctx.dual = dual; ctx.scalar = scalar; ctx.km = km; ctx.sc = sc; ctx.pairs = pairs; ctx.ez = ez;
-				{	/* double-buffer short reads with CIGARs (see ext_chunk) */
+				{	/* double-buffering is opt-in (see ext_chunk) */
 					const char *ev = getenv("KSW2AMD_DBUF");
-					ctx.dbuf = ev && *ev ? atoi(ev) != 0 : (!(pairs[0].flag & KSW_EZ_SCORE_ONLY) && path * 4.5e-6 < 0.010);
+					ctx.dbuf = ev && *ev ? atoi(ev) != 0 : 0;
 				}
-				if (run_pooled(ext_chunk, &ctx, n, cost, total, nchunks, &rc)) { free(cost); return rc; }
+				if (run_pooled(ext_chunk, &ctx, n, cost, total, nchunks, chunk_pairs, &rc)) { free(cost); return rc; }
 			}
 			free(cost);
 		}
@@ -1908,7 +1968,7 @@ int ksw2amd_exts_batch(void *km, const ksw2amd_splice_t *sc, int n, const ksw2am
 			exts_ctx_t ctx;
 			for (i = 0; i < n; ++i) { cost[i] = 1.0 + (double)imax(pairs[i].qlen, 0) * imax(pairs[i].tlen, 0); total += cost[i]; }
 			ctx.km = km; ctx.sc = sc; ctx.pairs = pairs; ctx.ez = ez;
-			if (run_pooled(exts_chunk, &ctx, n, cost, total, nchunks, &rc)) { free(cost); return rc; }
+			if (run_pooled(exts_chunk, &ctx, n, cost, total, nchunks, 0, &rc)) { free(cost); return rc; }
 		}
 		free(cost);
 	}
@@ -2360,7 +2420,7 @@ int ksw2amd_extf_batch(void *km, int8_t mch, int8_t mis, int8_t e, int n, const 
 			extf_ctx_t ctx;
 			for (i = 0; i < n; ++i) { cost[i] = 1.0 + (double)imax(pairs[i].qlen, 0) + imax(pairs[i].tlen, 0); total += cost[i]; }
 			ctx.km = km; ctx.mch = mch; ctx.mis = mis; ctx.e = e; ctx.pairs = pairs; ctx.ez = ez;
-			if (run_pooled(extf_chunk, &ctx, n, cost, total, nchunks, &rc)) { free(cost); return rc; }
+			if (run_pooled(extf_chunk, &ctx, n, cost, total, nchunks, 0, &rc)) { free(cost); return rc; }
 		}
 		free(cost);
 	}

@@ -146,7 +146,7 @@ K2A_FN uint32_t k2a_pack_dirs(k2a_pk d0, k2a_pk d1)
 /* Codes only (LDSROW_ = 2): the exact score-only kernel of the 16-row geometry holds 178-190 registers, two wavefronts per
  * SIMD; with the two code planes (32 registers) in LDS it fits three.  Nothing else changes: the planes are read-only
  * between strip starts, two LDS loads per row and step. */
-#define K2A_PK_LDSCODES(G, C, DUAL, MODE, NOMAX) ((G) == 64 && (C) == 16 && !(DUAL) && (MODE) == K2A_MODE_SCORE && !(NOMAX))
+#define K2A_PK_LDSCODES(G, C, DUAL, MODE, NOMAX) ((G) == 64 && (C) == 16 && !(DUAL) && (MODE) == K2A_MODE_SCORE)
 #define K2A_PK_LDSCODE_WORDS(C) (2 * (C) * 64)       /* per wavefront */
 
 template<int G, int C, bool DUAL, int MODE = K2A_MODE_SCORE, bool RB = false, bool NOMAX = false, int LDSROW_ = 0>

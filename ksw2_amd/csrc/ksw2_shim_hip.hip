@@ -1350,13 +1350,14 @@ static const fill_pk_fn g_fill_pk_lds[2][2] = {
 	{ k2a_fill_pk_kernel<64, 16, true, 1, true, false, 1>,  k2a_fill_pk_kernel<64, 16, true, 2, true, false, 1> } };
 
 /* exact score-only kernels of the 16-row geometry with the code planes in LDS (three wavefronts per SIMD): [rebased] */
-static const fill_pk_fn g_fill_pk_ldscodes[2] = { k2a_fill_pk_kernel<64, 16, false, 0, false, false, 2>, k2a_fill_pk_kernel<64, 16, false, 0, true, false, 2> };
+static const fill_pk_fn g_fill_pk_ldscodes[2][2] = { { k2a_fill_pk_kernel<64, 16, false, 0, false, false, 2>, k2a_fill_pk_kernel<64, 16, false, 0, true, false, 2> },
+                                                     { k2a_fill_pk_kernel<64, 16, false, 0, false, true, 2>,  k2a_fill_pk_kernel<64, 16, false, 0, true, true, 2> } };      /* [nomax][rebased] */
 /* worth it once SIMDs would hold a third wavefront; KSW2AMD_LDSCODES=0 / 1 forces the choice */
 static bool k2a_use_ldscodes(int waves)
 {
 	const char *ev = getenv("KSW2AMD_LDSCODES");
 	if (ev) return atoi(ev) != 0;
-	return (long)waves > 2 * (long)k2a_shim_simd_count();
+	return 2 * (long)waves >= 3 * (long)k2a_shim_simd_count();      /* a pooled batch launches chunks of two wavefronts per SIMD side by side */
 }
 
 /* Row state in LDS (two wavefronts per SIMD) or in registers (one): the LDS form wins as soon as SIMDs hold two
@@ -1496,7 +1497,7 @@ int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax,
 	const int blocks = (ntasks + per_block - 1) / per_block;
 	const bool lds = K2A_PK_LDSROWS(k2a_pkcfg_G[cfg], k2a_pkcfg_C[cfg], dual, mode, nomax) && k2a_use_ldsrows(ntasks);
 	const bool ldc = K2A_PK_LDSCODES(k2a_pkcfg_G[cfg], k2a_pkcfg_C[cfg], dual, mode, nomax) && k2a_use_ldscodes(ntasks);
-	hipLaunchKernelGGL(lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1] : ldc ? g_fill_pk_ldscodes[rebased ? 1 : 0] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
+	hipLaunchKernelGGL(lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1] : ldc ? g_fill_pk_ldscodes[nomax ? 1 : 0][rebased ? 1 : 0] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
 	                   *sc, pairs, order2, ntasks, seq, tb, res);
 	CHECK(hipGetLastError());
 	return 0;

@@ -354,7 +354,8 @@ static const fill_pk_fn g_fill_pk[2][2][K2A_NPKCFG][2][3] = { PK_SET(false), PK_
 static const fill_pk_fn g_fill_pk_lds[2][2] = {
 	{ sim_fill_pk<64, 16, true, 1, false, false, 1>, sim_fill_pk<64, 16, true, 2, false, false, 1> },
 	{ sim_fill_pk<64, 16, true, 1, true, false, 1>,  sim_fill_pk<64, 16, true, 2, true, false, 1> } };
-static const fill_pk_fn g_fill_pk_ldscodes[2] = { sim_fill_pk<64, 16, false, 0, false, false, 2>, sim_fill_pk<64, 16, false, 0, true, false, 2> };
+static const fill_pk_fn g_fill_pk_ldscodes[2][2] = { { sim_fill_pk<64, 16, false, 0, false, false, 2>, sim_fill_pk<64, 16, false, 0, true, false, 2> },
+                                                     { sim_fill_pk<64, 16, false, 0, false, true, 2>,  sim_fill_pk<64, 16, false, 0, true, true, 2> } };      /* [nomax][rebased] */
 /* the code planes in LDS (exact score-only kernel of the 16-row geometry): taken unless KSW2AMD_LDSCODES=0 */
 static bool sim_use_ldscodes(void) { const char *ev = getenv("KSW2AMD_LDSCODES"); return !ev || atoi(ev) != 0; }
 /* the simulator takes the LDS form of the row state unless KSW2AMD_LDSROWS=0 (the GPU launcher decides by the number of tasks) */
@@ -928,7 +929,7 @@ int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax,
 {
 	const bool lds = K2A_PK_LDSROWS(k2a_pkcfg_G[cfg], k2a_pkcfg_C[cfg], dual, mode, nomax) && sim_use_ldsrows();
 	const bool ldc = K2A_PK_LDSCODES(k2a_pkcfg_G[cfg], k2a_pkcfg_C[cfg], dual, mode, nomax) && sim_use_ldscodes();
-	if (ntasks > 0) (lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1] : ldc ? g_fill_pk_ldscodes[rebased ? 1 : 0] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode])(*sc, pairs, order2, ntasks, seq, tb, res);
+	if (ntasks > 0) (lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1] : ldc ? g_fill_pk_ldscodes[nomax ? 1 : 0][rebased ? 1 : 0] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode])(*sc, pairs, order2, ntasks, seq, tb, res);
 	return 0;
 }
 int k2a_shim_launch_trace_pk(int cfg, int dual, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb,
