@@ -995,7 +995,10 @@ static size_t pair_device_bytes(int dual, const ksw2amd_pair_t *a)
 		if (w <= 1040 || a->tlen <= 2048)
 			b += steps * 64 * (dual ? 32 : 16) / (w <= 68 ? 8 : w <= 284 ? 4 : w <= 536 ? 2 : 1) + 256;
 		else   /* generation-serial: one (qlen + 63)-step sweep per 1024 rows, 64 lanes x 16 rows per step */
-			b += (((size_t)a->tlen / 1024 + 1) * ((size_t)a->qlen + 72) + K2A_TB_PAD) * 64 * 16 + 24 * (size_t)a->qlen + 320 + 131072;   /* packed class: 32 bytes per lane-step and two pairs */
+			/* int32 and dual-gap packed classes: 16 bytes per lane-step and pair; single-gap packed class (4-bit codes): 8.  A
+			 * single-gap pair that ends up in the int32 class (wildcards, generic matrix, too few tasks) needs twice this: the
+			 * callers halve a plan whose allocation fails */
+			b += (((size_t)a->tlen / 1024 + 1) * ((size_t)a->qlen + 72) + K2A_TB_PAD) * 64 * (dual ? 16 : 8) + 24 * (size_t)a->qlen + 320 + 131072;
 		b += ((size_t)a->qlen + a->tlen + 2) * 4;
 	}
 	return b;
@@ -1003,13 +1006,19 @@ static size_t pair_device_bytes(int dual, const ksw2amd_pair_t *a)
 
 /* One slice of a batch on the calling thread: plan(s) sized to `1 / share` of the device's free memory (share = threads that
  * work on this device at the same time), each created, run on the thread's own stream, fetched and destroyed. */
+static double now_ms(void);
+static int trace_on(void);
+static int unit_pairs(const ksw2amd_pair_t *a);
 static int run_serial(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez, int share)
 {
 	size_t budget, free_b = 0, total_b = 0, acc;
 	const char *env = getenv("KSW2AMD_MAX_BYTES");
-	int beg = 0, end;
+	int beg = 0, end, unit;
+	double t0;
 	if (n <= 0) return KSW2AMD_OK;
 	if (share < 1) share = 1;
+	unit = unit_pairs(&pairs[0]);
+	if (unit <= 0) unit = k2a_shim_simd_count();          /* generation-serial classes: two tasks of two pairs per CU */
 	if (env && atoll(env) > 0) budget = (size_t)atoll(env);
 	else {
 		/* small batches (the single-pair entry points above all) skip the free-memory query: it costs ~0.1 ms */
@@ -1032,7 +1041,11 @@ static int run_serial(int dual, int scalar, void *km, const ksw2amd_scoring_t *s
 			if (end > beg && (acc + b > budget || seq + sq > 3000000000u || cig + cg > 3000000000u || end - beg >= (1 << 22))) break;
 			acc += b; seq += sq; cig += cg;
 		}
+		/* a batch that is split anyway: whole device fills per plan (see uniform_chunks; config 4 through 249-pair plans fell
+		 * back to the int32 class, one wavefront on a quarter of the SIMDs: 254 GCUPS end to end) */
+		if (end < n && unit > 0 && end - beg > unit) end = beg + (end - beg) / unit * unit;
 		/* the footprint estimate is an upper bound in practice; should the device still run out, retry with half the pairs */
+		t0 = now_ms();
 		for (p = 0; p == 0; ) {
 			if (end - beg > limit) end = beg + limit;
 			p = plan_create_ex(dual, scalar, sc, end - beg, pairs + beg);
@@ -1041,9 +1054,16 @@ static int run_serial(int dual, int scalar, void *km, const ksw2amd_scoring_t *s
 			release_thread_cache();
 			limit = (end - beg) / 2;
 		}
-		rc = ksw2amd_plan_run(p, thread_stream());
-		if (rc == KSW2AMD_OK) rc = ksw2amd_plan_fetch(p, km, ez + beg);
-		ksw2amd_plan_destroy(p);
+		{
+			const double t1 = now_ms();
+			double t2, t3;
+			rc = ksw2amd_plan_run(p, thread_stream());
+			t2 = now_ms();
+			if (rc == KSW2AMD_OK) rc = ksw2amd_plan_fetch(p, km, ez + beg);
+			t3 = now_ms();
+			ksw2amd_plan_destroy(p);
+			if (trace_on()) fprintf(stderr, "[ksw2_amd] serial plan @%d n=%d: create %.2f ms, launch %.2f ms, wait+fetch %.2f ms, destroy %.2f ms, budget %zu\n", beg, end - beg, t1 - t0, t2 - t1, t3 - t2, now_ms() - t3, budget);
+		}
 		if (rc) return rc;
 		beg = end;
 	}
@@ -1427,9 +1447,15 @@ static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc
 	if (k2a_shim_device_count() <= 0) return fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend());
 	if (n >= (pool_min_pairs() ? pool_min_pairs() : 512) && tpd > 0 && !g_is_worker) {
 		const int workers = tpd * (g_ndev_set > 0 ? g_ndev_set : 1);
-		double *cost = (double*)malloc(sizeof(double) * (size_t)n), bytes = 0, cells = 0, total = 0, path = 0;
+		double *cost = (double*)malloc(sizeof(double) * (size_t)n), bytes = 0, cells = 0, total = 0, path = 0, dev_bytes = 0;
 		int i, nchunks, rc = 0, uniform = 1, chunk_pairs = 0;
 		if (cost) {
+			for (i = 0; i < n; ++i) dev_bytes += (double)pair_device_bytes(dual, &pairs[i]);
+			if (dev_bytes > 64e9 && !pool_min_pairs()) {
+				/* traceback memory is what splits this batch: one plan at a time with the whole device, not a slice per worker */
+				size_t free_b = 0, total_b = 0;
+				if (k2a_shim_mem_info(&free_b, &total_b) == 0 && dev_bytes > 0.5 * (double)total_b && g_ndev_set <= 1) { free(cost); return run_serial(dual, scalar, km, sc, n, pairs, ez, 1); }
+			}
 			for (i = 0; i < n; ++i) {
 				const int ql = imax(pairs[i].qlen, 0), tl = imax(pairs[i].tlen, 0), mx = imax(ql, tl);
 				if (pairs[i].qlen != pairs[0].qlen || pairs[i].tlen != pairs[0].tlen || pairs[i].w != pairs[0].w || ((pairs[i].flag ^ pairs[0].flag) & KSW_EZ_SCORE_ONLY)) uniform = 0;
