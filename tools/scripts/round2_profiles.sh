@@ -2,7 +2,7 @@
 # GPU box: everything the round-2 entries of profiles/ come from.  usage: tools/scripts/round2_profiles.sh <tag>
 TAG=$1
 mkdir -p gpurun_out/profiles
-for w in 10k cfg2 cfg3 cfg4 cfg5; do bash tools/scripts/profile_round.sh $TAG $w 3 > gpurun_out/prof_${TAG}_$w.log 2>&1; done
+for w in 10k 10k-cigar cfg2 cfg3 cfg4 cfg5 exts extf; do bash tools/scripts/profile_round.sh $TAG $w 3 > gpurun_out/prof_${TAG}_$w.log 2>&1; done
 for w in 10k 10k-cigar cfg2 cfg3 cfg4 cfg5 exts extf; do
 	n=$(echo $w | tr - _)
 	timeout 900 python bench.py --workload $w --steps 10 --warmup 2 --cpu-seconds 8 --no-also 2> gpurun_out/bench_${TAG}_$w.err | tail -1 > gpurun_out/profiles/${TAG}_bench_$n.json
