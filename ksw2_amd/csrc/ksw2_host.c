@@ -1295,6 +1295,7 @@ static int uniform_chunks(int n, int unit, double bytes, int workers, int ndev, 
 	double cu = with_cigar ? 1.0 : path_s >= long_path_s() ? 2.0 : 0.5, kmax = 2.0 * workers;
 	const double units = (double)n / unit;
 	int k;
+	if (workers <= 0 || n < 512 || (bytes < 4.0 * 1048576.0 && units * unit * path_steps * 64 < 2e9)) return 0;      /* as plan_chunks: too small to be worth the hand-off */
 	if (ndev > 1) kmax = 3.0 * workers;
 	if (bytes / cap_b > kmax) kmax = bytes / cap_b;
 	while (units / cu > kmax) cu *= 2;

@@ -71,6 +71,26 @@ def test_pooled_batch_several_devices(sim, monkeypatch):
         sim.release_cache()
 
 
+@pytest.mark.parametrize("score_only,expect_chunks", [(True, 4), (False, 4)])
+def test_uniform_batch_is_cut_at_device_fills(sim, monkeypatch, score_only, expect_chunks):
+    """A batch of one shape is cut into chunks that are multiples of a device fill (ksw2_host.c::uniform_chunks); here a
+    simulated device of 4 SIMDs: (8 lanes x 18 rows) / (16 x 8) geometry -> 64 / 32 pairs per unit, doubled until three workers
+    have at most two chunks each -> four chunks of 1 024 pairs."""
+    monkeypatch.setenv("KSW2AMD_SIM_SIMDS", "4")
+    monkeypatch.setenv("KSW2AMD_SIMDS", "0")
+    monkeypatch.setenv("KSW2AMD_THREADS", "3")
+    n = 4096
+    qs, ts = synth.fixed_batch(77, n, 1000, 1000, sub=0.05, ind=0.1)
+    mat = synth.simple_mat(5, 2, 4, -1)
+    fl = po.SCORE_ONLY if score_only else 0
+    s0 = sim.host_stats()
+    m, _ = check_batch(sim, False, list(qs), list(ts), mat, 4, 2, 24, 1, w=8, zdrop=-1, flag=fl)
+    s1 = sim.host_stats()
+    assert m == n
+    assert s1["pool_batches"] == s0["pool_batches"] + 1
+    assert s1["pool_chunks"] == s0["pool_chunks"] + expect_chunks
+
+
 def test_pool_off_and_inline_paths_agree(sim, monkeypatch):
     qs, ts, w, zd, fl = _ragged(31, 60)
     mat = synth.simple_mat(5, 2, 4, -1)
