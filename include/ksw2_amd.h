@@ -156,7 +156,7 @@ int ksw2amd_set_device(int device);    /* device used by the calling thread's su
  * calling thread's and those of the library's worker threads */
 void ksw2amd_release_cache(void);
 /* Devices the batch entry points below shard their work over (process-wide; pairs are independent, so this is host-side
- * sharding without any collective: the library's worker threads -- KSW2AMD_THREADS per device, default 4 -- pull chunks of
+ * sharding without any collective: the library's worker threads -- KSW2AMD_THREADS per device, default 6 -- pull chunks of
  * the batch from a shared counter).  n = 0 (the default): the calling thread's current device only.
  * Replaces nothing in the reference (ksw2.h has no device notion); SURVEY.md section 8b "device selection / multi-GPU inside". */
 int ksw2amd_set_devices(int n, const int *devices);

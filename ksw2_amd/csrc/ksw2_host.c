@@ -1287,7 +1287,7 @@ static int unit_pairs(const ksw2amd_pair_t *a)
  * (unit_pairs).  Chunks are 2^j x the smallest useful size -- half a unit for short score-only reads, one unit with CIGARs, two
  * units for long score-only reads (the 10 k headline: 12 chunks of 4 096 pairs 3 276, 24 of 2 048 3 211, 6 of 8 192 3 095) -- with
  * at most two chunks per worker.  Returns the chunk count (0 = one plan on the calling thread) and the chunk size. */
-static int uniform_chunks(int n, int unit, double bytes, int workers, int ndev, int with_cigar, double path_steps, int *chunk_pairs)
+static int uniform_chunks(int n, int unit, double bytes, double cells, int workers, int ndev, int with_cigar, double path_steps, int *chunk_pairs)
 {
 	const char *e1 = getenv("KSW2AMD_CHUNK_MB");
 	const double cap_b = (e1 && atof(e1) > 0 ? atof(e1) : 128.0) * 1048576.0;
@@ -1295,7 +1295,7 @@ static int uniform_chunks(int n, int unit, double bytes, int workers, int ndev, 
 	double cu = with_cigar ? 1.0 : path_s >= long_path_s() ? 2.0 : 0.5, kmax = 2.0 * workers;
 	const double units = (double)n / unit;
 	int k;
-	if (workers <= 0 || n < 512 || (bytes < 4.0 * 1048576.0 && units * unit * path_steps * 64 < 2e9)) return 0;      /* as plan_chunks: too small to be worth the hand-off */
+	if (workers <= 0 || n < 512 || (bytes < 4.0 * 1048576.0 && cells < 2e9)) return 0;      /* as plan_chunks: too small to be worth the hand-off */
 	if (ndev > 1) kmax = 3.0 * workers;
 	if (bytes / cap_b > kmax) kmax = bytes / cap_b;
 	while (units / cu > kmax) cu *= 2;
@@ -1474,7 +1474,7 @@ static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc
 			}
 			{
 				const int unit = uniform && !pool_min_pairs() && !getenv("KSW2AMD_CHUNKS") && !getenv("KSW2AMD_NO_UNITS") ? unit_pairs(&pairs[0]) : 0;
-				if (unit > 0) nchunks = uniform_chunks(n, unit, bytes, workers, g_ndev_set, !(pairs[0].flag & KSW_EZ_SCORE_ONLY), path, &chunk_pairs);
+				if (unit > 0) nchunks = uniform_chunks(n, unit, bytes, cells, workers, g_ndev_set, !(pairs[0].flag & KSW_EZ_SCORE_ONLY), path, &chunk_pairs);
 				else nchunks = plan_chunks(n, bytes, cells, workers, g_ndev_set, !(pairs[0].flag & KSW_EZ_SCORE_ONLY), path);
 			}
 			if (nchunks >= 2) {
