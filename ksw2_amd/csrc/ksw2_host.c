@@ -399,8 +399,13 @@ static int cmp_cost_desc(const void *a, const void *b)
 
 /* `scalar`: the call came through ksw_extz / ksw_extd / ksw_gg* (matrix used as given, no end bonus, no mismatch-vs-gap
  * reject, gap pieces kept in the caller's order).  Decided by the entry point, never by a bit in the caller's flags. */
+static double now_ms(void);
+static int trace_level(void) { static int t = -1; if (t < 0) { const char *e = getenv("KSW2AMD_TRACE"); t = e ? atoi(e) : 0; } return t; }
+
 static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs)
 {
+	double tph[6] = { 0, 0, 0, 0, 0, 0 };
+	const int tlev = trace_level() >= 2;
 	ksw2amd_plan_t *p;
 	int i, k, q, e, q2, e2, m, lo, ci;
 	size_t off, mat_off = 0;
@@ -416,6 +421,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	const int use_pkmp = !getenv("KSW2AMD_NO_PKMP");                          /* A/B runs and tests: wide bands through the int32 generation-serial kernels */
 	const int pk_first = getenv("KSW2AMD_PK_FIRST") ? atoi(getenv("KSW2AMD_PK_FIRST")) : 0;   /* A/B runs: skip the smaller packed geometries */
 
+	if (tlev) tph[0] = now_ms();
 	g_err[0] = 0;
 	if (n < 0 || (n > 0 && !pairs) || !sc) { fail(KSW2AMD_E_PARAM, "plan_create: bad arguments%s", 0); return 0; }
 	if (k2a_shim_device_count() <= 0) { fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend()); return 0; }
@@ -461,6 +467,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, p->seq_bytes, &p->cap[BUF_HSEQ]);
 	if (!p->h_seq) { fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
 
+	if (tlev) tph[1] = now_ms();
 	/* pass 1: copy the codes; geometry class, traceback / CIGAR / boundary space, packed-int16 eligibility per pair */
 	pkinfo[0].ok = pkinfo[1].ok = -1;
 	pk_ok = (uint8_t*)calloc((size_t)n + 1, 1);
@@ -519,6 +526,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 		}
 	}
 
+	if (tlev) tph[2] = now_ms();
 	/* Alignments without a partner of identical shape would be paired with themselves.  With traceback on a
 	 * one-alignment-per-wavefront geometry that is slower than the int32 kernel (tools/scripts/ragged_probe.py: 10 k reads of
 	 * unique lengths, CIGAR: 707 vs 825 GCUPS) and writes twice the direction bytes, so the odd one of every shape goes back.
@@ -583,6 +591,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 		for (i = 0; i < n; ++i) if (p->h_cls[i] >= 0 && pk_ok[i] == PASS_SOLO && (simds <= 0 || cnt[p->h_cls[i]] < 4 * simds)) pk_ok[i] = 0;
 	}
 
+	if (tlev) tph[3] = now_ms();
 	/* the sequence arena goes up while the host sorts out the task lists (pinned staging: the copy is asynchronous) */
 	if (m > 5) {
 		build_eff(dual, m, sc->mat, e, e2, 0, (int8_t*)p->h_seq + mat_off);
@@ -647,6 +656,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 		free(srt); srt = 0;
 	}
 
+	if (tlev) tph[4] = now_ms();
 	/* packed generation-serial tasks: boundary entries + the four wavefronts' row-maximum keys (ksw2_shim.h), shared by the two alignments */
 	for (k = 0; k < p->ncls; ++k) {
 		const cls_t *c = &p->cls[k];
@@ -688,6 +698,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 		}
 	}
 
+	if (tlev) tph[5] = now_ms();
 	/* upload the rest */
 	p->d_pairs = (K2aPair*)cache_get(BUF_PAIRS, sizeof(K2aPair) * ((size_t)n + 1), &p->cap[BUF_PAIRS]);
 	p->d_res = (K2aResult*)cache_get(BUF_RES, sizeof(K2aResult) * ((size_t)n + 1), &p->cap[BUF_RES]);
@@ -713,6 +724,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	/* the uploads are complete: the plan no longer refers to the creating thread's stream (which may be gone -- thread exit,
 	 * ksw2amd_release_cache, ksw2amd_set_device -- before the plan runs or is destroyed) */
 	p->stream = 0; p->stream_used = 0;
+	if (tlev) { const double t6 = now_ms(); fprintf(stderr, "[ksw2_amd] plan_create n=%d: host arrays + arena layout %.3f, copy + classify %.3f, shape parity + demotions %.3f, sequence upload call + task lists %.3f, traceback layout %.3f, uploads + sync %.3f ms\n", n, tph[1] - tph[0], tph[2] - tph[1], tph[3] - tph[2], tph[4] - tph[3] , tph[5] - tph[4], t6 - tph[5]); }
 	return p;
 err:
 	free(srt); free(pk_ok); free(solo_ok);
