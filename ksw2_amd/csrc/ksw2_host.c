@@ -665,7 +665,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 			K2aPair *da = &p->h_pairs[p->h_order[c->first + 2 * i]], *db = &p->h_pairs[p->h_order[c->first + 2 * i + 1]];
 			p->bnd_words = align_up(p->bnd_words, 4);
 			da->bnd_off = db->bnd_off = (uint32_t)p->bnd_words;
-			p->bnd_words += align_up((size_t)da->qlen * (dual ? 5 : 4) + 16, 4) + 4 * (size_t)(64 * 16 * 2 * 2);      /* K2A_PKMP_BND_WORDS + 4 x K2A_PKMP_SPILL_WORDS(16) */
+			p->bnd_words += align_up((size_t)da->qlen * (dual ? 5 : 4) + 16, 4) + K2A_PKMP_WAVES * (size_t)(64 * 16 * 2 * 2);      /* K2A_PKMP_BND_WORDS + K2A_PKMP_WAVES x K2A_PKMP_SPILL_WORDS(16) */
 			if (p->bnd_words > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "plan_create: boundary rows over 16 GiB in one plan%s", 0); goto err; }
 		}
 	}

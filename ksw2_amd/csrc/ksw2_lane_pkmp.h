@@ -24,11 +24,12 @@
 #define KSW2_LANE_PKMP_H_
 
 #include "ksw2_lane_pk.h"
+#include "ksw2_shim.h"
 
 #define K2A_PKMP_T    64            /* steps between re-bases (a power of two) */
 #define K2A_PKMP_DEAD (-8192)       /* relative values below this are -inf */
 #define K2A_PKMP_RMAX_LIMIT 12000   /* a window's row maximum further above the base than this is merged into its key */
-#define K2A_PKMP_WAVES 4            /* wavefronts (generations in flight) per pair of alignments */
+/* K2A_PKMP_WAVES, the wavefronts (generations in flight) per pair of alignments: ksw2_shim.h (the host sizes the key blocks by it) */
 #define K2A_PKMP_SPILL_WORDS(C) (64 * (C) * 2 * 2)     /* uint32 per wavefront: one 64-bit key per row, lane and alignment */
 #define K2A_PKMP_BND_WORDS(qlen, dual) ((((size_t)(qlen) * ((dual) ? 5 : 4) + 16) + 3) & ~(size_t)3)   /* uint32 per task: {H, E, baseA, baseB}[qlen] (+ E~[qlen]), rounded so that the 64-bit keys behind it stay aligned */
 

@@ -22,6 +22,9 @@ extern "C" {
 static const int k2a_cfg_G[K2A_NCFG] = { 16, 64, 64, 64, 64 };
 static const int k2a_cfg_C[K2A_NCFG] = {  8,  8, 16, 32, 16 };
 /* geometry classes of the packed-int16 kernels (two same-shape alignments per lane group) */
+#ifndef K2A_PKMP_WAVES
+#define K2A_PKMP_WAVES 4      /* packed generation-serial class: wavefronts (generations in flight) per task */
+#endif
 #define K2A_NPKCFG 5
 #define K2A_PKCFG_MP 4    /* packed generation-serial class (ksw2_lane_pkmp.h): any band, a workgroup of 4 wavefronts per task */
 static const int k2a_pkcfg_G[K2A_NPKCFG] = {  8, 16, 64, 64, 64 };
@@ -76,7 +79,7 @@ int k2a_shim_launch_trace_pk(int cfg, int dual, const K2aPair *pairs, const uint
 
 /* Packed generation-serial fill (class K2A_PKCFG_MP): one task (two same-shape alignments) per workgroup of four wavefronts that
  * pipeline the task's generations of 1024 target rows.  Both K2aPair entries of a task share bnd_off: K2A_PKMP_BND_WORDS
- * (ksw2_lane_pkmp.h) uint32 of boundary entries followed by 4 x K2A_PKMP_SPILL_WORDS(16) of row-maximum keys, 16-byte aligned;
+ * (ksw2_lane_pkmp.h) uint32 of boundary entries followed by K2A_PKMP_WAVES x K2A_PKMP_SPILL_WORDS(16) of row-maximum keys, 16-byte aligned;
  * traceback block as for the int32 generation-serial class but 32 bytes per lane-step.  The packed trace launch with
  * cfg = K2A_PKCFG_MP walks it. */
 int k2a_shim_launch_fill_pkmp(int dual, int mode, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2, int ntasks,

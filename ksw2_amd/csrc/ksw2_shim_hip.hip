@@ -655,14 +655,14 @@ k2a_trace_pk_kernel(const K2aPair *__restrict__ pairs, const uint32_t *__restric
 }
 
 /* Packed-int16 generation-serial fill (ksw2_lane_pkmp.h): ONE pair of same-shape alignments per workgroup of K2A_PKMP_WAVES
- * wavefronts; wavefront v runs generations v, v + 4, v + 8, ... (1024 target rows each), so up to four generations of a pair are
+ * wavefronts; wavefront v runs generations v, v + W, v + 2W, ... (1024 target rows each), so up to W generations of a pair are
  * in flight, each reading the boundary row its predecessor streams into HBM ({H, E, baseA, baseB} per column, L1-bypassing
  * loads two columns ahead).  No spinning: the wavefronts advance in phases of K2A_PKMP_T steps with one workgroup barrier per
  * phase, and generation g + 1 starts k2a_pkmp_lag phases after generation g -- late enough that every boundary column it reads
  * was written in an earlier phase and that its strip epilogues (row order!) come after all of generation g's.  The schedule
  * (start phase of every generation) is a function of the shape alone and is tabulated once per workgroup. */
 template<bool DUAL, int MODE>
-__global__ void __launch_bounds__(64 * K2A_PKMP_WAVES, 2)
+__global__ void __launch_bounds__(64 * K2A_PKMP_WAVES, K2A_PKMP_WAVES > 4 ? 3 : 2)
 k2a_fill_pkmp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
                      const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, uint32_t *bnd, K2aResult *__restrict__ res)
 {
@@ -691,7 +691,8 @@ k2a_fill_pkmp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 	K2aBook *bkA = &book[0], *bkB = &book[1];
 	if (threadIdx.x == 0) {
 		k2a_book_reset(bkA); k2a_book_reset(bkB);
-		int pend[W] = { 0, 0, 0, 0 }, prev_start = 0, prev_jlo = 0, total = 0;
+		int pend[W], prev_start = 0, prev_jlo = 0, total = 0;
+		for (int x = 0; x < W; ++x) pend[x] = 0;
 		for (int x = 0; x < ngen; ++x) {
 			int jlo, ns;
 			k2a_gen_cols<G, C>(x, qlen, tlen, w, &jlo, &ns);
