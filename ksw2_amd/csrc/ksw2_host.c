@@ -1989,6 +1989,24 @@ static int exts_serial(void *km, const ksw2amd_splice_t *sc, int n, const ksw2am
 /* the splice-aware and the X-drop batches through the same worker pool as the extz / extd batches (run_pooled): one chunk per
  * worker, each packed, run and fetched on the worker's own streams -- the packing (per-position splice constants, interleaved
  * lane blocks) is what bounds these functions end to end */
+/* chunk count and size for these one-alignment-per-wavefront classes: one chunk per worker; a batch of one shape is cut at
+ * multiples of a device fill (one wavefront per SIMD) like the extz / extd batches (uniform_chunks) */
+static int wave_chunks(int n, int workers, int uniform, int *chunk_pairs)
+{
+	const char *e3 = getenv("KSW2AMD_CHUNKS");
+	const int simds = k2a_shim_simd_count();
+	int k = imin(workers, n / 256);
+	if (e3 && atoi(e3) > 0) k = atoi(e3);
+	*chunk_pairs = 0;
+	if (uniform && simds > 0 && k >= 2 && n >= 2 * simds && !getenv("KSW2AMD_NO_UNITS")) {
+		int cp = (n + k - 1) / k;
+		cp = (cp + simds - 1) / simds * simds;
+		*chunk_pairs = cp;
+		k = (n + cp - 1) / cp;
+	}
+	return k;
+}
+
 typedef struct { void *km; const ksw2amd_splice_t *sc; const ksw2amd_spair_t *pairs; ksw_extz_t *ez; } exts_ctx_t;
 static int exts_chunk(void *ctx_, int beg, int end, int share, pend_t *pd)
 {
@@ -2002,14 +2020,16 @@ int ksw2amd_exts_batch(void *km, const ksw2amd_splice_t *sc, int n, const ksw2am
 {
 	const int tpd = pool_threads_per_device();
 	if (n >= (pool_min_pairs() ? pool_min_pairs() : 2048) && tpd > 0 && !g_is_worker && k2a_shim_device_count() > 0) {
-		const int workers = tpd * (g_ndev_set > 0 ? g_ndev_set : 1), nchunks = imin(workers, n / 256);
+		const int workers = tpd * (g_ndev_set > 0 ? g_ndev_set : 1);
 		double *cost = (double*)malloc(sizeof(double) * (size_t)n), total = 0;
-		int i, rc = 0;
+		int i, rc = 0, uniform = 1, chunk_pairs = 0, nchunks;
+		for (i = 1; i < n && uniform; ++i) uniform = pairs[i].qlen == pairs[0].qlen && pairs[i].tlen == pairs[0].tlen;
+		nchunks = wave_chunks(n, workers, uniform, &chunk_pairs);
 		if (cost && nchunks >= 2) {
 			exts_ctx_t ctx;
 			for (i = 0; i < n; ++i) { cost[i] = 1.0 + (double)imax(pairs[i].qlen, 0) * imax(pairs[i].tlen, 0); total += cost[i]; }
 			ctx.km = km; ctx.sc = sc; ctx.pairs = pairs; ctx.ez = ez;
-			if (run_pooled(exts_chunk, &ctx, n, cost, total, nchunks, 0, &rc)) { free(cost); return rc; }
+			if (run_pooled(exts_chunk, &ctx, n, cost, total, nchunks, chunk_pairs, &rc)) { free(cost); return rc; }
 		}
 		free(cost);
 	}
@@ -2454,14 +2474,16 @@ int ksw2amd_extf_batch(void *km, int8_t mch, int8_t mis, int8_t e, int n, const 
 	const int tpd = pool_threads_per_device();
 	/* (batches big enough for the one-extension-per-lane form stay whole: it needs every wavefront it can get) */
 	if (n >= (pool_min_pairs() ? pool_min_pairs() : 2048) && n < 131072 && tpd > 0 && !g_is_worker && k2a_shim_device_count() > 0) {
-		const int workers = tpd * (g_ndev_set > 0 ? g_ndev_set : 1), nchunks = imin(workers, n / 256);
+		const int workers = tpd * (g_ndev_set > 0 ? g_ndev_set : 1);
 		double *cost = (double*)malloc(sizeof(double) * (size_t)n), total = 0;
-		int i, rc = 0;
+		int i, rc = 0, uniform = 1, chunk_pairs = 0, nchunks;
+		for (i = 1; i < n && uniform; ++i) uniform = pairs[i].qlen == pairs[0].qlen && pairs[i].tlen == pairs[0].tlen && pairs[i].w == pairs[0].w;
+		nchunks = wave_chunks(n, workers, uniform, &chunk_pairs);
 		if (cost && nchunks >= 2) {
 			extf_ctx_t ctx;
 			for (i = 0; i < n; ++i) { cost[i] = 1.0 + (double)imax(pairs[i].qlen, 0) + imax(pairs[i].tlen, 0); total += cost[i]; }
 			ctx.km = km; ctx.mch = mch; ctx.mis = mis; ctx.e = e; ctx.pairs = pairs; ctx.ez = ez;
-			if (run_pooled(extf_chunk, &ctx, n, cost, total, nchunks, 0, &rc)) { free(cost); return rc; }
+			if (run_pooled(extf_chunk, &ctx, n, cost, total, nchunks, chunk_pairs, &rc)) { free(cost); return rc; }
 		}
 		free(cost);
 	}
