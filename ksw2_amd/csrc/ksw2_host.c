@@ -1758,38 +1758,6 @@ static int queue_one(const char *fn, int dual, void *km, const ksw2amd_scoring_t
 
 /* ---------------------------------------------------------------- splice-aware extension (ksw_exts2_sse) */
 
-/* donor[t] / acceptor[t] of the reference's splice model (ksw2_exts2_sse.c:121-173; residues 0/1/2/3 = A/C/G/T):
- * -noncan everywhere, 0 where an intron may start after t (G T | C T on the reverse strand, read through a reversed
- * CIGAR as G A | C A) resp. end at t (A G | A C, reversed T G | T C) with the preferred flanking base, half the penalty
- * (KSW_EZ_SPLICE_FLANK) or 0 without it; junc_bonus on annotated junction positions.  Packed with the residue code. */
-static void splice_constants(const ksw2amd_splice_t *sc, const ksw2amd_spair_t *a, uint32_t *out)
-{
-	const int tlen = a->tlen, fl = a->flag;
-	const uint8_t *T = a->target, *J = a->junc;
-	const int fwd = !!(fl & KSW_EZ_SPLICE_FOR), rev = !!(fl & KSW_EZ_SPLICE_REV), rc = !!(fl & KSW_EZ_REV_CIGAR);
-	const int on = fwd || rev, base = on ? -sc->noncan : 0, semi = (fl & KSW_EZ_SPLICE_FLANK) ? -sc->noncan / 2 : 0;
-	/* motif bases seen from position t: donor looks at t+1, t+2 (flank t+3), acceptor at t-1, t (flank t-2) */
-	const int d1f = 2, d1r = 1, d2 = rc ? 0 : 3, a1 = rc ? 3 : 0, a2f = 2, a2r = 1;
-	const int jd_f = rc ? 2 : 1, jd_r = rc ? 4 : 8, ja_f = rc ? 1 : 2, ja_r = rc ? 8 : 4;
-	int t;
-	for (t = 0; t < tlen; ++t) {
-		int don = base, acc = base;
-		if (on) {
-			if (t < tlen - 4 && T[t + 2] == d2 && ((fwd && T[t + 1] == d1f) || (rev && T[t + 1] == d1r))) {
-				const int flank = rc ? (T[t + 3] == 1 || T[t + 3] == 3) : (T[t + 3] == 0 || T[t + 3] == 2);
-				don = flank ? 0 : semi;
-			}
-			if (J && t < tlen - 1 && ((fwd && (J[t + 1] & jd_f)) || (rev && (J[t + 1] & jd_r)))) don = (int8_t)(don + sc->junc_bonus);
-			if (t >= 2 && T[t - 1] == a1 && ((fwd && T[t] == a2f) || (rev && T[t] == a2r))) {
-				const int flank = rc ? (T[t - 2] == 0 || T[t - 2] == 2) : (T[t - 2] == 1 || T[t - 2] == 3);
-				acc = flank ? 0 : semi;
-			}
-			if (J && ((fwd && (J[t] & ja_f)) || (rev && (J[t] & ja_r)))) acc = (int8_t)(acc + sc->junc_bonus);
-		}
-		out[t] = (uint32_t)T[t] | (uint32_t)(uint8_t)(int8_t)don << 8 | (uint32_t)(uint8_t)(int8_t)acc << 16;
-	}
-}
-
 static int exts_long_thres(int q, int e, int q2)           /* ksw2_exts2_sse.c:102-104 */
 {
 	int lt = (q2 - q) / e - 1;
@@ -1802,7 +1770,7 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 	ksw2amd_plan_t *p;
 	const int m = sc ? sc->m : 0;
 	int i, k, g, lo;
-	size_t off, mat_off;
+	size_t off, mat_off, up_bytes = 0, cst_words = 0;
 	void *up;
 	uint32_t fill[3][2][3];
 	int wn;
@@ -1858,14 +1826,17 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 		d->qlen = a->qlen; d->tlen = d->tlen_full = a->tlen;
 		d->w = imax(a->qlen, a->tlen);                 /* no band: k2a_finish must never see an unreachable corner */
 		d->zdrop = a->zdrop; d->end_bonus = K2A_NEG;   /* no end bonus in this function */
-		d->flag = fl & (KSW_EZ_EXTZ_ONLY | KSW_EZ_REV_CIGAR | KSW_EZ_SCORE_ONLY);
+		d->flag = fl & (KSW_EZ_EXTZ_ONLY | KSW_EZ_REV_CIGAR | KSW_EZ_SCORE_ONLY | KSW_EZ_SPLICE_FOR | KSW_EZ_SPLICE_REV | KSW_EZ_SPLICE_FLANK);   /* the splice bits: k2a_splice_const */
+		if (a->junc) d->flag |= K2A_F_HAS_JUNC;
 		if (is_approx(fl)) {
 			d->zdrop = -1;
 			if (fl & KSW_EZ_EXTZ_ONLY) d->flag |= KSW_EZ_SCORE_ONLY;
 		}
+		/* uploaded: query, target, annotation bytes; the per-position dwords (bnd_off) are built on the device behind them */
 		off = align_up(off, 4); d->qoff = (uint32_t)off; off += (size_t)a->qlen;
-		off = align_up(off, 4); d->bnd_off = (uint32_t)(off / 4); off += 4 * (size_t)a->tlen;
-		if (off > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "exts: more than 4 GiB of sequence in one plan%s", 0); goto err; }
+		off = align_up(off, 4); d->toff = (uint32_t)off; off += align_up((size_t)a->tlen, 4) + (a->junc ? align_up((size_t)a->tlen, 4) : 0) + 4;
+		cst_words += (size_t)a->tlen;
+		if (off + 4 * cst_words > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "exts: more than 4 GiB of sequence in one plan%s", 0); goto err; }
 		p->cells += (int64_t)a->qlen * a->tlen;
 		if (mode != K2A_MODE_SCORE) {
 			d->tb_off = p->tb_bytes;
@@ -1877,8 +1848,11 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 	}
 	off = align_up(off + 256, 256);
 	mat_off = off; off = align_up(off + 2 * (size_t)m * m, 256);
-	p->seq_bytes = off;
-	p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, p->seq_bytes, &p->cap[BUF_HSEQ]);
+	up_bytes = off;                                   /* what goes over the link; the constants follow on the device only */
+	for (i = 0; i < n; ++i)
+		if (p->h_cls[i] >= 0) { p->h_pairs[i].bnd_off = (uint32_t)(off / 4); off += 4 * (size_t)p->h_pairs[i].tlen; }
+	p->seq_bytes = align_up(off + 256, 256);
+	p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, up_bytes, &p->cap[BUF_HSEQ]);
 	if (!p->h_seq) { fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
 	for (k = 0, i = 0; i < 3; ++i)
 		for (g = 0; g < 2; ++g)
@@ -1888,7 +1862,8 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 		const ksw2amd_spair_t *a = &pairs[i];
 		if (p->h_cls[i] < 0) continue;
 		memcpy(p->h_seq + p->h_pairs[i].qoff, a->query, (size_t)a->qlen);
-		splice_constants(sc, a, (uint32_t*)p->h_seq + p->h_pairs[i].bnd_off);
+		memcpy(p->h_seq + p->h_pairs[i].toff, a->target, (size_t)a->tlen);
+		if (a->junc) memcpy(p->h_seq + p->h_pairs[i].toff + align_up((size_t)a->tlen, 4), a->junc, (size_t)a->tlen);
 		p->h_order[fill[p->h_cls[i] / 6][(p->h_cls[i] / 3) & 1][p->h_cls[i] % 3]++] = (uint32_t)i;
 	}
 	build_eff(0, m, sc->mat, sc->e, 0, 0, (int8_t*)p->h_seq + mat_off);
@@ -1908,9 +1883,10 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 	}
 	up = thread_upload_stream();
 	p->stream = up; p->stream_used = 1;
-	if (k2a_shim_h2d(p->d_seq, p->h_seq, p->seq_bytes, up) || k2a_shim_h2d(p->d_pairs, p->h_pairs, sizeof(K2aPair) * (size_t)n, up) ||
+	if (k2a_shim_h2d(p->d_seq, p->h_seq, up_bytes, up) || k2a_shim_h2d(p->d_pairs, p->h_pairs, sizeof(K2aPair) * (size_t)n, up) ||
 	    k2a_shim_h2d(p->d_order, p->h_order, sizeof(uint32_t) * (size_t)p->norder, up) ||
-	    k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)n, up) || k2a_shim_stream_sync(up)) {
+	    k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)n, up) ||
+	    k2a_shim_launch_splice_const(p->d_pairs, n, p->d_seq, sc->noncan, sc->junc_bonus, up) || k2a_shim_stream_sync(up)) {
 		fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error());
 		goto err;
 	}
@@ -1971,14 +1947,21 @@ static int exts_serial(void *km, const ksw2amd_splice_t *sc, int n, const ksw2am
 		int end, rc;
 		for (end = beg; end < n; ++end) {
 			const size_t ql = (size_t)imax(pairs[end].qlen, 0), tl = (size_t)imax(pairs[end].tlen, 0);
-			const size_t b = ql + 4 * tl + 256 + ((pairs[end].flag & KSW_EZ_SCORE_ONLY) ? 0 : (ql + tl) * (ql < tl ? ql : tl) + 4 * (ql + tl) + 512);
-			if (end > beg && (acc + b > budget || seq + ql + 4 * tl > 3000000000u || end - beg >= (1 << 22))) break;
-			acc += b; seq += ql + 4 * tl + 16;
+			const size_t b = ql + 6 * tl + 256 + ((pairs[end].flag & KSW_EZ_SCORE_ONLY) ? 0 : (ql + tl) * (ql < tl ? ql : tl) + 4 * (ql + tl) + 512);      /* query, target, annotation, 4 bytes of constants per position */
+			if (end > beg && (acc + b > budget || seq + ql + 6 * tl > 3000000000u || end - beg >= (1 << 22))) break;
+			acc += b; seq += ql + 6 * tl + 32;
 		}
-		p = ksw2amd_exts_plan_create(sc, end - beg, pairs + beg);
-		if (!p) return strstr(g_err, "alloc") ? KSW2AMD_E_NOMEM : strstr(g_err, "device") ? KSW2AMD_E_NODEVICE : KSW2AMD_E_PARAM;
-		rc = ksw2amd_plan_run(p, thread_stream());
-		if (rc == KSW2AMD_OK) rc = ksw2amd_plan_fetch(p, km, ez + beg);
+		{
+			const double t0 = now_ms();
+			double t1, t2;
+			p = ksw2amd_exts_plan_create(sc, end - beg, pairs + beg);
+			if (!p) return strstr(g_err, "alloc") ? KSW2AMD_E_NOMEM : strstr(g_err, "device") ? KSW2AMD_E_NODEVICE : KSW2AMD_E_PARAM;
+			t1 = now_ms();
+			rc = ksw2amd_plan_run(p, thread_stream());
+			t2 = now_ms();
+			if (rc == KSW2AMD_OK) rc = ksw2amd_plan_fetch(p, km, ez + beg);
+			if (trace_on()) fprintf(stderr, "[ksw2_amd] exts plan @%d n=%d: pack+upload %.2f ms, launch %.2f ms, wait+fetch %.2f ms\n", beg, end - beg, t1 - t0, t2 - t1, now_ms() - t2);
+		}
 		ksw2amd_plan_destroy(p);
 		if (rc) return rc;
 		beg = end;

@@ -132,4 +132,35 @@ K2A_FN int k2a_dm_trace(const uint8_t *tb, int ncol, int i, int j, uint32_t *out
 	return n;
 }
 
+
+/* donor[t] / acceptor[t] of the reference's splice model (ksw2_exts2_sse.c:121-173; residues 0/1/2/3 = A/C/G/T), packed with
+ * the residue code into the per-position dword the kernels read: -noncan everywhere, 0 where an intron may start after t
+ * (G T | C T on the reverse strand, read through a reversed CIGAR as G A | C A) resp. end at t (A G | A C, reversed T G | T C) with
+ * the preferred flanking base, half the penalty (KSW_EZ_SPLICE_FLANK) or 0 without it; junc_bonus on annotated junction positions.
+ * `fl`: the KSW_EZ_SPLICE_* / REV_CIGAR bits; J = 0: no annotation.  Runs on the device (k2a_splice_const_kernel): the host
+ * uploads target and annotation bytes, not four bytes per position. */
+K2A_FN uint32_t k2a_splice_const(const uint8_t *T, const uint8_t *J, int t, int tlen, int fl, int noncan, int junc_bonus)
+{
+	const bool fwd = (fl & K2A_F_SPLICE_FOR) != 0, rev = (fl & K2A_F_SPLICE_REV) != 0, rc = (fl & K2A_F_REV_CIGAR) != 0;
+	const bool on = fwd || rev;
+	const int base = on ? -noncan : 0, semi = (fl & K2A_F_SPLICE_FLANK) ? -noncan / 2 : 0;
+	/* motif bases seen from position t: donor looks at t+1, t+2 (flank t+3), acceptor at t-1, t (flank t-2) */
+	const int d1f = 2, d1r = 1, d2 = rc ? 0 : 3, a1 = rc ? 3 : 0, a2f = 2, a2r = 1;
+	const int jd_f = rc ? 2 : 1, jd_r = rc ? 4 : 8, ja_f = rc ? 1 : 2, ja_r = rc ? 8 : 4;
+	int don = base, acc = base;
+	if (on) {
+		if (t < tlen - 4 && T[t + 2] == d2 && ((fwd && T[t + 1] == d1f) || (rev && T[t + 1] == d1r))) {
+			const bool flank = rc ? (T[t + 3] == 1 || T[t + 3] == 3) : (T[t + 3] == 0 || T[t + 3] == 2);
+			don = flank ? 0 : semi;
+		}
+		if (J && t < tlen - 1 && ((fwd && (J[t + 1] & jd_f)) || (rev && (J[t + 1] & jd_r)))) don = (int)(int8_t)(don + junc_bonus);
+		if (t >= 2 && T[t - 1] == a1 && ((fwd && T[t] == a2f) || (rev && T[t] == a2r))) {
+			const bool flank = rc ? (T[t - 2] == 0 || T[t - 2] == 2) : (T[t - 2] == 1 || T[t - 2] == 3);
+			acc = flank ? 0 : semi;
+		}
+		if (J && ((fwd && (J[t] & ja_f)) || (rev && (J[t] & ja_r)))) acc = (int)(int8_t)(acc + junc_bonus);
+	}
+	return (uint32_t)T[t] | (uint32_t)(uint8_t)(int8_t)don << 8 | (uint32_t)(uint8_t)(int8_t)acc << 16;
+}
+
 #endif

@@ -99,6 +99,7 @@ int k2a_shim_launch_trace_solo(const K2aPair *pairs, const uint32_t *order, int 
  * them with the intron state.  order[t] = index into pairs / res, as for the fill kernels.
  * win = register window class 0 / 1: diagonals up to K2A_DM_DIAG(K2A_DM_SLOTS_S / K2A_DM_SLOTS) cells; win = 2: any length,
  * state in `scratch` (9 * tlen ints per alignment at 4 * pairs[i].pad). */
+int k2a_shim_launch_splice_const(const K2aPair *pairs, int n, uint8_t *seq, int noncan, int junc_bonus, void *stream);   /* per-position constants from the uploaded targets */
 int k2a_shim_launch_exts(int mode, int win, const K2aSplice *sp, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
                          uint8_t *tb, int32_t *scratch, K2aResult *res, void *stream);
 int k2a_shim_launch_exts_trace(const K2aSplice *sp, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb,

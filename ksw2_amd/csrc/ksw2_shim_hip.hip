@@ -1035,6 +1035,20 @@ k2a_exts_trace_kernel(const K2aSplice sp, const K2aPair *__restrict__ pairs, con
 	res[pi].n_cigar = n;
 }
 
+/* per-position constants of the splice-aware plans (k2a_splice_const): one workgroup per pair, from the target (and annotation)
+ * bytes at pr.toff into the dwords at pr.bnd_off that the fill kernels read */
+__global__ void __launch_bounds__(256)
+k2a_splice_const_kernel(const K2aPair *__restrict__ pairs, int n, uint8_t *seq, int noncan, int junc_bonus)
+{
+	const int i = blockIdx.x;
+	if (i >= n) return;
+	const K2aPair pr = pairs[i];
+	if (pr.qlen <= 0 || pr.tlen_full <= 0) return;
+	const uint8_t *T = seq + pr.toff, *J = (pr.flag & K2A_F_HAS_JUNC) ? T + ((pr.tlen_full + 3) & ~3) : 0;
+	uint32_t *out = (uint32_t*)seq + pr.bnd_off;
+	for (int t = threadIdx.x; t < pr.tlen_full; t += 256) out[t] = k2a_splice_const(T, J, t, pr.tlen_full, pr.flag, noncan, junc_bonus);
+}
+
 /* ---------------------------------------------------------------- SSE-compatible mode (ksw2_lane_ssec.h) */
 
 /* One alignment per wavefront, lane <-> target position, one step per anti-diagonal; the reference's byte arrays u v x y
@@ -1567,6 +1581,14 @@ int k2a_shim_launch_exts(int mode, int win, const K2aSplice *sp, const K2aPair *
 		else if (mode == 1) hipLaunchKernelGGL(k2a_exts_big_kernel<1>, grid, block, 0, (hipStream_t)stream, *sp, pairs, order, ntasks, seq, tb, scratch, res);
 		else hipLaunchKernelGGL(k2a_exts_big_kernel<2>, grid, block, 0, (hipStream_t)stream, *sp, pairs, order, ntasks, seq, tb, scratch, res);
 	} else hipLaunchKernelGGL(fn[mode][win], grid, block, 0, (hipStream_t)stream, *sp, pairs, order, ntasks, seq, tb, res);
+	CHECK(hipGetLastError());
+	return 0;
+}
+
+int k2a_shim_launch_splice_const(const K2aPair *pairs, int n, uint8_t *seq, int noncan, int junc_bonus, void *stream)
+{
+	if (n <= 0) return 0;
+	hipLaunchKernelGGL(k2a_splice_const_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, pairs, n, seq, noncan, junc_bonus);
 	CHECK(hipGetLastError());
 	return 0;
 }

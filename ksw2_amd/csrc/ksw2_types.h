@@ -15,6 +15,10 @@
 #define K2A_F_SCORE_ONLY 0x01
 #define K2A_F_EXTZ_ONLY 0x40
 #define K2A_F_REV_CIGAR 0x80
+#define K2A_F_SPLICE_FOR   0x100        /* splice-aware plans: K2aPair.flag carries the KSW_EZ_SPLICE_* bits for k2a_splice_const */
+#define K2A_F_SPLICE_REV   0x200
+#define K2A_F_SPLICE_FLANK 0x400
+#define K2A_F_HAS_JUNC     0x10000000   /* ... and whether annotation bytes follow the target in the arena */
 
 /* kernel MODE */
 #define K2A_MODE_SCORE 0     /* no traceback                                      */

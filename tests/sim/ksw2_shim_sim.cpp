@@ -982,6 +982,17 @@ int k2a_shim_launch_compact(const K2aPair *pairs, const K2aResult *res, const ui
 	return 0;
 }
 
+int k2a_shim_launch_splice_const(const K2aPair *pairs, int n, uint8_t *seq, int noncan, int junc_bonus, void *)
+{
+	for (int i = 0; i < n; ++i) {
+		const K2aPair pr = pairs[i];
+		if (pr.qlen <= 0 || pr.tlen_full <= 0) continue;
+		const uint8_t *T = seq + pr.toff, *J = (pr.flag & K2A_F_HAS_JUNC) ? T + ((pr.tlen_full + 3) & ~3) : 0;
+		uint32_t *out = (uint32_t*)seq + pr.bnd_off;
+		for (int t = 0; t < pr.tlen_full; ++t) out[t] = k2a_splice_const(T, J, t, pr.tlen_full, pr.flag, noncan, junc_bonus);
+	}
+	return 0;
+}
 int k2a_shim_launch_exts(int mode, int win, const K2aSplice *sp, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
                          uint8_t *tb, int32_t *scratch, K2aResult *res, void *)
 {
