@@ -868,12 +868,17 @@ k2a_exts_kernel(const K2aSplice sp, const K2aPair *__restrict__ pairs, const uin
                 const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, K2aResult *__restrict__ res)
 {
 	__shared__ int8_t mtab[K2A_MAXM * K2A_MAXM];
+	/* this diagonal's H by window position: the bookkeeping reads five cells by position (last, first, <= 3 tail cells).  Finding
+	 * them with v_readlane inside the slot loop cost ~35 scalar instructions per slot and diagonal for the range tests -- the
+	 * kernel ran on the CU's one scalar unit (PMC: 967 k SALU against 835 k VALU instructions per wavefront) */
+	__shared__ int hrow[K2A_WPB][K * 64];
 	for (int x = threadIdx.x; x < sp.m * sp.m; x += blockDim.x) mtab[x] = sp.mat[x];
 	__syncthreads();
 
 	const int lane = threadIdx.x & 63, wave = k2a_wave_id<true>();
 	const int task = blockIdx.x * K2A_WPB + wave;
 	if (task >= ntasks) return;                       /* whole wavefronts leave; nobody synchronises below */
+	int *const hw = hrow[wave];                       /* (plain LDS accesses: one wavefront's DS operations execute in order) */
 	const uint32_t pi = order[task];
 	const K2aPair pr = pairs[pi];
 	const int qlen = pr.qlen, tlen = pr.tlen_full, ncol = min(qlen, tlen);
@@ -906,6 +911,7 @@ k2a_exts_kernel(const K2aSplice sp, const K2aPair *__restrict__ pairs, const uin
 		}
 		const uint32_t qcur = qnext;
 		qnext = qry[min(r + 1, qlen - 1)];                               /* used one diagonal later */
+		const int br = k2a_dm_border(sp, r), br1 = k2a_dm_border(sp, r + 1);
 		int cH2 = K2A_NEG, cEn = K2A_NEG, cE2n = K2A_NEG, cQ = 0;
 		int A = K2A_NEG, S = K2A_NEG, T0 = K2A_NEG, T1 = K2A_NEG, T2 = K2A_NEG;
 		int bH = K2A_NEG, bT = -1;
@@ -921,11 +927,13 @@ k2a_exts_kernel(const K2aSplice sp, const K2aPair *__restrict__ pairs, const uin
 			cE2n = __builtin_amdgcn_readlane(E2n[s], 63); cQ = __builtin_amdgcn_readlane((int)Q[s], 63);
 			Q[s] = t == 0 ? qcur : qs;
 			if (t0 <= en0 && t0 + 63 >= st0) {                              /* the slot holds cells of this diagonal */
+				/* first row: t == 0, first column: t == r -- the border values both need are those of r and r + 1 (uniform, formed
+				 * once per diagonal: as border(t) inside the slot loop they were divergent scalar branches in every slot) */
 				const bool active = t >= st0 && t <= en0, first_row = t == 0, first_col = t == r;
-				const int diag = first_row ? k2a_dm_border(sp, r) : first_col ? k2a_dm_border(sp, t) : h2s;
-				const int ein = first_row ? k2a_dm_border(sp, r + 1) - sp.q - sp.e : ens;
-				const int e2in = first_row ? k2a_dm_border(sp, r + 1) - sp.q2 : e2ns;
-				const int fin = first_col ? k2a_dm_border(sp, t + 1) - sp.q - sp.e : Fn[s];
+				const int diag = (first_row || first_col) ? br : h2s;
+				const int ein = first_row ? br1 - sp.q - sp.e : ens;
+				const int e2in = first_row ? br1 - sp.q2 : e2ns;
+				const int fin = first_col ? br1 - sp.q - sp.e : Fn[s];
 				const uint32_t c = Cst[s];
 				const int sc = (int)mtab[(c & 0xffu) * (uint32_t)sp.m + (Q[s] & 0xffu)];
 				int z, en, e2n, fn;
@@ -936,13 +944,21 @@ k2a_exts_kernel(const K2aSplice sp, const K2aPair *__restrict__ pairs, const uin
 					if (MODE != K2A_MODE_SCORE) tbp[(size_t)r * ncol + (t - st0)] = (uint8_t)dir;
 					if (t < en1 && z > bH) { bH = z; bT = t; }
 				}
-				/* the cells the bookkeeping reads by position: the diagonal's last and first cell, the (<= 3) tail cells */
-				if (en0 >= t0 && en0 < t0 + 64) A = __builtin_amdgcn_readlane(H1[s], en0 & 63);
-				if (st0 >= t0 && st0 < t0 + 64) S = __builtin_amdgcn_readlane(H1[s], st0 & 63);
-				if (en1 < en0 && en1 >= t0 && en1 < t0 + 64) T0 = __builtin_amdgcn_readlane(H1[s], en1 & 63);
-				if (en1 + 1 < en0 && en1 + 1 >= t0 && en1 + 1 < t0 + 64) T1 = __builtin_amdgcn_readlane(H1[s], (en1 + 1) & 63);
-				if (en1 + 2 < en0 && en1 + 2 >= t0 && en1 + 2 < t0 + 64) T2 = __builtin_amdgcn_readlane(H1[s], (en1 + 2) & 63);
+				hw[s * 64 + lane] = H1[s];                                    /* read back by position below */
 			}
+		}
+		{
+			/* the cells the bookkeeping reads by position: the diagonal's last and first cell, the (<= 3) tail cells; lane x
+			 * fetches the x-th of them (every one lies in [st0, en0], inside the window) */
+			const int wb = base * 64;
+			const int pos = lane == 0 ? en0 : lane == 1 ? st0 : min(en1 + (lane - 2), en0);
+			__builtin_amdgcn_wave_barrier();
+			const int v = lane < 5 ? hw[pos - wb] : K2A_NEG;
+			__builtin_amdgcn_wave_barrier();
+			A = __builtin_amdgcn_readlane(v, 0); S = __builtin_amdgcn_readlane(v, 1);
+			if (en1 < en0) T0 = __builtin_amdgcn_readlane(v, 2);
+			if (en1 + 1 < en0) T1 = __builtin_amdgcn_readlane(v, 3);
+			if (en1 + 2 < en0) T2 = __builtin_amdgcn_readlane(v, 4);
 		}
 		const uint64_t Bkey = k2a_wave_max_u64(bT >= 0 ? k2a_dm_key(bH, bT, st0) : 0ull);
 		if (k2a_dm_book(&book, r, st0, en0, qlen, tlen, pr.zdrop, A, Bkey, T0, T1, T2, S)) break;
