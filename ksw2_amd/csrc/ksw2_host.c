@@ -50,7 +50,8 @@ int ksw2amd_set_device(int device)
  * Device allocations and page-locking cost milliseconds; a minimap2-style caller issues many batches (or single-pair
  * calls) from the same thread.  Each thread therefore keeps the buffers of its last plan (one per kind) and hands them to
  * the next plan when they are large enough.  ksw2amd_release_cache() returns them; switching device flushes them. */
-enum { BUF_HSEQ, BUF_SEQ, BUF_PAIRS, BUF_RES, BUF_ORDER, BUF_TB, BUF_CIG, BUF_BND, BUF_POS, BUF_POOL, BUF_KINDS };
+enum { BUF_HSEQ, BUF_SEQ, BUF_PAIRS, BUF_RES, BUF_ORDER, BUF_TB, BUF_CIG, BUF_BND, BUF_POS, BUF_POOL, BUF_HPOOL, BUF_KINDS };
+#define BUF_IS_HOST(k) ((k) == BUF_HSEQ || (k) == BUF_HPOOL)      /* pinned host staging; everything else is device memory */
 static __thread struct { void *p; size_t cap; } g_cache[BUF_KINDS];
 static __thread void *g_ev_cache[3];
 /* Every host thread uploads and (in the one-shot entry points) computes on a stream of its own, so concurrent callers --
@@ -95,7 +96,7 @@ static int side_streams(void)
 	return 0;
 }
 
-static void cache_free_raw(int kind, void *p) { if (kind == BUF_HSEQ) k2a_shim_host_free(p); else k2a_shim_free(p); }
+static void cache_free_raw(int kind, void *p) { if (BUF_IS_HOST(kind)) k2a_shim_host_free(p); else k2a_shim_free(p); }
 
 static void *cache_get(int kind, size_t bytes, size_t *cap)
 {
@@ -106,7 +107,7 @@ static void *cache_get(int kind, size_t bytes, size_t *cap)
 		return p;
 	}
 	*cap = bytes + bytes / 8 + 256;                       /* a little slack so slightly larger follow-up batches still fit */
-	return kind == BUF_HSEQ ? k2a_shim_host_malloc(*cap) : k2a_shim_malloc(*cap);
+	return BUF_IS_HOST(kind) ? k2a_shim_host_malloc(*cap) : k2a_shim_malloc(*cap);
 }
 
 static void cache_put(int kind, void *p, size_t cap)
@@ -907,7 +908,7 @@ static int plan_fetch_ex(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez, ksw_extz_t
 {
 	int i, rc = fetch_results(p);
 	uint32_t *pool = 0;
-	size_t total = 0, *pos = 0;
+	size_t total = 0, *pos = 0, cap_hpool = 0;
 	if (rc) return rc;
 	if (!p->reject_all && p->cig_words) {
 		/* bring every CIGAR back with one D2H: prefix-sum the counts, compact on the device, download the pool */
@@ -921,7 +922,9 @@ static int plan_fetch_ex(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez, ksw_extz_t
 			pos[i] = total; hpos[i] = (uint32_t)total;
 			total += (size_t)p->h_res[i].n_cigar;
 		}
-		pool = (uint32_t*)malloc(sizeof(uint32_t) * (total + 1));
+		/* pinned (from the thread's cache): a download into pageable memory is staged by the runtime at a third of the link's
+		 * rate, and config 5's CIGARs are 200 MB per batch */
+		pool = (uint32_t*)cache_get(BUF_HPOOL, sizeof(uint32_t) * (total + 1), &cap_hpool);
 		if (!pool) { free(hpos); free(pos); return fail(KSW2AMD_E_NOMEM, "plan_fetch: host allocation failed%s", 0); }
 		if (total > 0) {
 			/* device scratch from the thread's buffer cache: an allocation costs milliseconds and synchronises the device */
@@ -935,7 +938,7 @@ static int plan_fetch_ex(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez, ksw_extz_t
 			cache_put(BUF_POS, d_pos, cap_pos); cache_put(BUF_POOL, d_pool, cap_pool);
 		}
 		free(hpos);
-		if (bad) { free(pos); free(pool); return fail(KSW2AMD_E_NODEVICE, "plan_fetch: %s", k2a_shim_last_error()); }
+		if (bad) { free(pos); cache_put(BUF_HPOOL, pool, cap_hpool); return fail(KSW2AMD_E_NODEVICE, "plan_fetch: %s", k2a_shim_last_error()); }
 	}
 	if (km || kmp) pthread_mutex_lock(&g_km_mu);
 	for (i = 0; i < p->n; ++i) {
@@ -968,7 +971,7 @@ static int plan_fetch_ex(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez, ksw_extz_t
 		}
 	}
 	if (km || kmp) pthread_mutex_unlock(&g_km_mu);
-	free(pos); free(pool);
+	free(pos); cache_put(BUF_HPOOL, pool, cap_hpool);
 	return KSW2AMD_OK;
 }
 
@@ -986,7 +989,7 @@ static size_t thread_cached_device_bytes(void)
 {
 	size_t b = 0;
 	int k;
-	for (k = 0; k < BUF_KINDS; ++k) if (k != BUF_HSEQ && g_cache[k].p) b += g_cache[k].cap;
+	for (k = 0; k < BUF_KINDS; ++k) if (!BUF_IS_HOST(k) && g_cache[k].p) b += g_cache[k].cap;
 	return b;
 }
 static size_t device_budget(size_t free_b, size_t total_b, int share)
