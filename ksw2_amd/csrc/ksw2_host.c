@@ -961,10 +961,9 @@ static int plan_fetch_ex(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez, ksw_extz_t
 		}
 		if (r->n_cigar > 0) {
 			const uint32_t *src = pool + pos[i];
-			int k, nc = r->n_cigar;
+			int nc = r->n_cigar;
 			ez_reserve(km, z, nc);
-			if (p->h_flag[i] & KSW_EZ_REV_CIGAR) memcpy(z->cigar, src, sizeof(uint32_t) * (size_t)nc);
-			else for (k = 0; k < nc; ++k) z->cigar[k] = src[nc - 1 - k];        /* ksw2.h:157-159 */
+			memcpy(z->cigar, src, sizeof(uint32_t) * (size_t)nc);               /* already in the caller's order (k2a_compact_kernel; ksw2.h:157-159) */
 			z->n_cigar = nc;
 			if (p->dual && (p->h_flag[i] & KSW_EZ_EQX) && !(p->h_flag[i] & F_SCALAR_CONTRACT))
 				eqx_rewrite(km, p->h_seq + p->h_pairs[i].qoff, p->h_seq + p->h_pairs[i].toff, 1, z);

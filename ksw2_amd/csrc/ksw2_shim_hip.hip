@@ -611,7 +611,10 @@ k2a_compact_kernel(const K2aPair *__restrict__ pairs, const K2aResult *__restric
 	const int nc = res[i].n_cigar;
 	const uint32_t *src = cig + pairs[i].cig_off;
 	uint32_t *dst = pool + pos[i];
-	for (int k = threadIdx.x; k < nc; k += 64) dst[k] = src[k];
+	/* the walk emits end -> start; callers get start -> end unless KSW_EZ_REV_CIGAR (ksw2.h:157-159): turned round here, so that
+	 * the host's assembly is one memcpy per alignment */
+	const bool rev = (pairs[i].flag & K2A_F_REV_CIGAR) != 0;
+	for (int k = threadIdx.x; k < nc; k += 64) dst[k] = src[rev ? k : nc - 1 - k];
 }
 
 /* ---------------------------------------------------------------- dispatch tables */

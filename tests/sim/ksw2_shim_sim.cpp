@@ -978,7 +978,7 @@ int k2a_shim_launch_compact(const K2aPair *pairs, const K2aResult *res, const ui
                             uint32_t *pool, void *)
 {
 	for (int i = 0; i < n; ++i)
-		for (int k = 0; k < res[i].n_cigar; ++k) pool[pos[i] + k] = cig[pairs[i].cig_off + k];
+		for (int k = 0; k < res[i].n_cigar; ++k) pool[pos[i] + k] = cig[pairs[i].cig_off + ((pairs[i].flag & K2A_F_REV_CIGAR) ? k : res[i].n_cigar - 1 - k)];
 	return 0;
 }
 

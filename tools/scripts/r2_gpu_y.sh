@@ -1,11 +1,10 @@
 #!/bin/bash
-mkdir -p gpurun_out/profiles
-bash tools/scripts/profile_round.sh r2z exts 3 > gpurun_out/prof_r2z_exts.log 2>&1
-tail -16 gpurun_out/prof_r2z_exts.log
-timeout 900 python bench.py --workload exts --steps 10 --warmup 2 --cpu-seconds 8 --no-also 2> gpurun_out/bench_r2z_exts.err | tail -1 > gpurun_out/profiles/r2z_bench_exts.json
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/profiles/r2z_bench_exts.json').read())
-print(d['value'], d['value_hbm_resident'], d['roofline']['frac'], d['cpu_baseline']['value'], d.get('gpu_over_cpu_1thread'))
-PY
-python tools/scripts/exts_classes.py 2>&1 | tail -20 > gpurun_out/profiles/r2z_exts_classes.txt; cat gpurun_out/profiles/r2z_exts_classes.txt
+run() { timeout 600 python bench.py --workload $1 --steps $3 --warmup 2 --no-cpu --no-also 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1 $2 steps=$3 e2e', d['value'], 'resident', d['value_hbm_resident'], 'ms/step', d['ms_per_step'])"; }
+for rep in 1 2; do
+run cfg5 pinned-pool 5
+run cfg3 pinned-pool 30
+run 10k-cigar pinned-pool 12
+run exts pinned-pool 8
+run cfg4 pinned-pool 2
+done
+timeout 900 python -m pytest tests -m gpu -x -q -k "cigar or golden or cfg3 or reuse or thread" 2>&1 | tail -3
