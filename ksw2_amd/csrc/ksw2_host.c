@@ -400,6 +400,12 @@ static int cmp_cost_desc(const void *a, const void *b)
 
 /* `scalar`: the call came through ksw_extz / ksw_extd / ksw_gg* (matrix used as given, no end bonus, no mismatch-vs-gap
  * reject, gap pieces kept in the caller's order).  Decided by the entry point, never by a bit in the caller's flags. */
+/* the sequence copy of a plan (pass 1 of plan_create_ex): the bytes into the pinned arena, a wildcard flag per pair.  A big plan
+ * created outside the worker pool has the pool's threads share the copy (parallel_copy, behind the pool) */
+typedef struct { uint8_t *h_seq; const K2aPair *hp; const ksw2amd_pair_t *pairs; uint8_t *wild; } copy_ctx_t;
+static void copy_range(const copy_ctx_t *c, int beg, int end);
+static int parallel_copy(copy_ctx_t *c, int n, size_t bytes);
+
 static double now_ms(void);
 static int trace_level(void) { static int t = -1; if (t < 0) { const char *e = getenv("KSW2AMD_TRACE"); t = e ? atoi(e) : 0; } return t; }
 
@@ -474,15 +480,18 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	pk_ok = (uint8_t*)calloc((size_t)n + 1, 1);
 	solo_ok = (uint8_t*)calloc((size_t)n + 1, 1);
 	if (!pk_ok || !solo_ok) { fail(KSW2AMD_E_NOMEM, "plan_create: host allocation failed%s", 0); goto err; }
+	{
+		copy_ctx_t cc;
+		cc.h_seq = p->h_seq; cc.hp = p->h_pairs; cc.pairs = pairs; cc.wild = solo_ok;              /* (solo_ok doubles as the wildcard flags until the loop below sets it) */
+		if (!parallel_copy(&cc, n, p->seq_bytes)) copy_range(&cc, 0, n);
+	}
 	for (i = 0; i < n; ++i) {
 		const ksw2amd_pair_t *a = &pairs[i];
 		K2aPair *d = &p->h_pairs[i];
 		const int fl = p->h_flag[i];
 		int w = a->w, cfg, mode, generic, mx, wild;
 		if (a->qlen <= 0 || a->tlen <= 0) continue;
-		wild = copy_scan(p->h_seq + d->qoff, a->query, a->qlen);
-		wild |= copy_scan(p->h_seq + d->toff, a->target, a->tlen);
-		memset(p->h_seq + d->toff + a->tlen, 0, 64);                                                /* rows read past the target end */
+		wild = solo_ok[i]; solo_ok[i] = 0;
 		mx = imax(a->qlen, a->tlen);
 		if (w < 0 || w > mx) w = mx;                                                               /* ksw2_extz2_sse.c:72 */
 		d->qlen = a->qlen; d->tlen_full = a->tlen; d->w = w;
@@ -1100,6 +1109,7 @@ typedef struct {
 	int next;                                   /* next chunk, atomic */
 	int ndev, dev[POOL_MAXDEV], share;          /* devices of the job, worker threads per device */
 	int flush;                                  /* instead of chunks: every worker returns its cached buffers */
+	int quiet;                                  /* not a batch: keep it out of the host statistics */
 	int rc; char err[512];                      /* first failure */
 	int pending;                                /* participating workers still busy */
 } job_t;
@@ -1192,7 +1202,7 @@ static int pool_run(job_t *j)
 	for (i = 0, j->pending = 0; i < g_pool.nw; ++i) j->pending += job_has_dev(j, g_pool.dev[i]);
 	if (j->pending == 0) { pthread_mutex_unlock(&g_pool.mu); pthread_mutex_unlock(&g_pool.submit); return -1; }
 	g_pool.job = j; ++g_pool.gen;
-	if (!j->flush) { g_stat[0] += 1; g_stat[1] += j->nchunks; }
+	if (!j->flush && !j->quiet) { g_stat[0] += 1; g_stat[1] += j->nchunks; }
 	pthread_cond_broadcast(&g_pool.work);
 	while (j->pending > 0) pthread_cond_wait(&g_pool.done, &g_pool.mu);
 	g_pool.job = 0;
@@ -1263,6 +1273,46 @@ static int make_chunks(int n, const double *cost, double total, int nchunks, int
 	}
 	cbeg[++c] = n;
 	return c;
+}
+
+static void copy_range(const copy_ctx_t *c, int beg, int end)
+{
+	int i;
+	for (i = beg; i < end; ++i) {
+		const ksw2amd_pair_t *a = &c->pairs[i];
+		if (a->qlen <= 0 || a->tlen <= 0) continue;
+		c->wild[i] = (uint8_t)(copy_scan(c->h_seq + c->hp[i].qoff, a->query, a->qlen) | copy_scan(c->h_seq + c->hp[i].toff, a->target, a->tlen));
+		memset(c->h_seq + c->hp[i].toff + a->tlen, 0, 64);                                          /* rows read past the target end */
+	}
+}
+static int copy_chunk(void *ctx, int beg, int end, int share, pend_t *pd)
+{
+	(void)share; (void)pd;
+	if (beg >= 0) copy_range((const copy_ctx_t*)ctx, beg, end);
+	return KSW2AMD_OK;
+}
+/* 1 = the pool's threads did the copy.  Only for plans of 32 MB and more created outside the pool (a single-plan batch, a
+ * caller's own ksw2amd_plan_create): config 5's 166 MB took 16 of the 22 ms of its plan creation on the calling thread */
+static int parallel_copy(copy_ctx_t *c, int n, size_t bytes)
+{
+	const int tpd = pool_threads_per_device();
+	job_t j;
+	int cbeg[POOL_MAXW + 2], k, i, nch;
+	if (g_is_worker || tpd < 2 || n < 2 * tpd || bytes < ((size_t)32 << 20) || getenv("KSW2AMD_NO_PARCOPY")) return 0;
+	nch = imin(tpd, POOL_MAXW);
+	for (k = 0, i = 0; k < nch; ++k) {                     /* equal byte ranges of the arena (the pairs lie in it in order) */
+		const size_t edge = bytes / (size_t)nch * (size_t)k;
+		while (i < n && (c->pairs[i].qlen <= 0 || c->pairs[i].tlen <= 0 || c->hp[i].qoff < edge)) ++i;
+		cbeg[k] = k ? i : 0;
+	}
+	cbeg[nch] = n;
+	memset(&j, 0, sizeof(j));
+	j.fn = copy_chunk; j.ctx = c; j.cbeg = cbeg; j.nchunks = nch; j.quiet = 1;
+	j.ndev = 1;                                            /* the creating thread's device's workers */
+	j.dev[0] = k2a_shim_get_device(); if (j.dev[0] < 0) j.dev[0] = 0;
+	j.share = nch;
+	if (pool_run(&j)) return 0;
+	return j.rc == 0;
 }
 
 static int pool_min_pairs(void)

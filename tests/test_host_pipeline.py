@@ -91,6 +91,27 @@ def test_uniform_batch_is_cut_at_device_fills(sim, monkeypatch, score_only, expe
     assert s1["pool_chunks"] == s0["pool_chunks"] + expect_chunks
 
 
+def test_big_plan_copies_its_sequences_on_the_pool(sim, monkeypatch):
+    """A plan of 32 MB or more created on the caller's thread has the pool's threads share the sequence copy
+    (ksw2_host.c::parallel_copy); every pair must still see its own bytes (a wildcard in one pair only, narrow band)."""
+    monkeypatch.setenv("KSW2AMD_THREADS", "3")
+    n, L = 3400, 5000
+    qs, ts = synth.fixed_batch(91, n, L, L, sub=0.03, ind=0.02)
+    qs, ts = [np.array(q) for q in qs], [np.array(t) for t in ts]
+    qs[1234][100] = 4                                   # a wildcard: that pair alone leaves the packed class
+    mat = synth.simple_mat(5, 2, 4, -1)
+    b = sim.make_batch(qs, ts, mat, 4, 2, 24, 1, w=1, zdrop=-1, end_bonus=0, flag=po.SCORE_ONLY)
+    s0 = sim.host_stats()
+    plan = b.plan(False)
+    plan.run()
+    res = plan.fetch()
+    plan.close()
+    assert sim.host_stats()["pool_batches"] == s0["pool_batches"]          # the copy job is not a batch
+    for i in list(range(0, n, 97)) + [1233, 1234, 1235, n - 1]:
+        exp = po.align("oracle", "extz", qs[i], ts[i], mat, 4, 2, 24, 1, w=1, zdrop=-1, end_bonus=0, flag=po.SCORE_ONLY)
+        assert not diff(res[i], exp), i
+
+
 def test_pool_off_and_inline_paths_agree(sim, monkeypatch):
     qs, ts, w, zd, fl = _ragged(31, 60)
     mat = synth.simple_mat(5, 2, 4, -1)
