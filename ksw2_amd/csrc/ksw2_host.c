@@ -213,6 +213,7 @@ struct ksw2amd_plan_s {
 	K2aExtf f_par;
 	/* SSE-compatible plans (ksw2amd_sse_plan_create, splice == 3): tasks grouped by kernel mode in s_first / s_count[mode][0][0] */
 	K2aSsec c_par;
+	size_t c_lds[3];               /* SSE-compatible plans: per-wavefront LDS bytes of the tasks whose state fits LDS, per mode (0 = none) */
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -2280,6 +2281,9 @@ static int wants_ssec(int flag)
 	return (flag & KSW_EZ_APPROX_MAX) && (flag & KSW_EZ_APPROX_DROP) && !drop_exact;
 }
 
+/* state bytes per alignment up to which the SSE-compatible kernel keeps them in LDS.  What the LDS form gains in latency it loses
+ * in wavefronts per CU: 512-base reads (4.6 KB) 106 -> 133 GCUPS, 2 048-base reads (18-22 KB: seven wavefronts per CU) 126 -> 79 */
+#define SSEC_LDS_MAX ((size_t)8 * 1024)
 static int ssec_ncol(int qlen, int tlen, int w)            /* = k2a_ssec_ncol (ksw2_lane_ssec.h) */
 {
 	const int n = imin(imin(qlen, tlen), w + 1);
@@ -2301,7 +2305,7 @@ ksw2amd_plan_t *ksw2amd_sse_plan_create(int dual, const ksw2amd_scoring_t *sc, i
 	int i, k, mode, m, q, e, q2, e2, lo;
 	size_t off, mat_off;
 	void *up;
-	uint32_t fill[3];
+	uint32_t fill[6];
 
 	g_err[0] = 0;
 	if (n < 0 || (n > 0 && !pairs) || !sc) { fail(KSW2AMD_E_PARAM, "sse plan: bad arguments%s", 0); return 0; }
@@ -2341,8 +2345,13 @@ ksw2amd_plan_t *ksw2amd_sse_plan_create(int dual, const ksw2amd_scoring_t *sc, i
 		mx = imax(a->qlen, a->tlen);
 		if (w < 0 || w > mx) w = mx;                                       /* a wider band than the sequences changes nothing (ksw2_extz2_sse.c:72) */
 		mode = (fl & KSW_EZ_SCORE_ONLY) ? K2A_MODE_SCORE : (fl & KSW_EZ_RIGHT) ? K2A_MODE_RIGHT : K2A_MODE_LEFT;
-		p->h_cls[i] = (int8_t)mode;
-		++p->s_count[mode][0][0];
+		{	/* state arrays of up to SSEC_LDS_MAX bytes live in LDS (k2a_ssec_kernel<.., LDS = true>); KSW2AMD_SSEC_HBM=1: never (tests) */
+			const size_t sb = (size_t)(dual ? 11 : 9) * (size_t)((a->tlen + 15) / 16 * 16);
+			const int lds = sb <= SSEC_LDS_MAX && !getenv("KSW2AMD_SSEC_HBM");
+			p->h_cls[i] = (int8_t)(mode + 3 * lds);
+			++p->s_count[mode][0][lds];
+			if (lds && sb > p->c_lds[mode]) p->c_lds[mode] = sb;
+		}
 		d->qlen = a->qlen; d->tlen = d->tlen_full = a->tlen; d->w = w;
 		d->zdrop = a->zdrop; d->end_bonus = a->end_bonus;
 		d->flag = fl & (KSW_EZ_EXTZ_ONLY | KSW_EZ_REV_CIGAR | KSW_EZ_SCORE_ONLY);
@@ -2369,7 +2378,7 @@ ksw2amd_plan_t *ksw2amd_sse_plan_create(int dual, const ksw2amd_scoring_t *sc, i
 	p->seq_bytes = off;
 	p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, p->seq_bytes, &p->cap[BUF_HSEQ]);
 	if (!p->h_seq) { fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
-	for (k = 0, mode = 0; mode < 3; ++mode) { p->s_first[mode][0][0] = k; fill[mode] = (uint32_t)k; k += p->s_count[mode][0][0]; }
+	for (k = 0, mode = 0; mode < 6; ++mode) { p->s_first[mode % 3][0][mode / 3] = k; fill[mode] = (uint32_t)k; k += p->s_count[mode % 3][0][mode / 3]; }
 	p->ntasks = p->norder = k;
 	for (i = 0; i < n; ++i) {
 		if (p->h_cls[i] < 0) continue;
@@ -2422,14 +2431,14 @@ static int ssec_plan_run(ksw2amd_plan_t *p, void *stream)
 	p->stream = stream; p->ran = 1; p->stream_used = 1;
 	if (p->reject_all || p->ntasks == 0) return KSW2AMD_OK;
 	if (k2a_shim_event_record(p->ev[0], stream)) goto err;
-	for (mode = 0; mode < 3; ++mode)
-		if (p->s_count[mode][0][0] &&
-		    k2a_shim_launch_ssec(p->dual, mode, &p->c_par, p->d_pairs, p->d_order + p->s_first[mode][0][0], p->s_count[mode][0][0], p->d_seq, p->d_tb,
-		                         (uint8_t*)p->d_bnd, p->d_res, stream)) goto err;
+	for (mode = 0; mode < 6; ++mode)
+		if (p->s_count[mode % 3][0][mode / 3] &&
+		    k2a_shim_launch_ssec(p->dual, mode % 3, mode / 3 ? p->c_lds[mode % 3] : 0, &p->c_par, p->d_pairs, p->d_order + p->s_first[mode % 3][0][mode / 3],
+		                         p->s_count[mode % 3][0][mode / 3], p->d_seq, p->d_tb, (uint8_t*)p->d_bnd, p->d_res, stream)) goto err;
 	if (k2a_shim_event_record(p->ev[1], stream)) goto err;
-	for (mode = 1; mode < 3; ++mode)
-		if (p->s_count[mode][0][0] &&
-		    k2a_shim_launch_ssec_trace(p->d_pairs, p->d_order + p->s_first[mode][0][0], p->s_count[mode][0][0], p->d_tb, p->d_res, p->d_cig, stream)) goto err;
+	for (mode = 0; mode < 6; ++mode)
+		if (mode % 3 && p->s_count[mode % 3][0][mode / 3] &&
+		    k2a_shim_launch_ssec_trace(p->d_pairs, p->d_order + p->s_first[mode % 3][0][mode / 3], p->s_count[mode % 3][0][mode / 3], p->d_tb, p->d_res, p->d_cig, stream)) goto err;
 	if (k2a_shim_event_record(p->ev[2], stream)) goto err;
 	return KSW2AMD_OK;
 err:

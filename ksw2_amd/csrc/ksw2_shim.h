@@ -116,7 +116,8 @@ int k2a_shim_launch_extf(int cls, const K2aExtf *par, const K2aPair *pairs, cons
  * alignment per wavefront; pairs[i].bnd_off = offset of its state arrays in `scratch` in 16-byte units ((5 or 7) + 4 bytes per
  * 16-padded target position), tb_off = its direction matrix ((qlen + tlen - 1) * k2a_ssec_ncol bytes), pad = K2A_SSEC_* bits,
  * tlen = tlen_full, w = the band resolved as in ksw2_extz2_sse.c:72. */
-int k2a_shim_launch_ssec(int dual, int mode, const K2aSsec *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
+/* lds_bytes > 0: the tasks' state arrays fit that many bytes each and live in LDS (one wavefront per workgroup) instead of `scratch` */
+int k2a_shim_launch_ssec(int dual, int mode, size_t lds_bytes, const K2aSsec *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
                          uint8_t *tb, uint8_t *scratch, K2aResult *res, void *stream);
 int k2a_shim_launch_ssec_trace(const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb, K2aResult *res, uint32_t *cig, void *stream);
 

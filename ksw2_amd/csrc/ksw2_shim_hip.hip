@@ -1075,14 +1075,19 @@ k2a_splice_const_kernel(const K2aPair *__restrict__ pairs, int n, uint8_t *seq, 
  * L2-resident).  Positions move between lanes from one anti-diagonal to the next and the phases of an anti-diagonal read what
  * other lanes wrote in the phase before, so workgroup-scope release / acquire pairs separate them (writer and reader are
  * lanes of one wavefront; the CU's L1 is write-through). */
-#define K2A_SSEC_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
-template<bool DUAL, int MODE>
+/* LDS = true: the same arrays in the workgroup's dynamic LDS (one wavefront per workgroup, (5 or 7) + 4 bytes per padded target
+ * position): a wavefront's DS operations execute in order, so the phases need no memory fence, only the compiler kept from
+ * reordering -- and no L2 round trip per phase, which is what an anti-diagonal of the HBM form consists of. */
+#define K2A_SSEC_SYNC() do { if (LDS) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } \
+                             else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } } while (0)
+extern __shared__ uint8_t k2a_ssec_lds[];
+template<bool DUAL, int MODE, bool LDS>
 __global__ void __launch_bounds__(64 * K2A_WPB)
 k2a_ssec_kernel(const K2aSsec P, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
                 const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, uint8_t *scratch, K2aResult *__restrict__ res)
 {
 	const int lane = threadIdx.x & 63, wave = k2a_wave_id<true>();
-	const int task = blockIdx.x * K2A_WPB + wave;
+	const int task = LDS ? (int)blockIdx.x : blockIdx.x * K2A_WPB + wave;
 	if (task >= ntasks) return;                       /* whole wavefronts leave; nobody synchronises below */
 	const uint32_t pi = order[task];
 	const K2aPair pr = pairs[pi];
@@ -1090,7 +1095,7 @@ k2a_ssec_kernel(const K2aSsec P, const K2aPair *__restrict__ pairs, const uint32
 	const bool approx = (pr.pad & K2A_SSEC_APPROX) != 0, adrop = (pr.pad & K2A_SSEC_APPROX_DROP) != 0, generic = (pr.pad & K2A_SSEC_GENERIC) != 0;
 	const uint8_t *qry = seq + pr.qoff, *tgt = seq + pr.toff;
 	uint8_t *tbp = tb + pr.tb_off;
-	uint8_t *U = scratch + (size_t)pr.bnd_off * 16, *V = U + T16, *X = V + T16, *Y = X + T16;
+	uint8_t *U = LDS ? k2a_ssec_lds : scratch + (size_t)pr.bnd_off * 16, *V = U + T16, *X = V + T16, *Y = X + T16;
 	uint8_t *X2 = DUAL ? Y + T16 : Y, *Y2 = DUAL ? X2 + T16 : Y, *S = (DUAL ? Y2 : Y) + T16;
 	int32_t *H = (int32_t*)(S + T16);
 	const int slope = DUAL ? P.e2 : P.e;
@@ -1169,10 +1174,22 @@ k2a_ssec_kernel(const K2aSsec P, const K2aPair *__restrict__ pairs, const uint32
 						H[t] = h;
 						if (t < en1 && h > bH) { bH = h; bT = t; }
 					}
-					if (t0 == st0) Sv = __builtin_amdgcn_readlane(h, 0);
-					if (en1 < en0 && en1 >= t0 && en1 < t0 + 64) T0 = __builtin_amdgcn_readlane(h, (en1 - t0) & 63);
-					if (en1 + 1 < en0 && en1 + 1 >= t0 && en1 + 1 < t0 + 64) T1 = __builtin_amdgcn_readlane(h, (en1 + 1 - t0) & 63);
-					if (en1 + 2 < en0 && en1 + 2 >= t0 && en1 + 2 < t0 + 64) T2 = __builtin_amdgcn_readlane(h, (en1 + 2 - t0) & 63);
+					if (!LDS) {
+						if (t0 == st0) Sv = __builtin_amdgcn_readlane(h, 0);
+						if (en1 < en0 && en1 >= t0 && en1 < t0 + 64) T0 = __builtin_amdgcn_readlane(h, (en1 - t0) & 63);
+						if (en1 + 1 < en0 && en1 + 1 >= t0 && en1 + 1 < t0 + 64) T1 = __builtin_amdgcn_readlane(h, (en1 + 1 - t0) & 63);
+						if (en1 + 2 < en0 && en1 + 2 >= t0 && en1 + 2 < t0 + 64) T2 = __builtin_amdgcn_readlane(h, (en1 + 2 - t0) & 63);
+					}
+				}
+				if (LDS) {
+					/* the first cell and the (<= 3) tail cells by position, straight out of the row just written (four lanes, one
+					 * read) instead of range-tested v_readlane in every block: scalar instructions are half of this kernel */
+					__builtin_amdgcn_wave_barrier();
+					const int pos = lane == 0 ? st0 : en1 + lane - 1;
+					const int hv = (lane < 4 && pos < en0) ? H[pos] : K2A_NEG;
+					__builtin_amdgcn_wave_barrier();
+					if (st0 < en0) Sv = __builtin_amdgcn_readlane(hv, 0);
+					T0 = __builtin_amdgcn_readlane(hv, 1); T1 = __builtin_amdgcn_readlane(hv, 2); T2 = __builtin_amdgcn_readlane(hv, 3);
 				}
 				if (lane == 0) H[en0] = A;
 			} else {
@@ -1624,14 +1641,22 @@ int k2a_shim_launch_exts_trace(const K2aSplice *sp, const K2aPair *pairs, const 
 }
 
 typedef void (*ssec_fn)(const K2aSsec, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, uint8_t*, K2aResult*);
-static const ssec_fn g_ssec[2][3] = { { k2a_ssec_kernel<false, 0>, k2a_ssec_kernel<false, 1>, k2a_ssec_kernel<false, 2> },
-                                      { k2a_ssec_kernel<true, 0>,  k2a_ssec_kernel<true, 1>,  k2a_ssec_kernel<true, 2> } };
+static const ssec_fn g_ssec[2][2][3] = {      /* [state in LDS][dual][mode] */
+	{ { k2a_ssec_kernel<false, 0, false>, k2a_ssec_kernel<false, 1, false>, k2a_ssec_kernel<false, 2, false> },
+	  { k2a_ssec_kernel<true, 0, false>,  k2a_ssec_kernel<true, 1, false>,  k2a_ssec_kernel<true, 2, false> } },
+	{ { k2a_ssec_kernel<false, 0, true>,  k2a_ssec_kernel<false, 1, true>,  k2a_ssec_kernel<false, 2, true> },
+	  { k2a_ssec_kernel<true, 0, true>,   k2a_ssec_kernel<true, 1, true>,   k2a_ssec_kernel<true, 2, true> } } };
 
-int k2a_shim_launch_ssec(int dual, int mode, const K2aSsec *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
+int k2a_shim_launch_ssec(int dual, int mode, size_t lds_bytes, const K2aSsec *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
                          uint8_t *tb, uint8_t *scratch, K2aResult *res, void *stream)
 {
 	if (ntasks <= 0) return 0;
-	hipLaunchKernelGGL(g_ssec[dual ? 1 : 0][mode], dim3((ntasks + K2A_WPB - 1) / K2A_WPB), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
+	if (lds_bytes > 0) {
+		const ssec_fn f = g_ssec[1][dual ? 1 : 0][mode];
+		if (lds_bytes > 48 * 1024) CHECK(hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+		hipLaunchKernelGGL(f, dim3(ntasks), dim3(64), lds_bytes, (hipStream_t)stream, *par, pairs, order, ntasks, seq, tb, scratch, res);
+	} else
+	hipLaunchKernelGGL(g_ssec[0][dual ? 1 : 0][mode], dim3((ntasks + K2A_WPB - 1) / K2A_WPB), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
 	                   *par, pairs, order, ntasks, seq, tb, scratch, res);
 	CHECK(hipGetLastError());
 	return 0;

@@ -1027,7 +1027,7 @@ int k2a_shim_launch_fill_pkmp(int dual, int mode, const K2aScoring *sc, const K2
 	if (ntasks > 0) f[dual ? 1 : 0][mode](*sc, pairs, order2, ntasks, seq, tb, bnd, res);
 	return 0;
 }
-int k2a_shim_launch_ssec(int dual, int mode, const K2aSsec *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
+int k2a_shim_launch_ssec(int dual, int mode, size_t, const K2aSsec *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
                          uint8_t *tb, uint8_t *scratch, K2aResult *res, void *)
 {
 	typedef void (*fn)(const K2aSsec, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, uint8_t*, K2aResult*);
