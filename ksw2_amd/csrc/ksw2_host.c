@@ -50,8 +50,8 @@ int ksw2amd_set_device(int device)
  * Device allocations and page-locking cost milliseconds; a minimap2-style caller issues many batches (or single-pair
  * calls) from the same thread.  Each thread therefore keeps the buffers of its last plan (one per kind) and hands them to
  * the next plan when they are large enough.  ksw2amd_release_cache() returns them; switching device flushes them. */
-enum { BUF_HSEQ, BUF_SEQ, BUF_PAIRS, BUF_RES, BUF_ORDER, BUF_TB, BUF_CIG, BUF_BND, BUF_POS, BUF_POOL, BUF_HPOOL, BUF_KINDS };
-#define BUF_IS_HOST(k) ((k) == BUF_HSEQ || (k) == BUF_HPOOL)      /* pinned host staging; everything else is device memory */
+enum { BUF_HSEQ, BUF_SEQ, BUF_PAIRS, BUF_RES, BUF_ORDER, BUF_TB, BUF_CIG, BUF_BND, BUF_POS, BUF_POOL, BUF_HPOOL, BUF_HRES, BUF_KINDS };
+#define BUF_IS_HOST(k) ((k) == BUF_HSEQ || (k) == BUF_HPOOL || (k) == BUF_HRES)      /* pinned host staging; everything else is device memory */
 static __thread struct { void *p; size_t cap; } g_cache[BUF_KINDS];
 static __thread void *g_ev_cache[3];
 /* Every host thread uploads and (in the one-shot entry points) computes on a stream of its own, so concurrent callers --
@@ -385,7 +385,8 @@ void ksw2amd_plan_destroy(ksw2amd_plan_t *p)
 	cache_put(BUF_ORDER, p->d_order, p->cap[BUF_ORDER]); cache_put(BUF_CIG, p->d_cig, p->cap[BUF_CIG]);
 	cache_put(BUF_BND, p->d_bnd, p->cap[BUF_BND]);
 	for (i = 0; i < 3; ++i) if (p->ev[i]) { if (!g_ev_cache[i]) g_ev_cache[i] = p->ev[i]; else k2a_shim_event_destroy(p->ev[i]); }
-	free(p->h_pairs); free(p->h_cls); free(p->h_half); free(p->h_flag); free(p->h_order); free(p->h_res);
+	free(p->h_pairs); free(p->h_cls); free(p->h_half); free(p->h_flag); free(p->h_order);
+	cache_put(BUF_HRES, p->h_res, p->cap[BUF_HRES]);          /* pinned: the results come back with one asynchronous copy */
 	cache_put(BUF_HSEQ, p->h_seq, p->cap[BUF_HSEQ]);
 	free(p);
 }
@@ -441,7 +442,8 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	p->h_half = (uint8_t*)calloc((size_t)n + 1, 1);
 	p->h_flag = (int32_t*)malloc(sizeof(int32_t) * ((size_t)n + 1));
 	p->h_pairs = (K2aPair*)calloc((size_t)n + 1, sizeof(K2aPair));
-	p->h_res = (K2aResult*)calloc((size_t)n + 1, sizeof(K2aResult));
+	p->h_res = (K2aResult*)cache_get(BUF_HRES, sizeof(K2aResult) * ((size_t)n + 1), &p->cap[BUF_HRES]);
+	if (p->h_res) memset(p->h_res, 0, sizeof(K2aResult) * ((size_t)n + 1));
 	if (!p->h_cls || !p->h_half || !p->h_flag || !p->h_pairs || !p->h_res) { fail(KSW2AMD_E_NOMEM, "plan_create: host allocation failed%s", 0); goto err; }
 	for (i = 0; i < n; ++i) { p->h_cls[i] = -1; p->h_flag[i] = (pairs[i].flag & ~F_SCALAR_CONTRACT) | (scalar ? F_SCALAR_CONTRACT : 0); }
 
@@ -1838,7 +1840,8 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 	p->h_half = (uint8_t*)calloc((size_t)n + 1, 1);
 	p->h_flag = (int32_t*)malloc(sizeof(int32_t) * ((size_t)n + 1));
 	p->h_pairs = (K2aPair*)calloc((size_t)n + 1, sizeof(K2aPair));
-	p->h_res = (K2aResult*)calloc((size_t)n + 1, sizeof(K2aResult));
+	p->h_res = (K2aResult*)cache_get(BUF_HRES, sizeof(K2aResult) * ((size_t)n + 1), &p->cap[BUF_HRES]);
+	if (p->h_res) memset(p->h_res, 0, sizeof(K2aResult) * ((size_t)n + 1));
 	p->h_order = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n + 1));
 	if (!p->h_cls || !p->h_half || !p->h_flag || !p->h_pairs || !p->h_res || !p->h_order) { fail(KSW2AMD_E_NOMEM, "exts: host allocation failed%s", 0); goto err; }
 	for (i = 0; i < n; ++i) { p->h_cls[i] = -1; p->h_flag[i] = pairs[i].flag & ~F_SCALAR_CONTRACT; }
@@ -2116,7 +2119,8 @@ ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n
 	p->h_half = (uint8_t*)calloc((size_t)n + 1, 1);
 	p->h_flag = (int32_t*)calloc((size_t)n + 1, sizeof(int32_t));
 	p->h_pairs = (K2aPair*)calloc((size_t)n + 1, sizeof(K2aPair));
-	p->h_res = (K2aResult*)calloc((size_t)n + 1, sizeof(K2aResult));
+	p->h_res = (K2aResult*)cache_get(BUF_HRES, sizeof(K2aResult) * ((size_t)n + 1), &p->cap[BUF_HRES]);
+	if (p->h_res) memset(p->h_res, 0, sizeof(K2aResult) * ((size_t)n + 1));
 	p->h_order = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n + 1));
 	if (!p->h_cls || !p->h_half || !p->h_flag || !p->h_pairs || !p->h_res || !p->h_order) { fail(KSW2AMD_E_NOMEM, "extf: host allocation failed%s", 0); goto err; }
 	p->f_par.mch = mch; p->f_par.mis = mis < 0 ? mis : -mis; p->f_par.e = e;      /* ksw2_extf2_sse.c:18-20 */
@@ -2318,7 +2322,8 @@ ksw2amd_plan_t *ksw2amd_sse_plan_create(int dual, const ksw2amd_scoring_t *sc, i
 	p->h_half = (uint8_t*)calloc((size_t)n + 1, 1);
 	p->h_flag = (int32_t*)malloc(sizeof(int32_t) * ((size_t)n + 1));
 	p->h_pairs = (K2aPair*)calloc((size_t)n + 1, sizeof(K2aPair));
-	p->h_res = (K2aResult*)calloc((size_t)n + 1, sizeof(K2aResult));
+	p->h_res = (K2aResult*)cache_get(BUF_HRES, sizeof(K2aResult) * ((size_t)n + 1), &p->cap[BUF_HRES]);
+	if (p->h_res) memset(p->h_res, 0, sizeof(K2aResult) * ((size_t)n + 1));
 	p->h_order = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n + 1));
 	if (!p->h_cls || !p->h_half || !p->h_flag || !p->h_pairs || !p->h_res || !p->h_order) { fail(KSW2AMD_E_NOMEM, "sse plan: host allocation failed%s", 0); goto err; }
 	for (i = 0; i < n; ++i) { p->h_cls[i] = -1; p->h_flag[i] = pairs[i].flag & ~F_SCALAR_CONTRACT; }
