@@ -231,6 +231,36 @@ class Job:
             f = L.lib.ksw2amd_extd_batch if self.kind == "extd" else L.lib.ksw2amd_extz_batch
             L._check(f(None, ctypes.byref(b.sc), b.n, b.pairs, self.ez))
 
+    # ---- correctness evidence attached to the number: outside the clock, a few pairs of the batch the timed loop just aligned
+    def parity_sample(self, k=16):
+        """Compare k evenly spaced results of the last e2e_step (self.ez, i.e. what the timed calls returned) with the oracle:
+        every ksw_extz_t field and the CIGAR.  Returns a JSON-able verdict."""
+        from oracle import pyoracle as po
+        if self.ez is None or self.n == 0:
+            return {"pairs": 0, "result": "not run"}
+        wl, S = self.wl, SCORING
+        idx = sorted({int(x) for x in np.linspace(0, self.n - 1, min(k, self.n))})
+        fields = ksw2_amd.FIELDS + ([] if self.kind == "extf" else ["cigar"])
+        bad = []
+        for i in idx:
+            got = ksw2_amd.ez_to_dict(self.ez[i])
+            if self.kind == "exts":
+                P = SPLICE_SCORING
+                exp = po.exts2("oracle", self.q[i], self.t[i], self.mat, P["q"], P["e"], P["q2"], P["noncan"], zdrop=wl["zdrop"], flag=wl["flag"])
+            elif self.kind == "extf":
+                P = LINEAR_SCORING
+                exp = po.extf2("oracle", self.q[i], self.t[i], P["mch"], P["mis"], P["e"], wl["w"], wl["zdrop"])
+            elif self.sse:
+                return {"pairs": 0, "result": "not sampled (SSE-compatible mode: tests/test_gpu_parity.py::test_sse_compatible_mode)"}
+            else:
+                exp = po.align("oracle", "extd2" if self.kind == "extd" else "extz2", self.q[i], self.t[i], self.mat, S["q"], S["e"], S["q2"], S["e2"],
+                               w=wl["w"], zdrop=wl["zdrop"], end_bonus=0, flag=wl["flag"])
+            d = [f for f in fields if exp[f] != got[f]]
+            if d:
+                bad.append({"pair": i, "fields": d})
+        return {"pairs": len(idx), "result": "ok" if not bad else "MISMATCH", "checked": "all ksw_extz_t fields" + ("" if self.kind == "extf" else " + CIGAR") +
+                " of the timed batch's last step vs oracle/ (CPU restatement pinned to the compiled reference)", **({"mismatches": bad[:4]} if bad else {})}
+
     def free_ez(self):
         if self.ez is not None:
             for i in range(self.n):
@@ -270,7 +300,8 @@ class Job:
         else:
             done = int(cells_of_rows(self.qlen[:nn], np.minimum(rows, self.tlen[:nn]), self.weff[:nn]).sum())
         res = dict(n=nn, cells=cells, steps=k, wall_s=wall, kernel_ms=float(np.mean(total_ms)), fill_ms=float(np.mean(fill_ms)),
-                   cells_done=done, zdropped=int(raw[:, 1].sum()), packed_pairs=plan.packed_pairs(), device_bytes=plan.device_bytes())
+                   cells_done=done, zdropped=int(raw[:, 1].sum()), packed_pairs=plan.packed_pairs(), device_bytes=plan.device_bytes(),
+                   kernels=plan.describe() if self.kind in ("extz", "extd") and not self.sse else [])
         plan.close()
         return res
 
@@ -299,6 +330,8 @@ def roofline_of(job, res, workload_key):
             "kernel_gcups": round(res["cells"] / kern_s / 1e9, 2), "pairs_per_launch": res["n"], "cells_per_launch": res["cells"],
             "kernel_gcups_cells_filled": round(res["cells_done"] / kern_s / 1e9, 2),
             "early_stop_fraction": round(1.0 - res["cells_done"] / max(res["cells"], 1), 5), "zdropped_pairs": res["zdropped"],
+            "kernels": ["%s(%d,%d) gaps=%d %s%s%s %s x%d" % (c["kernel"], c["G"], c["C"], c["gaps"], c["mode"], " rebased" if c["rebased"] else "",
+                                                             " nomax" if c["nomax"] else "", c["form"], c["tasks"]) for c in res.get("kernels", [])],
             "algorithmic_bytes": alg_bytes, "hbm_algorithmic_GBps": round(alg_bytes / kern_s / 1e9, 2), "hbm_peak_GBps": HBM_PEAK / 1e9}
 
 
@@ -432,6 +465,7 @@ def main():
         pairs_all = job.n * world
     else:
         cells_all, pairs_all = float(job.cells), job.n
+    parity = job.parity_sample(16) if rank == 0 else None      # outside the timed region: the results the timed calls returned
     job.free_ez()
     lib.release_cache()
     barrier()
@@ -461,6 +495,7 @@ def main():
                        "host_pipeline": {k: stats1[k] - stats0[k] for k in stats1},
                        "parallelism": "pairs sharded over %d GPU(s), one process per GPU, no collective in the data path" % world},
             "roofline": rl,
+            "parity_sample": parity["result"], "parity_detail": parity,
         }
         if sg:
             out["config"]["rank0_scatter_gather"] = sg
@@ -482,6 +517,7 @@ def main():
                 j.e2e_step()
                 k += 1
             edt = time.perf_counter() - t0
+            jpar = j.parity_sample(1 if WORKLOADS[name].get("mt") else 6)
             j.free_ez()
             lib.release_cache()
             r = j.resident(3, 1, stream, min_seconds=1.0)
@@ -489,8 +525,9 @@ def main():
             rr = roofline_of(j, r, name)
             also.append({"workload": describe(j, world), "value": round(j.cells * k / edt / 1e9, 2), "value_hbm_resident": rr["kernel_gcups"],
                          "unit": "GCUPS", "pairs_per_s": round(j.n * k / edt, 1), "steps": k, "ms_per_step": round(edt / k * 1e3, 3),
-                         "dtype": dtype_of(j, r), "roofline": {x: rr[x] for x in ("frac", "kernel_ms", "fill_kernel_ms", "ops_per_cell", "pairs_per_launch",
-                                                                                   "kernel_gcups_cells_filled", "early_stop_fraction", "zdropped_pairs", "traffic", "traffic_source")}})
+                         "dtype": dtype_of(j, r), "parity_sample": "%s (%d pairs)" % (jpar["result"], jpar["pairs"]),
+                         "roofline": {x: rr[x] for x in ("frac", "kernel_ms", "fill_kernel_ms", "ops_per_cell", "pairs_per_launch", "kernels",
+                                                         "kernel_gcups_cells_filled", "early_stop_fraction", "zdropped_pairs", "traffic", "traffic_source")}})
             del j
         except Exception as exc:                                  # one workload must not take the headline with it
             also.append({"workload": name, "error": "%s: %s" % (type(exc).__name__, exc)})

@@ -40,7 +40,7 @@ extern "C" {
 #define KSW_EZ_RIGHT       0x02                   /* (ksw2.h:9)  right-align gaps */
 #define KSW_EZ_GENERIC_SC  0x04                   /* (ksw2.h:10) use mat[] for every residue pair */
 #define KSW_EZ_APPROX_MAX  0x08                   /* (ksw2.h:11) alone: like the reference only score + corner CIGAR are returned */
-#define KSW_EZ_APPROX_DROP 0x10                   /* (ksw2.h:12) with APPROX_MAX: computed exactly (the reference's drop heuristic is band-padding dependent) */
+#define KSW_EZ_APPROX_DROP 0x10                   /* (ksw2.h:12) with APPROX_MAX: routed to the SSE-compatible kernels, which reproduce the reference's drop heuristic (see KSW2AMD_EZ_SSE_COMPAT below) */
 #define KSW_EZ_EXTZ_ONLY   0x40                   /* (ksw2.h:13) extension only */
 #define KSW_EZ_REV_CIGAR   0x80                   /* (ksw2.h:14) CIGAR in end->start order */
 #define KSW_EZ_SPLICE_FOR   0x100                  /* (ksw2.h:15) exts2: GT..AG signals (forward transcript strand) */
@@ -226,6 +226,13 @@ int64_t ksw2amd_plan_cells(const ksw2amd_plan_t *plan);
 int64_t ksw2amd_plan_device_bytes(const ksw2amd_plan_t *plan);
 /* alignments routed to the packed-int16 kernels (two same-shape alignments per lane group) */
 int64_t ksw2amd_plan_packed_pairs(const ksw2amd_plan_t *plan);
+/* diagnostics: one text line per kernel class the plan's next run launches --
+ *   "kernel=pk G=64 C=16 gaps=1 mode=score rebased=1 nomax=0 generic=0 form=ldscodes tasks=1536"
+ * (kernel: int32 / mp / pk / pkmp / solo; form: registers / ldsrows / ldscodes, the launch-time choice).  Returns
+ * the number of classes; extz / extd plans only.  Tests use it to assert which kernel an unforced launch took. */
+int ksw2amd_plan_describe(const ksw2amd_plan_t *plan, char *buf, int cap);
+/* The KSW2AMD_* environment switches (tuning, A/B runs, tests) are read once per process; this reads them again. */
+void ksw2amd_reload_env(void);
 /* a resident plan of SSE-compatible alignments (every pair, whatever its flags); run / fetch / timing / cells / destroy as above */
 ksw2amd_plan_t *ksw2amd_sse_plan_create(int dual, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs);
 /* a resident plan of splice-aware extensions; run / fetch / timing / cells / destroy as above */

@@ -70,7 +70,14 @@ EXPORTS = ["ksw_extz2_sse", "ksw_extd2_sse", "ksw_gg2", "ksw_gg2_sse", "ksw_extz
            "ksw2amd_plan_fetch_raw", "ksw_exts2_sse", "ksw_exts2_sse41", "ksw_exts2_sse2", "ksw2amd_exts_batch", "ksw2amd_exts_plan_create",
            "ksw_extf2_sse", "ksw2amd_extf_batch", "ksw2amd_extf_plan_create",
            "ksw2amd_set_devices", "ksw2amd_set_error_handler", "ksw2amd_error_count", "ksw2amd_host_stats",
-           "ksw2amd_set_sse_compat", "ksw2amd_sse_plan_create"]
+           "ksw2amd_set_sse_compat", "ksw2amd_sse_plan_create", "ksw2amd_plan_describe", "ksw2amd_reload_env"]
+# entry points whose behaviour depends on KSW2AMD_* switches: the library reads its environment once per process, so this binding
+# re-reads it in front of each of them (tests and A/B scripts flip switches inside one process)
+_ENV_ENTRIES = ["ksw_extz2_sse", "ksw_extd2_sse", "ksw_gg2", "ksw_gg2_sse", "ksw_extz", "ksw_extd", "ksw_gg", "ksw_extz2_sse41",
+                "ksw_extz2_sse2", "ksw_extd2_sse41", "ksw_extd2_sse2", "ksw_exts2_sse", "ksw_exts2_sse41", "ksw_exts2_sse2", "ksw_extf2_sse",
+                "ksw2amd_extz_batch", "ksw2amd_extd_batch", "ksw2amd_exts_batch", "ksw2amd_extf_batch", "ksw2amd_plan_create",
+                "ksw2amd_sse_plan_create", "ksw2amd_exts_plan_create", "ksw2amd_extf_plan_create", "ksw2amd_plan_run",
+                "ksw2amd_plan_describe"]
 ERROR_FN = ctypes.CFUNCTYPE(None, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_void_p)
 KSW_EZ_SPLICE_FOR, KSW_EZ_SPLICE_REV, KSW_EZ_SPLICE_FLANK = 0x100, 0x200, 0x400
 
@@ -164,6 +171,17 @@ class Library:
         L.ksw2amd_release_cache.restype = None
         L.ksw2amd_host_stats.argtypes = [ctypes.POINTER(ctypes.c_int64)]
         L.ksw2amd_host_stats.restype = None
+        L.ksw2amd_plan_describe.argtypes = [ctypes.c_void_p, ctypes.c_char_p, _int]
+        L.ksw2amd_reload_env.restype = None
+        reload_env = L.ksw2amd_reload_env
+
+        def with_env(fn):
+            def call(*a):
+                reload_env()
+                return fn(*a)
+            return call
+        for name in _ENV_ENTRIES:
+            setattr(L, name, with_env(getattr(L, name)))
 
     # ---- info
     def backend(self):
@@ -451,6 +469,17 @@ class Plan:
 
     def packed_pairs(self):
         return int(self.L.lib.ksw2amd_plan_packed_pairs(self.h))
+
+    def describe(self):
+        """ksw2amd_plan_describe -> one dict per kernel class the next run() launches (kernel, G, C, gaps, mode, rebased, nomax,
+        generic, form, tasks)."""
+        buf = ctypes.create_string_buffer(16384)
+        self.L.lib.ksw2amd_plan_describe(self.h, buf, len(buf))
+        out = []
+        for line in buf.value.decode().splitlines():
+            d = dict(kv.split("=") for kv in line.split())
+            out.append({k: (int(v) if v.lstrip("-").isdigit() else v) for k, v in d.items()})
+        return out
 
     def device_bytes(self):
         return int(self.L.lib.ksw2amd_plan_device_bytes(self.h))

@@ -39,6 +39,80 @@ static int fail(int code, const char *fmt, const char *detail)
 void ksw2amd_release_cache(void);
 static void release_thread_cache(void);
 
+/* ---------------------------------------------------------------- environment switches
+ * Every KSW2AMD_* switch (A/B runs, tests, tuning) is read ONCE per process into a table -- the call paths, the coalesced
+ * single-pair calls above all, never touch getenv().  ksw2amd_reload_env() reads them again (tests that flip a switch inside
+ * one process; the Python binding calls it before every plan / batch). */
+#define K2A_ENV_LIST \
+	X(APPROX_DROP_EXACT) \
+	X(CHUNKS) \
+	X(CHUNK_GCELLS) \
+	X(CHUNK_MB) \
+	X(COALESCE_SLOTS) \
+	X(DBUF) \
+	X(EXTF_HBM) \
+	X(EXTF_LANE) \
+	X(EXTF_LDS) \
+	X(EXTF_WIN) \
+	X(EXTS_BIG) \
+	X(EXTS_REG) \
+	X(KEEP_LEFTOVERS) \
+	X(LDSCODES) \
+	X(LDSROWS) \
+	X(LONG_MS) \
+	X(MAX_BYTES) \
+	X(NO_PARCOPY) \
+	X(NO_PK) \
+	X(NO_PKMP) \
+	X(NO_RB) \
+	X(NO_UNITS) \
+	X(PK_FIRST) \
+	X(POOL_MIN) \
+	X(RAMP) \
+	X(SERIAL) \
+	X(SIMDS) \
+	X(SOLO) \
+	X(SSEC_HBM) \
+	X(SSE_COMPAT) \
+	X(THREADS) \
+	X(TRACE)
+enum {
+#define X(n) ENV_##n,
+	K2A_ENV_LIST
+#undef X
+	ENV_COUNT
+};
+static const char *const g_env_name[ENV_COUNT] = {
+#define X(n) "KSW2AMD_" #n,
+	K2A_ENV_LIST
+#undef X
+};
+static const char *g_env[ENV_COUNT];
+static volatile int g_env_ready;
+static int g_env_gen;                                /* bumped by every (re)load: function-local caches key on it */
+static pthread_mutex_t g_env_mu = PTHREAD_MUTEX_INITIALIZER;
+static int env_switch(const char *v);
+static void env_load(void)
+{
+	int i;
+	pthread_mutex_lock(&g_env_mu);
+	for (i = 0; i < ENV_COUNT; ++i) {
+		const char *v = getenv(g_env_name[i]);
+		/* values are kept for the life of the process: another thread may still hold the previous pointer */
+		if (v && (!g_env[i] || strcmp(g_env[i], v))) g_env[i] = strdup(v);
+		else if (!v) g_env[i] = 0;
+	}
+	k2a_shim_set_option(K2A_OPT_LDSCODES, env_switch(g_env[ENV_LDSCODES]));
+	k2a_shim_set_option(K2A_OPT_LDSROWS, env_switch(g_env[ENV_LDSROWS]));
+	++g_env_gen;
+	g_env_ready = 1;
+	pthread_mutex_unlock(&g_env_mu);
+}
+static int env_switch(const char *v) { return v && *v ? (atoi(v) != 0) : -1; }      /* -1 = automatic */
+#define ENV(n) (g_env_ready ? g_env[ENV_##n] : (env_load(), g_env[ENV_##n]))
+static int env_flag(const char *e, int dflt) { return e && *e ? atoi(e) != 0 : dflt; }
+void ksw2amd_reload_env(void) { env_load(); }
+
 int ksw2amd_set_device(int device)
 {
 	release_thread_cache();                                 /* cached buffers belong to the previous device */
@@ -409,7 +483,7 @@ static void copy_range(const copy_ctx_t *c, int beg, int end);
 static int parallel_copy(copy_ctx_t *c, int n, size_t bytes);
 
 static double now_ms(void);
-static int trace_level(void) { static int t = -1; if (t < 0) { const char *e = getenv("KSW2AMD_TRACE"); t = e ? atoi(e) : 0; } return t; }
+static int trace_level(void) { const char *e = ENV(TRACE); return e ? atoi(e) : 0; }
 
 static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs)
 {
@@ -424,11 +498,11 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	uint8_t *pk_ok = 0, *solo_ok = 0;
 	/* KSW2AMD_SOLO: unset = alignments without a partner of identical shape take the solo kernel when there are enough of them
 	 * to keep four wavefronts on every SIMD, 1 = always, all = every eligible alignment (tests), 0 = never */
-	const char *solo_env = getenv("KSW2AMD_SOLO");
+	const char *solo_env = ENV(SOLO);
 	const int solo_mode = !solo_env ? 3 : !strcmp(solo_env, "0") ? 0 : !strcmp(solo_env, "all") ? 2 : 1;
-	const int use_pk = !getenv("KSW2AMD_NO_PK"), use_rb = !getenv("KSW2AMD_NO_RB");
-	const int use_pkmp = !getenv("KSW2AMD_NO_PKMP");                          /* A/B runs and tests: wide bands through the int32 generation-serial kernels */
-	const int pk_first = getenv("KSW2AMD_PK_FIRST") ? atoi(getenv("KSW2AMD_PK_FIRST")) : 0;   /* A/B runs: skip the smaller packed geometries */
+	const int use_pk = !ENV(NO_PK), use_rb = !ENV(NO_RB);
+	const int use_pkmp = !ENV(NO_PKMP);                          /* A/B runs and tests: wide bands through the int32 generation-serial kernels */
+	const int pk_first = ENV(PK_FIRST) ? atoi(ENV(PK_FIRST)) : 0;   /* A/B runs: skip the smaller packed geometries */
 
 	if (tlev) tph[0] = now_ms();
 	g_err[0] = 0;
@@ -544,7 +618,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	 * one-alignment-per-wavefront geometry that is slower than the int32 kernel (tools/scripts/ragged_probe.py: 10 k reads of
 	 * unique lengths, CIGAR: 707 vs 825 GCUPS) and writes twice the direction bytes, so the odd one of every shape goes back.
 	 * Parity of every (class, shape) key in one pass over an open-addressing table. */
-	if (n > 0 && !getenv("KSW2AMD_KEEP_LEFTOVERS")) {
+	if (n > 0 && !ENV(KEEP_LEFTOVERS)) {
 		size_t cap = 16, h;
 		struct slot { uint64_t k1, k2; int32_t last, odd; } *tab;
 		int any = 0;
@@ -574,7 +648,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	 * packed candidates of a one-alignment-per-wavefront class go back to the int32 kernels (KSW2AMD_SIMDS overrides the
 	 * device's SIMD count, 0 = off). */
 	{
-		const char *ev = getenv("KSW2AMD_SIMDS");
+		const char *ev = ENV(SIMDS);
 		const int simds = ev ? atoi(ev) : k2a_shim_simd_count();
 		if (simds > 0) {
 			int cnt[NCLS_MAX * NPASS], b;
@@ -596,7 +670,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	 * ahead only with enough wavefronts per SIMD to hide that (tools/scripts/ragged_probe.py, 10 k reads of unique lengths,
 	 * score only: 2048 reads 1212 vs 1422 GCUPS, 6144 reads 2077 vs 1822).  Below four per SIMD they go back to int32. */
 	if (solo_mode == 3) {
-		const char *ev = getenv("KSW2AMD_SIMDS");
+		const char *ev = ENV(SIMDS);
 		const int simds = ev ? atoi(ev) : k2a_shim_simd_count();
 		int cnt[NCLS_MAX];
 		memset(cnt, 0, sizeof(cnt));
@@ -764,7 +838,7 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 	p->stream = stream; p->ran = 1; p->stream_used = 1;
 	if (p->reject_all || p->ntasks == 0) return KSW2AMD_OK;
 	if (k2a_shim_event_record(p->ev[0], stream)) goto err;
-	if (p->ncls > 1 && !getenv("KSW2AMD_SERIAL") && side_streams() == 0) {
+	if (p->ncls > 1 && !ENV(SERIAL) && side_streams() == 0) {
 		/* several classes: fork them over the caller's stream and the side streams (fill, then that class's traceback, in
 		 * stream order), join on the caller's stream.  The fill / traceback split of plan_timing is then meaningless:
 		 * both report the whole run (KSW2AMD_SERIAL=1 restores the two-phase order for profiling). */
@@ -853,6 +927,25 @@ int64_t ksw2amd_plan_packed_pairs(const ksw2amd_plan_t *p)
 				n += p->h_order[p->cls[c].first + 2 * i] == p->h_order[p->cls[c].first + 2 * i + 1] ? 1 : 2;
 		else if (p->cls[c].solo) n += p->cls[c].count;
 	return n;
+}
+/* one line per kernel class of an extz / extd plan, as the next ksw2amd_plan_run would launch it */
+int ksw2amd_plan_describe(const ksw2amd_plan_t *p, char *buf, int cap)
+{
+	static const char *const mode_name[3] = { "score", "left", "right" }, *const form_name[3] = { "registers", "ldsrows", "ldscodes" };
+	int c, len = 0;
+	if (!p || !buf || cap <= 0) return 0;
+	buf[0] = 0;
+	if (p->splice || p->reject_all) return 0;
+	for (c = 0; c < p->ncls && len < cap - 1; ++c) {
+		const cls_t *k = &p->cls[c];
+		const char *kind = k->solo ? "solo" : k->pk ? (k->cfg == K2A_PKCFG_MP ? "pkmp" : "pk") : (k->cfg == K2A_CFG_MP ? "mp" : "int32");
+		const int G = k->solo ? 64 : k->pk ? k2a_pkcfg_G[k->cfg] : k2a_cfg_G[k->cfg], C = k->solo ? 2 * K2A_SOLO_C : k->pk ? k2a_pkcfg_C[k->cfg] : k2a_cfg_C[k->cfg];
+		const int form = k->solo ? 0 : k->pk ? (k->cfg == K2A_PKCFG_MP ? 0 : k2a_shim_pk_form(k->cfg, p->dual, k->mode, k->nomax, k->count))
+		                                     : (k->cfg == K2A_CFG_MP ? k2a_shim_mp_form(p->dual, k->mode, k->count) : 0);
+		len += snprintf(buf + len, (size_t)(cap - len), "kernel=%s G=%d C=%d gaps=%d mode=%s rebased=%d nomax=%d generic=%d form=%s tasks=%d\n",
+		                kind, G, C, p->dual ? 2 : 1, mode_name[k->mode], k->rb, k->nomax, k->generic, form_name[form], k->count);
+	}
+	return p->ncls;
 }
 int64_t ksw2amd_plan_device_bytes(const ksw2amd_plan_t *p)
 {
@@ -1038,7 +1131,7 @@ static int unit_pairs(const ksw2amd_pair_t *a);
 static int run_serial(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez, int share)
 {
 	size_t budget, free_b = 0, total_b = 0, acc;
-	const char *env = getenv("KSW2AMD_MAX_BYTES");
+	const char *env = ENV(MAX_BYTES);
 	int beg = 0, end, unit;
 	double t0;
 	if (n <= 0) return KSW2AMD_OK;
@@ -1176,7 +1269,7 @@ static void *pool_worker(void *arg_)
 
 static int pool_threads_per_device(void)
 {
-	const char *e = getenv("KSW2AMD_THREADS");
+	const char *e = ENV(THREADS);
 	int t = e ? atoi(e) : 6;
 	return t < 0 ? 0 : t > 16 ? 16 : t;
 }
@@ -1249,7 +1342,6 @@ void ksw2amd_release_cache(void)
 	}
 }
 
-static int env_flag(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) != 0 : dflt; }
 /* cut [0, n) into at most `nchunks` (+ 2 * workers) chunks of consecutive pairs; cost[i] >= 1.  With enough chunks the first
  * ones are small (the device gets its first kernels after a quarter of a chunk's packing time, not a whole one) and so are the
  * last ones (the results of the final chunks come back quickly): weights 1/4, 1/2, 1 ... 1, 1/2.  Returns the chunk count, cbeg[0..count] */
@@ -1261,7 +1353,7 @@ static int make_chunks(int n, const double *cost, double total, int nchunks, int
 		cbeg[c] = n;
 		return c;
 	}
-	const int ramp = nchunks >= 3 * workers && workers > 0 && env_flag("KSW2AMD_RAMP", 0), nc = ramp ? nchunks + 2 * workers : nchunks;
+	const int ramp = nchunks >= 3 * workers && workers > 0 && env_flag(ENV(RAMP), 0), nc = ramp ? nchunks + 2 * workers : nchunks;
 	double wsum = 0, acc = 0, edge = 0;
 	int i, c = 0;
 	for (i = 0; i < nc; ++i) wsum += !ramp ? 1.0 : i < workers ? 0.25 : (i < 2 * workers || i >= nc - workers) ? 0.5 : 1.0;
@@ -1301,7 +1393,7 @@ static int parallel_copy(copy_ctx_t *c, int n, size_t bytes)
 	const int tpd = pool_threads_per_device();
 	job_t j;
 	int cbeg[POOL_MAXW + 2], k, i, nch;
-	if (g_is_worker || tpd < 2 || n < 2 * tpd || bytes < ((size_t)32 << 20) || getenv("KSW2AMD_NO_PARCOPY")) return 0;
+	if (g_is_worker || tpd < 2 || n < 2 * tpd || bytes < ((size_t)32 << 20) || ENV(NO_PARCOPY)) return 0;
 	nch = imin(tpd, POOL_MAXW);
 	for (k = 0, i = 0; k < nch; ++k) {                     /* equal byte ranges of the arena (the pairs lie in it in order) */
 		const size_t edge = bytes / (size_t)nch * (size_t)k;
@@ -1320,16 +1412,15 @@ static int parallel_copy(copy_ctx_t *c, int n, size_t bytes)
 
 static int pool_min_pairs(void)
 {
-	const char *e = getenv("KSW2AMD_POOL_MIN");           /* tests: pool batches of this many pairs or more, whatever their size */
+	const char *e = ENV(POOL_MIN);           /* tests: pool batches of this many pairs or more, whatever their size */
 	return e && atoi(e) > 0 ? atoi(e) : 0;
 }
 
 /* critical path of a fill (seconds) from which a batch counts as "long alignments" in plan_chunks; KSW2AMD_LONG_MS overrides */
 static double long_path_s(void)
 {
-	static double v = -1;
-	if (v < 0) { const char *e = getenv("KSW2AMD_LONG_MS"); v = e && atof(e) > 0 ? atof(e) * 1e-3 : 0.010; }
-	return v;
+	const char *e = ENV(LONG_MS);
+	return e && atof(e) > 0 ? atof(e) * 1e-3 : 0.010;
 }
 
 /* pairs that put one wavefront on every SIMD, for a batch of this pair's shape: the first packed geometry that holds the band
@@ -1356,7 +1447,7 @@ static int unit_pairs(const ksw2amd_pair_t *a)
  * at most two chunks per worker.  Returns the chunk count (0 = one plan on the calling thread) and the chunk size. */
 static int uniform_chunks(int n, int unit, double bytes, double cells, int workers, int ndev, int with_cigar, double path_steps, int *chunk_pairs)
 {
-	const char *e1 = getenv("KSW2AMD_CHUNK_MB");
+	const char *e1 = ENV(CHUNK_MB);
 	const double cap_b = (e1 && atof(e1) > 0 ? atof(e1) : 128.0) * 1048576.0;
 	const double path_s = path_steps * (with_cigar ? 4.5e-6 : 2.5e-6);
 	double cu = with_cigar ? 1.0 : path_s >= long_path_s() ? 2.0 : 0.5, kmax = 2.0 * workers;
@@ -1373,7 +1464,7 @@ static int uniform_chunks(int n, int unit, double bytes, double cells, int worke
 
 static int plan_chunks(int n, double bytes, double cells, int workers, int ndev, int with_cigar, double path_steps)
 {
-	const char *e1 = getenv("KSW2AMD_CHUNK_MB"), *e2 = getenv("KSW2AMD_CHUNK_GCELLS");
+	const char *e1 = ENV(CHUNK_MB), *e2 = ENV(CHUNK_GCELLS);
 	const double cap_b = (e1 && atof(e1) > 0 ? atof(e1) : 128.0) * 1048576.0, cap_c = (e2 && atof(e2) > 0 ? atof(e2) : 40.0) * 1e9;
 	const int forced = pool_min_pairs(), min_chunk = forced ? imax(forced / 4, 1) : 256;
 	double k;
@@ -1416,14 +1507,14 @@ static int plan_chunks(int n, double bytes, double cells, int workers, int ndev,
 		else if (k > (with_cigar ? 2 : 1) * workers && bytes / cap_b <= (with_cigar ? 2 : 1) * workers) k = (with_cigar ? 2 : 1) * workers;
 	}
 	if (ndev > 1 && k < 3 * workers) k = 3 * workers;      /* several devices: finer grains balance them */
-	{ const char *e3 = getenv("KSW2AMD_CHUNKS"); if (e3 && atoi(e3) > 0) k = atoi(e3); }      /* experiments: this many chunks, whatever the batch */
+	{ const char *e3 = ENV(CHUNKS); if (e3 && atoi(e3) > 0) k = atoi(e3); }      /* experiments: this many chunks, whatever the batch */
 	if (k > n / min_chunk) k = n / min_chunk;
 	return k < 2 ? 0 : (int)(k + 0.999);
 }
 
 typedef struct { int dual, scalar, dbuf; void *km; const ksw2amd_scoring_t *sc; const ksw2amd_pair_t *pairs; ksw_extz_t *ez; } ext_ctx_t;
 static double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
-static int trace_on(void) { static int t = -1; if (t < 0) t = getenv("KSW2AMD_TRACE") != 0; return t; }
+static int trace_on(void) { return ENV(TRACE) != 0; }
 
 static int ext_finish(ext_ctx_t *c, pend_t *pd)
 {
@@ -1450,7 +1541,7 @@ static int ext_chunk(void *ctx_, int beg, int end, int share, pend_t *pd)
 {
 	ext_ctx_t *c = (ext_ctx_t*)ctx_;
 	size_t bytes = 0, free_b = 0, total_b = 0, budget = (size_t)1 << 30;
-	const char *env = getenv("KSW2AMD_MAX_BYTES");
+	const char *env = ENV(MAX_BYTES);
 	ksw2amd_plan_t *p;
 	double t0, t1;
 	int i, rc, rc2;
@@ -1540,7 +1631,7 @@ static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc
 				total += cost[i];
 			}
 			{
-				const int unit = uniform && !pool_min_pairs() && !getenv("KSW2AMD_CHUNKS") && !getenv("KSW2AMD_NO_UNITS") ? unit_pairs(&pairs[0]) : 0;
+				const int unit = uniform && !pool_min_pairs() && !ENV(CHUNKS) && !ENV(NO_UNITS) ? unit_pairs(&pairs[0]) : 0;
 				if (unit > 0) nchunks = uniform_chunks(n, unit, bytes, cells, workers, g_ndev_set, !(pairs[0].flag & KSW_EZ_SCORE_ONLY), path, &chunk_pairs);
 				else nchunks = plan_chunks(n, bytes, cells, workers, g_ndev_set, !(pairs[0].flag & KSW_EZ_SCORE_ONLY), path);
 			}
@@ -1548,7 +1639,7 @@ static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc
 				ext_ctx_t ctx;
 				ctx.dual = dual; ctx.scalar = scalar; ctx.km = km; ctx.sc = sc; ctx.pairs = pairs; ctx.ez = ez;
 				{	/* double-buffering is opt-in (see ext_chunk) */
-					const char *ev = getenv("KSW2AMD_DBUF");
+					const char *ev = ENV(DBUF);
 					ctx.dbuf = ev && *ev ? atoi(ev) != 0 : 0;
 				}
 				if (run_pooled(ext_chunk, &ctx, n, cost, total, nchunks, chunk_pairs, &rc)) { free(cost); return rc; }
@@ -1772,9 +1863,9 @@ static void coal_process(creq_t *list)
 /* 1 = handled (result or failure delivered), 0 = coalescing is off: the caller runs the pair itself */
 static int queue_one(const char *fn, int dual, void *km, const ksw2amd_scoring_t *sc, const ksw2amd_pair_t *pr, ksw_extz_t *ez)
 {
-	static int slots = -1;
 	creq_t me;
-	if (slots < 0) { const char *e = getenv("KSW2AMD_COALESCE_SLOTS"); slots = e ? atoi(e) : 4; if (slots < 0) slots = 0; }
+	const char *se = ENV(COALESCE_SLOTS);
+	const int slots = se ? imax(atoi(se), 0) : 4;
 	if (slots == 0 || g_is_worker) return 0;
 	memset(&me, 0, sizeof(me));
 	me.dual = dual; me.sc = sc; me.pr = pr; me.km = km; me.ez = ez;
@@ -1870,8 +1961,8 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 		/* register windows wherever the diagonal fits one: faster than the HBM-state kernel in every mode
 		 * (tools/scripts/exts_classes.py) */
 		wn = imin(a->qlen, a->tlen) <= K2A_DM_DIAG(K2A_DM_SLOTS_S) ? 0 : imin(a->qlen, a->tlen) <= K2A_DM_DIAG(K2A_DM_SLOTS) ? 1 : 2;
-		if (getenv("KSW2AMD_EXTS_BIG")) wn = 2;        /* tests: every pair through the HBM-state kernel */
-		else if (getenv("KSW2AMD_EXTS_REG") && imin(a->qlen, a->tlen) <= K2A_DM_DIAG(K2A_DM_SLOTS)) wn = imin(wn, 1);   /* tests: 16 slots with traceback */
+		if (ENV(EXTS_BIG)) wn = 2;        /* tests: every pair through the HBM-state kernel */
+		else if (ENV(EXTS_REG) && imin(a->qlen, a->tlen) <= K2A_DM_DIAG(K2A_DM_SLOTS)) wn = imin(wn, 1);   /* tests: 16 slots with traceback */
 		if (wn == 2) {                                 /* 9 ints of state per target position, 16-byte granules */
 			d->pad = (uint32_t)(p->bnd_words / 4);
 			p->bnd_words += align_up(9 * (size_t)a->tlen, 4);
@@ -1988,7 +2079,7 @@ static int exts_serial(void *km, const ksw2amd_splice_t *sc, int n, const ksw2am
 {
 	int beg = 0;
 	size_t budget, free_b = 0, total_b = 0;
-	const char *env = getenv("KSW2AMD_MAX_BYTES");
+	const char *env = ENV(MAX_BYTES);
 	if (n <= 0) return KSW2AMD_OK;
 	if (k2a_shim_device_count() <= 0) return fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend());
 	if (env && atoll(env) > 0) budget = (size_t)atoll(env);
@@ -2032,12 +2123,12 @@ static int exts_serial(void *km, const ksw2amd_splice_t *sc, int n, const ksw2am
  * multiples of a device fill (one wavefront per SIMD) like the extz / extd batches (uniform_chunks) */
 static int wave_chunks(int n, int workers, int uniform, int *chunk_pairs)
 {
-	const char *e3 = getenv("KSW2AMD_CHUNKS");
+	const char *e3 = ENV(CHUNKS);
 	const int simds = k2a_shim_simd_count();
 	int k = imin(workers, n / 256);
 	if (e3 && atoi(e3) > 0) k = atoi(e3);
 	*chunk_pairs = 0;
-	if (uniform && simds > 0 && k >= 2 && n >= 2 * simds && !getenv("KSW2AMD_NO_UNITS")) {
+	if (uniform && simds > 0 && k >= 2 && n >= 2 * simds && !ENV(NO_UNITS)) {
 		int cp = (n + k - 1) / k;
 		cp = (cp + simds - 1) / simds * simds;
 		*chunk_pairs = cp;
@@ -2130,7 +2221,7 @@ ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n
 		/* measured (profiles/r2_extf_lane.txt): the lane form reaches ~600 GCUPS from 4 wavefronts per SIMD (262 144 extensions) and
 		 * scales down linearly below 131 072; the position-per-lane forms do 180 / 460 / 760 GCUPS at 30 / 100 / 300 positions in
 		 * the band whatever the batch size.  Take the lane form where it is ahead by 15 %. */
-		const char *ev = getenv("KSW2AMD_EXTF_LANE");
+		const char *ev = ENV(EXTF_LANE);
 		double span_sum = 0, lane_rate, wave_rate;
 		int nv = 0;
 		for (i = 0; i < n; ++i)
@@ -2142,7 +2233,7 @@ ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n
 		wave_rate = nv ? 60.0 + 4.0 * span_sum / nv : 0.0;
 		if (wave_rate > 760.0) wave_rate = 760.0;
 		use_lane = ev && *ev ? atoi(ev) != 0 : lane_rate > 1.15 * wave_rate;
-		if (getenv("KSW2AMD_EXTF_LDS") || getenv("KSW2AMD_EXTF_WIN") || getenv("KSW2AMD_EXTF_HBM")) use_lane = ev && *ev ? atoi(ev) != 0 : 0;
+		if (ENV(EXTF_LDS) || ENV(EXTF_WIN) || ENV(EXTF_HBM)) use_lane = ev && *ev ? atoi(ev) != 0 : 0;
 	}
 	for (i = 0; i < n; ++i) {
 		const ksw2amd_fpair_t *a = &pairs[i];
@@ -2158,9 +2249,9 @@ ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n
 		span = imin(imin(a->qlen, a->tlen), d->w < 0x7ffffff0 ? d->w + 1 : d->w);
 		/* (tools/scripts/extf_classes.py: equal to the LDS form up to ~128 positions on short targets -- both are bound by
 		 * the per-anti-diagonal bookkeeping -- and 1.5-1.8 x faster on wider bands and wherever the LDS form needs 12 KiB or more) */
-		if (!getenv("KSW2AMD_EXTF_LDS") && (span > 128 || c > 0)) c = span <= K2A_EXTF_WIN_SPAN(4) ? 4 : span <= K2A_EXTF_WIN_SPAN(8) ? 5 : c;
-		if (getenv("KSW2AMD_EXTF_WIN")) c = span <= K2A_EXTF_WIN_SPAN(4) ? 4 : span <= K2A_EXTF_WIN_SPAN(8) ? 5 : c;   /* tests: the window wherever it fits */
-		if (getenv("KSW2AMD_EXTF_HBM")) c = 3;            /* tests: every pair through the HBM-state kernel */
+		if (!ENV(EXTF_LDS) && (span > 128 || c > 0)) c = span <= K2A_EXTF_WIN_SPAN(4) ? 4 : span <= K2A_EXTF_WIN_SPAN(8) ? 5 : c;
+		if (ENV(EXTF_WIN)) c = span <= K2A_EXTF_WIN_SPAN(4) ? 4 : span <= K2A_EXTF_WIN_SPAN(8) ? 5 : c;   /* tests: the window wherever it fits */
+		if (ENV(EXTF_HBM)) c = 3;            /* tests: every pair through the HBM-state kernel */
 		p->cells += band_cells(a->qlen, a->tlen, d->w);
 		if (use_lane) { p->h_cls[i] = 6; ++p->f_count[6]; ++nlane; continue; }          /* sequences and state: grouped below */
 		if (c == 3) { d->tb_off = p->tb_bytes; p->tb_bytes += align_up(3 * align_up((size_t)a->tlen, 16), 256); }
@@ -2279,8 +2370,8 @@ void ksw2amd_set_sse_compat(int on) { g_sse_compat = on ? 1 : 0; }
 static int wants_ssec(int flag)
 {
 	static int drop_exact = -1;
-	if (g_sse_compat < 0) g_sse_compat = env_flag("KSW2AMD_SSE_COMPAT", 0);
-	if (drop_exact < 0) drop_exact = env_flag("KSW2AMD_APPROX_DROP_EXACT", 0);
+	if (g_sse_compat < 0) g_sse_compat = env_flag(ENV(SSE_COMPAT), 0);
+	if (drop_exact < 0) drop_exact = env_flag(ENV(APPROX_DROP_EXACT), 0);
 	if (g_sse_compat || (flag & KSW2AMD_EZ_SSE_COMPAT)) return 1;
 	return (flag & KSW_EZ_APPROX_MAX) && (flag & KSW_EZ_APPROX_DROP) && !drop_exact;
 }
@@ -2352,7 +2443,7 @@ ksw2amd_plan_t *ksw2amd_sse_plan_create(int dual, const ksw2amd_scoring_t *sc, i
 		mode = (fl & KSW_EZ_SCORE_ONLY) ? K2A_MODE_SCORE : (fl & KSW_EZ_RIGHT) ? K2A_MODE_RIGHT : K2A_MODE_LEFT;
 		{	/* state arrays of up to SSEC_LDS_MAX bytes live in LDS (k2a_ssec_kernel<.., LDS = true>); KSW2AMD_SSEC_HBM=1: never (tests) */
 			const size_t sb = (size_t)(dual ? 11 : 9) * (size_t)((a->tlen + 15) / 16 * 16);
-			const int lds = sb <= SSEC_LDS_MAX && !getenv("KSW2AMD_SSEC_HBM");
+			const int lds = sb <= SSEC_LDS_MAX && !ENV(SSEC_HBM);
 			p->h_cls[i] = (int8_t)(mode + 3 * lds);
 			++p->s_count[mode][0][lds];
 			if (lds && sb > p->c_lds[mode]) p->c_lds[mode] = sb;
@@ -2455,7 +2546,7 @@ static int ssec_run(int dual, void *km, const ksw2amd_scoring_t *sc, int n, cons
 {
 	int beg = 0;
 	size_t budget, free_b = 0, total_b = 0;
-	const char *env = getenv("KSW2AMD_MAX_BYTES");
+	const char *env = ENV(MAX_BYTES);
 	if (n <= 0) return KSW2AMD_OK;
 	if (k2a_shim_device_count() <= 0) return fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend());
 	if (env && atoll(env) > 0) budget = (size_t)atoll(env);

@@ -38,6 +38,14 @@ int   k2a_shim_set_device(int dev);
 int   k2a_shim_get_device(void);             /* device of the calling thread; -1 = none */
 int   k2a_shim_mem_info(size_t *free_b, size_t *total_b);
 
+/* launch-time kernel forms: every choice the launcher makes can be forced (-1 = automatic, 0 / 1) and is reported */
+#define K2A_OPT_LDSCODES 0     /* exact score-only packed (64,16) kernels: target-code planes in LDS */
+#define K2A_OPT_LDSROWS  1     /* two-piece traceback packed (64,16) and int32 generation-serial traceback kernels: row state in LDS */
+#define K2A_NOPT 2
+void  k2a_shim_set_option(int opt, int value);
+int   k2a_shim_pk_form(int cfg, int dual, int mode, int nomax, int ntasks);   /* what k2a_shim_launch_fill_pk takes: 0 registers, 1 row state in LDS, 2 code planes in LDS */
+int   k2a_shim_mp_form(int dual, int mode, int ntasks);                        /* k2a_shim_launch_fill, class K2A_CFG_MP: 1 = row state in LDS */
+
 void *k2a_shim_malloc(size_t bytes);               /* device memory */
 void  k2a_shim_free(void *p);
 void *k2a_shim_host_malloc(size_t bytes);          /* pinned host staging */

@@ -1403,21 +1403,25 @@ static const fill_pk_fn g_fill_pk_lds[2][2] = {
 /* exact score-only kernels of the 16-row geometry with the code planes in LDS (three wavefronts per SIMD): [rebased] */
 static const fill_pk_fn g_fill_pk_ldscodes[2][2] = { { k2a_fill_pk_kernel<64, 16, false, 0, false, false, 2>, k2a_fill_pk_kernel<64, 16, false, 0, true, false, 2> },
                                                      { k2a_fill_pk_kernel<64, 16, false, 0, false, true, 2>,  k2a_fill_pk_kernel<64, 16, false, 0, true, true, 2> } };      /* [nomax][rebased] */
-/* worth it once SIMDs would hold a third wavefront; KSW2AMD_LDSCODES=0 / 1 forces the choice */
+/* Launch-time kernel forms.  Every choice the launcher makes has a forcing switch (k2a_shim_set_option: -1 automatic, 0 / 1
+ * forced; the host maps KSW2AMD_LDSCODES / KSW2AMD_LDSROWS onto it) and is reported by k2a_shim_pk_form / k2a_shim_mp_form, so
+ * that tests can pin each form against the oracle and check which one an unforced launch took. */
+static int g_opt[K2A_NOPT] = { -1, -1 };
+
+/* code planes in LDS: worth it once SIMDs would hold a third wavefront (a pooled batch launches chunks of two wavefronts
+ * per SIMD side by side) */
 static bool k2a_use_ldscodes(int waves)
 {
-	const char *ev = getenv("KSW2AMD_LDSCODES");
-	if (ev) return atoi(ev) != 0;
-	return 2 * (long)waves >= 3 * (long)k2a_shim_simd_count();      /* a pooled batch launches chunks of two wavefronts per SIMD side by side */
+	if (g_opt[K2A_OPT_LDSCODES] >= 0) return g_opt[K2A_OPT_LDSCODES] != 0;
+	return 2 * (long)waves >= 3 * (long)k2a_shim_simd_count();
 }
 
 /* Row state in LDS (two wavefronts per SIMD) or in registers (one): the LDS form wins as soon as SIMDs hold two
  * wavefronts, the register form when they hold one (measured: config 5, 8 per SIMD, 836 -> 1035 GCUPS; config 4, one per
- * SIMD, 757 -> 640).  KSW2AMD_LDSROWS=0 / 1 forces the choice. */
+ * SIMD, 757 -> 640). */
 static bool k2a_use_ldsrows(int waves)
 {
-	const char *ev = getenv("KSW2AMD_LDSROWS");
-	if (ev) return atoi(ev) != 0;
+	if (g_opt[K2A_OPT_LDSROWS] >= 0) return g_opt[K2A_OPT_LDSROWS] != 0;
 	return 2 * (long)waves >= 3 * (long)k2a_shim_simd_count();
 }
 #define TRACE_PK_ROW(D) { k2a_trace_pk_kernel<8, 18, D>, k2a_trace_pk_kernel<16, 8, D>, k2a_trace_pk_kernel<64, 8, D>, k2a_trace_pk_kernel<64, 16, D>, \
@@ -1428,6 +1432,18 @@ static const trace_fn g_trace_pk[2][K2A_NPKCFG] = { TRACE_PK_ROW(false), TRACE_P
 extern "C" {
 
 const char *k2a_shim_backend(void) { return "hip:gfx950"; }
+
+void k2a_shim_set_option(int opt, int value) { if (opt >= 0 && opt < K2A_NOPT) g_opt[opt] = value < 0 ? -1 : value != 0; }
+
+int k2a_shim_pk_form(int cfg, int dual, int mode, int nomax, int ntasks)
+{
+	if (cfg < 0 || cfg >= K2A_NPKCFG) return 0;
+	if (K2A_PK_LDSROWS(k2a_pkcfg_G[cfg], k2a_pkcfg_C[cfg], dual, mode, nomax) && k2a_use_ldsrows(ntasks)) return 1;
+	if (K2A_PK_LDSCODES(k2a_pkcfg_G[cfg], k2a_pkcfg_C[cfg], dual, mode, nomax) && k2a_use_ldscodes(ntasks)) return 2;
+	return 0;
+}
+
+int k2a_shim_mp_form(int dual, int mode, int ntasks) { return !dual && mode != K2A_MODE_SCORE && k2a_use_ldsrows(ntasks); }
 const char *k2a_shim_last_error(void) { return g_err; }
 
 int k2a_shim_device_count(void)
@@ -1518,7 +1534,7 @@ int k2a_shim_launch_fill(int cfg, int dual, int mode, const K2aScoring *sc, cons
 	const int per_block = K2A_WPB * (64 / k2a_cfg_G[cfg]);
 	const int blocks = (ntasks + per_block - 1) / per_block;
 	if (cfg == K2A_CFG_MP)
-		hipLaunchKernelGGL((!dual && mode != K2A_MODE_SCORE && k2a_use_ldsrows(ntasks)) ? g_fill_mp_lds[mode - 1] : g_fill_mp[dual ? 1 : 0][mode],
+		hipLaunchKernelGGL(k2a_shim_mp_form(dual, mode, ntasks) ? g_fill_mp_lds[mode - 1] : g_fill_mp[dual ? 1 : 0][mode],
 		                   dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream, *sc, pairs, order, ntasks, seq, tb, bnd, res);
 	else
 		hipLaunchKernelGGL(g_fill[cfg][dual ? 1 : 0][mode], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
@@ -1546,8 +1562,8 @@ int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax,
 	if (cfg < 0 || cfg >= K2A_NPKCFG || mode < 0 || mode > 2) { snprintf(g_err, sizeof(g_err), "bad packed kernel class"); return -1; }
 	const int per_block = K2A_WPB * (64 / k2a_pkcfg_G[cfg]);
 	const int blocks = (ntasks + per_block - 1) / per_block;
-	const bool lds = K2A_PK_LDSROWS(k2a_pkcfg_G[cfg], k2a_pkcfg_C[cfg], dual, mode, nomax) && k2a_use_ldsrows(ntasks);
-	const bool ldc = K2A_PK_LDSCODES(k2a_pkcfg_G[cfg], k2a_pkcfg_C[cfg], dual, mode, nomax) && k2a_use_ldscodes(ntasks);
+	const int form = k2a_shim_pk_form(cfg, dual, mode, nomax, ntasks);
+	const bool lds = form == 1, ldc = form == 2;
 	hipLaunchKernelGGL(lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1] : ldc ? g_fill_pk_ldscodes[nomax ? 1 : 0][rebased ? 1 : 0] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
 	                   *sc, pairs, order2, ntasks, seq, tb, res);
 	CHECK(hipGetLastError());

@@ -356,10 +356,20 @@ static const fill_pk_fn g_fill_pk_lds[2][2] = {
 	{ sim_fill_pk<64, 16, true, 1, true, false, 1>,  sim_fill_pk<64, 16, true, 2, true, false, 1> } };
 static const fill_pk_fn g_fill_pk_ldscodes[2][2] = { { sim_fill_pk<64, 16, false, 0, false, false, 2>, sim_fill_pk<64, 16, false, 0, true, false, 2> },
                                                      { sim_fill_pk<64, 16, false, 0, false, true, 2>,  sim_fill_pk<64, 16, false, 0, true, true, 2> } };      /* [nomax][rebased] */
-/* the code planes in LDS (exact score-only kernel of the 16-row geometry): taken unless KSW2AMD_LDSCODES=0 */
-static bool sim_use_ldscodes(void) { const char *ev = getenv("KSW2AMD_LDSCODES"); return !ev || atoi(ev) != 0; }
-/* the simulator takes the LDS form of the row state unless KSW2AMD_LDSROWS=0 (the GPU launcher decides by the number of tasks) */
-static bool sim_use_ldsrows(void) { const char *ev = getenv("KSW2AMD_LDSROWS"); return !ev || atoi(ev) != 0; }
+/* launch-time forms (ksw2_shim.h): the simulator takes the LDS forms unless the option says 0 (the GPU launcher decides by the
+ * number of tasks when the option is -1) */
+static int g_opt[K2A_NOPT] = { -1, -1 };
+static bool sim_use_ldscodes(void) { return g_opt[K2A_OPT_LDSCODES] != 0; }
+static bool sim_use_ldsrows(void) { return g_opt[K2A_OPT_LDSROWS] != 0; }
+void k2a_shim_set_option(int opt, int value) { if (opt >= 0 && opt < K2A_NOPT) g_opt[opt] = value < 0 ? -1 : value != 0; }
+int k2a_shim_pk_form(int cfg, int dual, int mode, int nomax, int)
+{
+	if (cfg < 0 || cfg >= K2A_NPKCFG) return 0;
+	if (K2A_PK_LDSROWS(k2a_pkcfg_G[cfg], k2a_pkcfg_C[cfg], dual, mode, nomax) && sim_use_ldsrows()) return 1;
+	if (K2A_PK_LDSCODES(k2a_pkcfg_G[cfg], k2a_pkcfg_C[cfg], dual, mode, nomax) && sim_use_ldscodes()) return 2;
+	return 0;
+}
+int k2a_shim_mp_form(int dual, int mode, int) { return !dual && mode != K2A_MODE_SCORE && sim_use_ldsrows(); }
 #define TRACE_PK_ROW(D) { sim_trace_pk<8, 18, D>, sim_trace_pk<16, 8, D>, sim_trace_pk<64, 8, D>, sim_trace_pk<64, 16, D>, sim_trace_pk<64, 16, D, true> }
 static const trace_fn g_trace_pk[2][K2A_NPKCFG] = { TRACE_PK_ROW(false), TRACE_PK_ROW(true) };
 
@@ -920,15 +930,15 @@ int k2a_shim_launch_fill(int cfg, int dual, int mode, const K2aScoring *sc, cons
                          int ntasks, const uint8_t *seq, uint8_t *tb, int32_t *bnd, K2aResult *res, void *)
 {
 	if (ntasks <= 0) return 0;
-	if (cfg == K2A_CFG_MP) ((!dual && mode != K2A_MODE_SCORE && sim_use_ldsrows()) ? g_fill_mp_lds[mode - 1] : g_fill_mp[dual ? 1 : 0][mode])(*sc, pairs, order, ntasks, seq, tb, bnd, res);
+	if (cfg == K2A_CFG_MP) (k2a_shim_mp_form(dual, mode, ntasks) ? g_fill_mp_lds[mode - 1] : g_fill_mp[dual ? 1 : 0][mode])(*sc, pairs, order, ntasks, seq, tb, bnd, res);
 	else g_fill[cfg][dual ? 1 : 0][mode](*sc, pairs, order, ntasks, seq, tb, res);
 	return 0;
 }
 int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2,
                             int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, void *)
 {
-	const bool lds = K2A_PK_LDSROWS(k2a_pkcfg_G[cfg], k2a_pkcfg_C[cfg], dual, mode, nomax) && sim_use_ldsrows();
-	const bool ldc = K2A_PK_LDSCODES(k2a_pkcfg_G[cfg], k2a_pkcfg_C[cfg], dual, mode, nomax) && sim_use_ldscodes();
+	const int form = k2a_shim_pk_form(cfg, dual, mode, nomax, ntasks);
+	const bool lds = form == 1, ldc = form == 2;
 	if (ntasks > 0) (lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1] : ldc ? g_fill_pk_ldscodes[nomax ? 1 : 0][rebased ? 1 : 0] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode])(*sc, pairs, order2, ntasks, seq, tb, res);
 	return 0;
 }

@@ -684,6 +684,46 @@ def test_row_state_in_registers_and_in_lds(lib, lds, monkeypatch):
         check_batch(lib, False, qs, ts, mat, q, e, q2, e2, w=np.array([-1, 1500, 2000, -1]), zdrop=np.array([-1, 400, -1, 1000]), flag=flag)
 
 
+@pytest.mark.parametrize("ldc", ["0", "1"])
+def test_code_planes_in_registers_and_in_lds(lib, ldc, monkeypatch):
+    """KSW2AMD_LDSCODES=0 / 1 forces the launcher's choice for the score-only packed kernels of the (64, 16) geometry: target-code
+    planes in registers / in LDS.  =1 runs k2a_fill_pk_kernel<64, 16, false, 0, RB, NOMAX, 2> -- all four g_fill_pk_ldscodes
+    entries, among them the kernel the headline benchmark times -- against the oracle: plain and re-based, exact and
+    KSW_EZ_APPROX_MAX, Z-drop on / off, shapes in pairs, triples and singles; the plan reports the form it will launch."""
+    from tests.test_sim_parity import _check_code_plane_forms
+    monkeypatch.setenv("KSW2AMD_LDSCODES", ldc)
+    for seed in (31, 32, 33):
+        _check_code_plane_forms(lib, "ldscodes" if ldc == "1" else "registers", seed=seed)
+
+
+def test_headline_kernel_at_scale_unforced(lib, monkeypatch):
+    """The headline workload's own launch, nothing forced: 3 200 pairs of 10 000 x 10 000, band 500, Z-drop 400, score only,
+    under the production occupancy rules.  The launcher must take the code-planes-in-LDS form on its own (>= 1.5 wavefronts
+    per SIMD); every 50th pair equals the oracle, and the whole batch equals the register form (KSW2AMD_LDSCODES=0) field by
+    field.  A fifth of the pairs get a random tail so that Z-drop fires."""
+    monkeypatch.delenv("KSW2AMD_SIMDS", raising=False)
+    monkeypatch.delenv("KSW2AMD_LDSCODES", raising=False)
+    n = 3200
+    q, t = synth.fast_fixed(6, n, 10000, 10000, sub=0.05, ind=0.06, tail_random_frac=0.25, tail_pairs=0.2)
+    mat = synth.simple_mat(5, 2, 4, -1)
+    b = lib.make_batch(q, t, mat, 4, 2, 24, 1, w=500, zdrop=400, flag=po.SCORE_ONLY)
+    p = b.plan(False)
+    d = p.describe()
+    assert len(d) == 1 and d[0]["kernel"] == "pk" and (d[0]["G"], d[0]["C"], d[0]["rebased"], d[0]["nomax"]) == (64, 16, 1, 0), d
+    assert d[0]["form"] == "ldscodes" and d[0]["tasks"] == n // 2, d
+    p.run(); r1 = p.fetch_raw().copy(); p.close()
+    monkeypatch.setenv("KSW2AMD_LDSCODES", "0")
+    p = b.plan(False)
+    assert p.describe()[0]["form"] == "registers"
+    p.run(); r0 = p.fetch_raw().copy(); p.close()
+    assert np.array_equal(r0, r1)
+    assert 0 < int(r1[:, 1].sum()) < n                         # some pairs Z-dropped, most did not
+    names = ["max", "zdropped", "max_q", "max_t", "mqe", "mqe_t", "mte", "mte_q", "score", "reach_end"]
+    for i in range(0, n, 50):
+        exp = po.align("oracle", "extz2", q[i], t[i], mat, 4, 2, w=500, zdrop=400, flag=po.SCORE_ONLY)
+        assert all(int(r1[i, k]) == exp[f] for k, f in enumerate(names)), (i, exp, r1[i])
+
+
 def test_automatic_kernel_choices_at_scale(lib, monkeypatch):
     """The host's and launcher's own choices, which need thousands of wavefronts to trigger: unique-shape long reads go to the
     solo kernel (>= 4 wavefronts per SIMD), a big two-piece traceback class takes the LDS row form (>= 1.5 per SIMD).

@@ -24,7 +24,8 @@ lib = ka.Library(os.environ["KSW2AMD_FUZZ_LIB"]) if os.environ.get("KSW2AMD_FUZZ
 ENVS = [{}, {"KSW2AMD_SOLO": "1"}, {"KSW2AMD_SOLO": "all"}, {"KSW2AMD_LDSROWS": "0"}, {"KSW2AMD_LDSROWS": "1"}, {"KSW2AMD_NO_PK": "1"},
         {"KSW2AMD_SIMDS": "0"}, {"KSW2AMD_EXTF_WIN": "1"}, {"KSW2AMD_EXTF_LDS": "1"}, {"KSW2AMD_EXTS_REG": "1"},
         {"KSW2AMD_POOL_MIN": "8", "KSW2AMD_THREADS": "3"}, {"KSW2AMD_POOL_MIN": "4", "KSW2AMD_SIMDS": "0"}, {"KSW2AMD_NO_PKMP": "1"},
-        {"KSW2AMD_SIMDS": "0", "KSW2AMD_KEEP_LEFTOVERS": "1"}]
+        {"KSW2AMD_SIMDS": "0", "KSW2AMD_KEEP_LEFTOVERS": "1"}, {"KSW2AMD_LDSCODES": "0", "KSW2AMD_SIMDS": "0"}, {"KSW2AMD_LDSCODES": "1", "KSW2AMD_SIMDS": "0"},
+        {"KSW2AMD_LDSCODES": "1", "KSW2AMD_LDSROWS": "1"}]
 KEYS = sorted({k for e in ENVS for k in e})
 t0 = time.time()
 rounds = pairs = 0
