@@ -397,7 +397,7 @@ static void pk_scoring(int dual, int m, const int8_t *mat, int q, int e, int q2,
 	o->ok = ok;
 }
 
-/* ... and every in-band H, E, F must provably stay inside (-16384 + qemax, 16383 - qemax):
+/* ... and every in-band H, E, F must provably stay inside (K2A_NEG16 + qemax, K2A_PK_VMAX - qemax) = (-16384 + qemax, 12287 - qemax):
  *   H(i,j) <= smax * min(qlen, tlen);   H(i,j) >= Hb(|i-j|) + (min(i,j)+1) * smin >= -(q + e*w) + min(qlen,tlen) * min(smin,0)
  * (gap along the border, then the diagonal: a path that stays inside the band). */
 static int pk_eligible(const pkinfo_t *k, int qlen, int tlen, int w)
@@ -407,7 +407,7 @@ static int pk_eligible(const pkinfo_t *k, int qlen, int tlen, int w)
 	if (k->ok <= 0 || qlen > 32000 || tlen > 32000) return 0;   /* (the score bound below is far tighter) */
 	hmax = (int64_t)imax(k->smax, 0) * L + (int64_t)k->e * tlen;     /* + row bias e*i carried by the packed kernels */
 	hmin = -((int64_t)k->q + (int64_t)k->e * (w + 1)) + (int64_t)imin(k->smin, 0) * L;
-	return hmax < 16383 - 2 * k->qemax - 8 && hmin > -16384 + 2 * k->qemax + 8;
+	return hmax < K2A_PK_VMAX - 2 * k->qemax - 8 && hmin > K2A_NEG16 + 2 * k->qemax + 8;      /* the offset form's range: ksw2_types.h */
 }
 
 /* Re-based packed kernels: a strip's values are relative to the H diagonally above its first cell, so what has to fit is
@@ -420,18 +420,22 @@ static int pk_window_ok(const pkinfo_t *k, int qlen, int tlen, int w, int C)
 {
 	const int64_t D = imax(imax(k->smax, 0) + k->qemin, -k->smin) + k->e;
 	if (k->ok <= 0 || qlen > 65000 || tlen > 65000) return 0;          /* column / row indices travel as unsigned 16-bit halves */
+	/* ... and what is added to or taken from -inf before the band mask clamps it again (two base shifts, a score, a gap
+	 * cost) must stay inside the K2A_PK_SLACK units the offset form keeps below it (ksw2_types.h) */
+	if ((int64_t)4 * C * D + 2 * k->qemax + imax(k->smax, 0) + 64 > K2A_PK_SLACK) return 0;
 	return ((int64_t)2 * w + 2 * C + 2) * D + 2 * k->qemax + (int64_t)4 * C * D + 64 <= 12000;
 }
 
 /* Packed generation-serial class (ksw2_lane_pkmp.h): the base slides, so the read length does not matter; what must fit between
- * the -inf sentinel's guard band (K2A_PKMP_DEAD = -8192) and +16383 is what a lane holds at one column (C rows) plus the drift
+ * the -inf sentinel's guard band (K2A_PKMP_DEAD = -8192) and K2A_PK_VMAX is what a lane holds at one column (C rows) plus the drift
  * of K2A_PKMP_T steps until the next re-base, each unit step changing H by at most D (as in pk_window_ok), E / F up to
  * qemax + D below their H. */
 static int pk_slide_ok(const pkinfo_t *k, int qlen, int tlen)
 {
 	const int64_t D = imax(imax(k->smax, 0) + k->qemin, -k->smin) + k->e;
 	if (k->ok <= 0 || qlen > 65000 || tlen > 65000) return 0;
-	return (64 + 2 * 16 + 4) * D + 2 * k->qemax + 64 <= 6000;
+	if (K2A_PKMP_RMAX_LIMIT + (K2A_PKMP_T + 4) * D + 2 * k->qemax + 64 > K2A_PK_VMAX) return 0;      /* a row maximum between two checks */
+	return (K2A_PKMP_T + 2 * 16 + 4) * D + 2 * k->qemax + 64 <= 6000;
 }
 
 /* copy a sequence into the staging arena and report whether it holds a residue code >= 4 (the wildcard of a 5-letter

@@ -18,10 +18,16 @@
  * row handed to the next lane is shifted by the difference of the two bases (`delta`, one v_pk_add per value per step),
  * and the strip epilogue adds the base back.  Re-based launches always use the sequential epilogue.
  *
- * Number format inside the fill loop: every DP value v is held as v + 0x8000 per half ("offset" form, K2A_OFS).  Order is
- * preserved under unsigned compare (v_pk_max_u16), differences of two values are unchanged, and -- the point -- adding
- * or subtracting a small non-negative constant can then be ONE 32-bit v_add_u32 / v_sub_u32 for both halves, because the
- * low half can neither carry nor borrow while values stay inside the 16-bit window.  On gfx950 v_add_u32, v_sub_u32,
+ * Number format inside the fill loop: every DP value v is held as v + 0x4C00 per half ("offset" form, K2A_OFS), so that the
+ * whole working range -- -inf = -16384 with 3072 units of slack below it, real values up to +12287 -- maps onto the bit
+ * patterns 0x0000 .. 0x7BFF.  Order is preserved under unsigned compare (v_pk_max_u16), differences of two values are
+ * unchanged, adding or subtracting a small non-negative constant can be ONE 32-bit v_add_u32 / v_sub_u32 for both halves
+ * (the low half can neither carry nor borrow while values stay inside the window), and -- new in round 3 -- those patterns
+ * are exactly the non-negative finite IEEE halves, whose float order is their integer order: gfx950's
+ * v_pk_maximum3_f16 returns the selected operand bit for bit (denormals included; tools/probe/max3_probe.hip,
+ * profiles/r3_max3_probe.txt), so H = max(cand, E, F) is ONE instruction (5.1 cycles at four wavefronts per SIMD) instead of
+ * two v_pk_max_u16 (2 x 4.4).  A pattern outside 0x0000 .. 0x7BFF (only garbage that a band mask discards anyway) yields
+ * garbage, which the same mask discards.  On gfx950 v_add_u32, v_sub_u32,
  * v_xor_b32, v_bitop3_b32 issue a wave64 in 2 cycles, every v_pk_*_i16 (and v_bfi, v_bfe, v_max_i32) in 4
  * (tools/probe/valu_rate.hip, profiles/r1d_valu_rate.txt).  Score-only kernels also keep the target codes as two bit
  * planes pre-multiplied with D = match - mismatch, so "mismatch ? D : 0" is xor + one v_bitop3 and the diagonal
@@ -29,8 +35,8 @@
  *
  * Preconditions, checked by the host (ksw2_host.c::pk_eligible / pk_window_ok): m = 5 with a match / mismatch / wildcard score
  * structure (always true without KSW_EZ_GENERIC_SC), no wildcard code in either sequence (such pairs take the
- * int32 kernels), gap costs and match + e and match - mismatch non-negative, and every in-band H, E, F provably inside (-16384 + max(q+e, q2+e2), 16383 - max(q+e, q2+e2))
- * so that -16384 can stand for -infinity.
+ * int32 kernels), gap costs and match + e and match - mismatch non-negative, and every in-band H, E, F provably inside (-16384 + max(q+e, q2+e2), 12287 - max(q+e, q2+e2))
+ * so that -16384 can stand for -infinity (K2A_PK_VMAX = 12287 is the largest value the offset form holds, ksw2_types.h).
  */
 #ifndef KSW2_LANE_PK_H_
 #define KSW2_LANE_PK_H_
@@ -39,15 +45,15 @@
 
 #define K2A_PK_STAGE(C) (3 * (C) + 4)    /* LDS words per lane group for a strip's staged rows: H, row max, arg-max; first row, bases */
 typedef uint32_t k2a_pk;                 /* { int16 lo = alignment A, int16 hi = alignment B } */
-#define K2A_NEG16 (-16384)
-#define K2A_OFS   0x80008000u            /* offset form of the fill loop: value + 0x8000 per half */
+#define K2A_OFS   (K2A_OFS16 * 0x10001u) /* K2A_OFS16, K2A_NEG16, K2A_PK_VMAX, K2A_PK_SLACK: ksw2_types.h (the host's range checks use them) */
 
 K2A_FN k2a_pk k2a_pk2(int v) { return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16); }
 K2A_FN int k2a_pk_lo(k2a_pk v) { return (int)(int16_t)(v & 0xffffu); }
 K2A_FN int k2a_pk_hi(k2a_pk v) { return (int)(int16_t)(v >> 16); }
 K2A_FN k2a_pk k2a_pk_sel(k2a_pk m, k2a_pk a, k2a_pk b) { return (m & a) | (~m & b); }   /* v_bfi / v_bitop3 */
 K2A_FN k2a_pk k2a_pair16(uint32_t lo, uint32_t hi) { return lo | (hi << 16); }                /* two small codes -> halves */
-K2A_FN k2a_pk k2a_pku(int v) { return k2a_pk2(v) ^ K2A_OFS; }                                   /* constant in offset form */
+K2A_FN uint32_t k2a_h16(int v) { return (uint32_t)(v + K2A_OFS16) & 0xffffu; }                 /* one half in offset form */
+K2A_FN k2a_pk k2a_pku(int v) { return k2a_pk2(v + K2A_OFS16); }                                 /* constant in offset form */
 /* both halves at once with one 32-bit op: exact as long as the low half neither carries nor borrows (offset form,
  * non-negative addend); the simulator build runs the very same 32-bit arithmetic, so a violated range shows up there */
 K2A_FN k2a_pk k2a_add32(k2a_pk a, k2a_pk b) { return a + b; }
@@ -61,6 +67,12 @@ K2A_FN k2a_pk k2a_pk_sub(k2a_pk a, k2a_pk b) { return __builtin_bit_cast(k2a_pk,
 K2A_FN k2a_pk k2a_pk_max(k2a_pk a, k2a_pk b) { return __builtin_bit_cast(k2a_pk, __builtin_elementwise_max(__builtin_bit_cast(k2a_s2, a), __builtin_bit_cast(k2a_s2, b))); }
 K2A_FN k2a_pk k2a_pk_min(k2a_pk a, k2a_pk b) { return __builtin_bit_cast(k2a_pk, __builtin_elementwise_min(__builtin_bit_cast(k2a_s2, a), __builtin_bit_cast(k2a_s2, b))); }
 K2A_FN k2a_pk k2a_pk_maxu(k2a_pk a, k2a_pk b) { return __builtin_bit_cast(k2a_pk, __builtin_elementwise_max(__builtin_bit_cast(k2a_u2, a), __builtin_bit_cast(k2a_u2, b))); }
+K2A_FN k2a_pk k2a_pk_max3u(k2a_pk a, k2a_pk b, k2a_pk c)   /* per half max of three offset-form values (patterns 0 .. 0x7BFF) */
+{
+	k2a_pk d;
+	asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+	return d;
+}
 K2A_FN k2a_pk k2a_or_xor(k2a_pk a, k2a_pk b, k2a_pk c)     /* a | (b ^ c) */
 {
 	k2a_pk d;
@@ -114,6 +126,21 @@ K2A_FN k2a_pk k2a_pk_maxu(k2a_pk a, k2a_pk b)
 	const uint32_t al = a & 0xffffu, ah = a >> 16, bl = b & 0xffffu, bh = b >> 16;
 	return (al > bl ? al : bl) | ((ah > bh ? ah : bh) << 16);
 }
+/* what v_pk_maximum3_f16 computes on the patterns the kernels feed it; outside them the hardware compares them as floats
+ * (negative numbers, NaNs): the simulator returns a poison pattern instead, so that a range violation which reaches a live
+ * cell cannot go unnoticed on the CPU test tier */
+K2A_FN k2a_pk k2a_pk_max3u(k2a_pk a, k2a_pk b, k2a_pk c)
+{
+	uint32_t r = 0;
+	for (int h = 0; h < 2; ++h) {
+		const uint32_t x = (a >> (16 * h)) & 0xffffu, y = (b >> (16 * h)) & 0xffffu, z = (c >> (16 * h)) & 0xffffu;
+		uint32_t m = x > y ? x : y;
+		m = m > z ? m : z;
+		if (m > 0x7BFFu) m = 0x7BFFu - (m & 0xffu);            /* poison: a large, wrong, in-range value */
+		r |= m << (16 * h);
+	}
+	return r;
+}
 K2A_FN k2a_pk k2a_or_xor(k2a_pk a, k2a_pk b, k2a_pk c) { return a | (b ^ c); }
 K2A_FN k2a_pk k2a_pk_minu(k2a_pk a, k2a_pk b)
 {
@@ -130,6 +157,10 @@ K2A_FN uint32_t k2a_pack_dirs(k2a_pk d0, k2a_pk d1)
 	return (d0 & 0xffu) | ((d0 >> 16 & 0xffu) << 8) | ((d1 & 0xffu) << 16) | ((d1 >> 16 & 0xffu) << 24);
 }
 #endif
+
+/* plain int16 halves <-> offset form (cold code: strip prologues and epilogues) */
+K2A_FN k2a_pk k2a_ofs_on(k2a_pk plain) { return k2a_pk_add(plain, K2A_OFS); }
+K2A_FN k2a_pk k2a_ofs_off(k2a_pk ofs) { return k2a_pk_sub(ofs, K2A_OFS); }
 
 /* packed traceback: one byte per cell and alignment in the reference's own layout (ksw2.h:125-128): bits 0-2 winner
  * {0 diag, 1 E, 2 F, 3 E~, 4 F~}, 0x08/0x10/0x20/0x40 = the E/F/E~/F~ gap leaving the cell is an extension.
@@ -202,7 +233,7 @@ struct K2aLanePk {
 		Snext = gl;
 		schedule_next();
 		const k2a_pk neg = k2a_pku(K2A_NEG16);
-		hout = eout = e2out = hd0 = hu_prev = neg; qb = 0;
+		hout = eout = e2out = hd0 = hu_prev = neg; qb = 0; qwA = qwB = 0;
 		baseA = baseB = 0; delta = 0;
 		local_reset();
 #pragma unroll
@@ -253,7 +284,7 @@ struct K2aLanePk {
 		const int hcorner = k2a_border<DUAL>(sc, i0) + sc.e * (i0 - 1);   /* H(i0-1,-1), carrying the bias of row i0-1 */
 		if (RB) {
 			/* new base = the diagonal input of the strip's first cell; hu_prev is still relative to the base above */
-			const int nbA = js == 0 ? hcorner : bsA + k2a_pk_lo(hu_prev ^ K2A_OFS), nbB = js == 0 ? hcorner : bsB + k2a_pk_hi(hu_prev ^ K2A_OFS);
+			const int nbA = js == 0 ? hcorner : bsA + k2a_pk_lo(k2a_ofs_off(hu_prev)), nbB = js == 0 ? hcorner : bsB + k2a_pk_hi(k2a_ofs_off(hu_prev));
 			delta = S == 0 ? 0u : k2a_pair16((uint32_t)(bsA - nbA) & 0xffffu, (uint32_t)(bsB - nbB) & 0xffffu);
 			baseA = nbA; baseB = nbB;
 		}
@@ -262,7 +293,7 @@ struct K2aLanePk {
 			for (int c = 0; c < C; ++c) {                        /* ksw2_extz.c:43-44, ksw2_extd.c:49-52; row bias e*i */
 				const int hb = k2a_border<DUAL>(sc, i0 + c + 1) + sc.e * (i0 + c);
 				if (i0 + c <= w) {
-					hl[c] = k2a_pair16((uint32_t)(hb - baseA) & 0xffffu, (uint32_t)(hb - baseB) & 0xffffu) ^ K2A_OFS;
+					hl[c] = k2a_ofs_on(k2a_pair16((uint32_t)(hb - baseA) & 0xffffu, (uint32_t)(hb - baseB) & 0xffffu));
 					f[c] = k2a_pk_sub(hl[c], k2a_pk2(sc.q + sc.e));
 					if (DUAL) f2[c] = k2a_pk_sub(hl[c], k2a_pk2(sc.q2 + sc.e2));
 				}
@@ -280,7 +311,7 @@ struct K2aLanePk {
 	{
 		if (S == 0) {
 			const int hb = k2a_border<DUAL>(sc, k - koff + 1);
-			const k2a_pk h0 = k2a_pair16((uint32_t)(hb - baseA) & 0xffffu, (uint32_t)(hb - baseB) & 0xffffu) ^ K2A_OFS;
+			const k2a_pk h0 = k2a_ofs_on(k2a_pair16((uint32_t)(hb - baseA) & 0xffffu, (uint32_t)(hb - baseB) & 0xffffu));
 			hin = k2a_pk_sub(h0, k2a_pk2(sc.e));               /* row -1 carries bias -e, E(0,.) and E~(0,.) bias 0 */
 			ein = k2a_pk_sub(h0, k2a_pk2(sc.q + sc.e)); e2in = k2a_pk_sub(h0, k2a_pk2(sc.q2 + sc.e2));
 		}
@@ -329,8 +360,8 @@ struct K2aLanePk {
 			const k2a_pk fc = f[c];
 			k2a_pk h = cand[c], d = 0;
 			if (MODE == K2A_MODE_SCORE) {
-				h = k2a_pk_maxu(k2a_pk_maxu(h, e), fc);
-				if (DUAL) h = k2a_pk_maxu(k2a_pk_maxu(h, e2), f2[c]);
+				h = k2a_pk_max3u(h, e, fc);                    /* one v_pk_maximum3_f16: see "Number format" above */
+				if (DUAL) h = k2a_pk_max3u(h, e2, f2[c]);
 			} else if (MODE == K2A_MODE_LEFT) {            /* winner changes only on a strictly larger gap state */
 				d = k2a_pk_sign(k2a_pk_sub(h, e)) & 0x00010001u;                     h = k2a_pk_maxu(h, e);
 				d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, fc)), 0x00020002u, d);      h = k2a_pk_maxu(h, fc);
@@ -402,13 +433,40 @@ struct K2aLanePk {
 		return k2a_pair16(qa[jc], qbp[jc]);
 	}
 
+	/* The same, four steps at a time (k2a_fill_pk_kernel): qwA / qwB hold the codes of this lane's columns at the steps
+	 * kg .. kg + 3 of the current group (kg = k & ~3), one byte per step, fetched with ONE unaligned dword load per alignment
+	 * and group instead of a byte load, an address and a clamp per step; query_pick is one v_perm_b32 with a scalar selector.
+	 * A strip that starts inside a group re-loads the group under its own column offset (load_query_group from the init
+	 * branch).  Bytes of columns outside the query are garbage that only dead cells see (the arena is padded). */
+	uint32_t qwA, qwB;
+	K2A_FN void load_query_group(int kg, int koff_use, uint32_t &a, uint32_t &b) const
+	{
+		const int j = kg - koff_use;                               /* column at step kg */
+		const int jc = k2a_min(k2a_max(j, 0), qlen - 1);
+		uint32_t va, vb;
+		__builtin_memcpy(&va, qa + jc, 4); __builtin_memcpy(&vb, qbp + jc, 4);
+		if (j < 0) {                                               /* the strip's column 0 comes -j steps into the group */
+			const int sh = 8 * k2a_min(-j, 3);
+			va <<= sh; vb <<= sh;
+		}
+		a = va; b = vb;
+	}
+	K2A_FN static uint32_t query_pick(uint32_t a, uint32_t b, int kk)      /* { code A, code B } of step kg + kk */
+	{
+#if defined(__HIP_DEVICE_COMPILE__)
+		return __builtin_amdgcn_perm(b, a, 0x0c040c00u + (uint32_t)kk * 0x00010001u);
+#else
+		return k2a_pair16((a >> (8 * kk)) & 0xffu, (b >> (8 * kk)) & 0xffu);
+#endif
+	}
+
 	/* Strip epilogues.  Both forms first stage the strip's rows {H(i, last column), row max, arg-max} in an LDS row
 	 * buffer (K2A_PK_STAGE(C) words per lane group) and then walk them in a ROLLED loop: unrolled, hipcc materialises every row's
 	 * constants and unpacked halves at once and the kernel loses a wave of occupancy for code that runs once per strip. */
 	K2A_FN void stage_rows(uint32_t *rowbuf) const
 	{
 #pragma unroll
-		for (int c = 0; c < C; ++c) { rowbuf[c] = hl[c] ^ K2A_OFS; rowbuf[C + c] = rmax(c) ^ K2A_OFS; rowbuf[2 * C + c] = rmj(c); }   /* plain int16 halves */
+		for (int c = 0; c < C; ++c) { rowbuf[c] = k2a_ofs_off(hl[c]); rowbuf[C + c] = k2a_ofs_off(rmax(c)); rowbuf[2 * C + c] = rmj(c); }   /* plain int16 halves */
 		rowbuf[3 * C] = (uint32_t)i0;
 		if (RB) { rowbuf[3 * C + 1] = (uint32_t)baseA; rowbuf[3 * C + 2] = (uint32_t)baseB; }
 	}
@@ -461,10 +519,10 @@ struct K2aLanePk {
 	{
 		if (i0 + C >= tlen || i0 + C - 1 + w >= qlen - 1) return false;
 		/* rows compare without their bias: v_c = rmax[c] - e*c = H(row) + (e*i0 - base) */
-		k2a_pk m = rmax(0) ^ K2A_OFS, mn = m, arg = 0, argj = rmj(0);
+		k2a_pk m = k2a_ofs_off(rmax(0)), mn = m, arg = 0, argj = rmj(0);
 #pragma unroll
 		for (int c = 1; c < (NOMAX ? 1 : C); ++c) {
-			const k2a_pk v = k2a_pk_sub(rmax(c) ^ K2A_OFS, k2a_pk2(sc.e * c));
+			const k2a_pk v = k2a_pk_sub(rmax(c), k2a_pk2(sc.e * c + K2A_OFS16));
 			const k2a_pk gt = k2a_pk_sign(k2a_pk_sub(m, v));                        /* strictly larger: first row keeps a tie */
 			arg = k2a_pk_sel(gt, k2a_pk2(c), arg);
 			argj = k2a_pk_sel(gt, rmj(c), argj);
@@ -537,7 +595,7 @@ struct K2aLanePk {
 		if (tlen == tlen_full && last >= i0 && last < i0 + C && last + w >= qlen - 1) {
 			k2a_pk v = 0;
 #pragma unroll
-			for (int c = 0; c < C; ++c) if (i0 + c == last) v = hl[c] ^ K2A_OFS;
+			for (int c = 0; c < C; ++c) if (i0 + c == last) v = k2a_ofs_off(hl[c]);
 			bA->score = k2a_pk_lo(v) + (RB ? baseA : 0) - sc.e * last;
 			bB->score = k2a_pk_hi(v) + (RB ? baseB : 0) - sc.e * last;
 		}

@@ -26,9 +26,7 @@
 #include "ksw2_lane_pk.h"
 #include "ksw2_shim.h"
 
-#define K2A_PKMP_T    64            /* steps between re-bases (a power of two) */
-#define K2A_PKMP_DEAD (-8192)       /* relative values below this are -inf */
-#define K2A_PKMP_RMAX_LIMIT 12000   /* a window's row maximum further above the base than this is merged into its key */
+/* K2A_PKMP_T, K2A_PKMP_DEAD, K2A_PKMP_RMAX_LIMIT: ksw2_types.h (the host's range check pk_slide_ok uses them) */
 /* K2A_PKMP_WAVES, the wavefronts (generations in flight) per pair of alignments: ksw2_shim.h (the host sizes the key blocks by it) */
 #define K2A_PKMP_SPILL_WORDS(C) (64 * (C) * 2 * 2)     /* uint32 per wavefront: one 64-bit key per row, lane and alignment */
 #define K2A_PKMP_BND_WORDS(qlen, dual) ((((size_t)(qlen) * ((dual) ? 5 : 4) + 16) + 3) & ~(size_t)3)   /* uint32 per task: {H, E, baseA, baseB}[qlen] (+ E~[qlen]), rounded so that the 64-bit keys behind it stay aligned */
@@ -95,16 +93,16 @@ struct K2aLanePkMp {
 	/* a value arriving from the lane above (relative to ITS base): -inf stays -inf, anything else moves to this lane's base */
 	K2A_FN k2a_pk adopt(k2a_pk raw) const
 	{
-		const k2a_pk dead = k2a_pk_sign(k2a_pk_sub(raw ^ K2A_OFS, k2a_pk2(K2A_PKMP_DEAD)));       /* per half: raw < DEAD */
+		const k2a_pk dead = k2a_pk_sign(k2a_pk_sub(raw, k2a_pku(K2A_PKMP_DEAD)));       /* per half: raw < DEAD */
 		return k2a_pk_sel(dead, k2a_pku(K2A_NEG16), k2a_pk_add(raw, P.delta));
 	}
 
 	/* v - d per half with -inf kept at -16384 (offset form in and out) */
 	K2A_FN static k2a_pk shift(k2a_pk v, k2a_pk d)
 	{
-		const k2a_pk s = k2a_pk_sub(v ^ K2A_OFS, d);
-		const k2a_pk dead = k2a_pk_sign(k2a_pk_sub(s, k2a_pk2(K2A_PKMP_DEAD)));
-		return k2a_pk_sel(dead, k2a_pk2(K2A_NEG16), s) ^ K2A_OFS;
+		const k2a_pk s = k2a_pk_sub(v, d);                                           /* still in offset form */
+		const k2a_pk dead = k2a_pk_sign(k2a_pk_sub(s, k2a_pku(K2A_PKMP_DEAD)));
+		return k2a_pk_sel(dead, k2a_pku(K2A_NEG16), s);
 	}
 
 	/* merge the window's row maxima into the per-row keys and start a new window (needs the bases the values are relative to) */
@@ -112,7 +110,7 @@ struct K2aLanePkMp {
 	{
 #pragma unroll
 		for (int c = 0; c < C; ++c) {
-			const k2a_pk m = P.rmax(c) ^ K2A_OFS, j = P.rmj(c);
+			const k2a_pk m = k2a_ofs_off(P.rmax(c)), j = P.rmj(c);
 			const int mA = k2a_pk_lo(m), mB = k2a_pk_hi(m);
 			const uint32_t jA = j & 0xffffu, jB = j >> 16;
 			if (mA > K2A_PKMP_DEAD) k2a_key_max(&spill[2 * c], ((unsigned long long)((uint32_t)(mA + P.baseA) ^ 0x80000000u) << 32) | (FIRSTJ ? 0xffffu - jA : jA));
@@ -131,13 +129,13 @@ struct K2aLanePkMp {
 		k2a_pk m = P.hl[0];
 #pragma unroll
 		for (int c = 1; c < C; ++c) m = k2a_pk_maxu(m, P.hl[c]);
-		m ^= K2A_OFS;
+		m = k2a_ofs_off(m);
 		const k2a_pk dead = k2a_pk_sign(k2a_pk_sub(m, k2a_pk2(K2A_PKMP_DEAD)));
 		const k2a_pk d = k2a_pk_sel(dead, 0u, m);                                   /* no live row: stay */
 		/* would any row maximum overflow after the shift?  (offset form: plain value = stored ^ OFS) */
 		k2a_pk over = 0;
 #pragma unroll
-		for (int c = 0; c < C; ++c) over |= k2a_pk_sign(k2a_pk_sub(k2a_pk2(K2A_PKMP_RMAX_LIMIT), k2a_pk_sub(P.rmax(c) ^ K2A_OFS, d)));
+		for (int c = 0; c < C; ++c) over |= k2a_pk_sign(k2a_pk_sub(k2a_pk2(K2A_PKMP_RMAX_LIMIT), k2a_pk_sub(k2a_ofs_off(P.rmax(c)), d)));
 		if (over != 0) flush_rowmax();                                              /* with the bases the maxima are relative to */
 		P.baseA += k2a_pk_lo(d); P.baseB += k2a_pk_hi(d);
 #pragma unroll
@@ -163,7 +161,7 @@ struct K2aLanePkMp {
 	{
 		const int zslope = DUAL ? sc.e2 : sc.e;
 #pragma unroll
-		for (int c = 0; c < C; ++c) rowbuf[c] = P.hl[c] ^ K2A_OFS;
+		for (int c = 0; c < C; ++c) rowbuf[c] = k2a_ofs_off(P.hl[c]);
 #pragma nounroll
 		for (int half = 0; half < 2; ++half) {
 			K2aBook *b = half ? bB : bA;

@@ -106,14 +106,14 @@ struct K2aLaneSolo {
 		for (int c = 0; c < C; ++c) { hl[c] = neg; f[c] = neg; if (DUAL) f2[c] = neg; rmax[c] = neg; rmj[c] = 0; }
 		/* base = the diagonal input of the low half's first cell */
 		const int hcorner = k2a_border<DUAL>(sc, i0) + sc.e * (i0 - 1);
-		const int nb = js == 0 ? hcorner : bs + k2a_pk_hi(hu_prev ^ K2A_OFS);          /* what arrived: the high half of the lane above */
+		const int nb = js == 0 ? hcorner : bs + k2a_pk_hi(k2a_ofs_off(hu_prev));          /* what arrived: the high half of the lane above */
 		delta = D == 0 ? 0u : ((uint32_t)(bs - nb) & 0xffffu);
 		base = nb;
 		if (i0 <= w) {                                          /* rows starting at column 0: virtual column -1 (ksw2_extz.c:43-44) */
 #pragma unroll
 			for (int c = 0; c < C; ++c) {
 				const int ha = k2a_border<DUAL>(sc, i0 + c + 1) + sc.e * (i0 + c);
-				const uint32_t va = i0 + c <= w ? ((uint32_t)(ha - base) & 0xffffu) ^ 0x8000u : (K2A_NEG16 + 0x8000) & 0xffffu;
+				const uint32_t va = i0 + c <= w ? k2a_h16(ha - base) : k2a_h16(K2A_NEG16);
 				hl[c] = k2a_pair16(va, neg >> 16);
 				const k2a_pk fl = k2a_pk_sub(hl[c], k2a_pk2(sc.q + sc.e));
 				f[c] = k2a_pair16(i0 + c <= w ? fl & 0xffffu : neg & 0xffffu, neg >> 16);
@@ -126,7 +126,7 @@ struct K2aLaneSolo {
 		/* diagonal input of the low half's first cell: 0 by construction of the base.  The high half takes the low half's bottom
 		 * row one step later; when its rows start at column 0 init_high() loads its virtual column -1 just before that step
 		 * (the step in between runs the high half dead and would wipe it). */
-		hd0 = k2a_pair16(0x8000u, neg >> 16);
+		hd0 = k2a_pair16(k2a_h16(0), neg >> 16);
 		bfirst = i0b <= w && rowsB_m1 >= 0;
 		Dnext += G;
 		schedule_next();
@@ -138,21 +138,21 @@ struct K2aLaneSolo {
 	K2A_FN void init_high(const K2aScoring &sc)
 	{
 		const int i0b = i0 + C;
-		const uint32_t negh = (uint32_t)(K2A_NEG16 + 0x8000) & 0xffffu;
+		const uint32_t negh = (uint32_t)k2a_h16(K2A_NEG16);
 #pragma unroll
 		for (int c = 0; c < C; ++c) {
 			const bool in = i0b + c <= w;
 			const int hb = k2a_border<DUAL>(sc, i0b + c + 1) + sc.e * (i0b + c) - base;
-			const uint32_t vb = in ? ((uint32_t)hb & 0xffffu) ^ 0x8000u : negh;
-			const uint32_t fb = in ? ((uint32_t)(hb - (sc.q + sc.e)) & 0xffffu) ^ 0x8000u : negh;
+			const uint32_t vb = in ? k2a_h16(hb) : negh;
+			const uint32_t fb = in ? k2a_h16(hb - (sc.q + sc.e)) : negh;
 			hl[c] = (hl[c] & 0xffffu) | (vb << 16);
 			f[c] = (f[c] & 0xffffu) | (fb << 16);
 			if (DUAL) {
-				const uint32_t fb2 = in ? ((uint32_t)(hb - (sc.q2 + sc.e2)) & 0xffffu) ^ 0x8000u : negh;
+				const uint32_t fb2 = in ? k2a_h16(hb - (sc.q2 + sc.e2)) : negh;
 				f2[c] = (f2[c] & 0xffffu) | (fb2 << 16);
 			}
 		}
-		const uint32_t d0 = ((uint32_t)(k2a_border<DUAL>(sc, i0b) + sc.e * (i0b - 1) - base) & 0xffffu) ^ 0x8000u;
+		const uint32_t d0 = k2a_h16(k2a_border<DUAL>(sc, i0b) + sc.e * (i0b - 1) - base);
 		hd0 = (hd0 & 0xffffu) | (d0 << 16);
 		bfirst = false;
 	}
@@ -162,8 +162,8 @@ struct K2aLaneSolo {
 	{
 		if (D == 0) {
 			const int hb = k2a_border<DUAL>(sc, k - koff + 1) - base;
-			const uint32_t h0 = ((uint32_t)(hb - sc.e) & 0xffffu) ^ 0x8000u, e0 = ((uint32_t)(hb - (sc.q + sc.e)) & 0xffffu) ^ 0x8000u;
-			const uint32_t e20 = ((uint32_t)(hb - (sc.q2 + sc.e2)) & 0xffffu) ^ 0x8000u;
+			const uint32_t h0 = k2a_h16(hb - sc.e), e0 = k2a_h16(hb - (sc.q + sc.e));
+			const uint32_t e20 = k2a_h16(hb - (sc.q2 + sc.e2));
 			hin = (hin & 0xffff0000u) | h0; ein = (ein & 0xffff0000u) | e0; e2in = (e2in & 0xffff0000u) | e20;
 		}
 	}
@@ -200,8 +200,8 @@ struct K2aLaneSolo {
 			const k2a_pk fc = f[c];
 			k2a_pk h = cand[c], d = 0;
 			if (MODE == K2A_MODE_SCORE) {
-				h = k2a_pk_maxu(k2a_pk_maxu(h, e), fc);
-				if (DUAL) h = k2a_pk_maxu(k2a_pk_maxu(h, e2), f2[c]);
+				h = k2a_pk_max3u(h, e, fc);                    /* v_pk_maximum3_f16 on offset-form patterns (ksw2_lane_pk.h) */
+				if (DUAL) h = k2a_pk_max3u(h, e2, f2[c]);
 			} else if (MODE == K2A_MODE_LEFT) {
 				d = k2a_pk_sign(k2a_pk_sub(h, e)) & 0x00010001u;                     h = k2a_pk_maxu(h, e);
 				d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, fc)), 0x00020002u, d);      h = k2a_pk_maxu(h, fc);
@@ -274,7 +274,7 @@ struct K2aLaneSolo {
 	{
 #pragma unroll
 		for (int c = 0; c < C; ++c) {
-			const k2a_pk hA = (rowsB_m1 >= 0 ? hsave[c] : hl[c]) ^ K2A_OFS, hB = hl[c] ^ K2A_OFS, m = rmax[c] ^ K2A_OFS;
+			const k2a_pk hA = k2a_ofs_off(rowsB_m1 >= 0 ? hsave[c] : hl[c]), hB = k2a_ofs_off(hl[c]), m = k2a_ofs_off(rmax[c]);
 			rowbuf[c] = hA & 0xffffu; rowbuf[C + c] = hB >> 16;
 			rowbuf[2 * C + c] = m & 0xffffu; rowbuf[3 * C + c] = m >> 16;
 			rowbuf[4 * C + c] = rmj[c] & 0xffffu; rowbuf[5 * C + c] = rmj[c] >> 16;
@@ -318,10 +318,10 @@ struct K2aLaneSolo {
 		if (i0 + 2 * C >= tlen || i0 + 2 * C - 1 + w >= qlen - 1) return false;
 		/* rows compare without their bias: low half v_c = rmax[c] - e*c, high half rmax[c] - e*(C+c) */
 		const k2a_pk hb = k2a_pair16(0u, (uint32_t)(sc.e * C) & 0xffffu);
-		k2a_pk m = k2a_pk_sub(rmax[0] ^ K2A_OFS, hb), mn = m, arg = 0, argj = rmj[0];
+		k2a_pk m = k2a_pk_sub(k2a_ofs_off(rmax[0]), hb), mn = m, arg = 0, argj = rmj[0];
 #pragma unroll
 		for (int c = 1; c < C; ++c) {
-			const k2a_pk v = k2a_pk_sub(k2a_pk_sub(rmax[c] ^ K2A_OFS, hb), k2a_pk2(sc.e * c));
+			const k2a_pk v = k2a_pk_sub(k2a_pk_sub(k2a_ofs_off(rmax[c]), hb), k2a_pk2(sc.e * c));
 			const k2a_pk gt = k2a_pk_sign(k2a_pk_sub(m, v));
 			arg = k2a_pk_sel(gt, k2a_pk2(c), arg);
 			argj = k2a_pk_sel(gt, rmj[c], argj);

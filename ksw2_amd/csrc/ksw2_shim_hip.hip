@@ -254,7 +254,9 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	for (int g = 1; g < NG; ++g) ktop = max(ktop, __builtin_amdgcn_readlane(ktop1, g * G));
 
 	bool gdone = !valid;
-	L.qb = L.next_query_codes(-1);
+	/* query codes: one unaligned dword per alignment and four steps (K2aLanePk::load_query_group) */
+	uint32_t qpa = 0, qpb = 0;
+	L.load_query_group(0, L.knext == 0 ? L.koff_next : L.koff, L.qwA, L.qwB);
 	const size_t tbsteps = (size_t)(klast + 1);
 	uint8_t *tbp = tb + prA.tb_off;
 	constexpr int WB = Lane::TBWORDS * 4;
@@ -274,11 +276,15 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 		const bool ninit = L.need_init(k);
 		if (__builtin_amdgcn_ballot_w64(ninit) != 0) {
 			const int bsA = RB ? k2a_rot1<G>(L.baseA) : 0, bsB = RB ? k2a_rot1<G>(L.baseB) : 0;
-			if (ninit) L.do_init(sc, bsA, bsB);               /* uses hu_prev = what arrived one step ago */
+			if (ninit) {
+				L.do_init(sc, bsA, bsB);                          /* uses hu_prev = what arrived one step ago */
+				if (k & 3) L.load_query_group(k & ~3, L.koff, L.qwA, L.qwB);      /* the group was fetched under the previous strip's offset */
+			}
 		}
 		L.hu_prev = hin;
 		if (RB) { hin = k2a_pk_add(hin, L.delta); ein = k2a_pk_add(ein, L.delta); if (DUAL) e2in = k2a_pk_add(e2in, L.delta); }
-		const uint32_t qnext = L.next_query_codes(k);
+		if ((k & 3) == 3) L.load_query_group(k + 1, k + 1 == L.knext ? L.koff_next : L.koff, qpa, qpb);   /* in flight during this step */
+		L.qb = Lane::query_pick(L.qwA, L.qwB, k & 3);
 		if (k <= ktop) L.top_inputs(sc, k, hin, ein, e2in);
 
 		uint32_t tw[Lane::TBWORDS];
@@ -317,7 +323,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 				__builtin_amdgcn_wave_barrier();
 			}
 		}
-		L.qb = qnext;
+		if ((k & 3) == 3) { L.qwA = qpa; L.qwB = qpb; }
 		if (zseq && __builtin_amdgcn_ballot_w64(!(gdone || k >= klast)) == 0) break;   /* only a Z-drop ends a group early */
 	}
 	if (STAGED) ST.finish(kdone);

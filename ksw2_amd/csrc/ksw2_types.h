@@ -32,6 +32,18 @@
 
 /* packed traceback words: single-gap kernels of the 16-row geometries write 4 bits per cell (2-bit winner + E / F continuation,
  * the int32 kernels' code), everything else one byte per cell in the reference's layout (ksw2.h:125-128) */
+/* number format of the packed-int16 kernels (ksw2_lane_pk.h): a value v is held as the 16-bit pattern v + K2A_OFS16, and every
+ * pattern the fill loops compare lies in 0x0000 .. 0x7BFF (the non-negative finite IEEE halves, so that v_pk_maximum3_f16 is an
+ * integer maximum): -inf = K2A_NEG16 -> 0x0C00 with K2A_PK_SLACK units below it, largest value K2A_PK_VMAX -> 0x7BFF */
+#define K2A_NEG16    (-16384)
+#define K2A_OFS16    0x4C00
+#define K2A_PK_VMAX  (0x7BFF - K2A_OFS16)       /* 12287 */
+#define K2A_PK_SLACK (K2A_OFS16 + K2A_NEG16)    /* 3072: room below -inf for the base shifts and gap costs applied to it */
+/* packed generation-serial class (ksw2_lane_pkmp.h): sliding base */
+#define K2A_PKMP_T    64            /* steps between re-bases (a power of two) */
+#define K2A_PKMP_DEAD (-8192)       /* relative values below this are -inf */
+#define K2A_PKMP_RMAX_LIMIT 10000   /* a window's row maximum further above the base than this is merged into its key; it may drift
+                                     * K2A_PKMP_T steps further before the next check and must still fit K2A_PK_VMAX */
 #define K2A_PK_NIBBLES(C, dual) (!(dual) && (C) == 16)
 #define K2A_PK_TB_BYTES(C, dual) (K2A_PK_NIBBLES(C, dual) ? (C) : 2 * (C))        /* per lane-step: C rows x 2 alignments */
 

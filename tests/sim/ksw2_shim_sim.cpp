@@ -132,7 +132,7 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 			klast[lane] = L[lane].last_step();
 			if (klast[lane] > kmax) kmax = klast[lane];
 			gdone[lane] = !valid[lane];
-			L[lane].qb = L[lane].next_query_codes(-1);
+			L[lane].load_query_group(0, L[lane].knext == 0 ? L[lane].koff_next : L[lane].koff, L[lane].qwA, L[lane].qwB);
 			zseq |= valid[lane] && (zdA[lane] >= 0 || zdB[lane] >= 0);
 			if (valid[lane]) {
 				const int kt = k2a_min(prA[lane].qlen - 1, k2a_min(C - 1, prA[lane].tlen - 1) + prA[lane].w);
@@ -141,7 +141,7 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 		}
 		for (int k = 0; k <= kmax; ++k) {
 			k2a_pk hin[64], ein[64], e2in[64];
-			uint32_t qnext[64];
+			static thread_local uint32_t qpa[64], qpb[64];
 			for (int lane = 0; lane < 64; ++lane) {
 				const int grp = lane / G, gl = lane % G, src = grp * G + (gl + G - 1) % G;
 				hin[lane] = L[src].hout; ein[lane] = L[src].eout; e2in[lane] = DUAL ? L[src].e2out : 0;
@@ -153,13 +153,17 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 				bsA[lane] = L[src].baseA; bsB[lane] = L[src].baseB;
 			}
 			for (int lane = 0; lane < 64; ++lane) {
-				if (L[lane].need_init(k)) L[lane].do_init(sc, bsA[lane], bsB[lane]);
+				if (L[lane].need_init(k)) {
+					L[lane].do_init(sc, bsA[lane], bsB[lane]);
+					if (k & 3) L[lane].load_query_group(k & ~3, L[lane].koff, L[lane].qwA, L[lane].qwB);
+				}
 				L[lane].hu_prev = hin[lane];
 				if (RB) {
 					hin[lane] = k2a_pk_add(hin[lane], L[lane].delta); ein[lane] = k2a_pk_add(ein[lane], L[lane].delta);
 					if (DUAL) e2in[lane] = k2a_pk_add(e2in[lane], L[lane].delta);
 				}
-				qnext[lane] = L[lane].next_query_codes(k);
+				if ((k & 3) == 3) L[lane].load_query_group(k + 1, k + 1 == L[lane].knext ? L[lane].koff_next : L[lane].koff, qpa[lane], qpb[lane]);
+				L[lane].qb = Lane::query_pick(L[lane].qwA, L[lane].qwB, k & 3);
 				if (k <= ktop) L[lane].top_inputs(sc, k, hin[lane], ein[lane], e2in[lane]);
 			}
 			for (int lane = 0; lane < 64; ++lane) {
@@ -197,7 +201,7 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 			}
 			bool all_done = true;
 			for (int lane = 0; lane < 64; ++lane) {
-				L[lane].qb = qnext[lane];
+				if ((k & 3) == 3) { L[lane].qwA = qpa[lane]; L[lane].qwB = qpb[lane]; }
 				if (!(gdone[lane] || k >= klast[lane])) all_done = false;
 			}
 			if (zseq && all_done) break;
