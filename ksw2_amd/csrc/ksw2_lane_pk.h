@@ -52,6 +52,14 @@ K2A_FN int k2a_pk_lo(k2a_pk v) { return (int)(int16_t)(v & 0xffffu); }
 K2A_FN int k2a_pk_hi(k2a_pk v) { return (int)(int16_t)(v >> 16); }
 K2A_FN k2a_pk k2a_pk_sel(k2a_pk m, k2a_pk a, k2a_pk b) { return (m & a) | (~m & b); }   /* v_bfi / v_bitop3 */
 K2A_FN k2a_pk k2a_pair16(uint32_t lo, uint32_t hi) { return lo | (hi << 16); }                /* two small codes -> halves */
+K2A_FN k2a_pk k2a_byte_pair(uint32_t a, uint32_t b, int r)                                      /* { byte r of a, byte r of b } -> halves; r constant */
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __builtin_amdgcn_perm(b, a, 0x0c040c00u + (uint32_t)r * 0x00010001u);
+#else
+	return ((a >> (8 * r)) & 0xffu) | (((b >> (8 * r)) & 0xffu) << 16);
+#endif
+}
 K2A_FN uint32_t k2a_h16(int v) { return (uint32_t)(v + K2A_OFS16) & 0xffffu; }                 /* one half in offset form */
 K2A_FN k2a_pk k2a_pku(int v) { return k2a_pk2(v + K2A_OFS16); }                                 /* constant in offset form */
 /* both halves at once with one 32-bit op: exact as long as the low half neither carries nor borrows (offset form,
@@ -174,10 +182,10 @@ K2A_FN k2a_pk k2a_ofs_off(k2a_pk ofs) { return k2a_pk_sub(ofs, K2A_OFS); }
  * exposed and the register form is faster, so both are built and the launcher picks by the number of tasks. */
 #define K2A_PK_LDSROWS(G, C, DUAL, MODE, NOMAX) ((G) == 64 && (C) == 16 && (DUAL) && (MODE) != K2A_MODE_SCORE && !(NOMAX))
 #define K2A_PK_LDSROW_WORDS(C) (3 * (C) * 64)        /* per wavefront */
-/* Codes only (LDSROW_ = 2): the exact score-only kernel of the 16-row geometry holds 178-190 registers, two wavefronts per
- * SIMD; with the two code planes (32 registers) in LDS it fits three.  Nothing else changes: the planes are read-only
- * between strip starts, two LDS loads per row and step. */
-#define K2A_PK_LDSCODES(G, C, DUAL, MODE, NOMAX) ((G) == 64 && (C) == 16 && !(DUAL) && (MODE) == K2A_MODE_SCORE)
+/* Codes only (LDSROW_ = 2): the exact score-only kernels hold 178-224 registers, two wavefronts per SIMD; with the two code
+ * planes (2 x C registers) in LDS the 16-row geometry fits four, the (8, 18) geometry of short reads three.  Nothing else
+ * changes: the planes are read-only between strip starts, two LDS loads per row and step. */
+#define K2A_PK_LDSCODES(G, C, DUAL, MODE, NOMAX) ((((G) == 64 && (C) == 16) || ((G) == 8 && (C) == 18) || ((G) == 16 && (C) == 8)) && !(DUAL) && (MODE) == K2A_MODE_SCORE)
 #define K2A_PK_LDSCODE_WORDS(C) (2 * (C) * 64)       /* per wavefront */
 
 template<int G, int C, bool DUAL, int MODE = K2A_MODE_SCORE, bool RB = false, bool NOMAX = false, int LDSROW_ = 0>
@@ -260,26 +268,29 @@ struct K2aLanePk {
 		const int js = k2a_max(0, i0 - w);
 		const k2a_pk neg = k2a_pku(K2A_NEG16);
 		const uint32_t dmis = (uint32_t)(sc.pk_a - sc.pk_b);                 /* D */
-		/* target codes of the strip's rows, two rows per 16-bit load and alignment (C is even and targets are 16-byte
-		 * aligned, the arena is padded past the last row).  Not prefetched: one L2 round trip per strip is noise next
-		 * to the strip's ~2w+C steps. */
-		const uint16_t *tpa = (const uint16_t*)(ta + (size_t)S * C), *tpb = (const uint16_t*)(tbq + (size_t)S * C);
+		/* target codes of the strip's rows, four rows per (unaligned) dword load and alignment; the arena is padded past the last
+		 * row.  Not prefetched: one L2 round trip per strip is noise next to the strip's ~2w+C steps.  The bit planes of four rows
+		 * are formed together (one byte per row: D <= 255), a v_perm_b32 per row and plane then pairs alignment A's byte with
+		 * alignment B's -- this code runs with one lane per group active, every 17-19 steps: it was 11 % of the kernel. */
+		const uint8_t *tpa = ta + (size_t)S * C, *tpb = tbq + (size_t)S * C;
 #pragma unroll
-		for (int c = 0; c < C; c += 2) {
-			const uint32_t ua = tpa[c >> 1], ub = tpb[c >> 1];
-			const k2a_pk c0 = k2a_pair16(ua & 0xffu, ub & 0xffu), c1 = k2a_pair16(ua >> 8, ub >> 8);
+		for (int c4 = 0; c4 < C; c4 += 4) {
+			uint32_t da, db;
+			__builtin_memcpy(&da, tpa + c4, 4); __builtin_memcpy(&db, tpb + c4, 4);
 			if (PLANES) {
-				set_tc(c, (c0 & 0x00010001u) * dmis); set_tc1(c, ((c0 >> 1) & 0x00010001u) * dmis);
-				if (c + 1 < C) { set_tc(c + 1, (c1 & 0x00010001u) * dmis); set_tc1(c + 1, ((c1 >> 1) & 0x00010001u) * dmis); }
+				const uint32_t a0 = (da & 0x01010101u) * dmis, a1 = ((da >> 1) & 0x01010101u) * dmis;
+				const uint32_t b0 = (db & 0x01010101u) * dmis, b1 = ((db >> 1) & 0x01010101u) * dmis;
+#pragma unroll
+				for (int r = 0; r < 4 && c4 + r < C; ++r) { set_tc(c4 + r, k2a_byte_pair(a0, b0, r)); set_tc1(c4 + r, k2a_byte_pair(a1, b1, r)); }
 			} else {
-				set_tc(c, c0);
-				if (c + 1 < C) set_tc(c + 1, c1);
+#pragma unroll
+				for (int r = 0; r < 4 && c4 + r < C; ++r) set_tc(c4 + r, k2a_byte_pair(da, db, r));
 			}
 		}
 #pragma unroll
 		for (int c = 0; c < C; ++c) {
 			hl[c] = neg; f[c] = neg; if (DUAL) f2[c] = neg;
-			if (!NOMAX) { set_rmax(c, neg); set_rmj(c, 0); }
+			if (!NOMAX) set_rmax(c, neg);                        /* the arg-max column is written with the row's first live cell */
 		}
 		const int hcorner = k2a_border<DUAL>(sc, i0) + sc.e * (i0 - 1);   /* H(i0-1,-1), carrying the bias of row i0-1 */
 		if (RB) {
@@ -338,87 +349,97 @@ struct K2aLanePk {
 		const uint32_t live = ((1u << cnt) - 1u) << (lo & 31);       /* lo >= 32 only with cnt = 0 */
 		const k2a_pk qcode = qb;
 		const k2a_pk jjpk = k2a_pk2(k - koff);
-		k2a_pk cand[C];
-		if (PLANES) {
-			/* mismatch ? D : 0 from the bit planes: (t0 ^ q0) | (t1 ^ q1), everything pre-multiplied with D */
-			const uint32_t dmis = (uint32_t)(sc.pk_a - sc.pk_b);
-			const k2a_pk q0 = (qcode & 0x00010001u) * dmis, q1 = ((qcode >> 1) & 0x00010001u) * dmis;
+		/* rows in chunks of CH: phase 1 of a chunk (its diagonal candidates, from the old H row) right before its phase 2, so only
+		 * CH candidates are alive at a time instead of C (16-18 registers: what keeps these kernels a wavefront short).  The one
+		 * old H a chunk needs from the chunk above -- the row just above its first row -- is saved before that row is rewritten. */
+		constexpr int CH = (C % 6 == 0) ? 6 : (C % 4 == 0) ? 4 : C;
+		const uint32_t dmis = (uint32_t)(sc.pk_a - sc.pk_b);
+		const k2a_pk q0 = (qcode & 0x00010001u) * dmis, q1 = ((qcode >> 1) & 0x00010001u) * dmis;   /* PLANES: query bit planes x D */
+		k2a_pk dprev = 0, above_old = hd0;
 #pragma unroll
-			for (int c = 0; c < C; ++c)
-				cand[c] = k2a_sub32(k2a_add32(c == 0 ? hd0 : hl[c - 1], mat_a), k2a_or_xor(tc(c) ^ q0, tc1(c), q1));
-		} else {
+		for (int c0 = 0; c0 < C; c0 += CH) {
+			k2a_pk cand[CH];
+			const k2a_pk last_old = hl[c0 + CH - 1];
 #pragma unroll
-			for (int c = 0; c < C; ++c) {
-				/* score: a on equal codes, b otherwise (no wildcards in this class) */
-				const k2a_pk ne01 = k2a_pk_minu(tc(c) ^ qcode, 0x00010001u);
-				cand[c] = k2a_pk_add(c == 0 ? hd0 : hl[c - 1], k2a_pk_mad(ne01, mat_bma, mat_a));
+			for (int r = 0; r < CH; ++r) {
+				const int c = c0 + r;
+				const k2a_pk up = r == 0 ? above_old : hl[c - 1];
+				if (PLANES)        /* mismatch ? D : 0 from the bit planes: (t0 ^ q0) | (t1 ^ q1), everything pre-multiplied with D */
+					cand[r] = k2a_sub32(k2a_add32(up, mat_a), k2a_or_xor(tc(c) ^ q0, tc1(c), q1));
+				else {             /* score: a on equal codes, b otherwise (no wildcards in this class) */
+					const k2a_pk ne01 = k2a_pk_minu(tc(c) ^ qcode, 0x00010001u);
+					cand[r] = k2a_pk_add(up, k2a_pk_mad(ne01, mat_bma, mat_a));
+				}
 			}
-		}
-		k2a_pk dprev = 0;
+			above_old = last_old;
+			if (CH < C) K2A_SCHED_FENCE();
 #pragma unroll
-		for (int c = 0; c < C; ++c) {
-			const k2a_pk fc = f[c];
-			k2a_pk h = cand[c], d = 0;
-			if (MODE == K2A_MODE_SCORE) {
-				h = k2a_pk_max3u(h, e, fc);                    /* one v_pk_maximum3_f16: see "Number format" above */
-				if (DUAL) h = k2a_pk_max3u(h, e2, f2[c]);
-			} else if (MODE == K2A_MODE_LEFT) {            /* winner changes only on a strictly larger gap state */
-				d = k2a_pk_sign(k2a_pk_sub(h, e)) & 0x00010001u;                     h = k2a_pk_maxu(h, e);
-				d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, fc)), 0x00020002u, d);      h = k2a_pk_maxu(h, fc);
+			for (int r = 0; r < CH; ++r) {
+				const int c = c0 + r;
+				const k2a_pk fc = f[c];
+				k2a_pk h = cand[r], d = 0;
+				if (MODE == K2A_MODE_SCORE) {
+					h = k2a_pk_max3u(h, e, fc);                    /* one v_pk_maximum3_f16: see "Number format" above */
+					if (DUAL) h = k2a_pk_max3u(h, e2, f2[c]);
+				} else if (MODE == K2A_MODE_LEFT) {            /* winner changes only on a strictly larger gap state */
+					d = k2a_pk_sign(k2a_pk_sub(h, e)) & 0x00010001u;                     h = k2a_pk_maxu(h, e);
+					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, fc)), 0x00020002u, d);      h = k2a_pk_maxu(h, fc);
+					if (DUAL) {
+						d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, e2)), 0x00030003u, d);    h = k2a_pk_maxu(h, e2);
+						d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, f2[c])), 0x00040004u, d); h = k2a_pk_maxu(h, f2[c]);
+					}
+				} else {                                       /* right-aligned: a tie already moves to the gap state */
+					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e, h)), 0u, 0x00010001u);      h = k2a_pk_maxu(h, e);
+					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(fc, h)), d, 0x00020002u);      h = k2a_pk_maxu(h, fc);
+					if (DUAL) {
+						d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e2, h)), d, 0x00030003u);    h = k2a_pk_maxu(h, e2);
+						d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(f2[c], h)), d, 0x00040004u); h = k2a_pk_maxu(h, f2[c]);
+					}
+				}
+				h = k2a_pk_sel(k2a_bit_mask(live, c), h, neg);
+				/* running row maximum: ties to the last column (keep the old arg-max only where h < max), except
+				 * extz + RIGHT + CIGAR where the first column wins (take the new one only where max < h); SURVEY 8a rule 3 */
+				if (!NOMAX) {
+					const k2a_pk rm = rmax(c), rj = rmj(c);
+					if (!DUAL && MODE == K2A_MODE_RIGHT) set_rmj(c, k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(rm, h)), jjpk, rj));
+					else set_rmj(c, k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(h, rm)), rj, jjpk));
+					set_rmax(c, k2a_pk_maxu(rm, h));
+				}
+				/* gaps leaving the cell, all in row-biased form: opening = H' - q; the extension cost cancels against the bias
+				 * for E (next row), stays e for F (same row), becomes e2 - e for E~ and stays e2 for F~.  "extension beats
+				 * opening" (ksw2_extz.c:79-86 / 105-112) compares the gap state with the opening value directly. */
+				const k2a_pk t = k2a_sub32(h, gq);
+				if (MODE == K2A_MODE_LEFT) {                   /* extension strictly better than opening */
+					d |= k2a_pk_sign(k2a_pk_sub(t, e)) & (NIB ? 0x00040004u : 0x00080008u);
+					d |= k2a_pk_sign(k2a_pk_sub(t, fc)) & (NIB ? 0x00080008u : 0x00100010u);
+				} else if (MODE == K2A_MODE_RIGHT) {           /* extension at least as good as opening */
+					d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e, t)), 0u, NIB ? 0x00040004u : 0x00080008u);
+					d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(fc, t)), 0u, NIB ? 0x00080008u : 0x00100010u);
+				}
+				e = k2a_pk_maxu(e, t);
+				f[c] = k2a_sub32(k2a_pk_maxu(fc, t), ge);
 				if (DUAL) {
-					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, e2)), 0x00030003u, d);    h = k2a_pk_maxu(h, e2);
-					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, f2[c])), 0x00040004u, d); h = k2a_pk_maxu(h, f2[c]);
+					const k2a_pk t2 = k2a_sub32(h, gq2);
+					if (MODE == K2A_MODE_LEFT) {
+						d |= k2a_pk_sign(k2a_pk_sub(t2, e2)) & 0x00200020u;
+						d |= k2a_pk_sign(k2a_pk_sub(t2, f2[c])) & 0x00400040u;
+					} else if (MODE == K2A_MODE_RIGHT) {
+						d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e2, t2)), 0u, 0x00200020u);
+						d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(f2[c], t2)), 0u, 0x00400040u);
+					}
+					e2 = k2a_pk_sub(k2a_pk_maxu(e2, t2), de2);           /* e2 - e may be negative: packed subtract */
+					f2[c] = k2a_sub32(k2a_pk_maxu(f2[c], t2), ge2);
 				}
-			} else {                                       /* right-aligned: a tie already moves to the gap state */
-				d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e, h)), 0u, 0x00010001u);      h = k2a_pk_maxu(h, e);
-				d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(fc, h)), d, 0x00020002u);      h = k2a_pk_maxu(h, fc);
-				if (DUAL) {
-					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e2, h)), d, 0x00030003u);    h = k2a_pk_maxu(h, e2);
-					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(f2[c], h)), d, 0x00040004u); h = k2a_pk_maxu(h, f2[c]);
+				if (MODE != K2A_MODE_SCORE) {
+					if (NIB) {
+						dprev = (c & 3) ? k2a_pk_mad(dprev, 0x00100010u, d) : d;      /* both halves: code << 4 | next row's code */
+						if ((c & 3) == 3) tbw[c >> 2] = dprev;
+					} else if (c & 1) tbw[c >> 1] = k2a_pack_dirs(dprev, d);    /* bytes {A(c-1), B(c-1), A(c), B(c)} */
+					else dprev = d;
 				}
+				hl[c] = h;
 			}
-			h = k2a_pk_sel(k2a_bit_mask(live, c), h, neg);
-			/* running row maximum: ties to the last column (keep the old arg-max only where h < max), except
-			 * extz + RIGHT + CIGAR where the first column wins (take the new one only where max < h); SURVEY 8a rule 3 */
-			if (!NOMAX) {
-				const k2a_pk rm = rmax(c), rj = rmj(c);
-				if (!DUAL && MODE == K2A_MODE_RIGHT) set_rmj(c, k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(rm, h)), jjpk, rj));
-				else set_rmj(c, k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(h, rm)), rj, jjpk));
-				set_rmax(c, k2a_pk_maxu(rm, h));
-			}
-			/* gaps leaving the cell, all in row-biased form: opening = H' - q; the extension cost cancels against the bias
-			 * for E (next row), stays e for F (same row), becomes e2 - e for E~ and stays e2 for F~.  "extension beats
-			 * opening" (ksw2_extz.c:79-86 / 105-112) compares the gap state with the opening value directly. */
-			const k2a_pk t = k2a_sub32(h, gq);
-			if (MODE == K2A_MODE_LEFT) {                   /* extension strictly better than opening */
-				d |= k2a_pk_sign(k2a_pk_sub(t, e)) & (NIB ? 0x00040004u : 0x00080008u);
-				d |= k2a_pk_sign(k2a_pk_sub(t, fc)) & (NIB ? 0x00080008u : 0x00100010u);
-			} else if (MODE == K2A_MODE_RIGHT) {           /* extension at least as good as opening */
-				d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e, t)), 0u, NIB ? 0x00040004u : 0x00080008u);
-				d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(fc, t)), 0u, NIB ? 0x00080008u : 0x00100010u);
-			}
-			e = k2a_pk_maxu(e, t);
-			f[c] = k2a_sub32(k2a_pk_maxu(fc, t), ge);
-			if (DUAL) {
-				const k2a_pk t2 = k2a_sub32(h, gq2);
-				if (MODE == K2A_MODE_LEFT) {
-					d |= k2a_pk_sign(k2a_pk_sub(t2, e2)) & 0x00200020u;
-					d |= k2a_pk_sign(k2a_pk_sub(t2, f2[c])) & 0x00400040u;
-				} else if (MODE == K2A_MODE_RIGHT) {
-					d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e2, t2)), 0u, 0x00200020u);
-					d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(f2[c], t2)), 0u, 0x00400040u);
-				}
-				e2 = k2a_pk_sub(k2a_pk_maxu(e2, t2), de2);           /* e2 - e may be negative: packed subtract */
-				f2[c] = k2a_sub32(k2a_pk_maxu(f2[c], t2), ge2);
-			}
-			if (MODE != K2A_MODE_SCORE) {
-				if (NIB) {
-					dprev = (c & 3) ? k2a_pk_mad(dprev, 0x00100010u, d) : d;      /* both halves: code << 4 | next row's code */
-					if ((c & 3) == 3) tbw[c >> 2] = dprev;
-				} else if (c & 1) tbw[c >> 1] = k2a_pack_dirs(dprev, d);    /* bytes {A(c-1), B(c-1), A(c), B(c)} */
-				else dprev = d;
-			}
-			hl[c] = h;
+			if (CH < C) K2A_SCHED_FENCE();
 		}
 		hd0 = hin;
 		hout = hl[C - 1]; eout = e; e2out = e2;
@@ -439,24 +460,25 @@ struct K2aLanePk {
 	 * A strip that starts inside a group re-loads the group under its own column offset (load_query_group from the init
 	 * branch).  Bytes of columns outside the query are garbage that only dead cells see (the arena is padded). */
 	uint32_t qwA, qwB;
-	K2A_FN void load_query_group(int kg, int koff_use, uint32_t &a, uint32_t &b) const
+	K2A_FN void load_query_group(int kg, int koff_use, uint32_t &a, uint32_t &b) const      /* prefetch: nothing here waits for the loads */
 	{
-		const int j = kg - koff_use;                               /* column at step kg */
-		const int jc = k2a_min(k2a_max(j, 0), qlen - 1);
+		const int jc = k2a_min(k2a_max(kg - koff_use, 0), qlen - 1);    /* column at step kg; a negative one belongs to a lane without a strip */
+		__builtin_memcpy(&a, qa + jc, 4); __builtin_memcpy(&b, qbp + jc, 4);
+	}
+	K2A_FN void reload_query_group(int k)                      /* from the init branch: this strip started at step k, inside a group */
+	{
+		const int j = (k & ~3) - koff;                             /* < 0: the strip's column 0 comes -j steps into the group */
+		const int sh = 8 * k2a_min(k2a_max(-j, 0), 3);
 		uint32_t va, vb;
-		__builtin_memcpy(&va, qa + jc, 4); __builtin_memcpy(&vb, qbp + jc, 4);
-		if (j < 0) {                                               /* the strip's column 0 comes -j steps into the group */
-			const int sh = 8 * k2a_min(-j, 3);
-			va <<= sh; vb <<= sh;
-		}
-		a = va; b = vb;
+		load_query_group(k & ~3, koff, va, vb);
+		qwA = va << sh; qwB = vb << sh;
 	}
 	K2A_FN static uint32_t query_pick(uint32_t a, uint32_t b, int kk)      /* { code A, code B } of step kg + kk */
 	{
 #if defined(__HIP_DEVICE_COMPILE__)
-		return __builtin_amdgcn_perm(b, a, 0x0c040c00u + (uint32_t)kk * 0x00010001u);
+		return __builtin_amdgcn_perm(b, a, 0x0c040c00u + (uint32_t)kk * 0x00010001u);      /* kk is wave-uniform: a scalar selector */
 #else
-		return k2a_pair16((a >> (8 * kk)) & 0xffu, (b >> (8 * kk)) & 0xffu);
+		return k2a_byte_pair(a, b, kk);
 #endif
 	}
 

@@ -214,7 +214,7 @@ struct K2aTbStage {
 
 /* Packed-int16 resident fill: two same-shape alignments per lane group (ksw2_lane_pk.h). */
 template<int G, int C, bool DUAL, int MODE, bool RB, bool NOMAX, int LDSROW = 0>      /* LDSROW: 1 = row state in LDS, 2 = only the target-code planes */
-__global__ void __launch_bounds__(64 * K2A_WPB, LDSROW == 2 ? 3 : LDSROW ? 2 : 1)      /* no floor elsewhere: capping the register form of the score-only kernels at 168 VGPRs spills and is 18 % slower */
+__global__ void __launch_bounds__(64 * K2A_WPB, LDSROW == 2 ? (G == 16 ? 4 : 3) : LDSROW ? 2 : 1)      /* no floor elsewhere: capping the register form of the score-only kernels at 168 VGPRs spills and is 18 % slower */
 k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
                    const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, K2aResult *__restrict__ res)
 {
@@ -278,7 +278,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 			const int bsA = RB ? k2a_rot1<G>(L.baseA) : 0, bsB = RB ? k2a_rot1<G>(L.baseB) : 0;
 			if (ninit) {
 				L.do_init(sc, bsA, bsB);                          /* uses hu_prev = what arrived one step ago */
-				if (k & 3) L.load_query_group(k & ~3, L.koff, L.qwA, L.qwB);      /* the group was fetched under the previous strip's offset */
+				if (k & 3) L.reload_query_group(k);                /* the group was fetched under the previous strip's offset */
 			}
 		}
 		L.hu_prev = hin;
@@ -1406,9 +1406,10 @@ static const fill_pk_fn g_fill_pk_lds[2][2] = {
 	{ k2a_fill_pk_kernel<64, 16, true, 1, false, false, 1>, k2a_fill_pk_kernel<64, 16, true, 2, false, false, 1> },
 	{ k2a_fill_pk_kernel<64, 16, true, 1, true, false, 1>,  k2a_fill_pk_kernel<64, 16, true, 2, true, false, 1> } };
 
-/* exact score-only kernels of the 16-row geometry with the code planes in LDS (three wavefronts per SIMD): [rebased] */
-static const fill_pk_fn g_fill_pk_ldscodes[2][2] = { { k2a_fill_pk_kernel<64, 16, false, 0, false, false, 2>, k2a_fill_pk_kernel<64, 16, false, 0, true, false, 2> },
-                                                     { k2a_fill_pk_kernel<64, 16, false, 0, false, true, 2>,  k2a_fill_pk_kernel<64, 16, false, 0, true, true, 2> } };      /* [nomax][rebased] */
+/* exact / no-maximum score-only kernels with the code planes in LDS: [geometry: (64, 16), (8, 18)][nomax][rebased] */
+#define LDSCODE_SET(G, C) { { k2a_fill_pk_kernel<G, C, false, 0, false, false, 2>, k2a_fill_pk_kernel<G, C, false, 0, true, false, 2> }, \
+                            { k2a_fill_pk_kernel<G, C, false, 0, false, true, 2>,  k2a_fill_pk_kernel<G, C, false, 0, true, true, 2> } }
+static const fill_pk_fn g_fill_pk_ldscodes[3][2][2] = { LDSCODE_SET(64, 16), LDSCODE_SET(8, 18), LDSCODE_SET(16, 8) };
 /* Launch-time kernel forms.  Every choice the launcher makes has a forcing switch (k2a_shim_set_option: -1 automatic, 0 / 1
  * forced; the host maps KSW2AMD_LDSCODES / KSW2AMD_LDSROWS onto it) and is reported by k2a_shim_pk_form / k2a_shim_mp_form, so
  * that tests can pin each form against the oracle and check which one an unforced launch took. */
@@ -1416,9 +1417,13 @@ static int g_opt[K2A_NOPT] = { -1, -1 };
 
 /* code planes in LDS: worth it once SIMDs would hold a third wavefront (a pooled batch launches chunks of two wavefronts
  * per SIMD side by side) */
-static bool k2a_use_ldscodes(int waves)
+static bool k2a_use_ldscodes(int waves, int G)
 {
 	if (g_opt[K2A_OPT_LDSCODES] >= 0) return g_opt[K2A_OPT_LDSCODES] != 0;
+	/* (8, 18) -- config 2's geometry -- goes from two to three wavefronts per SIMD this way (224 -> 168 registers) and LOSES:
+	 * 65 536 pairs of 512 x 512 are 4 096 wavefronts, two full rounds of two per SIMD but 1.33 rounds of three, and the LDS
+	 * reads are not free at that occupancy: 2 751 against 2 859 GCUPS (round 3, same box).  Forced form only (tests, A/B). */
+	if (G == 8) return false;
 	return 2 * (long)waves >= 3 * (long)k2a_shim_simd_count();
 }
 
@@ -1444,8 +1449,9 @@ void k2a_shim_set_option(int opt, int value) { if (opt >= 0 && opt < K2A_NOPT) g
 int k2a_shim_pk_form(int cfg, int dual, int mode, int nomax, int ntasks)
 {
 	if (cfg < 0 || cfg >= K2A_NPKCFG) return 0;
-	if (K2A_PK_LDSROWS(k2a_pkcfg_G[cfg], k2a_pkcfg_C[cfg], dual, mode, nomax) && k2a_use_ldsrows(ntasks)) return 1;
-	if (K2A_PK_LDSCODES(k2a_pkcfg_G[cfg], k2a_pkcfg_C[cfg], dual, mode, nomax) && k2a_use_ldscodes(ntasks)) return 2;
+	const int per_wave = 64 / k2a_pkcfg_G[cfg], waves = (ntasks + per_wave - 1) / per_wave;
+	if (K2A_PK_LDSROWS(k2a_pkcfg_G[cfg], k2a_pkcfg_C[cfg], dual, mode, nomax) && k2a_use_ldsrows(waves)) return 1;
+	if (K2A_PK_LDSCODES(k2a_pkcfg_G[cfg], k2a_pkcfg_C[cfg], dual, mode, nomax) && k2a_use_ldscodes(waves, k2a_pkcfg_G[cfg])) return 2;
 	return 0;
 }
 
@@ -1570,7 +1576,7 @@ int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax,
 	const int blocks = (ntasks + per_block - 1) / per_block;
 	const int form = k2a_shim_pk_form(cfg, dual, mode, nomax, ntasks);
 	const bool lds = form == 1, ldc = form == 2;
-	hipLaunchKernelGGL(lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1] : ldc ? g_fill_pk_ldscodes[nomax ? 1 : 0][rebased ? 1 : 0] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
+	hipLaunchKernelGGL(lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1] : ldc ? g_fill_pk_ldscodes[k2a_pkcfg_G[cfg] == 8 ? 1 : k2a_pkcfg_G[cfg] == 16 ? 2 : 0][nomax ? 1 : 0][rebased ? 1 : 0] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
 	                   *sc, pairs, order2, ntasks, seq, tb, res);
 	CHECK(hipGetLastError());
 	return 0;

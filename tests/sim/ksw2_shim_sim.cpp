@@ -155,7 +155,7 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 			for (int lane = 0; lane < 64; ++lane) {
 				if (L[lane].need_init(k)) {
 					L[lane].do_init(sc, bsA[lane], bsB[lane]);
-					if (k & 3) L[lane].load_query_group(k & ~3, L[lane].koff, L[lane].qwA, L[lane].qwB);
+					if (k & 3) L[lane].reload_query_group(k);
 				}
 				L[lane].hu_prev = hin[lane];
 				if (RB) {
@@ -358,8 +358,9 @@ static const fill_pk_fn g_fill_pk[2][2][K2A_NPKCFG][2][3] = { PK_SET(false), PK_
 static const fill_pk_fn g_fill_pk_lds[2][2] = {
 	{ sim_fill_pk<64, 16, true, 1, false, false, 1>, sim_fill_pk<64, 16, true, 2, false, false, 1> },
 	{ sim_fill_pk<64, 16, true, 1, true, false, 1>,  sim_fill_pk<64, 16, true, 2, true, false, 1> } };
-static const fill_pk_fn g_fill_pk_ldscodes[2][2] = { { sim_fill_pk<64, 16, false, 0, false, false, 2>, sim_fill_pk<64, 16, false, 0, true, false, 2> },
-                                                     { sim_fill_pk<64, 16, false, 0, false, true, 2>,  sim_fill_pk<64, 16, false, 0, true, true, 2> } };      /* [nomax][rebased] */
+#define LDSCODE_SET(G, C) { { sim_fill_pk<G, C, false, 0, false, false, 2>, sim_fill_pk<G, C, false, 0, true, false, 2> }, \
+                            { sim_fill_pk<G, C, false, 0, false, true, 2>,  sim_fill_pk<G, C, false, 0, true, true, 2> } }
+static const fill_pk_fn g_fill_pk_ldscodes[3][2][2] = { LDSCODE_SET(64, 16), LDSCODE_SET(8, 18), LDSCODE_SET(16, 8) };      /* [geometry][nomax][rebased] */
 /* launch-time forms (ksw2_shim.h): the simulator takes the LDS forms unless the option says 0 (the GPU launcher decides by the
  * number of tasks when the option is -1) */
 static int g_opt[K2A_NOPT] = { -1, -1 };
@@ -943,7 +944,7 @@ int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax,
 {
 	const int form = k2a_shim_pk_form(cfg, dual, mode, nomax, ntasks);
 	const bool lds = form == 1, ldc = form == 2;
-	if (ntasks > 0) (lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1] : ldc ? g_fill_pk_ldscodes[nomax ? 1 : 0][rebased ? 1 : 0] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode])(*sc, pairs, order2, ntasks, seq, tb, res);
+	if (ntasks > 0) (lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1] : ldc ? g_fill_pk_ldscodes[k2a_pkcfg_G[cfg] == 8 ? 1 : k2a_pkcfg_G[cfg] == 16 ? 2 : 0][nomax ? 1 : 0][rebased ? 1 : 0] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode])(*sc, pairs, order2, ntasks, seq, tb, res);
 	return 0;
 }
 int k2a_shim_launch_trace_pk(int cfg, int dual, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb,

@@ -686,10 +686,11 @@ def test_row_state_in_registers_and_in_lds(lib, lds, monkeypatch):
 
 @pytest.mark.parametrize("ldc", ["0", "1"])
 def test_code_planes_in_registers_and_in_lds(lib, ldc, monkeypatch):
-    """KSW2AMD_LDSCODES=0 / 1 forces the launcher's choice for the score-only packed kernels of the (64, 16) geometry: target-code
-    planes in registers / in LDS.  =1 runs k2a_fill_pk_kernel<64, 16, false, 0, RB, NOMAX, 2> -- all four g_fill_pk_ldscodes
-    entries, among them the kernel the headline benchmark times -- against the oracle: plain and re-based, exact and
-    KSW_EZ_APPROX_MAX, Z-drop on / off, shapes in pairs, triples and singles; the plan reports the form it will launch."""
+    """KSW2AMD_LDSCODES=0 / 1 forces the launcher's choice for the score-only packed kernels of the (64, 16) and (8, 18)
+    geometries: target-code planes in registers / in LDS.  =1 runs k2a_fill_pk_kernel<G, C, false, 0, RB, NOMAX, 2> -- all eight
+    g_fill_pk_ldscodes entries, among them the kernels the headline benchmark and config 2 time -- against the oracle: plain and
+    re-based, exact and KSW_EZ_APPROX_MAX, Z-drop on / off, shapes in pairs, triples and singles; the plan reports the form it
+    will launch."""
     from tests.test_sim_parity import _check_code_plane_forms
     monkeypatch.setenv("KSW2AMD_LDSCODES", ldc)
     for seed in (31, 32, 33):

@@ -484,47 +484,48 @@ def test_sim_row_state_in_registers_and_in_lds(sim, lds, monkeypatch):
 
 
 def _code_plane_batches(rng, scale=1.0):
-    """Score-only batches for the packed (64, 16) geometry (band 285..536 on targets of more than 512 rows), which is where the
-    launcher may keep the target-code planes in LDS: plain (short reads) and re-based (long reads) number format, exact and
-    KSW_EZ_APPROX_MAX launches, Z-drop on / off, extension flags; shapes in twos and threes (tasks pair up, a leftover is paired
-    with itself) plus a few reads of unique shape.  Yields (qs, ts, w, zdrop, end_bonus, flag, rebased, nomax)."""
-    for rebased in (False, True):
-        for nomax in (False, True):
-            qs, ts, ws = [], [], []
-            for k in range(5):
-                ql = int(rng.integers(5000, 9000) * scale) if rebased else int(rng.integers(600, 2600))
-                tl = max(520, ql + int(rng.integers(-40, 40)))
-                w = int(rng.choice([285, 300, 400, 500, 536]))
-                q, t = synth.fixed_batch(5100 + 10 * rebased + k, 2 + k % 2, ql, tl, sub=0.05, ind=0.08, tail_random_frac=0.3, tail_pairs=0.4)
-                qs += list(q); ts += list(t); ws += [w] * len(q)
-            n = len(qs)
-            zd = rng.choice([-1, 100, 400, 2000], size=n)
-            eb = rng.choice([0, 50], size=n)
-            fl = np.array([po.SCORE_ONLY | (0x08 if nomax else 0) | (po.EXTZ_ONLY if rng.random() < 0.3 else 0) for _ in range(n)])
-            yield qs, ts, np.array(ws), zd, eb, fl, rebased, nomax
+    """Score-only batches for the two packed geometries whose launcher may keep the target-code planes in LDS -- (64, 16): band
+    285..536 on targets of more than 512 rows; (8, 18): band up to 67; (16, 8): band 68 -- in the plain (short reads) and the re-based (long reads)
+    number format, exact and KSW_EZ_APPROX_MAX launches, Z-drop on / off, extension flags; shapes in twos and threes (tasks pair up,
+    a leftover is paired with itself).  Yields (qs, ts, w, zdrop, end_bonus, flag, (G, C), rebased, nomax)."""
+    for geom in ((64, 16), (8, 18), (16, 8)):
+        for rebased in (False, True):
+            for nomax in (False, True):
+                qs, ts, ws = [], [], []
+                for k in range(5):
+                    ql = int(rng.integers(5000, 9000) * scale) if rebased else int(rng.integers(600, 2600) if geom[0] == 64 else rng.integers(30, 1500))
+                    tl = max(520 if geom[0] == 64 else 1, ql + int(rng.integers(-40, 40)))
+                    w = int(rng.choice([285, 300, 400, 500, 536] if geom[0] == 64 else [0, 1, 7, 20, 40, 64, 67] if geom[0] == 8 else [68]))
+                    q, t = synth.fixed_batch(5100 + 10 * rebased + k, 2 + k % 2, ql, tl, sub=0.05, ind=0.08 if geom[0] == 64 else 0.02, tail_random_frac=0.3, tail_pairs=0.4)
+                    qs += list(q); ts += list(t); ws += [w] * len(q)
+                n = len(qs)
+                zd = rng.choice([-1, 100, 400, 2000], size=n)
+                eb = rng.choice([0, 50], size=n)
+                fl = np.array([po.SCORE_ONLY | (0x08 if nomax else 0) | (po.EXTZ_ONLY if rng.random() < 0.3 else 0) for _ in range(n)])
+                yield qs, ts, np.array(ws), zd, eb, fl, geom, rebased, nomax
 
 
 def _check_code_plane_forms(lib, form, scale=1.0, seed=31):
-    """All four instantiations behind g_fill_pk_ldscodes (plain / re-based x exact / no-maximum) or their register twins,
-    whichever `form` the caller forced, against the oracle; the plan must report exactly that form."""
+    """All twelve instantiations behind g_fill_pk_ldscodes ((64, 16) / (8, 18) / (16, 8) x plain / re-based x exact / no-maximum) or their
+    register twins, whichever `form` the caller forced, against the oracle; the plan must report exactly that form."""
     rng = np.random.Generator(np.random.PCG64(seed))
     mat, q, e = synth.simple_mat(5, 2, 4, -1), 4, 2
     seen = set()
-    for qs, ts, w, zd, eb, fl, rebased, nomax in _code_plane_batches(rng, scale):
+    for qs, ts, w, zd, eb, fl, geom, rebased, nomax in _code_plane_batches(rng, scale):
         p = lib.make_batch(qs, ts, mat, q, e, 0, 0, w=w, zdrop=zd, end_bonus=eb, flag=fl).plan(False)
         for c in p.describe():
-            if c["kernel"] == "pk" and (c["G"], c["C"], c["mode"]) == (64, 16, "score"):
+            if c["kernel"] == "pk" and (c["G"], c["C"]) == geom and c["mode"] == "score":
                 assert c["form"] == form, c
-                seen.add((c["rebased"], c["nomax"]))
+                seen.add((c["G"], c["rebased"], c["nomax"]))
         p.close()
         check_batch(lib, False, qs, ts, mat, q, e, 0, 0, w=w, zdrop=zd, end_bonus=eb, flag=fl)
-    assert seen == {(0, 0), (0, 1), (1, 0), (1, 1)}, seen
+    assert seen == {(g, r, m) for g in (64, 8, 16) for r in (0, 1) for m in (0, 1)}, seen
 
 
 @pytest.mark.parametrize("ldc", ["0", "1"])
 def test_sim_code_planes_in_registers_and_in_lds(sim, ldc, monkeypatch):
-    """KSW2AMD_LDSCODES=0 / 1: the exact and no-maximum score-only kernels of the 16-row geometry with the target-code planes in
-    registers / in LDS (the form the headline benchmark runs), plain and re-based."""
+    """KSW2AMD_LDSCODES=0 / 1: the exact and no-maximum score-only kernels of the (64, 16) and (8, 18) geometries with the target-code
+    planes in registers / in LDS (the forms the headline benchmark and config 2 run), plain and re-based."""
     monkeypatch.setenv("KSW2AMD_LDSCODES", ldc)
     _check_code_plane_forms(sim, "ldscodes" if ldc == "1" else "registers", scale=0.6)
 
