@@ -217,13 +217,34 @@ class Job:
         self.weff = np.where((wl["w"] < 0) | (wl["w"] > mx), mx, wl["w"]) if self.kind in ("extz", "extd", "extf") else mx
         self.cells = int(cells_of_rows(self.qlen, self.tlen, self.weff).sum()) if self.kind != "exts" else int((self.qlen * self.tlen).sum())
         self.ez = None
+        self.fbatch = None
+
+    def flat_ready(self, register=True):
+        """The same pairs as ONE arena + offsets (ksw2amd_flat_t), page-locked once like a caller's reusable read buffer."""
+        if self.kind not in ("extz", "extd") or self.sse:
+            return False
+        if self.fbatch is None:
+            wl, S = self.wl, SCORING
+            self.fbatch = self.lib.make_flat_batch(self.q, self.t, self.mat, S["q"], S["e"], S["q2"], S["e2"], w=wl["w"], zdrop=wl["zdrop"], end_bonus=0, flag=wl["flag"])
+            if register and not os.environ.get("KSW2_BENCH_NO_REGISTER"):
+                self.fbatch.register()
+        return True
+
+    def flat_done(self):
+        if self.fbatch is not None:
+            self.fbatch.unregister()
+            self.fbatch = None
 
     # ---- transfer-inclusive: one call of the batch entry point per step
-    def e2e_step(self):
+    def e2e_step(self, flat=False):
         b, L = self.batch, self.lib
         if self.ez is None:
             self.ez = (ksw2_amd.KswExtz * max(self.n, 1))()     # reused across steps like a caller would: CIGAR buffers are recycled
-        if self.kind == "exts":
+        if flat:
+            fb = self.fbatch
+            f = L.lib.ksw2amd_extd_batch_flat if self.kind == "extd" else L.lib.ksw2amd_extz_batch_flat
+            L._check(f(None, ctypes.byref(fb.sc), fb.n, ctypes.byref(fb.flat), self.ez))
+        elif self.kind == "exts":
             L._check(L.lib.ksw2amd_exts_batch(None, ctypes.byref(b.sc), b.n, b.pairs, self.ez))
         elif self.kind == "extf":
             L._check(L.lib.ksw2amd_extf_batch(None, *b.par, b.n, b.pairs, self.ez))
@@ -466,6 +487,24 @@ def main():
     else:
         cells_all, pairs_all = float(job.cells), job.n
     parity = job.parity_sample(16) if rank == 0 else None      # outside the timed region: the results the timed calls returned
+    # the same K steps through the flat entry point (one arena + offsets, page-locked once): what a caller that owns its read
+    # buffer would use.  Timed exactly like the loop above.
+    dt_flat = None
+    if job.flat_ready():
+        for _ in range(max(1, min(args.warmup, 2))):
+            job.e2e_step(flat=True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            job.e2e_step(flat=True)
+        barrier()
+        dt_flat = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt_flat], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_flat = float(tt.item())
+        parity_flat = job.parity_sample(8) if rank == 0 else None
+        job.flat_done()
     job.free_ez()
     lib.release_cache()
     barrier()
@@ -488,6 +527,9 @@ def main():
             "value_definition": "exact-band cells of all pairs / wall time of `steps` calls of the batch entry point on host-memory inputs: "
                                 "pack + H2D + kernels + D2H + ksw_extz_t assembly (SURVEY 8d)",
             "value_hbm_resident": rl["kernel_gcups"],
+            "value_flat_arena": round(cells_all * args.steps / dt_flat / 1e9, 3) if dt_flat else None,
+            "value_flat_arena_definition": "the same steps through ksw2amd_ext?_batch_flat: the batch as one page-locked host arena + offsets (no per-pair gather, "
+                                           "no host pass over the bytes); transfer-inclusive like `value`" if dt_flat else None,
             "pairs_per_s": round(pairs_all * args.steps / dt, 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "timed_region_s": round(dt, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_of(job, res), "data": "synthetic",
@@ -497,6 +539,8 @@ def main():
             "roofline": rl,
             "parity_sample": parity["result"], "parity_detail": parity,
         }
+        if dt_flat:
+            out["parity_sample_flat_arena"] = parity_flat["result"]
         if sg:
             out["config"]["rank0_scatter_gather"] = sg
     # ------------------------------------------------------------------ the other configurations (N = 1: one run covers them all)
@@ -518,12 +562,25 @@ def main():
                 k += 1
             edt = time.perf_counter() - t0
             jpar = j.parity_sample(1 if WORKLOADS[name].get("mt") else 6)
+            vflat = None
+            if j.flat_ready():
+                j.e2e_step(flat=True)
+                j.e2e_step(flat=True)
+                t0 = time.perf_counter()
+                kf = 0
+                while kf < 3 or time.perf_counter() - t0 < 1.5:
+                    j.e2e_step(flat=True)
+                    kf += 1
+                vflat = round(j.cells * kf / (time.perf_counter() - t0) / 1e9, 2)
+                jparf = j.parity_sample(1 if WORKLOADS[name].get("mt") else 4)
+                j.flat_done()
             j.free_ez()
             lib.release_cache()
             r = j.resident(3, 1, stream, min_seconds=1.0)
             lib.release_cache()
             rr = roofline_of(j, r, name)
-            also.append({"workload": describe(j, world), "value": round(j.cells * k / edt / 1e9, 2), "value_hbm_resident": rr["kernel_gcups"],
+            also.append({"workload": describe(j, world), "value": round(j.cells * k / edt / 1e9, 2), "value_flat_arena": vflat, "value_hbm_resident": rr["kernel_gcups"],
+                         **({"parity_sample_flat_arena": jparf["result"]} if vflat else {}),
                          "unit": "GCUPS", "pairs_per_s": round(j.n * k / edt, 1), "steps": k, "ms_per_step": round(edt / k * 1e3, 3),
                          "dtype": dtype_of(j, r), "parity_sample": "%s (%d pairs)" % (jpar["result"], jpar["pairs"]),
                          "roofline": {x: rr[x] for x in ("frac", "kernel_ms", "fill_kernel_ms", "ops_per_cell", "pairs_per_launch", "kernels",

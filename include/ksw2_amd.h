@@ -26,6 +26,7 @@
 #define KSW2_AMD_H_
 
 #include <stdint.h>
+#include <stddef.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -177,6 +178,32 @@ void ksw2amd_host_stats(int64_t out[4]);
 int ksw2amd_extz_batch(void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez);
 int ksw2amd_extd_batch(void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez);
 
+/* Flat batches (new; no reference counterpart): every sequence of the batch lies in ONE arena and a pair is two offsets and two
+ * lengths -- what a caller that reads its sequences into a buffer has anyway.  The library then uploads the arena's span as it
+ * is (one copy instead of 2 n gathers into staging; asynchronous and at link rate if the arena is page-locked, ksw2amd_host_register)
+ * and never walks over the bytes on the host: a pair with a wildcard code in a packed-int16 kernel is reported by the kernel
+ * and run again through the int32 kernels.  `on_device` != 0: `base` is device memory (a hipMalloc'ed arena of the calling
+ * thread's device, e.g. a shard that RCCL delivered): no upload at all.  Per-pair arrays w / zdrop / end_bonus / flag may be NULL:
+ * the *_all value then applies to every pair.  Results are those of the ordinary entry points on the same pairs. */
+typedef struct {
+	const uint8_t *base;                  /* the arena */
+	const uint64_t *qoff, *toff;          /* [n] byte offsets of query / target in the arena (one plan spans at most 4 GiB of it) */
+	const int32_t *qlen, *tlen;           /* [n] */
+	const int32_t *w, *zdrop, *end_bonus, *flag;      /* [n] or NULL */
+	int32_t w_all, zdrop_all, end_bonus_all, flag_all;
+	int32_t on_device;
+} ksw2amd_flat_t;
+int ksw2amd_extz_batch_flat(void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_flat_t *in, ksw_extz_t *ez);
+int ksw2amd_extd_batch_flat(void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_flat_t *in, ksw_extz_t *ez);
+/* device memory of the calling thread's device for a device-resident arena, without linking the HIP runtime (synchronous copies) */
+void *ksw2amd_device_alloc(size_t bytes);
+void  ksw2amd_device_free(void *d);
+int   ksw2amd_device_upload(void *dst, const void *src, size_t bytes);
+int   ksw2amd_device_download(void *dst, const void *src, size_t bytes);
+/* page-lock / release caller memory (an arena that is reused from batch to batch): uploads from it need no staging copy */
+int ksw2amd_host_register(const void *p, size_t bytes);
+int ksw2amd_host_unregister(const void *p);
+
 /* SSE-compatible mode (opt-in).  By default the "...2_sse" functions above return the exact-band, row-wise results of the
  * scalar ksw_extz / ksw_extd (the contract).  The reference's SSE kernels differ from that where their
  * 16-position blocks leak across the band edge, in their anti-diagonal Z-drop, in mte_q, in tie order.  A
@@ -219,6 +246,8 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 int  ksw2amd_plan_run(ksw2amd_plan_t *plan, void *stream);
 int  ksw2amd_plan_fetch(ksw2amd_plan_t *plan, void *km, ksw_extz_t *ez);
 void ksw2amd_plan_destroy(ksw2amd_plan_t *plan);
+/* a resident plan from a flat batch (host or device arena); run / fetch / timing / cells / destroy as below */
+ksw2amd_plan_t *ksw2amd_plan_create_flat(int dual, const ksw2amd_scoring_t *sc, int n, const ksw2amd_flat_t *in);
 /* device time of the last ksw2amd_plan_run (HIP events on its stream), fill kernels only / fill + traceback; ms */
 int  ksw2amd_plan_timing(ksw2amd_plan_t *plan, float *fill_ms, float *total_ms);
 /* in-band DP cells of the plan (exact band, all rows counted even if Z-drop stops early) and device bytes held */

@@ -55,6 +55,14 @@ class Pair(ctypes.Structure):
                 ("w", ctypes.c_int32), ("zdrop", ctypes.c_int32), ("end_bonus", ctypes.c_int32), ("flag", ctypes.c_int32)]
 
 
+class Flat(ctypes.Structure):
+    """ksw2amd_flat_t: one arena + offsets (include/ksw2_amd.h)."""
+    _fields_ = [("base", ctypes.c_void_p), ("qoff", ctypes.c_void_p), ("toff", ctypes.c_void_p), ("qlen", ctypes.c_void_p), ("tlen", ctypes.c_void_p),
+                ("w", ctypes.c_void_p), ("zdrop", ctypes.c_void_p), ("end_bonus", ctypes.c_void_p), ("flag", ctypes.c_void_p),
+                ("w_all", ctypes.c_int32), ("zdrop_all", ctypes.c_int32), ("end_bonus_all", ctypes.c_int32), ("flag_all", ctypes.c_int32),
+                ("on_device", ctypes.c_int32)]
+
+
 _u8p = ctypes.POINTER(ctypes.c_uint8)
 _i8p = ctypes.POINTER(ctypes.c_int8)
 _i8 = ctypes.c_int8
@@ -70,14 +78,16 @@ EXPORTS = ["ksw_extz2_sse", "ksw_extd2_sse", "ksw_gg2", "ksw_gg2_sse", "ksw_extz
            "ksw2amd_plan_fetch_raw", "ksw_exts2_sse", "ksw_exts2_sse41", "ksw_exts2_sse2", "ksw2amd_exts_batch", "ksw2amd_exts_plan_create",
            "ksw_extf2_sse", "ksw2amd_extf_batch", "ksw2amd_extf_plan_create",
            "ksw2amd_set_devices", "ksw2amd_set_error_handler", "ksw2amd_error_count", "ksw2amd_host_stats",
-           "ksw2amd_set_sse_compat", "ksw2amd_sse_plan_create", "ksw2amd_plan_describe", "ksw2amd_reload_env"]
+           "ksw2amd_set_sse_compat", "ksw2amd_sse_plan_create", "ksw2amd_plan_describe", "ksw2amd_reload_env",
+           "ksw2amd_extz_batch_flat", "ksw2amd_extd_batch_flat", "ksw2amd_plan_create_flat", "ksw2amd_host_register", "ksw2amd_host_unregister",
+           "ksw2amd_device_alloc", "ksw2amd_device_free", "ksw2amd_device_upload", "ksw2amd_device_download"]
 # entry points whose behaviour depends on KSW2AMD_* switches: the library reads its environment once per process, so this binding
 # re-reads it in front of each of them (tests and A/B scripts flip switches inside one process)
 _ENV_ENTRIES = ["ksw_extz2_sse", "ksw_extd2_sse", "ksw_gg2", "ksw_gg2_sse", "ksw_extz", "ksw_extd", "ksw_gg", "ksw_extz2_sse41",
                 "ksw_extz2_sse2", "ksw_extd2_sse41", "ksw_extd2_sse2", "ksw_exts2_sse", "ksw_exts2_sse41", "ksw_exts2_sse2", "ksw_extf2_sse",
                 "ksw2amd_extz_batch", "ksw2amd_extd_batch", "ksw2amd_exts_batch", "ksw2amd_extf_batch", "ksw2amd_plan_create",
                 "ksw2amd_sse_plan_create", "ksw2amd_exts_plan_create", "ksw2amd_extf_plan_create", "ksw2amd_plan_run",
-                "ksw2amd_plan_describe"]
+                "ksw2amd_plan_describe", "ksw2amd_extz_batch_flat", "ksw2amd_extd_batch_flat", "ksw2amd_plan_create_flat"]
 ERROR_FN = ctypes.CFUNCTYPE(None, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_void_p)
 KSW_EZ_SPLICE_FOR, KSW_EZ_SPLICE_REV, KSW_EZ_SPLICE_FLANK = 0x100, 0x200, 0x400
 
@@ -172,6 +182,19 @@ class Library:
         L.ksw2amd_host_stats.argtypes = [ctypes.POINTER(ctypes.c_int64)]
         L.ksw2amd_host_stats.restype = None
         L.ksw2amd_plan_describe.argtypes = [ctypes.c_void_p, ctypes.c_char_p, _int]
+        fl = [km, ctypes.POINTER(Scoring), _int, ctypes.POINTER(Flat), ezp]
+        L.ksw2amd_extz_batch_flat.argtypes = fl
+        L.ksw2amd_extd_batch_flat.argtypes = fl
+        L.ksw2amd_plan_create_flat.argtypes = [_int, ctypes.POINTER(Scoring), _int, ctypes.POINTER(Flat)]
+        L.ksw2amd_plan_create_flat.restype = ctypes.c_void_p
+        L.ksw2amd_host_register.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        L.ksw2amd_host_unregister.argtypes = [ctypes.c_void_p]
+        L.ksw2amd_device_alloc.argtypes = [ctypes.c_size_t]
+        L.ksw2amd_device_alloc.restype = ctypes.c_void_p
+        L.ksw2amd_device_free.argtypes = [ctypes.c_void_p]
+        L.ksw2amd_device_free.restype = None
+        L.ksw2amd_device_upload.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        L.ksw2amd_device_download.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
         L.ksw2amd_reload_env.restype = None
         reload_env = L.ksw2amd_reload_env
 
@@ -215,6 +238,18 @@ class Library:
     def set_sse_compat(self, on):
         """ksw2amd_set_sse_compat: process-wide, every extz2 / extd2 call returns what the reference's SSE kernels return."""
         self.lib.ksw2amd_set_sse_compat(1 if on else 0)
+
+    def device_copy(self, array):
+        """ksw2amd_device_alloc + ksw2amd_device_upload: a device copy of a numpy array; returns its address (free with device_free)."""
+        a = np.ascontiguousarray(array)
+        d = self.lib.ksw2amd_device_alloc(a.nbytes + 16)
+        if not d:
+            raise Ksw2Error("device_alloc failed: " + self.last_error())
+        self._check(self.lib.ksw2amd_device_upload(d, a.ctypes.data, a.nbytes))
+        return d
+
+    def device_free(self, d):
+        self.lib.ksw2amd_device_free(d)
 
     def host_stats(self):
         """ksw2amd_host_stats -> dict(pool_batches, pool_chunks, coalesced_calls, coalesced_batches)."""
@@ -331,6 +366,11 @@ class Library:
         b = self.make_batch(queries, targets, mat, q, e, 0, 0, **kw)
         return b.run_oneshot(dual=False)
 
+    def make_flat_batch(self, queries, targets, mat, q, e, q2=0, e2=0, w=-1, zdrop=-1, end_bonus=0, flag=0, m=None, device_base=None):
+        """ksw2amd_flat_t over one arena: the sequences concatenated in pair order (q0 t0 q1 t1 ...).  device_base: address of a
+        device copy of that arena (then the plan / batch never touches the host copy)."""
+        return FlatBatch(self, queries, targets, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, m, device_base)
+
     def extd_batch(self, queries, targets, mat, q, e, q2, e2, **kw):
         b = self.make_batch(queries, targets, mat, q, e, q2, e2, **kw)
         return b.run_oneshot(dual=True)
@@ -394,6 +434,58 @@ class Batch:
     def sse_plan(self, dual):
         """ksw2amd_sse_plan_create: every pair through the SSE-compatible kernels."""
         return Plan(self, dual, handle=self.L.lib.ksw2amd_sse_plan_create(1 if dual else 0, ctypes.byref(self.sc), self.n, self.pairs))
+
+
+class FlatBatch:
+    """Host-side description of n pairs as ONE arena + offsets (ksw2amd_flat_t); same results as Batch on the same pairs."""
+
+    def __init__(self, lib, queries, targets, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, m, device_base=None):
+        self.L = lib
+        self.n = n = len(queries)
+        if isinstance(queries, np.ndarray) and queries.ndim == 2 and isinstance(targets, np.ndarray) and targets.ndim == 2:
+            ql, tl = queries.shape[1], targets.shape[1]
+            self.arena = np.ascontiguousarray(np.concatenate([queries, targets], axis=1), dtype=np.uint8).reshape(-1)
+            self.qoff = (np.arange(n, dtype=np.uint64) * np.uint64(ql + tl))
+            self.toff = self.qoff + np.uint64(ql)
+            self.qlen = np.full(n, ql, dtype=np.int32)
+            self.tlen = np.full(n, tl, dtype=np.int32)
+        else:
+            qs = [np.ascontiguousarray(x, dtype=np.uint8) for x in queries]
+            ts = [np.ascontiguousarray(x, dtype=np.uint8) for x in targets]
+            self.qlen = np.array([len(x) for x in qs], dtype=np.int32)
+            self.tlen = np.array([len(x) for x in ts], dtype=np.int32)
+            lens = np.empty(2 * n, dtype=np.uint64)
+            lens[0::2], lens[1::2] = self.qlen, self.tlen
+            offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+            self.qoff, self.toff = offs[0:2 * n:2].copy(), offs[1:2 * n:2].copy()
+            parts = [None] * (2 * n)
+            parts[0::2], parts[1::2] = qs, ts
+            self.arena = np.concatenate(parts + [np.zeros(1, np.uint8)]).astype(np.uint8) if n else np.zeros(1, np.uint8)
+        self.per = [np.ascontiguousarray(_per_pair(v, n), dtype=np.int32) for v in (w, zdrop, end_bonus, flag)]
+        self.mat = np.ascontiguousarray(mat, dtype=np.int8)
+        self.sc = Scoring(int(round(len(self.mat) ** 0.5)) if m is None else m, self.mat.ctypes.data_as(_i8p), q, e, q2, e2)
+        self.flat = Flat(device_base if device_base is not None else self.arena.ctypes.data, self.qoff.ctypes.data, self.toff.ctypes.data,
+                         self.qlen.ctypes.data, self.tlen.ctypes.data, *[a.ctypes.data for a in self.per], 0, 0, 0, 0, 1 if device_base is not None else 0)
+        self.registered = False
+
+    def register(self):
+        """ksw2amd_host_register: page-lock the arena (a caller that reuses its buffer does this once)."""
+        self.L._check(self.L.lib.ksw2amd_host_register(self.arena.ctypes.data, self.arena.nbytes))
+        self.registered = True
+
+    def unregister(self):
+        if self.registered:
+            self.L.lib.ksw2amd_host_unregister(self.arena.ctypes.data)
+            self.registered = False
+
+    def run_oneshot(self, dual):
+        ez = (KswExtz * max(self.n, 1))()
+        f = self.L.lib.ksw2amd_extd_batch_flat if dual else self.L.lib.ksw2amd_extz_batch_flat
+        self.L._check(f(None, ctypes.byref(self.sc), self.n, ctypes.byref(self.flat), ez))
+        return [ez_to_dict(ez[i], free_cigar=True) for i in range(self.n)]
+
+    def plan(self, dual):
+        return Plan(self, dual, handle=self.L.lib.ksw2amd_plan_create_flat(1 if dual else 0, ctypes.byref(self.sc), self.n, ctypes.byref(self.flat)))
 
 
 class LinearBatch:

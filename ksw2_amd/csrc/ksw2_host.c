@@ -156,6 +156,25 @@ static void thread_owns_cache(void)
 }
 static void *thread_stream(void) { if (!g_stream) { thread_owns_cache(); g_stream = k2a_shim_stream_create(); } return g_stream; }
 static void *thread_upload_stream(void) { if (!g_up_stream) { thread_owns_cache(); g_up_stream = k2a_shim_stream_create(); } return g_up_stream; }
+/* Flat plans upload on ONE stream per device, shared by all host threads: their arena spans go up at link rate one after the
+ * other, in the order the plans were created, so the first chunk of a pooled batch is on the device after 1 / nchunks of the
+ * batch's upload time and its kernels run under the remaining uploads.  (Six workers uploading on six streams share the link:
+ * every chunk arrives at the END of the total upload time -- config 2: 0.9 ms for each 8 MB chunk, then the kernels.) */
+#define SHARED_UP_MAXDEV 16
+static void *g_shared_up[SHARED_UP_MAXDEV];
+static pthread_mutex_t g_shared_up_mu = PTHREAD_MUTEX_INITIALIZER;
+static void *shared_upload_stream(void)
+{
+	const int dev = k2a_shim_get_device();
+	void *s;
+	if (dev < 0 || dev >= SHARED_UP_MAXDEV) return 0;
+	pthread_mutex_lock(&g_shared_up_mu);
+	if (!g_shared_up[dev]) g_shared_up[dev] = k2a_shim_stream_create();
+	s = g_shared_up[dev];
+	pthread_mutex_unlock(&g_shared_up_mu);
+	return s;
+}
+
 /* side streams + events for plans with several kernel classes: the classes are independent, and a class of a few long
  * alignments would otherwise hold the whole device for the duration of one alignment while the next class waits */
 #define NSIDE 3
@@ -288,6 +307,11 @@ struct ksw2amd_plan_s {
 	/* SSE-compatible plans (ksw2amd_sse_plan_create, splice == 3): tasks grouped by kernel mode in s_first / s_count[mode][0][0] */
 	K2aSsec c_par;
 	size_t c_lds[3];               /* SSE-compatible plans: per-wavefront LDS bytes of the tasks whose state fits LDS, per mode (0 = none) */
+	/* flat plans (ksw2amd_plan_create_flat): the sequences went up as they lie in the caller's arena -- no staging copy, no host
+	 * scan for wildcard codes; the packed kernels report such codes and fetch re-runs those pairs (flat_rerun) */
+	int flat, flat_device, scalar;         /* flat: h_seq (host arenas) is the caller's memory, not a staging buffer */
+	ksw2amd_pair_t *src_pairs;             /* the caller's pairs (pointers into the arena), kept for the re-runs */
+	ksw2amd_scoring_t src_sc; int8_t *src_mat;
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -465,7 +489,8 @@ void ksw2amd_plan_destroy(ksw2amd_plan_t *p)
 	for (i = 0; i < 3; ++i) if (p->ev[i]) { if (!g_ev_cache[i]) g_ev_cache[i] = p->ev[i]; else k2a_shim_event_destroy(p->ev[i]); }
 	free(p->h_pairs); free(p->h_cls); free(p->h_half); free(p->h_flag); free(p->h_order);
 	cache_put(BUF_HRES, p->h_res, p->cap[BUF_HRES]);          /* pinned: the results come back with one asynchronous copy */
-	cache_put(BUF_HSEQ, p->h_seq, p->cap[BUF_HSEQ]);
+	if (!p->flat) cache_put(BUF_HSEQ, p->h_seq, p->cap[BUF_HSEQ]);      /* (a flat plan's h_seq is the caller's arena) */
+	free(p->src_pairs); free(p->src_mat);
 	free(p);
 }
 
@@ -489,13 +514,30 @@ static int parallel_copy(copy_ctx_t *c, int n, size_t bytes);
 static double now_ms(void);
 static int trace_level(void) { const char *e = ENV(TRACE); return e ? atoi(e) : 0; }
 
-static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs)
+/* `flat`: the pairs' query / target pointers all lie in ONE arena, in host memory or (flat->on_device) in device memory.  The plan
+ * then uploads (or copies on the device) the arena's span as it is and addresses the sequences where they lie: no per-pair gather,
+ * no staging copy, no host pass over the bytes.  What the gather pass also did was to look for wildcard codes (the packed kernels
+ * cannot score them): flat plans leave that to the packed kernels themselves (K2aLanePk::seen) and re-run what they report. */
+typedef struct { int on_device; } flat_src_t;
+static int pair_has_wild(const ksw2amd_pair_t *a)
+{
+	uint64_t acc = 0;
+	int i;
+	for (i = 0; i < a->qlen; ++i) acc |= a->query[i];
+	for (i = 0; i < a->tlen; ++i) acc |= a->target[i];
+	return (acc & 0xfc) != 0;
+}
+
+static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, const flat_src_t *flat)
 {
 	double tph[6] = { 0, 0, 0, 0, 0, 0 };
 	const int tlev = trace_level() >= 2;
 	ksw2amd_plan_t *p;
 	int i, k, q, e, q2, e2, m, lo, ci;
-	size_t off, mat_off = 0;
+	size_t off, mat_off = 0, flat_span = 0;
+	const uint8_t *flat_lo = 0;
+	uint8_t *flat_tmp = 0;
+	int shared_up = 0;
 	void *up;
 	sort_t *srt = 0;
 	pkinfo_t pkinfo[2];
@@ -541,6 +583,46 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 
 	/* pass 0: sequence arena (query 4-aligned, target 16-aligned and readable one strip past its end) in pinned staging */
 	off = 0;
+	if (flat) {
+		/* the span of the caller's arena that holds this plan's sequences; offsets are taken from its first byte.  (The kernels
+		 * read sequences with byte and unaligned dword loads; what they read past a sequence's end is only ever seen by cells
+		 * outside the target / the band.) */
+		const uint8_t *lo = 0, *hi = 0;
+		size_t sum = 0;
+		for (i = 0; i < n; ++i) {
+			const ksw2amd_pair_t *a = &pairs[i];
+			if (a->qlen <= 0 || a->tlen <= 0) continue;
+			if (!a->query || !a->target) { fail(KSW2AMD_E_PARAM, "plan_create: NULL sequence%s", 0); goto err; }
+			if (!lo || a->query < lo) lo = a->query;
+			if (a->target < lo) lo = a->target;
+			if (a->query + a->qlen > hi) hi = a->query + a->qlen;
+			if (a->target + a->tlen > hi) hi = a->target + a->tlen;
+			sum += (size_t)a->qlen + (size_t)a->tlen;
+		}
+		off = lo ? (size_t)(hi - lo) : 0;
+		flat_lo = lo;
+		/* pairs scattered over the arena (the span goes up whole), or a span beyond the 32-bit offsets: gather instead */
+		if (off > 0xfff00000u || off > 4 * sum + ((size_t)1 << 20)) {
+			if (flat->on_device) { fail(KSW2AMD_E_PARAM, "plan_create_flat: the pairs of one plan span more than 4 GiB (or lie scattered) in the device arena%s", 0); goto err; }
+			flat = 0; off = 0;
+		}
+	}
+	if (flat) {
+		const uint8_t *lo = flat_lo;
+		for (i = 0; i < n; ++i) {
+			const ksw2amd_pair_t *a = &pairs[i];
+			if (a->qlen <= 0 || a->tlen <= 0) continue;
+			p->h_pairs[i].qoff = (uint32_t)(a->query - lo); p->h_pairs[i].toff = (uint32_t)(a->target - lo);
+		}
+		flat_span = off;
+		p->flat = 1; p->flat_device = flat->on_device; p->scalar = scalar;
+		p->src_pairs = (ksw2amd_pair_t*)malloc(sizeof(*pairs) * ((size_t)n + 1));
+		p->src_mat = (int8_t*)malloc((size_t)(m > 0 ? m * m : 1));
+		if (!p->src_pairs || !p->src_mat) { fail(KSW2AMD_E_NOMEM, "plan_create: host allocation failed%s", 0); goto err; }
+		memcpy(p->src_pairs, pairs, sizeof(*pairs) * (size_t)n);
+		memcpy(p->src_mat, sc->mat, (size_t)m * m);
+		p->src_sc = *sc; p->src_sc.mat = p->src_mat;
+	} else
 	for (i = 0; i < n; ++i) {
 		const ksw2amd_pair_t *a = &pairs[i];
 		if (a->qlen <= 0 || a->tlen <= 0) continue;                                                 /* ksw2_extz2_sse.c:57 */
@@ -552,8 +634,11 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	off = align_up(off + 65536, 256);               /* idle lanes may prefetch codes a few hundred bytes past the last pair */
 	if (m > 5) { mat_off = off; off = align_up(off + 2 * (size_t)m * m, 256); }   /* wide alphabets: effective matrices, simple | generic */
 	p->seq_bytes = off;
-	p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, p->seq_bytes, &p->cap[BUF_HSEQ]);
-	if (!p->h_seq) { fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
+	if (flat) p->h_seq = flat->on_device ? 0 : (uint8_t*)flat_lo;      /* borrowed: EQX rewrites and re-runs read the sequences there */
+	else {
+		p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, p->seq_bytes, &p->cap[BUF_HSEQ]);
+		if (!p->h_seq) { fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
+	}
 
 	if (tlev) tph[1] = now_ms();
 	/* pass 1: copy the codes; geometry class, traceback / CIGAR / boundary space, packed-int16 eligibility per pair */
@@ -564,7 +649,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	{
 		copy_ctx_t cc;
 		cc.h_seq = p->h_seq; cc.hp = p->h_pairs; cc.pairs = pairs; cc.wild = solo_ok;              /* (solo_ok doubles as the wildcard flags until the loop below sets it) */
-		if (!parallel_copy(&cc, n, p->seq_bytes)) copy_range(&cc, 0, n);
+		if (!flat && !parallel_copy(&cc, n, p->seq_bytes)) copy_range(&cc, 0, n);                   /* flat: nothing is copied, nothing scanned (wild = 0) */
 	}
 	for (i = 0; i < n; ++i) {
 		const ksw2amd_pair_t *a = &pairs[i];
@@ -602,12 +687,15 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 				    (plain || (use_rb && pk_window_ok(&pkinfo[generic], a->qlen, d->tlen, w, k2a_pkcfg_C[pc])))) break;
 			/* no resident geometry holds the band: the packed generation-serial class (sliding base), exact modes only */
 			if (pc == K2A_PKCFG_MP && !(cfg == K2A_CFG_MP && use_rb && use_pkmp && !is_approx(fl) && pk_slide_ok(&pkinfo[generic], a->qlen, d->tlen))) pc = K2A_NPKCFG;
+			/* (flat plans: the generation-serial and solo kernels do not report wildcard codes, so a pair goes there only after a look
+			 * at its bytes -- which a device arena does not allow) */
+			if (pc == K2A_PKCFG_MP && flat && (flat->on_device || pair_has_wild(a))) pc = K2A_NPKCFG;
 			if (pc < K2A_NPKCFG) pk_ok[i] = (uint8_t)(1 + pc + ((plain && pc != K2A_PKCFG_MP) ? 0 : K2A_NPKCFG) + (is_approx(fl) ? 2 * K2A_NPKCFG : 0));
 			/* solo kernel: 2 * K2A_SOLO_C rows per lane share one base; a lane must finish a double strip before its next one starts */
 			if (solo_mode && !is_approx(fl) && pk_window_ok(&pkinfo[generic], a->qlen, d->tlen, w, 2 * K2A_SOLO_C) &&
 			    ((d->tlen + 2 * K2A_SOLO_C - 1) / (2 * K2A_SOLO_C) <= 64 || w < 64 * (K2A_SOLO_C + 1) - K2A_SOLO_C)) {
 				solo_ok[i] = 1;
-				if (solo_mode == 2) pk_ok[i] = PASS_SOLO;
+				if (solo_mode == 2 && !(flat && (flat->on_device || pair_has_wild(a)))) pk_ok[i] = PASS_SOLO;
 			}
 		}
 		if (cfg == K2A_CFG_MP) {                              /* boundary rows H, E, E~ between generations */
@@ -641,7 +729,13 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 				     h = (h + 1) & (cap - 1)) {}
 				tab[h].k1 = k1; tab[h].k2 = k2; tab[h].last = i; tab[h].odd ^= 1;
 			}
-			for (h = 0; h < cap; ++h) if (tab[h].k2 && tab[h].odd) pk_ok[tab[h].last] = (uint8_t)(solo_mode && solo_ok[tab[h].last] ? PASS_SOLO : 0);
+			for (h = 0; h < cap; ++h)
+				if (tab[h].k2 && tab[h].odd) {
+					const int last = tab[h].last;
+					int solo = solo_mode && solo_ok[last];
+					if (solo && flat && (flat->on_device || pair_has_wild(&pairs[last]))) solo = 0;
+					pk_ok[last] = (uint8_t)(solo ? PASS_SOLO : 0);
+				}
 			free(tab);
 		}
 	}
@@ -684,14 +778,28 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 
 	if (tlev) tph[3] = now_ms();
 	/* the sequence arena goes up while the host sorts out the task lists (pinned staging: the copy is asynchronous) */
-	if (m > 5) {
+	if (m > 5 && !flat) {
 		build_eff(dual, m, sc->mat, e, e2, 0, (int8_t*)p->h_seq + mat_off);
 		build_eff(dual, m, sc->mat, e, e2, 1, (int8_t*)p->h_seq + mat_off + (size_t)m * m);
 	}
 	p->d_seq = (uint8_t*)cache_get(BUF_SEQ, p->seq_bytes, &p->cap[BUF_SEQ]);
 	if (!p->d_seq) { fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error()); goto err; }
-	up = thread_upload_stream();
+	up = flat && !flat->on_device ? shared_upload_stream() : 0;
+	if (up) shared_up = 1; else up = thread_upload_stream();
 	p->stream = up; p->stream_used = 1;              /* plan_destroy waits for it before the buffers are recycled */
+	if (flat) {
+		/* the arena's span as it lies there (an upload from caller memory: asynchronous if the caller page-locked it,
+		 * ksw2amd_host_register); the padding behind it and the matrices of a wide alphabet from a small staging block */
+		const size_t tail = p->seq_bytes - flat_span;
+		flat_tmp = (uint8_t*)calloc(tail ? tail : 1, 1);           /* freed behind the stream synchronisation that ends plan creation */
+		if (!flat_tmp) { fail(KSW2AMD_E_NOMEM, "plan_create: host allocation failed%s", 0); goto err; }
+		if (m > 5) {
+			build_eff(dual, m, sc->mat, e, e2, 0, (int8_t*)flat_tmp + (mat_off - flat_span));
+			build_eff(dual, m, sc->mat, e, e2, 1, (int8_t*)flat_tmp + (mat_off - flat_span) + (size_t)m * m);
+		}
+		if ((flat->on_device ? k2a_shim_d2d(p->d_seq, flat_lo, flat_span, up) : k2a_shim_h2d(p->d_seq, flat_lo, flat_span, up)) ||
+		    k2a_shim_h2d(p->d_seq + flat_span, flat_tmp, tail, up)) { fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error()); goto err; }
+	} else
 	if (k2a_shim_h2d(p->d_seq, p->h_seq, p->seq_bytes, up)) { fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error()); goto err; }
 
 	/* pass 2: task lists per class, most expensive first (similar shapes end up in the same wavefront).  Packed-int16
@@ -721,7 +829,8 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 			cls_t *c;
 			if (cnt == 0) continue;
 			ci = b / NPASS;
-			qsort(g, (size_t)cnt, sizeof(sort_t), cmp_cost_desc);
+			for (i = 1; i < cnt && cmp_cost_desc(&g[i - 1], &g[i]) <= 0; ++i) {}       /* one shape: already in order */
+			if (i < cnt) qsort(g, (size_t)cnt, sizeof(sort_t), cmp_cost_desc);
 			c = &p->cls[p->ncls++];
 			c->solo = pass == PASS_SOLO;
 			c->cfg = c->solo ? 0 : pass ? (pass - 1) % K2A_NPKCFG : ci / 6; c->rb = pass && !c->solo ? ((pass - 1) / K2A_NPKCFG) & 1 : 0;
@@ -802,30 +911,34 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 		fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error());
 		goto err;
 	}
+	if (shared_up && !g_ev_cache[0]) g_ev_cache[0] = k2a_shim_event_create();
 	if (k2a_shim_h2d(p->d_pairs, p->h_pairs, sizeof(K2aPair) * (size_t)n, up) ||
 	    k2a_shim_h2d(p->d_order, p->h_order, sizeof(uint32_t) * (size_t)p->norder, up) ||
 	    k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)n, up) ||
-	    (p->bnd_words && k2a_shim_memset(p->d_bnd, 0xC0, p->bnd_words * 4, up)) || k2a_shim_stream_sync(up)) {
+	    (p->bnd_words && k2a_shim_memset(p->d_bnd, 0xC0, p->bnd_words * 4, up)) ||
+	    /* a shared stream also carries other threads' later uploads: wait for this plan's only */
+	    (shared_up ? (!g_ev_cache[0] || k2a_shim_event_record(g_ev_cache[0], up) || k2a_shim_event_sync(g_ev_cache[0])) : k2a_shim_stream_sync(up))) {
 		fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error());
 		goto err;
 	}
 	if (m > 5) for (k = 0; k < p->ncls; ++k) p->cls[k].sc.mat = (const int8_t*)p->d_seq + mat_off + (p->cls[k].generic ? (size_t)m * m : 0);
 	for (i = 0; i < 3; ++i) { p->ev[i] = g_ev_cache[i] ? g_ev_cache[i] : k2a_shim_event_create(); g_ev_cache[i] = 0; }
-	free(pk_ok); free(solo_ok);
+	free(pk_ok); free(solo_ok); free(flat_tmp);
 	/* the uploads are complete: the plan no longer refers to the creating thread's stream (which may be gone -- thread exit,
 	 * ksw2amd_release_cache, ksw2amd_set_device -- before the plan runs or is destroyed) */
 	p->stream = 0; p->stream_used = 0;
 	if (tlev) { const double t6 = now_ms(); fprintf(stderr, "[ksw2_amd] plan_create n=%d: host arrays + arena layout %.3f, copy + classify %.3f, shape parity + demotions %.3f, sequence upload call + task lists %.3f, traceback layout %.3f, uploads + sync %.3f ms\n", n, tph[1] - tph[0], tph[2] - tph[1], tph[3] - tph[2], tph[4] - tph[3] , tph[5] - tph[4], t6 - tph[5]); }
 	return p;
 err:
-	free(srt); free(pk_ok); free(solo_ok);
+	if (flat_tmp && p && p->stream_used && p->stream) k2a_shim_stream_sync(p->stream);
+	free(srt); free(pk_ok); free(solo_ok); free(flat_tmp);
 	ksw2amd_plan_destroy(p);
 	return 0;
 }
 
 ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs)
 {
-	return plan_create_ex(dual, 0, sc, n, pairs);
+	return plan_create_ex(dual, 0, sc, n, pairs, 0);
 }
 
 static int exts_plan_run(ksw2amd_plan_t *p, void *stream);
@@ -967,13 +1080,23 @@ static int fetch_results(ksw2amd_plan_t *p)
 	return KSW2AMD_OK;
 }
 
+static int flat_rerun(ksw2amd_plan_t *p, int i, void *km, ksw_extz_t *z);
 int ksw2amd_plan_fetch_raw(ksw2amd_plan_t *p, int32_t *out16)
 {
 	int i, rc = fetch_results(p);
 	if (rc) return rc;
 	memset(out16, 0, sizeof(int32_t) * 16 * (size_t)p->n);
 	for (i = 0; i < p->n; ++i)
-		if (p->h_cls[i] >= 0 && !p->reject_all) memcpy(out16 + 16 * (size_t)i, &p->h_res[i], sizeof(K2aResult));
+		if (p->h_cls[i] >= 0 && !p->reject_all && p->flat && p->h_res[i].pad[0]) {      /* see flat_rerun */
+			ksw_extz_t z;
+			int32_t *o = out16 + 16 * (size_t)i;
+			memset(&z, 0, sizeof(z));
+			rc = flat_rerun(p, i, 0, &z);
+			if (rc) { free(z.cigar); return rc; }
+			o[0] = (int32_t)z.max; o[1] = (int32_t)z.zdropped; o[2] = z.max_q; o[3] = z.max_t; o[4] = z.mqe; o[5] = z.mqe_t; o[6] = z.mte; o[7] = z.mte_q;
+			o[8] = z.score; o[9] = z.reach_end; o[10] = z.n_cigar; o[11] = p->h_res[i].rows_done; o[12] = o[13] = -1;
+			free(z.cigar);
+		} else if (p->h_cls[i] >= 0 && !p->reject_all) memcpy(out16 + 16 * (size_t)i, &p->h_res[i], sizeof(K2aResult));
 		else {
 			int32_t *o = out16 + 16 * (size_t)i;
 			o[2] = o[3] = o[5] = o[7] = -1; o[4] = o[6] = o[8] = KSW_NEG_INF; o[12] = o[13] = -1;
@@ -1012,10 +1135,31 @@ static void eqx_rewrite(void *km, const uint8_t *query, const uint8_t *target, i
 /* a kalloc pool has no locks (kalloc.c:24-28): the batch entry points' worker threads take this around every use of `km` */
 static pthread_mutex_t g_km_mu = PTHREAD_MUTEX_INITIALIZER;
 
+/* Flat plans: pairs in which a packed kernel met a wildcard code (K2aResult.pad[0], K2aLanePk::seen) have a wrong result on the
+ * device; each is run again through the ordinary gather path, where the host's scan sends it to the int32 kernels.  Host arenas
+ * read the sequences where they lie, device arenas bring those pairs' bytes back first. */
+static int run_serial(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez, int share, const flat_src_t *flat);
+static int flat_rerun(ksw2amd_plan_t *p, int i, void *km, ksw_extz_t *z)
+{
+	ksw2amd_pair_t a = p->src_pairs[i];
+	uint8_t *tmp = 0;
+	int rc;
+	if (p->flat_device) {
+		tmp = (uint8_t*)malloc((size_t)a.qlen + (size_t)a.tlen + 1);
+		if (!tmp) return fail(KSW2AMD_E_NOMEM, "plan_fetch: host allocation failed%s", 0);
+		if (k2a_shim_d2h(tmp, a.query, (size_t)a.qlen, p->stream) || k2a_shim_d2h(tmp + a.qlen, a.target, (size_t)a.tlen, p->stream) ||
+		    k2a_shim_stream_sync(p->stream)) { free(tmp); return fail(KSW2AMD_E_NODEVICE, "plan_fetch: %s", k2a_shim_last_error()); }
+		a.query = tmp; a.target = tmp + a.qlen;
+	}
+	rc = run_serial(p->dual, p->scalar, km, &p->src_sc, 1, &a, z, 1, 0);
+	free(tmp);
+	return rc;
+}
+
 /* results into ez[i] with CIGAR memory from `km`, or -- the coalesced single calls -- into *ezp[i] with memory from kmp[i] */
 static int plan_fetch_ex(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez, ksw_extz_t **ezp, void **kmp)
 {
-	int i, rc = fetch_results(p);
+	int i, rc = fetch_results(p), nrerun = 0;
 	uint32_t *pool = 0;
 	size_t total = 0, *pos = 0, cap_hpool = 0;
 	if (rc) return rc;
@@ -1061,6 +1205,7 @@ static int plan_fetch_ex(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez, ksw_extz_t
 			continue;
 		}
 		if (p->reject_all || p->h_cls[i] < 0) continue;
+		if (p->flat && r->pad[0]) { ++nrerun; continue; }           /* a wildcard code in a packed kernel: below */
 		z->max = (uint32_t)r->max; z->zdropped = (uint32_t)r->zdropped;
 		z->max_q = r->max_q; z->max_t = r->max_t; z->mqe = r->mqe; z->mqe_t = r->mqe_t;
 		z->mte = r->mte; z->mte_q = r->mte_q; z->score = r->score; z->reach_end = r->reach_end;
@@ -1074,13 +1219,23 @@ static int plan_fetch_ex(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez, ksw_extz_t
 			ez_reserve(km, z, nc);
 			memcpy(z->cigar, src, sizeof(uint32_t) * (size_t)nc);               /* already in the caller's order (k2a_compact_kernel; ksw2.h:157-159) */
 			z->n_cigar = nc;
-			if (p->dual && (p->h_flag[i] & KSW_EZ_EQX) && !(p->h_flag[i] & F_SCALAR_CONTRACT))
-				eqx_rewrite(km, p->h_seq + p->h_pairs[i].qoff, p->h_seq + p->h_pairs[i].toff, 1, z);
+			if (p->dual && (p->h_flag[i] & KSW_EZ_EQX) && !(p->h_flag[i] & F_SCALAR_CONTRACT)) {
+				if (p->flat_device) {                          /* the sequences are in device memory only: bring this pair's back */
+					const ksw2amd_pair_t *a = &p->src_pairs[i];
+					uint8_t *tmp = (uint8_t*)malloc((size_t)a->qlen + (size_t)a->tlen + 1);
+					if (tmp && !k2a_shim_d2h(tmp, a->query, (size_t)a->qlen, p->stream) && !k2a_shim_d2h(tmp + a->qlen, a->target, (size_t)a->tlen, p->stream) &&
+					    !k2a_shim_stream_sync(p->stream)) eqx_rewrite(km, tmp, tmp + a->qlen, 1, z);
+					else rc = fail(KSW2AMD_E_NODEVICE, "plan_fetch: %s", tmp ? k2a_shim_last_error() : "host allocation failed");
+					free(tmp);
+				} else eqx_rewrite(km, p->h_seq + p->h_pairs[i].qoff, p->h_seq + p->h_pairs[i].toff, 1, z);
+			}
 		}
 	}
 	if (km || kmp) pthread_mutex_unlock(&g_km_mu);
 	free(pos); cache_put(BUF_HPOOL, pool, cap_hpool);
-	return KSW2AMD_OK;
+	for (i = 0; nrerun > 0 && i < p->n && rc == KSW2AMD_OK; ++i)
+		if (p->h_cls[i] >= 0 && p->h_res[i].pad[0]) rc = flat_rerun(p, i, kmp ? kmp[i] : km, ezp ? ezp[i] : &ez[i]);
+	return rc;
 }
 
 int ksw2amd_plan_fetch(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez)
@@ -1132,7 +1287,7 @@ static size_t pair_device_bytes(int dual, const ksw2amd_pair_t *a)
 static double now_ms(void);
 static int trace_on(void);
 static int unit_pairs(const ksw2amd_pair_t *a);
-static int run_serial(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez, int share)
+static int run_serial(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez, int share, const flat_src_t *flat)
 {
 	size_t budget, free_b = 0, total_b = 0, acc;
 	const char *env = ENV(MAX_BYTES);
@@ -1171,7 +1326,7 @@ static int run_serial(int dual, int scalar, void *km, const ksw2amd_scoring_t *s
 		t0 = now_ms();
 		for (p = 0; p == 0; ) {
 			if (end - beg > limit) end = beg + limit;
-			p = plan_create_ex(dual, scalar, sc, end - beg, pairs + beg);
+			p = plan_create_ex(dual, scalar, sc, end - beg, pairs + beg, flat);
 			if (p) break;
 			if (!strstr(g_err, "alloc") || end - beg <= 1) return strstr(g_err, "alloc") ? KSW2AMD_E_NOMEM : g_err[0] && strstr(g_err, "device") ? KSW2AMD_E_NODEVICE : KSW2AMD_E_PARAM;
 			release_thread_cache();
@@ -1516,7 +1671,7 @@ static int plan_chunks(int n, double bytes, double cells, int workers, int ndev,
 	return k < 2 ? 0 : (int)(k + 0.999);
 }
 
-typedef struct { int dual, scalar, dbuf; void *km; const ksw2amd_scoring_t *sc; const ksw2amd_pair_t *pairs; ksw_extz_t *ez; } ext_ctx_t;
+typedef struct { int dual, scalar, dbuf; void *km; const ksw2amd_scoring_t *sc; const ksw2amd_pair_t *pairs; ksw_extz_t *ez; const flat_src_t *flat; } ext_ctx_t;
 static double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 static int trace_on(void) { return ENV(TRACE) != 0; }
 
@@ -1559,14 +1714,14 @@ static int ext_chunk(void *ctx_, int beg, int end, int share, pend_t *pd)
 	}
 	if (bytes > budget) {
 		rc = ext_finish(c, pd);
-		return rc ? rc : run_serial(c->dual, c->scalar, c->km, c->sc, end - beg, c->pairs + beg, c->ez + beg, share);
+		return rc ? rc : run_serial(c->dual, c->scalar, c->km, c->sc, end - beg, c->pairs + beg, c->ez + beg, share, c->flat);
 	}
 	t0 = now_ms();
-	p = plan_create_ex(c->dual, c->scalar, c->sc, end - beg, c->pairs + beg);
+	p = plan_create_ex(c->dual, c->scalar, c->sc, end - beg, c->pairs + beg, c->flat);
 	if (!p) {                                       /* out of device memory with two plans alive: finish the old one, go serial */
 		if (!strstr(g_err, "alloc")) return strstr(g_err, "device") ? KSW2AMD_E_NODEVICE : KSW2AMD_E_PARAM;
 		rc = ext_finish(c, pd);
-		return rc ? rc : run_serial(c->dual, c->scalar, c->km, c->sc, end - beg, c->pairs + beg, c->ez + beg, share);
+		return rc ? rc : run_serial(c->dual, c->scalar, c->km, c->sc, end - beg, c->pairs + beg, c->ez + beg, share, c->flat);
 	}
 	t1 = now_ms();
 	rc = ksw2amd_plan_run(p, thread_stream());
@@ -1605,7 +1760,7 @@ static int run_pooled(chunk_fn fn, void *ctx, int n, const double *cost, double 
 	return 1;
 }
 
-static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez)
+static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez, const flat_src_t *flat)
 {
 	const int tpd = pool_threads_per_device();
 	if (n <= 0) return KSW2AMD_OK;
@@ -1615,15 +1770,20 @@ static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc
 		double *cost = (double*)malloc(sizeof(double) * (size_t)n), bytes = 0, cells = 0, total = 0, path = 0, dev_bytes = 0;
 		int i, nchunks, rc = 0, uniform = 1, chunk_pairs = 0;
 		if (cost) {
-			for (i = 0; i < n; ++i) dev_bytes += (double)pair_device_bytes(dual, &pairs[i]);
+			/* one shape for the whole batch (the BASELINE configurations, reads trimmed to one length)?  Then the sums below are n x
+			 * the first pair's terms and the per-pair costs are never looked at (uniform_chunks cuts at fixed sizes): this loop was
+			 * 1.5-2 ms of the calling thread's time on config 2's 65 536 pairs, in front of a 1.4 ms kernel */
+			for (i = 1; i < n; ++i)
+				if (pairs[i].qlen != pairs[0].qlen || pairs[i].tlen != pairs[0].tlen || pairs[i].w != pairs[0].w || ((pairs[i].flag ^ pairs[0].flag) & KSW_EZ_SCORE_ONLY)) { uniform = 0; break; }
+			if (uniform) dev_bytes = (double)n * (double)pair_device_bytes(dual, &pairs[0]);
+			else for (i = 0; i < n; ++i) dev_bytes += (double)pair_device_bytes(dual, &pairs[i]);
 			if (dev_bytes > 64e9 && !pool_min_pairs()) {
 				/* traceback memory is what splits this batch: one plan at a time with the whole device, not a slice per worker */
 				size_t free_b = 0, total_b = 0;
-				if (k2a_shim_mem_info(&free_b, &total_b) == 0 && dev_bytes > 0.5 * (double)total_b && g_ndev_set <= 1) { free(cost); return run_serial(dual, scalar, km, sc, n, pairs, ez, 1); }
+				if (k2a_shim_mem_info(&free_b, &total_b) == 0 && dev_bytes > 0.5 * (double)total_b && g_ndev_set <= 1) { free(cost); return run_serial(dual, scalar, km, sc, n, pairs, ez, 1, flat); }
 			}
-			for (i = 0; i < n; ++i) {
+			for (i = 0; i < (uniform ? 1 : n); ++i) {
 				const int ql = imax(pairs[i].qlen, 0), tl = imax(pairs[i].tlen, 0), mx = imax(ql, tl);
-				if (pairs[i].qlen != pairs[0].qlen || pairs[i].tlen != pairs[0].tlen || pairs[i].w != pairs[0].w || ((pairs[i].flag ^ pairs[0].flag) & KSW_EZ_SCORE_ONLY)) uniform = 0;
 				const double b = (double)ql + tl, c = ql && tl ? (double)band_cells(ql, tl, (pairs[i].w < 0 || pairs[i].w > mx) ? mx : pairs[i].w) : 0;
 				bytes += b; cells += c;
 				{	/* steps of the pair's fill: columns + strips; wide bands on long targets run as generations of 1024 rows, four at a time */
@@ -1634,6 +1794,7 @@ static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc
 				cost[i] = 1.0 + c + 64.0 * b;              /* a byte costs the host about as much as 64 cells cost the device */
 				total += cost[i];
 			}
+			if (uniform) { bytes *= n; cells *= n; for (i = 1; i < n; ++i) cost[i] = cost[0]; total = cost[0] * n; }
 			{
 				const int unit = uniform && !pool_min_pairs() && !ENV(CHUNKS) && !ENV(NO_UNITS) ? unit_pairs(&pairs[0]) : 0;
 				if (unit > 0) nchunks = uniform_chunks(n, unit, bytes, cells, workers, g_ndev_set, !(pairs[0].flag & KSW_EZ_SCORE_ONLY), path, &chunk_pairs);
@@ -1641,7 +1802,7 @@ static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc
 			}
 			if (nchunks >= 2) {
 				ext_ctx_t ctx;
-				ctx.dual = dual; ctx.scalar = scalar; ctx.km = km; ctx.sc = sc; ctx.pairs = pairs; ctx.ez = ez;
+				ctx.dual = dual; ctx.scalar = scalar; ctx.km = km; ctx.sc = sc; ctx.pairs = pairs; ctx.ez = ez; ctx.flat = flat;
 				{	/* double-buffering is opt-in (see ext_chunk) */
 					const char *ev = ENV(DBUF);
 					ctx.dbuf = ev && *ev ? atoi(ev) != 0 : 0;
@@ -1651,7 +1812,7 @@ static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc
 			free(cost);
 		}
 	}
-	return run_serial(dual, scalar, km, sc, n, pairs, ez, 1);
+	return run_serial(dual, scalar, km, sc, n, pairs, ez, 1, flat);
 }
 
 static int wants_ssec(int flag);
@@ -1663,7 +1824,7 @@ static int route_batch(int dual, void *km, const ksw2amd_scoring_t *sc, int n, c
 {
 	int i, nc = 0, rc = KSW2AMD_OK, part;
 	for (i = 0; i < n; ++i) nc += wants_ssec(pairs[i].flag);
-	if (nc == 0) return run_batch(dual, 0, km, sc, n, pairs, ez);
+	if (nc == 0) return run_batch(dual, 0, km, sc, n, pairs, ez, 0);
 	if (nc == n) return ssec_run(dual, km, sc, n, pairs, ez);
 	for (part = 0; part < 2 && rc == KSW2AMD_OK; ++part) {
 		const int cnt = part ? nc : n - nc;
@@ -1672,7 +1833,7 @@ static int route_batch(int dual, void *km, const ksw2amd_scoring_t *sc, int n, c
 		int k = 0;
 		if (!pp || !zz) { free(pp); free(zz); return fail(KSW2AMD_E_NOMEM, "batch: host allocation failed%s", 0); }
 		for (i = 0; i < n; ++i) if (wants_ssec(pairs[i].flag) == part) { pp[k] = pairs[i]; zz[k] = ez[i]; ++k; }
-		rc = part ? ssec_run(dual, km, sc, cnt, pp, zz) : run_batch(dual, 0, km, sc, cnt, pp, zz);
+		rc = part ? ssec_run(dual, km, sc, cnt, pp, zz) : run_batch(dual, 0, km, sc, cnt, pp, zz, 0);
 		for (i = 0, k = 0; i < n; ++i) if (wants_ssec(pairs[i].flag) == part) ez[i] = zz[k++];      /* CIGAR buffers may have moved: always copy back */
 		free(pp); free(zz);
 	}
@@ -1687,6 +1848,82 @@ int ksw2amd_extz_batch(void *km, const ksw2amd_scoring_t *sc, int n, const ksw2a
 int ksw2amd_extd_batch(void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez)
 {
 	return route_batch(1, km, sc, n, pairs, ez);
+}
+
+/* ---------------------------------------------------------------- flat batches: one arena + offsets (include/ksw2_amd.h) */
+
+static ksw2amd_pair_t *flat_pairs(int n, const ksw2amd_flat_t *in)
+{
+	ksw2amd_pair_t *pp;
+	int i;
+	if (n < 0 || !in || (n > 0 && (!in->base || !in->qoff || !in->toff || !in->qlen || !in->tlen))) { fail(KSW2AMD_E_PARAM, "flat batch: bad arguments%s", 0); return 0; }
+	pp = (ksw2amd_pair_t*)malloc(sizeof(*pp) * ((size_t)n + 1));
+	if (!pp) { fail(KSW2AMD_E_NOMEM, "flat batch: host allocation failed%s", 0); return 0; }
+	for (i = 0; i < n; ++i) {
+		pp[i].query = in->base + in->qoff[i]; pp[i].target = in->base + in->toff[i];
+		pp[i].qlen = in->qlen[i]; pp[i].tlen = in->tlen[i];
+		pp[i].w = in->w ? in->w[i] : in->w_all; pp[i].zdrop = in->zdrop ? in->zdrop[i] : in->zdrop_all;
+		pp[i].end_bonus = in->end_bonus ? in->end_bonus[i] : in->end_bonus_all; pp[i].flag = in->flag ? in->flag[i] : in->flag_all;
+	}
+	return pp;
+}
+
+static int flat_batch(int dual, void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_flat_t *in, ksw_extz_t *ez)
+{
+	ksw2amd_pair_t *pp = flat_pairs(n, in);
+	flat_src_t fs;
+	int i, rc, plain = 1;
+	if (!pp) return g_err[0] && strstr(g_err, "alloc") ? KSW2AMD_E_NOMEM : KSW2AMD_E_PARAM;
+	fs.on_device = in->on_device != 0;
+	for (i = 0; i < n && plain; ++i) plain = !wants_ssec(pp[i].flag);
+	if (!plain) {                                      /* SSE-compatible pairs keep their own plans: the ordinary entry point sorts them out */
+		if (fs.on_device) { free(pp); return fail(KSW2AMD_E_PARAM, "flat batch: SSE-compatible pairs need a host arena%s", 0); }
+		rc = route_batch(dual, km, sc, n, pp, ez);
+	} else rc = run_batch(dual, 0, km, sc, n, pp, ez, &fs);
+	free(pp);
+	return rc;
+}
+
+int ksw2amd_extz_batch_flat(void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_flat_t *in, ksw_extz_t *ez) { return flat_batch(0, km, sc, n, in, ez); }
+int ksw2amd_extd_batch_flat(void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_flat_t *in, ksw_extz_t *ez) { return flat_batch(1, km, sc, n, in, ez); }
+
+ksw2amd_plan_t *ksw2amd_plan_create_flat(int dual, const ksw2amd_scoring_t *sc, int n, const ksw2amd_flat_t *in)
+{
+	ksw2amd_pair_t *pp = flat_pairs(n, in);
+	ksw2amd_plan_t *p;
+	flat_src_t fs;
+	if (!pp) return 0;
+	fs.on_device = in->on_device != 0;
+	p = plan_create_ex(dual, 0, sc, n, pp, &fs);
+	free(pp);
+	return p;
+}
+
+/* device memory for callers that build a device-resident arena without linking the HIP runtime themselves */
+void *ksw2amd_device_alloc(size_t bytes) { void *d = k2a_shim_malloc(bytes); if (!d) fail(KSW2AMD_E_NOMEM, "device_alloc: %s", k2a_shim_last_error()); return d; }
+void ksw2amd_device_free(void *d) { k2a_shim_free(d); }
+int ksw2amd_device_upload(void *dst, const void *src, size_t bytes)
+{
+	void *st = thread_stream();
+	if (k2a_shim_h2d(dst, src, bytes, st) || k2a_shim_stream_sync(st)) return fail(KSW2AMD_E_NODEVICE, "device_upload: %s", k2a_shim_last_error());
+	return KSW2AMD_OK;
+}
+int ksw2amd_device_download(void *dst, const void *src, size_t bytes)
+{
+	void *st = thread_stream();
+	if (k2a_shim_d2h(dst, src, bytes, st) || k2a_shim_stream_sync(st)) return fail(KSW2AMD_E_NODEVICE, "device_download: %s", k2a_shim_last_error());
+	return KSW2AMD_OK;
+}
+
+int ksw2amd_host_register(const void *p, size_t bytes)
+{
+	if (k2a_shim_host_register((void*)p, bytes)) return fail(KSW2AMD_E_NODEVICE, "host_register: %s", k2a_shim_last_error());
+	return KSW2AMD_OK;
+}
+int ksw2amd_host_unregister(const void *p)
+{
+	if (k2a_shim_host_unregister((void*)p)) return fail(KSW2AMD_E_NODEVICE, "host_unregister: %s", k2a_shim_last_error());
+	return KSW2AMD_OK;
 }
 
 /* ---------------------------------------------------------------- the ksw2-named single-pair calls */
@@ -1729,7 +1966,7 @@ static void one_pair(const char *fn, int dual, int scalar, void *km, int qlen, c
 		return;
 	}
 	if (!scalar && queue_one(fn, dual, km, &sc, &pr, ez)) return;     /* coalesced with other threads' calls */
-	rc = run_serial(dual, scalar, km, &sc, 1, &pr, ez, 1);
+	rc = run_serial(dual, scalar, km, &sc, 1, &pr, ez, 1, 0);
 	if (rc != KSW2AMD_OK) call_failed(fn, rc, ez);
 }
 
@@ -1853,7 +2090,7 @@ static void coal_process(creq_t *list)
 			r->taken = 1; mem[n] = r; pairs[n] = *r->pr; ezp[n] = r->ez; kmp[n] = r->km; ++n;
 		}
 		__sync_fetch_and_add(&g_stat[2], n); __sync_fetch_and_add(&g_stat[3], 1);
-		p = plan_create_ex(g->dual, 0, g->sc, n, pairs);
+		p = plan_create_ex(g->dual, 0, g->sc, n, pairs, 0);
 		if (!p) rc = strstr(g_err, "alloc") ? KSW2AMD_E_NOMEM : strstr(g_err, "device") ? KSW2AMD_E_NODEVICE : KSW2AMD_E_PARAM;
 		else {
 			rc = ksw2amd_plan_run(p, thread_stream());
@@ -1877,7 +2114,7 @@ static int queue_one(const char *fn, int dual, void *km, const ksw2amd_scoring_t
 	if (g_coal.busy < slots && g_coal.count == 0) {        /* a free slot and nobody waiting: run alone, now */
 		++g_coal.busy;
 		pthread_mutex_unlock(&g_coal.mu);
-		me.rc = run_serial(dual, 0, km, sc, 1, pr, ez, 1);
+		me.rc = run_serial(dual, 0, km, sc, 1, pr, ez, 1, 0);
 		if (me.rc) snprintf(me.err, sizeof(me.err), "%.190s", g_err);
 		pthread_mutex_lock(&g_coal.mu);
 		--g_coal.busy;

@@ -241,7 +241,7 @@ struct K2aLanePk {
 		Snext = gl;
 		schedule_next();
 		const k2a_pk neg = k2a_pku(K2A_NEG16);
-		hout = eout = e2out = hd0 = hu_prev = neg; qb = 0; qwA = qwB = 0;
+		hout = eout = e2out = hd0 = hu_prev = neg; qb = 0; qwA = qwB = 0; seen = 0;
 		baseA = baseB = 0; delta = 0;
 		local_reset();
 #pragma unroll
@@ -277,6 +277,8 @@ struct K2aLanePk {
 		for (int c4 = 0; c4 < C; c4 += 4) {
 			uint32_t da, db;
 			__builtin_memcpy(&da, tpa + c4, 4); __builtin_memcpy(&db, tpb + c4, 4);
+			if (c4 + 4 <= C) note_codes(da, db);                /* (C = 18: the last two rows' dword reaches into the next strip, which reports them itself) */
+			else note_codes(da & 0xffffu, db & 0xffffu);
 			if (PLANES) {
 				const uint32_t a0 = (da & 0x01010101u) * dmis, a1 = ((da >> 1) & 0x01010101u) * dmis;
 				const uint32_t b0 = (db & 0x01010101u) * dmis, b1 = ((db >> 1) & 0x01010101u) * dmis;
@@ -460,17 +462,26 @@ struct K2aLanePk {
 	 * A strip that starts inside a group re-loads the group under its own column offset (load_query_group from the init
 	 * branch).  Bytes of columns outside the query are garbage that only dead cells see (the arena is padded). */
 	uint32_t qwA, qwB;
-	K2A_FN void load_query_group(int kg, int koff_use, uint32_t &a, uint32_t &b) const      /* prefetch: nothing here waits for the loads */
+	/* OR of every code dword this lane fetched (k2a_fill_pk_kernel).  The packed kernels score match / mismatch only, so the host
+	 * keeps pairs with a wildcard code (>= 4) out of them -- by scanning the sequences while it copies them.  A flat batch
+	 * (ksw2amd_plan_create_flat) is uploaded as it lies in the caller's arena, unscanned: the kernel then reports "a code >= 4
+	 * was among the bytes I read" (K2aResult.pad[0]) and the host re-runs that pair through the int32 kernels.  Bytes that
+	 * belong to a neighbouring sequence can only cause a needless re-run. */
+	uint32_t seen;
+	K2A_FN void load_query_group(int kg, int koff_use, uint32_t &a, uint32_t &b)            /* prefetch: nothing here waits for the loads */
 	{
 		const int jc = k2a_min(k2a_max(kg - koff_use, 0), qlen - 1);    /* column at step kg; a negative one belongs to a lane without a strip */
 		__builtin_memcpy(&a, qa + jc, 4); __builtin_memcpy(&b, qbp + jc, 4);
 	}
+	K2A_FN void note_codes(uint32_t a, uint32_t b) { seen |= a | b; }
+	K2A_FN bool saw_wildcard() const { return (seen & 0xfcfcfcfcu) != 0; }
 	K2A_FN void reload_query_group(int k)                      /* from the init branch: this strip started at step k, inside a group */
 	{
 		const int j = (k & ~3) - koff;                             /* < 0: the strip's column 0 comes -j steps into the group */
 		const int sh = 8 * k2a_min(k2a_max(-j, 0), 3);
 		uint32_t va, vb;
 		load_query_group(k & ~3, koff, va, vb);
+		note_codes(va, vb);
 		qwA = va << sh; qwB = vb << sh;
 	}
 	K2A_FN static uint32_t query_pick(uint32_t a, uint32_t b, int kk)      /* { code A, code B } of step kg + kk */

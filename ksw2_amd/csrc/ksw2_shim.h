@@ -52,6 +52,9 @@ void *k2a_shim_host_malloc(size_t bytes);          /* pinned host staging */
 void  k2a_shim_host_free(void *p);
 int   k2a_shim_h2d(void *dst, const void *src, size_t bytes, void *stream);
 int   k2a_shim_d2h(void *dst, const void *src, size_t bytes, void *stream);
+int   k2a_shim_d2d(void *dst, const void *src, size_t bytes, void *stream);
+int   k2a_shim_host_register(void *p, size_t bytes);   /* page-lock caller memory so that uploads from it are asynchronous and at link rate */
+int   k2a_shim_host_unregister(void *p);
 int   k2a_shim_memset(void *dst, int v, size_t bytes, void *stream);
 
 void *k2a_shim_stream_create(void);
@@ -62,6 +65,7 @@ void  k2a_shim_event_destroy(void *ev);
 int   k2a_shim_event_record(void *ev, void *stream);
 int   k2a_shim_stream_wait_event(void *stream, void *ev);   /* later work on `stream` waits for `ev` */
 float k2a_shim_event_ms(void *start, void *stop);  /* blocks on `stop` */
+int   k2a_shim_event_sync(void *ev);               /* blocks until the work recorded before `ev` is done */
 
 /*
  * Fill kernel: ntasks alignments (order[t] = index into pairs/res) on geometry class `cfg`.

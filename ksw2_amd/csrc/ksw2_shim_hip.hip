@@ -257,6 +257,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	/* query codes: one unaligned dword per alignment and four steps (K2aLanePk::load_query_group) */
 	uint32_t qpa = 0, qpb = 0;
 	L.load_query_group(0, L.knext == 0 ? L.koff_next : L.koff, L.qwA, L.qwB);
+	L.note_codes(L.qwA, L.qwB);
 	const size_t tbsteps = (size_t)(klast + 1);
 	uint8_t *tbp = tb + prA.tb_off;
 	constexpr int WB = Lane::TBWORDS * 4;
@@ -323,7 +324,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 				__builtin_amdgcn_wave_barrier();
 			}
 		}
-		if ((k & 3) == 3) { L.qwA = qpa; L.qwB = qpb; }
+		if ((k & 3) == 3) { L.qwA = qpa; L.qwB = qpb; L.note_codes(qpa, qpb); }
 		if (zseq && __builtin_amdgcn_ballot_w64(!(gdone || k >= klast)) == 0) break;   /* only a Z-drop ends a group early */
 	}
 	if (STAGED) ST.finish(kdone);
@@ -348,10 +349,14 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 		}
 		__builtin_amdgcn_wave_barrier();
 	}
+	/* a code >= 4 among the bytes this group read: only an unscanned (flat) plan can get here with one; the host re-runs the pair */
+	const uint64_t sawmask = __builtin_amdgcn_ballot_w64(valid && L.saw_wildcard());
+	const bool gsaw = ((sawmask >> (grp * G)) & (G == 64 ? ~0ull : (1ull << (G & 63)) - 1)) != 0;
 	if (valid && gl == 0) {
 		const K2aBook a = *bkA, b = *bkB;
 		k2a_finish(prA, a, &res[piA]);
 		if (piB != piA) k2a_finish(prB, b, &res[piB]);
+		if (gsaw) { res[piA].pad[0] = 1; res[piB].pad[0] = 1; }
 	}
 }
 
@@ -1506,6 +1511,13 @@ int k2a_shim_d2h(void *dst, const void *src, size_t bytes, void *stream)
 	if (bytes) CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
 	return 0;
 }
+int k2a_shim_d2d(void *dst, const void *src, size_t bytes, void *stream)
+{
+	if (bytes) CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+	return 0;
+}
+int k2a_shim_host_register(void *p, size_t bytes) { CHECK(hipHostRegister(p, bytes, hipHostRegisterDefault)); return 0; }
+int k2a_shim_host_unregister(void *p) { CHECK(hipHostUnregister(p)); return 0; }
 int k2a_shim_memset(void *dst, int v, size_t bytes, void *stream)
 {
 	if (bytes) CHECK(hipMemsetAsync(dst, v, bytes, (hipStream_t)stream));
@@ -1530,6 +1542,7 @@ void *k2a_shim_event_create(void)
 void k2a_shim_event_destroy(void *ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
 int k2a_shim_event_record(void *ev, void *stream) { CHECK(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream)); return 0; }
 int k2a_shim_stream_wait_event(void *stream, void *ev) { CHECK(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0)); return 0; }
+int k2a_shim_event_sync(void *ev) { CHECK(hipEventSynchronize((hipEvent_t)ev)); return 0; }
 float k2a_shim_event_ms(void *start, void *stop)
 {
 	float ms = -1.0f;

@@ -133,6 +133,7 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 			if (klast[lane] > kmax) kmax = klast[lane];
 			gdone[lane] = !valid[lane];
 			L[lane].load_query_group(0, L[lane].knext == 0 ? L[lane].koff_next : L[lane].koff, L[lane].qwA, L[lane].qwB);
+			L[lane].note_codes(L[lane].qwA, L[lane].qwB);
 			zseq |= valid[lane] && (zdA[lane] >= 0 || zdB[lane] >= 0);
 			if (valid[lane]) {
 				const int kt = k2a_min(prA[lane].qlen - 1, k2a_min(C - 1, prA[lane].tlen - 1) + prA[lane].w);
@@ -201,7 +202,7 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 			}
 			bool all_done = true;
 			for (int lane = 0; lane < 64; ++lane) {
-				if ((k & 3) == 3) { L[lane].qwA = qpa[lane]; L[lane].qwB = qpb[lane]; }
+				if ((k & 3) == 3) { L[lane].qwA = qpa[lane]; L[lane].qwB = qpb[lane]; L[lane].note_codes(qpa[lane], qpb[lane]); }
 				if (!(gdone[lane] || k >= klast[lane])) all_done = false;
 			}
 			if (zseq && all_done) break;
@@ -229,8 +230,11 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 		}
 		for (int lane = 0; lane < 64; ++lane)
 			if (valid[lane] && lane % G == 0) {
+				bool gsaw = false;
+				for (int l = lane; l < lane + G; ++l) gsaw |= L[l].saw_wildcard();
 				k2a_finish(prA[lane], book[lane / G][0], &res[piA[lane]]);
 				if (piB[lane] != piA[lane]) k2a_finish(pairs[piB[lane]], book[lane / G][1], &res[piB[lane]]);
+				if (gsaw) { res[piA[lane]].pad[0] = 1; res[piB[lane]].pad[0] = 1; }
 			}
 	}
 }
@@ -917,12 +921,16 @@ void *k2a_shim_host_malloc(size_t bytes) { return malloc(bytes ? bytes : 16); }
 void k2a_shim_host_free(void *p) { free(p); }
 int k2a_shim_h2d(void *dst, const void *src, size_t bytes, void *) { memcpy(dst, src, bytes); return 0; }
 int k2a_shim_d2h(void *dst, const void *src, size_t bytes, void *) { memcpy(dst, src, bytes); return 0; }
+int k2a_shim_d2d(void *dst, const void *src, size_t bytes, void *) { memcpy(dst, src, bytes); return 0; }
+int k2a_shim_host_register(void *, size_t) { return 0; }
+int k2a_shim_host_unregister(void *) { return 0; }
 int k2a_shim_memset(void *dst, int v, size_t bytes, void *) { memset(dst, v, bytes); return 0; }
 void *k2a_shim_stream_create(void) { return (void*)1; }
 void k2a_shim_stream_destroy(void *) {}
 int k2a_shim_stream_sync(void *) { return 0; }
 void *k2a_shim_event_create(void) { return calloc(1, sizeof(double)); }
 void k2a_shim_event_destroy(void *ev) { free(ev); }
+int k2a_shim_event_sync(void *) { return 0; }
 int k2a_shim_stream_wait_event(void *, void *) { return 0; }
 int k2a_shim_event_record(void *ev, void *)
 {

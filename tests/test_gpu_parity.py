@@ -697,6 +697,47 @@ def test_code_planes_in_registers_and_in_lds(lib, ldc, monkeypatch):
         _check_code_plane_forms(lib, "ldscodes" if ldc == "1" else "registers", seed=seed)
 
 
+def test_flat_batches_host_and_device_arena(lib):
+    """ksw2amd_ext?_batch_flat / ksw2amd_plan_create_flat: one arena + offsets, from host memory and from a device-resident arena
+    (what an RCCL-delivered shard is): every field and CIGAR equal to the pointer entry points; pairs with a wildcard code are
+    reported by the packed kernels and re-run (host arena: where they lie; device arena: fetched back)."""
+    from tests.test_sim_parity import _check_flat
+    held = []
+
+    def device_copy(arena):
+        d = lib.device_copy(arena)
+        held.append(d)
+        return d, d
+
+    try:
+        assert _check_flat(lib, device_copy) == 6 * 2 * 36
+    finally:
+        for d in held:
+            lib.device_free(d)
+
+
+def test_flat_batch_full_size_config2(lib, monkeypatch):
+    """Config 2 at its full size through the flat entry point from a page-locked arena, production occupancy rules: all 65 536
+    results equal the pointer entry point's."""
+    monkeypatch.delenv("KSW2AMD_SIMDS", raising=False)
+    n = 65536
+    q, t = synth.fast_fixed(2, n, 512, 512, sub=0.05, ind=0.06)
+    mat = synth.simple_mat(5, 2, 4, -1)
+    b = lib.make_batch(q, t, mat, 4, 2, 24, 1, w=64, zdrop=-1, flag=po.SCORE_ONLY)
+    p = b.plan(False); p.run(); r1 = p.fetch_raw().copy(); p.close()
+    fb = lib.make_flat_batch(q, t, mat, 4, 2, 24, 1, w=64, zdrop=-1, flag=po.SCORE_ONLY)
+    fb.register()
+    try:
+        p = fb.plan(False); p.run(); r2 = p.fetch_raw().copy(); p.close()
+        ez = (ka.KswExtz * n)()
+        lib._check(lib.lib.ksw2amd_extz_batch_flat(None, ctypes.byref(fb.sc), n, ctypes.byref(fb.flat), ez))
+    finally:
+        fb.unregister()
+    assert np.array_equal(r1[:, :10], r2[:, :10])
+    sc = np.array([ez[i].score for i in range(0, n, 7)])
+    assert np.array_equal(sc, r1[::7, 8])
+
+
 def test_headline_kernel_at_scale_unforced(lib, monkeypatch):
     """The headline workload's own launch, nothing forced: 3 200 pairs of 10 000 x 10 000, band 500, Z-drop 400, score only,
     under the production occupancy rules.  The launcher must take the code-planes-in-LDS form on its own (>= 1.5 wavefronts

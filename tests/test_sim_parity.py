@@ -530,6 +530,75 @@ def test_sim_code_planes_in_registers_and_in_lds(sim, ldc, monkeypatch):
     _check_code_plane_forms(sim, "ldscodes" if ldc == "1" else "registers", scale=0.6)
 
 
+def _flat_cases(rng):
+    """Batches for the flat entry points: ragged and one-shape, score-only / CIGAR / EQX, both gap models, every band class, and in
+    each batch a few pairs with a wildcard code somewhere -- in the query, in the target, in the last byte -- which the packed
+    kernels must report so that the host re-runs them (ksw2_host.c::flat_rerun)."""
+    mat = synth.simple_mat(5, 2, 4, -1)
+    for rnd in range(6):
+        n = 36
+        if rnd % 2:
+            q, t = synth.fixed_batch(6100 + rnd, n, [300, 700, 2500][rnd // 2], [310, 690, 2480][rnd // 2], sub=0.05, ind=0.08, tail_random_frac=0.3, tail_pairs=0.3)
+            qs, ts = [x.copy() for x in q], [x.copy() for x in t]
+        else:
+            pairs = synth.ragged_pairs(rng, n, 1, [150, 900, 3000][rnd // 2], sub=0.05, ind=0.12)
+            qs, ts = [p[0].copy() for p in pairs], [p[1].copy() for p in pairs]
+        for i in range(2, n, 9):
+            (qs if i % 2 else ts)[i][int(rng.integers(len((qs if i % 2 else ts)[i])))] = 4
+        qs[5][-1] = 4
+        ts[6][-1] = 4
+        w = rng.choice([-1, 5, 20, 64, 68, 100, 284, 285, 500, 537, 1041], size=n)
+        zd = rng.choice([-1, 100, 400], size=n)
+        eb = rng.choice([0, 30], size=n)
+        for dual in (False, True):
+            mode = [po.SCORE_ONLY, 0, po.RIGHT][(rnd + dual) % 3]
+            fl = np.array([mode | (po.EXTZ_ONLY if rng.random() < 0.3 else 0) | (po.EQX if dual and mode != po.SCORE_ONLY and rng.random() < 0.3 else 0) |
+                           (0x08 if rng.random() < 0.15 else 0) for _ in range(n)])
+            yield dual, qs, ts, mat, w, zd, eb, fl
+
+
+def _check_flat(lib, device_copy=None):
+    """ksw2amd_ext?_batch_flat and ksw2amd_plan_create_flat against the ordinary entry points on the same pairs (every field, CIGAR
+    included) and against the oracle; device_copy(arena) -> device address runs the same through a device-resident arena."""
+    rng = np.random.Generator(np.random.PCG64(2027))
+    tot = 0
+    for dual, qs, ts, mat, w, zd, eb, fl in _flat_cases(rng):
+        ref = (lib.extd_batch(qs, ts, mat, 4, 2, 24, 1, w=w, zdrop=zd, end_bonus=eb, flag=fl) if dual else
+               lib.extz_batch(qs, ts, mat, 4, 2, w=w, zdrop=zd, end_bonus=eb, flag=fl))
+        fb = lib.make_flat_batch(qs, ts, mat, 4, 2, 24, 1, w=w, zdrop=zd, end_bonus=eb, flag=fl)
+        got = [fb.run_oneshot(dual)]
+        p = fb.plan(dual); p.run(); got.append(p.fetch()); p.close()
+        if device_copy is not None:
+            keep = device_copy(fb.arena)
+            fd = lib.make_flat_batch(qs, ts, mat, 4, 2, 24, 1, w=w, zdrop=zd, end_bonus=eb, flag=fl, device_base=keep[0])
+            got.append(fd.run_oneshot(dual))
+            p = fd.plan(dual); p.run(); got.append(p.fetch()); p.close()
+        for i in range(len(qs)):
+            for g in got:
+                assert not diff(ref[i], g[i]), (i, dual, int(w[i]), hex(int(fl[i])), diff(ref[i], g[i]))
+            if i % 5 == 0 and not (fl[i] & po.EQX):
+                exp = po.align("oracle", "extd2" if dual else "extz2", qs[i], ts[i], mat, 4, 2, 24, 1, w=int(w[i]), zdrop=int(zd[i]), end_bonus=int(eb[i]), flag=int(fl[i]))
+                assert not diff(exp, ref[i]), (i, dual)
+            tot += 1
+    return tot
+
+
+def test_sim_flat_batches(sim):
+    """One arena + offsets instead of 2 n pointers (include/ksw2_amd.h, "Flat batches"): same results as the pointer entry points,
+    wildcard pairs included -- the flat path uploads the arena unscanned, the packed kernels report codes >= 4, the host re-runs."""
+    held = []
+
+    def device_copy(arena):                      # the simulator's "device memory" is host memory: exercises the on_device code path
+        held.append(sim.device_copy(arena))
+        return held[-1], None
+
+    try:
+        assert _check_flat(sim, device_copy) == 6 * 2 * 36
+    finally:
+        for d in held:
+            sim.device_free(d)
+
+
 def test_sim_pairs_share_the_true_target_length(sim):
     """Found by tools/scripts/fuzz_gpu.py: two alignments with the same query length, band and rows inside the band but
     different true target lengths (one target cut off by the band, so it has no last row: mte / score stay unset) must not
