@@ -60,11 +60,16 @@ WORKLOADS = {
     # channel (|tlen - qlen| <= 450), band 500, extd2 with Z-drop 400 and CIGAR; 16 384 pairs = one eighth of the per-GPU share
     # of the 1 M pair config (which shards over 8 GPUs)
     "cfg5": dict(idx=5, n=16384, qlen=0, tlen=0, w=500, zdrop=400, dual=True, flag=0, sub=0.03, ind=0.15, ragged=True),
+    # config 5 at the per-GPU share BASELINE.json states: 1 M pairs over 8 GPUs = 125 000 pairs per GPU (1.26e12 cells, 2.5 GB of
+    # sequence, ~1.3 TB of direction bytes: the batch entry point runs it as several device-filling plans); resident figure on a slice
+    "cfg5-share": dict(idx=5, n=125000, qlen=0, tlen=0, w=500, zdrop=400, dual=True, flag=0, sub=0.03, ind=0.15, ragged=True, resident_n=16384),
     # splice-aware extension and gap-linear X-drop extension (N3): see DESIGN.md sections 3.6 / 3.7
     "exts": dict(idx=7, n=16384, qlen=400, tlen=1500, w=-1, zdrop=-1, dual=False, flag=0, sub=0.03, ind=0.0, splice=True),
     "extf": dict(idx=8, n=16384, qlen=1000, tlen=1000, w=100, zdrop=-1, dual=False, flag=SO, sub=0.05, ind=0.01, linear=True),
 }
-ALSO_DEFAULT = ["10k-n1024", "10k-cigar", "cfg2", "cfg3", "cfg5", "cfg4"]
+ALSO_DEFAULT = ["10k-n1024", "10k-cigar", "cfg2", "cfg3", "cfg5", "cfg4", "cfg5-share"]
+# N > 1: the configurations BASELINE.json quotes for several GPUs at their per-GPU share (config 4: 4 096 replicas / 8)
+ALSO_MULTI = {"cfg5-share": None, "cfg4": 512}
 SCORING = dict(a=2, b=4, sc_n=-1, q=4, e=2, q2=24, e2=1)
 LINEAR_SCORING = dict(mch=2, mis=-4, e=2)
 SPLICE_SCORING = dict(a=1, b=2, sc_n=0, q=2, e=1, q2=32, noncan=4)
@@ -297,6 +302,7 @@ class Job:
         if nres and nres < self.n:          # a plan of the whole batch does not fit one device: a slice of it
             S = SCORING
             b = self.lib.make_batch(self.q[:nres], self.t[:nres], self.mat, S["q"], S["e"], S["q2"], S["e2"], w=wl["w"], zdrop=wl["zdrop"], end_bonus=0, flag=wl["flag"])
+            b.qlen, b.tlen = self.qlen[:nres], self.tlen[:nres]
         plan = b.plan() if self.kind in ("exts", "extf") else b.sse_plan(wl["dual"]) if self.sse else b.plan(wl["dual"])
         cells = plan.cells()
         for _ in range(warmup):
@@ -435,12 +441,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
-    if not torch.cuda.is_available():
+    # KSW2_BENCH_PLUMBING_LIB=<tests/sim/libksw2_amd_sim.so>: the CPU test tier runs this script's multi-rank plumbing (rendezvous,
+    # barriers, reductions, the JSON line) against the lock-step simulator build with a handful of pairs.  The line then says so
+    # ("data": "... NOT A MEASUREMENT"); no GPU, no product library, no number anyone should read.
+    plumbing = os.environ.get("KSW2_BENCH_PLUMBING_LIB")
+    if not plumbing and not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product path has no CPU fallback")
     # KSW2_BENCH_BACKEND=gloo + KSW2_BENCH_ONE_DEVICE=1 exist only to exercise the multi-rank code path on a 1-GPU box
-    backend = os.environ.get("KSW2_BENCH_BACKEND", "nccl")
+    backend = "gloo" if plumbing else os.environ.get("KSW2_BENCH_BACKEND", "nccl")
     dev = 0 if os.environ.get("KSW2_BENCH_ONE_DEVICE") else local_rank
-    torch.cuda.set_device(dev)
+    if not plumbing:
+        torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -449,15 +460,23 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
-    lib = ksw2_amd.library()
-    lib.set_device(dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    if plumbing:
+        if not (0 < args.pairs <= 256):
+            sys.exit("KSW2_BENCH_PLUMBING_LIB needs --pairs <= 256: the simulator is a test vehicle")
+        lib = ksw2_amd.Library(plumbing)
+        stream = None
+    else:
+        lib = ksw2_amd.library()
+        lib.set_device(dev)
+        stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
-        torch.cuda.synchronize()
+        if not plumbing:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not plumbing:
+            torch.cuda.synchronize()
 
     # ------------------------------------------------------------------ headline
     job = Job(lib, args.workload, WORKLOADS[args.workload], rank, args.pairs or None, approx=args.approx, sse=args.sse_compat)
@@ -476,7 +495,13 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     stats1 = lib.host_stats()
+    per_rank = None
     if world > 1:
+        mine = torch.tensor([float(job.cells), dt], dtype=torch.float64, device=red_dev)
+        allr = [torch.zeros(2, dtype=torch.float64, device=red_dev) for _ in range(world)]
+        dist.all_gather(allr, mine)                                     # load balance: every rank's cells and its own loop time
+        per_rank = [{"rank": r, "cells_per_step": float(x[0].item()), "loop_seconds": round(float(x[1].item()), 4),
+                     "gcups": round(float(x[0].item()) * args.steps / float(x[1].item()) / 1e9, 1)} for r, x in enumerate(allr)]
         tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -532,7 +557,8 @@ def main():
                                            "no host pass over the bytes); transfer-inclusive like `value`" if dt_flat else None,
             "pairs_per_s": round(pairs_all * args.steps / dt, 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "timed_region_s": round(dt, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_of(job, res), "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_of(job, res),
+            "data": "synthetic" if not plumbing else "synthetic -- PLUMBING TEST ON THE CPU SIMULATOR, NOT A MEASUREMENT",
             "config": {"workload": describe(job, world), "cells_per_step_per_gpu": job.cells,
                        "host_pipeline": {k: stats1[k] - stats0[k] for k in stats1},
                        "parallelism": "pairs sharded over %d GPU(s), one process per GPU, no collective in the data path" % world},
@@ -543,35 +569,49 @@ def main():
             out["parity_sample_flat_arena"] = parity_flat["result"]
         if sg:
             out["config"]["rank0_scatter_gather"] = sg
+        if per_rank:
+            out["config"]["per_rank"] = per_rank
     # ------------------------------------------------------------------ the other configurations (N = 1: one run covers them all)
     names = ALSO_DEFAULT if args.also is None else [x for x in args.also.split(",") if x]
     if args.no_also or world > 1 or args.pairs or args.approx or args.sse_compat or args.workload != "10k":
         names = [] if args.also is None else names
+    if world > 1 and args.also is None and not (args.no_also or args.pairs or args.approx or args.sse_compat or args.workload != "10k"):
+        names = list(ALSO_MULTI)                                 # the multi-GPU configurations at their per-GPU share, every rank its own slice
     also = []
     for name in names:
         if name == args.workload:
             continue
         try:
-            j = Job(lib, name, WORKLOADS[name], rank)
-            j.e2e_step()                                         # warm-up: buffers, streams, worker threads (every worker's first
-            j.e2e_step()                                         # chunk allocates its device buffers)
-            t0 = time.perf_counter()
-            k = 0
-            while k < 3 or time.perf_counter() - t0 < 1.5:
-                j.e2e_step()
-                k += 1
-            edt = time.perf_counter() - t0
+            j = Job(lib, name, WORKLOADS[name], rank, ALSO_MULTI.get(name) if world > 1 else None)
+            big = j.cells > 5e11                                 # seconds per step: one warm-up, two timed steps
+            def timed(flat):
+                """>= 3 steps and >= 1.5 s (big workloads: 2 steps) of the batch entry point; N > 1: between barriers, the slowest rank's time,
+                every rank's cells."""
+                for _ in range(1 if big else 2):                 # warm-up: buffers, streams, worker threads (every worker's first chunk
+                    j.e2e_step(flat=flat)                        # allocates its device buffers)
+                barrier()
+                t0 = time.perf_counter()
+                kk = 0
+                while kk < (2 if big else 3) or (world == 1 and not big and time.perf_counter() - t0 < 1.5):
+                    j.e2e_step(flat=flat)
+                    kk += 1
+                barrier()
+                el = time.perf_counter() - t0
+                cells = float(j.cells)
+                if world > 1:
+                    red = torch.tensor([el, -cells], dtype=torch.float64, device=red_dev)
+                    dist.all_reduce(red, op=dist.ReduceOp.MAX)           # slowest rank
+                    el = float(red[0].item())
+                    tot = torch.tensor([cells], dtype=torch.float64, device=red_dev)
+                    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+                    cells = float(tot.item())
+                return kk, el, cells
+            k, edt, cells_sum = timed(False)
             jpar = j.parity_sample(1 if WORKLOADS[name].get("mt") else 6)
             vflat = None
             if j.flat_ready():
-                j.e2e_step(flat=True)
-                j.e2e_step(flat=True)
-                t0 = time.perf_counter()
-                kf = 0
-                while kf < 3 or time.perf_counter() - t0 < 1.5:
-                    j.e2e_step(flat=True)
-                    kf += 1
-                vflat = round(j.cells * kf / (time.perf_counter() - t0) / 1e9, 2)
+                kf, fdt, _ = timed(True)
+                vflat = round(cells_sum * kf / fdt / 1e9, 2)
                 jparf = j.parity_sample(1 if WORKLOADS[name].get("mt") else 4)
                 j.flat_done()
             j.free_ez()
@@ -579,9 +619,9 @@ def main():
             r = j.resident(3, 1, stream, min_seconds=1.0)
             lib.release_cache()
             rr = roofline_of(j, r, name)
-            also.append({"workload": describe(j, world), "value": round(j.cells * k / edt / 1e9, 2), "value_flat_arena": vflat, "value_hbm_resident": rr["kernel_gcups"],
+            also.append({"workload": describe(j, world), "n_gpus": world, "value": round(cells_sum * k / edt / 1e9, 2), "value_flat_arena": vflat, "value_hbm_resident": rr["kernel_gcups"],
                          **({"parity_sample_flat_arena": jparf["result"]} if vflat else {}),
-                         "unit": "GCUPS", "pairs_per_s": round(j.n * k / edt, 1), "steps": k, "ms_per_step": round(edt / k * 1e3, 3),
+                         "unit": "GCUPS", "pairs_per_s": round(j.n * world * k / edt, 1), "steps": k, "ms_per_step": round(edt / k * 1e3, 3),
                          "dtype": dtype_of(j, r), "parity_sample": "%s (%d pairs)" % (jpar["result"], jpar["pairs"]),
                          "roofline": {x: rr[x] for x in ("frac", "kernel_ms", "fill_kernel_ms", "ops_per_cell", "pairs_per_launch", "kernels",
                                                          "kernel_gcups_cells_filled", "early_stop_fraction", "zdropped_pairs", "traffic", "traffic_source")}})

@@ -519,13 +519,20 @@ static int trace_level(void) { const char *e = ENV(TRACE); return e ? atoi(e) : 
  * no staging copy, no host pass over the bytes.  What the gather pass also did was to look for wildcard codes (the packed kernels
  * cannot score them): flat plans leave that to the packed kernels themselves (K2aLanePk::seen) and re-run what they report. */
 typedef struct { int on_device; } flat_src_t;
+static uint64_t or_bytes(const uint8_t *p, int n)
+{
+	uint64_t acc = 0, v0, v1, v2, v3;
+	int i = 0;
+	for (; i + 32 <= n; i += 32) {
+		memcpy(&v0, p + i, 8); memcpy(&v1, p + i + 8, 8); memcpy(&v2, p + i + 16, 8); memcpy(&v3, p + i + 24, 8);
+		acc |= (v0 | v1) | (v2 | v3);
+	}
+	for (; i < n; ++i) acc |= p[i];
+	return acc;
+}
 static int pair_has_wild(const ksw2amd_pair_t *a)
 {
-	uint64_t acc = 0;
-	int i;
-	for (i = 0; i < a->qlen; ++i) acc |= a->query[i];
-	for (i = 0; i < a->tlen; ++i) acc |= a->target[i];
-	return (acc & 0xfc) != 0;
+	return ((or_bytes(a->query, a->qlen) | or_bytes(a->target, a->tlen)) & 0xfcfcfcfcfcfcfcfcull) != 0;
 }
 
 static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, const flat_src_t *flat)

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import KswExtz, LinearPair, Pair, Scoring, SplicePair, SpliceScoring, _i8p, _libc
+from . import Flat, KswExtz, LinearPair, Pair, Scoring, SplicePair, SpliceScoring, _i8p, _libc
 
 META = 8   # qlen, tlen, w, zdrop, end_bonus, flag, original index, has-junction-array
 RES = 12   # score, max, max_t, max_q, mqe, mqe_t, mte, mte_q, zdropped, reach_end, n_cigar, original index
@@ -83,9 +83,10 @@ def _exchange(ops):
             req.wait()
 
 
-def scatter_arrays(parts, dtypes, src=0, group=None):
+def scatter_arrays(parts, dtypes, src=0, group=None, keep_device=()):
     """Rank `src` holds parts[r] = tuple of numpy arrays for rank r (one per entry of `dtypes`); every rank returns its own
-    tuple.  Sizes travel in one broadcast, payloads in one group of point-to-point transfers of exactly their size."""
+    tuple.  Sizes travel in one broadcast, payloads in one group of point-to-point transfers of exactly their size.
+    keep_device: entries that a receiving rank gets back as the device tensor RCCL delivered (no copy to host memory)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     k = len(dtypes)
     sizes = torch.zeros((world, k), dtype=torch.int64)
@@ -112,7 +113,7 @@ def scatter_arrays(parts, dtypes, src=0, group=None):
         if sizes[rank, x]:
             ops.append(dist.P2POp(dist.irecv, bufs[x], _peer(group, src), group))
     _exchange(ops)
-    return tuple(_from_wire(b) for b in bufs)
+    return tuple(bufs[x] if (x in keep_device and bufs[x].is_cuda) else _from_wire(bufs[x]) for x in range(k))
 
 
 def gather_arrays(local, dtypes, dst=0, group=None):
@@ -166,21 +167,40 @@ def _bc(v, n):
     return np.full(n, int(a), dtype=np.int64) if a.ndim == 0 else a
 
 
-def align_flat(lib, kind, seq, meta, scoring, junc=None):
+def align_flat(lib, kind, seq, meta, scoring, junc=None, device_base=None):
     """One rank's shard through the C-ABI batch entry point.  `seq` = all queries then all targets of the shard (then all
-    junction arrays, exts only), `meta` int32 [n, META].  Returns (records int32 [n, RES], CIGAR words int32 flat)."""
+    junction arrays, exts only), `meta` int32 [n, META].  Returns (records int32 [n, RES], CIGAR words int32 flat).
+    A shard that RCCL delivered into device memory (`seq` a CUDA tensor, or `device_base` = its address) stays there: extz / extd
+    shards go through ksw2amd_ext?_batch_flat with on_device = 1 -- scatter -> align -> gather never copies the sequences through
+    host memory on a receiving rank."""
     n = len(meta)
     rec = np.zeros((n, RES), dtype=np.int32)
     if n == 0:
         return rec, np.zeros(0, dtype=np.int32)
-    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    on_device = device_base is not None or (isinstance(seq, torch.Tensor) and seq.is_cuda)
+    if on_device and kind not in ("extz", "extd"):          # the splice-aware / X-drop entry points take host pointers
+        seq = seq.cpu().numpy() if isinstance(seq, torch.Tensor) else seq
+        on_device, device_base = False, None
+    if on_device and device_base is None:
+        device_base = seq.data_ptr()
+    if not on_device:
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
     ql, tl = meta[:, 0].astype(np.int64), meta[:, 1].astype(np.int64)
-    base = seq.ctypes.data
+    base = 0 if on_device else seq.ctypes.data
     qoff = np.concatenate([[0], np.cumsum(ql)[:-1]])
     toff = int(ql.sum()) + np.concatenate([[0], np.cumsum(tl)[:-1]])
     ez = np.zeros(n, dtype=_EZ_DTYPE)
     ezp = ez.ctypes.data_as(ctypes.POINTER(KswExtz))
-    if kind in ("extz", "extd"):
+    if on_device:
+        qo, to = np.ascontiguousarray(qoff, dtype=np.uint64), np.ascontiguousarray(toff, dtype=np.uint64)
+        cols = [np.ascontiguousarray(meta[:, c], dtype=np.int32) for c in (0, 1, 2, 3, 4, 5)]
+        flat = Flat(device_base, qo.ctypes.data, to.ctypes.data, *[c.ctypes.data for c in cols], 0, 0, 0, 0, 1)
+        mat = np.ascontiguousarray(scoring["mat"], dtype=np.int8)
+        sc = Scoring(int(scoring.get("m") or round(len(mat) ** 0.5)), mat.ctypes.data_as(_i8p), scoring["q"], scoring["e"],
+                     scoring.get("q2", 0), scoring.get("e2", 0))
+        f = lib.lib.ksw2amd_extd_batch_flat if kind == "extd" else lib.lib.ksw2amd_extz_batch_flat
+        lib._check(f(None, ctypes.byref(sc), n, ctypes.byref(flat), ezp))
+    elif kind in ("extz", "extd"):
         pr = np.zeros(n, dtype=np.dtype([("query", "<u8"), ("target", "<u8"), ("qlen", "<i4"), ("tlen", "<i4"), ("w", "<i4"),
                                          ("zdrop", "<i4"), ("end_bonus", "<i4"), ("flag", "<i4")]))
         assert pr.dtype.itemsize == ctypes.sizeof(Pair)
@@ -252,7 +272,7 @@ def sharded(lib, kind, queries, targets, scoring, w=-1, zdrop=-1, end_bonus=0, f
                             m[row, 7] = 1
                             bufs.append(np.asarray(juncs[i], dtype=np.uint8))
             parts.append((m.reshape(-1), np.concatenate(bufs)))
-    meta, seq = scatter_arrays(parts, (np.int32, np.uint8), src, group)
+    meta, seq = scatter_arrays(parts, (np.int32, np.uint8), src, group, keep_device=(1,))      # the sequences stay where RCCL put them
     rec, cig = align_flat(lib, kind, seq, meta.reshape(-1, META), scoring)
     got = gather_arrays((rec.reshape(-1), cig), (np.int32, np.int32), src, group)
     if rank != src:

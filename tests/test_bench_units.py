@@ -66,3 +66,28 @@ def test_job_dry_run_on_the_simulator(sim, name, monkeypatch):
     if name not in ("exts",):
         assert r["cells"] == (j.cells if name != "cfg4" else int(bench.cells_of_rows(j.qlen[:3], j.tlen[:3], j.weff[:3]).sum()))
     assert bench.describe(j, 1).startswith(name) and bench.dtype_of(j, r)
+
+
+def test_bench_two_ranks_plumbing(sim, tmp_path):
+    """`python bench.py --gpus 2` end to end on the CPU tier: the script launches its own two ranks through torch.distributed.run
+    (before anything could touch a GPU), they rendezvous over gloo, time K steps between barriers, reduce MAX time / SUM cells,
+    run the rank-0 scatter/gather leg (ksw2_amd/parallel.py) and rank 0 prints ONE well-formed JSON line.  The simulator build stands
+    in for the per-rank GPU (KSW2_BENCH_PLUMBING_LIB): the line says that it is not a measurement."""
+    import json
+    import sys
+    root = os.path.dirname(SIM_DIR.rstrip("/")).rsplit("/tests", 1)[0]
+    env = dict(os.environ, KSW2_BENCH_PLUMBING_LIB=os.path.join(SIM_DIR, "libksw2_amd_sim.so"), MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "cfg3", "--pairs", "24",
+                        "--no-cpu", "--no-also"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "GCUPS"
+    assert d["value"] > 0 and d["parity_sample"] == "ok" and "NOT A MEASUREMENT" in d["data"]
+    pr = d["config"]["per_rank"]
+    assert [x["rank"] for x in pr] == [0, 1] and all(x["cells_per_step"] > 0 for x in pr)
+    assert d["config"]["rank0_scatter_gather"]["records_checked"] == 48
+    assert {"bound", "achieved", "peak", "frac", "traffic"} <= set(d["roofline"])

@@ -947,8 +947,26 @@ if rank == 0:
     pairs = synth.ragged_pairs(rng, 41, 50, 900, sub=0.05, ind=0.1)
     qs, ts = [p[0] for p in pairs], [p[1] for p in pairs]
 res = parallel.sharded(lib, "extd", qs, ts, dict(mat=mat, q=4, e=2, q2=24, e2=1), w=100, zdrop=200, flag=0)
+ok = True
 if rank == 0:
     ok = all(all(po.align("oracle", "extd2", qs[i], ts[i], mat, 4, 2, 24, 1, w=100, zdrop=200)[k] == res[i][k] for k in ka.FIELDS + ["cigar"]) for i in range(41))
+# the splice-aware and the gap-linear X-drop batches shard the same way (host pointers on the receiving rank)
+ss = st = None
+if rank == 0:
+    from oracle.gen_golden_exts import spliced_pair
+    rng = np.random.Generator(np.random.PCG64(5))
+    cases = [spliced_pair(rng, 300) for _ in range(13)]
+    ss, st = [c[0] for c in cases], [c[1] for c in cases]
+smat = synth.simple_mat(5, 1, 2, 0)
+res = parallel.sharded(lib, "exts", ss, st, dict(mat=smat, q=2, e=1, q2=32, noncan=4), zdrop=-1, flag=ka.KSW_EZ_SPLICE_FOR)
+if rank == 0:
+    ok &= all(all(po.exts2("oracle", ss[i], st[i], smat, 2, 1, 32, 4, zdrop=-1, flag=po.SPLICE_FOR)[k] == res[i][k] for k in ka.FIELDS + ["cigar"]) for i in range(13))
+fq = ft = None
+if rank == 0:
+    fq, ft = synth.fixed_batch(4, 33, 400, 410, sub=0.05, ind=0.03)
+res = parallel.sharded(lib, "extf", fq, ft, dict(mch=2, mis=-4, e=2), w=40, zdrop=50)
+if rank == 0:
+    ok &= all(all(po.extf2("oracle", fq[i], ft[i], 2, -4, 2, 40, 50)[k] == res[i][k] for k in ka.FIELDS) for i in range(33))
     print("NCCL_SHARD_OK" if ok else "NCCL_SHARD_BAD")
 dist.destroy_process_group()
 ''' % root

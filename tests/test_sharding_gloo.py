@@ -60,6 +60,23 @@ if rank == 0:
     for i in range(11):
         exp = po.extf2("oracle", q2d[i], t2d[i], 2, -4, 2, 25, 30)
         ok &= all(exp[k] == res[i][k] for k in ka.FIELDS)
+# a shard that arrived in device memory (what RCCL delivers on a receiving rank) is aligned where it lies: the simulator's
+# "device" memory stands in, through the same ksw2amd_ext?_batch_flat(on_device = 1) call
+rng = np.random.Generator(np.random.PCG64(23 + rank))
+pairs = synth.ragged_pairs(rng, 9, 20, 300, sub=0.05, ind=0.1)
+pq, pt = [p[0] for p in pairs], [p[1] for p in pairs]
+pq[2] = pq[2].copy(); pq[2][3] = 4                      # a wildcard: reported by the packed kernel, re-run from the device arena
+meta = np.zeros((9, parallel.META), dtype=np.int32)
+meta[:, 0], meta[:, 1], meta[:, 2], meta[:, 3], meta[:, 5], meta[:, 6] = [len(x) for x in pq], [len(x) for x in pt], 64, 100, 0, np.arange(9)
+seq = np.concatenate(pq + pt)
+dptr = lib.device_copy(seq)
+rec, cig = parallel.align_flat(lib, "extd", None, meta, dict(mat=mat, q=q, e=e, q2=q2, e2=e2), device_base=dptr)
+rec2, cig2 = parallel.align_flat(lib, "extd", seq, meta, dict(mat=mat, q=q, e=e, q2=q2, e2=e2))
+lib.device_free(dptr)
+assert np.array_equal(rec, rec2) and np.array_equal(cig, cig2), rank
+for i in range(9):
+    exp = po.align("oracle", "extd2", pq[i], pt[i], mat, q, e, q2, e2, w=64, zdrop=100)
+    assert exp["score"] == rec[i, 0] and exp["n_cigar"] == rec[i, 10], (rank, i)
 # an empty shard (more ranks than pairs) must work too
 res = parallel.sharded_align(lib, False, [np.array([1, 2], np.uint8)] if rank == 0 else None, [np.array([1, 2], np.uint8)] if rank == 0 else None, mat, q, e)
 if rank == 0:
