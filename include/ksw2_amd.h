@@ -16,9 +16,10 @@
  * narrow bands; two reference bugs are not reproduced (ksw_extd2_sse with e == e2; its first cell when it swaps the
  * gap pieces).  The SSE-compatible mode (KSW2AMD_EZ_SSE_COMPAT, below) returns the SSE functions' own results instead,
  * every field and the CIGAR, and KSW_EZ_APPROX_MAX | KSW_EZ_APPROX_DROP always does.
- * There is no CPU fallback: without a usable gfx950 device the ksw2-named entry points print the error
- * to stderr and abort() (or report through ksw2amd_set_error_handler); the ksw2amd_* entry points return a negative
- * code (see ksw2amd_last_error()).
+ * There is no CPU fallback: without a usable gfx950 device the ksw2-named entry points (which return void) reset *ez
+ * (score = KSW_NEG_INF, no CIGAR), count the failure (ksw2amd_error_count), keep its message (ksw2amd_last_error) and report it
+ * on stderr or through ksw2amd_set_error_handler -- they never abort across the C boundary unless KSW2AMD_ABORT_ON_ERROR=1 asks
+ * for it; the ksw2amd_* entry points return a negative code.
  *
  * Reference interface each declaration replaces is cited as (ksw2.h:LINE).
  */
@@ -161,9 +162,10 @@ void ksw2amd_release_cache(void);
  * the batch from a shared counter).  n = 0 (the default): the calling thread's current device only.
  * Replaces nothing in the reference (ksw2.h has no device notion); SURVEY.md section 8b "device selection / multi-GPU inside". */
 int ksw2amd_set_devices(int n, const int *devices);
-/* The ksw2-named functions return void (ksw2.h:61-76), so a device failure has no return channel.  Default: message on
- * stderr and abort() -- there is no CPU fallback to hide behind.  With a handler installed the failing call invokes it
- * (function name, KSW2AMD_E_* code, message) and returns with *ez reset (ksw2.h:184-189: score = KSW_NEG_INF, no CIGAR). */
+/* The ksw2-named functions return void (ksw2.h:61-76), so a device failure has no return channel.  The failing call returns with
+ * *ez reset (ksw2.h:184-189: score = KSW_NEG_INF, no CIGAR), ksw2amd_error_count() goes up, ksw2amd_last_error() holds the message;
+ * by default it is also printed on stderr (first occurrences), with a handler installed the handler gets (function name,
+ * KSW2AMD_E_* code, message) instead.  KSW2AMD_ABORT_ON_ERROR=1: abort() after the report. */
 typedef void (*ksw2amd_error_fn)(const char *func, int code, const char *msg, void *user);
 void ksw2amd_set_error_handler(ksw2amd_error_fn fn, void *user);
 long ksw2amd_error_count(void);        /* failed ksw2-named calls so far */

@@ -44,6 +44,7 @@ static void release_thread_cache(void);
  * single-pair calls above all, never touch getenv().  ksw2amd_reload_env() reads them again (tests that flip a switch inside
  * one process; the Python binding calls it before every plan / batch). */
 #define K2A_ENV_LIST \
+	X(ABORT_ON_ERROR) \
 	X(APPROX_DROP_EXACT) \
 	X(CHUNKS) \
 	X(CHUNK_GCELLS) \
@@ -1935,10 +1936,11 @@ int ksw2amd_host_unregister(const void *p)
 
 /* ---------------------------------------------------------------- the ksw2-named single-pair calls */
 
-/* The ksw2 signatures return void: a HIP failure (no device, out of memory) has no channel.  There is no CPU fallback, so by
- * default the library reports on stderr and aborts.  A caller that must survive installs a handler: it is called with the
- * function name, the KSW2AMD_E_* code and the message, and the call then returns with `ez` reset (score = KSW_NEG_INF,
- * no CIGAR) -- never with a made-up result.  ksw2amd_error_count() tells how often that happened. */
+/* The ksw2 signatures return void: a HIP failure (no device, out of memory) has no channel, and there is no CPU fallback to hide
+ * it behind.  A failing call never crosses the C boundary with an abort or a made-up result: it returns with `ez` reset (score =
+ * KSW_NEG_INF, no CIGAR -- "no alignment" in the reference's own terms, ksw2.h:184-189), counts itself (ksw2amd_error_count),
+ * leaves its message in ksw2amd_last_error() and says so on stderr (the first few times, then every 1000th).  A caller that wants
+ * to know at once installs a handler (function name, KSW2AMD_E_* code, message); KSW2AMD_ABORT_ON_ERROR=1 aborts instead. */
 static ksw2amd_error_fn g_err_fn;
 static void *g_err_user;
 static long g_err_count;
@@ -1951,8 +1953,9 @@ static void call_failed(const char *fn, int code, ksw_extz_t *ez)
 	__sync_fetch_and_add(&g_err_count, 1);
 	if (ez) ez_reset(ez);
 	if (g_err_fn) { g_err_fn(fn, code, g_err, g_err_user); return; }
-	fprintf(stderr, "[ksw2_amd] %s: %s -- libksw2_amd has no CPU fallback (install ksw2amd_set_error_handler() to survive), aborting\n", fn, g_err);
-	abort();
+	if (g_err_count <= 8 || g_err_count % 1000 == 0)
+		fprintf(stderr, "[ksw2_amd] %s failed (%ld so far): %s -- libksw2_amd has no CPU fallback; *ez is reset (score = KSW_NEG_INF)\n", fn, g_err_count, g_err);
+	if (env_flag(ENV(ABORT_ON_ERROR), 0)) abort();
 }
 
 static int queue_one(const char *fn, int dual, void *km, const ksw2amd_scoring_t *sc, const ksw2amd_pair_t *pr, ksw_extz_t *ez);

@@ -40,7 +40,9 @@
 #define K2A_PK_VMAX  (0x7BFF - K2A_OFS16)       /* 12287 */
 #define K2A_PK_SLACK (K2A_OFS16 + K2A_NEG16)    /* 3072: room below -inf for the base shifts and gap costs applied to it */
 /* packed generation-serial class (ksw2_lane_pkmp.h): sliding base */
+#ifndef K2A_PKMP_T
 #define K2A_PKMP_T    64            /* steps between re-bases (a power of two) */
+#endif
 #define K2A_PKMP_DEAD (-8192)       /* relative values below this are -inf */
 #define K2A_PKMP_RMAX_LIMIT 10000   /* a window's row maximum further above the base than this is merged into its key; it may drift
                                      * K2A_PKMP_T steps further before the next check and must still fit K2A_PK_VMAX */

@@ -160,6 +160,19 @@ def test_concurrent_single_calls_coalesce(sim):
             assert not diff(exp, out[t][i], CMP_FIELDS), (t, i)
 
 
+def test_failing_call_returns_reset_ez_without_a_handler(sim, capfd):
+    """No handler installed: the failing ksw2-named call does not abort -- it resets *ez, counts the failure, keeps the message and
+    says so on stderr."""
+    before = sim.error_count()
+    ez = ka.KswExtz()
+    ez.score = 123
+    mat = synth.simple_mat(5, 2, 4, -1)
+    sim.lib.ksw_extd2_sse(None, 5, None, 5, None, 5, mat.ctypes.data_as(ctypes.POINTER(ctypes.c_int8)), 4, 2, 24, 1, -1, -1, 0, 0, ctypes.byref(ez))
+    assert sim.error_count() == before + 1 and ez.score == ka.KSW_NEG_INF and ez.n_cigar == 0
+    assert "NULL" in sim.last_error()
+    assert "ksw_extd2_sse failed" in capfd.readouterr().err
+
+
 def test_error_handler_replaces_abort(sim, monkeypatch):
     """A failing ksw2-named call (here: a scoring matrix with more than 127 residue types is impossible through int8_t m, so
     an invalid device is used instead) calls the installed handler and returns with ez reset instead of aborting."""

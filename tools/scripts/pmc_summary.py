@@ -60,9 +60,13 @@ def main():
             cyc = c["GRBM_GUI_ACTIVE"] / 8.0                       # summed over 8 XCDs
             d["shader_cycles_per_xcd"] = cyc
             d["shader_clock_GHz"] = cyc / (d["avg_ms"] * 1e6)
-            # SQ_ACTIVE_INST_VALU is in quad-cycles, summed over the 1024 SIMDs
-            d["valu_pipe_busy_fraction"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 1024)
-            d["valu_cycles_per_inst"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"] if c.get("SQ_INSTS_VALU") else None
+            # What the counters give without assumptions: SIMD cycles that went by per wave64 VALU instruction issued (all 1024
+            # SIMDs, whole kernel).  On this part SQ_ACTIVE_INST_VALU reads the same as SQ_INSTS_VALU, and instructions do not
+            # cost a uniform 4 cycles (tools/probe/valu_rate.hip: 2.5 for 32-bit add / sub / logic / v_bitop3, 4.2-4.4 for packed,
+            # 5.1 for v_pk_maximum3_f16), so round 2's "valu_pipe_busy_fraction" (instructions x 4 / cycles, > 1 on the headline) is
+            # gone: compare this figure with the class-weighted cost of the kernel's instruction mix instead.
+            if c.get("SQ_INSTS_VALU"):
+                d["simd_cycles_per_valu_inst"] = cyc * 1024 / c["SQ_INSTS_VALU"]
             d["mean_resident_waves_per_simd"] = c.get("SQ_WAVE_CYCLES", 0.0) * 4.0 / (cyc * 1024)
     with open(os.path.join(dst, "%s_%s_pmc.json" % (tag, wl)), "w") as fp:
         json.dump(res, fp, indent=1)
