@@ -127,7 +127,8 @@ int ksw2amd_set_device(int device)
  * the next plan when they are large enough.  ksw2amd_release_cache() returns them; switching device flushes them. */
 enum { BUF_HSEQ, BUF_SEQ, BUF_PAIRS, BUF_RES, BUF_ORDER, BUF_TB, BUF_CIG, BUF_BND, BUF_POS, BUF_POOL, BUF_HPOOL, BUF_HRES, BUF_KINDS };
 #define BUF_IS_HOST(k) ((k) == BUF_HSEQ || (k) == BUF_HPOOL || (k) == BUF_HRES)      /* pinned host staging; everything else is device memory */
-static __thread struct { void *p; size_t cap; } g_cache[BUF_KINDS];
+#define CACHE_DEPTH 2                  /* a worker that queues its next chunk before it fetches the current one holds two plans */
+static __thread struct { void *p; size_t cap; } g_cache[BUF_KINDS][CACHE_DEPTH];
 static __thread void *g_ev_cache[3];
 /* Every host thread uploads and (in the one-shot entry points) computes on a stream of its own, so concurrent callers --
  * a minimap2-style thread pool -- overlap their copies and kernels instead of queueing on the device's default stream. */
@@ -195,9 +196,12 @@ static void cache_free_raw(int kind, void *p) { if (BUF_IS_HOST(kind)) k2a_shim_
 static void *cache_get(int kind, size_t bytes, size_t *cap)
 {
 	void *p;
-	if (g_cache[kind].p && g_cache[kind].cap >= bytes) {
-		p = g_cache[kind].p; *cap = g_cache[kind].cap;
-		g_cache[kind].p = 0; g_cache[kind].cap = 0;
+	int d, best = -1;
+	for (d = 0; d < CACHE_DEPTH; ++d)          /* the smallest cached buffer that is large enough */
+		if (g_cache[kind][d].p && g_cache[kind][d].cap >= bytes && (best < 0 || g_cache[kind][d].cap < g_cache[kind][best].cap)) best = d;
+	if (best >= 0) {
+		p = g_cache[kind][best].p; *cap = g_cache[kind][best].cap;
+		g_cache[kind][best].p = 0; g_cache[kind][best].cap = 0;
 		return p;
 	}
 	*cap = bytes + bytes / 8 + 256;                       /* a little slack so slightly larger follow-up batches still fit */
@@ -206,18 +210,26 @@ static void *cache_get(int kind, size_t bytes, size_t *cap)
 
 static void cache_put(int kind, void *p, size_t cap)
 {
+	int d, small = 0;
 	if (!p) return;
 	thread_owns_cache();
-	if (g_cache[kind].p == 0 || g_cache[kind].cap < cap) {
-		if (g_cache[kind].p) cache_free_raw(kind, g_cache[kind].p);
-		g_cache[kind].p = p; g_cache[kind].cap = cap;
+	for (d = 0; d < CACHE_DEPTH; ++d) {
+		if (!g_cache[kind][d].p) { g_cache[kind][d].p = p; g_cache[kind][d].cap = cap; return; }
+		if (g_cache[kind][d].cap < g_cache[kind][small].cap) small = d;
+	}
+	if (g_cache[kind][small].cap < cap) {                 /* keep the larger ones */
+		cache_free_raw(kind, g_cache[kind][small].p);
+		g_cache[kind][small].p = p; g_cache[kind][small].cap = cap;
 	} else cache_free_raw(kind, p);
 }
 
 static void release_thread_cache(void)
 {
 	int k;
-	for (k = 0; k < BUF_KINDS; ++k) { if (g_cache[k].p) cache_free_raw(k, g_cache[k].p); g_cache[k].p = 0; g_cache[k].cap = 0; }
+	for (k = 0; k < BUF_KINDS; ++k) {
+		int d;
+		for (d = 0; d < CACHE_DEPTH; ++d) { if (g_cache[k][d].p) cache_free_raw(k, g_cache[k][d].p); g_cache[k][d].p = 0; g_cache[k][d].cap = 0; }
+	}
 	for (k = 0; k < 3; ++k) { if (g_ev_cache[k]) k2a_shim_event_destroy(g_ev_cache[k]); g_ev_cache[k] = 0; }
 	if (g_stream) { k2a_shim_stream_sync(g_stream); k2a_shim_stream_destroy(g_stream); g_stream = 0; }
 	if (g_up_stream) { k2a_shim_stream_sync(g_up_stream); k2a_shim_stream_destroy(g_up_stream); g_up_stream = 0; }
@@ -311,6 +323,8 @@ struct ksw2amd_plan_s {
 	/* flat plans (ksw2amd_plan_create_flat): the sequences went up as they lie in the caller's arena -- no staging copy, no host
 	 * scan for wildcard codes; the packed kernels report such codes and fetch re-runs those pairs (flat_rerun) */
 	int flat, flat_device, scalar;         /* flat: h_seq (host arenas) is the caller's memory, not a staging buffer */
+	void *up_ev;                           /* flat plans from host arenas do not wait for their upload: the run's stream waits for this event */
+	uint8_t *flat_tail;                    /* ... and the staging block of the arena's padding lives as long as the plan */
 	ksw2amd_pair_t *src_pairs;             /* the caller's pairs (pointers into the arena), kept for the re-runs */
 	ksw2amd_scoring_t src_sc; int8_t *src_mat;
 };
@@ -482,6 +496,7 @@ void ksw2amd_plan_destroy(ksw2amd_plan_t *p)
 {
 	int i;
 	if (!p) return;
+	if (p->up_ev) { k2a_shim_event_sync(p->up_ev); k2a_shim_event_destroy(p->up_ev); p->up_ev = 0; }      /* the upload reads host blocks freed below */
 	if (p->stream_used) k2a_shim_stream_sync(p->stream);     /* nothing may still be running on buffers that get recycled */
 	cache_put(BUF_SEQ, p->d_seq, p->cap[BUF_SEQ]); cache_put(BUF_TB, p->d_tb, p->cap[BUF_TB]);
 	cache_put(BUF_PAIRS, p->d_pairs, p->cap[BUF_PAIRS]); cache_put(BUF_RES, p->d_res, p->cap[BUF_RES]);
@@ -491,7 +506,7 @@ void ksw2amd_plan_destroy(ksw2amd_plan_t *p)
 	free(p->h_pairs); free(p->h_cls); free(p->h_half); free(p->h_flag); free(p->h_order);
 	cache_put(BUF_HRES, p->h_res, p->cap[BUF_HRES]);          /* pinned: the results come back with one asynchronous copy */
 	if (!p->flat) cache_put(BUF_HSEQ, p->h_seq, p->cap[BUF_HSEQ]);      /* (a flat plan's h_seq is the caller's arena) */
-	free(p->src_pairs); free(p->src_mat);
+	free(p->src_pairs); free(p->src_mat); free(p->flat_tail);
 	free(p);
 }
 
@@ -919,20 +934,23 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 		fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error());
 		goto err;
 	}
-	if (shared_up && !g_ev_cache[0]) g_ev_cache[0] = k2a_shim_event_create();
+	if (shared_up) p->up_ev = k2a_shim_event_create();
 	if (k2a_shim_h2d(p->d_pairs, p->h_pairs, sizeof(K2aPair) * (size_t)n, up) ||
 	    k2a_shim_h2d(p->d_order, p->h_order, sizeof(uint32_t) * (size_t)p->norder, up) ||
 	    k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)n, up) ||
 	    (p->bnd_words && k2a_shim_memset(p->d_bnd, 0xC0, p->bnd_words * 4, up)) ||
-	    /* a shared stream also carries other threads' later uploads: wait for this plan's only */
-	    (shared_up ? (!g_ev_cache[0] || k2a_shim_event_record(g_ev_cache[0], up) || k2a_shim_event_sync(g_ev_cache[0])) : k2a_shim_stream_sync(up))) {
+	    /* the shared stream: nobody waits here -- the stream the plan runs on waits for this event (ksw2amd_plan_run), so the
+	     * creating thread can pack its next chunk while this one's bytes are still on the link */
+	    (shared_up ? (!p->up_ev || k2a_shim_event_record(p->up_ev, up)) : k2a_shim_stream_sync(up))) {
 		fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error());
 		goto err;
 	}
 	if (m > 5) for (k = 0; k < p->ncls; ++k) p->cls[k].sc.mat = (const int8_t*)p->d_seq + mat_off + (p->cls[k].generic ? (size_t)m * m : 0);
 	for (i = 0; i < 3; ++i) { p->ev[i] = g_ev_cache[i] ? g_ev_cache[i] : k2a_shim_event_create(); g_ev_cache[i] = 0; }
-	free(pk_ok); free(solo_ok); free(flat_tmp);
-	/* the uploads are complete: the plan no longer refers to the creating thread's stream (which may be gone -- thread exit,
+	free(pk_ok); free(solo_ok);
+	if (shared_up) { p->flat_tail = flat_tmp; flat_tmp = 0; }       /* still being read by the upload */
+	free(flat_tmp);
+	/* the uploads are complete (or fenced by up_ev): the plan no longer refers to the creating thread's stream (which may be gone -- thread exit,
 	 * ksw2amd_release_cache, ksw2amd_set_device -- before the plan runs or is destroyed) */
 	p->stream = 0; p->stream_used = 0;
 	if (tlev) { const double t6 = now_ms(); fprintf(stderr, "[ksw2_amd] plan_create n=%d: host arrays + arena layout %.3f, copy + classify %.3f, shape parity + demotions %.3f, sequence upload call + task lists %.3f, traceback layout %.3f, uploads + sync %.3f ms\n", n, tph[1] - tph[0], tph[2] - tph[1], tph[3] - tph[2], tph[4] - tph[3] , tph[5] - tph[4], t6 - tph[5]); }
@@ -961,6 +979,7 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 	if (p->splice == 2) return extf_plan_run(p, stream);
 	if (p->splice) return exts_plan_run(p, stream);
 	p->stream = stream; p->ran = 1; p->stream_used = 1;
+	if (p->up_ev && k2a_shim_stream_wait_event(stream, p->up_ev)) goto err;      /* the plan's upload (shared stream) before its kernels */
 	if (p->reject_all || p->ntasks == 0) return KSW2AMD_OK;
 	if (k2a_shim_event_record(p->ev[0], stream)) goto err;
 	if (p->ncls > 1 && !ENV(SERIAL) && side_streams() == 0) {
@@ -1260,7 +1279,7 @@ static size_t thread_cached_device_bytes(void)
 {
 	size_t b = 0;
 	int k;
-	for (k = 0; k < BUF_KINDS; ++k) if (!BUF_IS_HOST(k) && g_cache[k].p) b += g_cache[k].cap;
+	for (k = 0; k < BUF_KINDS; ++k) { int d; for (d = 0; d < CACHE_DEPTH; ++d) if (!BUF_IS_HOST(k) && g_cache[k][d].p) b += g_cache[k][d].cap; }
 	return b;
 }
 static size_t device_budget(size_t free_b, size_t total_b, int share)
@@ -1683,13 +1702,14 @@ typedef struct { int dual, scalar, dbuf; void *km; const ksw2amd_scoring_t *sc; 
 static double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 static int trace_on(void) { return ENV(TRACE) != 0; }
 
+static double g_batch_t0;                  /* KSW2AMD_TRACE: start of the current pooled batch, for the timeline */
 static int ext_finish(ext_ctx_t *c, pend_t *pd)
 {
 	int rc = KSW2AMD_OK;
 	if (pd->p) {
 		const double t0 = now_ms();
 		rc = ksw2amd_plan_fetch(pd->p, c->km, c->ez + pd->beg);
-		if (trace_on()) fprintf(stderr, "[ksw2_amd] chunk @%d n=%d: wait+fetch %.2f ms\n", pd->beg, pd->p->n, now_ms() - t0);
+		if (trace_on()) fprintf(stderr, "[ksw2_amd] chunk @%d n=%d: wait+fetch %.2f ms (from +%.2f to +%.2f ms of the batch)\n", pd->beg, pd->p->n, now_ms() - t0, t0 - g_batch_t0, now_ms() - g_batch_t0);
 		ksw2amd_plan_destroy(pd->p);
 		pd->p = 0;
 	}
@@ -1733,7 +1753,7 @@ static int ext_chunk(void *ctx_, int beg, int end, int share, pend_t *pd)
 	}
 	t1 = now_ms();
 	rc = ksw2amd_plan_run(p, thread_stream());
-	if (trace_on()) fprintf(stderr, "[ksw2_amd] chunk @%d n=%d: pack+upload %.2f ms, launch %.2f ms, %zu device bytes\n", beg, end - beg, t1 - t0, now_ms() - t1, bytes);
+	if (trace_on()) fprintf(stderr, "[ksw2_amd] chunk @%d n=%d: pack+upload %.2f ms, launch %.2f ms, %zu device bytes (from +%.2f ms of the batch)\n", beg, end - beg, t1 - t0, now_ms() - t1, bytes, t0 - g_batch_t0);
 	rc2 = ext_finish(c, pd);
 	if (rc) { ksw2amd_plan_destroy(p); return rc; }
 	pd->p = p; pd->beg = beg;
@@ -1761,7 +1781,9 @@ static int run_pooled(chunk_fn fn, void *ctx, int n, const double *cost, double 
 	j.nchunks = make_chunks(n, cost, total, nchunks, workers, chunk_pairs, cbeg);
 	job_devices(&j);
 	j.share = imax(1, imin(tpd, (j.nchunks + j.ndev - 1) / j.ndev));      /* plans alive per device at a time: the memory budget's divisor */
+	if (trace_on()) g_batch_t0 = now_ms();
 	if (pool_run(&j)) { free(cbeg); return 0; }
+	if (trace_on()) fprintf(stderr, "[ksw2_amd] pooled batch n=%d: %d chunks on %d workers, %.2f ms\n", n, j.nchunks, j.share * j.ndev, now_ms() - g_batch_t0);
 	free(cbeg);
 	if (j.rc) snprintf(g_err, sizeof(g_err), "%s", j.err);
 	*rc = j.rc;
@@ -1812,6 +1834,10 @@ static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc
 				ext_ctx_t ctx;
 				ctx.dual = dual; ctx.scalar = scalar; ctx.km = km; ctx.sc = sc; ctx.pairs = pairs; ctx.ez = ez; ctx.flat = flat;
 				{	/* double-buffering is opt-in (see ext_chunk) */
+					/* (flat batches too: their plans are created without waiting for the upload, so a worker could pack chunk k + 1 right
+					 * after launching chunk k -- measured on config 2, round 3: 930 against 1 030 GCUPS.  The timeline
+					 * (profiles/r3_cfg2_phases.txt) shows why nothing on the host side helps any more: all eight chunks are created and
+					 * launched 1.3 ms into the batch, but their eight half-empty kernels need until 3.5 ms.) */
 					const char *ev = ENV(DBUF);
 					ctx.dbuf = ev && *ev ? atoi(ev) != 0 : 0;
 				}
@@ -1904,6 +1930,9 @@ ksw2amd_plan_t *ksw2amd_plan_create_flat(int dual, const ksw2amd_scoring_t *sc, 
 	fs.on_device = in->on_device != 0;
 	p = plan_create_ex(dual, 0, sc, n, pp, &fs);
 	free(pp);
+	/* the batch entry points let the upload run on while they pack the next chunk; a caller of this function may reuse its arena
+	 * as soon as it returns */
+	if (p && p->up_ev) { k2a_shim_event_sync(p->up_ev); k2a_shim_event_destroy(p->up_ev); p->up_ev = 0; }
 	return p;
 }
 
@@ -2305,6 +2334,7 @@ static int exts_plan_run(ksw2amd_plan_t *p, void *stream)
 {
 	int mode, g, wn;
 	p->stream = stream; p->ran = 1; p->stream_used = 1;
+	if (p->up_ev && k2a_shim_stream_wait_event(stream, p->up_ev)) goto err;      /* the plan's upload (shared stream) before its kernels */
 	if (p->reject_all || p->ntasks == 0) return KSW2AMD_OK;
 	if (k2a_shim_event_record(p->ev[0], stream)) goto err;
 	for (mode = 0; mode < 3; ++mode)
@@ -2776,6 +2806,7 @@ static int ssec_plan_run(ksw2amd_plan_t *p, void *stream)
 {
 	int mode;
 	p->stream = stream; p->ran = 1; p->stream_used = 1;
+	if (p->up_ev && k2a_shim_stream_wait_event(stream, p->up_ev)) goto err;      /* the plan's upload (shared stream) before its kernels */
 	if (p->reject_all || p->ntasks == 0) return KSW2AMD_OK;
 	if (k2a_shim_event_record(p->ev[0], stream)) goto err;
 	for (mode = 0; mode < 6; ++mode)
