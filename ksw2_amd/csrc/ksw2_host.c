@@ -530,6 +530,39 @@ static int parallel_copy(copy_ctx_t *c, int n, size_t bytes);
 static double now_ms(void);
 static int trace_level(void) { const char *e = ENV(TRACE); return e ? atoi(e) : 0; }
 
+/* What every plan creator (extz / extd, splice-aware, X-drop, SSE-compatible) starts with: the plan record and its per-pair host
+ * arrays.  `with_order`: the task list is as long as the batch (one entry per pair) and allocated here. */
+static ksw2amd_plan_t *plan_new(const char *who, int n, int with_order)
+{
+	ksw2amd_plan_t *p;
+	if (k2a_shim_device_count() <= 0) { fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend()); return 0; }
+	p = (ksw2amd_plan_t*)calloc(1, sizeof(*p));
+	if (!p) { fail(KSW2AMD_E_NOMEM, "%s: host allocation failed", who); return 0; }
+	p->n = n;
+	p->h_cls = (int8_t*)malloc((size_t)n + 1);
+	p->h_half = (uint8_t*)calloc((size_t)n + 1, 1);
+	p->h_flag = (int32_t*)malloc(sizeof(int32_t) * ((size_t)n + 1));
+	p->h_pairs = (K2aPair*)calloc((size_t)n + 1, sizeof(K2aPair));
+	p->h_res = (K2aResult*)cache_get(BUF_HRES, sizeof(K2aResult) * ((size_t)n + 1), &p->cap[BUF_HRES]);
+	if (p->h_res) memset(p->h_res, 0, sizeof(K2aResult) * ((size_t)n + 1));
+	if (with_order) p->h_order = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n + 1));
+	if (!p->h_cls || !p->h_half || !p->h_flag || !p->h_pairs || !p->h_res || (with_order && !p->h_order)) {
+		fail(KSW2AMD_E_NOMEM, "%s: host allocation failed", who);
+		ksw2amd_plan_destroy(p);
+		return 0;
+	}
+	memset(p->h_cls, -1, (size_t)n + 1);
+	return p;
+}
+/* ... and ends with: the timing events from the thread's cache; the plan no longer refers to the creating thread's upload stream
+ * (which may be gone -- thread exit, ksw2amd_release_cache, ksw2amd_set_device -- before the plan runs or is destroyed) */
+static void plan_ready(ksw2amd_plan_t *p)
+{
+	int i;
+	for (i = 0; i < 3; ++i) { p->ev[i] = g_ev_cache[i] ? g_ev_cache[i] : k2a_shim_event_create(); g_ev_cache[i] = 0; }
+	p->stream = 0; p->stream_used = 0;
+}
+
 /* `flat`: the pairs' query / target pointers all lie in ONE arena, in host memory or (flat->on_device) in device memory.  The plan
  * then uploads (or copies on the device) the arena's span as it is and addresses the sequences where they lie: no per-pair gather,
  * no staging copy, no host pass over the bytes.  What the gather pass also did was to look for wildcard codes (the packed kernels
@@ -576,18 +609,10 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	if (tlev) tph[0] = now_ms();
 	g_err[0] = 0;
 	if (n < 0 || (n > 0 && !pairs) || !sc) { fail(KSW2AMD_E_PARAM, "plan_create: bad arguments%s", 0); return 0; }
-	if (k2a_shim_device_count() <= 0) { fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend()); return 0; }
-	p = (ksw2amd_plan_t*)calloc(1, sizeof(*p));
-	if (!p) { fail(KSW2AMD_E_NOMEM, "plan_create: host allocation failed%s", 0); return 0; }
-	p->dual = !!dual; p->n = n; p->m = m = sc->m;
+	p = plan_new("plan_create", n, 0);
+	if (!p) return 0;
+	p->dual = !!dual; p->m = m = sc->m;
 	q = sc->q; e = sc->e; q2 = sc->q2; e2 = sc->e2;
-	p->h_cls = (int8_t*)malloc((size_t)n + 1);
-	p->h_half = (uint8_t*)calloc((size_t)n + 1, 1);
-	p->h_flag = (int32_t*)malloc(sizeof(int32_t) * ((size_t)n + 1));
-	p->h_pairs = (K2aPair*)calloc((size_t)n + 1, sizeof(K2aPair));
-	p->h_res = (K2aResult*)cache_get(BUF_HRES, sizeof(K2aResult) * ((size_t)n + 1), &p->cap[BUF_HRES]);
-	if (p->h_res) memset(p->h_res, 0, sizeof(K2aResult) * ((size_t)n + 1));
-	if (!p->h_cls || !p->h_half || !p->h_flag || !p->h_pairs || !p->h_res) { fail(KSW2AMD_E_NOMEM, "plan_create: host allocation failed%s", 0); goto err; }
 	for (i = 0; i < n; ++i) { p->h_cls[i] = -1; p->h_flag[i] = (pairs[i].flag & ~F_SCALAR_CONTRACT) | (scalar ? F_SCALAR_CONTRACT : 0); }
 
 	/* batch-level early rejects of the "...2_sse" signatures; the scalar-contract entry points skip the
@@ -946,13 +971,10 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 		goto err;
 	}
 	if (m > 5) for (k = 0; k < p->ncls; ++k) p->cls[k].sc.mat = (const int8_t*)p->d_seq + mat_off + (p->cls[k].generic ? (size_t)m * m : 0);
-	for (i = 0; i < 3; ++i) { p->ev[i] = g_ev_cache[i] ? g_ev_cache[i] : k2a_shim_event_create(); g_ev_cache[i] = 0; }
 	free(pk_ok); free(solo_ok);
 	if (shared_up) { p->flat_tail = flat_tmp; flat_tmp = 0; }       /* still being read by the upload */
 	free(flat_tmp);
-	/* the uploads are complete (or fenced by up_ev): the plan no longer refers to the creating thread's stream (which may be gone -- thread exit,
-	 * ksw2amd_release_cache, ksw2amd_set_device -- before the plan runs or is destroyed) */
-	p->stream = 0; p->stream_used = 0;
+	plan_ready(p);                                                  /* the uploads are complete (or fenced by up_ev) */
 	if (tlev) { const double t6 = now_ms(); fprintf(stderr, "[ksw2_amd] plan_create n=%d: host arrays + arena layout %.3f, copy + classify %.3f, shape parity + demotions %.3f, sequence upload call + task lists %.3f, traceback layout %.3f, uploads + sync %.3f ms\n", n, tph[1] - tph[0], tph[2] - tph[1], tph[3] - tph[2], tph[4] - tph[3] , tph[5] - tph[4], t6 - tph[5]); }
 	return p;
 err:
@@ -2203,18 +2225,9 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 
 	g_err[0] = 0;
 	if (n < 0 || (n > 0 && !pairs) || !sc) { fail(KSW2AMD_E_PARAM, "exts: bad arguments%s", 0); return 0; }
-	if (k2a_shim_device_count() <= 0) { fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend()); return 0; }
-	p = (ksw2amd_plan_t*)calloc(1, sizeof(*p));
-	if (!p) { fail(KSW2AMD_E_NOMEM, "exts: host allocation failed%s", 0); return 0; }
-	p->splice = 1; p->n = n; p->m = m;
-	p->h_cls = (int8_t*)malloc((size_t)n + 1);
-	p->h_half = (uint8_t*)calloc((size_t)n + 1, 1);
-	p->h_flag = (int32_t*)malloc(sizeof(int32_t) * ((size_t)n + 1));
-	p->h_pairs = (K2aPair*)calloc((size_t)n + 1, sizeof(K2aPair));
-	p->h_res = (K2aResult*)cache_get(BUF_HRES, sizeof(K2aResult) * ((size_t)n + 1), &p->cap[BUF_HRES]);
-	if (p->h_res) memset(p->h_res, 0, sizeof(K2aResult) * ((size_t)n + 1));
-	p->h_order = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n + 1));
-	if (!p->h_cls || !p->h_half || !p->h_flag || !p->h_pairs || !p->h_res || !p->h_order) { fail(KSW2AMD_E_NOMEM, "exts: host allocation failed%s", 0); goto err; }
+	p = plan_new("exts", n, 1);
+	if (!p) return 0;
+	p->splice = 1; p->m = m;
 	for (i = 0; i < n; ++i) { p->h_cls[i] = -1; p->h_flag[i] = pairs[i].flag & ~F_SCALAR_CONTRACT; }
 	/* ksw2_exts2_sse.c:74,91: unusable model or a mismatch no gap pair could undercut -> results stay reset */
 	if (m <= 1 || !sc->mat || sc->q2 <= sc->q + sc->e) p->reject_all = 1;
@@ -2322,8 +2335,7 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 		p->s_par[g].long_thres = exts_long_thres(sc->q, sc->e, sc->q2);
 		p->s_par[g].mat = (const int8_t*)p->d_seq + mat_off + (g ? (size_t)m * m : 0);
 	}
-	for (i = 0; i < 3; ++i) { p->ev[i] = g_ev_cache[i] ? g_ev_cache[i] : k2a_shim_event_create(); g_ev_cache[i] = 0; }
-	p->stream = 0; p->stream_used = 0;             /* uploads complete, see plan_create_ex */
+	plan_ready(p);                                  /* uploads complete */
 	return p;
 err:
 	ksw2amd_plan_destroy(p);
@@ -2483,18 +2495,10 @@ ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n
 
 	g_err[0] = 0;
 	if (n < 0 || (n > 0 && !pairs)) { fail(KSW2AMD_E_PARAM, "extf: bad arguments%s", 0); return 0; }
-	if (k2a_shim_device_count() <= 0) { fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend()); return 0; }
-	p = (ksw2amd_plan_t*)calloc(1, sizeof(*p));
-	if (!p) { fail(KSW2AMD_E_NOMEM, "extf: host allocation failed%s", 0); return 0; }
-	p->splice = 2; p->n = n;
-	p->h_cls = (int8_t*)malloc((size_t)n + 1);
-	p->h_half = (uint8_t*)calloc((size_t)n + 1, 1);
-	p->h_flag = (int32_t*)calloc((size_t)n + 1, sizeof(int32_t));
-	p->h_pairs = (K2aPair*)calloc((size_t)n + 1, sizeof(K2aPair));
-	p->h_res = (K2aResult*)cache_get(BUF_HRES, sizeof(K2aResult) * ((size_t)n + 1), &p->cap[BUF_HRES]);
-	if (p->h_res) memset(p->h_res, 0, sizeof(K2aResult) * ((size_t)n + 1));
-	p->h_order = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n + 1));
-	if (!p->h_cls || !p->h_half || !p->h_flag || !p->h_pairs || !p->h_res || !p->h_order) { fail(KSW2AMD_E_NOMEM, "extf: host allocation failed%s", 0); goto err; }
+	p = plan_new("extf", n, 1);
+	if (!p) return 0;
+	p->splice = 2;
+	memset(p->h_flag, 0, sizeof(int32_t) * ((size_t)n + 1));
 	p->f_par.mch = mch; p->f_par.mis = mis < 0 ? mis : -mis; p->f_par.e = e;      /* ksw2_extf2_sse.c:18-20 */
 	/* One extension per lane instead of per wavefront: an order of magnitude fewer instructions per cell, but a wavefront then
 	 * holds 64 extensions and every lane walks its band serially: for big batches of narrow bands (KSW2AMD_EXTF_LANE=1 / 0 forces) */
@@ -2614,8 +2618,7 @@ ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n
 		fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error());
 		goto err;
 	}
-	for (i = 0; i < 3; ++i) { p->ev[i] = g_ev_cache[i] ? g_ev_cache[i] : k2a_shim_event_create(); g_ev_cache[i] = 0; }
-	p->stream = 0; p->stream_used = 0;             /* uploads complete, see plan_create_ex */
+	plan_ready(p);                                  /* uploads complete */
 	return p;
 err:
 	free(srt);
@@ -2685,19 +2688,10 @@ ksw2amd_plan_t *ksw2amd_sse_plan_create(int dual, const ksw2amd_scoring_t *sc, i
 
 	g_err[0] = 0;
 	if (n < 0 || (n > 0 && !pairs) || !sc) { fail(KSW2AMD_E_PARAM, "sse plan: bad arguments%s", 0); return 0; }
-	if (k2a_shim_device_count() <= 0) { fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend()); return 0; }
-	p = (ksw2amd_plan_t*)calloc(1, sizeof(*p));
-	if (!p) { fail(KSW2AMD_E_NOMEM, "sse plan: host allocation failed%s", 0); return 0; }
-	p->splice = 3; p->dual = !!dual; p->n = n; p->m = m = sc->m;
+	p = plan_new("sse plan", n, 1);
+	if (!p) return 0;
+	p->splice = 3; p->dual = !!dual; p->m = m = sc->m;
 	q = sc->q; e = sc->e; q2 = dual ? sc->q2 : 0; e2 = dual ? sc->e2 : 0;
-	p->h_cls = (int8_t*)malloc((size_t)n + 1);
-	p->h_half = (uint8_t*)calloc((size_t)n + 1, 1);
-	p->h_flag = (int32_t*)malloc(sizeof(int32_t) * ((size_t)n + 1));
-	p->h_pairs = (K2aPair*)calloc((size_t)n + 1, sizeof(K2aPair));
-	p->h_res = (K2aResult*)cache_get(BUF_HRES, sizeof(K2aResult) * ((size_t)n + 1), &p->cap[BUF_HRES]);
-	if (p->h_res) memset(p->h_res, 0, sizeof(K2aResult) * ((size_t)n + 1));
-	p->h_order = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n + 1));
-	if (!p->h_cls || !p->h_half || !p->h_flag || !p->h_pairs || !p->h_res || !p->h_order) { fail(KSW2AMD_E_NOMEM, "sse plan: host allocation failed%s", 0); goto err; }
 	for (i = 0; i < n; ++i) { p->h_cls[i] = -1; p->h_flag[i] = pairs[i].flag & ~F_SCALAR_CONTRACT; }
 	/* ksw2_extz2_sse.c:57,78-82 / ksw2_extd2_sse.c:76,96-100 */
 	if (m <= (dual ? 1 : 0) || !sc->mat) p->reject_all = 1;
@@ -2794,8 +2788,7 @@ ksw2amd_plan_t *ksw2amd_sse_plan_create(int dual, const ksw2amd_scoring_t *sc, i
 		p->c_par.long_thres = lt; p->c_par.long_diff = lt * (e - e2) - (q2 - q) - e2;
 	}
 	p->c_par.mat = (const int8_t*)p->d_seq + mat_off;
-	for (i = 0; i < 3; ++i) { p->ev[i] = g_ev_cache[i] ? g_ev_cache[i] : k2a_shim_event_create(); g_ev_cache[i] = 0; }
-	p->stream = 0; p->stream_used = 0;             /* uploads complete, see plan_create_ex */
+	plan_ready(p);                                  /* uploads complete */
 	return p;
 err:
 	ksw2amd_plan_destroy(p);

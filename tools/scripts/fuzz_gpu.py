@@ -68,6 +68,16 @@ while time.time() - t0 < budget:
             pairs += n
             rounds += 1
             continue
+        if rng.random() < 0.15:                                             # KSW_EZ_APPROX_MAX alone: the no-maximum kernels
+            fl = np.array([int(f) & ~po.EQX | po.APPROX_MAX for f in fl])
+        if rng.random() < 0.25:                                             # the flat entry (one arena + offsets, unscanned upload) on the same pairs
+            if rng.random() < 0.5:                                          # ... with a wildcard somewhere: reported by the packed kernels, re-run
+                k = int(rng.integers(n)); qs[k] = qs[k].copy(); qs[k][int(rng.integers(len(qs[k])))] = 4
+            fb = lib.make_flat_batch(qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl)
+            ref = lib.extd_batch(qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl) if dual else lib.extz_batch(qs, ts, mat, q, e, w=w, zdrop=zd, end_bonus=eb, flag=fl)
+            got = fb.run_oneshot(dual)
+            for i in range(n):
+                assert not diff(ref[i], got[i]), ("flat", env, dual, i, len(qs[i]), len(ts[i]), int(w[i]), hex(int(fl[i])), diff(ref[i], got[i]))
         try:
             check_batch(lib, dual, qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl)
         except AssertionError:

@@ -37,6 +37,12 @@ for n, L, w, dual, flag in [(2049, 300, 20, False, po.SCORE_ONLY), (5000, 300, 2
     s1 = lib.host_stats()
     bad = [i for i in range(n) if diff(a[i], b[i])]
     assert not bad, ("pooled vs single plan", n, L, w, dual, flag, bad[:5])
+    fb = lib.make_flat_batch(qs, ts, mat, 4, 2, 24, 1, w=w, zdrop=200, end_bonus=0, flag=flag)        # the flat entry, pooled, page-locked arena
+    fb.register()
+    c = fb.run_oneshot(dual)
+    fb.unregister()
+    bad = [i for i in range(n) if diff(a[i], c[i])]
+    assert not bad, ("flat entry vs pointer entry", n, L, w, dual, flag, bad[:5])
     for i in rng.choice(n, size=min(n, 60 if L > 1000 else 200), replace=False):
         exp = po.align("oracle", "extd" if dual else "extz", qs[i], ts[i], mat, 4, 2, 24, 1, w=w, zdrop=200, end_bonus=0, flag=flag)
         assert not diff(a[i], exp), ("oracle", n, L, w, dual, flag, int(i))
@@ -52,6 +58,9 @@ for n, hi, dual, flag in [(3000, 800, False, 0), (20000, 400, True, po.SCORE_ONL
     a, b = both(run)
     bad = [i for i in range(n) if diff(a[i], b[i])]
     assert not bad, ("ragged pooled vs single plan", n, hi, dual, flag, bad[:5])
+    c = lib.make_flat_batch(qs, ts, mat, 4, 2, 24, 1, w=wv, zdrop=150, end_bonus=5, flag=flag).run_oneshot(dual)      # wildcards (n_rate): re-runs
+    bad = [i for i in range(n) if diff(a[i], c[i])]
+    assert not bad, ("ragged flat entry vs pointer entry", n, hi, dual, flag, bad[:5])
     for i in rng.choice(n, size=150, replace=False):
         exp = po.align("oracle", "extd" if dual else "extz", qs[i], ts[i], mat, 4, 2, 24, 1, w=int(wv[i]), zdrop=150, end_bonus=5, flag=flag)
         assert not diff(a[i], exp), ("oracle ragged", n, hi, dual, flag, int(i))
