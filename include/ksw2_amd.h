@@ -264,6 +264,9 @@ int64_t ksw2amd_plan_packed_pairs(const ksw2amd_plan_t *plan);
 int ksw2amd_plan_describe(const ksw2amd_plan_t *plan, char *buf, int cap);
 /* The KSW2AMD_* environment switches (tuning, A/B runs, tests) are read once per process; this reads them again. */
 void ksw2amd_reload_env(void);
+/* pairs that a fetch ran a second time through the ordinary kernels since the library was loaded: flat batches' wildcard pairs, and
+ * alignments in which the deferred arg-max kernels could not rule out a Z-drop without the arg-max columns */
+int64_t ksw2amd_rerun_count(void);
 /* a resident plan of SSE-compatible alignments (every pair, whatever its flags); run / fetch / timing / cells / destroy as above */
 ksw2amd_plan_t *ksw2amd_sse_plan_create(int dual, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs);
 /* a resident plan of splice-aware extensions; run / fetch / timing / cells / destroy as above */

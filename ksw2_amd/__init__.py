@@ -80,7 +80,7 @@ EXPORTS = ["ksw_extz2_sse", "ksw_extd2_sse", "ksw_gg2", "ksw_gg2_sse", "ksw_extz
            "ksw2amd_set_devices", "ksw2amd_set_error_handler", "ksw2amd_error_count", "ksw2amd_host_stats",
            "ksw2amd_set_sse_compat", "ksw2amd_sse_plan_create", "ksw2amd_plan_describe", "ksw2amd_reload_env",
            "ksw2amd_extz_batch_flat", "ksw2amd_extd_batch_flat", "ksw2amd_plan_create_flat", "ksw2amd_host_register", "ksw2amd_host_unregister",
-           "ksw2amd_device_alloc", "ksw2amd_device_free", "ksw2amd_device_upload", "ksw2amd_device_download"]
+           "ksw2amd_device_alloc", "ksw2amd_device_free", "ksw2amd_device_upload", "ksw2amd_device_download", "ksw2amd_rerun_count"]
 # entry points whose behaviour depends on KSW2AMD_* switches: the library reads its environment once per process, so this binding
 # re-reads it in front of each of them (tests and A/B scripts flip switches inside one process)
 _ENV_ENTRIES = ["ksw_extz2_sse", "ksw_extd2_sse", "ksw_gg2", "ksw_gg2_sse", "ksw_extz", "ksw_extd", "ksw_gg", "ksw_extz2_sse41",
@@ -195,6 +195,7 @@ class Library:
         L.ksw2amd_device_free.restype = None
         L.ksw2amd_device_upload.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
         L.ksw2amd_device_download.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        L.ksw2amd_rerun_count.restype = ctypes.c_int64
         L.ksw2amd_reload_env.restype = None
         reload_env = L.ksw2amd_reload_env
 
@@ -250,6 +251,10 @@ class Library:
 
     def device_free(self, d):
         self.lib.ksw2amd_device_free(d)
+
+    def rerun_count(self):
+        """ksw2amd_rerun_count: pairs that a fetch ran again through the ordinary kernels (flat wildcard pairs, deferred arg-max)."""
+        return int(self.lib.ksw2amd_rerun_count())
 
     def host_stats(self):
         """ksw2amd_host_stats -> dict(pool_batches, pool_chunks, coalesced_calls, coalesced_batches)."""

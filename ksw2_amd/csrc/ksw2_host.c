@@ -25,6 +25,8 @@
 #define NCLS_ENTRIES (NCLS_MAX * NPASS)
 
 static __thread char g_err[512];
+static __thread int g_no_defer;
+static size_t thread_cached_device_bytes(void);            /* set around the re-run of a pair the deferred arg-max kernels handed back as inexact */
 
 const char *ksw2amd_last_error(void) { return g_err; }
 const char *ksw2amd_backend(void) { return k2a_shim_backend(); }
@@ -51,6 +53,7 @@ static void release_thread_cache(void);
 	X(CHUNK_MB) \
 	X(COALESCE_SLOTS) \
 	X(DBUF) \
+	X(DEFER) \
 	X(EXTF_HBM) \
 	X(EXTF_LANE) \
 	X(EXTF_LDS) \
@@ -282,7 +285,7 @@ static int is_approx(int flag)
 /* ---------------------------------------------------------------- plan */
 
 typedef struct {
-	int cfg, mode, generic, pk, rb, nomax, solo, first, count;   /* pk: packed-int16 tasks, two h_order entries per task; rb: per-strip bases;
+	int cfg, mode, generic, pk, rb, nomax, solo, defer, first, count;   /* defer: arg-max columns by a second pass (K2aLanePk, DEFER); pk: packed-int16 tasks, two h_order entries per task; rb: per-strip bases;
 	                                                        * nomax: KSW_EZ_APPROX_MAX launches without row maxima */
 	K2aScoring sc;
 } cls_t;
@@ -321,7 +324,7 @@ struct ksw2amd_plan_s {
 	K2aSsec c_par;
 	size_t c_lds[3];               /* SSE-compatible plans: per-wavefront LDS bytes of the tasks whose state fits LDS, per mode (0 = none) */
 	/* flat plans (ksw2amd_plan_create_flat): the sequences went up as they lie in the caller's arena -- no staging copy, no host
-	 * scan for wildcard codes; the packed kernels report such codes and fetch re-runs those pairs (flat_rerun) */
+	 * scan for wildcard codes; the packed kernels report such codes and fetch re-runs those pairs (pair_rerun) */
 	int flat, flat_device, scalar;         /* flat: h_seq (host arenas) is the caller's memory, not a staging buffer */
 	void *up_ev;                           /* flat plans from host arenas do not wait for their upload: the run's stream waits for this event */
 	uint8_t *flat_tail;                    /* ... and the staging block of the arena's padding lives as long as the plan */
@@ -628,6 +631,12 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 		}
 	}
 	if (p->reject_all || n == 0) return p;
+	/* the scoring, for pairs that fetch runs again (pair_rerun) */
+	p->scalar = scalar;
+	p->src_mat = (int8_t*)malloc((size_t)m * m);
+	if (!p->src_mat) { fail(KSW2AMD_E_NOMEM, "plan_create: host allocation failed%s", 0); goto err; }
+	memcpy(p->src_mat, sc->mat, (size_t)m * m);
+	p->src_sc = *sc; p->src_sc.mat = p->src_mat;
 
 	/* pass 0: sequence arena (query 4-aligned, target 16-aligned and readable one strip past its end) in pinned staging */
 	off = 0;
@@ -663,13 +672,10 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 			p->h_pairs[i].qoff = (uint32_t)(a->query - lo); p->h_pairs[i].toff = (uint32_t)(a->target - lo);
 		}
 		flat_span = off;
-		p->flat = 1; p->flat_device = flat->on_device; p->scalar = scalar;
+		p->flat = 1; p->flat_device = flat->on_device;
 		p->src_pairs = (ksw2amd_pair_t*)malloc(sizeof(*pairs) * ((size_t)n + 1));
-		p->src_mat = (int8_t*)malloc((size_t)(m > 0 ? m * m : 1));
-		if (!p->src_pairs || !p->src_mat) { fail(KSW2AMD_E_NOMEM, "plan_create: host allocation failed%s", 0); goto err; }
+		if (!p->src_pairs) { fail(KSW2AMD_E_NOMEM, "plan_create: host allocation failed%s", 0); goto err; }
 		memcpy(p->src_pairs, pairs, sizeof(*pairs) * (size_t)n);
-		memcpy(p->src_mat, sc->mat, (size_t)m * m);
-		p->src_sc = *sc; p->src_sc.mat = p->src_mat;
 	} else
 	for (i = 0; i < n; ++i) {
 		const ksw2amd_pair_t *a = &pairs[i];
@@ -918,6 +924,63 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 		}
 	}
 
+	/* Deferred arg-max (K2aLanePk, DEFER): the exact score-only single-gap packed classes track row maxima without their columns and
+	 * stream a checkpoint per wavefront and step into the traceback arena (unused by score-only tasks); a second kernel re-runs the
+	 * strips whose columns the results need.  3 of 15 instructions per row pair (11 of 51 cycles) for 512 bytes of coalesced writes per
+	 * wavefront and step: the 10 k x 10 k headline 3 985 -> 4 692 GCUPS (round 3, same box).  Every pair of a wavefront gets the wavefront's block: tb_off = byte offset, bnd_off = steps of the stream, cig_off =
+	 * strips per group in the header table (ksw2_shim.h).  KSW2AMD_DEFER=0 / 1 forces it; by default classes of at least 32 tasks
+	 * take it, unless the checkpoints of the plan would not fit beside everything else. */
+	{
+		const char *ev = ENV(DEFER);
+		const int forced = ev && *ev ? (atoi(ev) != 0) : -1;
+		size_t ck_total = 0;
+		for (k = 0; k < p->ncls; ++k) {
+			cls_t *c = &p->cls[k];
+			c->defer = c->pk && !c->solo && c->cfg != K2A_PKCFG_MP && !dual && c->mode == K2A_MODE_SCORE && !c->nomax && !g_no_defer &&
+			           /* by default the one-alignment-per-wavefront geometries only: config 2's (8, 18) measured 2 749 against 2 827 GCUPS
+			            * with it (two wavefronts per SIMD either way, a vector wavefront index in the store address), round 3 */
+			           (forced < 0 ? c->count >= 32 && k2a_pkcfg_G[c->cfg] == 64 : forced);
+		}
+		for (lo = 0; lo < 2; ++lo) {                       /* 0: size it, 1: lay it out */
+			size_t at = p->tb_bytes;
+			for (k = 0; k < p->ncls; ++k) {
+				const cls_t *c = &p->cls[k];
+				const int G = c->pk ? k2a_pkcfg_G[c->cfg] : 64, C = c->pk ? k2a_pkcfg_C[c->cfg] : 16, NG = 64 / G;
+				int t0;
+				if (!c->defer) continue;
+				for (t0 = 0; t0 < c->count; t0 += NG) {
+					uint32_t steps = 0, hs = 0;
+					int t;
+					size_t bytes;
+					for (t = t0; t < imin(c->count, t0 + NG); ++t) {
+						const K2aPair *d = &p->h_pairs[p->h_order[c->first + 2 * t]];
+						const uint32_t ns = (uint32_t)((d->tlen + C - 1) / C);
+						steps = (uint32_t)imax((int)steps, (int)ns - 1 + imin(d->qlen - 1, d->tlen - 1 + d->w) + 1);
+						hs = (uint32_t)imax((int)hs, (int)ns);
+					}
+					bytes = align_up((size_t)steps * 512 + (size_t)NG * hs * 16, 256);
+					if (lo) for (t = t0; t < imin(c->count, t0 + NG); ++t) {
+						K2aPair *da = &p->h_pairs[p->h_order[c->first + 2 * t]], *db = &p->h_pairs[p->h_order[c->first + 2 * t + 1]];
+						da->tb_off = db->tb_off = at; da->bnd_off = db->bnd_off = steps; da->cig_off = db->cig_off = hs;
+					}
+					at += bytes;
+				}
+			}
+			if (!lo) {
+				ck_total = at - p->tb_bytes;
+				if (ck_total > ((size_t)1 << 30) && forced < 0) {            /* big: only if it fits beside the rest of the device's tenants */
+					size_t free_b = 0, total_b = 0;
+					if (k2a_shim_mem_info(&free_b, &total_b) || ck_total > (free_b + thread_cached_device_bytes()) / 10 * 6) {
+						for (k = 0; k < p->ncls; ++k) p->cls[k].defer = 0;
+						ck_total = 0;
+						break;
+					}
+				}
+				if (ck_total == 0) break;
+			} else p->tb_bytes = at;
+		}
+	}
+
 	/* pass 3: traceback blocks (one per task: the two alignments of a packed task share theirs) and CIGAR scratch */
 	for (k = 0; k < p->ncls; ++k) {
 		const cls_t *c = &p->cls[k];
@@ -1026,7 +1089,7 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 			} else if (k->pk) {
 				if (k->cfg == K2A_PKCFG_MP ? k2a_shim_launch_fill_pkmp(p->dual, k->mode, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
 				                                                     (uint32_t*)p->d_bnd, p->d_res, s)
-				    : k2a_shim_launch_fill_pk(k->cfg, p->dual, k->mode, k->rb, k->nomax, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq,
+				    : k2a_shim_launch_fill_pk(k->cfg, p->dual, k->mode, k->rb, k->nomax, k->defer, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq,
 				                            p->d_tb, p->d_res, s)) goto err;
 				if (k->mode != K2A_MODE_SCORE &&
 				    k2a_shim_launch_trace_pk(k->cfg, p->dual, p->d_pairs, p->d_order + k->first, k->count, p->d_tb, p->d_res, p->d_cig, s)) goto err;
@@ -1051,7 +1114,7 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 		} else if (k->pk) {
 			if (k->cfg == K2A_PKCFG_MP ? k2a_shim_launch_fill_pkmp(p->dual, k->mode, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
 			                                                     (uint32_t*)p->d_bnd, p->d_res, stream)
-			    : k2a_shim_launch_fill_pk(k->cfg, p->dual, k->mode, k->rb, k->nomax, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
+			    : k2a_shim_launch_fill_pk(k->cfg, p->dual, k->mode, k->rb, k->nomax, k->defer, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
 			                            p->d_res, stream)) goto err;
 		} else if (k2a_shim_launch_fill(k->cfg, p->dual, k->mode, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
 		                                p->d_bnd, p->d_res, stream)) goto err;
@@ -1097,7 +1160,7 @@ int64_t ksw2amd_plan_packed_pairs(const ksw2amd_plan_t *p)
 /* one line per kernel class of an extz / extd plan, as the next ksw2amd_plan_run would launch it */
 int ksw2amd_plan_describe(const ksw2amd_plan_t *p, char *buf, int cap)
 {
-	static const char *const mode_name[3] = { "score", "left", "right" }, *const form_name[3] = { "registers", "ldsrows", "ldscodes" };
+	static const char *const mode_name[3] = { "score", "left", "right" }, *const form_name[4] = { "registers", "ldsrows", "ldscodes", "defer" };
 	int c, len = 0;
 	if (!p || !buf || cap <= 0) return 0;
 	buf[0] = 0;
@@ -1106,7 +1169,7 @@ int ksw2amd_plan_describe(const ksw2amd_plan_t *p, char *buf, int cap)
 		const cls_t *k = &p->cls[c];
 		const char *kind = k->solo ? "solo" : k->pk ? (k->cfg == K2A_PKCFG_MP ? "pkmp" : "pk") : (k->cfg == K2A_CFG_MP ? "mp" : "int32");
 		const int G = k->solo ? 64 : k->pk ? k2a_pkcfg_G[k->cfg] : k2a_cfg_G[k->cfg], C = k->solo ? 2 * K2A_SOLO_C : k->pk ? k2a_pkcfg_C[k->cfg] : k2a_cfg_C[k->cfg];
-		const int form = k->solo ? 0 : k->pk ? (k->cfg == K2A_PKCFG_MP ? 0 : k2a_shim_pk_form(k->cfg, p->dual, k->mode, k->nomax, k->count))
+		const int form = k->defer ? 3 : k->solo ? 0 : k->pk ? (k->cfg == K2A_PKCFG_MP ? 0 : k2a_shim_pk_form(k->cfg, p->dual, k->mode, k->nomax, k->count))
 		                                     : (k->cfg == K2A_CFG_MP ? k2a_shim_mp_form(p->dual, k->mode, k->count) : 0);
 		len += snprintf(buf + len, (size_t)(cap - len), "kernel=%s G=%d C=%d gaps=%d mode=%s rebased=%d nomax=%d generic=%d form=%s tasks=%d\n",
 		                kind, G, C, p->dual ? 2 : 1, mode_name[k->mode], k->rb, k->nomax, k->generic, form_name[form], k->count);
@@ -1129,18 +1192,21 @@ static int fetch_results(ksw2amd_plan_t *p)
 	return KSW2AMD_OK;
 }
 
-static int flat_rerun(ksw2amd_plan_t *p, int i, void *km, ksw_extz_t *z);
+static int needs_rerun(const ksw2amd_plan_t *p, int i);
+static int pair_rerun(ksw2amd_plan_t *p, int i, void *km, ksw_extz_t *z);
+static int64_t g_reruns;                   /* pairs that fetch ran again (diagnostics: ksw2amd_rerun_count) */
+int64_t ksw2amd_rerun_count(void) { return g_reruns; }
 int ksw2amd_plan_fetch_raw(ksw2amd_plan_t *p, int32_t *out16)
 {
 	int i, rc = fetch_results(p);
 	if (rc) return rc;
 	memset(out16, 0, sizeof(int32_t) * 16 * (size_t)p->n);
 	for (i = 0; i < p->n; ++i)
-		if (p->h_cls[i] >= 0 && !p->reject_all && p->flat && p->h_res[i].pad[0]) {      /* see flat_rerun */
+		if (!p->reject_all && needs_rerun(p, i)) {                                     /* see pair_rerun */
 			ksw_extz_t z;
 			int32_t *o = out16 + 16 * (size_t)i;
 			memset(&z, 0, sizeof(z));
-			rc = flat_rerun(p, i, 0, &z);
+			rc = pair_rerun(p, i, 0, &z);
 			if (rc) { free(z.cigar); return rc; }
 			o[0] = (int32_t)z.max; o[1] = (int32_t)z.zdropped; o[2] = z.max_q; o[3] = z.max_t; o[4] = z.mqe; o[5] = z.mqe_t; o[6] = z.mte; o[7] = z.mte_q;
 			o[8] = z.score; o[9] = z.reach_end; o[10] = z.n_cigar; o[11] = p->h_res[i].rows_done; o[12] = o[13] = -1;
@@ -1184,15 +1250,23 @@ static void eqx_rewrite(void *km, const uint8_t *query, const uint8_t *target, i
 /* a kalloc pool has no locks (kalloc.c:24-28): the batch entry points' worker threads take this around every use of `km` */
 static pthread_mutex_t g_km_mu = PTHREAD_MUTEX_INITIALIZER;
 
-/* Flat plans: pairs in which a packed kernel met a wildcard code (K2aResult.pad[0], K2aLanePk::seen) have a wrong result on the
- * device; each is run again through the ordinary gather path, where the host's scan sends it to the int32 kernels.  Host arenas
- * read the sequences where they lie, device arenas bring those pairs' bytes back first. */
+/* Pairs whose device result cannot be used are run again through the ordinary gather path, one by one:
+ *   K2aResult.pad[0] -- flat plans: a packed kernel met a wildcard code (K2aLanePk::seen); the gather path's scan sends the pair to
+ *                       the int32 kernels.  Host arenas read the sequences where they lie, device arenas bring them back first;
+ *   K2aResult.pad[1] -- deferred arg-max: a Z-drop could not be ruled out without the arg-max columns; the re-run keeps them. */
 static int run_serial(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez, int share, const flat_src_t *flat);
-static int flat_rerun(ksw2amd_plan_t *p, int i, void *km, ksw_extz_t *z)
+static int needs_rerun(const ksw2amd_plan_t *p, int i) { return p->h_cls[i] >= 0 && !p->splice && ((p->flat && p->h_res[i].pad[0]) || p->h_res[i].pad[1]); }
+static int pair_rerun(ksw2amd_plan_t *p, int i, void *km, ksw_extz_t *z)
 {
-	ksw2amd_pair_t a = p->src_pairs[i];
+	ksw2amd_pair_t a;
 	uint8_t *tmp = 0;
 	int rc;
+	if (p->flat) a = p->src_pairs[i];
+	else {                                             /* from the staging copy and the resolved parameters */
+		const K2aPair *d = &p->h_pairs[i];
+		a.query = p->h_seq + d->qoff; a.target = p->h_seq + d->toff; a.qlen = d->qlen; a.tlen = d->tlen_full;
+		a.w = d->w; a.zdrop = d->zdrop; a.end_bonus = p->scalar ? 0 : d->end_bonus; a.flag = p->h_flag[i] & ~F_SCALAR_CONTRACT;
+	}
 	if (p->flat_device) {
 		tmp = (uint8_t*)malloc((size_t)a.qlen + (size_t)a.tlen + 1);
 		if (!tmp) return fail(KSW2AMD_E_NOMEM, "plan_fetch: host allocation failed%s", 0);
@@ -1200,7 +1274,10 @@ static int flat_rerun(ksw2amd_plan_t *p, int i, void *km, ksw_extz_t *z)
 		    k2a_shim_stream_sync(p->stream)) { free(tmp); return fail(KSW2AMD_E_NODEVICE, "plan_fetch: %s", k2a_shim_last_error()); }
 		a.query = tmp; a.target = tmp + a.qlen;
 	}
+	++g_no_defer;
 	rc = run_serial(p->dual, p->scalar, km, &p->src_sc, 1, &a, z, 1, 0);
+	--g_no_defer;
+	__sync_fetch_and_add(&g_reruns, 1);
 	free(tmp);
 	return rc;
 }
@@ -1254,7 +1331,7 @@ static int plan_fetch_ex(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez, ksw_extz_t
 			continue;
 		}
 		if (p->reject_all || p->h_cls[i] < 0) continue;
-		if (p->flat && r->pad[0]) { ++nrerun; continue; }           /* a wildcard code in a packed kernel: below */
+		if (needs_rerun(p, i)) { ++nrerun; continue; }              /* pair_rerun, below */
 		z->max = (uint32_t)r->max; z->zdropped = (uint32_t)r->zdropped;
 		z->max_q = r->max_q; z->max_t = r->max_t; z->mqe = r->mqe; z->mqe_t = r->mqe_t;
 		z->mte = r->mte; z->mte_q = r->mte_q; z->score = r->score; z->reach_end = r->reach_end;
@@ -1283,7 +1360,7 @@ static int plan_fetch_ex(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez, ksw_extz_t
 	if (km || kmp) pthread_mutex_unlock(&g_km_mu);
 	free(pos); cache_put(BUF_HPOOL, pool, cap_hpool);
 	for (i = 0; nrerun > 0 && i < p->n && rc == KSW2AMD_OK; ++i)
-		if (p->h_cls[i] >= 0 && p->h_res[i].pad[0]) rc = flat_rerun(p, i, kmp ? kmp[i] : km, ezp ? ezp[i] : &ez[i]);
+		if (needs_rerun(p, i)) rc = pair_rerun(p, i, kmp ? kmp[i] : km, ezp ? ezp[i] : &ez[i]);
 	return rc;
 }
 

@@ -49,7 +49,7 @@ K2A_FN int k2a_border(const K2aScoring &sc, int k)
 K2A_FN void k2a_book_reset(K2aBook *b)
 {
 	b->max = 0; b->max_t = b->max_q = b->mqe_t = b->mte_q = -1;
-	b->mqe = b->mte = b->score = K2A_NEG; b->dropped = 0; b->rows = 0;
+	b->mqe = b->mte = b->score = K2A_NEG; b->dropped = 0; b->rows = 0; b->inexact = 0;
 }
 
 /* traceback cell encodings (our own layout; the walk in k2a_trace_pair() is the only reader)
@@ -516,7 +516,7 @@ K2A_FN void k2a_finish(const K2aPair &pr, const K2aBook &b, K2aResult *r)
 	else if (!dropped && (pr.flag & K2A_F_EXTZ_ONLY) && b.mqe + pr.end_bonus > b.max) {
 		r->reach_end = 1; ti = b.mqe_t; tj = pr.qlen - 1;
 	} else if (b.max_t >= 0 && b.max_q >= 0) { ti = b.max_t; tj = b.max_q; }
-	r->ti = ti; r->tj = tj; r->pad[0] = r->pad[1] = 0;
+	r->ti = ti; r->tj = tj; r->pad[0] = 0; r->pad[1] = b.inexact;
 }
 
 #endif

@@ -188,7 +188,17 @@ K2A_FN k2a_pk k2a_ofs_off(k2a_pk ofs) { return k2a_pk_sub(ofs, K2A_OFS); }
 #define K2A_PK_LDSCODES(G, C, DUAL, MODE, NOMAX) ((((G) == 64 && (C) == 16) || ((G) == 8 && (C) == 18) || ((G) == 16 && (C) == 8)) && !(DUAL) && (MODE) == K2A_MODE_SCORE)
 #define K2A_PK_LDSCODE_WORDS(C) (2 * (C) * 64)       /* per wavefront */
 
-template<int G, int C, bool DUAL, int MODE = K2A_MODE_SCORE, bool RB = false, bool NOMAX = false, int LDSROW_ = 0>
+/* DEFER (exact score-only kernels): the fill tracks every row's maximum but not its column -- three of the fifteen instructions
+ * of a row pair, 11 of 51 cycles.  Columns are needed for max_q (the row that holds the alignment's maximum), for mte_q (the last
+ * target row) and for the skew term of a Z-drop test; so the fill also streams the two values every lane receives from the strip
+ * above ({H, E} of its top neighbour, 8 bytes per lane and step, 512 contiguous bytes per wavefront and step) into a checkpoint
+ * block, a second small kernel (k2a_argmax_kernel) re-runs exactly the one or two strips per alignment whose columns are asked for --
+ * same lane code, arg-max on, inputs from the checkpoint --, and an alignment in which a Z-drop cannot be ruled out without the
+ * skew term (max - H > zdrop somewhere) is reported as "inexact" and run again by the host through the ordinary kernels. */
+struct K2aCkHead { int32_t baseA, baseB; uint32_t hd0, pad; };          /* per strip: what do_init derived from the neighbour lane */
+#define K2A_CK_STEP_BYTES 512                                            /* 64 lanes x { hin, ein } */
+
+template<int G, int C, bool DUAL, int MODE = K2A_MODE_SCORE, bool RB = false, bool NOMAX = false, int LDSROW_ = 0, bool DEFER = false>
 struct K2aLanePk {
 	enum { NIB = K2A_PK_NIBBLES(C, DUAL), TBWORDS = NIB ? C / 4 : C / 2 };
 	/* NIB (single gap, 16 rows): direction codes of 4 bits -- bits 0-1 winner {0 diag, 1 E, 2 F}, bit 2 / 3 = the E / F gap leaving the
@@ -210,17 +220,17 @@ struct K2aLanePk {
 	enum { PLANES = (MODE == K2A_MODE_SCORE && (!DUAL || C <= 16)) || C <= 8 };
 	enum { LDSROW = LDSROW_ == 1,       /* row maxima, arg-max columns and target codes in LDS */
 	       LDSTC = LDSROW_ != 0 };      /* 2: only the target codes (both planes) */
-	k2a_pk hl[C], f[C], f2[DUAL ? C : 1], rmax_[(NOMAX || LDSROW) ? 1 : C], rmj_[(NOMAX || LDSROW) ? 1 : C];       /* hl, f, f2, rmax and the ports above: offset form */
+	k2a_pk hl[C], f[C], f2[DUAL ? C : 1], rmax_[(NOMAX || LDSROW) ? 1 : C], rmj_[(NOMAX || LDSROW || DEFER) ? 1 : C];       /* hl, f, f2, rmax and the ports above: offset form */
 	k2a_pk tc_[LDSTC ? 1 : C], tc1_[(PLANES && !LDSTC) ? C : 1];   /* target codes {A, B}; PLANES: bit 0 / bit 1 of the codes, times D */
 	uint32_t *lrow;                                              /* LDSROW: this lane's column of the wavefront's [3][C][64] block; codes only: [2][C][64] */
 	enum { TCROW = LDSROW ? 2 : 0, TC1ROW = LDSROW ? 3 : 1 };
 	K2A_FN k2a_pk rmax(int c) const { return LDSROW ? lrow[(0 * C + c) * 64] : rmax_[(NOMAX || LDSROW) ? 0 : c]; }
-	K2A_FN k2a_pk rmj(int c) const { return LDSROW ? lrow[(1 * C + c) * 64] : rmj_[(NOMAX || LDSROW) ? 0 : c]; }
+	K2A_FN k2a_pk rmj(int c) const { return DEFER ? 0u : LDSROW ? lrow[(1 * C + c) * 64] : rmj_[(NOMAX || LDSROW) ? 0 : c]; }
 	K2A_FN k2a_pk tc(int c) const { return LDSTC ? lrow[(TCROW * C + c) * 64] : tc_[LDSTC ? 0 : c]; }
 	K2A_FN k2a_pk tc1(int c) const { return LDSTC ? lrow[(TC1ROW * C + c) * 64] : tc1_[(PLANES && !LDSTC) ? c : 0]; }
 	K2A_FN void set_tc1(int c, k2a_pk v) { if (LDSTC) lrow[(TC1ROW * C + c) * 64] = v; else tc1_[(PLANES && !LDSTC) ? c : 0] = v; }
 	K2A_FN void set_rmax(int c, k2a_pk v) { if (LDSROW) lrow[(0 * C + c) * 64] = v; else rmax_[(NOMAX || LDSROW) ? 0 : c] = v; }
-	K2A_FN void set_rmj(int c, k2a_pk v) { if (LDSROW) lrow[(1 * C + c) * 64] = v; else rmj_[(NOMAX || LDSROW) ? 0 : c] = v; }
+	K2A_FN void set_rmj(int c, k2a_pk v) { if (DEFER) return; if (LDSROW) lrow[(1 * C + c) * 64] = v; else rmj_[(NOMAX || LDSROW) ? 0 : c] = v; }
 	K2A_FN void set_tc(int c, k2a_pk v) { if (LDSTC) lrow[(TCROW * C + c) * 64] = v; else tc_[LDSTC ? 0 : c] = v; }
 
 	K2A_FN static int first_col(int S_, int w_) { return k2a_max(0, S_ * C - w_); }
@@ -246,7 +256,8 @@ struct K2aLanePk {
 		local_reset();
 #pragma unroll
 		for (int c = 0; c < C; ++c) { hl[c] = f[c] = neg; set_tc(c, 0); if (!NOMAX) { set_rmax(c, neg); set_rmj(c, 0); } if (PLANES) set_tc1(c, 0); if (DUAL) f2[c] = neg; }
-		if (NOMAX || LDSROW) { rmax_[0] = neg; rmj_[0] = 0; }
+		if (NOMAX || LDSROW) rmax_[0] = neg;
+		if (NOMAX || LDSROW || DEFER) rmj_[0] = 0;
 		if (LDSTC) tc_[0] = 0;
 		if (!DUAL) f2[0] = 0;
 		if (!PLANES || LDSTC) tc1_[0] = 0;
@@ -257,7 +268,8 @@ struct K2aLanePk {
 	K2A_FN bool need_fin(int k) const { return k == kfin; }
 
 	/* bsA / bsB: bases of the lane that owns the strip above (RB only; rotated in by the kernel) */
-	K2A_FN void do_init(const K2aScoring &sc, int bsA = 0, int bsB = 0)
+	/* forced (k2a_argmax_kernel): the strip's bases and first diagonal input come from its checkpoint header instead of the lane above */
+	K2A_FN void do_init(const K2aScoring &sc, int bsA = 0, int bsB = 0, const K2aCkHead *forced = 0)
 	{
 		S = Snext; i0 = S * C; koff = koff_next;
 		je = k2a_min(qlen - 1, k2a_min(i0 + C - 1, tlen - 1) + w);
@@ -295,7 +307,8 @@ struct K2aLanePk {
 			if (!NOMAX) set_rmax(c, neg);                        /* the arg-max column is written with the row's first live cell */
 		}
 		const int hcorner = k2a_border<DUAL>(sc, i0) + sc.e * (i0 - 1);   /* H(i0-1,-1), carrying the bias of row i0-1 */
-		if (RB) {
+		if (forced) { baseA = forced->baseA; baseB = forced->baseB; delta = 0; }
+		else if (RB) {
 			/* new base = the diagonal input of the strip's first cell; hu_prev is still relative to the base above */
 			const int nbA = js == 0 ? hcorner : bsA + k2a_pk_lo(k2a_ofs_off(hu_prev)), nbB = js == 0 ? hcorner : bsB + k2a_pk_hi(k2a_ofs_off(hu_prev));
 			delta = S == 0 ? 0u : k2a_pair16((uint32_t)(bsA - nbA) & 0xffffu, (uint32_t)(bsB - nbB) & 0xffffu);
@@ -312,7 +325,8 @@ struct K2aLanePk {
 				}
 			}
 		}
-		if (RB) hd0 = K2A_OFS;                                  /* 0 by construction of the base */
+		if (forced) hd0 = forced->hd0;
+		else if (RB) hd0 = K2A_OFS;                             /* 0 by construction of the base */
 		else if (js == 0) hd0 = k2a_pku(hcorner);
 		else hd0 = hu_prev;
 		Snext += G;
@@ -401,7 +415,8 @@ struct K2aLanePk {
 				h = k2a_pk_sel(k2a_bit_mask(live, c), h, neg);
 				/* running row maximum: ties to the last column (keep the old arg-max only where h < max), except
 				 * extz + RIGHT + CIGAR where the first column wins (take the new one only where max < h); SURVEY 8a rule 3 */
-				if (!NOMAX) {
+				if (!NOMAX && DEFER) set_rmax(c, k2a_pk_maxu(rmax(c), h));       /* the column comes from k2a_argmax_kernel */
+				else if (!NOMAX) {
 					const k2a_pk rm = rmax(c), rj = rmj(c);
 					if (!DUAL && MODE == K2A_MODE_RIGHT) set_rmj(c, k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(rm, h)), jjpk, rj));
 					else set_rmj(c, k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(h, rm)), rj, jjpk));
@@ -527,7 +542,11 @@ struct K2aLanePk {
 					if (reach && hend > bmqe) { bmqe = hend; bmqe_t = i; }
 					if (i == tlen_full - 1) { bmte = H; bmte_q = j; }
 					if (H > bmax) { bmax = H; bmax_t = i; bmax_q = j; }
-					else if (i >= bmax_t && j >= bmax_q) {
+					else if (DEFER) {
+						/* without the row's arg-max column neither "j >= max_q" nor the skew can be evaluated: a drop is impossible
+						 * while max - H <= zdrop, otherwise the alignment is handed back as inexact (and stops here) */
+						if (zdrop >= 0 && bmax - H > zdrop) { bdrop = 1; b->inexact = 1; }
+					} else if (i >= bmax_t && j >= bmax_q) {
 						const int dt = i - bmax_t, dq = j - bmax_q;
 						const int skew = dt > dq ? dt - dq : dq - dt;
 						if (zdrop >= 0 && bmax - H > zdrop + skew * zslope) bdrop = 1;

@@ -84,7 +84,12 @@ int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_
  * rebased: per-strip score bases (reads of any length whose band window fits 16 bits).
  * nomax: final score and direction bytes only (KSW_EZ_APPROX_MAX launches).
  * The packed trace kernel walks 2*ntasks alignments of such a launch. */
-int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2,
+/* defer (exact score-only single-gap classes): the fill tracks row maxima without their columns and streams a checkpoint of every
+ * lane's top inputs into `tb`; a second kernel of the same launch call re-runs the strips whose columns the results need
+ * (K2aLanePk, DEFER).  Every pair of a wavefront carries the wavefront's checkpoint block in tb_off (byte offset in tb), its
+ * stream length in steps in bnd_off and the strips-per-group stride of its header table in cig_off:
+ *   block = [bnd_off steps][64 lanes] x 8 bytes, then [64 / G groups][cig_off strips] x 16 bytes (K2aCkHead). */
+int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax, int defer, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2,
                             int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, void *stream);
 int k2a_shim_launch_trace_pk(int cfg, int dual, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb,
                              K2aResult *res, uint32_t *cig, void *stream);

@@ -213,13 +213,13 @@ struct K2aTbStage {
 #define K2A_PK_TB_NS(WB, LDSROW) ((WB) == 32 && (LDSROW) == 1 ? 2 : 8)      /* row state in LDS: two wavefronts per SIMD need the room */
 
 /* Packed-int16 resident fill: two same-shape alignments per lane group (ksw2_lane_pk.h). */
-template<int G, int C, bool DUAL, int MODE, bool RB, bool NOMAX, int LDSROW = 0>      /* LDSROW: 1 = row state in LDS, 2 = only the target-code planes */
+template<int G, int C, bool DUAL, int MODE, bool RB, bool NOMAX, int LDSROW = 0, bool DEFER = false>      /* LDSROW: 1 = row state in LDS, 2 = only the target-code planes; DEFER: K2aLanePk */
 __global__ void __launch_bounds__(64 * K2A_WPB, LDSROW == 2 ? (G == 16 ? 4 : 3) : LDSROW ? 2 : 1)      /* no floor elsewhere: capping the register form of the score-only kernels at 168 VGPRs spills and is 18 % slower */
 k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
                    const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, K2aResult *__restrict__ res)
 {
 	constexpr int NG = 64 / G;
-	typedef K2aLanePk<G, C, DUAL, MODE, RB, NOMAX, LDSROW> Lane;
+	typedef K2aLanePk<G, C, DUAL, MODE, RB, NOMAX, LDSROW, DEFER> Lane;
 	__shared__ K2aBook book[K2A_WPB][NG][2];
 	__shared__ uint32_t stage[K2A_WPB][(NG * K2A_PK_STAGE(C) > 64 * 5) ? NG * K2A_PK_STAGE(C) : 64 * 5];   /* row buffers / final lane records */
 
@@ -268,6 +268,14 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	Stage ST;
 	if (STAGED) ST.init(&tbstage[wave * Stage::WORDS], &tbruns[wave * 64], lane, tbp + k2a_tb_word(0, gl, tbsteps, G, WB));
 	int kdone = -1;
+	/* DEFER: this wavefront's checkpoint block in `tb` (the host gave every pair of the wavefront the same tb_off): the stream
+	 * [step][lane] of what each lane receives from above, then one header per group and strip (K2aCkHead).  Lane 0's task is
+	 * valid whenever the wavefront has one. */
+	const bool ckon = DEFER && __builtin_amdgcn_readfirstlane((int)valid) != 0;
+	const size_t ckoff = DEFER ? ((size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(prA.tb_off >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)prA.tb_off) : 0;
+	uint2 *ckst = (uint2*)(tb + ckoff) + lane;
+	K2aCkHead *ckhd = (K2aCkHead*)(tb + ckoff + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)prA.bnd_off) * K2A_CK_STEP_BYTES) +
+	                  (size_t)grp * (uint32_t)__builtin_amdgcn_readfirstlane((int)prA.cig_off);
 
 	for (int k = 0; k <= kmax; ++k) {
 		k2a_pk hin = (k2a_pk)k2a_rot1<G>((int)L.hout);
@@ -280,6 +288,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 			if (ninit) {
 				L.do_init(sc, bsA, bsB);                          /* uses hu_prev = what arrived one step ago */
 				if (k & 3) L.reload_query_group(k);                /* the group was fetched under the previous strip's offset */
+				if (ckon) { K2aCkHead h; h.baseA = L.baseA; h.baseB = L.baseB; h.hd0 = L.hd0; h.pad = 0; ckhd[L.S] = h; }
 			}
 		}
 		L.hu_prev = hin;
@@ -288,6 +297,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 		L.qb = Lane::query_pick(L.qwA, L.qwB, k & 3);
 		if (k <= ktop) L.top_inputs(sc, k, hin, ein, e2in);
 
+		if (ckon) ckst[(size_t)k * 64] = make_uint2(hin, ein);      /* 512 contiguous bytes per wavefront and step */
 		uint32_t tw[Lane::TBWORDS];
 		const bool live = L.step(sc, k, hin, ein, e2in, tw);
 		if (STAGED) { ST.put(k, tw, live); ST.step_done(k); kdone = k; }
@@ -357,6 +367,65 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 		k2a_finish(prA, a, &res[piA]);
 		if (piB != piA) k2a_finish(prB, b, &res[piB]);
 		if (gsaw) { res[piA].pad[0] = 1; res[piB].pad[0] = 1; }
+	}
+}
+
+/* Second pass of the deferred arg-max (K2aLanePk, DEFER): three jobs per task -- the strip that holds alignment A's maximum,
+ * the one that holds B's, and the strip of the last target row (mte_q of both) -- one job per LANE: every lane re-runs its strip
+ * with the ordinary exact lane code (arg-max on), its top inputs read back from the checkpoint stream, its bases from the strip's
+ * header, and writes the one or two columns that were asked for.  No lane talks to another. */
+template<int G, int C, bool RB>
+__global__ void __launch_bounds__(64 * K2A_WPB)
+k2a_argmax_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
+                  const uint8_t *__restrict__ seq, const uint8_t *__restrict__ ck, K2aResult *__restrict__ res)
+{
+	constexpr int NG = 64 / G;
+	typedef K2aLanePk<G, C, false, K2A_MODE_SCORE, RB, false, 0, false> Lane;
+	const int job = blockIdx.x * (64 * K2A_WPB) + threadIdx.x;
+	const int task = job / 3, which = job - 3 * task;
+	bool go = task < ntasks;
+	const uint32_t piA = order2[go ? 2 * task : 0], piB = order2[go ? 2 * task + 1 : 0];
+	const K2aPair prA = pairs[piA], prB = pairs[piB];
+	const bool inexA = res[piA].pad[1] != 0, inexB = res[piB].pad[1] != 0;
+	int row = -1;
+	if (go) {
+		if (which == 0) row = inexA ? -1 : res[piA].max_t;
+		else if (which == 1) row = (piB == piA || inexB) ? -1 : res[piB].max_t;
+		else row = (prA.tlen == prA.tlen_full && !(inexA && inexB)) ? prA.tlen_full - 1 : -1;
+	}
+	go = go && row >= 0;
+	const int S = go ? row / C : 0, grp = task % NG;
+	Lane L;
+	L.lrow = 0;
+	L.setup(prA, prB, seq, S % G, go);
+	L.Snext = S;
+	L.schedule_next();
+	const int kbeg = L.knext;
+	const uint8_t *blk = ck + prA.tb_off;
+	if (go) L.do_init(sc, 0, 0, (const K2aCkHead*)(blk + (size_t)prA.bnd_off * K2A_CK_STEP_BYTES) + (size_t)grp * prA.cig_off + S);
+	const int n = go ? L.kfin - kbeg + 1 : 0;
+	const uint2 *st = (const uint2*)blk + (grp * G + S % G);
+	for (int t = 0; __builtin_amdgcn_ballot_w64(t < n) != 0; ++t) {
+		if (t < n) {
+			const int k = kbeg + t;
+			const uint2 in = st[(size_t)k * 64];
+			const int jc = min(max(k - L.koff, 0), L.qlen - 1);
+			L.qb = k2a_pair16(L.qa[jc], L.qbp[jc]);
+			uint32_t tw[Lane::TBWORDS];
+			L.step(sc, k, in.x, in.y, 0u, tw);
+		}
+	}
+	if (go) {
+		const int c = row - S * C;
+		k2a_pk v = 0;
+#pragma unroll
+		for (int cc = 0; cc < C; ++cc) if (cc == c) v = L.rmj(cc);
+		if (which == 0) res[piA].max_q = (int)(v & 0xffffu);
+		else if (which == 1) res[piB].max_q = (int)(v >> 16);
+		else {
+			if (!inexA) res[piA].mte_q = (int)(v & 0xffffu);
+			if (piB != piA && !inexB) res[piB].mte_q = (int)(v >> 16);
+		}
 	}
 }
 
@@ -1415,6 +1484,14 @@ static const fill_pk_fn g_fill_pk_lds[2][2] = {
 #define LDSCODE_SET(G, C) { { k2a_fill_pk_kernel<G, C, false, 0, false, false, 2>, k2a_fill_pk_kernel<G, C, false, 0, true, false, 2> }, \
                             { k2a_fill_pk_kernel<G, C, false, 0, false, true, 2>,  k2a_fill_pk_kernel<G, C, false, 0, true, true, 2> } }
 static const fill_pk_fn g_fill_pk_ldscodes[3][2][2] = { LDSCODE_SET(64, 16), LDSCODE_SET(8, 18), LDSCODE_SET(16, 8) };
+/* exact score-only single-gap kernels with the arg-max deferred (K2aLanePk, DEFER) and their second pass: [cfg][rebased]; the
+ * fill in the form the launcher prefers for big launches of that geometry (code planes in LDS for (16, 8) and (64, 16)) */
+#define DEFER_ROW(G, C, LR) { k2a_fill_pk_kernel<G, C, false, 0, false, false, LR, true>, k2a_fill_pk_kernel<G, C, false, 0, true, false, LR, true> }
+static const fill_pk_fn g_fill_pk_defer[4][2] = { DEFER_ROW(8, 18, 0), DEFER_ROW(16, 8, 2), DEFER_ROW(64, 8, 0), DEFER_ROW(64, 16, 2) };
+typedef void (*argmax_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, const uint8_t*, K2aResult*);
+#define ARGMAX_ROW(G, C) { k2a_argmax_kernel<G, C, false>, k2a_argmax_kernel<G, C, true> }
+static const argmax_fn g_argmax[4][2] = { ARGMAX_ROW(8, 18), ARGMAX_ROW(16, 8), ARGMAX_ROW(64, 8), ARGMAX_ROW(64, 16) };
+
 /* Launch-time kernel forms.  Every choice the launcher makes has a forcing switch (k2a_shim_set_option: -1 automatic, 0 / 1
  * forced; the host maps KSW2AMD_LDSCODES / KSW2AMD_LDSROWS onto it) and is reported by k2a_shim_pk_form / k2a_shim_mp_form, so
  * that tests can pin each form against the oracle and check which one an unforced launch took. */
@@ -1580,13 +1657,24 @@ int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_
 	return 0;
 }
 
-int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2,
+int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax, int defer, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2,
                             int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, void *stream)
 {
 	if (ntasks <= 0) return 0;
 	if (cfg < 0 || cfg >= K2A_NPKCFG || mode < 0 || mode > 2) { snprintf(g_err, sizeof(g_err), "bad packed kernel class"); return -1; }
 	const int per_block = K2A_WPB * (64 / k2a_pkcfg_G[cfg]);
 	const int blocks = (ntasks + per_block - 1) / per_block;
+	if (defer) {
+		/* deferred arg-max: the fill streams its checkpoints into `tb` (block offsets in K2aPair.tb_off / bnd_off / cig_off),
+		 * the second pass fills in max_q / mte_q */
+		if (cfg >= K2A_PKCFG_MP || dual || mode != K2A_MODE_SCORE || nomax || !tb) { snprintf(g_err, sizeof(g_err), "bad deferred arg-max class"); return -1; }
+		hipLaunchKernelGGL(g_fill_pk_defer[cfg][rebased ? 1 : 0], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream, *sc, pairs, order2, ntasks, seq, tb, res);
+		CHECK(hipGetLastError());
+		hipLaunchKernelGGL(g_argmax[cfg][rebased ? 1 : 0], dim3((3 * ntasks + 64 * K2A_WPB - 1) / (64 * K2A_WPB)), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
+		                   *sc, pairs, order2, ntasks, seq, (const uint8_t*)tb, res);
+		CHECK(hipGetLastError());
+		return 0;
+	}
 	const int form = k2a_shim_pk_form(cfg, dual, mode, nomax, ntasks);
 	const bool lds = form == 1, ldc = form == 2;
 	hipLaunchKernelGGL(lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1] : ldc ? g_fill_pk_ldscodes[k2a_pkcfg_G[cfg] == 8 ? 1 : k2a_pkcfg_G[cfg] == 16 ? 2 : 0][nomax ? 1 : 0][rebased ? 1 : 0] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,

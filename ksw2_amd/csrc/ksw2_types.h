@@ -110,12 +110,13 @@ typedef struct K2aPair {
 typedef struct K2aResult {
 	int32_t max, zdropped, max_q, max_t, mqe, mqe_t, mte, mte_q, score, reach_end, n_cigar, rows_done;
 	int32_t ti, tj;                  /* traceback start cell chosen by k2a_finish(); -1 = no CIGAR          */
-	int32_t pad[2];
+	int32_t pad[2];                  /* [0]: a packed kernel read a wildcard code (unscanned flat plans), [1]: inexact (deferred arg-max): the host re-runs the pair */
 } K2aResult;
 
 /* per-group bookkeeping state (LDS on the GPU): the scalar reference's ez fields while rows complete */
 typedef struct K2aBook {
 	int32_t max, max_t, max_q, mqe, mqe_t, mte, mte_q, score, dropped, rows;
+	int32_t inexact;             /* deferred arg-max kernels: a Z-drop could not be ruled out without the columns -> K2aResult.pad[1] */
 } K2aBook;
 
 

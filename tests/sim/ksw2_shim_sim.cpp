@@ -105,12 +105,12 @@ static void sim_fill(const K2aScoring sc, const K2aPair *pairs, const uint32_t *
 }
 
 /* mirrors k2a_fill_pk_kernel */
-template<int G, int C, bool DUAL, int MODE, bool RB, bool NOMAX, int LDSROW = 0>
+template<int G, int C, bool DUAL, int MODE, bool RB, bool NOMAX, int LDSROW = 0, bool DEFER = false>
 static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *seq, uint8_t *tb,
                         K2aResult *res)
 {
 	constexpr int NG = 64 / G;
-	typedef K2aLanePk<G, C, DUAL, MODE, RB, NOMAX, LDSROW> Lane;
+	typedef K2aLanePk<G, C, DUAL, MODE, RB, NOMAX, LDSROW, DEFER> Lane;
 	const int nwaves = (ntasks + NG - 1) / NG;
 	for (int wv = 0; wv < nwaves; ++wv) {
 		static thread_local Lane L[64];
@@ -157,6 +157,10 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 				if (L[lane].need_init(k)) {
 					L[lane].do_init(sc, bsA[lane], bsB[lane]);
 					if (k & 3) L[lane].reload_query_group(k);
+					if (DEFER && valid[0]) {                    /* the strip's checkpoint header (mirrors k2a_fill_pk_kernel) */
+						K2aCkHead h; h.baseA = L[lane].baseA; h.baseB = L[lane].baseB; h.hd0 = L[lane].hd0; h.pad = 0;
+						((K2aCkHead*)(tb + prA[0].tb_off + (size_t)prA[0].bnd_off * K2A_CK_STEP_BYTES))[(size_t)(lane / G) * prA[0].cig_off + L[lane].S] = h;
+					}
 				}
 				L[lane].hu_prev = hin[lane];
 				if (RB) {
@@ -169,6 +173,7 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 			}
 			for (int lane = 0; lane < 64; ++lane) {
 				uint32_t tw[Lane::TBWORDS];
+				if (DEFER && valid[0]) { uint32_t *ck = (uint32_t*)(tb + prA[0].tb_off) + 2 * ((size_t)k * 64 + lane); ck[0] = hin[lane]; ck[1] = ein[lane]; }
 				const bool live = L[lane].step(sc, k, hin[lane], ein[lane], e2in[lane], tw);
 				if (MODE != K2A_MODE_SCORE && live)
 					memcpy(tb + prA[lane].tb_off + k2a_tb_word((size_t)k, lane % G, (size_t)(klast[lane] + 1), G, Lane::TBWORDS * 4), tw, sizeof(tw));
@@ -236,6 +241,49 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 				if (piB[lane] != piA[lane]) k2a_finish(pairs[piB[lane]], book[lane / G][1], &res[piB[lane]]);
 				if (gsaw) { res[piA[lane]].pad[0] = 1; res[piB[lane]].pad[0] = 1; }
 			}
+	}
+}
+
+/* mirrors k2a_argmax_kernel: one job per (task, which), every job an independent lane */
+template<int G, int C, bool RB>
+static void sim_argmax(const K2aScoring sc, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *seq, const uint8_t *ck, K2aResult *res)
+{
+	constexpr int NG = 64 / G;
+	typedef K2aLanePk<G, C, false, K2A_MODE_SCORE, RB, false, 0, false> Lane;
+	for (int job = 0; job < 3 * ntasks; ++job) {
+		const int task = job / 3, which = job % 3;
+		const uint32_t piA = order2[2 * task], piB = order2[2 * task + 1];
+		const K2aPair prA = pairs[piA], prB = pairs[piB];
+		const bool inexA = res[piA].pad[1] != 0, inexB = res[piB].pad[1] != 0;
+		int row;
+		if (which == 0) row = inexA ? -1 : res[piA].max_t;
+		else if (which == 1) row = (piB == piA || inexB) ? -1 : res[piB].max_t;
+		else row = (prA.tlen == prA.tlen_full && !(inexA && inexB)) ? prA.tlen_full - 1 : -1;
+		if (row < 0) continue;
+		const int S = row / C, grp = task % NG;
+		static thread_local Lane L;
+		L.lrow = 0;
+		L.setup(prA, prB, seq, S % G, true);
+		L.Snext = S;
+		L.schedule_next();
+		const int kbeg = L.knext;
+		const uint8_t *blk = ck + prA.tb_off;
+		L.do_init(sc, 0, 0, (const K2aCkHead*)(blk + (size_t)prA.bnd_off * K2A_CK_STEP_BYTES) + (size_t)grp * prA.cig_off + S);
+		const uint32_t *st = (const uint32_t*)blk;
+		for (int k = kbeg; k <= L.kfin; ++k) {
+			const size_t at = 2 * ((size_t)k * 64 + grp * G + S % G);
+			const int jc = k2a_min(k2a_max(k - L.koff, 0), L.qlen - 1);
+			L.qb = k2a_pair16(L.qa[jc], L.qbp[jc]);
+			uint32_t tw[Lane::TBWORDS];
+			L.step(sc, k, st[at], st[at + 1], 0u, tw);
+		}
+		const k2a_pk v = L.rmj(row - S * C);
+		if (which == 0) res[piA].max_q = (int)(v & 0xffffu);
+		else if (which == 1) res[piB].max_q = (int)(v >> 16);
+		else {
+			if (!inexA) res[piA].mte_q = (int)(v & 0xffffu);
+			if (piB != piA && !inexB) res[piB].mte_q = (int)(v >> 16);
+		}
 	}
 }
 
@@ -947,9 +995,20 @@ int k2a_shim_launch_fill(int cfg, int dual, int mode, const K2aScoring *sc, cons
 	else g_fill[cfg][dual ? 1 : 0][mode](*sc, pairs, order, ntasks, seq, tb, res);
 	return 0;
 }
-int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2,
+#define DEFER_ROW(G, C, LR) { sim_fill_pk<G, C, false, 0, false, false, LR, true>, sim_fill_pk<G, C, false, 0, true, false, LR, true> }
+static const fill_pk_fn g_fill_pk_defer[4][2] = { DEFER_ROW(8, 18, 0), DEFER_ROW(16, 8, 2), DEFER_ROW(64, 8, 0), DEFER_ROW(64, 16, 2) };
+typedef void (*argmax_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, const uint8_t*, K2aResult*);
+#define ARGMAX_ROW(G, C) { sim_argmax<G, C, false>, sim_argmax<G, C, true> }
+static const argmax_fn g_argmax[4][2] = { ARGMAX_ROW(8, 18), ARGMAX_ROW(16, 8), ARGMAX_ROW(64, 8), ARGMAX_ROW(64, 16) };
+
+int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax, int defer, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2,
                             int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, void *)
 {
+	if (defer && ntasks > 0) {
+		g_fill_pk_defer[cfg][rebased ? 1 : 0](*sc, pairs, order2, ntasks, seq, tb, res);
+		g_argmax[cfg][rebased ? 1 : 0](*sc, pairs, order2, ntasks, seq, tb, res);
+		return 0;
+	}
 	const int form = k2a_shim_pk_form(cfg, dual, mode, nomax, ntasks);
 	const bool lds = form == 1, ldc = form == 2;
 	if (ntasks > 0) (lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1] : ldc ? g_fill_pk_ldscodes[k2a_pkcfg_G[cfg] == 8 ? 1 : k2a_pkcfg_G[cfg] == 16 ? 2 : 0][nomax ? 1 : 0][rebased ? 1 : 0] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode])(*sc, pairs, order2, ntasks, seq, tb, res);

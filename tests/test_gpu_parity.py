@@ -693,6 +693,7 @@ def test_code_planes_in_registers_and_in_lds(lib, ldc, monkeypatch):
     will launch."""
     from tests.test_sim_parity import _check_code_plane_forms
     monkeypatch.setenv("KSW2AMD_LDSCODES", ldc)
+    monkeypatch.setenv("KSW2AMD_DEFER", "0")              # (the deferred arg-max kernels have their own forms: next test)
     for seed in (31, 32, 33):
         _check_code_plane_forms(lib, "ldscodes" if ldc == "1" else "registers", seed=seed)
 
@@ -738,13 +739,26 @@ def test_flat_batch_full_size_config2(lib, monkeypatch):
     assert np.array_equal(sc, r1[::7, 8])
 
 
+@pytest.mark.parametrize("defer", ["0", "1"])
+def test_deferred_argmax_forced_on_and_off(lib, defer, monkeypatch):
+    """KSW2AMD_DEFER=1 / 0: the exact score-only single-gap kernels that track row maxima without their columns, stream their
+    checkpoints and leave max_q / mte_q to k2a_argmax_kernel (all four geometries, plain and re-based; alignments in which a Z-drop
+    cannot be ruled out come back as inexact and are re-run), against the ordinary kernels and the oracle."""
+    from tests.test_sim_parity import _check_deferred_argmax
+    monkeypatch.setenv("KSW2AMD_DEFER", defer)
+    for seed in (41, 42):
+        _check_deferred_argmax(lib, defer == "1", seed=seed)
+
+
 def test_headline_kernel_at_scale_unforced(lib, monkeypatch):
     """The headline workload's own launch, nothing forced: 3 200 pairs of 10 000 x 10 000, band 500, Z-drop 400, score only,
-    under the production occupancy rules.  The launcher must take the code-planes-in-LDS form on its own (>= 1.5 wavefronts
-    per SIMD); every 50th pair equals the oracle, and the whole batch equals the register form (KSW2AMD_LDSCODES=0) field by
-    field.  A fifth of the pairs get a random tail so that Z-drop fires."""
+    under the production occupancy rules.  The host must take the deferred-arg-max kernels on its own; the whole batch equals,
+    field by field, the ordinary kernels with their code planes in LDS (KSW2AMD_DEFER=0: the launcher's own choice at >= 1.5
+    wavefronts per SIMD) and in registers (KSW2AMD_LDSCODES=0), and every 50th pair equals the oracle.  A fifth of the pairs get a
+    random tail so that Z-drop fires (those are the ones the deferred kernels hand back)."""
     monkeypatch.delenv("KSW2AMD_SIMDS", raising=False)
     monkeypatch.delenv("KSW2AMD_LDSCODES", raising=False)
+    monkeypatch.delenv("KSW2AMD_DEFER", raising=False)
     n = 3200
     q, t = synth.fast_fixed(6, n, 10000, 10000, sub=0.05, ind=0.06, tail_random_frac=0.25, tail_pairs=0.2)
     mat = synth.simple_mat(5, 2, 4, -1)
@@ -752,13 +766,19 @@ def test_headline_kernel_at_scale_unforced(lib, monkeypatch):
     p = b.plan(False)
     d = p.describe()
     assert len(d) == 1 and d[0]["kernel"] == "pk" and (d[0]["G"], d[0]["C"], d[0]["rebased"], d[0]["nomax"]) == (64, 16, 1, 0), d
-    assert d[0]["form"] == "ldscodes" and d[0]["tasks"] == n // 2, d
+    assert d[0]["form"] == "defer" and d[0]["tasks"] == n // 2, d
+    r0 = lib.rerun_count()
     p.run(); r1 = p.fetch_raw().copy(); p.close()
+    assert lib.rerun_count() > r0                                # the dropped pairs were handed back
+    monkeypatch.setenv("KSW2AMD_DEFER", "0")
+    p = b.plan(False)
+    assert p.describe()[0]["form"] == "ldscodes"
+    p.run(); r2 = p.fetch_raw().copy(); p.close()
     monkeypatch.setenv("KSW2AMD_LDSCODES", "0")
     p = b.plan(False)
     assert p.describe()[0]["form"] == "registers"
     p.run(); r0 = p.fetch_raw().copy(); p.close()
-    assert np.array_equal(r0, r1)
+    assert np.array_equal(r0[:, :11], r1[:, :11]) and np.array_equal(r0[:, :11], r2[:, :11])
     assert 0 < int(r1[:, 1].sum()) < n                         # some pairs Z-dropped, most did not
     names = ["max", "zdropped", "max_q", "max_t", "mqe", "mqe_t", "mte", "mte_q", "score", "reach_end"]
     for i in range(0, n, 50):

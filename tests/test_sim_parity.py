@@ -527,7 +527,47 @@ def test_sim_code_planes_in_registers_and_in_lds(sim, ldc, monkeypatch):
     """KSW2AMD_LDSCODES=0 / 1: the exact and no-maximum score-only kernels of the (64, 16) and (8, 18) geometries with the target-code
     planes in registers / in LDS (the forms the headline benchmark and config 2 run), plain and re-based."""
     monkeypatch.setenv("KSW2AMD_LDSCODES", ldc)
+    monkeypatch.setenv("KSW2AMD_DEFER", "0")              # (the deferred arg-max kernels have their own forms: test below)
     _check_code_plane_forms(sim, "ldscodes" if ldc == "1" else "registers", scale=0.6)
+
+
+def _check_deferred_argmax(lib, on, scale=1.0, seed=41):
+    """KSW2AMD_DEFER=1 / 0 (set by the caller): exact score-only single-gap batches of all four packed geometries, plain and re-based,
+    through the kernels that track row maxima without columns + the arg-max recovery pass, or through the ordinary ones; Z-drop
+    thresholds low enough that some alignments are handed back as inexact and re-run.  Every pair against the oracle."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    mat, q, e = synth.simple_mat(5, 2, 4, -1), 4, 2
+    seen, r0 = set(), lib.rerun_count()
+    for geom, wset, lens in (((8, 18), [0, 1, 7, 40, 64, 67], (30, 1500)), ((16, 8), [68], (100, 1500)), ((64, 8), [69, 100, 284], (520, 2500)),
+                             ((64, 16), [285, 400, 536], (600, 2600))):
+        for rebased in (False, True):
+            qs, ts, ws = [], [], []
+            for k in range(5):
+                ql = int(rng.integers(5000, 8000) * scale) if rebased else int(rng.integers(*lens))
+                tl = max(520 if geom[0] == 64 else 1, ql + int(rng.integers(-40, 40)))
+                qq, tt = synth.fixed_batch(7100 + 10 * rebased + k, 2 + k % 2, ql, tl, sub=0.05, ind=0.05, tail_random_frac=0.3, tail_pairs=0.4)
+                qs += list(qq); ts += list(tt); ws += [int(rng.choice(wset))] * len(qq)
+            n = len(qs)
+            zd = rng.choice([-1, 60, 400, 2000], size=n)
+            eb = rng.choice([0, 50], size=n)
+            fl = np.array([po.SCORE_ONLY | (po.EXTZ_ONLY if rng.random() < 0.3 else 0) for _ in range(n)])
+            p = lib.make_batch(qs, ts, mat, q, e, 0, 0, w=np.array(ws), zdrop=zd, end_bonus=eb, flag=fl).plan(False)
+            for c in p.describe():
+                if c["kernel"] == "pk" and (c["G"], c["C"]) == geom:
+                    assert (c["form"] == "defer") == on, c
+                    seen.add((c["G"], c["rebased"]))
+            p.run(); raw = p.fetch_raw().copy(); p.close()
+            _, res = check_batch(lib, False, qs, ts, mat, q, e, 0, 0, w=np.array(ws), zdrop=zd, end_bonus=eb, flag=fl)
+            assert all(raw[i, 2] == res[i]["max_q"] and raw[i, 7] == res[i]["mte_q"] and raw[i, 8] == res[i]["score"] for i in range(n))   # resident plan == batch entry
+    assert seen == {(g, r) for g in (8, 16, 64) for r in (0, 1)}, seen
+    assert (lib.rerun_count() > r0) == on                       # some alignments dropped: handed back and run again
+
+
+@pytest.mark.parametrize("defer", ["0", "1"])
+def test_sim_deferred_argmax(sim, defer, monkeypatch):
+    """K2aLanePk DEFER + k2a_argmax twin on the simulator."""
+    monkeypatch.setenv("KSW2AMD_DEFER", defer)
+    _check_deferred_argmax(sim, defer == "1", scale=0.6)
 
 
 def _flat_cases(rng):
