@@ -1404,6 +1404,11 @@ static size_t pair_device_bytes(int dual, const ksw2amd_pair_t *a)
 			 * callers halve a plan whose allocation fails */
 			b += (((size_t)a->tlen / 1024 + 1) * ((size_t)a->qlen + 72) + K2A_TB_PAD) * 64 * (dual ? 16 : 8) + 24 * (size_t)a->qlen + 320 + 131072;
 		b += ((size_t)a->qlen + a->tlen + 2) * 4;
+	} else if (!dual && a->qlen > 0 && a->tlen > 0 && !g_no_defer && !(ENV(DEFER) && atoi(ENV(DEFER)) == 0)) {
+		/* score only, single gap: the deferred arg-max kernels' checkpoint stream of the one-alignment-per-wavefront geometries
+		 * (plan_create_ex): 512 bytes per step of a wavefront that two pairs share */
+		const int mx = imax(a->qlen, a->tlen), w = (a->w < 0 || a->w > mx) ? mx : a->w;
+		if (w > 68 && w <= 536 && !(a->flag & KSW_EZ_APPROX_MAX)) b += ((size_t)a->qlen + (size_t)a->tlen / 8 + 64) * 256 + (size_t)a->tlen;
 	}
 	return b;
 }
