@@ -796,9 +796,11 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 
 	/* A packed launch has half the wavefronts of the int32 launch of the same pairs.  When that leaves SIMDs without a
 	 * wavefront (a few hundred long reads), the wider int32 launch finishes earlier: measured on MI355X, 1024 pairs of
-	 * 10k x 10k, w = 500: 512 packed wavefronts 11.5 ms, 1024 int32 wavefronts 8.8 ms.  Below 0.6 wavefronts per SIMD the
-	 * packed candidates of a one-alignment-per-wavefront class go back to the int32 kernels (KSW2AMD_SIMDS overrides the
-	 * device's SIMD count, 0 = off). */
+	 * 10k x 10k, w = 500: 512 packed wavefronts 11.5 ms, 1024 int32 wavefronts 8.8 ms (round 2).  Round 3's packed kernels are
+	 * faster than the int32 ones wavefront for wavefront (the same 512 packed wavefronts from registers: 8.05 ms, int32 8.58 ms;
+	 * profiles/r3_small_launch_ab.txt), so half a wavefront per SIMD now stays packed; below 0.4 wavefronts per SIMD the packed
+	 * candidates of a one-alignment-per-wavefront class go back to the int32 kernels, whose twice as many wavefronts still reach
+	 * SIMDs the packed launch leaves empty (KSW2AMD_SIMDS overrides the device's SIMD count, 0 = off). */
 	{
 		const char *ev = ENV(SIMDS);
 		const int simds = ev ? atoi(ev) : k2a_shim_simd_count();
@@ -812,7 +814,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 					const int64_t waves = ((int64_t)(cnt[b] + 1) / 2 * G + 63) / 64 * (pcb == K2A_PKCFG_MP ? 4 : 1);     /* that class: four wavefronts per task */
 					/* one-alignment-per-wavefront classes only: for the short shapes of the multi-group geometries the gain is a
 					 * fraction of a millisecond per call and costs 2-3 x the SIMD time, which concurrent callers would rather keep */
-					cnt[b] = G == 64 && waves * 10 < (int64_t)simds * 6;        /* 1 = demote */
+					cnt[b] = G == 64 && waves * 10 < (int64_t)simds * 4;        /* 1 = demote */
 				}
 			for (i = 0; i < n; ++i) if (p->h_cls[i] >= 0 && pk_ok[i] && pk_ok[i] != PASS_SOLO && cnt[p->h_cls[i] * NPASS + pk_ok[i]]) pk_ok[i] = 0;
 		}
@@ -929,7 +931,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	 * strips whose columns the results need.  3 of 15 instructions per row pair (11 of 51 cycles) for 512 bytes of coalesced writes per
 	 * wavefront and step: the 10 k x 10 k headline 3 985 -> 4 692 GCUPS (round 3, same box).  Every pair of a wavefront gets the wavefront's block: tb_off = byte offset, bnd_off = steps of the stream, cig_off =
 	 * strips per group in the header table (ksw2_shim.h).  KSW2AMD_DEFER=0 / 1 forces it; by default classes of at least 32 tasks
-	 * take it, unless the checkpoints of the plan would not fit beside everything else. */
+	 * take it if they keep 1.5 wavefronts on every SIMD, unless the checkpoints of the plan would not fit beside everything else. */
 	{
 		const char *ev = ENV(DEFER);
 		const int forced = ev && *ev ? (atoi(ev) != 0) : -1;
@@ -939,7 +941,10 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 			c->defer = c->pk && !c->solo && c->cfg != K2A_PKCFG_MP && !dual && c->mode == K2A_MODE_SCORE && !c->nomax && !g_no_defer &&
 			           /* by default the one-alignment-per-wavefront geometries only: config 2's (8, 18) measured 2 749 against 2 827 GCUPS
 			            * with it (two wavefronts per SIMD either way, a vector wavefront index in the store address), round 3 */
-			           (forced < 0 ? c->count >= 32 && k2a_pkcfg_G[c->cfg] == 64 : forced);
+			           /* ... and only where the launch keeps at least 1.5 wavefronts on every SIMD: the deferred kernels of the 16-row
+			            * geometry have their code planes in LDS, whose latency a lone wavefront cannot hide (1 024 pairs of 10 k x 10 k =
+			            * 512 wavefronts: 1 063 GCUPS deferred against 1 241 from registers) */
+			           (forced < 0 ? k2a_pkcfg_G[c->cfg] == 64 && (k2a_shim_simd_count() > 0 ? 2 * (int64_t)c->count >= 3 * (int64_t)k2a_shim_simd_count() : c->count >= 32) : forced);
 		}
 		for (lo = 0; lo < 2; ++lo) {                       /* 0: size it, 1: lay it out */
 			size_t at = p->tb_bytes;

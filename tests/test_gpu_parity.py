@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _small_batches_stay_packed(monkeypatch):
     """Test batches are far too small to fill 1024 SIMDs; without this the host would send their packed-int16 candidates
-    back to the int32 kernels (ksw2_host.c, "0.6 wavefronts per SIMD") and the packed kernels would go untested."""
+    back to the int32 kernels (ksw2_host.c, "0.4 wavefronts per SIMD") and the packed kernels would go untested."""
     monkeypatch.setenv("KSW2AMD_SIMDS", "0")
 
 
