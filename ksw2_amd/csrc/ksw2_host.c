@@ -745,9 +745,11 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 			 * at its bytes -- which a device arena does not allow) */
 			if (pc == K2A_PKCFG_MP && flat && (flat->on_device || pair_has_wild(a))) pc = K2A_NPKCFG;
 			if (pc < K2A_NPKCFG) pk_ok[i] = (uint8_t)(1 + pc + ((plain && pc != K2A_PKCFG_MP) ? 0 : K2A_NPKCFG) + (is_approx(fl) ? 2 * K2A_NPKCFG : 0));
-			/* solo kernel: 2 * K2A_SOLO_C rows per lane share one base; a lane must finish a double strip before its next one starts */
-			if (solo_mode && !is_approx(fl) && pk_window_ok(&pkinfo[generic], a->qlen, d->tlen, w, 2 * K2A_SOLO_C) &&
-			    ((d->tlen + 2 * K2A_SOLO_C - 1) / (2 * K2A_SOLO_C) <= 64 || w < 64 * (K2A_SOLO_C + 1) - K2A_SOLO_C)) {
+			/* solo kernel: two strips of SC rows per lane, each with its own base (the window of an SC-row strip); a lane must finish
+			 * a double strip before its next one starts: 2 * 64 steps + 2 * SC * 64 columns later, against 2 * w + 2 * SC columns */
+			const int SC = K2A_SOLO_ROWS(mode == K2A_MODE_SCORE);
+			if (solo_mode && !is_approx(fl) && pk_window_ok(&pkinfo[generic], a->qlen, d->tlen, w, SC) &&
+			    ((d->tlen + 2 * SC - 1) / (2 * SC) <= 64 || w < 64 * (SC + 1) - SC)) {
 				solo_ok[i] = 1;
 				if (solo_mode == 2 && !(flat && (flat->on_device || pair_has_wild(a)))) pk_ok[i] = PASS_SOLO;
 			}
@@ -1173,7 +1175,7 @@ int ksw2amd_plan_describe(const ksw2amd_plan_t *p, char *buf, int cap)
 	for (c = 0; c < p->ncls && len < cap - 1; ++c) {
 		const cls_t *k = &p->cls[c];
 		const char *kind = k->solo ? "solo" : k->pk ? (k->cfg == K2A_PKCFG_MP ? "pkmp" : "pk") : (k->cfg == K2A_CFG_MP ? "mp" : "int32");
-		const int G = k->solo ? 64 : k->pk ? k2a_pkcfg_G[k->cfg] : k2a_cfg_G[k->cfg], C = k->solo ? 2 * K2A_SOLO_C : k->pk ? k2a_pkcfg_C[k->cfg] : k2a_cfg_C[k->cfg];
+		const int G = k->solo ? 64 : k->pk ? k2a_pkcfg_G[k->cfg] : k2a_cfg_G[k->cfg], C = k->solo ? 2 * K2A_SOLO_ROWS(k->mode == K2A_MODE_SCORE) : k->pk ? k2a_pkcfg_C[k->cfg] : k2a_cfg_C[k->cfg];
 		const int form = k->defer ? 3 : k->solo ? 0 : k->pk ? (k->cfg == K2A_PKCFG_MP ? 0 : k2a_shim_pk_form(k->cfg, p->dual, k->mode, k->nomax, k->count))
 		                                     : (k->cfg == K2A_CFG_MP ? k2a_shim_mp_form(p->dual, k->mode, k->count) : 0);
 		len += snprintf(buf + len, (size_t)(cap - len), "kernel=%s G=%d C=%d gaps=%d mode=%s rebased=%d nomax=%d generic=%d form=%s tasks=%d\n",

@@ -122,8 +122,21 @@ K2A_FN uint32_t k2a_pack_dirs(k2a_pk d0, k2a_pk d1)   /* low bytes of the four h
 	return __builtin_amdgcn_perm(d1, d0, 0x06040200u);
 }
 #define K2A_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+/* Loads whose result is needed many steps later.
+ * k2a_load_early: a plain dword load (a volatile one becomes a system-scope flat load with its wait right behind it); its
+ * s_waitcnt lands in front of the first use as for any load.  For values DEFINED UNCONDITIONALLY in the block that issues
+ * them (the query dword of the next group of four steps: issued at the top of a group, used below the group's steps).  A load into
+ * a variable that is set under a condition and lives around the step loop must not be written this way: hipcc copies the loaded
+ * register right behind the load (the phi of "loaded now / kept from before") and therefore waits there -- which is how every
+ * kernel's query "prefetch" used to be a blocking load (s_waitcnt vmcnt(0) two instructions after global_load_dword: 23-26 % of a
+ * lone wavefront's time, profiles/r3_solo_experiments.txt).
+ * (An inline-asm load that the compiler does not know as one, with a hand-placed s_waitcnt, does not work for those either:
+ * the register allocator copies the in-flight register at the loop's back edge -- tools/scripts/async_load_audit.py found that
+ * in every kernel it was tried in.) */
+K2A_FN uint32_t k2a_load_early(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 #else
 #define K2A_SCHED_FENCE() do {} while (0)
+K2A_FN uint32_t k2a_load_early(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 K2A_FN k2a_pk k2a_pk_mk(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
 K2A_FN k2a_pk k2a_pk_add(k2a_pk a, k2a_pk b) { return k2a_pk_mk(k2a_pk_lo(a) + k2a_pk_lo(b), k2a_pk_hi(a) + k2a_pk_hi(b)); }
 K2A_FN k2a_pk k2a_pk_sub(k2a_pk a, k2a_pk b) { return k2a_pk_mk(k2a_pk_lo(a) - k2a_pk_lo(b), k2a_pk_hi(a) - k2a_pk_hi(b)); }
@@ -474,8 +487,9 @@ struct K2aLanePk {
 	/* The same, four steps at a time (k2a_fill_pk_kernel): qwA / qwB hold the codes of this lane's columns at the steps
 	 * kg .. kg + 3 of the current group (kg = k & ~3), one byte per step, fetched with ONE unaligned dword load per alignment
 	 * and group instead of a byte load, an address and a clamp per step; query_pick is one v_perm_b32 with a scalar selector.
-	 * A strip that starts inside a group re-loads the group under its own column offset (load_query_group from the init
-	 * branch).  Bytes of columns outside the query are garbage that only dead cells see (the arena is padded). */
+	 * The kernel asks for a group at the top of the group before it (k2a_load_early: four steps in flight) and takes it over
+	 * below that group's last step.  A strip that starts inside a group re-loads the group under its own column offset
+	 * (reload_query_group from the init branch, which does wait).  Bytes of columns outside the query are garbage that only dead cells see (the arena is padded). */
 	uint32_t qwA, qwB;
 	/* OR of every code dword this lane fetched (k2a_fill_pk_kernel).  The packed kernels score match / mismatch only, so the host
 	 * keeps pairs with a wildcard code (>= 4) out of them -- by scanning the sequences while it copies them.  A flat batch
@@ -483,10 +497,10 @@ struct K2aLanePk {
 	 * was among the bytes I read" (K2aResult.pad[0]) and the host re-runs that pair through the int32 kernels.  Bytes that
 	 * belong to a neighbouring sequence can only cause a needless re-run. */
 	uint32_t seen;
-	K2A_FN void load_query_group(int kg, int koff_use, uint32_t &a, uint32_t &b)            /* prefetch: nothing here waits for the loads */
+	K2A_FN void load_query_group(int kg, int koff_use, uint32_t &a, uint32_t &b)            /* the wait comes with the first use of a / b */
 	{
 		const int jc = k2a_min(k2a_max(kg - koff_use, 0), qlen - 1);    /* column at step kg; a negative one belongs to a lane without a strip */
-		__builtin_memcpy(&a, qa + jc, 4); __builtin_memcpy(&b, qbp + jc, 4);
+		a = k2a_load_early(qa + jc); b = k2a_load_early(qbp + jc);
 	}
 	K2A_FN void note_codes(uint32_t a, uint32_t b) { seen |= a | b; }
 	K2A_FN bool saw_wildcard() const { return (seen & 0xfcfcfcfcu) != 0; }

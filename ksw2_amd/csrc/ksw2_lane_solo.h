@@ -4,8 +4,14 @@
  * [i0+C, i0+2C) at column jj-1.  The two halves are two consecutive strips of the schedule of ksw2_lane.h (strip 2D and
  * 2D+1, one step apart), so the low half's bottom row reaches the high half inside the lane one step later, and the high
  * half's bottom row reaches the next lane's low half through the usual one-lane rotate.  Same cell update and number
- * format as K2aLanePk (offset form, row bias, per-strip score base = re-based variant; one base per double strip), but no
- * partner alignment of identical shape is needed: this is the kernel for reads whose shape is unique in their batch.
+ * format as K2aLanePk (offset form, row bias, per-strip score base = re-based variant; each half has its own base, like the
+ * two alignments of a K2aLanePk lane, so the band window a half must hold is that of a C-row strip), but no partner
+ * alignment of identical shape is needed: this is the kernel for reads whose shape is unique in their batch, and for
+ * batches of so few long reads that one read per wavefront fills more SIMDs than two (1 024 reads of 10 k on 1 024 SIMDs).
+ * Rows per half: K2A_SOLO_C with a traceback, K2A_SOLO_CS score only (ksw2_shim.h).
+ *
+ * Query codes: the high half works on the column the low half had one step earlier, so the lane keeps the previous code in
+ * the high half of `qb`; the codes themselves come four steps per unaligned dword (load_query_group, as in K2aLanePk).
  *
  * Differences to K2aLanePk worth knowing when reading step(): the live-row mask, the "cell above is outside the band" test
  * and the column index differ between the halves; the strip epilogue runs once per double strip, over 2C rows, after the
@@ -36,10 +42,11 @@ struct K2aLaneSolo {
 	int gl, D, i0, koff, Dnext, knext, koff_next;
 	int kfin, kfinA, kd, kB0, rowsA_m1, rowsB_m1, wupA;   /* kB0: first step of the high half (its first in-band column) */
 	k2a_pk hout, eout, e2out, hd0, hu_prev;
-	int base;                              /* absolute (row-biased) score the double strip's values are relative to */
-	k2a_pk delta;                           /* low half: base of the double strip above minus this one; high half 0 */
-	bool bfirst;
-	uint32_t qb;                            /* { query code at column jj, at column jj-1 } */
+	int baseA, baseB;                      /* absolute (row-biased) scores the low / high half's values are relative to */
+	k2a_pk delta;                           /* low half: base of the lane above's high half minus baseA; high half: baseA - baseB */
+	uint32_t qb, qw;                        /* { query code at column jj, at column jj-1 }; the dword of the current four steps */
+	uint32_t tnA[(C + 3) / 4], tnB[(C + 3) / 4], qn0;   /* prefetched for the NEXT double strip: its target codes, its first query dword */
+	int qn_sh;
 	k2a_pk hl[C], f[C], f2[DUAL ? C : 1], rmax[C], rmj[C], tc[C], tc1[C], hsave[C];
 
 	K2A_FN static int first_col(int D_, int w_) { return k2a_max(0, D_ * 2 * C - w_); }
@@ -47,6 +54,25 @@ struct K2aLaneSolo {
 	{
 		koff_next = 2 * Dnext;
 		knext = Dnext < nds ? koff_next + first_col(Dnext, w) : K2A_KNONE;
+	}
+
+	/* What the next double strip's do_init needs from memory, asked for one strip early (about a thousand steps): with one
+	 * wavefront per SIMD nobody else covers a load's latency, and a strip starts somewhere in the wavefront every 16 steps
+	 * (profiles/r3_solo_experiments.txt: 26 % of the kernel's time was s_waitcnt).  hipcc still waits for these right behind the
+	 * loads (they are set under a condition and live around the step loop: ksw2_lane_pk.h, k2a_load_early), but the wait then
+	 * overlaps the rest of do_init instead of standing in front of it.  Target codes of its 2C rows and the query
+	 * dword of the group of four steps its first step falls in (shifted when column 0 comes later than the group's first step). */
+	K2A_FN void prefetch_next()
+	{
+		qn_sh = 0;
+		if (Dnext < nds) {
+			const uint8_t *tp = ta + (size_t)Dnext * 2 * C;
+#pragma unroll
+			for (int x = 0; x < (C + 3) / 4; ++x) { tnA[x] = k2a_load_early(tp + 4 * x); tnB[x] = k2a_load_early(tp + C + 4 * x); }
+			const int j = (knext & ~3) - koff_next;                    /* < 0: the strip's column 0 comes -j steps into the group */
+			qn_sh = 8 * k2a_min(k2a_max(-j, 0), 3);
+			qn0 = k2a_load_early(qa + k2a_min(k2a_max(j, 0), qlen - 1));
+		}
 	}
 
 	K2A_FN void setup(const K2aPair &pr, const uint8_t *seq, int lane, bool valid)
@@ -58,8 +84,12 @@ struct K2aLaneSolo {
 		D = -1; i0 = 0; koff = 0; kfin = kfinA = K2A_KNONE; kd = 0; kB0 = 0; rowsA_m1 = rowsB_m1 = -1; wupA = w;
 		Dnext = gl;
 		schedule_next();
+#pragma unroll
+		for (int x = 0; x < (C + 3) / 4; ++x) tnA[x] = tnB[x] = 0;
+		qn0 = 0;
+		prefetch_next();
 		const k2a_pk neg = k2a_pku(K2A_NEG16);
-		hout = eout = e2out = hd0 = hu_prev = neg; qb = 0; base = 0; delta = 0; bfirst = false;
+		hout = eout = e2out = hd0 = hu_prev = neg; qb = 0; qw = 0; baseA = baseB = 0; delta = 0;
 #pragma unroll
 		for (int c = 0; c < C; ++c) { hl[c] = f[c] = rmax[c] = hsave[c] = neg; rmj[c] = 0; tc[c] = tc1[c] = 0; if (DUAL) f2[c] = neg; }
 		if (!DUAL) f2[0] = 0;
@@ -76,7 +106,7 @@ struct K2aLaneSolo {
 	K2A_FN bool need_fin(int k) const { return k == kfin; }
 	K2A_FN bool need_save(int k) const { return k == kfinA; }
 
-	/* bs = base of the double strip above (rotated in by the kernel) */
+	/* bs = base of the high half of the double strip above (rotated in by the kernel) */
 	K2A_FN void do_init(const K2aScoring &sc, int bs)
 	{
 		D = Dnext; i0 = D * 2 * C; koff = koff_next;
@@ -88,32 +118,34 @@ struct K2aLaneSolo {
 		kfinA = koff + jeA;
 		kfin = rowsB_m1 >= 0 ? koff + 1 + jeB : kfinA;
 		kd = koff + i0;
-		kB0 = koff + 1 + k2a_max(0, i0b - w);
+		kB0 = rowsB_m1 >= 0 ? koff + 1 + k2a_max(0, i0b - w) : K2A_KNONE;
 		wupA = w + (D == 0 ? 1 : 0);
 		const int js = k2a_max(0, i0 - w);
 		const k2a_pk neg = k2a_pku(K2A_NEG16);
 		const uint32_t dmis = (uint32_t)(sc.pk_a - sc.pk_b);
-		/* target codes of the 2C rows as bit planes x D (ksw2_lane_pk.h), low half = rows i0.., high half = rows i0+C.. */
-		const uint16_t *tpa = (const uint16_t*)(ta + (size_t)i0), *tpb = (const uint16_t*)(ta + (size_t)i0b);
+		/* target codes of the 2C rows as bit planes x D (ksw2_lane_pk.h), low half = rows i0.., high half = rows i0+C..: four
+		 * rows of both halves per pair of dwords, a plane of a row is one and + one multiply on both halves at once */
 #pragma unroll
-		for (int c = 0; c < C; c += 2) {
-			const uint32_t ua = tpa[c >> 1], ub = tpb[c >> 1];
-			const k2a_pk c0 = k2a_pair16(ua & 0xffu, ub & 0xffu), c1 = k2a_pair16(ua >> 8, ub >> 8);
-			tc[c] = (c0 & 0x00010001u) * dmis; tc1[c] = ((c0 >> 1) & 0x00010001u) * dmis;
-			if (c + 1 < C) { tc[c + 1] = (c1 & 0x00010001u) * dmis; tc1[c + 1] = ((c1 >> 1) & 0x00010001u) * dmis; }
+		for (int c4 = 0; c4 < C; c4 += 4) {
+			const uint32_t da = tnA[c4 / 4], db = tnB[c4 / 4];             /* prefetch_next(), one strip ago */
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				const k2a_pk cc = k2a_byte_pair(da, db, r);
+				tc[c4 + r] = (cc & 0x00010001u) * dmis; tc1[c4 + r] = ((cc >> 1) & 0x00010001u) * dmis;
+			}
 		}
 #pragma unroll
 		for (int c = 0; c < C; ++c) { hl[c] = neg; f[c] = neg; if (DUAL) f2[c] = neg; rmax[c] = neg; rmj[c] = 0; }
 		/* base = the diagonal input of the low half's first cell */
 		const int hcorner = k2a_border<DUAL>(sc, i0) + sc.e * (i0 - 1);
 		const int nb = js == 0 ? hcorner : bs + k2a_pk_hi(k2a_ofs_off(hu_prev));          /* what arrived: the high half of the lane above */
-		delta = D == 0 ? 0u : ((uint32_t)(bs - nb) & 0xffffu);
-		base = nb;
+		delta = D == 0 ? 0u : ((uint32_t)(bs - nb) & 0xffffu);                            /* high half: 0 until start_high() */
+		baseA = nb;
 		if (i0 <= w) {                                          /* rows starting at column 0: virtual column -1 (ksw2_extz.c:43-44) */
 #pragma unroll
 			for (int c = 0; c < C; ++c) {
 				const int ha = k2a_border<DUAL>(sc, i0 + c + 1) + sc.e * (i0 + c);
-				const uint32_t va = i0 + c <= w ? k2a_h16(ha - base) : k2a_h16(K2A_NEG16);
+				const uint32_t va = i0 + c <= w ? k2a_h16(ha - baseA) : k2a_h16(K2A_NEG16);
 				hl[c] = k2a_pair16(va, neg >> 16);
 				const k2a_pk fl = k2a_pk_sub(hl[c], k2a_pk2(sc.q + sc.e));
 				f[c] = k2a_pair16(i0 + c <= w ? fl & 0xffffu : neg & 0xffffu, neg >> 16);
@@ -124,44 +156,49 @@ struct K2aLaneSolo {
 			}
 		}
 		/* diagonal input of the low half's first cell: 0 by construction of the base.  The high half takes the low half's bottom
-		 * row one step later; when its rows start at column 0 init_high() loads its virtual column -1 just before that step
-		 * (the step in between runs the high half dead and would wipe it). */
+		 * row one step later: start_high() gives it its own base just before its first step. */
 		hd0 = k2a_pair16(k2a_h16(0), neg >> 16);
-		bfirst = i0b <= w && rowsB_m1 >= 0;
+		qw = qn0 << qn_sh;                                      /* this strip's first group of query codes */
 		Dnext += G;
 		schedule_next();
+		prefetch_next();
 	}
 
-	K2A_FN bool need_init_high(int k) const { return bfirst && k == kB0; }
+	K2A_FN bool need_init_high(int k) const { return k == kB0; }
 
-	/* high half, rows starting at column 0: H / F / F~ of the virtual column -1 and the first diagonal input */
-	K2A_FN void init_high(const K2aScoring &sc)
+	/* The high half's first step.  Its base is the diagonal input of its first cell: H(i0b - 1, first column - 1), which is what
+	 * the low half's bottom row handed over one step ago (hd0's high half, still relative to baseA: delta's high half is 0
+	 * since do_init) -- or the virtual column -1 when the rows start at column 0, whose H / F / F~ are loaded here too (any
+	 * earlier and the steps in between, which run the high half dead, would wipe them). */
+	K2A_FN void start_high(const K2aScoring &sc)
 	{
 		const int i0b = i0 + C;
-		const uint32_t negh = (uint32_t)k2a_h16(K2A_NEG16);
+		if (i0b <= w) {
+			const uint32_t negh = (uint32_t)k2a_h16(K2A_NEG16);
+			baseB = k2a_border<DUAL>(sc, i0b) + sc.e * (i0b - 1);
 #pragma unroll
-		for (int c = 0; c < C; ++c) {
-			const bool in = i0b + c <= w;
-			const int hb = k2a_border<DUAL>(sc, i0b + c + 1) + sc.e * (i0b + c) - base;
-			const uint32_t vb = in ? k2a_h16(hb) : negh;
-			const uint32_t fb = in ? k2a_h16(hb - (sc.q + sc.e)) : negh;
-			hl[c] = (hl[c] & 0xffffu) | (vb << 16);
-			f[c] = (f[c] & 0xffffu) | (fb << 16);
-			if (DUAL) {
-				const uint32_t fb2 = in ? k2a_h16(hb - (sc.q2 + sc.e2)) : negh;
-				f2[c] = (f2[c] & 0xffffu) | (fb2 << 16);
+			for (int c = 0; c < C; ++c) {
+				const bool in = i0b + c <= w;
+				const int hb = k2a_border<DUAL>(sc, i0b + c + 1) + sc.e * (i0b + c) - baseB;
+				const uint32_t vb = in ? k2a_h16(hb) : negh;
+				const uint32_t fb = in ? k2a_h16(hb - (sc.q + sc.e)) : negh;
+				hl[c] = (hl[c] & 0xffffu) | (vb << 16);
+				f[c] = (f[c] & 0xffffu) | (fb << 16);
+				if (DUAL) {
+					const uint32_t fb2 = in ? k2a_h16(hb - (sc.q2 + sc.e2)) : negh;
+					f2[c] = (f2[c] & 0xffffu) | (fb2 << 16);
+				}
 			}
-		}
-		const uint32_t d0 = k2a_h16(k2a_border<DUAL>(sc, i0b) + sc.e * (i0b - 1) - base);
-		hd0 = (hd0 & 0xffffu) | (d0 << 16);
-		bfirst = false;
+		} else baseB = baseA + k2a_pk_hi(k2a_ofs_off(hd0));
+		hd0 = (hd0 & 0xffffu) | ((uint32_t)k2a_h16(0) << 16);
+		delta = (delta & 0xffffu) | (((uint32_t)(baseA - baseB) & 0xffffu) << 16);
 	}
 
 	/* double strip 0, low half only: the cells above row 0 are the virtual row -1 (ksw2_extz.c:32-35) */
 	K2A_FN void top_inputs(const K2aScoring &sc, int k, k2a_pk &hin, k2a_pk &ein, k2a_pk &e2in) const
 	{
 		if (D == 0) {
-			const int hb = k2a_border<DUAL>(sc, k - koff + 1) - base;
+			const int hb = k2a_border<DUAL>(sc, k - koff + 1) - baseA;
 			const uint32_t h0 = k2a_h16(hb - sc.e), e0 = k2a_h16(hb - (sc.q + sc.e));
 			const uint32_t e20 = k2a_h16(hb - (sc.q2 + sc.e2));
 			hin = (hin & 0xffff0000u) | h0; ein = (ein & 0xffff0000u) | e0; e2in = (e2in & 0xffff0000u) | e20;
@@ -169,8 +206,8 @@ struct K2aLaneSolo {
 	}
 
 	/* One step: column jj = k - koff for the low half's rows, jj - 1 for the high half's.  hin / ein / e2in: low half = bottom
-	 * row of the lane above's high half (already shifted by delta), high half = this lane's own low-half bottom row of the
-	 * previous step. */
+	 * row of the lane above's high half, high half = this lane's own low-half bottom row of the previous step (both already
+	 * shifted by delta).  Rows in chunks of CH as in K2aLanePk::step. */
 	K2A_FN bool step(const K2aScoring &sc, int k, k2a_pk hin, k2a_pk ein, k2a_pk e2in, uint32_t *tbw)
 	{
 		const int ddA = k - kd, ddB = ddA - C - 1;
@@ -179,88 +216,112 @@ struct K2aLaneSolo {
 		const k2a_pk mat_a = k2a_pk2(sc.pk_a + sc.e);
 		/* the cell above is outside the band: per half */
 		const k2a_pk cut = k2a_pair16(ddA >= wupA ? 0xffffu : 0u, ddB >= w ? 0xffffu : 0u);
-		k2a_pk e = k2a_pk_sel(cut, neg, ein), e2 = k2a_pk_sel(cut, neg, e2in);
+		k2a_pk e = k2a_pk_sel(cut, neg, ein), e2 = DUAL ? k2a_pk_sel(cut, neg, e2in) : 0u;
 		/* the low half keeps stepping after its last column while the high half finishes, the high half is carried along before
 		 * its first column: no live rows there */
 		const int loA = k2a_max(0, ddA - w), hiA = k2a_min(rowsA_m1, ddA + w), cntA = k <= kfinA ? k2a_max(hiA - loA + 1, 0) : 0;
 		const int loB = k2a_max(0, ddB - w), hiB = k2a_min(rowsB_m1, ddB + w), cntB = k >= kB0 ? k2a_max(hiB - loB + 1, 0) : 0;
 		const uint32_t liveA = ((1u << cntA) - 1u) << (loA & 31), liveB = ((1u << cntB) - 1u) << (loB & 31);   /* lo >= 32 only with cnt = 0 */
-		k2a_pk lv = k2a_pair16(liveA << (15 - (C - 1)), liveB << (15 - (C - 1)));      /* bit C-1 of each half at bit 15; row c at bit 15 - (C-1-c) */
+		/* row c of the low half at bit c, of the high half at bit 16 + c: ONE 32-bit shift by 15 - c puts both at their halves'
+		 * sign bits (what the low half's higher rows spill into the high half stays below bit 31) */
+		const uint32_t lv = liveA | (liveB << 16);
 		const k2a_pk qcode = qb;
 		const k2a_pk jjpk = k2a_pair16((uint32_t)(k - koff) & 0xffffu, (uint32_t)(k - koff - 1) & 0xffffu);
 		const uint32_t dmis = (uint32_t)(sc.pk_a - sc.pk_b);
 		const k2a_pk q0 = (qcode & 0x00010001u) * dmis, q1 = ((qcode >> 1) & 0x00010001u) * dmis;
-		k2a_pk cand[C];
+		/* score only: all rows' candidates at once -- these tasks run at one or two wavefronts per SIMD, where the longer
+		 * independent stretch is worth more than the registers (1 024 x 10 k x 10 k: 6.74 ms against 7.07 ms) */
+		constexpr int CH = (MODE != K2A_MODE_SCORE && C % 4 == 0) ? 4 : C;
+		k2a_pk dprev = 0, above_old = hd0;
 #pragma unroll
-		for (int c = 0; c < C; ++c)
-			cand[c] = k2a_sub32(k2a_add32(c == 0 ? hd0 : hl[c - 1], mat_a), k2a_or_xor(tc[c] ^ q0, tc1[c], q1));
-		k2a_pk dprev = 0;
+		for (int c0 = 0; c0 < C; c0 += CH) {
+			k2a_pk cand[CH];
+			const k2a_pk last_old = hl[c0 + CH - 1];
 #pragma unroll
-		for (int c = 0; c < C; ++c) {
-			const k2a_pk fc = f[c];
-			k2a_pk h = cand[c], d = 0;
-			if (MODE == K2A_MODE_SCORE) {
-				h = k2a_pk_max3u(h, e, fc);                    /* v_pk_maximum3_f16 on offset-form patterns (ksw2_lane_pk.h) */
-				if (DUAL) h = k2a_pk_max3u(h, e2, f2[c]);
-			} else if (MODE == K2A_MODE_LEFT) {
-				d = k2a_pk_sign(k2a_pk_sub(h, e)) & 0x00010001u;                     h = k2a_pk_maxu(h, e);
-				d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, fc)), 0x00020002u, d);      h = k2a_pk_maxu(h, fc);
-				if (DUAL) {
-					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, e2)), 0x00030003u, d);    h = k2a_pk_maxu(h, e2);
-					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, f2[c])), 0x00040004u, d); h = k2a_pk_maxu(h, f2[c]);
-				}
-			} else {
-				d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e, h)), 0u, 0x00010001u);      h = k2a_pk_maxu(h, e);
-				d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(fc, h)), d, 0x00020002u);      h = k2a_pk_maxu(h, fc);
-				if (DUAL) {
-					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e2, h)), d, 0x00030003u);    h = k2a_pk_maxu(h, e2);
-					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(f2[c], h)), d, 0x00040004u); h = k2a_pk_maxu(h, f2[c]);
-				}
+			for (int r = 0; r < CH; ++r) {
+				const int c = c0 + r;
+				cand[r] = k2a_sub32(k2a_add32(r == 0 ? above_old : hl[c - 1], mat_a), k2a_or_xor(tc[c] ^ q0, tc1[c], q1));
 			}
-			/* live mask of row c, per half: the row's bit sits at bit 15 - (C-1-c) of lv's halves */
-			h = k2a_pk_sel(k2a_pk_sign(k2a_pk_shl(lv, C - 1 - c)), h, neg);
-			if (!DUAL && MODE == K2A_MODE_RIGHT) rmj[c] = k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(rmax[c], h)), jjpk, rmj[c]);
-			else rmj[c] = k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(h, rmax[c])), rmj[c], jjpk);
-			rmax[c] = k2a_pk_maxu(rmax[c], h);
-			const k2a_pk t = k2a_sub32(h, gq);
-			if (MODE == K2A_MODE_LEFT) {
-				d |= k2a_pk_sign(k2a_pk_sub(t, e)) & 0x00080008u;
-				d |= k2a_pk_sign(k2a_pk_sub(t, fc)) & 0x00100010u;
-			} else if (MODE == K2A_MODE_RIGHT) {
-				d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e, t)), 0u, 0x00080008u);
-				d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(fc, t)), 0u, 0x00100010u);
-			}
-			e = k2a_pk_maxu(e, t);
-			f[c] = k2a_sub32(k2a_pk_maxu(fc, t), ge);
-			if (DUAL) {
-				const k2a_pk t2 = k2a_sub32(h, gq2);
+			above_old = last_old;
+			if (CH < C) K2A_SCHED_FENCE();
+#pragma unroll
+			for (int r = 0; r < CH; ++r) {
+				const int c = c0 + r;
+				const k2a_pk fc = f[c];
+				k2a_pk h = cand[r], d = 0;
+				if (MODE == K2A_MODE_SCORE) {
+					h = k2a_pk_max3u(h, e, fc);                    /* v_pk_maximum3_f16 on offset-form patterns (ksw2_lane_pk.h) */
+					if (DUAL) h = k2a_pk_max3u(h, e2, f2[c]);
+				} else if (MODE == K2A_MODE_LEFT) {
+					d = k2a_pk_sign(k2a_pk_sub(h, e)) & 0x00010001u;                     h = k2a_pk_maxu(h, e);
+					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, fc)), 0x00020002u, d);      h = k2a_pk_maxu(h, fc);
+					if (DUAL) {
+						d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, e2)), 0x00030003u, d);    h = k2a_pk_maxu(h, e2);
+						d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, f2[c])), 0x00040004u, d); h = k2a_pk_maxu(h, f2[c]);
+					}
+				} else {
+					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e, h)), 0u, 0x00010001u);      h = k2a_pk_maxu(h, e);
+					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(fc, h)), d, 0x00020002u);      h = k2a_pk_maxu(h, fc);
+					if (DUAL) {
+						d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e2, h)), d, 0x00030003u);    h = k2a_pk_maxu(h, e2);
+						d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(f2[c], h)), d, 0x00040004u); h = k2a_pk_maxu(h, f2[c]);
+					}
+				}
+				h = k2a_pk_sel(k2a_pk_sign(lv << (15 - c)), h, neg);                 /* live mask of row c, per half */
+				if (!DUAL && MODE == K2A_MODE_RIGHT) rmj[c] = k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(rmax[c], h)), jjpk, rmj[c]);
+				else rmj[c] = k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(h, rmax[c])), rmj[c], jjpk);
+				rmax[c] = k2a_pk_maxu(rmax[c], h);
+				const k2a_pk t = k2a_sub32(h, gq);
 				if (MODE == K2A_MODE_LEFT) {
-					d |= k2a_pk_sign(k2a_pk_sub(t2, e2)) & 0x00200020u;
-					d |= k2a_pk_sign(k2a_pk_sub(t2, f2[c])) & 0x00400040u;
+					d |= k2a_pk_sign(k2a_pk_sub(t, e)) & 0x00080008u;
+					d |= k2a_pk_sign(k2a_pk_sub(t, fc)) & 0x00100010u;
 				} else if (MODE == K2A_MODE_RIGHT) {
-					d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e2, t2)), 0u, 0x00200020u);
-					d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(f2[c], t2)), 0u, 0x00400040u);
+					d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e, t)), 0u, 0x00080008u);
+					d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(fc, t)), 0u, 0x00100010u);
 				}
-				e2 = k2a_pk_sub(k2a_pk_maxu(e2, t2), de2);
-				f2[c] = k2a_sub32(k2a_pk_maxu(f2[c], t2), ge2);
+				e = k2a_pk_maxu(e, t);
+				f[c] = k2a_sub32(k2a_pk_maxu(fc, t), ge);
+				if (DUAL) {
+					const k2a_pk t2 = k2a_sub32(h, gq2);
+					if (MODE == K2A_MODE_LEFT) {
+						d |= k2a_pk_sign(k2a_pk_sub(t2, e2)) & 0x00200020u;
+						d |= k2a_pk_sign(k2a_pk_sub(t2, f2[c])) & 0x00400040u;
+					} else if (MODE == K2A_MODE_RIGHT) {
+						d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e2, t2)), 0u, 0x00200020u);
+						d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(f2[c], t2)), 0u, 0x00400040u);
+					}
+					e2 = k2a_pk_sub(k2a_pk_maxu(e2, t2), de2);
+					f2[c] = k2a_sub32(k2a_pk_maxu(f2[c], t2), ge2);
+				}
+				if (MODE != K2A_MODE_SCORE) {
+					if (c & 1) tbw[c >> 1] = k2a_pack_dirs(dprev, d);
+					else dprev = d;
+				}
+				hl[c] = h;
 			}
-			if (MODE != K2A_MODE_SCORE) {
-				if (c & 1) tbw[c >> 1] = k2a_pack_dirs(dprev, d);
-				else dprev = d;
-			}
-			hl[c] = h;
+			if (CH < C) K2A_SCHED_FENCE();
 		}
 		hd0 = hin;
 		hout = hl[C - 1]; eout = e; e2out = e2;
 		return (liveA | liveB) != 0;
 	}
 
-	/* query codes for step k+1: columns jj and jj-1 */
-	K2A_FN uint32_t next_query_codes(int k) const
+	/* Query codes, four steps per unaligned dword (K2aLanePk::load_query_group): the group of steps kg .. kg+3 under the column
+	 * offset `koff_use`; nothing here waits for the load.  The kernel asks for a group four steps before its first step; a double
+	 * strip that starts in between brings its own first group (prefetch_next). */
+	K2A_FN void load_query_group(int kg, int koff_use, uint32_t &a) const
 	{
-		const int j = k + 1 - ((k + 1 == knext) ? koff_next : koff);
-		const int ja = k2a_min(k2a_max(j, 0), qlen - 1), jb = k2a_min(k2a_max(j - 1, 0), qlen - 1);
-		return k2a_pair16(qa[ja], qa[jb]);
+		const int jc = k2a_min(k2a_max(kg - koff_use, 0), qlen - 1);
+		a = k2a_load_early(qa + jc);
+	}
+	/* the codes of step kg + kk: the low half's from the group, the high half's = what the low half had one step ago */
+	K2A_FN void advance_query(int kk)
+	{
+#if defined(__HIP_DEVICE_COMPILE__)
+		qb = __builtin_amdgcn_perm(qb, qw, 0x0c040c00u + (uint32_t)kk);
+#else
+		qb = ((qw >> (8 * kk)) & 0xffu) | ((qb & 0xffu) << 16);
+#endif
 	}
 
 	/* the low half is done C+1 steps before the high half and keeps stepping over dead cells: keep its last-column H */
@@ -292,7 +353,7 @@ struct K2aLaneSolo {
 			const int i = i0 + c;
 			if (i < tlen && !bdrop) {
 				const bool reach = i + w >= qlen - 1;
-				const int unb = base - sc.e * i;
+				const int unb = (c < C ? baseA : baseB) - sc.e * i;
 				const int hend = (int)(int16_t)rowbuf[c] + unb, H = (int)(int16_t)rowbuf[2 * C + c] + unb;
 				const int j = (int)(uint16_t)rowbuf[4 * C + c];
 				if (reach && hend > bmqe) { bmqe = hend; bmqe_t = i; }
@@ -328,9 +389,9 @@ struct K2aLaneSolo {
 			m = k2a_pk_max(m, v);
 			mn = k2a_pk_min(mn, v);
 		}
-		const int off = base - sc.e * i0;
-		const int MA = k2a_pk_lo(m) + off, MB = k2a_pk_hi(m) + off;
-		const int mnn = k2a_min(k2a_pk_lo(mn), k2a_pk_hi(mn)) + off;
+		const int offA = baseA - sc.e * i0, offB = baseB - sc.e * i0;
+		const int MA = k2a_pk_lo(m) + offA, MB = k2a_pk_hi(m) + offB;
+		const int mnn = k2a_min(k2a_pk_lo(mn) + offA, k2a_pk_hi(mn) + offB);
 		const int M = k2a_max(MA, MB), bm = b->max;
 		if (b->dropped) { end_strip(); return true; }
 		if (zdrop >= 0 && k2a_max(bm, M) - mnn > zdrop) return false;

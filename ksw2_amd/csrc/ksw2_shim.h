@@ -104,7 +104,12 @@ int k2a_shim_launch_fill_pkmp(int dual, int mode, const K2aScoring *sc, const K2
 
 /* Solo packed fill (ksw2_lane_solo.h): ONE alignment per wavefront using both 16-bit halves (rows [i0,i0+C) and [i0+C,i0+2C) of
  * a double strip), for alignments without a partner of identical shape.  K2A_SOLO_C rows per half; order[t] = pair index. */
-#define K2A_SOLO_C 8
+#define K2A_SOLO_C 8       /* tasks with a traceback */
+/* score-only tasks: 16 rows per half fit the registers (208 VGPRs) and halve the per-step overhead per cell, but 64 lanes x 32
+ * rows = 2 048 rows in flight want a band that wide -- at w = 500 half the lanes idle (measured, 1 024 x 10 k x 10 k: 9.5 ms
+ * against 7.1 ms with 8 rows, profiles/r3_solo_experiments.txt).  The steps of a task are its columns whatever the height. */
+#define K2A_SOLO_CS 8
+#define K2A_SOLO_ROWS(score_only) ((score_only) ? K2A_SOLO_CS : K2A_SOLO_C)
 int k2a_shim_launch_fill_solo(int dual, int mode, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order, int ntasks,
                               const uint8_t *seq, uint8_t *tb, K2aResult *res, void *stream);
 int k2a_shim_launch_trace_solo(const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb, K2aResult *res,

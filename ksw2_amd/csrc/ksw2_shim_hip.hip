@@ -255,7 +255,6 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 
 	bool gdone = !valid;
 	/* query codes: one unaligned dword per alignment and four steps (K2aLanePk::load_query_group) */
-	uint32_t qpa = 0, qpb = 0;
 	L.load_query_group(0, L.knext == 0 ? L.koff_next : L.koff, L.qwA, L.qwB);
 	L.note_codes(L.qwA, L.qwB);
 	const size_t tbsteps = (size_t)(klast + 1);
@@ -277,7 +276,15 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	K2aCkHead *ckhd = (K2aCkHead*)(tb + ckoff + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)prA.bnd_off) * K2A_CK_STEP_BYTES) +
 	                  (size_t)grp * (uint32_t)__builtin_amdgcn_readfirstlane((int)prA.cig_off);
 
-	for (int k = 0; k <= kmax; ++k) {
+	/* Steps in groups of four: the query dwords of the NEXT group are asked for at the top of a group and taken over below its
+	 * last step, four steps in flight (K2aLanePk::load_query_group).  The inner loop stays rolled. */
+	bool stop = false;
+	for (int kg = 0; kg <= kmax && !stop; kg += 4) {
+	uint32_t qpa, qpb;
+	L.load_query_group(kg + 4, L.knext <= kg + 4 ? L.koff_next : L.koff, qpa, qpb);
+	const int kge = min(kg + 3, kmax);
+#pragma nounroll
+	for (int k = kg; k <= kge; ++k) {
 		k2a_pk hin = (k2a_pk)k2a_rot1<G>((int)L.hout);
 		k2a_pk ein = (k2a_pk)k2a_rot1<G>((int)L.eout);
 		k2a_pk e2in = DUAL ? (k2a_pk)k2a_rot1<G>((int)L.e2out) : 0u;
@@ -293,7 +300,6 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 		}
 		L.hu_prev = hin;
 		if (RB) { hin = k2a_pk_add(hin, L.delta); ein = k2a_pk_add(ein, L.delta); if (DUAL) e2in = k2a_pk_add(e2in, L.delta); }
-		if ((k & 3) == 3) L.load_query_group(k + 1, k + 1 == L.knext ? L.koff_next : L.koff, qpa, qpb);   /* in flight during this step */
 		L.qb = Lane::query_pick(L.qwA, L.qwB, k & 3);
 		if (k <= ktop) L.top_inputs(sc, k, hin, ein, e2in);
 
@@ -334,8 +340,9 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 				__builtin_amdgcn_wave_barrier();
 			}
 		}
-		if ((k & 3) == 3) { L.qwA = qpa; L.qwB = qpb; L.note_codes(qpa, qpb); }
-		if (zseq && __builtin_amdgcn_ballot_w64(!(gdone || k >= klast)) == 0) break;   /* only a Z-drop ends a group early */
+		if (zseq && __builtin_amdgcn_ballot_w64(!(gdone || k >= klast)) == 0) { stop = true; break; }   /* only a Z-drop ends a group early */
+	}
+	L.qwA = qpa; L.qwB = qpb; L.note_codes(qpa, qpb);
 	}
 	if (STAGED) ST.finish(kdone);
 	__builtin_amdgcn_wave_barrier();
@@ -457,7 +464,8 @@ k2a_fill_solo_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 	const int ktop = valid ? min(pr.qlen - 1, min(C - 1, pr.tlen - 1) + pr.w) : -1;
 	const size_t tbsteps = k2a_solo_steps<C>(pr.qlen, pr.tlen, pr.w);
 	uint8_t *tbp = tb + pr.tb_off;
-	L.qb = L.next_query_codes(-1);
+	/* query codes: one unaligned dword per four steps (K2aLaneSolo::load_query_group) */
+	L.load_query_group(0, L.knext == 0 ? L.koff_next : L.koff, L.qw);
 	/* traceback words as whole cache lines (K2aTbStage, see the packed kernels): config 5's unique read shapes run here */
 	constexpr int WB = Lane::TBWORDS * 4;
 	constexpr bool STAGED = MODE != K2A_MODE_SCORE && (WB == 16 || WB == 32);
@@ -468,7 +476,13 @@ k2a_fill_solo_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 	if (STAGED) ST.init(&tbstage[wave * Stage::WORDS], &tbruns[wave * 64], lane, tbp + k2a_tb_word(0, lane, tbsteps, 64, WB));
 	int kdone = -1;
 
-	for (int k = 0; k <= klast; ++k) {
+	bool stop = false;
+	for (int kg = 0; kg <= klast && !stop; kg += 4) {        /* groups of four steps as in k2a_fill_pk_kernel */
+	uint32_t qp;
+	L.load_query_group(kg + 4, L.knext <= kg + 4 ? L.koff_next : L.koff, qp);
+	const int kge = min(kg + 3, klast);
+#pragma nounroll
+	for (int k = kg; k <= kge; ++k) {
 		const k2a_pk rh = (k2a_pk)k2a_rot1<64>((int)L.hout);
 		k2a_pk hin = __builtin_amdgcn_alignbit(L.hout, rh, 16);                                   /* { lane above's high half, own low half } */
 		k2a_pk ein = __builtin_amdgcn_alignbit(L.eout, (k2a_pk)k2a_rot1<64>((int)L.eout), 16);
@@ -476,16 +490,16 @@ k2a_fill_solo_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 
 		const bool ninit = L.need_init(k);
 		if (__builtin_amdgcn_ballot_w64(ninit) != 0) {
-			const int bs = k2a_rot1<64>(L.base);
-			if (ninit) L.do_init(sc, bs);                      /* uses hu_prev = what arrived one step ago */
+			const int bs = k2a_rot1<64>(L.baseB);
+			if (ninit) L.do_init(sc, bs);                      /* uses hu_prev = what arrived one step ago; brings its first query group along */
 		}
 		const bool nhigh = L.need_init_high(k);
 		if (__builtin_amdgcn_ballot_w64(nhigh) != 0) {
-			if (nhigh) L.init_high(sc);
+			if (nhigh) L.start_high(sc);                       /* the high half's base: uses hd0 = what its low half handed over */
 		}
 		L.hu_prev = rh;
 		hin = k2a_pk_add(hin, L.delta); ein = k2a_pk_add(ein, L.delta); if (DUAL) e2in = k2a_pk_add(e2in, L.delta);
-		const uint32_t qnext = L.next_query_codes(k);
+		L.advance_query(k & 3);
 		if (k <= ktop) L.top_inputs(sc, k, hin, ein, e2in);
 
 		uint32_t tw[Lane::TBWORDS];
@@ -510,10 +524,11 @@ k2a_fill_solo_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 			if (__builtin_amdgcn_ballot_w64(slow) != 0) {
 				if (slow) { L.stage_rows(stage[wave]); L.do_fin_seq(sc, bk, pr.zdrop, stage[wave]); }
 				__builtin_amdgcn_wave_barrier();
-				if (bk->dropped) break;
+				if (bk->dropped) { stop = true; break; }
 			}
 		}
-		L.qb = qnext;
+	}
+	L.qw = qp;
 	}
 	if (STAGED) ST.finish(kdone);
 	__builtin_amdgcn_wave_barrier();
@@ -715,8 +730,8 @@ static const trace_fn g_trace[K2A_NCFG][2] = { TRACE_ROW(16, 8, false), TRACE_RO
                                                TRACE_ROW(64, 32, false), TRACE_ROW(64, 16, true) };
 
 static const fill_fn g_fill_solo[2][3] = {
-	{ k2a_fill_solo_kernel<K2A_SOLO_C, false, 0>, k2a_fill_solo_kernel<K2A_SOLO_C, false, 1>, k2a_fill_solo_kernel<K2A_SOLO_C, false, 2> },
-	{ k2a_fill_solo_kernel<K2A_SOLO_C, true, 0>,  k2a_fill_solo_kernel<K2A_SOLO_C, true, 1>,  k2a_fill_solo_kernel<K2A_SOLO_C, true, 2> } };
+	{ k2a_fill_solo_kernel<K2A_SOLO_CS, false, 0>, k2a_fill_solo_kernel<K2A_SOLO_C, false, 1>, k2a_fill_solo_kernel<K2A_SOLO_C, false, 2> },
+	{ k2a_fill_solo_kernel<K2A_SOLO_CS, true, 0>,  k2a_fill_solo_kernel<K2A_SOLO_C, true, 1>,  k2a_fill_solo_kernel<K2A_SOLO_C, true, 2> } };
 
 /* packed walk: thread t = alignment (t & 1) of task (t >> 1) */
 template<int G, int C, bool DUAL, bool MP = false>

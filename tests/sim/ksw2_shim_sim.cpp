@@ -167,7 +167,7 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 					hin[lane] = k2a_pk_add(hin[lane], L[lane].delta); ein[lane] = k2a_pk_add(ein[lane], L[lane].delta);
 					if (DUAL) e2in[lane] = k2a_pk_add(e2in[lane], L[lane].delta);
 				}
-				if ((k & 3) == 3) L[lane].load_query_group(k + 1, k + 1 == L[lane].knext ? L[lane].koff_next : L[lane].koff, qpa[lane], qpb[lane]);
+				if ((k & 3) == 0) L[lane].load_query_group(k + 4, L[lane].knext <= k + 4 ? L[lane].koff_next : L[lane].koff, qpa[lane], qpb[lane]);
 				L[lane].qb = Lane::query_pick(L[lane].qwA, L[lane].qwB, k & 3);
 				if (k <= ktop) L[lane].top_inputs(sc, k, hin[lane], ein[lane], e2in[lane]);
 			}
@@ -799,25 +799,26 @@ static void sim_fill_solo(const K2aScoring sc, const K2aPair *pairs, const uint3
 		const int ktop = k2a_min(pr.qlen - 1, k2a_min(C - 1, pr.tlen - 1) + pr.w);
 		const size_t tbsteps = k2a_solo_steps<C>(pr.qlen, pr.tlen, pr.w);
 		uint8_t *tbp = tb + pr.tb_off;
-		for (int l = 0; l < 64; ++l) L[l].qb = L[l].next_query_codes(-1);
+		uint32_t qp[64];
+		for (int l = 0; l < 64; ++l) { qp[l] = 0; L[l].load_query_group(0, L[l].knext == 0 ? L[l].koff_next : L[l].koff, L[l].qw); }
 		bool done = false;
 		for (int k = 0; k <= klast && !done; ++k) {
 			k2a_pk rh[64], re[64], re2[64];
 			int rb[64];
 			for (int l = 0; l < 64; ++l) {
 				const int src = (l + 63) & 63;
-				rh[l] = L[src].hout; re[l] = L[src].eout; re2[l] = L[src].e2out; rb[l] = L[src].base;
+				rh[l] = L[src].hout; re[l] = L[src].eout; re2[l] = L[src].e2out; rb[l] = L[src].baseB;
 			}
 			k2a_pk oh[64], oe[64], oe2[64];
 			for (int l = 0; l < 64; ++l) { oh[l] = L[l].hout; oe[l] = L[l].eout; oe2[l] = L[l].e2out; }
-			uint32_t qnext[64];
 			for (int l = 0; l < 64; ++l) {
 				if (L[l].need_init(k)) L[l].do_init(sc, rb[l]);
-				if (L[l].need_init_high(k)) L[l].init_high(sc);
+				if (L[l].need_init_high(k)) L[l].start_high(sc);
 				L[l].hu_prev = rh[l];
 				k2a_pk hin = (rh[l] >> 16) | (oh[l] << 16), ein = (re[l] >> 16) | (oe[l] << 16), e2in = DUAL ? (re2[l] >> 16) | (oe2[l] << 16) : 0u;
 				hin = k2a_pk_add(hin, L[l].delta); ein = k2a_pk_add(ein, L[l].delta); if (DUAL) e2in = k2a_pk_add(e2in, L[l].delta);
-				qnext[l] = L[l].next_query_codes(k);
+				if ((k & 3) == 0) L[l].load_query_group(k + 4, L[l].knext <= k + 4 ? L[l].koff_next : L[l].koff, qp[l]);
+				L[l].advance_query(k & 3);
 				if (k <= ktop) L[l].top_inputs(sc, k, hin, ein, e2in);
 				uint32_t tw[Lane::TBWORDS];
 				const bool live = L[l].step(sc, k, hin, ein, e2in, tw);
@@ -830,7 +831,7 @@ static void sim_fill_solo(const K2aScoring sc, const K2aPair *pairs, const uint3
 				if (!L[l].fin_fast(sc, &book, pr.zdrop)) { L[l].stage_rows(rowbuf); L[l].do_fin_seq(sc, &book, pr.zdrop, rowbuf); }
 				if (book.dropped) done = true;
 			}
-			for (int l = 0; l < 64; ++l) L[l].qb = qnext[l];
+			if ((k & 3) == 3) for (int l = 0; l < 64; ++l) L[l].qw = qp[l];
 		}
 		k2a_finish(pr, book, &res[pi]);
 	}
@@ -1130,8 +1131,8 @@ int k2a_shim_launch_fill_solo(int dual, int mode, const K2aScoring *sc, const K2
                               const uint8_t *seq, uint8_t *tb, K2aResult *res, void *)
 {
 	typedef void (*fn_t)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*);
-	static const fn_t fn[2][3] = { { sim_fill_solo<K2A_SOLO_C, false, 0>, sim_fill_solo<K2A_SOLO_C, false, 1>, sim_fill_solo<K2A_SOLO_C, false, 2> },
-	                               { sim_fill_solo<K2A_SOLO_C, true, 0>, sim_fill_solo<K2A_SOLO_C, true, 1>, sim_fill_solo<K2A_SOLO_C, true, 2> } };
+	static const fn_t fn[2][3] = { { sim_fill_solo<K2A_SOLO_CS, false, 0>, sim_fill_solo<K2A_SOLO_C, false, 1>, sim_fill_solo<K2A_SOLO_C, false, 2> },
+	                               { sim_fill_solo<K2A_SOLO_CS, true, 0>, sim_fill_solo<K2A_SOLO_C, true, 1>, sim_fill_solo<K2A_SOLO_C, true, 2> } };
 	if (ntasks > 0) fn[dual ? 1 : 0][mode](*sc, pairs, order, ntasks, seq, tb, res);
 	return 0;
 }
