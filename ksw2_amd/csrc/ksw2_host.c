@@ -601,8 +601,8 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	sort_t *srt = 0;
 	pkinfo_t pkinfo[2];
 	uint8_t *pk_ok = 0, *solo_ok = 0;
-	/* KSW2AMD_SOLO: unset = alignments without a partner of identical shape take the solo kernel when there are enough of them
-	 * to keep four wavefronts on every SIMD, 1 = always, all = every eligible alignment (tests), 0 = never */
+	/* KSW2AMD_SOLO: unset = alignments without a partner of identical shape take the solo kernel, and so do classes of so few long
+	 * reads that each can have a SIMD of its own; 1 = only the former, all = every eligible alignment (tests), 0 = never */
 	const char *solo_env = ENV(SOLO);
 	const int solo_mode = !solo_env ? 3 : !strcmp(solo_env, "0") ? 0 : !strcmp(solo_env, "all") ? 2 : 1;
 	const int use_pk = !ENV(NO_PK), use_rb = !ENV(NO_RB);
@@ -796,13 +796,15 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 		}
 	}
 
-	/* A packed launch has half the wavefronts of the int32 launch of the same pairs.  When that leaves SIMDs without a
-	 * wavefront (a few hundred long reads), the wider int32 launch finishes earlier: measured on MI355X, 1024 pairs of
-	 * 10k x 10k, w = 500: 512 packed wavefronts 11.5 ms, 1024 int32 wavefronts 8.8 ms (round 2).  Round 3's packed kernels are
-	 * faster than the int32 ones wavefront for wavefront (the same 512 packed wavefronts from registers: 8.05 ms, int32 8.58 ms;
-	 * profiles/r3_small_launch_ab.txt), so half a wavefront per SIMD now stays packed; below 0.4 wavefronts per SIMD the packed
-	 * candidates of a one-alignment-per-wavefront class go back to the int32 kernels, whose twice as many wavefronts still reach
-	 * SIMDs the packed launch leaves empty (KSW2AMD_SIMDS overrides the device's SIMD count, 0 = off). */
+	/* Few long reads.  A packed launch has half the wavefronts of a launch with one read per wavefront, and a wavefront alone on
+	 * its SIMD runs at little more than half the SIMD's rate (it cannot issue faster than one instruction per ~6 cycles and nobody
+	 * covers its waits: profiles/r3_single_wave_issue.txt, r3_solo_experiments.txt).  So a one-alignment-per-wavefront class of at
+	 * most as many reads as the device has SIMDs goes to the solo kernel, read by read: every read gets a SIMD of its own and both
+	 * register halves (MI355X, 10 k x 10 k, w = 500, profiles/r3_solo_crossover.txt: 1 024 reads score only 6.2 ms solo, 7.6 ms in
+	 * pairs, 8.5 ms int32; with CIGAR 15.4 / 17.8 / 17.4 ms; dual gap with CIGAR 19.3 / 24.5 / 25.4 ms; from 1 536 reads on pairs
+	 * win, 17.2 against 21.2 ms).  What cannot go there (approximate modes, a window the solo halves cannot hold, flat plans whose
+	 * bytes the host has not seen) falls back to the int32 kernels below 0.4 packed wavefronts per SIMD as before (round 2: 512
+	 * packed wavefronts 11.5 ms, 1 024 int32 wavefronts 8.8 ms).  KSW2AMD_SIMDS overrides the device's SIMD count, 0 = both off. */
 	{
 		const char *ev = ENV(SIMDS);
 		const int simds = ev ? atoi(ev) : k2a_shim_simd_count();
@@ -816,23 +818,19 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 					const int64_t waves = ((int64_t)(cnt[b] + 1) / 2 * G + 63) / 64 * (pcb == K2A_PKCFG_MP ? 4 : 1);     /* that class: four wavefronts per task */
 					/* one-alignment-per-wavefront classes only: for the short shapes of the multi-group geometries the gain is a
 					 * fraction of a millisecond per call and costs 2-3 x the SIMD time, which concurrent callers would rather keep */
-					cnt[b] = G == 64 && waves * 10 < (int64_t)simds * 4;        /* 1 = demote */
+					cnt[b] = G != 64 ? 0 : (solo_mode == 3 && pcb != K2A_PKCFG_MP && cnt[b] <= simds ? 2 : 0) | (waves * 10 < (int64_t)simds * 4 ? 1 : 0);   /* 2 = solo, 1 = int32 */
 				}
-			for (i = 0; i < n; ++i) if (p->h_cls[i] >= 0 && pk_ok[i] && pk_ok[i] != PASS_SOLO && cnt[p->h_cls[i] * NPASS + pk_ok[i]]) pk_ok[i] = 0;
+			for (i = 0; i < n; ++i)
+				if (p->h_cls[i] >= 0 && pk_ok[i] && pk_ok[i] != PASS_SOLO) {
+					const int what = cnt[p->h_cls[i] * NPASS + pk_ok[i]];
+					if ((what & 2) && solo_ok[i] && !(flat && (flat->on_device || pair_has_wild(&pairs[i])))) pk_ok[i] = PASS_SOLO;
+					else if (what & 1) pk_ok[i] = 0;
+				}
 		}
 	}
-
-	/* The solo kernel has fewer instructions per cell than the int32 kernel but most of them at half the issue rate; it is
-	 * ahead only with enough wavefronts per SIMD to hide that (tools/scripts/ragged_probe.py, 10 k reads of unique lengths,
-	 * score only: 2048 reads 1212 vs 1422 GCUPS, 6144 reads 2077 vs 1822).  Below four per SIMD they go back to int32. */
-	if (solo_mode == 3) {
-		const char *ev = ENV(SIMDS);
-		const int simds = ev ? atoi(ev) : k2a_shim_simd_count();
-		int cnt[NCLS_MAX];
-		memset(cnt, 0, sizeof(cnt));
-		for (i = 0; i < n; ++i) if (p->h_cls[i] >= 0 && pk_ok[i] == PASS_SOLO) ++cnt[p->h_cls[i]];
-		for (i = 0; i < n; ++i) if (p->h_cls[i] >= 0 && pk_ok[i] == PASS_SOLO && (simds <= 0 || cnt[p->h_cls[i]] < 4 * simds)) pk_ok[i] = 0;
-	}
+	/* (Reads without a partner of their shape take the solo kernel whatever their number: with round 3's kernel it is ahead of the
+	 * int32 kernels and of pairing a read with itself at every batch size -- unique 8-12 k reads, 256 to 8 192 of them: score only
+	 * 1.3-1.4 x int32, dual gap with CIGAR 1.4-2.1 x, r3_solo_crossover.txt.  Round 2 sent them back below four per SIMD.) */
 
 	if (tlev) tph[3] = now_ms();
 	/* the sequence arena goes up while the host sorts out the task lists (pinned staging: the copy is asynchronous) */

@@ -363,16 +363,21 @@ def test_packed_rebased_long_reads(lib, dual):
     assert npk > ntot // 2
 
 
-def test_small_packed_class_goes_back_to_int32(lib, monkeypatch):
-    """Fewer packed wavefronts than 0.6 per SIMD: the class runs on the int32 kernels instead; same results."""
+def test_small_packed_class_leaves_the_pair_kernels(lib, monkeypatch):
+    """A one-alignment-per-wavefront class of fewer reads than the device has SIMDs: every read to the solo kernel (a SIMD
+    of its own); what the solo kernel cannot take (approximate mode here) goes back to the int32 kernels below 0.4 packed
+    wavefronts per SIMD.  Same results either way."""
     n = 64
     q, t = synth.fixed_batch(2, n, 1500, 1500, sub=0.05, ind=0.06, stream=3)
     mat = synth.simple_mat(5, 2, 4, -1)
-    b = lib.make_batch(q, t, mat, 4, 2, 24, 1, w=200, zdrop=-1, flag=po.SCORE_ONLY)        # (64,8): one packed pair per wavefront
-    p = b.plan(False); assert p.packed_pairs() == n; p.run(); r1 = p.fetch_raw().copy(); p.close()
-    monkeypatch.delenv("KSW2AMD_SIMDS")
-    p = b.plan(False); assert p.packed_pairs() == 0; p.run(); r0 = p.fetch_raw().copy(); p.close()
-    assert (r0 == r1).all()
+    for flag, kernel in ((po.SCORE_ONLY, "solo"), (po.SCORE_ONLY | po.APPROX_MAX, "int32")):
+        monkeypatch.setenv("KSW2AMD_SIMDS", "0")
+        b = lib.make_batch(q, t, mat, 4, 2, 24, 1, w=200, zdrop=-1, flag=flag)                   # (64,8): one packed pair per wavefront
+        p = b.plan(False); assert p.packed_pairs() == n and p.describe()[0]["kernel"] == "pk"; p.run(); r1 = p.fetch_raw().copy(); p.close()
+        monkeypatch.delenv("KSW2AMD_SIMDS")
+        p = b.plan(False); assert [d["kernel"] for d in p.describe()] == [kernel]; p.run(); r0 = p.fetch_raw().copy(); p.close()
+        if flag & po.APPROX_MAX: assert (r0[:, 8] == r1[:, 8]).all()      # only the score exists in this mode (include/ksw2_amd.h)
+        else: assert (r0 == r1).all()
 
 
 def test_wide_alphabets(lib):
@@ -788,7 +793,8 @@ def test_headline_kernel_at_scale_unforced(lib, monkeypatch):
 
 def test_automatic_kernel_choices_at_scale(lib, monkeypatch):
     """The host's and launcher's own choices, which need thousands of wavefronts to trigger: unique-shape long reads go to the
-    solo kernel (>= 4 wavefronts per SIMD), a big two-piece traceback class takes the LDS row form (>= 1.5 per SIMD).
+    solo kernel, a big two-piece traceback class takes the LDS row form (>= 1.5 per SIMD), a same-shape class of fewer reads
+    than the device has SIMDs goes to the solo kernel too.
     A sample of each batch against the oracle."""
     monkeypatch.delenv("KSW2AMD_SIMDS", raising=False)          # the occupancy rules as in production
     rng = np.random.Generator(np.random.PCG64(4242))
@@ -804,6 +810,22 @@ def test_automatic_kernel_choices_at_scale(lib, monkeypatch):
     qs, ts = synth.fixed_batch(903, n, 2000, 1990, sub=0.05, ind=0.1, tail_random_frac=0.3, tail_pairs=0.3)
     zd = rng.choice([-1, 400, 2000], size=n)
     check_batch(lib, True, qs, ts, mat, q, e, q2, e2, w=330, zdrop=zd, flag=0, sample=list(range(0, n, 97)))
+    # a few hundred same-shape long reads: every read a wavefront (and a SIMD) of its own instead of two per wavefront
+    n = 600
+    qs, ts = synth.fixed_batch(904, n, 4000, 3990, sub=0.05, ind=0.08, tail_random_frac=0.3, tail_pairs=0.2)
+    for dual, flag in ((False, po.SCORE_ONLY), (True, 0)):
+        b = lib.make_batch(qs, ts, mat, q, e, q2, e2, w=400, zdrop=400, flag=flag)
+        p = b.plan(dual)
+        d = p.describe()
+        assert len(d) == 1 and d[0]["kernel"] == "solo" and d[0]["tasks"] == n, d
+        p.run(); r1 = p.fetch_raw().copy(); p.close()
+        monkeypatch.setenv("KSW2AMD_SOLO", "0")
+        p = b.plan(dual)
+        assert p.describe()[0]["kernel"] != "solo"
+        p.run(); r0 = p.fetch_raw().copy(); p.close()
+        monkeypatch.delenv("KSW2AMD_SOLO")
+        assert np.array_equal(r0[:, :11], r1[:, :11])
+        check_batch(lib, dual, qs, ts, mat, q, e, q2, e2, w=400, zdrop=400, flag=flag, sample=list(range(0, n, 41)))
 
 
 def test_pairs_share_the_true_target_length(lib):
