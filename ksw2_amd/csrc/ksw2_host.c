@@ -56,6 +56,7 @@ static void release_thread_cache(void);
 	X(DEFER) \
 	X(EXTF_HBM) \
 	X(EXTF_LANE) \
+	X(EXTF_RING) \
 	X(EXTF_LDS) \
 	X(EXTF_WIN) \
 	X(EXTS_BIG) \
@@ -1169,6 +1170,17 @@ int ksw2amd_plan_describe(const ksw2amd_plan_t *p, char *buf, int cap)
 	int c, len = 0;
 	if (!p || !buf || cap <= 0) return 0;
 	buf[0] = 0;
+	if (p->splice == 2 && !p->reject_all) {          /* ksw_extf2_sse plans: one line per kernel class in use */
+		static const char *const fkind[7] = { "extf-lds", "extf-lds", "extf-lds", "extf-hbm", "extf-win4", "extf-win8", "extf-lane" };
+		int nl = 0;
+		for (c = 0; c < 7 && len < cap - 1; ++c)
+			if (p->f_count[c]) {
+				len += snprintf(buf + len, (size_t)(cap - len), "kernel=%s form=%s ring=%d tasks=%d\n", fkind[c], c == 6 && p->f_par.ring ? "ldsring" : c == 6 ? "hbm" : "-",
+				                c == 6 ? p->f_par.ring : 0, p->f_count[c]);
+				++nl;
+			}
+		return nl;
+	}
 	if (p->splice || p->reject_all) return 0;
 	for (c = 0; c < p->ncls && len < cap - 1; ++c) {
 		const cls_t *k = &p->cls[c];
@@ -2664,6 +2676,23 @@ ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n
 			p->tb_bytes += 3 * trows * 256;
 		}
 		p->f_state_bytes = p->tb_bytes;                       /* (class 3 blocks, if any, were laid out before: none when this class is on) */
+		/* the state arrays as LDS rings where every lane's band fits one (k2a_extf_lane_ring_kernel; KSW2AMD_EXTF_RING=0: HBM scratch) */
+		{
+			int need = 0;
+			for (k = 0; k < nlane; ++k) {
+				const K2aPair *d = &p->h_pairs[srt[k].idx];
+				need = imax(need, K2A_EXTF_RING_ROWS(imin(imin(d->qlen, d->tlen) - 1, d->w)));
+			}
+			/* 3 x rows x 256 bytes of LDS per wavefront: at most 64 rows (48 KB).  Measured (tools/scripts/extf_lane_probe.py,
+			 * profiles/r3_extf_lane_ring.txt): the rings win while the launch has few wavefronts per SIMD (65 536 x 1 000^2, band 100:
+			 * 382 against 300 GCUPS; band 30: 312 against 272), the HBM form with its four and more wavefronts per SIMD wins on big
+			 * launches (262 144 x 1 000^2: 601 against 343) -- the lane's loop is serial and wants the wavefronts more than the
+			 * bandwidth.  Unset: rings up to 1.5 wavefronts per SIMD; 1 = wherever they fit, 0 = never. */
+			need = (need + 3) & ~3;
+			if (need < 16) need = 16;
+			p->f_par.ring = need > 64 ? 0 : ENV(EXTF_RING) ? (atoi(ENV(EXTF_RING)) ? need : 0)
+			              : (k2a_shim_simd_count() > 0 && (int64_t)(nlane + 63) / 64 * 2 <= 3 * (int64_t)k2a_shim_simd_count() ? need : 0);
+		}
 	}
 	p->ntasks = p->norder = i;
 	if (p->ntasks == 0) return p;

@@ -102,27 +102,36 @@ K2A_FN void k2a_extf_win_cell(const K2aExtf &par, const K2aExtfDiag &d, int r, i
  * (2.7 wavefront instructions per cell in the position-per-lane kernels above, 0.4 here); it needs >= 64 extensions per
  * wavefront, so the host takes it for large batches (ksw2_host.c). */
 struct K2aExtfLaneMem {
-	uint32_t *U4, *V4, *S4;            /* state, this lane's column: index (x >> 2) * 64 */
+	uint32_t *U4, *V4, *S4;            /* state, this lane's column: index (x >> 2) * 64 -- or, as a ring, ((x >> 2) % ring) * 64 */
 	const uint32_t *TT, *QR;           /* target codes by position, reversed query by k: same layout, zero past the ends */
+	int ring, ztop;                    /* ring: rows of the LDS ring (0: whole arrays in HBM scratch, zeroed by the host side);
+	                                    * ztop: first row the ring has not handed out yet -- a row entering the window is zeroed
+	                                    * first, like the reference's freshly allocated arrays (its slot held row - ring) */
+	K2A_FN size_t row(int x4) const { return (size_t)(ring ? x4 % ring : x4) * 64; }
 };
 K2A_FN uint32_t k2a_funnel(uint32_t lo, uint32_t hi, int bytes) { return bytes == 0 ? lo : (lo >> (8 * bytes)) | (hi << (32 - 8 * bytes)); }
 
 /* anti-diagonal r of one lane's pair; false = the lane stops (band left the matrix or X-drop) */
-K2A_FN bool k2a_extf_lane_diag(const K2aExtf &par, int qlen, int tlen, int w, int tpad, int xdrop, int r, const K2aExtfLaneMem &m,
+K2A_FN bool k2a_extf_lane_diag(const K2aExtf &par, int qlen, int tlen, int w, int tpad, int xdrop, int r, K2aExtfLaneMem &m,
                                int &prev_lo, int &prev_hi, K2aExtfBook &bk)
 {
 	K2aExtfDiag d;
 	if (!k2a_extf_diag(r, qlen, tlen, w, tpad, d)) return false;
+	if (m.ring) {                                                  /* rows entering the window: up to the followed cell's neighbour */
+		const int top = k2a_max(k2a_max(d.bhi, d.fresh_end - 1), bk.follow + 1) >> 2;
+		for (; m.ztop <= top; ++m.ztop) { const size_t z = m.row(m.ztop); m.U4[z] = 0u; m.V4[z] = 0u; m.S4[z] = 0u; }
+	}
 	const uint32_t two_e = (uint32_t)(par.e * 2) & 0xffu, mch = (uint32_t)par.mch & 0xffu, mis = (uint32_t)par.mis & 0xffu;
 	const bool top0 = d.bhi >= r;                                  /* ksw2_extf2_sse.c:46 */
 	const int last = k2a_max(d.bhi, d.fresh_end - 1), k0 = qlen - 1 - r;
 	uint32_t carry = 0;                                            /* V of position blo - 1 on the previous anti-diagonal (:45) */
-	if (d.blo > 0 && d.blo - 1 >= prev_lo && d.blo - 1 <= prev_hi) carry = (m.V4[(size_t)((d.blo - 1) >> 2) * 64] >> (8 * ((d.blo - 1) & 3))) & 0xffu;
-	for (int x4 = d.blo >> 2; x4 <= last >> 2; ++x4) {
+	if (d.blo > 0 && d.blo - 1 >= prev_lo && d.blo - 1 <= prev_hi) carry = (m.V4[m.row((d.blo - 1) >> 2)] >> (8 * ((d.blo - 1) & 3))) & 0xffu;
+	int slot = m.ring ? (d.blo >> 2) % m.ring : d.blo >> 2;        /* the ring index by increments: one modulo per anti-diagonal */
+	for (int x4 = d.blo >> 2; x4 <= last >> 2; ++x4, slot = (m.ring && slot + 1 == m.ring) ? 0 : slot + 1) {
 		const int x0 = x4 << 2;
-		const size_t row = (size_t)x4 * 64;
+		const size_t row = (size_t)slot * 64;
 		uint32_t u4 = m.U4[row], v4 = m.V4[row], s4 = m.S4[row];
-		const uint32_t t4 = m.TT[row];
+		const uint32_t t4 = m.TT[(size_t)x4 * 64];
 		/* QR[k0 + x0 .. +3]; k0 + x0 < 0 only where the dword starts below lo: positions of it at or above lo read QR[0..] */
 		const int k = k0 + x0, kc = k2a_max(k, 0);
 		uint32_t q4 = k2a_funnel(m.QR[(size_t)(kc >> 2) * 64], m.QR[(size_t)((kc >> 2) + 1) * 64], kc & 3);
@@ -146,8 +155,8 @@ K2A_FN bool k2a_extf_lane_diag(const K2aExtf &par, int qlen, int tlen, int w, in
 	}
 	/* the followed cell reads the updated bytes (it may sit one position below lo: not touched on this anti-diagonal) */
 	const int f0 = bk.follow, f1 = bk.follow + 1;
-	const uint32_t vf = r == 0 ? (m.V4[0] & 0xffu) : (m.V4[(size_t)(f0 >> 2) * 64] >> (8 * (f0 & 3))) & 0xffu;
-	const uint32_t un = r == 0 ? 0u : (m.U4[(size_t)(f1 >> 2) * 64] >> (8 * (f1 & 3))) & 0xffu;
+	const uint32_t vf = r == 0 ? (m.V4[0] & 0xffu) : (m.V4[m.row(f0 >> 2)] >> (8 * (f0 & 3))) & 0xffu;
+	const uint32_t un = r == 0 ? 0u : (m.U4[m.row(f1 >> 2)] >> (8 * (f1 & 3))) & 0xffu;
 	if (!k2a_extf_follow(bk, d, r, par.e, xdrop, vf, un)) return false;
 	prev_lo = d.blo; prev_hi = d.bhi;
 	return true;

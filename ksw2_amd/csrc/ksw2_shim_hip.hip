@@ -824,14 +824,20 @@ k2a_fill_pkmp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 	uint4 cur = make_uint4(0, 0, 0, 0), nxt = cur;
 	uint32_t cur2 = 0, nxt2 = 0;
 	int bs0A = 0, bs0B = 0;                           /* bases of column jlo - 1 (the first cell's diagonal input) */
-	auto fetch = [&](int j, uint4 &v, uint32_t &v2) {
-		v = make_uint4(neg, neg, 0, 0); v2 = neg;     /* past what the generation above wrote: outside the band */
-		if (j <= je_prev) {
-			const uint32_t *e = (const uint32_t*)&B1[j];
-			v.x = __hip_atomic_load(&e[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v.y = __hip_atomic_load(&e[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			v.z = __hip_atomic_load(&e[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v.w = __hip_atomic_load(&e[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if (DUAL) v2 = __hip_atomic_load(&B2[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		}
+	/* The boundary entry of column j.  EVERY lane loads it, from the same (wave-uniform, clamped) address -- one request -- and in
+	 * every step, although only lane 0 of the generations > 0 uses it: a load under `if (feeder)` into a variable that lives around
+	 * the step loop is waited for right behind the load (hipcc's phi copy, ksw2_lane_pk.h: k2a_load_early), and that wait, an L2
+	 * round trip, stood in every step of every wavefront of config 4.  Unconditional, the entry is in flight for a whole step; whether
+	 * it is one the generation above wrote is decided when it is used (`take`). */
+	auto fetch_raw = [&](int j, uint4 &v, uint32_t &v2) {
+		const int jc = min(max(j, 0), qlen - 1);
+		const uint32_t *e = (const uint32_t*)&B1[jc];
+		v.x = __hip_atomic_load(&e[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v.y = __hip_atomic_load(&e[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		v.z = __hip_atomic_load(&e[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v.w = __hip_atomic_load(&e[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		v2 = DUAL ? __hip_atomic_load(&B2[jc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+	};
+	auto take = [&](int j, uint4 &v, uint32_t &v2) {        /* past what the generation above wrote: outside the band */
+		if (j > je_prev || j < 0) { v = make_uint4(neg, neg, 0, 0); v2 = neg; }
 	};
 
 	for (int phase = 0; phase < total_phases; ++phase) {
@@ -845,14 +851,15 @@ k2a_fill_pkmp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 				feeder = lane == 0 && g > 0;
 				drain = lane == G - 1 && g + 1 < ngen;
 				je_prev = g > 0 ? min(qlen - 1, g * R - 1 + w) : -1;          /* last column the generation above wrote */
-				if (feeder) {
+				if (g > 0) {
 					if (jlo > 0) {                                            /* H(i0 - 1, jlo - 1): the diagonal input of the first cell */
 						uint4 pv; uint32_t pv2;
-						fetch(jlo - 1, pv, pv2);
-						L.P.hu_prev = pv.x; bs0A = (int)pv.z; bs0B = (int)pv.w;
+						fetch_raw(jlo - 1, pv, pv2);
+						take(jlo - 1, pv, pv2);
+						if (feeder) { L.P.hu_prev = pv.x; bs0A = (int)pv.z; bs0B = (int)pv.w; }
 					}
-					fetch(jlo, cur, cur2);
-					fetch(jlo + 1, nxt, nxt2);
+					fetch_raw(jlo, cur, cur2);
+					fetch_raw(jlo + 1, nxt, nxt2);
 				}
 				L.P.qb = L.P.next_query_codes(-1);
 				kdone = -1;
@@ -872,11 +879,12 @@ k2a_fill_pkmp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 					L.refresh_delta(bsA, bsB);                           /* a base changed: every lane re-reads its neighbour's */
 				}
 				if (feeder) {
+					take(jlo + k, cur, cur2);
 					hin = cur.x; ein = cur.y; e2in = cur2;
 					L.refresh_delta((int)cur.z, (int)cur.w);             /* every entry carries the bases it is relative to */
-					cur = nxt; cur2 = nxt2;
-					fetch(jlo + k + 2, nxt, nxt2);
 				}
+				cur = nxt; cur2 = nxt2;
+				fetch_raw(jlo + k + 2, nxt, nxt2);                       /* every lane: see fetch_raw */
 				L.P.hu_prev = hin;
 				hin = L.adopt(hin); ein = L.adopt(ein);
 				if (DUAL) e2in = L.adopt(e2in);
@@ -1398,6 +1406,41 @@ k2a_extf_lane_kernel(const K2aExtf par, const K2aPair *__restrict__ pairs, const
 	K2aExtfLaneMem m;
 	m.U4 = (uint32_t*)(scratch + pr.tb_off) + lane; m.V4 = m.U4 + rows; m.S4 = m.V4 + rows;
 	m.TT = (const uint32_t*)(seq + pr.toff) + lane; m.QR = (const uint32_t*)(seq + pr.qoff) + lane;
+	m.ring = 0; m.ztop = 0;
+	K2aExtfBook bk;
+	k2a_extf_book_reset(bk);
+	int prev_lo = -1, prev_hi = -1, r = 0;
+	const int nr = qlen + tlen - 1;
+	bool go = valid;
+	while (__builtin_amdgcn_ballot_w64(go && r < nr) != 0) {
+		if (go && r < nr) {
+			if (k2a_extf_lane_diag(par, qlen, tlen, w, tpad, xdrop, r, m, prev_lo, prev_hi, bk)) ++r;
+			else go = false;
+		}
+	}
+	if (valid) k2a_extf_finish(bk, r == nr, &res[pi]);
+}
+
+/* The same with the state arrays in LDS: a lane only ever touches the few dozen rows around its band (K2A_EXTF_RING_ROWS), so
+ * they live in a ring of par.ring rows per array -- 3 x ring x 256 bytes per wavefront, one wavefront per workgroup -- instead of
+ * whole arrays in HBM scratch, whose re-reading on every anti-diagonal was ~9 bytes of HBM traffic per cell (round 2:
+ * profiles/r2z_extf-lane_pmc.json, 488 GB per launch of 262 144 extensions).  Target codes and the reversed query still come from
+ * the interleaved blocks in global memory (read only). */
+__global__ void __launch_bounds__(64)
+k2a_extf_lane_ring_kernel(const K2aExtf par, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
+                          const uint8_t *__restrict__ seq, K2aResult *__restrict__ res)
+{
+	extern __shared__ uint32_t k2a_ring[];
+	const int lane = threadIdx.x & 63;
+	const int task = blockIdx.x * 64 + lane;
+	const bool valid = task < ntasks;
+	const uint32_t pi = order[valid ? task : 0];
+	const K2aPair pr = pairs[pi];
+	const int qlen = pr.qlen, tlen = pr.tlen, w = pr.w, xdrop = pr.zdrop, tpad = (tlen + 15) & ~15;
+	K2aExtfLaneMem m;
+	m.ring = par.ring; m.ztop = 0;
+	m.U4 = k2a_ring + lane; m.V4 = m.U4 + (size_t)par.ring * 64; m.S4 = m.V4 + (size_t)par.ring * 64;
+	m.TT = (const uint32_t*)(seq + pr.toff) + lane; m.QR = (const uint32_t*)(seq + pr.qoff) + lane;
 	K2aExtfBook bk;
 	k2a_extf_book_reset(bk);
 	int prev_lo = -1, prev_hi = -1, r = 0;
@@ -1825,6 +1868,12 @@ int k2a_shim_launch_extf(int cls, const K2aExtf *par, const K2aPair *pairs, cons
 	if (cls < 0 || cls > 6) { snprintf(g_err, sizeof(g_err), "bad kernel class"); return -1; }
 	if (cls == 6) {                                   /* one extension per lane: 64 tasks per wavefront */
 		const int waves = (ntasks + 63) / 64;
+		if (par->ring > 0) {
+			static int raised;
+			const size_t lds = (size_t)3 * par->ring * 256;
+			if (!raised && lds > 48 * 1024) { CHECK(hipFuncSetAttribute((const void*)k2a_extf_lane_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); raised = 1; }
+			hipLaunchKernelGGL(k2a_extf_lane_ring_kernel, dim3(waves), dim3(64), lds, (hipStream_t)stream, *par, pairs, order, ntasks, seq, res);
+		} else
 		hipLaunchKernelGGL(k2a_extf_lane_kernel, dim3((waves + K2A_WPB - 1) / K2A_WPB), dim3(64 * K2A_WPB), 0, (hipStream_t)stream, *par, pairs, order, ntasks, seq, scratch, res);
 	} else if (cls >= 4) {
 		const int blocks = (ntasks + K2A_WPB - 1) / K2A_WPB;

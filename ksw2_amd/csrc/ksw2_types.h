@@ -76,7 +76,12 @@ typedef struct K2aSplice {
 /* batch-uniform parameters of the gap-linear X-drop extension (ksw2_lane_extf.h), passed by value */
 typedef struct K2aExtf {
 	int32_t mch, mis, e;         /* mis <= 0 (ksw2_extf2_sse.c:20) */
+	int32_t ring;                /* one-extension-per-lane form: 0 = state arrays in HBM scratch, else rows (dwords per lane and array) of the LDS ring */
 } K2aExtf;
+/* rows of four positions a lane of the one-extension-per-lane form touches on one anti-diagonal, at most: from the dword of
+ * position blo - 1 (the carry into the band, the followed cell) to the one of hi + 15 (the padded block, the S refresh), with
+ * hi - lo <= min(w, qlen, tlen) and blo >= lo - 15 (ksw2_lane_extf.h) */
+#define K2A_EXTF_RING_ROWS(span) (((span) + 30) / 4 + 3)
 
 /* batch-uniform parameters of the SSE-compatible mode (ksw2_lane_ssec.h), passed by value */
 typedef struct K2aSsec {

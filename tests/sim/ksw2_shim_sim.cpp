@@ -1039,6 +1039,12 @@ static void sim_extf_lane(const K2aExtf par, const K2aPair *pairs, const uint32_
 		K2aExtfLaneMem m;
 		m.U4 = (uint32_t*)(scratch + pr.tb_off) + lane; m.V4 = m.U4 + rows; m.S4 = m.V4 + rows;
 		m.TT = (const uint32_t*)(seq + pr.toff) + lane; m.QR = (const uint32_t*)(seq + pr.qoff) + lane;
+		m.ring = par.ring; m.ztop = 0;
+		std::vector<uint32_t> ringbuf;
+		if (par.ring) {                                     /* mirrors k2a_extf_lane_ring_kernel: the lane's three rings, filled with garbage first */
+			ringbuf.assign((size_t)3 * par.ring * 64, 0xdeadbeefu);
+			m.U4 = ringbuf.data(); m.V4 = m.U4 + (size_t)par.ring * 64; m.S4 = m.V4 + (size_t)par.ring * 64;
+		}
 		K2aExtfBook bk;
 		k2a_extf_book_reset(bk);
 		int prev_lo = -1, prev_hi = -1, r = 0;

@@ -1023,14 +1023,11 @@ def test_linear_xdrop_one_extension_per_lane(lib, monkeypatch):
     """k2a_extf_lane_kernel on the GPU: all 2000 reference cases of ksw_extf2_sse in batches of mixed shapes (groups of 64 with very
     different lengths and bands: divergent lanes), a same-shape batch large enough to fill a few wavefronts per SIMD, and the host's
     own choice of the form on a big narrow-band batch."""
+    from tests.test_sim_parity import _check_extf_lane_forms
     monkeypatch.setenv("KSW2AMD_EXTF_LANE", "1")
     fc = gu.ExtfCases()
     cases = [fc.case(k) for k in range(fc.n)]
-    for sc in sorted({(c["mch"], c["mis"], c["e"]) for c in cases}):
-        sub = [c for c in cases if (c["mch"], c["mis"], c["e"]) == sc]
-        res = lib.extf_batch([c["q"] for c in sub], [c["t"] for c in sub], *sc, w=[c["w"] for c in sub], xdrop=[c["xdrop"] for c in sub])
-        for r, c in zip(res, sub):
-            assert not diff(r, c["expect"], gu.FIELDS), (sc, len(c["q"]), len(c["t"]), c["w"], c["xdrop"])
+    _check_extf_lane_forms(lib, cases, monkeypatch)          # LDS rings of 32 / 48 / 64 rows and the HBM-scratch form, by plan diagnostics
     monkeypatch.delenv("KSW2AMD_EXTF_LANE")
     q, t = synth.fast_fixed(8, 200000, 200, 200, sub=0.05, ind=0.02)
     res = lib.extf_batch(list(q), list(t), 2, -4, 2, w=20, xdrop=40)          # 200 000 extensions, 21 positions in the band: the lane form by itself

@@ -714,17 +714,49 @@ def test_sim_packed_generation_serial(sim, monkeypatch):
     p.close()
 
 
+def _extf_ring_rows(c):
+    """K2A_EXTF_RING_ROWS (ksw2_types.h) of a case: rows of four positions around the band"""
+    w = c["w"] if c["w"] >= 0 else max(len(c["q"]), len(c["t"]))
+    return (min(min(len(c["q"]), len(c["t"])) - 1, w) + 30) // 4 + 3
+
+
+def _check_extf_lane_forms(lib, cases, monkeypatch):
+    """Every reference case through the lane form, per scoring: the narrow-band cases as batches that fit LDS rings of up to 20, 32,
+    48 and 64 rows (plan diagnostics say which form ran and with how many rows), everything again with the state arrays in HBM
+    scratch (KSW2AMD_EXTF_RING=0)."""
+    seen = set()
+    for sc in sorted({(c["mch"], c["mis"], c["e"]) for c in cases}):
+        sub = [c for c in cases if (c["mch"], c["mis"], c["e"]) == sc and len(c["q"]) and len(c["t"])]
+        def rows_of(part):
+            return max(16, (max(_extf_ring_rows(c) for c in part) + 3) & ~3)
+        parts = [[c for c in sub if _extf_ring_rows(c) <= 20], [c for c in sub if 20 < _extf_ring_rows(c) <= 32], [c for c in sub if 32 < _extf_ring_rows(c) <= 48],
+                 [c for c in sub if 48 < _extf_ring_rows(c) <= 64]]
+        parts = [("ldsring", rows_of(x), x) for x in parts if x] + [("hbm", 0, [c for c in sub if _extf_ring_rows(c) > 64]), ("hbm", 0, sub)]
+        for form, ring, part in parts:
+            if not part:
+                continue
+            monkeypatch.setenv("KSW2AMD_EXTF_RING", "0" if form == "hbm" and part is sub else "1")
+            b = lib.make_linear_batch([c["q"] for c in part], [c["t"] for c in part], *sc, w=[c["w"] for c in part], xdrop=[c["xdrop"] for c in part])
+            p = b.plan()
+            d = p.describe()
+            assert len(d) == 1 and d[0]["kernel"] == "extf-lane" and d[0]["form"] == form and d[0]["ring"] == ring, (d, form, ring)
+            p.run()
+            res = p.fetch()
+            p.close()
+            monkeypatch.delenv("KSW2AMD_EXTF_RING", raising=False)
+            seen.add((form, ring))
+            for r, c in zip(res, part):
+                assert not diff(r, c["expect"], gu.FIELDS), (sc, form, ring, len(c["q"]), len(c["t"]), c["w"], c["xdrop"])
+    assert ("hbm", 0) in seen and len({r for f, r in seen if f == "ldsring"}) >= 3, seen
+
+
 def test_sim_linear_xdrop_one_extension_per_lane(sim, monkeypatch):
     """The lane-per-extension form of ksw_extf2_sse (k2a_extf_lane_kernel: interleaved sequences and state, four positions per dword):
     every reference case in batches of mixed shapes, so groups of 64 hold very different lengths and bands."""
     monkeypatch.setenv("KSW2AMD_EXTF_LANE", "1")
     fc = gu.ExtfCases()
     cases = [fc.case(k) for k in range(fc.n)]
-    for sc in sorted({(c["mch"], c["mis"], c["e"]) for c in cases}):
-        sub = [c for c in cases if (c["mch"], c["mis"], c["e"]) == sc]
-        res = sim.extf_batch([c["q"] for c in sub], [c["t"] for c in sub], *sc, w=[c["w"] for c in sub], xdrop=[c["xdrop"] for c in sub])
-        for r, c in zip(res, sub):
-            assert not diff(r, c["expect"], gu.FIELDS), (sc, len(c["q"]), len(c["t"]), c["w"], c["xdrop"])
+    _check_extf_lane_forms(sim, cases, monkeypatch)
     e = np.zeros(0, np.uint8); one = np.array([2], np.uint8)
     res = sim.extf_batch([e, one, one, e], [e, e, one, one], 2, -4, 2, w=-1, xdrop=50)
     for r, (q, t) in zip(res, ((e, e), (one, e), (one, one), (e, one))):
