@@ -70,6 +70,7 @@ static void release_thread_cache(void);
 	X(NO_PK) \
 	X(NO_PKMP) \
 	X(NO_RB) \
+	X(NO_SHARED_UP) \
 	X(NO_UNITS) \
 	X(PK_FIRST) \
 	X(POOL_MIN) \
@@ -841,7 +842,14 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	}
 	p->d_seq = (uint8_t*)cache_get(BUF_SEQ, p->seq_bytes, &p->cap[BUF_SEQ]);
 	if (!p->d_seq) { fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error()); goto err; }
-	up = flat && !flat->on_device ? shared_upload_stream() : 0;
+	/* Big uploads go through ONE stream per device, whoever issues them: the chunks of a big batch are packed by several worker
+	 * threads at once, and six 80 MB copies on six streams share the link -- all of them arrive after 9-13 ms and the device idles
+	 * until then (KSW2AMD_TRACE=2 timeline of the 10 k headline); in one queue the first chunk's bytes are there 1.6 ms after its
+	 * packing ends and its kernel starts while the others still travel (pointer entry, MI355X: headline 4 024 -> 4 336 GCUPS end to
+	 * end, config 2 968 -> 1 165, 10 k with CIGAR 1 290 -> 1 321; config 3's 8 MB chunks and config 5 unchanged within noise).  Plans
+	 * under 16 MB (single calls, coalesced batches, small chunks) keep the calling thread's own stream and wait for it: an event per
+	 * call would only add latency there.  KSW2AMD_NO_SHARED_UP=1: the old behaviour, for A/B runs. */
+	up = (flat && !flat->on_device) || (!flat && p->seq_bytes >= ((size_t)16 << 20) && !ENV(NO_SHARED_UP)) ? shared_upload_stream() : 0;
 	if (up) shared_up = 1; else up = thread_upload_stream();
 	p->stream = up; p->stream_used = 1;              /* plan_destroy waits for it before the buffers are recycled */
 	if (flat) {
