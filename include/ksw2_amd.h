@@ -259,8 +259,10 @@ int64_t ksw2amd_plan_device_bytes(const ksw2amd_plan_t *plan);
 int64_t ksw2amd_plan_packed_pairs(const ksw2amd_plan_t *plan);
 /* diagnostics: one text line per kernel class the plan's next run launches --
  *   "kernel=pk G=64 C=16 gaps=1 mode=score rebased=1 nomax=0 generic=0 form=ldscodes tasks=1536"
- * (kernel: int32 / mp / pk / pkmp / solo; form: registers / ldsrows / ldscodes, the launch-time choice).  Returns
- * the number of classes; extz / extd plans only.  Tests use it to assert which kernel an unforced launch took. */
+ * (kernel: int32 / mp / pk / pkmp / solo; form: registers / ldsrows / ldscodes / defer, the launch-time choice);
+ * ksw_extf2_sse plans: "kernel=extf-lane form=ldsring ring=36 tasks=65536" (extf-lds / extf-hbm / extf-win4 / extf-win8 / extf-lane;
+ * form of the lane class: hbm / ldsring with its rows).  Returns the number of lines; extz / extd / extf plans.  Tests use it to
+ * assert which kernel an unforced launch took. */
 int ksw2amd_plan_describe(const ksw2amd_plan_t *plan, char *buf, int cap);
 /* The KSW2AMD_* environment switches (tuning, A/B runs, tests) are read once per process; this reads them again. */
 void ksw2amd_reload_env(void);
