@@ -169,6 +169,16 @@ int ksw2amd_set_devices(int n, const int *devices);
 typedef void (*ksw2amd_error_fn)(const char *func, int code, const char *msg, void *user);
 void ksw2amd_set_error_handler(ksw2amd_error_fn fn, void *user);
 long ksw2amd_error_count(void);        /* failed ksw2-named calls so far */
+
+/* Opt-in host path for tiny single calls (replaces nothing of the reference; its one-pair-per-call pattern is cli.c:50-132 /
+ * README.md:54-87).  A ksw2-named single-pair call costs a launch and two PCIe round trips here, ~0.5 ms whatever its size.  With
+ * cells > 0, every such call whose exact band has at most `cells` DP cells is computed on the calling thread by the library's own
+ * scalar code instead -- same result contract, bit for bit (tests/test_small_calls.py) -- and ksw2amd_small_call_count() counts
+ * them.  Default 0 = never (KSW2AMD_SMALL_CELLS sets the default).  Not a fallback: it is never taken because something failed,
+ * the batch entry points never use it, and the device is initialised by the first call all the same.  KSW_EZ_APPROX_MAX requests
+ * and the SSE-compatible mode always go to the device.  Measured crossover and rates: INTEGRATION.md. */
+void ksw2amd_set_small_call_cells(int64_t cells);
+long ksw2amd_small_call_count(void);
 /* diagnostics: { batches run on the worker pool, chunks they were cut into, single-pair calls that were coalesced with other
  * threads' calls, device batches those formed } since the library was loaded */
 void ksw2amd_host_stats(int64_t out[4]);

@@ -80,7 +80,8 @@ EXPORTS = ["ksw_extz2_sse", "ksw_extd2_sse", "ksw_gg2", "ksw_gg2_sse", "ksw_extz
            "ksw2amd_set_devices", "ksw2amd_set_error_handler", "ksw2amd_error_count", "ksw2amd_host_stats",
            "ksw2amd_set_sse_compat", "ksw2amd_sse_plan_create", "ksw2amd_plan_describe", "ksw2amd_reload_env",
            "ksw2amd_extz_batch_flat", "ksw2amd_extd_batch_flat", "ksw2amd_plan_create_flat", "ksw2amd_host_register", "ksw2amd_host_unregister",
-           "ksw2amd_device_alloc", "ksw2amd_device_free", "ksw2amd_device_upload", "ksw2amd_device_download", "ksw2amd_rerun_count"]
+           "ksw2amd_device_alloc", "ksw2amd_device_free", "ksw2amd_device_upload", "ksw2amd_device_download", "ksw2amd_rerun_count",
+           "ksw2amd_set_small_call_cells", "ksw2amd_small_call_count"]
 # entry points whose behaviour depends on KSW2AMD_* switches: the library reads its environment once per process, so this binding
 # re-reads it in front of each of them (tests and A/B scripts flip switches inside one process)
 _ENV_ENTRIES = ["ksw_extz2_sse", "ksw_extd2_sse", "ksw_gg2", "ksw_gg2_sse", "ksw_extz", "ksw_extd", "ksw_gg", "ksw_extz2_sse41",
@@ -196,6 +197,9 @@ class Library:
         L.ksw2amd_device_upload.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
         L.ksw2amd_device_download.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
         L.ksw2amd_rerun_count.restype = ctypes.c_int64
+        L.ksw2amd_set_small_call_cells.argtypes = [ctypes.c_int64]
+        L.ksw2amd_set_small_call_cells.restype = None
+        L.ksw2amd_small_call_count.restype = ctypes.c_long
         L.ksw2amd_reload_env.restype = None
         reload_env = L.ksw2amd_reload_env
 
@@ -251,6 +255,13 @@ class Library:
 
     def device_free(self, d):
         self.lib.ksw2amd_device_free(d)
+
+    def set_small_call_cells(self, cells):
+        """ksw2amd_set_small_call_cells: single calls of at most `cells` band cells run on the calling thread (0 = never, the default)."""
+        self.lib.ksw2amd_set_small_call_cells(int(cells))
+
+    def small_call_count(self):
+        return int(self.lib.ksw2amd_small_call_count())
 
     def rerun_count(self):
         """ksw2amd_rerun_count: pairs that a fetch ran again through the ordinary kernels (flat wildcard pairs, deferred arg-max)."""

@@ -77,6 +77,7 @@ static void release_thread_cache(void);
 	X(RAMP) \
 	X(SERIAL) \
 	X(SIMDS) \
+	X(SMALL_CELLS) \
 	X(SOLO) \
 	X(SSEC_HBM) \
 	X(SSE_COMPAT) \
@@ -2099,6 +2100,8 @@ int ksw2amd_host_unregister(const void *p)
  * KSW_NEG_INF, no CIGAR -- "no alignment" in the reference's own terms, ksw2.h:184-189), counts itself (ksw2amd_error_count),
  * leaves its message in ksw2amd_last_error() and says so on stderr (the first few times, then every 1000th).  A caller that wants
  * to know at once installs a handler (function name, KSW2AMD_E_* code, message); KSW2AMD_ABORT_ON_ERROR=1 aborts instead. */
+static long g_small_calls;
+long ksw2amd_small_call_count(void) { return g_small_calls; }
 static ksw2amd_error_fn g_err_fn;
 static void *g_err_user;
 static long g_err_count;
@@ -2118,6 +2121,160 @@ static void call_failed(const char *fn, int code, ksw_extz_t *ez)
 
 static int queue_one(const char *fn, int dual, void *km, const ksw2amd_scoring_t *sc, const ksw2amd_pair_t *pr, ksw_extz_t *ez);
 
+/* ---------------------------------------------------------------- opt-in host path for tiny single calls
+ * One pair per call from one thread (cli.c:50-132, README.md:54-87 of the reference) costs a launch and two PCIe round trips
+ * here -- ~0.5 ms whatever the size -- where the reference's SSE kernel needs tens of microseconds for a few hundred bases, and
+ * coalescing concurrent callers (below) only helps callers that are concurrent.  A caller that has such calls can hand the
+ * small ones to this code instead: ksw2amd_set_small_call_cells(c) / KSW2AMD_SMALL_CELLS=c sends every call of the ksw2-named
+ * single-pair entry points whose exact band has at most c cells through the scalar routine below, on the calling thread.
+ * OFF by default (c = 0), never taken because something failed, never used by the batch entry points, and only in a process
+ * whose device works (the first call still initialises it: without a GPU the library fails as loudly as before).
+ * It is the product's own restatement of the result contract (ksw2_extz.c:38-133, ksw2_extd.c:42-173 are
+ * the loops it replaces), written against the same rules as the kernels -- cell update, direction byte and continuation bits,
+ * row maxima with their tie rules, per-row bookkeeping and Z-drop, start of the traceback, =/X rewrite -- and tested like them:
+ * against the oracle and the golden vectors (tests/test_small_calls.py), never through the oracle. */
+static volatile int64_t g_small_cells = -1;              /* -1: not set by the API, KSW2AMD_SMALL_CELLS decides */
+void ksw2amd_set_small_call_cells(int64_t cells) { g_small_cells = cells < 0 ? 0 : cells; }
+static int64_t small_cells_limit(void)
+{
+	if (g_small_cells >= 0) return g_small_cells;
+	return ENV(SMALL_CELLS) ? atoll(ENV(SMALL_CELLS)) : 0;
+}
+static int small_border(int dual, int q, int e, int q2, int e2, int k)       /* H on the virtual row / column -1 at distance k */
+{
+	int a = -(q + k * e);
+	if (dual) { const int b = -(q2 + k * e2); if (b > a) a = b; }
+	return k <= 0 ? 0 : a;
+}
+/* returns a KSW2AMD_* code; *z is complete on KSW2AMD_OK */
+static int small_pair(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc, const ksw2amd_pair_t *a, ksw_extz_t *z)
+{
+	const int m = sc->m, qlen = a->qlen, tlen_full = a->tlen, fl = a->flag;
+	int q = sc->q, e = sc->e, q2 = sc->q2, e2 = sc->e2, w = a->w, i, j, k, lo;
+	const int generic = (fl & KSW_EZ_GENERIC_SC) || scalar, right = !!(fl & KSW_EZ_RIGHT), score_only = !!(fl & KSW_EZ_SCORE_ONLY);
+	const int with_tb = !score_only, firstj = !dual && right && with_tb;          /* extz + RIGHT + CIGAR: row-maximum ties to the first column */
+	int8_t eff[K2A_MAXM * K2A_MAXM];
+	int32_t *H, *E, *E2;
+	uint8_t *dir = 0;
+	int tlen, bw, bmax = 0, bmax_t = -1, bmax_q = -1, bmqe = K2A_NEG, bmqe_t = -1, bmte = K2A_NEG, bmte_q = -1, bscore = K2A_NEG, bdrop = 0;
+	int ti = -1, tj = -1, reach_end = 0, zslope;
+	ez_reset(z);
+	if (m <= 0 || (dual && m <= 1) || !sc->mat || qlen <= 0 || tlen_full <= 0) return KSW2AMD_OK;     /* ksw2_extz2_sse.c:57, ksw2_extd2_sse.c:76 */
+	if (m > K2A_MAXM) return fail(KSW2AMD_E_PARAM, "more than 127 residue types (int8_t m, ksw2.h:61)%s", 0);
+	if (!a->query || !a->target) return fail(KSW2AMD_E_PARAM, "NULL sequence%s", 0);
+	if (dual && !scalar && q2 + e2 < q + e) { int t = q; q = q2; q2 = t; t = e; e = e2; e2 = t; }      /* ksw2_extd2_sse.c:78 */
+	for (k = 1, lo = sc->mat[m * m > 1 ? 1 : 0]; k < m * m; ++k) lo = imin(lo, sc->mat[k]);
+	if (!scalar && -lo > 2 * (q + e)) return KSW2AMD_OK;                                              /* ksw2_extz2_sse.c:78-82 */
+	build_eff(dual, m, sc->mat, e, e2, generic, eff);
+	{ const int mx = imax(qlen, tlen_full); if (w < 0 || w > mx) w = mx; }                            /* ksw2_extz2_sse.c:72 */
+	tlen = (int64_t)qlen + w < tlen_full ? qlen + w : tlen_full;                                      /* rows i with i - w <= qlen - 1 */
+	bw = imin(qlen, 2 * w + 1);
+	zslope = dual ? e2 : e;
+	H = (int32_t*)malloc(sizeof(int32_t) * 3 * ((size_t)qlen + 2));
+	if (with_tb) dir = (uint8_t*)malloc((size_t)tlen * (size_t)bw + 1);
+	if (!H || (with_tb && !dir)) { free(H); free(dir); return fail(KSW2AMD_E_NOMEM, "small call: host allocation failed%s", 0); }
+	E = H + qlen + 2; E2 = E + qlen + 2;
+	/* row -1: H(-1, j) and the gap states it opens into row 0 (ksw2_extz.c:32-35, ksw2_extd.c:33-41) */
+	for (j = 0; j < qlen; ++j) {
+		if (j <= w) { const int hb = small_border(dual, q, e, q2, e2, j + 1); H[j] = hb; E[j] = hb - (q + e); E2[j] = hb - (q2 + e2); }
+		else H[j] = E[j] = E2[j] = K2A_NEG;
+	}
+	for (i = 0; i < tlen && !bdrop; ++i) {
+		const int st = imax(0, i - w), en = imin(qlen - 1, i + w), reach = i + w >= qlen - 1;
+		const uint8_t tc = a->target[i];
+		const int8_t *srow = eff + (size_t)tc * m;
+		int hdiag = st == 0 ? small_border(dual, q, e, q2, e2, i) : H[st - 1];         /* H(i-1, st-1) */
+		int f, f2, rm = K2A_NEG, rj = -1, hend = K2A_NEG;
+		uint8_t *drow = with_tb ? dir + (size_t)i * bw : 0;
+		if (st == 0) { const int hb = small_border(dual, q, e, q2, e2, i + 1); f = hb - (q + e); f2 = hb - (q2 + e2); }      /* column -1 (ksw2_extz.c:43-44) */
+		else f = f2 = K2A_NEG;
+		for (j = st; j <= en; ++j) {
+			int h = hdiag + srow[a->query[j]], ee = E[j], ee2 = dual ? E2[j] : K2A_NEG, t, ex, fx;
+			unsigned d = 0;
+			if (i > 0 && j - i >= w) { ee = K2A_NEG; ee2 = K2A_NEG; }                   /* the cell above is outside the band */
+			hdiag = H[j];                                                             /* H(i-1, j): the next column's diagonal */
+			if (!right) {                                                             /* ksw2_extz.c:72-75, ksw2_extd.c:88-95 */
+				d = h >= ee ? 0u : 1u; h = imax(h, ee);
+				d = h >= f ? d : 2u;   h = imax(h, f);
+				if (dual) { d = h >= ee2 ? d : 3u; h = imax(h, ee2); d = h >= f2 ? d : 4u; h = imax(h, f2); }
+			} else {                                                                  /* ksw2_extz.c:98-101, ksw2_extd.c:126-133 */
+				d = h > ee ? 0u : 1u;  h = imax(h, ee);
+				d = h > f ? d : 2u;    h = imax(h, f);
+				if (dual) { d = h > ee2 ? d : 3u; h = imax(h, ee2); d = h > f2 ? d : 4u; h = imax(h, f2); }
+			}
+			if (firstj ? h > rm : h >= rm) rj = j;                                     /* SURVEY 8a rule 3 */
+			rm = imax(rm, h);
+			t = h - (q + e); ex = ee - e; fx = f - e;
+			if (!right) { d |= (ex > t ? 1u : 0u) << 3; d |= (fx > t ? 1u : 0u) << 4; }
+			else { d |= (ex >= t ? 1u : 0u) << 3; d |= (fx >= t ? 1u : 0u) << 4; }
+			E[j] = imax(ex, t); f = imax(fx, t);
+			if (dual) {
+				const int t2 = h - (q2 + e2), ex2 = ee2 - e2, fx2 = f2 - e2;
+				if (!right) { d |= (ex2 > t2 ? 1u : 0u) << 5; d |= (fx2 > t2 ? 1u : 0u) << 6; }
+				else { d |= (ex2 >= t2 ? 1u : 0u) << 5; d |= (fx2 >= t2 ? 1u : 0u) << 6; }
+				E2[j] = imax(ex2, t2); f2 = imax(fx2, t2);
+			}
+			H[j] = h;
+			if (drow) drow[j - st] = (uint8_t)d;
+			hend = h;
+		}
+		if (st > 0) H[st - 1] = K2A_NEG;                                                 /* left the band */
+		/* the row's epilogue (ksw2_extz.c:116-124, ksw2_extd.c:156-164; ksw2.h:191-207 with is_rot = 0) */
+		if (reach && hend > bmqe) { bmqe = hend; bmqe_t = i; }
+		if (i == tlen_full - 1) { bmte = rm; bmte_q = rj; }
+		if (rm > bmax) { bmax = rm; bmax_t = i; bmax_q = rj; }
+		else if (i >= bmax_t && rj >= bmax_q) {
+			const int dt = i - bmax_t, dq = rj - bmax_q, skew = dt > dq ? dt - dq : dq - dt;
+			if (a->zdrop >= 0 && bmax - rm > a->zdrop + skew * zslope) bdrop = 1;
+		}
+		if (!bdrop && i == tlen_full - 1 && reach) bscore = hend;
+	}
+	/* rows, or the corner column, that the band cannot reach: stop like the SSE kernels do (ksw2_extz2_sse.c:111-114) */
+	if (!bdrop && (tlen < tlen_full || (tlen_full - 1) + w < qlen - 1)) bdrop = 1;
+	z->max = (uint32_t)bmax; z->zdropped = (uint32_t)bdrop; z->max_q = bmax_q; z->max_t = bmax_t;
+	z->mqe = bmqe; z->mqe_t = bmqe_t; z->mte = bmte; z->mte_q = bmte_q; z->score = bscore;
+	/* start of the traceback (ksw2_extz2_sse.c:292-301 / ksw2_extz.c:127-133) */
+	if (score_only) { }
+	else if (!bdrop && !(fl & KSW_EZ_EXTZ_ONLY)) { ti = tlen_full - 1; tj = qlen - 1; }
+	else if (!bdrop && (fl & KSW_EZ_EXTZ_ONLY) && bmqe + (scalar ? K2A_NEG : a->end_bonus) > bmax) { reach_end = 1; ti = bmqe_t; tj = qlen - 1; }
+	else if (bmax_t >= 0 && bmax_q >= 0) { ti = bmax_t; tj = bmax_q; }
+	z->reach_end = reach_end;
+	if (ti >= 0 && tj >= 0) {                                                           /* ksw_backtrack, ksw2.h:129-161 */
+		uint32_t *cg = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)qlen + tlen_full + 2));
+		uint32_t last_op = 0xffffffffu, run = 0;
+		int n = 0, state = 0;
+		if (!cg) { free(H); free(dir); return fail(KSW2AMD_E_NOMEM, "small call: host allocation failed%s", 0); }
+		i = ti; j = tj;
+		while (i >= 0 && j >= 0) {
+			const unsigned d = dir[(size_t)i * bw + (j - imax(0, i - w))];
+			uint32_t op;
+			if (state == 0) state = d & 7;
+			else if (!((d >> (state + 2)) & 1)) state = 0;
+			if (state == 0) state = d & 7;
+			if (state == 0) { op = 0; --i; --j; }
+			else if (state == 1 || state == 3) { op = 2; --i; }
+			else { op = 1; --j; }
+			if (op == last_op) ++run;
+			else { if (run) cg[n++] = run << 4 | last_op; last_op = op; run = 1; }
+		}
+		if (i >= 0) { if (last_op == 2) run += (uint32_t)i + 1; else { if (run) cg[n++] = run << 4 | last_op; last_op = 2; run = (uint32_t)i + 1; } }
+		if (j >= 0) { if (last_op == 1) run += (uint32_t)j + 1; else { if (run) cg[n++] = run << 4 | last_op; last_op = 1; run = (uint32_t)j + 1; } }
+		if (run) cg[n++] = run << 4 | last_op;
+		if (n > 0) {
+			if (km) pthread_mutex_lock(&g_km_mu);
+			ez_reserve(km, z, n);
+			for (k = 0; k < n; ++k) z->cigar[k] = cg[(fl & KSW_EZ_REV_CIGAR) ? k : n - 1 - k];           /* ksw2.h:157-159 */
+			z->n_cigar = n;
+			if (dual && (fl & KSW_EZ_EQX) && !scalar) eqx_rewrite(km, a->query, a->target, 1, z);
+			if (km) pthread_mutex_unlock(&g_km_mu);
+		}
+		free(cg);
+	}
+	free(H); free(dir);
+	return KSW2AMD_OK;
+}
+
+
 static void one_pair(const char *fn, int dual, int scalar, void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m,
                      const int8_t *mat, int8_t q, int8_t e, int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag,
                      ksw_extz_t *ez)
@@ -2132,6 +2289,16 @@ static void one_pair(const char *fn, int dual, int scalar, void *km, int qlen, c
 		rc = ssec_run(dual, km, &sc, 1, &pr, ez);
 		if (rc != KSW2AMD_OK) call_failed(fn, rc, ez);
 		return;
+	}
+	{	/* opt-in: tiny pairs on the calling thread (small_pair); the device is brought up first all the same */
+		const int64_t lim = small_cells_limit();
+		const int wn = (w < 0 || w > imax(qlen, tlen)) ? imax(qlen, tlen) : w;
+		if (lim > 0 && !is_approx(pr.flag | (scalar ? F_SCALAR_CONTRACT : 0)) && qlen > 0 && tlen > 0 && band_cells(qlen, tlen, wn) <= lim && thread_stream()) {
+			rc = small_pair(dual, scalar, km, &sc, &pr, ez);
+			if (rc != KSW2AMD_OK) call_failed(fn, rc, ez);
+			else __sync_fetch_and_add(&g_small_calls, 1);
+			return;
+		}
 	}
 	if (!scalar && queue_one(fn, dual, km, &sc, &pr, ez)) return;     /* coalesced with other threads' calls */
 	rc = run_serial(dual, scalar, km, &sc, 1, &pr, ez, 1, 0);
