@@ -744,8 +744,8 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 				    (plain || (use_rb && pk_window_ok(&pkinfo[generic], a->qlen, d->tlen, w, k2a_pkcfg_C[pc])))) break;
 			/* no resident geometry holds the band: the packed generation-serial class (sliding base), exact modes only */
 			if (pc == K2A_PKCFG_MP && !(cfg == K2A_CFG_MP && use_rb && use_pkmp && !is_approx(fl) && pk_slide_ok(&pkinfo[generic], a->qlen, d->tlen))) pc = K2A_NPKCFG;
-			/* (flat plans: the generation-serial and solo kernels do not report wildcard codes, so a pair goes there only after a look
-			 * at its bytes -- which a device arena does not allow) */
+			/* (flat plans: the generation-serial kernels do not report wildcard codes, so a pair goes there only after a look at its
+			 * bytes -- which a device arena does not allow; the packed and the solo kernels report them and the host re-runs the pair) */
 			if (pc == K2A_PKCFG_MP && flat && (flat->on_device || pair_has_wild(a))) pc = K2A_NPKCFG;
 			if (pc < K2A_NPKCFG) pk_ok[i] = (uint8_t)(1 + pc + ((plain && pc != K2A_PKCFG_MP) ? 0 : K2A_NPKCFG) + (is_approx(fl) ? 2 * K2A_NPKCFG : 0));
 			/* solo kernel: two strips of SC rows per lane, each with its own base (the window of an SC-row strip); a lane must finish
@@ -754,7 +754,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 			if (solo_mode && !is_approx(fl) && pk_window_ok(&pkinfo[generic], a->qlen, d->tlen, w, SC) &&
 			    ((d->tlen + 2 * SC - 1) / (2 * SC) <= 64 || w < 64 * (SC + 1) - SC)) {
 				solo_ok[i] = 1;
-				if (solo_mode == 2 && !(flat && (flat->on_device || pair_has_wild(a)))) pk_ok[i] = PASS_SOLO;
+				if (solo_mode == 2) pk_ok[i] = PASS_SOLO;
 			}
 		}
 		if (cfg == K2A_CFG_MP) {                              /* boundary rows H, E, E~ between generations */
@@ -791,8 +791,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 			for (h = 0; h < cap; ++h)
 				if (tab[h].k2 && tab[h].odd) {
 					const int last = tab[h].last;
-					int solo = solo_mode && solo_ok[last];
-					if (solo && flat && (flat->on_device || pair_has_wild(&pairs[last]))) solo = 0;
+					const int solo = solo_mode && solo_ok[last];
 					pk_ok[last] = (uint8_t)(solo ? PASS_SOLO : 0);
 				}
 			free(tab);
@@ -805,8 +804,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	 * most as many reads as the device has SIMDs goes to the solo kernel, read by read: every read gets a SIMD of its own and both
 	 * register halves (MI355X, 10 k x 10 k, w = 500, profiles/r3_solo_crossover.txt: 1 024 reads score only 6.2 ms solo, 7.6 ms in
 	 * pairs, 8.5 ms int32; with CIGAR 15.4 / 17.8 / 17.4 ms; dual gap with CIGAR 19.3 / 24.5 / 25.4 ms; from 1 536 reads on pairs
-	 * win, 17.2 against 21.2 ms).  What cannot go there (approximate modes, a window the solo halves cannot hold, flat plans whose
-	 * bytes the host has not seen) falls back to the int32 kernels below 0.4 packed wavefronts per SIMD as before (round 2: 512
+	 * win, 17.2 against 21.2 ms).  What cannot go there (approximate modes, a window the solo halves cannot hold) falls back to the int32 kernels below 0.4 packed wavefronts per SIMD as before (round 2: 512
 	 * packed wavefronts 11.5 ms, 1 024 int32 wavefronts 8.8 ms).  KSW2AMD_SIMDS overrides the device's SIMD count, 0 = both off. */
 	{
 		const char *ev = ENV(SIMDS);
@@ -826,7 +824,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 			for (i = 0; i < n; ++i)
 				if (p->h_cls[i] >= 0 && pk_ok[i] && pk_ok[i] != PASS_SOLO) {
 					const int what = cnt[p->h_cls[i] * NPASS + pk_ok[i]];
-					if ((what & 2) && solo_ok[i] && !(flat && (flat->on_device || pair_has_wild(&pairs[i])))) pk_ok[i] = PASS_SOLO;
+					if ((what & 2) && solo_ok[i]) pk_ok[i] = PASS_SOLO;
 					else if (what & 1) pk_ok[i] = 0;
 				}
 		}

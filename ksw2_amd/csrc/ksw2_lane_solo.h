@@ -47,6 +47,9 @@ struct K2aLaneSolo {
 	uint32_t qb, qw;                        /* { query code at column jj, at column jj-1 }; the dword of the current four steps */
 	uint32_t tnA[(C + 3) / 4], tnB[(C + 3) / 4], qn0;   /* prefetched for the NEXT double strip: its target codes, its first query dword */
 	int qn_sh;
+	uint32_t seen;                          /* OR of every code dword this lane used (K2aLanePk::seen: a flat plan's unscanned bytes; code >= 4 = wildcard -> the host re-runs the pair) */
+	K2A_FN void note_codes(uint32_t a) { seen |= a; }
+	K2A_FN bool saw_wildcard() const { return (seen & 0xfcfcfcfcu) != 0; }
 	k2a_pk hl[C], f[C], f2[DUAL ? C : 1], rmax[C], rmj[C], tc[C], tc1[C], hsave[C];
 
 	K2A_FN static int first_col(int D_, int w_) { return k2a_max(0, D_ * 2 * C - w_); }
@@ -86,7 +89,7 @@ struct K2aLaneSolo {
 		schedule_next();
 #pragma unroll
 		for (int x = 0; x < (C + 3) / 4; ++x) tnA[x] = tnB[x] = 0;
-		qn0 = 0;
+		qn0 = 0; seen = 0;
 		prefetch_next();
 		const k2a_pk neg = k2a_pku(K2A_NEG16);
 		hout = eout = e2out = hd0 = hu_prev = neg; qb = 0; qw = 0; baseA = baseB = 0; delta = 0;
@@ -128,6 +131,7 @@ struct K2aLaneSolo {
 #pragma unroll
 		for (int c4 = 0; c4 < C; c4 += 4) {
 			const uint32_t da = tnA[c4 / 4], db = tnB[c4 / 4];             /* prefetch_next(), one strip ago */
+			note_codes(da | db);                                           /* (rows past the target's end read the arena's next bytes: at worst a needless re-run) */
 #pragma unroll
 			for (int r = 0; r < 4; ++r) {
 				const k2a_pk cc = k2a_byte_pair(da, db, r);
@@ -159,6 +163,7 @@ struct K2aLaneSolo {
 		 * row one step later: start_high() gives it its own base just before its first step. */
 		hd0 = k2a_pair16(k2a_h16(0), neg >> 16);
 		qw = qn0 << qn_sh;                                      /* this strip's first group of query codes */
+		note_codes(qn0);
 		Dnext += G;
 		schedule_next();
 		prefetch_next();

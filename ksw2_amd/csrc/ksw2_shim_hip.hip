@@ -466,6 +466,7 @@ k2a_fill_solo_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 	uint8_t *tbp = tb + pr.tb_off;
 	/* query codes: one unaligned dword per four steps (K2aLaneSolo::load_query_group) */
 	L.load_query_group(0, L.knext == 0 ? L.koff_next : L.koff, L.qw);
+	L.note_codes(L.qw);
 	/* traceback words as whole cache lines (K2aTbStage, see the packed kernels): config 5's unique read shapes run here */
 	constexpr int WB = Lane::TBWORDS * 4;
 	constexpr bool STAGED = MODE != K2A_MODE_SCORE && (WB == 16 || WB == 32);
@@ -528,13 +529,16 @@ k2a_fill_solo_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 			}
 		}
 	}
-	L.qw = qp;
+	L.qw = qp; L.note_codes(qp);
 	}
 	if (STAGED) ST.finish(kdone);
 	__builtin_amdgcn_wave_barrier();
+	/* a code >= 4 among the bytes this wavefront read: only an unscanned (flat) plan can get here with one; the host re-runs the pair */
+	const bool saw = __builtin_amdgcn_ballot_w64(valid && L.saw_wildcard()) != 0;
 	if (valid && lane == 0) {
 		const K2aBook b = *bk;
 		k2a_finish(pr, b, &res[pi]);
+		if (saw) res[pi].pad[0] = 1;
 	}
 }
 

@@ -800,7 +800,7 @@ static void sim_fill_solo(const K2aScoring sc, const K2aPair *pairs, const uint3
 		const size_t tbsteps = k2a_solo_steps<C>(pr.qlen, pr.tlen, pr.w);
 		uint8_t *tbp = tb + pr.tb_off;
 		uint32_t qp[64];
-		for (int l = 0; l < 64; ++l) { qp[l] = 0; L[l].load_query_group(0, L[l].knext == 0 ? L[l].koff_next : L[l].koff, L[l].qw); }
+		for (int l = 0; l < 64; ++l) { qp[l] = 0; L[l].load_query_group(0, L[l].knext == 0 ? L[l].koff_next : L[l].koff, L[l].qw); L[l].note_codes(L[l].qw); }
 		bool done = false;
 		for (int k = 0; k <= klast && !done; ++k) {
 			k2a_pk rh[64], re[64], re2[64];
@@ -831,9 +831,12 @@ static void sim_fill_solo(const K2aScoring sc, const K2aPair *pairs, const uint3
 				if (!L[l].fin_fast(sc, &book, pr.zdrop)) { L[l].stage_rows(rowbuf); L[l].do_fin_seq(sc, &book, pr.zdrop, rowbuf); }
 				if (book.dropped) done = true;
 			}
-			if ((k & 3) == 3) for (int l = 0; l < 64; ++l) L[l].qw = qp[l];
+			if ((k & 3) == 3) for (int l = 0; l < 64; ++l) { L[l].qw = qp[l]; L[l].note_codes(qp[l]); }
 		}
 		k2a_finish(pr, book, &res[pi]);
+		bool saw = false;
+		for (int l = 0; l < 64; ++l) saw |= L[l].saw_wildcard();
+		if (saw) res[pi].pad[0] = 1;
 	}
 }
 

@@ -602,12 +602,15 @@ def _check_flat(lib, device_copy=None):
     included) and against the oracle; device_copy(arena) -> device address runs the same through a device-resident arena."""
     rng = np.random.Generator(np.random.PCG64(2027))
     tot = 0
+    kinds = set()
     for dual, qs, ts, mat, w, zd, eb, fl in _flat_cases(rng):
         ref = (lib.extd_batch(qs, ts, mat, 4, 2, 24, 1, w=w, zdrop=zd, end_bonus=eb, flag=fl) if dual else
                lib.extz_batch(qs, ts, mat, 4, 2, w=w, zdrop=zd, end_bonus=eb, flag=fl))
         fb = lib.make_flat_batch(qs, ts, mat, 4, 2, 24, 1, w=w, zdrop=zd, end_bonus=eb, flag=fl)
         got = [fb.run_oneshot(dual)]
-        p = fb.plan(dual); p.run(); got.append(p.fetch()); p.close()
+        p = fb.plan(dual)
+        kinds.update(d["kernel"] for d in p.describe())
+        p.run(); got.append(p.fetch()); p.close()
         if device_copy is not None:
             keep = device_copy(fb.arena)
             fd = lib.make_flat_batch(qs, ts, mat, 4, 2, 24, 1, w=w, zdrop=zd, end_bonus=eb, flag=fl, device_base=keep[0])
@@ -620,6 +623,7 @@ def _check_flat(lib, device_copy=None):
                 exp = po.align("oracle", "extd2" if dual else "extz2", qs[i], ts[i], mat, 4, 2, 24, 1, w=int(w[i]), zdrop=int(zd[i]), end_bonus=int(eb[i]), flag=int(fl[i]))
                 assert not diff(exp, ref[i]), (i, dual)
             tot += 1
+    assert {"pk", "solo", "int32"} <= kinds, kinds         # unscanned arenas reach the packed AND the solo kernels (both report wildcard codes)
     return tot
 
 
