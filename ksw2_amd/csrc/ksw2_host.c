@@ -57,6 +57,7 @@ static void release_thread_cache(void);
 	X(EXTF_HBM) \
 	X(EXTF_LANE) \
 	X(EXTF_RING) \
+	X(GROW) \
 	X(EXTF_LDS) \
 	X(EXTF_WIN) \
 	X(EXTS_BIG) \
@@ -1667,6 +1668,13 @@ static int make_chunks(int n, const double *cost, double total, int nchunks, int
 		cbeg[c] = n;
 		return c;
 	}
+	if (chunk_pairs < 0) {                                /* ... growing: two chunks of that size, then chunks of twice the size (uniform_chunks) */
+		const int cp = -chunk_pairs;
+		int c = 0, b = 0;
+		while (b < n) { cbeg[c] = b; b += c < 2 ? cp : 2 * cp; ++c; }
+		cbeg[c] = n;
+		return c;
+	}
 	const int ramp = nchunks >= 3 * workers && workers > 0 && env_flag(ENV(RAMP), 0), nc = ramp ? nchunks + 2 * workers : nchunks;
 	double wsum = 0, acc = 0, edge = 0;
 	int i, c = 0;
@@ -1773,6 +1781,14 @@ static int uniform_chunks(int n, int unit, double bytes, double cells, int worke
 	while (units / cu > kmax) cu *= 2;
 	*chunk_pairs = (int)(cu * unit);
 	k = (n + *chunk_pairs - 1) / *chunk_pairs;
+	/* Long score-only reads, six chunks and more: the first two chunks at this size (two wavefronts per SIMD each: the device starts
+	 * after one such chunk's packing and upload), the rest twice as big -- a kernel that fills the device by itself loses nothing
+	 * when it is the last one running, where a two-per-SIMD kernel alone runs at two thirds of the rate (MI355X, 10 k headline end to
+	 * end: 4 290 -> 4 370 GCUPS through the pointer entry, 4 330 -> 4 500 through the flat entry; KSW2AMD_GROW=0: all chunks equal) */
+	if (!with_cigar && cu == 2.0 && path_s >= long_path_s() && k >= 6 && env_flag(ENV(GROW), 1)) {
+		*chunk_pairs = -*chunk_pairs;
+		k = 2 + (k - 2 + 1) / 2;
+	}
 	return k < 2 ? 0 : k;
 }
 
