@@ -496,6 +496,13 @@ def test_cli_matches_reference_cli(lib):
         a = subprocess.run([ours, "-t", "extz", "-K"] + gz, capture_output=True, text=True)
         b = subprocess.run([ref, "-t", "extz", "-K"] + gz, capture_output=True, text=True)
         assert a.stdout == b.stdout, (a.stdout[:300], b.stdout[:300])
+    # the opt-in host path for tiny single calls (KSW2AMD_SMALL_CELLS): the per-pair mode's calls computed on the host, same bytes out,
+    # with -K too (CIGARs from the caller's pool)
+    small = dict(os.environ, KSW2AMD_SMALL_CELLS="1000000000")
+    for opts, t, q in runs[:8] + [(["-t", "extz", "-w", "500"], mh, mo), (["-t", "extd", "-w", "500", "-r"], mh, mo), (["-t", "extd2_sse", "-K"], t1, q1)]:
+        a = subprocess.run([ours] + opts + [t, q], capture_output=True, text=True, env=small)
+        b = subprocess.run([ours] + opts + [t, q], capture_output=True, text=True)
+        assert a.returncode == 0 and a.stdout == b.stdout, (opts, a.stdout[:300], b.stdout[:300])
     # batched mode prints the same lines as the per-pair mode
     a = subprocess.run([ours, "-t", "extz2_sse", "-b", t1, q1], capture_output=True, text=True)
     b = subprocess.run([ours, "-t", "extz2_sse", t1, q1], capture_output=True, text=True)
