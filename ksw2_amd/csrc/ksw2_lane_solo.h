@@ -417,22 +417,35 @@ struct K2aLaneSolo {
 template<int C>
 K2A_FN int k2a_trace_solo(const uint8_t *tb, int i, int j, uint32_t *out, int qlen, int tlen, int w)
 {
-	enum { WB = 2 * C };
+	enum { WB = 2 * C, AHEAD = 8 };
 	int n = 0, state = 0;
 	uint32_t last_op = 0xffffffffu, run = 0;
 	const size_t nsteps = k2a_solo_steps<C>(qlen, tlen, w);
+	/* The walk is a chain of dependent loads and most moves are diagonal (k2a_trace_walk, ksw2_lane.h): the bytes of the next AHEAD
+	 * cells on the diagonal -- one step and one row back each, i.e. WB + 2 bytes lower in the lane's run, as long as the row stays
+	 * in the same half of the double strip -- are requested together and consumed while the path really is diagonal. */
 	while (i >= 0 && j >= 0) {
 		const int D = i / (2 * C), r = i - D * 2 * C, half = r >= C ? 1 : 0, c = r - half * C;
-		const uint32_t d = tb[k2a_tb_word((size_t)(j + 2 * D + half), D % 64, nsteps, 64, WB) + 2 * c + half];
-		if (state == 0) state = d & 7;
-		else if (!((d >> (state + 2)) & 1)) state = 0;
-		if (state == 0) state = d & 7;
-		uint32_t op;
-		if (state == 0) { op = 0; --i; --j; }
-		else if (state == 1 || state == 3) { op = 2; --i; }
-		else { op = 1; --j; }
-		if (op == last_op) ++run;
-		else { if (run) out[n++] = run << 4 | last_op; last_op = op; run = 1; }
+		const uint8_t *p = tb + k2a_tb_word((size_t)(j + 2 * D + half), D % 64, nsteps, 64, WB) + 2 * c + half;
+		const int nq = k2a_min(k2a_min(AHEAD, c + 1), k2a_min(i, j) + 1);
+		uint32_t bq[AHEAD];
+#pragma unroll
+		for (int k = 0; k < AHEAD; ++k) bq[k] = p[-(ptrdiff_t)k2a_min(k, nq - 1) * (WB + 2)];
+		bool diagonal = true;
+#pragma unroll
+		for (int k = 0; k < AHEAD; ++k) {
+			if (k >= nq || !diagonal) break;
+			const uint32_t d = bq[k];
+			if (state == 0) state = d & 7;
+			else if (!((d >> (state + 2)) & 1)) state = 0;
+			if (state == 0) state = d & 7;
+			uint32_t op;
+			if (state == 0) { op = 0; --i; --j; }
+			else if (state == 1 || state == 3) { op = 2; --i; diagonal = false; }
+			else { op = 1; --j; diagonal = false; }
+			if (op == last_op) ++run;
+			else { if (run) out[n++] = run << 4 | last_op; last_op = op; run = 1; }
+		}
 	}
 	if (i >= 0) {
 		if (last_op == 2) run += i + 1;
