@@ -351,6 +351,16 @@ def roofline_of(job, res, workload_key):
     # the PMC passes under profiles/ are of the plain workloads: a different kernel runs with --approx / --sse-compat or a resized batch
     plain = not os.environ.get("KSW2AMD_NO_PKMP") and not getattr(job, "sse", False) and not (job.wl["flag"] & 0x08 and not WORKLOADS[workload_key]["flag"] & 0x08) and res["n"] == (WORKLOADS[workload_key].get("resident_n") or WORKLOADS[workload_key]["n"])
     traffic, src = recorded_traffic(workload_key) if plain else (None, None)
+    defer = any(c.get("form") == "defer" for c in res.get("kernels", []))
+    out = _roofline_dict(job, res, ops, kern_s, achieved, alg_bytes, traffic, src)
+    if defer and traffic:
+        # the deferred arg-max kernels write, once, 8 bytes per lane and step (512 B per wavefront-step) as checkpoints for the second
+        # pass: that stream is by design, not a re-read; at ~1.4 TB/s it is far from the HBM bound
+        out["traffic_note"] = "write-once checkpoint stream of the deferred arg-max (DESIGN.md 3.11): 512 B per wavefront-step; sequences + results are the algorithmic bytes"
+    return out
+
+
+def _roofline_dict(job, res, ops, kern_s, achieved, alg_bytes, traffic, src):
     return {"bound": "valu", "achieved": round(achieved / 1e12, 4), "peak": VALU_PEAK_PK16 / 1e12, "unit": "Tiop/s",
             "frac": round(achieved / VALU_PEAK_PK16, 5), "traffic": traffic, "traffic_source": src,
             "ops_per_cell": ops, "kernel_ms": round(res["kernel_ms"], 4), "fill_kernel_ms": round(res["fill_ms"], 4),
