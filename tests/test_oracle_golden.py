@@ -169,3 +169,28 @@ def test_50k_anchor():
     exp = [r for r in ka if r["func"] == "ksw_extz2_sse" and r["w"] == 500][0]
     res = po.align("oracle", "extz2", qs[0], ts[0], mat, 4, 2, w=500, zdrop=400, flag=po.SCORE_ONLY)
     _check(res, exp, gu.SSE_LOOSE_FIELDS)
+
+
+def test_gg_family_golden():
+    """ksw_gg / ksw_gg2 / ksw_gg2_sse (ksw2_gg.c:6-102, ksw2_gg2.c:4-114, ksw2_gg2_sse.c:11-126): 900 committed cases -- bands -1, |d|,
+    |d| + 1, 20, 64, 500, wildcards, score only and with CIGAR -- pin kso_gg / kso_gg2; ksw_gg2 / ksw_gg2_sse cases only where the
+    reference's function agrees with its own ksw_gg (recorded in the fixture); w < |d| is the library's definition (KSW_NEG_INF, no CIGAR)."""
+    gc = gu.GgCases()
+    assert gc.n >= 600
+    cnt = {"gg": 0, "gg2": 0, "gg2_sse": 0, "contract": 0}
+    for k in gc.contract_cases():
+        c = gc.case(k)
+        s, cg = po.global_align("oracle", "gg" if c["func"] == "gg" else "gg2", c["q"], c["t"], c["mat"], c["gq"], c["ge"], w=c["w"], with_cigar=c["with_cigar"])
+        assert s == c["score"], (k, c["func"], c["w"], s, c["score"])
+        assert cg == c["cigar"], (k, c["func"], c["w"])
+        cnt["contract" if c["origin"] else c["func"]] += 1
+    assert cnt["gg"] > 200 and cnt["gg2"] > 200 and cnt["gg2_sse"] > 120 and cnt["contract"] > 100, cnt
+    # what the fixture records about the reference itself: its scalar ksw_gg2 leaves the exact band on a few w <= 2 cases
+    # (cells outside the band get difference values 0, not -infinity: ksw2_gg2.c:36-41), its SSE twin on about a third
+    differ = {"gg2": [], "gg2_sse": []}
+    for k in range(gc.n):
+        c = gc.case(k)
+        if not c["agree"]:
+            differ[c["func"]].append(c["w"])
+    assert 0 < len(differ["gg2"]) < 10 and all(0 <= w <= 2 for w in differ["gg2"]), differ["gg2"]
+    assert len(differ["gg2_sse"]) > 50

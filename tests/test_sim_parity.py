@@ -765,3 +765,16 @@ def test_sim_linear_xdrop_one_extension_per_lane(sim, monkeypatch):
     res = sim.extf_batch([e, one, one, e], [e, e, one, one], 2, -4, 2, w=-1, xdrop=50)
     for r, (q, t) in zip(res, ((e, e), (one, e), (one, one), (e, one))):
         assert not diff(r, po.extf2("oracle", q, t, 2, -4, 2, -1, 50), gu.FIELDS)
+
+
+def test_sim_gg_family_golden(sim):
+    """Every third committed case of the global family (tests/golden/gg_cases.npz: reference outputs of ksw_gg / ksw_gg2 / ksw_gg2_sse,
+    bands -1 ... 500 and the band-cannot-reach-the-corner definition) through the product's ksw_gg / ksw_gg2 / ksw_gg2_sse."""
+    gc = gu.GgCases()
+    n = 0
+    for k in gc.contract_cases()[::3]:
+        c = gc.case(k)
+        s, cg = sim.gg(c["func"], c["q"], c["t"], c["mat"], c["gq"], c["ge"], w=c["w"], with_cigar=c["with_cigar"])
+        assert s == c["score"] and list(cg) == c["cigar"], (k, c["func"], c["w"], c["origin"], s, c["score"])
+        n += 1
+    assert n >= 250
