@@ -279,6 +279,12 @@ void ksw2amd_reload_env(void);
 /* pairs that a fetch ran a second time through the ordinary kernels since the library was loaded: flat batches' wildcard pairs, and
  * alignments in which the deferred arg-max kernels could not rule out a Z-drop without the arg-max columns */
 int64_t ksw2amd_rerun_count(void);
+/* Streamed plans (new; replaces nothing in the reference): a one-shape score-only batch handed to the batch entry points runs as ONE
+ * plan whose sequence arena goes up in pieces while a single persistent launch per kernel class starts each wavefront's tasks as
+ * their pieces land.  out[0] = streamed plans run since the library was loaded, out[1] = runs in which a
+ * launch gave up waiting for its inputs (bounded wait) and the plan was run again behind its upload.  KSW2AMD_STREAM=0 / 1:
+ * never / every plan that can. */
+void ksw2amd_stream_stats(int64_t out[2]);
 /* a resident plan of SSE-compatible alignments (every pair, whatever its flags); run / fetch / timing / cells / destroy as above */
 ksw2amd_plan_t *ksw2amd_sse_plan_create(int dual, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs);
 /* a resident plan of splice-aware extensions; run / fetch / timing / cells / destroy as above */

@@ -81,7 +81,7 @@ EXPORTS = ["ksw_extz2_sse", "ksw_extd2_sse", "ksw_gg2", "ksw_gg2_sse", "ksw_extz
            "ksw2amd_set_sse_compat", "ksw2amd_sse_plan_create", "ksw2amd_plan_describe", "ksw2amd_reload_env",
            "ksw2amd_extz_batch_flat", "ksw2amd_extd_batch_flat", "ksw2amd_plan_create_flat", "ksw2amd_host_register", "ksw2amd_host_unregister",
            "ksw2amd_device_alloc", "ksw2amd_device_free", "ksw2amd_device_upload", "ksw2amd_device_download", "ksw2amd_rerun_count",
-           "ksw2amd_set_small_call_cells", "ksw2amd_small_call_count"]
+           "ksw2amd_set_small_call_cells", "ksw2amd_small_call_count", "ksw2amd_stream_stats"]
 # entry points whose behaviour depends on KSW2AMD_* switches: the library reads its environment once per process, so this binding
 # re-reads it in front of each of them (tests and A/B scripts flip switches inside one process)
 _ENV_ENTRIES = ["ksw_extz2_sse", "ksw_extd2_sse", "ksw_gg2", "ksw_gg2_sse", "ksw_extz", "ksw_extd", "ksw_gg", "ksw_extz2_sse41",
@@ -200,6 +200,7 @@ class Library:
         L.ksw2amd_set_small_call_cells.argtypes = [ctypes.c_int64]
         L.ksw2amd_set_small_call_cells.restype = None
         L.ksw2amd_small_call_count.restype = ctypes.c_long
+        L.ksw2amd_stream_stats.restype = None
         L.ksw2amd_reload_env.restype = None
         reload_env = L.ksw2amd_reload_env
 
@@ -266,6 +267,12 @@ class Library:
     def rerun_count(self):
         """ksw2amd_rerun_count: pairs that a fetch ran again through the ordinary kernels (flat wildcard pairs, deferred arg-max)."""
         return int(self.lib.ksw2amd_rerun_count())
+
+    def stream_stats(self):
+        """ksw2amd_stream_stats -> dict(streamed_plans, aborted_runs): plans whose batch ran as one persistent launch under its upload."""
+        out = (ctypes.c_int64 * 2)()
+        self.lib.ksw2amd_stream_stats(out)
+        return dict(streamed_plans=int(out[0]), aborted_runs=int(out[1]))
 
     def host_stats(self):
         """ksw2amd_host_stats -> dict(pool_batches, pool_chunks, coalesced_calls, coalesced_batches)."""

@@ -82,6 +82,12 @@ static void release_thread_cache(void);
 	X(SOLO) \
 	X(SSEC_HBM) \
 	X(SSE_COMPAT) \
+	X(STREAM) \
+	X(STREAM_FAULT) \
+	X(STREAM_MIN_CELLS) \
+	X(STREAM_PIECE_KB) \
+	X(STREAM_SLEEP_US) \
+	X(STREAM_TIMEOUT_MS) \
 	X(THREADS) \
 	X(TRACE)
 enum {
@@ -132,8 +138,8 @@ int ksw2amd_set_device(int device)
  * Device allocations and page-locking cost milliseconds; a minimap2-style caller issues many batches (or single-pair
  * calls) from the same thread.  Each thread therefore keeps the buffers of its last plan (one per kind) and hands them to
  * the next plan when they are large enough.  ksw2amd_release_cache() returns them; switching device flushes them. */
-enum { BUF_HSEQ, BUF_SEQ, BUF_PAIRS, BUF_RES, BUF_ORDER, BUF_TB, BUF_CIG, BUF_BND, BUF_POS, BUF_POOL, BUF_HPOOL, BUF_HRES, BUF_KINDS };
-#define BUF_IS_HOST(k) ((k) == BUF_HSEQ || (k) == BUF_HPOOL || (k) == BUF_HRES)      /* pinned host staging; everything else is device memory */
+enum { BUF_HSEQ, BUF_SEQ, BUF_PAIRS, BUF_RES, BUF_ORDER, BUF_TB, BUF_CIG, BUF_BND, BUF_POS, BUF_POOL, BUF_HPOOL, BUF_HRES, BUF_WM, BUF_HMETA, BUF_KINDS };
+#define BUF_IS_HOST(k) ((k) == BUF_HSEQ || (k) == BUF_HPOOL || (k) == BUF_HRES || (k) == BUF_HMETA)      /* pinned host staging; everything else is device memory */
 #define CACHE_DEPTH 2                  /* a worker that queues its next chunk before it fetches the current one holds two plans */
 static __thread struct { void *p; size_t cap; } g_cache[BUF_KINDS][CACHE_DEPTH];
 static __thread void *g_ev_cache[3];
@@ -212,6 +218,15 @@ static void *cache_get(int kind, size_t bytes, size_t *cap)
 		return p;
 	}
 	*cap = bytes + bytes / 8 + 256;                       /* a little slack so slightly larger follow-up batches still fit */
+	if (g_env_ready && g_env[ENV_TRACE] && atoi(g_env[ENV_TRACE]) >= 2) {
+		struct timespec a, b; void *q;
+		clock_gettime(CLOCK_MONOTONIC, &a);
+		q = BUF_IS_HOST(kind) ? k2a_shim_host_malloc(*cap) : k2a_shim_malloc(*cap);
+		clock_gettime(CLOCK_MONOTONIC, &b);
+		fprintf(stderr, "[ksw2_amd] buffer cache miss: kind %d, %zu bytes (%s), %.2f ms; cached of that kind: %zu / %zu\n", kind, *cap, BUF_IS_HOST(kind) ? "pinned host" : "device",
+		        (b.tv_sec - a.tv_sec) * 1e3 + (b.tv_nsec - a.tv_nsec) * 1e-6, g_cache[kind][0].cap, g_cache[kind][1].cap);
+		return q;
+	}
 	return BUF_IS_HOST(kind) ? k2a_shim_host_malloc(*cap) : k2a_shim_malloc(*cap);
 }
 
@@ -244,6 +259,89 @@ static void release_thread_cache(void)
 	for (k = 0; k <= NSIDE; ++k) if (g_side_ev[k]) { k2a_shim_event_destroy(g_side_ev[k]); g_side_ev[k] = 0; }
 }
 
+/* ---------------------------------------------------------------- streamed plans
+ * A batch entry point used to cut a batch into chunks so that uploads overlap kernels -- and paid for it on short reads: eight
+ * kernels of half a wavefront per SIMD take 3 ms of device time for what one full launch does in 1.4 (config 2, round 3,
+ * profiles/r3_cfg2_phases.txt).  A streamed plan is ONE plan for the whole batch: its sequence arena goes up in pieces on the
+ * device's upload stream, behind every piece a block filled with the piece's number is copied onto the plan's watermark block
+ * (K2A_WM_BYTES: a size the runtime moves with the DMA engines -- smaller copies, hipStreamWriteValue32 and one-thread "publish"
+ * kernels all need a wavefront slot and do not get one while a persistent launch holds the device: tools/probe/
+ * stream_publish_probe.hip, profiles/r4_stream_publish_probe.txt), and every packed class runs as one persistent launch whose
+ * wavefronts pop wavefront-tasks from a counter, longest first, and start one only when the watermark says its sequences have
+ * landed (K2aQueueDesc, k2a_queue_pop).  The wait is bounded (KSW2AMD_STREAM_TIMEOUT_MS, default 2000): a wavefront that gives
+ * up raises the launch's abort word, fetch sees it, waits for the upload and runs the plan again as an ordinary one.
+ * KSW2AMD_STREAM=0 never, =1 every plan that can (tests), unset: the batch entry points' one-shape score-only batches. */
+#define K2A_MAXPIECES 48
+#define K2A_STREAM_MARGIN 256          /* bytes past a sequence's end that the kernels may touch (dword query loads, one strip of target codes) */
+static int stream_env(void) { return env_switch(ENV(STREAM)); }
+static int64_t stream_min_cells(void) { const char *e = ENV(STREAM_MIN_CELLS); return e && atoll(e) >= 0 ? atoll(e) : 1000000; }      /* cells per pair from which one-shape batches are streamed by default */
+static int64_t g_stream_stat[2];           /* streamed plans run, runs that were aborted and repeated unstreamed */
+void ksw2amd_stream_stats(int64_t out[2]) { out[0] = g_stream_stat[0]; out[1] = g_stream_stat[1]; }
+/* the watermark source: page-locked, block k filled with k + 1, one per device for the life of the process */
+static uint32_t *g_wm_src[SHARED_UP_MAXDEV];
+static pthread_mutex_t g_wm_mu = PTHREAD_MUTEX_INITIALIZER;
+static const uint32_t *wm_source(void)
+{
+	const int dev = k2a_shim_get_device();
+	uint32_t *b;
+	if (dev < 0 || dev >= SHARED_UP_MAXDEV) return 0;
+	pthread_mutex_lock(&g_wm_mu);
+	if (!g_wm_src[dev]) {
+		b = (uint32_t*)k2a_shim_host_malloc((size_t)(K2A_MAXPIECES + 1) * K2A_WM_BYTES);
+		if (b) {
+			size_t k, i;
+			for (k = 0; k <= K2A_MAXPIECES; ++k)                    /* (the last block: zeros, what a plan's watermark starts from) */
+				for (i = 0; i < K2A_WM_BYTES / 4; ++i) b[k * (K2A_WM_BYTES / 4) + i] = k < K2A_MAXPIECES ? (uint32_t)k + 1 : 0u;
+			g_wm_src[dev] = b;
+		}
+	}
+	b = g_wm_src[dev];
+	pthread_mutex_unlock(&g_wm_mu);
+	return b;
+}
+/* the upload side of a streamed plan: pieces [pb[k], pb[k + 1]) of the arena, issued in order by whoever finishes the gap */
+typedef struct {
+	int np, next, fault, sleep_us;         /* next: first piece not yet issued; fault / sleep_us: test hooks (KSW2AMD_STREAM_FAULT / _SLEEP_US) */
+	double issue_ms, t0, t_first, t_last;  /* KSW2AMD_TRACE: host time spent in the upload calls; creation, first and last piece issued (now_ms) */
+	int hold, all_ready;                   /* hold: pieces that may go up for now (the plan's small arrays must not queue behind the whole arena:
+	                                        * two pieces, the arrays, then the rest); all_ready: a flat arena -- nothing to wait for */
+	size_t pb[K2A_MAXPIECES + 1];
+	int pfirst[K2A_MAXPIECES + 1];         /* gather plans: first pair of each piece (the copy's work units) */
+	uint8_t done[K2A_MAXPIECES];
+	int left[K2A_MAXPIECES];               /* gather plans: copy chunks of the piece still outstanding (the copy's work units are finer than the pieces) */
+	const uint8_t *src; size_t src_bytes;  /* host (or device, flat device arenas) bytes of [0, src_bytes); the rest of the last piece comes from `tail` */
+	const uint8_t *tail;
+	int src_on_device;
+	uint8_t *d_seq, *d_wm;
+	const uint32_t *wm_src;
+	void *up;
+	int rc;
+	pthread_mutex_t mu;
+} stream_up_t;
+/* issue every piece that is ready and allowed, in order; called with piece `k` just completed (k < 0: only look again) */
+static double now_ms(void);
+static void stream_issue(stream_up_t *u, int k)
+{
+	const double t0 = now_ms();
+	pthread_mutex_lock(&u->mu);
+	if (k >= 0) u->done[k] = 1;
+	while (u->next < u->np && u->next < u->hold && (u->all_ready || u->done[u->next]) && !u->rc) {
+		const int c = u->next++;
+		if (c == 0) u->t_first = t0;
+		u->t_last = t0;
+		const size_t lo = u->pb[c], hi = u->pb[c + 1], mid = hi < u->src_bytes ? hi : u->src_bytes > lo ? u->src_bytes : lo;
+		if (u->sleep_us > 0) {                           /* tests: the kernel must really wait for its pieces */
+			struct timespec ts; ts.tv_sec = 0; ts.tv_nsec = (long)u->sleep_us * 1000L;
+			k2a_shim_stream_sync(u->up); nanosleep(&ts, 0);
+		}
+		if (mid > lo && (u->src_on_device ? k2a_shim_d2d(u->d_seq + lo, u->src + lo, mid - lo, u->up) : k2a_shim_h2d(u->d_seq + lo, u->src + lo, mid - lo, u->up))) u->rc = -1;
+		if (hi > mid && u->tail && k2a_shim_h2d(u->d_seq + mid, u->tail + (mid - u->src_bytes), hi - mid, u->up)) u->rc = -1;
+		if (u->fault && c >= u->np / 2) continue;        /* tests: the watermarks of the second half never arrive -> the launch times out and aborts */
+		if (k2a_shim_h2d(u->d_wm, (const uint8_t*)u->wm_src + (size_t)c * K2A_WM_BYTES, K2A_WM_BYTES, u->up)) u->rc = -1;
+	}
+	u->issue_ms += now_ms() - t0;
+	pthread_mutex_unlock(&u->mu);
+}
 /* ---------------------------------------------------------------- CIGAR memory */
 
 typedef void *(*krealloc_fn)(void *km, void *p, size_t size);
@@ -289,6 +387,7 @@ static int is_approx(int flag)
 /* ---------------------------------------------------------------- plan */
 
 typedef struct {
+	int qd;                                /* >= 0: index of the class's K2aQueueDesc (streamed plans) */
 	int cfg, mode, generic, pk, rb, nomax, solo, defer, first, count;   /* defer: arg-max columns by a second pass (K2aLanePk, DEFER); pk: packed-int16 tasks, two h_order entries per task; rb: per-strip bases;
 	                                                        * nomax: KSW_EZ_APPROX_MAX launches without row maxima */
 	K2aScoring sc;
@@ -299,7 +398,7 @@ struct ksw2amd_plan_s {
 	int m;
 	K2aPair *h_pairs;
 	int8_t *h_cls;                 /* class index per pair, -1 = rejected before the device */
-	uint8_t *h_half;               /* 0 = own sequence copy, 1 / 2 = alignment A / B of a packed task (interleaved copy) */
+	uint8_t *h_half;               /* streamed plans: upload pieces that must have landed before the pair's sequences are complete on the device */
 	int32_t *h_flag;               /* caller's flag per pair */
 	uint32_t *h_order;
 	int ntasks;
@@ -334,6 +433,19 @@ struct ksw2amd_plan_s {
 	uint8_t *flat_tail;                    /* ... and the staging block of the arena's padding lives as long as the plan */
 	ksw2amd_pair_t *src_pairs;             /* the caller's pairs (pointers into the arena), kept for the re-runs */
 	ksw2amd_scoring_t src_sc; int8_t *src_mat;
+	/* streamed plans (section "streamed plans" below): the sequence arena goes up in pieces, a persistent launch per packed class
+	 * starts its wavefront-tasks as their pieces land */
+	int streamed;                          /* classes with cls_t.qd >= 0 exist and the next run launches them as queues */
+	int unscanned;                         /* a streamed plan's gathered arena is copied, not scanned: wildcard pairs are reported by the kernels like in flat plans */
+	stream_up_t *up_state;                 /* the piece-wise upload (lives as long as the plan: the gather's workers issue pieces) */
+	struct gather_s *gather;               /* the gather of a streamed plan, running on the pool's threads until gather_wait() */
+	int npieces;
+	void *wm_ev;                           /* behind the copy that zeroes the watermark block (upload stream) */
+	uint8_t *h_meta;                       /* page-locked staging of the small arrays (streamed plans) */
+	void *meta_ev;                         /* behind the plan's small arrays (upload stream): what a streamed run waits for before its first launch */
+	uint8_t *d_wm;                         /* watermark block (K2A_WM_BYTES) followed by the K2aQueueDesc array of the streamed classes */
+	K2aQueueDesc *h_qd; int nqd;
+	size_t need_words;                     /* per-wavefront-task piece counts, behind the task lists in d_order */
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -499,16 +611,22 @@ static int copy_scan(uint8_t *dst, const uint8_t *src, int n)
 	return (acc & 0xfcfcfcfcfcfcfcfcull) != 0;
 }
 
+static int gather_wait(ksw2amd_plan_t *p);
 void ksw2amd_plan_destroy(ksw2amd_plan_t *p)
 {
 	int i;
 	if (!p) return;
+	if (p->gather) gather_wait(p);
 	if (p->up_ev) { k2a_shim_event_sync(p->up_ev); k2a_shim_event_destroy(p->up_ev); p->up_ev = 0; }      /* the upload reads host blocks freed below */
+	if (p->up_state) { pthread_mutex_destroy(&p->up_state->mu); free(p->up_state); p->up_state = 0; }
+	if (p->wm_ev) { k2a_shim_event_destroy(p->wm_ev); p->wm_ev = 0; }
+	if (p->meta_ev) { k2a_shim_event_destroy(p->meta_ev); p->meta_ev = 0; }
 	if (p->stream_used) k2a_shim_stream_sync(p->stream);     /* nothing may still be running on buffers that get recycled */
 	cache_put(BUF_SEQ, p->d_seq, p->cap[BUF_SEQ]); cache_put(BUF_TB, p->d_tb, p->cap[BUF_TB]);
 	cache_put(BUF_PAIRS, p->d_pairs, p->cap[BUF_PAIRS]); cache_put(BUF_RES, p->d_res, p->cap[BUF_RES]);
 	cache_put(BUF_ORDER, p->d_order, p->cap[BUF_ORDER]); cache_put(BUF_CIG, p->d_cig, p->cap[BUF_CIG]);
-	cache_put(BUF_BND, p->d_bnd, p->cap[BUF_BND]);
+	cache_put(BUF_BND, p->d_bnd, p->cap[BUF_BND]); cache_put(BUF_WM, p->d_wm, p->cap[BUF_WM]); cache_put(BUF_HMETA, p->h_meta, p->cap[BUF_HMETA]);
+	free(p->h_qd);
 	for (i = 0; i < 3; ++i) if (p->ev[i]) { if (!g_ev_cache[i]) g_ev_cache[i] = p->ev[i]; else k2a_shim_event_destroy(p->ev[i]); }
 	free(p->h_pairs); free(p->h_cls); free(p->h_half); free(p->h_flag); free(p->h_order);
 	cache_put(BUF_HRES, p->h_res, p->cap[BUF_HRES]);          /* pinned: the results come back with one asynchronous copy */
@@ -530,35 +648,38 @@ static int cmp_cost_desc(const void *a, const void *b)
  * reject, gap pieces kept in the caller's order).  Decided by the entry point, never by a bit in the caller's flags. */
 /* the sequence copy of a plan (pass 1 of plan_create_ex): the bytes into the pinned arena, a wildcard flag per pair.  A big plan
  * created outside the worker pool has the pool's threads share the copy (parallel_copy, behind the pool) */
-typedef struct { uint8_t *h_seq; const K2aPair *hp; const ksw2amd_pair_t *pairs; uint8_t *wild; } copy_ctx_t;
+typedef struct { uint8_t *h_seq; const K2aPair *hp; const ksw2amd_pair_t *pairs; uint8_t *wild; stream_up_t *su; } copy_ctx_t;   /* su: streamed plans -- chunk k of the copy is piece k of the upload */
 static void copy_range(const copy_ctx_t *c, int beg, int end);
 static int parallel_copy(copy_ctx_t *c, int n, size_t bytes);
 
+static int gather_start(ksw2amd_plan_t *p, stream_up_t *su, const ksw2amd_pair_t *pairs, int n);
 static double now_ms(void);
 static int trace_level(void) { const char *e = ENV(TRACE); return e ? atoi(e) : 0; }
 
 /* What every plan creator (extz / extd, splice-aware, X-drop, SSE-compatible) starts with: the plan record and its per-pair host
  * arrays.  `with_order`: the task list is as long as the batch (one entry per pair) and allocated here. */
-static ksw2amd_plan_t *plan_new(const char *who, int n, int with_order)
+static ksw2amd_plan_t *plan_new(const char *who, int n, int with_order)      /* with_order < 0: extz / extd plans -- they initialise every record they use themselves */
 {
+	const int raw = with_order < 0;
 	ksw2amd_plan_t *p;
 	if (k2a_shim_device_count() <= 0) { fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend()); return 0; }
 	p = (ksw2amd_plan_t*)calloc(1, sizeof(*p));
 	if (!p) { fail(KSW2AMD_E_NOMEM, "%s: host allocation failed", who); return 0; }
 	p->n = n;
 	p->h_cls = (int8_t*)malloc((size_t)n + 1);
-	p->h_half = (uint8_t*)calloc((size_t)n + 1, 1);
+	p->h_half = raw ? (uint8_t*)malloc((size_t)n + 1) : (uint8_t*)calloc((size_t)n + 1, 1);
 	p->h_flag = (int32_t*)malloc(sizeof(int32_t) * ((size_t)n + 1));
-	p->h_pairs = (K2aPair*)calloc((size_t)n + 1, sizeof(K2aPair));
+	/* (65 536 records are 3.6 MB: clearing them was 0.15 ms of a 1 ms plan creation on config 2) */
+	p->h_pairs = raw ? (K2aPair*)malloc(((size_t)n + 1) * sizeof(K2aPair)) : (K2aPair*)calloc((size_t)n + 1, sizeof(K2aPair));
 	p->h_res = (K2aResult*)cache_get(BUF_HRES, sizeof(K2aResult) * ((size_t)n + 1), &p->cap[BUF_HRES]);
-	if (p->h_res) memset(p->h_res, 0, sizeof(K2aResult) * ((size_t)n + 1));
-	if (with_order) p->h_order = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n + 1));
-	if (!p->h_cls || !p->h_half || !p->h_flag || !p->h_pairs || !p->h_res || (with_order && !p->h_order)) {
+	/* (not cleared: a fetch overwrites all n records before anything reads one, and a plan that launches nothing never looks at them) */
+	if (with_order > 0) p->h_order = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n + 1));
+	if (!p->h_cls || !p->h_half || !p->h_flag || !p->h_pairs || !p->h_res || (with_order > 0 && !p->h_order)) {
 		fail(KSW2AMD_E_NOMEM, "%s: host allocation failed", who);
 		ksw2amd_plan_destroy(p);
 		return 0;
 	}
-	memset(p->h_cls, -1, (size_t)n + 1);
+	if (!raw) memset(p->h_cls, -1, (size_t)n + 1);
 	return p;
 }
 /* ... and ends with: the timing events from the thread's cache; the plan no longer refers to the creating thread's upload stream
@@ -591,8 +712,12 @@ static int pair_has_wild(const ksw2amd_pair_t *a)
 	return ((or_bytes(a->query, a->qlen) | or_bytes(a->target, a->tlen)) & 0xfcfcfcfcfcfcfcfcull) != 0;
 }
 
-static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, const flat_src_t *flat)
+static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, const flat_src_t *flat, int want_stream)
 {
+	stream_up_t *su = 0;                   /* streamed plans: the piece-wise upload */
+	int tmpl = -1, pcur = 0, nfull = 0, ninvalid = 0, uni = 0;   /* one-shape batches: the pair whose classification the others take over; piece cursor;
+	                                        * nfull: pairs classified in full; uni: ONE shape, no empty pair -- every per-pair array is one value */
+	int64_t tmpl_cells = 0;
 	double tph[6] = { 0, 0, 0, 0, 0, 0 };
 	const int tlev = trace_level() >= 2;
 	ksw2amd_plan_t *p;
@@ -616,11 +741,15 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	if (tlev) tph[0] = now_ms();
 	g_err[0] = 0;
 	if (n < 0 || (n > 0 && !pairs) || !sc) { fail(KSW2AMD_E_PARAM, "plan_create: bad arguments%s", 0); return 0; }
-	p = plan_new("plan_create", n, 0);
+	p = plan_new("plan_create", n, -1);
 	if (!p) return 0;
 	p->dual = !!dual; p->m = m = sc->m;
 	q = sc->q; e = sc->e; q2 = sc->q2; e2 = sc->e2;
-	for (i = 0; i < n; ++i) { p->h_cls[i] = -1; p->h_flag[i] = (pairs[i].flag & ~F_SCALAR_CONTRACT) | (scalar ? F_SCALAR_CONTRACT : 0); }
+	for (i = 0; i < n; ++i) {
+		p->h_cls[i] = -1; p->h_flag[i] = (pairs[i].flag & ~F_SCALAR_CONTRACT) | (scalar ? F_SCALAR_CONTRACT : 0);
+		if (pairs[i].qlen <= 0 || pairs[i].tlen <= 0) memset(&p->h_pairs[i], 0, sizeof(K2aPair));     /* never aligned; the others are set field by field below */
+	}
+	p->h_cls[n] = -1; memset(&p->h_pairs[n], 0, sizeof(K2aPair)); p->h_half[n] = 0;
 
 	/* batch-level early rejects of the "...2_sse" signatures; the scalar-contract entry points skip the
 	 * mismatch-vs-gap test (ksw_extz has none) but still need a usable matrix */
@@ -704,9 +833,78 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	pk_ok = (uint8_t*)calloc((size_t)n + 1, 1);
 	solo_ok = (uint8_t*)calloc((size_t)n + 1, 1);
 	if (!pk_ok || !solo_ok) { fail(KSW2AMD_E_NOMEM, "plan_create: host allocation failed%s", 0); goto err; }
-	{
+	/* A streamed plan (section "streamed plans"): the arena goes up in pieces, each followed by its watermark, on the device's
+	 * upload stream -- a flat arena's first pieces right here, before anything is classified; a gathered one piece by piece as the
+	 * pool's threads complete them (gather_start: the copy runs on while this thread lays the plan out and launches it; no scan for
+	 * wildcard codes -- the kernels report them, as in flat plans).  Only two pieces go up before the plan's small arrays (they would
+	 * queue behind the whole arena otherwise), the rest behind them.  Whether the plan then RUNS streamed is decided once its classes
+	 * are known; the pieces go up either way. */
+	if (stream_env() == 0) want_stream = 0; else if (stream_env() == 1) want_stream = 1;
+	if (want_stream && n > 0 && (p->seq_bytes >= ((size_t)1 << 20) || stream_env() == 1) && (su = (stream_up_t*)calloc(1, sizeof(*su))) != 0) {
+		const char *pk_ = ENV(STREAM_PIECE_KB);
+		size_t pbytes = pk_ && atol(pk_) > 0 ? (size_t)atol(pk_) << 10 : p->seq_bytes / (flat ? 12 : 24);
+		if (!(pk_ && atol(pk_) > 0)) { if (pbytes < ((size_t)1 << 20)) pbytes = (size_t)1 << 20; if (pbytes > ((size_t)32 << 20)) pbytes = (size_t)32 << 20; }
+		if (pbytes * K2A_MAXPIECES < p->seq_bytes) pbytes = p->seq_bytes / K2A_MAXPIECES + 1;
+		pbytes = align_up(pbytes, 256);
+		p->up_state = su;
+		su->t0 = now_ms();
+		pthread_mutex_init(&su->mu, 0);
+		su->wm_src = wm_source();
+		su->up = shared_upload_stream();
+		su->fault = env_flag(ENV(STREAM_FAULT), 0); su->sleep_us = ENV(STREAM_SLEEP_US) ? atoi(ENV(STREAM_SLEEP_US)) : 0;
+		su->hold = 2;
+		p->d_seq = (uint8_t*)cache_get(BUF_SEQ, p->seq_bytes, &p->cap[BUF_SEQ]);
+		p->d_wm = (uint8_t*)cache_get(BUF_WM, K2A_WM_BYTES + NCLS_ENTRIES * sizeof(K2aQueueDesc), &p->cap[BUF_WM]);
+		if (!su->wm_src || !su->up || !p->d_seq || !p->d_wm) { fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error()); goto err; }
+		su->d_seq = p->d_seq; su->d_wm = p->d_wm;
+		/* the watermark starts at zero: on the thread's own stream and waited for, so it is there before the first piece's watermark */
+		/* the watermark starts at zero: a DMA copy of a zero block at the head of the upload stream, in front of the first piece's
+		 * watermark; the stream the plan runs on waits for the event behind it.  (Not a memset: hipMemsetAsync + a wait on the thread's
+		 * own stream took 15-25 ms here, in steps of 5 -- a blit kernel behind the previous plan's DMA copies, round 4.) */
+		p->wm_ev = k2a_shim_event_create();
+		if (!p->wm_ev || k2a_shim_h2d(p->d_wm, (const uint8_t*)su->wm_src + (size_t)K2A_MAXPIECES * K2A_WM_BYTES, K2A_WM_BYTES, su->up) ||
+		    k2a_shim_event_record(p->wm_ev, su->up)) { fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error()); goto err; }
+		if (m > 5 && !flat) {
+			build_eff(dual, m, sc->mat, e, e2, 0, (int8_t*)p->h_seq + mat_off);
+			build_eff(dual, m, sc->mat, e, e2, 1, (int8_t*)p->h_seq + mat_off + (size_t)m * m);
+		}
+		if (flat) {
+			const size_t tail = p->seq_bytes - flat_span;
+			flat_tmp = (uint8_t*)calloc(tail ? tail : 1, 1);
+			if (!flat_tmp) { fail(KSW2AMD_E_NOMEM, "plan_create: host allocation failed%s", 0); goto err; }
+			if (m > 5) {
+				build_eff(dual, m, sc->mat, e, e2, 0, (int8_t*)flat_tmp + (mat_off - flat_span));
+				build_eff(dual, m, sc->mat, e, e2, 1, (int8_t*)flat_tmp + (mat_off - flat_span) + (size_t)m * m);
+			}
+			su->src = flat_lo; su->src_bytes = flat_span; su->tail = flat_tmp; su->src_on_device = flat->on_device; su->all_ready = 1;
+			su->np = (int)((p->seq_bytes + pbytes - 1) / pbytes);
+			for (k = 0; k <= su->np; ++k) su->pb[k] = (size_t)k * pbytes < p->seq_bytes ? (size_t)k * pbytes : p->seq_bytes;
+		} else {
+			/* gathered arenas: pieces start at pair boundaries (the copy's work units); the pairs lie in the arena in index order */
+			su->src = p->h_seq; su->src_bytes = p->seq_bytes;
+			su->np = 0; su->pb[0] = 0; su->pfirst[0] = 0;
+			for (i = 0; i < n; ++i)
+				if (pairs[i].qlen > 0 && pairs[i].tlen > 0 && p->h_pairs[i].qoff >= su->pb[su->np] + pbytes && su->np + 1 < K2A_MAXPIECES) {
+					++su->np; su->pb[su->np] = p->h_pairs[i].qoff; su->pfirst[su->np] = i;
+				}
+			++su->np; su->pb[su->np] = p->seq_bytes; su->pfirst[su->np] = n;
+			p->unscanned = 1;
+		}
+		p->npieces = su->np;
+		p->stream = su->up; p->stream_used = 1; shared_up = 1;
+		if (flat) stream_issue(su, -1);
+		else if (gather_start(p, su, pairs, n)) {           /* the pool cannot take it (a worker's own plan, another caller's batch): copy here, piece by piece */
+			copy_ctx_t cc;
+			cc.h_seq = p->h_seq; cc.hp = p->h_pairs; cc.pairs = pairs; cc.wild = 0; cc.su = su;
+			su->hold = su->np;
+			for (k = 0; k < su->np; ++k) { copy_range(&cc, su->pfirst[k], su->pfirst[k + 1]); stream_issue(su, k); }      /* (cc.su is not consulted by copy_range itself) */
+		}
+		if (su->rc) { fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error()); goto err; }
+	} else {
 		copy_ctx_t cc;
+		su = 0;
 		cc.h_seq = p->h_seq; cc.hp = p->h_pairs; cc.pairs = pairs; cc.wild = solo_ok;              /* (solo_ok doubles as the wildcard flags until the loop below sets it) */
+		cc.su = 0;
 		if (!flat && !parallel_copy(&cc, n, p->seq_bytes)) copy_range(&cc, 0, n);                   /* flat: nothing is copied, nothing scanned (wild = 0) */
 	}
 	for (i = 0; i < n; ++i) {
@@ -714,11 +912,32 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 		K2aPair *d = &p->h_pairs[i];
 		const int fl = p->h_flag[i];
 		int w = a->w, cfg, mode, generic, mx, wild;
-		if (a->qlen <= 0 || a->tlen <= 0) continue;
+		if (a->qlen <= 0 || a->tlen <= 0) { ++ninvalid; continue; }
 		wild = solo_ok[i]; solo_ok[i] = 0;
+		if (su) {                                             /* the upload piece this pair's last byte (+ what the kernels may touch behind it) lies in */
+			const size_t qe = (size_t)d->qoff + (size_t)a->qlen, te = (size_t)d->toff + (size_t)a->tlen, end = qe > te ? qe : te;
+			const size_t lim = end + K2A_STREAM_MARGIN < p->seq_bytes ? end + K2A_STREAM_MARGIN : p->seq_bytes;
+			while (pcur + 1 < su->np && su->pb[pcur + 1] < lim) ++pcur;
+			while (pcur > 0 && su->pb[pcur] >= lim) --pcur;
+			p->h_half[i] = (uint8_t)(pcur + 1);
+		}
+		/* one-shape batches (and runs of one shape inside ragged ones): everything below depends on the pair's shape, parameters and
+		 * flags only -- take it over from the last pair that was classified in full (a pair with a wildcard code never is a template,
+		 * nor one of the generation-serial class, whose boundary rows are per pair) */
+		if (tmpl >= 0 && !wild && a->qlen == pairs[tmpl].qlen && a->tlen == pairs[tmpl].tlen && a->w == pairs[tmpl].w && a->zdrop == pairs[tmpl].zdrop &&
+		    a->end_bonus == pairs[tmpl].end_bonus && fl == p->h_flag[tmpl]) {
+			const K2aPair *t = &p->h_pairs[tmpl];
+			d->qlen = t->qlen; d->tlen = t->tlen; d->tlen_full = t->tlen_full; d->w = t->w; d->zdrop = t->zdrop; d->end_bonus = t->end_bonus; d->flag = t->flag;
+			d->cig_off = 0; d->tb_off = 0; d->bnd_off = 0; d->pad = 0;
+			p->h_cls[i] = p->h_cls[tmpl]; pk_ok[i] = pk_ok[tmpl]; solo_ok[i] = solo_ok[tmpl];
+			p->cells += tmpl_cells;
+			continue;
+		}
 		mx = imax(a->qlen, a->tlen);
 		if (w < 0 || w > mx) w = mx;                                                               /* ksw2_extz2_sse.c:72 */
 		d->qlen = a->qlen; d->tlen_full = a->tlen; d->w = w;
+		d->cig_off = 0; d->tb_off = 0; d->bnd_off = 0; d->pad = 0;
+		++nfull;
 		d->tlen = (int64_t)a->qlen + w < a->tlen ? a->qlen + w : a->tlen;      /* rows i with i-w <= qlen-1 */
 		d->zdrop = a->zdrop;
 		d->end_bonus = scalar ? K2A_NEG : a->end_bonus;
@@ -732,7 +951,9 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 		generic = (fl & (KSW_EZ_GENERIC_SC | F_SCALAR_CONTRACT)) ? 1 : 0;
 		ci = (cfg * 3 + mode) * 2 + generic;
 		p->h_cls[i] = (int8_t)ci;
-		p->cells += band_cells(a->qlen, a->tlen, w);
+		tmpl_cells = band_cells(a->qlen, a->tlen, w);
+		p->cells += tmpl_cells;
+		tmpl = (!wild && cfg != K2A_CFG_MP) ? i : -1;
 		if (pkinfo[generic].ok < 0) pk_scoring(dual, m, sc->mat, q, e, q2, e2, generic, &pkinfo[generic]);
 		if (use_pk && pkinfo[generic].ok > 0 && a->qlen <= 65000 && a->tlen <= 65000 && !wild) {
 			/* packed class: first geometry that holds the band, 1-based; scores that fit 16 bits outright use the plain
@@ -747,7 +968,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 			if (pc == K2A_PKCFG_MP && !(cfg == K2A_CFG_MP && use_rb && use_pkmp && !is_approx(fl) && pk_slide_ok(&pkinfo[generic], a->qlen, d->tlen))) pc = K2A_NPKCFG;
 			/* (flat plans: the generation-serial kernels do not report wildcard codes, so a pair goes there only after a look at its
 			 * bytes -- which a device arena does not allow; the packed and the solo kernels report them and the host re-runs the pair) */
-			if (pc == K2A_PKCFG_MP && flat && (flat->on_device || pair_has_wild(a))) pc = K2A_NPKCFG;
+			if (pc == K2A_PKCFG_MP && (flat || p->unscanned) && ((flat && flat->on_device) || pair_has_wild(a))) pc = K2A_NPKCFG;
 			if (pc < K2A_NPKCFG) pk_ok[i] = (uint8_t)(1 + pc + ((plain && pc != K2A_PKCFG_MP) ? 0 : K2A_NPKCFG) + (is_approx(fl) ? 2 * K2A_NPKCFG : 0));
 			/* solo kernel: two strips of SC rows per lane, each with its own base (the window of an SC-row strip); a lane must finish
 			 * a double strip before its next one starts: 2 * 64 steps + 2 * SC * 64 columns later, against 2 * w + 2 * SC columns */
@@ -770,6 +991,12 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	 * one-alignment-per-wavefront geometry that is slower than the int32 kernel (tools/scripts/ragged_probe.py: 10 k reads of
 	 * unique lengths, CIGAR: 707 vs 825 GCUPS) and writes twice the direction bytes, so the odd one of every shape goes back.
 	 * Parity of every (class, shape) key in one pass over an open-addressing table. */
+	uni = n > 1 && nfull == 1 && ninvalid == 0;          /* (nothing below has changed a pair's class yet) */
+	if (uni && !ENV(KEEP_LEFTOVERS)) {
+		/* one shape: the table below has one key; its odd one out is the last pair */
+		if ((n & 1) && p->h_cls[0] >= 0 && pk_ok[0] && pk_ok[0] != PASS_SOLO && ((p->h_cls[0] / 2) % 3 != K2A_MODE_SCORE || (solo_mode && solo_ok[0])) &&
+		    k2a_pkcfg_G[(pk_ok[0] - 1) % K2A_NPKCFG] == 64) { pk_ok[n - 1] = (uint8_t)(solo_mode && solo_ok[n - 1] ? PASS_SOLO : 0); uni = 0; }
+	} else
 	if (n > 0 && !ENV(KEEP_LEFTOVERS)) {
 		size_t cap = 16, h;
 		struct slot { uint64_t k1, k2; int32_t last, odd; } *tab;
@@ -813,6 +1040,8 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 		if (simds > 0) {
 			int cnt[NCLS_MAX * NPASS], b;
 			memset(cnt, 0, sizeof(cnt));
+			if (uni) { if (p->h_cls[0] >= 0 && pk_ok[0] && pk_ok[0] != PASS_SOLO) cnt[p->h_cls[0] * NPASS + pk_ok[0]] = n; }
+			else
 			for (i = 0; i < n; ++i) if (p->h_cls[i] >= 0 && pk_ok[i] && pk_ok[i] != PASS_SOLO) ++cnt[p->h_cls[i] * NPASS + pk_ok[i]];
 			for (b = 0; b < NCLS_MAX * NPASS; ++b)
 				if (cnt[b]) {
@@ -822,6 +1051,8 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 					 * fraction of a millisecond per call and costs 2-3 x the SIMD time, which concurrent callers would rather keep */
 					cnt[b] = G != 64 ? 0 : (solo_mode == 3 && pcb != K2A_PKCFG_MP && cnt[b] <= simds ? 2 : 0) | (waves * 10 < (int64_t)simds * 4 ? 1 : 0);   /* 2 = solo, 1 = int32 */
 				}
+			if (uni && !(p->h_cls[0] >= 0 && pk_ok[0] && pk_ok[0] != PASS_SOLO && cnt[p->h_cls[0] * NPASS + pk_ok[0]])) { /* one shape, nothing to demote */ }
+			else
 			for (i = 0; i < n; ++i)
 				if (p->h_cls[i] >= 0 && pk_ok[i] && pk_ok[i] != PASS_SOLO) {
 					const int what = cnt[p->h_cls[i] * NPASS + pk_ok[i]];
@@ -836,11 +1067,11 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 
 	if (tlev) tph[3] = now_ms();
 	/* the sequence arena goes up while the host sorts out the task lists (pinned staging: the copy is asynchronous) */
-	if (m > 5 && !flat) {
+	if (m > 5 && !flat && !su) {
 		build_eff(dual, m, sc->mat, e, e2, 0, (int8_t*)p->h_seq + mat_off);
 		build_eff(dual, m, sc->mat, e, e2, 1, (int8_t*)p->h_seq + mat_off + (size_t)m * m);
 	}
-	p->d_seq = (uint8_t*)cache_get(BUF_SEQ, p->seq_bytes, &p->cap[BUF_SEQ]);
+	if (!su) p->d_seq = (uint8_t*)cache_get(BUF_SEQ, p->seq_bytes, &p->cap[BUF_SEQ]);
 	if (!p->d_seq) { fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error()); goto err; }
 	/* Big uploads go through ONE stream per device, whoever issues them: the chunks of a big batch are packed by several worker
 	 * threads at once, and six 80 MB copies on six streams share the link -- all of them arrive after 9-13 ms and the device idles
@@ -849,10 +1080,11 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	 * end, config 2 968 -> 1 165, 10 k with CIGAR 1 290 -> 1 321; config 3's 8 MB chunks and config 5 unchanged within noise).  Plans
 	 * under 16 MB (single calls, coalesced batches, small chunks) keep the calling thread's own stream and wait for it: an event per
 	 * call would only add latency there.  KSW2AMD_NO_SHARED_UP=1: the old behaviour, for A/B runs. */
-	up = (flat && !flat->on_device) || (!flat && p->seq_bytes >= ((size_t)16 << 20) && !ENV(NO_SHARED_UP)) ? shared_upload_stream() : 0;
+	up = su ? su->up : (flat && !flat->on_device) || (!flat && p->seq_bytes >= ((size_t)16 << 20) && !ENV(NO_SHARED_UP)) ? shared_upload_stream() : 0;
 	if (up) shared_up = 1; else up = thread_upload_stream();
 	p->stream = up; p->stream_used = 1;              /* plan_destroy waits for it before the buffers are recycled */
-	if (flat) {
+	if (su) { /* the pieces are on their way (or there) already */ }
+	else if (flat) {
 		/* the arena's span as it lies there (an upload from caller memory: asynchronous if the caller page-locked it,
 		 * ksw2amd_host_register); the padding behind it and the matrices of a wide alphabet from a small staging block */
 		const size_t tail = p->seq_bytes - flat_span;
@@ -874,12 +1106,16 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 		enum { NB = NCLS_MAX * NPASS };
 		int bcnt[NB], bpos[NB], b;
 		p->ncls = 0; p->ntasks = 0;
-		p->h_order = (uint32_t*)malloc(sizeof(uint32_t) * (2 * (size_t)n + 2));
+		p->h_order = (uint32_t*)malloc(sizeof(uint32_t) * (3 * (size_t)n + 4));      /* task lists (two entries per packed task) + streamed plans' per-wavefront-task piece counts */
 		srt = (sort_t*)malloc(sizeof(sort_t) * ((size_t)n + 1));
 		if (!p->h_order || !srt) { fail(KSW2AMD_E_NOMEM, "plan_create: host allocation failed%s", 0); goto err; }
 		memset(bcnt, 0, sizeof(bcnt));
+		if (uni) bcnt[p->h_cls[0] * NPASS + pk_ok[0]] = n;        /* one shape, one class: the task list is the batch in its own order */
+		else
 		for (i = 0; i < n; ++i) if (p->h_cls[i] >= 0) ++bcnt[p->h_cls[i] * NPASS + pk_ok[i]];
 		for (b = 0, k = 0; b < NB; ++b) { bpos[b] = k; k += bcnt[b]; }
+		if (uni) { for (b = 0; b < NB; ++b) bpos[b] += bcnt[b]; }
+		else
 		for (i = 0; i < n; ++i)
 			if (p->h_cls[i] >= 0) {
 				sort_t *e_ = &srt[bpos[p->h_cls[i] * NPASS + pk_ok[i]]++];
@@ -894,14 +1130,20 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 			cls_t *c;
 			if (cnt == 0) continue;
 			ci = b / NPASS;
+			if (!uni) {
 			for (i = 1; i < cnt && cmp_cost_desc(&g[i - 1], &g[i]) <= 0; ++i) {}       /* one shape: already in order */
 			if (i < cnt) qsort(g, (size_t)cnt, sizeof(sort_t), cmp_cost_desc);
+			}
 			c = &p->cls[p->ncls++];
 			c->solo = pass == PASS_SOLO;
 			c->cfg = c->solo ? 0 : pass ? (pass - 1) % K2A_NPKCFG : ci / 6; c->rb = pass && !c->solo ? ((pass - 1) / K2A_NPKCFG) & 1 : 0;
 			c->nomax = !c->solo && pass > 2 * K2A_NPKCFG; c->mode = (ci / 2) % 3; c->generic = ci & 1; c->pk = pass != 0 && !c->solo; c->first = k;
 			build_scoring(dual, m, sc->mat, q, e, q2, e2, c->generic, &c->sc);
 			c->sc.pk_a = pkinfo[c->generic].a; c->sc.pk_b = pkinfo[c->generic].b; c->sc.pk_n = pkinfo[c->generic].n;
+			if (uni) {
+				if (!pass || c->solo) { for (i = 0; i < cnt; ++i) p->h_order[k++] = (uint32_t)i; ntask = cnt; }
+				else for (i = 0; i < cnt; i += 2, ++ntask) { p->h_order[k++] = (uint32_t)i; p->h_order[k++] = (uint32_t)(i + 1 < cnt ? i + 1 : i); }
+			} else
 			if (!pass || c->solo) {
 				for (i = 0; i < cnt; ++i) p->h_order[k++] = g[i].idx;
 				ntask = cnt;
@@ -1018,8 +1260,44 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 			p->cig_words += (size_t)da->qlen + da->tlen_full + 2;
 			if (ib != ia) { db->cig_off = (uint32_t)p->cig_words; p->cig_words += (size_t)db->qlen + db->tlen_full + 2; }
 			if (p->cig_words > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "plan_create: CIGAR scratch over 16 GiB in one plan%s", 0); goto err; }
-			p->h_half[ia] = c->pk ? 1 : 0;
-			if (ib != ia) p->h_half[ib] = 2;
+		}
+	}
+
+	/* streamed plans: which classes run as queues (the resident packed kernels), their descriptors, and per wavefront-task the
+	 * pieces it has to wait for */
+	for (k = 0; k < p->ncls; ++k) p->cls[k].qd = -1;
+	if (su) {
+		size_t at = 0;
+		const char *te = ENV(STREAM_TIMEOUT_MS);
+		const uint64_t ticks = (uint64_t)(te && atoi(te) > 0 ? atoi(te) : 2000) * 100000u;      /* 100 MHz wall clock */
+		for (k = 0; k < p->ncls; ++k) {
+			cls_t *c = &p->cls[k];
+			if (c->pk && !c->solo && c->cfg != K2A_PKCFG_MP) c->qd = p->nqd++;
+		}
+		if (p->nqd) {
+			p->h_qd = (K2aQueueDesc*)calloc((size_t)p->nqd, sizeof(K2aQueueDesc));
+			if (!p->h_qd) { fail(KSW2AMD_E_NOMEM, "plan_create: host allocation failed%s", 0); goto err; }
+			for (k = 0; k < p->ncls; ++k) {
+				const cls_t *c = &p->cls[k];
+				const int NG = c->qd >= 0 ? 64 / k2a_pkcfg_G[c->cfg] : 1, nwt = (c->count + NG - 1) / NG;
+				uint32_t *need = p->h_order + p->norder + at;
+				int wt, t;
+				if (c->qd < 0) continue;
+				for (wt = 0; wt < nwt; ++wt) {
+					uint32_t nd = 0;
+					for (t = wt * NG; t < imin(c->count, (wt + 1) * NG); ++t) {
+						const uint32_t na = p->h_half[p->h_order[c->first + 2 * t]], nb = p->h_half[p->h_order[c->first + 2 * t + 1]];
+						if (na > nd) nd = na;
+						if (nb > nd) nd = nb;
+					}
+					need[wt] = nd;
+				}
+				p->h_qd[c->qd].nwt = (uint32_t)nwt; p->h_qd[c->qd].timeout_ticks = ticks;
+				p->h_qd[c->qd].pad = (uint32_t)at;             /* (host side only: where this class's piece counts start) */
+				at += (size_t)nwt;
+			}
+			p->need_words = at;
+			p->streamed = 1;
 		}
 	}
 
@@ -1027,7 +1305,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	/* upload the rest */
 	p->d_pairs = (K2aPair*)cache_get(BUF_PAIRS, sizeof(K2aPair) * ((size_t)n + 1), &p->cap[BUF_PAIRS]);
 	p->d_res = (K2aResult*)cache_get(BUF_RES, sizeof(K2aResult) * ((size_t)n + 1), &p->cap[BUF_RES]);
-	p->d_order = (uint32_t*)cache_get(BUF_ORDER, sizeof(uint32_t) * ((size_t)p->norder + 1), &p->cap[BUF_ORDER]);
+	p->d_order = (uint32_t*)cache_get(BUF_ORDER, sizeof(uint32_t) * ((size_t)p->norder + p->need_words + 1), &p->cap[BUF_ORDER]);
 	p->d_tb = p->tb_bytes ? (uint8_t*)cache_get(BUF_TB, p->tb_bytes, &p->cap[BUF_TB]) : 0;
 	p->d_cig = p->cig_words ? (uint32_t*)cache_get(BUF_CIG, p->cig_words * 4, &p->cap[BUF_CIG]) : 0;
 	p->d_bnd = p->bnd_words ? (int32_t*)cache_get(BUF_BND, p->bnd_words * 4, &p->cap[BUF_BND]) : 0;
@@ -1037,6 +1315,50 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 		goto err;
 	}
 	if (shared_up) p->up_ev = k2a_shim_event_create();
+	if (su) {
+		/* a streamed plan's small arrays go up on the upload stream itself, between the second piece and the third (su->hold): nothing
+		 * of the plan waits on the host for them -- the stream the plan runs on waits for the event behind them (meta_ev), then the
+		 * persistent launches start.  (On a stream of their own with a host-side wait they took 15-25 ms whenever the DMA engines
+		 * were busy with the pieces: round 4, every process but the first on a box.)  up_ev marks the end of the pieces: unstreamed
+		 * classes of the plan, a repeated run after an abort and plan_destroy wait for it. */
+		for (k = 0; k < p->nqd; ++k) {
+			p->h_qd[k].need = p->d_order + p->norder + p->h_qd[k].pad; p->h_qd[k].pad = 0;
+			p->h_qd[k].wm = (const uint32_t*)p->d_wm;
+		}
+		p->meta_ev = k2a_shim_event_create();
+		/* ... from page-locked staging: copies the DMA engines do by themselves, like the pieces.  (From pageable memory the runtime
+		 * stages them with the caller waiting; a memset is a kernel.  The result records need no clearing when every class of the plan
+		 * is a queue class: k2a_finish writes all of a record.) */
+		{
+			const size_t b_pairs = align_up(sizeof(K2aPair) * (size_t)n, 256), b_order = align_up(sizeof(uint32_t) * ((size_t)p->norder + p->need_words), 256),
+			             b_qd = sizeof(K2aQueueDesc) * (size_t)p->nqd;
+			int all_queues = p->nqd > 0;
+			for (k = 0; k < p->ncls; ++k) if (p->cls[k].qd < 0) all_queues = 0;
+			p->h_meta = (uint8_t*)cache_get(BUF_HMETA, b_pairs + b_order + b_qd + 256, &p->cap[BUF_HMETA]);
+			if (!p->h_meta) { fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
+			memcpy(p->h_meta, p->h_pairs, sizeof(K2aPair) * (size_t)n);
+			memcpy(p->h_meta + b_pairs, p->h_order, sizeof(uint32_t) * ((size_t)p->norder + p->need_words));
+			if (b_qd) memcpy(p->h_meta + b_pairs + b_order, p->h_qd, b_qd);
+		pthread_mutex_lock(&su->mu);                        /* (the gather's workers issue pieces on the same stream: keep the order) */
+		if (!p->meta_ev ||
+		    k2a_shim_h2d(p->d_pairs, p->h_meta, sizeof(K2aPair) * (size_t)n, up) ||
+		    k2a_shim_h2d(p->d_order, p->h_meta + b_pairs, sizeof(uint32_t) * ((size_t)p->norder + p->need_words), up) ||
+		    (p->nqd && k2a_shim_h2d(p->d_wm + K2A_WM_BYTES, p->h_meta + b_pairs + b_order, b_qd, up)) ||
+		    (!all_queues && k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)n, up)) ||
+		    (p->bnd_words && k2a_shim_memset(p->d_bnd, 0xC0, p->bnd_words * 4, up)) ||
+		    k2a_shim_event_record(p->meta_ev, up)) {
+			pthread_mutex_unlock(&su->mu);
+			fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error());
+			goto err;
+		}
+		su->hold = su->np;
+		pthread_mutex_unlock(&su->mu);
+		}
+		/* now the rest of the arena (what the gather has not completed yet follows as its workers get there) */
+		stream_issue(su, -1);
+		if (su->rc || !p->up_ev) { fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error()); goto err; }
+		if (!p->gather && k2a_shim_event_record(p->up_ev, up)) { fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error()); goto err; }   /* (with a gather in flight: recorded by gather_wait) */
+	} else
 	if (k2a_shim_h2d(p->d_pairs, p->h_pairs, sizeof(K2aPair) * (size_t)n, up) ||
 	    k2a_shim_h2d(p->d_order, p->h_order, sizeof(uint32_t) * (size_t)p->norder, up) ||
 	    k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)n, up) ||
@@ -1052,10 +1374,11 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	if (shared_up) { p->flat_tail = flat_tmp; flat_tmp = 0; }       /* still being read by the upload */
 	free(flat_tmp);
 	plan_ready(p);                                                  /* the uploads are complete (or fenced by up_ev) */
-	if (tlev) { const double t6 = now_ms(); fprintf(stderr, "[ksw2_amd] plan_create n=%d: host arrays + arena layout %.3f, copy + classify %.3f, shape parity + demotions %.3f, sequence upload call + task lists %.3f, traceback layout %.3f, uploads + sync %.3f ms\n", n, tph[1] - tph[0], tph[2] - tph[1], tph[3] - tph[2], tph[4] - tph[3] , tph[5] - tph[4], t6 - tph[5]); }
+	if (tlev) { const double t6 = now_ms(); char tmsg[96]; tmsg[0] = 0; if (su) snprintf(tmsg, sizeof(tmsg), "; streamed: %d pieces, %.3f ms in the upload calls so far", su->np, su->issue_ms); fprintf(stderr, "[ksw2_amd] plan_create n=%d: host arrays + arena layout %.3f, copy + classify %.3f, shape parity + demotions %.3f, sequence upload call + task lists %.3f, traceback layout %.3f, uploads + sync %.3f ms%s\n", n, tph[1] - tph[0], tph[2] - tph[1], tph[3] - tph[2], tph[4] - tph[3] , tph[5] - tph[4], t6 - tph[5], tmsg); }
 	return p;
 err:
-	if (flat_tmp && p && p->stream_used && p->stream) k2a_shim_stream_sync(p->stream);
+	if (p && p->gather) gather_wait(p);
+	if ((flat_tmp || su) && p && p->stream_used && p->stream) k2a_shim_stream_sync(p->stream);
 	free(srt); free(pk_ok); free(solo_ok); free(flat_tmp);
 	ksw2amd_plan_destroy(p);
 	return 0;
@@ -1063,7 +1386,7 @@ err:
 
 ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs)
 {
-	return plan_create_ex(dual, 0, sc, n, pairs, 0);
+	return plan_create_ex(dual, 0, sc, n, pairs, 0, 0);      /* (KSW2AMD_STREAM=1 streams these too: tests, A/B runs) */
 }
 
 static int exts_plan_run(ksw2amd_plan_t *p, void *stream);
@@ -1072,26 +1395,50 @@ static int ssec_plan_run(ksw2amd_plan_t *p, void *stream);
 
 int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 {
-	int c;
+	int c, streaming = 0, nrest = 0;
 	if (!p) return fail(KSW2AMD_E_PARAM, "plan_run: NULL plan%s", 0);
 	if (p->splice == 3) return ssec_plan_run(p, stream);
 	if (p->splice == 2) return extf_plan_run(p, stream);
 	if (p->splice) return exts_plan_run(p, stream);
 	p->stream = stream; p->ran = 1; p->stream_used = 1;
-	if (p->up_ev && k2a_shim_stream_wait_event(stream, p->up_ev)) goto err;      /* the plan's upload (shared stream) before its kernels */
+	if (p->gather && (!k2a_shim_async_launches() || !p->streamed)) gather_wait(p);      /* an ordinary launch, or one that runs inside the call, needs the whole arena */
+	streaming = p->streamed && p->nqd > 0;
+	if (p->up_ev && !streaming && k2a_shim_stream_wait_event(stream, p->up_ev)) goto err;      /* the plan's upload (shared stream) before its kernels */
 	if (p->reject_all || p->ntasks == 0) return KSW2AMD_OK;
 	if (k2a_shim_event_record(p->ev[0], stream)) goto err;
-	if (p->ncls > 1 && !ENV(SERIAL) && side_streams() == 0) {
+	if (streaming && ((p->wm_ev && k2a_shim_stream_wait_event(stream, p->wm_ev)) || (p->meta_ev && k2a_shim_stream_wait_event(stream, p->meta_ev)))) goto err;
+	if (streaming) {
+		/* streamed plan: every resident packed class as ONE persistent launch that starts now, under the upload, and takes its
+		 * wavefront-tasks as their pieces land (k2a_queue_pop); then, behind the whole upload, whatever else the plan holds */
+		K2aQueueDesc *d_qd = (K2aQueueDesc*)(p->d_wm + K2A_WM_BYTES);
+		__sync_fetch_and_add(&g_stream_stat[0], 1);
+		for (c = 0; c < p->ncls; ++c) {
+			const cls_t *k = &p->cls[c];
+			if (k->qd < 0) { ++nrest; continue; }
+			if (k2a_shim_memset(d_qd + k->qd, 0, 8, stream) ||           /* next = abort = 0 */
+			    k2a_shim_launch_fill_pk(k->cfg, p->dual, k->mode, k->rb, k->nomax, k->defer, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq,
+			                            p->d_tb, p->d_res, d_qd + k->qd, stream)) goto err;
+			if (k->mode != K2A_MODE_SCORE &&
+			    k2a_shim_launch_trace_pk(k->cfg, p->dual, p->d_pairs, p->d_order + k->first, k->count, p->d_tb, p->d_res, p->d_cig, stream)) goto err;
+		}
+		if (nrest == 0) {
+			if (k2a_shim_event_record(p->ev[1], stream) || k2a_shim_event_record(p->ev[2], stream)) goto err;
+			return KSW2AMD_OK;
+		}
+		if (p->up_ev && k2a_shim_stream_wait_event(stream, p->up_ev)) goto err;
+	} else nrest = p->ncls;
+	if (nrest > 1 && !ENV(SERIAL) && side_streams() == 0) {
 		/* several classes: fork them over the caller's stream and the side streams (fill, then that class's traceback, in
 		 * stream order), join on the caller's stream.  The fill / traceback split of plan_timing is then meaningless:
 		 * both report the whole run (KSW2AMD_SERIAL=1 restores the two-phase order for profiling). */
 		int used = 0, ord[NCLS_ENTRIES], x, y;
 		/* small classes first: their few wavefronts get their slots at once and run beside the big launches instead of after them */
-		for (c = 0; c < p->ncls; ++c) ord[c] = c;
-		for (x = 1; x < p->ncls; ++x)
+		int nord = 0;
+		for (c = 0; c < p->ncls; ++c) if (!(streaming && p->cls[c].qd >= 0)) ord[nord++] = c;      /* (streamed classes are running already) */
+		for (x = 1; x < nord; ++x)
 			for (y = x; y > 0 && p->cls[ord[y]].count < p->cls[ord[y - 1]].count; --y) { const int t = ord[y]; ord[y] = ord[y - 1]; ord[y - 1] = t; }
 		if (k2a_shim_event_record(g_side_ev[NSIDE], stream)) goto err;
-		for (x = 0; x < p->ncls; ++x) {
+		for (x = 0; x < nord; ++x) {
 			const cls_t *k = &p->cls[ord[x]];
 			const int lane = x % (NSIDE + 1);
 			void *s = lane == 0 ? stream : g_side[lane - 1];
@@ -1104,7 +1451,7 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 				if (k->cfg == K2A_PKCFG_MP ? k2a_shim_launch_fill_pkmp(p->dual, k->mode, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
 				                                                     (uint32_t*)p->d_bnd, p->d_res, s)
 				    : k2a_shim_launch_fill_pk(k->cfg, p->dual, k->mode, k->rb, k->nomax, k->defer, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq,
-				                            p->d_tb, p->d_res, s)) goto err;
+				                            p->d_tb, p->d_res, 0, s)) goto err;
 				if (k->mode != K2A_MODE_SCORE &&
 				    k2a_shim_launch_trace_pk(k->cfg, p->dual, p->d_pairs, p->d_order + k->first, k->count, p->d_tb, p->d_res, p->d_cig, s)) goto err;
 			} else {
@@ -1123,20 +1470,21 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 	}
 	for (c = 0; c < p->ncls; ++c) {
 		const cls_t *k = &p->cls[c];
+		if (streaming && k->qd >= 0) continue;
 		if (k->solo) {
 			if (k2a_shim_launch_fill_solo(p->dual, k->mode, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb, p->d_res, stream)) goto err;
 		} else if (k->pk) {
 			if (k->cfg == K2A_PKCFG_MP ? k2a_shim_launch_fill_pkmp(p->dual, k->mode, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
 			                                                     (uint32_t*)p->d_bnd, p->d_res, stream)
 			    : k2a_shim_launch_fill_pk(k->cfg, p->dual, k->mode, k->rb, k->nomax, k->defer, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
-			                            p->d_res, stream)) goto err;
+			                            p->d_res, 0, stream)) goto err;
 		} else if (k2a_shim_launch_fill(k->cfg, p->dual, k->mode, &k->sc, p->d_pairs, p->d_order + k->first, k->count, p->d_seq, p->d_tb,
 		                                p->d_bnd, p->d_res, stream)) goto err;
 	}
 	if (k2a_shim_event_record(p->ev[1], stream)) goto err;
 	for (c = 0; c < p->ncls; ++c) {
 		const cls_t *k = &p->cls[c];
-		if (k->mode == K2A_MODE_SCORE) continue;
+		if (k->mode == K2A_MODE_SCORE || (streaming && k->qd >= 0)) continue;
 		if (k->solo) {
 			if (k2a_shim_launch_trace_solo(p->d_pairs, p->d_order + k->first, k->count, p->d_tb, p->d_res, p->d_cig, stream)) goto err;
 		} else if (k->pk) {
@@ -1210,8 +1558,28 @@ int64_t ksw2amd_plan_device_bytes(const ksw2amd_plan_t *p)
 static int fetch_results(ksw2amd_plan_t *p)
 {
 	if (!p || !p->ran) return fail(KSW2AMD_E_PARAM, "plan_fetch: plan has not run%s", 0);
+	if (p->gather && gather_wait(p)) return fail(KSW2AMD_E_NODEVICE, "plan_fetch: upload failed: %s", k2a_shim_last_error());
 	if (p->reject_all || p->ntasks == 0) return KSW2AMD_OK;
-	if (k2a_shim_stream_sync(p->stream) || k2a_shim_d2h(p->h_res, p->d_res, sizeof(K2aResult) * (size_t)p->n, p->stream) ||
+	if (k2a_shim_stream_sync(p->stream)) return fail(KSW2AMD_E_NODEVICE, "plan_fetch: %s", k2a_shim_last_error());
+	if (p->streamed && p->nqd > 0) {
+		/* did every persistent launch get its inputs?  A wavefront that waited longer than the launch's timeout raised `abort` and the
+		 * queue was left unfinished: wait for the upload, then run the whole plan again the ordinary way (bounded, never a hang) */
+		K2aQueueDesc back[NCLS_ENTRIES];
+		int k, aborted = 0;
+		if (k2a_shim_d2h(back, p->d_wm + K2A_WM_BYTES, sizeof(K2aQueueDesc) * (size_t)p->nqd, p->stream) || k2a_shim_stream_sync(p->stream))
+			return fail(KSW2AMD_E_NODEVICE, "plan_fetch: %s", k2a_shim_last_error());
+		for (k = 0; k < p->nqd; ++k) aborted |= back[k].abort != 0 || back[k].next < back[k].nwt;
+		if (aborted) {
+			void *st = p->stream;
+			__sync_fetch_and_add(&g_stream_stat[1], 1);
+			if (trace_level()) fprintf(stderr, "[ksw2_amd] streamed plan n=%d: a launch gave up waiting for its inputs; running the plan again behind its upload\n", p->n);
+			p->streamed = 0;
+			if ((p->up_ev && k2a_shim_event_sync(p->up_ev)) || k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)p->n, st) ||
+			    ksw2amd_plan_run(p, st) || k2a_shim_stream_sync(st))
+				return fail(KSW2AMD_E_NODEVICE, "plan_fetch: %s", k2a_shim_last_error());
+		}
+	}
+	if (k2a_shim_d2h(p->h_res, p->d_res, sizeof(K2aResult) * (size_t)p->n, p->stream) ||
 	    k2a_shim_stream_sync(p->stream))
 		return fail(KSW2AMD_E_NODEVICE, "plan_fetch: %s", k2a_shim_last_error());
 	return KSW2AMD_OK;
@@ -1279,8 +1647,8 @@ static pthread_mutex_t g_km_mu = PTHREAD_MUTEX_INITIALIZER;
  *   K2aResult.pad[0] -- flat plans: a packed kernel met a wildcard code (K2aLanePk::seen); the gather path's scan sends the pair to
  *                       the int32 kernels.  Host arenas read the sequences where they lie, device arenas bring them back first;
  *   K2aResult.pad[1] -- deferred arg-max: a Z-drop could not be ruled out without the arg-max columns; the re-run keeps them. */
-static int run_serial(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez, int share, const flat_src_t *flat);
-static int needs_rerun(const ksw2amd_plan_t *p, int i) { return p->h_cls[i] >= 0 && !p->splice && ((p->flat && p->h_res[i].pad[0]) || p->h_res[i].pad[1]); }
+static int run_serial(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez, int share, const flat_src_t *flat, int want_stream);
+static int needs_rerun(const ksw2amd_plan_t *p, int i) { return p->h_cls[i] >= 0 && !p->splice && (((p->flat || p->unscanned) && p->h_res[i].pad[0]) || p->h_res[i].pad[1]); }
 static int pair_rerun(ksw2amd_plan_t *p, int i, void *km, ksw_extz_t *z)
 {
 	ksw2amd_pair_t a;
@@ -1300,52 +1668,25 @@ static int pair_rerun(ksw2amd_plan_t *p, int i, void *km, ksw_extz_t *z)
 		a.query = tmp; a.target = tmp + a.qlen;
 	}
 	++g_no_defer;
-	rc = run_serial(p->dual, p->scalar, km, &p->src_sc, 1, &a, z, 1, 0);
+	rc = run_serial(p->dual, p->scalar, km, &p->src_sc, 1, &a, z, 1, 0, 0);
 	--g_no_defer;
 	__sync_fetch_and_add(&g_reruns, 1);
 	free(tmp);
 	return rc;
 }
 
-/* results into ez[i] with CIGAR memory from `km`, or -- the coalesced single calls -- into *ezp[i] with memory from kmp[i] */
-static int plan_fetch_ex(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez, ksw_extz_t **ezp, void **kmp)
+/* results of pairs [beg, end) into the caller's records: ez[i] with CIGAR memory from `km`, or -- the coalesced single calls -- *ezp[i]
+ * with memory from kmp[i] */
+typedef struct { ksw2amd_plan_t *p; void *km; ksw_extz_t *ez, **ezp; void **kmp; const uint32_t *pool; const size_t *pos; int nrerun, rc; } asm_ctx_t;
+static void assemble_range(asm_ctx_t *c, int beg, int end)
 {
-	int i, rc = fetch_results(p), nrerun = 0;
-	uint32_t *pool = 0;
-	size_t total = 0, *pos = 0, cap_hpool = 0;
-	if (rc) return rc;
-	if (!p->reject_all && p->cig_words) {
-		/* bring every CIGAR back with one D2H: prefix-sum the counts, compact on the device, download the pool */
-		uint32_t *hpos = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)p->n + 1)), *d_pos = 0, *d_pool = 0;
-		size_t cap_pos = 0, cap_pool = 0;
-		int bad = 0;
-		pos = (size_t*)malloc(sizeof(size_t) * ((size_t)p->n + 1));
-		if (!hpos || !pos) { free(hpos); free(pos); return fail(KSW2AMD_E_NOMEM, "plan_fetch: host allocation failed%s", 0); }
-		for (i = 0; i < p->n; ++i) {
-			if (p->h_cls[i] < 0) p->h_res[i].n_cigar = 0;
-			pos[i] = total; hpos[i] = (uint32_t)total;
-			total += (size_t)p->h_res[i].n_cigar;
-		}
-		/* pinned (from the thread's cache): a download into pageable memory is staged by the runtime at a third of the link's
-		 * rate, and config 5's CIGARs are 200 MB per batch */
-		pool = (uint32_t*)cache_get(BUF_HPOOL, sizeof(uint32_t) * (total + 1), &cap_hpool);
-		if (!pool) { free(hpos); free(pos); return fail(KSW2AMD_E_NOMEM, "plan_fetch: host allocation failed%s", 0); }
-		if (total > 0) {
-			/* device scratch from the thread's buffer cache: an allocation costs milliseconds and synchronises the device */
-			d_pos = (uint32_t*)cache_get(BUF_POS, sizeof(uint32_t) * (size_t)p->n, &cap_pos);
-			d_pool = (uint32_t*)cache_get(BUF_POOL, sizeof(uint32_t) * total, &cap_pool);
-			bad = !d_pos || !d_pool || total > 0xfff00000u ||
-			      k2a_shim_h2d(d_pos, hpos, sizeof(uint32_t) * (size_t)p->n, p->stream) ||
-			      k2a_shim_launch_compact(p->d_pairs, p->d_res, d_pos, p->n, p->d_cig, d_pool, p->stream) ||
-			      k2a_shim_d2h(pool, d_pool, sizeof(uint32_t) * total, p->stream) || k2a_shim_stream_sync(p->stream);
-			if (bad) k2a_shim_stream_sync(p->stream);
-			cache_put(BUF_POS, d_pos, cap_pos); cache_put(BUF_POOL, d_pool, cap_pool);
-		}
-		free(hpos);
-		if (bad) { free(pos); cache_put(BUF_HPOOL, pool, cap_hpool); return fail(KSW2AMD_E_NODEVICE, "plan_fetch: %s", k2a_shim_last_error()); }
-	}
-	if (km || kmp) pthread_mutex_lock(&g_km_mu);
-	for (i = 0; i < p->n; ++i) {
+	ksw2amd_plan_t *p = c->p;
+	ksw_extz_t *ez = c->ez, **ezp = c->ezp;
+	void *km = c->km, **kmp = c->kmp;
+	const uint32_t *pool = c->pool;
+	const size_t *pos = c->pos;
+	int i, nrerun = 0, rc = KSW2AMD_OK;
+	for (i = beg; i < end; ++i) {
 		ksw_extz_t *z = ezp ? ezp[i] : &ez[i];
 		const K2aResult *r = &p->h_res[i];
 		if (kmp) km = kmp[i];
@@ -1382,10 +1723,62 @@ static int plan_fetch_ex(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez, ksw_extz_t
 			}
 		}
 	}
-	if (km || kmp) pthread_mutex_unlock(&g_km_mu);
+	if (nrerun) __sync_fetch_and_add(&c->nrerun, nrerun);
+	if (rc) c->rc = rc;
+}
+static int assemble_parallel(asm_ctx_t *c);
+static int rerun_pairs(ksw2amd_plan_t *p, int nrerun, void *km, ksw_extz_t *ez, ksw_extz_t **ezp, void **kmp);
+
+static int plan_fetch_ex(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez, ksw_extz_t **ezp, void **kmp)
+{
+	int i, rc = fetch_results(p), nrerun = 0;
+	uint32_t *pool = 0;
+	size_t total = 0, *pos = 0, cap_hpool = 0;
+	if (rc) return rc;
+	if (!p->reject_all && p->cig_words) {
+		/* bring every CIGAR back with one D2H: prefix-sum the counts, compact on the device, download the pool */
+		uint32_t *hpos = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)p->n + 1)), *d_pos = 0, *d_pool = 0;
+		size_t cap_pos = 0, cap_pool = 0;
+		int bad = 0;
+		pos = (size_t*)malloc(sizeof(size_t) * ((size_t)p->n + 1));
+		if (!hpos || !pos) { free(hpos); free(pos); return fail(KSW2AMD_E_NOMEM, "plan_fetch: host allocation failed%s", 0); }
+		for (i = 0; i < p->n; ++i) {
+			if (p->h_cls[i] < 0) p->h_res[i].n_cigar = 0;
+			pos[i] = total; hpos[i] = (uint32_t)total;
+			total += (size_t)p->h_res[i].n_cigar;
+		}
+		/* pinned (from the thread's cache): a download into pageable memory is staged by the runtime at a third of the link's
+		 * rate, and config 5's CIGARs are 200 MB per batch */
+		pool = (uint32_t*)cache_get(BUF_HPOOL, sizeof(uint32_t) * (total + 1), &cap_hpool);
+		if (!pool) { free(hpos); free(pos); return fail(KSW2AMD_E_NOMEM, "plan_fetch: host allocation failed%s", 0); }
+		if (total > 0) {
+			/* device scratch from the thread's buffer cache: an allocation costs milliseconds and synchronises the device */
+			d_pos = (uint32_t*)cache_get(BUF_POS, sizeof(uint32_t) * (size_t)p->n, &cap_pos);
+			d_pool = (uint32_t*)cache_get(BUF_POOL, sizeof(uint32_t) * total, &cap_pool);
+			bad = !d_pos || !d_pool || total > 0xfff00000u ||
+			      k2a_shim_h2d(d_pos, hpos, sizeof(uint32_t) * (size_t)p->n, p->stream) ||
+			      k2a_shim_launch_compact(p->d_pairs, p->d_res, d_pos, p->n, p->d_cig, d_pool, p->stream) ||
+			      k2a_shim_d2h(pool, d_pool, sizeof(uint32_t) * total, p->stream) || k2a_shim_stream_sync(p->stream);
+			if (bad) k2a_shim_stream_sync(p->stream);
+			cache_put(BUF_POS, d_pos, cap_pos); cache_put(BUF_POOL, d_pool, cap_pool);
+		}
+		free(hpos);
+		if (bad) { free(pos); cache_put(BUF_HPOOL, pool, cap_hpool); return fail(KSW2AMD_E_NODEVICE, "plan_fetch: %s", k2a_shim_last_error()); }
+	}
+	{
+		asm_ctx_t ac;
+		ac.p = p; ac.km = km; ac.ez = ez; ac.ezp = ezp; ac.kmp = kmp; ac.pool = pool; ac.pos = pos; ac.nrerun = 0; ac.rc = KSW2AMD_OK;
+		/* a big score-only plan (a streamed batch: one plan for everything): its records are assembled by the pool's threads, as the
+		 * chunks of the same batch were before -- 65 536 ksw_extz_t of config 2 are 1.3 ms on one thread, next to a 1.4 ms kernel */
+		if (!(!p->cig_words && !km && !kmp && p->n >= 16384 && assemble_parallel(&ac))) {
+			if (km || kmp) pthread_mutex_lock(&g_km_mu);
+			assemble_range(&ac, 0, p->n);
+			if (km || kmp) pthread_mutex_unlock(&g_km_mu);
+		}
+		nrerun = ac.nrerun; if (ac.rc) rc = ac.rc;
+	}
 	free(pos); cache_put(BUF_HPOOL, pool, cap_hpool);
-	for (i = 0; nrerun > 0 && i < p->n && rc == KSW2AMD_OK; ++i)
-		if (needs_rerun(p, i)) rc = pair_rerun(p, i, kmp ? kmp[i] : km, ezp ? ezp[i] : &ez[i]);
+	if (nrerun > 0 && rc == KSW2AMD_OK) rc = rerun_pairs(p, nrerun, km, ez, ezp, kmp);
 	return rc;
 }
 
@@ -1443,7 +1836,7 @@ static size_t pair_device_bytes(int dual, const ksw2amd_pair_t *a)
 static double now_ms(void);
 static int trace_on(void);
 static int unit_pairs(const ksw2amd_pair_t *a);
-static int run_serial(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez, int share, const flat_src_t *flat)
+static int run_serial(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez, int share, const flat_src_t *flat, int want_stream)
 {
 	size_t budget, free_b = 0, total_b = 0, acc;
 	const char *env = ENV(MAX_BYTES);
@@ -1482,7 +1875,7 @@ static int run_serial(int dual, int scalar, void *km, const ksw2amd_scoring_t *s
 		t0 = now_ms();
 		for (p = 0; p == 0; ) {
 			if (end - beg > limit) end = beg + limit;
-			p = plan_create_ex(dual, scalar, sc, end - beg, pairs + beg, flat);
+			p = plan_create_ex(dual, scalar, sc, end - beg, pairs + beg, flat, want_stream && beg == 0 && end == n);
 			if (p) break;
 			if (!strstr(g_err, "alloc") || end - beg <= 1) return strstr(g_err, "alloc") ? KSW2AMD_E_NOMEM : g_err[0] && strstr(g_err, "device") ? KSW2AMD_E_NODEVICE : KSW2AMD_E_PARAM;
 			release_thread_cache();
@@ -1495,8 +1888,13 @@ static int run_serial(int dual, int scalar, void *km, const ksw2amd_scoring_t *s
 			t2 = now_ms();
 			if (rc == KSW2AMD_OK) rc = ksw2amd_plan_fetch(p, km, ez + beg);
 			t3 = now_ms();
-			ksw2amd_plan_destroy(p);
-			if (trace_on()) fprintf(stderr, "[ksw2_amd] serial plan @%d n=%d: create %.2f ms, launch %.2f ms, wait+fetch %.2f ms, destroy %.2f ms, budget %zu\n", beg, end - beg, t1 - t0, t2 - t1, t3 - t2, now_ms() - t3, budget);
+			if (!trace_on()) { ksw2amd_plan_destroy(p); p = 0; }
+			if (trace_on()) {
+				float dev_ms = -1.0f;
+				if (rc == KSW2AMD_OK && p->ran && !p->reject_all && p->ntasks > 0) dev_ms = k2a_shim_event_ms(p->ev[0], p->ev[2]);
+				ksw2amd_plan_destroy(p); p = 0;
+				fprintf(stderr, "[ksw2_amd] serial plan @%d n=%d: create %.2f ms, launch %.2f ms, wait+fetch %.2f ms (device: %.2f ms from the first launch to the last kernel's end), destroy %.2f ms, budget %zu\n", beg, end - beg, t1 - t0, t2 - t1, t3 - t2, dev_ms, now_ms() - t3, budget);
+			}
 		}
 		if (rc) return rc;
 		beg = end;
@@ -1525,12 +1923,12 @@ typedef struct {
 	int pending;                                /* participating workers still busy */
 } job_t;
 static struct {
-	pthread_mutex_t mu, submit;
-	pthread_cond_t work, done;
-	int nw, gen;
+	pthread_mutex_t mu;
+	pthread_cond_t work, done, idle;
+	int nw, gen, busy;
 	int dev[POOL_MAXW];
 	job_t *job;
-} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, 0, 0, {0}, 0 };
+} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, 0, 0, 0, {0}, 0 };
 static int64_t g_stat[4];                          /* pooled batches, their chunks, coalesced single calls, the batches they formed */
 static int g_ndev_set, g_dev_set[POOL_MAXDEV];     /* ksw2amd_set_devices(); 0 = the calling thread's device */
 static __thread int g_is_worker;
@@ -1589,12 +1987,16 @@ static int pool_threads_per_device(void)
 	return t < 0 ? 0 : t > 16 ? 16 : t;
 }
 
-/* run `j` on the pool (workers for its devices are created on first use); returns -1 if the pool cannot take it now */
-static int pool_run(job_t *j)
+/* pool_start + pool_wait = pool_run in two halves: the submitting thread does something else while the workers run the job (the
+ * gather of a streamed plan: plan_create_ex goes on to lay the plan out and launch it).  Between the two the pool is taken: other
+ * submitters, this thread included, run their work inline. */
+static int pool_start(job_t *j)
 {
 	int i, d, have;
-	if (g_is_worker || pthread_mutex_trylock(&g_pool.submit)) return -1;      /* busy with another caller's batch: that caller runs inline */
+	if (g_is_worker) return -1;
 	pthread_mutex_lock(&g_pool.mu);
+	if (g_pool.busy) { pthread_mutex_unlock(&g_pool.mu); return -1; }      /* busy with another caller's batch (or this thread's gather): that caller runs inline */
+	g_pool.busy = 1;                        /* (a flag under `mu`, not a mutex held across calls: the plan that owns a gather may be fetched by another thread) */
 	for (d = 0; d < j->ndev; ++d) {
 		for (i = 0, have = 0; i < g_pool.nw; ++i) have += g_pool.dev[i] == j->dev[d];
 		for (; have < j->share && g_pool.nw < POOL_MAXW; ++have) {
@@ -1611,14 +2013,26 @@ static int pool_run(job_t *j)
 		}
 	}
 	for (i = 0, j->pending = 0; i < g_pool.nw; ++i) j->pending += job_has_dev(j, g_pool.dev[i]);
-	if (j->pending == 0) { pthread_mutex_unlock(&g_pool.mu); pthread_mutex_unlock(&g_pool.submit); return -1; }
+	if (j->pending == 0) { g_pool.busy = 0; pthread_mutex_unlock(&g_pool.mu); return -1; }
 	g_pool.job = j; ++g_pool.gen;
 	if (!j->flush && !j->quiet) { g_stat[0] += 1; g_stat[1] += j->nchunks; }
 	pthread_cond_broadcast(&g_pool.work);
-	while (j->pending > 0) pthread_cond_wait(&g_pool.done, &g_pool.mu);
-	g_pool.job = 0;
 	pthread_mutex_unlock(&g_pool.mu);
-	pthread_mutex_unlock(&g_pool.submit);
+	return 0;
+}
+static void pool_wait(job_t *j)
+{
+	pthread_mutex_lock(&g_pool.mu);
+	while (j->pending > 0) pthread_cond_wait(&g_pool.done, &g_pool.mu);
+	g_pool.job = 0; g_pool.busy = 0;
+	pthread_cond_broadcast(&g_pool.idle);
+	pthread_mutex_unlock(&g_pool.mu);
+}
+/* run `j` on the pool (workers for its devices are created on first use); returns -1 if the pool cannot take it now */
+static int pool_run(job_t *j)
+{
+	if (pool_start(j)) return -1;
+	pool_wait(j);
 	return 0;
 }
 
@@ -1634,10 +2048,11 @@ int ksw2amd_set_devices(int n, const int *devices)
 	if (n < 0 || n > POOL_MAXDEV || (n > 0 && !devices)) return fail(KSW2AMD_E_PARAM, "set_devices: bad arguments%s", 0);
 	for (i = 0; i < n; ++i)
 		if (devices[i] < 0 || devices[i] >= k2a_shim_device_count()) return fail(KSW2AMD_E_NODEVICE, "set_devices: no such device%s", 0);
-	pthread_mutex_lock(&g_pool.submit);
+	pthread_mutex_lock(&g_pool.mu);
+	while (g_pool.busy) pthread_cond_wait(&g_pool.idle, &g_pool.mu);       /* not under a running batch */
 	for (i = 0; i < n; ++i) g_dev_set[i] = devices[i];
 	g_ndev_set = n;
-	pthread_mutex_unlock(&g_pool.submit);
+	pthread_mutex_unlock(&g_pool.mu);
 	return KSW2AMD_OK;
 }
 
@@ -1698,14 +2113,23 @@ static void copy_range(const copy_ctx_t *c, int beg, int end)
 	for (i = beg; i < end; ++i) {
 		const ksw2amd_pair_t *a = &c->pairs[i];
 		if (a->qlen <= 0 || a->tlen <= 0) continue;
-		c->wild[i] = (uint8_t)(copy_scan(c->h_seq + c->hp[i].qoff, a->query, a->qlen) | copy_scan(c->h_seq + c->hp[i].toff, a->target, a->tlen));
+		if (c->wild) c->wild[i] = (uint8_t)(copy_scan(c->h_seq + c->hp[i].qoff, a->query, a->qlen) | copy_scan(c->h_seq + c->hp[i].toff, a->target, a->tlen));
+		else { memcpy(c->h_seq + c->hp[i].qoff, a->query, (size_t)a->qlen); memcpy(c->h_seq + c->hp[i].toff, a->target, (size_t)a->tlen); }   /* unscanned (streamed plans) */
 		memset(c->h_seq + c->hp[i].toff + a->tlen, 0, 64);                                          /* rows read past the target end */
 	}
 }
 static int copy_chunk(void *ctx, int beg, int end, int share, pend_t *pd)
 {
+	const copy_ctx_t *c = (const copy_ctx_t*)ctx;
 	(void)share; (void)pd;
-	if (beg >= 0) copy_range((const copy_ctx_t*)ctx, beg, end);
+	if (beg >= 0) {
+		copy_range(c, beg, end);
+		if (c->su) {                                        /* a streamed plan: this chunk is part of a piece of the upload; the piece's last chunk issues what is ready */
+			int k = 0;
+			while (k + 1 < c->su->np && c->su->pfirst[k + 1] <= beg) ++k;
+			if (__sync_sub_and_fetch(&c->su->left[k], 1) == 0) stream_issue(c->su, k);
+		}
+	}
 	return KSW2AMD_OK;
 }
 /* 1 = the pool's threads did the copy.  Only for plans of 32 MB and more created outside the pool (a single-plan batch, a
@@ -1717,19 +2141,156 @@ static int parallel_copy(copy_ctx_t *c, int n, size_t bytes)
 	int cbeg[POOL_MAXW + 2], k, i, nch;
 	if (g_is_worker || tpd < 2 || n < 2 * tpd || bytes < ((size_t)32 << 20) || ENV(NO_PARCOPY)) return 0;
 	nch = imin(tpd, POOL_MAXW);
+	if (c->su) {                                           /* streamed plans: the upload's pieces are the work units, taken in order */
+		nch = imin(c->su->np, POOL_MAXW);
+		for (k = 0; k <= nch; ++k) cbeg[k] = c->su->pfirst[k];
+		for (k = 0; k < nch; ++k) c->su->left[k] = 1;
+	} else {
 	for (k = 0, i = 0; k < nch; ++k) {                     /* equal byte ranges of the arena (the pairs lie in it in order) */
 		const size_t edge = bytes / (size_t)nch * (size_t)k;
 		while (i < n && (c->pairs[i].qlen <= 0 || c->pairs[i].tlen <= 0 || c->hp[i].qoff < edge)) ++i;
 		cbeg[k] = k ? i : 0;
 	}
 	cbeg[nch] = n;
+	}
 	memset(&j, 0, sizeof(j));
 	j.fn = copy_chunk; j.ctx = c; j.cbeg = cbeg; j.nchunks = nch; j.quiet = 1;
 	j.ndev = 1;                                            /* the creating thread's device's workers */
 	j.dev[0] = k2a_shim_get_device(); if (j.dev[0] < 0) j.dev[0] = 0;
-	j.share = nch;
+	j.share = imin(nch, tpd);
 	if (pool_run(&j)) return 0;
 	return j.rc == 0;
+}
+
+/* the record assembly of a big plan on the pool's threads (plan_fetch_ex); 1 = done */
+static int asm_chunk(void *ctx, int beg, int end, int share, pend_t *pd)
+{
+	(void)share; (void)pd;
+	if (beg >= 0) assemble_range((asm_ctx_t*)ctx, beg, end);
+	return KSW2AMD_OK;
+}
+static int assemble_parallel(asm_ctx_t *c)
+{
+	const int tpd = pool_threads_per_device(), n = c->p->n;
+	job_t j;
+	int cbeg[POOL_MAXW + 2], k, nch;
+	if (g_is_worker || tpd < 2) return 0;
+	nch = imin(tpd, POOL_MAXW);
+	for (k = 0; k <= nch; ++k) cbeg[k] = (int)((int64_t)n * k / nch);
+	memset(&j, 0, sizeof(j));
+	j.fn = asm_chunk; j.ctx = c; j.cbeg = cbeg; j.nchunks = nch; j.quiet = 1;
+	j.ndev = 1;
+	j.dev[0] = k2a_shim_get_device(); if (j.dev[0] < 0) j.dev[0] = 0;
+	j.share = nch;
+	if (pool_run(&j)) return 0;
+	return 1;
+}
+
+/* Pairs whose device result cannot be used (needs_rerun) go through the ordinary gather path again -- as ONE batch: a batch of long
+ * reads of which a tenth may drop would otherwise pay a plan, a launch and a fetch per pair (round 3: one by one).  The coalesced
+ * single calls (one km per pair) keep the pair-by-pair form; they are single pairs to begin with. */
+static int rerun_pairs(ksw2amd_plan_t *p, int nrerun, void *km, ksw_extz_t *ez, ksw_extz_t **ezp, void **kmp)
+{
+	ksw2amd_pair_t *a;
+	ksw_extz_t *zz;
+	uint8_t *tmp = 0;
+	size_t tmp_bytes = 0, at = 0;
+	int i, k = 0, rc = KSW2AMD_OK;
+	if (kmp || nrerun == 1) {
+		for (i = 0; i < p->n && rc == KSW2AMD_OK; ++i)
+			if (needs_rerun(p, i)) rc = pair_rerun(p, i, kmp ? kmp[i] : km, ezp ? ezp[i] : &ez[i]);
+		return rc;
+	}
+	a = (ksw2amd_pair_t*)malloc(sizeof(*a) * (size_t)nrerun);
+	zz = (ksw_extz_t*)malloc(sizeof(*zz) * (size_t)nrerun);
+	if (!a || !zz) { free(a); free(zz); return fail(KSW2AMD_E_NOMEM, "plan_fetch: host allocation failed%s", 0); }
+	for (i = 0; i < p->n && k < nrerun; ++i) {
+		if (!needs_rerun(p, i)) continue;
+		if (p->flat) a[k] = p->src_pairs[i];
+		else {                                             /* from the staging copy and the resolved parameters */
+			const K2aPair *d = &p->h_pairs[i];
+			a[k].query = p->h_seq + d->qoff; a[k].target = p->h_seq + d->toff; a[k].qlen = d->qlen; a[k].tlen = d->tlen_full;
+			a[k].w = d->w; a[k].zdrop = d->zdrop; a[k].end_bonus = p->scalar ? 0 : d->end_bonus; a[k].flag = p->h_flag[i] & ~F_SCALAR_CONTRACT;
+		}
+		tmp_bytes += (size_t)a[k].qlen + (size_t)a[k].tlen;
+		zz[k] = ezp ? *ezp[i] : ez[i];
+		++k;
+	}
+	nrerun = k;
+	if (p->flat_device) {                                  /* the sequences are in device memory only: bring these pairs' back */
+		tmp = (uint8_t*)malloc(tmp_bytes + 1);
+		if (!tmp) { free(a); free(zz); return fail(KSW2AMD_E_NOMEM, "plan_fetch: host allocation failed%s", 0); }
+		for (k = 0; k < nrerun && rc == KSW2AMD_OK; ++k) {
+			if (k2a_shim_d2h(tmp + at, a[k].query, (size_t)a[k].qlen, p->stream) || k2a_shim_d2h(tmp + at + a[k].qlen, a[k].target, (size_t)a[k].tlen, p->stream))
+				rc = fail(KSW2AMD_E_NODEVICE, "plan_fetch: %s", k2a_shim_last_error());
+			a[k].query = tmp + at; a[k].target = tmp + at + a[k].qlen;
+			at += (size_t)a[k].qlen + (size_t)a[k].tlen;
+		}
+		if (k2a_shim_stream_sync(p->stream) && rc == KSW2AMD_OK) rc = fail(KSW2AMD_E_NODEVICE, "plan_fetch: %s", k2a_shim_last_error());
+	}
+	if (rc == KSW2AMD_OK) {
+		++g_no_defer;
+		rc = run_serial(p->dual, p->scalar, km, &p->src_sc, nrerun, a, zz, 1, 0, 0);
+		--g_no_defer;
+		__sync_fetch_and_add(&g_reruns, nrerun);
+	}
+	for (i = 0, k = 0; i < p->n && k < nrerun; ++i)
+		if (needs_rerun(p, i)) { if (ezp) *ezp[i] = zz[k]; else ez[i] = zz[k]; ++k; }      /* (CIGAR buffers may have moved: always copy back) */
+	free(a); free(zz); free(tmp);
+	return rc;
+}
+
+/* The gather of a streamed plan on the pool's threads, asynchronously: chunk k = piece k of the upload, copied (not scanned) into the
+ * pinned arena and issued by whichever worker closes the gap (copy_chunk -> stream_issue).  More threads than a batch's chunks get:
+ * the copy is memory-bound and a thread moves 4-5 GB/s (config 2: 67 MB in 2.8 ms on six).  0 = started; the plan owns the job until
+ * gather_wait(), which also records the event that marks the end of the plan's upload. */
+#define K2A_GATHER_SUB 8                /* copy chunks per upload piece: the first piece is complete after an eighth of a piece's copy time, not a whole one */
+struct gather_s { job_t j; copy_ctx_t cc; int cbeg[K2A_MAXPIECES * K2A_GATHER_SUB + 2]; };
+static int gather_start(ksw2amd_plan_t *p, stream_up_t *su, const ksw2amd_pair_t *pairs, int n)
+{
+	const int tpd = pool_threads_per_device();
+	struct gather_s *g;
+	int k, nth;
+	(void)n;
+	if (g_is_worker || tpd < 2 || ENV(NO_PARCOPY)) return -1;
+	g = (struct gather_s*)calloc(1, sizeof(*g));
+	if (!g) return -1;
+	nth = (int)(p->seq_bytes >> 22);                       /* a thread per 4 MB, between the batch workers' count and 24 */
+	nth = imax(tpd, imin(nth, 24)); nth = imin(nth, su->np * K2A_GATHER_SUB);
+	g->cc.h_seq = p->h_seq; g->cc.hp = p->h_pairs; g->cc.pairs = pairs; g->cc.wild = 0; g->cc.su = su;
+	{	/* the workers take the chunks in order (job_t.next), so the pieces complete roughly in order, the first one early */
+		int nc = 0, x;
+		for (k = 0; k < su->np; ++k) {
+			const int lo = su->pfirst[k], hi = su->pfirst[k + 1], sub = imax(1, imin(K2A_GATHER_SUB, hi - lo));
+			su->left[k] = sub;
+			for (x = 0; x < sub; ++x) g->cbeg[nc++] = lo + (int)((int64_t)(hi - lo) * x / sub);
+		}
+		g->cbeg[nc] = su->pfirst[su->np];
+		g->j.nchunks = nc;
+	}
+	g->j.fn = copy_chunk; g->j.ctx = &g->cc; g->j.cbeg = g->cbeg; g->j.quiet = 1;
+	g->j.ndev = 1;
+	g->j.dev[0] = k2a_shim_get_device(); if (g->j.dev[0] < 0) g->j.dev[0] = 0;
+	g->j.share = nth;
+	if (pool_start(&g->j)) { free(g); return -1; }
+	p->gather = g;
+	return 0;
+}
+static int gather_wait(ksw2amd_plan_t *p)
+{
+	struct gather_s *g = p->gather;
+	int rc = 0;
+	if (!g) return 0;
+	pool_wait(&g->j);
+	p->gather = 0;
+	if (trace_level() >= 2 && p->up_state) fprintf(stderr, "[ksw2_amd]   gather of %zu MB on %d threads: first piece issued +%.2f ms, last piece +%.2f ms, waited for at +%.2f ms of the plan\n", p->seq_bytes >> 20, g->j.share, p->up_state->t_first - p->up_state->t0, p->up_state->t_last - p->up_state->t0, now_ms() - p->up_state->t0);
+	if (g->j.rc || (p->up_state && p->up_state->rc)) rc = -1;
+	if (p->up_state) {                                     /* everything has been issued by now: mark the end of the upload */
+		stream_issue(p->up_state, -1);
+		if (p->up_ev && k2a_shim_event_record(p->up_ev, p->up_state->up)) rc = -1;
+	}
+	free(g);
+	return rc;
 }
 
 static int pool_min_pairs(void)
@@ -1886,14 +2447,14 @@ static int ext_chunk(void *ctx_, int beg, int end, int share, pend_t *pd)
 	}
 	if (bytes > budget) {
 		rc = ext_finish(c, pd);
-		return rc ? rc : run_serial(c->dual, c->scalar, c->km, c->sc, end - beg, c->pairs + beg, c->ez + beg, share, c->flat);
+		return rc ? rc : run_serial(c->dual, c->scalar, c->km, c->sc, end - beg, c->pairs + beg, c->ez + beg, share, c->flat, 0);
 	}
 	t0 = now_ms();
-	p = plan_create_ex(c->dual, c->scalar, c->sc, end - beg, c->pairs + beg, c->flat);
+	p = plan_create_ex(c->dual, c->scalar, c->sc, end - beg, c->pairs + beg, c->flat, 0);
 	if (!p) {                                       /* out of device memory with two plans alive: finish the old one, go serial */
 		if (!strstr(g_err, "alloc")) return strstr(g_err, "device") ? KSW2AMD_E_NODEVICE : KSW2AMD_E_PARAM;
 		rc = ext_finish(c, pd);
-		return rc ? rc : run_serial(c->dual, c->scalar, c->km, c->sc, end - beg, c->pairs + beg, c->ez + beg, share, c->flat);
+		return rc ? rc : run_serial(c->dual, c->scalar, c->km, c->sc, end - beg, c->pairs + beg, c->ez + beg, share, c->flat, 0);
 	}
 	t1 = now_ms();
 	rc = ksw2amd_plan_run(p, thread_stream());
@@ -1941,20 +2502,36 @@ static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc
 	if (k2a_shim_device_count() <= 0) return fail(KSW2AMD_E_NODEVICE, "no usable %s device", k2a_shim_backend());
 	if (n >= (pool_min_pairs() ? pool_min_pairs() : 512) && tpd > 0 && !g_is_worker) {
 		const int workers = tpd * (g_ndev_set > 0 ? g_ndev_set : 1);
-		double *cost = (double*)malloc(sizeof(double) * (size_t)n), bytes = 0, cells = 0, total = 0, path = 0, dev_bytes = 0;
+		double *cost, bytes = 0, cells = 0, total = 0, path = 0, dev_bytes = 0;
 		int i, nchunks, rc = 0, uniform = 1, chunk_pairs = 0;
+		/* one shape for the whole batch (the BASELINE configurations, reads trimmed to one length)?  Then the sums below are n x
+		 * the first pair's terms and the per-pair costs are never looked at (uniform_chunks cuts at fixed sizes): this loop was
+		 * 1.5-2 ms of the calling thread's time on config 2's 65 536 pairs, in front of a 1.4 ms kernel */
+		for (i = 1; i < n; ++i)
+			if (pairs[i].qlen != pairs[0].qlen || pairs[i].tlen != pairs[0].tlen || pairs[i].w != pairs[0].w || ((pairs[i].flag ^ pairs[0].flag) & KSW_EZ_SCORE_ONLY)) { uniform = 0; break; }
+		if (uniform) dev_bytes = (double)n * (double)pair_device_bytes(dual, &pairs[0]);
+		else for (i = 0; i < n; ++i) dev_bytes += (double)pair_device_bytes(dual, &pairs[i]);
+		/* One-shape score-only batches that fit the device: ONE streamed plan (section "streamed plans") instead of chunks -- a
+		 * single persistent launch that works through the batch as its pieces land, longest first, at full occupancy, started under
+		 * the upload.  Where it pays is where the kernels are long against the host's per-pair work: the 10 k headline (MI355X, round 4,
+		 * same box: 4 060 against 3 800 GCUPS through the pointer entry, 4 510 against 4 270 through the flat one), not 512-base reads,
+		 * whose plan creation on one thread costs what six workers' chunks cost together (config 2: 3.9 against 3.4-4.0 ms) -- so by
+		 * default batches of at least 1 M cells per pair.  KSW2AMD_STREAM=1: every one-shape score-only batch; =0: chunks. */
+		if (uniform && (pairs[0].flag & KSW_EZ_SCORE_ONLY) && stream_env() != 0 && g_ndev_set <= 1 && !pool_min_pairs() && !ENV(CHUNKS) &&
+		    (double)n * ((double)imax(pairs[0].qlen, 0) + imax(pairs[0].tlen, 0)) >= 4.0 * 1048576.0) {
+			const int mx0 = imax(pairs[0].qlen, pairs[0].tlen);
+			const int64_t c0 = pairs[0].qlen > 0 && pairs[0].tlen > 0 ? band_cells(pairs[0].qlen, pairs[0].tlen, (pairs[0].w < 0 || pairs[0].w > mx0) ? mx0 : pairs[0].w) : 0;
+			size_t free_b = 0, total_b = 0;
+			if ((stream_env() == 1 || c0 >= stream_min_cells()) &&
+			    (dev_bytes <= 256e6 || (k2a_shim_mem_info(&free_b, &total_b) == 0 && dev_bytes <= (double)device_budget(free_b, total_b, 1))))
+				return run_serial(dual, scalar, km, sc, n, pairs, ez, 1, flat, 1);
+		}
+		cost = (double*)malloc(sizeof(double) * (size_t)n);
 		if (cost) {
-			/* one shape for the whole batch (the BASELINE configurations, reads trimmed to one length)?  Then the sums below are n x
-			 * the first pair's terms and the per-pair costs are never looked at (uniform_chunks cuts at fixed sizes): this loop was
-			 * 1.5-2 ms of the calling thread's time on config 2's 65 536 pairs, in front of a 1.4 ms kernel */
-			for (i = 1; i < n; ++i)
-				if (pairs[i].qlen != pairs[0].qlen || pairs[i].tlen != pairs[0].tlen || pairs[i].w != pairs[0].w || ((pairs[i].flag ^ pairs[0].flag) & KSW_EZ_SCORE_ONLY)) { uniform = 0; break; }
-			if (uniform) dev_bytes = (double)n * (double)pair_device_bytes(dual, &pairs[0]);
-			else for (i = 0; i < n; ++i) dev_bytes += (double)pair_device_bytes(dual, &pairs[i]);
 			if (dev_bytes > 64e9 && !pool_min_pairs()) {
 				/* traceback memory is what splits this batch: one plan at a time with the whole device, not a slice per worker */
 				size_t free_b = 0, total_b = 0;
-				if (k2a_shim_mem_info(&free_b, &total_b) == 0 && dev_bytes > 0.5 * (double)total_b && g_ndev_set <= 1) { free(cost); return run_serial(dual, scalar, km, sc, n, pairs, ez, 1, flat); }
+				if (k2a_shim_mem_info(&free_b, &total_b) == 0 && dev_bytes > 0.5 * (double)total_b && g_ndev_set <= 1) { free(cost); return run_serial(dual, scalar, km, sc, n, pairs, ez, 1, flat, 0); }
 			}
 			for (i = 0; i < (uniform ? 1 : n); ++i) {
 				const int ql = imax(pairs[i].qlen, 0), tl = imax(pairs[i].tlen, 0), mx = imax(ql, tl);
@@ -1990,7 +2567,7 @@ static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc
 			free(cost);
 		}
 	}
-	return run_serial(dual, scalar, km, sc, n, pairs, ez, 1, flat);
+	return run_serial(dual, scalar, km, sc, n, pairs, ez, 1, flat, 0);
 }
 
 static int wants_ssec(int flag);
@@ -2072,7 +2649,7 @@ ksw2amd_plan_t *ksw2amd_plan_create_flat(int dual, const ksw2amd_scoring_t *sc, 
 	flat_src_t fs;
 	if (!pp) return 0;
 	fs.on_device = in->on_device != 0;
-	p = plan_create_ex(dual, 0, sc, n, pp, &fs);
+	p = plan_create_ex(dual, 0, sc, n, pp, &fs, 0);
 	free(pp);
 	/* the batch entry points let the upload run on while they pack the next chunk; a caller of this function may reuse its arena
 	 * as soon as it returns */
@@ -2315,7 +2892,7 @@ static void one_pair(const char *fn, int dual, int scalar, void *km, int qlen, c
 		}
 	}
 	if (!scalar && queue_one(fn, dual, km, &sc, &pr, ez)) return;     /* coalesced with other threads' calls */
-	rc = run_serial(dual, scalar, km, &sc, 1, &pr, ez, 1, 0);
+	rc = run_serial(dual, scalar, km, &sc, 1, &pr, ez, 1, 0, 0);
 	if (rc != KSW2AMD_OK) call_failed(fn, rc, ez);
 }
 
@@ -2439,7 +3016,7 @@ static void coal_process(creq_t *list)
 			r->taken = 1; mem[n] = r; pairs[n] = *r->pr; ezp[n] = r->ez; kmp[n] = r->km; ++n;
 		}
 		__sync_fetch_and_add(&g_stat[2], n); __sync_fetch_and_add(&g_stat[3], 1);
-		p = plan_create_ex(g->dual, 0, g->sc, n, pairs, 0);
+		p = plan_create_ex(g->dual, 0, g->sc, n, pairs, 0, 0);
 		if (!p) rc = strstr(g_err, "alloc") ? KSW2AMD_E_NOMEM : strstr(g_err, "device") ? KSW2AMD_E_NODEVICE : KSW2AMD_E_PARAM;
 		else {
 			rc = ksw2amd_plan_run(p, thread_stream());
@@ -2463,7 +3040,7 @@ static int queue_one(const char *fn, int dual, void *km, const ksw2amd_scoring_t
 	if (g_coal.busy < slots && g_coal.count == 0) {        /* a free slot and nobody waiting: run alone, now */
 		++g_coal.busy;
 		pthread_mutex_unlock(&g_coal.mu);
-		me.rc = run_serial(dual, 0, km, sc, 1, pr, ez, 1, 0);
+		me.rc = run_serial(dual, 0, km, sc, 1, pr, ez, 1, 0, 0);
 		if (me.rc) snprintf(me.err, sizeof(me.err), "%.190s", g_err);
 		pthread_mutex_lock(&g_coal.mu);
 		--g_coal.busy;

@@ -32,6 +32,8 @@ static const int k2a_pkcfg_C[K2A_NPKCFG] = { 18,  8,  8, 16, 16 };
 
 const char *k2a_shim_backend(void);                /* "hip:gfx950" or "sim" */
 const char *k2a_shim_last_error(void);
+int   k2a_shim_async_launches(void);         /* 1: launches run on the device behind the call (hip); 0: inside the call (the simulator): what a
+                                              * launch waits for on the device must then be complete before the call */
 int   k2a_shim_device_count(void);
 int   k2a_shim_simd_count(void);               /* SIMDs (wavefront slots side by side) of the current device; 0 = unknown */
 int   k2a_shim_set_device(int dev);
@@ -89,8 +91,10 @@ int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_
  * (K2aLanePk, DEFER).  Every pair of a wavefront carries the wavefront's checkpoint block in tb_off (byte offset in tb), its
  * stream length in steps in bnd_off and the strips-per-group stride of its header table in cig_off:
  *   block = [bnd_off steps][64 lanes] x 8 bytes, then [64 / G groups][cig_off strips] x 16 bytes (K2aCkHead). */
+/* qd != NULL (device pointer, K2aQueueDesc in ksw2_types.h): a streamed launch -- at most as many workgroups as the device holds at
+ * once, wavefronts pop their wavefront-tasks from qd->next and wait for qd->need[] pieces of the upload. */
 int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax, int defer, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2,
-                            int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, void *stream);
+                            int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, K2aQueueDesc *qd, void *stream);
 int k2a_shim_launch_trace_pk(int cfg, int dual, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb,
                              K2aResult *res, uint32_t *cig, void *stream);
 

@@ -212,11 +212,36 @@ struct K2aTbStage {
 };
 #define K2A_PK_TB_NS(WB, LDSROW) ((WB) == 32 && (LDSROW) == 1 ? 2 : 8)      /* row state in LDS: two wavefronts per SIMD need the room */
 
+/* Streamed launches (K2aQueueDesc, ksw2_types.h): the next wavefront-task of a persistent launch, or -1 when the queue is empty or
+ * the launch was aborted.  Wave-uniform.  Before it returns a task it waits until the upload pieces the task's sequences lie in have
+ * landed: word 0 of the plan's watermark block, written by DMA copies that the upload stream orders behind each piece, polled with
+ * system-scope loads between s_sleep's.  The wait is bounded: past qd->timeout_ticks (100 MHz) the wavefront raises qd->abort and
+ * every wavefront leaves at its next pop -- a kernel of this library never spins on data that may not come. */
+__device__ __forceinline__ int k2a_queue_pop(K2aQueueDesc *qd)
+{
+	uint32_t wt = 0;
+	if ((threadIdx.x & 63) == 0) wt = __hip_atomic_fetch_add(&qd->next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	wt = (uint32_t)__builtin_amdgcn_readfirstlane((int)wt);
+	if (wt >= qd->nwt) return -1;
+	if (__hip_atomic_load(&qd->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return -1;
+	const uint32_t need = qd->need[wt];
+	if (need) {
+		const uint32_t *wm = qd->wm;
+		const uint64_t t0 = wall_clock64(), limit = qd->timeout_ticks;
+		for (int it = 0; __hip_atomic_load(wm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < need; ++it) {
+			if (__hip_atomic_load(&qd->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return -1;
+			if (wall_clock64() - t0 > limit) { __hip_atomic_store(&qd->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return -1; }
+			if (it < 16) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(127);      /* ~0.4 us, then ~3.4 us */
+		}
+	}
+	return (int)wt;
+}
+
 /* Packed-int16 resident fill: two same-shape alignments per lane group (ksw2_lane_pk.h). */
 template<int G, int C, bool DUAL, int MODE, bool RB, bool NOMAX, int LDSROW = 0, bool DEFER = false>      /* LDSROW: 1 = row state in LDS, 2 = only the target-code planes; DEFER: K2aLanePk */
 __global__ void __launch_bounds__(64 * K2A_WPB, LDSROW == 2 ? (G == 16 ? 4 : 3) : LDSROW ? 2 : 1)      /* no floor elsewhere: capping the register form of the score-only kernels at 168 VGPRs spills and is 18 % slower */
 k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
-                   const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, K2aResult *__restrict__ res)
+                   const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, K2aResult *__restrict__ res, K2aQueueDesc *qd)
 {
 	constexpr int NG = 64 / G;
 	typedef K2aLanePk<G, C, DUAL, MODE, RB, NOMAX, LDSROW, DEFER> Lane;
@@ -225,7 +250,10 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 
 	const int lane = threadIdx.x & 63, wave = k2a_wave_id<(C <= 8 || LDSROW || (NOMAX && DUAL && MODE != K2A_MODE_SCORE))>();   /* 16 rows, two-piece, traceback: part of what gets those kernels to two wavefronts */
 	const int grp = lane / G, gl = lane % G;
-	const int task = (blockIdx.x * K2A_WPB + wave) * NG + grp;
+	/* one wavefront-task (NG tasks) per wavefront by position in the grid, or -- streamed launches, qd != NULL -- as many as this
+	 * wavefront gets from the launch's queue (k2a_queue_pop), each one started only when its inputs are on the device */
+	for (int wt = qd ? k2a_queue_pop(qd) : blockIdx.x * K2A_WPB + wave; wt >= 0; wt = qd ? k2a_queue_pop(qd) : -1) {
+	const int task = wt * NG + grp;
 	const bool valid = task < ntasks;
 	const uint32_t piA = order2[valid ? 2 * task : 0], piB = order2[valid ? 2 * task + 1 : 0];
 	const K2aPair prA = pairs[piA], prB = pairs[piB];
@@ -374,6 +402,8 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 		k2a_finish(prA, a, &res[piA]);
 		if (piB != piA) k2a_finish(prB, b, &res[piB]);
 		if (gsaw) { res[piA].pad[0] = 1; res[piB].pad[0] = 1; }
+	}
+	__builtin_amdgcn_wave_barrier();                   /* the books and stages in LDS are the next wavefront-task's */
 	}
 }
 
@@ -1531,7 +1561,7 @@ k2a_extf_win_kernel(const K2aExtf par, const K2aPair *__restrict__ pairs, const 
 	if (lane == 0) k2a_extf_finish(bk, r == nr, &res[pi]);
 }
 
-typedef void (*fill_pk_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*);
+typedef void (*fill_pk_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*, K2aQueueDesc*);
 #define PK_ROW(G, C, RB, NM) { { k2a_fill_pk_kernel<G, C, false, 0, RB, NM>, k2a_fill_pk_kernel<G, C, false, 1, RB, NM>, k2a_fill_pk_kernel<G, C, false, 2, RB, NM> }, \
                                { k2a_fill_pk_kernel<G, C, true, 0, RB, NM>,  k2a_fill_pk_kernel<G, C, true, 1, RB, NM>,  k2a_fill_pk_kernel<G, C, true, 2, RB, NM> } }
 #define PK_SET(NM) { { PK_ROW(8, 18, false, NM), PK_ROW(16, 8, false, NM), PK_ROW(64, 8, false, NM), PK_ROW(64, 16, false, NM) }, \
@@ -1640,6 +1670,7 @@ void *k2a_shim_host_malloc(size_t bytes)
 }
 void k2a_shim_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
+int k2a_shim_async_launches(void) { return 1; }
 int k2a_shim_h2d(void *dst, const void *src, size_t bytes, void *stream)
 {
 	if (bytes) CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
@@ -1719,8 +1750,20 @@ int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_
 	return 0;
 }
 
+/* workgroups of a streamed (persistent) launch: what the device holds at once -- more would only queue up behind wavefronts that
+ * do not leave before the task queue is empty */
+static int k2a_resident_blocks(fill_pk_fn fn, int blocks)
+{
+	int per_cu = 0, dev = 0;
+	hipDeviceProp_t pr;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, 64 * K2A_WPB, 0) != hipSuccess || per_cu <= 0) return blocks;
+	if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return blocks;
+	const long cap = (long)per_cu * pr.multiProcessorCount;
+	return cap < blocks ? (int)cap : blocks;
+}
+
 int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax, int defer, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2,
-                            int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, void *stream)
+                            int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, K2aQueueDesc *qd, void *stream)
 {
 	if (ntasks <= 0) return 0;
 	if (cfg < 0 || cfg >= K2A_NPKCFG || mode < 0 || mode > 2) { snprintf(g_err, sizeof(g_err), "bad packed kernel class"); return -1; }
@@ -1730,7 +1773,8 @@ int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax,
 		/* deferred arg-max: the fill streams its checkpoints into `tb` (block offsets in K2aPair.tb_off / bnd_off / cig_off),
 		 * the second pass fills in max_q / mte_q */
 		if (cfg >= K2A_PKCFG_MP || dual || mode != K2A_MODE_SCORE || nomax || !tb) { snprintf(g_err, sizeof(g_err), "bad deferred arg-max class"); return -1; }
-		hipLaunchKernelGGL(g_fill_pk_defer[cfg][rebased ? 1 : 0], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream, *sc, pairs, order2, ntasks, seq, tb, res);
+		const fill_pk_fn fn = g_fill_pk_defer[cfg][rebased ? 1 : 0];
+		hipLaunchKernelGGL(fn, dim3(qd ? k2a_resident_blocks(fn, blocks) : blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream, *sc, pairs, order2, ntasks, seq, tb, res, qd);
 		CHECK(hipGetLastError());
 		hipLaunchKernelGGL(g_argmax[cfg][rebased ? 1 : 0], dim3((3 * ntasks + 64 * K2A_WPB - 1) / (64 * K2A_WPB)), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
 		                   *sc, pairs, order2, ntasks, seq, (const uint8_t*)tb, res);
@@ -1739,8 +1783,9 @@ int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax,
 	}
 	const int form = k2a_shim_pk_form(cfg, dual, mode, nomax, ntasks);
 	const bool lds = form == 1, ldc = form == 2;
-	hipLaunchKernelGGL(lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1] : ldc ? g_fill_pk_ldscodes[k2a_pkcfg_G[cfg] == 8 ? 1 : k2a_pkcfg_G[cfg] == 16 ? 2 : 0][nomax ? 1 : 0][rebased ? 1 : 0] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode], dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
-	                   *sc, pairs, order2, ntasks, seq, tb, res);
+	const fill_pk_fn fn = lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1] : ldc ? g_fill_pk_ldscodes[k2a_pkcfg_G[cfg] == 8 ? 1 : k2a_pkcfg_G[cfg] == 16 ? 2 : 0][nomax ? 1 : 0][rebased ? 1 : 0] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode];
+	hipLaunchKernelGGL(fn, dim3(qd ? k2a_resident_blocks(fn, blocks) : blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
+	                   *sc, pairs, order2, ntasks, seq, tb, res, qd);
 	CHECK(hipGetLastError());
 	return 0;
 }

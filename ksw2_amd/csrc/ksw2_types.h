@@ -118,6 +118,26 @@ typedef struct K2aResult {
 	int32_t pad[2];                  /* [0]: a packed kernel read a wildcard code (unscanned flat plans), [1]: inexact (deferred arg-max): the host re-runs the pair */
 } K2aResult;
 
+/* Streamed launches (ksw2_host.c, "streamed plans"): ONE persistent launch of a packed fill kernel whose wavefronts pop
+ * wavefront-tasks (the 64 / G consecutive tasks one wavefront runs) from a counter, longest first, and start a task only once the
+ * upload pieces its sequences lie in have landed: the host uploads the sequence arena in pieces on another stream and behind
+ * each piece copies a block of K2A_WM_BYTES filled with the piece's number onto the plan's watermark block (a DMA copy like the
+ * piece itself, ordered behind it by the stream: word 0 of the block = pieces that have landed).  A wavefront whose inputs do not
+ * arrive within `timeout_ticks` (100 MHz) sets `abort` and everybody leaves; the host then runs the plan again, unstreamed.
+ * Device-resident, one per launch, uploaded with the task lists. */
+#define K2A_WM_BYTES 65536            /* large enough that the runtime moves it with the DMA engines like the pieces themselves, never with a kernel
+                                       * (a persistent launch may hold every wavefront slot: tools/probe/stream_publish_probe.hip) */
+typedef struct K2aQueueDesc {
+	uint32_t next;                    /* next wavefront-task, atomic */
+	uint32_t abort;                   /* (the host zeroes these two words before every run) */
+	uint32_t nwt;                     /* wavefront-tasks of the launch */
+	uint32_t pad;
+	const uint32_t *need;             /* [nwt] pieces that must have landed before the wavefront-task may start (0 = none) */
+	const uint32_t *wm;               /* the plan's watermark block */
+	uint64_t timeout_ticks;
+	uint64_t pad2[3];
+} K2aQueueDesc;                       /* 64 bytes */
+
 /* per-group bookkeeping state (LDS on the GPU): the scalar reference's ez fields while rows complete */
 typedef struct K2aBook {
 	int32_t max, max_t, max_q, mqe, mqe_t, mte, mte_q, score, dropped, rows;

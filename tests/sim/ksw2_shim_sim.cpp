@@ -107,12 +107,20 @@ static void sim_fill(const K2aScoring sc, const K2aPair *pairs, const uint32_t *
 /* mirrors k2a_fill_pk_kernel */
 template<int G, int C, bool DUAL, int MODE, bool RB, bool NOMAX, int LDSROW = 0, bool DEFER = false>
 static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *seq, uint8_t *tb,
-                        K2aResult *res)
+                        K2aResult *res, K2aQueueDesc *qd)
 {
 	constexpr int NG = 64 / G;
 	typedef K2aLanePk<G, C, DUAL, MODE, RB, NOMAX, LDSROW, DEFER> Lane;
 	const int nwaves = (ntasks + NG - 1) / NG;
 	for (int wv = 0; wv < nwaves; ++wv) {
+		/* streamed launches (k2a_queue_pop): wavefront-tasks in queue order; the simulator's uploads are synchronous, so a piece
+		 * that has not landed by now never will -- what the kernel finds out by its timeout */
+		if (qd) {
+			if (qd->nwt != (uint32_t)nwaves) { qd->abort = 2; break; }
+			qd->next = (uint32_t)wv + 1;
+			if (qd->abort) break;
+			if (qd->need[wv] > qd->wm[0]) { qd->abort = 1; break; }
+		}
 		static thread_local Lane L[64];
 		static thread_local uint32_t lrows[K2A_PK_LDSROW_WORDS(C)];
 		K2aBook book[NG][2];
@@ -401,7 +409,7 @@ static void sim_trace_pk(const K2aPair *pairs, const uint32_t *order2, int ntask
 	}
 }
 
-typedef void (*fill_pk_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*);
+typedef void (*fill_pk_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*, K2aQueueDesc*);
 #define PK_ROW(G, C, RB, NM) { { sim_fill_pk<G, C, false, 0, RB, NM>, sim_fill_pk<G, C, false, 1, RB, NM>, sim_fill_pk<G, C, false, 2, RB, NM> }, \
                                { sim_fill_pk<G, C, true, 0, RB, NM>,  sim_fill_pk<G, C, true, 1, RB, NM>,  sim_fill_pk<G, C, true, 2, RB, NM> } }
 #define PK_SET(NM) { { PK_ROW(8, 18, false, NM), PK_ROW(16, 8, false, NM), PK_ROW(64, 8, false, NM), PK_ROW(64, 16, false, NM) }, \
@@ -971,6 +979,7 @@ void *k2a_shim_malloc(size_t bytes) { return calloc(bytes ? bytes : 16, 1); }
 void k2a_shim_free(void *p) { free(p); }
 void *k2a_shim_host_malloc(size_t bytes) { return malloc(bytes ? bytes : 16); }
 void k2a_shim_host_free(void *p) { free(p); }
+int k2a_shim_async_launches(void) { return 0; }
 int k2a_shim_h2d(void *dst, const void *src, size_t bytes, void *) { memcpy(dst, src, bytes); return 0; }
 int k2a_shim_d2h(void *dst, const void *src, size_t bytes, void *) { memcpy(dst, src, bytes); return 0; }
 int k2a_shim_d2d(void *dst, const void *src, size_t bytes, void *) { memcpy(dst, src, bytes); return 0; }
@@ -1006,16 +1015,16 @@ typedef void (*argmax_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int
 static const argmax_fn g_argmax[4][2] = { ARGMAX_ROW(8, 18), ARGMAX_ROW(16, 8), ARGMAX_ROW(64, 8), ARGMAX_ROW(64, 16) };
 
 int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax, int defer, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2,
-                            int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, void *)
+                            int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, K2aQueueDesc *qd, void *)
 {
 	if (defer && ntasks > 0) {
-		g_fill_pk_defer[cfg][rebased ? 1 : 0](*sc, pairs, order2, ntasks, seq, tb, res);
+		g_fill_pk_defer[cfg][rebased ? 1 : 0](*sc, pairs, order2, ntasks, seq, tb, res, qd);
 		g_argmax[cfg][rebased ? 1 : 0](*sc, pairs, order2, ntasks, seq, tb, res);
 		return 0;
 	}
 	const int form = k2a_shim_pk_form(cfg, dual, mode, nomax, ntasks);
 	const bool lds = form == 1, ldc = form == 2;
-	if (ntasks > 0) (lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1] : ldc ? g_fill_pk_ldscodes[k2a_pkcfg_G[cfg] == 8 ? 1 : k2a_pkcfg_G[cfg] == 16 ? 2 : 0][nomax ? 1 : 0][rebased ? 1 : 0] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode])(*sc, pairs, order2, ntasks, seq, tb, res);
+	if (ntasks > 0) (lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1] : ldc ? g_fill_pk_ldscodes[k2a_pkcfg_G[cfg] == 8 ? 1 : k2a_pkcfg_G[cfg] == 16 ? 2 : 0][nomax ? 1 : 0][rebased ? 1 : 0] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode])(*sc, pairs, order2, ntasks, seq, tb, res, qd);
 	return 0;
 }
 int k2a_shim_launch_trace_pk(int cfg, int dual, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb,

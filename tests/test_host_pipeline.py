@@ -79,6 +79,7 @@ def test_uniform_batch_is_cut_at_device_fills(sim, monkeypatch, score_only, expe
     monkeypatch.setenv("KSW2AMD_SIM_SIMDS", "4")
     monkeypatch.setenv("KSW2AMD_SIMDS", "0")
     monkeypatch.setenv("KSW2AMD_THREADS", "3")
+    monkeypatch.setenv("KSW2AMD_STREAM", "0")            # the chunked path is what this test is about (a streamed batch is one plan)
     n = 4096
     qs, ts = synth.fixed_batch(77, n, 1000, 1000, sub=0.05, ind=0.1)
     mat = synth.simple_mat(5, 2, 4, -1)

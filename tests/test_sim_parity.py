@@ -14,7 +14,7 @@ import ksw2_amd as ka
 from ksw2_amd import synth
 from oracle import pyoracle as po
 from tests import golden_util as gu
-from tests.parity_util import check_batch, diff
+from tests.parity_util import check_batch, diff, CMP_FIELDS as CMP
 
 SIM_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sim")
 
@@ -778,3 +778,53 @@ def test_sim_gg_family_golden(sim):
         assert s == c["score"] and list(cg) == c["cigar"], (k, c["func"], c["w"], c["origin"], s, c["score"])
         n += 1
     assert n >= 250
+
+
+def _one_shape_batch(seed, n, ql, tl, wild_at=()):
+    q, t = synth.fixed_batch(seed, n, ql, tl, sub=0.05, ind=0.06)
+    q, t = [np.array(x) for x in q], [np.array(x) for x in t]
+    for i in wild_at:
+        q[i][len(q[i]) // 2] = 4                         # a wildcard: a streamed plan's arena is not scanned, the kernel reports it, fetch re-runs the pair
+    return q, t
+
+
+@pytest.mark.parametrize("flat", [False, True])
+def test_sim_streamed_plans(sim, monkeypatch, flat):
+    """Streamed plans (ksw2_host.c "streamed plans") forced on for every plan that can: one-shape batches through
+    the batch entry points, the arena in small pieces, the packed classes as queue launches (K2aQueueDesc) -- against the oracle on
+    every pair: score-only and CIGAR classes, both gap models, an odd pair count, wildcard pairs (re-run in one batch), Z-drops with
+    the deferred arg-max (inexact pairs re-run), and the fault hook (the last watermark never arrives: the launch gives up, the plan
+    runs again behind its upload)."""
+    monkeypatch.setenv("KSW2AMD_SIMDS", "0")
+    monkeypatch.setenv("KSW2AMD_STREAM", "1")
+    monkeypatch.setenv("KSW2AMD_STREAM_PIECE_KB", "64")
+    mat, q, e, q2, e2 = synth.simple_mat(5, 2, 4, -1), 4, 2, 24, 1
+    cases = [(1501, 400, 420, 64, po.SCORE_ONLY, False, 30, (7, 800, 1500)), (1200, 500, 500, 100, 0, True, 100, ()),
+             (1400, 700, 700, 300, po.SCORE_ONLY, False, 60, (3,)), (2400, 300, 330, 64, po.SCORE_ONLY | po.APPROX_MAX, False, -1, ())]
+    for fault in (0, 1):
+        monkeypatch.setenv("KSW2AMD_STREAM_FAULT", str(fault))
+        for ci, (n, ql, tl, w, flag, dual, zd, wild) in enumerate(cases[:2] if fault else cases):
+            qs, ts = _one_shape_batch(100 + ci, n, ql, tl, wild)
+            s0, r0 = sim.stream_stats(), sim.rerun_count()
+            if flat:
+                fb = sim.make_flat_batch(qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=0, flag=flag)
+                res = fb.run_oneshot(dual)
+            else:
+                res = (sim.extd_batch(qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, flag=flag) if dual else sim.extz_batch(qs, ts, mat, q, e, w=w, zdrop=zd, flag=flag))
+            s1 = sim.stream_stats()
+            assert s1["streamed_plans"] > s0["streamed_plans"], (ci, flat)
+            assert (s1["aborted_runs"] > s0["aborted_runs"]) == bool(fault), (ci, flat, fault)
+            if wild:
+                assert sim.rerun_count() >= r0 + len(wild)
+            for i in range(n):
+                exp = (ApproxLike.run(qs[i], ts[i], mat, w, flag) if flag & po.APPROX_MAX else
+                       po.align("oracle", "extd2" if dual else "extz2", qs[i], ts[i], mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=0, flag=flag))
+                d = diff(exp, res[i], ["score"] if flag & po.APPROX_MAX else CMP)
+                assert not d, (ci, flat, fault, i, d)
+
+
+class ApproxLike:
+    """KSW_EZ_APPROX_MAX returns only the score (and the corner CIGAR): the exact computation's score without Z-drop."""
+    @staticmethod
+    def run(qq, tt, mat, w, flag):
+        return po.align("oracle", "extz2", qq, tt, mat, 4, 2, w=w, zdrop=-1, end_bonus=0, flag=flag & ~po.APPROX_MAX)

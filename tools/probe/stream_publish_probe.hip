@@ -78,11 +78,13 @@ static void run(const char *name, int mode, int blocks, int delay_us)
 	uint32_t *hvals;
 	CK(hipHostMalloc(&hvals, 256));
 	CK(hipMalloc(&d, total));
-	CK(hipMalloc(&flag, 256));
+	CK(hipMalloc(&flag, mode >= 16 ? mode : 256));
+	uint32_t *hblk = 0;
+	if (mode >= 16) { CK(hipHostMalloc(&hblk, (size_t)mode * 8)); for (int p = 0; p < 8; ++p) for (int i = 0; i < mode / 4; ++i) hblk[(size_t)p * (mode / 4) + i] = (uint32_t)(p + 1); }
 	CK(hipMalloc(&sums, (size_t)blocks * 4 * 4));
 	CK(hipMalloc(&seen, (size_t)blocks * 4 * 8));
 	CK(hipMemset(d, 0x11, total));                       // the OLD bytes
-	CK(hipMemset(flag, 0, 256));
+	CK(hipMemset(flag, 0, mode >= 16 ? mode : 256));
 	for (size_t i = 0; i < total / 4; ++i) h[i] = (uint32_t)(i * 2654435761u) ^ 0x5bd1e995u;
 	hipStream_t sk, su;
 	CK(hipStreamCreateWithFlags(&sk, hipStreamNonBlocking));
@@ -103,6 +105,7 @@ static void run(const char *name, int mode, int blocks, int delay_us)
 		if (mode == 0) CK(hipStreamWriteValue32(su, flag, (uint32_t)(p + 1), 0));
 		else if (mode == 1) hipLaunchKernelGGL(publish, dim3(1), dim3(64), 0, su, flag, (uint32_t)(p + 1));
 		else if (mode == 2) { hvals[p] = (uint32_t)(p + 1); CK(hipMemcpyAsync(flag, &hvals[p], 4, hipMemcpyHostToDevice, su)); }
+		else if (mode >= 16) CK(hipMemcpyAsync(flag, hblk + (size_t)p * (mode / 4), mode, hipMemcpyHostToDevice, su));
 		if (delay_us) { CK(hipStreamSynchronize(su)); usleep(delay_us); }
 	}
 	CK(hipStreamSynchronize(su));
@@ -152,6 +155,13 @@ int main()
 	run<8, false>("data sentinel, small kernel, 8 WG/CU", 3, cus * 8, 0);
 	run<8, false>("data sentinel, small kernel, 2 WG/CU", 3, cus * 2, 0);
 	run<8, false>("flag by 4-byte copy, small kernel, 2 WG/CU", 2, cus * 2, 0);
+	run<8, false>("flag by 1 KB copy, small kernel, 8 WG/CU", 1024, cus * 8, 0);
+	run<8, false>("flag by 4 KB copy, small kernel, 8 WG/CU", 4096, cus * 8, 0);
+	run<8, false>("flag by 16 KB copy, small kernel, 8 WG/CU", 16384, cus * 8, 0);
+	run<8, false>("flag by 64 KB copy, small kernel, 8 WG/CU", 65536, cus * 8, 0);
+	run<8, false>("flag by 256 KB copy, small kernel, 8 WG/CU", 262144, cus * 8, 0);
+	run<8, false>("flag by 1 MB copy, small kernel, 8 WG/CU", 1048576, cus * 8, 0);
+	run<116, false>("flag by 64 KB copy, 128 VGPR pollers, 4 WG/CU", 65536, cus * 4, 0);
 	run<116, false>("write-value, 128 VGPR pollers, 4 WG/CU", 0, cus * 4, 0);
 	run<116, false>("flag by 4-byte copy, 128 VGPR pollers, 4 WG/CU", 2, cus * 4, 0);
 	run<116, false>("data sentinel, 128 VGPR pollers, 4 WG/CU", 3, cus * 4, 0);
