@@ -66,8 +66,17 @@ WORKLOADS = {
     # splice-aware extension and gap-linear X-drop extension (N3): see DESIGN.md sections 3.6 / 3.7
     "exts": dict(idx=7, n=16384, qlen=400, tlen=1500, w=-1, zdrop=-1, dual=False, flag=0, sub=0.03, ind=0.0, splice=True),
     "extf": dict(idx=8, n=16384, qlen=1000, tlen=1000, w=100, zdrop=-1, dual=False, flag=SO, sub=0.05, ind=0.01, linear=True),
+    # the headline's shape where extensions DO drop: a fifth of the pairs get the last quarter of the query replaced by random bases, so the
+    # Z-drop fires there -- what the deferred arg-max costs when it has to hand alignments back is in this line
+    "10k-zdrop": dict(idx=6, n=12288, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=SO, sub=0.05, ind=0.06, tail_frac=0.25, tail_pairs=0.20),
+    # ... and where 1 % of the pairs hold a wildcard base: those leave the packed kernels (they score match / mismatch only)
+    "10k-N": dict(idx=6, n=12288, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=SO, sub=0.05, ind=0.06, wild_pairs=0.01),
+    # ... and in the SSE-compatible mode (the reference's SSE kernels' own results): every pair through k2a_ssec_kernel
+    "10k-ssec": dict(idx=6, n=1024, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=SO, sub=0.05, ind=0.06, sse=True),
 }
-ALSO_DEFAULT = ["10k-n1024", "10k-cigar", "cfg2", "cfg3", "cfg5", "cfg4", "cfg5-share"]
+ALSO_DEFAULT = ["10k-n1024", "10k-cigar", "cfg2", "cfg3", "cfg5", "cfg4", "cfg5-share", "10k-zdrop", "10k-N", "exts", "extf", "10k-ssec"]
+# pairs of each workload's last timed batch that are compared with the oracle outside the clock (the MT pair costs ~1 s per pair on the host)
+PARITY_PAIRS = {"cfg4": 16, "cfg4-so": 4, "cfg5": 16, "cfg5-share": 16}
 # N > 1: the configurations BASELINE.json quotes for several GPUs at their per-GPU share (config 4: 4 096 replicas / 8)
 ALSO_MULTI = {"cfg5-share": None, "cfg4": 512}
 SCORING = dict(a=2, b=4, sc_n=-1, q=4, e=2, q2=24, e2=1)
@@ -102,8 +111,14 @@ def make_batch(wl, rank, n):
         _, qs = gu.read_fasta("MT-orang.fa")
         q1, t1 = np.ascontiguousarray(qs[0]), np.ascontiguousarray(ts[0])
         return [q1] * n, [t1] * n                        # same bytes; every replica is still packed, uploaded and computed
-    return synth.fast_fixed(wl["idx"], n, wl["qlen"], wl["tlen"], sub=wl["sub"], ind=wl["ind"],
+    q, t = synth.fast_fixed(wl["idx"], n, wl["qlen"], wl["tlen"], sub=wl["sub"], ind=wl["ind"],
                             tail_random_frac=wl.get("tail_frac", 0.0), tail_pairs=wl.get("tail_pairs", 0.0), first=rank * n)
+    if wl.get("wild_pairs"):                             # one wildcard base (code 4) somewhere in the query of every 1 / wild_pairs-th pair
+        rng = np.random.Generator(np.random.PCG64(wl["idx"] * 1000003 + rank))
+        step = max(1, int(round(1.0 / wl["wild_pairs"])))
+        for i in range(step // 2, n, step):
+            q[i, int(rng.integers(wl["qlen"]))] = 4
+    return q, t
 
 
 def cells_of_rows(qlen, rows, w):
@@ -191,6 +206,8 @@ class Job:
         self.lib, self.name, self.rank, self.sse = lib, name, rank, sse
         if approx:
             wl = dict(wl, flag=wl["flag"] | 0x08)
+        sse = sse or bool(wl.get("sse"))
+        self.sse = sse
         if sse:                                  # the SSE kernels' own results: every pair through k2a_ssec_kernel
             wl = dict(wl, flag=wl["flag"] | ksw2_amd.KSW2AMD_EZ_SSE_COMPAT)
         self.wl = wl
@@ -258,12 +275,39 @@ class Job:
             L._check(f(None, ctypes.byref(b.sc), b.n, b.pairs, self.ez))
 
     # ---- correctness evidence attached to the number: outside the clock, a few pairs of the batch the timed loop just aligned
-    def parity_sample(self, k=16):
+    def decoy_then_step(self, flat):
+        """Score-only one-shape batches (what the batch entry points stream): one step on a DECOY batch of the same shapes
+        but other bases, then one more step on the real batch -- outside the clock.  The timed loop aligns the same batch K times, so the
+        device arena, the staging buffers and the caches hold its bytes from the step before: a kernel that read a sequence before its
+        upload had landed, or out of a stale cache line, would still return the right answer there.  After a decoy it would not."""
+        if self.kind not in ("extz", "extd") or not self.score_only or not isinstance(self.q, np.ndarray) or self.sse:
+            return False
+        rng = np.random.Generator(np.random.PCG64(12345))
+        dq = rng.integers(0, 4, size=self.q.shape, dtype=np.uint8)
+        dt = rng.integers(0, 4, size=self.t.shape, dtype=np.uint8)
+        wl, S = self.wl, SCORING
+        keep = (self.batch, self.fbatch)
+        if flat:
+            self.fbatch = self.lib.make_flat_batch(dq, dt, self.mat, S["q"], S["e"], S["q2"], S["e2"], w=wl["w"], zdrop=wl["zdrop"], end_bonus=0, flag=wl["flag"])
+            self.fbatch.register()
+        else:
+            self.batch = self.lib.make_batch(dq, dt, self.mat, S["q"], S["e"], S["q2"], S["e2"], w=wl["w"], zdrop=wl["zdrop"], end_bonus=0, flag=wl["flag"])
+        try:
+            self.e2e_step(flat=flat)
+        finally:
+            if flat:
+                self.fbatch.unregister()
+            self.batch, self.fbatch = keep
+        self.e2e_step(flat=flat)
+        return True
+
+    def parity_sample(self, k=16, flat=False):
         """Compare k evenly spaced results of the last e2e_step (self.ez, i.e. what the timed calls returned) with the oracle:
         every ksw_extz_t field and the CIGAR.  Returns a JSON-able verdict."""
         from oracle import pyoracle as po
         if self.ez is None or self.n == 0:
             return {"pairs": 0, "result": "not run"}
+        decoyed = self.decoy_then_step(flat)
         wl, S = self.wl, SCORING
         idx = sorted({int(x) for x in np.linspace(0, self.n - 1, min(k, self.n))})
         fields = ksw2_amd.FIELDS + ([] if self.kind == "extf" else ["cigar"])
@@ -276,8 +320,9 @@ class Job:
             elif self.kind == "extf":
                 P = LINEAR_SCORING
                 exp = po.extf2("oracle", self.q[i], self.t[i], P["mch"], P["mis"], P["e"], wl["w"], wl["zdrop"])
-            elif self.sse:
-                return {"pairs": 0, "result": "not sampled (SSE-compatible mode: tests/test_gpu_parity.py::test_sse_compatible_mode)"}
+            elif self.sse:                     # the oracle's restatement of the SSE kernels' memory image (oracle/ksw2_oracle_sse.c, pinned by 1 500 reference vectors)
+                exp = po.align("oracle", "extd2_sse" if self.kind == "extd" else "extz2_sse", self.q[i], self.t[i], self.mat, S["q"], S["e"], S["q2"], S["e2"],
+                               w=wl["w"], zdrop=wl["zdrop"], end_bonus=0, flag=wl["flag"] & ~ksw2_amd.KSW2AMD_EZ_SSE_COMPAT)
             else:
                 exp = po.align("oracle", "extd2" if self.kind == "extd" else "extz2", self.q[i], self.t[i], self.mat, S["q"], S["e"], S["q2"], S["e2"],
                                w=wl["w"], zdrop=wl["zdrop"], end_bonus=0, flag=wl["flag"])
@@ -285,7 +330,8 @@ class Job:
             if d:
                 bad.append({"pair": i, "fields": d})
         return {"pairs": len(idx), "result": "ok" if not bad else "MISMATCH", "checked": "all ksw_extz_t fields" + ("" if self.kind == "extf" else " + CIGAR") +
-                " of the timed batch's last step vs oracle/ (CPU restatement pinned to the compiled reference)", **({"mismatches": bad[:4]} if bad else {})}
+                (" of one more step of the timed batch, run behind a decoy batch of the same shapes (other bases), vs oracle/" if decoyed else
+                 " of the timed batch's last step vs oracle/") + " (CPU restatement pinned to the compiled reference)", **({"mismatches": bad[:4]} if bad else {})}
 
     def free_ez(self):
         if self.ez is not None:
@@ -415,6 +461,63 @@ def scatter_gather_leg(lib, job, rank, world, barrier, red_dev, steps=3):
             "what": "rank 0 holds the batch: LPT partition, torch.distributed point-to-point scatter, per-rank batch call, gather to rank 0"}
 
 
+def pin_to_gpu(dev, local_rank, local_world):
+    """Put this rank (and so every thread the library starts later) on the cores next to its GPU: /sys/bus/pci/devices/<bdf>/
+    local_cpulist of the device's PCI function, shared evenly by the ranks whose GPUs hang off the same NUMA node.  Eight ranks x (six
+    batch workers + up to 24 gather threads + pinned staging) on one 256-thread host is where weak scaling bleeds first.  Returns what
+    it did for the JSON line; no /sys entry (or KSW2_BENCH_NO_PIN=1): nothing is changed."""
+    info = {"pinned": False}
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(dev)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        base = "/sys/bus/pci/devices/" + bdf
+        node = int(open(base + "/numa_node").read().strip())
+        cpus = []
+        for part in open(base + "/local_cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus += list(range(int(a), int(b or a) + 1))
+        info.update({"pci": bdf, "numa_node": node, "local_cpus": len(cpus)})
+        # ranks whose GPU reports the same local CPU list split it (device order = rank order on one node)
+        same = [d for d in range(local_world) if _local_cpulist(d) == cpus]
+        if os.environ.get("KSW2_BENCH_NO_PIN") or not cpus or dev not in same:
+            return info
+        k, share = same.index(dev), max(1, len(cpus) // len(same))
+        mine = cpus[k * share:(k + 1) * share] or cpus
+        os.sched_setaffinity(0, mine)
+        info.update({"pinned": True, "cpus": len(mine), "cpu_first": mine[0], "cpu_last": mine[-1]})
+    except Exception as exc:                              # no such attribute / file: leave the affinity alone
+        info["note"] = "%s: %s" % (type(exc).__name__, exc)
+    return info
+
+
+def _local_cpulist(dev):
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(dev)
+        out = []
+        for part in open("/sys/bus/pci/devices/%04x:%02x:%02x.0/local_cpulist" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)).read().strip().split(","):
+            a, _, b = part.partition("-")
+            out += list(range(int(a), int(b or a) + 1))
+        return out
+    except Exception:
+        return None
+
+
+def lpt_imbalance(world):
+    """Config 5 as BASELINE.json states it (1 M ONT-like pairs) cut for `world` ranks by ksw2_amd/parallel.py::lpt_partition on the
+    exact band cells: the largest share over the mean share -- what the rank-0-holds-the-batch form of the multi-GPU path would lose
+    to imbalance.  Lengths only (no sequences are generated)."""
+    from ksw2_amd import parallel
+    wl = WORKLOADS["cfg5-share"]
+    n = 1000000
+    ql, tl = synth.ragged_lengths(wl["idx"], n, 300, 20000, sub=wl["sub"], ind=wl["ind"], maxdiff=450)
+    cost = parallel.band_cells(ql, tl, np.full(n, wl["w"]))
+    parts = parallel.lpt_partition(cost, world)
+    share = np.array([float(cost[idx].sum()) for idx in parts])
+    return {"pairs": n, "ranks": world, "max_over_mean_cells": round(float(share.max() / share.mean()), 6), "cells_total": float(cost.sum())}
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -462,6 +565,8 @@ def main():
     dev = 0 if os.environ.get("KSW2_BENCH_ONE_DEVICE") else local_rank
     if not plumbing:
         torch.cuda.set_device(dev)
+    # before the library starts any thread: this rank's threads next to its GPU (reported per rank in config.per_rank)
+    affinity = pin_to_gpu(dev, local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if not plumbing and world > 1 else {"pinned": False}
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -518,6 +623,10 @@ def main():
         dist.all_gather(allr, mine)                                     # load balance: every rank's cells and its own loop time
         per_rank = [{"rank": r, "cells_per_step": float(x[0].item()), "loop_seconds": round(float(x[1].item()), 4),
                      "gcups": round(float(x[0].item()) * args.steps / float(x[1].item()) / 1e9, 1)} for r, x in enumerate(allr)]
+        aff = [None] * world
+        dist.all_gather_object(aff, affinity)                           # NUMA node / cores every rank ran on
+        for r in range(world):
+            per_rank[r]["affinity"] = aff[r]
         tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -530,7 +639,7 @@ def main():
     parity = job.parity_sample(16) if rank == 0 else None      # outside the timed region: the results the timed calls returned
     # the same K steps through the flat entry point (one arena + offsets, page-locked once): what a caller that owns its read
     # buffer would use.  Timed exactly like the loop above.
-    dt_flat = None
+    dt_flat, parity_flat = None, None
     if job.flat_ready():
         for _ in range(max(1, min(args.warmup, 2))):
             job.e2e_step(flat=True)
@@ -544,7 +653,7 @@ def main():
             tt = torch.tensor([dt_flat], dtype=torch.float64, device=red_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt_flat = float(tt.item())
-        parity_flat = job.parity_sample(8) if rank == 0 else None
+        parity_flat = job.parity_sample(8, flat=True) if rank == 0 else None
         job.flat_done()
     job.free_ez()
     lib.release_cache()
@@ -588,6 +697,11 @@ def main():
             out["config"]["rank0_scatter_gather"] = sg
         if per_rank:
             out["config"]["per_rank"] = per_rank
+        if world > 1 and not plumbing:
+            try:
+                out["config"]["cfg5_lpt_imbalance"] = lpt_imbalance(world)
+            except Exception as exc:
+                out["config"]["cfg5_lpt_imbalance"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     # ------------------------------------------------------------------ the other configurations (N = 1: one run covers them all)
     names = ALSO_DEFAULT if args.also is None else [x for x in args.also.split(",") if x]
     if args.no_also or world > 1 or args.pairs or args.approx or args.sse_compat or args.workload != "10k":
@@ -595,12 +709,37 @@ def main():
     if world > 1 and args.also is None and not (args.no_also or args.pairs or args.approx or args.sse_compat or args.workload != "10k"):
         names = list(ALSO_MULTI)                                 # the multi-GPU configurations at their per-GPU share, every rank its own slice
     also = []
+    mismatch = parity is not None and parity["result"] == "MISMATCH"
+    if dt_flat and rank == 0 and parity_flat is not None and parity_flat["result"] == "MISMATCH":
+        mismatch = True
+
+    def all_ok(ok):
+        """N > 1: every rank must get through a set-up step before any of them enters a collective -- a rank that failed alone (an
+        allocation, say) would otherwise leave the others waiting in the barrier until the RCCL timeout."""
+        if world == 1:
+            return ok
+        f = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        return bool(f.item() > 0.5)
+
     for name in names:
         if name == args.workload:
             continue
+        j, err = None, None
         try:
             j = Job(lib, name, WORKLOADS[name], rank, ALSO_MULTI.get(name) if world > 1 else None)
+        except Exception as exc:
+            err = "%s: %s" % (type(exc).__name__, exc)
+        if not all_ok(j is not None):
+            also.append({"workload": name, "error": err or "set-up failed on another rank"})
+            lib.release_cache()
+            continue
+        try:
             big = j.cells > 5e11                                 # seconds per step: one warm-up, two timed steps
+            if world > 1:                                        # (step counts from the SAME figure on every rank)
+                bt = torch.tensor([float(j.cells)], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(bt, op=dist.ReduceOp.MAX)
+                big = float(bt.item()) > 5e11
             def timed(flat):
                 """>= 3 steps and >= 1.5 s (big workloads: 2 steps) of the batch entry point; N > 1: between barriers, the slowest rank's time,
                 every rank's cells."""
@@ -624,18 +763,20 @@ def main():
                     cells = float(tot.item())
                 return kk, el, cells
             k, edt, cells_sum = timed(False)
-            jpar = j.parity_sample(1 if WORKLOADS[name].get("mt") else 6)
+            jpar = j.parity_sample(PARITY_PAIRS.get(name, 8))
             vflat = None
             if j.flat_ready():
                 kf, fdt, _ = timed(True)
                 vflat = round(cells_sum * kf / fdt / 1e9, 2)
-                jparf = j.parity_sample(1 if WORKLOADS[name].get("mt") else 4)
+                jparf = j.parity_sample(max(4, PARITY_PAIRS.get(name, 8) // 4), flat=True)
+                mismatch = mismatch or jparf["result"] == "MISMATCH"
                 j.flat_done()
             j.free_ez()
             lib.release_cache()
             r = j.resident(3, 1, stream, min_seconds=1.0)
             lib.release_cache()
             rr = roofline_of(j, r, name)
+            mismatch = mismatch or jpar["result"] == "MISMATCH"
             also.append({"workload": describe(j, world), "n_gpus": world, "value": round(cells_sum * k / edt / 1e9, 2), "value_flat_arena": vflat, "value_hbm_resident": rr["kernel_gcups"],
                          **({"parity_sample_flat_arena": jparf["result"]} if vflat else {}),
                          "unit": "GCUPS", "pairs_per_s": round(j.n * world * k / edt, 1), "steps": k, "ms_per_step": round(edt / k * 1e3, 3),
@@ -644,6 +785,8 @@ def main():
                                                          "kernel_gcups_cells_filled", "early_stop_fraction", "zdropped_pairs", "traffic", "traffic_source")}})
             del j
         except Exception as exc:                                  # one workload must not take the headline with it
+            if world > 1:
+                raise                                             # ... but with several ranks a lone failure inside the collectives cannot be contained: fail loudly
             also.append({"workload": name, "error": "%s: %s" % (type(exc).__name__, exc)})
             lib.release_cache()
     if rank == 0:
@@ -655,9 +798,13 @@ def main():
                 out["gpu_over_cpu_1thread"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
                 if "all_cores" in out["cpu_baseline"]:
                     out["gpu_over_cpu_all_cores"] = round(out["value"] / out["cpu_baseline"]["all_cores"]["value"], 1)
+        if mismatch:
+            out["parity_failed"] = True                           # a timed batch whose sampled results differ from the oracle: the number is void
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    if rank == 0 and mismatch:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -195,7 +195,8 @@ int ksw2amd_extd_batch(void *km, const ksw2amd_scoring_t *sc, int n, const ksw2a
  * is (one copy instead of 2 n gathers into staging; asynchronous and at link rate if the arena is page-locked, ksw2amd_host_register)
  * and never walks over the bytes on the host: a pair with a wildcard code in a packed-int16 kernel is reported by the kernel
  * and run again through the int32 kernels.  `on_device` != 0: `base` is device memory (a hipMalloc'ed arena of the calling
- * thread's device, e.g. a shard that RCCL delivered): no upload at all.  Per-pair arrays w / zdrop / end_bonus / flag may be NULL:
+ * thread's device, e.g. a shard that RCCL delivered): no upload at all (pairs that ask for the SSE kernels' own results, which keep
+ * their state on the host side of the plan, have the arena's span brought back first).  Per-pair arrays w / zdrop / end_bonus / flag may be NULL:
  * the *_all value then applies to every pair.  Results are those of the ordinary entry points on the same pairs. */
 typedef struct {
 	const uint8_t *base;                  /* the arena */
@@ -258,7 +259,10 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 int  ksw2amd_plan_run(ksw2amd_plan_t *plan, void *stream);
 int  ksw2amd_plan_fetch(ksw2amd_plan_t *plan, void *km, ksw_extz_t *ez);
 void ksw2amd_plan_destroy(ksw2amd_plan_t *plan);
-/* a resident plan from a flat batch (host or device arena); run / fetch / timing / cells / destroy as below */
+/* a resident plan from a flat batch (host or device arena); run / fetch / timing / cells / destroy as below.  The upload is complete
+ * when this returns, but the plan BORROWS the arena: its bytes must stay valid and unchanged until ksw2amd_plan_destroy -- a fetch
+ * reads the sequences there for =/X CIGARs (KSW_EZ_EQX) and for the pairs it runs again (wildcard codes met by a packed kernel,
+ * alignments the deferred arg-max kernels handed back).  The batch entry points above borrow the arena for the duration of the call only. */
 ksw2amd_plan_t *ksw2amd_plan_create_flat(int dual, const ksw2amd_scoring_t *sc, int n, const ksw2amd_flat_t *in);
 /* device time of the last ksw2amd_plan_run (HIP events on its stream), fill kernels only / fill + traceback; ms */
 int  ksw2amd_plan_timing(ksw2amd_plan_t *plan, float *fill_ms, float *total_ms);
@@ -280,8 +284,8 @@ void ksw2amd_reload_env(void);
  * alignments in which the deferred arg-max kernels could not rule out a Z-drop without the arg-max columns */
 int64_t ksw2amd_rerun_count(void);
 /* Streamed plans (new; replaces nothing in the reference): a one-shape score-only batch handed to the batch entry points runs as ONE
- * plan whose sequence arena goes up in pieces while a single persistent launch per kernel class starts each wavefront's tasks as
- * their pieces land.  out[0] = streamed plans run since the library was loaded, out[1] = runs in which a
+ * plan whose sequence arena goes up in pieces while a single launch per kernel class runs under the upload, each wavefront starting its
+ * task when the task's pieces have landed.  out[0] = streamed plans run since the library was loaded, out[1] = runs in which a
  * launch gave up waiting for its inputs (bounded wait) and the plan was run again behind its upload.  KSW2AMD_STREAM=0 / 1:
  * never / every plan that can. */
 void ksw2amd_stream_stats(int64_t out[2]);

@@ -10,7 +10,11 @@
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 #include <stdio.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <pthread.h>
 #include <string.h>
@@ -47,6 +51,7 @@ static void release_thread_cache(void);
  * one process; the Python binding calls it before every plan / batch). */
 #define K2A_ENV_LIST \
 	X(ABORT_ON_ERROR) \
+	X(BACKTRACE) \
 	X(APPROX_DROP_EXACT) \
 	X(CHUNKS) \
 	X(CHUNK_GCELLS) \
@@ -106,6 +111,17 @@ static volatile int g_env_ready;
 static int g_env_gen;                                /* bumped by every (re)load: function-local caches key on it */
 static pthread_mutex_t g_env_mu = PTHREAD_MUTEX_INITIALIZER;
 static int env_switch(const char *v);
+/* KSW2AMD_BACKTRACE=1 (debugging on boxes without a debugger): the library's frames of a crash on stderr, then the default action */
+static void crash_handler(int sig)
+{
+	void *fr[48];
+	const int n = backtrace(fr, 48);
+	static const char msg[] = "[ksw2_amd] fatal signal; frames:\n";
+	if (write(2, msg, sizeof(msg) - 1) < 0) { }
+	backtrace_symbols_fd(fr, n, 2);
+	signal(sig, SIG_DFL);
+	raise(sig);
+}
 static void env_load(void)
 {
 	int i;
@@ -116,6 +132,7 @@ static void env_load(void)
 		if (v && (!g_env[i] || strcmp(g_env[i], v))) g_env[i] = strdup(v);
 		else if (!v) g_env[i] = 0;
 	}
+	if (g_env[ENV_BACKTRACE] && atoi(g_env[ENV_BACKTRACE])) { signal(SIGSEGV, crash_handler); signal(SIGBUS, crash_handler); signal(SIGABRT, crash_handler); }
 	k2a_shim_set_option(K2A_OPT_LDSCODES, env_switch(g_env[ENV_LDSCODES]));
 	k2a_shim_set_option(K2A_OPT_LDSROWS, env_switch(g_env[ENV_LDSROWS]));
 	++g_env_gen;
@@ -265,10 +282,10 @@ static void release_thread_cache(void)
  * profiles/r3_cfg2_phases.txt).  A streamed plan is ONE plan for the whole batch: its sequence arena goes up in pieces on the
  * device's upload stream, behind every piece a block filled with the piece's number is copied onto the plan's watermark block
  * (K2A_WM_BYTES: a size the runtime moves with the DMA engines -- smaller copies, hipStreamWriteValue32 and one-thread "publish"
- * kernels all need a wavefront slot and do not get one while a persistent launch holds the device: tools/probe/
- * stream_publish_probe.hip, profiles/r4_stream_publish_probe.txt), and every packed class runs as one persistent launch whose
- * wavefronts pop wavefront-tasks from a counter, longest first, and start one only when the watermark says its sequences have
- * landed (K2aQueueDesc, k2a_queue_pop).  The wait is bounded (KSW2AMD_STREAM_TIMEOUT_MS, default 2000): a wavefront that gives
+ * kernels all need a wavefront slot and do not get one while a launch of waiting wavefronts holds the device: tools/probe/
+ * stream_publish_probe.hip, profiles/r4_stream_publish_probe.txt), and every score-only packed class runs as ONE launch over the
+ * whole batch, started under the upload, whose wavefronts -- dispatched in task order, longest first -- each wait in front of their
+ * task until the watermark says its sequences have landed (K2aQueueDesc, k2a_queue_wait).  The wait is bounded (KSW2AMD_STREAM_TIMEOUT_MS, default 2000): a wavefront that gives
  * up raises the launch's abort word, fetch sees it, waits for the upload and runs the plan again as an ordinary one.
  * KSW2AMD_STREAM=0 never, =1 every plan that can (tests), unset: the batch entry points' one-shape score-only batches. */
 #define K2A_MAXPIECES 48
@@ -433,8 +450,8 @@ struct ksw2amd_plan_s {
 	uint8_t *flat_tail;                    /* ... and the staging block of the arena's padding lives as long as the plan */
 	ksw2amd_pair_t *src_pairs;             /* the caller's pairs (pointers into the arena), kept for the re-runs */
 	ksw2amd_scoring_t src_sc; int8_t *src_mat;
-	/* streamed plans (section "streamed plans" below): the sequence arena goes up in pieces, a persistent launch per packed class
-	 * starts its wavefront-tasks as their pieces land */
+	/* streamed plans (section "streamed plans" below): the sequence arena goes up in pieces, one launch per score-only packed class
+	 * starts under the upload, every wavefront waiting for its own task's pieces */
 	int streamed;                          /* classes with cls_t.qd >= 0 exist and the next run launches them as queues */
 	int unscanned;                         /* a streamed plan's gathered arena is copied, not scanned: wildcard pairs are reported by the kernels like in flat plans */
 	stream_up_t *up_state;                 /* the piece-wise upload (lives as long as the plan: the gather's workers issue pieces) */
@@ -840,6 +857,8 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	 * queue behind the whole arena otherwise), the rest behind them.  Whether the plan then RUNS streamed is decided once its classes
 	 * are known; the pieces go up either way. */
 	if (stream_env() == 0) want_stream = 0; else if (stream_env() == 1) want_stream = 1;
+	if (g_no_defer) want_stream = 0;                     /* a fetch's re-run of pairs the kernels handed back: through the SCANNED gather path, whose
+	                                                      * wildcard flags send a pair to the int32 kernels -- unscanned it would come back again */
 	if (want_stream && n > 0 && (p->seq_bytes >= ((size_t)1 << 20) || stream_env() == 1) && (su = (stream_up_t*)calloc(1, sizeof(*su))) != 0) {
 		const char *pk_ = ENV(STREAM_PIECE_KB);
 		size_t pbytes = pk_ && atol(pk_) > 0 ? (size_t)atol(pk_) << 10 : p->seq_bytes / (flat ? 12 : 24);
@@ -1272,7 +1291,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 		const uint64_t ticks = (uint64_t)(te && atoi(te) > 0 ? atoi(te) : 2000) * 100000u;      /* 100 MHz wall clock */
 		for (k = 0; k < p->ncls; ++k) {
 			cls_t *c = &p->cls[k];
-			if (c->pk && !c->solo && c->cfg != K2A_PKCFG_MP) c->qd = p->nqd++;
+			if (c->pk && !c->solo && c->cfg != K2A_PKCFG_MP && c->mode == K2A_MODE_SCORE) c->qd = p->nqd++;      /* (the QUEUE builds of the kernels: score-only) */
 		}
 		if (p->nqd) {
 			p->h_qd = (K2aQueueDesc*)calloc((size_t)p->nqd, sizeof(K2aQueueDesc));
@@ -1318,7 +1337,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	if (su) {
 		/* a streamed plan's small arrays go up on the upload stream itself, between the second piece and the third (su->hold): nothing
 		 * of the plan waits on the host for them -- the stream the plan runs on waits for the event behind them (meta_ev), then the
-		 * persistent launches start.  (On a stream of their own with a host-side wait they took 15-25 ms whenever the DMA engines
+		 * streamed launches start.  (On a stream of their own with a host-side wait they took 15-25 ms whenever the DMA engines
 		 * were busy with the pieces: round 4, every process but the first on a box.)  up_ev marks the end of the pieces: unstreamed
 		 * classes of the plan, a repeated run after an abort and plan_destroy wait for it. */
 		for (k = 0; k < p->nqd; ++k) {
@@ -1408,8 +1427,8 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 	if (k2a_shim_event_record(p->ev[0], stream)) goto err;
 	if (streaming && ((p->wm_ev && k2a_shim_stream_wait_event(stream, p->wm_ev)) || (p->meta_ev && k2a_shim_stream_wait_event(stream, p->meta_ev)))) goto err;
 	if (streaming) {
-		/* streamed plan: every resident packed class as ONE persistent launch that starts now, under the upload, and takes its
-		 * wavefront-tasks as their pieces land (k2a_queue_pop); then, behind the whole upload, whatever else the plan holds */
+		/* streamed plan: every score-only packed class as ONE launch that starts now, under the upload, each wavefront waiting for the
+		 * pieces of its own task (k2a_queue_wait); then, behind the whole upload, whatever else the plan holds */
 		K2aQueueDesc *d_qd = (K2aQueueDesc*)(p->d_wm + K2A_WM_BYTES);
 		__sync_fetch_and_add(&g_stream_stat[0], 1);
 		for (c = 0; c < p->ncls; ++c) {
@@ -1425,6 +1444,10 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 			if (k2a_shim_event_record(p->ev[1], stream) || k2a_shim_event_record(p->ev[2], stream)) goto err;
 			return KSW2AMD_OK;
 		}
+		/* the plan's other classes are ordinary launches: behind the WHOLE arena.  The event that marks its end is recorded when the
+		 * gather's last piece has been issued (gather_wait) -- waiting for an event nobody has recorded yet is no wait at all, and the
+		 * int32 / solo classes of a mixed plan then read sequences that are not there (found by the fuzz script's streamed entries) */
+		if (p->gather && gather_wait(p)) goto err;
 		if (p->up_ev && k2a_shim_stream_wait_event(stream, p->up_ev)) goto err;
 	} else nrest = p->ncls;
 	if (nrest > 1 && !ENV(SERIAL) && side_streams() == 0) {
@@ -1562,7 +1585,7 @@ static int fetch_results(ksw2amd_plan_t *p)
 	if (p->reject_all || p->ntasks == 0) return KSW2AMD_OK;
 	if (k2a_shim_stream_sync(p->stream)) return fail(KSW2AMD_E_NODEVICE, "plan_fetch: %s", k2a_shim_last_error());
 	if (p->streamed && p->nqd > 0) {
-		/* did every persistent launch get its inputs?  A wavefront that waited longer than the launch's timeout raised `abort` and the
+		/* did every streamed launch get its inputs?  A wavefront that waited longer than the launch's timeout raised `abort` and the
 		 * queue was left unfinished: wait for the upload, then run the whole plan again the ordinary way (bounded, never a hang) */
 		K2aQueueDesc back[NCLS_ENTRIES];
 		int k, aborted = 0;
@@ -1640,8 +1663,23 @@ static void eqx_rewrite(void *km, const uint8_t *query, const uint8_t *target, i
 	free(old);
 }
 
-/* a kalloc pool has no locks (kalloc.c:24-28): the batch entry points' worker threads take this around every use of `km` */
-static pthread_mutex_t g_km_mu = PTHREAD_MUTEX_INITIALIZER;
+/* A kalloc pool has no locks (kalloc.c:24-28), and the library's worker threads assemble CIGARs into the caller's pools: every use
+ * of a pool is bracketed by ONE OF 64 mutexes chosen by the pool's address -- callers with a pool per thread (the minimap2 pattern)
+ * no longer serialise on one process-wide lock while their CIGARs are assembled (round 3: g_km_mu).  km == NULL is libc's realloc,
+ * which needs none. */
+#define KM_LOCKS 64
+static pthread_mutex_t g_km_mu[KM_LOCKS];
+static pthread_once_t g_km_once = PTHREAD_ONCE_INIT;
+static void km_init(void) { int i; for (i = 0; i < KM_LOCKS; ++i) pthread_mutex_init(&g_km_mu[i], 0); }
+static pthread_mutex_t *km_mutex(const void *km)
+{
+	uint64_t h = (uint64_t)(uintptr_t)km;
+	pthread_once(&g_km_once, km_init);
+	h ^= h >> 33; h *= 0xff51afd7ed558ccdull; h ^= h >> 29;
+	return &g_km_mu[h & (KM_LOCKS - 1)];
+}
+static void km_lock(const void *km) { if (km) pthread_mutex_lock(km_mutex(km)); }
+static void km_unlock(const void *km) { if (km) pthread_mutex_unlock(km_mutex(km)); }
 
 /* Pairs whose device result cannot be used are run again through the ordinary gather path, one by one:
  *   K2aResult.pad[0] -- flat plans: a packed kernel met a wildcard code (K2aLanePk::seen); the gather path's scan sends the pair to
@@ -1708,6 +1746,7 @@ static void assemble_range(asm_ctx_t *c, int beg, int end)
 		if (r->n_cigar > 0) {
 			const uint32_t *src = pool + pos[i];
 			int nc = r->n_cigar;
+			if (kmp) km_lock(km);
 			ez_reserve(km, z, nc);
 			memcpy(z->cigar, src, sizeof(uint32_t) * (size_t)nc);               /* already in the caller's order (k2a_compact_kernel; ksw2.h:157-159) */
 			z->n_cigar = nc;
@@ -1721,6 +1760,7 @@ static void assemble_range(asm_ctx_t *c, int beg, int end)
 					free(tmp);
 				} else eqx_rewrite(km, p->h_seq + p->h_pairs[i].qoff, p->h_seq + p->h_pairs[i].toff, 1, z);
 			}
+			if (kmp) km_unlock(km);
 		}
 	}
 	if (nrerun) __sync_fetch_and_add(&c->nrerun, nrerun);
@@ -1771,9 +1811,9 @@ static int plan_fetch_ex(ksw2amd_plan_t *p, void *km, ksw_extz_t *ez, ksw_extz_t
 		/* a big score-only plan (a streamed batch: one plan for everything): its records are assembled by the pool's threads, as the
 		 * chunks of the same batch were before -- 65 536 ksw_extz_t of config 2 are 1.3 ms on one thread, next to a 1.4 ms kernel */
 		if (!(!p->cig_words && !km && !kmp && p->n >= 16384 && assemble_parallel(&ac))) {
-			if (km || kmp) pthread_mutex_lock(&g_km_mu);
+			if (!kmp) km_lock(km);                            /* one pool for the batch: once around the loop; a pool per pair (coalesced calls): pair by pair, inside */
 			assemble_range(&ac, 0, p->n);
-			if (km || kmp) pthread_mutex_unlock(&g_km_mu);
+			if (!kmp) km_unlock(km);
 		}
 		nrerun = ac.nrerun; if (ac.rc) rc = ac.rc;
 	}
@@ -2512,8 +2552,8 @@ static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc
 		if (uniform) dev_bytes = (double)n * (double)pair_device_bytes(dual, &pairs[0]);
 		else for (i = 0; i < n; ++i) dev_bytes += (double)pair_device_bytes(dual, &pairs[i]);
 		/* One-shape score-only batches that fit the device: ONE streamed plan (section "streamed plans") instead of chunks -- a
-		 * single persistent launch that works through the batch as its pieces land, longest first, at full occupancy, started under
-		 * the upload.  Where it pays is where the kernels are long against the host's per-pair work: the 10 k headline (MI355X, round 4,
+		 * single launch over the whole batch, started under the upload, whose wavefronts wait for their pieces, longest task first, at full
+		 * occupancy.  Where it pays is where the kernels are long against the host's per-pair work: the 10 k headline (MI355X, round 4,
 		 * same box: 4 060 against 3 800 GCUPS through the pointer entry, 4 510 against 4 270 through the flat one), not 512-base reads,
 		 * whose plan creation on one thread costs what six workers' chunks cost together (config 2: 3.9 against 3.4-4.0 ms) -- so by
 		 * default batches of at least 1 M cells per pair.  KSW2AMD_STREAM=1: every one-shape score-only batch; =0: chunks. */
@@ -2632,8 +2672,28 @@ static int flat_batch(int dual, void *km, const ksw2amd_scoring_t *sc, int n, co
 	fs.on_device = in->on_device != 0;
 	for (i = 0; i < n && plain; ++i) plain = !wants_ssec(pp[i].flag);
 	if (!plain) {                                      /* SSE-compatible pairs keep their own plans: the ordinary entry point sorts them out */
-		if (fs.on_device) { free(pp); return fail(KSW2AMD_E_PARAM, "flat batch: SSE-compatible pairs need a host arena%s", 0); }
+		uint8_t *host = 0;
+		if (fs.on_device) {
+			/* ... from host memory: bring the span of a device arena back first (a sharded run whose flags ask for the SSE kernels'
+			 * results -- KSW2AMD_EZ_SSE_COMPAT, APPROX_MAX | APPROX_DROP, the process-wide switch -- reaches this on every receiving rank) */
+			const uint8_t *lo = 0, *hi = 0;
+			void *st = thread_stream();
+			for (i = 0; i < n; ++i) {
+				if (pp[i].qlen <= 0 || pp[i].tlen <= 0) continue;
+				if (!lo || pp[i].query < lo) lo = pp[i].query;
+				if (pp[i].target < lo) lo = pp[i].target;
+				if (pp[i].query + pp[i].qlen > hi) hi = pp[i].query + pp[i].qlen;
+				if (pp[i].target + pp[i].tlen > hi) hi = pp[i].target + pp[i].tlen;
+			}
+			if (lo) {
+				host = (uint8_t*)malloc((size_t)(hi - lo) + 1);
+				if (!host) { free(pp); return fail(KSW2AMD_E_NOMEM, "flat batch: host allocation failed%s", 0); }
+				if (!st || k2a_shim_d2h(host, lo, (size_t)(hi - lo), st) || k2a_shim_stream_sync(st)) { free(host); free(pp); return fail(KSW2AMD_E_NODEVICE, "flat batch: %s", k2a_shim_last_error()); }
+				for (i = 0; i < n; ++i) { pp[i].query = host + (pp[i].query - lo); pp[i].target = host + (pp[i].target - lo); }
+			}
+		}
 		rc = route_batch(dual, km, sc, n, pp, ez);
+		free(host);
 	} else rc = run_batch(dual, 0, km, sc, n, pp, ez, &fs);
 	free(pp);
 	return rc;
@@ -2651,9 +2711,10 @@ ksw2amd_plan_t *ksw2amd_plan_create_flat(int dual, const ksw2amd_scoring_t *sc, 
 	fs.on_device = in->on_device != 0;
 	p = plan_create_ex(dual, 0, sc, n, pp, &fs, 0);
 	free(pp);
-	/* the batch entry points let the upload run on while they pack the next chunk; a caller of this function may reuse its arena
-	 * as soon as it returns */
-	if (p && p->up_ev) { k2a_shim_event_sync(p->up_ev); k2a_shim_event_destroy(p->up_ev); p->up_ev = 0; }
+	/* the batch entry points let the upload run on while they pack the next chunk; here it is complete on return.  The plan still
+	 * BORROWS the arena until ksw2amd_plan_destroy (include/ksw2_amd.h): =/X rewrites and re-runs of a fetch read the sequences there */
+	if (p && p->gather) gather_wait(p);
+	if (p && p->up_ev) { k2a_shim_event_sync(p->up_ev); }
 	return p;
 }
 
@@ -2852,12 +2913,12 @@ static int small_pair(int dual, int scalar, void *km, const ksw2amd_scoring_t *s
 		if (j >= 0) { if (last_op == 1) run += (uint32_t)j + 1; else { if (run) cg[n++] = run << 4 | last_op; last_op = 1; run = (uint32_t)j + 1; } }
 		if (run) cg[n++] = run << 4 | last_op;
 		if (n > 0) {
-			if (km) pthread_mutex_lock(&g_km_mu);
+			km_lock(km);
 			ez_reserve(km, z, n);
 			for (k = 0; k < n; ++k) z->cigar[k] = cg[(fl & KSW_EZ_REV_CIGAR) ? k : n - 1 - k];           /* ksw2.h:157-159 */
 			z->n_cigar = n;
 			if (dual && (fl & KSW_EZ_EQX) && !scalar) eqx_rewrite(km, a->query, a->target, 1, z);
-			if (km) pthread_mutex_unlock(&g_km_mu);
+			km_unlock(km);
 		}
 		free(cg);
 	}

@@ -92,7 +92,8 @@ int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_
  * stream length in steps in bnd_off and the strips-per-group stride of its header table in cig_off:
  *   block = [bnd_off steps][64 lanes] x 8 bytes, then [64 / G groups][cig_off strips] x 16 bytes (K2aCkHead). */
 /* qd != NULL (device pointer, K2aQueueDesc in ksw2_types.h): a streamed launch -- at most as many workgroups as the device holds at
- * once, wavefronts pop their wavefront-tasks from qd->next and wait for qd->need[] pieces of the upload. */
+ * once, wavefronts pop their wavefront-tasks from qd->next and wait for qd->need[] pieces of the upload.  Score-only classes only
+ * (mode == K2A_MODE_SCORE): those are what the batch entry points stream. */
 int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax, int defer, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2,
                             int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, K2aQueueDesc *qd, void *stream);
 int k2a_shim_launch_trace_pk(int cfg, int dual, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb,

@@ -212,33 +212,40 @@ struct K2aTbStage {
 };
 #define K2A_PK_TB_NS(WB, LDSROW) ((WB) == 32 && (LDSROW) == 1 ? 2 : 8)      /* row state in LDS: two wavefronts per SIMD need the room */
 
-/* Streamed launches (K2aQueueDesc, ksw2_types.h): the next wavefront-task of a persistent launch, or -1 when the queue is empty or
- * the launch was aborted.  Wave-uniform.  Before it returns a task it waits until the upload pieces the task's sequences lie in have
- * landed: word 0 of the plan's watermark block, written by DMA copies that the upload stream orders behind each piece, polled with
- * system-scope loads between s_sleep's.  The wait is bounded: past qd->timeout_ticks (100 MHz) the wavefront raises qd->abort and
- * every wavefront leaves at its next pop -- a kernel of this library never spins on data that may not come. */
-__device__ __forceinline__ int k2a_queue_pop(K2aQueueDesc *qd)
+/* Streamed launches (K2aQueueDesc, ksw2_types.h): before a wavefront of a QUEUE build starts its wavefront-task it waits until the
+ * upload pieces the task's sequences lie in have landed: word 0 of the plan's watermark block, written by DMA copies that the upload
+ * stream orders behind each piece, polled with system-scope loads between s_sleep's.  Wave-uniform; false = do not run (the launch
+ * was aborted).  The wait is bounded: past qd->timeout_ticks (100 MHz) the wavefront raises qd->abort and every wavefront that
+ * starts later leaves at once -- a kernel of this library never spins on data that may not come.  Tasks are dispatched in grid
+ * order, longest first, which for a batch in its arena's order is the order of the pieces; a wavefront that waits holds its slot,
+ * but the pieces arrive whatever the CUs do (the DMA engines move them), so the launch always makes progress.
+ * (Round 4 first ran these launches as persistent loops over a task counter: the loop cost the kernels 6-40 registers -- the
+ * headline's a resident wavefront, 4 830 -> 4 610 GCUPS -- for nothing a wait in front of the body does not give.) */
+__device__ __forceinline__ bool k2a_queue_wait(K2aQueueDesc *qd, int wt)
 {
-	uint32_t wt = 0;
-	if ((threadIdx.x & 63) == 0) wt = __hip_atomic_fetch_add(&qd->next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	wt = (uint32_t)__builtin_amdgcn_readfirstlane((int)wt);
-	if (wt >= qd->nwt) return -1;
-	if (__hip_atomic_load(&qd->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return -1;
+	if ((uint32_t)wt >= qd->nwt) return true;                   /* (an idle wavefront of the last workgroup) */
+	if (__hip_atomic_load(&qd->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
 	const uint32_t need = qd->need[wt];
 	if (need) {
 		const uint32_t *wm = qd->wm;
 		const uint64_t t0 = wall_clock64(), limit = qd->timeout_ticks;
 		for (int it = 0; __hip_atomic_load(wm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < need; ++it) {
-			if (__hip_atomic_load(&qd->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return -1;
-			if (wall_clock64() - t0 > limit) { __hip_atomic_store(&qd->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return -1; }
+			if (__hip_atomic_load(&qd->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+			if (wall_clock64() - t0 > limit) { __hip_atomic_store(&qd->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
 			if (it < 16) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(127);      /* ~0.4 us, then ~3.4 us */
 		}
 	}
-	return (int)wt;
+	/* ONE acquire behind the poll, system scope: the pieces were written by the DMA engines while this kernel was already running,
+	 * and without it the sequence loads that follow are served stale lines (MI355X_MICROARCH.md, "Consumer, always: ONE relaxed
+	 * poll -> ONE acquire -> plain loads"; found by the fuzz script: batches whose data lands after the launch read the PREVIOUS
+	 * plan's bytes from the recycled arena -- which a test that runs the same batch twice never sees).  Once per wavefront-task. */
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+	if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&qd->next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      /* tasks started: what the host checks a run by */
+	return true;
 }
 
 /* Packed-int16 resident fill: two same-shape alignments per lane group (ksw2_lane_pk.h). */
-template<int G, int C, bool DUAL, int MODE, bool RB, bool NOMAX, int LDSROW = 0, bool DEFER = false>      /* LDSROW: 1 = row state in LDS, 2 = only the target-code planes; DEFER: K2aLanePk */
+template<int G, int C, bool DUAL, int MODE, bool RB, bool NOMAX, int LDSROW = 0, bool DEFER = false, bool QUEUE = false>      /* LDSROW: 1 = row state in LDS, 2 = only the target-code planes; DEFER: K2aLanePk; QUEUE: streamed launches */
 __global__ void __launch_bounds__(64 * K2A_WPB, LDSROW == 2 ? (G == 16 ? 4 : 3) : LDSROW ? 2 : 1)      /* no floor elsewhere: capping the register form of the score-only kernels at 168 VGPRs spills and is 18 % slower */
 k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
                    const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, K2aResult *__restrict__ res, K2aQueueDesc *qd)
@@ -250,9 +257,11 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 
 	const int lane = threadIdx.x & 63, wave = k2a_wave_id<(C <= 8 || LDSROW || (NOMAX && DUAL && MODE != K2A_MODE_SCORE))>();   /* 16 rows, two-piece, traceback: part of what gets those kernels to two wavefronts */
 	const int grp = lane / G, gl = lane % G;
-	/* one wavefront-task (NG tasks) per wavefront by position in the grid, or -- streamed launches, qd != NULL -- as many as this
-	 * wavefront gets from the launch's queue (k2a_queue_pop), each one started only when its inputs are on the device */
-	for (int wt = qd ? k2a_queue_pop(qd) : blockIdx.x * K2A_WPB + wave; wt >= 0; wt = qd ? k2a_queue_pop(qd) : -1) {
+	/* one wavefront-task (NG tasks) per wavefront, by position in the grid; the QUEUE builds (streamed launches) first wait for the
+	 * task's inputs (k2a_queue_wait) */
+	const int wt = blockIdx.x * K2A_WPB + wave;
+	if (QUEUE && !k2a_queue_wait(qd, wt)) return;
+	{
 	const int task = wt * NG + grp;
 	const bool valid = task < ntasks;
 	const uint32_t piA = order2[valid ? 2 * task : 0], piB = order2[valid ? 2 * task + 1 : 0];
@@ -403,7 +412,6 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 		if (piB != piA) k2a_finish(prB, b, &res[piB]);
 		if (gsaw) { res[piA].pad[0] = 1; res[piB].pad[0] = 1; }
 	}
-	__builtin_amdgcn_wave_barrier();                   /* the books and stages in LDS are the next wavefront-task's */
 	}
 }
 
@@ -1567,6 +1575,11 @@ typedef void (*fill_pk_fn)(const K2aScoring, const K2aPair*, const uint32_t*, in
 #define PK_SET(NM) { { PK_ROW(8, 18, false, NM), PK_ROW(16, 8, false, NM), PK_ROW(64, 8, false, NM), PK_ROW(64, 16, false, NM) }, \
                      { PK_ROW(8, 18, true, NM),  PK_ROW(16, 8, true, NM),  PK_ROW(64, 8, true, NM),  PK_ROW(64, 16, true, NM) } }
 static const fill_pk_fn g_fill_pk[2][2][K2A_NPKCFG][2][3] = { PK_SET(false), PK_SET(true) };     /* [nomax][rebased][cfg][dual][mode] */
+/* the QUEUE builds (streamed launches): score-only kernels only -- what the batch entry points stream; [nomax][rebased][cfg][dual] */
+#define PKQ_ROW(G, C, RB, NM) { k2a_fill_pk_kernel<G, C, false, 0, RB, NM, 0, false, true>, k2a_fill_pk_kernel<G, C, true, 0, RB, NM, 0, false, true> }
+#define PKQ_SET(NM) { { PKQ_ROW(8, 18, false, NM), PKQ_ROW(16, 8, false, NM), PKQ_ROW(64, 8, false, NM), PKQ_ROW(64, 16, false, NM) }, \
+                      { PKQ_ROW(8, 18, true, NM),  PKQ_ROW(16, 8, true, NM),  PKQ_ROW(64, 8, true, NM),  PKQ_ROW(64, 16, true, NM) } }
+static const fill_pk_fn g_fill_pkq[2][2][K2A_NPKCFG][2] = { PKQ_SET(false), PKQ_SET(true) };
 /* the K2A_PK_LDSROWS classes with their row state in LDS: [rebased][mode - 1] */
 static const fill_pk_fn g_fill_pk_lds[2][2] = {
 	{ k2a_fill_pk_kernel<64, 16, true, 1, false, false, 1>, k2a_fill_pk_kernel<64, 16, true, 2, false, false, 1> },
@@ -1576,10 +1589,15 @@ static const fill_pk_fn g_fill_pk_lds[2][2] = {
 #define LDSCODE_SET(G, C) { { k2a_fill_pk_kernel<G, C, false, 0, false, false, 2>, k2a_fill_pk_kernel<G, C, false, 0, true, false, 2> }, \
                             { k2a_fill_pk_kernel<G, C, false, 0, false, true, 2>,  k2a_fill_pk_kernel<G, C, false, 0, true, true, 2> } }
 static const fill_pk_fn g_fill_pk_ldscodes[3][2][2] = { LDSCODE_SET(64, 16), LDSCODE_SET(8, 18), LDSCODE_SET(16, 8) };
+#define LDSCODEQ_SET(G, C) { { k2a_fill_pk_kernel<G, C, false, 0, false, false, 2, false, true>, k2a_fill_pk_kernel<G, C, false, 0, true, false, 2, false, true> }, \
+                             { k2a_fill_pk_kernel<G, C, false, 0, false, true, 2, false, true>,  k2a_fill_pk_kernel<G, C, false, 0, true, true, 2, false, true> } }
+static const fill_pk_fn g_fill_pkq_ldscodes[3][2][2] = { LDSCODEQ_SET(64, 16), LDSCODEQ_SET(8, 18), LDSCODEQ_SET(16, 8) };
 /* exact score-only single-gap kernels with the arg-max deferred (K2aLanePk, DEFER) and their second pass: [cfg][rebased]; the
  * fill in the form the launcher prefers for big launches of that geometry (code planes in LDS for (16, 8) and (64, 16)) */
 #define DEFER_ROW(G, C, LR) { k2a_fill_pk_kernel<G, C, false, 0, false, false, LR, true>, k2a_fill_pk_kernel<G, C, false, 0, true, false, LR, true> }
 static const fill_pk_fn g_fill_pk_defer[4][2] = { DEFER_ROW(8, 18, 0), DEFER_ROW(16, 8, 2), DEFER_ROW(64, 8, 0), DEFER_ROW(64, 16, 2) };
+#define DEFERQ_ROW(G, C, LR) { k2a_fill_pk_kernel<G, C, false, 0, false, false, LR, true, true>, k2a_fill_pk_kernel<G, C, false, 0, true, false, LR, true, true> }
+static const fill_pk_fn g_fill_pkq_defer[4][2] = { DEFERQ_ROW(8, 18, 0), DEFERQ_ROW(16, 8, 2), DEFERQ_ROW(64, 8, 0), DEFERQ_ROW(64, 16, 2) };
 typedef void (*argmax_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, const uint8_t*, K2aResult*);
 #define ARGMAX_ROW(G, C) { k2a_argmax_kernel<G, C, false>, k2a_argmax_kernel<G, C, true> }
 static const argmax_fn g_argmax[4][2] = { ARGMAX_ROW(8, 18), ARGMAX_ROW(16, 8), ARGMAX_ROW(64, 8), ARGMAX_ROW(64, 16) };
@@ -1750,18 +1768,6 @@ int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_
 	return 0;
 }
 
-/* workgroups of a streamed (persistent) launch: what the device holds at once -- more would only queue up behind wavefronts that
- * do not leave before the task queue is empty */
-static int k2a_resident_blocks(fill_pk_fn fn, int blocks)
-{
-	int per_cu = 0, dev = 0;
-	hipDeviceProp_t pr;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, 64 * K2A_WPB, 0) != hipSuccess || per_cu <= 0) return blocks;
-	if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return blocks;
-	const long cap = (long)per_cu * pr.multiProcessorCount;
-	return cap < blocks ? (int)cap : blocks;
-}
-
 int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax, int defer, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2,
                             int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, K2aQueueDesc *qd, void *stream)
 {
@@ -1773,8 +1779,8 @@ int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax,
 		/* deferred arg-max: the fill streams its checkpoints into `tb` (block offsets in K2aPair.tb_off / bnd_off / cig_off),
 		 * the second pass fills in max_q / mte_q */
 		if (cfg >= K2A_PKCFG_MP || dual || mode != K2A_MODE_SCORE || nomax || !tb) { snprintf(g_err, sizeof(g_err), "bad deferred arg-max class"); return -1; }
-		const fill_pk_fn fn = g_fill_pk_defer[cfg][rebased ? 1 : 0];
-		hipLaunchKernelGGL(fn, dim3(qd ? k2a_resident_blocks(fn, blocks) : blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream, *sc, pairs, order2, ntasks, seq, tb, res, qd);
+		const fill_pk_fn fn = (qd ? g_fill_pkq_defer : g_fill_pk_defer)[cfg][rebased ? 1 : 0];
+		hipLaunchKernelGGL(fn, dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream, *sc, pairs, order2, ntasks, seq, tb, res, qd);
 		CHECK(hipGetLastError());
 		hipLaunchKernelGGL(g_argmax[cfg][rebased ? 1 : 0], dim3((3 * ntasks + 64 * K2A_WPB - 1) / (64 * K2A_WPB)), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
 		                   *sc, pairs, order2, ntasks, seq, (const uint8_t*)tb, res);
@@ -1783,8 +1789,11 @@ int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax,
 	}
 	const int form = k2a_shim_pk_form(cfg, dual, mode, nomax, ntasks);
 	const bool lds = form == 1, ldc = form == 2;
-	const fill_pk_fn fn = lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1] : ldc ? g_fill_pk_ldscodes[k2a_pkcfg_G[cfg] == 8 ? 1 : k2a_pkcfg_G[cfg] == 16 ? 2 : 0][nomax ? 1 : 0][rebased ? 1 : 0] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode];
-	hipLaunchKernelGGL(fn, dim3(qd ? k2a_resident_blocks(fn, blocks) : blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
+	if (qd && (mode != K2A_MODE_SCORE || lds)) { snprintf(g_err, sizeof(g_err), "streamed launches exist for the score-only packed kernels only"); return -1; }
+	const fill_pk_fn fn = lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1]
+	                    : ldc ? (qd ? g_fill_pkq_ldscodes : g_fill_pk_ldscodes)[k2a_pkcfg_G[cfg] == 8 ? 1 : k2a_pkcfg_G[cfg] == 16 ? 2 : 0][nomax ? 1 : 0][rebased ? 1 : 0]
+	                    : qd ? g_fill_pkq[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode];
+	hipLaunchKernelGGL(fn, dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
 	                   *sc, pairs, order2, ntasks, seq, tb, res, qd);
 	CHECK(hipGetLastError());
 	return 0;

@@ -118,17 +118,18 @@ typedef struct K2aResult {
 	int32_t pad[2];                  /* [0]: a packed kernel read a wildcard code (unscanned flat plans), [1]: inexact (deferred arg-max): the host re-runs the pair */
 } K2aResult;
 
-/* Streamed launches (ksw2_host.c, "streamed plans"): ONE persistent launch of a packed fill kernel whose wavefronts pop
- * wavefront-tasks (the 64 / G consecutive tasks one wavefront runs) from a counter, longest first, and start a task only once the
- * upload pieces its sequences lie in have landed: the host uploads the sequence arena in pieces on another stream and behind
- * each piece copies a block of K2A_WM_BYTES filled with the piece's number onto the plan's watermark block (a DMA copy like the
- * piece itself, ordered behind it by the stream: word 0 of the block = pieces that have landed).  A wavefront whose inputs do not
- * arrive within `timeout_ticks` (100 MHz) sets `abort` and everybody leaves; the host then runs the plan again, unstreamed.
- * Device-resident, one per launch, uploaded with the task lists. */
+/* Streamed launches (ksw2_host.c, "streamed plans"): ONE launch of a packed fill kernel over the whole batch, started under the
+ * batch's upload.  Its wavefronts take their wavefront-tasks (the 64 / G consecutive tasks one wavefront runs) by position in the
+ * grid, longest first, and each waits in front of its task until the upload pieces its sequences lie in have landed: the host
+ * uploads the sequence arena in pieces on another stream and behind each piece copies a block of K2A_WM_BYTES filled with the piece's
+ * number onto the plan's watermark block (a DMA copy like the piece itself, ordered behind it by the stream: word 0 of the block =
+ * pieces that have landed).  A wavefront whose inputs do not arrive within `timeout_ticks` (100 MHz) sets `abort` and the wavefronts
+ * that start later leave at once; the host then runs the plan again, unstreamed.  Device-resident, one per launch, uploaded with the
+ * task lists. */
 #define K2A_WM_BYTES 65536            /* large enough that the runtime moves it with the DMA engines like the pieces themselves, never with a kernel
-                                       * (a persistent launch may hold every wavefront slot: tools/probe/stream_publish_probe.hip) */
+                                       * (a launch that fills the device leaves a copy kernel no wavefront slot: tools/probe/stream_publish_probe.hip) */
 typedef struct K2aQueueDesc {
-	uint32_t next;                    /* next wavefront-task, atomic */
+	uint32_t next;                    /* wavefront-tasks started (atomic); == nwt after a complete run */
 	uint32_t abort;                   /* (the host zeroes these two words before every run) */
 	uint32_t nwt;                     /* wavefront-tasks of the launch */
 	uint32_t pad;

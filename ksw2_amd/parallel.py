@@ -113,6 +113,10 @@ def scatter_arrays(parts, dtypes, src=0, group=None, keep_device=()):
         if sizes[rank, x]:
             ops.append(dist.P2POp(dist.irecv, bufs[x], _peer(group, src), group))
     _exchange(ops)
+    if any(x in keep_device and bufs[x].is_cuda for x in range(k)):
+        # a device tensor goes to the library, which copies it on a stream of its own: the receive must be complete on the device
+        # first (req.wait() orders torch's current stream only), whatever else this function downloads
+        torch.cuda.current_stream(bufs[0].device).synchronize()
     return tuple(bufs[x] if (x in keep_device and bufs[x].is_cuda) else _from_wire(bufs[x]) for x in range(k))
 
 

@@ -180,6 +180,14 @@ def fast_fixed(config_index, n, qlen, tlen, sub=0.05, ind=0.06, tail_random_frac
     return q, t
 
 
+def ragged_lengths(config_index, n, lo, hi, sub=0.03, ind=0.15, maxdiff=450, first=0):
+    """The (qlen, tlen) arrays fast_ragged would produce, without the sequences (partition studies on a million pairs)."""
+    ql = np.empty(n, dtype=np.int32)
+    tl = np.empty(n, dtype=np.int32)
+    _fast_lib().k2s_ragged_lengths(BASE_SEED + int(config_index), int(first), n, lo, hi, sub, ind, maxdiff, ql.ctypes.data, tl.ctypes.data, _threads())
+    return ql, tl
+
+
 def fast_ragged(config_index, n, lo, hi, sub=0.03, ind=0.15, maxdiff=450, first=0):
     """Config 5's mix: query length uniform in [lo, hi], target = the query through the channel (its natural length; redrawn
     while |tlen - qlen| > maxdiff).  Returns two lists of uint8 views into two flat arrays (kept alive by the views)."""

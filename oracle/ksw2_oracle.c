@@ -388,3 +388,26 @@ int64_t kso_band_cells(int qlen, int tlen, int w)
 	}
 	return n;
 }
+
+int kso_cigar_score(int n_cigar, const uint32_t *cigar, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat,
+                    int q, int e, int q2, int e2, int *qused, int *tused)
+{
+	int x = 0, y = 0, k, i;        /* x: target bases consumed, y: query bases */
+	int64_t sc = 0;
+	for (k = 0; k < n_cigar; ++k) {
+		const int op = (int)(cigar[k] & 0xf), len = (int)(cigar[k] >> 4);
+		if (op == 0) {
+			if (x + len > tlen || y + len > qlen) return KSO_NEG_INF;
+			for (i = 0; i < len; ++i) sc += mat[(int)target[x + i] * m + query[y + i]];
+			x += len; y += len;
+		} else if (op == 1 || op == 2) {
+			int64_t c = (int64_t)q + (int64_t)len * e;
+			if (q2 >= 0) { const int64_t c2 = (int64_t)q2 + (int64_t)len * e2; if (c2 < c) c = c2; }
+			sc -= c;
+			if (op == 2) { x += len; if (x > tlen) return KSO_NEG_INF; } else { y += len; if (y > qlen) return KSO_NEG_INF; }
+		} else return KSO_NEG_INF;
+	}
+	if (qused) *qused = y;
+	if (tused) *tused = x;
+	return (int)sc;
+}

@@ -92,6 +92,12 @@ void kso_extf2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, 
 
 /* number of DP cells inside the exact band |i-j|<=w (SURVEY.md section 8d metric definition) */
 int64_t kso_band_cells(int qlen, int tlen, int w);
+/* Score of a CIGAR (M / I / D runs from the start of both sequences, in the caller's order: ksw2.h:22-27 encoding, len << 4 | op) under
+ * the affine (q2 < 0) or two-piece affine gap model: sum of mat[t * m + q] over M columns minus min(q + l e, q2 + l e2) per gap run.
+ * *qused / *tused = bases consumed.  A size-independent property check for batches far too big for the oracle itself: an optimal
+ * alignment's CIGAR re-scores to the reported score (ksw2_extz.c:127-133 start cells).  Returns KSO_NEG_INF on a malformed CIGAR. */
+int kso_cigar_score(int n_cigar, const uint32_t *cigar, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat,
+                    int q, int e, int q2, int e2, int *qused, int *tused);
 
 /* splice-aware extension (ksw2_oracle_exts.c): contract of ksw_exts2_sse, ksw2.h:73-74 */
 void kso_exts2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,

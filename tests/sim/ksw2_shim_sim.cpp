@@ -113,7 +113,7 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 	typedef K2aLanePk<G, C, DUAL, MODE, RB, NOMAX, LDSROW, DEFER> Lane;
 	const int nwaves = (ntasks + NG - 1) / NG;
 	for (int wv = 0; wv < nwaves; ++wv) {
-		/* streamed launches (k2a_queue_pop): wavefront-tasks in queue order; the simulator's uploads are synchronous, so a piece
+		/* streamed launches (k2a_queue_wait): wavefront-tasks in grid order; the simulator's uploads are synchronous, so a piece
 		 * that has not landed by now never will -- what the kernel finds out by its timeout */
 		if (qd) {
 			if (qd->nwt != (uint32_t)nwaves) { qd->abort = 2; break; }

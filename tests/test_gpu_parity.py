@@ -1093,14 +1093,166 @@ def test_streamed_plans_forced_on_and_off(lib, monkeypatch, flat):
 
         off, ns, na = run(KSW2AMD_STREAM=0)
         assert ns == 0 and na == 0
+        streams = bool(flag & po.SCORE_ONLY)              # the queue builds of the kernels exist for the score-only classes; a CIGAR batch keeps ordinary launches behind its pieces
+        # A decoy batch of the same shapes but other bases goes through the same path first: the device arena, the staging and the
+        # caches then hold ITS bytes, and a wavefront that read anything that was not uploaded for this batch -- too early, or out of
+        # a stale cache line -- would differ.  (Running the same batch twice hides exactly that: round 4's missing acquire behind the
+        # watermark poll passed such a test and failed the fuzz script.)
+        keep = (qs, ts)
+        qs, ts = [np.random.default_rng(7 + ci).integers(0, 4, len(x), dtype=np.uint8) for x in keep[0]], [np.random.default_rng(9 + ci).integers(0, 4, len(x), dtype=np.uint8) for x in keep[1]]
+        run(KSW2AMD_STREAM=1, KSW2AMD_STREAM_PIECE_KB=512, KSW2AMD_STREAM_SLEEP_US=200)
+        qs, ts = keep
         on, ns, na = run(KSW2AMD_STREAM=1, KSW2AMD_STREAM_PIECE_KB=512, KSW2AMD_STREAM_SLEEP_US=200)
-        assert ns >= 1 and na == 0, (ci, ns, na)
+        assert (ns >= 1) == streams and na == 0, (ci, ns, na)
         bad = [i for i in range(n) if diff(off[i], on[i])]
         assert not bad, (ci, flat, bad[:5])
+        qs, ts = [np.random.default_rng(17 + ci).integers(0, 4, len(x), dtype=np.uint8) for x in keep[0]], [np.random.default_rng(19 + ci).integers(0, 4, len(x), dtype=np.uint8) for x in keep[1]]
+        run(KSW2AMD_STREAM=1)                              # (decoy once more, default pieces, nothing slowed down)
+        qs, ts = keep
+        on2, ns, na = run(KSW2AMD_STREAM=1)
+        bad = [i for i in range(n) if diff(off[i], on2[i])]
+        assert not bad, (ci, flat, "default pieces", bad[:5])
         flt, ns, na = run(KSW2AMD_STREAM=1, KSW2AMD_STREAM_PIECE_KB=512, KSW2AMD_STREAM_FAULT=1, KSW2AMD_STREAM_TIMEOUT_MS=20)
-        assert ns >= 1 and na >= 1, (ci, ns, na)
+        assert (ns >= 1 and na >= 1) == streams, (ci, ns, na)
         bad = [i for i in range(n) if diff(off[i], flt[i])]
         assert not bad, (ci, flat, "fault", bad[:5])
         for i in list(range(0, n, max(1, n // 40))) + list(wild):
             exp = po.align("oracle", "extd2" if dual else "extz2", qs[i], ts[i], mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=0, flag=flag)
             assert not diff(exp, on[i]), (ci, flat, i)
+
+
+_EZ_DT = np.dtype({"names": ["max_zd", "max_q", "max_t", "mqe", "mqe_t", "mte", "mte_q", "score", "m_cigar", "n_cigar", "reach_end", "cigar"],
+                   "formats": ["<u4"] + ["<i4"] * 10 + ["<u8"], "offsets": [0, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 48], "itemsize": 56})
+
+
+def _raw_batch(lib, dual, batch):
+    """One call of the batch entry point into a ctypes record array (no Python objects per pair: for batches of 10^5 pairs with CIGARs);
+    returns (ez, structured numpy view of the records)."""
+    ez = (ka.KswExtz * batch.n)()
+    f = lib.lib.ksw2amd_extd_batch if dual else lib.lib.ksw2amd_extz_batch
+    lib._check(f(None, ctypes.byref(batch.sc), batch.n, batch.pairs, ez))
+    return ez, np.frombuffer(ez, dtype=_EZ_DT)
+
+
+def _free_raw(ez, view):
+    for p in view["cigar"]:
+        if p:
+            ka._libc.free(ctypes.c_void_p(int(p)))
+
+
+def _cigar_words(view, i):
+    n = int(view["n_cigar"][i])
+    return np.ctypeslib.as_array(ctypes.cast(int(view["cigar"][i]), ctypes.POINTER(ctypes.c_uint32)), (n,)) if n else np.zeros(0, np.uint32)
+
+
+def test_cfg4_full_size_properties(lib):
+    """BASELINE config 4 at its full size: MT-human x MT-orang replicated 4 096 x, unbanded extz2 with CIGAR, through ksw2amd_extz_batch
+    (four device-filling plans of the packed generation-serial class).  Every replica's record equals the reference's known answer
+    (score 16102, max 17054 at (16568, 16024)) and every CIGAR equals the first replica's word for word, whose md5 is the
+    golden ea0524d904ed."""
+    ka_ = gu.known_answers()
+    exp = [r for r in ka_["mt"] if r["func"] == "ksw_extz" and r["w"] == -1 and r.get("flag", 0) == 0 and r.get("zdrop", -1) == -1][0]
+    assert exp["cigar_md5_12"] == "ea0524d904ed"
+    _, ts = gu.read_fasta("MT-human.fa")
+    _, qs = gu.read_fasta("MT-orang.fa")
+    n = 4096
+    q1, t1 = np.ascontiguousarray(qs[0]), np.ascontiguousarray(ts[0])
+    lib.release_cache()
+    b = lib.make_batch([q1] * n, [t1] * n, gu.simple_mat(5, 2, 4, 0), 4, 2, 0, 0, w=-1, zdrop=-1, end_bonus=0, flag=0)
+    ez, v = _raw_batch(lib, False, b)
+    try:
+        for f, name in (("score", "score"), ("max_q", "max_q"), ("max_t", "max_t"), ("mqe", "mqe"), ("mqe_t", "mqe_t"), ("mte", "mte"), ("mte_q", "mte_q"),
+                        ("reach_end", "reach_end"), ("n_cigar", "n_cigar")):
+            assert (v[f] == exp[name]).all(), (name, np.flatnonzero(v[f] != exp[name])[:5])
+        assert ((v["max_zd"] & 0x7fffffff) == exp["max"]).all() and ((v["max_zd"] >> 31) == exp["zdropped"]).all()
+        c0 = _cigar_words(v, 0).copy()
+        s0 = gu.cigar_string([int(x) for x in c0])
+        assert hashlib.md5((s0 + "\n").encode()).hexdigest()[:12] == "ea0524d904ed"
+        for i in range(1, n):
+            assert np.array_equal(_cigar_words(v, i), c0), i
+    finally:
+        _free_raw(ez, v)
+        lib.release_cache()
+
+
+def test_cfg5_share_properties(lib, monkeypatch):
+    """BASELINE config 5 at the per-GPU share it states (1 M pairs over 8 GPUs = 125 000 ONT-like pairs, qlen in [300, 20 000], 15 %
+    indels, band 500, extd2, Z-drop 400, CIGAR; production occupancy rules: seven device-filling plans, the solo kernel's rules, the
+    LPT order).  The default launch, KSW2AMD_SOLO=0 and KSW2AMD_NO_PK=1 (the int32 kernels) agree on every record and every CIGAR; every
+    CIGAR spans exactly the prefixes its record names and re-scores to the reported score / maximum (oracle/kso_cigar_score); every
+    500th pair equals the oracle in every field."""
+    monkeypatch.delenv("KSW2AMD_SIMDS", raising=False)
+    lib.release_cache()                                 # the buffers the earlier tests' plans left in the thread's cache (config 4: 140 GB of direction codes)
+    n = 125000
+    qs, ts = synth.fast_ragged(5, n, 300, 20000, sub=0.03, ind=0.15, maxdiff=450)
+    mat = synth.simple_mat(5, 2, 4, -1)
+    b = lib.make_batch(qs, ts, mat, 4, 2, 24, 1, w=500, zdrop=400, end_bonus=0, flag=0)
+    ez0, v0 = _raw_batch(lib, True, b)
+    olib = po.oracle_lib()
+    olib.kso_cigar_score.restype = ctypes.c_int
+    olib.kso_cigar_score.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    try:
+        ndrop = 0
+        qu, tu = ctypes.c_int(0), ctypes.c_int(0)
+        for i in range(n):
+            sc = olib.kso_cigar_score(int(v0["n_cigar"][i]), int(v0["cigar"][i]), len(qs[i]), qs[i].ctypes.data, len(ts[i]), ts[i].ctypes.data, 5, mat.ctypes.data,
+                                      4, 2, 24, 1, ctypes.byref(qu), ctypes.byref(tu))
+            if v0["max_zd"][i] >> 31:
+                ndrop += 1
+                assert (qu.value, tu.value) == (v0["max_q"][i] + 1, v0["max_t"][i] + 1) and sc == (v0["max_zd"][i] & 0x7fffffff), i
+            else:
+                assert (qu.value, tu.value) == (len(qs[i]), len(ts[i])) and sc == v0["score"][i], i
+        assert ndrop < n // 20, ndrop
+        for env in ({"KSW2AMD_SOLO": "0"}, {"KSW2AMD_NO_PK": "1"}):
+            for k, val in env.items():
+                monkeypatch.setenv(k, val)
+            ez1, v1 = _raw_batch(lib, True, b)
+            try:
+                for f in _EZ_DT.names:
+                    if f not in ("cigar", "m_cigar"):
+                        assert (v0[f] == v1[f]).all(), (env, f, np.flatnonzero(v0[f] != v1[f])[:5])
+                for i in range(n):
+                    assert np.array_equal(_cigar_words(v0, i), _cigar_words(v1, i)), (env, i)
+            finally:
+                _free_raw(ez1, v1)
+            for k in env:
+                monkeypatch.delenv(k)
+        for i in range(0, n, 500):
+            exp = po.align("oracle", "extd2", qs[i], ts[i], mat, 4, 2, 24, 1, w=500, zdrop=400, end_bonus=0, flag=0)
+            got = dict(score=int(v0["score"][i]), max=int(v0["max_zd"][i] & 0x7fffffff), zdropped=int(v0["max_zd"][i] >> 31), max_q=int(v0["max_q"][i]), max_t=int(v0["max_t"][i]),
+                       mqe=int(v0["mqe"][i]), mqe_t=int(v0["mqe_t"][i]), mte=int(v0["mte"][i]), mte_q=int(v0["mte_q"][i]), reach_end=int(v0["reach_end"][i]),
+                       n_cigar=int(v0["n_cigar"][i]), cigar=[int(x) for x in _cigar_words(v0, i)])
+            assert not diff(exp, got, CMP_FIELDS), i
+    finally:
+        _free_raw(ez0, v0)
+        lib.release_cache()
+
+
+def test_set_devices_two_worker_sets_on_one_gpu(lib, monkeypatch):
+    """ksw2amd_set_devices on real hardware (the in-process multi-GPU form a C caller would use; tests/test_host_pipeline.py runs it on
+    simulated devices): the device list { 0, 0 } -- two entries, so the pool shards the batch with its several-devices rules (finer
+    chunks, three per worker) -- must return what the single-device call returns, on a config-3 shaped batch (one shape, extd2, Z-drop,
+    CIGAR) and a config-5 shaped one (ragged, band 500), every field and CIGAR, with samples against the oracle."""
+    monkeypatch.delenv("KSW2AMD_SIMDS", raising=False)
+    mat = synth.simple_mat(5, 2, 4, -1)
+    q3, t3 = synth.fixed_batch(3, 4096, 2048, 2048, sub=0.05, ind=0.10, tail_random_frac=0.25, tail_pairs=0.10)
+    q5, t5 = synth.fast_ragged(5, 3000, 300, 20000, sub=0.03, ind=0.15, maxdiff=450)
+    one3 = lib.extd_batch(q3, t3, mat, 4, 2, 24, 1, w=256, zdrop=400, flag=0)
+    one5 = lib.extd_batch(q5, t5, mat, 4, 2, 24, 1, w=500, zdrop=400, flag=0)
+    s0 = lib.host_stats()
+    lib.set_devices([0, 0])
+    try:
+        two3 = lib.extd_batch(q3, t3, mat, 4, 2, 24, 1, w=256, zdrop=400, flag=0)
+        two5 = lib.extd_batch(q5, t5, mat, 4, 2, 24, 1, w=500, zdrop=400, flag=0)
+    finally:
+        lib.set_devices([])
+        lib.release_cache()
+    assert lib.host_stats()["pool_batches"] >= s0["pool_batches"] + 2          # both went through the pool's multi-device path
+    for a, b, name in ((one3, two3, "cfg3"), (one5, two5, "cfg5")):
+        bad = [i for i in range(len(a)) if diff(a[i], b[i])]
+        assert not bad, (name, bad[:5])
+    for i in range(0, 4096, 512):
+        assert not diff(po.align("oracle", "extd2", q3[i], t3[i], mat, 4, 2, 24, 1, w=256, zdrop=400, flag=0), two3[i]), i
+    for i in range(0, 3000, 500):
+        assert not diff(po.align("oracle", "extd2", q5[i], t5[i], mat, 4, 2, 24, 1, w=500, zdrop=400, flag=0), two5[i]), i

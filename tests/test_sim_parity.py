@@ -624,6 +624,22 @@ def _check_flat(lib, device_copy=None):
                 assert not diff(exp, ref[i]), (i, dual)
             tot += 1
     assert {"pk", "solo", "int32"} <= kinds, kinds         # unscanned arenas reach the packed AND the solo kernels (both report wildcard codes)
+    if device_copy is not None:
+        # a DEVICE arena whose pairs ask for the SSE kernels' own results (what a sharded run with those flags hands every receiving
+        # rank, ksw2_amd/parallel.py): the span comes back to the host and takes the SSE-compatible plans -- same results as the pointer entry
+        pairs = synth.ragged_pairs(rng, 24, 30, 300, sub=0.08, ind=0.15)
+        qs, ts = [p[0] for p in pairs], [p[1] for p in pairs]
+        mat = synth.simple_mat(5, 2, 4, -1)
+        w = rng.choice([-1, 3, 9, 33, 100], size=24)
+        fl = np.array([int(rng.choice([ka.KSW2AMD_EZ_SSE_COMPAT, po.APPROX_MAX | po.APPROX_DROP, 0])) | int(rng.choice([0, po.SCORE_ONLY])) for _ in range(24)])
+        for dual in (False, True):
+            ref = (lib.extd_batch(qs, ts, mat, 4, 2, 24, 1, w=w, zdrop=60, end_bonus=5, flag=fl) if dual else lib.extz_batch(qs, ts, mat, 4, 2, w=w, zdrop=60, end_bonus=5, flag=fl))
+            fb = lib.make_flat_batch(qs, ts, mat, 4, 2, 24, 1, w=w, zdrop=60, end_bonus=5, flag=fl)
+            keep = device_copy(fb.arena)
+            fd = lib.make_flat_batch(qs, ts, mat, 4, 2, 24, 1, w=w, zdrop=60, end_bonus=5, flag=fl, device_base=keep[0])
+            got = fd.run_oneshot(dual)
+            for i in range(24):
+                assert not diff(ref[i], got[i]), ("device arena + SSE-compatible flags", i, dual, hex(int(fl[i])), diff(ref[i], got[i]))
     return tot
 
 
@@ -812,8 +828,9 @@ def test_sim_streamed_plans(sim, monkeypatch, flat):
             else:
                 res = (sim.extd_batch(qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, flag=flag) if dual else sim.extz_batch(qs, ts, mat, q, e, w=w, zdrop=zd, flag=flag))
             s1 = sim.stream_stats()
-            assert s1["streamed_plans"] > s0["streamed_plans"], (ci, flat)
-            assert (s1["aborted_runs"] > s0["aborted_runs"]) == bool(fault), (ci, flat, fault)
+            streams = bool(flag & po.SCORE_ONLY)          # the queue builds of the kernels exist for the score-only classes
+            assert (s1["streamed_plans"] > s0["streamed_plans"]) == streams, (ci, flat)
+            assert (s1["aborted_runs"] > s0["aborted_runs"]) == bool(fault and streams), (ci, flat, fault)
             if wild:
                 assert sim.rerun_count() >= r0 + len(wild)
             for i in range(n):

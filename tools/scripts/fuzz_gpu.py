@@ -81,6 +81,9 @@ while time.time() - t0 < budget:
             ref = lib.extd_batch(qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl) if dual else lib.extz_batch(qs, ts, mat, q, e, w=w, zdrop=zd, end_bonus=eb, flag=fl)
             got = fb.run_oneshot(dual)
             for i in range(n):
+                if diff(ref[i], got[i]):
+                    import pickle
+                    pickle.dump(dict(qs=qs, ts=ts, mat=mat, sc=(q, e, q2, e2), w=w, zd=zd, eb=eb, fl=fl, dual=dual), open("/tmp/fuzz_fail.pkl", "wb"))
                 assert not diff(ref[i], got[i]), ("flat", env, dual, i, len(qs[i]), len(ts[i]), int(w[i]), hex(int(fl[i])), diff(ref[i], got[i]))
         try:
             check_batch(lib, dual, qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=eb, flag=fl)

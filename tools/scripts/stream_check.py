@@ -44,12 +44,15 @@ if SIM:
     cases = [(c[0] // 16, c[1] // 2, c[2] // 2, c[3], c[4], c[5]) for c in cases]
 for (n, ql, tl, w, flag, dual) in cases:
     q, t = synth.fixed_batch(3, n, ql, tl, sub=0.05, ind=0.06)
-    for flat in (False, True):
+    dq, dt = synth.fixed_batch(4, n, ql, tl, sub=0.05, ind=0.06)       # decoy: same shapes, other bases -- run before every streamed run, so that arenas,
+    for flat in (False, True):                                         # staging and caches hold ITS bytes (a repeated batch hides stale or early reads)
         r0, s0, d0 = run(q, t, w, flag, dual, flat, KSW2AMD_STREAM=0)
-        outs = [("auto", run(q, t, w, flag, dual, flat)),
-                ("forced small pieces", run(q, t, w, flag, dual, flat, KSW2AMD_STREAM=1, KSW2AMD_STREAM_PIECE_KB=256)),
-                ("slow upload", run(q, t, w, flag, dual, flat, KSW2AMD_STREAM=1, KSW2AMD_STREAM_PIECE_KB=1024, KSW2AMD_STREAM_SLEEP_US=300)),
-                ("fault", run(q, t, w, flag, dual, flat, KSW2AMD_STREAM=1, KSW2AMD_STREAM_FAULT=1, KSW2AMD_STREAM_TIMEOUT_MS=20))]
+        outs = []
+        for name, env in (("auto", {}), ("forced small pieces", dict(KSW2AMD_STREAM=1, KSW2AMD_STREAM_PIECE_KB=256)),
+                          ("slow upload", dict(KSW2AMD_STREAM=1, KSW2AMD_STREAM_PIECE_KB=1024, KSW2AMD_STREAM_SLEEP_US=300)),
+                          ("fault", dict(KSW2AMD_STREAM=1, KSW2AMD_STREAM_FAULT=1, KSW2AMD_STREAM_TIMEOUT_MS=20))):
+            run(dq, dt, w, flag, dual, flat, **env)
+            outs.append((name, run(q, t, w, flag, dual, flat, **env)))
         for name, (r, s, d) in outs:
             bad = [i for i in range(n) if any(r0[i][f] != r[i][f] for f in ka.FIELDS + ["cigar"])]
             bad_total += len(bad)
