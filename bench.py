@@ -68,9 +68,9 @@ WORKLOADS = {
     "extf": dict(idx=8, n=16384, qlen=1000, tlen=1000, w=100, zdrop=-1, dual=False, flag=SO, sub=0.05, ind=0.01, linear=True),
     # the headline's shape where extensions DO drop: a fifth of the pairs get the last quarter of the query replaced by random bases, so the
     # Z-drop fires there -- what the deferred arg-max costs when it has to hand alignments back is in this line
-    "10k-zdrop": dict(idx=6, n=12288, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=SO, sub=0.05, ind=0.06, tail_frac=0.25, tail_pairs=0.20),
+    "10k-zdrop": dict(idx=6, n=49152, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=SO, sub=0.05, ind=0.06, tail_frac=0.25, tail_pairs=0.20),
     # ... and where 1 % of the pairs hold a wildcard base: those leave the packed kernels (they score match / mismatch only)
-    "10k-N": dict(idx=6, n=12288, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=SO, sub=0.05, ind=0.06, wild_pairs=0.01),
+    "10k-N": dict(idx=6, n=49152, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=SO, sub=0.05, ind=0.06, wild_pairs=0.01),
     # ... and in the SSE-compatible mode (the reference's SSE kernels' own results): every pair through k2a_ssec_kernel
     "10k-ssec": dict(idx=6, n=1024, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=SO, sub=0.05, ind=0.06, sse=True),
 }

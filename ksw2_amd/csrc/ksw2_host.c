@@ -53,11 +53,9 @@ static void release_thread_cache(void);
 	X(ABORT_ON_ERROR) \
 	X(BACKTRACE) \
 	X(APPROX_DROP_EXACT) \
-	X(CHUNKS) \
 	X(CHUNK_GCELLS) \
 	X(CHUNK_MB) \
 	X(COALESCE_SLOTS) \
-	X(DBUF) \
 	X(DEFER) \
 	X(EXTF_HBM) \
 	X(EXTF_LANE) \
@@ -67,7 +65,6 @@ static void release_thread_cache(void);
 	X(EXTF_WIN) \
 	X(EXTS_BIG) \
 	X(EXTS_REG) \
-	X(KEEP_LEFTOVERS) \
 	X(LDSCODES) \
 	X(LDSROWS) \
 	X(LONG_MS) \
@@ -77,10 +74,8 @@ static void release_thread_cache(void);
 	X(NO_PKMP) \
 	X(NO_RB) \
 	X(NO_SHARED_UP) \
-	X(NO_UNITS) \
 	X(PK_FIRST) \
 	X(POOL_MIN) \
-	X(RAMP) \
 	X(SERIAL) \
 	X(SIMDS) \
 	X(SMALL_CELLS) \
@@ -857,6 +852,8 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	 * queue behind the whole arena otherwise), the rest behind them.  Whether the plan then RUNS streamed is decided once its classes
 	 * are known; the pieces go up either way. */
 	if (stream_env() == 0) want_stream = 0; else if (stream_env() == 1) want_stream = 1;
+	if (flat && flat->on_device) want_stream = 0;        /* a device-resident arena: nothing to overlap (one device-to-device copy at HBM rate), and that copy is a
+	                                                      * KERNEL, which a launch of waiting wavefronts that fills the device would starve (tools/probe/stream_publish_probe.hip) */
 	if (g_no_defer) want_stream = 0;                     /* a fetch's re-run of pairs the kernels handed back: through the SCANNED gather path, whose
 	                                                      * wildcard flags send a pair to the int32 kernels -- unscanned it would come back again */
 	if (want_stream && n > 0 && (p->seq_bytes >= ((size_t)1 << 20) || stream_env() == 1) && (su = (stream_up_t*)calloc(1, sizeof(*su))) != 0) {
@@ -1011,12 +1008,12 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	 * unique lengths, CIGAR: 707 vs 825 GCUPS) and writes twice the direction bytes, so the odd one of every shape goes back.
 	 * Parity of every (class, shape) key in one pass over an open-addressing table. */
 	uni = n > 1 && nfull == 1 && ninvalid == 0;          /* (nothing below has changed a pair's class yet) */
-	if (uni && !ENV(KEEP_LEFTOVERS)) {
+	if (uni) {
 		/* one shape: the table below has one key; its odd one out is the last pair */
 		if ((n & 1) && p->h_cls[0] >= 0 && pk_ok[0] && pk_ok[0] != PASS_SOLO && ((p->h_cls[0] / 2) % 3 != K2A_MODE_SCORE || (solo_mode && solo_ok[0])) &&
 		    k2a_pkcfg_G[(pk_ok[0] - 1) % K2A_NPKCFG] == 64) { pk_ok[n - 1] = (uint8_t)(solo_mode && solo_ok[n - 1] ? PASS_SOLO : 0); uni = 0; }
 	} else
-	if (n > 0 && !ENV(KEEP_LEFTOVERS)) {
+	if (n > 0) {
 		size_t cap = 16, h;
 		struct slot { uint64_t k1, k2; int32_t last, odd; } *tab;
 		int any = 0;
@@ -2112,9 +2109,7 @@ void ksw2amd_release_cache(void)
 	}
 }
 
-/* cut [0, n) into at most `nchunks` (+ 2 * workers) chunks of consecutive pairs; cost[i] >= 1.  With enough chunks the first
- * ones are small (the device gets its first kernels after a quarter of a chunk's packing time, not a whole one) and so are the
- * last ones (the results of the final chunks come back quickly): weights 1/4, 1/2, 1 ... 1, 1/2.  Returns the chunk count, cbeg[0..count] */
+/* cut [0, n) into at most `nchunks` chunks of consecutive pairs of about equal cost; cost[i] >= 1.  Returns the chunk count, cbeg[0..count] */
 static int make_chunks(int n, const double *cost, double total, int nchunks, int workers, int chunk_pairs, int *cbeg)
 {
 	if (chunk_pairs > 0) {                                /* batches of one shape: whole device fills (uniform_chunks) */
@@ -2130,17 +2125,17 @@ static int make_chunks(int n, const double *cost, double total, int nchunks, int
 		cbeg[c] = n;
 		return c;
 	}
-	const int ramp = nchunks >= 3 * workers && workers > 0 && env_flag(ENV(RAMP), 0), nc = ramp ? nchunks + 2 * workers : nchunks;
-	double wsum = 0, acc = 0, edge = 0;
+	const int nc = nchunks;
+	double acc = 0, edge = 0;
 	int i, c = 0;
-	for (i = 0; i < nc; ++i) wsum += !ramp ? 1.0 : i < workers ? 0.25 : (i < 2 * workers || i >= nc - workers) ? 0.5 : 1.0;
+	(void)workers;
 	cbeg[0] = 0;
-	edge = (!ramp ? 1.0 : 0.25) / wsum * total;
+	edge = total / nc;
 	for (i = 0; i < n; ++i) {
 		acc += cost[i];
 		if (c + 1 < nc && acc >= edge && i + 1 < n) {
 			cbeg[++c] = i + 1;
-			edge += (!ramp ? 1.0 : c < workers ? 0.25 : (c < 2 * workers || c >= nc - workers) ? 0.5 : 1.0) / wsum * total;
+			edge += total / nc;
 		}
 	}
 	cbeg[++c] = n;
@@ -2438,12 +2433,11 @@ static int plan_chunks(int n, double bytes, double cells, int workers, int ndev,
 		else if (k > (with_cigar ? 2 : 1) * workers && bytes / cap_b <= (with_cigar ? 2 : 1) * workers) k = (with_cigar ? 2 : 1) * workers;
 	}
 	if (ndev > 1 && k < 3 * workers) k = 3 * workers;      /* several devices: finer grains balance them */
-	{ const char *e3 = ENV(CHUNKS); if (e3 && atoi(e3) > 0) k = atoi(e3); }      /* experiments: this many chunks, whatever the batch */
 	if (k > n / min_chunk) k = n / min_chunk;
 	return k < 2 ? 0 : (int)(k + 0.999);
 }
 
-typedef struct { int dual, scalar, dbuf; void *km; const ksw2amd_scoring_t *sc; const ksw2amd_pair_t *pairs; ksw_extz_t *ez; const flat_src_t *flat; } ext_ctx_t;
+typedef struct { int dual, scalar; void *km; const ksw2amd_scoring_t *sc; const ksw2amd_pair_t *pairs; ksw_extz_t *ez; const flat_src_t *flat; } ext_ctx_t;
 static double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 static int trace_on(void) { return ENV(TRACE) != 0; }
 
@@ -2461,14 +2455,10 @@ static int ext_finish(ext_ctx_t *c, pend_t *pd)
 	return rc;
 }
 
-/* One chunk on a pool worker: pack, upload, run, fetch.  Single-buffered, the workers are what overlaps the phases of
- * different chunks; double-buffered (`dbuf`), a worker queues chunk k + 1 before it waits for chunk k, so the device always has
- * kernels behind the ones it runs while the workers download and assemble CIGARs.  Measured (profiles/r2_chunk_grid.txt,
- * r2_pipeline_traces.txt): score-only long reads lose with it (10 k headline 2 720 vs 3 100 GCUPS: twice the plans in flight, each
- * kernel filling less of the device); short reads with CIGARs gained over chunks that did not tile the SIMDs (config 3: 735 vs
- * 540) but lose against chunks that do (600-670 vs 745-765, r2_chunk_units.txt), and over many batches it degrades badly
- * (config 3: 597 GCUPS over 10 batches, 42 over 30; not run down -- a worker's second live plan misses the one-deep buffer cache
- * once per batch, i.e. a multi-GB hipMalloc + hipFree per worker and batch, which is the suspect): off unless KSW2AMD_DBUF=1.  A chunk that does not fit one plan (traceback memory) takes the serial path. */
+/* One chunk on a pool worker: pack, upload, run, fetch; the workers are what overlaps the phases of different chunks.  (A worker
+ * that queued chunk k + 1 before it waited for chunk k -- rounds 2 and 3, behind a switch -- lost on every configuration once the
+ * chunks tiled the SIMDs, and degraded over many batches: removed in round 4.)  A chunk that does not fit one plan (traceback
+ * memory) takes the serial path. */
 static int ext_chunk(void *ctx_, int beg, int end, int share, pend_t *pd)
 {
 	ext_ctx_t *c = (ext_ctx_t*)ctx_;
@@ -2482,8 +2472,8 @@ static int ext_chunk(void *ctx_, int beg, int end, int share, pend_t *pd)
 	if (env && atoll(env) > 0) budget = (size_t)atoll(env);
 	else if (bytes > ((size_t)256 << 20)) {
 		if (k2a_shim_mem_info(&free_b, &total_b)) return fail(KSW2AMD_E_NODEVICE, "mem_info: %s", k2a_shim_last_error());
-		/* what is free now, plus what this worker's pending plan and cache will hand back, over two plans per worker */
-		budget = device_budget(free_b, total_b, share * (c->dbuf ? 2 : 1));
+		/* what is free now, plus what this worker's cache will hand back */
+		budget = device_budget(free_b, total_b, share);
 	}
 	if (bytes > budget) {
 		rc = ext_finish(c, pd);
@@ -2491,7 +2481,7 @@ static int ext_chunk(void *ctx_, int beg, int end, int share, pend_t *pd)
 	}
 	t0 = now_ms();
 	p = plan_create_ex(c->dual, c->scalar, c->sc, end - beg, c->pairs + beg, c->flat, 0);
-	if (!p) {                                       /* out of device memory with two plans alive: finish the old one, go serial */
+	if (!p) {                                       /* out of device memory: go serial (plans sized to what is free) */
 		if (!strstr(g_err, "alloc")) return strstr(g_err, "device") ? KSW2AMD_E_NODEVICE : KSW2AMD_E_PARAM;
 		rc = ext_finish(c, pd);
 		return rc ? rc : run_serial(c->dual, c->scalar, c->km, c->sc, end - beg, c->pairs + beg, c->ez + beg, share, c->flat, 0);
@@ -2502,7 +2492,7 @@ static int ext_chunk(void *ctx_, int beg, int end, int share, pend_t *pd)
 	rc2 = ext_finish(c, pd);
 	if (rc) { ksw2amd_plan_destroy(p); return rc; }
 	pd->p = p; pd->beg = beg;
-	if (!c->dbuf) { rc = ext_finish(c, pd); if (!rc2) rc2 = rc; }                       /* single-buffered: finish this chunk before taking the next */
+	rc = ext_finish(c, pd); if (!rc2) rc2 = rc;                                        /* finish this chunk before taking the next */
 	return rc2;
 }
 
@@ -2557,7 +2547,7 @@ static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc
 		 * same box: 4 060 against 3 800 GCUPS through the pointer entry, 4 510 against 4 270 through the flat one), not 512-base reads,
 		 * whose plan creation on one thread costs what six workers' chunks cost together (config 2: 3.9 against 3.4-4.0 ms) -- so by
 		 * default batches of at least 1 M cells per pair.  KSW2AMD_STREAM=1: every one-shape score-only batch; =0: chunks. */
-		if (uniform && (pairs[0].flag & KSW_EZ_SCORE_ONLY) && stream_env() != 0 && g_ndev_set <= 1 && !pool_min_pairs() && !ENV(CHUNKS) &&
+		if (uniform && (pairs[0].flag & KSW_EZ_SCORE_ONLY) && stream_env() != 0 && g_ndev_set <= 1 && !pool_min_pairs() &&
 		    (double)n * ((double)imax(pairs[0].qlen, 0) + imax(pairs[0].tlen, 0)) >= 4.0 * 1048576.0) {
 			const int mx0 = imax(pairs[0].qlen, pairs[0].tlen);
 			const int64_t c0 = pairs[0].qlen > 0 && pairs[0].tlen > 0 ? band_cells(pairs[0].qlen, pairs[0].tlen, (pairs[0].w < 0 || pairs[0].w > mx0) ? mx0 : pairs[0].w) : 0;
@@ -2587,21 +2577,13 @@ static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc
 			}
 			if (uniform) { bytes *= n; cells *= n; for (i = 1; i < n; ++i) cost[i] = cost[0]; total = cost[0] * n; }
 			{
-				const int unit = uniform && !pool_min_pairs() && !ENV(CHUNKS) && !ENV(NO_UNITS) ? unit_pairs(&pairs[0]) : 0;
+				const int unit = uniform && !pool_min_pairs() ? unit_pairs(&pairs[0]) : 0;
 				if (unit > 0) nchunks = uniform_chunks(n, unit, bytes, cells, workers, g_ndev_set, !(pairs[0].flag & KSW_EZ_SCORE_ONLY), path, &chunk_pairs);
 				else nchunks = plan_chunks(n, bytes, cells, workers, g_ndev_set, !(pairs[0].flag & KSW_EZ_SCORE_ONLY), path);
 			}
 			if (nchunks >= 2) {
 				ext_ctx_t ctx;
 				ctx.dual = dual; ctx.scalar = scalar; ctx.km = km; ctx.sc = sc; ctx.pairs = pairs; ctx.ez = ez; ctx.flat = flat;
-				{	/* double-buffering is opt-in (see ext_chunk) */
-					/* (flat batches too: their plans are created without waiting for the upload, so a worker could pack chunk k + 1 right
-					 * after launching chunk k -- measured on config 2, round 3: 930 against 1 030 GCUPS.  The timeline
-					 * (profiles/r3_cfg2_phases.txt) shows why nothing on the host side helps any more: all eight chunks are created and
-					 * launched 1.3 ms into the batch, but their eight half-empty kernels need until 3.5 ms.) */
-					const char *ev = ENV(DBUF);
-					ctx.dbuf = ev && *ev ? atoi(ev) != 0 : 0;
-				}
 				if (run_pooled(ext_chunk, &ctx, n, cost, total, nchunks, chunk_pairs, &rc)) { free(cost); return rc; }
 			}
 			free(cost);
@@ -3342,12 +3324,10 @@ static int exts_serial(void *km, const ksw2amd_splice_t *sc, int n, const ksw2am
  * multiples of a device fill (one wavefront per SIMD) like the extz / extd batches (uniform_chunks) */
 static int wave_chunks(int n, int workers, int uniform, int *chunk_pairs)
 {
-	const char *e3 = ENV(CHUNKS);
 	const int simds = k2a_shim_simd_count();
 	int k = imin(workers, n / 256);
-	if (e3 && atoi(e3) > 0) k = atoi(e3);
 	*chunk_pairs = 0;
-	if (uniform && simds > 0 && k >= 2 && n >= 2 * simds && !ENV(NO_UNITS)) {
+	if (uniform && simds > 0 && k >= 2 && n >= 2 * simds) {
 		int cp = (n + k - 1) / k;
 		cp = (cp + simds - 1) / simds * simds;
 		*chunk_pairs = cp;

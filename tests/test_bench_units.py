@@ -62,7 +62,7 @@ def test_job_dry_run_on_the_simulator(sim, name, monkeypatch):
     j.free_ez()
     r = j.resident(2, 1, None)
     rl = bench.roofline_of(j, r, name)
-    assert r["cells"] > 0 and 0 <= rl["early_stop_fraction"] <= 1 and rl["kernel_gcups"] > 0
+    assert r["cells"] > 0 and 0 <= rl["early_stop_fraction"] <= 1 and rl["kernel_gcups"] >= 0 and r["kernel_ms"] > 0      # (the simulator's rate rounds to 0.00 on a busy box)
     if name not in ("exts",):
         assert r["cells"] == (j.cells if name != "cfg4" else int(bench.cells_of_rows(j.qlen[:3], j.tlen[:3], j.weff[:3]).sum()))
     assert bench.describe(j, 1).startswith(name) and bench.dtype_of(j, r)

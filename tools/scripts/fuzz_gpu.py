@@ -24,7 +24,7 @@ lib = ka.Library(os.environ["KSW2AMD_FUZZ_LIB"]) if os.environ.get("KSW2AMD_FUZZ
 ENVS = [{}, {"KSW2AMD_SOLO": "1"}, {"KSW2AMD_SOLO": "all"}, {"KSW2AMD_LDSROWS": "0"}, {"KSW2AMD_LDSROWS": "1"}, {"KSW2AMD_NO_PK": "1"},
         {"KSW2AMD_SIMDS": "0"}, {"KSW2AMD_EXTF_WIN": "1"}, {"KSW2AMD_EXTF_LDS": "1"}, {"KSW2AMD_EXTS_REG": "1"},
         {"KSW2AMD_POOL_MIN": "8", "KSW2AMD_THREADS": "3"}, {"KSW2AMD_POOL_MIN": "4", "KSW2AMD_SIMDS": "0"}, {"KSW2AMD_NO_PKMP": "1"},
-        {"KSW2AMD_SIMDS": "0", "KSW2AMD_KEEP_LEFTOVERS": "1"}, {"KSW2AMD_LDSCODES": "0", "KSW2AMD_SIMDS": "0"}, {"KSW2AMD_LDSCODES": "1", "KSW2AMD_SIMDS": "0"},
+        {"KSW2AMD_LDSCODES": "0", "KSW2AMD_SIMDS": "0"}, {"KSW2AMD_LDSCODES": "1", "KSW2AMD_SIMDS": "0"},
         {"KSW2AMD_LDSCODES": "1", "KSW2AMD_LDSROWS": "1"}, {"KSW2AMD_DEFER": "1", "KSW2AMD_SIMDS": "0"}, {"KSW2AMD_DEFER": "0"},
         {"KSW2AMD_DEFER": "1"}, {"KSW2AMD_SOLO": "0"}, {"KSW2AMD_EXTF_LANE": "1", "KSW2AMD_EXTF_RING": "1"}, {"KSW2AMD_EXTF_LANE": "1", "KSW2AMD_EXTF_RING": "0"},
         # streamed plans (round 4): every plan that can, the arena in small pieces; with the packed kernels forced for small test batches
