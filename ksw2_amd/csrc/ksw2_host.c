@@ -56,6 +56,8 @@ static void release_thread_cache(void);
 	X(CHUNK_GCELLS) \
 	X(CHUNK_MB) \
 	X(COALESCE_SLOTS) \
+	X(COALESCE_WINDOW_US) \
+	X(COALESCE_PLAIN_STREAMS) \
 	X(DEFER) \
 	X(EXTF_HBM) \
 	X(EXTF_LANE) \
@@ -101,6 +103,8 @@ static const char *const g_env_name[ENV_COUNT] = {
 	K2A_ENV_LIST
 #undef X
 };
+static __thread void *g_plan_stream;                 /* ... and this is the stream it will run on: its uploads go there too (in order: no event, no second queue) */
+static __thread int g_latency_plan;                  /* this thread is creating the plan of a single-pair call (or of a coalesced batch of them) */
 static const char *g_env[ENV_COUNT];
 static volatile int g_env_ready;
 static int g_env_gen;                                /* bumped by every (re)load: function-local caches key on it */
@@ -748,7 +752,11 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	const int solo_mode = !solo_env ? 3 : !strcmp(solo_env, "0") ? 0 : !strcmp(solo_env, "all") ? 2 : 1;
 	const int use_pk = !ENV(NO_PK), use_rb = !ENV(NO_RB);
 	const int use_pkmp = !ENV(NO_PKMP);                          /* A/B runs and tests: wide bands through the int32 generation-serial kernels */
-	const int pk_first = ENV(PK_FIRST) ? atoi(ENV(PK_FIRST)) : 0;   /* A/B runs: skip the smaller packed geometries */
+	/* A/B runs: skip the smaller packed geometries.  Single-pair calls and their coalesced batches (g_latency_plan) skip them by
+	 * themselves: 8 or 16 lanes x 18 / 8 rows per alignment is the geometry that fills a device, but a lane then walks 4 strips of
+	 * 18 rows one after the other -- one 512 x 512, w = 64 pair takes 0.455 ms that way and 0.33 ms with 64 lanes x 8 rows (or the
+	 * solo kernel), and a caller that waits for ONE pair, or 64 threads that wait for their 64, wait for exactly that. */
+	const int pk_first = ENV(PK_FIRST) ? atoi(ENV(PK_FIRST)) : (g_latency_plan && n <= 256) ? 2 : 0;
 
 	if (tlev) tph[0] = now_ms();
 	g_err[0] = 0;
@@ -1097,7 +1105,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	 * under 16 MB (single calls, coalesced batches, small chunks) keep the calling thread's own stream and wait for it: an event per
 	 * call would only add latency there.  KSW2AMD_NO_SHARED_UP=1: the old behaviour, for A/B runs. */
 	up = su ? su->up : (flat && !flat->on_device) || (!flat && p->seq_bytes >= ((size_t)16 << 20) && !ENV(NO_SHARED_UP)) ? shared_upload_stream() : 0;
-	if (up) shared_up = 1; else up = thread_upload_stream();
+	if (up) shared_up = 1; else up = g_plan_stream ? g_plan_stream : thread_upload_stream();
 	p->stream = up; p->stream_used = 1;              /* plan_destroy waits for it before the buffers are recycled */
 	if (su) { /* the pieces are on their way (or there) already */ }
 	else if (flat) {
@@ -1374,20 +1382,32 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 		stream_issue(su, -1);
 		if (su->rc || !p->up_ev) { fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error()); goto err; }
 		if (!p->gather && k2a_shim_event_record(p->up_ev, up)) { fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error()); goto err; }   /* (with a gather in flight: recorded by gather_wait) */
-	} else
-	if (k2a_shim_h2d(p->d_pairs, p->h_pairs, sizeof(K2aPair) * (size_t)n, up) ||
-	    k2a_shim_h2d(p->d_order, p->h_order, sizeof(uint32_t) * (size_t)p->norder, up) ||
-	    k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)n, up) ||
-	    (p->bnd_words && k2a_shim_memset(p->d_bnd, 0xC0, p->bnd_words * 4, up)) ||
-	    /* the shared stream: nobody waits here -- the stream the plan runs on waits for this event (ksw2amd_plan_run), so the
-	     * creating thread can pack its next chunk while this one's bytes are still on the link */
-	    (shared_up ? (!p->up_ev || k2a_shim_event_record(p->up_ev, up)) : k2a_shim_stream_sync(up))) {
-		fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error());
-		goto err;
+	} else {
+		/* every other plan: the same staging and the same rule -- nobody waits here.  The small arrays leave from page-locked staging, an
+		 * event behind them is what the stream the plan runs on waits for (ksw2amd_plan_run), and the creating thread goes on to the
+		 * launches (a coalesced batch of single-pair calls: one host wait per batch, in fetch) or to packing its next chunk.  The result
+		 * records are cleared only where something reads a record no kernel writes: the CIGAR compaction walks every pair of the plan,
+		 * the invalid ones too (k2a_finish writes all of a record for every pair that is in a class). */
+		const size_t b_pairs = align_up(sizeof(K2aPair) * (size_t)n, 256);
+		const int need_clear = ninvalid > 0 && p->cig_words > 0;
+		p->h_meta = (uint8_t*)cache_get(BUF_HMETA, b_pairs + sizeof(uint32_t) * (size_t)p->norder + 256, &p->cap[BUF_HMETA]);
+		if (!p->h_meta) { fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
+		memcpy(p->h_meta, p->h_pairs, sizeof(K2aPair) * (size_t)n);
+		memcpy(p->h_meta + b_pairs, p->h_order, sizeof(uint32_t) * (size_t)p->norder);
+		if (!p->up_ev) p->up_ev = k2a_shim_event_create();
+		if (!p->up_ev ||
+		    k2a_shim_h2d(p->d_pairs, p->h_meta, sizeof(K2aPair) * (size_t)n, up) ||
+		    k2a_shim_h2d(p->d_order, p->h_meta + b_pairs, sizeof(uint32_t) * (size_t)p->norder, up) ||
+		    (need_clear && k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)n, up)) ||
+		    (p->bnd_words && k2a_shim_memset(p->d_bnd, 0xC0, p->bnd_words * 4, up)) ||
+		    k2a_shim_event_record(p->up_ev, up)) {
+			fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error());
+			goto err;
+		}
 	}
 	if (m > 5) for (k = 0; k < p->ncls; ++k) p->cls[k].sc.mat = (const int8_t*)p->d_seq + mat_off + (p->cls[k].generic ? (size_t)m * m : 0);
 	free(pk_ok); free(solo_ok);
-	if (shared_up) { p->flat_tail = flat_tmp; flat_tmp = 0; }       /* still being read by the upload */
+	p->flat_tail = flat_tmp; flat_tmp = 0;                          /* still being read by the upload */
 	free(flat_tmp);
 	plan_ready(p);                                                  /* the uploads are complete (or fenced by up_ev) */
 	if (tlev) { const double t6 = now_ms(); char tmsg[96]; tmsg[0] = 0; if (su) snprintf(tmsg, sizeof(tmsg), "; streamed: %d pieces, %.3f ms in the upload calls so far", su->np, su->issue_ms); fprintf(stderr, "[ksw2_amd] plan_create n=%d: host arrays + arena layout %.3f, copy + classify %.3f, shape parity + demotions %.3f, sequence upload call + task lists %.3f, traceback layout %.3f, uploads + sync %.3f ms%s\n", n, tph[1] - tph[0], tph[2] - tph[1], tph[3] - tph[2], tph[4] - tph[3] , tph[5] - tph[4], t6 - tph[5], tmsg); }
@@ -1580,8 +1600,8 @@ static int fetch_results(ksw2amd_plan_t *p)
 	if (!p || !p->ran) return fail(KSW2AMD_E_PARAM, "plan_fetch: plan has not run%s", 0);
 	if (p->gather && gather_wait(p)) return fail(KSW2AMD_E_NODEVICE, "plan_fetch: upload failed: %s", k2a_shim_last_error());
 	if (p->reject_all || p->ntasks == 0) return KSW2AMD_OK;
-	if (k2a_shim_stream_sync(p->stream)) return fail(KSW2AMD_E_NODEVICE, "plan_fetch: %s", k2a_shim_last_error());
 	if (p->streamed && p->nqd > 0) {
+		if (k2a_shim_stream_sync(p->stream)) return fail(KSW2AMD_E_NODEVICE, "plan_fetch: %s", k2a_shim_last_error());
 		/* did every streamed launch get its inputs?  A wavefront that waited longer than the launch's timeout raised `abort` and the
 		 * queue was left unfinished: wait for the upload, then run the whole plan again the ordinary way (bounded, never a hang) */
 		K2aQueueDesc back[NCLS_ENTRIES];
@@ -1921,7 +1941,7 @@ static int run_serial(int dual, int scalar, void *km, const ksw2amd_scoring_t *s
 		{
 			const double t1 = now_ms();
 			double t2, t3;
-			rc = ksw2amd_plan_run(p, thread_stream());
+			rc = ksw2amd_plan_run(p, g_plan_stream ? g_plan_stream : thread_stream());
 			t2 = now_ms();
 			if (rc == KSW2AMD_OK) rc = ksw2amd_plan_fetch(p, km, ez + beg);
 			t3 = now_ms();
@@ -2439,6 +2459,7 @@ static int plan_chunks(int n, double bytes, double cells, int workers, int ndev,
 
 typedef struct { int dual, scalar; void *km; const ksw2amd_scoring_t *sc; const ksw2amd_pair_t *pairs; ksw_extz_t *ez; const flat_src_t *flat; } ext_ctx_t;
 static double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+static int64_t now_ns(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (int64_t)ts.tv_sec * 1000000000 + ts.tv_nsec; }
 static int trace_on(void) { return ENV(TRACE) != 0; }
 
 static double g_batch_t0;                  /* KSW2AMD_TRACE: start of the current pooled batch, for the timeline */
@@ -2935,7 +2956,9 @@ static void one_pair(const char *fn, int dual, int scalar, void *km, int qlen, c
 		}
 	}
 	if (!scalar && queue_one(fn, dual, km, &sc, &pr, ez)) return;     /* coalesced with other threads' calls */
+	g_latency_plan = 1;
 	rc = run_serial(dual, scalar, km, &sc, 1, &pr, ez, 1, 0, 0);
+	g_latency_plan = 0;
 	if (rc != KSW2AMD_OK) call_failed(fn, rc, ez);
 }
 
@@ -3007,15 +3030,31 @@ int ksw_gg2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_
  * A minimap2-style caller runs a pool of host threads that each call ksw_extz2_sse / ksw_extd2_sse for one pair at a time.
  * One pair is far too little work for a launch: the call costs ~0.45 ms of fixed latency, and the runtime serialises the
  * threads' API calls.  So at most KSW2AMD_COALESCE_SLOTS (default 4, 0 = off) device batches of single-pair calls are in
- * flight at a time.  A call that finds a free slot runs at once, alone, exactly as before.  A call that finds none queues
- * up; the first one in the queue becomes the leader, waits for a slot -- while every other arriving call joins the queue --
- * and then runs everybody's pairs as ONE batch per (function, scoring) group, each result into the caller's own ksw_extz_t
- * with CIGAR memory from the caller's own km.  Few threads: no added latency.  Many threads: batches of about half the
- * thread count alternate on the device.  Results are identical either way. */
+ * flight at a time.  A call that finds a free slot and no crowd runs at once, alone, exactly as before.  Otherwise it pushes
+ * its request on a lock-free list; whoever pushed onto the EMPTY list is the leader of that list: it waits for a slot -- while
+ * every other arriving call joins the list -- takes the list, and runs everybody's pairs as ONE batch per (function, scoring)
+ * group, each result into the caller's own ksw_extz_t with CIGAR memory from the caller's own km.  Few threads: no added
+ * latency.  Many threads: one batch per round trip of the pool.  Results are identical either way.
+ *
+ * Round 4 (64 threads, 512 x 512: 33 k -> see INTEGRATION.md section 1): what bounded the rate was not the device but the
+ * hand-overs.  (1) A pool whose calls come back together calls again together: the first one back found the slots free,
+ * ran ALONE, and the other 63 waited for its 0.5 ms launch before their batch could start -- a one-pair plan in front of every
+ * batch.  Calls are counted per millisecond; eight or more in this or the last one is a crowd, and in a crowd nobody runs
+ * alone: the leader collects for at most KSW2AMD_COALESCE_WINDOW_US (default 200), or until as many calls have arrived as the
+ * last batches held (the usual end: a few microseconds).  (2) One mutex and one condition variable woke 63 followers through
+ * 63 serial hand-overs of that mutex, and the same threads queued up on it again to enter their next call.  The list is a
+ * compare-and-swap push, a follower sleeps on one process-wide futex word that a finished batch bumps once (one system call
+ * wakes everybody; a follower of another batch looks at its own flag and sleeps again), and nothing is locked anywhere. */
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <limits.h>
+#include <sched.h>
 #define COAL_MAXQ 512
+#define COAL_IDS 64                     /* lists alive at a time: one per slot and the one being collected; a request record is aligned to this */
 typedef struct creq_s {
 	struct creq_s *next;
-	int dual, done, rc, taken;
+	int dual, rc, taken;
+	volatile int done;
 	const ksw2amd_scoring_t *sc;
 	const ksw2amd_pair_t *pr;
 	void *km;
@@ -3023,11 +3062,23 @@ typedef struct creq_s {
 	char err[200];
 } creq_t;
 static struct {
-	pthread_mutex_t mu;
-	pthread_cond_t arrive, finished;
-	creq_t *head, *tail;
-	int count, leader, busy;
-} g_coal = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, 0, 0, 0, 0, 0 };
+	uintptr_t head;                        /* lock-free LIFO of waiting requests: the top record's address | the list's number (COAL_IDS - 1 low bits' worth);
+	                                        * pushing onto 0 makes the pusher the leader of a new list */
+	int count;                             /* requests on the list (approximate while a leader takes it) */
+	int busy;                              /* bit k: slot k has a batch on the device; also the futex word a leader without a slot sleeps on */
+	int gen[COAL_IDS];                     /* gen[list number]: bumped when that list's batch is done -- the futex word its followers sleep on */
+	int next_id;
+	int expect;                            /* the size the last batches had */
+	int win_n, win_prev;                   /* calls in the current / the previous millisecond */
+	int64_t win_t0;
+} g_coal;
+
+#if defined(__x86_64__) || defined(__i386__)
+#define cpu_relax() __builtin_ia32_pause()
+#else
+#define cpu_relax() ((void)0)
+#endif
+static long futex_call(int *addr, int op, int val, const struct timespec *to) { return syscall(SYS_futex, addr, op, val, to, 0, 0); }
 
 static int same_scoring(const creq_t *a, const creq_t *b)
 {
@@ -3038,7 +3089,7 @@ static int same_scoring(const creq_t *a, const creq_t *b)
 	return memcmp(x->mat, y->mat, (size_t)x->m * x->m) == 0;
 }
 
-static void coal_process(creq_t *list)
+static void coal_process(creq_t *list, void *stream)
 {
 	creq_t *r, *g;
 	for (g = list; g; g = g->next) {
@@ -3059,10 +3110,12 @@ static void coal_process(creq_t *list)
 			r->taken = 1; mem[n] = r; pairs[n] = *r->pr; ezp[n] = r->ez; kmp[n] = r->km; ++n;
 		}
 		__sync_fetch_and_add(&g_stat[2], n); __sync_fetch_and_add(&g_stat[3], 1);
+		g_latency_plan = 1; g_plan_stream = stream;
 		p = plan_create_ex(g->dual, 0, g->sc, n, pairs, 0, 0);
+		g_latency_plan = 0; g_plan_stream = 0;
 		if (!p) rc = strstr(g_err, "alloc") ? KSW2AMD_E_NOMEM : strstr(g_err, "device") ? KSW2AMD_E_NODEVICE : KSW2AMD_E_PARAM;
 		else {
-			rc = ksw2amd_plan_run(p, thread_stream());
+			rc = ksw2amd_plan_run(p, stream ? stream : thread_stream());
 			if (rc == KSW2AMD_OK) rc = plan_fetch_ex(p, 0, 0, ezp, kmp);
 			ksw2amd_plan_destroy(p);
 		}
@@ -3070,44 +3123,116 @@ static void coal_process(creq_t *list)
 	}
 }
 
+/* Slots are numbered, and each one owns a stream per device.  The device has FOUR hardware queues and the runtime deals its streams
+ * onto them in turn: 64 caller threads with a stream each share them 16 to a queue, and two batches whose leaders' streams meet on
+ * one queue run one after the other -- a one-pair plan's device time read 0.33 ms alone and 0.66 ms next to another thread's batch
+ * (tools/probe/concurrent_small_kernels_probe.hip: four streams overlap perfectly, 0.32 ms per 0.30 ms kernel; eight take 0.59).
+ * A batch therefore runs on its slot's stream, uploads included (in order: no event, no second queue), whoever its leader is. */
+#define COAL_MAXSLOTS 8
+static void *g_coal_stream[COAL_MAXSLOTS][SHARED_UP_MAXDEV];
+static int coal_try_slot(int slots)
+{
+	int b = __atomic_load_n(&g_coal.busy, __ATOMIC_RELAXED), k;
+	for (;;) {
+		for (k = 0; k < slots && (b >> k & 1); ++k) {}
+		if (k >= slots) return -1;
+		if (__atomic_compare_exchange_n(&g_coal.busy, &b, b | 1 << k, 0, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED)) return k;
+	}
+}
+static void coal_free_slot(int k)
+{
+	__atomic_fetch_and(&g_coal.busy, ~(1 << k), __ATOMIC_RELEASE);
+	futex_call(&g_coal.busy, FUTEX_WAKE_PRIVATE, 1, 0);                 /* a leader without a slot */
+}
+static void *coal_slot_stream(int k)                                      /* (only the slot's holder gets here) */
+{
+	const int dev = k2a_shim_get_device();
+	if (dev < 0 || dev >= SHARED_UP_MAXDEV) return 0;
+	if (!g_coal_stream[k][dev]) g_coal_stream[k][dev] = ENV(COALESCE_PLAIN_STREAMS) ? k2a_shim_stream_create() : k2a_shim_stream_create_high();
+	return g_coal_stream[k][dev];
+}
+
 /* 1 = handled (result or failure delivered), 0 = coalescing is off: the caller runs the pair itself */
 static int queue_one(const char *fn, int dual, void *km, const ksw2amd_scoring_t *sc, const ksw2amd_pair_t *pr, ksw_extz_t *ez)
 {
-	creq_t me;
-	const char *se = ENV(COALESCE_SLOTS);
-	const int slots = se ? imax(atoi(se), 0) : 4;
+	creq_t me __attribute__((aligned(COAL_IDS)));
+	const char *se = ENV(COALESCE_SLOTS), *we = ENV(COALESCE_WINDOW_US);
+	const int slots = imin(se ? imax(atoi(se), 0) : 4, COAL_MAXSLOTS);
+	const int64_t window_ns = (we ? imax(atoi(we), 0) : 200) * (int64_t)1000;
+	int64_t t_in, t0;
+	int crowd, wn, slot, id = 0;
+	uintptr_t old;
 	if (slots == 0 || g_is_worker) return 0;
-	memset(&me, 0, sizeof(me));
-	me.dual = dual; me.sc = sc; me.pr = pr; me.km = km; me.ez = ez;
-	pthread_mutex_lock(&g_coal.mu);
-	if (g_coal.busy < slots && g_coal.count == 0) {        /* a free slot and nobody waiting: run alone, now */
-		++g_coal.busy;
-		pthread_mutex_unlock(&g_coal.mu);
-		me.rc = run_serial(dual, 0, km, sc, 1, pr, ez, 1, 0, 0);
-		if (me.rc) snprintf(me.err, sizeof(me.err), "%.190s", g_err);
-		pthread_mutex_lock(&g_coal.mu);
-		--g_coal.busy;
-		pthread_cond_signal(&g_coal.arrive);                 /* a slot is free: wakes a waiting leader */
-	} else {
-		if (g_coal.tail) g_coal.tail->next = &me; else g_coal.head = &me;
-		g_coal.tail = &me; ++g_coal.count;
-		if (!g_coal.leader) {
-			creq_t *list, *r, *nx;
-			g_coal.leader = 1;
-			while (g_coal.busy >= slots) pthread_cond_wait(&g_coal.arrive, &g_coal.mu);    /* others keep joining the queue meanwhile */
-			list = g_coal.head;
-			g_coal.head = g_coal.tail = 0; g_coal.count = 0; g_coal.leader = 0;
-			++g_coal.busy;
-			pthread_mutex_unlock(&g_coal.mu);
-			coal_process(list);
-			pthread_mutex_lock(&g_coal.mu);
-			--g_coal.busy;
-			for (r = list; r; r = nx) { nx = r->next; r->done = 1; }      /* `me` included; a follower's record dies when it returns */
-			pthread_cond_broadcast(&g_coal.finished);
-			pthread_cond_signal(&g_coal.arrive);
-		} else while (!me.done) pthread_cond_wait(&g_coal.finished, &g_coal.mu);
+	me.next = 0; me.dual = dual; me.rc = 0; me.taken = 0; me.done = 0; me.sc = sc; me.pr = pr; me.km = km; me.ez = ez; me.err[0] = 0;
+	/* how many callers are there?  (counters without a lock: a lost update changes nothing that matters) */
+	t_in = now_ns();
+	t0 = __atomic_load_n(&g_coal.win_t0, __ATOMIC_RELAXED);
+	if (t_in - t0 > 1000000) {
+		__atomic_store_n(&g_coal.win_prev, t_in - t0 > 2000000 ? 0 : __atomic_load_n(&g_coal.win_n, __ATOMIC_RELAXED), __ATOMIC_RELAXED);
+		__atomic_store_n(&g_coal.win_n, 0, __ATOMIC_RELAXED);
+		__atomic_store_n(&g_coal.win_t0, t_in, __ATOMIC_RELAXED);
 	}
-	pthread_mutex_unlock(&g_coal.mu);
+	wn = __atomic_add_fetch(&g_coal.win_n, 1, __ATOMIC_RELAXED);
+	crowd = window_ns > 0 && (wn >= 8 || __atomic_load_n(&g_coal.win_prev, __ATOMIC_RELAXED) >= 8);
+	if (!crowd && __atomic_load_n(&g_coal.head, __ATOMIC_RELAXED) == 0 && (slot = coal_try_slot(slots)) >= 0) {      /* a free slot, nobody waiting, no crowd: run alone, now */
+		g_latency_plan = 1; g_plan_stream = coal_slot_stream(slot);
+		me.rc = run_serial(dual, 0, km, sc, 1, pr, ez, 1, 0, 0);
+		g_latency_plan = 0; g_plan_stream = 0;
+		if (me.rc) snprintf(me.err, sizeof(me.err), "%.190s", g_err);
+		coal_free_slot(slot);
+	} else {
+		/* the list's number travels in the low bits of the head word, so a pusher learns it with its push: followers of list i sleep on
+		 * gen[i], and a finished batch wakes its own followers only (one word for everybody: four pools woke each other four times per
+		 * round trip, and every leader paid for waking all of them) */
+		const int fresh = __atomic_fetch_add(&g_coal.next_id, 1, __ATOMIC_RELAXED) & (COAL_IDS - 1);
+		old = __atomic_load_n(&g_coal.head, __ATOMIC_RELAXED);
+		do {
+			me.next = (creq_t*)(old & ~(uintptr_t)(COAL_IDS - 1));
+			id = old ? (int)(old & (COAL_IDS - 1)) : fresh;
+		} while (!__atomic_compare_exchange_n(&g_coal.head, &old, (uintptr_t)&me | (uintptr_t)id, 0, __ATOMIC_RELEASE, __ATOMIC_RELAXED));
+		__atomic_fetch_add(&g_coal.count, 1, __ATOMIC_RELAXED);
+		if (old == 0) {                                                       /* onto the empty list: the leader of whatever it holds when taken */
+			creq_t *list, *r, *nx;
+			const int expect = __atomic_load_n(&g_coal.expect, __ATOMIC_RELAXED);
+			int n = 0;
+			const int tl = trace_level();
+			int64_t t_slot, t_col, t_done, t_woken;
+			while ((slot = coal_try_slot(slots)) < 0) {                         /* others keep joining the list meanwhile */
+				const int b = __atomic_load_n(&g_coal.busy, __ATOMIC_RELAXED);
+				if (b == (1 << slots) - 1) futex_call(&g_coal.busy, FUTEX_WAIT_PRIVATE, b, 0);
+			}
+			t_slot = tl ? now_ns() : 0;
+			if (crowd) {                                                        /* the collection window (one thread polls; nobody is woken for it) */
+				const int64_t t_dl = t_in + window_ns;
+				int spins = 0;
+				while (__atomic_load_n(&g_coal.count, __ATOMIC_RELAXED) < imin(expect, COAL_MAXQ) && now_ns() < t_dl)
+					if (++spins & 15) cpu_relax(); else sched_yield();
+			}
+			t_col = tl ? now_ns() : 0;
+			list = (creq_t*)(__atomic_exchange_n(&g_coal.head, (uintptr_t)0, __ATOMIC_ACQUIRE) & ~(uintptr_t)(COAL_IDS - 1));       /* (the next push starts a new list with a leader of its own) */
+			for (r = list; r; r = r->next) ++n;
+			__atomic_fetch_sub(&g_coal.count, n, __ATOMIC_RELAXED);
+			__atomic_store_n(&g_coal.expect, n >= expect ? n : expect - (expect - n + 1) / 2, __ATOMIC_RELAXED);      /* (follows a shrinking pool in a few batches) */
+			coal_process(list, coal_slot_stream(slot));
+			t_done = tl ? now_ns() : 0;
+			coal_free_slot(slot);
+			for (r = list; r; r = nx) { nx = r->next; if (r != &me) __atomic_store_n(&r->done, 1, __ATOMIC_RELEASE); }      /* (a follower's record dies as soon as it sees this) */
+			__atomic_fetch_add(&g_coal.gen[id], 1, __ATOMIC_RELEASE);
+			if (n > 1) futex_call(&g_coal.gen[id], FUTEX_WAKE_PRIVATE, INT_MAX, 0);
+			if (tl) {
+				t_woken = now_ns();
+				fprintf(stderr, "[ksw2_amd] coalesced batch of %d (expected %d): waited %.3f ms for a slot, collected for %.3f, plan + run + fetch %.3f, wake-up calls %.3f ms\n",
+				        n, expect, (t_slot - t_in) * 1e-6, (t_col - t_slot) * 1e-6, (t_done - t_col) * 1e-6, (t_woken - t_done) * 1e-6);
+			}
+		} else {
+			int *word = &g_coal.gen[id];
+			for (;;) {
+				const int g = __atomic_load_n(word, __ATOMIC_ACQUIRE);
+				if (__atomic_load_n(&me.done, __ATOMIC_ACQUIRE)) break;
+				futex_call(word, FUTEX_WAIT_PRIVATE, g, 0);
+			}
+		}
+	}
 	if (me.rc) { snprintf(g_err, sizeof(g_err), "%s", me.err); call_failed(fn, me.rc, ez); }
 	return 1;
 }

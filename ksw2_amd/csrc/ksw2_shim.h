@@ -60,6 +60,7 @@ int   k2a_shim_host_unregister(void *p);
 int   k2a_shim_memset(void *dst, int v, size_t bytes, void *stream);
 
 void *k2a_shim_stream_create(void);
+void *k2a_shim_stream_create_high(void);      /* highest priority: hardware queues apart from the ordinary streams' */
 void  k2a_shim_stream_destroy(void *stream);
 int   k2a_shim_stream_sync(void *stream);
 void *k2a_shim_event_create(void);

@@ -1718,6 +1718,16 @@ void *k2a_shim_stream_create(void)
 	if (set_err(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate")) return 0;
 	return (void*)s;
 }
+/* a stream of the highest priority the device offers: the runtime keeps a pool of hardware queues PER PRIORITY and deals a new stream the
+ * least used queue of its pool, so a handful of these get hardware queues of their own, whatever else the process has created */
+void *k2a_shim_stream_create_high(void)
+{
+	hipStream_t s = 0;
+	int lo = 0, hi = 0;
+	if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; }
+	if (set_err(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi), "hipStreamCreateWithPriority")) return 0;
+	return (void*)s;
+}
 void k2a_shim_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy((hipStream_t)stream); }
 int k2a_shim_stream_sync(void *stream) { CHECK(hipStreamSynchronize((hipStream_t)stream)); return 0; }
 

@@ -987,6 +987,7 @@ int k2a_shim_host_register(void *, size_t) { return 0; }
 int k2a_shim_host_unregister(void *) { return 0; }
 int k2a_shim_memset(void *dst, int v, size_t bytes, void *) { memset(dst, v, bytes); return 0; }
 void *k2a_shim_stream_create(void) { return (void*)1; }
+void *k2a_shim_stream_create_high(void) { return (void*)1; }
 void k2a_shim_stream_destroy(void *) {}
 int k2a_shim_stream_sync(void *) { return 0; }
 void *k2a_shim_event_create(void) { return calloc(1, sizeof(double)); }
