@@ -58,6 +58,7 @@ static void release_thread_cache(void);
 	X(COALESCE_SLOTS) \
 	X(COALESCE_WINDOW_US) \
 	X(COALESCE_PLAIN_STREAMS) \
+	X(SHARED_UP_MIN_MB) \
 	X(DEFER) \
 	X(EXTF_HBM) \
 	X(EXTF_LANE) \
@@ -194,6 +195,7 @@ static void *thread_upload_stream(void) { if (!g_up_stream) { thread_owns_cache(
 #define SHARED_UP_MAXDEV 16
 static void *g_shared_up[SHARED_UP_MAXDEV];
 static pthread_mutex_t g_shared_up_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_mutex_t g_shared_issue_mu = PTHREAD_MUTEX_INITIALIZER;      /* held while ONE plan's copies go into the shared stream */
 static void *shared_upload_stream(void)
 {
 	const int dev = k2a_shim_get_device();
@@ -636,7 +638,7 @@ void ksw2amd_plan_destroy(ksw2amd_plan_t *p)
 	if (p->up_ev) { k2a_shim_event_sync(p->up_ev); k2a_shim_event_destroy(p->up_ev); p->up_ev = 0; }      /* the upload reads host blocks freed below */
 	if (p->up_state) { pthread_mutex_destroy(&p->up_state->mu); free(p->up_state); p->up_state = 0; }
 	if (p->wm_ev) { k2a_shim_event_destroy(p->wm_ev); p->wm_ev = 0; }
-	if (p->meta_ev) { k2a_shim_event_destroy(p->meta_ev); p->meta_ev = 0; }
+	if (p->meta_ev) { k2a_shim_event_sync(p->meta_ev); k2a_shim_event_destroy(p->meta_ev); p->meta_ev = 0; }      /* (its copies read the page-locked staging recycled below) */
 	if (p->stream_used) k2a_shim_stream_sync(p->stream);     /* nothing may still be running on buffers that get recycled */
 	cache_put(BUF_SEQ, p->d_seq, p->cap[BUF_SEQ]); cache_put(BUF_TB, p->d_tb, p->cap[BUF_TB]);
 	cache_put(BUF_PAIRS, p->d_pairs, p->cap[BUF_PAIRS]); cache_put(BUF_RES, p->d_res, p->cap[BUF_RES]);
@@ -1104,7 +1106,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	 * end, config 2 968 -> 1 165, 10 k with CIGAR 1 290 -> 1 321; config 3's 8 MB chunks and config 5 unchanged within noise).  Plans
 	 * under 16 MB (single calls, coalesced batches, small chunks) keep the calling thread's own stream and wait for it: an event per
 	 * call would only add latency there.  KSW2AMD_NO_SHARED_UP=1: the old behaviour, for A/B runs. */
-	up = su ? su->up : (flat && !flat->on_device) || (!flat && p->seq_bytes >= ((size_t)16 << 20) && !ENV(NO_SHARED_UP)) ? shared_upload_stream() : 0;
+	up = su ? su->up : (flat && !flat->on_device) || (!flat && p->seq_bytes >= ((size_t)(ENV(SHARED_UP_MIN_MB) ? imax(atoi(ENV(SHARED_UP_MIN_MB)), 0) : 4) << 20) && !ENV(NO_SHARED_UP)) ? shared_upload_stream() : 0;
 	if (up) shared_up = 1; else up = g_plan_stream ? g_plan_stream : thread_upload_stream();
 	p->stream = up; p->stream_used = 1;              /* plan_destroy waits for it before the buffers are recycled */
 	if (su) { /* the pieces are on their way (or there) already */ }
@@ -1118,10 +1120,17 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 			build_eff(dual, m, sc->mat, e, e2, 0, (int8_t*)flat_tmp + (mat_off - flat_span));
 			build_eff(dual, m, sc->mat, e, e2, 1, (int8_t*)flat_tmp + (mat_off - flat_span) + (size_t)m * m);
 		}
-		if ((flat->on_device ? k2a_shim_d2d(p->d_seq, flat_lo, flat_span, up) : k2a_shim_h2d(p->d_seq, flat_lo, flat_span, up)) ||
-		    k2a_shim_h2d(p->d_seq + flat_span, flat_tmp, tail, up)) { fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error()); goto err; }
+		if (!shared_up &&
+		    ((flat->on_device ? k2a_shim_d2d(p->d_seq, flat_lo, flat_span, up) : k2a_shim_h2d(p->d_seq, flat_lo, flat_span, up)) ||
+		     k2a_shim_h2d(p->d_seq + flat_span, flat_tmp, tail, up))) { fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error()); goto err; }
 	} else
-	if (k2a_shim_h2d(p->d_seq, p->h_seq, p->seq_bytes, up)) { fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error()); goto err; }
+	if (!shared_up && k2a_shim_h2d(p->d_seq, p->h_seq, p->seq_bytes, up)) { fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error()); goto err; }
+	/* (On the shared stream a plan's copies are issued TOGETHER, below, once its small arrays exist: sequences, small arrays, event.
+	 * Issued here, the sequences were followed by the other workers' sequences before this plan's small arrays got into the queue:
+	 * the first chunk of config 2 had its 10 MB on the device after 0.16 ms and its kernel started 1.06 ms into the batch, when the
+	 * sixth chunk's bytes had arrived too -- round 4, rocprofv3 timeline of the pooled batch, tools/scripts/timeline.py.  The small
+	 * arrays on a stream of their own are no way out: their copies are blit kernels that queue up behind another chunk's fill on
+	 * whichever hardware queue the stream shares -- config 2 1 160 -> 900 GCUPS, 10 k with CIGAR 1 280 -> 1 040.) */
 
 	/* pass 2: task lists per class, most expensive first (similar shapes end up in the same wavefront).  Packed-int16
 	 * candidates of a class are paired up with a neighbour of identical (qlen, tlen, rows inside the band, w); a leftover is
@@ -1338,7 +1347,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 		fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error());
 		goto err;
 	}
-	if (shared_up) p->up_ev = k2a_shim_event_create();
+	if (su) p->up_ev = k2a_shim_event_create();
 	if (su) {
 		/* a streamed plan's small arrays go up on the upload stream itself, between the second piece and the third (su->hold): nothing
 		 * of the plan waits on the host for them -- the stream the plan runs on waits for the event behind them (meta_ev), then the
@@ -1394,16 +1403,22 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 		if (!p->h_meta) { fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
 		memcpy(p->h_meta, p->h_pairs, sizeof(K2aPair) * (size_t)n);
 		memcpy(p->h_meta + b_pairs, p->h_order, sizeof(uint32_t) * (size_t)p->norder);
-		if (!p->up_ev) p->up_ev = k2a_shim_event_create();
+		p->up_ev = k2a_shim_event_create();
+		if (shared_up) pthread_mutex_lock(&g_shared_issue_mu);      /* one plan's copies in one piece */
 		if (!p->up_ev ||
+		    (shared_up && flat && ((flat->on_device ? k2a_shim_d2d(p->d_seq, flat_lo, flat_span, up) : k2a_shim_h2d(p->d_seq, flat_lo, flat_span, up)) ||
+		                           k2a_shim_h2d(p->d_seq + flat_span, flat_tmp, p->seq_bytes - flat_span, up))) ||
+		    (shared_up && !flat && k2a_shim_h2d(p->d_seq, p->h_seq, p->seq_bytes, up)) ||
 		    k2a_shim_h2d(p->d_pairs, p->h_meta, sizeof(K2aPair) * (size_t)n, up) ||
 		    k2a_shim_h2d(p->d_order, p->h_meta + b_pairs, sizeof(uint32_t) * (size_t)p->norder, up) ||
 		    (need_clear && k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)n, up)) ||
 		    (p->bnd_words && k2a_shim_memset(p->d_bnd, 0xC0, p->bnd_words * 4, up)) ||
 		    k2a_shim_event_record(p->up_ev, up)) {
+			if (shared_up) pthread_mutex_unlock(&g_shared_issue_mu);
 			fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error());
 			goto err;
 		}
+		if (shared_up) pthread_mutex_unlock(&g_shared_issue_mu);
 	}
 	if (m > 5) for (k = 0; k < p->ncls; ++k) p->cls[k].sc.mat = (const int8_t*)p->d_seq + mat_off + (p->cls[k].generic ? (size_t)m * m : 0);
 	free(pk_ok); free(solo_ok);
@@ -2478,7 +2493,8 @@ static int ext_finish(ext_ctx_t *c, pend_t *pd)
 
 /* One chunk on a pool worker: pack, upload, run, fetch; the workers are what overlaps the phases of different chunks.  (A worker
  * that queued chunk k + 1 before it waited for chunk k -- rounds 2 and 3, behind a switch -- lost on every configuration once the
- * chunks tiled the SIMDs, and degraded over many batches: removed in round 4.)  A chunk that does not fit one plan (traceback
+ * chunks tiled the SIMDs, and degraded over many batches: removed in round 4; tried once more behind the in-order upload stream
+ * for small chunks: config 2 1 061 -> 973, 10 k with CIGAR 1 318 -> 1 186, the others unchanged.)  A chunk that does not fit one plan (traceback
  * memory) takes the serial path. */
 static int ext_chunk(void *ctx_, int beg, int end, int share, pend_t *pd)
 {
