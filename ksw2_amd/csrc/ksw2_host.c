@@ -454,6 +454,7 @@ struct ksw2amd_plan_s {
 	/* streamed plans (section "streamed plans" below): the sequence arena goes up in pieces, one launch per score-only packed class
 	 * starts under the upload, every wavefront waiting for its own task's pieces */
 	int streamed;                          /* classes with cls_t.qd >= 0 exist and the next run launches them as queues */
+	int meta_folded;                       /* 1: d_order lies inside d_pairs' buffer; 2: both lie inside d_seq's (one upload per plan) */
 	int unscanned;                         /* a streamed plan's gathered arena is copied, not scanned: wildcard pairs are reported by the kernels like in flat plans */
 	stream_up_t *up_state;                 /* the piece-wise upload (lives as long as the plan: the gather's workers issue pieces) */
 	struct gather_s *gather;               /* the gather of a streamed plan, running on the pool's threads until gather_wait() */
@@ -641,8 +642,10 @@ void ksw2amd_plan_destroy(ksw2amd_plan_t *p)
 	if (p->meta_ev) { k2a_shim_event_sync(p->meta_ev); k2a_shim_event_destroy(p->meta_ev); p->meta_ev = 0; }      /* (its copies read the page-locked staging recycled below) */
 	if (p->stream_used) k2a_shim_stream_sync(p->stream);     /* nothing may still be running on buffers that get recycled */
 	cache_put(BUF_SEQ, p->d_seq, p->cap[BUF_SEQ]); cache_put(BUF_TB, p->d_tb, p->cap[BUF_TB]);
-	cache_put(BUF_PAIRS, p->d_pairs, p->cap[BUF_PAIRS]); cache_put(BUF_RES, p->d_res, p->cap[BUF_RES]);
-	cache_put(BUF_ORDER, p->d_order, p->cap[BUF_ORDER]); cache_put(BUF_CIG, p->d_cig, p->cap[BUF_CIG]);
+	if (p->meta_folded != 2) cache_put(BUF_PAIRS, p->d_pairs, p->cap[BUF_PAIRS]);
+	cache_put(BUF_RES, p->d_res, p->cap[BUF_RES]);
+	if (!p->meta_folded) cache_put(BUF_ORDER, p->d_order, p->cap[BUF_ORDER]);
+	cache_put(BUF_CIG, p->d_cig, p->cap[BUF_CIG]);
 	cache_put(BUF_BND, p->d_bnd, p->cap[BUF_BND]); cache_put(BUF_WM, p->d_wm, p->cap[BUF_WM]); cache_put(BUF_HMETA, p->h_meta, p->cap[BUF_HMETA]);
 	free(p->h_qd);
 	for (i = 0; i < 3; ++i) if (p->ev[i]) { if (!g_ev_cache[i]) g_ev_cache[i] = p->ev[i]; else k2a_shim_event_destroy(p->ev[i]); }
@@ -714,6 +717,8 @@ static void plan_ready(ksw2amd_plan_t *p)
  * no staging copy, no host pass over the bytes.  What the gather pass also did was to look for wildcard codes (the packed kernels
  * cannot score them): flat plans leave that to the packed kernels themselves (K2aLanePk::seen) and re-run what they report. */
 typedef struct { int on_device; } flat_src_t;
+/* room for a plan's small arrays behind its sequences: K2aPair per pair, the task lists (two entries per packed task at most), slack */
+#define META_ROOM(n) (align_up(sizeof(K2aPair) * ((size_t)(n) + 1), 256) + sizeof(uint32_t) * (3 * (size_t)(n) + 8) + 512)
 static uint64_t or_bytes(const uint8_t *p, int n)
 {
 	uint64_t acc = 0, v0, v1, v2, v3;
@@ -845,7 +850,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 	p->seq_bytes = off;
 	if (flat) p->h_seq = flat->on_device ? 0 : (uint8_t*)flat_lo;      /* borrowed: EQX rewrites and re-runs read the sequences there */
 	else {
-		p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, p->seq_bytes, &p->cap[BUF_HSEQ]);
+		p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, p->seq_bytes + META_ROOM(n), &p->cap[BUF_HSEQ]);      /* (+ the small arrays: one upload per plan) */
 		if (!p->h_seq) { fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
 	}
 
@@ -1097,7 +1102,7 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 		build_eff(dual, m, sc->mat, e, e2, 0, (int8_t*)p->h_seq + mat_off);
 		build_eff(dual, m, sc->mat, e, e2, 1, (int8_t*)p->h_seq + mat_off + (size_t)m * m);
 	}
-	if (!su) p->d_seq = (uint8_t*)cache_get(BUF_SEQ, p->seq_bytes, &p->cap[BUF_SEQ]);
+	if (!su) p->d_seq = (uint8_t*)cache_get(BUF_SEQ, p->seq_bytes + (flat ? 0 : META_ROOM(n)), &p->cap[BUF_SEQ]);
 	if (!p->d_seq) { fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error()); goto err; }
 	/* Big uploads go through ONE stream per device, whoever issues them: the chunks of a big batch are packed by several worker
 	 * threads at once, and six 80 MB copies on six streams share the link -- all of them arrive after 9-13 ms and the device idles
@@ -1120,12 +1125,8 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 			build_eff(dual, m, sc->mat, e, e2, 0, (int8_t*)flat_tmp + (mat_off - flat_span));
 			build_eff(dual, m, sc->mat, e, e2, 1, (int8_t*)flat_tmp + (mat_off - flat_span) + (size_t)m * m);
 		}
-		if (!shared_up &&
-		    ((flat->on_device ? k2a_shim_d2d(p->d_seq, flat_lo, flat_span, up) : k2a_shim_h2d(p->d_seq, flat_lo, flat_span, up)) ||
-		     k2a_shim_h2d(p->d_seq + flat_span, flat_tmp, tail, up))) { fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error()); goto err; }
-	} else
-	if (!shared_up && k2a_shim_h2d(p->d_seq, p->h_seq, p->seq_bytes, up)) { fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error()); goto err; }
-	/* (On the shared stream a plan's copies are issued TOGETHER, below, once its small arrays exist: sequences, small arrays, event.
+	}
+	/* (A plan's copies are issued TOGETHER, below, once its small arrays exist: sequences, small arrays, event -- one copy for a gathered plan.
 	 * Issued here, the sequences were followed by the other workers' sequences before this plan's small arrays got into the queue:
 	 * the first chunk of config 2 had its 10 MB on the device after 0.16 ms and its kernel started 1.06 ms into the batch, when the
 	 * sixth chunk's bytes had arrived too -- round 4, rocprofv3 timeline of the pooled batch, tools/scripts/timeline.py.  The small
@@ -1336,9 +1337,21 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 
 	if (tlev) tph[5] = now_ms();
 	/* upload the rest */
-	p->d_pairs = (K2aPair*)cache_get(BUF_PAIRS, sizeof(K2aPair) * ((size_t)n + 1), &p->cap[BUF_PAIRS]);
+	/* the small arrays: behind the sequences in the same buffer (gathered plans: ONE upload), or the task lists behind the pairs (flat
+	 * plans, whose sequences come from the caller's arena); a streamed plan keeps them apart (its pieces are on their way already) */
+	if (su) {
+		p->d_pairs = (K2aPair*)cache_get(BUF_PAIRS, sizeof(K2aPair) * ((size_t)n + 1), &p->cap[BUF_PAIRS]);
+		p->d_order = (uint32_t*)cache_get(BUF_ORDER, sizeof(uint32_t) * ((size_t)p->norder + p->need_words + 1), &p->cap[BUF_ORDER]);
+	} else if (flat) {
+		p->d_pairs = (K2aPair*)cache_get(BUF_PAIRS, META_ROOM(n), &p->cap[BUF_PAIRS]);
+		p->d_order = p->d_pairs ? (uint32_t*)((uint8_t*)p->d_pairs + align_up(sizeof(K2aPair) * (size_t)n, 256)) : 0;
+		p->meta_folded = 1;
+	} else {
+		p->d_pairs = (K2aPair*)(p->d_seq + align_up(p->seq_bytes, 256));
+		p->d_order = (uint32_t*)((uint8_t*)p->d_pairs + align_up(sizeof(K2aPair) * (size_t)n, 256));
+		p->meta_folded = 2;
+	}
 	p->d_res = (K2aResult*)cache_get(BUF_RES, sizeof(K2aResult) * ((size_t)n + 1), &p->cap[BUF_RES]);
-	p->d_order = (uint32_t*)cache_get(BUF_ORDER, sizeof(uint32_t) * ((size_t)p->norder + p->need_words + 1), &p->cap[BUF_ORDER]);
 	p->d_tb = p->tb_bytes ? (uint8_t*)cache_get(BUF_TB, p->tb_bytes, &p->cap[BUF_TB]) : 0;
 	p->d_cig = p->cig_words ? (uint32_t*)cache_get(BUF_CIG, p->cig_words * 4, &p->cap[BUF_CIG]) : 0;
 	p->d_bnd = p->bnd_words ? (int32_t*)cache_get(BUF_BND, p->bnd_words * 4, &p->cap[BUF_BND]) : 0;
@@ -1397,20 +1410,27 @@ static ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scorin
 		 * launches (a coalesced batch of single-pair calls: one host wait per batch, in fetch) or to packing its next chunk.  The result
 		 * records are cleared only where something reads a record no kernel writes: the CIGAR compaction walks every pair of the plan,
 		 * the invalid ones too (k2a_finish writes all of a record for every pair that is in a class). */
-		const size_t b_pairs = align_up(sizeof(K2aPair) * (size_t)n, 256);
+		const size_t b_pairs = align_up(sizeof(K2aPair) * (size_t)n, 256), b_meta = b_pairs + sizeof(uint32_t) * (size_t)p->norder;
+		const size_t meta_off = align_up(p->seq_bytes, 256), tail = flat ? p->seq_bytes - flat_span : 0;
 		const int need_clear = ninvalid > 0 && p->cig_words > 0;
-		p->h_meta = (uint8_t*)cache_get(BUF_HMETA, b_pairs + sizeof(uint32_t) * (size_t)p->norder + 256, &p->cap[BUF_HMETA]);
-		if (!p->h_meta) { fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
-		memcpy(p->h_meta, p->h_pairs, sizeof(K2aPair) * (size_t)n);
-		memcpy(p->h_meta + b_pairs, p->h_order, sizeof(uint32_t) * (size_t)p->norder);
+		uint8_t *hm;
+		if (flat) {
+			/* pairs + task lists + the arena's padding and the matrices of a wide alphabet (flat_tmp), from one page-locked block */
+			p->h_meta = (uint8_t*)cache_get(BUF_HMETA, b_meta + tail + 256, &p->cap[BUF_HMETA]);
+			if (!p->h_meta) { fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
+			hm = p->h_meta;
+			memcpy(hm + align_up(b_meta, 256), flat_tmp, tail);
+		} else hm = p->h_seq + meta_off;
+		if (b_meta + 256 > META_ROOM(n)) { fail(KSW2AMD_E_PARAM, "plan_create: task lists larger than planned%s", 0); goto err; }
+		memcpy(hm, p->h_pairs, sizeof(K2aPair) * (size_t)n);
+		memcpy(hm + b_pairs, p->h_order, sizeof(uint32_t) * (size_t)p->norder);
 		p->up_ev = k2a_shim_event_create();
 		if (shared_up) pthread_mutex_lock(&g_shared_issue_mu);      /* one plan's copies in one piece */
 		if (!p->up_ev ||
-		    (shared_up && flat && ((flat->on_device ? k2a_shim_d2d(p->d_seq, flat_lo, flat_span, up) : k2a_shim_h2d(p->d_seq, flat_lo, flat_span, up)) ||
-		                           k2a_shim_h2d(p->d_seq + flat_span, flat_tmp, p->seq_bytes - flat_span, up))) ||
-		    (shared_up && !flat && k2a_shim_h2d(p->d_seq, p->h_seq, p->seq_bytes, up)) ||
-		    k2a_shim_h2d(p->d_pairs, p->h_meta, sizeof(K2aPair) * (size_t)n, up) ||
-		    k2a_shim_h2d(p->d_order, p->h_meta + b_pairs, sizeof(uint32_t) * (size_t)p->norder, up) ||
+		    (flat && ((flat->on_device ? k2a_shim_d2d(p->d_seq, flat_lo, flat_span, up) : k2a_shim_h2d(p->d_seq, flat_lo, flat_span, up)) ||
+		              k2a_shim_h2d(p->d_seq + flat_span, hm + align_up(b_meta, 256), tail, up) ||
+		              k2a_shim_h2d(p->d_pairs, hm, b_meta, up))) ||
+		    (!flat && k2a_shim_h2d(p->d_seq, p->h_seq, meta_off + b_meta, up)) ||
 		    (need_clear && k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)n, up)) ||
 		    (p->bnd_words && k2a_shim_memset(p->d_bnd, 0xC0, p->bnd_words * 4, up)) ||
 		    k2a_shim_event_record(p->up_ev, up)) {
