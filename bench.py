@@ -122,7 +122,7 @@ def make_batch(wl, rank, n):
 
 
 def cells_of_rows(qlen, rows, w):
-    """In-band cells of target rows [0, rows) for arrays of (qlen, rows, w): the closed form of ksw2_host.c::band_cells."""
+    """In-band cells of target rows [0, rows) for arrays of (qlen, rows, w): the closed form of ksw2_host_plan.c::band_cells."""
     qlen, rows, w = (np.asarray(x, dtype=np.int64) for x in (qlen, rows, w))
     T = np.minimum(qlen + w, rows)
     a = qlen - 1 - w

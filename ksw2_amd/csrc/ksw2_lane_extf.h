@@ -100,7 +100,7 @@ K2A_FN void k2a_extf_win_cell(const K2aExtf &par, const K2aExtfDiag &d, int r, i
  * own copy (ksw2_extf2_sse.c:31), QR[k] = query[qlen - 1 - k]: the codes of positions x .. x+3 on anti-diagonal r are QR[k0 + x ..]
  * with k0 = qlen - 1 - r, one funnel shift of two neighbouring dwords.  Per cell this costs about 25 instructions of ONE lane
  * (2.7 wavefront instructions per cell in the position-per-lane kernels above, 0.4 here); it needs >= 64 extensions per
- * wavefront, so the host takes it for large batches (ksw2_host.c). */
+ * wavefront, so the host takes it for large batches (ksw2_host_*.c). */
 struct K2aExtfLaneMem {
 	uint32_t *U4, *V4, *S4;            /* state, this lane's column: index (x >> 2) * 64 -- or, as a ring, ((x >> 2) % ring) * 64 */
 	const uint32_t *TT, *QR;           /* target codes by position, reversed query by k: same layout, zero past the ends */

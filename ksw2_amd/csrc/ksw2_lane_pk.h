@@ -33,7 +33,7 @@
  * planes pre-multiplied with D = match - mismatch, so "mismatch ? D : 0" is xor + one v_bitop3 and the diagonal
  * candidate is H + (match + e) - that: 8 cycles instead of 14.  Cold code (init, epilogues) converts at its edges.
  *
- * Preconditions, checked by the host (ksw2_host.c::pk_eligible / pk_window_ok): m = 5 with a match / mismatch / wildcard score
+ * Preconditions, checked by the host (ksw2_host_plan.c::pk_eligible / pk_window_ok): m = 5 with a match / mismatch / wildcard score
  * structure (always true without KSW_EZ_GENERIC_SC), no wildcard code in either sequence (such pairs take the
  * int32 kernels), gap costs and match + e and match - mismatch non-negative, and every in-band H, E, F provably inside (-16384 + max(q+e, q2+e2), 12287 - max(q+e, q2+e2))
  * so that -16384 can stand for -infinity (K2A_PK_VMAX = 12287 is the largest value the offset form holds, ksw2_types.h).
@@ -186,7 +186,7 @@ K2A_FN k2a_pk k2a_ofs_off(k2a_pk ofs) { return k2a_pk_sub(ofs, K2A_OFS); }
 /* packed traceback: one byte per cell and alignment in the reference's own layout (ksw2.h:125-128): bits 0-2 winner
  * {0 diag, 1 E, 2 F, 3 E~, 4 F~}, 0x08/0x10/0x20/0x40 = the E/F/E~/F~ gap leaving the cell is an extension.
  * A lane-step word holds C cells x 2 alignments: byte 2c = alignment A, byte 2c+1 = alignment B. */
-/* NOMAX: KSW_EZ_APPROX_MAX launches (ksw2_host.c::is_approx) need the final score and the direction bytes only: no row
+/* NOMAX: KSW_EZ_APPROX_MAX launches (ksw2_host_int.h::is_approx) need the final score and the direction bytes only: no row
  * maximum, no arg-max, no Z-drop -- four instructions per row and two registers per row less. */
 /* Classes whose per-row maxima, arg-max columns and target codes live in LDS instead of registers (3 x C dwords per
  * lane, [array][row][lane]): the two-piece traceback kernels of the 16-row geometry, which otherwise need 290-330

@@ -1,5 +1,5 @@
 /*
- * ksw2_shim.h -- the thin C-ABI between the C host (ksw2_host.c) and the device runtime.
+ * ksw2_shim.h -- the thin C-ABI between the C host (ksw2_host_*.c) and the device runtime.
  *
  * The product library links ksw2_shim_hip.hip (HIP runtime + gfx950 kernels).  tests/sim/ links the very
  * same host code against a host-memory, lock-step wave simulator of the same interface so that the

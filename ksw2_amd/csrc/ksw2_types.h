@@ -1,5 +1,5 @@
 /*
- * ksw2_types.h -- plain-C data layout shared by the C host (ksw2_host.c), the device shim
+ * ksw2_types.h -- plain-C data layout shared by the C host (ksw2_host_*.c), the device shim
  * (ksw2_shim_hip.hip) and the per-lane kernel code (ksw2_lane.h).
  */
 #ifndef KSW2_TYPES_H_
@@ -118,7 +118,7 @@ typedef struct K2aResult {
 	int32_t pad[2];                  /* [0]: a packed kernel read a wildcard code (unscanned flat plans), [1]: inexact (deferred arg-max): the host re-runs the pair */
 } K2aResult;
 
-/* Streamed launches (ksw2_host.c, "streamed plans"): ONE launch of a packed fill kernel over the whole batch, started under the
+/* Streamed launches (ksw2_host_plan.c, "streamed plans"): ONE launch of a packed fill kernel over the whole batch, started under the
  * batch's upload.  Its wavefronts take their wavefront-tasks (the 64 / G consecutive tasks one wavefront runs) by position in the
  * grid, longest first, and each waits in front of its task until the upload pieces its sequences lie in have landed: the host
  * uploads the sequence arena in pieces on another stream and behind each piece copies a block of K2A_WM_BYTES filled with the piece's

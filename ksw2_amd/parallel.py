@@ -29,7 +29,7 @@ assert _EZ_DTYPE.itemsize == ctypes.sizeof(KswExtz)
 
 
 def band_cells(qlen, tlen, w):
-    """Exact-band cells per pair (arrays): the closed form of ksw2_host.c::band_cells.  w < 0 = unbanded."""
+    """Exact-band cells per pair (arrays): the closed form of ksw2_host_plan.c::band_cells.  w < 0 = unbanded."""
     qlen, tlen, w = (np.asarray(x, dtype=np.int64) for x in (qlen, tlen, w))
     mx = np.maximum(qlen, tlen)
     w = np.where((w < 0) | (w > mx), mx, w)

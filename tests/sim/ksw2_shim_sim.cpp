@@ -1,7 +1,7 @@
 /*
  * ksw2_shim_sim.cpp -- TEST INFRASTRUCTURE: a host-memory implementation of ksw2_shim.h that runs the
  * very same per-lane code (ksw2_amd/csrc/ksw2_lane.h) for 64 "lanes" in lock step, mirroring the control
- * flow of k2a_fill_kernel in ksw2_shim_hip.hip line by line.  Linked with ksw2_host.c into
+ * flow of k2a_fill_kernel in ksw2_shim_hip.hip line by line.  Linked with ksw2_host_*.c into
  * tests/sim/libksw2_amd_sim.so so the packing / geometry / scheduling / bookkeeping logic can be checked
  * against the oracle in the CPU test tier.  It is never part of the product library libksw2_amd.so.
  */

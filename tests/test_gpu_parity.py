@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _small_batches_stay_packed(monkeypatch):
     """Test batches are far too small to fill 1024 SIMDs; without this the host would send their packed-int16 candidates
-    back to the int32 kernels (ksw2_host.c, "0.4 wavefronts per SIMD") and the packed kernels would go untested."""
+    back to the int32 kernels (ksw2_host_plan.c, "0.4 wavefronts per SIMD") and the packed kernels would go untested."""
     monkeypatch.setenv("KSW2AMD_SIMDS", "0")
 
 
@@ -1058,7 +1058,7 @@ def test_linear_xdrop_one_extension_per_lane(lib, monkeypatch):
 
 @pytest.mark.parametrize("flat", [False, True])
 def test_streamed_plans_forced_on_and_off(lib, monkeypatch, flat):
-    """Streamed plans (ksw2_host.c "streamed plans"): one persistent launch per packed class that takes its
+    """Streamed plans (ksw2_host_plan.c "streamed plans"): one persistent launch per packed class that takes its
     wavefront-tasks from a queue as the arena's pieces land (k2a_queue_pop).  Forced on (KSW2AMD_STREAM=1) with small pieces and a
     slowed-down upload, so the wavefronts really wait for their watermarks; against the forced-off run on every pair and the oracle on
     a sample; then the fault hook with a 20 ms timeout: the launch must give up, the plan must be run again behind its upload and still

@@ -1,6 +1,6 @@
 """CPU: the host-side machinery around the kernels -- the chunked worker pool behind the batch entry points (one device and
 several), the coalescing of concurrent single-pair calls, the error handler -- on the simulator build of the product's own
-ksw2_host.c, against the oracle.  Results must not depend on how a batch is cut or on who runs it."""
+ksw2_host_*.c, against the oracle.  Results must not depend on how a batch is cut or on who runs it."""
 import ctypes
 import os
 import subprocess
@@ -73,7 +73,7 @@ def test_pooled_batch_several_devices(sim, monkeypatch):
 
 @pytest.mark.parametrize("score_only,expect_chunks", [(True, 4), (False, 4)])
 def test_uniform_batch_is_cut_at_device_fills(sim, monkeypatch, score_only, expect_chunks):
-    """A batch of one shape is cut into chunks that are multiples of a device fill (ksw2_host.c::uniform_chunks); here a
+    """A batch of one shape is cut into chunks that are multiples of a device fill (ksw2_host_pool.c::uniform_chunks); here a
     simulated device of 4 SIMDs: (8 lanes x 18 rows) / (16 x 8) geometry -> 64 / 32 pairs per unit, doubled until three workers
     have at most two chunks each -> four chunks of 1 024 pairs."""
     monkeypatch.setenv("KSW2AMD_SIM_SIMDS", "4")
@@ -94,7 +94,7 @@ def test_uniform_batch_is_cut_at_device_fills(sim, monkeypatch, score_only, expe
 
 def test_big_plan_copies_its_sequences_on_the_pool(sim, monkeypatch):
     """A plan of 32 MB or more created on the caller's thread has the pool's threads share the sequence copy
-    (ksw2_host.c::parallel_copy); every pair must still see its own bytes (a wildcard in one pair only, narrow band)."""
+    (ksw2_host_pool.c::parallel_copy); every pair must still see its own bytes (a wildcard in one pair only, narrow band)."""
     monkeypatch.setenv("KSW2AMD_THREADS", "3")
     n, L = 3400, 5000
     qs, ts = synth.fixed_batch(91, n, L, L, sub=0.03, ind=0.02)

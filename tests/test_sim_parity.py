@@ -1,4 +1,4 @@
-"""CPU: the product's host code (ksw2_host.c) and per-lane kernel code (ksw2_lane.h) linked against the
+"""CPU: the product's host code (ksw2_host_*.c) and per-lane kernel code (ksw2_lane.h) linked against the
 host-memory lock-step wave simulator (tests/sim), checked against the oracle through the same C-ABI.
 
 This does not replace the GPU parity tests (tests/test_gpu_parity.py): it pins the packing, geometry choice,
@@ -573,7 +573,7 @@ def test_sim_deferred_argmax(sim, defer, monkeypatch):
 def _flat_cases(rng):
     """Batches for the flat entry points: ragged and one-shape, score-only / CIGAR / EQX, both gap models, every band class, and in
     each batch a few pairs with a wildcard code somewhere -- in the query, in the target, in the last byte -- which the packed
-    kernels must report so that the host re-runs them (ksw2_host.c::flat_rerun)."""
+    kernels must report so that the host re-runs them (ksw2_host_plan.c::pair_rerun)."""
     mat = synth.simple_mat(5, 2, 4, -1)
     for rnd in range(6):
         n = 36
@@ -806,7 +806,7 @@ def _one_shape_batch(seed, n, ql, tl, wild_at=()):
 
 @pytest.mark.parametrize("flat", [False, True])
 def test_sim_streamed_plans(sim, monkeypatch, flat):
-    """Streamed plans (ksw2_host.c "streamed plans") forced on for every plan that can: one-shape batches through
+    """Streamed plans (ksw2_host_plan.c "streamed plans") forced on for every plan that can: one-shape batches through
     the batch entry points, the arena in small pieces, the packed classes as queue launches (K2aQueueDesc) -- against the oracle on
     every pair: score-only and CIGAR classes, both gap models, an odd pair count, wildcard pairs (re-run in one batch), Z-drops with
     the deferred arg-max (inexact pairs re-run), and the fault hook (the last watermark never arrives: the launch gives up, the plan

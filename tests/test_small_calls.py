@@ -1,9 +1,9 @@
-"""The opt-in host path for tiny single calls (ksw2amd_set_small_call_cells, ksw2_host.c: small_pair): the library's own scalar
+"""The opt-in host path for tiny single calls (ksw2amd_set_small_call_cells, ksw2_host_single.c: small_pair): the library's own scalar
 code for single-pair calls below a cell count, on the calling thread.  It must return exactly what the kernels return: every
 committed reference vector of the scalar functions, the "...2_sse" signatures' flag semantics (end bonus, EXTZ_ONLY, REV_CIGAR,
 EQX, early rejects), the global functions, and random pairs against the oracle AND against the library's device path.
 
-CPU tier: through the simulator build (tests/sim), whose host side is the product's own ksw2_host.c -- the code under test -- with
+CPU tier: through the simulator build (tests/sim), whose host side is the product's own ksw2_host_*.c -- the code under test -- with
 the lock-step simulator standing in for the device path it is compared with.  GPU tier: the same checks on libksw2_amd.so."""
 import os
 import subprocess

@@ -1,7 +1,7 @@
 /*
  * coalesce_bench.c -- an UNCHANGED minimap2-style caller: T host threads, each calling ksw_extz2_sse / ksw_extd2_sse for one
  * pair at a time with its own ksw_extz_t (cli.c:50-132, README.md:54-87 pattern).  Measures calls/s through libksw2_amd.so
- * (which coalesces concurrent calls into device batches, ksw2_host.c::queue_one) and checks every result against the batch
+ * (which coalesces concurrent calls into device batches, ksw2_host_single.c::queue_one) and checks every result against the batch
  * entry point's result for the same pair (which the parity tests pin to the oracle).
  *
  *   coalesce_bench [threads=64] [calls per thread=2000] [len=512] [band=64] [cigar=0|1]

@@ -2,7 +2,7 @@
 // device taken), a host that uploads a buffer in pieces on ANOTHER stream and publishes "pieces <= k have landed" in a device word
 // behind each piece, wavefronts that poll that word (system-scope loads + s_sleep, bounded) and then checksum their slice.
 //   build + run (GPU box):  hipcc --offload-arch=gfx950 -O3 -o /tmp/spp tools/probe/stream_publish_probe.hip && /tmp/spp
-// Questions (round 4, the streamed plans of ksw2_host.c):
+// Questions (round 4, the streamed plans of ksw2_host_plan.c):
 //   1. does hipStreamWriteValue32 on plain hipMalloc memory work, and how long after the copy does a poller see the value?
 //   2. does a one-wavefront "publish" kernel on the upload stream get a slot while the device is full of pollers
 //      (a) at 2 wavefronts per SIMD of 224 VGPRs (64 registers left per SIMD), (b) at 4 x 128 VGPRs (none left)?

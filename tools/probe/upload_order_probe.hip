@@ -1,5 +1,5 @@
 // Why did a pageable 3.6 MB hipMemcpyAsync block its caller for 15-25 ms (in steps of 5) when it followed two pieces of a page-locked
-// (hipHostRegister) arena on the same stream -- in every process but the first one on a box (round 4, streamed plans of ksw2_host.c)?
+// (hipHostRegister) arena on the same stream -- in every process but the first one on a box (round 4, streamed plans of ksw2_host_plan.c)?
 // One stream, per step: [zero block 64 KB] [2 pieces of the arena + 64 KB blocks] [small arrays] [the other pieces + blocks]; the time
 // the small-array call takes on the host is printed for: arena registered vs hipHostMalloc'ed, small arrays pageable vs pinned.
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/uop tools/probe/upload_order_probe.hip && /tmp/uop && /tmp/uop
