@@ -36,6 +36,7 @@
 	X(COALESCE_SLOTS) \
 	X(COALESCE_WINDOW_US) \
 	X(COALESCE_PLAIN_STREAMS) \
+	X(COALESCE_CROWD) \
 	X(SHARED_UP_MIN_MB) \
 	X(DEFER) \
 	X(EXTF_HBM) \

@@ -414,6 +414,7 @@ static int queue_one(const char *fn, int dual, void *km, const ksw2amd_scoring_t
 	const char *se = ENV(COALESCE_SLOTS), *we = ENV(COALESCE_WINDOW_US);
 	const int slots = imin(se ? imax(atoi(se), 0) : 4, COAL_MAXSLOTS);
 	const int64_t window_ns = (we ? imax(atoi(we), 0) : 200) * (int64_t)1000;
+	const int crowd_min = ENV(COALESCE_CROWD) ? imax(atoi(ENV(COALESCE_CROWD)), 1) : 8;      /* calls per millisecond that make a crowd (tests: 1 = always) */
 	int64_t t_in, t0;
 	int crowd, wn, slot, id = 0;
 	uintptr_t old;
@@ -428,7 +429,7 @@ static int queue_one(const char *fn, int dual, void *km, const ksw2amd_scoring_t
 		__atomic_store_n(&g_coal.win_t0, t_in, __ATOMIC_RELAXED);
 	}
 	wn = __atomic_add_fetch(&g_coal.win_n, 1, __ATOMIC_RELAXED);
-	crowd = window_ns > 0 && (wn >= 8 || __atomic_load_n(&g_coal.win_prev, __ATOMIC_RELAXED) >= 8);
+	crowd = window_ns > 0 && (wn >= crowd_min || __atomic_load_n(&g_coal.win_prev, __ATOMIC_RELAXED) >= crowd_min);
 	if (!crowd && __atomic_load_n(&g_coal.head, __ATOMIC_RELAXED) == 0 && (slot = coal_try_slot(slots)) >= 0) {      /* a free slot, nobody waiting, no crowd: run alone, now */
 		g_latency_plan = 1; g_plan_stream = coal_slot_stream(slot);
 		me.rc = run_serial(dual, 0, km, sc, 1, pr, ez, 1, 0, 0);

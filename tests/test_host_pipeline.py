@@ -124,10 +124,17 @@ def test_pool_off_and_inline_paths_agree(sim, monkeypatch):
     assert all(not diff(x, y) for x, y in zip(a, b))
 
 
-def test_concurrent_single_calls_coalesce(sim):
+@pytest.mark.parametrize("env", [{}, {"KSW2AMD_COALESCE_CROWD": "1", "KSW2AMD_COALESCE_WINDOW_US": "3000"},
+                                 {"KSW2AMD_COALESCE_CROWD": "1", "KSW2AMD_COALESCE_WINDOW_US": "500", "KSW2AMD_COALESCE_SLOTS": "1"},
+                                 {"KSW2AMD_COALESCE_CROWD": "1", "KSW2AMD_COALESCE_WINDOW_US": "20000", "KSW2AMD_COALESCE_SLOTS": "2"}],
+                         ids=["default", "crowd", "crowd-1slot", "crowd-2slots-long-window"])
+def test_concurrent_single_calls_coalesce(sim, env, monkeypatch):
     """Many host threads inside ksw_extz2_sse / ksw_extd2_sse at once (a minimap2-style pool): the library batches them;
     every caller still gets exactly its own result, CIGAR included."""
     nthreads, per = 12, 25
+    for k, v in env.items():                    # the collection window of a crowd (a leader waits for the callers the last batches held)
+        monkeypatch.setenv(k, v)
+    sim.lib.ksw2amd_reload_env()
     mat = synth.simple_mat(5, 2, 4, -1)
     work = []
     for t in range(nthreads):
