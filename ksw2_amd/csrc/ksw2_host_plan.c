@@ -584,10 +584,11 @@ ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc
 	const int use_pk = !ENV(NO_PK), use_rb = !ENV(NO_RB);
 	const int use_pkmp = !ENV(NO_PKMP);                          /* A/B runs and tests: wide bands through the int32 generation-serial kernels */
 	/* A/B runs: skip the smaller packed geometries.  Single-pair calls and their coalesced batches (g_latency_plan) skip them by
-	 * themselves: 8 or 16 lanes x 18 / 8 rows per alignment is the geometry that fills a device, but a lane then walks 4 strips of
-	 * 18 rows one after the other -- one 512 x 512, w = 64 pair takes 0.455 ms that way and 0.33 ms with 64 lanes x 8 rows (or the
-	 * solo kernel), and a caller that waits for ONE pair, or 64 threads that wait for their 64, wait for exactly that. */
-	const int pk_first = ENV(PK_FIRST) ? atoi(ENV(PK_FIRST)) : (g_latency_plan && n <= 256) ? 2 : 0;
+	 * themselves: 8 lanes x 18 rows per alignment is the geometry that fills a device, but a lane then walks 4 strips of 18 rows one
+	 * after the other -- one 512 x 512, w = 64 pair takes 0.455 ms that way and 0.33 ms with 8 rows per lane, and a caller that waits
+	 * for ONE pair, or 64 threads that wait for their 64, wait for exactly that.  (16 lanes x 8 rows, 64 x 8, the solo kernel and 64 x 16
+	 * are within 10 % of each other, the first ahead at every batch size up to 256: profiles/r4_latency_probe.txt.) */
+	const int pk_first = ENV(PK_FIRST) ? atoi(ENV(PK_FIRST)) : (g_latency_plan && n <= 256) ? 1 : 0;
 
 	if (tlev) tph[0] = now_ms();
 	g_err[0] = 0;
