@@ -928,8 +928,10 @@ def test_fuzz_slice(mode):
     assert r.returncode == 0 and "fuzz ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
-@pytest.mark.parametrize("cigar", [0, 1])
-def test_unchanged_threaded_caller_is_coalesced(cigar):
+@pytest.mark.parametrize("cigar,extra", [(0, {}), (1, {}), (0, {"KSW2AMD_COALESCE_WINDOW_US": "0"}), (1, {"KSW2AMD_COALESCE_SLOTS": "1"}),
+                                         (0, {"KSW2AMD_COALESCE_SLOTS": "8", "KSW2AMD_COALESCE_PLAIN_STREAMS": "1"})],
+                         ids=["score", "cigar", "no-window", "cigar-1slot", "8-plain-slots"])
+def test_unchanged_threaded_caller_is_coalesced(cigar, extra):
     """tools/coalesce-bench: 64 host threads calling ksw_extz2_sse / ksw_extd2_sse one pair at a time (the minimap2 pattern).  The
     library batches concurrent calls behind the unchanged symbols; every call returns exactly what the batch entry point returns."""
     import json
@@ -940,6 +942,7 @@ def test_unchanged_threaded_caller_is_coalesced(cigar):
     if not os.path.exists(exe):
         subprocess.run(["make", "-C", os.path.join(root, "tools"), "coalesce-bench"], check=True, capture_output=True)
     env = {k: v for k, v in os.environ.items() if not k.startswith("KSW2AMD_")}
+    env.update(extra)                           # (the collection window off, one slot, eight slots on ordinary streams: same results)
     r = subprocess.run([exe, "64", "300", "512", "64", str(cigar)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-1000:])
     d = json.loads(r.stdout.strip().splitlines()[-1])
