@@ -624,6 +624,18 @@ def _check_flat(lib, device_copy=None):
                 assert not diff(exp, ref[i]), (i, dual)
             tot += 1
     assert {"pk", "solo", "int32"} <= kinds, kinds         # unscanned arenas reach the packed AND the solo kernels (both report wildcard codes)
+    # wide alphabets through the flat entry: the effective matrices travel in the arena's tail block (page-locked staging since round 4)
+    for rnd in range(3):
+        m, wmat, qs, ts, w, zd, fl = _wide_alphabet_cases(rng, rnd)
+        for dual in (False, True):
+            ref = (lib.extd_batch(qs, ts, wmat, 6, 2, 20, 1, w=w, zdrop=zd, flag=fl, m=m) if dual else lib.extz_batch(qs, ts, wmat, 6, 2, w=w, zdrop=zd, flag=fl, m=m))
+            fb = lib.make_flat_batch(qs, ts, wmat, 6, 2, 20, 1, w=w, zdrop=zd, flag=fl, m=m)
+            got = fb.run_oneshot(dual)
+            for i in range(len(qs)):
+                assert not diff(ref[i], got[i]), ("flat, wide alphabet", m, i, dual, hex(int(fl[i])), diff(ref[i], got[i]))
+                if i % 3 == 0:
+                    exp = po.align("oracle", "extd2" if dual else "extz2", qs[i], ts[i], wmat, 6, 2, 20, 1, w=int(w[i]), zdrop=int(zd[i]), flag=int(fl[i]), m=m)
+                    assert not diff(exp, got[i]), ("flat vs oracle, wide alphabet", m, i, dual)
     if device_copy is not None:
         # a DEVICE arena whose pairs ask for the SSE kernels' own results (what a sharded run with those flags hands every receiving
         # rank, ksw2_amd/parallel.py): the span comes back to the host and takes the SSE-compatible plans -- same results as the pointer entry
