@@ -173,7 +173,7 @@ def cpu_baseline(wl, q, t, mat, seconds=10.0):
     for threads in sorted({1, ncores}):
         el = ctypes.c_double(0)
         done = olib.kso_cpu_bench(fn, mode, threads, seconds, ns, qp.ctypes.data, tp.ctypes.data, ql.ctypes.data, tl.ctypes.data, None,
-                                  5, mat.ctypes.data, S["q"], S["e"], S["q2"], S["e2"], wl["w"], wl["zdrop"], wl["flag"], ctypes.byref(el))
+                                  5, mat.ctypes.data, S["q"], S["e"], S["q2"], S["e2"], wl["w"], wl["zdrop"], wl["flag"] & 0xffff, ctypes.byref(el))      # (the reference's own flag bits only)
         # pairs are taken in order (index mod ns): cells of the pairs actually aligned
         full, rem = divmod(int(done), ns)
         c = full * cells.sum() + cells[:rem].sum()
@@ -370,11 +370,25 @@ class Job:
         nn = b.n
         if self.kind == "exts":
             done = cells
+        elif self.kind == "extf":
+            # rows_done = anti-diagonals completed before the X-drop (k2a_extf_finish); cells of those diagonals, per distinct shape
+            done = 0
+            shapes = {}
+            for i in range(nn):
+                shapes.setdefault((int(self.qlen[i]), int(self.tlen[i]), int(self.weff[i])), []).append(i)
+            for (ql_, tl_, w_), idx in shapes.items():
+                r = np.arange(ql_ + tl_ - 1, dtype=np.int64)
+                lo = np.maximum(np.maximum(0, r - ql_ + 1), (r - w_ + 1) >> 1)
+                hi = np.minimum(np.minimum(tl_ - 1, r), (r + w_) >> 1)
+                cum = np.concatenate([[0], np.cumsum(np.maximum(hi - lo + 1, 0))])
+                tot = int(cells_of_rows(ql_, tl_, w_))
+                nd = np.clip(rows[idx], 0, len(r))
+                done += int((cum[nd] * (tot / max(int(cum[-1]), 1))).sum())      # scaled to the row-band cell count `cells` is quoted in
         else:
             done = int(cells_of_rows(self.qlen[:nn], np.minimum(rows, self.tlen[:nn]), self.weff[:nn]).sum())
         res = dict(n=nn, cells=cells, steps=k, wall_s=wall, kernel_ms=float(np.mean(total_ms)), fill_ms=float(np.mean(fill_ms)),
                    cells_done=done, zdropped=int(raw[:, 1].sum()), packed_pairs=plan.packed_pairs(), device_bytes=plan.device_bytes(),
-                   kernels=plan.describe() if self.kind in ("extz", "extd") and not self.sse else [])
+                   kernels=plan.describe())
         plan.close()
         return res
 
@@ -406,15 +420,25 @@ def roofline_of(job, res, workload_key):
     return out
 
 
+def _kernel_line(c):
+    """One line of ksw2amd_plan_describe as a short string (extz / extd classes carry a geometry, the others their own fields)."""
+    if "G" in c:
+        return "%s(%d,%d) gaps=%d %s%s%s %s x%d" % (c["kernel"], c["G"], c["C"], c["gaps"], c["mode"], " rebased" if c["rebased"] else "",
+                                                    " nomax" if c["nomax"] else "", c["form"], c["tasks"])
+    return "%s %s x%d" % (c["kernel"], " ".join("%s=%s" % (k, v) for k, v in c.items() if k not in ("kernel", "tasks")), c["tasks"])
+
+
 def _roofline_dict(job, res, ops, kern_s, achieved, alg_bytes, traffic, src):
     return {"bound": "valu", "achieved": round(achieved / 1e12, 4), "peak": VALU_PEAK_PK16 / 1e12, "unit": "Tiop/s",
             "frac": round(achieved / VALU_PEAK_PK16, 5), "traffic": traffic, "traffic_source": src,
+            # rocprofv3 --pmc cannot run inside this process: `traffic` is replayed from the newest committed PMC summary of this workload
+            "traffic_measured_in": ("%s (round %s; separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --workload ... --resident-only`, "
+                                    "tools/scripts/profile_round.sh)" % (src, os.path.basename(src).split("_")[0].lstrip("r")[:1])) if src else None,
             "ops_per_cell": ops, "kernel_ms": round(res["kernel_ms"], 4), "fill_kernel_ms": round(res["fill_ms"], 4),
             "kernel_gcups": round(res["cells"] / kern_s / 1e9, 2), "pairs_per_launch": res["n"], "cells_per_launch": res["cells"],
             "kernel_gcups_cells_filled": round(res["cells_done"] / kern_s / 1e9, 2),
             "early_stop_fraction": round(1.0 - res["cells_done"] / max(res["cells"], 1), 5), "zdropped_pairs": res["zdropped"],
-            "kernels": ["%s(%d,%d) gaps=%d %s%s%s %s x%d" % (c["kernel"], c["G"], c["C"], c["gaps"], c["mode"], " rebased" if c["rebased"] else "",
-                                                             " nomax" if c["nomax"] else "", c["form"], c["tasks"]) for c in res.get("kernels", [])],
+            "kernels": [_kernel_line(c) for c in res.get("kernels", [])],
             "algorithmic_bytes": alg_bytes, "hbm_algorithmic_GBps": round(alg_bytes / kern_s / 1e9, 2), "hbm_peak_GBps": HBM_PEAK / 1e9}
 
 
@@ -535,6 +559,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=0, help="override pairs per step and GPU (parity/debug only)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--also-cpu-seconds", type=float, default=3.0, help="CPU sample per `also` workload (1 thread, then all cores); 0 = none")
     ap.add_argument("--also", default=None, help="comma-separated workloads for the `also` array ('' = none; default: the other configs at N = 1)")
     ap.add_argument("--no-also", action="store_true")
     ap.add_argument("--resident-only", action="store_true", help="profiling: only the HBM-resident kernel loop (what rocprofv3 should see)")
@@ -782,7 +807,10 @@ def main():
                          "unit": "GCUPS", "pairs_per_s": round(j.n * world * k / edt, 1), "steps": k, "ms_per_step": round(edt / k * 1e3, 3),
                          "dtype": dtype_of(j, r), "parity_sample": "%s (%d pairs)" % (jpar["result"], jpar["pairs"]),
                          "roofline": {x: rr[x] for x in ("frac", "kernel_ms", "fill_kernel_ms", "ops_per_cell", "pairs_per_launch", "kernels",
-                                                         "kernel_gcups_cells_filled", "early_stop_fraction", "zdropped_pairs", "traffic", "traffic_source")}})
+                                                         "kernel_gcups_cells_filled", "early_stop_fraction", "zdropped_pairs", "traffic", "traffic_source",
+                                                         "traffic_measured_in")},
+                         # SURVEY 8d "per config": the reference's own function on this box's host cores, a bounded sample of this batch
+                         **({"cpu_baseline": cpu_baseline(j.wl, j.q, j.t, j.mat, seconds=args.also_cpu_seconds)} if not args.no_cpu and args.also_cpu_seconds > 0 else {})})
             del j
         except Exception as exc:                                  # one workload must not take the headline with it
             if world > 1:

@@ -1434,6 +1434,25 @@ int ksw2amd_plan_describe(const ksw2amd_plan_t *p, char *buf, int cap)
 			}
 		return nl;
 	}
+	if (p->splice == 1 && !p->reject_all) {          /* ksw_exts2_sse plans: register windows of 8 / 16 slots, or the HBM-state kernel */
+		static const char *const skind[3] = { "exts-win8", "exts-win16", "exts-hbm" };
+		int nl = 0, mode, g, wn;
+		for (mode = 0; mode < 3; ++mode) for (g = 0; g < 2; ++g) for (wn = 0; wn < 3 && len < cap - 1; ++wn)
+			if (p->s_count[mode][g][wn]) {
+				len += snprintf(buf + len, (size_t)(cap - len), "kernel=%s mode=%s generic=%d tasks=%d\n", skind[wn], mode_name[mode], g, p->s_count[mode][g][wn]);
+				++nl;
+			}
+		return nl;
+	}
+	if (p->splice == 3 && !p->reject_all) {          /* SSE-compatible plans: state arrays in LDS or in HBM scratch */
+		int nl = 0, mode, lds;
+		for (mode = 0; mode < 3; ++mode) for (lds = 0; lds < 2 && len < cap - 1; ++lds)
+			if (p->s_count[mode][0][lds]) {
+				len += snprintf(buf + len, (size_t)(cap - len), "kernel=ssec gaps=%d mode=%s form=%s tasks=%d\n", p->dual ? 2 : 1, mode_name[mode], lds ? "lds" : "hbm", p->s_count[mode][0][lds]);
+				++nl;
+			}
+		return nl;
+	}
 	if (p->splice || p->reject_all) return 0;
 	for (c = 0; c < p->ncls && len < cap - 1; ++c) {
 		const cls_t *k = &p->cls[c];

@@ -162,13 +162,16 @@ K2A_FN bool k2a_extf_lane_diag(const K2aExtf &par, int qlen, int tlen, int w, in
 	return true;
 }
 
-K2A_FN void k2a_extf_finish(const K2aExtfBook &b, bool complete, K2aResult *r)
+/* rdone = anti-diagonals completed, nr = anti-diagonals of the pair; K2aResult.rows_done carries rdone here (diagnostics: the cells an
+ * X-drop saved) */
+K2A_FN void k2a_extf_finish(const K2aExtfBook &b, int rdone, int nr, K2aResult *r)
 {
+	const bool complete = rdone == nr;
 	r->max = b.max; r->max_t = b.max_t; r->max_q = b.max_q;
 	r->zdropped = complete ? 0 : 1;
 	r->score = complete ? b.H0 : K2A_NEG;
 	r->mqe = r->mte = K2A_NEG; r->mqe_t = r->mte_q = -1;
-	r->reach_end = 0; r->n_cigar = 0; r->rows_done = 0; r->ti = r->tj = -1;
+	r->reach_end = 0; r->n_cigar = 0; r->rows_done = rdone; r->ti = r->tj = -1;
 }
 
 #endif

@@ -422,9 +422,14 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 template<int G, int C, bool RB>
 __global__ void __launch_bounds__(64 * K2A_WPB)
 k2a_argmax_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
-                  const uint8_t *__restrict__ seq, const uint8_t *__restrict__ ck, K2aResult *__restrict__ res)
+                  const uint8_t *__restrict__ seq, const uint8_t *__restrict__ ck, K2aResult *__restrict__ res, const K2aQueueDesc *qd)
 {
 	constexpr int NG = 64 / G;
+	/* behind a streamed fill that was abandoned (k2a_queue_wait: abort raised, or wavefront-tasks that never started): the result
+	 * records and checkpoint blocks of the tasks the fill never ran hold whatever the recycled buffers held before -- a stale max_t
+	 * would index strips megabytes past the task's block.  Nothing to do here then: the host repeats the whole plan unstreamed. */
+	if (qd && (__hip_atomic_load(&qd->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+	           __hip_atomic_load(&qd->next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != qd->nwt)) return;
 	typedef K2aLanePk<G, C, false, K2A_MODE_SCORE, RB, false, 0, false> Lane;
 	const int job = blockIdx.x * (64 * K2A_WPB) + threadIdx.x;
 	const int task = job / 3, which = job - 3 * task;
@@ -1427,7 +1432,7 @@ k2a_extf_kernel(const K2aExtf par, const K2aPair *__restrict__ pairs, const uint
 		if (!k2a_extf_follow(bk, d, r, par.e, xdrop, vf, un)) break;
 		prev_lo = d.blo; prev_hi = d.bhi;
 	}
-	if (lane == 0) k2a_extf_finish(bk, r == nr, &res[pi]);
+	if (lane == 0) k2a_extf_finish(bk, r, nr, &res[pi]);
 }
 
 /* One extension per lane (ksw2_lane_extf.h, K2aExtfLaneMem): task t of the launch = lane t & 63 of wavefront t >> 6; the pairs of a
@@ -1460,7 +1465,7 @@ k2a_extf_lane_kernel(const K2aExtf par, const K2aPair *__restrict__ pairs, const
 			else go = false;
 		}
 	}
-	if (valid) k2a_extf_finish(bk, r == nr, &res[pi]);
+	if (valid) k2a_extf_finish(bk, r, nr, &res[pi]);
 }
 
 /* The same with the state arrays in LDS: a lane only ever touches the few dozen rows around its band (K2A_EXTF_RING_ROWS), so
@@ -1494,7 +1499,7 @@ k2a_extf_lane_ring_kernel(const K2aExtf par, const K2aPair *__restrict__ pairs, 
 			else go = false;
 		}
 	}
-	if (valid) k2a_extf_finish(bk, r == nr, &res[pi]);
+	if (valid) k2a_extf_finish(bk, r, nr, &res[pi]);
 }
 
 /* Register-window form: bands up to K2A_EXTF_WIN_SPAN(K) positions wide.  U, V, S and the target code of K x 64 positions
@@ -1566,7 +1571,7 @@ k2a_extf_win_kernel(const K2aExtf par, const K2aPair *__restrict__ pairs, const 
 		if (!k2a_extf_follow(bk, d, r, par.e, xdrop, vf, un)) break;
 		prev_lo = d.blo; prev_hi = d.bhi;
 	}
-	if (lane == 0) k2a_extf_finish(bk, r == nr, &res[pi]);
+	if (lane == 0) k2a_extf_finish(bk, r, nr, &res[pi]);
 }
 
 typedef void (*fill_pk_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*, K2aQueueDesc*);
@@ -1598,7 +1603,7 @@ static const fill_pk_fn g_fill_pkq_ldscodes[3][2][2] = { LDSCODEQ_SET(64, 16), L
 static const fill_pk_fn g_fill_pk_defer[4][2] = { DEFER_ROW(8, 18, 0), DEFER_ROW(16, 8, 2), DEFER_ROW(64, 8, 0), DEFER_ROW(64, 16, 2) };
 #define DEFERQ_ROW(G, C, LR) { k2a_fill_pk_kernel<G, C, false, 0, false, false, LR, true, true>, k2a_fill_pk_kernel<G, C, false, 0, true, false, LR, true, true> }
 static const fill_pk_fn g_fill_pkq_defer[4][2] = { DEFERQ_ROW(8, 18, 0), DEFERQ_ROW(16, 8, 2), DEFERQ_ROW(64, 8, 0), DEFERQ_ROW(64, 16, 2) };
-typedef void (*argmax_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, const uint8_t*, K2aResult*);
+typedef void (*argmax_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, const uint8_t*, K2aResult*, const K2aQueueDesc*);
 #define ARGMAX_ROW(G, C) { k2a_argmax_kernel<G, C, false>, k2a_argmax_kernel<G, C, true> }
 static const argmax_fn g_argmax[4][2] = { ARGMAX_ROW(8, 18), ARGMAX_ROW(16, 8), ARGMAX_ROW(64, 8), ARGMAX_ROW(64, 16) };
 
@@ -1793,7 +1798,7 @@ int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax,
 		hipLaunchKernelGGL(fn, dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream, *sc, pairs, order2, ntasks, seq, tb, res, qd);
 		CHECK(hipGetLastError());
 		hipLaunchKernelGGL(g_argmax[cfg][rebased ? 1 : 0], dim3((3 * ntasks + 64 * K2A_WPB - 1) / (64 * K2A_WPB)), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
-		                   *sc, pairs, order2, ntasks, seq, (const uint8_t*)tb, res);
+		                   *sc, pairs, order2, ntasks, seq, (const uint8_t*)tb, res, (const K2aQueueDesc*)qd);
 		CHECK(hipGetLastError());
 		return 0;
 	}

@@ -901,7 +901,7 @@ static void sim_extf(const K2aExtf par, const K2aPair *pairs, const uint32_t *or
 			if (!k2a_extf_follow(bk, d, r, par.e, xdrop, V[bk.follow], U[bk.follow + 1])) break;
 			prev_lo = d.blo; prev_hi = d.bhi;
 		}
-		k2a_extf_finish(bk, r == nr, &res[pi]);
+		k2a_extf_finish(bk, r, nr, &res[pi]);
 	}
 }
 
@@ -959,7 +959,7 @@ static void sim_extf_win(const K2aExtf par, const K2aPair *pairs, const uint32_t
 			if (!k2a_extf_follow(bk, d, r, par.e, xdrop, vf, un)) break;
 			prev_lo = d.blo; prev_hi = d.bhi;
 		}
-		k2a_extf_finish(bk, r == nr, &res[pi]);
+		k2a_extf_finish(bk, r, nr, &res[pi]);
 	}
 }
 
@@ -1063,7 +1063,7 @@ static void sim_extf_lane(const K2aExtf par, const K2aPair *pairs, const uint32_
 		int prev_lo = -1, prev_hi = -1, r = 0;
 		const int nr = qlen + tlen - 1;
 		while (r < nr && k2a_extf_lane_diag(par, qlen, tlen, w, tpad, xdrop, r, m, prev_lo, prev_hi, bk)) ++r;
-		k2a_extf_finish(bk, r == nr, &res[pi]);
+		k2a_extf_finish(bk, r, nr, &res[pi]);
 	}
 }
 
