@@ -71,10 +71,13 @@ WORKLOADS = {
     "10k-zdrop": dict(idx=6, n=49152, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=SO, sub=0.05, ind=0.06, tail_frac=0.25, tail_pairs=0.20),
     # ... and where 1 % of the pairs hold a wildcard base: those leave the packed kernels (they score match / mismatch only)
     "10k-N": dict(idx=6, n=49152, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=SO, sub=0.05, ind=0.06, wild_pairs=0.01),
+    # ... and under a scoring matrix without match / mismatch structure (KSW_EZ_GENERIC_SC; transitions -2, transversions -4): the reference
+    # takes any matrix at its full rate (ksw2_extz2_sse.c:142-143), and since round 5 so do the packed kernels (column profiles)
+    "10k-generic": dict(idx=6, n=49152, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=SO | ksw2_amd.KSW_EZ_GENERIC_SC, sub=0.05, ind=0.06, tstv=True),
     # ... and in the SSE-compatible mode (the reference's SSE kernels' own results): every pair through k2a_ssec_kernel
     "10k-ssec": dict(idx=6, n=1024, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=SO, sub=0.05, ind=0.06, sse=True),
 }
-ALSO_DEFAULT = ["10k-n1024", "10k-cigar", "cfg2", "cfg3", "cfg5", "cfg4", "cfg5-share", "10k-zdrop", "10k-N", "exts", "extf", "10k-ssec"]
+ALSO_DEFAULT = ["10k-n1024", "10k-cigar", "cfg2", "cfg3", "cfg5", "cfg4", "cfg5-share", "10k-zdrop", "10k-N", "10k-generic", "exts", "extf", "10k-ssec"]
 # pairs of each workload's last timed batch that are compared with the oracle outside the clock (the MT pair costs ~1 s per pair on the host)
 PARITY_PAIRS = {"cfg4": 16, "cfg4-so": 4, "cfg5": 16, "cfg5-share": 16}
 # N > 1: the configurations BASELINE.json quotes for several GPUs at their per-GPU share (config 4: 4 096 replicas / 8)
@@ -229,6 +232,8 @@ class Job:
             self.kind = "extf"
         else:
             self.mat = synth.simple_mat(5, S["a"], S["b"], 0 if wl.get("mt") else S["sc_n"])
+            if wl.get("tstv"):                   # A<->G and C<->T (codes 0<->2, 1<->3) cost 2, the other substitutions 4
+                self.mat = np.array([[2, -4, -2, -4, -1], [-4, 2, -4, -2, -1], [-2, -4, 2, -4, -1], [-4, -2, -4, 2, -1], [-1, -1, -1, -1, -1]], dtype=np.int8).reshape(-1)
             self.batch = lib.make_batch(self.q, self.t, self.mat, S["q"], S["e"], S["q2"], S["e2"], w=wl["w"], zdrop=wl["zdrop"], end_bonus=0, flag=wl["flag"])
             self.kind = "extd" if wl["dual"] else "extz"
         self.score_only = bool(wl["flag"] & SO)

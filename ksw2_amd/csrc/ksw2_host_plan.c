@@ -376,34 +376,30 @@ static void build_scoring(int dual, int m, const int8_t *mat, int q, int e, int 
 	}
 }
 
-/* Packed-int16 class (ksw2_lane_pk.h): the scoring must be match / mismatch / wildcard on a 5-letter alphabet ... */
-typedef struct { int ok, a, b, n, smax, smin, qemax, qemin, q, e; } pkinfo_t;
+/* Packed-int16 class (ksw2_lane_pk.h): ANY scoring matrix over at most five residue codes -- the reference's kernels take any `mat`
+ * at their full rate (ksw2_extz2_sse.c:142-143, ksw2_extd2_sse.c:182-183), and since round 5 so do these: the kernels hold a score
+ * as its penalty below the matrix's largest entry and look it up in per-query-code column profiles (K2aScoring.cp).  A profile
+ * has four bytes, target codes 0..3: pairs whose TARGET holds code 4 leave this class (plan_create_ex), a query's code 4 is table
+ * entry 4.  What must hold ... */
+typedef struct { int ok, smax, smin, qemax, qemin, q, e; uint32_t cp[8]; } pkinfo_t;
 
 static void pk_scoring(int dual, int m, const int8_t *mat, int q, int e, int q2, int e2, int generic, pkinfo_t *o)
 {
-	K2aScoring t;
-	int x, y, ok = (m == 5);
+	int8_t eff[25];
+	int x, y, ok = (m >= 1 && m <= 5);
 	memset(o, 0, sizeof(*o));
 	if (ok) {
-		int8_t eff[25];
-		build_scoring(dual, m, mat, q, e, q2, e2, generic, &t);
-		for (x = 0; x < 5; ++x)
-			for (y = 0; y < 5; ++y)
-				eff[x * 5 + y] = y < 4 ? (int8_t)(t.prof[x] >> (8 * y)) : (int8_t)t.colw[x];
-		o->a = eff[0]; o->b = eff[1]; o->n = eff[24];
+		build_eff(dual, m, mat, e, e2, generic, eff);
 		o->smax = o->smin = eff[0];
-		for (x = 0; x < 5; ++x)
-			for (y = 0; y < 5; ++y) {
-				const int want = (x == 4 || y == 4) ? o->n : x == y ? o->a : o->b;
-				if (eff[x * 5 + y] != want) ok = 0;
-				o->smax = imax(o->smax, eff[x * 5 + y]); o->smin = imin(o->smin, eff[x * 5 + y]);
-			}
+		for (x = 0; x < m * m; ++x) { o->smax = imax(o->smax, eff[x]); o->smin = imin(o->smin, eff[x]); }
+		for (y = 0; y < m; ++y)                              /* column profile of query code y: penalties against target codes 0..3 */
+			for (x = 0; x < 4 && x < m; ++x) o->cp[y] |= (uint32_t)(o->smax - eff[x * m + y]) << (8 * x);
 	}
 	o->q = q; o->e = e;
 	o->qemax = dual ? imax(q + e, q2 + e2) : q + e;
 	o->qemin = dual ? imin(q + e, q2 + e2) : q + e;
 	/* the fill loop adds these as unsigned 32-bit constants to both halves at once (ksw2_lane_pk.h, offset form) */
-	if (q < 0 || e < 0 || (dual && (q2 < 0 || e2 < 0)) || o->a + e < 0 || o->a - o->b < 0) ok = 0;
+	if (q < 0 || e < 0 || (dual && (q2 < 0 || e2 < 0)) || o->smax + e < 0) ok = 0;
 	o->ok = ok;
 }
 
@@ -432,7 +428,7 @@ static int pk_window_ok(const pkinfo_t *k, int qlen, int tlen, int w, int C)
 	if (k->ok <= 0 || qlen > 65000 || tlen > 65000) return 0;          /* column / row indices travel as unsigned 16-bit halves */
 	/* ... and what is added to or taken from -inf before the band mask clamps it again (two base shifts, a score, a gap
 	 * cost) must stay inside the K2A_PK_SLACK units the offset form keeps below it (ksw2_types.h) */
-	if ((int64_t)4 * C * D + 2 * k->qemax + imax(k->smax, 0) + 64 > K2A_PK_SLACK) return 0;
+	if ((int64_t)4 * C * D + 2 * k->qemax + imax(k->smax, 0) + (k->smax - k->smin) + 64 > K2A_PK_SLACK) return 0;      /* (smax - smin: the largest penalty a candidate loses) */
 	return ((int64_t)2 * w + 2 * C + 2) * D + 2 * k->qemax + (int64_t)4 * C * D + 64 <= 12000;
 }
 
@@ -554,9 +550,9 @@ static uint64_t or_bytes(const uint8_t *p, int n)
 	for (; i < n; ++i) acc |= p[i];
 	return acc;
 }
-static int pair_has_wild(const ksw2amd_pair_t *a)
+static int pair_has_wild(const ksw2amd_pair_t *a)         /* a wildcard code in the TARGET: what keeps a pair out of the packed kernels (pk_scoring) */
 {
-	return ((or_bytes(a->query, a->qlen) | or_bytes(a->target, a->tlen)) & 0xfcfcfcfcfcfcfcfcull) != 0;
+	return (or_bytes(a->target, a->tlen) & 0xfcfcfcfcfcfcfcfcull) != 0;
 }
 
 ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, const flat_src_t *flat, int want_stream)
@@ -998,7 +994,7 @@ ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc
 			c->cfg = c->solo ? 0 : pass ? (pass - 1) % K2A_NPKCFG : ci / 6; c->rb = pass && !c->solo ? ((pass - 1) / K2A_NPKCFG) & 1 : 0;
 			c->nomax = !c->solo && pass > 2 * K2A_NPKCFG; c->mode = (ci / 2) % 3; c->generic = ci & 1; c->pk = pass != 0 && !c->solo; c->first = k;
 			build_scoring(dual, m, sc->mat, q, e, q2, e2, c->generic, &c->sc);
-			c->sc.pk_a = pkinfo[c->generic].a; c->sc.pk_b = pkinfo[c->generic].b; c->sc.pk_n = pkinfo[c->generic].n;
+			if (pkinfo[c->generic].ok > 0) { memcpy(c->sc.cp, pkinfo[c->generic].cp, sizeof(c->sc.cp)); c->sc.pk_smax = pkinfo[c->generic].smax; }
 			if (uni) {
 				if (!pass || c->solo) { for (i = 0; i < cnt; ++i) p->h_order[k++] = (uint32_t)i; ntask = cnt; }
 				else for (i = 0; i < cnt; i += 2, ++ntask) { p->h_order[k++] = (uint32_t)i; p->h_order[k++] = (uint32_t)(i + 1 < cnt ? i + 1 : i); }
@@ -1063,6 +1059,7 @@ ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc
 				const int G = c->pk ? k2a_pkcfg_G[c->cfg] : 64, C = c->pk ? k2a_pkcfg_C[c->cfg] : 16, NG = 64 / G;
 				int t0;
 				if (!c->defer) continue;
+				at += align_up(4 * K2A_ZLIST_WORDS(c->count), 256);      /* the class's list of frozen books, right in front of its first checkpoint block (ksw2_types.h) */
 				for (t0 = 0; t0 < c->count; t0 += NG) {
 					uint32_t steps = 0, hs = 0;
 					int t;
@@ -1575,8 +1572,10 @@ void km_unlock(const void *km) { if (km) pthread_mutex_unlock(km_mutex(km)); }
 /* Pairs whose device result cannot be used are run again through the ordinary gather path, one by one:
  *   K2aResult.pad[0] -- flat plans: a packed kernel met a wildcard code (K2aLanePk::seen); the gather path's scan sends the pair to
  *                       the int32 kernels.  Host arenas read the sequences where they lie, device arenas bring them back first;
- *   K2aResult.pad[1] -- deferred arg-max: a Z-drop could not be ruled out without the arg-max columns; the re-run keeps them. */
-int needs_rerun(const ksw2amd_plan_t *p, int i) { return p->h_cls[i] >= 0 && !p->splice && (((p->flat || p->unscanned) && p->h_res[i].pad[0]) || p->h_res[i].pad[1]); }
+ *   K2aResult.pad[1] == 1 -- deferred arg-max: a Z-drop could not be ruled out without the arg-max columns, and the second pass (k2a_argmax_kernel)
+ *                       found that the reference's test does NOT hold at the row the fill stopped at: the re-run keeps the columns.
+ *                       (2 = the second pass settled the drop: the record is final.) */
+int needs_rerun(const ksw2amd_plan_t *p, int i) { return p->h_cls[i] >= 0 && !p->splice && (((p->flat || p->unscanned) && p->h_res[i].pad[0]) || p->h_res[i].pad[1] == 1); }
 int pair_rerun(ksw2amd_plan_t *p, int i, void *km, ksw_extz_t *z)
 {
 	ksw2amd_pair_t a;

@@ -208,8 +208,11 @@ void copy_range(const copy_ctx_t *c, int beg, int end)
 	for (i = beg; i < end; ++i) {
 		const ksw2amd_pair_t *a = &c->pairs[i];
 		if (a->qlen <= 0 || a->tlen <= 0) continue;
-		if (c->wild) c->wild[i] = (uint8_t)(copy_scan(c->h_seq + c->hp[i].qoff, a->query, a->qlen) | copy_scan(c->h_seq + c->hp[i].toff, a->target, a->tlen));
-		else { memcpy(c->h_seq + c->hp[i].qoff, a->query, (size_t)a->qlen); memcpy(c->h_seq + c->hp[i].toff, a->target, (size_t)a->tlen); }   /* unscanned (streamed plans) */
+		/* the scan looks for wildcard codes in the TARGET: the packed kernels' row profiles hold target codes 0..3 (pk_scoring); a
+		 * query's wildcard is an entry of their column-profile table like any other code */
+		memcpy(c->h_seq + c->hp[i].qoff, a->query, (size_t)a->qlen);
+		if (c->wild) c->wild[i] = (uint8_t)copy_scan(c->h_seq + c->hp[i].toff, a->target, a->tlen);
+		else memcpy(c->h_seq + c->hp[i].toff, a->target, (size_t)a->tlen);      /* unscanned (streamed plans) */
 		memset(c->h_seq + c->hp[i].toff + a->tlen, 0, 64);                                          /* rows read past the target end */
 	}
 }

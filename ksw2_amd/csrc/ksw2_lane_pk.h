@@ -29,13 +29,21 @@
  * two v_pk_max_u16 (2 x 4.4).  A pattern outside 0x0000 .. 0x7BFF (only garbage that a band mask discards anyway) yields
  * garbage, which the same mask discards.  On gfx950 v_add_u32, v_sub_u32,
  * v_xor_b32, v_bitop3_b32 issue a wave64 in 2 cycles, every v_pk_*_i16 (and v_bfi, v_bfe, v_max_i32) in 4
- * (tools/probe/valu_rate.hip, profiles/r1d_valu_rate.txt).  Score-only kernels also keep the target codes as two bit
- * planes pre-multiplied with D = match - mismatch, so "mismatch ? D : 0" is xor + one v_bitop3 and the diagonal
- * candidate is H + (match + e) - that: 8 cycles instead of 14.  Cold code (init, epilogues) converts at its edges.
+ * (tools/probe/valu_rate.hip, profiles/r1d_valu_rate.txt).  Cold code (init, epilogues) converts at its edges.
  *
- * Preconditions, checked by the host (ksw2_host_plan.c::pk_eligible / pk_window_ok): m = 5 with a match / mismatch / wildcard score
- * structure (always true without KSW_EZ_GENERIC_SC), no wildcard code in either sequence (such pairs take the
- * int32 kernels), gap costs and match + e and match - mismatch non-negative, and every in-band H, E, F provably inside (-16384 + max(q+e, q2+e2), 12287 - max(q+e, q2+e2))
+ * Scores (round 5: "column profiles", any matrix -- ksw2_extz2_sse.c:142-143 / ksw2_extd2_sse.c:182-183 take any m x m `mat` at
+ * full rate, and so do these kernels for m <= 5): a score is held as its penalty below the matrix's largest entry, smax - s(t, q),
+ * one byte.  Per step a lane looks up the COLUMN profile of its query code -- cp[q] = the four penalties against target codes
+ * 0..3, one dword from an 8-entry table in LDS (K2aScoring.cp), fetched one step ahead -- for each of its two alignments; per row
+ * it keeps ONE register, the byte selector { tA, 0x0c, 4 + tB, 0x0c } formed when the strip starts, and the diagonal candidate is
+ *     H(i-1,j-1) + (smax + e) - v_perm_b32(cpB, cpA, selector[row])
+ * : three instructions, 9 cycles, for any matrix (rounds 1-4: two bit planes of the target codes x (match - mismatch), xor + v_bitop3,
+ * four instructions, two registers per row, match / mismatch scoring only; the traceback kernels compare + multiply-add, 15 cycles).
+ * The query's wildcard (code 4) is table entry 4.  A TARGET code of 4 has no byte in a four-byte profile: such pairs take the
+ * int32 kernels (the host's scan finds them; kernels of unscanned plans report them, K2aLanePk::seen).
+ *
+ * Preconditions, checked by the host (ksw2_host_plan.c::pk_eligible / pk_window_ok): m <= 5, no wildcard code in the TARGET, gap
+ * costs and smax + e non-negative, and every in-band H, E, F provably inside (-16384 + max(q+e, q2+e2), 12287 - max(q+e, q2+e2))
  * so that -16384 can stand for -infinity (K2A_PK_VMAX = 12287 is the largest value the offset form holds, ksw2_types.h).
  */
 #ifndef KSW2_LANE_PK_H_
@@ -60,6 +68,29 @@ K2A_FN k2a_pk k2a_byte_pair(uint32_t a, uint32_t b, int r)                      
 	return ((a >> (8 * r)) & 0xffu) | (((b >> (8 * r)) & 0xffu) << 16);
 #endif
 }
+/* v_perm_b32 with a register selector: result byte k = byte sel[k] of the eight bytes { s1 (0..3), s0 (4..7) }; selector values
+ * 8..11 = 0x00 / 0xff by the sign bit of byte 1 / 3 / 5 / 7, 12 = 0x00, >= 13 = 0xff (ISA: V_PERM_B32).  The simulator build runs
+ * the C twin; tools/probe/perm_probe.hip compares the two on the device for every selector value. */
+K2A_FN uint32_t k2a_perm(uint32_t s0, uint32_t s1, uint32_t sel)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __builtin_amdgcn_perm(s0, s1, sel);
+#else
+	const uint64_t src = ((uint64_t)s0 << 32) | s1;
+	uint32_t r = 0;
+	for (int k = 0; k < 4; ++k) {
+		const uint32_t x = (sel >> (8 * k)) & 0xffu;
+		uint32_t b;
+		if (x >= 13) b = 0xffu;
+		else if (x == 12) b = 0u;
+		else if (x >= 8) b = ((src >> (16 * (x - 8) + 15)) & 1u) ? 0xffu : 0u;
+		else b = (uint32_t)(src >> (8 * x)) & 0xffu;
+		r |= b << (8 * k);
+	}
+	return r;
+#endif
+}
+#define K2A_TSEL_BASE 0x0c040c00u           /* row selector = { tA, 0x0c, 4 + tB, 0x0c }: byte tA of cpA -> low half, byte tB of cpB -> high half */
 K2A_FN uint32_t k2a_h16(int v) { return (uint32_t)(v + K2A_OFS16) & 0xffffu; }                 /* one half in offset form */
 K2A_FN k2a_pk k2a_pku(int v) { return k2a_pk2(v + K2A_OFS16); }                                 /* constant in offset form */
 /* both halves at once with one 32-bit op: exact as long as the low half neither carries nor borrows (offset form,
@@ -79,18 +110,6 @@ K2A_FN k2a_pk k2a_pk_max3u(k2a_pk a, k2a_pk b, k2a_pk c)   /* per half max of th
 {
 	k2a_pk d;
 	asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-	return d;
-}
-K2A_FN k2a_pk k2a_or_xor(k2a_pk a, k2a_pk b, k2a_pk c)     /* a | (b ^ c) */
-{
-	k2a_pk d;
-	asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xf6" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-	return d;
-}
-K2A_FN k2a_pk k2a_pk_minu(k2a_pk a, k2a_pk b)
-{
-	k2a_pk d;      /* asm keeps this arithmetic: hipcc would turn min(x,1)*k back into compare + select per half */
-	asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
 	return d;
 }
 K2A_FN k2a_pk k2a_pk_mad(k2a_pk a, k2a_pk b, k2a_pk c)
@@ -162,12 +181,6 @@ K2A_FN k2a_pk k2a_pk_max3u(k2a_pk a, k2a_pk b, k2a_pk c)
 	}
 	return r;
 }
-K2A_FN k2a_pk k2a_or_xor(k2a_pk a, k2a_pk b, k2a_pk c) { return a | (b ^ c); }
-K2A_FN k2a_pk k2a_pk_minu(k2a_pk a, k2a_pk b)
-{
-	const uint32_t al = a & 0xffffu, ah = a >> 16, bl = b & 0xffffu, bh = b >> 16;
-	return (al < bl ? al : bl) | ((ah < bh ? ah : bh) << 16);
-}
 K2A_FN k2a_pk k2a_pk_mad(k2a_pk a, k2a_pk b, k2a_pk c) { return k2a_pk_mk(k2a_pk_lo(a) * k2a_pk_lo(b) + k2a_pk_lo(c), k2a_pk_hi(a) * k2a_pk_hi(b) + k2a_pk_hi(c)); }
 K2A_FN k2a_pk k2a_pk_sign(k2a_pk a) { return ((a & 0x8000u) ? 0xffffu : 0u) | ((a & 0x80000000u) ? 0xffff0000u : 0u); }
 K2A_FN k2a_pk k2a_pk_selv(k2a_pk m, k2a_pk a, k2a_pk b) { return k2a_pk_sel(m, a, b); }
@@ -195,11 +208,11 @@ K2A_FN k2a_pk k2a_ofs_off(k2a_pk ofs) { return k2a_pk_sub(ofs, K2A_OFS); }
  * exposed and the register form is faster, so both are built and the launcher picks by the number of tasks. */
 #define K2A_PK_LDSROWS(G, C, DUAL, MODE, NOMAX) ((G) == 64 && (C) == 16 && (DUAL) && (MODE) != K2A_MODE_SCORE && !(NOMAX))
 #define K2A_PK_LDSROW_WORDS(C) (3 * (C) * 64)        /* per wavefront */
-/* Codes only (LDSROW_ = 2): the exact score-only kernels hold 178-224 registers, two wavefronts per SIMD; with the two code
- * planes (2 x C registers) in LDS the 16-row geometry fits four, the (8, 18) geometry of short reads three.  Nothing else
- * changes: the planes are read-only between strip starts, two LDS loads per row and step. */
+/* Codes only (LDSROW_ = 2): the exact score-only kernels held 178-224 registers, two wavefronts per SIMD, with the rows' target
+ * codes in registers; with them (round 5: ONE selector per row) in LDS the 16-row geometry fits four, the (8, 18) geometry of
+ * short reads three.  Nothing else changes: the selectors are read-only between strip starts, one LDS load per row and step. */
 #define K2A_PK_LDSCODES(G, C, DUAL, MODE, NOMAX) ((((G) == 64 && (C) == 16) || ((G) == 8 && (C) == 18) || ((G) == 16 && (C) == 8)) && !(DUAL) && (MODE) == K2A_MODE_SCORE)
-#define K2A_PK_LDSCODE_WORDS(C) (2 * (C) * 64)       /* per wavefront */
+#define K2A_PK_LDSCODE_WORDS(C) ((C) * 64)           /* per wavefront */
 
 /* DEFER (exact score-only kernels): the fill tracks every row's maximum but not its column -- three of the fifteen instructions
  * of a row pair, 11 of 51 cycles.  Columns are needed for max_q (the row that holds the alignment's maximum), for mte_q (the last
@@ -207,7 +220,9 @@ K2A_FN k2a_pk k2a_ofs_off(k2a_pk ofs) { return k2a_pk_sub(ofs, K2A_OFS); }
  * above ({H, E} of its top neighbour, 8 bytes per lane and step, 512 contiguous bytes per wavefront and step) into a checkpoint
  * block, a second small kernel (k2a_argmax_kernel) re-runs exactly the one or two strips per alignment whose columns are asked for --
  * same lane code, arg-max on, inputs from the checkpoint --, and an alignment in which a Z-drop cannot be ruled out without the
- * skew term (max - H > zdrop somewhere) is reported as "inexact" and run again by the host through the ordinary kernels. */
+ * skew term (max - H > zdrop somewhere) has its book frozen at that row; a third kernel (k2a_zscan_kernel, round 5) re-runs the
+ * strips from there on, sixteen at a time, and folds their rows into the book with the reference's exact test until the drop or
+ * the last row.  (Rounds 3-4 reported such an alignment as "inexact" and the host ran it again through the ordinary kernels.) */
 struct K2aCkHead { int32_t baseA, baseB; uint32_t hd0, pad; };          /* per strip: what do_init derived from the neighbour lane */
 #define K2A_CK_STEP_BYTES 512                                            /* 64 lanes x { hin, ein } */
 
@@ -228,20 +243,21 @@ struct K2aLanePk {
 	int baseA, baseB;                   /* RB: absolute (row-biased) score that the strip's packed values are relative to */
 	k2a_pk delta;                       /* RB: base of the strip above minus this strip's base, added to incoming ports */
 	uint32_t qb;                        /* { query code A, query code B } of this step's column */
+	const uint32_t *cptab;              /* the column profiles (K2aScoring.cp), in LDS on the device */
+	uint32_t cpA, cpB;                  /* cp[query code] of this step's column for alignment A / B: penalties against target codes 0..3 */
+	/* the step's query codes and their column profiles.  The kernels call it for step k + 1 right behind step k (the table
+	 * look-ups are then a step old when the first row needs them), and again behind a do_init that changed the lane's codes */
+	K2A_FN void set_qb(uint32_t q) { qb = q; cpA = cptab[q & 7u]; cpB = cptab[(q >> 16) & 7u]; }
 	/* rows */
-	/* target codes as bit planes x D: one register more per row, so only where the kernel keeps its occupancy */
-	enum { PLANES = (MODE == K2A_MODE_SCORE && (!DUAL || C <= 16)) || C <= 8 };
-	enum { LDSROW = LDSROW_ == 1,       /* row maxima, arg-max columns and target codes in LDS */
-	       LDSTC = LDSROW_ != 0 };      /* 2: only the target codes (both planes) */
+	enum { LDSROW = LDSROW_ == 1,       /* row maxima, arg-max columns and target selectors in LDS */
+	       LDSTC = LDSROW_ != 0 };      /* 2: only the target selectors */
 	k2a_pk hl[C], f[C], f2[DUAL ? C : 1], rmax_[(NOMAX || LDSROW) ? 1 : C], rmj_[(NOMAX || LDSROW || DEFER) ? 1 : C];       /* hl, f, f2, rmax and the ports above: offset form */
-	k2a_pk tc_[LDSTC ? 1 : C], tc1_[(PLANES && !LDSTC) ? C : 1];   /* target codes {A, B}; PLANES: bit 0 / bit 1 of the codes, times D */
-	uint32_t *lrow;                                              /* LDSROW: this lane's column of the wavefront's [3][C][64] block; codes only: [2][C][64] */
-	enum { TCROW = LDSROW ? 2 : 0, TC1ROW = LDSROW ? 3 : 1 };
+	k2a_pk tc_[LDSTC ? 1 : C];                                   /* per row: the v_perm_b32 selector of the rows' target codes {A, B} (K2A_TSEL_BASE) */
+	uint32_t *lrow;                                              /* LDSROW: this lane's column of the wavefront's [3][C][64] block; selectors only: [C][64] */
+	enum { TCROW = LDSROW ? 2 : 0 };
 	K2A_FN k2a_pk rmax(int c) const { return LDSROW ? lrow[(0 * C + c) * 64] : rmax_[(NOMAX || LDSROW) ? 0 : c]; }
 	K2A_FN k2a_pk rmj(int c) const { return DEFER ? 0u : LDSROW ? lrow[(1 * C + c) * 64] : rmj_[(NOMAX || LDSROW) ? 0 : c]; }
 	K2A_FN k2a_pk tc(int c) const { return LDSTC ? lrow[(TCROW * C + c) * 64] : tc_[LDSTC ? 0 : c]; }
-	K2A_FN k2a_pk tc1(int c) const { return LDSTC ? lrow[(TC1ROW * C + c) * 64] : tc1_[(PLANES && !LDSTC) ? c : 0]; }
-	K2A_FN void set_tc1(int c, k2a_pk v) { if (LDSTC) lrow[(TC1ROW * C + c) * 64] = v; else tc1_[(PLANES && !LDSTC) ? c : 0] = v; }
 	K2A_FN void set_rmax(int c, k2a_pk v) { if (LDSROW) lrow[(0 * C + c) * 64] = v; else rmax_[(NOMAX || LDSROW) ? 0 : c] = v; }
 	K2A_FN void set_rmj(int c, k2a_pk v) { if (DEFER) return; if (LDSROW) lrow[(1 * C + c) * 64] = v; else rmj_[(NOMAX || LDSROW) ? 0 : c] = v; }
 	K2A_FN void set_tc(int c, k2a_pk v) { if (LDSTC) lrow[(TCROW * C + c) * 64] = v; else tc_[LDSTC ? 0 : c] = v; }
@@ -254,8 +270,9 @@ struct K2aLanePk {
 		knext = Snext < nstrips ? koff_next + first_col(Snext, w) : K2A_KNONE;
 	}
 
-	K2A_FN void setup(const K2aPair &pr, const K2aPair &prB, const uint8_t *seq, int lane_in_group, bool valid)
+	K2A_FN void setup(const K2aPair &pr, const K2aPair &prB, const uint8_t *seq, int lane_in_group, bool valid, const uint32_t *cptab_)
 	{
+		cptab = cptab_; cpA = cpB = 0;
 		qlen = pr.qlen; tlen = pr.tlen; tlen_full = pr.tlen_full; w = pr.w;
 		qa = seq + pr.qoff; ta = seq + pr.toff; qbp = seq + prB.qoff; tbq = seq + prB.toff;
 		nstrips = valid ? (tlen + C - 1) / C : 0;
@@ -268,12 +285,11 @@ struct K2aLanePk {
 		baseA = baseB = 0; delta = 0;
 		local_reset();
 #pragma unroll
-		for (int c = 0; c < C; ++c) { hl[c] = f[c] = neg; set_tc(c, 0); if (!NOMAX) { set_rmax(c, neg); set_rmj(c, 0); } if (PLANES) set_tc1(c, 0); if (DUAL) f2[c] = neg; }
+		for (int c = 0; c < C; ++c) { hl[c] = f[c] = neg; set_tc(c, K2A_TSEL_BASE); if (!NOMAX) { set_rmax(c, neg); set_rmj(c, 0); } if (DUAL) f2[c] = neg; }
 		if (NOMAX || LDSROW) rmax_[0] = neg;
 		if (NOMAX || LDSROW || DEFER) rmj_[0] = 0;
 		if (LDSTC) tc_[0] = 0;
 		if (!DUAL) f2[0] = 0;
-		if (!PLANES || LDSTC) tc1_[0] = 0;
 	}
 
 	K2A_FN int last_step() const { return nstrips > 0 ? (nstrips - 1) + k2a_min(qlen - 1, tlen - 1 + w) : -1; }
@@ -292,11 +308,10 @@ struct K2aLanePk {
 		wup = w + (S == 0 ? 1 : 0);                        /* the virtual row -1 reaches one column further (E(0,w) exists) */
 		const int js = k2a_max(0, i0 - w);
 		const k2a_pk neg = k2a_pku(K2A_NEG16);
-		const uint32_t dmis = (uint32_t)(sc.pk_a - sc.pk_b);                 /* D */
 		/* target codes of the strip's rows, four rows per (unaligned) dword load and alignment; the arena is padded past the last
-		 * row.  Not prefetched: one L2 round trip per strip is noise next to the strip's ~2w+C steps.  The bit planes of four rows
-		 * are formed together (one byte per row: D <= 255), a v_perm_b32 per row and plane then pairs alignment A's byte with
-		 * alignment B's -- this code runs with one lane per group active, every 17-19 steps: it was 11 % of the kernel. */
+		 * row.  Not prefetched: one L2 round trip per strip is noise next to the strip's ~2w+C steps.  Per row one v_perm_b32 pairs
+		 * alignment A's code with alignment B's and one add turns the pair into the row's selector -- this code runs with one lane
+		 * per group active, every 17-19 steps: it was 11 % of the kernel when it went byte by byte. */
 		const uint8_t *tpa = ta + (size_t)S * C, *tpb = tbq + (size_t)S * C;
 #pragma unroll
 		for (int c4 = 0; c4 < C; c4 += 4) {
@@ -304,15 +319,8 @@ struct K2aLanePk {
 			__builtin_memcpy(&da, tpa + c4, 4); __builtin_memcpy(&db, tpb + c4, 4);
 			if (c4 + 4 <= C) note_codes(da, db);                /* (C = 18: the last two rows' dword reaches into the next strip, which reports them itself) */
 			else note_codes(da & 0xffffu, db & 0xffffu);
-			if (PLANES) {
-				const uint32_t a0 = (da & 0x01010101u) * dmis, a1 = ((da >> 1) & 0x01010101u) * dmis;
-				const uint32_t b0 = (db & 0x01010101u) * dmis, b1 = ((db >> 1) & 0x01010101u) * dmis;
 #pragma unroll
-				for (int r = 0; r < 4 && c4 + r < C; ++r) { set_tc(c4 + r, k2a_byte_pair(a0, b0, r)); set_tc1(c4 + r, k2a_byte_pair(a1, b1, r)); }
-			} else {
-#pragma unroll
-				for (int r = 0; r < 4 && c4 + r < C; ++r) set_tc(c4 + r, k2a_byte_pair(da, db, r));
-			}
+			for (int r = 0; r < 4 && c4 + r < C; ++r) set_tc(c4 + r, k2a_byte_pair(da, db, r) + K2A_TSEL_BASE);
 		}
 #pragma unroll
 		for (int c = 0; c < C; ++c) {
@@ -368,7 +376,7 @@ struct K2aLanePk {
 		const int dd = k - kd;                                 /* jj - i0 */
 		const k2a_pk neg = k2a_pku(K2A_NEG16);
 		const k2a_pk gq = k2a_pk2(sc.q), ge = k2a_pk2(sc.e), gq2 = k2a_pk2(sc.q2), ge2 = k2a_pk2(sc.e2), de2 = k2a_pk2(sc.e2 - sc.e);
-		const k2a_pk mat_a = k2a_pk2(sc.pk_a + sc.e), mat_bma = k2a_pk2(sc.pk_b - sc.pk_a);     /* score + row-bias step */
+		const k2a_pk bias = k2a_pk2(sc.pk_smax + sc.e);        /* largest score + row-bias step; the rows subtract their penalties from it */
 		k2a_pk e = ein, e2 = e2in;
 		if (dd >= wup) { e = neg; e2 = neg; }                  /* the cell above is outside the band */
 		/* live rows lo..hi of this strip at this column (none while the lane owns no strip: rows_m1 = -1) */
@@ -376,14 +384,11 @@ struct K2aLanePk {
 		const int hi = k2a_min(rows_m1, dd + w);
 		const int cnt = k2a_max(hi - lo + 1, 0);
 		const uint32_t live = ((1u << cnt) - 1u) << (lo & 31);       /* lo >= 32 only with cnt = 0 */
-		const k2a_pk qcode = qb;
 		const k2a_pk jjpk = k2a_pk2(k - koff);
 		/* rows in chunks of CH: phase 1 of a chunk (its diagonal candidates, from the old H row) right before its phase 2, so only
 		 * CH candidates are alive at a time instead of C (16-18 registers: what keeps these kernels a wavefront short).  The one
 		 * old H a chunk needs from the chunk above -- the row just above its first row -- is saved before that row is rewritten. */
 		constexpr int CH = (C % 6 == 0) ? 6 : (C % 4 == 0) ? 4 : C;
-		const uint32_t dmis = (uint32_t)(sc.pk_a - sc.pk_b);
-		const k2a_pk q0 = (qcode & 0x00010001u) * dmis, q1 = ((qcode >> 1) & 0x00010001u) * dmis;   /* PLANES: query bit planes x D */
 		k2a_pk dprev = 0, above_old = hd0;
 #pragma unroll
 		for (int c0 = 0; c0 < C; c0 += CH) {
@@ -393,12 +398,8 @@ struct K2aLanePk {
 			for (int r = 0; r < CH; ++r) {
 				const int c = c0 + r;
 				const k2a_pk up = r == 0 ? above_old : hl[c - 1];
-				if (PLANES)        /* mismatch ? D : 0 from the bit planes: (t0 ^ q0) | (t1 ^ q1), everything pre-multiplied with D */
-					cand[r] = k2a_sub32(k2a_add32(up, mat_a), k2a_or_xor(tc(c) ^ q0, tc1(c), q1));
-				else {             /* score: a on equal codes, b otherwise (no wildcards in this class) */
-					const k2a_pk ne01 = k2a_pk_minu(tc(c) ^ qcode, 0x00010001u);
-					cand[r] = k2a_pk_add(up, k2a_pk_mad(ne01, mat_bma, mat_a));
-				}
+				/* H(i-1,j-1) + s(i,j) + e: the row's penalty bytes { smax - s(tA, qA), 0, smax - s(tB, qB), 0 } out of the column profiles */
+				cand[r] = k2a_sub32(k2a_add32(up, bias), k2a_perm(cpB, cpA, tc(c)));
 			}
 			above_old = last_old;
 			if (CH < C) K2A_SCHED_FENCE();
@@ -491,11 +492,12 @@ struct K2aLanePk {
 	 * below that group's last step.  A strip that starts inside a group re-loads the group under its own column offset
 	 * (reload_query_group from the init branch, which does wait).  Bytes of columns outside the query are garbage that only dead cells see (the arena is padded). */
 	uint32_t qwA, qwB;
-	/* OR of every code dword this lane fetched (k2a_fill_pk_kernel).  The packed kernels score match / mismatch only, so the host
-	 * keeps pairs with a wildcard code (>= 4) out of them -- by scanning the sequences while it copies them.  A flat batch
-	 * (ksw2amd_plan_create_flat) is uploaded as it lies in the caller's arena, unscanned: the kernel then reports "a code >= 4
-	 * was among the bytes I read" (K2aResult.pad[0]) and the host re-runs that pair through the int32 kernels.  Bytes that
-	 * belong to a neighbouring sequence can only cause a needless re-run. */
+	/* OR of every TARGET code dword this lane fetched (k2a_fill_pk_kernel).  A row's profile has four bytes, target codes 0..3, so
+	 * the host keeps pairs whose target holds a wildcard code (>= 4) out of the packed kernels -- by scanning the sequences while it
+	 * copies them.  A flat batch (ksw2amd_plan_create_flat) is uploaded as it lies in the caller's arena, unscanned: the kernel
+	 * then reports "a code >= 4 was among the target bytes I read" (K2aResult.pad[0]) and the host re-runs that pair through the
+	 * int32 kernels.  Bytes that belong to a neighbouring sequence can only cause a needless re-run.  (Query codes are table
+	 * indices, 0..4 by the caller's contract `codes < m`; nothing to report.) */
 	uint32_t seen;
 	K2A_FN void load_query_group(int kg, int koff_use, uint32_t &a, uint32_t &b)            /* the wait comes with the first use of a / b */
 	{
@@ -510,7 +512,6 @@ struct K2aLanePk {
 		const int sh = 8 * k2a_min(k2a_max(-j, 0), 3);
 		uint32_t va, vb;
 		load_query_group(k & ~3, koff, va, vb);
-		note_codes(va, vb);
 		qwA = va << sh; qwB = vb << sh;
 	}
 	K2A_FN static uint32_t query_pick(uint32_t a, uint32_t b, int kk)      /* { code A, code B } of step kg + kk */
@@ -558,7 +559,8 @@ struct K2aLanePk {
 					if (H > bmax) { bmax = H; bmax_t = i; bmax_q = j; }
 					else if (DEFER) {
 						/* without the row's arg-max column neither "j >= max_q" nor the skew can be evaluated: a drop is impossible
-						 * while max - H <= zdrop, otherwise the alignment is handed back as inexact (and stops here) */
+						 * while max - H <= zdrop; otherwise the book is FROZEN here (dropped = 1, inexact = 1, rows = this row + 1) and
+						 * the third pass (k2a_zscan_kernel) takes the rows from this one on, with their columns */
 						if (zdrop >= 0 && bmax - H > zdrop) { bdrop = 1; b->inexact = 1; }
 					} else if (i >= bmax_t && j >= bmax_q) {
 						const int dt = i - bmax_t, dq = j - bmax_q;
@@ -668,6 +670,39 @@ struct K2aLanePk {
 		end_strip();
 	}
 };
+
+/* The rows of ONE finished strip folded into the book of ONE alignment (half = 0 / 1) of a single-gap task: the exact branch of
+ * K2aLanePk::do_fin_seq -- the scalar reference's per-row epilogue (ksw2_extz.c:116-124, ksw2.h:191-207) -- on rows another lane
+ * staged (stage_rows).  k2a_zscan_kernel folds the strips it re-ran with it, in row order. */
+template<int C>
+K2A_FN void k2a_fin_rows_half(const K2aScoring &sc, K2aBook *b, int zdrop, const uint32_t *rowbuf, int half, bool rb, int qlen, int tlen, int tlen_full, int w)
+{
+	const int i0 = (int)rowbuf[3 * C], base = rb ? (int)rowbuf[3 * C + 1 + half] : 0, sh = half ? 16 : 0;
+	int bmax = b->max, bmax_t = b->max_t, bmax_q = b->max_q, bmqe = b->mqe, bmqe_t = b->mqe_t;
+	int bmte = b->mte, bmte_q = b->mte_q, bscore = b->score, bdrop = b->dropped, brows = b->rows;
+#pragma nounroll
+	for (int c = 0; c < C; ++c) {
+		const int i = i0 + c;
+		if (i < tlen && !bdrop) {
+			const bool reach = i + w >= qlen - 1;
+			const int unb = base - sc.e * i;                                                        /* plus base, minus row bias */
+			const int hend = (int)(int16_t)(rowbuf[c] >> sh) + unb, H = (int)(int16_t)(rowbuf[C + c] >> sh) + unb;
+			const int j = (int)(uint16_t)(rowbuf[2 * C + c] >> sh);
+			if (reach && hend > bmqe) { bmqe = hend; bmqe_t = i; }
+			if (i == tlen_full - 1) { bmte = H; bmte_q = j; }
+			if (H > bmax) { bmax = H; bmax_t = i; bmax_q = j; }
+			else if (i >= bmax_t && j >= bmax_q) {
+				const int dt = i - bmax_t, dq = j - bmax_q;
+				const int skew = dt > dq ? dt - dq : dq - dt;
+				if (zdrop >= 0 && bmax - H > zdrop + skew * sc.e) bdrop = 1;
+			}
+			if (!bdrop && i == tlen_full - 1 && reach) bscore = hend;
+			brows = i + 1;
+		}
+	}
+	b->max = bmax; b->max_t = bmax_t; b->max_q = bmax_q; b->mqe = bmqe; b->mqe_t = bmqe_t;
+	b->mte = bmte; b->mte_q = bmte_q; b->score = bscore; b->dropped = bdrop; b->rows = brows;
+}
 
 /* Traceback walk for one alignment (half = 0/1) of a packed task: direction bytes in the reference layout at byte
  * 2c + half of the (step, lane) word (K2aWalk layout 2). */

@@ -55,9 +55,9 @@ struct K2aLanePkMp {
 	Pk P;
 	unsigned long long *spill;          /* this lane's C x 2 keys: spill[c * 2 + half] (per-wavefront block, lane-major) */
 
-	K2A_FN void setup(const K2aPair &prA, const K2aPair &prB, const uint8_t *seq, int lane, bool valid, unsigned long long *spill_wave)
+	K2A_FN void setup(const K2aPair &prA, const K2aPair &prB, const uint8_t *seq, int lane, bool valid, unsigned long long *spill_wave, const uint32_t *cptab)
 	{
-		P.setup(prA, prB, seq, lane, valid);
+		P.setup(prA, prB, seq, lane, valid, cptab);
 		P.Snext = 0; P.knext = K2A_KNONE;
 		spill = spill_wave + (size_t)lane * (C * 2);
 	}

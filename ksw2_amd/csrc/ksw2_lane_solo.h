@@ -47,10 +47,12 @@ struct K2aLaneSolo {
 	uint32_t qb, qw;                        /* { query code at column jj, at column jj-1 }; the dword of the current four steps */
 	uint32_t tnA[(C + 3) / 4], tnB[(C + 3) / 4], qn0;   /* prefetched for the NEXT double strip: its target codes, its first query dword */
 	int qn_sh;
-	uint32_t seen;                          /* OR of every code dword this lane used (K2aLanePk::seen: a flat plan's unscanned bytes; code >= 4 = wildcard -> the host re-runs the pair) */
+	const uint32_t *cptab;                  /* column profiles (K2aLanePk): cpA = cp[code at column jj] for the low half, cpB = what the low half had one step ago */
+	uint32_t cpA, cpB;
+	uint32_t seen;                          /* OR of every TARGET code dword this lane used (K2aLanePk::seen: a flat plan's unscanned bytes; code >= 4 = wildcard -> the host re-runs the pair) */
 	K2A_FN void note_codes(uint32_t a) { seen |= a; }
 	K2A_FN bool saw_wildcard() const { return (seen & 0xfcfcfcfcu) != 0; }
-	k2a_pk hl[C], f[C], f2[DUAL ? C : 1], rmax[C], rmj[C], tc[C], tc1[C], hsave[C];
+	k2a_pk hl[C], f[C], f2[DUAL ? C : 1], rmax[C], rmj[C], tc[C], hsave[C];      /* tc: per row the v_perm_b32 selector { t(row c), 0x0c, 4 + t(row C + c), 0x0c } */
 
 	K2A_FN static int first_col(int D_, int w_) { return k2a_max(0, D_ * 2 * C - w_); }
 	K2A_FN void schedule_next()
@@ -78,8 +80,9 @@ struct K2aLaneSolo {
 		}
 	}
 
-	K2A_FN void setup(const K2aPair &pr, const uint8_t *seq, int lane, bool valid)
+	K2A_FN void setup(const K2aPair &pr, const uint8_t *seq, int lane, bool valid, const uint32_t *cptab_)
 	{
+		cptab = cptab_; cpA = cpB = 0;
 		qlen = pr.qlen; tlen = pr.tlen; tlen_full = pr.tlen_full; w = pr.w;
 		qa = seq + pr.qoff; ta = seq + pr.toff;
 		nds = valid ? (tlen + 2 * C - 1) / (2 * C) : 0;
@@ -94,7 +97,7 @@ struct K2aLaneSolo {
 		const k2a_pk neg = k2a_pku(K2A_NEG16);
 		hout = eout = e2out = hd0 = hu_prev = neg; qb = 0; qw = 0; baseA = baseB = 0; delta = 0;
 #pragma unroll
-		for (int c = 0; c < C; ++c) { hl[c] = f[c] = rmax[c] = hsave[c] = neg; rmj[c] = 0; tc[c] = tc1[c] = 0; if (DUAL) f2[c] = neg; }
+		for (int c = 0; c < C; ++c) { hl[c] = f[c] = rmax[c] = hsave[c] = neg; rmj[c] = 0; tc[c] = K2A_TSEL_BASE; if (DUAL) f2[c] = neg; }
 		if (!DUAL) f2[0] = 0;
 	}
 
@@ -125,18 +128,14 @@ struct K2aLaneSolo {
 		wupA = w + (D == 0 ? 1 : 0);
 		const int js = k2a_max(0, i0 - w);
 		const k2a_pk neg = k2a_pku(K2A_NEG16);
-		const uint32_t dmis = (uint32_t)(sc.pk_a - sc.pk_b);
-		/* target codes of the 2C rows as bit planes x D (ksw2_lane_pk.h), low half = rows i0.., high half = rows i0+C..: four
-		 * rows of both halves per pair of dwords, a plane of a row is one and + one multiply on both halves at once */
+		/* target codes of the 2C rows as selectors into the step's column profiles (ksw2_lane_pk.h), low half = rows i0.., high
+		 * half = rows i0+C..: four rows of both halves per pair of dwords */
 #pragma unroll
 		for (int c4 = 0; c4 < C; c4 += 4) {
 			const uint32_t da = tnA[c4 / 4], db = tnB[c4 / 4];             /* prefetch_next(), one strip ago */
 			note_codes(da | db);                                           /* (rows past the target's end read the arena's next bytes: at worst a needless re-run) */
 #pragma unroll
-			for (int r = 0; r < 4; ++r) {
-				const k2a_pk cc = k2a_byte_pair(da, db, r);
-				tc[c4 + r] = (cc & 0x00010001u) * dmis; tc1[c4 + r] = ((cc >> 1) & 0x00010001u) * dmis;
-			}
+			for (int r = 0; r < 4; ++r) tc[c4 + r] = k2a_byte_pair(da, db, r) + K2A_TSEL_BASE;
 		}
 #pragma unroll
 		for (int c = 0; c < C; ++c) { hl[c] = neg; f[c] = neg; if (DUAL) f2[c] = neg; rmax[c] = neg; rmj[c] = 0; }
@@ -163,7 +162,6 @@ struct K2aLaneSolo {
 		 * row one step later: start_high() gives it its own base just before its first step. */
 		hd0 = k2a_pair16(k2a_h16(0), neg >> 16);
 		qw = qn0 << qn_sh;                                      /* this strip's first group of query codes */
-		note_codes(qn0);
 		Dnext += G;
 		schedule_next();
 		prefetch_next();
@@ -218,7 +216,7 @@ struct K2aLaneSolo {
 		const int ddA = k - kd, ddB = ddA - C - 1;
 		const k2a_pk neg = k2a_pku(K2A_NEG16);
 		const k2a_pk gq = k2a_pk2(sc.q), ge = k2a_pk2(sc.e), gq2 = k2a_pk2(sc.q2), ge2 = k2a_pk2(sc.e2), de2 = k2a_pk2(sc.e2 - sc.e);
-		const k2a_pk mat_a = k2a_pk2(sc.pk_a + sc.e);
+		const k2a_pk bias = k2a_pk2(sc.pk_smax + sc.e);        /* largest score + row-bias step; the rows subtract their penalties from it */
 		/* the cell above is outside the band: per half */
 		const k2a_pk cut = k2a_pair16(ddA >= wupA ? 0xffffu : 0u, ddB >= w ? 0xffffu : 0u);
 		k2a_pk e = k2a_pk_sel(cut, neg, ein), e2 = DUAL ? k2a_pk_sel(cut, neg, e2in) : 0u;
@@ -230,10 +228,7 @@ struct K2aLaneSolo {
 		/* row c of the low half at bit c, of the high half at bit 16 + c: ONE 32-bit shift by 15 - c puts both at their halves'
 		 * sign bits (what the low half's higher rows spill into the high half stays below bit 31) */
 		const uint32_t lv = liveA | (liveB << 16);
-		const k2a_pk qcode = qb;
 		const k2a_pk jjpk = k2a_pair16((uint32_t)(k - koff) & 0xffffu, (uint32_t)(k - koff - 1) & 0xffffu);
-		const uint32_t dmis = (uint32_t)(sc.pk_a - sc.pk_b);
-		const k2a_pk q0 = (qcode & 0x00010001u) * dmis, q1 = ((qcode >> 1) & 0x00010001u) * dmis;
 		/* score only: all rows' candidates at once -- these tasks run at one or two wavefronts per SIMD, where the longer
 		 * independent stretch is worth more than the registers (1 024 x 10 k x 10 k: 6.74 ms against 7.07 ms) */
 		constexpr int CH = (MODE != K2A_MODE_SCORE && C % 4 == 0) ? 4 : C;
@@ -245,7 +240,7 @@ struct K2aLaneSolo {
 #pragma unroll
 			for (int r = 0; r < CH; ++r) {
 				const int c = c0 + r;
-				cand[r] = k2a_sub32(k2a_add32(r == 0 ? above_old : hl[c - 1], mat_a), k2a_or_xor(tc[c] ^ q0, tc1[c], q1));
+				cand[r] = k2a_sub32(k2a_add32(r == 0 ? above_old : hl[c - 1], bias), k2a_perm(cpB, cpA, tc[c]));
 			}
 			above_old = last_old;
 			if (CH < C) K2A_SCHED_FENCE();
@@ -319,7 +314,8 @@ struct K2aLaneSolo {
 		const int jc = k2a_min(k2a_max(kg - koff_use, 0), qlen - 1);
 		a = k2a_load_early(qa + jc);
 	}
-	/* the codes of step kg + kk: the low half's from the group, the high half's = what the low half had one step ago */
+	/* the codes of step kg + kk: the low half's from the group, the high half's = what the low half had one step ago -- and the
+	 * same for their column profiles: ONE table look-up per step */
 	K2A_FN void advance_query(int kk)
 	{
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -327,6 +323,7 @@ struct K2aLaneSolo {
 #else
 		qb = ((qw >> (8 * kk)) & 0xffu) | ((qb & 0xffu) << 16);
 #endif
+		cpB = cpA; cpA = cptab[qb & 7u];
 	}
 
 	/* the low half is done C+1 steps before the high half and keeps stepping over dead cells: keep its last-column H */

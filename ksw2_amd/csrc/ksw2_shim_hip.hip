@@ -244,6 +244,17 @@ __device__ __forceinline__ bool k2a_queue_wait(K2aQueueDesc *qd, int wt)
 	return true;
 }
 
+/* The column profiles of the packed kernels (K2aScoring.cp, ksw2_lane_pk.h) in LDS, one copy per wavefront: wavefronts of these
+ * kernels never synchronise with each other (and wavefronts of a streamed launch may leave before others start). */
+__device__ __forceinline__ void k2a_cptab_fill(const K2aScoring &sc, uint32_t *tab, int lane)
+{
+	uint32_t v = sc.cp[0];
+#pragma unroll
+	for (int x = 1; x < 8; ++x) v = lane == x ? sc.cp[x] : v;
+	if (lane < 8) tab[lane] = v;
+	__builtin_amdgcn_wave_barrier();
+}
+
 /* Packed-int16 resident fill: two same-shape alignments per lane group (ksw2_lane_pk.h). */
 template<int G, int C, bool DUAL, int MODE, bool RB, bool NOMAX, int LDSROW = 0, bool DEFER = false, bool QUEUE = false>      /* LDSROW: 1 = row state in LDS, 2 = only the target-code planes; DEFER: K2aLanePk; QUEUE: streamed launches */
 __global__ void __launch_bounds__(64 * K2A_WPB, LDSROW == 2 ? (G == 16 ? 4 : 3) : LDSROW ? 2 : 1)      /* no floor elsewhere: capping the register form of the score-only kernels at 168 VGPRs spills and is 18 % slower */
@@ -260,6 +271,10 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	/* one wavefront-task (NG tasks) per wavefront, by position in the grid; the QUEUE builds (streamed launches) first wait for the
 	 * task's inputs (k2a_queue_wait) */
 	const int wt = blockIdx.x * K2A_WPB + wave;
+	if (DEFER && blockIdx.x == 0 && threadIdx.x == 0) {      /* the list of frozen books (k2a_argmax_kernel fills it, k2a_zscan_kernel works it off): empty */
+		uint32_t *zlist = (uint32_t*)(tb + pairs[order2[0]].tb_off) - K2A_ZLIST_WORDS(ntasks);
+		__hip_atomic_store(&zlist[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
 	if (QUEUE && !k2a_queue_wait(qd, wt)) return;
 	{
 	const int task = wt * NG + grp;
@@ -272,9 +287,11 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 
 	constexpr int LROW_WORDS = LDSROW == 1 ? K2A_PK_LDSROW_WORDS(C) : LDSROW == 2 ? K2A_PK_LDSCODE_WORDS(C) : 0;
 	__shared__ uint32_t lrows[LDSROW ? K2A_WPB * LROW_WORDS : 1];   /* per-row maxima / arg-max / target codes of the LDSROW classes */
+	__shared__ uint32_t cptab[K2A_WPB][8];
+	k2a_cptab_fill(sc, cptab[wave], lane);
 	Lane L;
 	L.lrow = &lrows[LDSROW ? wave * LROW_WORDS + lane : 0];
-	L.setup(prA, prB, seq, gl, valid);
+	L.setup(prA, prB, seq, gl, valid, cptab[wave]);
 	K2aBook *bkA = &book[wave][grp][0], *bkB = &book[wave][grp][1];
 	if (gl == 0) { k2a_book_reset(bkA); k2a_book_reset(bkB); }
 	__builtin_amdgcn_wave_barrier();
@@ -293,7 +310,6 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	bool gdone = !valid;
 	/* query codes: one unaligned dword per alignment and four steps (K2aLanePk::load_query_group) */
 	L.load_query_group(0, L.knext == 0 ? L.koff_next : L.koff, L.qwA, L.qwB);
-	L.note_codes(L.qwA, L.qwB);
 	const size_t tbsteps = (size_t)(klast + 1);
 	uint8_t *tbp = tb + prA.tb_off;
 	constexpr int WB = Lane::TBWORDS * 4;
@@ -337,7 +353,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 		}
 		L.hu_prev = hin;
 		if (RB) { hin = k2a_pk_add(hin, L.delta); ein = k2a_pk_add(ein, L.delta); if (DUAL) e2in = k2a_pk_add(e2in, L.delta); }
-		L.qb = Lane::query_pick(L.qwA, L.qwB, k & 3);
+		L.set_qb(Lane::query_pick(L.qwA, L.qwB, k & 3));      /* the codes and their column profiles (one LDS look-up per alignment) */
 		if (k <= ktop) L.top_inputs(sc, k, hin, ein, e2in);
 
 		if (ckon) ckst[(size_t)k * 64] = make_uint2(hin, ein);      /* 512 contiguous bytes per wavefront and step */
@@ -365,7 +381,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 				if (__builtin_amdgcn_ballot_w64(slow) != 0) {
 					if (slow) { L.stage_rows(rowbuf); L.do_fin_seq(sc, bkA, bkB, zdropA, zdropB, rowbuf); }
 					__builtin_amdgcn_wave_barrier();
-					if (bkA->dropped && bkB->dropped) gdone = true;
+					if (!DEFER && bkA->dropped && bkB->dropped) gdone = true;      /* (DEFER: "dropped" there = book frozen; the third pass needs the checkpoints of the strips that follow) */
 				}
 			} else {
 				/* at most one strip per group ends at a step; all lanes of that group share its rows */
@@ -379,7 +395,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 		}
 		if (zseq && __builtin_amdgcn_ballot_w64(!(gdone || k >= klast)) == 0) { stop = true; break; }   /* only a Z-drop ends a group early */
 	}
-	L.qwA = qpa; L.qwB = qpb; L.note_codes(qpa, qpb);
+	L.qwA = qpa; L.qwB = qpb;
 	}
 	if (STAGED) ST.finish(kdone);
 	__builtin_amdgcn_wave_barrier();
@@ -418,11 +434,13 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 /* Second pass of the deferred arg-max (K2aLanePk, DEFER): three jobs per task -- the strip that holds alignment A's maximum,
  * the one that holds B's, and the strip of the last target row (mte_q of both) -- one job per LANE: every lane re-runs its strip
  * with the ordinary exact lane code (arg-max on), its top inputs read back from the checkpoint stream, its bases from the strip's
- * header, and writes the one or two columns that were asked for.  No lane talks to another. */
+ * header, and writes the one or two columns that were asked for.  No lane talks to another.  An alignment whose book the fill froze
+ * (K2aResult.pad[1]: a Z-drop could not be ruled out without columns) is entered in the class's list for the third pass
+ * (k2a_zscan_kernel); its max_q is found here like everybody's. */
 template<int G, int C, bool RB>
 __global__ void __launch_bounds__(64 * K2A_WPB)
 k2a_argmax_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
-                  const uint8_t *__restrict__ seq, const uint8_t *__restrict__ ck, K2aResult *__restrict__ res, const K2aQueueDesc *qd)
+                  const uint8_t *__restrict__ seq, uint8_t *__restrict__ ck, K2aResult *__restrict__ res, const K2aQueueDesc *qd)
 {
 	constexpr int NG = 64 / G;
 	/* behind a streamed fill that was abandoned (k2a_queue_wait: abort raised, or wavefront-tasks that never started): the result
@@ -434,20 +452,23 @@ k2a_argmax_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const 
 	const int job = blockIdx.x * (64 * K2A_WPB) + threadIdx.x;
 	const int task = job / 3, which = job - 3 * task;
 	bool go = task < ntasks;
+	const bool live = go;
 	const uint32_t piA = order2[go ? 2 * task : 0], piB = order2[go ? 2 * task + 1 : 0];
 	const K2aPair prA = pairs[piA], prB = pairs[piB];
 	const bool inexA = res[piA].pad[1] != 0, inexB = res[piB].pad[1] != 0;
 	int row = -1;
 	if (go) {
-		if (which == 0) row = inexA ? -1 : res[piA].max_t;
-		else if (which == 1) row = (piB == piA || inexB) ? -1 : res[piB].max_t;
+		if (which == 0) row = res[piA].max_t;
+		else if (which == 1) row = piB == piA ? -1 : res[piB].max_t;
 		else row = (prA.tlen == prA.tlen_full && !(inexA && inexB)) ? prA.tlen_full - 1 : -1;
 	}
 	go = go && row >= 0;
 	const int S = go ? row / C : 0, grp = task % NG;
+	__shared__ uint32_t cptab[K2A_WPB][8];
+	k2a_cptab_fill(sc, cptab[threadIdx.x >> 6], (int)(threadIdx.x & 63));
 	Lane L;
 	L.lrow = 0;
-	L.setup(prA, prB, seq, S % G, go);
+	L.setup(prA, prB, seq, S % G, go, cptab[threadIdx.x >> 6]);
 	L.Snext = S;
 	L.schedule_next();
 	const int kbeg = L.knext;
@@ -460,7 +481,7 @@ k2a_argmax_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const 
 			const int k = kbeg + t;
 			const uint2 in = st[(size_t)k * 64];
 			const int jc = min(max(k - L.koff, 0), L.qlen - 1);
-			L.qb = k2a_pair16(L.qa[jc], L.qbp[jc]);
+			L.set_qb(k2a_pair16(L.qa[jc], L.qbp[jc]));
 			uint32_t tw[Lane::TBWORDS];
 			L.step(sc, k, in.x, in.y, 0u, tw);
 		}
@@ -476,6 +497,103 @@ k2a_argmax_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const 
 			if (!inexA) res[piA].mte_q = (int)(v & 0xffffu);
 			if (piB != piA && !inexB) res[piB].mte_q = (int)(v >> 16);
 		}
+	}
+	/* frozen books: into the list of the third pass, { task, half } (the list lies in front of the class's first checkpoint block;
+	 * the fill kernel zeroed its counter) */
+	if (live && ((which == 0 && inexA) || (which == 1 && inexB && piB != piA))) {
+		uint32_t *zlist = (uint32_t*)(ck + pairs[order2[0]].tb_off) - K2A_ZLIST_WORDS(ntasks);
+		const uint32_t at = __hip_atomic_fetch_add(&zlist[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		zlist[1 + at] = (uint32_t)task * 2u + (uint32_t)which;
+	}
+}
+
+/* Third pass of the deferred arg-max: the alignments whose book the fill froze at a row where a Z-drop could not be ruled out
+ * without the arg-max columns (max - H > zdrop there; no earlier row came that far).  The reference's test (ksw2.h:191-207) also
+ * wants j >= max_q and adds |dt - dq| * e to the threshold, and on reads whose tail diverges the best cell of a row wanders off the
+ * diagonal of the maximum: the drop comes tens to hundreds of rows AFTER the first row that is zdrop below the maximum (round 5,
+ * measured on the simulator: of 44 frozen alignments none dropped at that first row).  So the fill no longer stops such an
+ * alignment's wavefront, its checkpoints run on to the last strip, and here a group of 16 lanes takes one frozen alignment: the
+ * lanes re-run 16 consecutive strips at once from the frozen row's strip on -- every strip is independent given its checkpoints --
+ * with the exact lane code, stage their rows in LDS, and the group's first lane folds them into the book in row order with the
+ * reference's own per-row logic (k2a_fin_rows_half = K2aLanePk::do_fin_seq's exact branch): 256 rows per round, until the drop or
+ * the last row.  Then the record is rewritten from the book like any fill's (k2a_finish).  Nothing is handed back to the host any
+ * more (rounds 3-4: every frozen alignment was run again from the start by the ordinary kernels behind the batch -- 10 k reads of
+ * which a fifth drops ran at 0.75 of the rate of reads that do not). */
+template<int G, int C, bool RB>
+__global__ void __launch_bounds__(64 * K2A_WPB)
+k2a_zscan_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
+                 const uint8_t *__restrict__ seq, const uint8_t *__restrict__ ck, K2aResult *__restrict__ res, const K2aQueueDesc *qd)
+{
+	constexpr int NG = 64 / G, ZG = 16, ZNG = 64 / ZG;
+	if (qd && (__hip_atomic_load(&qd->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+	           __hip_atomic_load(&qd->next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != qd->nwt)) return;
+	typedef K2aLanePk<G, C, false, K2A_MODE_SCORE, RB, false, 0, false> Lane;
+	__shared__ uint32_t stage[K2A_WPB][64][K2A_PK_STAGE(C)];
+	__shared__ K2aBook book[K2A_WPB][ZNG];
+	__shared__ int done[K2A_WPB][ZNG];
+	__shared__ uint32_t cptab[K2A_WPB][8];
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int zg = lane / ZG, zl = lane % ZG;
+	const uint32_t *zlist = (const uint32_t*)(ck + pairs[order2[0]].tb_off) - K2A_ZLIST_WORDS(ntasks);
+	const int count = (int)zlist[0];
+	const int gi = (blockIdx.x * K2A_WPB + wave) * ZNG + zg;
+	const bool active = gi < count;
+	if (__builtin_amdgcn_ballot_w64(active) == 0) return;
+	k2a_cptab_fill(sc, cptab[wave], lane);
+	const uint32_t ent = zlist[1 + (active ? gi : 0)];
+	const int task = (int)(ent >> 1), half = (int)(ent & 1u);
+	const uint32_t piA = order2[2 * task], piB = order2[2 * task + 1], pi = half ? piB : piA;
+	const K2aPair prA = pairs[piA], prB = pairs[piB], pr = half ? prB : prA;
+	const int grp = task % NG, nstrips = (prA.tlen + C - 1) / C;
+	K2aBook *bk = &book[wave][zg];
+	const K2aResult r0 = res[pi];
+	if (zl == 0) {
+		K2aBook b;
+		b.max = r0.max; b.max_t = r0.max_t; b.max_q = r0.max_q; b.mqe = r0.mqe; b.mqe_t = r0.mqe_t; b.mte = r0.mte; b.mte_q = r0.mte_q;
+		b.score = r0.score; b.dropped = 0; b.rows = r0.rows_done; b.inexact = 0;
+		*bk = b;
+		done[wave][zg] = active ? 0 : 1;
+	}
+	__builtin_amdgcn_wave_barrier();
+	const int S1 = active ? max(r0.rows_done - 1, 0) / C : 0;            /* the strip of the row the fill froze the book at */
+	const uint8_t *blk = ck + prA.tb_off;
+	for (int round = 0; ; ++round) {
+		const bool open = done[wave][zg] == 0;
+		const int S = S1 + round * ZG + zl;
+		const bool go = open && S < nstrips;
+		Lane L;
+		L.lrow = 0;
+		L.setup(prA, prB, seq, S % G, go, cptab[wave]);
+		L.Snext = go ? S : 0;
+		L.schedule_next();
+		const int kbeg = L.knext;
+		if (go) L.do_init(sc, 0, 0, (const K2aCkHead*)(blk + (size_t)prA.bnd_off * K2A_CK_STEP_BYTES) + (size_t)grp * prA.cig_off + S);
+		const int n = go ? L.kfin - kbeg + 1 : 0;
+		const uint2 *st = (const uint2*)blk + (grp * G + S % G);
+		for (int t = 0; __builtin_amdgcn_ballot_w64(t < n) != 0; ++t) {
+			if (t < n) {
+				const int k = kbeg + t;
+				const uint2 in = st[(size_t)k * 64];
+				const int jc = min(max(k - L.koff, 0), L.qlen - 1);
+				L.set_qb(k2a_pair16(L.qa[jc], L.qbp[jc]));
+				uint32_t tw[Lane::TBWORDS];
+				L.step(sc, k, in.x, in.y, 0u, tw);
+			}
+		}
+		if (go) L.stage_rows(stage[wave][lane]);
+		__builtin_amdgcn_wave_barrier();
+		if (open && zl == 0) {
+			int l = 0;
+			for (; l < ZG && S1 + round * ZG + l < nstrips && !bk->dropped; ++l)
+				k2a_fin_rows_half<C>(sc, bk, pr.zdrop, stage[wave][zg * ZG + l], half, RB, pr.qlen, pr.tlen, pr.tlen_full, pr.w);
+			if (bk->dropped || S1 + (round + 1) * ZG >= nstrips) {
+				const K2aBook b = *bk;
+				k2a_finish(pr, b, &res[pi]);                                  /* (pad[1] = 0: settled) */
+				done[wave][zg] = 1;
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+		if (__builtin_amdgcn_ballot_w64(done[wave][zg] == 0) == 0) break;
 	}
 }
 
@@ -497,8 +615,10 @@ k2a_fill_solo_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 	const uint32_t pi = order[valid ? task : 0];
 	const K2aPair pr = pairs[pi];
 
+	__shared__ uint32_t cptab[K2A_WPB][8];
+	k2a_cptab_fill(sc, cptab[wave], lane);
 	Lane L;
-	L.setup(pr, seq, lane, valid);
+	L.setup(pr, seq, lane, valid, cptab[wave]);
 	K2aBook *bk = &book[wave];
 	if (lane == 0) k2a_book_reset(bk);
 	__builtin_amdgcn_wave_barrier();
@@ -509,7 +629,6 @@ k2a_fill_solo_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 	uint8_t *tbp = tb + pr.tb_off;
 	/* query codes: one unaligned dword per four steps (K2aLaneSolo::load_query_group) */
 	L.load_query_group(0, L.knext == 0 ? L.koff_next : L.koff, L.qw);
-	L.note_codes(L.qw);
 	/* traceback words as whole cache lines (K2aTbStage, see the packed kernels): config 5's unique read shapes run here */
 	constexpr int WB = Lane::TBWORDS * 4;
 	constexpr bool STAGED = MODE != K2A_MODE_SCORE && (WB == 16 || WB == 32);
@@ -572,7 +691,7 @@ k2a_fill_solo_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 			}
 		}
 	}
-	L.qw = qp; L.note_codes(qp);
+	L.qw = qp;
 	}
 	if (STAGED) ST.finish(kdone);
 	__builtin_amdgcn_wave_barrier();
@@ -830,9 +949,11 @@ k2a_fill_pkmp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 	const int qlen = prA.qlen, tlen = prA.tlen, w = prA.w;
 	const int ngen = (tlen + R - 1) / R;
 
+	__shared__ uint32_t cptab[W][8];
+	k2a_cptab_fill(sc, cptab[wave], lane);
 	Lane L;
 	/* the task's block of `bnd`: boundary entries, then one block of row-maximum keys per wavefront */
-	L.setup(prA, prB, seq, lane, true, (unsigned long long*)(bnd + prA.bnd_off + K2A_PKMP_BND_WORDS(qlen, DUAL)) + (size_t)wave * (K2A_PKMP_SPILL_WORDS(C) / 2));
+	L.setup(prA, prB, seq, lane, true, (unsigned long long*)(bnd + prA.bnd_off + K2A_PKMP_BND_WORDS(qlen, DUAL)) + (size_t)wave * (K2A_PKMP_SPILL_WORDS(C) / 2), cptab[wave]);
 	K2aBook *bkA = &book[0], *bkB = &book[1];
 	if (threadIdx.x == 0) {
 		k2a_book_reset(bkA); k2a_book_reset(bkB);
@@ -908,7 +1029,7 @@ k2a_fill_pkmp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 					fetch_raw(jlo, cur, cur2);
 					fetch_raw(jlo + 1, nxt, nxt2);
 				}
-				L.P.qb = L.P.next_query_codes(-1);
+				L.P.set_qb(L.P.next_query_codes(-1));
 				kdone = -1;
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   /* the cleared keys are in place before any atomic on them */
 			}
@@ -953,7 +1074,7 @@ k2a_fill_pkmp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 					if (nfin) L.do_fin(sc, bkA, bkB, zdropA, zdropB, rowbuf[wave]);
 					__builtin_amdgcn_wave_barrier();
 				}
-				L.P.qb = qnext;
+				L.P.set_qb(qnext);                                       /* next step's codes and column profiles */
 				if ((k & (T - 1)) == T - 1) {
 					const k2a_pk d = L.rebase();
 					const k2a_pk da = (k2a_pk)k2a_rot1<G>((int)d);
@@ -1603,9 +1724,12 @@ static const fill_pk_fn g_fill_pkq_ldscodes[3][2][2] = { LDSCODEQ_SET(64, 16), L
 static const fill_pk_fn g_fill_pk_defer[4][2] = { DEFER_ROW(8, 18, 0), DEFER_ROW(16, 8, 2), DEFER_ROW(64, 8, 0), DEFER_ROW(64, 16, 2) };
 #define DEFERQ_ROW(G, C, LR) { k2a_fill_pk_kernel<G, C, false, 0, false, false, LR, true, true>, k2a_fill_pk_kernel<G, C, false, 0, true, false, LR, true, true> }
 static const fill_pk_fn g_fill_pkq_defer[4][2] = { DEFERQ_ROW(8, 18, 0), DEFERQ_ROW(16, 8, 2), DEFERQ_ROW(64, 8, 0), DEFERQ_ROW(64, 16, 2) };
-typedef void (*argmax_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, const uint8_t*, K2aResult*, const K2aQueueDesc*);
+typedef void (*argmax_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*, const K2aQueueDesc*);
 #define ARGMAX_ROW(G, C) { k2a_argmax_kernel<G, C, false>, k2a_argmax_kernel<G, C, true> }
 static const argmax_fn g_argmax[4][2] = { ARGMAX_ROW(8, 18), ARGMAX_ROW(16, 8), ARGMAX_ROW(64, 8), ARGMAX_ROW(64, 16) };
+typedef void (*zscan_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, const uint8_t*, K2aResult*, const K2aQueueDesc*);
+#define ZSCAN_ROW(G, C) { k2a_zscan_kernel<G, C, false>, k2a_zscan_kernel<G, C, true> }
+static const zscan_fn g_zscan[4][2] = { ZSCAN_ROW(8, 18), ZSCAN_ROW(16, 8), ZSCAN_ROW(64, 8), ZSCAN_ROW(64, 16) };
 
 /* Launch-time kernel forms.  Every choice the launcher makes has a forcing switch (k2a_shim_set_option: -1 automatic, 0 / 1
  * forced; the host maps KSW2AMD_LDSCODES / KSW2AMD_LDSROWS onto it) and is reported by k2a_shim_pk_form / k2a_shim_mp_form, so
@@ -1798,6 +1922,11 @@ int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax,
 		hipLaunchKernelGGL(fn, dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream, *sc, pairs, order2, ntasks, seq, tb, res, qd);
 		CHECK(hipGetLastError());
 		hipLaunchKernelGGL(g_argmax[cfg][rebased ? 1 : 0], dim3((3 * ntasks + 64 * K2A_WPB - 1) / (64 * K2A_WPB)), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
+		                   *sc, pairs, order2, ntasks, seq, tb, res, (const K2aQueueDesc*)qd);
+		CHECK(hipGetLastError());
+		/* third pass: one group of 16 lanes per frozen book; the grid covers every alignment of the class, wavefronts beyond the
+		 * list's length leave at once (the list is filled by the kernel in front: its length is not known here) */
+		hipLaunchKernelGGL(g_zscan[cfg][rebased ? 1 : 0], dim3((2 * ntasks + 4 * K2A_WPB - 1) / (4 * K2A_WPB)), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
 		                   *sc, pairs, order2, ntasks, seq, (const uint8_t*)tb, res, (const K2aQueueDesc*)qd);
 		CHECK(hipGetLastError());
 		return 0;

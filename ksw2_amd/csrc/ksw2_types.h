@@ -54,7 +54,11 @@ typedef struct K2aScoring {
 	int32_t q, e, q2, e2;        /* gap open / extend; (q2,e2) only for the two-piece model, q+e <= q2+e2 */
 	uint32_t prof[5];            /* prof[t] = bytes { s(t,0), s(t,1), s(t,2), s(t,3) } for target code t   */
 	int32_t colw[5];             /* colw[t] = s(t, 4): score against the query wildcard (code 4)          */
-	int32_t pk_a, pk_b, pk_n;    /* match / mismatch / wildcard score when the matrix has that structure   */
+	/* packed-int16 kernels (ksw2_lane_pk.h, "column profiles"): any matrix over codes 0..3 x 0..4 as penalties below its largest
+	 * entry.  cp[q] = bytes { smax - s(0,q), smax - s(1,q), smax - s(2,q), smax - s(3,q) } for query code q (4 = the query's
+	 * wildcard; 5..7 unused, zero); the diagonal candidate is H + (pk_smax + e) - byte t of cp[q]: one v_perm_b32 per row. */
+	uint32_t cp[8];
+	int32_t pk_smax;
 	int32_t m;                   /* residue types; m > 5: scores come from `mat` (staged in LDS), prof/colw unused */
 	const int8_t *mat;           /* device copy of the effective m x m matrix, mat[target*m + query]       */
 } K2aScoring;
@@ -115,7 +119,7 @@ typedef struct K2aPair {
 typedef struct K2aResult {
 	int32_t max, zdropped, max_q, max_t, mqe, mqe_t, mte, mte_q, score, reach_end, n_cigar, rows_done;
 	int32_t ti, tj;                  /* traceback start cell chosen by k2a_finish(); -1 = no CIGAR          */
-	int32_t pad[2];                  /* [0]: a packed kernel read a wildcard code (unscanned flat plans), [1]: inexact (deferred arg-max): the host re-runs the pair */
+	int32_t pad[2];                  /* [0]: a packed kernel read a wildcard code in a target (unscanned plans); [1]: deferred arg-max -- 1 = the fill stopped at a row whose Z-drop test needs columns and the second pass could not settle it: the host re-runs the pair; 2 = the second pass settled the drop */
 } K2aResult;
 
 /* Streamed launches (ksw2_host_plan.c, "streamed plans"): ONE launch of a packed fill kernel over the whole batch, started under the
@@ -138,6 +142,10 @@ typedef struct K2aQueueDesc {
 	uint64_t timeout_ticks;
 	uint64_t pad2[3];
 } K2aQueueDesc;                       /* 64 bytes */
+
+/* deferred arg-max classes: the list of alignments whose book the fill froze (k2a_argmax_kernel -> k2a_zscan_kernel), uint32
+ * { count, entries (task * 2 + half) ... }, lies in the traceback arena right in front of the class's first checkpoint block */
+#define K2A_ZLIST_WORDS(ntasks) ((2 * (size_t)(ntasks) + 16 + 63) & ~(size_t)63)
 
 /* per-group bookkeeping state (LDS on the GPU): the scalar reference's ez fields while rows complete */
 typedef struct K2aBook {

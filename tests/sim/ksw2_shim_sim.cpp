@@ -135,13 +135,12 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 			prA[lane] = pairs[piA[lane]];
 			zdA[lane] = prA[lane].zdrop; zdB[lane] = pairs[piB[lane]].zdrop;
 			L[lane].lrow = lrows + lane;
-			L[lane].setup(prA[lane], pairs[piB[lane]], seq, gl, valid[lane]);
+			L[lane].setup(prA[lane], pairs[piB[lane]], seq, gl, valid[lane], sc.cp);
 			if (gl == 0) { k2a_book_reset(&book[grp][0]); k2a_book_reset(&book[grp][1]); }
 			klast[lane] = L[lane].last_step();
 			if (klast[lane] > kmax) kmax = klast[lane];
 			gdone[lane] = !valid[lane];
 			L[lane].load_query_group(0, L[lane].knext == 0 ? L[lane].koff_next : L[lane].koff, L[lane].qwA, L[lane].qwB);
-			L[lane].note_codes(L[lane].qwA, L[lane].qwB);
 			zseq |= valid[lane] && (zdA[lane] >= 0 || zdB[lane] >= 0);
 			if (valid[lane]) {
 				const int kt = k2a_min(prA[lane].qlen - 1, k2a_min(C - 1, prA[lane].tlen - 1) + prA[lane].w);
@@ -176,7 +175,7 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 					if (DUAL) e2in[lane] = k2a_pk_add(e2in[lane], L[lane].delta);
 				}
 				if ((k & 3) == 0) L[lane].load_query_group(k + 4, L[lane].knext <= k + 4 ? L[lane].koff_next : L[lane].koff, qpa[lane], qpb[lane]);
-				L[lane].qb = Lane::query_pick(L[lane].qwA, L[lane].qwB, k & 3);
+				L[lane].set_qb(Lane::query_pick(L[lane].qwA, L[lane].qwB, k & 3));
 				if (k <= ktop) L[lane].top_inputs(sc, k, hin[lane], ein[lane], e2in[lane]);
 			}
 			for (int lane = 0; lane < 64; ++lane) {
@@ -211,11 +210,11 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 					}
 				if (zseq)
 					for (int lane = 0; lane < 64; ++lane)
-						if (book[lane / G][0].dropped && book[lane / G][1].dropped) gdone[lane] = true;
+						if (!DEFER && book[lane / G][0].dropped && book[lane / G][1].dropped) gdone[lane] = true;
 			}
 			bool all_done = true;
 			for (int lane = 0; lane < 64; ++lane) {
-				if ((k & 3) == 3) { L[lane].qwA = qpa[lane]; L[lane].qwB = qpb[lane]; L[lane].note_codes(qpa[lane], qpb[lane]); }
+				if ((k & 3) == 3) { L[lane].qwA = qpa[lane]; L[lane].qwB = qpb[lane]; }
 				if (!(gdone[lane] || k >= klast[lane])) all_done = false;
 			}
 			if (zseq && all_done) break;
@@ -252,26 +251,29 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 	}
 }
 
-/* mirrors k2a_argmax_kernel: one job per (task, which), every job an independent lane */
+/* mirrors k2a_argmax_kernel: one job per (task, which), every job an independent lane; frozen books go into the class's list */
 template<int G, int C, bool RB>
-static void sim_argmax(const K2aScoring sc, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *seq, const uint8_t *ck, K2aResult *res)
+static void sim_argmax(const K2aScoring sc, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *seq, uint8_t *ck, K2aResult *res)
 {
 	constexpr int NG = 64 / G;
 	typedef K2aLanePk<G, C, false, K2A_MODE_SCORE, RB, false, 0, false> Lane;
+	uint32_t *zlist = (uint32_t*)(ck + pairs[order2[0]].tb_off) - K2A_ZLIST_WORDS(ntasks);
+	zlist[0] = 0;                                         /* (the device's fill kernel does this) */
 	for (int job = 0; job < 3 * ntasks; ++job) {
 		const int task = job / 3, which = job % 3;
 		const uint32_t piA = order2[2 * task], piB = order2[2 * task + 1];
 		const K2aPair prA = pairs[piA], prB = pairs[piB];
 		const bool inexA = res[piA].pad[1] != 0, inexB = res[piB].pad[1] != 0;
+		if ((which == 0 && inexA) || (which == 1 && inexB && piB != piA)) zlist[1 + zlist[0]++] = (uint32_t)task * 2u + (uint32_t)which;
 		int row;
-		if (which == 0) row = inexA ? -1 : res[piA].max_t;
-		else if (which == 1) row = (piB == piA || inexB) ? -1 : res[piB].max_t;
+		if (which == 0) row = res[piA].max_t;
+		else if (which == 1) row = piB == piA ? -1 : res[piB].max_t;
 		else row = (prA.tlen == prA.tlen_full && !(inexA && inexB)) ? prA.tlen_full - 1 : -1;
 		if (row < 0) continue;
 		const int S = row / C, grp = task % NG;
 		static thread_local Lane L;
 		L.lrow = 0;
-		L.setup(prA, prB, seq, S % G, true);
+		L.setup(prA, prB, seq, S % G, true, sc.cp);
 		L.Snext = S;
 		L.schedule_next();
 		const int kbeg = L.knext;
@@ -281,7 +283,7 @@ static void sim_argmax(const K2aScoring sc, const K2aPair *pairs, const uint32_t
 		for (int k = kbeg; k <= L.kfin; ++k) {
 			const size_t at = 2 * ((size_t)k * 64 + grp * G + S % G);
 			const int jc = k2a_min(k2a_max(k - L.koff, 0), L.qlen - 1);
-			L.qb = k2a_pair16(L.qa[jc], L.qbp[jc]);
+			L.set_qb(k2a_pair16(L.qa[jc], L.qbp[jc]));
 			uint32_t tw[Lane::TBWORDS];
 			L.step(sc, k, st[at], st[at + 1], 0u, tw);
 		}
@@ -291,6 +293,54 @@ static void sim_argmax(const K2aScoring sc, const K2aPair *pairs, const uint32_t
 		else {
 			if (!inexA) res[piA].mte_q = (int)(v & 0xffffu);
 			if (piB != piA && !inexB) res[piB].mte_q = (int)(v >> 16);
+		}
+	}
+}
+
+/* mirrors k2a_zscan_kernel: per frozen book, rounds of 16 strips re-run with the exact lane code and folded into the book in row order */
+template<int G, int C, bool RB>
+static void sim_zscan(const K2aScoring sc, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *seq, const uint8_t *ck, K2aResult *res)
+{
+	constexpr int NG = 64 / G, ZG = 16;
+	typedef K2aLanePk<G, C, false, K2A_MODE_SCORE, RB, false, 0, false> Lane;
+	const uint32_t *zlist = (const uint32_t*)(ck + pairs[order2[0]].tb_off) - K2A_ZLIST_WORDS(ntasks);
+	for (uint32_t gi = 0; gi < zlist[0]; ++gi) {
+		const uint32_t ent = zlist[1 + gi];
+		const int task = (int)(ent >> 1), half = (int)(ent & 1u);
+		const uint32_t piA = order2[2 * task], piB = order2[2 * task + 1], pi = half ? piB : piA;
+		const K2aPair prA = pairs[piA], prB = pairs[piB], pr = half ? prB : prA;
+		const int grp = task % NG, nstrips = (prA.tlen + C - 1) / C;
+		const K2aResult r0 = res[pi];
+		K2aBook b;
+		b.max = r0.max; b.max_t = r0.max_t; b.max_q = r0.max_q; b.mqe = r0.mqe; b.mqe_t = r0.mqe_t; b.mte = r0.mte; b.mte_q = r0.mte_q;
+		b.score = r0.score; b.dropped = 0; b.rows = r0.rows_done; b.inexact = 0;
+		const int S1 = k2a_max(r0.rows_done - 1, 0) / C;
+		const uint8_t *blk = ck + prA.tb_off;
+		for (int round = 0; ; ++round) {
+			static thread_local uint32_t stage[ZG][K2A_PK_STAGE(C)];
+			for (int zl = 0; zl < ZG; ++zl) {
+				const int S = S1 + round * ZG + zl;
+				if (S >= nstrips) continue;
+				static thread_local Lane L;
+				L.lrow = 0;
+				L.setup(prA, prB, seq, S % G, true, sc.cp);
+				L.Snext = S;
+				L.schedule_next();
+				const int kbeg = L.knext;
+				L.do_init(sc, 0, 0, (const K2aCkHead*)(blk + (size_t)prA.bnd_off * K2A_CK_STEP_BYTES) + (size_t)grp * prA.cig_off + S);
+				const uint32_t *st = (const uint32_t*)blk;
+				for (int k = kbeg; k <= L.kfin; ++k) {
+					const size_t at = 2 * ((size_t)k * 64 + grp * G + S % G);
+					const int jc = k2a_min(k2a_max(k - L.koff, 0), L.qlen - 1);
+					L.set_qb(k2a_pair16(L.qa[jc], L.qbp[jc]));
+					uint32_t tw[Lane::TBWORDS];
+					L.step(sc, k, st[at], st[at + 1], 0u, tw);
+				}
+				L.stage_rows(stage[zl]);
+			}
+			for (int l = 0; l < ZG && S1 + round * ZG + l < nstrips && !b.dropped; ++l)
+				k2a_fin_rows_half<C>(sc, &b, pr.zdrop, stage[l], half, RB, pr.qlen, pr.tlen, pr.tlen_full, pr.w);
+			if (b.dropped || S1 + (round + 1) * ZG >= nstrips) { k2a_finish(pr, b, &res[pi]); break; }
 		}
 	}
 }
@@ -720,7 +770,7 @@ static void sim_fill_pkmp(const K2aScoring sc, const K2aPair *pairs, const uint3
 			/* (a wavefront's lane state does not survive begin_generation / do_init -- bases are re-derived at every init -- so
 			 * setting the lanes up afresh for every generation is equivalent to the device's wavefront g mod 4 carrying on) */
 			for (int l = 0; l < 64; ++l) {
-				L[l].setup(prA, prB, seq, l, true, spill + (size_t)wave * (K2A_PKMP_SPILL_WORDS(C) / 2));
+				L[l].setup(prA, prB, seq, l, true, spill + (size_t)wave * (K2A_PKMP_SPILL_WORDS(C) / 2), sc.cp);
 				L[l].begin_generation(g, jlo); L[l].clear_spill();
 			}
 			int bs0A = 0, bs0B = 0;
@@ -729,7 +779,7 @@ static void sim_fill_pkmp(const K2aScoring sc, const K2aPair *pairs, const uint3
 				if (j <= je_prev) { for (int x = 0; x < 4; ++x) v[x] = B1[4 * (size_t)j + x]; if (DUAL) v2 = B2[j]; }
 			};
 			if (g > 0 && jlo > 0) { uint32_t pv[4], pv2; fetch(jlo - 1, pv, pv2); L[0].P.hu_prev = pv[0]; bs0A = (int)pv[2]; bs0B = (int)pv[3]; }
-			for (int l = 0; l < 64; ++l) L[l].P.qb = L[l].P.next_query_codes(-1);
+			for (int l = 0; l < 64; ++l) L[l].P.set_qb(L[l].P.next_query_codes(-1));
 			for (int k = 0; k < nsteps && !stop; ++k) {
 				k2a_pk hin[64], ein[64], e2in[64];
 				uint32_t qnext[64];
@@ -773,7 +823,7 @@ static void sim_fill_pkmp(const K2aScoring sc, const K2aPair *pairs, const uint3
 					for (int l = 0; l < 64; ++l) if (nfin[l]) { L[l].flush_rowmax(); L[l].do_fin(sc, &bkA, &bkB, prA.zdrop, prB.zdrop, rowbuf); }
 					if (bkA.dropped && bkB.dropped) stop = true;
 				}
-				for (int l = 0; l < 64; ++l) L[l].P.qb = qnext[l];
+				for (int l = 0; l < 64; ++l) L[l].P.set_qb(qnext[l]);
 				if ((k & (T - 1)) == T - 1) {
 					k2a_pk d[64];
 					for (int l = 0; l < 64; ++l) d[l] = L[l].rebase();
@@ -802,13 +852,13 @@ static void sim_fill_solo(const K2aScoring sc, const K2aPair *pairs, const uint3
 		K2aBook book;
 		uint32_t rowbuf[K2A_SOLO_STAGE(C)];
 		k2a_book_reset(&book);
-		for (int l = 0; l < 64; ++l) { L[l].setup(pr, seq, l, true); }
+		for (int l = 0; l < 64; ++l) { L[l].setup(pr, seq, l, true, sc.cp); }
 		const int klast = L[0].last_step();
 		const int ktop = k2a_min(pr.qlen - 1, k2a_min(C - 1, pr.tlen - 1) + pr.w);
 		const size_t tbsteps = k2a_solo_steps<C>(pr.qlen, pr.tlen, pr.w);
 		uint8_t *tbp = tb + pr.tb_off;
 		uint32_t qp[64];
-		for (int l = 0; l < 64; ++l) { qp[l] = 0; L[l].load_query_group(0, L[l].knext == 0 ? L[l].koff_next : L[l].koff, L[l].qw); L[l].note_codes(L[l].qw); }
+		for (int l = 0; l < 64; ++l) { qp[l] = 0; L[l].load_query_group(0, L[l].knext == 0 ? L[l].koff_next : L[l].koff, L[l].qw); }
 		bool done = false;
 		for (int k = 0; k <= klast && !done; ++k) {
 			k2a_pk rh[64], re[64], re2[64];
@@ -839,7 +889,7 @@ static void sim_fill_solo(const K2aScoring sc, const K2aPair *pairs, const uint3
 				if (!L[l].fin_fast(sc, &book, pr.zdrop)) { L[l].stage_rows(rowbuf); L[l].do_fin_seq(sc, &book, pr.zdrop, rowbuf); }
 				if (book.dropped) done = true;
 			}
-			if ((k & 3) == 3) for (int l = 0; l < 64; ++l) { L[l].qw = qp[l]; L[l].note_codes(qp[l]); }
+			if ((k & 3) == 3) for (int l = 0; l < 64; ++l) { L[l].qw = qp[l]; }
 		}
 		k2a_finish(pr, book, &res[pi]);
 		bool saw = false;
@@ -1011,16 +1061,21 @@ int k2a_shim_launch_fill(int cfg, int dual, int mode, const K2aScoring *sc, cons
 }
 #define DEFER_ROW(G, C, LR) { sim_fill_pk<G, C, false, 0, false, false, LR, true>, sim_fill_pk<G, C, false, 0, true, false, LR, true> }
 static const fill_pk_fn g_fill_pk_defer[4][2] = { DEFER_ROW(8, 18, 0), DEFER_ROW(16, 8, 2), DEFER_ROW(64, 8, 0), DEFER_ROW(64, 16, 2) };
-typedef void (*argmax_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, const uint8_t*, K2aResult*);
+typedef void (*argmax_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*);
 #define ARGMAX_ROW(G, C) { sim_argmax<G, C, false>, sim_argmax<G, C, true> }
 static const argmax_fn g_argmax[4][2] = { ARGMAX_ROW(8, 18), ARGMAX_ROW(16, 8), ARGMAX_ROW(64, 8), ARGMAX_ROW(64, 16) };
+typedef void (*zscan_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, const uint8_t*, K2aResult*);
+#define ZSCAN_ROW(G, C) { sim_zscan<G, C, false>, sim_zscan<G, C, true> }
+static const zscan_fn g_zscan[4][2] = { ZSCAN_ROW(8, 18), ZSCAN_ROW(16, 8), ZSCAN_ROW(64, 8), ZSCAN_ROW(64, 16) };
 
 int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax, int defer, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2,
                             int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, K2aQueueDesc *qd, void *)
 {
 	if (defer && ntasks > 0) {
 		g_fill_pk_defer[cfg][rebased ? 1 : 0](*sc, pairs, order2, ntasks, seq, tb, res, qd);
+		if (qd && (qd->abort || qd->next != qd->nwt)) return 0;      /* the device's second and third pass leave at once behind an abandoned streamed fill */
 		g_argmax[cfg][rebased ? 1 : 0](*sc, pairs, order2, ntasks, seq, tb, res);
+		g_zscan[cfg][rebased ? 1 : 0](*sc, pairs, order2, ntasks, seq, tb, res);
 		return 0;
 	}
 	const int form = k2a_shim_pk_form(cfg, dual, mode, nomax, ntasks);

@@ -1,6 +1,7 @@
 """GPU: the HIP path through the C-ABI (libksw2_amd.so) against the oracle and the golden vectors. Bit-exact."""
 import ctypes
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -1057,6 +1058,35 @@ def test_linear_xdrop_one_extension_per_lane(lib, monkeypatch):
     res = lib.extf_batch(list(q), list(t), 2, -4, 2, w=20, xdrop=40)          # 200 000 extensions, 21 positions in the band: the lane form by itself
     for i in range(0, 200000, 1999):
         assert not diff(res[i], po.extf2("oracle", q[i], t[i], 2, -4, 2, 20, 40), gu.FIELDS), i
+
+
+def test_packed_kernels_on_generic_matrices(lib, monkeypatch):
+    """KSW_EZ_GENERIC_SC through the packed kernels (round 5, column profiles: ksw2_lane_pk.h; the reference takes any matrix at its
+    full rate, ksw2_extz2_sse.c:142-143): transition / transversion, asymmetric random, all-different 5 x 5 matrices and alphabets of
+    four and three codes through the resident geometries (plain, re-based), the solo kernel, the generation-serial class and, forced,
+    the deferred arg-max; score-only and both traceback modes, both gap models, Z-drops, wildcards in the query -- every field and
+    CIGAR against the oracle, and the plan's description asserts that no pair left the packed kernels for its matrix."""
+    from tests.test_sim_parity import _check_generic_packed
+    monkeypatch.setenv("KSW2AMD_SIMDS", "0")                    # (small test batches: keep the occupancy rules from demoting them)
+    _check_generic_packed(lib)
+    monkeypatch.setenv("KSW2AMD_DEFER", "1")
+    assert "pk-defer" in _check_generic_packed(lib)
+
+
+def test_lane_primitives_match_their_simulator_twins(tmp_path):
+    """tools/probe/lane_ops_probe.hip: every register primitive of the packed kernels (inline asm / builtins: v_perm_b32 with every
+    selector byte value, v_bitop3_b32 0xe4, v_pk_mad_i16, v_pk_maximum3_f16, v_pk_ashrrev_i16 ...) on the device against the C twin the
+    lock-step simulator runs, 4 M operand triples each, bit for bit.  The CPU test tier stands on those twins."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    twin, obj, exe = str(tmp_path / "twin.o"), str(tmp_path / "probe.o"), str(tmp_path / "probe")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-c", "-o", twin, os.path.join(root, "tools/probe/lane_ops_twin.cpp")], check=True)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-o", obj, os.path.join(root, "tools/probe/lane_ops_probe.hip")], check=True)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-o", exe, obj, twin], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "all primitives agree" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
 
 
 @pytest.mark.parametrize("flat", [False, True])
