@@ -435,14 +435,18 @@ struct K2aWalk {
 	{
 		const uint8_t *pk = p - (size_t)k * WB;
 		const int ck = c - k;
-		/* LAYOUT 3 (packed single-gap, 4-bit codes): word ck / 4 of the lane-step, 16-bit half `half`, rows 4g..4g+3 from the top nibble down */
-		return LAYOUT == 3 ? pk[4 * (ck >> 2) + 2 * half + (1 - ((ck & 3) >> 1))] : LAYOUT == 2 ? pk[2 * ck + half] : LAYOUT == 1 ? pk[ck] : pk[ck >> 1];
+		/* LAYOUT 3 (packed single-gap, 4-bit flags): word ck / 4 of the lane-step, 16-bit half `half`, rows 4g..4g+3 from the lowest nibble up */
+		return LAYOUT == 3 ? pk[4 * (ck >> 2) + 2 * half + ((ck & 3) >> 1)] : LAYOUT == 2 ? pk[2 * ck + half] : LAYOUT == 1 ? pk[ck] : pk[ck >> 1];
 	}
-	/* direction code in the reference's byte layout (ksw2.h:125-128) from that byte; ck = row of the cell in the strip */
+	/* direction code in the reference's byte layout (ksw2.h:125-128) from that byte; ck = row of the cell in the strip.  The packed
+	 * kernels (LAYOUT 2 / 3) store direction FLAGS -- bit 0 E wins, 1 F wins [, 2 E~ wins, 3 F~ wins], then the extension flags; the
+	 * winner is the highest win flag (ksw2_lane_pk.h: k2a_dir_flags) */
 	K2A_FN uint32_t decode(uint32_t b, int ck) const
 	{
-		if (LAYOUT == 1 || LAYOUT == 2) return b;
-		const uint32_t r4 = LAYOUT == 3 ? ((ck & 1) ? b & 0xfu : b >> 4) : (b >> ((ck & 1) * 4)) & 0xfu;
+		if (LAYOUT == 1) return b;
+		if (LAYOUT == 2) { const uint32_t win = (b & 8u) ? 4u : (b & 4u) ? 3u : (b & 2u) ? 2u : (b & 1u); return win | ((b >> 4) << 3); }
+		const uint32_t r4 = (b >> ((ck & 1) * 4)) & 0xfu;
+		if (LAYOUT == 3) return ((r4 & 2u) ? 2u : (r4 & 1u)) | ((r4 & 4u) << 1) | ((r4 & 8u) << 1);
 		return (r4 & 3u) | ((r4 & 4u) << 1) | ((r4 & 8u) << 1);
 	}
 };

@@ -136,10 +136,6 @@ K2A_FN k2a_pk k2a_pk_shl(k2a_pk a, int n)   /* per half, n a compile-time consta
 	return n == 0 ? a : __builtin_bit_cast(k2a_pk, (k2a_u2)(__builtin_bit_cast(k2a_u2, a) << (k2a_u2)(unsigned short)n));
 }
 K2A_FN k2a_pk k2a_bit_mask(uint32_t bits, int c) { return (k2a_pk)__builtin_amdgcn_sbfe((int)bits, c, 1); }
-K2A_FN uint32_t k2a_pack_dirs(k2a_pk d0, k2a_pk d1)   /* low bytes of the four halves -> one word */
-{
-	return __builtin_amdgcn_perm(d1, d0, 0x06040200u);
-}
 #define K2A_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 /* Loads whose result is needed many steps later.
  * k2a_load_early: a plain dword load (a volatile one becomes a system-scope flat load with its wait right behind it); its
@@ -186,12 +182,41 @@ K2A_FN k2a_pk k2a_pk_sign(k2a_pk a) { return ((a & 0x8000u) ? 0xffffu : 0u) | ((
 K2A_FN k2a_pk k2a_pk_selv(k2a_pk m, k2a_pk a, k2a_pk b) { return k2a_pk_sel(m, a, b); }
 K2A_FN k2a_pk k2a_pk_shl(k2a_pk a, int n) { return (((a & 0xffffu) << n) & 0xffffu) | ((((a >> 16) << n) & 0xffffu) << 16); }
 K2A_FN k2a_pk k2a_bit_mask(uint32_t bits, int c) { return ((bits >> c) & 1u) ? 0xffffffffu : 0u; }
-K2A_FN uint32_t k2a_pack_dirs(k2a_pk d0, k2a_pk d1)
-{
-	return (d0 & 0xffu) | ((d0 >> 16 & 0xffu) << 8) | ((d1 & 0xffu) << 16) | ((d1 >> 16 & 0xffu) << 24);
-}
 #endif
 
+/* Direction flags of one row for both halves (traceback kernels, round 5).  Every decision of the reference's direction logic
+ * (ksw2_extz.c:72-86 / 98-112, ksw2_extd.c:88-114 / 126-152) is the SIGN of a packed difference: s1..s4 = candidate - gap state in
+ * the order E, F, E~, F~ (each against the running maximum before it: "the gap state wins"), x1..x4 = opening - gap state ("the gap
+ * leaving the cell is an extension").  Rounds 1-4 turned every sign into a mask (v_pk_ashrrev_i16), positioned it (v_and) and merged
+ * it (v_or / v_bitop3): three instructions per decision.  v_perm_b32's selectors 8..11 deliver the sign of a 16-bit half as a whole
+ * byte: ONE v_perm_b32 gathers the four sign bytes of two differences { s.A, s.B, x.A, x.B }, bit-interleaving v_bitop3_b32's
+ * (2.5 cycles each) merge them, and one shifted merge folds the x-bytes onto the s-bytes:
+ *   result byte 0 = alignment A, byte 1 = alignment B: bit 0 E wins, 1 F wins, [2 E~ wins, 3 F~ wins,] then the extension flags
+ *   E, F [, E~, F~] -- at bits 2, 3 (single gap, four-bit form; the byte's upper nibble is garbage) or 4..7 (one byte per cell;
+ *   single gap: bits 2, 3, 6, 7 cleared).  Bytes 2 and 3 are garbage.
+ * The winner is the HIGHEST set win flag (a later gap state was compared against the maximum that already included the earlier
+ * ones); k2a_flags_decode turns a flag byte into the reference's code (ksw2.h:125-128) for the walks.  Right-aligned mode compares
+ * the other way round (gap state - candidate: set = the gap state does NOT win) and inverts the word before it is stored. */
+#define K2A_SGN_SEL 0x09080b0au             /* v_perm_b32(s, x, .) -> { sign(s.lo), sign(s.hi), sign(x.lo), sign(x.hi) } as 0x00 / 0xff bytes */
+template<bool DUAL, bool NIBBLE, bool INV>
+K2A_FN uint32_t k2a_dir_flags(uint32_t s1, uint32_t s2, uint32_t s3, uint32_t s4, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4)
+{
+	const uint32_t q1 = k2a_perm(s1, x1, K2A_SGN_SEL), q2 = k2a_perm(s2, x2, K2A_SGN_SEL);
+	uint32_t r = k2a_pk_selv(0x55555555u, q1, q2);                          /* per byte: even bits E, odd bits F */
+	if (DUAL) {
+		const uint32_t q3 = k2a_perm(s3, x3, K2A_SGN_SEL), q4 = k2a_perm(s4, x4, K2A_SGN_SEL);
+		r = k2a_pk_selv(0x33333333u, r, k2a_pk_selv(0x55555555u, q3, q4));  /* bits 0-1 first piece, 2-3 second piece, repeated up the byte */
+	}
+	if (INV) r = ~r;
+	if (NIBBLE) return k2a_pk_selv(0x03030303u, r, r >> 16);                /* win flags at bits 0-1, extension flags at 2-3 */
+	const uint32_t t = k2a_pk_selv(0x0f0f0f0fu, r, r >> 16);                /* win flags in the low nibble, extension flags in the high one */
+	return DUAL ? t : t & 0x33333333u;
+}
+K2A_FN uint32_t k2a_flags_decode(uint32_t b)                               /* flag byte -> the reference's direction byte (ksw2.h:125-128) */
+{
+	const uint32_t win = (b & 8u) ? 4u : (b & 4u) ? 3u : (b & 2u) ? 2u : (b & 1u);
+	return win | ((b >> 4) << 3);
+}
 /* plain int16 halves <-> offset form (cold code: strip prologues and epilogues) */
 K2A_FN k2a_pk k2a_ofs_on(k2a_pk plain) { return k2a_pk_add(plain, K2A_OFS); }
 K2A_FN k2a_pk k2a_ofs_off(k2a_pk ofs) { return k2a_pk_sub(ofs, K2A_OFS); }
@@ -229,9 +254,9 @@ struct K2aCkHead { int32_t baseA, baseB; uint32_t hd0, pad; };          /* per s
 template<int G, int C, bool DUAL, int MODE = K2A_MODE_SCORE, bool RB = false, bool NOMAX = false, int LDSROW_ = 0, bool DEFER = false>
 struct K2aLanePk {
 	enum { NIB = K2A_PK_NIBBLES(C, DUAL), TBWORDS = NIB ? C / 4 : C / 2 };
-	/* NIB (single gap, 16 rows): direction codes of 4 bits -- bits 0-1 winner {0 diag, 1 E, 2 F}, bit 2 / 3 = the E / F gap leaving the
-	 * cell is an extension -- four consecutive rows per 16-bit half (row 4g at bits 15-12 ... row 4g+3 at bits 3-0), word g of a
-	 * lane-step = { alignment A, alignment B }: half the traceback bytes of the byte layout, for one v_pk_mad per row */
+	/* NIB (single gap, 16 rows): direction flags of 4 bits (k2a_dir_flags: bit 0 E wins, 1 F wins, 2 / 3 = the E / F gap leaving the
+	 * cell is an extension) -- four consecutive rows per 16-bit half (row 4g at bits 3-0 ... row 4g+3 at bits 15-12), word g of a
+	 * lane-step = { alignment A, alignment B }: half the traceback bytes of the byte layout */
 	/* group-uniform (both alignments share the shape) */
 	int qlen, tlen, tlen_full, w, nstrips;
 	const uint8_t *qa, *qbp, *ta, *tbq;   /* query / target codes of alignment A and of alignment B */
@@ -389,7 +414,7 @@ struct K2aLanePk {
 		 * CH candidates are alive at a time instead of C (16-18 registers: what keeps these kernels a wavefront short).  The one
 		 * old H a chunk needs from the chunk above -- the row just above its first row -- is saved before that row is rewritten. */
 		constexpr int CH = (C % 6 == 0) ? 6 : (C % 4 == 0) ? 4 : C;
-		k2a_pk dprev = 0, above_old = hd0;
+		k2a_pk dprev = 0, uprev = 0, above_old = hd0;
 #pragma unroll
 		for (int c0 = 0; c0 < C; c0 += CH) {
 			k2a_pk cand[CH];
@@ -407,24 +432,18 @@ struct K2aLanePk {
 			for (int r = 0; r < CH; ++r) {
 				const int c = c0 + r;
 				const k2a_pk fc = f[c];
-				k2a_pk h = cand[r], d = 0;
+				k2a_pk h = cand[r], s1 = 0, s2 = 0, s3 = 0, s4 = 0, x1 = 0, x2 = 0, x3 = 0, x4 = 0;      /* the differences whose signs are the direction flags (k2a_dir_flags) */
 				if (MODE == K2A_MODE_SCORE) {
 					h = k2a_pk_max3u(h, e, fc);                    /* one v_pk_maximum3_f16: see "Number format" above */
 					if (DUAL) h = k2a_pk_max3u(h, e2, f2[c]);
-				} else if (MODE == K2A_MODE_LEFT) {            /* winner changes only on a strictly larger gap state */
-					d = k2a_pk_sign(k2a_pk_sub(h, e)) & 0x00010001u;                     h = k2a_pk_maxu(h, e);
-					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, fc)), 0x00020002u, d);      h = k2a_pk_maxu(h, fc);
-					if (DUAL) {
-						d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, e2)), 0x00030003u, d);    h = k2a_pk_maxu(h, e2);
-						d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, f2[c])), 0x00040004u, d); h = k2a_pk_maxu(h, f2[c]);
-					}
-				} else {                                       /* right-aligned: a tie already moves to the gap state */
-					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e, h)), 0u, 0x00010001u);      h = k2a_pk_maxu(h, e);
-					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(fc, h)), d, 0x00020002u);      h = k2a_pk_maxu(h, fc);
-					if (DUAL) {
-						d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e2, h)), d, 0x00030003u);    h = k2a_pk_maxu(h, e2);
-						d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(f2[c], h)), d, 0x00040004u); h = k2a_pk_maxu(h, f2[c]);
-					}
+				} else if (MODE == K2A_MODE_LEFT) {            /* winner changes only on a strictly larger gap state: negative = the gap state wins */
+					s1 = k2a_pk_sub(h, e);  h = k2a_pk_maxu(h, e);
+					s2 = k2a_pk_sub(h, fc); h = k2a_pk_maxu(h, fc);
+					if (DUAL) { s3 = k2a_pk_sub(h, e2); h = k2a_pk_maxu(h, e2); s4 = k2a_pk_sub(h, f2[c]); h = k2a_pk_maxu(h, f2[c]); }
+				} else {                                       /* right-aligned: a tie already moves to the gap state: negative = it does NOT win */
+					s1 = k2a_pk_sub(e, h);  h = k2a_pk_maxu(h, e);
+					s2 = k2a_pk_sub(fc, h); h = k2a_pk_maxu(h, fc);
+					if (DUAL) { s3 = k2a_pk_sub(e2, h); h = k2a_pk_maxu(h, e2); s4 = k2a_pk_sub(f2[c], h); h = k2a_pk_maxu(h, f2[c]); }
 				}
 				h = k2a_pk_sel(k2a_bit_mask(live, c), h, neg);
 				/* running row maximum: ties to the last column (keep the old arg-max only where h < max), except
@@ -440,33 +459,25 @@ struct K2aLanePk {
 				 * for E (next row), stays e for F (same row), becomes e2 - e for E~ and stays e2 for F~.  "extension beats
 				 * opening" (ksw2_extz.c:79-86 / 105-112) compares the gap state with the opening value directly. */
 				const k2a_pk t = k2a_sub32(h, gq);
-				if (MODE == K2A_MODE_LEFT) {                   /* extension strictly better than opening */
-					d |= k2a_pk_sign(k2a_pk_sub(t, e)) & (NIB ? 0x00040004u : 0x00080008u);
-					d |= k2a_pk_sign(k2a_pk_sub(t, fc)) & (NIB ? 0x00080008u : 0x00100010u);
-				} else if (MODE == K2A_MODE_RIGHT) {           /* extension at least as good as opening */
-					d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e, t)), 0u, NIB ? 0x00040004u : 0x00080008u);
-					d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(fc, t)), 0u, NIB ? 0x00080008u : 0x00100010u);
-				}
+				if (MODE == K2A_MODE_LEFT) { x1 = k2a_pk_sub(t, e); x2 = k2a_pk_sub(t, fc); }              /* extension strictly better than opening */
+				else if (MODE == K2A_MODE_RIGHT) { x1 = k2a_pk_sub(e, t); x2 = k2a_pk_sub(fc, t); }        /* extension at least as good as opening */
 				e = k2a_pk_maxu(e, t);
 				f[c] = k2a_sub32(k2a_pk_maxu(fc, t), ge);
 				if (DUAL) {
 					const k2a_pk t2 = k2a_sub32(h, gq2);
-					if (MODE == K2A_MODE_LEFT) {
-						d |= k2a_pk_sign(k2a_pk_sub(t2, e2)) & 0x00200020u;
-						d |= k2a_pk_sign(k2a_pk_sub(t2, f2[c])) & 0x00400040u;
-					} else if (MODE == K2A_MODE_RIGHT) {
-						d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e2, t2)), 0u, 0x00200020u);
-						d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(f2[c], t2)), 0u, 0x00400040u);
-					}
+					if (MODE == K2A_MODE_LEFT) { x3 = k2a_pk_sub(t2, e2); x4 = k2a_pk_sub(t2, f2[c]); }
+					else if (MODE == K2A_MODE_RIGHT) { x3 = k2a_pk_sub(e2, t2); x4 = k2a_pk_sub(f2[c], t2); }
 					e2 = k2a_pk_sub(k2a_pk_maxu(e2, t2), de2);           /* e2 - e may be negative: packed subtract */
 					f2[c] = k2a_sub32(k2a_pk_maxu(f2[c], t2), ge2);
 				}
 				if (MODE != K2A_MODE_SCORE) {
-					if (NIB) {
-						dprev = (c & 3) ? k2a_pk_mad(dprev, 0x00100010u, d) : d;      /* both halves: code << 4 | next row's code */
-						if ((c & 3) == 3) tbw[c >> 2] = dprev;
-					} else if (c & 1) tbw[c >> 1] = k2a_pack_dirs(dprev, d);    /* bytes {A(c-1), B(c-1), A(c), B(c)} */
-					else dprev = d;
+					const uint32_t fl = k2a_dir_flags<DUAL, NIB != 0, MODE == K2A_MODE_RIGHT>(s1, s2, s3, s4, x1, x2, x3, x4);      /* byte 0 = alignment A, byte 1 = B */
+					if (!(c & 1)) dprev = fl;
+					else if (NIB) {
+						const uint32_t u = k2a_pk_selv(0x0f0f0f0fu, dprev, fl << 4);      /* rows c - 1 | c: two four-bit codes per byte */
+						if ((c & 3) == 3) tbw[c >> 2] = k2a_perm(u, uprev, 0x05010400u);  /* { A rows 4g..4g+3 from bit 0 up, B likewise } */
+						else uprev = u;
+					} else tbw[c >> 1] = k2a_perm(fl, dprev, 0x05040100u);               /* bytes {A(c-1), B(c-1), A(c), B(c)} */
 				}
 				hl[c] = h;
 			}

@@ -248,54 +248,39 @@ struct K2aLaneSolo {
 			for (int r = 0; r < CH; ++r) {
 				const int c = c0 + r;
 				const k2a_pk fc = f[c];
-				k2a_pk h = cand[r], d = 0;
+				k2a_pk h = cand[r], s1 = 0, s2 = 0, s3 = 0, s4 = 0, x1 = 0, x2 = 0, x3 = 0, x4 = 0;
 				if (MODE == K2A_MODE_SCORE) {
 					h = k2a_pk_max3u(h, e, fc);                    /* v_pk_maximum3_f16 on offset-form patterns (ksw2_lane_pk.h) */
 					if (DUAL) h = k2a_pk_max3u(h, e2, f2[c]);
-				} else if (MODE == K2A_MODE_LEFT) {
-					d = k2a_pk_sign(k2a_pk_sub(h, e)) & 0x00010001u;                     h = k2a_pk_maxu(h, e);
-					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, fc)), 0x00020002u, d);      h = k2a_pk_maxu(h, fc);
-					if (DUAL) {
-						d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, e2)), 0x00030003u, d);    h = k2a_pk_maxu(h, e2);
-						d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(h, f2[c])), 0x00040004u, d); h = k2a_pk_maxu(h, f2[c]);
-					}
-				} else {
-					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e, h)), 0u, 0x00010001u);      h = k2a_pk_maxu(h, e);
-					d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(fc, h)), d, 0x00020002u);      h = k2a_pk_maxu(h, fc);
-					if (DUAL) {
-						d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e2, h)), d, 0x00030003u);    h = k2a_pk_maxu(h, e2);
-						d = k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(f2[c], h)), d, 0x00040004u); h = k2a_pk_maxu(h, f2[c]);
-					}
+				} else if (MODE == K2A_MODE_LEFT) {            /* negative = the gap state wins (K2aLanePk::step, k2a_dir_flags) */
+					s1 = k2a_pk_sub(h, e);  h = k2a_pk_maxu(h, e);
+					s2 = k2a_pk_sub(h, fc); h = k2a_pk_maxu(h, fc);
+					if (DUAL) { s3 = k2a_pk_sub(h, e2); h = k2a_pk_maxu(h, e2); s4 = k2a_pk_sub(h, f2[c]); h = k2a_pk_maxu(h, f2[c]); }
+				} else {                                       /* right-aligned: negative = the gap state does NOT win */
+					s1 = k2a_pk_sub(e, h);  h = k2a_pk_maxu(h, e);
+					s2 = k2a_pk_sub(fc, h); h = k2a_pk_maxu(h, fc);
+					if (DUAL) { s3 = k2a_pk_sub(e2, h); h = k2a_pk_maxu(h, e2); s4 = k2a_pk_sub(f2[c], h); h = k2a_pk_maxu(h, f2[c]); }
 				}
 				h = k2a_pk_sel(k2a_pk_sign(lv << (15 - c)), h, neg);                 /* live mask of row c, per half */
 				if (!DUAL && MODE == K2A_MODE_RIGHT) rmj[c] = k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(rmax[c], h)), jjpk, rmj[c]);
 				else rmj[c] = k2a_pk_selv(k2a_pk_sign(k2a_pk_sub(h, rmax[c])), rmj[c], jjpk);
 				rmax[c] = k2a_pk_maxu(rmax[c], h);
 				const k2a_pk t = k2a_sub32(h, gq);
-				if (MODE == K2A_MODE_LEFT) {
-					d |= k2a_pk_sign(k2a_pk_sub(t, e)) & 0x00080008u;
-					d |= k2a_pk_sign(k2a_pk_sub(t, fc)) & 0x00100010u;
-				} else if (MODE == K2A_MODE_RIGHT) {
-					d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e, t)), 0u, 0x00080008u);
-					d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(fc, t)), 0u, 0x00100010u);
-				}
+				if (MODE == K2A_MODE_LEFT) { x1 = k2a_pk_sub(t, e); x2 = k2a_pk_sub(t, fc); }
+				else if (MODE == K2A_MODE_RIGHT) { x1 = k2a_pk_sub(e, t); x2 = k2a_pk_sub(fc, t); }
 				e = k2a_pk_maxu(e, t);
 				f[c] = k2a_sub32(k2a_pk_maxu(fc, t), ge);
 				if (DUAL) {
 					const k2a_pk t2 = k2a_sub32(h, gq2);
-					if (MODE == K2A_MODE_LEFT) {
-						d |= k2a_pk_sign(k2a_pk_sub(t2, e2)) & 0x00200020u;
-						d |= k2a_pk_sign(k2a_pk_sub(t2, f2[c])) & 0x00400040u;
-					} else if (MODE == K2A_MODE_RIGHT) {
-						d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(e2, t2)), 0u, 0x00200020u);
-						d |= k2a_pk_sel(k2a_pk_sign(k2a_pk_sub(f2[c], t2)), 0u, 0x00400040u);
-					}
+					if (MODE == K2A_MODE_LEFT) { x3 = k2a_pk_sub(t2, e2); x4 = k2a_pk_sub(t2, f2[c]); }
+					else if (MODE == K2A_MODE_RIGHT) { x3 = k2a_pk_sub(e2, t2); x4 = k2a_pk_sub(f2[c], t2); }
 					e2 = k2a_pk_sub(k2a_pk_maxu(e2, t2), de2);
 					f2[c] = k2a_sub32(k2a_pk_maxu(f2[c], t2), ge2);
 				}
-				if (MODE != K2A_MODE_SCORE) {
-					if (c & 1) tbw[c >> 1] = k2a_pack_dirs(dprev, d);
-					else dprev = d;
+				if (MODE != K2A_MODE_SCORE) {                  /* one flag byte per cell: byte 0 = the low half's row, byte 1 = the high half's */
+					const uint32_t fl = k2a_dir_flags<DUAL, false, MODE == K2A_MODE_RIGHT>(s1, s2, s3, s4, x1, x2, x3, x4);
+					if (c & 1) tbw[c >> 1] = k2a_perm(fl, dprev, 0x05040100u);
+					else dprev = fl;
 				}
 				hl[c] = h;
 			}
@@ -432,7 +417,7 @@ K2A_FN int k2a_trace_solo(const uint8_t *tb, int i, int j, uint32_t *out, int ql
 #pragma unroll
 		for (int k = 0; k < AHEAD; ++k) {
 			if (k >= nq || !diagonal) break;
-			const uint32_t d = bq[k];
+			const uint32_t d = k2a_flags_decode(bq[k]);             /* flag byte -> the reference's direction byte */
 			if (state == 0) state = d & 7;
 			else if (!((d >> (state + 2)) & 1)) state = 0;
 			if (state == 0) state = d & 7;

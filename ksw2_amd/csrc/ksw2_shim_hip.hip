@@ -570,12 +570,30 @@ k2a_zscan_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const u
 		if (go) L.do_init(sc, 0, 0, (const K2aCkHead*)(blk + (size_t)prA.bnd_off * K2A_CK_STEP_BYTES) + (size_t)grp * prA.cig_off + S);
 		const int n = go ? L.kfin - kbeg + 1 : 0;
 		const uint2 *st = (const uint2*)blk + (grp * G + S % G);
-		for (int t = 0; __builtin_amdgcn_ballot_w64(t < n) != 0; ++t) {
-			if (t < n) {
-				const int k = kbeg + t;
-				const uint2 in = st[(size_t)k * 64];
-				const int jc = min(max(k - L.koff, 0), L.qlen - 1);
-				L.set_qb(k2a_pair16(L.qa[jc], L.qbp[jc]));
+		/* the group's lanes walk the fill's steps TOGETHER: at one iteration all of them read the same step of the checkpoint stream,
+		 * sixteen neighbouring 8-byte entries (strip S + 1 belonged to the fill's next lane and started C + 1 steps later) -- one
+		 * 128-byte line per group instead of one line per lane; lanes whose strip has not begun or is over sit the iteration out */
+		const int kfirst = __builtin_amdgcn_readlane(kbeg, 0) * (zg == 0) + __builtin_amdgcn_readlane(kbeg, 16) * (zg == 1) +
+		                   __builtin_amdgcn_readlane(kbeg, 32) * (zg == 2) + __builtin_amdgcn_readlane(kbeg, 48) * (zg == 3);      /* first step of the group's first strip */
+		const int off = go ? kbeg - kfirst : 0;
+		/* what step t needs from memory -- the checkpoint entry and the two query codes -- is asked for one iteration ahead and by every
+		 * lane, unconditionally (clamped into the lane's own range; a lane without a strip reads step 0 of its block): two wavefronts
+		 * per SIMD do not hide an L2 round trip per step, and hipcc waits right behind a load that sits under a condition */
+		uint2 in_n; uint32_t qa_n, qb_n;
+		{
+			const int k = n > 0 ? kbeg : 0, jc = min(max(k - L.koff, 0), L.qlen - 1);
+			in_n = st[(size_t)k * 64]; qa_n = L.qa[jc]; qb_n = L.qbp[jc];
+		}
+		for (int t = 0; __builtin_amdgcn_ballot_w64(t < off + n) != 0; ++t) {
+			const uint2 in = in_n;
+			const uint32_t qc = k2a_pair16(qa_n, qb_n);
+			{
+				const int k = n > 0 ? kfirst + min(max(t + 1, off), off + n - 1) : 0, jc = min(max(k - L.koff, 0), L.qlen - 1);
+				in_n = st[(size_t)k * 64]; qa_n = L.qa[jc]; qb_n = L.qbp[jc];
+			}
+			if (t >= off && t < off + n) {
+				const int k = kfirst + t;
+				L.set_qb(qc);
 				uint32_t tw[Lane::TBWORDS];
 				L.step(sc, k, in.x, in.y, 0u, tw);
 			}
@@ -589,6 +607,7 @@ k2a_zscan_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const u
 			if (bk->dropped || S1 + (round + 1) * ZG >= nstrips) {
 				const K2aBook b = *bk;
 				k2a_finish(pr, b, &res[pi]);                                  /* (pad[1] = 0: settled) */
+				res[pi].pad[0] = r0.pad[0];                                   /* ... and what the fill reported stays: a wildcard code in the target (unscanned plans: the host re-runs the pair) */
 				done[wave][zg] = 1;
 			}
 		}

@@ -340,7 +340,10 @@ static void sim_zscan(const K2aScoring sc, const K2aPair *pairs, const uint32_t 
 			}
 			for (int l = 0; l < ZG && S1 + round * ZG + l < nstrips && !b.dropped; ++l)
 				k2a_fin_rows_half<C>(sc, &b, pr.zdrop, stage[l], half, RB, pr.qlen, pr.tlen, pr.tlen_full, pr.w);
-			if (b.dropped || S1 + (round + 1) * ZG >= nstrips) { k2a_finish(pr, b, &res[pi]); break; }
+			if (b.dropped || S1 + (round + 1) * ZG >= nstrips) {
+				if (getenv("K2A_DBG")) fprintf(stderr, "zscan: frozen at row %d, settled at row %d (%s), %d rows later, %d round(s)\n", r0.rows_done - 1, b.rows - 1, b.dropped ? "drop" : "end", b.rows - r0.rows_done, round + 1);
+				k2a_finish(pr, b, &res[pi]); res[pi].pad[0] = r0.pad[0]; break;
+			}
 		}
 	}
 }

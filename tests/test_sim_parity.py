@@ -640,6 +640,39 @@ def _check_deferred_argmax(lib, on, scale=1.0, seed=41):
     assert ndrop >= 20 and lib.rerun_count() == r0, (ndrop, lib.rerun_count() - r0)
 
 
+def _check_frozen_books_with_wildcards(lib, monkeypatch):
+    """Round 5's fuzz find: an unscanned (streamed / flat) plan whose deferred fill froze a book AND met a wildcard code in the same
+    pair's target -- the third pass rewrote the record and with it the fill's wildcard report, and the pair came back mis-scored
+    instead of being re-run.  Diverging tails (every pair freezes at Z-drop 60 / 200), wildcards in every third target and in
+    some queries, through the streamed pointer entry and the flat entry, against the oracle."""
+    monkeypatch.setenv("KSW2AMD_SIMDS", "0")
+    monkeypatch.setenv("KSW2AMD_DEFER", "1")
+    monkeypatch.setenv("KSW2AMD_STREAM", "1")
+    monkeypatch.setenv("KSW2AMD_STREAM_PIECE_KB", "64")
+    mat = synth.simple_mat(5, 2, 4, -3)
+    for ql, tl, w, zd in ((900, 880, 20, 200), (1500, 1500, 300, 60)):
+        qs, ts = synth.fixed_batch(4242 + w, 24, ql, tl, sub=0.05, ind=0.05, tail_random_frac=0.4, tail_pairs=1.0)
+        qs, ts = [np.array(x) for x in qs], [np.array(x) for x in ts]
+        for i in range(0, 24, 3):
+            ts[i][tl // 4] = 4
+        for i in range(1, 24, 5):
+            qs[i][ql // 3] = 4
+        r0 = lib.rerun_count()
+        res = lib.extz_batch(qs, ts, mat, 4, 2, w=w, zdrop=zd, flag=po.SCORE_ONLY)
+        fres = lib.make_flat_batch(qs, ts, mat, 4, 2, 0, 0, w=w, zdrop=zd, end_bonus=0, flag=po.SCORE_ONLY).run_oneshot(False)
+        assert lib.rerun_count() >= r0 + 16                     # the eight target wildcards, twice; nothing else
+        ndrop = 0
+        for i in range(24):
+            exp = po.align("oracle", "extz2", qs[i], ts[i], mat, 4, 2, w=w, zdrop=zd, flag=po.SCORE_ONLY)
+            assert not diff(exp, res[i], CMP) and not diff(exp, fres[i], CMP), (w, i, diff(exp, res[i], CMP), diff(exp, fres[i], CMP))
+            ndrop += exp["zdropped"]
+        assert ndrop >= 12, ndrop
+
+
+def test_sim_frozen_books_with_wildcards(sim, monkeypatch):
+    _check_frozen_books_with_wildcards(sim, monkeypatch)
+
+
 @pytest.mark.parametrize("defer", ["0", "1"])
 def test_sim_deferred_argmax(sim, defer, monkeypatch):
     """K2aLanePk DEFER + k2a_argmax twin on the simulator."""
