@@ -68,6 +68,7 @@
 	X(STREAM_FAULT) \
 	X(STREAM_MIN_CELLS) \
 	X(STREAM_PIECE_KB) \
+	X(UNIFORM) \
 	X(STREAM_SLEEP_US) \
 	X(STREAM_TIMEOUT_MS) \
 	X(THREADS) \
@@ -195,10 +196,12 @@ struct ksw2amd_plan_s {
 	void *meta_ev;                         /* behind the plan's small arrays (upload stream): what a streamed run waits for before its first launch */
 	uint8_t *d_wm;                         /* watermark block (K2A_WM_BYTES) followed by the K2aQueueDesc array of the streamed classes */
 	K2aQueueDesc *h_qd; int nqd;
+	K2aUniform *uni;                       /* uniform plans (plan_create_uniform): records, task list and piece counts are written on the device by rule */
 	size_t need_words;                     /* per-wavefront-task piece counts, behind the task lists in d_order */
 };
 typedef struct { int64_t cost; uint32_t idx, tf; } sort_t;      /* tf = true target length: part of a packed pair's shape */
-typedef struct { uint8_t *h_seq; const K2aPair *hp; const ksw2amd_pair_t *pairs; uint8_t *wild; stream_up_t *su; } copy_ctx_t;   /* su: streamed plans -- chunk k of the copy is piece k of the upload */
+typedef struct { uint8_t *h_seq; const K2aPair *hp; const ksw2amd_pair_t *pairs; uint8_t *wild; stream_up_t *su;      /* su: streamed plans -- chunk k of the copy is piece k of the upload */
+                 ksw2amd_plan_t *uni_plan; int uni_cls, uni_flag; } copy_ctx_t;                                              /* uniform plans: the copy's workers fill the host's per-pair arrays of their range first */
 typedef struct { int on_device; } flat_src_t;
 #define META_ROOM(n) (align_up(sizeof(K2aPair) * ((size_t)(n) + 1), 256) + sizeof(uint32_t) * (3 * (size_t)(n) + 8) + 512)
 typedef struct { ksw2amd_plan_t *p; void *km; ksw_extz_t *ez, **ezp; void **kmp; const uint32_t *pool; const size_t *pos; int nrerun, rc; } asm_ctx_t;
@@ -246,6 +249,9 @@ int assemble_parallel(asm_ctx_t *c);
 int rerun_pairs(ksw2amd_plan_t *p, int nrerun, void *km, ksw_extz_t *ez, ksw_extz_t **ezp, void **kmp);
 int gather_start(ksw2amd_plan_t *p, stream_up_t *su, const ksw2amd_pair_t *pairs, int n);
 int gather_wait(ksw2amd_plan_t *p);
+int gather_start_uniform(ksw2amd_plan_t *p, stream_up_t *su, const ksw2amd_pair_t *pairs, int n, int cls0, int flag0);
+void uni_fill_range(const K2aUniform *u, K2aPair *hp, int8_t *h_cls, int32_t *h_flag, uint32_t *h_order, int cls0, int flag0, int beg, int end);
+ksw2amd_plan_t *plan_create_uniform_entry(int dual, int scalar, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs);
 int pool_min_pairs(void);
 int unit_pairs(const ksw2amd_pair_t *a);
 int uniform_chunks(int n, int unit, double bytes, double cells, int workers, int ndev, int with_cigar, double path_steps, int *chunk_pairs);

@@ -16,6 +16,10 @@
 
 __thread char g_err[512];
 __thread int g_no_defer;
+/* > 0: plan_create_ex is asked for the CLASS only -- the kernel family, geometry and form a batch of this many tasks of the given
+ * pairs' shape would run as, by the very rules every plan is made by -- and returns before anything is copied, allocated on the
+ * device or uploaded (plan_create_uniform) */
+static __thread int g_probe_tasks;
 size_t thread_cached_device_bytes(void);            /* set around the re-run of a pair the deferred arg-max kernels handed back as inexact */
 
 const char *ksw2amd_last_error(void) { return g_err; }
@@ -219,7 +223,9 @@ void ksw2amd_stream_stats(int64_t out[2]) { out[0] = g_stream_stat[0]; out[1] = 
 /* the watermark source: page-locked, block k filled with k + 1, one per device for the life of the process */
 static uint32_t *g_wm_src[SHARED_UP_MAXDEV];
 static pthread_mutex_t g_wm_mu = PTHREAD_MUTEX_INITIALIZER;
-static const uint32_t *wm_source(void)
+const uint32_t *k2a_wm_source(void);
+static const uint32_t *wm_source(void) { return k2a_wm_source(); }
+const uint32_t *k2a_wm_source(void)
 {
 	const int dev = k2a_shim_get_device();
 	uint32_t *b;
@@ -480,7 +486,7 @@ void ksw2amd_plan_destroy(ksw2amd_plan_t *p)
 	free(p->h_pairs); free(p->h_cls); free(p->h_half); free(p->h_flag); free(p->h_order);
 	cache_put(BUF_HRES, p->h_res, p->cap[BUF_HRES]);          /* pinned: the results come back with one asynchronous copy */
 	if (!p->flat) cache_put(BUF_HSEQ, p->h_seq, p->cap[BUF_HSEQ]);      /* (a flat plan's h_seq is the caller's arena) */
-	free(p->src_pairs); free(p->src_mat); free(p->flat_tail);
+	free(p->src_pairs); free(p->src_mat); free(p->flat_tail); free(p->uni);
 	free(p);
 }
 
@@ -670,7 +676,7 @@ ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc
 	if (m > 5) { mat_off = off; off = align_up(off + 2 * (size_t)m * m, 256); }   /* wide alphabets: effective matrices, simple | generic */
 	p->seq_bytes = off;
 	if (flat) p->h_seq = flat->on_device ? 0 : (uint8_t*)flat_lo;      /* borrowed: EQX rewrites and re-runs read the sequences there */
-	else {
+	else if (!g_probe_tasks) {
 		p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, p->seq_bytes + META_ROOM(n), &p->cap[BUF_HSEQ]);      /* (+ the small arrays: one upload per plan) */
 		if (!p->h_seq) { fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
 	}
@@ -690,6 +696,7 @@ ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc
 	if (stream_env() == 0) want_stream = 0; else if (stream_env() == 1) want_stream = 1;
 	if (flat && flat->on_device) want_stream = 0;        /* a device-resident arena: nothing to overlap (one device-to-device copy at HBM rate), and that copy is a
 	                                                      * KERNEL, which a launch of waiting wavefronts that fills the device would starve (tools/probe/stream_publish_probe.hip) */
+	if (g_probe_tasks) want_stream = 0;
 	if (g_no_defer) want_stream = 0;                     /* a fetch's re-run of pairs the kernels handed back: through the SCANNED gather path, whose
 	                                                      * wildcard flags send a pair to the int32 kernels -- unscanned it would come back again */
 	if (want_stream && n > 0 && (p->seq_bytes >= ((size_t)1 << 20) || stream_env() == 1) && (su = (stream_up_t*)calloc(1, sizeof(*su))) != 0) {
@@ -746,18 +753,18 @@ ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc
 		p->stream = su->up; p->stream_used = 1; shared_up = 1;
 		if (flat) stream_issue(su, -1);
 		else if (gather_start(p, su, pairs, n)) {           /* the pool cannot take it (a worker's own plan, another caller's batch): copy here, piece by piece */
-			copy_ctx_t cc;
+			copy_ctx_t cc = { 0 };
 			cc.h_seq = p->h_seq; cc.hp = p->h_pairs; cc.pairs = pairs; cc.wild = 0; cc.su = su;
 			su->hold = su->np;
 			for (k = 0; k < su->np; ++k) { copy_range(&cc, su->pfirst[k], su->pfirst[k + 1]); stream_issue(su, k); }      /* (cc.su is not consulted by copy_range itself) */
 		}
 		if (su->rc) { fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error()); goto err; }
 	} else {
-		copy_ctx_t cc;
+		copy_ctx_t cc = { 0 };
 		su = 0;
 		cc.h_seq = p->h_seq; cc.hp = p->h_pairs; cc.pairs = pairs; cc.wild = solo_ok;              /* (solo_ok doubles as the wildcard flags until the loop below sets it) */
 		cc.su = 0;
-		if (!flat && !parallel_copy(&cc, n, p->seq_bytes)) copy_range(&cc, 0, n);                   /* flat: nothing is copied, nothing scanned (wild = 0) */
+		if (!flat && !g_probe_tasks && !parallel_copy(&cc, n, p->seq_bytes)) copy_range(&cc, 0, n);  /* flat: nothing is copied, nothing scanned (wild = 0) */
 	}
 	for (i = 0; i < n; ++i) {
 		const ksw2amd_pair_t *a = &pairs[i];
@@ -892,7 +899,7 @@ ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc
 		if (simds > 0) {
 			int cnt[NCLS_MAX * NPASS], b;
 			memset(cnt, 0, sizeof(cnt));
-			if (uni) { if (p->h_cls[0] >= 0 && pk_ok[0] && pk_ok[0] != PASS_SOLO) cnt[p->h_cls[0] * NPASS + pk_ok[0]] = n; }
+			if (uni) { if (p->h_cls[0] >= 0 && pk_ok[0] && pk_ok[0] != PASS_SOLO) cnt[p->h_cls[0] * NPASS + pk_ok[0]] = g_probe_tasks ? 2 * g_probe_tasks : n; }
 			else
 			for (i = 0; i < n; ++i) if (p->h_cls[i] >= 0 && pk_ok[i] && pk_ok[i] != PASS_SOLO) ++cnt[p->h_cls[i] * NPASS + pk_ok[i]];
 			for (b = 0; b < NCLS_MAX * NPASS; ++b)
@@ -923,8 +930,8 @@ ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc
 		build_eff(dual, m, sc->mat, e, e2, 0, (int8_t*)p->h_seq + mat_off);
 		build_eff(dual, m, sc->mat, e, e2, 1, (int8_t*)p->h_seq + mat_off + (size_t)m * m);
 	}
-	if (!su) p->d_seq = (uint8_t*)cache_get(BUF_SEQ, p->seq_bytes + (flat ? 0 : META_ROOM(n)), &p->cap[BUF_SEQ]);
-	if (!p->d_seq) { fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error()); goto err; }
+	if (!su && !g_probe_tasks) p->d_seq = (uint8_t*)cache_get(BUF_SEQ, p->seq_bytes + (flat ? 0 : META_ROOM(n)), &p->cap[BUF_SEQ]);
+	if (!p->d_seq && !g_probe_tasks) { fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error()); goto err; }
 	/* Big uploads go through ONE stream per device, whoever issues them: the chunks of a big batch are packed by several worker
 	 * threads at once, and six 80 MB copies on six streams share the link -- all of them arrive after 9-13 ms and the device idles
 	 * until then (KSW2AMD_TRACE=2 timeline of the 10 k headline); in one queue the first chunk's bytes are there 1.6 ms after its
@@ -934,7 +941,7 @@ ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc
 	 * call would only add latency there.  KSW2AMD_NO_SHARED_UP=1: the old behaviour, for A/B runs. */
 	up = su ? su->up : (flat && !flat->on_device) || (!flat && p->seq_bytes >= ((size_t)(ENV(SHARED_UP_MIN_MB) ? imax(atoi(ENV(SHARED_UP_MIN_MB)), 0) : 4) << 20) && !ENV(NO_SHARED_UP)) ? shared_upload_stream() : 0;
 	if (up) shared_up = 1; else up = g_plan_stream ? g_plan_stream : thread_upload_stream();
-	p->stream = up; p->stream_used = 1;              /* plan_destroy waits for it before the buffers are recycled */
+	p->stream = up; p->stream_used = !g_probe_tasks;  /* plan_destroy waits for it before the buffers are recycled */
 	if (su) { /* the pieces are on their way (or there) already */ }
 	else if (flat) {
 		/* the arena's span as it lies there (an upload from caller memory: asynchronous if the caller page-locked it,
@@ -1050,8 +1057,10 @@ ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc
 			           /* ... and only where the launch keeps at least 1.5 wavefronts on every SIMD: the deferred kernels of the 16-row
 			            * geometry have their code planes in LDS, whose latency a lone wavefront cannot hide (1 024 pairs of 10 k x 10 k =
 			            * 512 wavefronts: 1 063 GCUPS deferred against 1 241 from registers) */
-			           (forced < 0 ? k2a_pkcfg_G[c->cfg] == 64 && (k2a_shim_simd_count() > 0 ? 2 * (int64_t)c->count >= 3 * (int64_t)k2a_shim_simd_count() : c->count >= 32) : forced);
+			           (forced < 0 ? k2a_pkcfg_G[c->cfg] == 64 && (k2a_shim_simd_count() > 0 ? 2 * (int64_t)(g_probe_tasks ? g_probe_tasks : c->count) >= 3 * (int64_t)k2a_shim_simd_count()
+			                                                                                      : (g_probe_tasks ? g_probe_tasks : c->count) >= 32) : forced);
 		}
+		if (g_probe_tasks) { free(pk_ok); free(solo_ok); return p; }      /* the class is known: nothing was copied, allocated on the device or uploaded */
 		for (lo = 0; lo < 2; ++lo) {                       /* 0: size it, 1: lay it out */
 			size_t at = p->tb_bytes;
 			for (k = 0; k < p->ncls; ++k) {
@@ -1277,6 +1286,180 @@ err:
 	return 0;
 }
 
+/* ---------------------------------------------------------------- uniform batches
+ * A score-only batch whose pairs all have one shape and one set of parameters (config 2; the 10 k headline) is the case where the
+ * host's per-pair work is pure overhead: plan_create_ex walks the batch half a dozen times on ONE thread -- offsets, classification,
+ * task list, piece counts, a copy of the records into page-locked staging -- about 40 ns per pair, 2.5 ms for config 2's 65 536 pairs
+ * next to a 1.3 ms kernel (KSW2AMD_TRACE=2, round 5), which is why such batches went through eight chunk plans on six workers
+ * instead of one streamed launch.  Here nothing per pair is left on the creating thread:
+ *   - the class comes from plan_create_ex itself, asked about TWO of the pairs as if they were n (g_probe_tasks): one set of rules;
+ *   - the arena is laid out by rule (pair i at i * stride) and the device writes its own records, task list and piece counts
+ *     (K2aUniform, k2a_uniform_layout_kernel, launched by ksw2amd_plan_run in front of the fill): nothing of them is uploaded;
+ *   - the pool's threads copy the sequences piece by piece into page-locked staging, as for every streamed plan, and fill the host's
+ *     per-pair arrays of their ranges on the way (what a fetch looks at: class, flags, offsets for a re-run).
+ * Returns NULL with g_err empty when the batch is not of this kind (the caller takes the general path), NULL with a message on a
+ * real failure.  KSW2AMD_UNIFORM=0: never.  The caller guarantees that every pair equals pairs[0] in qlen, tlen, w, zdrop,
+ * end_bonus and flag and that none is empty. */
+#define K2A_UNI_MIN_PAIRS 2048
+void uni_fill_range(const K2aUniform *u, K2aPair *hp, int8_t *h_cls, int32_t *h_flag, uint32_t *h_order, int cls0, int flag0, int beg, int end)
+{
+	int i;
+	for (i = beg; i < end; ++i) {
+		K2aPair d = u->tmpl;
+		d.qoff = (uint32_t)i * u->stride; d.toff = (uint32_t)i * u->stride + u->qpad;
+		if (u->defer) d.tb_off = u->blk_base + (uint64_t)(((uint32_t)i >> 1) / u->ng) * u->blk_bytes;
+		hp[i] = d; h_cls[i] = (int8_t)cls0; h_flag[i] = flag0; h_order[i] = (uint32_t)i;
+	}
+}
+
+static ksw2amd_plan_t *plan_create_uniform(int dual, int scalar, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs)
+{
+	ksw2amd_plan_t *t, *p = 0;
+	stream_up_t *su = 0;
+	K2aUniform *u = 0;
+	cls_t c0;
+	K2aPair tm;
+	int cls0, flag0, k, G, C, NG, nwt, mx, w;
+	size_t pbytes, ppp;
+	const char *ev = ENV(UNIFORM);
+	g_err[0] = 0;
+	if ((ev && atoi(ev) == 0) || n < K2A_UNI_MIN_PAIRS || (n & 1) || !pairs || !sc || sc->m > 5 || sc->m <= 0 || !sc->mat) return 0;
+	if (!(pairs[0].flag & KSW_EZ_SCORE_ONLY) || pairs[0].qlen <= 0 || pairs[0].tlen <= 0 || !pairs[0].query || !pairs[0].target) return 0;
+	if (stream_env() == 0 || g_no_defer || g_probe_tasks || 0) return 0;
+	/* the class, by the rules of every plan */
+	g_probe_tasks = n / 2;
+	t = plan_create_ex(dual, scalar, sc, 2, pairs, 0, 0);
+	g_probe_tasks = 0;
+	if (!t) return 0;                                            /* (a real failure: g_err says which) */
+	if (t->reject_all || t->ncls != 1 || !t->cls[0].pk || t->cls[0].solo || t->cls[0].cfg == K2A_PKCFG_MP || t->cls[0].mode != K2A_MODE_SCORE || t->cls[0].count != 1) {
+		ksw2amd_plan_destroy(t); g_err[0] = 0; return 0;
+	}
+	c0 = t->cls[0]; tm = t->h_pairs[0]; cls0 = t->h_cls[0]; flag0 = t->h_flag[0];
+	p = plan_new("plan_create", n, -1);
+	if (!p) { ksw2amd_plan_destroy(t); return 0; }
+	p->dual = !!dual; p->m = sc->m; p->scalar = scalar;
+	p->src_mat = t->src_mat; t->src_mat = 0;
+	p->src_sc = *sc; p->src_sc.mat = p->src_mat;
+	ksw2amd_plan_destroy(t);
+	p->h_cls[n] = -1; memset(&p->h_pairs[n], 0, sizeof(K2aPair)); p->h_half[n] = 0;
+	u = (K2aUniform*)calloc(1, sizeof(*u));
+	p->h_order = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n + 4));
+	if (!u || !p->h_order) { free(u); fail(KSW2AMD_E_NOMEM, "plan_create: host allocation failed%s", 0); goto err; }
+	p->uni = u;
+	mx = imax(pairs[0].qlen, pairs[0].tlen); w = pairs[0].w; if (w < 0 || w > mx) w = mx;
+	p->cells = (int64_t)n * band_cells(pairs[0].qlen, pairs[0].tlen, w);
+	/* the arena: query 16-aligned, target 16-aligned and readable one strip past its end, like every gathered arena */
+	u->n = (uint32_t)n; u->ntasks = (uint32_t)(n / 2);
+	u->qpad = (uint32_t)align_up((size_t)pairs[0].qlen, 16); u->stride = u->qpad + (uint32_t)align_up((size_t)pairs[0].tlen + 64, 16);
+	if ((uint64_t)n * u->stride > 0xfff00000u - 65536u) { g_err[0] = 0; goto na; }
+	p->seq_bytes = align_up((size_t)n * u->stride + 65536, 256);
+	u->seq_bytes = p->seq_bytes; u->margin = K2A_STREAM_MARGIN;
+	tm.cig_off = 0; tm.tb_off = 0; tm.bnd_off = 0; tm.pad = 0;
+	/* the one class */
+	G = k2a_pkcfg_G[c0.cfg]; C = k2a_pkcfg_C[c0.cfg]; NG = 64 / G; nwt = (n / 2 + NG - 1) / NG;
+	u->ng = (uint32_t)NG;
+	p->ncls = 1; p->cls[0] = c0; p->cls[0].first = 0; p->cls[0].count = n / 2; p->cls[0].qd = 0; p->ntasks = n / 2; p->norder = n;
+	if (c0.defer) {                                              /* checkpoint blocks, one per wavefront-task (plan_create_ex, "Deferred arg-max") */
+		const uint32_t ns = (uint32_t)((tm.tlen + C - 1) / C), steps = ns - 1 + (uint32_t)imin(tm.qlen - 1, tm.tlen - 1 + tm.w) + 1;
+		const size_t bytes = align_up((size_t)steps * 512 + (size_t)NG * ns * 16, 256), zl = align_up(4 * K2A_ZLIST_WORDS(n / 2), 256);
+		size_t free_b = 0, total_b = 0;
+		if (zl + (size_t)nwt * bytes > ((size_t)1 << 30) && !(ENV(DEFER) && *ENV(DEFER)) &&
+		    (k2a_shim_mem_info(&free_b, &total_b) || zl + (size_t)nwt * bytes > (free_b + thread_cached_device_bytes()) / 10 * 6)) { g_err[0] = 0; goto na; }   /* (the general path decides what then) */
+		u->defer = 1; u->blk_base = zl; u->blk_bytes = bytes;
+		tm.bnd_off = steps; tm.cig_off = ns;
+		p->tb_bytes = zl + (size_t)nwt * bytes;
+	}
+	u->tmpl = tm;
+	/* page-locked staging, device arena, watermark: as every streamed plan */
+	p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, p->seq_bytes + 256, &p->cap[BUF_HSEQ]);
+	su = (stream_up_t*)calloc(1, sizeof(*su));
+	if (!p->h_seq || !su) { free(su); su = 0; fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
+	p->up_state = su;
+	su->t0 = now_ms();
+	pthread_mutex_init(&su->mu, 0);
+	{
+		const char *pk_ = ENV(STREAM_PIECE_KB);
+		pbytes = pk_ && atol(pk_) > 0 ? (size_t)atol(pk_) << 10 : p->seq_bytes / 24;
+		if (!(pk_ && atol(pk_) > 0)) { if (pbytes < ((size_t)1 << 20)) pbytes = (size_t)1 << 20; if (pbytes > ((size_t)32 << 20)) pbytes = (size_t)32 << 20; }
+		if (pbytes * (K2A_MAXPIECES - 1) < p->seq_bytes) pbytes = p->seq_bytes / (K2A_MAXPIECES - 1) + 1;
+		ppp = (pbytes + u->stride - 1) / u->stride;              /* pairs per piece: pieces start at pair boundaries (the copy's work units) */
+		if (ppp < 1) ppp = 1;
+		while (((size_t)n + ppp - 1) / ppp > K2A_MAXPIECES) ++ppp;
+	}
+	su->np = (int)(((size_t)n + ppp - 1) / ppp);
+	for (k = 0; k <= su->np; ++k) {
+		const size_t first = (size_t)k * ppp < (size_t)n ? (size_t)k * ppp : (size_t)n;
+		su->pfirst[k] = (int)first; su->pb[k] = k < su->np ? first * u->stride : p->seq_bytes;
+		u->pb[k] = su->pb[k];
+	}
+	u->npieces = (uint32_t)su->np;
+	su->wm_src = 0;
+	{
+		extern const uint32_t *k2a_wm_source(void);
+		su->wm_src = k2a_wm_source();
+	}
+	su->up = shared_upload_stream();
+	su->fault = env_flag(ENV(STREAM_FAULT), 0); su->sleep_us = ENV(STREAM_SLEEP_US) ? atoi(ENV(STREAM_SLEEP_US)) : 0;
+	su->src = p->h_seq; su->src_bytes = p->seq_bytes;
+	p->d_seq = (uint8_t*)cache_get(BUF_SEQ, p->seq_bytes, &p->cap[BUF_SEQ]);
+	p->d_wm = (uint8_t*)cache_get(BUF_WM, K2A_WM_BYTES + NCLS_ENTRIES * sizeof(K2aQueueDesc), &p->cap[BUF_WM]);
+	p->d_pairs = (K2aPair*)cache_get(BUF_PAIRS, sizeof(K2aPair) * ((size_t)n + 1), &p->cap[BUF_PAIRS]);
+	p->d_order = (uint32_t*)cache_get(BUF_ORDER, sizeof(uint32_t) * ((size_t)n + (size_t)nwt + 1), &p->cap[BUF_ORDER]);
+	p->d_res = (K2aResult*)cache_get(BUF_RES, sizeof(K2aResult) * ((size_t)n + 1), &p->cap[BUF_RES]);
+	p->d_tb = p->tb_bytes ? (uint8_t*)cache_get(BUF_TB, p->tb_bytes, &p->cap[BUF_TB]) : 0;
+	p->h_meta = (uint8_t*)cache_get(BUF_HMETA, 256, &p->cap[BUF_HMETA]);
+	p->h_qd = (K2aQueueDesc*)calloc(1, sizeof(K2aQueueDesc));
+	p->wm_ev = k2a_shim_event_create(); p->meta_ev = k2a_shim_event_create(); p->up_ev = k2a_shim_event_create();
+	if (!su->wm_src || !su->up || !p->d_seq || !p->d_wm || !p->d_pairs || !p->d_order || !p->d_res || (p->tb_bytes && !p->d_tb) || !p->h_meta || !p->h_qd ||
+	    !p->wm_ev || !p->meta_ev || !p->up_ev) { fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error()); goto err; }
+	su->d_seq = p->d_seq; su->d_wm = p->d_wm;
+	p->unscanned = 1; p->npieces = su->np; p->stream = su->up; p->stream_used = 1;
+	/* the launch's descriptor: the one thing that is uploaded besides the sequences (64 bytes, behind the zeroed watermark) */
+	{
+		const char *te = ENV(STREAM_TIMEOUT_MS);
+		p->nqd = 1; p->need_words = (size_t)nwt;
+		p->h_qd[0].nwt = (uint32_t)nwt; p->h_qd[0].timeout_ticks = (uint64_t)(te && atoi(te) > 0 ? atoi(te) : 2000) * 100000u;
+		p->h_qd[0].need = p->d_order + p->norder; p->h_qd[0].wm = (const uint32_t*)p->d_wm;
+		memcpy(p->h_meta, p->h_qd, sizeof(K2aQueueDesc));
+	}
+	if (k2a_shim_h2d(p->d_wm, (const uint8_t*)su->wm_src + (size_t)K2A_MAXPIECES * K2A_WM_BYTES, K2A_WM_BYTES, su->up) || k2a_shim_event_record(p->wm_ev, su->up) ||
+	    k2a_shim_h2d(p->d_wm + K2A_WM_BYTES, p->h_meta, sizeof(K2aQueueDesc), su->up) || k2a_shim_event_record(p->meta_ev, su->up)) {
+		fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error()); goto err;
+	}
+	su->hold = su->np;                                            /* nothing else has to get in front of the pieces */
+	p->streamed = 1;
+	/* the copy (and the host's per-pair arrays) on the pool's threads, piece by piece, each piece issued as it completes */
+	{
+		extern int gather_start_uniform(ksw2amd_plan_t *p, stream_up_t *su, const ksw2amd_pair_t *pairs, int n, int cls0, int flag0);
+		if (gather_start_uniform(p, su, pairs, n, cls0, flag0)) {      /* the pool cannot take it: here, piece by piece */
+			copy_ctx_t cc = { 0 };
+			memset(&cc, 0, sizeof(cc));
+			cc.h_seq = p->h_seq; cc.hp = p->h_pairs; cc.pairs = pairs; cc.su = su;
+			for (k = 0; k < su->np; ++k) {
+				uni_fill_range(u, p->h_pairs, p->h_cls, p->h_flag, p->h_order, cls0, flag0, su->pfirst[k], su->pfirst[k + 1]);
+				copy_range(&cc, su->pfirst[k], su->pfirst[k + 1]);
+				stream_issue(su, k);
+			}
+			if (su->rc || k2a_shim_event_record(p->up_ev, su->up)) { fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error()); goto err; }
+		}
+	}
+	plan_ready(p);
+	p->stream = su->up; p->stream_used = 1;
+	return p;
+na:
+err:
+	if (p && p->gather) gather_wait(p);
+	if (p && p->stream_used && p->stream) k2a_shim_stream_sync(p->stream);
+	{
+		char keep[sizeof(g_err)];
+		memcpy(keep, g_err, sizeof(keep));
+		ksw2amd_plan_destroy(p);
+		memcpy(g_err, keep, sizeof(keep));
+	}
+	return 0;
+}
+ksw2amd_plan_t *plan_create_uniform_entry(int dual, int scalar, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs) { return plan_create_uniform(dual, scalar, sc, n, pairs); }
+
 ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs)
 {
 	return plan_create_ex(dual, 0, sc, n, pairs, 0, 0);      /* (KSW2AMD_STREAM=1 streams these too: tests, A/B runs) */
@@ -1295,6 +1478,9 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 	streaming = p->streamed && p->nqd > 0;
 	if (p->up_ev && !streaming && k2a_shim_stream_wait_event(stream, p->up_ev)) goto err;      /* the plan's upload (shared stream) before its kernels */
 	if (p->reject_all || p->ntasks == 0) return KSW2AMD_OK;
+	/* uniform plans: the records, the task list and the piece counts are written on the device by rule (K2aUniform), in front of the
+	 * launches that read them; nothing of them was built or uploaded by the host */
+	if (p->uni && k2a_shim_launch_uniform_layout(p->uni, p->d_pairs, p->d_order, p->nqd ? p->d_order + p->norder : 0, stream)) goto err;
 	if (k2a_shim_event_record(p->ev[0], stream)) goto err;
 	if (streaming && ((p->wm_ev && k2a_shim_stream_wait_event(stream, p->wm_ev)) || (p->meta_ev && k2a_shim_stream_wait_event(stream, p->meta_ev)))) goto err;
 	if (streaming) {
@@ -1457,8 +1643,8 @@ int ksw2amd_plan_describe(const ksw2amd_plan_t *p, char *buf, int cap)
 		const int G = k->solo ? 64 : k->pk ? k2a_pkcfg_G[k->cfg] : k2a_cfg_G[k->cfg], C = k->solo ? 2 * K2A_SOLO_ROWS(k->mode == K2A_MODE_SCORE) : k->pk ? k2a_pkcfg_C[k->cfg] : k2a_cfg_C[k->cfg];
 		const int form = k->defer ? 3 : k->solo ? 0 : k->pk ? (k->cfg == K2A_PKCFG_MP ? 0 : k2a_shim_pk_form(k->cfg, p->dual, k->mode, k->nomax, k->count))
 		                                     : (k->cfg == K2A_CFG_MP ? k2a_shim_mp_form(p->dual, k->mode, k->count) : 0);
-		len += snprintf(buf + len, (size_t)(cap - len), "kernel=%s G=%d C=%d gaps=%d mode=%s rebased=%d nomax=%d generic=%d form=%s tasks=%d\n",
-		                kind, G, C, p->dual ? 2 : 1, mode_name[k->mode], k->rb, k->nomax, k->generic, form_name[form], k->count);
+		len += snprintf(buf + len, (size_t)(cap - len), "kernel=%s G=%d C=%d gaps=%d mode=%s rebased=%d nomax=%d generic=%d form=%s tasks=%d uniform=%d\n",
+		                kind, G, C, p->dual ? 2 : 1, mode_name[k->mode], k->rb, k->nomax, k->generic, form_name[form], k->count, p->uni ? 1 : 0);
 	}
 	return p->ncls;
 }

@@ -77,10 +77,12 @@ static void *pool_worker(void *arg_)
 	return 0;
 }
 
+/* > 0: the batch being cut wants this many workers per device instead of the default (run_batch: batches with CIGARs) */
+static __thread int g_job_threads;
 int pool_threads_per_device(void)
 {
 	const char *e = ENV(THREADS);
-	int t = e ? atoi(e) : 6;
+	int t = e ? atoi(e) : g_job_threads > 0 ? g_job_threads : 6;
 	return t < 0 ? 0 : t > 16 ? 16 : t;
 }
 
@@ -221,6 +223,8 @@ static int copy_chunk(void *ctx, int beg, int end, int share, pend_t *pd)
 	const copy_ctx_t *c = (const copy_ctx_t*)ctx;
 	(void)share; (void)pd;
 	if (beg >= 0) {
+		if (c->uni_plan)                                    /* a uniform plan: the host's per-pair arrays of this range first (copy_range reads the offsets) */
+			uni_fill_range(c->uni_plan->uni, c->uni_plan->h_pairs, c->uni_plan->h_cls, c->uni_plan->h_flag, c->uni_plan->h_order, c->uni_cls, c->uni_flag, beg, end);
 		copy_range(c, beg, end);
 		if (c->su) {                                        /* a streamed plan: this chunk is part of a piece of the upload; the piece's last chunk issues what is ready */
 			int k = 0;
@@ -344,7 +348,7 @@ int rerun_pairs(ksw2amd_plan_t *p, int nrerun, void *km, ksw_extz_t *ez, ksw_ext
  * gather_wait(), which also records the event that marks the end of the plan's upload. */
 #define K2A_GATHER_SUB 8                /* copy chunks per upload piece: the first piece is complete after an eighth of a piece's copy time, not a whole one */
 struct gather_s { job_t j; copy_ctx_t cc; int cbeg[K2A_MAXPIECES * K2A_GATHER_SUB + 2]; };
-int gather_start(ksw2amd_plan_t *p, stream_up_t *su, const ksw2amd_pair_t *pairs, int n)
+static int gather_start_ex(ksw2amd_plan_t *p, stream_up_t *su, const ksw2amd_pair_t *pairs, int n, int uniform, int cls0, int flag0)
 {
 	const int tpd = pool_threads_per_device();
 	struct gather_s *g;
@@ -356,6 +360,7 @@ int gather_start(ksw2amd_plan_t *p, stream_up_t *su, const ksw2amd_pair_t *pairs
 	nth = (int)(p->seq_bytes >> 22);                       /* a thread per 4 MB, between the batch workers' count and 24 */
 	nth = imax(tpd, imin(nth, 24)); nth = imin(nth, su->np * K2A_GATHER_SUB);
 	g->cc.h_seq = p->h_seq; g->cc.hp = p->h_pairs; g->cc.pairs = pairs; g->cc.wild = 0; g->cc.su = su;
+	g->cc.uni_plan = uniform ? p : 0; g->cc.uni_cls = cls0; g->cc.uni_flag = flag0;
 	{	/* the workers take the chunks in order (job_t.next), so the pieces complete roughly in order, the first one early */
 		int nc = 0, x;
 		for (k = 0; k < su->np; ++k) {
@@ -374,6 +379,8 @@ int gather_start(ksw2amd_plan_t *p, stream_up_t *su, const ksw2amd_pair_t *pairs
 	p->gather = g;
 	return 0;
 }
+int gather_start(ksw2amd_plan_t *p, stream_up_t *su, const ksw2amd_pair_t *pairs, int n) { return gather_start_ex(p, su, pairs, n, 0, 0, 0); }
+int gather_start_uniform(ksw2amd_plan_t *p, stream_up_t *su, const ksw2amd_pair_t *pairs, int n, int cls0, int flag0) { return gather_start_ex(p, su, pairs, n, 1, cls0, flag0); }
 int gather_wait(ksw2amd_plan_t *p)
 {
 	struct gather_s *g = p->gather;
@@ -590,7 +597,21 @@ int run_pooled(chunk_fn fn, void *ctx, int n, const double *cost, double total, 
 	return 1;
 }
 
+static int run_batch_(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez, const flat_src_t *flat);
 static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez, const flat_src_t *flat)
+{
+	/* Batches with CIGARs: eight workers per device instead of six.  A worker of such a batch spends most of a chunk's time waiting
+	 * for kernels and then bringing CIGARs back, the one-shape rule cuts 2^j chunks (config 3: eight), and eight chunks on six workers
+	 * are two rounds whose second runs on a third of the device (round 5, same box: config 3 717 -> 765-791 GCUPS end to end, config 5
+	 * 926 -> 1 028, 10 k with CIGAR unchanged; profiles/r5_e2e_threads_ab.txt).  Score-only batches keep six: their workers pack and
+	 * upload most of the time and more of them only share the host's memory bandwidth (config 2's chunks: 935 -> 580). */
+	int rc;
+	g_job_threads = n > 0 && pairs && !(pairs[0].flag & KSW_EZ_SCORE_ONLY) ? 8 : 0;
+	rc = run_batch_(dual, scalar, km, sc, n, pairs, ez, flat);
+	g_job_threads = 0;
+	return rc;
+}
+static int run_batch_(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez, const flat_src_t *flat)
 {
 	const int tpd = pool_threads_per_device();
 	if (n <= 0) return KSW2AMD_OK;
@@ -598,12 +619,15 @@ static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc
 	if (n >= (pool_min_pairs() ? pool_min_pairs() : 512) && tpd > 0 && !g_is_worker) {
 		const int workers = tpd * (g_ndev_set > 0 ? g_ndev_set : 1);
 		double *cost, bytes = 0, cells = 0, total = 0, path = 0, dev_bytes = 0;
-		int i, nchunks, rc = 0, uniform = 1, chunk_pairs = 0;
+		int i, nchunks, rc = 0, uniform = 1, chunk_pairs = 0, same = 1;      /* same: every pair equals pair 0 in every parameter, none is empty (plan_create_uniform) */
 		/* one shape for the whole batch (the BASELINE configurations, reads trimmed to one length)?  Then the sums below are n x
 		 * the first pair's terms and the per-pair costs are never looked at (uniform_chunks cuts at fixed sizes): this loop was
 		 * 1.5-2 ms of the calling thread's time on config 2's 65 536 pairs, in front of a 1.4 ms kernel */
-		for (i = 1; i < n; ++i)
+		for (i = 1; i < n; ++i) {
 			if (pairs[i].qlen != pairs[0].qlen || pairs[i].tlen != pairs[0].tlen || pairs[i].w != pairs[0].w || ((pairs[i].flag ^ pairs[0].flag) & KSW_EZ_SCORE_ONLY)) { uniform = 0; break; }
+			if (pairs[i].zdrop != pairs[0].zdrop || pairs[i].end_bonus != pairs[0].end_bonus || pairs[i].flag != pairs[0].flag || !pairs[i].query || !pairs[i].target) same = 0;
+		}
+		if (!uniform || pairs[0].qlen <= 0 || pairs[0].tlen <= 0) same = 0;
 		if (uniform) dev_bytes = (double)n * (double)pair_device_bytes(dual, &pairs[0]);
 		else for (i = 0; i < n; ++i) dev_bytes += (double)pair_device_bytes(dual, &pairs[i]);
 		/* One-shape score-only batches that fit the device: ONE streamed plan (section "streamed plans") instead of chunks -- a
@@ -613,12 +637,25 @@ static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc
 		 * whose plan creation on one thread costs what six workers' chunks cost together (config 2: 3.9 against 3.4-4.0 ms) -- so by
 		 * default batches of at least 1 M cells per pair.  KSW2AMD_STREAM=1: every one-shape score-only batch; =0: chunks. */
 		if (uniform && (pairs[0].flag & KSW_EZ_SCORE_ONLY) && stream_env() != 0 && g_ndev_set <= 1 && !pool_min_pairs() &&
-		    (double)n * ((double)imax(pairs[0].qlen, 0) + imax(pairs[0].tlen, 0)) >= 4.0 * 1048576.0) {
+		    ((double)n * ((double)imax(pairs[0].qlen, 0) + imax(pairs[0].tlen, 0)) >= 4.0 * 1048576.0 || (same && ENV(UNIFORM) && atoi(ENV(UNIFORM)) == 1))) {      /* (KSW2AMD_UNIFORM=1: tests, small batches) */
 			const int mx0 = imax(pairs[0].qlen, pairs[0].tlen);
 			const int64_t c0 = pairs[0].qlen > 0 && pairs[0].tlen > 0 ? band_cells(pairs[0].qlen, pairs[0].tlen, (pairs[0].w < 0 || pairs[0].w > mx0) ? mx0 : pairs[0].w) : 0;
 			size_t free_b = 0, total_b = 0;
-			if ((stream_env() == 1 || c0 >= stream_min_cells()) &&
-			    (dev_bytes <= 256e6 || (k2a_shim_mem_info(&free_b, &total_b) == 0 && dev_bytes <= (double)device_budget(free_b, total_b, 1))))
+			const int fits = dev_bytes <= 256e6 || (k2a_shim_mem_info(&free_b, &total_b) == 0 && dev_bytes <= (double)device_budget(free_b, total_b, 1));
+			/* one shape AND one set of parameters, from ordinary host memory: a uniform plan (ksw2_host_plan.c "uniform batches") -- no
+			 * per-pair work on this thread, the records built on the device, ONE streamed launch -- whatever the reads' length (round 5:
+			 * config 2, whose plan creation used to cost more than its kernel, goes this way too) */
+			if (same && fits && !flat) {
+				ksw2amd_plan_t *up = plan_create_uniform_entry(dual, scalar, sc, n, pairs);
+				if (up) {
+					rc = ksw2amd_plan_run(up, g_plan_stream ? g_plan_stream : thread_stream());
+					if (rc == KSW2AMD_OK) rc = ksw2amd_plan_fetch(up, km, ez);
+					ksw2amd_plan_destroy(up);
+					return rc;
+				}
+				if (g_err[0]) return strstr(g_err, "alloc") ? KSW2AMD_E_NOMEM : strstr(g_err, "device") || strstr(g_err, "upload") ? KSW2AMD_E_NODEVICE : KSW2AMD_E_PARAM;
+			}
+			if ((stream_env() == 1 || c0 >= stream_min_cells()) && fits)
 				return run_serial(dual, scalar, km, sc, n, pairs, ez, 1, flat, 1);
 		}
 		cost = (double*)malloc(sizeof(double) * (size_t)n);

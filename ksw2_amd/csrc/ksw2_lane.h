@@ -504,6 +504,25 @@ K2A_FN int k2a_trace_pair(const uint8_t *tb, int i, int j, uint32_t *out, int ql
 	return k2a_trace_walk<G, C, DUAL ? 1 : 0, MP>(tb, 0, i, j, out, qlen, tlen, w);
 }
 
+/* Uniform plans (K2aUniform): record of pair i, and the pieces wavefront-task wt of a streamed launch waits for -- the rules the
+ * host's gather follows when it copies the sequences (ksw2_host_plan.c: uni_fill_range) */
+K2A_FN K2aPair k2a_uniform_pair(const K2aUniform &u, uint32_t i)
+{
+	K2aPair p = u.tmpl;
+	p.qoff = i * u.stride; p.toff = i * u.stride + u.qpad;
+	if (u.defer) p.tb_off = u.blk_base + (uint64_t)((i >> 1) / u.ng) * u.blk_bytes;
+	return p;
+}
+K2A_FN uint32_t k2a_uniform_need(const K2aUniform &u, uint32_t wt)
+{
+	const uint32_t last = k2a_min((int)u.n, (int)((wt + 1) * u.ng * 2)) - 1;                    /* the task's pairs lie in the arena in index order */
+	uint64_t lim = (uint64_t)last * u.stride + u.qpad + (uint32_t)u.tmpl.tlen_full + u.margin;
+	if (lim > u.seq_bytes) lim = u.seq_bytes;
+	uint32_t k = 0;
+	while (k + 1 < u.npieces && u.pb[k + 1] < lim) ++k;
+	return k + 1;
+}
+
 /* Finish one alignment after the fill: turn the bookkeeping state into the ksw_extz_t fields and pick
  * the traceback start (ksw2_extz2_sse.c:292-301 / ksw2_extz.c:127-133; SURVEY 8a rules 6-7). */
 K2A_FN void k2a_finish(const K2aPair &pr, const K2aBook &b, K2aResult *r)

@@ -100,6 +100,10 @@ int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax,
 int k2a_shim_launch_trace_pk(int cfg, int dual, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb,
                              K2aResult *res, uint32_t *cig, void *stream);
 
+/* uniform plans (K2aUniform, ksw2_types.h): write pairs[n], order2[2 * ntasks] and -- need != NULL -- the streamed launch's
+ * need[ceil(ntasks / ng)] on the device */
+int k2a_shim_launch_uniform_layout(const K2aUniform *u, K2aPair *pairs, uint32_t *order2, uint32_t *need, void *stream);
+
 /* Packed generation-serial fill (class K2A_PKCFG_MP): one task (two same-shape alignments) per workgroup of four wavefronts that
  * pipeline the task's generations of 1024 target rows.  Both K2aPair entries of a task share bnd_off: K2A_PKMP_BND_WORDS
  * (ksw2_lane_pkmp.h) uint32 of boundary entries followed by K2A_PKMP_WAVES x K2A_PKMP_SPILL_WORDS(16) of row-maximum keys, 16-byte aligned;

@@ -897,6 +897,18 @@ k2a_compact_kernel(const K2aPair *__restrict__ pairs, const K2aResult *__restric
 	for (int k = threadIdx.x; k < nc; k += 64) dst[k] = src[rev ? k : nc - 1 - k];
 }
 
+/* uniform plans (K2aUniform): the batch's records, task list and piece counts by rule, one thread per pair */
+__global__ void __launch_bounds__(256)
+k2a_uniform_layout_kernel(const K2aUniform u, K2aPair *__restrict__ pairs, uint32_t *__restrict__ order2, uint32_t *__restrict__ need)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < u.n) {
+		pairs[i] = k2a_uniform_pair(u, i);
+		order2[i] = i;                                                    /* task t = pairs 2t, 2t + 1 */
+	}
+	if (need && i < (u.ntasks + u.ng - 1) / u.ng) need[i] = k2a_uniform_need(u, i);
+}
+
 /* ---------------------------------------------------------------- dispatch tables */
 
 typedef void (*fill_fn)(const K2aScoring, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*);
@@ -1958,6 +1970,14 @@ int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax,
 	                    : qd ? g_fill_pkq[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode];
 	hipLaunchKernelGGL(fn, dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
 	                   *sc, pairs, order2, ntasks, seq, tb, res, qd);
+	CHECK(hipGetLastError());
+	return 0;
+}
+
+int k2a_shim_launch_uniform_layout(const K2aUniform *u, K2aPair *pairs, uint32_t *order2, uint32_t *need, void *stream)
+{
+	if (!u || u->n == 0) return 0;
+	hipLaunchKernelGGL(k2a_uniform_layout_kernel, dim3((u->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *u, pairs, order2, need);
 	CHECK(hipGetLastError());
 	return 0;
 }

@@ -147,6 +147,22 @@ typedef struct K2aQueueDesc {
  * { count, entries (task * 2 + half) ... }, lies in the traceback arena right in front of the class's first checkpoint block */
 #define K2A_ZLIST_WORDS(ntasks) ((2 * (size_t)(ntasks) + 16 + 63) & ~(size_t)63)
 
+/* Uniform plans (ksw2_host_plan.c "uniform batches"): a score-only batch whose pairs all have ONE shape and ONE set of parameters is
+ * laid out by rule -- pair i's query at i * stride, its target at i * stride + qpad -- so its K2aPair records, its task list (pairs
+ * 2t and 2t + 1 form task t) and a streamed launch's per-wavefront-task piece counts are functions of i: a small kernel
+ * (k2a_uniform_layout_kernel) writes them where the fill kernels read them, and the host neither builds nor uploads them. */
+#define K2A_UNI_MAXPIECES 48
+typedef struct K2aUniform {
+	K2aPair tmpl;                    /* everything but qoff / toff / tb_off */
+	uint32_t n, ntasks, ng;          /* pairs; tasks (n / 2); tasks per wavefront-task (64 / G) */
+	uint32_t stride, qpad;           /* bytes from one pair's query to the next pair's; from a pair's query to its target */
+	uint32_t defer;                  /* deferred arg-max: one checkpoint block per wavefront-task */
+	uint64_t blk_base, blk_bytes;    /* ... block wt at blk_base + wt * blk_bytes (K2aPair.tb_off of its pairs; bnd_off / cig_off come with the template) */
+	uint32_t npieces, margin;        /* streamed launches: upload pieces; bytes past a target's end the kernels may touch */
+	uint64_t seq_bytes;
+	uint64_t pb[K2A_UNI_MAXPIECES + 1];    /* piece k = arena bytes [pb[k], pb[k + 1]) */
+} K2aUniform;
+
 /* per-group bookkeeping state (LDS on the GPU): the scalar reference's ez fields while rows complete */
 typedef struct K2aBook {
 	int32_t max, max_t, max_q, mqe, mqe_t, mte, mte_q, score, dropped, rows;

@@ -1086,6 +1086,14 @@ int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax,
 	if (ntasks > 0) (lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1] : ldc ? g_fill_pk_ldscodes[k2a_pkcfg_G[cfg] == 8 ? 1 : k2a_pkcfg_G[cfg] == 16 ? 2 : 0][nomax ? 1 : 0][rebased ? 1 : 0] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode])(*sc, pairs, order2, ntasks, seq, tb, res, qd);
 	return 0;
 }
+int k2a_shim_launch_uniform_layout(const K2aUniform *u, K2aPair *pairs, uint32_t *order2, uint32_t *need, void *)
+{
+	if (!u) return 0;
+	for (uint32_t i = 0; i < u->n; ++i) { pairs[i] = k2a_uniform_pair(*u, i); order2[i] = i; }
+	if (need) for (uint32_t wt = 0; wt < (u->ntasks + u->ng - 1) / u->ng; ++wt) need[wt] = k2a_uniform_need(*u, wt);
+	return 0;
+}
+
 int k2a_shim_launch_trace_pk(int cfg, int dual, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb,
                              K2aResult *res, uint32_t *cig, void *)
 {

@@ -1080,6 +1080,33 @@ def test_frozen_books_with_wildcards(lib, monkeypatch):
     _check_frozen_books_with_wildcards(lib, monkeypatch)
 
 
+def test_uniform_plans(lib, monkeypatch):
+    """tests/test_sim_parity.py::_check_uniform_plans on the device: small forced batches of three shapes (plain class, deferred arg-max
+    forced on and off, Z-drops, wildcards, the fault hook), then config 2 at full size through the default routing: ONE uniform
+    streamed plan, every record against the general path's."""
+    from tests.test_sim_parity import _check_uniform_plans
+    _check_uniform_plans(lib, monkeypatch, [(2048, 60, 64, 10, -1, None), (4098, 300, 290, 30, 40, 1), (2048, 700, 700, 300, 100, 1), (3000, 512, 512, 64, 100, 0)])
+    for k in ("KSW2AMD_UNIFORM", "KSW2AMD_STREAM_PIECE_KB", "KSW2AMD_STREAM_SLEEP_US", "KSW2AMD_STREAM_FAULT", "KSW2AMD_STREAM_TIMEOUT_MS", "KSW2AMD_DEFER", "KSW2AMD_SIMDS"):
+        monkeypatch.delenv(k, raising=False)
+    q, t = synth.fast_fixed(2, 65536, 512, 512, sub=0.05, ind=0.06)
+    mat = synth.simple_mat(5, 2, 4, -1)
+    b = lib.make_batch(q, t, mat, 4, 2, 0, 0, w=64, zdrop=-1, end_bonus=0, flag=po.SCORE_ONLY)
+    s0 = lib.stream_stats()
+    ez1, v1 = _raw_batch(lib, False, b)
+    assert lib.stream_stats()["streamed_plans"] == s0["streamed_plans"] + 1      # the default routing took the uniform plan
+    monkeypatch.setenv("KSW2AMD_UNIFORM", "0")
+    ez0, v0 = _raw_batch(lib, False, b)
+    try:
+        for f in _EZ_DT.names:
+            if f not in ("cigar", "m_cigar"):
+                assert (v0[f] == v1[f]).all(), (f, np.flatnonzero(v0[f] != v1[f])[:5])
+        for i in range(0, 65536, 4099):
+            exp = po.align("oracle", "extz2", q[i], t[i], mat, 4, 2, w=64, zdrop=-1, end_bonus=0, flag=po.SCORE_ONLY)
+            assert exp["score"] == v1["score"][i] and exp["max"] == (v1["max_zd"][i] & 0x7fffffff) and exp["max_q"] == v1["max_q"][i] and exp["mte_q"] == v1["mte_q"][i], i
+    finally:
+        _free_raw(ez0, v0); _free_raw(ez1, v1)
+
+
 def test_lane_primitives_match_their_simulator_twins(tmp_path):
     """tools/probe/lane_ops_probe.hip: every register primitive of the packed kernels (inline asm / builtins: v_perm_b32 with every
     selector byte value, v_bitop3_b32 0xe4, v_pk_mad_i16, v_pk_maximum3_f16, v_pk_ashrrev_i16 ...) on the device against the C twin the

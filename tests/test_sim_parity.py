@@ -965,6 +965,59 @@ def test_sim_streamed_plans(sim, monkeypatch, flat):
                 assert not d, (ci, flat, fault, i, d)
 
 
+def _check_uniform_plans(lib, monkeypatch, shapes):
+    """Uniform plans (ksw2_host_plan.c "uniform batches", round 5): a score-only batch of one shape and one set of parameters handed to
+    the batch entry point -- the class from a two-pair probe, the records / task list / piece counts written on the device by rule
+    (k2a_uniform_layout_kernel), one streamed launch, the host's per-pair arrays filled by the copy's workers.  Forced off
+    (KSW2AMD_UNIFORM=0: the general path) against the default on every pair, both against the oracle on a sample; the plain and the
+    deferred arg-max class, Z-drops (frozen books), wildcards in queries (scored in place) and in targets (handed back and re-run
+    from the uniform plan's own host arrays), small pieces with a slowed-down upload, and the fault hook (the launch gives up, the
+    plan is repeated unstreamed from the same device-built records)."""
+    monkeypatch.setenv("KSW2AMD_SIMDS", "0")
+    mat = synth.simple_mat(5, 2, 4, -1)
+    for si, (n, ql, tl, w, zd, defer) in enumerate(shapes):
+        qs, ts = synth.fixed_batch(9100 + si, n, ql, tl, sub=0.05, ind=0.06, tail_random_frac=0.3, tail_pairs=0.2)
+        qs, ts = [np.array(x) for x in qs], [np.array(x) for x in ts]
+        qs[5][ql // 2] = 4; ts[n // 2][tl // 3] = 4; ts[n - 1][0] = 4
+        fl = po.SCORE_ONLY | (po.EXTZ_ONLY if si % 2 else 0)
+
+        def run(**env):
+            for k in ("KSW2AMD_UNIFORM", "KSW2AMD_STREAM_PIECE_KB", "KSW2AMD_STREAM_SLEEP_US", "KSW2AMD_STREAM_FAULT", "KSW2AMD_STREAM_TIMEOUT_MS", "KSW2AMD_DEFER"):
+                monkeypatch.delenv(k, raising=False)
+            if defer is not None:
+                monkeypatch.setenv("KSW2AMD_DEFER", str(defer))
+            for k, v in env.items():
+                monkeypatch.setenv(k, str(v))
+            s0, r0 = lib.stream_stats(), lib.rerun_count()
+            res = lib.extz_batch(qs, ts, mat, 4, 2, w=w, zdrop=zd, end_bonus=7, flag=fl)
+            s1 = lib.stream_stats()
+            return res, s1["streamed_plans"] - s0["streamed_plans"], s1["aborted_runs"] - s0["aborted_runs"], lib.rerun_count() - r0
+
+        off, ns, na, nr = run(KSW2AMD_UNIFORM=0)
+        decoy = ([np.random.default_rng(3 + si).integers(0, 4, ql, dtype=np.uint8) for _ in range(n)], [np.random.default_rng(5 + si).integers(0, 4, tl, dtype=np.uint8) for _ in range(n)])
+        keep = (qs, ts)
+        qs, ts = decoy
+        run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64)     # a decoy batch of the same shape through the same buffers first
+        qs, ts = keep
+        on, ns, na, nr = run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64, KSW2AMD_STREAM_SLEEP_US=100)
+        assert ns == 1 and na == 0 and nr == 4, (si, ns, na, nr)       # ONE streamed plan; the two tasks that hold a target wildcard were handed back (both pairs of a task)
+        b = lib.make_batch(qs, ts, mat, 4, 2, 0, 0, w=w, zdrop=zd, end_bonus=7, flag=fl)
+        bad = [i for i in range(n) if diff(off[i], on[i])]
+        assert not bad, (si, bad[:5], off[bad[0]], on[bad[0]])
+        flt, ns, na, nr = run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64, KSW2AMD_STREAM_FAULT=1, KSW2AMD_STREAM_TIMEOUT_MS=20)
+        assert ns == 1 and na == 1, (si, ns, na)
+        bad = [i for i in range(n) if diff(off[i], flt[i])]
+        assert not bad, (si, "fault", bad[:5])
+        for i in list(range(0, n, max(1, n // 24))) + [5, n // 2, n - 1]:
+            exp = po.align("oracle", "extz2", qs[i], ts[i], mat, 4, 2, w=w, zdrop=zd, end_bonus=7, flag=fl)
+            assert not diff(exp, on[i], CMP), (si, i, diff(exp, on[i], CMP))
+        del b
+
+
+def test_sim_uniform_plans(sim, monkeypatch):
+    _check_uniform_plans(sim, monkeypatch, [(2048, 60, 64, 10, -1, None), (2050, 150, 140, 30, 40, 1), (2048, 90, 90, 70, 100, 0)])
+
+
 class ApproxLike:
     """KSW_EZ_APPROX_MAX returns only the score (and the corner CIGAR): the exact computation's score without Z-drop."""
     @staticmethod
