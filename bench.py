@@ -349,6 +349,9 @@ class Job:
     def resident(self, steps, warmup, stream, min_seconds=0.0):
         wl = self.wl
         nres = wl.get("resident_n")
+        if os.environ.get("KSW2_BENCH_ONE_DEVICE") and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            # the host-contention rehearsal (N ranks on ONE GPU): the ranks' resident plans share one device's memory
+            nres = max(256, (nres or self.n) // int(os.environ["WORLD_SIZE"]))
         b = self.batch
         if nres and nres < self.n:          # a plan of the whole batch does not fit one device: a slice of it
             S = SCORING

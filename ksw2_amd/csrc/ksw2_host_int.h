@@ -14,6 +14,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <pthread.h>
+#include <sched.h>
 #include <string.h>
 #include <time.h>
 #include "../../include/ksw2_amd.h"
@@ -56,6 +57,7 @@
 	X(NO_PKMP) \
 	X(NO_RB) \
 	X(NO_SHARED_UP) \
+	X(PIN) \
 	X(PK_FIRST) \
 	X(POOL_MIN) \
 	X(SERIAL) \

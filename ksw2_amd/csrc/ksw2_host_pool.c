@@ -39,6 +39,36 @@ static int job_has_dev(const job_t *j, int dev)
 
 typedef struct { int idx, dev, seen; } worker_arg_t;
 
+/* The pool's threads run on the cores next to their GPU: its PCI function's local_cpulist under /sys (the NUMA node the device hangs
+ * off).  What they do all day is copy sequences into page-locked staging that the device's DMA engines read: from the other socket
+ * every byte crosses the inter-socket link twice.  Intersected with the affinity the process already has (a launcher's or bench.py's
+ * per-rank pinning stays in force); no /sys entry, an empty intersection or KSW2AMD_PIN=0: nothing is changed. */
+static void pin_worker_to_device_node(void)
+{
+	char bdf[64], path[160], line[4096];
+	cpu_set_t have, want;
+	FILE *fp;
+	char *c;
+	int n = 0;
+	if (ENV(PIN) && atoi(ENV(PIN)) == 0) return;
+	if (k2a_shim_pci_bus_id(bdf, (int)sizeof(bdf)) || sched_getaffinity(0, sizeof(have), &have)) return;
+	snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+	fp = fopen(path, "r");
+	if (!fp) return;
+	if (!fgets(line, sizeof(line), fp)) { fclose(fp); return; }
+	fclose(fp);
+	CPU_ZERO(&want);
+	for (c = line; *c && *c != '\n'; ) {                    /* "0-63,128-191" */
+		char *e;
+		long a = strtol(c, &e, 10), b = a;
+		if (e == c) break;
+		if (*e == '-') { c = e + 1; b = strtol(c, &e, 10); }
+		for (; a <= b && a < CPU_SETSIZE; ++a) if (CPU_ISSET((int)a, &have)) { CPU_SET((int)a, &want); ++n; }
+		c = *e == ',' ? e + 1 : e;
+	}
+	if (n >= 2) sched_setaffinity(0, sizeof(want), &want);
+}
+
 static void *pool_worker(void *arg_)
 {
 	worker_arg_t *arg = (worker_arg_t*)arg_;
@@ -47,6 +77,7 @@ static void *pool_worker(void *arg_)
 	free(arg);
 	g_is_worker = 1;
 	k2a_shim_set_device(dev);
+	pin_worker_to_device_node();
 	pthread_mutex_lock(&g_pool.mu);
 	for (;;) {
 		job_t *j;

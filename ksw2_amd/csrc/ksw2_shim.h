@@ -37,6 +37,7 @@ int   k2a_shim_async_launches(void);         /* 1: launches run on the device be
 int   k2a_shim_device_count(void);
 int   k2a_shim_simd_count(void);               /* SIMDs (wavefront slots side by side) of the current device; 0 = unknown */
 int   k2a_shim_set_device(int dev);
+int   k2a_shim_pci_bus_id(char *buf, int cap);  /* the current device's directory name under /sys/bus/pci/devices; -1 = unknown */
 int   k2a_shim_get_device(void);             /* device of the calling thread; -1 = none */
 int   k2a_shim_mem_info(size_t *free_b, size_t *total_b);
 

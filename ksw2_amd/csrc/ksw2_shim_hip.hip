@@ -1827,6 +1827,15 @@ int k2a_shim_simd_count(void)
 	return simds[dev] = 4 * cus;
 }
 
+/* "dddd:bb:dd.f" of the current device (its directory name under /sys/bus/pci/devices), or -1 */
+int k2a_shim_pci_bus_id(char *buf, int cap)
+{
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(buf, cap, dev) != hipSuccess) return -1;
+	for (char *c = buf; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+	return 0;
+}
+
 int k2a_shim_set_device(int dev) { CHECK(hipSetDevice(dev)); return 0; }
 int k2a_shim_get_device(void) { int dev = -1; return hipGetDevice(&dev) == hipSuccess ? dev : -1; }
 

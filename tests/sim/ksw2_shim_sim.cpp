@@ -1025,6 +1025,7 @@ const char *k2a_shim_last_error(void) { return g_err; }
 static thread_local int g_sim_dev = 0;
 int k2a_shim_device_count(void) { const char *e = getenv("KSW2AMD_SIM_DEVICES"); const int n = e ? atoi(e) : 1; return n > 0 ? n : 1; }
 int k2a_shim_simd_count(void) { const char *e = getenv("KSW2AMD_SIM_SIMDS"); return e ? atoi(e) : 0; }      /* tests of the host's chunking rules: a small simulated device */
+int k2a_shim_pci_bus_id(char *, int) { return -1; }
 int k2a_shim_set_device(int dev) { if (dev < 0 || dev >= k2a_shim_device_count()) return -1; g_sim_dev = dev; return 0; }
 int k2a_shim_get_device(void) { return g_sim_dev; }
 int k2a_shim_mem_info(size_t *free_b, size_t *total_b) { *free_b = (size_t)8 << 30; *total_b = (size_t)8 << 30; return 0; }

@@ -1,0 +1,12 @@
+#!/bin/bash
+# GPU box: tools/scripts/profile_round.sh for every workload of bench.py's default `also` list + the headline.
+#   usage: tools/scripts/profile_all.sh <tag> [workload ...]      -> gpurun_out/profiles/<tag>_<workload>_{kernel_stats.csv,pmc.json}
+TAG=${1:-r5p}; shift
+WLS=${@:-10k 10k-n1024 10k-cigar cfg2 cfg3 cfg5 cfg4 10k-zdrop 10k-N 10k-generic exts extf 10k-ssec}
+for wl in $WLS; do
+	st=3; case $wl in cfg2) st=10;; exts|extf|10k-n1024) st=6;; esac
+	t0=$(date +%s)
+	bash tools/scripts/profile_round.sh $TAG $wl $st > gpurun_out/prof_${TAG}_${wl}.log 2>&1
+	echo "$wl: $(( $(date +%s) - t0 )) s; $(tail -c 200 gpurun_out/prof_${TAG}_${wl}.log | tr '\n' ' ')"
+	rm -rf gpurun_out/prof_${TAG}_${wl}          # the raw rocprofv3 output; the summaries are under gpurun_out/profiles/
+done
