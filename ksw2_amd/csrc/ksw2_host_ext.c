@@ -477,6 +477,7 @@ int wants_ssec(int flag)
 /* state bytes per alignment up to which the SSE-compatible kernel keeps them in LDS.  What the LDS form gains in latency it loses
  * in wavefronts per CU: 512-base reads (4.6 KB) 106 -> 133 GCUPS, 2 048-base reads (18-22 KB: seven wavefronts per CU) 126 -> 79 */
 #define SSEC_LDS_MAX ((size_t)8 * 1024)
+#define SSECB_SPAN 960                /* = K2A_SSECB_SPAN (ksw2_lane_ssecb.h) */
 static int ssec_ncol(int qlen, int tlen, int w)            /* = k2a_ssec_ncol (ksw2_lane_ssec.h) */
 {
 	const int n = imin(imin(qlen, tlen), w + 1);
@@ -498,7 +499,7 @@ ksw2amd_plan_t *ksw2amd_sse_plan_create(int dual, const ksw2amd_scoring_t *sc, i
 	int i, k, mode, m, q, e, q2, e2, lo;
 	size_t off, mat_off;
 	void *up;
-	uint32_t fill[6];
+	uint32_t fill[9];
 
 	g_err[0] = 0;
 	if (n < 0 || (n > 0 && !pairs) || !sc) { fail(KSW2AMD_E_PARAM, "sse plan: bad arguments%s", 0); return 0; }
@@ -530,12 +531,17 @@ ksw2amd_plan_t *ksw2amd_sse_plan_create(int dual, const ksw2amd_scoring_t *sc, i
 		mx = imax(a->qlen, a->tlen);
 		if (w < 0 || w > mx) w = mx;                                       /* a wider band than the sequences changes nothing (ksw2_extz2_sse.c:72) */
 		mode = (fl & KSW_EZ_SCORE_ONLY) ? K2A_MODE_SCORE : (fl & KSW_EZ_RIGHT) ? K2A_MODE_RIGHT : K2A_MODE_LEFT;
-		{	/* state arrays of up to SSEC_LDS_MAX bytes live in LDS (k2a_ssec_kernel<.., LDS = true>); KSW2AMD_SSEC_HBM=1: never (tests) */
+		{	/* kernel form.  2: state in registers (k2a_ssec_blk_kernel: score-only, simple scoring, bands up to SSECB_SPAN positions;
+			 * KSW2AMD_SSEC_BLK=0: never); 1: state arrays of up to SSEC_LDS_MAX bytes in LDS (k2a_ssec_kernel<.., LDS = true>);
+			 * 0: in HBM scratch (KSW2AMD_SSEC_HBM=1: always, tests) */
 			const size_t sb = (size_t)(dual ? 11 : 9) * (size_t)((a->tlen + 15) / 16 * 16);
-			const int lds = sb <= SSEC_LDS_MAX && !ENV(SSEC_HBM);
-			p->h_cls[i] = (int8_t)(mode + 3 * lds);
-			++p->s_count[mode][0][lds];
-			if (lds && sb > p->c_lds[mode]) p->c_lds[mode] = sb;
+			const char *blk = ENV(SSEC_BLK);
+			int form = sb <= SSEC_LDS_MAX;
+			if (mode == K2A_MODE_SCORE && !(fl & KSW_EZ_GENERIC_SC) && imin(imin(a->qlen, a->tlen), w + 1) <= SSECB_SPAN && !(blk && blk[0] == '0')) form = 2;
+			if (ENV(SSEC_HBM)) form = 0;
+			p->h_cls[i] = (int8_t)(mode + 3 * form);
+			++p->s_count[mode][0][form];
+			if (form == 1 && sb > p->c_lds[mode]) p->c_lds[mode] = sb;
 		}
 		d->qlen = a->qlen; d->tlen = d->tlen_full = a->tlen; d->w = w;
 		d->zdrop = a->zdrop; d->end_bonus = a->end_bonus;
@@ -563,7 +569,7 @@ ksw2amd_plan_t *ksw2amd_sse_plan_create(int dual, const ksw2amd_scoring_t *sc, i
 	p->seq_bytes = off;
 	p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, p->seq_bytes, &p->cap[BUF_HSEQ]);
 	if (!p->h_seq) { fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
-	for (k = 0, mode = 0; mode < 6; ++mode) { p->s_first[mode % 3][0][mode / 3] = k; fill[mode] = (uint32_t)k; k += p->s_count[mode % 3][0][mode / 3]; }
+	for (k = 0, mode = 0; mode < 9; ++mode) { p->s_first[mode % 3][0][mode / 3] = k; fill[mode] = (uint32_t)k; k += p->s_count[mode % 3][0][mode / 3]; }
 	p->ntasks = p->norder = k;
 	for (i = 0; i < n; ++i) {
 		if (p->h_cls[i] < 0) continue;
@@ -616,6 +622,8 @@ int ssec_plan_run(ksw2amd_plan_t *p, void *stream)
 	if (p->up_ev && k2a_shim_stream_wait_event(stream, p->up_ev)) goto err;      /* the plan's upload (shared stream) before its kernels */
 	if (p->reject_all || p->ntasks == 0) return KSW2AMD_OK;
 	if (k2a_shim_event_record(p->ev[0], stream)) goto err;
+	if (p->s_count[0][0][2] &&
+	    k2a_shim_launch_ssec_blk(p->dual, &p->c_par, p->d_pairs, p->d_order + p->s_first[0][0][2], p->s_count[0][0][2], p->d_seq, p->d_res, stream)) goto err;
 	for (mode = 0; mode < 6; ++mode)
 		if (p->s_count[mode % 3][0][mode / 3] &&
 		    k2a_shim_launch_ssec(p->dual, mode % 3, mode / 3 ? p->c_lds[mode % 3] : 0, &p->c_par, p->d_pairs, p->d_order + p->s_first[mode % 3][0][mode / 3],

@@ -65,6 +65,7 @@
 	X(SMALL_CELLS) \
 	X(SOLO) \
 	X(SSEC_HBM) \
+	X(SSEC_BLK) \
 	X(SSE_COMPAT) \
 	X(STREAM) \
 	X(STREAM_FAULT) \

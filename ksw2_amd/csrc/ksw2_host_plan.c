@@ -1627,11 +1627,12 @@ int ksw2amd_plan_describe(const ksw2amd_plan_t *p, char *buf, int cap)
 			}
 		return nl;
 	}
-	if (p->splice == 3 && !p->reject_all) {          /* SSE-compatible plans: state arrays in LDS or in HBM scratch */
+	if (p->splice == 3 && !p->reject_all) {          /* SSE-compatible plans: state arrays in HBM scratch, in LDS or in registers */
+		static const char *const form_name[3] = { "hbm", "lds", "blk" };
 		int nl = 0, mode, lds;
-		for (mode = 0; mode < 3; ++mode) for (lds = 0; lds < 2 && len < cap - 1; ++lds)
+		for (mode = 0; mode < 3; ++mode) for (lds = 0; lds < 3 && len < cap - 1; ++lds)
 			if (p->s_count[mode][0][lds]) {
-				len += snprintf(buf + len, (size_t)(cap - len), "kernel=ssec gaps=%d mode=%s form=%s tasks=%d\n", p->dual ? 2 : 1, mode_name[mode], lds ? "lds" : "hbm", p->s_count[mode][0][lds]);
+				len += snprintf(buf + len, (size_t)(cap - len), "kernel=ssec gaps=%d mode=%s form=%s tasks=%d\n", p->dual ? 2 : 1, mode_name[mode], form_name[lds], p->s_count[mode][0][lds]);
 				++nl;
 			}
 		return nl;

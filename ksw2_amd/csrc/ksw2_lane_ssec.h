@@ -135,15 +135,16 @@ K2A_FN void k2a_ssec_cell(const K2aSsec &P, int s, int xt1, int vt1, int x2t1, i
 template<bool DUAL>
 K2A_FN int k2a_ssec_dh(const K2aSsec &P, int byte) { return DUAL ? k2a_s8(byte) : k2a_u8(byte) - (P.q + P.e); }
 
-/* ksw_apply_zdrop with is_rot = 1 (ksw2.h:191-207) on the book; returns 1 on a drop */
+/* ksw_apply_zdrop with is_rot = 1 (ksw2.h:191-207) on the book; returns 1 on a drop.  Written as selects: from an if / else that
+ * stores to different fields hipcc makes ONE store through a selected address, and the book leaves its registers for scratch memory. */
 K2A_FN int k2a_ssec_zdrop(K2aBook *b, int H, int r, int t, int zdrop, int slope)
 {
-	if (H > b->max) { b->max = H; b->max_t = t; b->max_q = r - t; }
-	else if (t >= b->max_t && r - t >= b->max_q) {
-		const int tl = t - b->max_t, ql = (r - t) - b->max_q, l = tl > ql ? tl - ql : ql - tl;
-		if (zdrop >= 0 && b->max - H > zdrop + l * slope) { b->dropped = 1; return 1; }
-	}
-	return 0;
+	const bool up = H > b->max;
+	const int tl = t - b->max_t, ql = (r - t) - b->max_q, l = tl > ql ? tl - ql : ql - tl;
+	const int drop = (!up && tl >= 0 && ql >= 0 && zdrop >= 0 && b->max - H > zdrop + l * slope) ? 1 : 0;
+	b->max_t = up ? t : b->max_t; b->max_q = up ? r - t : b->max_q; b->max = up ? H : b->max;
+	b->dropped |= drop;
+	return drop;
 }
 
 /* exact mode, uniform values of one anti-diagonal (ksw2_extz2_sse.c:229-269): A = H at en0, Bkey = winner of the four-lane

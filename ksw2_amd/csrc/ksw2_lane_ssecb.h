@@ -1,0 +1,222 @@
+/*
+ * ksw2_lane_ssecb.h -- the SSE-COMPATIBLE mode (ksw2_lane_ssec.h: ksw_extz2_sse / ksw_extd2_sse exactly as the reference's SSE
+ * kernels return them, ksw2_extz2_sse.c:101-301, ksw2_extd2_sse.c:131-398) with the state in REGISTERS: one 16-position block
+ * of the reference's byte arrays per lane -- a lane is one __m128i of the reference's inner loop.
+ *
+ * The position-per-lane kernel (k2a_ssec_kernel) keeps u, v, x, y [, x~, y~], s as byte arrays in LDS or HBM and walks an
+ * anti-diagonal in passes of 64 positions with a fence between its phases: 1 100 cycles per pass, 65 GCUPS on 10 k reads (0.006 of
+ * the VALU roofline, round 4).  Here target position p lives in lane (p >> 4) & 63, slot p & 15, for as long as it is in the band:
+ * the band of anti-diagonal r covers at most w + 1 positions, so 64 lanes hold bands up to 960 positions, and a lane whose block
+ * falls out of the band below takes the block that enters 64 blocks above (a ring: no data ever moves).  One step = one
+ * anti-diagonal = every lane updates its 16 positions.
+ *
+ * Number format: the reference's arithmetic is WRAPPING int8 with signed and unsigned byte comparisons, and the padded positions
+ * of the edge blocks compute on whatever their bytes hold ("leaky band") -- nothing about value ranges may be assumed.
+ * A byte b is held as the 16-bit number b << 8, two positions per 32-bit register: v_pk_add_u16 / v_pk_sub_u16 then wrap exactly
+ * like paddb / psubb, v_pk_max_i16 / v_pk_min_i16 are pmaxsb / pminsb, v_pk_max_u16 / v_pk_min_u16 are pmaxub / pminub (the low
+ * bytes are zero and stay zero).  13 packed instructions update two positions of the single-gap recurrence, 25 of the two-piece
+ * one, with no range checks anywhere.  The value of position p - 1 (the reference's shifted loads) is the neighbouring half:
+ * one v_alignbit_b32 per register, the previous lane's last position through one DPP rotate.
+ * H (exact-max mode; int32 per position) lives in a 1 024-entry LDS ring per wavefront: it is read and written by position
+ * (last in-band cell, the three tail cells, the first cell), which registers cannot do without a select chain per access.
+ *
+ * Score-only tasks (KSW_EZ_SCORE_ONLY; the approximate modes with KSW_EZ_EXTZ_ONLY included), simple scoring (no
+ * KSW_EZ_GENERIC_SC), bands of at most K2A_SSECB_SPAN positions; everything else keeps the position-per-lane kernel.  Same
+ * bookkeeping code as there (k2a_ssec_book / k2a_ssec_follow): the results are the same bits.
+ */
+#ifndef KSW2_LANE_SSECB_H_
+#define KSW2_LANE_SSECB_H_
+
+#include "ksw2_lane_ssec.h"
+#include "ksw2_lane_pk.h"
+
+#define K2A_SSECB_RING 1024                       /* positions the 64 lanes hold */
+#define K2A_SSECB_SPAN (K2A_SSECB_RING - 64)      /* widest band (positions of one anti-diagonal): the blocks from the one that holds
+                                                   * position st - 1 to the one the score refresh reaches must be 64 different lanes */
+
+K2A_FN uint32_t k2a_sb_c(int v) { const uint32_t h = ((uint32_t)v << 8) & 0xffffu; return h | (h << 16); }      /* the byte v in both halves */
+#if defined(__HIP_DEVICE_COMPILE__)
+K2A_FN uint32_t k2a_sb_minu(uint32_t a, uint32_t b)      /* asm: against the constant 1 hipcc expands the builtin into compares, selects and a v_perm */
+{
+	uint32_t d;
+	asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+	return d;
+}
+K2A_FN uint32_t k2a_sb_shift(uint32_t cur, uint32_t below) { return __builtin_amdgcn_alignbit(cur, below, 16); }   /* { high half of `below`, low half of `cur` } */
+#else
+K2A_FN uint32_t k2a_sb_minu(uint32_t a, uint32_t b)
+{
+	const uint32_t al = a & 0xffffu, ah = a >> 16, bl = b & 0xffffu, bh = b >> 16;
+	return (al < bl ? al : bl) | ((ah < bh ? ah : bh) << 16);
+}
+K2A_FN uint32_t k2a_sb_shift(uint32_t cur, uint32_t below) { return (below >> 16) | (cur << 16); }
+#endif
+/* a block: 16 positions, two per register.  A vector type, so that a read or write by slot number is an element extract / insert on a
+ * value (register indexing or a select chain, the compiler's choice) and never an address into a stack copy of the lane's state */
+typedef uint32_t k2a_blk __attribute__((vector_size(32)));
+/* one position's byte out of a block (slot 0..15), as the low 8 bits */
+K2A_FN uint32_t k2a_sb_get(const k2a_blk &a, int slot)
+{
+	const uint32_t d = a[slot >> 1];
+	return ((slot & 1) ? d >> 24 : d >> 8) & 0xffu;
+}
+K2A_FN void k2a_sb_set(k2a_blk &a, int slot, int byte)
+{
+	const uint32_t h = ((uint32_t)byte << 8) & 0xffffu, d = a[slot >> 1];
+	a[slot >> 1] = (slot & 1) ? (d & 0x0000ffffu) | (h << 16) : (d & 0xffff0000u) | h;
+}
+
+template<bool DUAL>
+struct K2aSsecBlk {
+	int blk;                                   /* the block this lane holds: positions 16 * blk .. 16 * blk + 15; -1: none yet */
+	k2a_blk U, V, X, Y, X2, Y2, S;             /* the reference's bytes, b << 8 per half (X2, Y2: two-piece only; S of the single-gap kernel: with the 2 (q + e)
+	                                            * its cell adds first (ksw2_extz2_sse.c:163) already in) */
+	k2a_blk TC, TN;                            /* target codes of the block's positions (one per half); 0xffff where the code is the wildcard */
+	k2a_blk QW;                                /* query codes r - p of the block's positions on the current anti-diagonal (0 outside the query), bit 15: wildcard */
+	uint32_t qn;                               /* the query byte slot 0 pairs with on the next anti-diagonal (ask_query) */
+
+	K2A_FN int p0() const { return blk << 4; }
+
+	/* the query code position p pairs with on anti-diagonal r (k2a_ssec_qcode): the byte at the clamped index (an index past the
+	 * query belongs to a position the refresh never reaches, p < st0; the clamp only keeps the load inside the arena), then what
+	 * the code is */
+	K2A_FN static uint32_t qbyte(const uint8_t *qry, int qlen, int r, int p) { return qry[k2a_min(k2a_max(r - p, 0), qlen - 1)]; }
+	K2A_FN static uint32_t qcode_of(const K2aSsec &P, uint32_t byte, int r, int p)
+	{
+		const uint32_t c = r - p >= 0 ? byte : 0u;
+		return c | (c == (uint32_t)(P.m - 1) ? 0x8000u : 0u);               /* bit 15: the wildcard (a code is below 128) */
+	}
+	K2A_FN static uint32_t qcode(const K2aSsec &P, const uint8_t *qry, int qlen, int r, int p) { return qcode_of(P, qbyte(qry, qlen, r, p), r, p); }
+
+	/* take block b: the reference's freshly allocated arrays (zeros / the gap-open differences, ksw2_extz2_sse.c:84,
+	 * ksw2_extd2_sse.c:111-116), the target codes (0 past the target's end), the query codes of anti-diagonal r */
+	K2A_FN void init_block(const K2aSsec &P, int b, const uint8_t *tgt, int tlen, const uint8_t *qry, int qlen, int r)
+	{
+		const uint32_t g1 = DUAL ? k2a_sb_c(-P.q - P.e) : 0u, g2 = k2a_sb_c(-P.q2 - P.e2);
+		blk = b;
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			const int p = (b << 4) + 2 * i;
+			const uint32_t t0 = p < tlen ? tgt[p] : 0u, t1 = p + 1 < tlen ? tgt[p + 1] : 0u;
+			U[i] = V[i] = X[i] = Y[i] = g1; S[i] = DUAL ? 0u : k2a_sb_c(2 * (P.q + P.e));
+			if (DUAL) { X2[i] = g2; Y2[i] = g2; }
+			TC[i] = t0 | (t1 << 16);
+			TN[i] = (t0 == (uint32_t)(P.m - 1) ? 0xffffu : 0u) | (t1 == (uint32_t)(P.m - 1) ? 0xffff0000u : 0u);
+			QW[i] = qcode(P, qry, qlen, r, p) | (qcode(P, qry, qlen, r, p + 1) << 16);
+		}
+	}
+
+	/* anti-diagonal r - 1 -> r: every position's query index grows by one, i.e. the codes move one slot up; `qn` is the byte asked
+	 * for on the previous anti-diagonal (ask_query) */
+	K2A_FN void shift_query(const K2aSsec &P, int r)
+	{
+#pragma unroll
+		for (int i = 7; i > 0; --i) QW[i] = k2a_sb_shift(QW[i], QW[i - 1]);
+		QW[0] = (QW[0] << 16) | qcode_of(P, qn, r, p0());
+	}
+	/* the byte slot 0 pairs with on anti-diagonal r + 1.  Called once per anti-diagonal, unconditionally and after the lane may have
+	 * taken a new block: a load under a condition into a value that lives around the loop is waited for on the spot
+	 * (ksw2_lane_pk.h, k2a_load_early) */
+	K2A_FN void ask_query(const uint8_t *qry, int qlen, int r) { qn = qbyte(qry, qlen, r + 1, p0()); }
+
+	/* 16-bit slot mask of the block's positions inside [lo, hi) */
+	K2A_FN uint32_t slot_mask(int lo, int hi) const
+	{
+		const int a = k2a_min(k2a_max(lo - p0(), 0), 16), b = k2a_min(k2a_max(hi - p0(), 0), 16);
+		return b > a ? ((1u << b) - 1u) & ~((1u << a) - 1u) : 0u;
+	}
+	K2A_FN static uint32_t half_mask(uint32_t m16, int i)   /* slots 2i, 2i + 1 of a slot mask as a halves mask */
+	{
+		return k2a_pk_sel(0x0000ffffu, k2a_bit_mask(m16, 2 * i), k2a_bit_mask(m16, 2 * i + 1));
+	}
+
+	/* the scores of positions [st0, pend) below the padded target length (ksw2_extz2_sse.c:125-140, simple scoring) */
+	K2A_FN void refresh_scores(const K2aSsec &P, int st0, int pend)
+	{
+		const uint32_t em = slot_mask(st0, pend);
+		if (em == 0) return;
+		const int ofs = DUAL ? 0 : 2 * (P.q + P.e);
+		const uint32_t cm = k2a_sb_c(P.sc_mch + ofs), cd = k2a_sb_c(P.sc_mis - P.sc_mch), cn = k2a_sb_c(P.sc_N + ofs);
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			const uint32_t ne = k2a_sb_minu(TC[i] ^ QW[i], 0x00010001u);                          /* 1 where the codes differ */
+			uint32_t sc = k2a_pk_mad(ne, cd, cm);                                                  /* sc_mch or sc_mis, << 8 (wrapping like the byte) */
+			sc = k2a_pk_sel(TN[i] | k2a_pk_sign(QW[i]), cn, sc);
+			S[i] = k2a_pk_sel(half_mask(em, i), sc, S[i]);
+		}
+	}
+
+	/* One anti-diagonal for the block (ksw2_extz2_sse.c:146-222 / ksw2_extd2_sse.c:189-321, score-only forms): pv / px / px2 = the
+	 * previous anti-diagonal's v / x / x~ of position 16 * blk - 1 in the HIGH half (the lane below's last register, or the band
+	 * edge's constants).  Only for a block inside [st, en]. */
+	K2A_FN void update(const K2aSsec &P, uint32_t pv, uint32_t px, uint32_t px2)
+	{
+		if (!DUAL) {
+			const uint32_t ccap = k2a_sb_c(P.sc_mch + 2 * (P.q + P.e)), cq = k2a_sb_c(P.q);
+			uint32_t vb = pv, xb = px;
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				const uint32_t vo = V[i], xo = X[i];
+				const uint32_t vt1 = k2a_sb_shift(vo, vb), xt1 = k2a_sb_shift(xo, xb);
+				const uint32_t a = k2a_pk_add(xt1, vt1), b = k2a_pk_add(Y[i], U[i]);
+				const uint32_t z = k2a_pk_max(S[i], a);
+				uint32_t zu = k2a_pk_maxu(z, b);
+				zu = k2a_sb_minu(zu, ccap);
+				const uint32_t z2 = k2a_pk_sub(zu, cq);
+				vb = vo; xb = xo;
+				V[i] = k2a_pk_sub(zu, U[i]); U[i] = k2a_pk_sub(zu, vt1);
+				X[i] = k2a_pk_max(k2a_pk_sub(a, z2), 0u); Y[i] = k2a_pk_max(k2a_pk_sub(b, z2), 0u);
+			}
+		} else {
+			const uint32_t cm = k2a_sb_c(P.sc_mch), cq = k2a_sb_c(P.q), cq2 = k2a_sb_c(P.q2), cqe = k2a_sb_c(P.q + P.e), cqe2 = k2a_sb_c(P.q2 + P.e2);
+			uint32_t vb = pv, xb = px, x2b = px2;
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				const uint32_t vo = V[i], xo = X[i], x2o = X2[i];
+				const uint32_t vt1 = k2a_sb_shift(vo, vb), xt1 = k2a_sb_shift(xo, xb), x2t1 = k2a_sb_shift(x2o, x2b);
+				uint32_t a = k2a_pk_add(xt1, vt1), b = k2a_pk_add(Y[i], U[i]), a2 = k2a_pk_add(x2t1, vt1), b2 = k2a_pk_add(Y2[i], U[i]);
+				uint32_t z = k2a_pk_max(k2a_pk_max(S[i], a), k2a_pk_max(b, k2a_pk_max(a2, b2)));
+				z = k2a_pk_min(z, cm);
+				vb = vo; xb = xo; x2b = x2o;
+				V[i] = k2a_pk_sub(z, U[i]); U[i] = k2a_pk_sub(z, vt1);
+				uint32_t tmp = k2a_pk_sub(z, cq);
+				X[i] = k2a_pk_sub(k2a_pk_max(k2a_pk_sub(a, tmp), 0u), cqe); Y[i] = k2a_pk_sub(k2a_pk_max(k2a_pk_sub(b, tmp), 0u), cqe);
+				tmp = k2a_pk_sub(z, cq2);
+				X2[i] = k2a_pk_sub(k2a_pk_max(k2a_pk_sub(a2, tmp), 0u), cqe2); Y2[i] = k2a_pk_sub(k2a_pk_max(k2a_pk_sub(b2, tmp), 0u), cqe2);
+			}
+		}
+	}
+
+	/* what the v byte of slot s adds to H (k2a_ssec_dh) */
+	K2A_FN int dh(const K2aSsec &P, int s) const
+	{
+		const uint32_t d = V[s >> 1];
+		if (DUAL) return (s & 1) ? (int)d >> 24 : (int)(d << 16) >> 24;
+		return (int)((s & 1) ? d >> 24 : (d >> 8) & 0xffu) - (P.q + P.e);
+	}
+
+	/* Exact mode (ksw2_extz2_sse.c:238-247): H += v for all 16 positions of the block, from `hv` (their H before this anti-diagonal,
+	 * read out of the ring `hl` ahead of time) back into the ring; returns the block's best cell of the four-lane region [st0, en1)
+	 * as k2a_dm_key (0: none).  Only the positions in [st0, en0) are H values; what the others receive is never used: the one at en0
+	 * is assigned by the caller, those above are assigned before they enter, those below st0 have left -- except the one the next
+	 * anti-diagonal's last cell starts from while the band is a single position, which the caller carries itself.
+	 * Inside the block a cell is better if its H is higher, then if its lane class (t - st0) & 3 is lower, then if t is lower --
+	 * the order of k2a_dm_key -- held as H * 64 + rank with |H| < 2^25. */
+	K2A_FN uint64_t advance_H(const K2aSsec &P, int *hl, const int *hv, int st0, int en1)
+	{
+		const uint32_t em = slot_mask(st0, en1);
+		int *hp = hl + (p0() & (K2A_SSECB_RING - 1));
+		int best = INT32_MIN;
+#pragma unroll
+		for (int s = 0; s < 16; ++s) {
+			const int h = hv[s] + dh(P, s);
+			hp[s] = h;
+			const int key = (int)(((uint32_t)h << 6) + (uint32_t)(63 - ((((s - st0) & 3) << 4) | s)));
+			best = k2a_max(best, (int)k2a_pk_selv(k2a_bit_mask(em, s), (uint32_t)key, (uint32_t)INT32_MIN));
+		}
+		if (best == INT32_MIN) return 0;
+		return k2a_dm_key(best >> 6, p0() + (15 - (best & 15)), st0);
+	}
+};
+
+#endif

@@ -18,6 +18,7 @@
 #include "ksw2_lane_dm.h"
 #include "ksw2_lane_extf.h"
 #include "ksw2_lane_ssec.h"
+#include "ksw2_lane_ssecb.h"
 
 #define K2A_WPB 4          /* wavefronts per workgroup; waves never synchronise with each other */
 /* The traceback walk is a chain of dependent loads and a few dozen instructions per step on ONE lane; what it needs is many
@@ -1513,6 +1514,130 @@ k2a_ssec_kernel(const K2aSsec P, const K2aPair *__restrict__ pairs, const uint32
 	if (lane == 0) k2a_finish(pr, book, &res[pi]);
 }
 
+/* The same mode with the state in registers (ksw2_lane_ssecb.h): lane <-> one 16-position block of the reference's arrays (a ring
+ * of 64 blocks), one step per anti-diagonal, H in a 1 024-entry LDS ring per wavefront.  Score-only tasks, simple scoring, bands up
+ * to K2A_SSECB_SPAN positions.  What is uniform per anti-diagonal (the band's bounds, the first block's left edge, the cell at
+ * position r, the book) is computed by every lane on scalar registers; the values it needs by position come from the owning lane
+ * through v_readlane (u, v bytes) or from the LDS ring (H). */
+#define K2A_SSECB_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+/* the anti-diagonals of one task; APPROX: the approximate modes' one followed cell instead of H (a template parameter and not the
+ * task's flag tested per anti-diagonal: with both forms in one loop hipcc merges their stores into the book through a selected
+ * address and the book moves to scratch memory) */
+template<bool DUAL, bool APPROX>
+__device__ __forceinline__ void k2a_ssec_blk_task(const K2aSsec &P, const K2aPair &pr, const uint8_t *__restrict__ seq, int *hl, int lane, K2aBook &book)
+{
+	const int qlen = pr.qlen, tlen = pr.tlen_full, w = pr.w, T16 = (tlen + 15) / 16 * 16;
+	const bool adrop = (pr.pad & K2A_SSEC_APPROX_DROP) != 0;
+	const uint8_t *qry = seq + pr.qoff, *tgt = seq + pr.toff;
+	const int slope = DUAL ? P.e2 : P.e;
+
+	K2aSsecBlk<DUAL> B;
+	B.blk = -1; B.qn = 0;
+	B.U = B.V = B.X = B.Y = B.X2 = B.Y2 = B.S = B.TC = B.TN = B.QW = k2a_blk{ 0, 0, 0, 0, 0, 0, 0, 0 };
+	k2a_book_reset(&book);
+	K2aSsecFollow fol = { 0, 0 };
+	int last_st = -1, last_en = -1, last_st0 = 0, last_en0 = 0, hprev = 0;
+	for (int r = 0; r < qlen + tlen - 1; ++r) {
+		int st0, en0, st, en;
+		if (!k2a_ssec_bounds(r, qlen, tlen, w, st0, en0, st, en)) { book.dropped = 1; break; }      /* ksw2_extz2_sse.c:111-114 */
+		const int pend = min(st0 + ((en0 - st0) / 16 + 1) * 16, T16);       /* the score refresh's end (:125-140), see k2a_ssec_kernel */
+		B.shift_query(P, r);
+		/* blocks that enter: the lane's next turn in the ring */
+		{
+			const int need = max(en, pend - 1) >> 4, nb = B.blk < 0 ? lane : B.blk + 64;
+			if (nb <= need) {
+				B.init_block(P, nb, tgt, tlen, qry, qlen, r);
+				int *hp = hl + ((nb << 4) & (K2A_SSECB_RING - 1));
+#pragma unroll
+				for (int s = 0; s < 16; ++s) hp[s] = K2A_NEG;
+			}
+		}
+		B.ask_query(qry, qlen, r);
+		const bool act = B.blk >= (st >> 4) && B.blk <= (en >> 4);
+		/* exact mode: the block's H and the H the last in-band cell starts from (:229), asked for now and used after the update.  The
+		 * ring's entry is that H unless the position was below the band already (the band is one position wide and did not move): then
+		 * it is the value carried from the previous anti-diagonal (see advance_H) */
+		int hv[16], hnew = 0;
+		if (!APPROX && r > 0) {
+			K2A_SSECB_SYNC();
+			if (act) {
+				const int *hp = hl + (B.p0() & (K2A_SSECB_RING - 1));
+#pragma unroll
+				for (int s = 0; s < 16; ++s) hv[s] = hp[s];
+			}
+			hnew = hl[(en0 > 0 ? en0 - 1 : en0) & (K2A_SSECB_RING - 1)];
+		}
+		/* the cell at position r (first column) and what the first block reads to its left */
+		const bool prev_ok = st > 0 && st - 1 >= last_st && st - 1 <= last_en;
+		int cv, cx, cx2 = 0;
+		if (!DUAL) {
+			cx = 0; cv = st > 0 ? 0 : (r ? P.q : 0);
+			if (en >= r && B.blk == (r >> 4)) { k2a_sb_set(B.Y, r & 15, 0); k2a_sb_set(B.U, r & 15, r ? P.q : 0); }
+		} else {
+			const int edge = k2a_ssec_edge(P, r);
+			cx = -P.q - P.e; cx2 = -P.q2 - P.e2; cv = st > 0 ? -P.q - P.e : edge;
+			if (en >= r && B.blk == (r >> 4)) { k2a_sb_set(B.Y, r & 15, -P.q - P.e); k2a_sb_set(B.Y2, r & 15, -P.q2 - P.e2); k2a_sb_set(B.U, r & 15, edge); }
+		}
+		uint32_t pv = (uint32_t)k2a_rot1<64>((int)B.V[7]), px = (uint32_t)k2a_rot1<64>((int)B.X[7]), px2 = DUAL ? (uint32_t)k2a_rot1<64>((int)B.X2[7]) : 0u;
+		if (B.blk == (st >> 4) && !prev_ok) { pv = k2a_sb_c(cv); px = k2a_sb_c(cx); px2 = k2a_sb_c(cx2); }
+		B.refresh_scores(P, st0, pend);
+		if (act) B.update(P, pv, px, px2);
+		int stop;
+		if (!APPROX) {
+			int A, Sv, T0 = K2A_NEG, T1 = K2A_NEG, T2 = K2A_NEG;
+			uint64_t bk = 0;
+			const int en1 = st0 + (en0 - st0) / 4 * 4;
+			if (r > 0) {
+				if (!(en0 == last_en0 && en0 - 1 < last_st0 && en0 > 0)) hprev = __builtin_amdgcn_readfirstlane(hnew);
+				int dl;
+				if (en0 > 0) dl = __builtin_amdgcn_readlane((int)k2a_sb_get(B.U, en0 & 15), (en0 >> 4) & 63);
+				else dl = __builtin_amdgcn_readlane((int)k2a_sb_get(B.V, 0), 0);
+				A = hprev + k2a_ssec_dh<DUAL>(P, dl);
+				if (act) bk = B.advance_H(P, hl, hv, st0, en1);
+				K2A_SSECB_SYNC();
+				const int pos = lane == 0 ? st0 : en1 + lane - 1;
+				const int hvv = (lane < 4 && pos < en0) ? hl[pos & (K2A_SSECB_RING - 1)] : K2A_NEG;
+				Sv = st0 < en0 ? __builtin_amdgcn_readlane(hvv, 0) : A;
+				T0 = __builtin_amdgcn_readlane(hvv, 1); T1 = __builtin_amdgcn_readlane(hvv, 2); T2 = __builtin_amdgcn_readlane(hvv, 3);
+				K2A_SSECB_SYNC();
+				if (lane == 0) hl[en0 & (K2A_SSECB_RING - 1)] = A;
+			} else {
+				A = Sv = k2a_ssec_dh<DUAL>(P, __builtin_amdgcn_readlane((int)k2a_sb_get(B.V, 0), 0)) - (DUAL ? P.qe_first : P.q + P.e);
+				if (lane == 0) hl[0] = A;
+			}
+			K2A_SSECB_SYNC();
+			const uint64_t Bkey = k2a_wave_max_u64(bk);
+			stop = k2a_ssec_book(&book, r, st0, en0, en, qlen, tlen, pr.zdrop, slope, A, Bkey, T0, T1, T2, Sv);
+		} else {
+			const int l0 = min(max(fol.last, 0), T16 - 1), l1 = min(max(fol.last + 1, 0), T16 - 1);
+			const int vl = __builtin_amdgcn_readlane((int)k2a_sb_get(B.V, l0 & 15), (l0 >> 4) & 63);
+			const int un = __builtin_amdgcn_readlane((int)k2a_sb_get(B.U, l1 & 15), (l1 >> 4) & 63);
+			const int v0 = __builtin_amdgcn_readlane((int)k2a_sb_get(B.V, 0), 0);
+			stop = k2a_ssec_follow<DUAL>(P, fol, &book, r, st0, en0, qlen, tlen, pr.zdrop, adrop, vl, un, v0);
+		}
+		if (stop) break;
+		last_st = st; last_en = en; last_st0 = st0; last_en0 = en0;
+	}
+}
+
+template<bool DUAL>
+__global__ void __launch_bounds__(64 * K2A_WPB)
+k2a_ssec_blk_kernel(const K2aSsec P, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
+                    const uint8_t *__restrict__ seq, K2aResult *__restrict__ res)
+{
+	__shared__ int hl_all[K2A_WPB][K2A_SSECB_RING];
+	const int lane = threadIdx.x & 63, wave = k2a_wave_id<true>();
+	const int task = blockIdx.x * K2A_WPB + wave;
+	if (task >= ntasks) return;                       /* whole wavefronts leave; nobody synchronises below */
+	int *hl = hl_all[wave];
+	const uint32_t pi = order[task];
+	const K2aPair pr = pairs[pi];
+	K2aBook book;
+	if (pr.pad & K2A_SSEC_APPROX) k2a_ssec_blk_task<DUAL, true>(P, pr, seq, hl, lane, book);
+	else k2a_ssec_blk_task<DUAL, false>(P, pr, seq, hl, lane, book);
+	if (lane == 0) k2a_finish(pr, book, &res[pi]);
+}
+
 __global__ void __launch_bounds__(64)
 k2a_ssec_trace_kernel(const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
                       const uint8_t *__restrict__ tb, K2aResult *__restrict__ res, uint32_t *__restrict__ cig, int ppw)
@@ -2095,6 +2220,16 @@ int k2a_shim_launch_ssec(int dual, int mode, size_t lds_bytes, const K2aSsec *pa
 	} else
 	hipLaunchKernelGGL(g_ssec[0][dual ? 1 : 0][mode], dim3((ntasks + K2A_WPB - 1) / K2A_WPB), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
 	                   *par, pairs, order, ntasks, seq, tb, scratch, res);
+	CHECK(hipGetLastError());
+	return 0;
+}
+
+/* score-only tasks with the state in registers (k2a_ssec_blk_kernel) */
+int k2a_shim_launch_ssec_blk(int dual, const K2aSsec *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, K2aResult *res, void *stream)
+{
+	if (ntasks <= 0) return 0;
+	if (dual) hipLaunchKernelGGL(k2a_ssec_blk_kernel<true>, dim3((ntasks + K2A_WPB - 1) / K2A_WPB), dim3(64 * K2A_WPB), 0, (hipStream_t)stream, *par, pairs, order, ntasks, seq, res);
+	else hipLaunchKernelGGL(k2a_ssec_blk_kernel<false>, dim3((ntasks + K2A_WPB - 1) / K2A_WPB), dim3(64 * K2A_WPB), 0, (hipStream_t)stream, *par, pairs, order, ntasks, seq, res);
 	CHECK(hipGetLastError());
 	return 0;
 }

@@ -19,6 +19,7 @@
 #include "../../ksw2_amd/csrc/ksw2_lane_pk.h"
 #include "../../ksw2_amd/csrc/ksw2_lane_pkmp.h"
 #include "../../ksw2_amd/csrc/ksw2_lane_ssec.h"
+#include "../../ksw2_amd/csrc/ksw2_lane_ssecb.h"
 
 static thread_local char g_err[256] = "";
 
@@ -741,6 +742,99 @@ static void sim_ssec(const K2aSsec P, const K2aPair *pairs, const uint32_t *orde
 	}
 }
 
+/* mirrors k2a_ssec_blk_kernel: 64 lanes, each one 16-position block of the ring; the phases of an anti-diagonal in the kernel's order */
+template<bool DUAL>
+static void sim_ssec_blk(const K2aSsec P, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, K2aResult *res)
+{
+	const int RM = K2A_SSECB_RING - 1;
+	for (int task = 0; task < ntasks; ++task) {
+		const uint32_t pi = order[task];
+		const K2aPair pr = pairs[pi];
+		const int qlen = pr.qlen, tlen = pr.tlen_full, w = pr.w, T16 = (tlen + 15) / 16 * 16;
+		const bool approx = (pr.pad & K2A_SSEC_APPROX) != 0, adrop = (pr.pad & K2A_SSEC_APPROX_DROP) != 0;
+		const uint8_t *qry = seq + pr.qoff, *tgt = seq + pr.toff;
+		const int slope = DUAL ? P.e2 : P.e;
+		std::vector<K2aSsecBlk<DUAL>> Bv(64);
+		std::vector<int> hl(K2A_SSECB_RING, 0);
+		for (int l = 0; l < 64; ++l) {
+			K2aSsecBlk<DUAL> &B = Bv[l];
+			B.blk = -1; B.qn = 0;
+			B.U = B.V = B.X = B.Y = B.X2 = B.Y2 = B.S = B.TC = B.TN = B.QW = k2a_blk{ 0, 0, 0, 0, 0, 0, 0, 0 };
+		}
+		K2aBook book;
+		k2a_book_reset(&book);
+		K2aSsecFollow fol = { 0, 0 };
+		int last_st = -1, last_en = -1, last_st0 = 0, last_en0 = 0, hprev = 0;
+		for (int r = 0; r < qlen + tlen - 1; ++r) {
+			int st0, en0, st, en;
+			if (!k2a_ssec_bounds(r, qlen, tlen, w, st0, en0, st, en)) { book.dropped = 1; break; }
+			const int pend = k2a_min(st0 + ((en0 - st0) / 16 + 1) * 16, T16);
+			const int need = k2a_max(en, pend - 1) >> 4;
+			const bool prev_ok = st > 0 && st - 1 >= last_st && st - 1 <= last_en;
+			int cv, cx, cx2 = 0;
+			if (!DUAL) { cx = 0; cv = st > 0 ? 0 : (r ? P.q : 0); }
+			else { cx = -P.q - P.e; cx2 = -P.q2 - P.e2; cv = st > 0 ? -P.q - P.e : k2a_ssec_edge(P, r); }
+			for (int l = 0; l < 64; ++l) {
+				K2aSsecBlk<DUAL> &B = Bv[l];
+				B.shift_query(P, r);
+				const int nb = B.blk < 0 ? l : B.blk + 64;
+				if (nb <= need) {
+					B.init_block(P, nb, tgt, tlen, qry, qlen, r);
+					for (int s2 = 0; s2 < 16; ++s2) hl[((nb << 4) & RM) + s2] = K2A_NEG;
+				}
+				B.ask_query(qry, qlen, r);
+				if (en >= r && B.blk == (r >> 4)) {
+					if (!DUAL) { k2a_sb_set(B.Y, r & 15, 0); k2a_sb_set(B.U, r & 15, r ? P.q : 0); }
+					else { k2a_sb_set(B.Y, r & 15, -P.q - P.e); k2a_sb_set(B.Y2, r & 15, -P.q2 - P.e2); k2a_sb_set(B.U, r & 15, k2a_ssec_edge(P, r)); }
+				}
+			}
+			bool act[64];
+			int hv[64][16], hnew = 0;
+			for (int l = 0; l < 64; ++l) {
+				act[l] = Bv[l].blk >= (st >> 4) && Bv[l].blk <= (en >> 4);
+				if (!approx && r > 0 && act[l]) for (int s2 = 0; s2 < 16; ++s2) hv[l][s2] = hl[(Bv[l].p0() & RM) + s2];
+			}
+			if (!approx && r > 0) hnew = hl[(en0 > 0 ? en0 - 1 : en0) & RM];
+			uint32_t pv[64], px[64], px2[64];
+			for (int l = 0; l < 64; ++l) { const K2aSsecBlk<DUAL> &Bp = Bv[(l + 63) & 63]; pv[l] = Bp.V[7]; px[l] = Bp.X[7]; px2[l] = DUAL ? Bp.X2[7] : 0u; }
+			for (int l = 0; l < 64; ++l) {
+				K2aSsecBlk<DUAL> &B = Bv[l];
+				if (B.blk == (st >> 4) && !prev_ok) { pv[l] = k2a_sb_c(cv); px[l] = k2a_sb_c(cx); px2[l] = k2a_sb_c(cx2); }
+				B.refresh_scores(P, st0, pend);
+				if (act[l]) B.update(P, pv[l], px[l], px2[l]);
+			}
+			int stop;
+			if (!approx) {
+				int A, Sv, T[3] = { K2A_NEG, K2A_NEG, K2A_NEG };
+				uint64_t Bkey = 0;
+				const int en1 = st0 + (en0 - st0) / 4 * 4;
+				if (r > 0) {
+					if (!(en0 == last_en0 && en0 - 1 < last_st0 && en0 > 0)) hprev = hnew;
+					const K2aSsecBlk<DUAL> &Bo = Bv[(en0 >> 4) & 63];
+					const int dl = (int)(en0 > 0 ? k2a_sb_get(Bo.U, en0 & 15) : k2a_sb_get(Bo.V, en0 & 15));
+					A = hprev + k2a_ssec_dh<DUAL>(P, dl);
+					for (int l = 0; l < 64; ++l) if (act[l]) { const uint64_t k = Bv[l].advance_H(P, hl.data(), hv[l], st0, en1); if (k > Bkey) Bkey = k; }
+					Sv = st0 < en0 ? hl[st0 & RM] : A;
+					for (int k = 0; k < 3; ++k) if (en1 + k < en0) T[k] = hl[(en1 + k) & RM];
+					hl[en0 & RM] = A;
+				} else {
+					A = Sv = k2a_ssec_dh<DUAL>(P, (int)k2a_sb_get(Bv[0].V, 0)) - (DUAL ? P.qe_first : P.q + P.e);
+					hl[0] = A;
+				}
+				stop = k2a_ssec_book(&book, r, st0, en0, en, qlen, tlen, pr.zdrop, slope, A, Bkey, T[0], T[1], T[2], Sv);
+			} else {
+				const int l0 = k2a_min(k2a_max(fol.last, 0), T16 - 1), l1 = k2a_min(k2a_max(fol.last + 1, 0), T16 - 1);
+				const int vl = (int)k2a_sb_get(Bv[(l0 >> 4) & 63].V, l0 & 15), un = (int)k2a_sb_get(Bv[(l1 >> 4) & 63].U, l1 & 15);
+				const int v0 = (int)k2a_sb_get(Bv[0].V, 0);
+				stop = k2a_ssec_follow<DUAL>(P, fol, &book, r, st0, en0, qlen, tlen, pr.zdrop, adrop, vl, un, v0);
+			}
+			if (stop) break;
+			last_st = st; last_en = en; last_st0 = st0; last_en0 = en0;
+		}
+		k2a_finish(pr, book, &res[pi]);
+	}
+}
+
 /* mirrors k2a_fill_pkmp_kernel.  The generations of a task run one after the other here (on the device four wavefronts pipeline
  * them; the data flow -- boundary entries through `bnd`, row-maximum keys in the task's spill blocks, a re-base every
  * K2A_PKMP_T steps -- is the same, and so is every value). */
@@ -1202,6 +1296,12 @@ int k2a_shim_launch_ssec(int dual, int mode, size_t, const K2aSsec *par, const K
 	typedef void (*fn)(const K2aSsec, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, uint8_t*, K2aResult*);
 	static const fn f[2][3] = { { sim_ssec<false, 0>, sim_ssec<false, 1>, sim_ssec<false, 2> }, { sim_ssec<true, 0>, sim_ssec<true, 1>, sim_ssec<true, 2> } };
 	f[dual ? 1 : 0][mode](*par, pairs, order, ntasks, seq, tb, scratch, res);
+	return 0;
+}
+int k2a_shim_launch_ssec_blk(int dual, const K2aSsec *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, K2aResult *res, void *)
+{
+	if (dual) sim_ssec_blk<true>(*par, pairs, order, ntasks, seq, res);
+	else sim_ssec_blk<false>(*par, pairs, order, ntasks, seq, res);
 	return 0;
 }
 int k2a_shim_launch_ssec_trace(const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb, K2aResult *res, uint32_t *cig, void *)

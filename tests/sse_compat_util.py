@@ -85,3 +85,45 @@ def check_long(lib, n=4, length=3000, w=100):
         for i in range(n):
             exp = po.align("oracle", "extd2_sse" if dual else "extz2_sse", qs[i], ts[i], mat, 4, 2, 24, 1, w=w, zdrop=200, flag=flag)
             assert all(exp[f] == res[i][f] for f in ALL), (dual, hex(flag), i, [f for f in ALL if exp[f] != res[i][f]])
+
+
+def check_register_form(lib, setenv, rounds=6, long_len=2600):
+    """Score-only tasks take the kernel with the state in registers (k2a_ssec_blk_kernel, ksw2_lane_ssecb.h): bands from one
+    position to the 960 the ring holds (wider ones keep the position-per-lane kernel), targets longer than the ring so that every
+    lane takes several blocks, both gap models, exact maximum and the approximate modes, wildcards, Z-drop, unequal lengths whose
+    band ends against a sequence end -- against the oracle, and the same batch with the form switched off (KSW2AMD_SSEC_BLK=0)."""
+    from ksw2_amd import synth
+    rng = np.random.Generator(np.random.PCG64(4242))
+    mats = [(po.simple_mat(5, 2, 4, -1), 4, 2, 24, 1), (po.simple_mat(5, 1, 3, 0), 6, 1, 13, 0), (po.simple_mat(5, 5, 4, 1), 2, 3, 20, 2)]
+    nblk = 0
+    for rnd in range(rounds):
+        n = 8
+        lo, hi = [(20, 200), (long_len // 3, long_len), (30, 90)][rnd % 3]
+        pairs = synth.ragged_pairs(rng, n - 2, lo, hi, sub=float(rng.choice([0.03, 0.1, 0.25])), ind=float(rng.choice([0.02, 0.1, 0.2])), n_rate=float(rng.choice([0, 0.01])))
+        qs, ts = [p[0] for p in pairs], [p[1] for p in pairs]
+        qs += [rng.integers(0, 4, size=int(rng.integers(1, 150)), dtype=np.uint8) for _ in range(2)]       # unrelated, unequal lengths
+        ts += [rng.integers(0, 4, size=int(rng.integers(1, 150)), dtype=np.uint8) for _ in range(2)]
+        w = rng.choice([0, 1, 2, 5, 16, 17, 100, 700, 959, 960, 1100, -1], size=n)
+        zd = rng.choice([-1, 20, 100, 400], size=n)
+        so = po.SCORE_ONLY
+        base = rng.choice([so, so | po.EXTZ_ONLY, so | po.APPROX_MAX | po.EXTZ_ONLY, so | po.APPROX_MAX | po.APPROX_DROP | po.EXTZ_ONLY, so | po.APPROX_MAX], size=n)
+        mat, gq, ge, gq2, ge2 = mats[rnd % 3]
+        for dual in (False, True):
+            func = "extd2_sse" if dual else "extz2_sse"
+            exp = [po.align("oracle", func, qs[i], ts[i], mat, gq, ge, gq2, ge2, w=int(w[i]), zdrop=int(zd[i]), end_bonus=3, flag=int(base[i])) for i in range(n)]
+            for off in (False, True):
+                setenv("KSW2AMD_SSEC_BLK", "0" if off else "")
+                b = lib.make_batch(qs, ts, mat, gq, ge, gq2, ge2, w=w, zdrop=zd, end_bonus=3, flag=base | COMPAT)
+                p = b.sse_plan(dual)
+                forms = {d["form"]: d["tasks"] for d in p.describe()}
+                p.close()
+                span = [min(len(qs[i]), len(ts[i]), (int(w[i]) if 0 <= w[i] <= max(len(qs[i]), len(ts[i])) else max(len(qs[i]), len(ts[i]))) + 1) for i in range(n)]
+                assert forms.get("blk", 0) == (0 if off else sum(1 for x in span if x <= 960)), (forms, span)
+                nblk += forms.get("blk", 0)
+                res = lib.extd_batch(qs, ts, mat, gq, ge, gq2, ge2, w=w, zdrop=zd, end_bonus=3, flag=base | COMPAT) if dual else \
+                    lib.extz_batch(qs, ts, mat, gq, ge, w=w, zdrop=zd, end_bonus=3, flag=base | COMPAT)
+                for i in range(n):
+                    bad = [f for f in ALL if exp[i][f] != res[i][f]]
+                    assert not bad, (rnd, dual, off, i, len(qs[i]), len(ts[i]), int(w[i]), int(zd[i]), hex(int(base[i])), bad)
+    setenv("KSW2AMD_SSEC_BLK", "")
+    return nblk

@@ -961,6 +961,27 @@ def test_sse_compatible_mode(lib):
     su.check_long(lib, n=6, length=6000, w=150)
 
 
+def test_sse_compatible_register_form(lib, monkeypatch):
+    """k2a_ssec_blk_kernel on the GPU (score-only SSE-compatible tasks, state in registers, H in an LDS ring): bands of 1 to 960
+    positions, targets several rings long, both gap models, exact and approximate maxima, Z-drop -- against the oracle and against
+    the position-per-lane kernel; the golden set with the form off; 10 k reads at band 500 against the position-per-lane kernel."""
+    from tests import sse_compat_util as su
+    assert su.check_register_form(lib, monkeypatch.setenv, rounds=9, long_len=5000) > 60
+    monkeypatch.setenv("KSW2AMD_SSEC_BLK", "0")
+    assert su.check_golden(lib) >= 1500
+    mat = synth.simple_mat(5, 2, 4, -1)
+    q, t = synth.fixed_batch(21, 24, 10000, 10000, sub=0.05, ind=0.06, tail_random_frac=0.3, tail_pairs=0.3)
+    for dual, flag in ((False, po.SCORE_ONLY), (True, po.SCORE_ONLY), (False, po.SCORE_ONLY | po.APPROX_MAX | po.APPROX_DROP | po.EXTZ_ONLY)):
+        fl = np.full(24, flag | ka.KSW2AMD_EZ_SSE_COMPAT)
+        out = []
+        for off in ("0", ""):
+            monkeypatch.setenv("KSW2AMD_SSEC_BLK", off)
+            out.append(lib.extd_batch(list(q), list(t), mat, 4, 2, 24, 1, w=500, zdrop=400, flag=fl) if dual else lib.extz_batch(list(q), list(t), mat, 4, 2, w=500, zdrop=400, flag=fl))
+        assert any(r["zdropped"] for r in out[0]) and not all(r["zdropped"] for r in out[0])
+        for a, b in zip(*out):
+            assert not diff(a, b, gu.FIELDS)
+
+
 def test_packed_generation_serial(lib, monkeypatch):
     """The packed generation-serial class on the GPU (k2a_fill_pkmp_kernel: four wavefronts pipeline a task's generations, one
     workgroup barrier per 64 steps): same-shape batches whose band no resident geometry holds -- 2 to 25 generations, unbanded

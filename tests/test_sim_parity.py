@@ -831,6 +831,15 @@ def test_sim_sse_compatible_mode(sim):
     su.check_long(sim, n=3, length=1500, w=60)
 
 
+def test_sim_sse_compatible_register_form(sim, monkeypatch):
+    """Score-only SSE-compatible tasks through the simulator twin of k2a_ssec_blk_kernel (one 16-position block of the reference's
+    arrays per lane, tests/sse_compat_util.check_register_form), and the full golden set once more with the form off."""
+    from tests import sse_compat_util as su
+    assert su.check_register_form(sim, monkeypatch.setenv, rounds=6, long_len=2200) > 40
+    monkeypatch.setenv("KSW2AMD_SSEC_BLK", "0")
+    assert su.check_golden(sim, step=2) >= 750
+
+
 def test_sim_packed_generation_serial(sim, monkeypatch):
     """Same-shape pairs whose band no resident geometry holds take the packed generation-serial class (ksw2_lane_pkmp.h: sliding
     score base, row maxima merged as keys, boundary entries between generations): unbanded and wide bands, one to six
