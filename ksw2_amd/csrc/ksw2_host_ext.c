@@ -280,13 +280,14 @@ void ksw_exts2_sse2(void *km, int qlen, const uint8_t *query, int tlen, const ui
 #define EXTF_LDS_T0 1024
 #define EXTF_LDS_T1 4096
 #define EXTF_LDS_T2 21504          /* 3 x 21504 bytes = 63 KiB of LDS for one wavefront */
+#define EXTFB_SPAN 160              /* = K2A_EXTFB_SPAN (ksw2_lane_extfb.h) */
 
 ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n, const ksw2amd_fpair_t *pairs)
 {
 	ksw2amd_plan_t *p;
 	int i, c, span, nlane = 0, use_lane;
 	size_t off = 0;
-	uint32_t fill[7];
+	uint32_t fill[8];
 	void *up;
 	sort_t *srt = 0;
 
@@ -334,6 +335,12 @@ ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n
 		if (!ENV(EXTF_LDS) && (span > 128 || c > 0)) c = span <= K2A_EXTF_WIN_SPAN(4) ? 4 : span <= K2A_EXTF_WIN_SPAN(8) ? 5 : c;
 		if (ENV(EXTF_WIN)) c = span <= K2A_EXTF_WIN_SPAN(4) ? 4 : span <= K2A_EXTF_WIN_SPAN(8) ? 5 : c;   /* tests: the window wherever it fits */
 		if (ENV(EXTF_HBM)) c = 3;            /* tests: every pair through the HBM-state kernel */
+		/* narrow bands: four extensions per wavefront (k2a_extf_grp_kernel; KSW2AMD_EXTF_GRP=0 never, =1 wherever the band fits) */
+		{
+			const char *gv = ENV(EXTF_GRP);
+			const int forced = ENV(EXTF_LDS) || ENV(EXTF_WIN) || ENV(EXTF_HBM);
+			if (span <= EXTFB_SPAN && (gv && *gv ? atoi(gv) != 0 : !forced)) c = 7;
+		}
 		p->cells += band_cells(a->qlen, a->tlen, d->w);
 		if (use_lane) { p->h_cls[i] = 6; ++p->f_count[6]; ++nlane; continue; }          /* sequences and state: grouped below */
 		if (c == 3) { d->tb_off = p->tb_bytes; p->tb_bytes += align_up(3 * align_up((size_t)a->tlen, 16), 256); }
@@ -342,7 +349,7 @@ ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n
 		off = align_up(off, 4); d->toff = (uint32_t)off; off += (size_t)a->tlen;
 		if (off > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "extf: more than 4 GiB of sequence in one plan%s", 0); goto err; }
 	}
-	for (c = 0, i = 0; c < 7; ++c) { p->f_first[c] = i; fill[c] = (uint32_t)i; i += p->f_count[c]; }
+	for (c = 0, i = 0; c < 8; ++c) { p->f_first[c] = i; fill[c] = (uint32_t)i; i += p->f_count[c]; }
 	if (nlane) {
 		/* groups of 64 pairs of similar shape (sorted by target, query, band); per group: target codes and the reversed query
 		 * interleaved by lane in the sequence arena, three state arrays of `rows` dwords per lane in the scratch block */
@@ -447,7 +454,7 @@ int extf_plan_run(ksw2amd_plan_t *p, void *stream)
 	if (p->ntasks == 0) return KSW2AMD_OK;
 	if (k2a_shim_event_record(p->ev[0], stream)) goto err;
 	if (p->f_count[6] && k2a_shim_memset(p->d_tb, 0, p->f_state_bytes, stream)) goto err;     /* the reference's zeroed arrays (ksw2_extf2_sse.c:25) */
-	for (c = 6; c >= 0; --c)
+	for (c = 7; c >= 0; --c)
 		if (p->f_count[c] && k2a_shim_launch_extf(c, &p->f_par, p->d_pairs, p->d_order + p->f_first[c], p->f_count[c], p->d_seq, p->d_tb, p->d_res, stream))
 			goto err;
 	if (k2a_shim_event_record(p->ev[1], stream) || k2a_shim_event_record(p->ev[2], stream)) goto err;

@@ -53,17 +53,30 @@ K2A_FN uint32_t k2a_sb_shift(uint32_t cur, uint32_t below) { return (below >> 16
 #endif
 /* a block: 16 positions, two per register.  A vector type, so that a read or write by slot number is an element extract / insert on a
  * value (register indexing or a select chain, the compiler's choice) and never an address into a stack copy of the lane's state */
+#if defined(__clang__)
+typedef uint32_t k2a_blk __attribute__((ext_vector_type(8)));      /* subscripts are element extracts / inserts (a vector_size type's are addresses) */
+typedef uint32_t k2a_quad __attribute__((ext_vector_type(4)));
+#else
 typedef uint32_t k2a_blk __attribute__((vector_size(32)));
-/* one position's byte out of a block (slot 0..15), as the low 8 bits */
+typedef uint32_t k2a_quad __attribute__((vector_size(16)));
+#endif
+/* one position's byte out of a block (slot 0..15), as the low 8 bits.  Selects over the eight registers and no subscript by the slot
+ * number: hipcc turns such a subscript on a member into an address, and the lane's whole state then lives in scratch memory */
 K2A_FN uint32_t k2a_sb_get(const k2a_blk &a, int slot)
 {
-	const uint32_t d = a[slot >> 1];
+	uint32_t d = 0;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) d |= a[i] & (uint32_t)-(int)((slot >> 1) == i);
 	return ((slot & 1) ? d >> 24 : d >> 8) & 0xffu;
 }
 K2A_FN void k2a_sb_set(k2a_blk &a, int slot, int byte)
 {
-	const uint32_t h = ((uint32_t)byte << 8) & 0xffffu, d = a[slot >> 1];
-	a[slot >> 1] = (slot & 1) ? (d & 0x0000ffffu) | (h << 16) : (d & 0xffff0000u) | h;
+	const uint32_t h = ((uint32_t)byte << 8) & 0xffffu, keep = (slot & 1) ? 0x0000ffffu : 0xffff0000u, put = (slot & 1) ? h << 16 : h;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		const uint32_t m = (uint32_t)-(int)((slot >> 1) == i);
+		a[i] = (a[i] & (keep | ~m)) | (put & m);
+	}
 }
 
 template<bool DUAL>

@@ -961,6 +961,23 @@ def test_sse_compatible_mode(lib):
     su.check_long(lib, n=6, length=6000, w=150)
 
 
+def test_linear_xdrop_group_form(lib, monkeypatch):
+    """k2a_extf_grp_kernel on the GPU (tests/test_sim_parity._check_extf_group_form), and a batch of 4 099 extensions of 1 000 x 1 000
+    at band 100 -- the bench workload's shape, a last wavefront with three empty groups -- against the position-per-lane kernels."""
+    from tests.test_sim_parity import _check_extf_group_form
+    _check_extf_group_form(lib, monkeypatch, rounds=60, maxlen=6000)
+    from oracle.gen_golden_extf import noisy_pair
+    rng = np.random.Generator(np.random.PCG64(5))
+    qs, ts = zip(*[noisy_pair(rng, 1000, k % 3) for k in range(4099)])
+    out = []
+    for off in ("", "0"):
+        monkeypatch.setenv("KSW2AMD_EXTF_GRP", off)
+        out.append(lib.extf_batch(list(qs), list(ts), 2, -4, 2, w=100, xdrop=[-1 if k % 2 else 150 for k in range(4099)]))
+    assert any(r["zdropped"] for r in out[0]) and not all(r["zdropped"] for r in out[0])
+    for a, b in zip(*out):
+        assert not diff(a, b, gu.FIELDS)
+
+
 def test_sse_compatible_register_form(lib, monkeypatch):
     """k2a_ssec_blk_kernel on the GPU (score-only SSE-compatible tasks, state in registers, H in an LDS ring): bands of 1 to 960
     positions, targets several rings long, both gap models, exact and approximate maxima, Z-drop -- against the oracle and against

@@ -533,6 +533,48 @@ def test_sim_linear_xdrop_golden_and_batches(sim, monkeypatch):
         assert not diff(sim.extf2(q, t, 2, -4, 2, -1, 50), po.extf2("oracle", q, t, 2, -4, 2, -1, 50), gu.FIELDS), (len(q), len(t))
 
 
+def _check_extf_group_form(lib, monkeypatch, rounds, maxlen):
+    """ksw_extf2_sse for narrow bands, four extensions per wavefront (k2a_extf_grp_kernel, ksw2_lane_extfb.h): the golden cases whose
+    band fits (asserted from the plan's description), random extensions with bands of 1 to 160 positions over targets several rings
+    long, X-drop, groups of unequal lengths and task counts that leave a wavefront's last groups empty -- against the reference's
+    outputs and the oracle; the same batches with the form off take the other kernels."""
+    from oracle.gen_golden_extf import noisy_pair
+    fc = gu.ExtfCases()
+    cases = [fc.case(k) for k in range(fc.n)]
+    ngrp = 0
+    for sc in sorted({(c["mch"], c["mis"], c["e"]) for c in cases}):
+        sub = [c for c in cases if (c["mch"], c["mis"], c["e"]) == sc]
+        kw = dict(w=[c["w"] for c in sub], xdrop=[c["xdrop"] for c in sub])
+        p = lib.make_linear_batch([c["q"] for c in sub], [c["t"] for c in sub], *sc, **kw).plan()
+        span = [min(len(c["q"]), len(c["t"]), (c["w"] if c["w"] >= 0 else max(len(c["q"]), len(c["t"]))) + 1) for c in sub if len(c["q"]) and len(c["t"])]
+        got = sum(d["tasks"] for d in p.describe() if d["kernel"] == "extf-grp")
+        p.close()
+        assert got == sum(1 for x in span if x <= 160), (got, sc)
+        ngrp += got
+        res = lib.extf_batch([c["q"] for c in sub], [c["t"] for c in sub], *sc, **kw)
+        for r, c in zip(res, sub):
+            assert not diff(r, c["expect"], gu.FIELDS), (sc, len(c["q"]), len(c["t"]), c["w"], c["xdrop"])
+    assert ngrp > 1500
+    rng = np.random.Generator(np.random.PCG64(77))
+    for it in range(rounds):
+        n = int(rng.choice([1, 3, 4, 5, 9]))
+        qs, ts = zip(*[noisy_pair(rng, int(rng.integers(20, maxlen)), (it + k) % 3) for k in range(n)])
+        w = [int(x) for x in rng.choice([0, 1, 5, 15, 16, 40, 100, 158, 159, 160, 300], size=n)]
+        xd = [int(x) for x in rng.choice([-1, 30, 200], size=n)]
+        mch, mis, e = [(2, -4, 2), (1, -3, 1), (3, -2, 4)][it % 3]
+        exp = [po.extf2("oracle", qs[k], ts[k], mch, mis, e, w[k], xd[k]) for k in range(n)]
+        for off in ("", "0"):
+            monkeypatch.setenv("KSW2AMD_EXTF_GRP", off)
+            res = lib.extf_batch(list(qs), list(ts), mch, mis, e, w=w, xdrop=xd)
+            for k in range(n):
+                assert not diff(res[k], exp[k], gu.FIELDS), (it, off, k, len(qs[k]), len(ts[k]), w[k], xd[k])
+    monkeypatch.delenv("KSW2AMD_EXTF_GRP")
+
+
+def test_sim_linear_xdrop_group_form(sim, monkeypatch):
+    _check_extf_group_form(sim, monkeypatch, rounds=24, maxlen=2500)
+
+
 @pytest.mark.parametrize("lds", ["0", "1"])
 def test_sim_row_state_in_registers_and_in_lds(sim, lds, monkeypatch):
     """The classes that can keep row maxima / arg-max columns (and, packed, target codes) in LDS -- packed (64, 16) two-piece
