@@ -269,7 +269,7 @@ class Library:
         return int(self.lib.ksw2amd_rerun_count())
 
     def stream_stats(self):
-        """ksw2amd_stream_stats -> dict(streamed_plans, aborted_runs): plans whose batch ran as one persistent launch under its upload."""
+        """ksw2amd_stream_stats -> dict(streamed_plans, aborted_runs): plans whose batch ran as one launch started under its upload (wavefronts wait for their pieces)."""
         out = (ctypes.c_int64 * 2)()
         self.lib.ksw2amd_stream_stats(out)
         return dict(streamed_plans=int(out[0]), aborted_runs=int(out[1]))

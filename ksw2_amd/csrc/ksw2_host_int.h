@@ -67,6 +67,7 @@
 	X(SSEC_HBM) \
 	X(SSEC_BLK) \
 	X(EXTF_GRP) \
+	X(STREAM_LANES) \
 	X(SSE_COMPAT) \
 	X(STREAM) \
 	X(STREAM_FAULT) \
@@ -129,6 +130,7 @@ typedef struct {
 	uint8_t *d_seq, *d_wm;
 	const uint32_t *wm_src;
 	void *up;
+	void *up2, *ev2[K2A_MAXPIECES];        /* two copy lanes (KSW2AMD_STREAM_LANES): odd pieces travel on a second stream, an event behind each (stream_issue) */
 	int rc;
 	pthread_mutex_t mu;
 } stream_up_t;
@@ -201,6 +203,7 @@ struct ksw2amd_plan_s {
 	uint8_t *d_wm;                         /* watermark block (K2A_WM_BYTES) followed by the K2aQueueDesc array of the streamed classes */
 	K2aQueueDesc *h_qd; int nqd;
 	K2aUniform *uni;                       /* uniform plans (plan_create_uniform): records, task list and piece counts are written on the device by rule */
+	int clear_res, clear_bnd;        /* the first run clears the result records / fills the boundary scratch on its own stream (never the shared upload stream) */
 	size_t need_words;                     /* per-wavefront-task piece counts, behind the task lists in d_order */
 };
 typedef struct { int64_t cost; uint32_t idx, tf; } sort_t;      /* tf = true target length: part of a packed pair's shape */

@@ -135,6 +135,23 @@ void *shared_upload_stream(void)
 	return s;
 }
 
+/* the second copy lane of streamed plans (stream_issue): its own stream, i.e. its own DMA engine */
+static void *g_shared_up2[SHARED_UP_MAXDEV];
+static void *shared_upload_stream2(void)
+{
+	const int dev = k2a_shim_get_device();
+	void *s;
+	if (dev < 0 || dev >= SHARED_UP_MAXDEV) return 0;
+	pthread_mutex_lock(&g_shared_up_mu);
+	if (!g_shared_up2[dev]) g_shared_up2[dev] = k2a_shim_stream_create();
+	s = g_shared_up2[dev];
+	pthread_mutex_unlock(&g_shared_up_mu);
+	return s;
+}
+/* KSW2AMD_STREAM_LANES=1 / 2 forces; unset: two lanes for flat arenas (nothing but the copies to wait for: +15-20 % on config 2), one
+ * where a gather fills the staging buffer at the same time (two lose there: profiles/r5_stream_lanes_ab.txt) */
+static int stream_lanes(int flat) { const char *e = ENV(STREAM_LANES); return e && *e ? (atoi(e) >= 2 ? 2 : 1) : flat ? 2 : 1; }
+
 /* side streams + events for plans with several kernel classes: the classes are independent, and a class of a few long
  * alignments would otherwise hold the whole device for the duration of one alignment while the next class waits */
 #define NSIDE 3
@@ -259,8 +276,18 @@ void stream_issue(stream_up_t *u, int k)
 			struct timespec ts; ts.tv_sec = 0; ts.tv_nsec = (long)u->sleep_us * 1000L;
 			k2a_shim_stream_sync(u->up); nanosleep(&ts, 0);
 		}
-		if (mid > lo && (u->src_on_device ? k2a_shim_d2d(u->d_seq + lo, u->src + lo, mid - lo, u->up) : k2a_shim_h2d(u->d_seq + lo, u->src + lo, mid - lo, u->up))) u->rc = -1;
-		if (hi > mid && u->tail && k2a_shim_h2d(u->d_seq + mid, u->tail + (mid - u->src_bytes), hi - mid, u->up)) u->rc = -1;
+		{
+			/* two lanes: the odd pieces' bytes travel on the second stream (another DMA engine, at the same time as the even pieces' on
+			 * the first), an event behind each; the first stream waits for that event in front of the piece's watermark -- the
+			 * watermarks stay on ONE stream, in order, each behind all the bytes it vouches for */
+			void *lane = (u->up2 && (c & 1)) ? u->up2 : u->up;
+			if (mid > lo && (u->src_on_device ? k2a_shim_d2d(u->d_seq + lo, u->src + lo, mid - lo, lane) : k2a_shim_h2d(u->d_seq + lo, u->src + lo, mid - lo, lane))) u->rc = -1;
+			if (hi > mid && u->tail && k2a_shim_h2d(u->d_seq + mid, u->tail + (mid - u->src_bytes), hi - mid, lane)) u->rc = -1;
+			if (lane != u->up) {
+				if (!u->ev2[c]) u->ev2[c] = k2a_shim_event_create();
+				if (!u->ev2[c] || k2a_shim_event_record(u->ev2[c], lane) || k2a_shim_stream_wait_event(u->up, u->ev2[c])) u->rc = -1;
+			}
+		}
 		if (u->fault && c >= u->np / 2) continue;        /* tests: the watermarks of the second half never arrive -> the launch times out and aborts */
 		if (k2a_shim_h2d(u->d_wm, (const uint8_t*)u->wm_src + (size_t)c * K2A_WM_BYTES, K2A_WM_BYTES, u->up)) u->rc = -1;
 	}
@@ -471,7 +498,11 @@ void ksw2amd_plan_destroy(ksw2amd_plan_t *p)
 	if (!p) return;
 	if (p->gather) gather_wait(p);
 	if (p->up_ev) { k2a_shim_event_sync(p->up_ev); k2a_shim_event_destroy(p->up_ev); p->up_ev = 0; }      /* the upload reads host blocks freed below */
-	if (p->up_state) { pthread_mutex_destroy(&p->up_state->mu); free(p->up_state); p->up_state = 0; }
+	if (p->up_state) {
+		int k;
+		for (k = 0; k < K2A_MAXPIECES; ++k) if (p->up_state->ev2[k]) k2a_shim_event_destroy(p->up_state->ev2[k]);
+		pthread_mutex_destroy(&p->up_state->mu); free(p->up_state); p->up_state = 0;
+	}
 	if (p->wm_ev) { k2a_shim_event_destroy(p->wm_ev); p->wm_ev = 0; }
 	if (p->meta_ev) { k2a_shim_event_sync(p->meta_ev); k2a_shim_event_destroy(p->meta_ev); p->meta_ev = 0; }      /* (its copies read the page-locked staging recycled below) */
 	if (p->stream_used) k2a_shim_stream_sync(p->stream);     /* nothing may still be running on buffers that get recycled */
@@ -710,6 +741,7 @@ ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc
 		pthread_mutex_init(&su->mu, 0);
 		su->wm_src = wm_source();
 		su->up = shared_upload_stream();
+		su->up2 = stream_lanes(flat != 0) == 2 ? shared_upload_stream2() : 0;
 		su->fault = env_flag(ENV(STREAM_FAULT), 0); su->sleep_us = ENV(STREAM_SLEEP_US) ? atoi(ENV(STREAM_SLEEP_US)) : 0;
 		su->hold = 2;
 		p->d_seq = (uint8_t*)cache_get(BUF_SEQ, p->seq_bytes, &p->cap[BUF_SEQ]);
@@ -1211,6 +1243,9 @@ ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc
 			             b_qd = sizeof(K2aQueueDesc) * (size_t)p->nqd;
 			int all_queues = p->nqd > 0;
 			for (k = 0; k < p->ncls; ++k) if (p->cls[k].qd < 0) all_queues = 0;
+			/* (the clears are kernels: on the stream the plan first runs on, never on the shared upload stream -- a kernel there gets no
+			 * wavefront slot while a device-filling launch waits for pieces queued behind it) */
+			p->clear_res = !all_queues; p->clear_bnd = p->bnd_words > 0;
 			p->h_meta = (uint8_t*)cache_get(BUF_HMETA, b_pairs + b_order + b_qd + 256, &p->cap[BUF_HMETA]);
 			if (!p->h_meta) { fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
 			memcpy(p->h_meta, p->h_pairs, sizeof(K2aPair) * (size_t)n);
@@ -1221,8 +1256,6 @@ ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc
 		    k2a_shim_h2d(p->d_pairs, p->h_meta, sizeof(K2aPair) * (size_t)n, up) ||
 		    k2a_shim_h2d(p->d_order, p->h_meta + b_pairs, sizeof(uint32_t) * ((size_t)p->norder + p->need_words), up) ||
 		    (p->nqd && k2a_shim_h2d(p->d_wm + K2A_WM_BYTES, p->h_meta + b_pairs + b_order, b_qd, up)) ||
-		    (!all_queues && k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)n, up)) ||
-		    (p->bnd_words && k2a_shim_memset(p->d_bnd, 0xC0, p->bnd_words * 4, up)) ||
 		    k2a_shim_event_record(p->meta_ev, up)) {
 			pthread_mutex_unlock(&su->mu);
 			fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error());
@@ -1256,14 +1289,13 @@ ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc
 		memcpy(hm, p->h_pairs, sizeof(K2aPair) * (size_t)n);
 		memcpy(hm + b_pairs, p->h_order, sizeof(uint32_t) * (size_t)p->norder);
 		p->up_ev = k2a_shim_event_create();
+		p->clear_res = need_clear; p->clear_bnd = p->bnd_words > 0;   /* on the stream of the first run (see the streamed branch) */
 		if (shared_up) pthread_mutex_lock(&g_shared_issue_mu);      /* one plan's copies in one piece */
 		if (!p->up_ev ||
 		    (flat && ((flat->on_device ? k2a_shim_d2d(p->d_seq, flat_lo, flat_span, up) : k2a_shim_h2d(p->d_seq, flat_lo, flat_span, up)) ||
 		              k2a_shim_h2d(p->d_seq + flat_span, hm + align_up(b_meta, 256), tail, up) ||
 		              k2a_shim_h2d(p->d_pairs, hm, b_meta, up))) ||
 		    (!flat && k2a_shim_h2d(p->d_seq, p->h_seq, meta_off + b_meta, up)) ||
-		    (need_clear && k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)n, up)) ||
-		    (p->bnd_words && k2a_shim_memset(p->d_bnd, 0xC0, p->bnd_words * 4, up)) ||
 		    k2a_shim_event_record(p->up_ev, up)) {
 			if (shared_up) pthread_mutex_unlock(&g_shared_issue_mu);
 			fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error());
@@ -1399,6 +1431,7 @@ static ksw2amd_plan_t *plan_create_uniform(int dual, int scalar, const ksw2amd_s
 		su->wm_src = k2a_wm_source();
 	}
 	su->up = shared_upload_stream();
+	su->up2 = stream_lanes(0) == 2 ? shared_upload_stream2() : 0;
 	su->fault = env_flag(ENV(STREAM_FAULT), 0); su->sleep_us = ENV(STREAM_SLEEP_US) ? atoi(ENV(STREAM_SLEEP_US)) : 0;
 	su->src = p->h_seq; su->src_bytes = p->seq_bytes;
 	p->d_seq = (uint8_t*)cache_get(BUF_SEQ, p->seq_bytes, &p->cap[BUF_SEQ]);
@@ -1462,7 +1495,11 @@ ksw2amd_plan_t *plan_create_uniform_entry(int dual, int scalar, const ksw2amd_sc
 
 ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs)
 {
-	return plan_create_ex(dual, 0, sc, n, pairs, 0, 0);      /* (KSW2AMD_STREAM=1 streams these too: tests, A/B runs) */
+	/* (KSW2AMD_STREAM=1 streams these too: tests, A/B runs.)  create = pack + upload: the caller may free its inputs on return, so a
+	 * gather still reading them on the pool's threads is waited for here (the batch entries call plan_create_ex and keep the overlap) */
+	ksw2amd_plan_t *p = plan_create_ex(dual, 0, sc, n, pairs, 0, 0);
+	if (p && p->gather) gather_wait(p);
+	return p;
 }
 
 
@@ -1478,6 +1515,10 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 	streaming = p->streamed && p->nqd > 0;
 	if (p->up_ev && !streaming && k2a_shim_stream_wait_event(stream, p->up_ev)) goto err;      /* the plan's upload (shared stream) before its kernels */
 	if (p->reject_all || p->ntasks == 0) return KSW2AMD_OK;
+	/* first run: the records no kernel writes (invalid pairs, read by the CIGAR compaction) and the boundary scratch's -inf pattern */
+	if ((p->clear_res && k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)p->n, stream)) ||
+	    (p->clear_bnd && k2a_shim_memset(p->d_bnd, 0xC0, p->bnd_words * 4, stream))) goto err;
+	p->clear_res = p->clear_bnd = 0;
 	/* uniform plans: the records, the task list and the piece counts are written on the device by rule (K2aUniform), in front of the
 	 * launches that read them; nothing of them was built or uploaded by the host */
 	if (p->uni && k2a_shim_launch_uniform_layout(p->uni, p->d_pairs, p->d_order, p->nqd ? p->d_order + p->norder : 0, stream)) goto err;

@@ -646,6 +646,12 @@ static int run_batch(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc
 	g_job_threads = 0;
 	return rc;
 }
+/* plans created on the calling thread run on ITS current device: only where that is the device the caller selected
+ * (ksw2amd_set_devices(1, &d) with another d: the pool's workers, which switch to d, take the batch) */
+static int calling_thread_on_set_device(void)
+{
+	return g_ndev_set == 0 || (g_ndev_set == 1 && g_dev_set[0] == k2a_shim_get_device());
+}
 static int run_batch_(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez, const flat_src_t *flat)
 {
 	const int tpd = pool_threads_per_device();
@@ -671,7 +677,7 @@ static int run_batch_(int dual, int scalar, void *km, const ksw2amd_scoring_t *s
 		 * same box: 4 060 against 3 800 GCUPS through the pointer entry, 4 510 against 4 270 through the flat one), not 512-base reads,
 		 * whose plan creation on one thread costs what six workers' chunks cost together (config 2: 3.9 against 3.4-4.0 ms) -- so by
 		 * default batches of at least 1 M cells per pair.  KSW2AMD_STREAM=1: every one-shape score-only batch; =0: chunks. */
-		if (uniform && (pairs[0].flag & KSW_EZ_SCORE_ONLY) && stream_env() != 0 && g_ndev_set <= 1 && !pool_min_pairs() &&
+		if (uniform && (pairs[0].flag & KSW_EZ_SCORE_ONLY) && stream_env() != 0 && calling_thread_on_set_device() && !pool_min_pairs() &&
 		    ((double)n * ((double)imax(pairs[0].qlen, 0) + imax(pairs[0].tlen, 0)) >= 4.0 * 1048576.0 || (same && ENV(UNIFORM) && atoi(ENV(UNIFORM)) == 1))) {      /* (KSW2AMD_UNIFORM=1: tests, small batches) */
 			const int mx0 = imax(pairs[0].qlen, pairs[0].tlen);
 			const int64_t c0 = pairs[0].qlen > 0 && pairs[0].tlen > 0 ? band_cells(pairs[0].qlen, pairs[0].tlen, (pairs[0].w < 0 || pairs[0].w > mx0) ? mx0 : pairs[0].w) : 0;
@@ -698,7 +704,7 @@ static int run_batch_(int dual, int scalar, void *km, const ksw2amd_scoring_t *s
 			if (dev_bytes > 64e9 && !pool_min_pairs()) {
 				/* traceback memory is what splits this batch: one plan at a time with the whole device, not a slice per worker */
 				size_t free_b = 0, total_b = 0;
-				if (k2a_shim_mem_info(&free_b, &total_b) == 0 && dev_bytes > 0.5 * (double)total_b && g_ndev_set <= 1) { free(cost); return run_serial(dual, scalar, km, sc, n, pairs, ez, 1, flat, 0); }
+				if (k2a_shim_mem_info(&free_b, &total_b) == 0 && dev_bytes > 0.5 * (double)total_b && calling_thread_on_set_device()) { free(cost); return run_serial(dual, scalar, km, sc, n, pairs, ez, 1, flat, 0); }
 			}
 			for (i = 0; i < (uniform ? 1 : n); ++i) {
 				const int ql = imax(pairs[i].qlen, 0), tl = imax(pairs[i].tlen, 0), mx = imax(ql, tl);

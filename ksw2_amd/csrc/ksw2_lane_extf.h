@@ -27,7 +27,7 @@ K2A_FN bool k2a_extf_diag(int r, int qlen, int tlen, int w, int tpad, K2aExtfDia
 	d.hi = k2a_min(k2a_min(tlen - 1, r), (r + w) >> 1);
 	if (d.lo > d.hi) return false;
 	d.blo = d.lo & ~15; d.bhi = d.hi | 15;
-	d.fresh_end = k2a_min(tpad, d.lo + ((d.hi - d.lo) / 16 + 1) * 16);
+	d.fresh_end = k2a_min(tpad, d.lo + (int)(((uint32_t)(d.hi - d.lo) >> 4) + 1u) * 16);      /* (hi >= lo: a shift, not a signed division) */
 	return true;
 }
 

@@ -40,7 +40,7 @@ K2A_FN bool k2a_ssec_bounds(int r, int qlen, int tlen, int w, int &st0, int &en0
 	if (a < (r - w + 1) >> 1) a = (r - w + 1) >> 1;
 	if (b > (r + w) >> 1) b = (r + w) >> 1;
 	st0 = a; en0 = b;
-	st = a / 16 * 16; en = (b + 16) / 16 * 16 - 1;
+	st = a & ~15; en = ((b + 16) & ~15) - 1;               /* a, b >= 0 where the range is not empty */
 	return a <= b;
 }
 
@@ -152,7 +152,7 @@ K2A_FN int k2a_ssec_zdrop(K2aBook *b, int H, int r, int t, int zdrop, int slope)
 K2A_FN int k2a_ssec_book(K2aBook *b, int r, int st0, int en0, int en, int qlen, int tlen, int zdrop, int slope,
                          int A, uint64_t Bkey, int T0, int T1, int T2, int S)
 {
-	const int en1 = st0 + (en0 - st0) / 4 * 4;
+	const int en1 = st0 + (int)((uint32_t)(en0 - st0) & ~3u);
 	int max_H = A, max_t = en0;
 	if (Bkey != 0 && k2a_dm_key_H(Bkey) > max_H) { max_H = k2a_dm_key_H(Bkey); max_t = k2a_dm_key_t(Bkey); }
 	if (en1 < en0 && T0 > max_H) { max_H = T0; max_t = en1; }

@@ -64,9 +64,11 @@ typedef uint32_t k2a_quad __attribute__((vector_size(16)));
  * number: hipcc turns such a subscript on a member into an address, and the lane's whole state then lives in scratch memory */
 K2A_FN uint32_t k2a_sb_get(const k2a_blk &a, int slot)
 {
-	uint32_t d = 0;
-#pragma unroll
-	for (int i = 0; i < 8; ++i) d |= a[i] & (uint32_t)-(int)((slot >> 1) == i);
+	/* a tree of seven selects on the three bits of the register number (three masks): 10 instructions where one compare and select
+	 * per register takes 24 */
+	const uint32_t m0 = k2a_bit_mask((uint32_t)slot, 1), m1 = k2a_bit_mask((uint32_t)slot, 2), m2 = k2a_bit_mask((uint32_t)slot, 3);
+	const uint32_t t01 = k2a_pk_selv(m0, a[1], a[0]), t23 = k2a_pk_selv(m0, a[3], a[2]), t45 = k2a_pk_selv(m0, a[5], a[4]), t67 = k2a_pk_selv(m0, a[7], a[6]);
+	const uint32_t d = k2a_pk_selv(m2, k2a_pk_selv(m1, t67, t45), k2a_pk_selv(m1, t23, t01));
 	return ((slot & 1) ? d >> 24 : d >> 8) & 0xffu;
 }
 K2A_FN void k2a_sb_set(k2a_blk &a, int slot, int byte)

@@ -93,9 +93,12 @@ int k2a_shim_launch_trace(int cfg, int dual, const K2aPair *pairs, const uint32_
  * (K2aLanePk, DEFER).  Every pair of a wavefront carries the wavefront's checkpoint block in tb_off (byte offset in tb), its
  * stream length in steps in bnd_off and the strips-per-group stride of its header table in cig_off:
  *   block = [bnd_off steps][64 lanes] x 8 bytes, then [64 / G groups][cig_off strips] x 16 bytes (K2aCkHead). */
-/* qd != NULL (device pointer, K2aQueueDesc in ksw2_types.h): a streamed launch -- at most as many workgroups as the device holds at
- * once, wavefronts pop their wavefront-tasks from qd->next and wait for qd->need[] pieces of the upload.  Score-only classes only
- * (mode == K2A_MODE_SCORE): those are what the batch entry points stream. */
+/* qd != NULL (device pointer, K2aQueueDesc in ksw2_types.h): a streamed launch -- the ordinary full grid, every wavefront's task given
+ * by its position in the grid, started under the upload: a wavefront first waits (k2a_queue_wait) until the watermark says that the
+ * qd->need[] pieces its task lies in have landed, or gives up after the timeout and sets qd->abort; qd->next only counts the
+ * wavefront-tasks that started (the fetch compares it with the task count).  Because the grid can fill the device with waiting
+ * wavefronts, nothing the pieces depend on may be a kernel queued behind it.  Score-only classes only (mode == K2A_MODE_SCORE):
+ * those are what the batch entry points stream. */
 int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax, int defer, const K2aScoring *sc, const K2aPair *pairs, const uint32_t *order2,
                             int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, K2aQueueDesc *qd, void *stream);
 int k2a_shim_launch_trace_pk(int cfg, int dual, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb,

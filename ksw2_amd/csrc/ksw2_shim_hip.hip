@@ -1541,7 +1541,7 @@ __device__ __forceinline__ void k2a_ssec_blk_task(const K2aSsec &P, const K2aPai
 	for (int r = 0; r < qlen + tlen - 1; ++r) {
 		int st0, en0, st, en;
 		if (!k2a_ssec_bounds(r, qlen, tlen, w, st0, en0, st, en)) { book.dropped = 1; break; }      /* ksw2_extz2_sse.c:111-114 */
-		const int pend = min(st0 + ((en0 - st0) / 16 + 1) * 16, T16);       /* the score refresh's end (:125-140), see k2a_ssec_kernel */
+		const int pend = min(st0 + (int)(((uint32_t)(en0 - st0) >> 4) + 1u) * 16, T16);       /* the score refresh's end (:125-140), see k2a_ssec_kernel */
 		B.shift_query(P, r);
 		/* blocks that enter: the lane's next turn in the ring */
 		{
@@ -1587,7 +1587,7 @@ __device__ __forceinline__ void k2a_ssec_blk_task(const K2aSsec &P, const K2aPai
 		if (!APPROX) {
 			int A, Sv, T0 = K2A_NEG, T1 = K2A_NEG, T2 = K2A_NEG;
 			uint64_t bk = 0;
-			const int en1 = st0 + (en0 - st0) / 4 * 4;
+			const int en1 = st0 + (int)((uint32_t)(en0 - st0) & ~3u);
 			if (r > 0) {
 				if (!(en0 == last_en0 && en0 - 1 < last_st0 && en0 > 0)) hprev = __builtin_amdgcn_readfirstlane(hnew);
 				int dl;
