@@ -642,6 +642,7 @@ def main():
     for _ in range(args.warmup):
         job.e2e_step()
     stats0 = lib.host_stats()
+    phase0 = lib.host_phase_ms()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -649,6 +650,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     stats1 = lib.host_stats()
+    phase1 = lib.host_phase_ms()
+    # host-thread milliseconds per step of this rank's batch entry calls (summed over its worker threads): plan creation = pack / gather /
+    # uploads issued; launch calls; waiting for the device + fetch + ksw_extz_t assembly.  In config.per_rank: which side a slow rank was slow on.
+    host_ms = {k: round((phase1[k] - phase0[k]) / max(args.steps, 1), 3) for k in ("create_ms", "launch_ms", "wait_fetch_ms")}
+    host_ms["plans_per_step"] = round((phase1["plans"] - phase0["plans"]) / max(args.steps, 1), 2)
     per_rank = None
     if world > 1:
         mine = torch.tensor([float(job.cells), dt], dtype=torch.float64, device=red_dev)
@@ -658,8 +664,11 @@ def main():
                      "gcups": round(float(x[0].item()) * args.steps / float(x[1].item()) / 1e9, 1)} for r, x in enumerate(allr)]
         aff = [None] * world
         dist.all_gather_object(aff, affinity)                           # NUMA node / cores every rank ran on
+        hm = [None] * world
+        dist.all_gather_object(hm, host_ms)
         for r in range(world):
             per_rank[r]["affinity"] = aff[r]
+            per_rank[r]["host_thread_ms_per_step"] = hm[r]
         tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -730,6 +739,8 @@ def main():
             out["config"]["rank0_scatter_gather"] = sg
         if per_rank:
             out["config"]["per_rank"] = per_rank
+        else:
+            out["config"]["host_thread_ms_per_step"] = host_ms
         if world > 1 and not plumbing:
             try:
                 out["config"]["cfg5_lpt_imbalance"] = lpt_imbalance(world)

@@ -182,6 +182,10 @@ long ksw2amd_small_call_count(void);
 /* diagnostics: { batches run on the worker pool, chunks they were cut into, single-pair calls that were coalesced with other
  * threads' calls, device batches those formed } since the library was loaded */
 void ksw2amd_host_stats(int64_t out[4]);
+/* where the batch entry points' host threads spent their time, in microseconds summed over threads since the library was loaded:
+ * { plan creation (pack / gather into page-locked staging, uploads issued), launch calls, waiting for the device + fetch + ksw_extz_t
+ * assembly, plans run }.  For a multi-rank job's per-rank report (bench.py config.per_rank): which side a slow rank was slow on. */
+void ksw2amd_host_phase_us(int64_t out[4]);
 
 /* n independent alignments; ez[i] ends up exactly as after
  *   ksw_extz2_sse(km, pairs[i].qlen, pairs[i].query, ..., sc->m, sc->mat, sc->q, sc->e, w, zdrop, end_bonus, flag, &ez[i])

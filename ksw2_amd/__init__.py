@@ -81,7 +81,7 @@ EXPORTS = ["ksw_extz2_sse", "ksw_extd2_sse", "ksw_gg2", "ksw_gg2_sse", "ksw_extz
            "ksw2amd_set_sse_compat", "ksw2amd_sse_plan_create", "ksw2amd_plan_describe", "ksw2amd_reload_env",
            "ksw2amd_extz_batch_flat", "ksw2amd_extd_batch_flat", "ksw2amd_plan_create_flat", "ksw2amd_host_register", "ksw2amd_host_unregister",
            "ksw2amd_device_alloc", "ksw2amd_device_free", "ksw2amd_device_upload", "ksw2amd_device_download", "ksw2amd_rerun_count",
-           "ksw2amd_set_small_call_cells", "ksw2amd_small_call_count", "ksw2amd_stream_stats"]
+           "ksw2amd_set_small_call_cells", "ksw2amd_small_call_count", "ksw2amd_stream_stats", "ksw2amd_host_phase_us"]
 # entry points whose behaviour depends on KSW2AMD_* switches: the library reads its environment once per process, so this binding
 # re-reads it in front of each of them (tests and A/B scripts flip switches inside one process)
 _ENV_ENTRIES = ["ksw_extz2_sse", "ksw_extd2_sse", "ksw_gg2", "ksw_gg2_sse", "ksw_extz", "ksw_extd", "ksw_gg", "ksw_extz2_sse41",
@@ -182,6 +182,8 @@ class Library:
         L.ksw2amd_release_cache.restype = None
         L.ksw2amd_host_stats.argtypes = [ctypes.POINTER(ctypes.c_int64)]
         L.ksw2amd_host_stats.restype = None
+        L.ksw2amd_host_phase_us.argtypes = [ctypes.POINTER(ctypes.c_int64)]
+        L.ksw2amd_host_phase_us.restype = None
         L.ksw2amd_plan_describe.argtypes = [ctypes.c_void_p, ctypes.c_char_p, _int]
         fl = [km, ctypes.POINTER(Scoring), _int, ctypes.POINTER(Flat), ezp]
         L.ksw2amd_extz_batch_flat.argtypes = fl
@@ -273,6 +275,12 @@ class Library:
         out = (ctypes.c_int64 * 2)()
         self.lib.ksw2amd_stream_stats(out)
         return dict(streamed_plans=int(out[0]), aborted_runs=int(out[1]))
+
+    def host_phase_ms(self):
+        """ksw2amd_host_phase_us -> dict(create_ms, launch_ms, wait_fetch_ms, plans): host-thread time of the batch entry points, summed over threads."""
+        out = (ctypes.c_int64 * 4)()
+        self.lib.ksw2amd_host_phase_us(out)
+        return dict(create_ms=out[0] / 1000.0, launch_ms=out[1] / 1000.0, wait_fetch_ms=out[2] / 1000.0, plans=int(out[3]))
 
     def host_stats(self):
         """ksw2amd_host_stats -> dict(pool_batches, pool_chunks, coalesced_calls, coalesced_batches)."""

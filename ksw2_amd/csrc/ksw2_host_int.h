@@ -97,6 +97,7 @@ extern int64_t g_reruns;
 extern int64_t g_stat[4];
 extern __thread int g_is_worker;
 extern int g_ndev_set, g_dev_set[POOL_MAXDEV];
+void phase_add(double create_ms, double launch_ms, double fetch_ms);      /* ksw2amd_host_phase_us */
 extern const char *g_env[ENV_COUNT];
 extern volatile int g_env_ready;
 extern __thread char g_err[512];

@@ -1987,6 +1987,18 @@ size_t pair_device_bytes(int dual, const ksw2amd_pair_t *a)
 
 /* One slice of a batch on the calling thread: plan(s) sized to `1 / share` of the device's free memory (share = threads that
  * work on this device at the same time), each created, run on the thread's own stream, fetched and destroyed. */
+int64_t g_phase_us[4];                   /* ksw2amd_host_phase_us */
+void phase_add(double create_ms, double launch_ms, double fetch_ms)
+{
+	__sync_fetch_and_add(&g_phase_us[0], (int64_t)(create_ms * 1000.0)); __sync_fetch_and_add(&g_phase_us[1], (int64_t)(launch_ms * 1000.0));
+	__sync_fetch_and_add(&g_phase_us[2], (int64_t)(fetch_ms * 1000.0)); __sync_fetch_and_add(&g_phase_us[3], 1);
+}
+void ksw2amd_host_phase_us(int64_t out[4])
+{
+	int i;
+	for (i = 0; i < 4; ++i) out[i] = g_phase_us[i];
+}
+
 int run_serial(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, ksw_extz_t *ez, int share, const flat_src_t *flat, int want_stream)
 {
 	size_t budget, free_b = 0, total_b = 0, acc;
@@ -2039,6 +2051,7 @@ int run_serial(int dual, int scalar, void *km, const ksw2amd_scoring_t *sc, int 
 			t2 = now_ms();
 			if (rc == KSW2AMD_OK) rc = ksw2amd_plan_fetch(p, km, ez + beg);
 			t3 = now_ms();
+			phase_add(t1 - t0, t2 - t1, t3 - t2);
 			if (!trace_on()) { ksw2amd_plan_destroy(p); p = 0; }
 			if (trace_on()) {
 				float dev_ms = -1.0f;

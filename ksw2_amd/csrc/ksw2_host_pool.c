@@ -687,10 +687,15 @@ static int run_batch_(int dual, int scalar, void *km, const ksw2amd_scoring_t *s
 			 * per-pair work on this thread, the records built on the device, ONE streamed launch -- whatever the reads' length (round 5:
 			 * config 2, whose plan creation used to cost more than its kernel, goes this way too) */
 			if (same && fits && !flat) {
+				const double tu0 = now_ms();
 				ksw2amd_plan_t *up = plan_create_uniform_entry(dual, scalar, sc, n, pairs);
 				if (up) {
+					const double tu1 = now_ms();
+					double tu2;
 					rc = ksw2amd_plan_run(up, g_plan_stream ? g_plan_stream : thread_stream());
+					tu2 = now_ms();
 					if (rc == KSW2AMD_OK) rc = ksw2amd_plan_fetch(up, km, ez);
+					phase_add(tu1 - tu0, tu2 - tu1, now_ms() - tu2);
 					ksw2amd_plan_destroy(up);
 					return rc;
 				}

@@ -29,7 +29,10 @@ ENVS = [{}, {"KSW2AMD_SOLO": "1"}, {"KSW2AMD_SOLO": "all"}, {"KSW2AMD_LDSROWS": 
         {"KSW2AMD_DEFER": "1"}, {"KSW2AMD_SOLO": "0"}, {"KSW2AMD_EXTF_LANE": "1", "KSW2AMD_EXTF_RING": "1"}, {"KSW2AMD_EXTF_LANE": "1", "KSW2AMD_EXTF_RING": "0"},
         # streamed plans (round 4): every plan that can, the arena in small pieces; with the packed kernels forced for small test batches
         {"KSW2AMD_STREAM": "1", "KSW2AMD_STREAM_PIECE_KB": "64", "KSW2AMD_SIMDS": "0"}, {"KSW2AMD_STREAM": "1", "KSW2AMD_STREAM_PIECE_KB": "256", "KSW2AMD_DEFER": "1", "KSW2AMD_SIMDS": "0"},
-        {"KSW2AMD_STREAM": "0"}]
+        {"KSW2AMD_STREAM": "0"},
+        # round 5: the SSE-compatible score-only tasks and the narrow-band X-drop extensions through their other kernels; two copy lanes
+        {"KSW2AMD_SSEC_BLK": "0"}, {"KSW2AMD_EXTF_GRP": "0"}, {"KSW2AMD_EXTF_GRP": "1", "KSW2AMD_EXTF_LDS": "1"},
+        {"KSW2AMD_STREAM": "1", "KSW2AMD_STREAM_PIECE_KB": "64", "KSW2AMD_STREAM_LANES": "2", "KSW2AMD_SIMDS": "0"}, {"KSW2AMD_UNIFORM": "1", "KSW2AMD_POOL_MIN": "4", "KSW2AMD_SIMDS": "0"}]
 KEYS = sorted({k for e in ENVS for k in e})
 t0 = time.time()
 rounds = pairs = 0
@@ -60,7 +63,7 @@ while time.time() - t0 < budget:
         fl = np.array([mode | (po.EXTZ_ONLY if rng.random() < 0.3 else 0) | (po.REV_CIGAR if rng.random() < 0.3 else 0) |
                        (po.GENERIC_SC if rng.random() < 0.2 else 0) | (po.EQX if dual and rng.random() < 0.2 else 0) for _ in range(n)])
         if not LONG and rng.random() < 0.3:                                 # the SSE kernels' own results: opt-in flag, or the APPROX_DROP route
-            wn = rng.choice([-1, 0, 1, 2, 5, 9, 16, 33, 64, 100, 300], size=n)
+            wn = rng.choice([-1, 0, 1, 2, 5, 9, 16, 33, 64, 100, 300, 700, 959, 960], size=n)
             fl2 = np.array([int(f) & ~po.EQX | (po.EQX if dual and rng.random() < 0.1 and not (f & po.SCORE_ONLY) else 0) |
                             int(rng.choice([ka.KSW2AMD_EZ_SSE_COMPAT, ka.KSW2AMD_EZ_SSE_COMPAT | po.APPROX_MAX, po.APPROX_MAX | po.APPROX_DROP])) for f in fl])
             res = lib.extd_batch(qs, ts, mat, q, e, q2, e2, w=wn, zdrop=zd, end_bonus=eb, flag=fl2) if dual else \
@@ -96,7 +99,7 @@ while time.time() - t0 < budget:
     elif kind == 2:                                                       # extf2
         n = int(rng.integers(4, 40))
         prs = [noisy_pair(rng, int(rng.integers(1, int(rng.choice([200, 1500, 6000])))), int(rng.integers(7))) for _ in range(n)]
-        w = rng.choice([-1, 0, 3, 16, 33, 100, 146, 147, 300, 402, 403, 900], size=n)
+        w = rng.choice([-1, 0, 3, 16, 33, 100, 146, 147, 158, 159, 160, 300, 402, 403, 900], size=n)
         xd = rng.choice([-1, 10, 60, 500], size=n)
         mch, mis, e = [(1, -2, 1), (2, -4, 2), (4, -6, 3)][int(rng.integers(3))]
         res = lib.extf_batch([p[0] for p in prs], [p[1] for p in prs], mch, mis, e, w=w, xdrop=xd)
