@@ -76,8 +76,12 @@ WORKLOADS = {
     "10k-generic": dict(idx=6, n=49152, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=SO | ksw2_amd.KSW_EZ_GENERIC_SC, sub=0.05, ind=0.06, tstv=True),
     # ... and in the SSE-compatible mode (the reference's SSE kernels' own results): every pair through k2a_ssec_kernel
     "10k-ssec": dict(idx=6, n=1024, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=SO, sub=0.05, ind=0.06, sse=True),
+    # ... at four wavefronts per SIMD instead of one (the kernel holds one alignment per wavefront: 1 024 pairs are one wavefront per SIMD,
+    # which issues at half the rate a SIMD reaches with four) and with KSW_EZ_APPROX_MAX (one followed cell instead of H: the reference's fast mode)
+    "10k-ssec-n4096": dict(idx=6, n=4096, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=SO, sub=0.05, ind=0.06, sse=True),
+    "10k-ssec-approx": dict(idx=6, n=4096, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=SO | 0x08, sub=0.05, ind=0.06, sse=True),
 }
-ALSO_DEFAULT = ["10k-n1024", "10k-cigar", "cfg2", "cfg3", "cfg5", "cfg4", "cfg5-share", "10k-zdrop", "10k-N", "10k-generic", "exts", "extf", "10k-ssec"]
+ALSO_DEFAULT = ["10k-n1024", "10k-cigar", "cfg2", "cfg3", "cfg5", "cfg4", "cfg5-share", "10k-zdrop", "10k-N", "10k-generic", "exts", "extf", "10k-ssec", "10k-ssec-n4096", "10k-ssec-approx"]
 # pairs of each workload's last timed batch that are compared with the oracle outside the clock (the MT pair costs ~1 s per pair on the host)
 PARITY_PAIRS = {"cfg4": 16, "cfg4-so": 4, "cfg5": 16, "cfg5-share": 16}
 # N > 1: the configurations BASELINE.json quotes for several GPUs at their per-GPU share (config 4: 4 096 replicas / 8)
