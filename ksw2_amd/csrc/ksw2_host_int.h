@@ -68,6 +68,8 @@
 	X(SSEC_BLK) \
 	X(EXTF_GRP) \
 	X(STREAM_LANES) \
+	X(WIRE4) \
+	X(PLAIN_UP_STREAMS) \
 	X(SSE_COMPAT) \
 	X(STREAM) \
 	X(STREAM_FAULT) \
@@ -84,7 +86,7 @@ enum {
 #undef X
 	ENV_COUNT
 };
-enum { BUF_HSEQ, BUF_SEQ, BUF_PAIRS, BUF_RES, BUF_ORDER, BUF_TB, BUF_CIG, BUF_BND, BUF_POS, BUF_POOL, BUF_HPOOL, BUF_HRES, BUF_WM, BUF_HMETA, BUF_KINDS };
+enum { BUF_HSEQ, BUF_SEQ, BUF_PAIRS, BUF_RES, BUF_ORDER, BUF_TB, BUF_CIG, BUF_BND, BUF_POS, BUF_POOL, BUF_HPOOL, BUF_HRES, BUF_WM, BUF_HMETA, BUF_PK4, BUF_KINDS };
 #define BUF_IS_HOST(k) ((k) == BUF_HSEQ || (k) == BUF_HPOOL || (k) == BUF_HRES || (k) == BUF_HMETA)      /* pinned host staging; everything else is device memory */
 #define CACHE_DEPTH 2                  /* a worker that queues its next chunk before it fetches the current one holds two plans */
 #define SHARED_UP_MAXDEV 16
@@ -97,6 +99,8 @@ extern int64_t g_reruns;
 extern int64_t g_stat[4];
 extern __thread int g_is_worker;
 extern int g_ndev_set, g_dev_set[POOL_MAXDEV];
+void wire4_pair(const ksw2amd_plan_t *p, int i, uint8_t *out);
+int plan_wire4(const ksw2amd_plan_t *p);
 void phase_add(double create_ms, double launch_ms, double fetch_ms);      /* ksw2amd_host_phase_us */
 extern const char *g_env[ENV_COUNT];
 extern volatile int g_env_ready;
@@ -131,6 +135,7 @@ typedef struct {
 	uint8_t *d_seq, *d_wm;
 	const uint32_t *wm_src;
 	void *up;
+	int wire4, wire_bad;                   /* uniform plans: the staging buffer and the upload hold two codes per byte; a source byte above 15 was met (the batch is repeated on the general path) */
 	void *up2, *ev2[K2A_MAXPIECES];        /* two copy lanes (KSW2AMD_STREAM_LANES): odd pieces travel on a second stream, an event behind each (stream_issue) */
 	int rc;
 	pthread_mutex_t mu;
@@ -204,6 +209,7 @@ struct ksw2amd_plan_s {
 	uint8_t *d_wm;                         /* watermark block (K2A_WM_BYTES) followed by the K2aQueueDesc array of the streamed classes */
 	K2aQueueDesc *h_qd; int nqd;
 	K2aUniform *uni;                       /* uniform plans (plan_create_uniform): records, task list and piece counts are written on the device by rule */
+	uint8_t *d_pk4;                  /* uniform plans on the 4-bit wire format: the device copy of the upload (the arena the kernels read is d_seq) */
 	int clear_res, clear_bnd;        /* the first run clears the result records / fills the boundary scratch on its own stream (never the shared upload stream) */
 	size_t need_words;                     /* per-wavefront-task piece counts, behind the task lists in d_order */
 };

@@ -129,7 +129,7 @@ void *shared_upload_stream(void)
 	void *s;
 	if (dev < 0 || dev >= SHARED_UP_MAXDEV) return 0;
 	pthread_mutex_lock(&g_shared_up_mu);
-	if (!g_shared_up[dev]) g_shared_up[dev] = k2a_shim_stream_create();
+	if (!g_shared_up[dev]) g_shared_up[dev] = ENV(PLAIN_UP_STREAMS) ? k2a_shim_stream_create() : k2a_shim_stream_create_low();
 	s = g_shared_up[dev];
 	pthread_mutex_unlock(&g_shared_up_mu);
 	return s;
@@ -143,7 +143,7 @@ static void *shared_upload_stream2(void)
 	void *s;
 	if (dev < 0 || dev >= SHARED_UP_MAXDEV) return 0;
 	pthread_mutex_lock(&g_shared_up_mu);
-	if (!g_shared_up2[dev]) g_shared_up2[dev] = k2a_shim_stream_create();
+	if (!g_shared_up2[dev]) g_shared_up2[dev] = ENV(PLAIN_UP_STREAMS) ? k2a_shim_stream_create() : k2a_shim_stream_create_low();
 	s = g_shared_up2[dev];
 	pthread_mutex_unlock(&g_shared_up_mu);
 	return s;
@@ -512,6 +512,7 @@ void ksw2amd_plan_destroy(ksw2amd_plan_t *p)
 	if (!p->meta_folded) cache_put(BUF_ORDER, p->d_order, p->cap[BUF_ORDER]);
 	cache_put(BUF_CIG, p->d_cig, p->cap[BUF_CIG]);
 	cache_put(BUF_BND, p->d_bnd, p->cap[BUF_BND]); cache_put(BUF_WM, p->d_wm, p->cap[BUF_WM]); cache_put(BUF_HMETA, p->h_meta, p->cap[BUF_HMETA]);
+	cache_put(BUF_PK4, p->d_pk4, p->cap[BUF_PK4]);
 	free(p->h_qd);
 	for (i = 0; i < 3; ++i) if (p->ev[i]) { if (!g_ev_cache[i]) g_ev_cache[i] = p->ev[i]; else k2a_shim_event_destroy(p->ev[i]); }
 	free(p->h_pairs); free(p->h_cls); free(p->h_half); free(p->h_flag); free(p->h_order);
@@ -1351,8 +1352,9 @@ static ksw2amd_plan_t *plan_create_uniform(int dual, int scalar, const ksw2amd_s
 	K2aUniform *u = 0;
 	cls_t c0;
 	K2aPair tm;
-	int cls0, flag0, k, G, C, NG, nwt, mx, w;
+	int cls0, flag0, k, G, C, NG, nwt, mx, w, wire4;
 	size_t pbytes, ppp;
+	uint8_t *d_pk = 0;
 	const char *ev = ENV(UNIFORM);
 	g_err[0] = 0;
 	if ((ev && atoi(ev) == 0) || n < K2A_UNI_MIN_PAIRS || (n & 1) || !pairs || !sc || sc->m > 5 || sc->m <= 0 || !sc->mat) return 0;
@@ -1402,8 +1404,12 @@ static ksw2amd_plan_t *plan_create_uniform(int dual, int scalar, const ksw2amd_s
 		p->tb_bytes = zl + (size_t)nwt * bytes;
 	}
 	u->tmpl = tm;
+	/* the 4-bit wire format (KSW2AMD_WIRE4=0: never): staging and upload hold two residue codes per byte -- half the bytes for the
+	 * gather to write and for the DMA engines to move -- and every wavefront-task expands its own pairs into the arena before it
+	 * reads them (K2aQueueDesc.unp_*, k2a_queue_wait).  The pieces keep their pair boundaries; all offsets of the upload side halve. */
+	wire4 = !(ENV(WIRE4) && atoi(ENV(WIRE4)) == 0);
 	/* page-locked staging, device arena, watermark: as every streamed plan */
-	p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, p->seq_bytes + 256, &p->cap[BUF_HSEQ]);
+	p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, (wire4 ? p->seq_bytes / 2 : p->seq_bytes) + 256, &p->cap[BUF_HSEQ]);
 	su = (stream_up_t*)calloc(1, sizeof(*su));
 	if (!p->h_seq || !su) { free(su); su = 0; fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
 	p->up_state = su;
@@ -1413,6 +1419,7 @@ static ksw2amd_plan_t *plan_create_uniform(int dual, int scalar, const ksw2amd_s
 		const char *pk_ = ENV(STREAM_PIECE_KB);
 		pbytes = pk_ && atol(pk_) > 0 ? (size_t)atol(pk_) << 10 : p->seq_bytes / 24;
 		if (!(pk_ && atol(pk_) > 0)) { if (pbytes < ((size_t)1 << 20)) pbytes = (size_t)1 << 20; if (pbytes > ((size_t)32 << 20)) pbytes = (size_t)32 << 20; }
+		if (wire4 && pbytes < 2 * (size_t)K2A_WM_BYTES) pbytes = 2 * (size_t)K2A_WM_BYTES;      /* half of it travels: never a copy so small that the runtime moves it with a kernel (K2A_WM_BYTES) */
 		if (pbytes * (K2A_MAXPIECES - 1) < p->seq_bytes) pbytes = p->seq_bytes / (K2A_MAXPIECES - 1) + 1;
 		ppp = (pbytes + u->stride - 1) / u->stride;              /* pairs per piece: pieces start at pair boundaries (the copy's work units) */
 		if (ppp < 1) ppp = 1;
@@ -1423,7 +1430,9 @@ static ksw2amd_plan_t *plan_create_uniform(int dual, int scalar, const ksw2amd_s
 		const size_t first = (size_t)k * ppp < (size_t)n ? (size_t)k * ppp : (size_t)n;
 		su->pfirst[k] = (int)first; su->pb[k] = k < su->np ? first * u->stride : p->seq_bytes;
 		u->pb[k] = su->pb[k];
+		if (wire4) su->pb[k] >>= 1;                               /* (the device counts pieces in arena offsets, the upload moves half of them) */
 	}
+	su->wire4 = wire4;
 	u->npieces = (uint32_t)su->np;
 	su->wm_src = 0;
 	{
@@ -1433,8 +1442,9 @@ static ksw2amd_plan_t *plan_create_uniform(int dual, int scalar, const ksw2amd_s
 	su->up = shared_upload_stream();
 	su->up2 = stream_lanes(0) == 2 ? shared_upload_stream2() : 0;
 	su->fault = env_flag(ENV(STREAM_FAULT), 0); su->sleep_us = ENV(STREAM_SLEEP_US) ? atoi(ENV(STREAM_SLEEP_US)) : 0;
-	su->src = p->h_seq; su->src_bytes = p->seq_bytes;
+	su->src = p->h_seq; su->src_bytes = wire4 ? p->seq_bytes / 2 : p->seq_bytes;
 	p->d_seq = (uint8_t*)cache_get(BUF_SEQ, p->seq_bytes, &p->cap[BUF_SEQ]);
+	if (wire4) d_pk = (uint8_t*)cache_get(BUF_PK4, p->seq_bytes / 2, &p->cap[BUF_PK4]);
 	p->d_wm = (uint8_t*)cache_get(BUF_WM, K2A_WM_BYTES + NCLS_ENTRIES * sizeof(K2aQueueDesc), &p->cap[BUF_WM]);
 	p->d_pairs = (K2aPair*)cache_get(BUF_PAIRS, sizeof(K2aPair) * ((size_t)n + 1), &p->cap[BUF_PAIRS]);
 	p->d_order = (uint32_t*)cache_get(BUF_ORDER, sizeof(uint32_t) * ((size_t)n + (size_t)nwt + 1), &p->cap[BUF_ORDER]);
@@ -1444,8 +1454,9 @@ static ksw2amd_plan_t *plan_create_uniform(int dual, int scalar, const ksw2amd_s
 	p->h_qd = (K2aQueueDesc*)calloc(1, sizeof(K2aQueueDesc));
 	p->wm_ev = k2a_shim_event_create(); p->meta_ev = k2a_shim_event_create(); p->up_ev = k2a_shim_event_create();
 	if (!su->wm_src || !su->up || !p->d_seq || !p->d_wm || !p->d_pairs || !p->d_order || !p->d_res || (p->tb_bytes && !p->d_tb) || !p->h_meta || !p->h_qd ||
-	    !p->wm_ev || !p->meta_ev || !p->up_ev) { fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error()); goto err; }
-	su->d_seq = p->d_seq; su->d_wm = p->d_wm;
+	    !p->wm_ev || !p->meta_ev || !p->up_ev || (wire4 && !d_pk)) { fail(KSW2AMD_E_NOMEM, "device allocation failed: %s", k2a_shim_last_error()); goto err; }
+	su->d_seq = wire4 ? d_pk : p->d_seq; su->d_wm = p->d_wm;
+	p->d_pk4 = d_pk;
 	p->unscanned = 1; p->npieces = su->np; p->stream = su->up; p->stream_used = 1;
 	/* the launch's descriptor: the one thing that is uploaded besides the sequences (64 bytes, behind the zeroed watermark) */
 	{
@@ -1453,6 +1464,10 @@ static ksw2amd_plan_t *plan_create_uniform(int dual, int scalar, const ksw2amd_s
 		p->nqd = 1; p->need_words = (size_t)nwt;
 		p->h_qd[0].nwt = (uint32_t)nwt; p->h_qd[0].timeout_ticks = (uint64_t)(te && atoi(te) > 0 ? atoi(te) : 2000) * 100000u;
 		p->h_qd[0].need = p->d_order + p->norder; p->h_qd[0].wm = (const uint32_t*)p->d_wm;
+		if (wire4) {
+			p->h_qd[0].unp_src = d_pk; p->h_qd[0].unp_dst = p->d_seq;
+			p->h_qd[0].unp_bytes = 2u * (uint32_t)NG * u->stride; p->h_qd[0].unp_total = (uint32_t)n * u->stride;
+		}
 		memcpy(p->h_meta, p->h_qd, sizeof(K2aQueueDesc));
 	}
 	if (k2a_shim_h2d(p->d_wm, (const uint8_t*)su->wm_src + (size_t)K2A_MAXPIECES * K2A_WM_BYTES, K2A_WM_BYTES, su->up) || k2a_shim_event_record(p->wm_ev, su->up) ||
@@ -1469,8 +1484,9 @@ static ksw2amd_plan_t *plan_create_uniform(int dual, int scalar, const ksw2amd_s
 			memset(&cc, 0, sizeof(cc));
 			cc.h_seq = p->h_seq; cc.hp = p->h_pairs; cc.pairs = pairs; cc.su = su;
 			for (k = 0; k < su->np; ++k) {
+				extern void copy_or_pack_range(const copy_ctx_t *c, int beg, int end);
 				uni_fill_range(u, p->h_pairs, p->h_cls, p->h_flag, p->h_order, cls0, flag0, su->pfirst[k], su->pfirst[k + 1]);
-				copy_range(&cc, su->pfirst[k], su->pfirst[k + 1]);
+				copy_or_pack_range(&cc, su->pfirst[k], su->pfirst[k + 1]);
 				stream_issue(su, k);
 			}
 			if (su->rc || k2a_shim_event_record(p->up_ev, su->up)) { fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error()); goto err; }
@@ -1685,8 +1701,9 @@ int ksw2amd_plan_describe(const ksw2amd_plan_t *p, char *buf, int cap)
 		const int G = k->solo ? 64 : k->pk ? k2a_pkcfg_G[k->cfg] : k2a_cfg_G[k->cfg], C = k->solo ? 2 * K2A_SOLO_ROWS(k->mode == K2A_MODE_SCORE) : k->pk ? k2a_pkcfg_C[k->cfg] : k2a_cfg_C[k->cfg];
 		const int form = k->defer ? 3 : k->solo ? 0 : k->pk ? (k->cfg == K2A_PKCFG_MP ? 0 : k2a_shim_pk_form(k->cfg, p->dual, k->mode, k->nomax, k->count))
 		                                     : (k->cfg == K2A_CFG_MP ? k2a_shim_mp_form(p->dual, k->mode, k->count) : 0);
-		len += snprintf(buf + len, (size_t)(cap - len), "kernel=%s G=%d C=%d gaps=%d mode=%s rebased=%d nomax=%d generic=%d form=%s tasks=%d uniform=%d\n",
-		                kind, G, C, p->dual ? 2 : 1, mode_name[k->mode], k->rb, k->nomax, k->generic, form_name[form], k->count, p->uni ? 1 : 0);
+		len += snprintf(buf + len, (size_t)(cap - len), "kernel=%s G=%d C=%d gaps=%d mode=%s rebased=%d nomax=%d generic=%d form=%s tasks=%d uniform=%d wire4=%d\n",
+		                kind, G, C, p->dual ? 2 : 1, mode_name[k->mode], k->rb, k->nomax, k->generic, form_name[form], k->count, p->uni ? 1 : 0,
+		                p->up_state && p->up_state->wire4 ? 1 : 0);
 	}
 	return p->ncls;
 }
@@ -1713,9 +1730,11 @@ static int fetch_results(ksw2amd_plan_t *p)
 		if (aborted) {
 			void *st = p->stream;
 			__sync_fetch_and_add(&g_stream_stat[1], 1);
-			if (trace_level()) fprintf(stderr, "[ksw2_amd] streamed plan n=%d: a launch gave up waiting for its inputs; running the plan again behind its upload\n", p->n);
+			if (trace_level()) fprintf(stderr, "[ksw2_amd] streamed plan n=%d: a launch gave up waiting for its inputs (abort %u, started %u of %u wavefront-tasks, %d pieces); running the plan again behind its upload\n", p->n, back[0].abort, back[0].next, back[0].nwt, p->npieces);
 			p->streamed = 0;
+			/* (4-bit wire format: the wavefront-tasks that never started have not expanded their pairs -- the whole arena, now) */
 			if ((p->up_ev && k2a_shim_event_sync(p->up_ev)) || k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)p->n, st) ||
+			    (plan_wire4(p) && k2a_shim_launch_wire4_expand(p->d_pk4, p->d_seq, (size_t)p->uni->n * p->uni->stride, st)) ||
 			    ksw2amd_plan_run(p, st) || k2a_shim_stream_sync(st))
 				return fail(KSW2AMD_E_NODEVICE, "plan_fetch: %s", k2a_shim_last_error());
 		}
@@ -1804,6 +1823,17 @@ void km_unlock(const void *km) { if (km) pthread_mutex_unlock(km_mutex(km)); }
  *                       found that the reference's test does NOT hold at the row the fill stopped at: the re-run keeps the columns.
  *                       (2 = the second pass settled the drop: the record is final.) */
 int needs_rerun(const ksw2amd_plan_t *p, int i) { return p->h_cls[i] >= 0 && !p->splice && (((p->flat || p->unscanned) && p->h_res[i].pad[0]) || p->h_res[i].pad[1] == 1); }
+/* uniform plans on the 4-bit wire format keep two codes per byte in their staging copy: pair i's query and target, one code per byte,
+ * into out[0 .. qlen) and out[qlen .. qlen + tlen) */
+void wire4_pair(const ksw2amd_plan_t *p, int i, uint8_t *out)
+{
+	const K2aPair *d = &p->h_pairs[i];
+	int x;
+	for (x = 0; x < d->qlen; ++x) { const uint8_t b = p->h_seq[((size_t)d->qoff + (size_t)x) >> 1]; out[x] = (x & 1) ? b >> 4 : b & 15; }
+	for (x = 0; x < d->tlen_full; ++x) { const uint8_t b = p->h_seq[((size_t)d->toff + (size_t)x) >> 1]; out[d->qlen + x] = (x & 1) ? b >> 4 : b & 15; }
+}
+int plan_wire4(const ksw2amd_plan_t *p) { return p->up_state && p->up_state->wire4; }
+
 int pair_rerun(ksw2amd_plan_t *p, int i, void *km, ksw_extz_t *z)
 {
 	ksw2amd_pair_t a;
@@ -1815,7 +1845,12 @@ int pair_rerun(ksw2amd_plan_t *p, int i, void *km, ksw_extz_t *z)
 		a.query = p->h_seq + d->qoff; a.target = p->h_seq + d->toff; a.qlen = d->qlen; a.tlen = d->tlen_full;
 		a.w = d->w; a.zdrop = d->zdrop; a.end_bonus = p->scalar ? 0 : d->end_bonus; a.flag = p->h_flag[i] & ~F_SCALAR_CONTRACT;
 	}
-	if (p->flat_device) {
+	if (plan_wire4(p)) {
+		tmp = (uint8_t*)malloc((size_t)a.qlen + (size_t)a.tlen + 1);
+		if (!tmp) return fail(KSW2AMD_E_NOMEM, "plan_fetch: host allocation failed%s", 0);
+		wire4_pair(p, i, tmp);
+		a.query = tmp; a.target = tmp + a.qlen;
+	} else if (p->flat_device) {
 		tmp = (uint8_t*)malloc((size_t)a.qlen + (size_t)a.tlen + 1);
 		if (!tmp) return fail(KSW2AMD_E_NOMEM, "plan_fetch: host allocation failed%s", 0);
 		if (k2a_shim_d2h(tmp, a.query, (size_t)a.qlen, p->stream) || k2a_shim_d2h(tmp + a.qlen, a.target, (size_t)a.tlen, p->stream) ||

@@ -253,6 +253,49 @@ void copy_range(const copy_ctx_t *c, int beg, int end)
 		memset(c->h_seq + c->hp[i].toff + a->tlen, 0, 64);                                          /* rows read past the target end */
 	}
 }
+/* The 4-bit wire format of uniform plans: two residue codes per byte into the staging buffer (half the bytes for the gather to write
+ * and for the DMA engines to move: config 2's step waits for its upload), expanded on the device by the wavefront that needs them
+ * (k2a_queue_wait).  Returns the OR of all source bytes: a code above 15 does not fit and sends the batch to the general path. */
+#include <emmintrin.h>
+static unsigned pack4(uint8_t *dst, const uint8_t *src, int n)
+{
+	const __m128i lo = _mm_set1_epi16(0x00ff);
+	__m128i acc = _mm_setzero_si128();
+	unsigned bad = 0;
+	int k = 0;
+	for (; k + 32 <= n; k += 32) {
+		const __m128i a = _mm_loadu_si128((const __m128i*)(src + k)), b = _mm_loadu_si128((const __m128i*)(src + k + 16));
+		/* 16-bit lanes { even byte, odd byte } -> even | odd << 4 in the low byte */
+		const __m128i pa = _mm_and_si128(_mm_or_si128(a, _mm_srli_epi16(a, 4)), lo), pb = _mm_and_si128(_mm_or_si128(b, _mm_srli_epi16(b, 4)), lo);
+		acc = _mm_or_si128(acc, _mm_or_si128(a, b));
+		_mm_storeu_si128((__m128i*)(dst + (k >> 1)), _mm_packus_epi16(pa, pb));
+	}
+	{
+		uint8_t t[16];
+		int x;
+		_mm_storeu_si128((__m128i*)t, acc);
+		for (x = 0; x < 16; ++x) bad |= t[x];
+	}
+	for (; k + 2 <= n; k += 2) { bad |= src[k] | src[k + 1]; dst[k >> 1] = (uint8_t)((src[k] & 15) | (src[k + 1] << 4)); }
+	if (k < n) { bad |= src[k]; dst[k >> 1] = (uint8_t)(src[k] & 15); }
+	return bad;
+}
+static void pack_range(const copy_ctx_t *c, int beg, int end)
+{
+	unsigned bad = 0;
+	int i;
+	for (i = beg; i < end; ++i) {
+		const ksw2amd_pair_t *a = &c->pairs[i];
+		uint8_t *t;
+		if (a->qlen <= 0 || a->tlen <= 0) continue;
+		bad |= pack4(c->h_seq + (c->hp[i].qoff >> 1), a->query, a->qlen);
+		t = c->h_seq + (c->hp[i].toff >> 1);
+		bad |= pack4(t, a->target, a->tlen);
+		memset(t + ((a->tlen + 1) >> 1), 0, 32);                                 /* rows read past the target end (copy_range) */
+	}
+	if (bad > 15) __sync_fetch_and_or(&c->su->wire_bad, 1);
+}
+void copy_or_pack_range(const copy_ctx_t *c, int beg, int end) { if (c->su && c->su->wire4) pack_range(c, beg, end); else copy_range(c, beg, end); }
 static int copy_chunk(void *ctx, int beg, int end, int share, pend_t *pd)
 {
 	const copy_ctx_t *c = (const copy_ctx_t*)ctx;
@@ -260,7 +303,7 @@ static int copy_chunk(void *ctx, int beg, int end, int share, pend_t *pd)
 	if (beg >= 0) {
 		if (c->uni_plan)                                    /* a uniform plan: the host's per-pair arrays of this range first (copy_range reads the offsets) */
 			uni_fill_range(c->uni_plan->uni, c->uni_plan->h_pairs, c->uni_plan->h_cls, c->uni_plan->h_flag, c->uni_plan->h_order, c->uni_cls, c->uni_flag, beg, end);
-		copy_range(c, beg, end);
+		copy_or_pack_range(c, beg, end);
 		if (c->su) {                                        /* a streamed plan: this chunk is part of a piece of the upload; the piece's last chunk issues what is ready */
 			int k = 0;
 			while (k + 1 < c->su->np && c->su->pfirst[k + 1] <= beg) ++k;
@@ -354,6 +397,17 @@ int rerun_pairs(ksw2amd_plan_t *p, int nrerun, void *km, ksw_extz_t *ez, ksw_ext
 		++k;
 	}
 	nrerun = k;
+	if (plan_wire4(p)) {                                   /* the staging copy holds two codes per byte: one per byte for the re-run */
+		tmp = (uint8_t*)malloc(tmp_bytes + 1);
+		if (!tmp) { free(a); free(zz); return fail(KSW2AMD_E_NOMEM, "plan_fetch: host allocation failed%s", 0); }
+		for (i = 0, k = 0; i < p->n && k < nrerun; ++i) {
+			if (!needs_rerun(p, i)) continue;
+			wire4_pair(p, i, tmp + at);
+			a[k].query = tmp + at; a[k].target = tmp + at + a[k].qlen;
+			at += (size_t)a[k].qlen + (size_t)a[k].tlen;
+			++k;
+		}
+	} else
 	if (p->flat_device) {                                  /* the sequences are in device memory only: bring these pairs' back */
 		tmp = (uint8_t*)malloc(tmp_bytes + 1);
 		if (!tmp) { free(a); free(zz); return fail(KSW2AMD_E_NOMEM, "plan_fetch: host allocation failed%s", 0); }
@@ -696,10 +750,14 @@ static int run_batch_(int dual, int scalar, void *km, const ksw2amd_scoring_t *s
 					tu2 = now_ms();
 					if (rc == KSW2AMD_OK) rc = ksw2amd_plan_fetch(up, km, ez);
 					phase_add(tu1 - tu0, tu2 - tu1, now_ms() - tu2);
-					ksw2amd_plan_destroy(up);
-					return rc;
+					{
+						const int refit = up->up_state && up->up_state->wire_bad;      /* a residue code above 15: not through the 4-bit wire format */
+						ksw2amd_plan_destroy(up);
+						if (!refit) return rc;
+						for (i = 0; i < n; ++i) ez_reset(&ez[i]);
+					}
 				}
-				if (g_err[0]) return strstr(g_err, "alloc") ? KSW2AMD_E_NOMEM : strstr(g_err, "device") || strstr(g_err, "upload") ? KSW2AMD_E_NODEVICE : KSW2AMD_E_PARAM;
+				else if (g_err[0]) return strstr(g_err, "alloc") ? KSW2AMD_E_NOMEM : strstr(g_err, "device") || strstr(g_err, "upload") ? KSW2AMD_E_NODEVICE : KSW2AMD_E_PARAM;
 			}
 			if ((stream_env() == 1 || c0 >= stream_min_cells()) && fits)
 				return run_serial(dual, scalar, km, sc, n, pairs, ez, 1, flat, 1);

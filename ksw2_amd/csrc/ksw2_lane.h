@@ -504,6 +504,15 @@ K2A_FN int k2a_trace_pair(const uint8_t *tb, int i, int j, uint32_t *out, int ql
 	return k2a_trace_walk<G, C, DUAL ? 1 : 0, MP>(tb, 0, i, j, out, qlen, tlen, w);
 }
 
+/* the 4-bit wire format of uniform plans (K2aQueueDesc.unp_*): byte k of the upload holds residue codes 2k (low nibble) and 2k + 1;
+ * four upload bytes -> eight arena bytes */
+K2A_FN void k2a_wire4_expand(uint32_t w4, uint32_t &lo, uint32_t &hi)
+{
+	const uint32_t ev = w4 & 0x0f0f0f0fu, od = (w4 >> 4) & 0x0f0f0f0fu;
+	lo = (ev & 0xffu) | ((od & 0xffu) << 8) | ((ev & 0xff00u) << 8) | ((od & 0xff00u) << 16);
+	hi = ((ev >> 16) & 0xffu) | (((od >> 16) & 0xffu) << 8) | ((ev >> 24) << 16) | ((od >> 24) << 24);
+}
+
 /* Uniform plans (K2aUniform): record of pair i, and the pieces wavefront-task wt of a streamed launch waits for -- the rules the
  * host's gather follows when it copies the sequences (ksw2_host_plan.c: uni_fill_range) */
 K2A_FN K2aPair k2a_uniform_pair(const K2aUniform &u, uint32_t i)

@@ -62,6 +62,7 @@ int   k2a_shim_memset(void *dst, int v, size_t bytes, void *stream);
 
 void *k2a_shim_stream_create(void);
 void *k2a_shim_stream_create_high(void);      /* highest priority: hardware queues apart from the ordinary streams' */
+void *k2a_shim_stream_create_low(void);       /* lowest priority: the upload streams (copies only), apart from every stream that runs kernels */
 void  k2a_shim_stream_destroy(void *stream);
 int   k2a_shim_stream_sync(void *stream);
 void *k2a_shim_event_create(void);
@@ -106,6 +107,8 @@ int k2a_shim_launch_trace_pk(int cfg, int dual, const K2aPair *pairs, const uint
 
 /* uniform plans (K2aUniform, ksw2_types.h): write pairs[n], order2[2 * ntasks] and -- need != NULL -- the streamed launch's
  * need[ceil(ntasks / ng)] on the device */
+/* 4-bit wire format of uniform plans: bytes / 2 upload bytes at src -> bytes arena bytes at dst (bytes a multiple of 8) */
+int k2a_shim_launch_wire4_expand(const uint8_t *src, uint8_t *dst, size_t bytes, void *stream);
 int k2a_shim_launch_uniform_layout(const K2aUniform *u, K2aPair *pairs, uint32_t *order2, uint32_t *need, void *stream);
 
 /* Packed generation-serial fill (class K2A_PKCFG_MP): one task (two same-shape alignments) per workgroup of four wavefronts that

@@ -242,6 +242,21 @@ __device__ __forceinline__ bool k2a_queue_wait(K2aQueueDesc *qd, int wt)
 	 * poll -> ONE acquire -> plain loads"; found by the fuzz script: batches whose data lands after the launch read the PREVIOUS
 	 * plan's bytes from the recycled arena -- which a test that runs the same batch twice never sees).  Once per wavefront-task. */
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+	/* 4-bit wire format (uniform plans): this wavefront-task's pairs from the upload into the arena, eight codes per lane and round;
+	 * then the arena bytes this wavefront wrote are what it reads (release / acquire at agent scope: the L1 may hold lines of the
+	 * recycled arena that a neighbour's look past its own sequences brought in). */
+	if (qd->unp_bytes) {
+		const uint32_t b0 = (uint32_t)wt * qd->unp_bytes, b1 = min(b0 + qd->unp_bytes, qd->unp_total);
+		const uint32_t *src = (const uint32_t*)(qd->unp_src + (b0 >> 1));
+		uint2 *dst = (uint2*)(qd->unp_dst + b0);
+		for (uint32_t x = threadIdx.x & 63; x < (b1 - b0) >> 3; x += 64) {
+			uint32_t lo, hi;
+			k2a_wire4_expand(src[x], lo, hi);
+			dst[x] = make_uint2(lo, hi);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+	}
 	if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&qd->next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      /* tasks started: what the host checks a run by */
 	return true;
 }
@@ -2023,6 +2038,17 @@ void *k2a_shim_stream_create_high(void)
 	if (set_err(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi), "hipStreamCreateWithPriority")) return 0;
 	return (void*)s;
 }
+/* ... and of the lowest: the per-device upload streams.  They carry DMA copies and events only, and a copy must never sit in a hardware
+ * queue behind a kernel of a streamed launch that waits for that very copy (two ordinary streams may share a queue, whichever the
+ * runtime deals them: the launch then only ends by its timeout) */
+void *k2a_shim_stream_create_low(void)
+{
+	hipStream_t s = 0;
+	int lo = 0, hi = 0;
+	if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; }
+	if (set_err(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lo), "hipStreamCreateWithPriority")) return 0;
+	return (void*)s;
+}
 void k2a_shim_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy((hipStream_t)stream); }
 int k2a_shim_stream_sync(void *stream) { CHECK(hipStreamSynchronize((hipStream_t)stream)); return 0; }
 
@@ -2105,6 +2131,25 @@ int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax,
 	                    : qd ? g_fill_pkq[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode];
 	hipLaunchKernelGGL(fn, dim3(blocks), dim3(64 * K2A_WPB), 0, (hipStream_t)stream,
 	                   *sc, pairs, order2, ntasks, seq, tb, res, qd);
+	CHECK(hipGetLastError());
+	return 0;
+}
+
+__global__ void __launch_bounds__(256)
+k2a_wire4_expand_kernel(const uint32_t *__restrict__ src, uint2 *__restrict__ dst, size_t n8)
+{
+	for (size_t x = (size_t)blockIdx.x * 256 + threadIdx.x; x < n8; x += (size_t)gridDim.x * 256) {
+		uint32_t lo, hi;
+		k2a_wire4_expand(src[x], lo, hi);
+		dst[x] = make_uint2(lo, hi);
+	}
+}
+int k2a_shim_launch_wire4_expand(const uint8_t *src, uint8_t *dst, size_t bytes, void *stream)
+{
+	const size_t n8 = bytes >> 3;
+	if (n8 == 0) return 0;
+	hipLaunchKernelGGL(k2a_wire4_expand_kernel, dim3((unsigned)((n8 + 255) / 256 < 65536 ? (n8 + 255) / 256 : 65536)), dim3(256), 0, (hipStream_t)stream,
+	                   (const uint32_t*)src, (uint2*)dst, n8);
 	CHECK(hipGetLastError());
 	return 0;
 }

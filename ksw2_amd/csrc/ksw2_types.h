@@ -140,7 +140,12 @@ typedef struct K2aQueueDesc {
 	const uint32_t *need;             /* [nwt] pieces that must have landed before the wavefront-task may start (0 = none) */
 	const uint32_t *wm;               /* the plan's watermark block */
 	uint64_t timeout_ticks;
-	uint64_t pad2[3];
+	/* uniform plans on the 4-bit wire format (ksw2_host_plan.c): the upload carries two residue codes per byte into `unp_src`; a
+	 * wavefront-task first expands its own pairs' bytes -- unp_bytes per wavefront-task, the arena's first unp_total bytes in all --
+	 * into the arena the kernels read (unp_dst).  unp_bytes = 0: the upload is the arena itself. */
+	const uint8_t *unp_src;
+	uint8_t *unp_dst;
+	uint32_t unp_bytes, unp_total;
 } K2aQueueDesc;                       /* 64 bytes */
 
 /* deferred arg-max classes: the list of alignments whose book the fill froze (k2a_argmax_kernel -> k2a_zscan_kernel), uint32

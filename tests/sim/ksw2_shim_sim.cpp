@@ -122,6 +122,15 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 			qd->next = (uint32_t)wv + 1;
 			if (qd->abort) break;
 			if (qd->need[wv] > qd->wm[0]) { qd->abort = 1; break; }
+			if (qd->unp_bytes) {                                 /* 4-bit wire format: the wavefront-task expands its own pairs (k2a_queue_wait) */
+				const uint32_t b0 = (uint32_t)wv * qd->unp_bytes, b1 = std::min(b0 + qd->unp_bytes, qd->unp_total);
+				for (uint32_t x = 0; x < (b1 - b0) >> 3; ++x) {
+					uint32_t w4, lo, hi;
+					memcpy(&w4, qd->unp_src + (b0 >> 1) + 4 * (size_t)x, 4);
+					k2a_wire4_expand(w4, lo, hi);
+					memcpy(qd->unp_dst + b0 + 8 * (size_t)x, &lo, 4); memcpy(qd->unp_dst + b0 + 8 * (size_t)x + 4, &hi, 4);
+				}
+			}
 		}
 		static thread_local Lane L[64];
 		static thread_local uint32_t lrows[K2A_PK_LDSROW_WORDS(C)];
@@ -1137,6 +1146,7 @@ int k2a_shim_host_unregister(void *) { return 0; }
 int k2a_shim_memset(void *dst, int v, size_t bytes, void *) { memset(dst, v, bytes); return 0; }
 void *k2a_shim_stream_create(void) { return (void*)1; }
 void *k2a_shim_stream_create_high(void) { return (void*)1; }
+void *k2a_shim_stream_create_low(void) { return (void*)1; }
 void k2a_shim_stream_destroy(void *) {}
 int k2a_shim_stream_sync(void *) { return 0; }
 void *k2a_shim_event_create(void) { return calloc(1, sizeof(double)); }
@@ -1180,6 +1190,16 @@ int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax,
 	const int form = k2a_shim_pk_form(cfg, dual, mode, nomax, ntasks);
 	const bool lds = form == 1, ldc = form == 2;
 	if (ntasks > 0) (lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1] : ldc ? g_fill_pk_ldscodes[k2a_pkcfg_G[cfg] == 8 ? 1 : k2a_pkcfg_G[cfg] == 16 ? 2 : 0][nomax ? 1 : 0][rebased ? 1 : 0] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode])(*sc, pairs, order2, ntasks, seq, tb, res, qd);
+	return 0;
+}
+int k2a_shim_launch_wire4_expand(const uint8_t *src, uint8_t *dst, size_t bytes, void *)
+{
+	for (size_t x = 0; x < bytes >> 3; ++x) {
+		uint32_t w4, lo, hi;
+		memcpy(&w4, src + 4 * x, 4);
+		k2a_wire4_expand(w4, lo, hi);
+		memcpy(dst + 8 * x, &lo, 4); memcpy(dst + 8 * x + 4, &hi, 4);
+	}
 	return 0;
 }
 int k2a_shim_launch_uniform_layout(const K2aUniform *u, K2aPair *pairs, uint32_t *order2, uint32_t *need, void *)

@@ -1033,7 +1033,7 @@ def _check_uniform_plans(lib, monkeypatch, shapes):
         fl = po.SCORE_ONLY | (po.EXTZ_ONLY if si % 2 else 0)
 
         def run(**env):
-            for k in ("KSW2AMD_UNIFORM", "KSW2AMD_STREAM_PIECE_KB", "KSW2AMD_STREAM_SLEEP_US", "KSW2AMD_STREAM_FAULT", "KSW2AMD_STREAM_TIMEOUT_MS", "KSW2AMD_DEFER"):
+            for k in ("KSW2AMD_UNIFORM", "KSW2AMD_STREAM_PIECE_KB", "KSW2AMD_STREAM_SLEEP_US", "KSW2AMD_STREAM_FAULT", "KSW2AMD_STREAM_TIMEOUT_MS", "KSW2AMD_DEFER", "KSW2AMD_WIRE4"):
                 monkeypatch.delenv(k, raising=False)
             if defer is not None:
                 monkeypatch.setenv("KSW2AMD_DEFER", str(defer))
@@ -1055,6 +1055,20 @@ def _check_uniform_plans(lib, monkeypatch, shapes):
         b = lib.make_batch(qs, ts, mat, 4, 2, 0, 0, w=w, zdrop=zd, end_bonus=7, flag=fl)
         bad = [i for i in range(n) if diff(off[i], on[i])]
         assert not bad, (si, bad[:5], off[bad[0]], on[bad[0]])
+        # the 4-bit wire format (two codes per byte in staging and upload, expanded by the wavefront that needs them) off: the same results;
+        # a residue code above 15 does not fit it: the batch is repeated on the general path and comes back as the general path returns it
+        w8, ns, na, nr = run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64, KSW2AMD_WIRE4=0)
+        assert ns == 1 and na == 0 and not [i for i in range(n) if diff(off[i], w8[i])], (si, "wire4 off", ns, na)
+        if si == 0:
+            keepq = qs[7].copy()
+            qs[7][3] = 20
+            fat_off, _, _, _ = run(KSW2AMD_UNIFORM=0)
+            fat_on, ns, na, nr = run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64)
+            assert not [i for i in range(n) if diff(fat_off[i], fat_on[i])], (si, "code above 15")
+            qs[7] = keepq
+        qs, ts = decoy
+        run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64)         # (the arena holds the decoy's bases again: what the repeated run reads must have been expanded by IT)
+        qs, ts = keep
         flt, ns, na, nr = run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64, KSW2AMD_STREAM_FAULT=1, KSW2AMD_STREAM_TIMEOUT_MS=20)
         assert ns == 1 and na == 1, (si, ns, na)
         bad = [i for i in range(n) if diff(off[i], flt[i])]
