@@ -254,6 +254,11 @@ typedef struct {
 	int32_t w, xdrop;
 } ksw2amd_fpair_t;
 int ksw2amd_extf_batch(void *km, int8_t mch, int8_t mis, int8_t e, int n, const ksw2amd_fpair_t *pairs, ksw_extz_t *ez);
+/* The same two with the sequences (and junction arrays) in DEVICE memory: pairs[].query / target / junc are device pointers -- a
+ * shard of a multi-GPU job that RCCL delivered into HBM (ksw2_amd/parallel.py).  One kernel gathers them into the plan's arena;
+ * nothing of them crosses the link.  (Replaces nothing in the reference: ksw2.h has no notion of a device.) */
+int ksw2amd_exts_batch_device(void *km, const ksw2amd_splice_t *sc, int n, const ksw2amd_spair_t *pairs, ksw_extz_t *ez);
+int ksw2amd_extf_batch_device(void *km, int8_t mch, int8_t mis, int8_t e, int n, const ksw2amd_fpair_t *pairs, ksw_extz_t *ez);
 
 /* The same in three phases, for callers that keep batches resident in HBM (and for benchmarking the
  * device part alone): create = pack + upload, run = kernels only (asynchronous on `stream`, a hipStream_t

@@ -81,12 +81,12 @@ EXPORTS = ["ksw_extz2_sse", "ksw_extd2_sse", "ksw_gg2", "ksw_gg2_sse", "ksw_extz
            "ksw2amd_set_sse_compat", "ksw2amd_sse_plan_create", "ksw2amd_plan_describe", "ksw2amd_reload_env",
            "ksw2amd_extz_batch_flat", "ksw2amd_extd_batch_flat", "ksw2amd_plan_create_flat", "ksw2amd_host_register", "ksw2amd_host_unregister",
            "ksw2amd_device_alloc", "ksw2amd_device_free", "ksw2amd_device_upload", "ksw2amd_device_download", "ksw2amd_rerun_count",
-           "ksw2amd_set_small_call_cells", "ksw2amd_small_call_count", "ksw2amd_stream_stats", "ksw2amd_host_phase_us"]
+           "ksw2amd_set_small_call_cells", "ksw2amd_small_call_count", "ksw2amd_stream_stats", "ksw2amd_host_phase_us", "ksw2amd_exts_batch_device", "ksw2amd_extf_batch_device"]
 # entry points whose behaviour depends on KSW2AMD_* switches: the library reads its environment once per process, so this binding
 # re-reads it in front of each of them (tests and A/B scripts flip switches inside one process)
 _ENV_ENTRIES = ["ksw_extz2_sse", "ksw_extd2_sse", "ksw_gg2", "ksw_gg2_sse", "ksw_extz", "ksw_extd", "ksw_gg", "ksw_extz2_sse41",
                 "ksw_extz2_sse2", "ksw_extd2_sse41", "ksw_extd2_sse2", "ksw_exts2_sse", "ksw_exts2_sse41", "ksw_exts2_sse2", "ksw_extf2_sse",
-                "ksw2amd_extz_batch", "ksw2amd_extd_batch", "ksw2amd_exts_batch", "ksw2amd_extf_batch", "ksw2amd_plan_create",
+                "ksw2amd_extz_batch", "ksw2amd_extd_batch", "ksw2amd_exts_batch", "ksw2amd_extf_batch", "ksw2amd_exts_batch_device", "ksw2amd_extf_batch_device", "ksw2amd_plan_create",
                 "ksw2amd_sse_plan_create", "ksw2amd_exts_plan_create", "ksw2amd_extf_plan_create", "ksw2amd_plan_run",
                 "ksw2amd_plan_describe", "ksw2amd_extz_batch_flat", "ksw2amd_extd_batch_flat", "ksw2amd_plan_create_flat"]
 ERROR_FN = ctypes.CFUNCTYPE(None, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_void_p)
@@ -144,11 +144,13 @@ class Library:
             getattr(L, name).argtypes = s2
             getattr(L, name).restype = None
         L.ksw2amd_exts_batch.argtypes = [km, ctypes.POINTER(SpliceScoring), _int, ctypes.POINTER(SplicePair), ezp]
+        L.ksw2amd_exts_batch_device.argtypes = [km, ctypes.POINTER(SpliceScoring), _int, ctypes.POINTER(SplicePair), ezp]
         L.ksw2amd_exts_plan_create.argtypes = [ctypes.POINTER(SpliceScoring), _int, ctypes.POINTER(SplicePair)]
         L.ksw2amd_exts_plan_create.restype = ctypes.c_void_p
         L.ksw_extf2_sse.argtypes = [km, _int, _u8p, _int, _u8p, _i8, _i8, _i8, _int, _int, ezp]
         L.ksw_extf2_sse.restype = None
         L.ksw2amd_extf_batch.argtypes = [km, _i8, _i8, _i8, _int, ctypes.POINTER(LinearPair), ezp]
+        L.ksw2amd_extf_batch_device.argtypes = [km, _i8, _i8, _i8, _int, ctypes.POINTER(LinearPair), ezp]
         L.ksw2amd_extf_plan_create.argtypes = [_i8, _i8, _i8, _int, ctypes.POINTER(LinearPair)]
         L.ksw2amd_extf_plan_create.restype = ctypes.c_void_p
         L.ksw2amd_last_error.restype = ctypes.c_char_p

@@ -12,6 +12,26 @@ static int exts_long_thres(int q, int e, int q2)           /* ksw2_exts2_sse.c:1
 	return lt;
 }
 
+/* Device-resident sources (ksw2amd_exts_batch_device / ksw2amd_extf_batch_device: a shard that RCCL delivered into device memory):
+ * pairs[].query / target / junc are DEVICE pointers.  The plan's arena is laid out as ever; instead of the copy into page-locked
+ * staging, one kernel gathers the sequences from where they lie (k2a_gather_kernel: a table of { source, arena offset, length },
+ * one workgroup per entry) behind the upload of the rest (zeros, matrices).  Nothing of the sequences crosses the link. */
+static __thread int g_src_device;
+typedef struct { uint64_t src; uint32_t dst, len; } gather_ent_t;      /* = K2aGather (ksw2_shim.h) */
+static int gather_device_sources(ksw2amd_plan_t *p, const gather_ent_t *tab, int nent, void *up)
+{
+	size_t cap = 0;
+	void *d_tab;
+	int rc;
+	if (nent == 0) return 0;
+	d_tab = cache_get(BUF_POS, sizeof(gather_ent_t) * (size_t)nent, &cap);
+	if (!d_tab) return -1;
+	rc = k2a_shim_h2d(d_tab, tab, sizeof(gather_ent_t) * (size_t)nent, up) || k2a_shim_launch_gather((const K2aGather*)d_tab, nent, p->d_seq, up) ||
+	     k2a_shim_stream_sync(up);
+	cache_put(BUF_POS, d_tab, cap);
+	return rc;
+}
+
 ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, const ksw2amd_spair_t *pairs)
 {
 	ksw2amd_plan_t *p;
@@ -20,7 +40,8 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 	size_t off, mat_off, up_bytes = 0, cst_words = 0;
 	void *up;
 	uint32_t fill[3][2][3];
-	int wn;
+	int wn, ngt = 0;
+	gather_ent_t *gt = 0;
 
 	g_err[0] = 0;
 	if (n < 0 || (n > 0 && !pairs) || !sc) { fail(KSW2AMD_E_PARAM, "exts: bad arguments%s", 0); return 0; }
@@ -93,6 +114,11 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 	p->seq_bytes = align_up(off + 256, 256);
 	p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, up_bytes, &p->cap[BUF_HSEQ]);
 	if (!p->h_seq) { fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
+	if (g_src_device) {
+		memset(p->h_seq, 0, up_bytes);
+		gt = (gather_ent_t*)malloc(sizeof(gather_ent_t) * (3 * (size_t)n + 1));
+		if (!gt) { fail(KSW2AMD_E_NOMEM, "exts: host allocation failed%s", 0); goto err; }
+	}
 	for (k = 0, i = 0; i < 3; ++i)
 		for (g = 0; g < 2; ++g)
 			for (wn = 0; wn < 3; ++wn) { p->s_first[i][g][wn] = k; fill[i][g][wn] = (uint32_t)k; k += p->s_count[i][g][wn]; }
@@ -100,9 +126,15 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 	for (i = 0; i < n; ++i) {
 		const ksw2amd_spair_t *a = &pairs[i];
 		if (p->h_cls[i] < 0) continue;
+		if (g_src_device) {
+			gt[ngt].src = (uint64_t)(uintptr_t)a->query; gt[ngt].dst = p->h_pairs[i].qoff; gt[ngt++].len = (uint32_t)a->qlen;
+			gt[ngt].src = (uint64_t)(uintptr_t)a->target; gt[ngt].dst = p->h_pairs[i].toff; gt[ngt++].len = (uint32_t)a->tlen;
+			if (a->junc) { gt[ngt].src = (uint64_t)(uintptr_t)a->junc; gt[ngt].dst = p->h_pairs[i].toff + (uint32_t)align_up((size_t)a->tlen, 4); gt[ngt++].len = (uint32_t)a->tlen; }
+		} else {
 		memcpy(p->h_seq + p->h_pairs[i].qoff, a->query, (size_t)a->qlen);
 		memcpy(p->h_seq + p->h_pairs[i].toff, a->target, (size_t)a->tlen);
 		if (a->junc) memcpy(p->h_seq + p->h_pairs[i].toff + align_up((size_t)a->tlen, 4), a->junc, (size_t)a->tlen);
+		}
 		p->h_order[fill[p->h_cls[i] / 6][(p->h_cls[i] / 3) & 1][p->h_cls[i] % 3]++] = (uint32_t)i;
 	}
 	build_eff(0, m, sc->mat, sc->e, 0, 0, (int8_t*)p->h_seq + mat_off);
@@ -125,6 +157,7 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 	if (k2a_shim_h2d(p->d_seq, p->h_seq, up_bytes, up) || k2a_shim_h2d(p->d_pairs, p->h_pairs, sizeof(K2aPair) * (size_t)n, up) ||
 	    k2a_shim_h2d(p->d_order, p->h_order, sizeof(uint32_t) * (size_t)p->norder, up) ||
 	    k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)n, up) ||
+	    (gt && gather_device_sources(p, gt, ngt, up)) ||
 	    k2a_shim_launch_splice_const(p->d_pairs, n, p->d_seq, sc->noncan, sc->junc_bonus, up) || k2a_shim_stream_sync(up)) {
 		fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error());
 		goto err;
@@ -134,9 +167,11 @@ ksw2amd_plan_t *ksw2amd_exts_plan_create(const ksw2amd_splice_t *sc, int n, cons
 		p->s_par[g].long_thres = exts_long_thres(sc->q, sc->e, sc->q2);
 		p->s_par[g].mat = (const int8_t*)p->d_seq + mat_off + (g ? (size_t)m * m : 0);
 	}
+	free(gt);
 	plan_ready(p);                                  /* uploads complete */
 	return p;
 err:
+	free(gt);
 	ksw2amd_plan_destroy(p);
 	return 0;
 }
@@ -227,13 +262,19 @@ static int wave_chunks(int n, int workers, int uniform, int *chunk_pairs)
 	return k;
 }
 
-typedef struct { void *km; const ksw2amd_splice_t *sc; const ksw2amd_spair_t *pairs; ksw_extz_t *ez; } exts_ctx_t;
+typedef struct { void *km; const ksw2amd_splice_t *sc; const ksw2amd_spair_t *pairs; ksw_extz_t *ez; int src_device; } exts_ctx_t;
 int exts_chunk(void *ctx_, int beg, int end, int share, pend_t *pd)
 {
 	exts_ctx_t *c = (exts_ctx_t*)ctx_;
 	(void)pd;
 	if (beg < 0) return KSW2AMD_OK;
-	return exts_serial(c->km, c->sc, end - beg, c->pairs + beg, c->ez + beg, share);
+	{
+		int rc;
+		g_src_device = c->src_device;
+		rc = exts_serial(c->km, c->sc, end - beg, c->pairs + beg, c->ez + beg, share);
+		g_src_device = 0;
+		return rc;
+	}
 }
 
 int ksw2amd_exts_batch(void *km, const ksw2amd_splice_t *sc, int n, const ksw2amd_spair_t *pairs, ksw_extz_t *ez)
@@ -248,12 +289,21 @@ int ksw2amd_exts_batch(void *km, const ksw2amd_splice_t *sc, int n, const ksw2am
 		if (cost && nchunks >= 2) {
 			exts_ctx_t ctx;
 			for (i = 0; i < n; ++i) { cost[i] = 1.0 + (double)imax(pairs[i].qlen, 0) * imax(pairs[i].tlen, 0); total += cost[i]; }
-			ctx.km = km; ctx.sc = sc; ctx.pairs = pairs; ctx.ez = ez;
+			ctx.km = km; ctx.sc = sc; ctx.pairs = pairs; ctx.ez = ez; ctx.src_device = g_src_device;
 			if (run_pooled(exts_chunk, &ctx, n, cost, total, nchunks, chunk_pairs, &rc)) { free(cost); return rc; }
 		}
 		free(cost);
 	}
 	return exts_serial(km, sc, n, pairs, ez, 1);
+}
+
+int ksw2amd_exts_batch_device(void *km, const ksw2amd_splice_t *sc, int n, const ksw2amd_spair_t *pairs, ksw_extz_t *ez)
+{
+	int rc;
+	g_src_device = 1;
+	rc = ksw2amd_exts_batch(km, sc, n, pairs, ez);
+	g_src_device = 0;
+	return rc;
 }
 
 void ksw_exts2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t m, const int8_t *mat,
@@ -285,11 +335,12 @@ void ksw_exts2_sse2(void *km, int qlen, const uint8_t *query, int tlen, const ui
 ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n, const ksw2amd_fpair_t *pairs)
 {
 	ksw2amd_plan_t *p;
-	int i, c, span, nlane = 0, use_lane;
+	int i, c, span, nlane = 0, use_lane, ngt = 0;
 	size_t off = 0;
 	uint32_t fill[8];
 	void *up;
 	sort_t *srt = 0;
+	gather_ent_t *gt = 0;
 
 	g_err[0] = 0;
 	if (n < 0 || (n > 0 && !pairs)) { fail(KSW2AMD_E_PARAM, "extf: bad arguments%s", 0); return 0; }
@@ -317,6 +368,7 @@ ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n
 		if (wave_rate > 760.0) wave_rate = 760.0;
 		use_lane = ev && *ev ? atoi(ev) != 0 : lane_rate > 1.15 * wave_rate;
 		if (ENV(EXTF_LDS) || ENV(EXTF_WIN) || ENV(EXTF_HBM)) use_lane = ev && *ev ? atoi(ev) != 0 : 0;
+		if (g_src_device) use_lane = 0;                                      /* (that form's arena is interleaved by the host) */
 	}
 	for (i = 0; i < n; ++i) {
 		const ksw2amd_fpair_t *a = &pairs[i];
@@ -405,10 +457,20 @@ ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n
 	p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, p->seq_bytes, &p->cap[BUF_HSEQ]);
 	if (!p->h_seq) { fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
 	if (nlane) memset(p->h_seq, 0, p->seq_bytes);             /* the interleaved blocks read zero past every sequence's end */
+	if (g_src_device) {
+		memset(p->h_seq, 0, p->seq_bytes);
+		gt = (gather_ent_t*)malloc(sizeof(gather_ent_t) * (2 * (size_t)n + 1));
+		if (!gt) { fail(KSW2AMD_E_NOMEM, "extf: host allocation failed%s", 0); goto err; }
+	}
 	for (i = 0; i < n; ++i) {
 		if (p->h_cls[i] < 0 || p->h_cls[i] == 6) continue;
+		if (gt) {
+			gt[ngt].src = (uint64_t)(uintptr_t)pairs[i].query; gt[ngt].dst = p->h_pairs[i].qoff; gt[ngt++].len = (uint32_t)pairs[i].qlen;
+			gt[ngt].src = (uint64_t)(uintptr_t)pairs[i].target; gt[ngt].dst = p->h_pairs[i].toff; gt[ngt++].len = (uint32_t)pairs[i].tlen;
+		} else {
 		memcpy(p->h_seq + p->h_pairs[i].qoff, pairs[i].query, (size_t)pairs[i].qlen);
 		memcpy(p->h_seq + p->h_pairs[i].toff, pairs[i].target, (size_t)pairs[i].tlen);
+		}
 		p->h_order[fill[p->h_cls[i]]++] = (uint32_t)i;
 	}
 	for (i = 0; i < nlane; ++i) {                             /* lane = position in the class's task list, byte x of lane l at (x / 4 * 64 + l) * 4 + x % 4 */
@@ -435,14 +497,15 @@ ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n
 	p->stream = up; p->stream_used = 1;
 	if (k2a_shim_h2d(p->d_seq, p->h_seq, p->seq_bytes, up) || k2a_shim_h2d(p->d_pairs, p->h_pairs, sizeof(K2aPair) * (size_t)n, up) ||
 	    k2a_shim_h2d(p->d_order, p->h_order, sizeof(uint32_t) * (size_t)p->norder, up) ||
-	    k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)n, up) || k2a_shim_stream_sync(up)) {
+	    k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)n, up) || (gt && gather_device_sources(p, gt, ngt, up)) || k2a_shim_stream_sync(up)) {
 		fail(KSW2AMD_E_NODEVICE, "upload failed: %s", k2a_shim_last_error());
 		goto err;
 	}
+	free(gt);
 	plan_ready(p);                                  /* uploads complete */
 	return p;
 err:
-	free(srt);
+	free(srt); free(gt);
 	ksw2amd_plan_destroy(p);
 	return 0;
 }
@@ -704,13 +767,19 @@ static int extf_serial(void *km, int8_t mch, int8_t mis, int8_t e, int n, const 
 	return KSW2AMD_OK;
 }
 
-typedef struct { void *km; int8_t mch, mis, e; const ksw2amd_fpair_t *pairs; ksw_extz_t *ez; } extf_ctx_t;
+typedef struct { void *km; int8_t mch, mis, e; const ksw2amd_fpair_t *pairs; ksw_extz_t *ez; int src_device; } extf_ctx_t;
 int extf_chunk(void *ctx_, int beg, int end, int share, pend_t *pd)
 {
 	extf_ctx_t *c = (extf_ctx_t*)ctx_;
 	(void)pd; (void)share;
 	if (beg < 0) return KSW2AMD_OK;
-	return extf_serial(c->km, c->mch, c->mis, c->e, end - beg, c->pairs + beg, c->ez + beg);
+	{
+		int rc;
+		g_src_device = c->src_device;
+		rc = extf_serial(c->km, c->mch, c->mis, c->e, end - beg, c->pairs + beg, c->ez + beg);
+		g_src_device = 0;
+		return rc;
+	}
 }
 
 int ksw2amd_extf_batch(void *km, int8_t mch, int8_t mis, int8_t e, int n, const ksw2amd_fpair_t *pairs, ksw_extz_t *ez)
@@ -726,12 +795,21 @@ int ksw2amd_extf_batch(void *km, int8_t mch, int8_t mis, int8_t e, int n, const 
 		if (cost && nchunks >= 2) {
 			extf_ctx_t ctx;
 			for (i = 0; i < n; ++i) { cost[i] = 1.0 + (double)imax(pairs[i].qlen, 0) + imax(pairs[i].tlen, 0); total += cost[i]; }
-			ctx.km = km; ctx.mch = mch; ctx.mis = mis; ctx.e = e; ctx.pairs = pairs; ctx.ez = ez;
+			ctx.km = km; ctx.mch = mch; ctx.mis = mis; ctx.e = e; ctx.pairs = pairs; ctx.ez = ez; ctx.src_device = g_src_device;
 			if (run_pooled(extf_chunk, &ctx, n, cost, total, nchunks, chunk_pairs, &rc)) { free(cost); return rc; }
 		}
 		free(cost);
 	}
 	return extf_serial(km, mch, mis, e, n, pairs, ez);
+}
+
+int ksw2amd_extf_batch_device(void *km, int8_t mch, int8_t mis, int8_t e, int n, const ksw2amd_fpair_t *pairs, ksw_extz_t *ez)
+{
+	int rc;
+	g_src_device = 1;
+	rc = ksw2amd_extf_batch(km, mch, mis, e, n, pairs, ez);
+	g_src_device = 0;
+	return rc;
 }
 
 void ksw_extf2_sse(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t mch, int8_t mis, int8_t e, int w, int xdrop,

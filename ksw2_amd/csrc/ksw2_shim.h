@@ -107,6 +107,9 @@ int k2a_shim_launch_trace_pk(int cfg, int dual, const K2aPair *pairs, const uint
 
 /* uniform plans (K2aUniform, ksw2_types.h): write pairs[n], order2[2 * ntasks] and -- need != NULL -- the streamed launch's
  * need[ceil(ntasks / ng)] on the device */
+/* device-resident sources of the exts / extf batch entries: entry k copies len bytes from the device address src to dst + dst_off */
+typedef struct K2aGather { uint64_t src; uint32_t dst, len; } K2aGather;
+int k2a_shim_launch_gather(const K2aGather *tab, int n, uint8_t *dst, void *stream);
 /* 4-bit wire format of uniform plans: bytes / 2 upload bytes at src -> bytes arena bytes at dst (bytes a multiple of 8) */
 int k2a_shim_launch_wire4_expand(const uint8_t *src, uint8_t *dst, size_t bytes, void *stream);
 int k2a_shim_launch_uniform_layout(const K2aUniform *u, K2aPair *pairs, uint32_t *order2, uint32_t *need, void *stream);

@@ -2136,6 +2136,22 @@ int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax,
 }
 
 __global__ void __launch_bounds__(256)
+k2a_gather_kernel(const K2aGather *__restrict__ tab, uint8_t *__restrict__ dst)
+{
+	const K2aGather g = tab[blockIdx.x];
+	const uint8_t *src = (const uint8_t*)(uintptr_t)g.src;
+	uint8_t *d = dst + g.dst;
+	for (uint32_t x = threadIdx.x; x < g.len; x += 256) d[x] = src[x];
+}
+int k2a_shim_launch_gather(const K2aGather *tab, int n, uint8_t *dst, void *stream)
+{
+	if (n <= 0) return 0;
+	hipLaunchKernelGGL(k2a_gather_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, tab, dst);
+	CHECK(hipGetLastError());
+	return 0;
+}
+
+__global__ void __launch_bounds__(256)
 k2a_wire4_expand_kernel(const uint32_t *__restrict__ src, uint2 *__restrict__ dst, size_t n8)
 {
 	for (size_t x = (size_t)blockIdx.x * 256 + threadIdx.x; x < n8; x += (size_t)gridDim.x * 256) {

@@ -175,30 +175,28 @@ def align_flat(lib, kind, seq, meta, scoring, junc=None, device_base=None):
     """One rank's shard through the C-ABI batch entry point.  `seq` = all queries then all targets of the shard (then all
     junction arrays, exts only), `meta` int32 [n, META].  Returns (records int32 [n, RES], CIGAR words int32 flat).
     A shard that RCCL delivered into device memory (`seq` a CUDA tensor, or `device_base` = its address) stays there: extz / extd
-    shards go through ksw2amd_ext?_batch_flat with on_device = 1 -- scatter -> align -> gather never copies the sequences through
-    host memory on a receiving rank."""
+    shards go through ksw2amd_ext?_batch_flat with on_device = 1, exts / extf shards through ksw2amd_ext?_batch_device (device
+    pointers per pair, gathered into the plan's arena by one kernel) -- scatter -> align -> gather never copies the sequences
+    through host memory on a receiving rank."""
     n = len(meta)
     rec = np.zeros((n, RES), dtype=np.int32)
     if n == 0:
         return rec, np.zeros(0, dtype=np.int32)
     on_device = device_base is not None or (isinstance(seq, torch.Tensor) and seq.is_cuda)
-    if on_device and kind not in ("extz", "extd"):          # the splice-aware / X-drop entry points take host pointers
-        seq = seq.cpu().numpy() if isinstance(seq, torch.Tensor) else seq
-        on_device, device_base = False, None
     if on_device and device_base is None:
         device_base = seq.data_ptr()
     if not on_device:
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
     ql, tl = meta[:, 0].astype(np.int64), meta[:, 1].astype(np.int64)
-    base = 0 if on_device else seq.ctypes.data
+    base = int(device_base) if on_device else seq.ctypes.data
     qoff = np.concatenate([[0], np.cumsum(ql)[:-1]])
     toff = int(ql.sum()) + np.concatenate([[0], np.cumsum(tl)[:-1]])
     ez = np.zeros(n, dtype=_EZ_DTYPE)
     ezp = ez.ctypes.data_as(ctypes.POINTER(KswExtz))
-    if on_device:
+    if on_device and kind in ("extz", "extd"):
         qo, to = np.ascontiguousarray(qoff, dtype=np.uint64), np.ascontiguousarray(toff, dtype=np.uint64)
         cols = [np.ascontiguousarray(meta[:, c], dtype=np.int32) for c in (0, 1, 2, 3, 4, 5)]
-        flat = Flat(device_base, qo.ctypes.data, to.ctypes.data, *[c.ctypes.data for c in cols], 0, 0, 0, 0, 1)
+        flat = Flat(int(device_base), qo.ctypes.data, to.ctypes.data, *[c.ctypes.data for c in cols], 0, 0, 0, 0, 1)
         mat = np.ascontiguousarray(scoring["mat"], dtype=np.int8)
         sc = Scoring(int(scoring.get("m") or round(len(mat) ** 0.5)), mat.ctypes.data_as(_i8p), scoring["q"], scoring["e"],
                      scoring.get("q2", 0), scoring.get("e2", 0))
@@ -226,12 +224,14 @@ def align_flat(lib, kind, seq, meta, scoring, junc=None, device_base=None):
         mat = np.ascontiguousarray(scoring["mat"], dtype=np.int8)
         sc = SpliceScoring(int(scoring.get("m") or round(len(mat) ** 0.5)), mat.ctypes.data_as(_i8p), scoring["q"], scoring["e"],
                            scoring["q2"], scoring["noncan"], scoring.get("junc_bonus", 0))
-        lib._check(lib.lib.ksw2amd_exts_batch(None, ctypes.byref(sc), n, pr.ctypes.data_as(ctypes.POINTER(SplicePair)), ezp))
+        f = lib.lib.ksw2amd_exts_batch_device if on_device else lib.lib.ksw2amd_exts_batch
+        lib._check(f(None, ctypes.byref(sc), n, pr.ctypes.data_as(ctypes.POINTER(SplicePair)), ezp))
     elif kind == "extf":
         pr = np.zeros(n, dtype=np.dtype([("query", "<u8"), ("target", "<u8"), ("qlen", "<i4"), ("tlen", "<i4"), ("w", "<i4"), ("xdrop", "<i4")]))
         assert pr.dtype.itemsize == ctypes.sizeof(LinearPair)
         pr["query"], pr["target"], pr["qlen"], pr["tlen"], pr["w"], pr["xdrop"] = base + qoff, base + toff, ql, tl, meta[:, 2], meta[:, 3]
-        lib._check(lib.lib.ksw2amd_extf_batch(None, scoring["mch"], scoring["mis"], scoring["e"], n, pr.ctypes.data_as(ctypes.POINTER(LinearPair)), ezp))
+        f = lib.lib.ksw2amd_extf_batch_device if on_device else lib.lib.ksw2amd_extf_batch
+        lib._check(f(None, scoring["mch"], scoring["mis"], scoring["e"], n, pr.ctypes.data_as(ctypes.POINTER(LinearPair)), ezp))
     else:
         raise ValueError("kind must be extz, extd, exts or extf")
     rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3] = ez["score"], ez["max_zd"] & 0x7fffffff, ez["max_t"], ez["max_q"]

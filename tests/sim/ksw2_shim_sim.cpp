@@ -1192,6 +1192,11 @@ int k2a_shim_launch_fill_pk(int cfg, int dual, int mode, int rebased, int nomax,
 	if (ntasks > 0) (lds ? g_fill_pk_lds[rebased ? 1 : 0][mode - 1] : ldc ? g_fill_pk_ldscodes[k2a_pkcfg_G[cfg] == 8 ? 1 : k2a_pkcfg_G[cfg] == 16 ? 2 : 0][nomax ? 1 : 0][rebased ? 1 : 0] : g_fill_pk[nomax ? 1 : 0][rebased ? 1 : 0][cfg][dual ? 1 : 0][mode])(*sc, pairs, order2, ntasks, seq, tb, res, qd);
 	return 0;
 }
+int k2a_shim_launch_gather(const K2aGather *tab, int n, uint8_t *dst, void *)
+{
+	for (int k = 0; k < n; ++k) memcpy(dst + tab[k].dst, (const void*)(uintptr_t)tab[k].src, tab[k].len);
+	return 0;
+}
 int k2a_shim_launch_wire4_expand(const uint8_t *src, uint8_t *dst, size_t bytes, void *)
 {
 	for (size_t x = 0; x < bytes >> 3; ++x) {

@@ -961,6 +961,39 @@ def test_sse_compatible_mode(lib):
     su.check_long(lib, n=6, length=6000, w=150)
 
 
+def test_device_resident_ext_shards(lib):
+    """X-drop and splice-aware shards that lie in device memory (what RCCL delivers on a receiving rank) through
+    ksw2amd_ext?_batch_device -- device pointers per pair, one gather kernel into the plan's arena -- against the same shards from
+    host memory: a few pairs on the calling thread, and 2 600 pairs through the worker pool's chunks."""
+    from ksw2_amd import parallel
+    from oracle.gen_golden_extf import noisy_pair
+    from oracle.gen_golden_exts import spliced_pair
+    rng = np.random.Generator(np.random.PCG64(77))
+    for n in (9, 2600):
+        fp = [noisy_pair(rng, int(rng.integers(40, 600)), k % 3) for k in range(n)]
+        meta = np.zeros((n, parallel.META), dtype=np.int32)
+        meta[:, 0], meta[:, 1], meta[:, 2], meta[:, 3], meta[:, 6] = [len(a) for a, _ in fp], [len(b) for _, b in fp], 50, 80, np.arange(n)
+        seq = np.concatenate([a for a, _ in fp] + [b for _, b in fp])
+        dptr = lib.device_copy(seq)
+        rec, _ = parallel.align_flat(lib, "extf", None, meta, dict(mch=2, mis=-4, e=2), device_base=dptr)
+        rec2, _ = parallel.align_flat(lib, "extf", seq, meta, dict(mch=2, mis=-4, e=2))
+        lib.device_free(dptr)
+        assert np.array_equal(rec, rec2), n
+        for i in range(0, n, max(1, n // 12)):
+            exp = po.extf2("oracle", fp[i][0], fp[i][1], 2, -4, 2, 50, 80)
+            assert exp["score"] == rec[i, 0] and exp["max"] == rec[i, 1] and exp["max_t"] == rec[i, 2], (n, i)
+        sp = [spliced_pair(rng, int(rng.integers(60, 260)), k % 5 == 4) for k in range(n)]
+        meta = np.zeros((n, parallel.META), dtype=np.int32)
+        meta[:, 0], meta[:, 1], meta[:, 3], meta[:, 6] = [len(x[0]) for x in sp], [len(x[1]) for x in sp], 200, np.arange(n)
+        seq = np.concatenate([x[0] for x in sp] + [x[1] for x in sp])
+        dptr = lib.device_copy(seq)
+        ssc = dict(mat=synth.simple_mat(5, 1, 2, -1), q=2, e=1, q2=32, noncan=4)
+        rec, cig = parallel.align_flat(lib, "exts", None, meta, ssc, device_base=dptr)
+        rec2, cig2 = parallel.align_flat(lib, "exts", seq, meta, ssc)
+        lib.device_free(dptr)
+        assert np.array_equal(rec, rec2) and np.array_equal(cig, cig2), n
+
+
 def test_linear_xdrop_group_form(lib, monkeypatch):
     """k2a_extf_grp_kernel on the GPU (tests/test_sim_parity._check_extf_group_form), and a batch of 4 099 extensions of 1 000 x 1 000
     at band 100 -- the bench workload's shape, a last wavefront with three empty groups -- against the position-per-lane kernels."""

@@ -77,6 +77,31 @@ assert np.array_equal(rec, rec2) and np.array_equal(cig, cig2), rank
 for i in range(9):
     exp = po.align("oracle", "extd2", pq[i], pt[i], mat, q, e, q2, e2, w=64, zdrop=100)
     assert exp["score"] == rec[i, 0] and exp["n_cigar"] == rec[i, 10], (rank, i)
+# ... and so are X-drop and splice-aware shards (ksw2amd_ext?_batch_device: device pointers per pair, gathered into the plan's arena by a kernel)
+from oracle.gen_golden_extf import noisy_pair
+from oracle.gen_golden_exts import spliced_pair
+fp = [noisy_pair(rng, int(rng.integers(40, 400)), k %% 3) for k in range(7)]
+fmeta = np.zeros((7, parallel.META), dtype=np.int32)
+fmeta[:, 0], fmeta[:, 1], fmeta[:, 2], fmeta[:, 3], fmeta[:, 6] = [len(a) for a, _ in fp], [len(b) for _, b in fp], 40, 60, np.arange(7)
+fseq = np.concatenate([a for a, _ in fp] + [b for _, b in fp])
+dptr = lib.device_copy(fseq)
+frec, _ = parallel.align_flat(lib, "extf", None, fmeta, dict(mch=2, mis=-4, e=2), device_base=dptr)
+frec2, _ = parallel.align_flat(lib, "extf", fseq, fmeta, dict(mch=2, mis=-4, e=2))
+lib.device_free(dptr)
+assert np.array_equal(frec, frec2), rank
+for i in range(7):
+    exp = po.extf2("oracle", fp[i][0], fp[i][1], 2, -4, 2, 40, 60)
+    assert exp["score"] == frec[i, 0] and exp["max"] == frec[i, 1] and exp["max_t"] == frec[i, 2], (rank, i)
+sp = [spliced_pair(rng, int(rng.integers(60, 200)), k) for k in range(5)]
+smeta = np.zeros((5, parallel.META), dtype=np.int32)
+smeta[:, 0], smeta[:, 1], smeta[:, 3], smeta[:, 5], smeta[:, 6] = [len(x[0]) for x in sp], [len(x[1]) for x in sp], 200, 0, np.arange(5)
+sseq = np.concatenate([x[0] for x in sp] + [x[1] for x in sp])
+dptr = lib.device_copy(sseq)
+ssc = dict(mat=synth.simple_mat(5, 1, 2, -1), q=2, e=1, q2=32, noncan=4)
+srec, scig = parallel.align_flat(lib, "exts", None, smeta, ssc, device_base=dptr)
+srec2, scig2 = parallel.align_flat(lib, "exts", sseq, smeta, ssc)
+lib.device_free(dptr)
+assert np.array_equal(srec, srec2) and np.array_equal(scig, scig2) and srec[:, 10].min() > 0, rank
 # an empty shard (more ranks than pairs) must work too
 res = parallel.sharded_align(lib, False, [np.array([1, 2], np.uint8)] if rank == 0 else None, [np.array([1, 2], np.uint8)] if rank == 0 else None, mat, q, e)
 if rank == 0:
