@@ -31,6 +31,11 @@
 #include "ksw2_lane_pk.h"
 
 #define K2A_SSECB_RING 1024                       /* positions the 64 lanes hold */
+/* where position p's H lives in the LDS ring: a lane's 16 entries are contiguous (four 16-byte accesses), and every fourth lane's run
+ * starts four banks further on, so that the 16 lanes an access is served for at a time hit 64 different banks (unpadded, lanes L and
+ * L + 4 meet in the same banks: 126 of 1 053 quad-cycles per anti-diagonal went into bank conflicts, profiles/r5q_10k-ssec_pmc.json) */
+#define K2A_SSECB_RING_WORDS (K2A_SSECB_RING + K2A_SSECB_RING / 16)
+K2A_FN int k2a_ssecb_slot(int p) { const int x = p & (K2A_SSECB_RING - 1); return x + ((x >> 6) << 2); }
 #define K2A_SSECB_SPAN (K2A_SSECB_RING - 64)      /* widest band (positions of one anti-diagonal): the blocks from the one that holds
                                                    * position st - 1 to the one the score refresh reaches must be 64 different lanes */
 
@@ -220,7 +225,7 @@ struct K2aSsecBlk {
 	K2A_FN uint64_t advance_H(const K2aSsec &P, int *hl, const int *hv, int st0, int en1)
 	{
 		const uint32_t em = slot_mask(st0, en1);
-		int *hp = hl + (p0() & (K2A_SSECB_RING - 1));
+		int *hp = hl + k2a_ssecb_slot(p0());
 		int best = INT32_MIN;
 #pragma unroll
 		for (int s = 0; s < 16; ++s) {

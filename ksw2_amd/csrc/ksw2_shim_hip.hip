@@ -1563,7 +1563,7 @@ __device__ __forceinline__ void k2a_ssec_blk_task(const K2aSsec &P, const K2aPai
 			const int need = max(en, pend - 1) >> 4, nb = B.blk < 0 ? lane : B.blk + 64;
 			if (nb <= need) {
 				B.init_block(P, nb, tgt, tlen, qry, qlen, r);
-				int *hp = hl + ((nb << 4) & (K2A_SSECB_RING - 1));
+				int *hp = hl + k2a_ssecb_slot(nb << 4);
 #pragma unroll
 				for (int s = 0; s < 16; ++s) hp[s] = K2A_NEG;
 			}
@@ -1577,11 +1577,11 @@ __device__ __forceinline__ void k2a_ssec_blk_task(const K2aSsec &P, const K2aPai
 		if (!APPROX && r > 0) {
 			K2A_SSECB_SYNC();
 			if (act) {
-				const int *hp = hl + (B.p0() & (K2A_SSECB_RING - 1));
+				const int *hp = hl + k2a_ssecb_slot(B.p0());
 #pragma unroll
 				for (int s = 0; s < 16; ++s) hv[s] = hp[s];
 			}
-			hnew = hl[(en0 > 0 ? en0 - 1 : en0) & (K2A_SSECB_RING - 1)];
+			hnew = hl[k2a_ssecb_slot(en0 > 0 ? en0 - 1 : en0)];
 		}
 		/* the cell at position r (first column) and what the first block reads to its left */
 		const bool prev_ok = st > 0 && st - 1 >= last_st && st - 1 <= last_en;
@@ -1612,11 +1612,11 @@ __device__ __forceinline__ void k2a_ssec_blk_task(const K2aSsec &P, const K2aPai
 				if (act) bk = B.advance_H(P, hl, hv, st0, en1);
 				K2A_SSECB_SYNC();
 				const int pos = lane == 0 ? st0 : en1 + lane - 1;
-				const int hvv = (lane < 4 && pos < en0) ? hl[pos & (K2A_SSECB_RING - 1)] : K2A_NEG;
+				const int hvv = (lane < 4 && pos < en0) ? hl[k2a_ssecb_slot(pos)] : K2A_NEG;
 				Sv = st0 < en0 ? __builtin_amdgcn_readlane(hvv, 0) : A;
 				T0 = __builtin_amdgcn_readlane(hvv, 1); T1 = __builtin_amdgcn_readlane(hvv, 2); T2 = __builtin_amdgcn_readlane(hvv, 3);
 				K2A_SSECB_SYNC();
-				if (lane == 0) hl[en0 & (K2A_SSECB_RING - 1)] = A;
+				if (lane == 0) hl[k2a_ssecb_slot(en0)] = A;
 			} else {
 				A = Sv = k2a_ssec_dh<DUAL>(P, __builtin_amdgcn_readlane((int)k2a_sb_get(B.V, 0), 0)) - (DUAL ? P.qe_first : P.q + P.e);
 				if (lane == 0) hl[0] = A;
@@ -1641,7 +1641,7 @@ __global__ void __launch_bounds__(64 * K2A_WPB)
 k2a_ssec_blk_kernel(const K2aSsec P, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
                     const uint8_t *__restrict__ seq, K2aResult *__restrict__ res)
 {
-	__shared__ int hl_all[K2A_WPB][K2A_SSECB_RING];
+	__shared__ int hl_all[K2A_WPB][K2A_SSECB_RING_WORDS];
 	const int lane = threadIdx.x & 63, wave = k2a_wave_id<true>();
 	const int task = blockIdx.x * K2A_WPB + wave;
 	if (task >= ntasks) return;                       /* whole wavefronts leave; nobody synchronises below */

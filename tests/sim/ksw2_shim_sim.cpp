@@ -756,7 +756,6 @@ static void sim_ssec(const K2aSsec P, const K2aPair *pairs, const uint32_t *orde
 template<bool DUAL>
 static void sim_ssec_blk(const K2aSsec P, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, K2aResult *res)
 {
-	const int RM = K2A_SSECB_RING - 1;
 	for (int task = 0; task < ntasks; ++task) {
 		const uint32_t pi = order[task];
 		const K2aPair pr = pairs[pi];
@@ -765,7 +764,7 @@ static void sim_ssec_blk(const K2aSsec P, const K2aPair *pairs, const uint32_t *
 		const uint8_t *qry = seq + pr.qoff, *tgt = seq + pr.toff;
 		const int slope = DUAL ? P.e2 : P.e;
 		std::vector<K2aSsecBlk<DUAL>> Bv(64);
-		std::vector<int> hl(K2A_SSECB_RING, 0);
+		std::vector<int> hl(K2A_SSECB_RING_WORDS, 0);
 		for (int l = 0; l < 64; ++l) {
 			K2aSsecBlk<DUAL> &B = Bv[l];
 			B.blk = -1; B.qn = 0;
@@ -790,7 +789,7 @@ static void sim_ssec_blk(const K2aSsec P, const K2aPair *pairs, const uint32_t *
 				const int nb = B.blk < 0 ? l : B.blk + 64;
 				if (nb <= need) {
 					B.init_block(P, nb, tgt, tlen, qry, qlen, r);
-					for (int s2 = 0; s2 < 16; ++s2) hl[((nb << 4) & RM) + s2] = K2A_NEG;
+					for (int s2 = 0; s2 < 16; ++s2) hl[k2a_ssecb_slot(nb << 4) + s2] = K2A_NEG;
 				}
 				B.ask_query(qry, qlen, r);
 				if (en >= r && B.blk == (r >> 4)) {
@@ -802,9 +801,9 @@ static void sim_ssec_blk(const K2aSsec P, const K2aPair *pairs, const uint32_t *
 			int hv[64][16], hnew = 0;
 			for (int l = 0; l < 64; ++l) {
 				act[l] = Bv[l].blk >= (st >> 4) && Bv[l].blk <= (en >> 4);
-				if (!approx && r > 0 && act[l]) for (int s2 = 0; s2 < 16; ++s2) hv[l][s2] = hl[(Bv[l].p0() & RM) + s2];
+				if (!approx && r > 0 && act[l]) for (int s2 = 0; s2 < 16; ++s2) hv[l][s2] = hl[k2a_ssecb_slot(Bv[l].p0()) + s2];
 			}
-			if (!approx && r > 0) hnew = hl[(en0 > 0 ? en0 - 1 : en0) & RM];
+			if (!approx && r > 0) hnew = hl[k2a_ssecb_slot(en0 > 0 ? en0 - 1 : en0)];
 			uint32_t pv[64], px[64], px2[64];
 			for (int l = 0; l < 64; ++l) { const K2aSsecBlk<DUAL> &Bp = Bv[(l + 63) & 63]; pv[l] = Bp.V[7]; px[l] = Bp.X[7]; px2[l] = DUAL ? Bp.X2[7] : 0u; }
 			for (int l = 0; l < 64; ++l) {
@@ -824,9 +823,9 @@ static void sim_ssec_blk(const K2aSsec P, const K2aPair *pairs, const uint32_t *
 					const int dl = (int)(en0 > 0 ? k2a_sb_get(Bo.U, en0 & 15) : k2a_sb_get(Bo.V, en0 & 15));
 					A = hprev + k2a_ssec_dh<DUAL>(P, dl);
 					for (int l = 0; l < 64; ++l) if (act[l]) { const uint64_t k = Bv[l].advance_H(P, hl.data(), hv[l], st0, en1); if (k > Bkey) Bkey = k; }
-					Sv = st0 < en0 ? hl[st0 & RM] : A;
-					for (int k = 0; k < 3; ++k) if (en1 + k < en0) T[k] = hl[(en1 + k) & RM];
-					hl[en0 & RM] = A;
+					Sv = st0 < en0 ? hl[k2a_ssecb_slot(st0)] : A;
+					for (int k = 0; k < 3; ++k) if (en1 + k < en0) T[k] = hl[k2a_ssecb_slot(en1 + k)];
+					hl[k2a_ssecb_slot(en0)] = A;
 				} else {
 					A = Sv = k2a_ssec_dh<DUAL>(P, (int)k2a_sb_get(Bv[0].V, 0)) - (DUAL ? P.qe_first : P.q + P.e);
 					hl[0] = A;
