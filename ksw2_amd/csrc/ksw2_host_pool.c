@@ -740,7 +740,9 @@ static int run_batch_(int dual, int scalar, void *km, const ksw2amd_scoring_t *s
 			/* one shape AND one set of parameters, from ordinary host memory: a uniform plan (ksw2_host_plan.c "uniform batches") -- no
 			 * per-pair work on this thread, the records built on the device, ONE streamed launch -- whatever the reads' length (round 5:
 			 * config 2, whose plan creation used to cost more than its kernel, goes this way too) */
-			if (same && fits && !flat) {
+			/* (a flat batch in HOST memory goes the same way: its pairs point into the arena, and the gather that packs two codes per byte
+			 * moves half the bytes over the link that uploading the arena as it lies would -- config 2: 1 870 against 900 GCUPS) */
+			if (same && fits && (!flat || !flat->on_device)) {
 				const double tu0 = now_ms();
 				ksw2amd_plan_t *up = plan_create_uniform_entry(dual, scalar, sc, n, pairs);
 				if (up) {
