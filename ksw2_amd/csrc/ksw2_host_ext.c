@@ -248,9 +248,9 @@ static int exts_serial(void *km, const ksw2amd_splice_t *sc, int n, const ksw2am
  * lane blocks) is what bounds these functions end to end */
 /* chunk count and size for these one-alignment-per-wavefront classes: one chunk per worker; a batch of one shape is cut at
  * multiples of a device fill (one wavefront per SIMD) like the extz / extd batches (uniform_chunks) */
-static int wave_chunks(int n, int workers, int uniform, int *chunk_pairs)
+static int wave_chunks(int n, int workers, int uniform, int per_wave, int *chunk_pairs)      /* per_wave: alignments one wavefront of the batch's kernel holds */
 {
-	const int simds = k2a_shim_simd_count();
+	const int simds = k2a_shim_simd_count() * imax(per_wave, 1);
 	int k = imin(workers, n / 256);
 	*chunk_pairs = 0;
 	if (uniform && simds > 0 && k >= 2 && n >= 2 * simds) {
@@ -285,7 +285,7 @@ int ksw2amd_exts_batch(void *km, const ksw2amd_splice_t *sc, int n, const ksw2am
 		double *cost = (double*)malloc(sizeof(double) * (size_t)n), total = 0;
 		int i, rc = 0, uniform = 1, chunk_pairs = 0, nchunks;
 		for (i = 1; i < n && uniform; ++i) uniform = pairs[i].qlen == pairs[0].qlen && pairs[i].tlen == pairs[0].tlen;
-		nchunks = wave_chunks(n, workers, uniform, &chunk_pairs);
+		nchunks = wave_chunks(n, workers, uniform, 1, &chunk_pairs);
 		if (cost && nchunks >= 2) {
 			exts_ctx_t ctx;
 			for (i = 0; i < n; ++i) { cost[i] = 1.0 + (double)imax(pairs[i].qlen, 0) * imax(pairs[i].tlen, 0); total += cost[i]; }
@@ -791,7 +791,14 @@ int ksw2amd_extf_batch(void *km, int8_t mch, int8_t mis, int8_t e, int n, const 
 		double *cost = (double*)malloc(sizeof(double) * (size_t)n), total = 0;
 		int i, rc = 0, uniform = 1, chunk_pairs = 0, nchunks;
 		for (i = 1; i < n && uniform; ++i) uniform = pairs[i].qlen == pairs[0].qlen && pairs[i].tlen == pairs[0].tlen && pairs[i].w == pairs[0].w;
-		nchunks = wave_chunks(n, workers, uniform, &chunk_pairs);
+		{	/* narrow bands run four extensions per wavefront (k2a_extf_grp_kernel): a chunk of whole device fills is four times the pairs
+			 * (16 384 x 1 000^2, band 100: four chunks of 4 096 run at 680-715 GCUPS end to end, six of 3 072 at 460-490) */
+			const int wq = pairs[0].w < 0 ? imax(pairs[0].qlen, pairs[0].tlen) : pairs[0].w;
+			const int span0 = imin(imin(pairs[0].qlen, pairs[0].tlen), wq < 0x7ffffff0 ? wq + 1 : wq);
+			const char *gv = ENV(EXTF_GRP);
+			const int grp = uniform && span0 <= EXTFB_SPAN && !(gv && *gv && atoi(gv) == 0) && !(ENV(EXTF_LDS) || ENV(EXTF_WIN) || ENV(EXTF_HBM));
+			nchunks = wave_chunks(n, workers, uniform, grp ? 4 : 1, &chunk_pairs);
+		}
 		if (cost && nchunks >= 2) {
 			extf_ctx_t ctx;
 			for (i = 0; i < n; ++i) { cost[i] = 1.0 + (double)imax(pairs[i].qlen, 0) + imax(pairs[i].tlen, 0); total += cost[i]; }
