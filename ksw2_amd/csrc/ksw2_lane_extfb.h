@@ -6,7 +6,7 @@
  *
  * Why: an anti-diagonal of a band of 100 positions is two passes of the position-per-lane kernels, and what those spend per
  * anti-diagonal is the wavefront-uniform part -- band bounds, the followed cell, the loop: 79 vector + 120 scalar instructions for 101
- * cells (profiles/r5p_extf_pmc.json), 0.019 of the VALU roofline.  Here that part is computed by every lane for its own extension
+ * cells (profiles/r5p_extf_pmc.json: the LDS form), 0.019 of the VALU roofline.  Here that part is computed by every lane for its own extension
  * (16 lanes redundantly) and serves four extensions per instruction; the one-extension-per-lane form (k2a_extf_lane_diag) goes further
  * but needs 64 extensions per wavefront, i.e. batches of 10^5 extensions to fill the device, this one 4.
  *
