@@ -33,7 +33,8 @@
 #define K2A_SSECB_RING 1024                       /* positions the 64 lanes hold */
 /* where position p's H lives in the LDS ring: a lane's 16 entries are contiguous (four 16-byte accesses), and every fourth lane's run
  * starts four banks further on, so that the 16 lanes an access is served for at a time hit 64 different banks (unpadded, lanes L and
- * L + 4 meet in the same banks: 126 of 1 053 quad-cycles per anti-diagonal went into bank conflicts, profiles/r5z_10k-ssec_pmc.json) */
+ * L + 4 meet in the same banks: 126 of 1 053 quad-cycles per anti-diagonal went into bank conflicts; 21 of 1 025 now,
+ * profiles/r5z_10k-ssec_pmc.json) */
 #define K2A_SSECB_RING_WORDS (K2A_SSECB_RING + K2A_SSECB_RING / 16)
 K2A_FN int k2a_ssecb_slot(int p) { const int x = p & (K2A_SSECB_RING - 1); return x + ((x >> 6) << 2); }
 #define K2A_SSECB_SPAN (K2A_SSECB_RING - 64)      /* widest band (positions of one anti-diagonal): the blocks from the one that holds
