@@ -70,6 +70,7 @@
 	X(STREAM_LANES) \
 	X(WIRE4) \
 	X(PLAIN_UP_STREAMS) \
+	X(WORKER_PRIO) \
 	X(SSE_COMPAT) \
 	X(STREAM) \
 	X(STREAM_FAULT) \

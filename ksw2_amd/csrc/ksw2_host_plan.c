@@ -114,7 +114,8 @@ static void thread_owns_cache(void)
 	pthread_once(&g_exit_once, thread_exit_init);
 	if (!pthread_getspecific(g_exit_key)) pthread_setspecific(g_exit_key, (void*)1);
 }
-void *thread_stream(void) { if (!g_stream) { thread_owns_cache(); g_stream = k2a_shim_stream_create(); } return g_stream; }
+__thread int g_stream_high;              /* pool workers with an odd rank (KSW2AMD_WORKER_PRIO=1): their kernels' stream from the high-priority pool of hardware queues */
+void *thread_stream(void) { if (!g_stream) { thread_owns_cache(); g_stream = g_stream_high ? k2a_shim_stream_create_high() : k2a_shim_stream_create(); } return g_stream; }
 void *thread_upload_stream(void) { if (!g_up_stream) { thread_owns_cache(); g_up_stream = k2a_shim_stream_create(); } return g_up_stream; }
 /* Flat plans upload on ONE stream per device, shared by all host threads: their arena spans go up at link rate one after the
  * other, in the order the plans were created, so the first chunk of a pooled batch is on the device after 1 / nchunks of the

@@ -78,6 +78,10 @@ static void *pool_worker(void *arg_)
 	g_is_worker = 1;
 	k2a_shim_set_device(dev);
 	pin_worker_to_device_node();
+	/* every second worker's kernels on a high-priority stream: the runtime deals streams onto four hardware queues PER PRIORITY, so eight
+	 * workers' streams of one priority share queues in pairs and one chunk's traceback walk holds up the next chunk's fill behind it
+	 * (config 3: 19.9 -> 18.8 ms per batch, 10 k with CIGAR 32.4 -> 30.3; KSW2AMD_WORKER_PRIO=0: all ordinary) */
+	{ extern __thread int g_stream_high; const char *e = ENV(WORKER_PRIO); g_stream_high = !(e && *e && atoi(e) == 0) && (rank & 1); }
 	pthread_mutex_lock(&g_pool.mu);
 	for (;;) {
 		job_t *j;
