@@ -116,7 +116,7 @@ static void thread_owns_cache(void)
 }
 __thread int g_stream_high;              /* pool workers with an odd rank (KSW2AMD_WORKER_PRIO=1): their kernels' stream from the high-priority pool of hardware queues */
 void *thread_stream(void) { if (!g_stream) { thread_owns_cache(); g_stream = g_stream_high ? k2a_shim_stream_create_high() : k2a_shim_stream_create(); } return g_stream; }
-void *thread_upload_stream(void) { if (!g_up_stream) { thread_owns_cache(); g_up_stream = k2a_shim_stream_create(); } return g_up_stream; }
+void *thread_upload_stream(void) { if (!g_up_stream) { thread_owns_cache(); g_up_stream = ENV(PLAIN_UP_STREAMS) ? k2a_shim_stream_create() : k2a_shim_stream_create_low(); } return g_up_stream; }      /* copies only: see shared_upload_stream */
 /* Flat plans upload on ONE stream per device, shared by all host threads: their arena spans go up at link rate one after the
  * other, in the order the plans were created, so the first chunk of a pooled batch is on the device after 1 / nchunks of the
  * batch's upload time and its kernels run under the remaining uploads.  (Six workers uploading on six streams share the link:
