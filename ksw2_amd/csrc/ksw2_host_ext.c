@@ -601,13 +601,13 @@ ksw2amd_plan_t *ksw2amd_sse_plan_create(int dual, const ksw2amd_scoring_t *sc, i
 		mx = imax(a->qlen, a->tlen);
 		if (w < 0 || w > mx) w = mx;                                       /* a wider band than the sequences changes nothing (ksw2_extz2_sse.c:72) */
 		mode = (fl & KSW_EZ_SCORE_ONLY) ? K2A_MODE_SCORE : (fl & KSW_EZ_RIGHT) ? K2A_MODE_RIGHT : K2A_MODE_LEFT;
-		{	/* kernel form.  2: state in registers (k2a_ssec_blk_kernel: score-only, simple scoring, bands up to SSECB_SPAN positions;
+		{	/* kernel form.  2: state in registers (k2a_ssec_blk_kernel: simple scoring, bands up to SSECB_SPAN positions;
 			 * KSW2AMD_SSEC_BLK=0: never); 1: state arrays of up to SSEC_LDS_MAX bytes in LDS (k2a_ssec_kernel<.., LDS = true>);
 			 * 0: in HBM scratch (KSW2AMD_SSEC_HBM=1: always, tests) */
 			const size_t sb = (size_t)(dual ? 11 : 9) * (size_t)((a->tlen + 15) / 16 * 16);
 			const char *blk = ENV(SSEC_BLK);
 			int form = sb <= SSEC_LDS_MAX;
-			if (mode == K2A_MODE_SCORE && !(fl & KSW_EZ_GENERIC_SC) && imin(imin(a->qlen, a->tlen), w + 1) <= SSECB_SPAN && !(blk && blk[0] == '0')) form = 2;
+			if (!(fl & KSW_EZ_GENERIC_SC) && imin(imin(a->qlen, a->tlen), w + 1) <= SSECB_SPAN && !(blk && blk[0] == '0')) form = 2;
 			if (ENV(SSEC_HBM)) form = 0;
 			p->h_cls[i] = (int8_t)(mode + 3 * form);
 			++p->s_count[mode][0][form];
@@ -692,14 +692,15 @@ int ssec_plan_run(ksw2amd_plan_t *p, void *stream)
 	if (p->up_ev && k2a_shim_stream_wait_event(stream, p->up_ev)) goto err;      /* the plan's upload (shared stream) before its kernels */
 	if (p->reject_all || p->ntasks == 0) return KSW2AMD_OK;
 	if (k2a_shim_event_record(p->ev[0], stream)) goto err;
-	if (p->s_count[0][0][2] &&
-	    k2a_shim_launch_ssec_blk(p->dual, &p->c_par, p->d_pairs, p->d_order + p->s_first[0][0][2], p->s_count[0][0][2], p->d_seq, p->d_res, stream)) goto err;
+	for (mode = 0; mode < 3; ++mode)
+		if (p->s_count[mode][0][2] &&
+		    k2a_shim_launch_ssec_blk(p->dual, mode, &p->c_par, p->d_pairs, p->d_order + p->s_first[mode][0][2], p->s_count[mode][0][2], p->d_seq, p->d_tb, p->d_res, stream)) goto err;
 	for (mode = 0; mode < 6; ++mode)
 		if (p->s_count[mode % 3][0][mode / 3] &&
 		    k2a_shim_launch_ssec(p->dual, mode % 3, mode / 3 ? p->c_lds[mode % 3] : 0, &p->c_par, p->d_pairs, p->d_order + p->s_first[mode % 3][0][mode / 3],
 		                         p->s_count[mode % 3][0][mode / 3], p->d_seq, p->d_tb, (uint8_t*)p->d_bnd, p->d_res, stream)) goto err;
 	if (k2a_shim_event_record(p->ev[1], stream)) goto err;
-	for (mode = 0; mode < 6; ++mode)
+	for (mode = 0; mode < 9; ++mode)
 		if (mode % 3 && p->s_count[mode % 3][0][mode / 3] &&
 		    k2a_shim_launch_ssec_trace(p->d_pairs, p->d_order + p->s_first[mode % 3][0][mode / 3], p->s_count[mode % 3][0][mode / 3], p->d_tb, p->d_res, p->d_cig, stream)) goto err;
 	if (k2a_shim_event_record(p->ev[2], stream)) goto err;

@@ -57,6 +57,20 @@ K2A_FN uint32_t k2a_sb_minu(uint32_t a, uint32_t b)
 }
 K2A_FN uint32_t k2a_sb_shift(uint32_t cur, uint32_t below) { return (below >> 16) | (cur << 16); }
 #endif
+/* signed comparison of the bytes two registers hold: 0xffff per half where a > b.  The difference of two values of the full 16-bit range
+ * overflows: it saturates (v_pk_sub_i16 clamp), which keeps its sign */
+#if defined(__HIP_DEVICE_COMPILE__)
+K2A_FN uint32_t k2a_sb_subs(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }
+#else
+K2A_FN uint32_t k2a_sb_subs(uint32_t a, uint32_t b)
+{
+	int lo = k2a_pk_lo(a) - k2a_pk_lo(b), hi = k2a_pk_hi(a) - k2a_pk_hi(b);
+	lo = lo > 32767 ? 32767 : lo < -32768 ? -32768 : lo; hi = hi > 32767 ? 32767 : hi < -32768 ? -32768 : hi;
+	return k2a_pk_mk(lo, hi);
+}
+#endif
+K2A_FN uint32_t k2a_sb_gt(uint32_t a, uint32_t b) { return k2a_pk_sign(k2a_sb_subs(b, a)); }
+
 /* a block: 16 positions, two per register.  A vector type, so that a read or write by slot number is an element extract / insert on a
  * value (register indexing or a select chain, the compiler's choice) and never an address into a stack copy of the lane's state */
 #if defined(__clang__)
@@ -167,11 +181,15 @@ struct K2aSsecBlk {
 		}
 	}
 
-	/* One anti-diagonal for the block (ksw2_extz2_sse.c:146-222 / ksw2_extd2_sse.c:189-321, score-only forms): pv / px / px2 = the
-	 * previous anti-diagonal's v / x / x~ of position 16 * blk - 1 in the HIGH half (the lane below's last register, or the band
-	 * edge's constants).  Only for a block inside [st, en]. */
-	K2A_FN void update(const K2aSsec &P, uint32_t pv, uint32_t px, uint32_t px2)
+	/* One anti-diagonal for the block (ksw2_extz2_sse.c:146-222 / ksw2_extd2_sse.c:189-321): pv / px / px2 = the previous
+	 * anti-diagonal's v / x / x~ of position 16 * blk - 1 in the HIGH half (the lane below's last register, or the band edge's
+	 * constants).  Only for a block inside [st, en].  MODE != SCORE: dirw = the block's 16 direction bytes (k2a_ssec_cell: the
+	 * winner by the kernels' own strict / non-strict comparisons per alignment mode, the continuation flags from the signs of the
+	 * gap states before they are clipped at 0) in position order, as the reference stores them. */
+	template<int MODE>
+	K2A_FN void update(const K2aSsec &P, uint32_t pv, uint32_t px, uint32_t px2, uint32_t *dirw)
 	{
+		uint32_t dd[8];
 		if (!DUAL) {
 			const uint32_t ccap = k2a_sb_c(P.sc_mch + 2 * (P.q + P.e)), cq = k2a_sb_c(P.q);
 			uint32_t vb = pv, xb = px;
@@ -184,9 +202,19 @@ struct K2aSsecBlk {
 				uint32_t zu = k2a_pk_maxu(z, b);
 				zu = k2a_sb_minu(zu, ccap);
 				const uint32_t z2 = k2a_pk_sub(zu, cq);
+				const uint32_t a1 = k2a_pk_sub(a, z2), b1 = k2a_pk_sub(b, z2);
+				if (MODE == K2A_MODE_LEFT) {
+					uint32_t d = k2a_sb_gt(a, S[i]) & 0x00010001u;
+					d = k2a_pk_selv(k2a_sb_gt(b, z), 0x00020002u, d);
+					dd[i] = d | (k2a_sb_gt(a1, 0u) & 0x00080008u) | (k2a_sb_gt(b1, 0u) & 0x00100010u);
+				} else if (MODE == K2A_MODE_RIGHT) {
+					uint32_t d = ~k2a_sb_gt(S[i], a) & 0x00010001u;
+					d = k2a_pk_selv(k2a_sb_gt(z, b), d, 0x00020002u);
+					dd[i] = d | (~k2a_sb_gt(0u, a1) & 0x00080008u) | (~k2a_sb_gt(0u, b1) & 0x00100010u);
+				}
 				vb = vo; xb = xo;
 				V[i] = k2a_pk_sub(zu, U[i]); U[i] = k2a_pk_sub(zu, vt1);
-				X[i] = k2a_pk_max(k2a_pk_sub(a, z2), 0u); Y[i] = k2a_pk_max(k2a_pk_sub(b, z2), 0u);
+				X[i] = k2a_pk_max(a1, 0u); Y[i] = k2a_pk_max(b1, 0u);
 			}
 		} else {
 			const uint32_t cm = k2a_sb_c(P.sc_mch), cq = k2a_sb_c(P.q), cq2 = k2a_sb_c(P.q2), cqe = k2a_sb_c(P.q + P.e), cqe2 = k2a_sb_c(P.q2 + P.e2);
@@ -196,15 +224,37 @@ struct K2aSsecBlk {
 				const uint32_t vo = V[i], xo = X[i], x2o = X2[i];
 				const uint32_t vt1 = k2a_sb_shift(vo, vb), xt1 = k2a_sb_shift(xo, xb), x2t1 = k2a_sb_shift(x2o, x2b);
 				uint32_t a = k2a_pk_add(xt1, vt1), b = k2a_pk_add(Y[i], U[i]), a2 = k2a_pk_add(x2t1, vt1), b2 = k2a_pk_add(Y2[i], U[i]);
-				uint32_t z = k2a_pk_max(k2a_pk_max(S[i], a), k2a_pk_max(b, k2a_pk_max(a2, b2)));
+				uint32_t z = S[i], d = 0;
+				if (MODE == K2A_MODE_SCORE) z = k2a_pk_max(k2a_pk_max(z, a), k2a_pk_max(b, k2a_pk_max(a2, b2)));
+				else if (MODE == K2A_MODE_LEFT) {
+					d = k2a_sb_gt(a, z) & 0x00010001u;                  z = k2a_pk_max(z, a);
+					d = k2a_pk_selv(k2a_sb_gt(b, z), 0x00020002u, d);    z = k2a_pk_max(z, b);
+					d = k2a_pk_selv(k2a_sb_gt(a2, z), 0x00030003u, d);   z = k2a_pk_max(z, a2);
+					d = k2a_pk_selv(k2a_sb_gt(b2, z), 0x00040004u, d);   z = k2a_pk_max(z, b2);
+				} else {
+					d = ~k2a_sb_gt(z, a) & 0x00010001u;                 z = k2a_pk_max(z, a);
+					d = k2a_pk_selv(k2a_sb_gt(z, b), d, 0x00020002u);    z = k2a_pk_max(z, b);
+					d = k2a_pk_selv(k2a_sb_gt(z, a2), d, 0x00030003u);   z = k2a_pk_max(z, a2);
+					d = k2a_pk_selv(k2a_sb_gt(z, b2), d, 0x00040004u);   z = k2a_pk_max(z, b2);
+				}
 				z = k2a_pk_min(z, cm);
 				vb = vo; xb = xo; x2b = x2o;
 				V[i] = k2a_pk_sub(z, U[i]); U[i] = k2a_pk_sub(z, vt1);
 				uint32_t tmp = k2a_pk_sub(z, cq);
-				X[i] = k2a_pk_sub(k2a_pk_max(k2a_pk_sub(a, tmp), 0u), cqe); Y[i] = k2a_pk_sub(k2a_pk_max(k2a_pk_sub(b, tmp), 0u), cqe);
+				a = k2a_pk_sub(a, tmp); b = k2a_pk_sub(b, tmp);
 				tmp = k2a_pk_sub(z, cq2);
-				X2[i] = k2a_pk_sub(k2a_pk_max(k2a_pk_sub(a2, tmp), 0u), cqe2); Y2[i] = k2a_pk_sub(k2a_pk_max(k2a_pk_sub(b2, tmp), 0u), cqe2);
+				a2 = k2a_pk_sub(a2, tmp); b2 = k2a_pk_sub(b2, tmp);
+				if (MODE == K2A_MODE_LEFT)
+					dd[i] = d | (k2a_sb_gt(a, 0u) & 0x00080008u) | (k2a_sb_gt(b, 0u) & 0x00100010u) | (k2a_sb_gt(a2, 0u) & 0x00200020u) | (k2a_sb_gt(b2, 0u) & 0x00400040u);
+				else if (MODE == K2A_MODE_RIGHT)
+					dd[i] = d | (~k2a_sb_gt(0u, a) & 0x00080008u) | (~k2a_sb_gt(0u, b) & 0x00100010u) | (~k2a_sb_gt(0u, a2) & 0x00200020u) | (~k2a_sb_gt(0u, b2) & 0x00400040u);
+				X[i] = k2a_pk_sub(k2a_pk_max(a, 0u), cqe); Y[i] = k2a_pk_sub(k2a_pk_max(b, 0u), cqe);
+				X2[i] = k2a_pk_sub(k2a_pk_max(a2, 0u), cqe2); Y2[i] = k2a_pk_sub(k2a_pk_max(b2, 0u), cqe2);
 			}
+		}
+		if (MODE != K2A_MODE_SCORE) {
+#pragma unroll
+			for (int j = 0; j < 4; ++j) dirw[j] = k2a_perm(dd[2 * j + 1], dd[2 * j], 0x06040200u);      /* the low byte of each half, four positions per word */
 		}
 	}
 

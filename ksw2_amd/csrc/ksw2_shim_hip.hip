@@ -1539,10 +1539,10 @@ k2a_ssec_kernel(const K2aSsec P, const K2aPair *__restrict__ pairs, const uint32
 /* the anti-diagonals of one task; APPROX: the approximate modes' one followed cell instead of H (a template parameter and not the
  * task's flag tested per anti-diagonal: with both forms in one loop hipcc merges their stores into the book through a selected
  * address and the book moves to scratch memory) */
-template<bool DUAL, bool APPROX>
-__device__ __forceinline__ void k2a_ssec_blk_task(const K2aSsec &P, const K2aPair &pr, const uint8_t *__restrict__ seq, int *hl, int lane, K2aBook &book)
+template<bool DUAL, bool APPROX, int MODE>
+__device__ __forceinline__ void k2a_ssec_blk_task(const K2aSsec &P, const K2aPair &pr, const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, int *hl, int lane, K2aBook &book)
 {
-	const int qlen = pr.qlen, tlen = pr.tlen_full, w = pr.w, T16 = (tlen + 15) / 16 * 16;
+	const int qlen = pr.qlen, tlen = pr.tlen_full, w = pr.w, T16 = (tlen + 15) / 16 * 16, ncol = k2a_ssec_ncol(qlen, tlen, w);
 	const bool adrop = (pr.pad & K2A_SSEC_APPROX_DROP) != 0;
 	const uint8_t *qry = seq + pr.qoff, *tgt = seq + pr.toff;
 	const int slope = DUAL ? P.e2 : P.e;
@@ -1597,7 +1597,12 @@ __device__ __forceinline__ void k2a_ssec_blk_task(const K2aSsec &P, const K2aPai
 		uint32_t pv = (uint32_t)k2a_rot1<64>((int)B.V[7]), px = (uint32_t)k2a_rot1<64>((int)B.X[7]), px2 = DUAL ? (uint32_t)k2a_rot1<64>((int)B.X2[7]) : 0u;
 		if (B.blk == (st >> 4) && !prev_ok) { pv = k2a_sb_c(cv); px = k2a_sb_c(cx); px2 = k2a_sb_c(cx2); }
 		B.refresh_scores(P, st0, pend);
-		if (act) B.update(P, pv, px, px2);
+		if (act) {
+			uint32_t dirw[4];
+			B.template update<MODE>(P, pv, px, px2, dirw);
+			if (MODE != K2A_MODE_SCORE)                          /* the block's 16 direction bytes, where the reference's row r has them (k2a_ssec_trace) */
+				*(uint4*)(tb + pr.tb_off + (size_t)r * ncol + (size_t)(B.p0() - st)) = make_uint4(dirw[0], dirw[1], dirw[2], dirw[3]);
+		}
 		int stop;
 		if (!APPROX) {
 			int A, Sv, T0 = K2A_NEG, T1 = K2A_NEG, T2 = K2A_NEG;
@@ -1636,10 +1641,10 @@ __device__ __forceinline__ void k2a_ssec_blk_task(const K2aSsec &P, const K2aPai
 	}
 }
 
-template<bool DUAL>
+template<bool DUAL, int MODE>
 __global__ void __launch_bounds__(64 * K2A_WPB)
 k2a_ssec_blk_kernel(const K2aSsec P, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
-                    const uint8_t *__restrict__ seq, K2aResult *__restrict__ res)
+                    const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, K2aResult *__restrict__ res)
 {
 	__shared__ int hl_all[K2A_WPB][K2A_SSECB_RING_WORDS];
 	const int lane = threadIdx.x & 63, wave = k2a_wave_id<true>();
@@ -1649,8 +1654,8 @@ k2a_ssec_blk_kernel(const K2aSsec P, const K2aPair *__restrict__ pairs, const ui
 	const uint32_t pi = order[task];
 	const K2aPair pr = pairs[pi];
 	K2aBook book;
-	if (pr.pad & K2A_SSEC_APPROX) k2a_ssec_blk_task<DUAL, true>(P, pr, seq, hl, lane, book);
-	else k2a_ssec_blk_task<DUAL, false>(P, pr, seq, hl, lane, book);
+	if (pr.pad & K2A_SSEC_APPROX) k2a_ssec_blk_task<DUAL, true, MODE>(P, pr, seq, tb, hl, lane, book);
+	else k2a_ssec_blk_task<DUAL, false, MODE>(P, pr, seq, tb, hl, lane, book);
 	if (lane == 0) k2a_finish(pr, book, &res[pi]);
 }
 
@@ -2286,12 +2291,15 @@ int k2a_shim_launch_ssec(int dual, int mode, size_t lds_bytes, const K2aSsec *pa
 	return 0;
 }
 
-/* score-only tasks with the state in registers (k2a_ssec_blk_kernel) */
-int k2a_shim_launch_ssec_blk(int dual, const K2aSsec *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, K2aResult *res, void *stream)
+/* tasks with the state in registers (k2a_ssec_blk_kernel); mode != SCORE: direction bytes into tb at pairs[i].tb_off, as k2a_ssec_kernel lays them out */
+int k2a_shim_launch_ssec_blk(int dual, int mode, const K2aSsec *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, void *stream)
 {
+	typedef void (*blk_fn)(const K2aSsec, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*);
+	static const blk_fn fn[2][3] = { { k2a_ssec_blk_kernel<false, 0>, k2a_ssec_blk_kernel<false, 1>, k2a_ssec_blk_kernel<false, 2> },
+	                                 { k2a_ssec_blk_kernel<true, 0>, k2a_ssec_blk_kernel<true, 1>, k2a_ssec_blk_kernel<true, 2> } };
 	if (ntasks <= 0) return 0;
-	if (dual) hipLaunchKernelGGL(k2a_ssec_blk_kernel<true>, dim3((ntasks + K2A_WPB - 1) / K2A_WPB), dim3(64 * K2A_WPB), 0, (hipStream_t)stream, *par, pairs, order, ntasks, seq, res);
-	else hipLaunchKernelGGL(k2a_ssec_blk_kernel<false>, dim3((ntasks + K2A_WPB - 1) / K2A_WPB), dim3(64 * K2A_WPB), 0, (hipStream_t)stream, *par, pairs, order, ntasks, seq, res);
+	if (mode < 0 || mode > 2) { snprintf(g_err, sizeof(g_err), "bad kernel class"); return -1; }
+	hipLaunchKernelGGL(fn[dual ? 1 : 0][mode], dim3((ntasks + K2A_WPB - 1) / K2A_WPB), dim3(64 * K2A_WPB), 0, (hipStream_t)stream, *par, pairs, order, ntasks, seq, tb, res);
 	CHECK(hipGetLastError());
 	return 0;
 }

@@ -753,8 +753,8 @@ static void sim_ssec(const K2aSsec P, const K2aPair *pairs, const uint32_t *orde
 }
 
 /* mirrors k2a_ssec_blk_kernel: 64 lanes, each one 16-position block of the ring; the phases of an anti-diagonal in the kernel's order */
-template<bool DUAL>
-static void sim_ssec_blk(const K2aSsec P, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, K2aResult *res)
+template<bool DUAL, int MODE>
+static void sim_ssec_blk(const K2aSsec P, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res)
 {
 	for (int task = 0; task < ntasks; ++task) {
 		const uint32_t pi = order[task];
@@ -810,7 +810,11 @@ static void sim_ssec_blk(const K2aSsec P, const K2aPair *pairs, const uint32_t *
 				K2aSsecBlk<DUAL> &B = Bv[l];
 				if (B.blk == (st >> 4) && !prev_ok) { pv[l] = k2a_sb_c(cv); px[l] = k2a_sb_c(cx); px2[l] = k2a_sb_c(cx2); }
 				B.refresh_scores(P, st0, pend);
-				if (act[l]) B.update(P, pv[l], px[l], px2[l]);
+				if (act[l]) {
+					uint32_t dirw[4];
+					B.template update<MODE>(P, pv[l], px[l], px2[l], dirw);
+					if (MODE != K2A_MODE_SCORE) memcpy(tb + pr.tb_off + (size_t)r * k2a_ssec_ncol(qlen, tlen, w) + (size_t)(B.p0() - st), dirw, 16);
+				}
 			}
 			int stop;
 			if (!approx) {
@@ -1350,10 +1354,11 @@ int k2a_shim_launch_ssec(int dual, int mode, size_t, const K2aSsec *par, const K
 	f[dual ? 1 : 0][mode](*par, pairs, order, ntasks, seq, tb, scratch, res);
 	return 0;
 }
-int k2a_shim_launch_ssec_blk(int dual, const K2aSsec *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, K2aResult *res, void *)
+int k2a_shim_launch_ssec_blk(int dual, int mode, const K2aSsec *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, void *)
 {
-	if (dual) sim_ssec_blk<true>(*par, pairs, order, ntasks, seq, res);
-	else sim_ssec_blk<false>(*par, pairs, order, ntasks, seq, res);
+	typedef void (*fn)(const K2aSsec, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*);
+	static const fn f[2][3] = { { sim_ssec_blk<false, 0>, sim_ssec_blk<false, 1>, sim_ssec_blk<false, 2> }, { sim_ssec_blk<true, 0>, sim_ssec_blk<true, 1>, sim_ssec_blk<true, 2> } };
+	f[dual ? 1 : 0][mode](*par, pairs, order, ntasks, seq, tb, res);
 	return 0;
 }
 int k2a_shim_launch_ssec_trace(const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb, K2aResult *res, uint32_t *cig, void *)

@@ -88,7 +88,8 @@ def check_long(lib, n=4, length=3000, w=100):
 
 
 def check_register_form(lib, setenv, rounds=6, long_len=2600):
-    """Score-only tasks take the kernel with the state in registers (k2a_ssec_blk_kernel, ksw2_lane_ssecb.h): bands from one
+    """Tasks with simple scoring take the kernel with the state in registers (k2a_ssec_blk_kernel, ksw2_lane_ssecb.h; with a traceback it
+    writes the direction bytes the reference's walk reads): bands from one
     position to the 960 the ring holds (wider ones keep the position-per-lane kernel), targets longer than the ring so that every
     lane takes several blocks, both gap models, exact maximum and the approximate modes, wildcards, Z-drop, unequal lengths whose
     band ends against a sequence end -- against the oracle, and the same batch with the form switched off (KSW2AMD_SSEC_BLK=0)."""
@@ -106,7 +107,8 @@ def check_register_form(lib, setenv, rounds=6, long_len=2600):
         w = rng.choice([0, 1, 2, 5, 16, 17, 100, 700, 959, 960, 1100, -1], size=n)
         zd = rng.choice([-1, 20, 100, 400], size=n)
         so = po.SCORE_ONLY
-        base = rng.choice([so, so | po.EXTZ_ONLY, so | po.APPROX_MAX | po.EXTZ_ONLY, so | po.APPROX_MAX | po.APPROX_DROP | po.EXTZ_ONLY, so | po.APPROX_MAX], size=n)
+        base = rng.choice([so, so | po.EXTZ_ONLY, so | po.APPROX_MAX | po.EXTZ_ONLY, so | po.APPROX_MAX | po.APPROX_DROP | po.EXTZ_ONLY, so | po.APPROX_MAX,
+                           0, po.RIGHT, po.EXTZ_ONLY | po.REV_CIGAR, po.RIGHT | po.EXTZ_ONLY, po.APPROX_MAX, po.APPROX_MAX | po.APPROX_DROP | po.RIGHT], size=n)      # (half of them with a traceback)
         mat, gq, ge, gq2, ge2 = mats[rnd % 3]
         for dual in (False, True):
             func = "extd2_sse" if dual else "extz2_sse"
@@ -115,7 +117,9 @@ def check_register_form(lib, setenv, rounds=6, long_len=2600):
                 setenv("KSW2AMD_SSEC_BLK", "0" if off else "")
                 b = lib.make_batch(qs, ts, mat, gq, ge, gq2, ge2, w=w, zdrop=zd, end_bonus=3, flag=base | COMPAT)
                 p = b.sse_plan(dual)
-                forms = {d["form"]: d["tasks"] for d in p.describe()}
+                forms = {}
+                for d in p.describe():
+                    forms[d["form"]] = forms.get(d["form"], 0) + d["tasks"]
                 p.close()
                 span = [min(len(qs[i]), len(ts[i]), (int(w[i]) if 0 <= w[i] <= max(len(qs[i]), len(ts[i])) else max(len(qs[i]), len(ts[i]))) + 1) for i in range(n)]
                 assert forms.get("blk", 0) == (0 if off else sum(1 for x in span if x <= 960)), (forms, span)

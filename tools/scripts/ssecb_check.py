@@ -22,7 +22,8 @@ for rnd in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     qs, ts = [p[0] for p in pairs], [p[1] for p in pairs]
     w = rng.choice([0, 1, 2, 5, 15, 16, 17, 40, 100, 300, 700, 959, 960, 1100, -1], size=n)
     zd = rng.choice([-1, 20, 100, 400], size=n)
-    base = rng.choice([po.SCORE_ONLY, po.SCORE_ONLY | po.EXTZ_ONLY, po.SCORE_ONLY | po.APPROX_MAX | po.EXTZ_ONLY, po.SCORE_ONLY | po.APPROX_MAX | po.APPROX_DROP | po.EXTZ_ONLY, po.SCORE_ONLY | po.APPROX_MAX], size=n)
+    base = rng.choice([po.SCORE_ONLY, po.SCORE_ONLY | po.EXTZ_ONLY, po.SCORE_ONLY | po.APPROX_MAX | po.EXTZ_ONLY, po.SCORE_ONLY | po.APPROX_MAX | po.APPROX_DROP | po.EXTZ_ONLY, po.SCORE_ONLY | po.APPROX_MAX,
+                       0, po.RIGHT, po.EXTZ_ONLY, po.RIGHT | po.REV_CIGAR | po.EXTZ_ONLY, po.APPROX_MAX, po.APPROX_MAX | po.APPROX_DROP | po.RIGHT, po.REV_CIGAR], size=n)   # (with a traceback too)
     a, b, scn = [(2, 4, -1), (1, 3, 0), (5, 4, 1), (1, 9, -3)][rnd % 4]
     mat = po.simple_mat(5, a, b, scn)
     gq, ge, gq2, ge2 = [(4, 2, 24, 1), (6, 1, 13, 0), (2, 3, 20, 2), (5, 2, 5, 2)][(rnd // 4) % 4]
