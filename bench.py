@@ -66,6 +66,9 @@ WORKLOADS = {
     # splice-aware extension and gap-linear X-drop extension (N3): see DESIGN.md sections 3.6 / 3.7
     "exts": dict(idx=7, n=16384, qlen=400, tlen=1500, w=-1, zdrop=-1, dual=False, flag=0, sub=0.03, ind=0.0, splice=True),
     "extf": dict(idx=8, n=16384, qlen=1000, tlen=1000, w=100, zdrop=-1, dual=False, flag=SO, sub=0.05, ind=0.01, linear=True),
+    # ... at bands past the four-per-wavefront form: two / one extension per wavefront (32 / 64 lanes each)
+    "extf-w300": dict(idx=8, n=8192, qlen=2000, tlen=2000, w=300, zdrop=-1, dual=False, flag=SO, sub=0.05, ind=0.01, linear=True),
+    "extf-w900": dict(idx=8, n=4096, qlen=4000, tlen=4000, w=900, zdrop=-1, dual=False, flag=SO, sub=0.05, ind=0.01, linear=True),
     # the headline's shape where extensions DO drop: a fifth of the pairs get the last quarter of the query replaced by random bases, so the
     # Z-drop fires there -- what the deferred arg-max costs when it has to hand alignments back is in this line
     "10k-zdrop": dict(idx=6, n=49152, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=SO, sub=0.05, ind=0.06, tail_frac=0.25, tail_pairs=0.20),
@@ -83,7 +86,7 @@ WORKLOADS = {
     # ... and with the CIGAR (the direction bytes of the reference's SSE kernel, its own walk)
     "10k-ssec-cigar": dict(idx=6, n=1024, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=0, sub=0.05, ind=0.06, sse=True),
 }
-ALSO_DEFAULT = ["10k-n1024", "10k-cigar", "cfg2", "cfg3", "cfg5", "cfg4", "cfg5-share", "10k-zdrop", "10k-N", "10k-generic", "exts", "extf", "10k-ssec", "10k-ssec-n4096", "10k-ssec-approx", "10k-ssec-cigar"]
+ALSO_DEFAULT = ["10k-n1024", "10k-cigar", "cfg2", "cfg3", "cfg5", "cfg4", "cfg5-share", "10k-zdrop", "10k-N", "10k-generic", "exts", "extf", "extf-w300", "extf-w900", "10k-ssec", "10k-ssec-n4096", "10k-ssec-approx", "10k-ssec-cigar"]
 # pairs of each workload's last timed batch that are compared with the oracle outside the clock (the MT pair costs ~1 s per pair on the host)
 PARITY_PAIRS = {"cfg4": 16, "cfg4-so": 4, "cfg5": 16, "cfg5-share": 16}
 # N > 1: the configurations BASELINE.json quotes for several GPUs at their per-GPU share (config 4: 4 096 replicas / 8)

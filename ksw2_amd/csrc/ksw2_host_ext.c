@@ -330,14 +330,16 @@ void ksw_exts2_sse2(void *km, int qlen, const uint8_t *query, int tlen, const ui
 #define EXTF_LDS_T0 1024
 #define EXTF_LDS_T1 4096
 #define EXTF_LDS_T2 21504          /* 3 x 21504 bytes = 63 KiB of LDS for one wavefront */
-#define EXTFB_SPAN 160              /* = K2A_EXTFB_SPAN (ksw2_lane_extfb.h) */
+#define EXTFB_SPAN 160              /* = K2A_EXTFB_SPAN(16 / 32 / 64) (ksw2_lane_extfb.h) */
+#define EXTFB_SPAN32 416
+#define EXTFB_SPAN64 928
 
 ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n, const ksw2amd_fpair_t *pairs)
 {
 	ksw2amd_plan_t *p;
 	int i, c, span, nlane = 0, use_lane, ngt = 0;
 	size_t off = 0;
-	uint32_t fill[8];
+	uint32_t fill[10];
 	void *up;
 	sort_t *srt = 0;
 	gather_ent_t *gt = 0;
@@ -392,6 +394,9 @@ ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n
 			const char *gv = ENV(EXTF_GRP);
 			const int forced = ENV(EXTF_LDS) || ENV(EXTF_WIN) || ENV(EXTF_HBM);
 			if (span <= EXTFB_SPAN && (gv && *gv ? atoi(gv) != 0 : !forced)) c = 7;
+			/* ... two / one extension per wavefront for wider bands (G = 32 / 64 lanes each), in front of the register windows and the
+			 * LDS forms (KSW2AMD_EXTF_GRP=1: only the four-per-wavefront form) */
+			else if (span <= EXTFB_SPAN64 && (gv && *gv ? atoi(gv) >= 2 : !forced)) c = span <= EXTFB_SPAN32 ? 8 : 9;
 		}
 		p->cells += band_cells(a->qlen, a->tlen, d->w);
 		if (use_lane) { p->h_cls[i] = 6; ++p->f_count[6]; ++nlane; continue; }          /* sequences and state: grouped below */
@@ -401,7 +406,7 @@ ksw2amd_plan_t *ksw2amd_extf_plan_create(int8_t mch, int8_t mis, int8_t e, int n
 		off = align_up(off, 4); d->toff = (uint32_t)off; off += (size_t)a->tlen;
 		if (off > 0xfff00000u) { fail(KSW2AMD_E_PARAM, "extf: more than 4 GiB of sequence in one plan%s", 0); goto err; }
 	}
-	for (c = 0, i = 0; c < 8; ++c) { p->f_first[c] = i; fill[c] = (uint32_t)i; i += p->f_count[c]; }
+	for (c = 0, i = 0; c < 10; ++c) { p->f_first[c] = i; fill[c] = (uint32_t)i; i += p->f_count[c]; }
 	if (nlane) {
 		/* groups of 64 pairs of similar shape (sorted by target, query, band); per group: target codes and the reversed query
 		 * interleaved by lane in the sequence arena, three state arrays of `rows` dwords per lane in the scratch block */
@@ -517,7 +522,7 @@ int extf_plan_run(ksw2amd_plan_t *p, void *stream)
 	if (p->ntasks == 0) return KSW2AMD_OK;
 	if (k2a_shim_event_record(p->ev[0], stream)) goto err;
 	if (p->f_count[6] && k2a_shim_memset(p->d_tb, 0, p->f_state_bytes, stream)) goto err;     /* the reference's zeroed arrays (ksw2_extf2_sse.c:25) */
-	for (c = 7; c >= 0; --c)
+	for (c = 9; c >= 0; --c)
 		if (p->f_count[c] && k2a_shim_launch_extf(c, &p->f_par, p->d_pairs, p->d_order + p->f_first[c], p->f_count[c], p->d_seq, p->d_tb, p->d_res, stream))
 			goto err;
 	if (k2a_shim_event_record(p->ev[1], stream) || k2a_shim_event_record(p->ev[2], stream)) goto err;
@@ -797,8 +802,9 @@ int ksw2amd_extf_batch(void *km, int8_t mch, int8_t mis, int8_t e, int n, const 
 			const int wq = pairs[0].w < 0 ? imax(pairs[0].qlen, pairs[0].tlen) : pairs[0].w;
 			const int span0 = imin(imin(pairs[0].qlen, pairs[0].tlen), wq < 0x7ffffff0 ? wq + 1 : wq);
 			const char *gv = ENV(EXTF_GRP);
-			const int grp = uniform && span0 <= EXTFB_SPAN && !(gv && *gv && atoi(gv) == 0) && !(ENV(EXTF_LDS) || ENV(EXTF_WIN) || ENV(EXTF_HBM));
-			nchunks = wave_chunks(n, workers, uniform, grp ? 4 : 1, &chunk_pairs);
+			const int grp = uniform && !(gv && *gv && atoi(gv) == 0) && !(ENV(EXTF_LDS) || ENV(EXTF_WIN) || ENV(EXTF_HBM));
+			const int wide = !(gv && *gv && atoi(gv) == 1);
+			nchunks = wave_chunks(n, workers, uniform, !grp ? 1 : span0 <= EXTFB_SPAN ? 4 : (wide && span0 <= EXTFB_SPAN32) ? 2 : 1, &chunk_pairs);
 		}
 		if (cost && nchunks >= 2) {
 			extf_ctx_t ctx;

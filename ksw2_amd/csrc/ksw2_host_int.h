@@ -183,7 +183,7 @@ struct ksw2amd_plan_s {
 	int splice, s_first[3][2][3], s_count[3][2][3];   /* [mode][matrix variant][window class: 8 slots, 16 slots, state in HBM] */
 	K2aSplice s_par[2];
 	/* gap-linear X-drop plans (ksw2amd_extf_plan_create, splice == 2): tasks grouped by where the state arrays live */
-	int f_first[8], f_count[8];          /* [6]: one extension per lane, groups of 64 with interleaved sequences (ksw2_lane_extf.h); [7]: four per wavefront (ksw2_lane_extfb.h) */
+	int f_first[10], f_count[10];        /* [6]: one extension per lane, groups of 64 with interleaved sequences (ksw2_lane_extf.h); [7..9]: four / two / one per wavefront in registers (ksw2_lane_extfb.h) */
 	size_t f_state_bytes;                /* that class: zeroed state rows at the start of d_tb, re-zeroed by every run */
 	K2aExtf f_par;
 	/* SSE-compatible plans (ksw2amd_sse_plan_create, splice == 3): tasks grouped by kernel mode in s_first / s_count[mode][0][0] */

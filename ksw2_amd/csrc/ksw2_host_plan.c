@@ -1665,9 +1665,9 @@ int ksw2amd_plan_describe(const ksw2amd_plan_t *p, char *buf, int cap)
 	if (!p || !buf || cap <= 0) return 0;
 	buf[0] = 0;
 	if (p->splice == 2 && !p->reject_all) {          /* ksw_extf2_sse plans: one line per kernel class in use */
-		static const char *const fkind[8] = { "extf-lds", "extf-lds", "extf-lds", "extf-hbm", "extf-win4", "extf-win8", "extf-lane", "extf-grp" };
+		static const char *const fkind[10] = { "extf-lds", "extf-lds", "extf-lds", "extf-hbm", "extf-win4", "extf-win8", "extf-lane", "extf-grp", "extf-grp32", "extf-grp64" };
 		int nl = 0;
-		for (c = 0; c < 8 && len < cap - 1; ++c)
+		for (c = 0; c < 10 && len < cap - 1; ++c)
 			if (p->f_count[c]) {
 				len += snprintf(buf + len, (size_t)(cap - len), "kernel=%s form=%s ring=%d tasks=%d\n", fkind[c], c == 6 && p->f_par.ring ? "ldsring" : c == 6 ? "hbm" : "-",
 				                c == 6 ? p->f_par.ring : 0, p->f_count[c]);

@@ -1,6 +1,6 @@
 /*
- * ksw2_lane_extfb.h -- the gap-linear X-drop extension (ksw_extf2_sse, ksw2_extf2_sse.c:11-98; ksw2_lane_extf.h) for NARROW bands:
- * four extensions per wavefront, 16 lanes each, every lane one 16-position block of the reference's U / V / S byte arrays in
+ * ksw2_lane_extfb.h -- the gap-linear X-drop extension (ksw_extf2_sse, ksw2_extf2_sse.c:11-98; ksw2_lane_extf.h) in registers:
+ * four, two or one extensions per wavefront, G = 16 / 32 / 64 lanes each (bands up to 160 / 416 / 928 positions), every lane one 16-position block of the reference's U / V / S byte arrays in
  * registers (the number format and the block helpers of ksw2_lane_ssecb.h: a byte b is the 16-bit number b << 8, two positions per
  * register, so the packed 16-bit instructions wrap and compare exactly like the reference's byte instructions).
  *
@@ -10,10 +10,10 @@
  * (16 lanes redundantly) and serves four extensions per instruction; the one-extension-per-lane form (k2a_extf_lane_diag) goes further
  * but needs 64 extensions per wavefront, i.e. batches of 10^5 extensions to fill the device, this one 4.
  *
- * A lane's 16 lanes form a ring of 16 blocks (256 positions): the blocks from the one below the first updated block (the carry
+ * An extension's G lanes form a ring of G blocks (16 G positions): the blocks from the one below the first updated block (the carry
  * into it, the followed cell) to the one the score refresh reaches must be different lanes, and a lane that takes its next block
  * must have been fed that block's query codes for 16 anti-diagonals before the block is first refreshed: bands of at most
- * K2A_EXTFB_SPAN positions.  A lane takes its next block (16 blocks up) as soon as its block has left that range; the block's target
+ * K2A_EXTFB_SPAN(G) positions.  A lane takes its next block (G blocks up) as soon as its block has left that range; the block's target
  * codes were asked for on every anti-diagonal before (an unconditional load: ksw2_lane_pk.h, k2a_load_early).
  */
 #ifndef KSW2_LANE_EXTFB_H_
@@ -22,9 +22,10 @@
 #include "ksw2_lane_extf.h"
 #include "ksw2_lane_ssecb.h"
 
-#define K2A_EXTFB_SPAN 160        /* blocks in use <= span / 16 + 4 <= 14 of the ring's 16 */
+#define K2A_EXTFB_SPAN(G) (((G) - 6) * 16)      /* G lanes per extension: blocks in use <= span / 16 + 4 <= G - 2 of the ring's G (160, 416, 928) */
 
 /* one lane of a group of 16: its extension's parameters (the same in the 16 lanes), its block, the followed cell */
+template<int G>
 struct K2aExtfBlk {
 	int qlen, tlen, w, xdrop, tpad, nr;
 	const uint8_t *qa, *ta;
@@ -64,7 +65,7 @@ struct K2aExtfBlk {
 		U = V = QW = zero();
 		const uint32_t s0 = k2a_sb_c(2 * par.e);
 		S = k2a_blk{ s0, s0, s0, s0, s0, s0, s0, s0 };
-		ask_target(gl); take_target(gl); ask_target(gl + 16);
+		ask_target(gl); take_target(gl); ask_target(gl + G);
 		qn = qbyte(0);
 		k2a_extf_book_reset(bk);
 		prev_lo = prev_hi = -1; rdone = 0; done = !live;
@@ -84,7 +85,7 @@ struct K2aExtfBlk {
 		for (int i = 7; i > 0; --i) QW[i] = k2a_sb_shift(QW[i], QW[i - 1]);
 		QW[0] = (QW[0] << 16) | ((j >= 0 && j < qlen) ? qn : 0u);
 		if (blk < (d.blo >> 4) - 1) {
-			blk += 16;
+			blk += G;
 			take_target(blk);
 			U = V = zero();
 			const uint32_t s0 = k2a_sb_c(2 * par.e);
@@ -93,7 +94,7 @@ struct K2aExtfBlk {
 		if (d.bhi >= r && blk == (r >> 4)) k2a_sb_set(U, r & 15, 0);
 		return true;
 	}
-	K2A_FN void ask(int r) { qn = qbyte(r + 1); ask_target(blk + 16); }      /* every lane, every anti-diagonal: unconditional loads */
+	K2A_FN void ask(int r) { qn = qbyte(r + 1); ask_target(blk + G); }      /* every lane, every anti-diagonal: unconditional loads */
 
 	/* phase B: pv = V[7] of the lane below in the ring (previous anti-diagonal; position 16 * blk - 1 in the high half).  S refresh
 	 * (:48-61), the block's cells (:64-78) if it lies in [blo, bhi]; returns the followed cell's two bytes as this lane holds them */
@@ -127,8 +128,8 @@ struct K2aExtfBlk {
 		}
 		vsel = k2a_sb_get(V, bk.follow & 15); usel = k2a_sb_get(U, (bk.follow + 1) & 15);
 	}
-	K2A_FN int vlane() const { return (bk.follow >> 4) & 15; }        /* the lanes of the group that hold V[follow] / U[follow + 1] */
-	K2A_FN int ulane() const { return ((bk.follow + 1) >> 4) & 15; }
+	K2A_FN int vlane() const { return (bk.follow >> 4) & (G - 1); }        /* the lanes of the group that hold V[follow] / U[follow + 1] */
+	K2A_FN int ulane() const { return ((bk.follow + 1) >> 4) & (G - 1); }
 
 	/* phase C: the followed cell (:80-92) */
 	K2A_FN void finish_diag(const K2aExtf &par, int r, uint32_t vf, uint32_t un)

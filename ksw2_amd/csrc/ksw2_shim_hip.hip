@@ -1938,6 +1938,47 @@ static bool k2a_use_ldsrows(int waves)
 static const trace_fn g_trace_pk[2][K2A_NPKCFG] = { TRACE_PK_ROW(false), TRACE_PK_ROW(true) };      /* [dual][cfg] */
 
 
+/* 64 / G extensions per wavefront, G = 16 / 32 / 64 lanes each, one 16-position block of U / V / S per lane (ksw2_lane_extfb.h).  What
+ * is uniform per extension is computed by its G lanes; a lane's left neighbour is one DPP rotate inside its group (inside a row of
+ * 16; of the whole wavefront for G = 64; for G = 32 the whole-wavefront rotate with the two wrap-around lanes patched), the followed
+ * cell's two bytes come from their owner lanes through ds_bpermute_b32. */
+template<int G>
+__device__ __forceinline__ uint32_t k2a_extf_grp_rot(uint32_t v, int lane)
+{
+	if (G == 16) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121 /* row_ror:1 */, 0xf, 0xf, false);
+	const uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C /* wave_ror:1 */, 0xf, 0xf, false);
+	if (G == 64) return r;
+	const uint32_t v31 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31), v63 = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+	return lane == 0 ? v31 : lane == 32 ? v63 : r;
+}
+template<int G>
+__global__ void __launch_bounds__(64 * K2A_WPB)
+k2a_extf_grp_kernel(const K2aExtf par, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
+                    const uint8_t *__restrict__ seq, K2aResult *__restrict__ res)
+{
+	constexpr int NG = 64 / G;
+	const int lane = threadIdx.x & 63, wave = k2a_wave_id<false>(), gl = lane & (G - 1);
+	const int task0 = (blockIdx.x * K2A_WPB + wave) * NG, task = task0 + lane / G;
+	if (task0 >= ntasks) return;
+	const bool live = task < ntasks;
+	const uint32_t pi = order[live ? task : ntasks - 1];
+	const K2aPair pr = pairs[pi];
+	K2aExtfBlk<G> B;
+	B.start(par, pr, seq, gl, live);
+	for (int r = 0; ; ++r) {
+		const bool on = B.begin(par, r);
+		if (__builtin_amdgcn_ballot_w64(on) == 0) break;
+		B.ask(r);
+		const uint32_t pv = k2a_extf_grp_rot<G>(B.V[7], lane);
+		uint32_t vsel, usel;
+		B.update(par, pv, vsel, usel);
+		const uint32_t vf = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane & ~(G - 1)) | B.vlane()) << 2, (int)vsel);
+		const uint32_t un = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane & ~(G - 1)) | B.ulane()) << 2, (int)usel);
+		B.finish_diag(par, r, vf, un);
+	}
+	if (live && gl == 0) k2a_extf_finish(B.bk, B.rdone, B.nr, &res[pi]);
+}
+
 extern "C" {
 
 const char *k2a_shim_backend(void) { return "hip:gfx950"; }
@@ -2313,47 +2354,21 @@ int k2a_shim_launch_ssec_trace(const K2aPair *pairs, const uint32_t *order, int 
 	return 0;
 }
 
-/* narrow bands: four extensions per wavefront, 16 lanes each, one 16-position block of U / V / S per lane (ksw2_lane_extfb.h).  What
- * is uniform per extension is computed by its 16 lanes; a lane's left neighbour is one DPP rotate inside its row of 16, the followed
- * cell's two bytes come from their owner lanes through ds_bpermute_b32. */
-__global__ void __launch_bounds__(64 * K2A_WPB)
-k2a_extf_grp_kernel(const K2aExtf par, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
-                    const uint8_t *__restrict__ seq, K2aResult *__restrict__ res)
-{
-	const int lane = threadIdx.x & 63, wave = k2a_wave_id<false>(), gl = lane & 15;
-	const int task0 = (blockIdx.x * K2A_WPB + wave) * 4, task = task0 + (lane >> 4);
-	if (task0 >= ntasks) return;
-	const bool live = task < ntasks;
-	const uint32_t pi = order[live ? task : ntasks - 1];
-	const K2aPair pr = pairs[pi];
-	K2aExtfBlk B;
-	B.start(par, pr, seq, gl, live);
-	for (int r = 0; ; ++r) {
-		const bool on = B.begin(par, r);
-		if (__builtin_amdgcn_ballot_w64(on) == 0) break;
-		B.ask(r);
-		const uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)B.V[7], 0x121 /* row_ror:1 */, 0xf, 0xf, false);
-		uint32_t vsel, usel;
-		B.update(par, pv, vsel, usel);
-		const uint32_t vf = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane & 48) | B.vlane()) << 2, (int)vsel);
-		const uint32_t un = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane & 48) | B.ulane()) << 2, (int)usel);
-		B.finish_diag(par, r, vf, un);
-	}
-	if (live && gl == 0) k2a_extf_finish(B.bk, B.rdone, B.nr, &res[pi]);
-}
-
 /* cls 0..2: state in LDS (targets up to 1024 / 4096 / 21504 residues), 3: state in `scratch` (3 x padded length bytes at
  * pairs[i].tb_off), 4 / 5: state in registers (bands up to K2A_EXTF_WIN_SPAN(4 / 8) positions), 6: one extension per lane,
- * 7: four extensions per wavefront (bands up to K2A_EXTFB_SPAN positions) */
+ * 7 / 8 / 9: state in registers, four / two / one extensions per wavefront (bands up to K2A_EXTFB_SPAN(16 / 32 / 64) positions) */
 int k2a_shim_launch_extf(int cls, const K2aExtf *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
                          uint8_t *scratch, K2aResult *res, void *stream)
 {
 	static const int lds_bytes[4] = { 3 * 1024, 3 * 4096, 3 * 21504, 0 };
 	if (ntasks <= 0) return 0;
-	if (cls < 0 || cls > 7) { snprintf(g_err, sizeof(g_err), "bad kernel class"); return -1; }
-	if (cls == 7) {                                   /* narrow bands: four extensions per wavefront */
-		const int waves = (ntasks + 3) / 4;
-		hipLaunchKernelGGL(k2a_extf_grp_kernel, dim3((waves + K2A_WPB - 1) / K2A_WPB), dim3(64 * K2A_WPB), 0, (hipStream_t)stream, *par, pairs, order, ntasks, seq, res);
+	if (cls < 0 || cls > 9) { snprintf(g_err, sizeof(g_err), "bad kernel class"); return -1; }
+	if (cls >= 7) {                                   /* state in registers: four / two / one extensions per wavefront */
+		const int ng = cls == 7 ? 4 : cls == 8 ? 2 : 1, waves = (ntasks + ng - 1) / ng;
+		const dim3 grid((waves + K2A_WPB - 1) / K2A_WPB), block(64 * K2A_WPB);
+		if (cls == 7) hipLaunchKernelGGL(k2a_extf_grp_kernel<16>, grid, block, 0, (hipStream_t)stream, *par, pairs, order, ntasks, seq, res);
+		else if (cls == 8) hipLaunchKernelGGL(k2a_extf_grp_kernel<32>, grid, block, 0, (hipStream_t)stream, *par, pairs, order, ntasks, seq, res);
+		else hipLaunchKernelGGL(k2a_extf_grp_kernel<64>, grid, block, 0, (hipStream_t)stream, *par, pairs, order, ntasks, seq, res);
 	} else if (cls == 6) {                                   /* one extension per lane: 64 tasks per wavefront */
 		const int waves = (ntasks + 63) / 64;
 		if (par->ring > 0) {

@@ -1257,36 +1257,42 @@ static void sim_extf_lane(const K2aExtf par, const K2aPair *pairs, const uint32_
 	}
 }
 
+extern "C++" {
 /* mirrors k2a_extf_grp_kernel: wavefronts of four extensions, 16 lanes each; the phases of an anti-diagonal in the kernel's order */
+template<int G>
 static void sim_extf_grp(const K2aExtf par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, K2aResult *res)
 {
-	for (int task0 = 0; task0 < ntasks; task0 += 4) {
-		std::vector<K2aExtfBlk> Bv(64);
+	for (int task0 = 0; task0 < ntasks; task0 += 64 / G) {
+		std::vector<K2aExtfBlk<G>> Bv(64);
 		uint32_t pis[64];
 		bool live[64];
 		for (int l = 0; l < 64; ++l) {
-			const int task = task0 + (l >> 4);
+			const int task = task0 + l / G;
 			live[l] = task < ntasks;
 			pis[l] = order[live[l] ? task : ntasks - 1];
-			Bv[l].start(par, pairs[pis[l]], seq, l & 15, live[l]);
+			Bv[l].start(par, pairs[pis[l]], seq, l & (G - 1), live[l]);
 		}
 		for (int r = 0; ; ++r) {
 			bool any = false;
 			for (int l = 0; l < 64; ++l) any |= Bv[l].begin(par, r);
 			if (!any) break;
 			uint32_t pv[64], vsel[64], usel[64];
-			for (int l = 0; l < 64; ++l) { Bv[l].ask(r); pv[l] = Bv[(l & 48) | ((l + 15) & 15)].V[7]; }
+			for (int l = 0; l < 64; ++l) { Bv[l].ask(r); pv[l] = Bv[(l & ~(G - 1)) | ((l + G - 1) & (G - 1))].V[7]; }
 			for (int l = 0; l < 64; ++l) Bv[l].update(par, pv[l], vsel[l], usel[l]);
-			for (int l = 0; l < 64; ++l) Bv[l].finish_diag(par, r, vsel[(l & 48) | Bv[l].vlane()], usel[(l & 48) | Bv[l].ulane()]);
+			for (int l = 0; l < 64; ++l) Bv[l].finish_diag(par, r, vsel[(l & ~(G - 1)) | Bv[l].vlane()], usel[(l & ~(G - 1)) | Bv[l].ulane()]);
 		}
-		for (int l = 0; l < 64; l += 16) if (live[l]) k2a_extf_finish(Bv[l].bk, Bv[l].rdone, Bv[l].nr, &res[pis[l]]);
+		for (int l = 0; l < 64; l += G) if (live[l]) k2a_extf_finish(Bv[l].bk, Bv[l].rdone, Bv[l].nr, &res[pis[l]]);
 	}
+}
+
 }
 
 int k2a_shim_launch_extf(int cls, const K2aExtf *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
                          uint8_t *scratch, K2aResult *res, void *)
 {
-	if (ntasks > 0 && cls == 7) sim_extf_grp(*par, pairs, order, ntasks, seq, res);
+	if (ntasks > 0 && cls == 7) sim_extf_grp<16>(*par, pairs, order, ntasks, seq, res);
+	else if (ntasks > 0 && cls == 8) sim_extf_grp<32>(*par, pairs, order, ntasks, seq, res);
+	else if (ntasks > 0 && cls == 9) sim_extf_grp<64>(*par, pairs, order, ntasks, seq, res);
 	else if (ntasks > 0 && cls == 6) sim_extf_lane(*par, pairs, order, ntasks, seq, scratch, res);
 	else if (ntasks > 0 && cls == 4) sim_extf_win<4>(*par, pairs, order, ntasks, seq, res);
 	else if (ntasks > 0 && cls == 5) sim_extf_win<8>(*par, pairs, order, ntasks, seq, res);

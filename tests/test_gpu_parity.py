@@ -1011,6 +1011,24 @@ def test_linear_xdrop_group_form(lib, monkeypatch):
         assert not diff(a, b, gu.FIELDS)
 
 
+def test_linear_xdrop_wide_group_forms(lib, monkeypatch):
+    """k2a_extf_grp_kernel<32> / <64> on the GPU (tests/test_sim_parity._check_extf_wide_group_forms), and 1 027 extensions of 3 000 x 3 000
+    at bands 300 and 700 -- a last wavefront with an empty second group -- against the register-window / LDS kernels."""
+    from tests.test_sim_parity import _check_extf_wide_group_forms
+    _check_extf_wide_group_forms(lib, monkeypatch, rounds=30, maxlen=7000)
+    from oracle.gen_golden_extf import noisy_pair
+    rng = np.random.Generator(np.random.PCG64(6))
+    base = [noisy_pair(rng, 3000, k % 3) for k in range(64)]
+    qs, ts = [base[k % 64][0] for k in range(1027)], [base[k % 64][1] for k in range(1027)]
+    for w in (300, 700):
+        out = []
+        for env in ("", "1"):
+            monkeypatch.setenv("KSW2AMD_EXTF_GRP", env)
+            out.append(lib.extf_batch(qs, ts, 2, -4, 2, w=w, xdrop=[-1 if k % 2 else 400 for k in range(1027)]))
+        for a, b in zip(*out):
+            assert not diff(a, b, gu.FIELDS)
+
+
 def test_sse_compatible_register_form(lib, monkeypatch):
     """k2a_ssec_blk_kernel on the GPU (score-only SSE-compatible tasks, state in registers, H in an LDS ring): bands of 1 to 960
     positions, targets several rings long, both gap models, exact and approximate maxima, Z-drop -- against the oracle and against

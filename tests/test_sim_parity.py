@@ -571,8 +571,49 @@ def _check_extf_group_form(lib, monkeypatch, rounds, maxlen):
     monkeypatch.delenv("KSW2AMD_EXTF_GRP")
 
 
+def _check_extf_wide_group_forms(lib, monkeypatch, rounds, maxlen):
+    """The same kernel with 32 / 64 lanes per extension (two / one per wavefront; bands of 161..416 / 417..928 positions): bands on
+    both sides of each limit, targets several rings long (a lane takes its next block every 512 / 1 024 positions), X-drop, task
+    counts that leave the second group of a wavefront empty -- against the oracle, with the plan's description asserted for the
+    switch's four settings (unset / 2: every band that fits; 1: the four-per-wavefront form only; 0: none)."""
+    from oracle.gen_golden_extf import noisy_pair
+    rng = np.random.Generator(np.random.PCG64(78))
+    seen = {"extf-grp": 0, "extf-grp32": 0, "extf-grp64": 0}
+    for it in range(rounds):
+        n = int(rng.choice([1, 2, 3, 5]))
+        qs, ts = zip(*[noisy_pair(rng, int(rng.integers(maxlen // 3, maxlen)), (it + k) % 3) for k in range(n)])
+        w = [int(x) for x in rng.choice([100, 159, 160, 161, 250, 414, 415, 416, 500, 700, 926, 927, 928, 1200, -1], size=n)]
+        xd = [int(x) for x in rng.choice([-1, 100, 600], size=n)]
+        mch, mis, e = [(2, -4, 2), (1, -3, 1), (3, -2, 4)][it % 3]
+        exp = [po.extf2("oracle", qs[k], ts[k], mch, mis, e, w[k], xd[k]) for k in range(n)]
+        span = [min(len(qs[k]), len(ts[k]), (w[k] if w[k] >= 0 else max(len(qs[k]), len(ts[k]))) + 1) for k in range(n)]
+        for env in ("", "2", "1", "0"):
+            monkeypatch.setenv("KSW2AMD_EXTF_GRP", env)
+            p = lib.make_linear_batch(list(qs), list(ts), mch, mis, e, w=w, xdrop=xd).plan()
+            got = {}
+            for d in p.describe():
+                got[d["kernel"]] = got.get(d["kernel"], 0) + d["tasks"]
+            p.close()
+            want = {"extf-grp": sum(1 for x in span if x <= 160) if env != "0" else 0,
+                    "extf-grp32": sum(1 for x in span if 160 < x <= 416) if env in ("", "2") else 0,
+                    "extf-grp64": sum(1 for x in span if 416 < x <= 928) if env in ("", "2") else 0}
+            assert {k: got.get(k, 0) for k in want} == want, (env, got, span)
+            if env == "":
+                for k in want:
+                    seen[k] += want[k]
+            res = lib.extf_batch(list(qs), list(ts), mch, mis, e, w=w, xdrop=xd)
+            for k in range(n):
+                assert not diff(res[k], exp[k], gu.FIELDS), (it, env, k, len(qs[k]), len(ts[k]), w[k], xd[k])
+    monkeypatch.delenv("KSW2AMD_EXTF_GRP")
+    assert seen["extf-grp32"] >= rounds // 3 and seen["extf-grp64"] >= rounds // 3, seen
+
+
 def test_sim_linear_xdrop_group_form(sim, monkeypatch):
     _check_extf_group_form(sim, monkeypatch, rounds=24, maxlen=2500)
+
+
+def test_sim_linear_xdrop_wide_group_forms(sim, monkeypatch):
+    _check_extf_wide_group_forms(sim, monkeypatch, rounds=10, maxlen=3200)
 
 
 @pytest.mark.parametrize("lds", ["0", "1"])

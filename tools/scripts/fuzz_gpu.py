@@ -31,7 +31,7 @@ ENVS = [{}, {"KSW2AMD_SOLO": "1"}, {"KSW2AMD_SOLO": "all"}, {"KSW2AMD_LDSROWS": 
         {"KSW2AMD_STREAM": "1", "KSW2AMD_STREAM_PIECE_KB": "64", "KSW2AMD_SIMDS": "0"}, {"KSW2AMD_STREAM": "1", "KSW2AMD_STREAM_PIECE_KB": "256", "KSW2AMD_DEFER": "1", "KSW2AMD_SIMDS": "0"},
         {"KSW2AMD_STREAM": "0"},
         # round 5: the SSE-compatible score-only tasks and the narrow-band X-drop extensions through their other kernels; two copy lanes
-        {"KSW2AMD_SSEC_BLK": "0"}, {"KSW2AMD_EXTF_GRP": "0"}, {"KSW2AMD_EXTF_GRP": "1", "KSW2AMD_EXTF_LDS": "1"},
+        {"KSW2AMD_SSEC_BLK": "0"}, {"KSW2AMD_EXTF_GRP": "0"}, {"KSW2AMD_EXTF_GRP": "1", "KSW2AMD_EXTF_LDS": "1"}, {"KSW2AMD_EXTF_GRP": "1"}, {"KSW2AMD_EXTF_GRP": "2", "KSW2AMD_EXTF_WIN": "1"},
         {"KSW2AMD_STREAM": "1", "KSW2AMD_STREAM_PIECE_KB": "64", "KSW2AMD_STREAM_LANES": "2", "KSW2AMD_SIMDS": "0"}, {"KSW2AMD_UNIFORM": "1", "KSW2AMD_POOL_MIN": "4", "KSW2AMD_SIMDS": "0"}]
 KEYS = sorted({k for e in ENVS for k in e})
 t0 = time.time()
@@ -99,7 +99,7 @@ while time.time() - t0 < budget:
     elif kind == 2:                                                       # extf2
         n = int(rng.integers(4, 40))
         prs = [noisy_pair(rng, int(rng.integers(1, int(rng.choice([200, 1500, 6000])))), int(rng.integers(7))) for _ in range(n)]
-        w = rng.choice([-1, 0, 3, 16, 33, 100, 146, 147, 158, 159, 160, 300, 402, 403, 900], size=n)
+        w = rng.choice([-1, 0, 3, 16, 33, 100, 146, 147, 158, 159, 160, 300, 402, 403, 414, 415, 416, 700, 900, 926, 927, 928], size=n)
         xd = rng.choice([-1, 10, 60, 500], size=n)
         mch, mis, e = [(1, -2, 1), (2, -4, 2), (4, -6, 3)][int(rng.integers(3))]
         res = lib.extf_batch([p[0] for p in prs], [p[1] for p in prs], mch, mis, e, w=w, xdrop=xd)
