@@ -718,9 +718,9 @@ K2A_FN void k2a_fin_rows_half(const K2aScoring &sc, K2aBook *b, int zdrop, const
 /* Traceback walk for one alignment (half = 0/1) of a packed task: direction bytes in the reference layout at byte
  * 2c + half of the (step, lane) word (K2aWalk layout 2). */
 template<int G, int C, bool DUAL = true, bool MP = false>
-K2A_FN int k2a_trace_pair_pk(const uint8_t *tb, int half, int i, int j, uint32_t *out, int qlen, int tlen, int w)
+K2A_FN int k2a_trace_pair_pk(const uint8_t *tb, int half, int i, int j, uint32_t *out, int qlen, int tlen, int w, uint8_t *win)
 {
-	return k2a_trace_walk<G, C, K2A_PK_NIBBLES(C, DUAL) ? 3 : 2, MP>(tb, half, i, j, out, qlen, tlen, w);
+	return k2a_trace_walk<G, C, K2A_PK_NIBBLES(C, DUAL) ? 3 : 2, MP>(tb, half, i, j, out, qlen, tlen, w, win);
 }
 
 /* merge the lane-local bests of one alignment (half = 0/1) of a lane group: loc[l*5 + {0..4}] = lane l's

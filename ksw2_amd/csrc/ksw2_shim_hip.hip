@@ -26,11 +26,12 @@
  * wavefronts in flight, not many lanes per wavefront.  Walks per wavefront (1..8) so that a launch has about four wavefronts
  * per SIMD: measured on 10 k x 10 k CIGARs, 4096 walks: 8 per wavefront 6.7 ms, 1 per wavefront 5.7 ms; 16384 walks of
  * config 3: 8 -> 1.6 ms, 1 -> 3.3 ms. */
+#define K2A_TRACE_PPW_MAX 8
 static int k2a_trace_ppw(int nwalks)
 {
 	const int target_waves = 4096;
 	int ppw = (nwalks + target_waves - 1) / target_waves;
-	return ppw < 1 ? 1 : ppw > 8 ? 8 : ppw;
+	return ppw < 1 ? 1 : ppw > K2A_TRACE_PPW_MAX ? K2A_TRACE_PPW_MAX : ppw;
 }
 
 static thread_local char g_err[512] = "";
@@ -886,8 +887,9 @@ __global__ void __launch_bounds__(64)
 k2a_trace_kernel(const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
                  const uint8_t *__restrict__ tb, K2aResult *__restrict__ res, uint32_t *__restrict__ cig, int ppw)
 {
-	/* the walk is a chain of dependent, scattered byte loads: a few walks per wavefront on many wavefronts beats
+	/* the walk is a chain of dependent, scattered loads: a few walks per wavefront on many wavefronts beats
 	 * 64 walks whose loads serialise in one texture-address unit */
+	__shared__ K2aUnit16 win[K2A_TRACE_PPW_MAX][K2A_WALK_SLOT / 16];      /* every walk's window of lane-step words (k2a_trace_walk) */
 	if ((int)threadIdx.x >= ppw) return;
 	const int t = blockIdx.x * ppw + threadIdx.x;
 	if (t >= ntasks) return;
@@ -895,7 +897,7 @@ k2a_trace_kernel(const K2aPair *__restrict__ pairs, const uint32_t *__restrict__
 	const K2aPair pr = pairs[pi];
 	const int ti = res[pi].ti, tj = res[pi].tj;
 	int n = 0;
-	if (ti >= 0 && tj >= 0) n = k2a_trace_pair<G, C, DUAL, MP>(tb + pr.tb_off, ti, tj, cig + pr.cig_off, pr.qlen, pr.tlen, pr.w);
+	if (ti >= 0 && tj >= 0) n = k2a_trace_pair<G, C, DUAL, MP>(tb + pr.tb_off, ti, tj, cig + pr.cig_off, pr.qlen, pr.tlen, pr.w, (uint8_t*)win[threadIdx.x]);
 	res[pi].n_cigar = n;
 }
 
@@ -953,6 +955,7 @@ __global__ void __launch_bounds__(64)
 k2a_trace_pk_kernel(const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
                     const uint8_t *__restrict__ tb, K2aResult *__restrict__ res, uint32_t *__restrict__ cig, int ppw)
 {
+	__shared__ K2aUnit16 win[K2A_TRACE_PPW_MAX][K2A_WALK_SLOT / 16];
 	if ((int)threadIdx.x >= ppw) return;
 	const int t = blockIdx.x * ppw + threadIdx.x;
 	if (t >= 2 * ntasks) return;
@@ -962,7 +965,7 @@ k2a_trace_pk_kernel(const K2aPair *__restrict__ pairs, const uint32_t *__restric
 	const K2aPair pr = pairs[pi];
 	const int ti = res[pi].ti, tj = res[pi].tj;
 	int n = 0;
-	if (ti >= 0 && tj >= 0) n = k2a_trace_pair_pk<G, C, DUAL, MP>(tb + pr.tb_off, half, ti, tj, cig + pr.cig_off, pr.qlen, pr.tlen, pr.w);
+	if (ti >= 0 && tj >= 0) n = k2a_trace_pair_pk<G, C, DUAL, MP>(tb + pr.tb_off, half, ti, tj, cig + pr.cig_off, pr.qlen, pr.tlen, pr.w, (uint8_t*)win[threadIdx.x]);
 	res[pi].n_cigar = n;
 }
 

@@ -434,12 +434,13 @@ static void sim_fill_mp(const K2aScoring sc, const K2aPair *pairs, const uint32_
 template<int G, int C, bool DUAL, bool MP>
 static void sim_trace(const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb, K2aResult *res, uint32_t *cig)
 {
+	K2aUnit16 win[K2A_WALK_SLOT / 16];                 /* the walk's window (the kernels: LDS) */
 	for (int t = 0; t < ntasks; ++t) {
 		const uint32_t pi = order[t];
 		const K2aPair pr = pairs[pi];
 		int n = 0;
 		if (res[pi].ti >= 0 && res[pi].tj >= 0)
-			n = k2a_trace_pair<G, C, DUAL, MP>(tb + pr.tb_off, res[pi].ti, res[pi].tj, cig + pr.cig_off, pr.qlen, pr.tlen, pr.w);
+			n = k2a_trace_pair<G, C, DUAL, MP>(tb + pr.tb_off, res[pi].ti, res[pi].tj, cig + pr.cig_off, pr.qlen, pr.tlen, pr.w, (uint8_t*)win);
 		res[pi].n_cigar = n;
 	}
 }
@@ -461,6 +462,7 @@ static const trace_fn g_trace[K2A_NCFG][2] = { TRACE_ROW(16, 8, false), TRACE_RO
 template<int G, int C, bool DUAL, bool MP = false>
 static void sim_trace_pk(const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *tb, K2aResult *res, uint32_t *cig)
 {
+	K2aUnit16 win[K2A_WALK_SLOT / 16];
 	for (int t = 0; t < 2 * ntasks; ++t) {
 		const int half = t & 1;
 		const uint32_t piA = order2[t & ~1], pi = order2[t];
@@ -468,7 +470,7 @@ static void sim_trace_pk(const K2aPair *pairs, const uint32_t *order2, int ntask
 		const K2aPair pr = pairs[pi];
 		int n = 0;
 		if (res[pi].ti >= 0 && res[pi].tj >= 0)
-			n = k2a_trace_pair_pk<G, C, DUAL, MP>(tb + pr.tb_off, half, res[pi].ti, res[pi].tj, cig + pr.cig_off, pr.qlen, pr.tlen, pr.w);
+			n = k2a_trace_pair_pk<G, C, DUAL, MP>(tb + pr.tb_off, half, res[pi].ti, res[pi].tj, cig + pr.cig_off, pr.qlen, pr.tlen, pr.w, (uint8_t*)win);
 		res[pi].n_cigar = n;
 	}
 }
