@@ -426,7 +426,7 @@ def roofline_of(job, res, workload_key):
     seq_bytes = int(job.qlen[:res["n"]].sum() + job.tlen[:res["n"]].sum())
     alg_bytes = seq_bytes + 56 * res["n"] + (0 if job.score_only else res["cells"] // (1 if job.kind == "extd" else 2))
     # the PMC passes under profiles/ are of the plain workloads: a different kernel runs with --approx / --sse-compat or a resized batch
-    plain = not os.environ.get("KSW2AMD_NO_PKMP") and not getattr(job, "sse", False) and not (job.wl["flag"] & 0x08 and not WORKLOADS[workload_key]["flag"] & 0x08) and res["n"] == (WORKLOADS[workload_key].get("resident_n") or WORKLOADS[workload_key]["n"])
+    plain = not os.environ.get("KSW2AMD_NO_PKMP") and not (getattr(job, "sse", False) and not WORKLOADS[workload_key].get("sse")) and not (job.wl["flag"] & 0x08 and not WORKLOADS[workload_key]["flag"] & 0x08) and res["n"] == (WORKLOADS[workload_key].get("resident_n") or WORKLOADS[workload_key]["n"])
     traffic, src = recorded_traffic(workload_key) if plain else (None, None)
     defer = any(c.get("form") == "defer" for c in res.get("kernels", []))
     out = _roofline_dict(job, res, ops, kern_s, achieved, alg_bytes, traffic, src)
