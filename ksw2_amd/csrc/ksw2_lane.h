@@ -430,14 +430,6 @@ struct K2aWalk {
 		}
 	}
 
-	/* raw byte holding the code of the cell k diagonal moves ahead of the current one inside this strip (valid for k <= c) */
-	K2A_FN uint32_t raw(int k) const
-	{
-		const uint8_t *pk = p - (size_t)k * WB;
-		const int ck = c - k;
-		/* LAYOUT 3 (packed single-gap, 4-bit flags): word ck / 4 of the lane-step, 16-bit half `half`, rows 4g..4g+3 from the lowest nibble up */
-		return LAYOUT == 3 ? pk[4 * (ck >> 2) + 2 * half + ((ck & 3) >> 1)] : LAYOUT == 2 ? pk[2 * ck + half] : LAYOUT == 1 ? pk[ck] : pk[ck >> 1];
-	}
 	/* direction code in the reference's byte layout (ksw2.h:125-128) from that byte; ck = row of the cell in the strip.  The packed
 	 * kernels (LAYOUT 2 / 3) store direction FLAGS -- bit 0 E wins, 1 F wins [, 2 E~ wins, 3 F~ wins], then the extension flags; the
 	 * winner is the highest win flag (ksw2_lane_pk.h: k2a_dir_flags) */
@@ -449,7 +441,9 @@ struct K2aWalk {
 		if (LAYOUT == 3) return ((r4 & 2u) ? 2u : (r4 & 1u)) | ((r4 & 4u) << 1) | ((r4 & 8u) << 1);
 		return (r4 & 3u) | ((r4 & 4u) << 1) | ((r4 & 8u) << 1);
 	}
-	/* byte of row ck inside a lane-step word; "the winner is not the diagonal" from that byte (decode(b, ck) & 7 != 0) */
+	/* byte of row ck inside a lane-step word (LAYOUT 3 -- packed single gap, 4-bit flags: word ck / 4 of the lane-step, 16-bit half
+	 * `half`, rows 4g .. 4g + 3 from the lowest nibble up; LAYOUT 2: byte 2 ck + half; LAYOUT 1: byte ck; LAYOUT 0: nibble ck);
+	 * "the winner is not the diagonal" from that byte (decode(b, ck) & 7 != 0) */
 	K2A_FN int off(int ck) const { return LAYOUT == 3 ? 4 * (ck >> 2) + 2 * half + ((ck & 3) >> 1) : LAYOUT == 2 ? 2 * ck + half : LAYOUT == 1 ? ck : ck >> 1; }
 	K2A_FN uint32_t gap(uint32_t b, int ck) const
 	{
