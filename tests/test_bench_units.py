@@ -91,3 +91,14 @@ def test_bench_two_ranks_plumbing(sim, tmp_path):
     assert [x["rank"] for x in pr] == [0, 1] and all(x["cells_per_step"] > 0 for x in pr)
     assert d["config"]["rank0_scatter_gather"]["records_checked"] == 48
     assert {"bound", "achieved", "peak", "frac", "traffic"} <= set(d["roofline"])
+
+
+def test_recorded_traffic_names_the_latest_profile_of_the_same_workload():
+    """`roofline.traffic` replays the PMC summary under profiles/ whose name sorts last for exactly this workload: records of
+    attempts that were not kept (another kernel) carry another workload tag and must not be picked up."""
+    for wl, kern in (("10k-cigar", "k2a_fill_pk_kernel"), ("exts", "k2a_exts_kernel"), ("extf-w900", "k2a_extf_grp_kernel"), ("10k-ssec", "k2a_ssec_blk_kernel")):
+        traffic, src = bench.recorded_traffic(wl)
+        assert traffic and src and src.endswith("_%s_pmc.json" % wl), (wl, src)
+        import json
+        assert kern in json.load(open(os.path.join(bench.ROOT, src)))["derived"]["dominant_kernel"], (wl, src)
+    assert bench.recorded_traffic("no-such-workload") == (None, None)
