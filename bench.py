@@ -74,6 +74,9 @@ WORKLOADS = {
     "10k-zdrop": dict(idx=6, n=49152, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=SO, sub=0.05, ind=0.06, tail_frac=0.25, tail_pairs=0.20),
     # ... and where 1 % of the pairs hold a wildcard base: those leave the packed kernels (they score match / mismatch only)
     "10k-N": dict(idx=6, n=49152, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=SO, sub=0.05, ind=0.06, wild_pairs=0.01),
+    # ... and where 1 % of the TARGETS carry a run of 1-50 wildcard bases (reference genomes hold N runs; ksw2_extz2_sse.c:125-140 scores them at the
+    # full SIMD rate): what the packed kernels' target-wildcard rule costs (rules 3 and 9)
+    "10k-tN": dict(idx=6, n=49152, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=SO, sub=0.05, ind=0.06, twild_pairs=0.01),
     # ... and under a scoring matrix without match / mismatch structure (KSW_EZ_GENERIC_SC; transitions -2, transversions -4): the reference
     # takes any matrix at its full rate (ksw2_extz2_sse.c:142-143), and since round 5 so do the packed kernels (column profiles)
     "10k-generic": dict(idx=6, n=49152, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=SO | ksw2_amd.KSW_EZ_GENERIC_SC, sub=0.05, ind=0.06, tstv=True),
@@ -86,7 +89,7 @@ WORKLOADS = {
     # ... and with the CIGAR (the direction bytes of the reference's SSE kernel, its own walk)
     "10k-ssec-cigar": dict(idx=6, n=1024, qlen=10000, tlen=10000, w=500, zdrop=400, dual=False, flag=0, sub=0.05, ind=0.06, sse=True),
 }
-ALSO_DEFAULT = ["10k-n1024", "10k-cigar", "cfg2", "cfg3", "cfg5", "cfg4", "cfg5-share", "10k-zdrop", "10k-N", "10k-generic", "exts", "extf", "extf-w300", "extf-w900", "10k-ssec", "10k-ssec-n4096", "10k-ssec-approx", "10k-ssec-cigar"]
+ALSO_DEFAULT = ["10k-n1024", "10k-cigar", "cfg2", "cfg3", "cfg5", "cfg4", "cfg5-share", "10k-zdrop", "10k-N", "10k-tN", "10k-generic", "exts", "extf", "extf-w300", "extf-w900", "10k-ssec", "10k-ssec-n4096", "10k-ssec-approx", "10k-ssec-cigar"]
 # pairs of each workload's last timed batch that are compared with the oracle outside the clock (the MT pair costs ~1 s per pair on the host)
 PARITY_PAIRS = {"cfg4": 16, "cfg4-so": 4, "cfg5": 16, "cfg5-share": 16}
 # N > 1: the configurations BASELINE.json quotes for several GPUs at their per-GPU share (config 4: 4 096 replicas / 8)
@@ -130,6 +133,13 @@ def make_batch(wl, rank, n):
         step = max(1, int(round(1.0 / wl["wild_pairs"])))
         for i in range(step // 2, n, step):
             q[i, int(rng.integers(wl["qlen"]))] = 4
+    if wl.get("twild_pairs"):                            # a run of 1-50 wildcard bases somewhere in the target of every 1 / twild_pairs-th pair
+        rng = np.random.Generator(np.random.PCG64(wl["idx"] * 1000033 + rank))
+        step = max(1, int(round(1.0 / wl["twild_pairs"])))
+        for i in range(step // 2, n, step):
+            ln = int(rng.integers(1, 51))
+            at = int(rng.integers(wl["tlen"] - ln))
+            t[i, at:at + ln] = 4
     return q, t
 
 
