@@ -80,6 +80,7 @@
 	X(STREAM_SLEEP_US) \
 	X(STREAM_TIMEOUT_MS) \
 	X(THREADS) \
+	X(TN) \
 	X(TRACE)
 enum {
 #define X(n) ENV_##n,

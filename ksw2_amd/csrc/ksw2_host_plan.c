@@ -415,7 +415,7 @@ static void build_scoring(int dual, int m, const int8_t *mat, int q, int e, int 
  * as its penalty below the matrix's largest entry and look it up in per-query-code column profiles (K2aScoring.cp).  A profile
  * has four bytes, target codes 0..3: pairs whose TARGET holds code 4 leave this class (plan_create_ex), a query's code 4 is table
  * entry 4.  What must hold ... */
-typedef struct { int ok, smax, smin, qemax, qemin, q, e; uint32_t cp[8]; } pkinfo_t;
+typedef struct { int ok, smax, smin, qemax, qemin, q, e, tn1; uint32_t cp[8]; } pkinfo_t;
 
 static void pk_scoring(int dual, int m, const int8_t *mat, int q, int e, int q2, int e2, int generic, pkinfo_t *o)
 {
@@ -428,6 +428,13 @@ static void pk_scoring(int dual, int m, const int8_t *mat, int q, int e, int q2,
 		for (x = 0; x < m * m; ++x) { o->smax = imax(o->smax, eff[x]); o->smin = imin(o->smin, eff[x]); }
 		for (y = 0; y < m; ++y)                              /* column profile of query code y: penalties against target codes 0..3 */
 			for (x = 0; x < 4 && x < m; ++x) o->cp[y] |= (uint32_t)(o->smax - eff[x * m + y]) << (8 * x);
+		/* a TARGET wildcard (code 4) that scores the same against every query code -- every match / mismatch / N matrix -- stays
+		 * in the packed kernels as a row with penalty 0 out of the profile and a constant taken off its candidate
+		 * (K2aScoring.pk_tn1, K2aLanePk::step); KSW2AMD_TN=0: as before round 6 (such pairs take the int32 kernels or are re-run) */
+		if (m == 5 && !(ENV(TN) && ENV(TN)[0] == '0')) {
+			for (y = 1; y < 5 && eff[4 * 5 + y] == eff[4 * 5]; ++y) {}
+			if (y == 5) o->tn1 = o->smax - eff[4 * 5] + 1;
+		}
 	}
 	o->q = q; o->e = e;
 	o->qemax = dual ? imax(q + e, q2 + e2) : q + e;
@@ -478,19 +485,23 @@ static int pk_slide_ok(const pkinfo_t *k, int qlen, int tlen)
 	return (K2A_PKMP_T + 2 * 16 + 4) * D + 2 * k->qemax + 64 <= 6000;
 }
 
-/* copy a sequence into the staging arena and report whether it holds a residue code >= 4 (the wildcard of a 5-letter
- * alphabet): one pass over the bytes instead of a scan plus a memcpy */
+/* per byte of a word: 0x01 where the byte is above 4 (an OR over words cannot tell 4 | 1 from 5) */
+static inline uint64_t above4(uint64_t v) { return ((v >> 3 | v >> 4 | v >> 5 | v >> 6 | v >> 7) | ((v >> 2) & (v | (v >> 1)))) & 0x0101010101010101ull; }
+
+/* copy a sequence into the staging arena and report the residue codes >= 4 it holds: 0 = none, 1 = the wildcard of a 5-letter
+ * alphabet (code 4) and nothing above, 2 = a code above 4.  One pass over the bytes instead of a scan plus a memcpy */
 int copy_scan(uint8_t *dst, const uint8_t *src, int n)
 {
 	int i = 0;
-	uint64_t acc = 0, v0, v1, v2, v3;
+	uint64_t acc = 0, hi = 0, v0, v1, v2, v3;
 	for (; i + 32 <= n; i += 32) {
 		memcpy(&v0, src + i, 8); memcpy(&v1, src + i + 8, 8); memcpy(&v2, src + i + 16, 8); memcpy(&v3, src + i + 24, 8);
 		memcpy(dst + i, &v0, 8); memcpy(dst + i + 8, &v1, 8); memcpy(dst + i + 16, &v2, 8); memcpy(dst + i + 24, &v3, 8);
 		acc |= (v0 | v1) | (v2 | v3);
+		if (((v0 | v1) | (v2 | v3)) & 0x0404040404040404ull) hi |= (above4(v0) | above4(v1)) | (above4(v2) | above4(v3));      /* (rare: a word with bit 2 somewhere) */
 	}
-	for (; i < n; ++i) { dst[i] = src[i]; acc |= src[i]; }
-	return (acc & 0xfcfcfcfcfcfcfcfcull) != 0;
+	for (; i < n; ++i) { dst[i] = src[i]; acc |= src[i]; if (src[i] > 4) hi = 1; }
+	return (acc & 0xf8f8f8f8f8f8f8f8ull) || hi ? 2 : (acc & 0x0404040404040404ull) ? 1 : 0;
 }
 
 void ksw2amd_plan_destroy(ksw2amd_plan_t *p)
@@ -589,9 +600,16 @@ static uint64_t or_bytes(const uint8_t *p, int n)
 	for (; i < n; ++i) acc |= p[i];
 	return acc;
 }
-static int pair_has_wild(const ksw2amd_pair_t *a)         /* a wildcard code in the TARGET: what keeps a pair out of the packed kernels (pk_scoring) */
+/* codes >= 4 in the TARGET, as copy_scan reports them (0 none, 1 the wildcard code 4 only, 2 a code above 4): what keeps a pair out of
+ * the packed kernels -- level 1 only where the scoring has no constant wildcard row (pk_scoring, pkinfo_t.tn1) */
+static int pair_wild_level(const ksw2amd_pair_t *a)
 {
-	return (or_bytes(a->target, a->tlen) & 0xfcfcfcfcfcfcfcfcull) != 0;
+	const uint64_t acc = or_bytes(a->target, a->tlen);
+	int i;
+	if (acc & 0xf8f8f8f8f8f8f8f8ull) return 2;
+	if (!(acc & 0x0404040404040404ull)) return 0;
+	for (i = 0; i < a->tlen; ++i) if (a->target[i] > 4) return 2;      /* (rare: only targets that hold a wildcard get here) */
+	return 1;
 }
 
 ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc, int n, const ksw2amd_pair_t *pairs, const flat_src_t *flat, int want_stream)
@@ -806,7 +824,12 @@ ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc
 		const int fl = p->h_flag[i];
 		int w = a->w, cfg, mode, generic, mx, wild;
 		if (a->qlen <= 0 || a->tlen <= 0) { ++ninvalid; continue; }
-		wild = solo_ok[i]; solo_ok[i] = 0;
+		wild = solo_ok[i]; solo_ok[i] = 0;                    /* copy_scan's level: 0, 1 = code 4 only, 2 = above */
+		if (wild == 1) {                                      /* the target's wildcard: a packed row like any other where the scoring allows (pkinfo_t.tn1) */
+			const int gen_ = (fl & (KSW_EZ_GENERIC_SC | F_SCALAR_CONTRACT)) ? 1 : 0;
+			if (pkinfo[gen_].ok < 0) pk_scoring(dual, m, sc->mat, q, e, q2, e2, gen_, &pkinfo[gen_]);
+			if (pkinfo[gen_].tn1) wild = 0;
+		}
 		if (su) {                                             /* the upload piece this pair's last byte (+ what the kernels may touch behind it) lies in */
 			const size_t qe = (size_t)d->qoff + (size_t)a->qlen, te = (size_t)d->toff + (size_t)a->tlen, end = qe > te ? qe : te;
 			const size_t lim = end + K2A_STREAM_MARGIN < p->seq_bytes ? end + K2A_STREAM_MARGIN : p->seq_bytes;
@@ -861,7 +884,7 @@ ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc
 			if (pc == K2A_PKCFG_MP && !(cfg == K2A_CFG_MP && use_rb && use_pkmp && !is_approx(fl) && pk_slide_ok(&pkinfo[generic], a->qlen, d->tlen))) pc = K2A_NPKCFG;
 			/* (flat plans: the generation-serial kernels do not report wildcard codes, so a pair goes there only after a look at its
 			 * bytes -- which a device arena does not allow; the packed and the solo kernels report them and the host re-runs the pair) */
-			if (pc == K2A_PKCFG_MP && (flat || p->unscanned) && ((flat && flat->on_device) || pair_has_wild(a))) pc = K2A_NPKCFG;
+			if (pc == K2A_PKCFG_MP && (flat || p->unscanned) && ((flat && flat->on_device) || pair_wild_level(a) > (pkinfo[generic].tn1 ? 1 : 0))) pc = K2A_NPKCFG;
 			if (pc < K2A_NPKCFG) pk_ok[i] = (uint8_t)(1 + pc + ((plain && pc != K2A_PKCFG_MP) ? 0 : K2A_NPKCFG) + (is_approx(fl) ? 2 * K2A_NPKCFG : 0));
 			/* solo kernel: two strips of SC rows per lane, each with its own base (the window of an SC-row strip); a lane must finish
 			 * a double strip before its next one starts: 2 * 64 steps + 2 * SC * 64 columns later, against 2 * w + 2 * SC columns */
@@ -1035,7 +1058,7 @@ ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc
 			c->cfg = c->solo ? 0 : pass ? (pass - 1) % K2A_NPKCFG : ci / 6; c->rb = pass && !c->solo ? ((pass - 1) / K2A_NPKCFG) & 1 : 0;
 			c->nomax = !c->solo && pass > 2 * K2A_NPKCFG; c->mode = (ci / 2) % 3; c->generic = ci & 1; c->pk = pass != 0 && !c->solo; c->first = k;
 			build_scoring(dual, m, sc->mat, q, e, q2, e2, c->generic, &c->sc);
-			if (pkinfo[c->generic].ok > 0) { memcpy(c->sc.cp, pkinfo[c->generic].cp, sizeof(c->sc.cp)); c->sc.pk_smax = pkinfo[c->generic].smax; }
+			if (pkinfo[c->generic].ok > 0) { memcpy(c->sc.cp, pkinfo[c->generic].cp, sizeof(c->sc.cp)); c->sc.pk_smax = pkinfo[c->generic].smax; c->sc.pk_tn1 = pkinfo[c->generic].tn1; }
 			if (uni) {
 				if (!pass || c->solo) { for (i = 0; i < cnt; ++i) p->h_order[k++] = (uint32_t)i; ntask = cnt; }
 				else for (i = 0; i < cnt; i += 2, ++ntask) { p->h_order[k++] = (uint32_t)i; p->h_order[k++] = (uint32_t)(i + 1 < cnt ? i + 1 : i); }
@@ -1702,9 +1725,9 @@ int ksw2amd_plan_describe(const ksw2amd_plan_t *p, char *buf, int cap)
 		const int G = k->solo ? 64 : k->pk ? k2a_pkcfg_G[k->cfg] : k2a_cfg_G[k->cfg], C = k->solo ? 2 * K2A_SOLO_ROWS(k->mode == K2A_MODE_SCORE) : k->pk ? k2a_pkcfg_C[k->cfg] : k2a_cfg_C[k->cfg];
 		const int form = k->defer ? 3 : k->solo ? 0 : k->pk ? (k->cfg == K2A_PKCFG_MP ? 0 : k2a_shim_pk_form(k->cfg, p->dual, k->mode, k->nomax, k->count))
 		                                     : (k->cfg == K2A_CFG_MP ? k2a_shim_mp_form(p->dual, k->mode, k->count) : 0);
-		len += snprintf(buf + len, (size_t)(cap - len), "kernel=%s G=%d C=%d gaps=%d mode=%s rebased=%d nomax=%d generic=%d form=%s tasks=%d uniform=%d wire4=%d\n",
+		len += snprintf(buf + len, (size_t)(cap - len), "kernel=%s G=%d C=%d gaps=%d mode=%s rebased=%d nomax=%d generic=%d form=%s tasks=%d uniform=%d wire4=%d tn=%d\n",
 		                kind, G, C, p->dual ? 2 : 1, mode_name[k->mode], k->rb, k->nomax, k->generic, form_name[form], k->count, p->uni ? 1 : 0,
-		                p->up_state && p->up_state->wire4 ? 1 : 0);
+		                p->up_state && p->up_state->wire4 ? 1 : 0, (k->pk || k->solo) && k->sc.pk_tn1 ? 1 : 0);      /* tn: target wildcards are rows of this packed class (K2aScoring.pk_tn1) */
 	}
 	return p->ncls;
 }

@@ -184,6 +184,22 @@ K2A_FN k2a_pk k2a_pk_shl(k2a_pk a, int n) { return (((a & 0xffffu) << n) & 0xfff
 K2A_FN k2a_pk k2a_bit_mask(uint32_t bits, int c) { return ((bits >> c) & 1u) ? 0xffffffffu : 0u; }
 #endif
 
+/* Target wildcard rows (K2aScoring.pk_tn1, round 6).  x = { tA, 0, tB, 0 }, the raw codes of a row:
+ * k2a_tsel_wild: the row's selector with 0x0c ("byte 0x00": penalty 0) where the code has bit 2 set, the ordinary one elsewhere;
+ * k2a_tn_fix: what such a row's candidate loses instead -- bit 3 of a selector byte marks the half (ordinary bytes are 0..7);
+ * k2a_codes_above4: nonzero if a byte of a code dword is above 4 (an OR over dwords cannot tell 4 | 1 from 5). */
+K2A_FN uint32_t k2a_tsel_wild(uint32_t x)
+{
+	const uint32_t n = x & 0x00040004u;
+	return ((x ^ n) + K2A_TSEL_BASE) | n | (n << 1);
+}
+K2A_FN k2a_pk k2a_tn_fix(k2a_pk cand, uint32_t sel, int tn1)
+{
+	const uint32_t m = (sel >> 3) & 0x00010001u;                  /* 1 per half that holds a wildcard row */
+	return cand - m * ((uint32_t)(tn1 - 1) & 0xffu);              /* both halves with one 32-bit subtract (k2a_sub32: the low half does not borrow) */
+}
+K2A_FN uint32_t k2a_codes_above4(uint32_t d) { return (d & 0xf8f8f8f8u) | ((d >> 2) & (d | (d >> 1)) & 0x01010101u); }
+
 /* Direction flags of one row for both halves (traceback kernels, round 5).  Every decision of the reference's direction logic
  * (ksw2_extz.c:72-86 / 98-112, ksw2_extd.c:88-114 / 126-152) is the SIGN of a packed difference: s1..s4 = candidate - gap state in
  * the order E, F, E~, F~ (each against the running maximum before it: "the gap state wins"), x1..x4 = opening - gap state ("the gap
@@ -268,6 +284,11 @@ struct K2aLanePk {
 	int baseA, baseB;                   /* RB: absolute (row-biased) score that the strip's packed values are relative to */
 	k2a_pk delta;                       /* RB: base of the strip above minus this strip's base, added to incoming ports */
 	uint32_t qb;                        /* { query code A, query code B } of this step's column */
+	/* target wildcard rows (K2aScoring.pk_tn1): hasn = this lane's strip holds one; wn = some lane of the wavefront does (the kernels
+	 * refresh it where strips start and end: wavefront-uniform, so that step() tests a scalar).  A code above 4 among the target
+	 * bytes sets bit 31 of `seen`: still reported (K2aResult.pad[0]) */
+	uint32_t hasn;
+	bool wn;
 	const uint32_t *cptab;              /* the column profiles (K2aScoring.cp), in LDS on the device */
 	uint32_t cpA, cpB;                  /* cp[query code] of this step's column for alignment A / B: penalties against target codes 0..3 */
 	/* the step's query codes and their column profiles.  The kernels call it for step k + 1 right behind step k (the table
@@ -307,6 +328,7 @@ struct K2aLanePk {
 		schedule_next();
 		const k2a_pk neg = k2a_pku(K2A_NEG16);
 		hout = eout = e2out = hd0 = hu_prev = neg; qb = 0; qwA = qwB = 0; seen = 0;
+		hasn = 0; wn = false;
 		baseA = baseB = 0; delta = 0;
 		local_reset();
 #pragma unroll
@@ -338,14 +360,22 @@ struct K2aLanePk {
 		 * alignment A's code with alignment B's and one add turns the pair into the row's selector -- this code runs with one lane
 		 * per group active, every 17-19 steps: it was 11 % of the kernel when it went byte by byte. */
 		const uint8_t *tpa = ta + (size_t)S * C, *tpb = tbq + (size_t)S * C;
+		hasn = 0;
 #pragma unroll
 		for (int c4 = 0; c4 < C; c4 += 4) {
 			uint32_t da, db;
 			__builtin_memcpy(&da, tpa + c4, 4); __builtin_memcpy(&db, tpb + c4, 4);
-			if (c4 + 4 <= C) note_codes(da, db);                /* (C = 18: the last two rows' dword reaches into the next strip, which reports them itself) */
-			else note_codes(da & 0xffffu, db & 0xffffu);
+			if (c4 + 4 > C) { da &= 0xffffu; db &= 0xffffu; }     /* (C = 18: the last two rows' dword reaches into the next strip, which reports them itself) */
+			note_codes(da, db);
+			if (sc.pk_tn1 && ((da | db) & 0x04040404u)) {             /* a wildcard among these rows' target codes (rare; lane by lane) */
+				if (k2a_codes_above4(da) | k2a_codes_above4(db)) seen |= 0x80000000u;      /* a code above 4: still reported */
+				hasn = 1;
 #pragma unroll
-			for (int r = 0; r < 4 && c4 + r < C; ++r) set_tc(c4 + r, k2a_byte_pair(da, db, r) + K2A_TSEL_BASE);
+				for (int r = 0; r < 4 && c4 + r < C; ++r) set_tc(c4 + r, k2a_tsel_wild(k2a_byte_pair(da, db, r)));
+			} else {
+#pragma unroll
+				for (int r = 0; r < 4 && c4 + r < C; ++r) set_tc(c4 + r, k2a_byte_pair(da, db, r) + K2A_TSEL_BASE);
+			}
 		}
 #pragma unroll
 		for (int c = 0; c < C; ++c) {
@@ -425,6 +455,10 @@ struct K2aLanePk {
 				const k2a_pk up = r == 0 ? above_old : hl[c - 1];
 				/* H(i-1,j-1) + s(i,j) + e: the row's penalty bytes { smax - s(tA, qA), 0, smax - s(tB, qB), 0 } out of the column profiles */
 				cand[r] = k2a_sub32(k2a_add32(up, bias), k2a_perm(cpB, cpA, tc(c)));
+			}
+			if (wn) {                                            /* a target wildcard row somewhere in the wavefront (scalar test): its constant penalty */
+#pragma unroll
+				for (int r = 0; r < CH; ++r) cand[r] = k2a_tn_fix(cand[r], tc(c0 + r), sc.pk_tn1);
 			}
 			above_old = last_old;
 			if (CH < C) K2A_SCHED_FENCE();
@@ -516,7 +550,7 @@ struct K2aLanePk {
 		a = k2a_load_early(qa + jc); b = k2a_load_early(qbp + jc);
 	}
 	K2A_FN void note_codes(uint32_t a, uint32_t b) { seen |= a | b; }
-	K2A_FN bool saw_wildcard() const { return (seen & 0xfcfcfcfcu) != 0; }
+	K2A_FN bool saw_wildcard(const K2aScoring &sc) const { return (seen & (sc.pk_tn1 ? 0xf8f8f8f8u : 0xfcfcfcfcu)) != 0; }
 	K2A_FN void reload_query_group(int k)                      /* from the init branch: this strip started at step k, inside a group */
 	{
 		const int j = (k & ~3) - koff;                             /* < 0: the strip's column 0 comes -j steps into the group */
@@ -585,7 +619,7 @@ struct K2aLanePk {
 			b->max = bmax; b->max_t = bmax_t; b->max_q = bmax_q; b->mqe = bmqe; b->mqe_t = bmqe_t;
 			b->mte = bmte; b->mte_q = bmte_q; b->score = bscore; b->dropped = bdrop; b->rows = brows;
 		}
-		S = -1; je = -1; kfin = K2A_KNONE; rows_m1 = -1;
+		end_strip();
 	}
 
 	/* Shortcut in front of the sequential form, in registers and for both alignments at once.  For a full strip that
@@ -664,7 +698,7 @@ struct K2aLanePk {
 			if (i == tlen_full - 1 && tlen == tlen_full) { last_h = ph; last_m = pm; last_j = pj; }   /* mte / mte_q / score */
 		}
 	}
-	K2A_FN void end_strip() { S = -1; je = -1; kfin = K2A_KNONE; rows_m1 = -1; }
+	K2A_FN void end_strip() { S = -1; je = -1; kfin = K2A_KNONE; rows_m1 = -1; hasn = 0; }
 
 	/* NOMAX epilogue: the only thing a finished strip contributes is H(tlen-1, qlen-1), if it holds the last target row and
 	 * that row reaches the last column (ksw2_extz2_sse.c:284-285) */

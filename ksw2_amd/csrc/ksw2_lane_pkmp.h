@@ -70,7 +70,7 @@ struct K2aLanePkMp {
 	K2A_FN void begin_generation(int g, int jlo)
 	{
 		const k2a_pk neg = k2a_pku(K2A_NEG16);
-		P.S = -1; P.je = -1; P.kfin = K2A_KNONE; P.rows_m1 = -1;
+		P.S = -1; P.je = -1; P.kfin = K2A_KNONE; P.rows_m1 = -1; P.hasn = 0; P.wn = false;
 		P.Snext = g * G + P.gl;
 		P.koff_next = P.gl - jlo;
 		P.knext = P.Snext < P.nstrips ? P.koff_next + Pk::first_col(P.Snext, P.w) : K2A_KNONE;

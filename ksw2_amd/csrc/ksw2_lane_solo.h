@@ -50,8 +50,10 @@ struct K2aLaneSolo {
 	const uint32_t *cptab;                  /* column profiles (K2aLanePk): cpA = cp[code at column jj] for the low half, cpB = what the low half had one step ago */
 	uint32_t cpA, cpB;
 	uint32_t seen;                          /* OR of every TARGET code dword this lane used (K2aLanePk::seen: a flat plan's unscanned bytes; code >= 4 = wildcard -> the host re-runs the pair) */
+	uint32_t hasn;                          /* target wildcard rows, as in K2aLanePk (K2aScoring.pk_tn1) */
+	bool wn;
 	K2A_FN void note_codes(uint32_t a) { seen |= a; }
-	K2A_FN bool saw_wildcard() const { return (seen & 0xfcfcfcfcu) != 0; }
+	K2A_FN bool saw_wildcard(const K2aScoring &sc) const { return (seen & (sc.pk_tn1 ? 0xf8f8f8f8u : 0xfcfcfcfcu)) != 0; }
 	k2a_pk hl[C], f[C], f2[DUAL ? C : 1], rmax[C], rmj[C], tc[C], hsave[C];      /* tc: per row the v_perm_b32 selector { t(row c), 0x0c, 4 + t(row C + c), 0x0c } */
 
 	K2A_FN static int first_col(int D_, int w_) { return k2a_max(0, D_ * 2 * C - w_); }
@@ -92,7 +94,7 @@ struct K2aLaneSolo {
 		schedule_next();
 #pragma unroll
 		for (int x = 0; x < (C + 3) / 4; ++x) tnA[x] = tnB[x] = 0;
-		qn0 = 0; seen = 0;
+		qn0 = 0; seen = 0; hasn = 0; wn = false;
 		prefetch_next();
 		const k2a_pk neg = k2a_pku(K2A_NEG16);
 		hout = eout = e2out = hd0 = hu_prev = neg; qb = 0; qw = 0; baseA = baseB = 0; delta = 0;
@@ -130,12 +132,20 @@ struct K2aLaneSolo {
 		const k2a_pk neg = k2a_pku(K2A_NEG16);
 		/* target codes of the 2C rows as selectors into the step's column profiles (ksw2_lane_pk.h), low half = rows i0.., high
 		 * half = rows i0+C..: four rows of both halves per pair of dwords */
+		hasn = 0;
 #pragma unroll
 		for (int c4 = 0; c4 < C; c4 += 4) {
 			const uint32_t da = tnA[c4 / 4], db = tnB[c4 / 4];             /* prefetch_next(), one strip ago */
 			note_codes(da | db);                                           /* (rows past the target's end read the arena's next bytes: at worst a needless re-run) */
+			if (sc.pk_tn1 && ((da | db) & 0x04040404u)) {                       /* a wildcard among these rows' target codes (K2aLanePk::do_init) */
+				if (k2a_codes_above4(da) | k2a_codes_above4(db)) seen |= 0x80000000u;      /* a code above 4: still reported */
+				hasn = 1;
 #pragma unroll
-			for (int r = 0; r < 4; ++r) tc[c4 + r] = k2a_byte_pair(da, db, r) + K2A_TSEL_BASE;
+				for (int r = 0; r < 4; ++r) tc[c4 + r] = k2a_tsel_wild(k2a_byte_pair(da, db, r));
+			} else {
+#pragma unroll
+				for (int r = 0; r < 4; ++r) tc[c4 + r] = k2a_byte_pair(da, db, r) + K2A_TSEL_BASE;
+			}
 		}
 #pragma unroll
 		for (int c = 0; c < C; ++c) { hl[c] = neg; f[c] = neg; if (DUAL) f2[c] = neg; rmax[c] = neg; rmj[c] = 0; }
@@ -241,6 +251,10 @@ struct K2aLaneSolo {
 			for (int r = 0; r < CH; ++r) {
 				const int c = c0 + r;
 				cand[r] = k2a_sub32(k2a_add32(r == 0 ? above_old : hl[c - 1], bias), k2a_perm(cpB, cpA, tc[c]));
+			}
+			if (wn) {                                                /* a target wildcard row somewhere in the wavefront (K2aLanePk::step) */
+#pragma unroll
+				for (int r = 0; r < CH; ++r) cand[r] = k2a_tn_fix(cand[r], tc[c0 + r], sc.pk_tn1);
 			}
 			above_old = last_old;
 			if (CH < C) K2A_SCHED_FENCE();
@@ -391,7 +405,7 @@ struct K2aLaneSolo {
 		return true;
 	}
 
-	K2A_FN void end_strip() { D = -1; kfin = kfinA = K2A_KNONE; rowsA_m1 = rowsB_m1 = -1; }
+	K2A_FN void end_strip() { D = -1; kfin = kfinA = K2A_KNONE; rowsA_m1 = rowsB_m1 = -1; hasn = 0; }
 };
 
 /* Traceback walk over a solo task's direction bytes: cell (i, j) is byte 2c + half of the word written at step

@@ -273,6 +273,9 @@ __device__ __forceinline__ void k2a_cptab_fill(const K2aScoring &sc, uint32_t *t
 	__builtin_amdgcn_wave_barrier();
 }
 
+/* target wildcard rows (K2aLanePk::wn): "some lane of this wavefront holds one", refreshed where strips start and end */
+#define K2A_SYNC_WN(L) do { (L).wn = __builtin_amdgcn_ballot_w64((L).hasn != 0) != 0; } while (0)
+
 /* Packed-int16 resident fill: two same-shape alignments per lane group (ksw2_lane_pk.h). */
 template<int G, int C, bool DUAL, int MODE, bool RB, bool NOMAX, int LDSROW = 0, bool DEFER = false, bool QUEUE = false>      /* LDSROW: 1 = row state in LDS, 2 = only the target-code planes; DEFER: K2aLanePk; QUEUE: streamed launches */
 __global__ void __launch_bounds__(64 * K2A_WPB, LDSROW == 2 ? (G == 16 ? 4 : 3) : LDSROW ? 2 : 1)      /* no floor elsewhere: capping the register form of the score-only kernels at 168 VGPRs spills and is 18 % slower */
@@ -368,6 +371,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 				if (k & 3) L.reload_query_group(k);                /* the group was fetched under the previous strip's offset */
 				if (ckon) { K2aCkHead h; h.baseA = L.baseA; h.baseB = L.baseB; h.hd0 = L.hd0; h.pad = 0; ckhd[L.S] = h; }
 			}
+			K2A_SYNC_WN(L);
 		}
 		L.hu_prev = hin;
 		if (RB) { hin = k2a_pk_add(hin, L.delta); ein = k2a_pk_add(ein, L.delta); if (DUAL) e2in = k2a_pk_add(e2in, L.delta); }
@@ -410,6 +414,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 				if (nfin) L.end_strip();
 				__builtin_amdgcn_wave_barrier();
 			}
+			if (L.wn) K2A_SYNC_WN(L);
 		}
 		if (zseq && __builtin_amdgcn_ballot_w64(!(gdone || k >= klast)) == 0) { stop = true; break; }   /* only a Z-drop ends a group early */
 	}
@@ -438,7 +443,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 		__builtin_amdgcn_wave_barrier();
 	}
 	/* a code >= 4 among the bytes this group read: only an unscanned (flat) plan can get here with one; the host re-runs the pair */
-	const uint64_t sawmask = __builtin_amdgcn_ballot_w64(valid && L.saw_wildcard());
+	const uint64_t sawmask = __builtin_amdgcn_ballot_w64(valid && L.saw_wildcard(sc));
 	const bool gsaw = ((sawmask >> (grp * G)) & (G == 64 ? ~0ull : (1ull << (G & 63)) - 1)) != 0;
 	if (valid && gl == 0) {
 		const K2aBook a = *bkA, b = *bkB;
@@ -492,6 +497,7 @@ k2a_argmax_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const 
 	const int kbeg = L.knext;
 	const uint8_t *blk = ck + prA.tb_off;
 	if (go) L.do_init(sc, 0, 0, (const K2aCkHead*)(blk + (size_t)prA.bnd_off * K2A_CK_STEP_BYTES) + (size_t)grp * prA.cig_off + S);
+	K2A_SYNC_WN(L);
 	const int n = go ? L.kfin - kbeg + 1 : 0;
 	const uint2 *st = (const uint2*)blk + (grp * G + S % G);
 	for (int t = 0; __builtin_amdgcn_ballot_w64(t < n) != 0; ++t) {
@@ -586,6 +592,7 @@ k2a_zscan_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const u
 		L.schedule_next();
 		const int kbeg = L.knext;
 		if (go) L.do_init(sc, 0, 0, (const K2aCkHead*)(blk + (size_t)prA.bnd_off * K2A_CK_STEP_BYTES) + (size_t)grp * prA.cig_off + S);
+		K2A_SYNC_WN(L);
 		const int n = go ? L.kfin - kbeg + 1 : 0;
 		const uint2 *st = (const uint2*)blk + (grp * G + S % G);
 		/* the group's lanes walk the fill's steps TOGETHER: at one iteration all of them read the same step of the checkpoint stream,
@@ -692,6 +699,7 @@ k2a_fill_solo_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 		if (__builtin_amdgcn_ballot_w64(ninit) != 0) {
 			const int bs = k2a_rot1<64>(L.baseB);
 			if (ninit) L.do_init(sc, bs);                      /* uses hu_prev = what arrived one step ago; brings its first query group along */
+			K2A_SYNC_WN(L);
 		}
 		const bool nhigh = L.need_init_high(k);
 		if (__builtin_amdgcn_ballot_w64(nhigh) != 0) {
@@ -726,6 +734,7 @@ k2a_fill_solo_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 				__builtin_amdgcn_wave_barrier();
 				if (bk->dropped) { stop = true; break; }
 			}
+			if (L.wn) K2A_SYNC_WN(L);
 		}
 	}
 	L.qw = qp;
@@ -733,7 +742,7 @@ k2a_fill_solo_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 	if (STAGED) ST.finish(kdone);
 	__builtin_amdgcn_wave_barrier();
 	/* a code >= 4 among the bytes this wavefront read: only an unscanned (flat) plan can get here with one; the host re-runs the pair */
-	const bool saw = __builtin_amdgcn_ballot_w64(valid && L.saw_wildcard()) != 0;
+	const bool saw = __builtin_amdgcn_ballot_w64(valid && L.saw_wildcard(sc)) != 0;
 	if (valid && lane == 0) {
 		const K2aBook b = *bk;
 		k2a_finish(pr, b, &res[pi]);
@@ -1096,6 +1105,7 @@ k2a_fill_pkmp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 					if (ninit) L.do_init(sc, bsA, bsB);                  /* uses hu_prev = what arrived one step ago */
 					bsA = k2a_rot1<G>(L.P.baseA); bsB = k2a_rot1<G>(L.P.baseB);
 					L.refresh_delta(bsA, bsB);                           /* a base changed: every lane re-reads its neighbour's */
+					K2A_SYNC_WN(L.P);
 				}
 				if (feeder) {
 					take(jlo + k, cur, cur2);
@@ -1124,6 +1134,7 @@ k2a_fill_pkmp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   /* the keys' atomics (performed at L2) are done; do_fin reads them past L1 */
 					if (nfin) L.do_fin(sc, bkA, bkB, zdropA, zdropB, rowbuf[wave]);
 					__builtin_amdgcn_wave_barrier();
+					if (L.P.wn) K2A_SYNC_WN(L.P);
 				}
 				L.P.set_qb(qnext);                                       /* next step's codes and column profiles */
 				if ((k & (T - 1)) == T - 1) {

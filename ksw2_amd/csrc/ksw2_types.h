@@ -59,6 +59,11 @@ typedef struct K2aScoring {
 	 * wildcard; 5..7 unused, zero); the diagonal candidate is H + (pk_smax + e) - byte t of cp[q]: one v_perm_b32 per row. */
 	uint32_t cp[8];
 	int32_t pk_smax;
+	/* TARGET wildcard (code 4) in the packed kernels (round 6): where its scores do not depend on the query code -- s(4, q) = sN for q =
+	 * 0..4, as in every match / mismatch / N matrix -- a row whose target code is 4 takes penalty 0 out of the profile (selector byte
+	 * 0x0c) and has pk_tn1 - 1 = smax - sN taken off its candidate in a branch only wavefronts that hold such a row enter
+	 * (K2aLanePk::step).  0: off -- such pairs leave the packed kernels (scanned plans) or are reported and re-run (unscanned ones). */
+	int32_t pk_tn1;
 	int32_t m;                   /* residue types; m > 5: scores come from `mat` (staged in LDS), prof/colw unused */
 	const int8_t *mat;           /* device copy of the effective m x m matrix, mat[target*m + query]       */
 } K2aScoring;

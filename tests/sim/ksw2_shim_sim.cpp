@@ -189,6 +189,11 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 				L[lane].set_qb(Lane::query_pick(L[lane].qwA, L[lane].qwB, k & 3));
 				if (k <= ktop) L[lane].top_inputs(sc, k, hin[lane], ein[lane], e2in[lane]);
 			}
+			{	/* K2A_SYNC_WN: "some lane of the wavefront holds a target wildcard row" (the kernel refreshes it where strips start and end) */
+				bool wn = false;
+				for (int lane = 0; lane < 64; ++lane) wn |= L[lane].hasn != 0;
+				for (int lane = 0; lane < 64; ++lane) L[lane].wn = wn;
+			}
 			for (int lane = 0; lane < 64; ++lane) {
 				uint32_t tw[Lane::TBWORDS];
 				if (DEFER && valid[0]) { uint32_t *ck = (uint32_t*)(tb + prA[0].tb_off) + 2 * ((size_t)k * 64 + lane); ck[0] = hin[lane]; ck[1] = ein[lane]; }
@@ -254,7 +259,7 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 		for (int lane = 0; lane < 64; ++lane)
 			if (valid[lane] && lane % G == 0) {
 				bool gsaw = false;
-				for (int l = lane; l < lane + G; ++l) gsaw |= L[l].saw_wildcard();
+				for (int l = lane; l < lane + G; ++l) gsaw |= L[l].saw_wildcard(sc);
 				k2a_finish(prA[lane], book[lane / G][0], &res[piA[lane]]);
 				if (piB[lane] != piA[lane]) k2a_finish(pairs[piB[lane]], book[lane / G][1], &res[piB[lane]]);
 				if (gsaw) { res[piA[lane]].pad[0] = 1; res[piB[lane]].pad[0] = 1; }
@@ -290,6 +295,7 @@ static void sim_argmax(const K2aScoring sc, const K2aPair *pairs, const uint32_t
 		const int kbeg = L.knext;
 		const uint8_t *blk = ck + prA.tb_off;
 		L.do_init(sc, 0, 0, (const K2aCkHead*)(blk + (size_t)prA.bnd_off * K2A_CK_STEP_BYTES) + (size_t)grp * prA.cig_off + S);
+		L.wn = L.hasn != 0;                                  /* K2A_SYNC_WN: a wavefront-uniform "maybe" on the device, exact here -- the fix is a no-op on rows without a wildcard */
 		const uint32_t *st = (const uint32_t*)blk;
 		for (int k = kbeg; k <= L.kfin; ++k) {
 			const size_t at = 2 * ((size_t)k * 64 + grp * G + S % G);
@@ -339,6 +345,7 @@ static void sim_zscan(const K2aScoring sc, const K2aPair *pairs, const uint32_t 
 				L.schedule_next();
 				const int kbeg = L.knext;
 				L.do_init(sc, 0, 0, (const K2aCkHead*)(blk + (size_t)prA.bnd_off * K2A_CK_STEP_BYTES) + (size_t)grp * prA.cig_off + S);
+				L.wn = L.hasn != 0;
 				const uint32_t *st = (const uint32_t*)blk;
 				for (int k = kbeg; k <= L.kfin; ++k) {
 					const size_t at = 2 * ((size_t)k * 64 + grp * G + S % G);
@@ -913,6 +920,11 @@ static void sim_fill_pkmp(const K2aScoring sc, const K2aPair *pairs, const uint3
 					L[0].refresh_delta((int)v[2], (int)v[3]);
 				}
 				bool nfin[64], anyfin = false;
+				{	/* K2A_SYNC_WN */
+					bool wn = false;
+					for (int l = 0; l < 64; ++l) wn |= L[l].P.hasn != 0;
+					for (int l = 0; l < 64; ++l) L[l].P.wn = wn;
+				}
 				for (int l = 0; l < 64; ++l) {
 					L[l].P.hu_prev = hin[l];
 					hin[l] = L[l].adopt(hin[l]); ein[l] = L[l].adopt(ein[l]);
@@ -981,9 +993,16 @@ static void sim_fill_solo(const K2aScoring sc, const K2aPair *pairs, const uint3
 			}
 			k2a_pk oh[64], oe[64], oe2[64];
 			for (int l = 0; l < 64; ++l) { oh[l] = L[l].hout; oe[l] = L[l].eout; oe2[l] = L[l].e2out; }
-			for (int l = 0; l < 64; ++l) {
+			for (int l = 0; l < 64; ++l) {                        /* (every lane's do_init comes before any lane's step, as on the device) */
 				if (L[l].need_init(k)) L[l].do_init(sc, rb[l]);
 				if (L[l].need_init_high(k)) L[l].start_high(sc);
+			}
+			{	/* K2A_SYNC_WN */
+				bool wn = false;
+				for (int l = 0; l < 64; ++l) wn |= L[l].hasn != 0;
+				for (int l = 0; l < 64; ++l) L[l].wn = wn;
+			}
+			for (int l = 0; l < 64; ++l) {
 				L[l].hu_prev = rh[l];
 				k2a_pk hin = (rh[l] >> 16) | (oh[l] << 16), ein = (re[l] >> 16) | (oe[l] << 16), e2in = DUAL ? (re2[l] >> 16) | (oe2[l] << 16) : 0u;
 				hin = k2a_pk_add(hin, L[l].delta); ein = k2a_pk_add(ein, L[l].delta); if (DUAL) e2in = k2a_pk_add(e2in, L[l].delta);
@@ -1005,7 +1024,7 @@ static void sim_fill_solo(const K2aScoring sc, const K2aPair *pairs, const uint3
 		}
 		k2a_finish(pr, book, &res[pi]);
 		bool saw = false;
-		for (int l = 0; l < 64; ++l) saw |= L[l].saw_wildcard();
+		for (int l = 0; l < 64; ++l) saw |= L[l].saw_wildcard(sc);
 		if (saw) res[pi].pad[0] = 1;
 	}
 }

@@ -1169,6 +1169,13 @@ def test_frozen_books_with_wildcards(lib, monkeypatch):
     _check_frozen_books_with_wildcards(lib, monkeypatch)
 
 
+def test_target_wildcards_stay_packed(lib, monkeypatch):
+    """tests/parity_util.py::check_target_wildcards on the device (round 6): a target's wildcard code is a row of every packed kernel
+    family -- nothing demoted to int32, nothing handed back -- with KSW2AMD_TN=0 and a matrix whose wildcard row varies on the old rule."""
+    from tests.parity_util import check_target_wildcards
+    check_target_wildcards(lib, monkeypatch.setenv, monkeypatch.delenv, scale=3)
+
+
 def test_uniform_plans(lib, monkeypatch):
     """tests/test_sim_parity.py::_check_uniform_plans on the device: small forced batches of three shapes (plain class, deferred arg-max
     forced on and off, Z-drops, wildcards, the fault hook), then config 2 at full size through the default routing: ONE uniform

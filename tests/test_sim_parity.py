@@ -740,16 +740,24 @@ def _check_frozen_books_with_wildcards(lib, monkeypatch):
             ts[i][tl // 4] = 4
         for i in range(1, 24, 5):
             qs[i][ql // 3] = 4
-        r0 = lib.rerun_count()
-        res = lib.extz_batch(qs, ts, mat, 4, 2, w=w, zdrop=zd, flag=po.SCORE_ONLY)
-        fres = lib.make_flat_batch(qs, ts, mat, 4, 2, 0, 0, w=w, zdrop=zd, end_bonus=0, flag=po.SCORE_ONLY).run_oneshot(False)
-        assert lib.rerun_count() >= r0 + 16                     # the eight target wildcards, twice; nothing else
-        ndrop = 0
-        for i in range(24):
-            exp = po.align("oracle", "extz2", qs[i], ts[i], mat, 4, 2, w=w, zdrop=zd, flag=po.SCORE_ONLY)
-            assert not diff(exp, res[i], CMP) and not diff(exp, fres[i], CMP), (w, i, diff(exp, res[i], CMP), diff(exp, fres[i], CMP))
-            ndrop += exp["zdropped"]
-        assert ndrop >= 12, ndrop
+        for tn in ("0", None):                                  # KSW2AMD_TN=0: target wildcards are handed back (before round 6, and still for matrices whose wildcard row varies);
+            if tn is None:                                          # default: they are rows of the packed kernels like any other (K2aScoring.pk_tn1) -- nothing is re-run
+                monkeypatch.delenv("KSW2AMD_TN", raising=False)
+            else:
+                monkeypatch.setenv("KSW2AMD_TN", tn)
+            r0 = lib.rerun_count()
+            res = lib.extz_batch(qs, ts, mat, 4, 2, w=w, zdrop=zd, flag=po.SCORE_ONLY)
+            fres = lib.make_flat_batch(qs, ts, mat, 4, 2, 0, 0, w=w, zdrop=zd, end_bonus=0, flag=po.SCORE_ONLY).run_oneshot(False)
+            if tn == "0":
+                assert lib.rerun_count() >= r0 + 16                 # the eight target wildcards, twice; nothing else
+            else:
+                assert lib.rerun_count() == r0
+            ndrop = 0
+            for i in range(24):
+                exp = po.align("oracle", "extz2", qs[i], ts[i], mat, 4, 2, w=w, zdrop=zd, flag=po.SCORE_ONLY)
+                assert not diff(exp, res[i], CMP) and not diff(exp, fres[i], CMP), (w, tn, i, diff(exp, res[i], CMP), diff(exp, fres[i], CMP))
+                ndrop += exp["zdropped"]
+            assert ndrop >= 12, ndrop
 
 
 def test_sim_frozen_books_with_wildcards(sim, monkeypatch):
@@ -1038,23 +1046,30 @@ def test_sim_streamed_plans(sim, monkeypatch, flat):
         monkeypatch.setenv("KSW2AMD_STREAM_FAULT", str(fault))
         for ci, (n, ql, tl, w, flag, dual, zd, wild) in enumerate(cases[:2] if fault else cases):
             qs, ts = _one_shape_batch(100 + ci, n, ql, tl, wild)
-            s0, r0 = sim.stream_stats(), sim.rerun_count()
-            if flat:
-                fb = sim.make_flat_batch(qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=0, flag=flag)
-                res = fb.run_oneshot(dual)
-            else:
-                res = (sim.extd_batch(qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, flag=flag) if dual else sim.extz_batch(qs, ts, mat, q, e, w=w, zdrop=zd, flag=flag))
-            s1 = sim.stream_stats()
-            streams = bool(flag & po.SCORE_ONLY)          # the queue builds of the kernels exist for the score-only classes
-            assert (s1["streamed_plans"] > s0["streamed_plans"]) == streams, (ci, flat)
-            assert (s1["aborted_runs"] > s0["aborted_runs"]) == bool(fault and streams), (ci, flat, fault)
-            if wild:
-                assert sim.rerun_count() >= r0 + (len(wild) + 1) // 2      # the target wildcards (every other one) are handed back and re-run
-            for i in range(n):
-                exp = (ApproxLike.run(qs[i], ts[i], mat, w, flag) if flag & po.APPROX_MAX else
-                       po.align("oracle", "extd2" if dual else "extz2", qs[i], ts[i], mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=0, flag=flag))
-                d = diff(exp, res[i], ["score"] if flag & po.APPROX_MAX else CMP)
-                assert not d, (ci, flat, fault, i, d)
+            for tn in (("0", None) if wild else (None,)):          # target wildcards handed back (KSW2AMD_TN=0) / scored in place (default, round 6)
+                if tn is None:
+                    monkeypatch.delenv("KSW2AMD_TN", raising=False)
+                else:
+                    monkeypatch.setenv("KSW2AMD_TN", tn)
+                s0, r0 = sim.stream_stats(), sim.rerun_count()
+                if flat:
+                    fb = sim.make_flat_batch(qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=0, flag=flag)
+                    res = fb.run_oneshot(dual)
+                else:
+                    res = (sim.extd_batch(qs, ts, mat, q, e, q2, e2, w=w, zdrop=zd, flag=flag) if dual else sim.extz_batch(qs, ts, mat, q, e, w=w, zdrop=zd, flag=flag))
+                s1 = sim.stream_stats()
+                streams = bool(flag & po.SCORE_ONLY)          # the queue builds of the kernels exist for the score-only classes
+                assert (s1["streamed_plans"] > s0["streamed_plans"]) == streams, (ci, flat)
+                assert (s1["aborted_runs"] > s0["aborted_runs"]) == bool(fault and streams), (ci, flat, fault)
+                if wild and tn == "0":
+                    assert sim.rerun_count() >= r0 + (len(wild) + 1) // 2      # the target wildcards (every other one) are handed back and re-run
+                elif wild:
+                    assert sim.rerun_count() == r0                             # ... or stay where they are
+                for i in range(n):
+                    exp = (ApproxLike.run(qs[i], ts[i], mat, w, flag) if flag & po.APPROX_MAX else
+                           po.align("oracle", "extd2" if dual else "extz2", qs[i], ts[i], mat, q, e, q2, e2, w=w, zdrop=zd, end_bonus=0, flag=flag))
+                    d = diff(exp, res[i], ["score"] if flag & po.APPROX_MAX else CMP)
+                    assert not d, (ci, flat, fault, tn, i, d)
 
 
 def _check_uniform_plans(lib, monkeypatch, shapes):
@@ -1074,7 +1089,7 @@ def _check_uniform_plans(lib, monkeypatch, shapes):
         fl = po.SCORE_ONLY | (po.EXTZ_ONLY if si % 2 else 0)
 
         def run(**env):
-            for k in ("KSW2AMD_UNIFORM", "KSW2AMD_STREAM_PIECE_KB", "KSW2AMD_STREAM_SLEEP_US", "KSW2AMD_STREAM_FAULT", "KSW2AMD_STREAM_TIMEOUT_MS", "KSW2AMD_DEFER", "KSW2AMD_WIRE4"):
+            for k in ("KSW2AMD_UNIFORM", "KSW2AMD_STREAM_PIECE_KB", "KSW2AMD_STREAM_SLEEP_US", "KSW2AMD_STREAM_FAULT", "KSW2AMD_STREAM_TIMEOUT_MS", "KSW2AMD_DEFER", "KSW2AMD_WIRE4", "KSW2AMD_TN"):
                 monkeypatch.delenv(k, raising=False)
             if defer is not None:
                 monkeypatch.setenv("KSW2AMD_DEFER", str(defer))
@@ -1092,7 +1107,10 @@ def _check_uniform_plans(lib, monkeypatch, shapes):
         run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64)     # a decoy batch of the same shape through the same buffers first
         qs, ts = keep
         on, ns, na, nr = run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64, KSW2AMD_STREAM_SLEEP_US=100)
-        assert ns == 1 and na == 0 and nr == 4, (si, ns, na, nr)       # ONE streamed plan; the two tasks that hold a target wildcard were handed back (both pairs of a task)
+        assert ns == 1 and na == 0 and nr == 0, (si, ns, na, nr)       # ONE streamed plan; the target wildcards are rows of the packed kernel (round 6: K2aScoring.pk_tn1)
+        old, ns, na, nr = run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64, KSW2AMD_TN=0)
+        assert ns == 1 and na == 0 and nr == 4, (si, ns, na, nr)       # KSW2AMD_TN=0: the two tasks that hold one are handed back (both pairs of a task) ...
+        assert not [i for i in range(n) if diff(old[i], on[i])], (si, "tn off")      # ... and come back with the same records
         b = lib.make_batch(qs, ts, mat, 4, 2, 0, 0, w=w, zdrop=zd, end_bonus=7, flag=fl)
         bad = [i for i in range(n) if diff(off[i], on[i])]
         assert not bad, (si, bad[:5], off[bad[0]], on[bad[0]])
@@ -1129,3 +1147,8 @@ class ApproxLike:
     @staticmethod
     def run(qq, tt, mat, w, flag):
         return po.align("oracle", "extz2", qq, tt, mat, 4, 2, w=w, zdrop=-1, end_bonus=0, flag=flag & ~po.APPROX_MAX)
+
+
+def test_sim_target_wildcards_stay_packed(sim, monkeypatch):
+    from tests.parity_util import check_target_wildcards
+    check_target_wildcards(sim, monkeypatch.setenv, monkeypatch.delenv)

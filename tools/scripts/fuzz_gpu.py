@@ -32,7 +32,11 @@ ENVS = [{}, {"KSW2AMD_SOLO": "1"}, {"KSW2AMD_SOLO": "all"}, {"KSW2AMD_LDSROWS": 
         {"KSW2AMD_STREAM": "0"},
         # round 5: the SSE-compatible score-only tasks and the narrow-band X-drop extensions through their other kernels; two copy lanes
         {"KSW2AMD_SSEC_BLK": "0"}, {"KSW2AMD_EXTF_GRP": "0"}, {"KSW2AMD_EXTF_GRP": "1", "KSW2AMD_EXTF_LDS": "1"}, {"KSW2AMD_EXTF_GRP": "1"}, {"KSW2AMD_EXTF_GRP": "2", "KSW2AMD_EXTF_WIN": "1"},
-        {"KSW2AMD_STREAM": "1", "KSW2AMD_STREAM_PIECE_KB": "64", "KSW2AMD_STREAM_LANES": "2", "KSW2AMD_SIMDS": "0"}, {"KSW2AMD_UNIFORM": "1", "KSW2AMD_POOL_MIN": "4", "KSW2AMD_SIMDS": "0"}]
+        {"KSW2AMD_STREAM": "1", "KSW2AMD_STREAM_PIECE_KB": "64", "KSW2AMD_STREAM_LANES": "2", "KSW2AMD_SIMDS": "0"},
+        # uniform plans (one shape, one parameter set, >= 2 048 pairs: the `uniform` rounds below build such batches; a POOL_MIN here would switch the route off)
+        {"KSW2AMD_UNIFORM": "1", "KSW2AMD_SIMDS": "0"}, {"KSW2AMD_UNIFORM": "1", "KSW2AMD_WIRE4": "0", "KSW2AMD_SIMDS": "0"},
+        # round 6: target wildcards as rows of the packed kernels (default) against the rule before it
+        {"KSW2AMD_TN": "0"}, {"KSW2AMD_TN": "0", "KSW2AMD_SIMDS": "0", "KSW2AMD_STREAM": "1", "KSW2AMD_STREAM_PIECE_KB": "64"}]
 KEYS = sorted({k for e in ENVS for k in e})
 t0 = time.time()
 rounds = pairs = 0
@@ -42,6 +46,43 @@ while time.time() - t0 < budget:
         os.environ.pop(k, None)
     os.environ.update(env)
     kind = rounds % 2 if LONG else rounds % 4
+    if "KSW2AMD_UNIFORM" in env and not LONG:
+        # one shape, one parameter set, score only, >= 2 048 pairs: the uniform plan (device-built records, 4-bit wire format or not), with
+        # now and then a wildcard run in a target, a query wildcard, and a residue code above 15 (does not fit the wire format: general path)
+        n = int(rng.integers(1024, 1200)) * 2                             # (an even count: the odd one out of a packed class ends the uniform route)
+        ql = int(rng.integers(30, 260)); tl = max(1, ql + int(rng.integers(-20, 20)))
+        w_, zd_ = int(rng.choice([8, 20, 64, 300])), int(rng.choice([-1, 40, 200]))
+        a, b, q, e = [(2, 4, 4, 2), (1, 3, 4, 1)][int(rng.integers(2))]
+        mat = synth.simple_mat(5, a, b, int(rng.choice([0, -1, -3])))
+        qs, ts = synth.fixed_batch(int(rng.integers(1 << 30)), n, ql, tl, sub=0.05, ind=0.08, tail_random_frac=0.3, tail_pairs=0.2)
+        qs, ts = [np.array(x, dtype=np.uint8) for x in qs], [np.array(x, dtype=np.uint8) for x in ts]
+        for i in rng.integers(0, n, size=int(rng.integers(0, 6))):
+            ln = int(rng.integers(1, min(tl, 30) + 1)); at = int(rng.integers(0, tl - ln + 1)); ts[int(i)][at:at + ln] = 4
+        for i in rng.integers(0, n, size=int(rng.integers(0, 4))):
+            qs[int(i)][int(rng.integers(ql))] = 4
+        fl_ = po.SCORE_ONLY | (po.EXTZ_ONLY if rng.random() < 0.3 else 0)
+        s0 = lib.stream_stats()["streamed_plans"]
+        res = lib.extz_batch(qs, ts, mat, q, e, w=w_, zdrop=zd_, end_bonus=int(rng.choice([0, 7])), flag=fl_)
+        assert lib.stream_stats()["streamed_plans"] == s0 + 1, ("uniform route not taken", env, n, ql, tl, w_)
+        os.environ["KSW2AMD_UNIFORM"] = "0"
+        ref = lib.extz_batch(qs, ts, mat, q, e, w=w_, zdrop=zd_, end_bonus=0, flag=fl_)
+        os.environ["KSW2AMD_UNIFORM"] = "1"
+        got = lib.extz_batch(qs, ts, mat, q, e, w=w_, zdrop=zd_, end_bonus=0, flag=fl_)
+        badi = [i for i in range(n) if diff(ref[i], got[i])]
+        assert not badi, ("uniform vs general path", env, n, ql, tl, w_, zd_, badi[:4])
+        for i in [int(x) for x in rng.integers(0, n, size=32)] + [0, n - 1]:
+            exp = po.align("oracle", "extz2", qs[i], ts[i], mat, q, e, w=w_, zdrop=zd_, end_bonus=0, flag=fl_)
+            assert not diff(exp, got[i]), ("uniform vs oracle", env, i, ql, tl, w_, zd_, diff(exp, got[i]))
+        if rng.random() < 0.3:                                              # a code the wire format cannot hold
+            qs[3][1] = 20
+            os.environ["KSW2AMD_UNIFORM"] = "0"
+            ref = lib.extz_batch(qs, ts, mat, q, e, w=w_, zdrop=zd_, end_bonus=0, flag=fl_)
+            os.environ["KSW2AMD_UNIFORM"] = "1"
+            got = lib.extz_batch(qs, ts, mat, q, e, w=w_, zdrop=zd_, end_bonus=0, flag=fl_)
+            assert not [i for i in range(n) if diff(ref[i], got[i])], ("uniform, code above 15", env)
+        pairs += n
+        rounds += 1
+        continue
     if kind < 2:                                                          # extz2 / extd2
         dual = bool(kind)
         a, b, q, e, q2, e2 = [(2, 4, 4, 2, 24, 1), (1, 3, 4, 1, 24, 1), (2, 4, 4, 2, 13, 1), (2, 5, 5, 3, 20, 2)][int(rng.integers(4))]
@@ -52,6 +93,10 @@ while time.time() - t0 < budget:
             ql = int(rng.integers(hi // 2 if LONG else 20, hi)); tl = max(1, ql + int(rng.integers(-40, 40)))
             qs, ts = synth.fixed_batch(int(rng.integers(1 << 30)), n, ql, tl, sub=0.05, ind=0.1, tail_random_frac=0.3, tail_pairs=0.3)
             qs, ts = list(qs), list(ts)
+            if rng.random() < 0.35:                                        # wildcard runs in some targets: rows of the packed kernels (round 6), or int32 / handed back (KSW2AMD_TN=0)
+                ts = [np.array(x, dtype=np.uint8) for x in ts]
+                for k in range(0, n, int(rng.integers(1, 4))):
+                    ln = int(rng.integers(1, min(len(ts[k]), 50) + 1)); at = int(rng.integers(0, len(ts[k]) - ln + 1)); ts[k][at:at + ln] = 4
         else:
             pr = synth.ragged_pairs(rng, n, hi // 3 if LONG else 1, hi, sub=0.05, ind=0.12, n_rate=0.01 if rng.random() < 0.2 else 0.0)
             qs, ts = [p[0] for p in pr], [p[1] for p in pr]
