@@ -639,5 +639,7 @@ def library():
     """The product library (HIP).  Raises if it has not been built: there is no fallback."""
     global _default
     if _default is None:
-        _default = Library(DEFAULT_SO)
+        # KSW2AMD_LIB: another build of the SAME library (A/B runs of kernel variants under build_ab/, tools/scripts/ab_libs.sh) -- so that
+        # no script ever has to copy a variant over the product .so
+        _default = Library(os.environ.get("KSW2AMD_LIB") or DEFAULT_SO)
     return _default

@@ -1538,7 +1538,17 @@ ksw2amd_plan_t *ksw2amd_plan_create(int dual, const ksw2amd_scoring_t *sc, int n
 	/* (KSW2AMD_STREAM=1 streams these too: tests, A/B runs.)  create = pack + upload: the caller may free its inputs on return, so a
 	 * gather still reading them on the pool's threads is waited for here (the batch entries call plan_create_ex and keep the overlap) */
 	ksw2amd_plan_t *p = plan_create_ex(dual, 0, sc, n, pairs, 0, 0);
-	if (p && p->gather) gather_wait(p);
+	if (p && p->gather && gather_wait(p)) {              /* a piece's copy or upload failed: gather_wait is the only consumer of that verdict (it clears p->gather) */
+		fail(KSW2AMD_E_NODEVICE, "plan_create: upload failed: %s", k2a_shim_last_error());
+		if (p->stream_used && p->stream) k2a_shim_stream_sync(p->stream);
+		{
+			char keep[sizeof(g_err)];
+			memcpy(keep, g_err, sizeof(keep));
+			ksw2amd_plan_destroy(p);
+			memcpy(g_err, keep, sizeof(keep));
+		}
+		return 0;
+	}
 	return p;
 }
 
@@ -1551,7 +1561,8 @@ int ksw2amd_plan_run(ksw2amd_plan_t *p, void *stream)
 	if (p->splice == 2) return extf_plan_run(p, stream);
 	if (p->splice) return exts_plan_run(p, stream);
 	p->stream = stream; p->ran = 1; p->stream_used = 1;
-	if (p->gather && (!k2a_shim_async_launches() || !p->streamed)) gather_wait(p);      /* an ordinary launch, or one that runs inside the call, needs the whole arena */
+	if (p->gather && (!k2a_shim_async_launches() || !p->streamed) && gather_wait(p))      /* an ordinary launch, or one that runs inside the call, needs the whole arena */
+		return fail(KSW2AMD_E_NODEVICE, "plan_run: upload failed: %s", k2a_shim_last_error());
 	streaming = p->streamed && p->nqd > 0;
 	if (p->up_ev && !streaming && k2a_shim_stream_wait_event(stream, p->up_ev)) goto err;      /* the plan's upload (shared stream) before its kernels */
 	if (p->reject_all || p->ntasks == 0) return KSW2AMD_OK;
@@ -1845,7 +1856,7 @@ void km_unlock(const void *km) { if (km) pthread_mutex_unlock(km_mutex(km)); }
  *                       the int32 kernels.  Host arenas read the sequences where they lie, device arenas bring them back first;
  *   K2aResult.pad[1] == 1 -- deferred arg-max: a Z-drop could not be ruled out without the arg-max columns, and the second pass (k2a_argmax_kernel)
  *                       found that the reference's test does NOT hold at the row the fill stopped at: the re-run keeps the columns.
- *                       (2 = the second pass settled the drop: the record is final.) */
+ *                       (0 = exact, or settled on the device by the third pass, k2a_zscan_kernel: the record is final.) */
 int needs_rerun(const ksw2amd_plan_t *p, int i) { return p->h_cls[i] >= 0 && !p->splice && (((p->flat || p->unscanned) && p->h_res[i].pad[0]) || p->h_res[i].pad[1] == 1); }
 /* uniform plans on the 4-bit wire format keep two codes per byte in their staging copy: pair i's query and target, one code per byte,
  * into out[0 .. qlen) and out[qlen .. qlen + tlen) */

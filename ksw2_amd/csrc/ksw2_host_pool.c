@@ -2,6 +2,9 @@
  * ksw2_host_pool.c -- worker pool: chunked, pipelined, multi-device batches; gathers; the batch entry points; flat batches.
  */
 #include "ksw2_host_int.h"
+#if defined(__SSE2__)
+#include <emmintrin.h>                    /* pack4: the 4-bit wire format's packing loop; a host without SSE2 takes its scalar tail loop for everything */
+#endif
 
 /* ---------------------------------------------------------------- worker pool: chunked, pipelined, multi-device batches
  * A large batch handed to one ksw2amd_ext?_batch call is cut into chunks of consecutive pairs that a few persistent worker
@@ -260,13 +263,13 @@ void copy_range(const copy_ctx_t *c, int beg, int end)
 /* The 4-bit wire format of uniform plans: two residue codes per byte into the staging buffer (half the bytes for the gather to write
  * and for the DMA engines to move: config 2's step waits for its upload), expanded on the device by the wavefront that needs them
  * (k2a_queue_wait).  Returns the OR of all source bytes: a code above 15 does not fit and sends the batch to the general path. */
-#include <emmintrin.h>
 static unsigned pack4(uint8_t *dst, const uint8_t *src, int n)
 {
-	const __m128i lo = _mm_set1_epi16(0x00ff);
-	__m128i acc = _mm_setzero_si128();
 	unsigned bad = 0;
 	int k = 0;
+#if defined(__SSE2__)
+	const __m128i lo = _mm_set1_epi16(0x00ff);
+	__m128i acc = _mm_setzero_si128();
 	for (; k + 32 <= n; k += 32) {
 		const __m128i a = _mm_loadu_si128((const __m128i*)(src + k)), b = _mm_loadu_si128((const __m128i*)(src + k + 16));
 		/* 16-bit lanes { even byte, odd byte } -> even | odd << 4 in the low byte */
@@ -280,6 +283,7 @@ static unsigned pack4(uint8_t *dst, const uint8_t *src, int n)
 		_mm_storeu_si128((__m128i*)t, acc);
 		for (x = 0; x < 16; ++x) bad |= t[x];
 	}
+#endif      /* (any other host: the byte loop below takes the whole range) */
 	for (; k + 2 <= n; k += 2) { bad |= src[k] | src[k + 1]; dst[k >> 1] = (uint8_t)((src[k] & 15) | (src[k + 1] << 4)); }
 	if (k < n) { bad |= src[k]; dst[k >> 1] = (uint8_t)(src[k] & 15); }
 	return bad;

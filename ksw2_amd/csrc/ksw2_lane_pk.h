@@ -267,7 +267,10 @@ K2A_FN k2a_pk k2a_ofs_off(k2a_pk ofs) { return k2a_pk_sub(ofs, K2A_OFS); }
 struct K2aCkHead { int32_t baseA, baseB; uint32_t hd0, pad; };          /* per strip: what do_init derived from the neighbour lane */
 #define K2A_CK_STEP_BYTES 512                                            /* 64 lanes x { hin, ein } */
 
-template<int G, int C, bool DUAL, int MODE = K2A_MODE_SCORE, bool RB = false, bool NOMAX = false, int LDSROW_ = 0, bool DEFER = false>
+/* TN: the build for wavefront-tasks whose targets hold a wildcard code (K2aScoring.pk_tn1; the kernels look at their targets first and
+ * take this build or the plain one as a whole -- a test inside the plain step costs every batch 1-3 %, 10 % at one wavefront per SIMD:
+ * profiles/r6_ab_tn.txt) */
+template<int G, int C, bool DUAL, int MODE = K2A_MODE_SCORE, bool RB = false, bool NOMAX = false, int LDSROW_ = 0, bool DEFER = false, bool TN = false>
 struct K2aLanePk {
 	enum { NIB = K2A_PK_NIBBLES(C, DUAL), TBWORDS = NIB ? C / 4 : C / 2 };
 	/* NIB (single gap, 16 rows): direction flags of 4 bits (k2a_dir_flags: bit 0 E wins, 1 F wins, 2 / 3 = the E / F gap leaving the
@@ -284,9 +287,8 @@ struct K2aLanePk {
 	int baseA, baseB;                   /* RB: absolute (row-biased) score that the strip's packed values are relative to */
 	k2a_pk delta;                       /* RB: base of the strip above minus this strip's base, added to incoming ports */
 	uint32_t qb;                        /* { query code A, query code B } of this step's column */
-	/* target wildcard rows (K2aScoring.pk_tn1): hasn = this lane's strip holds one; wn = some lane of the wavefront does (the kernels
-	 * refresh it where strips start and end: wavefront-uniform, so that step() tests a scalar).  A code above 4 among the target
-	 * bytes sets bit 31 of `seen`: still reported (K2aResult.pad[0]) */
+	/* TN builds: hasn = this lane's strip holds a target wildcard row; wn = some lane of the wavefront does (the kernels refresh it
+	 * where strips start and end: wavefront-uniform, so that step() tests a scalar) */
 	uint32_t hasn;
 	bool wn;
 	const uint32_t *cptab;              /* the column profiles (K2aScoring.cp), in LDS on the device */
@@ -367,8 +369,7 @@ struct K2aLanePk {
 			__builtin_memcpy(&da, tpa + c4, 4); __builtin_memcpy(&db, tpb + c4, 4);
 			if (c4 + 4 > C) { da &= 0xffffu; db &= 0xffffu; }     /* (C = 18: the last two rows' dword reaches into the next strip, which reports them itself) */
 			note_codes(da, db);
-			if (sc.pk_tn1 && ((da | db) & 0x04040404u)) {             /* a wildcard among these rows' target codes (rare; lane by lane) */
-				if (k2a_codes_above4(da) | k2a_codes_above4(db)) seen |= 0x80000000u;      /* a code above 4: still reported */
+			if (TN && sc.pk_tn1 && ((da | db) & 0x04040404u)) {       /* a wildcard among these rows' target codes (rare; lane by lane) */
 				hasn = 1;
 #pragma unroll
 				for (int r = 0; r < 4 && c4 + r < C; ++r) set_tc(c4 + r, k2a_tsel_wild(k2a_byte_pair(da, db, r)));
@@ -456,7 +457,7 @@ struct K2aLanePk {
 				/* H(i-1,j-1) + s(i,j) + e: the row's penalty bytes { smax - s(tA, qA), 0, smax - s(tB, qB), 0 } out of the column profiles */
 				cand[r] = k2a_sub32(k2a_add32(up, bias), k2a_perm(cpB, cpA, tc(c)));
 			}
-			if (wn) {                                            /* a target wildcard row somewhere in the wavefront (scalar test): its constant penalty */
+			if (TN && wn) {                                      /* a target wildcard row somewhere in the wavefront (scalar test): its constant penalty */
 #pragma unroll
 				for (int r = 0; r < CH; ++r) cand[r] = k2a_tn_fix(cand[r], tc(c0 + r), sc.pk_tn1);
 			}
@@ -550,7 +551,7 @@ struct K2aLanePk {
 		a = k2a_load_early(qa + jc); b = k2a_load_early(qbp + jc);
 	}
 	K2A_FN void note_codes(uint32_t a, uint32_t b) { seen |= a | b; }
-	K2A_FN bool saw_wildcard(const K2aScoring &sc) const { return (seen & (sc.pk_tn1 ? 0xf8f8f8f8u : 0xfcfcfcfcu)) != 0; }
+	K2A_FN bool saw_wildcard() const { return (seen & 0xfcfcfcfcu) != 0; }      /* (with K2aScoring.pk_tn1 the kernels' own look at the targets decides: k2a_scan_codes) */
 	K2A_FN void reload_query_group(int k)                      /* from the init branch: this strip started at step k, inside a group */
 	{
 		const int j = (k & ~3) - koff;                             /* < 0: the strip's column 0 comes -j steps into the group */

@@ -48,9 +48,9 @@ K2A_FN void k2a_key_max(unsigned long long *slot, unsigned long long key) { if (
 K2A_FN unsigned long long k2a_key_load(const unsigned long long *slot) { return *slot; }
 #endif
 
-template<int C, bool DUAL, int MODE>
+template<int C, bool DUAL, int MODE, bool TN = false>
 struct K2aLanePkMp {
-	typedef K2aLanePk<64, C, DUAL, MODE, true, false, 0> Pk;
+	typedef K2aLanePk<64, C, DUAL, MODE, true, false, 0, false, TN> Pk;
 	enum { G = 64, TBWORDS = Pk::TBWORDS, FIRSTJ = (!DUAL && MODE == K2A_MODE_RIGHT) };    /* extz + RIGHT + CIGAR: ties to the first column */
 	Pk P;
 	unsigned long long *spill;          /* this lane's C x 2 keys: spill[c * 2 + half] (per-wavefront block, lane-major) */

@@ -34,7 +34,7 @@ K2A_FN size_t k2a_solo_steps(int qlen, int tlen, int w)
 	return nds > 0 ? (size_t)(2 * (nds - 1) + 2 + k2a_min(qlen - 1, tlen - 1 + w)) : 0;
 }
 
-template<int C, bool DUAL, int MODE = K2A_MODE_SCORE>
+template<int C, bool DUAL, int MODE = K2A_MODE_SCORE, bool TN = false>      /* TN: K2aLanePk */
 struct K2aLaneSolo {
 	enum { G = 64, TBWORDS = C / 2 };
 	int qlen, tlen, tlen_full, w, nds;      /* nds = double strips */
@@ -53,7 +53,7 @@ struct K2aLaneSolo {
 	uint32_t hasn;                          /* target wildcard rows, as in K2aLanePk (K2aScoring.pk_tn1) */
 	bool wn;
 	K2A_FN void note_codes(uint32_t a) { seen |= a; }
-	K2A_FN bool saw_wildcard(const K2aScoring &sc) const { return (seen & (sc.pk_tn1 ? 0xf8f8f8f8u : 0xfcfcfcfcu)) != 0; }
+	K2A_FN bool saw_wildcard() const { return (seen & 0xfcfcfcfcu) != 0; }
 	k2a_pk hl[C], f[C], f2[DUAL ? C : 1], rmax[C], rmj[C], tc[C], hsave[C];      /* tc: per row the v_perm_b32 selector { t(row c), 0x0c, 4 + t(row C + c), 0x0c } */
 
 	K2A_FN static int first_col(int D_, int w_) { return k2a_max(0, D_ * 2 * C - w_); }
@@ -137,8 +137,7 @@ struct K2aLaneSolo {
 		for (int c4 = 0; c4 < C; c4 += 4) {
 			const uint32_t da = tnA[c4 / 4], db = tnB[c4 / 4];             /* prefetch_next(), one strip ago */
 			note_codes(da | db);                                           /* (rows past the target's end read the arena's next bytes: at worst a needless re-run) */
-			if (sc.pk_tn1 && ((da | db) & 0x04040404u)) {                       /* a wildcard among these rows' target codes (K2aLanePk::do_init) */
-				if (k2a_codes_above4(da) | k2a_codes_above4(db)) seen |= 0x80000000u;      /* a code above 4: still reported */
+			if (TN && sc.pk_tn1 && ((da | db) & 0x04040404u)) {                 /* a wildcard among these rows' target codes (K2aLanePk::do_init) */
 				hasn = 1;
 #pragma unroll
 				for (int r = 0; r < 4; ++r) tc[c4 + r] = k2a_tsel_wild(k2a_byte_pair(da, db, r));
@@ -252,7 +251,7 @@ struct K2aLaneSolo {
 				const int c = c0 + r;
 				cand[r] = k2a_sub32(k2a_add32(r == 0 ? above_old : hl[c - 1], bias), k2a_perm(cpB, cpA, tc[c]));
 			}
-			if (wn) {                                                /* a target wildcard row somewhere in the wavefront (K2aLanePk::step) */
+			if (TN && wn) {                                          /* a target wildcard row somewhere in the wavefront (K2aLanePk::step) */
 #pragma unroll
 				for (int r = 0; r < CH; ++r) cand[r] = k2a_tn_fix(cand[r], tc[c0 + r], sc.pk_tn1);
 			}

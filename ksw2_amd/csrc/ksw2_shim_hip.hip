@@ -273,31 +273,54 @@ __device__ __forceinline__ void k2a_cptab_fill(const K2aScoring &sc, uint32_t *t
 	__builtin_amdgcn_wave_barrier();
 }
 
-/* target wildcard rows (K2aLanePk::wn): "some lane of this wavefront holds one", refreshed where strips start and end */
+/* Target wildcards in the packed kernels (K2aScoring.pk_tn1, round 6).  A wavefront-task first LOOKS at its targets (k2a_scan_codes:
+ * a few microseconds against a task of milliseconds; unscanned arenas -- flat, streamed, uniform plans -- need no host pass for it) and
+ * then runs ONE of two builds of the kernel body: the plain one, or the TN one, whose lanes turn a wildcard row's selector into
+ * "penalty 0" and take the row's constant off its candidate in a branch that only steps with such a row in the wavefront enter
+ * (K2aLanePk<.., TN>).  That branch inside the plain build cost every batch 1-3 % (profiles/r6_ab_tn.txt); here the plain build is
+ * the code of round 5, and only wavefronts that hold a wildcard pay.  K2A_SYNC_WN: "some lane of this wavefront holds a wildcard row",
+ * refreshed where strips start and end.
+ * k2a_scan_codes: the codes >= 4 among target bytes [0, n) as seen by lane gl of a group of G: bit 0 = the wildcard (4), bit 1 = a code
+ * above 4 (reported like before: K2aResult.pad[0], the host re-runs the pair). */
 #define K2A_SYNC_WN(L) do { (L).wn = __builtin_amdgcn_ballot_w64((L).hasn != 0) != 0; } while (0)
+template<int G>
+__device__ __forceinline__ uint32_t k2a_scan_codes(const uint8_t *__restrict__ t, int n, int gl)
+{
+	uint32_t acc = 0, hi = 0;
+	/* sixteen bytes per lane and round, the four loads in flight together (unaligned dword loads, as everywhere; the arena is readable
+	 * past a sequence's end -- what lies there is masked off) */
+	for (int x = gl * 16; x < n; x += G * 16) {
+		uint32_t d[4];
+#pragma unroll
+		for (int y = 0; y < 4; ++y) __builtin_memcpy(&d[y], t + x + 4 * y, 4);
+#pragma unroll
+		for (int y = 0; y < 4; ++y) {
+			const int left = n - (x + 4 * y);                  /* bytes of this dword inside the target */
+			const uint32_t v = left >= 4 ? d[y] : left > 0 ? d[y] & ((1u << (8 * left)) - 1u) : 0u;
+			acc |= v;
+			if (v & 0x04040404u) hi |= k2a_codes_above4(v);
+		}
+	}
+	return ((acc & 0x04040404u) ? 1u : 0u) | ((hi | (acc & 0xf8f8f8f8u)) ? 2u : 0u);
+}
 
-/* Packed-int16 resident fill: two same-shape alignments per lane group (ksw2_lane_pk.h). */
-template<int G, int C, bool DUAL, int MODE, bool RB, bool NOMAX, int LDSROW = 0, bool DEFER = false, bool QUEUE = false>      /* LDSROW: 1 = row state in LDS, 2 = only the target-code planes; DEFER: K2aLanePk; QUEUE: streamed launches */
-__global__ void __launch_bounds__(64 * K2A_WPB, LDSROW == 2 ? (G == 16 ? 4 : 3) : LDSROW ? 2 : 1)      /* no floor elsewhere: capping the register form of the score-only kernels at 168 VGPRs spills and is 18 % slower */
-k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
-                   const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, K2aResult *__restrict__ res, K2aQueueDesc *qd)
+/* Packed-int16 resident fill: two same-shape alignments per lane group (ksw2_lane_pk.h).  k2a_fill_pk_body = one wavefront-task, in the
+ * plain build or the TN one (target wildcard rows, see k2a_scan_codes); scan = what the task's look at its targets found (TN: bit 1 per
+ * lane = a code above 4 in its group's targets). */
+template<int G, int C, bool DUAL, int MODE, bool RB, bool NOMAX, int LDSROW, bool DEFER, bool TN>
+__device__ __forceinline__ void
+k2a_fill_pk_body(const K2aScoring &sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
+                 const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, K2aResult *__restrict__ res,
+                 int wt, int wave, int lane, int grp, int gl, bool scan_on, uint32_t scan,
+                 K2aBook (*book)[64 / G][2], uint32_t *stage_w, uint32_t *lrows, uint32_t (*cptab)[8], uint4 *tbstage, unsigned long long *tbruns)
 {
 	constexpr int NG = 64 / G;
-	typedef K2aLanePk<G, C, DUAL, MODE, RB, NOMAX, LDSROW, DEFER> Lane;
-	__shared__ K2aBook book[K2A_WPB][NG][2];
-	__shared__ uint32_t stage[K2A_WPB][(NG * K2A_PK_STAGE(C) > 64 * 5) ? NG * K2A_PK_STAGE(C) : 64 * 5];   /* row buffers / final lane records */
+	typedef K2aLanePk<G, C, DUAL, MODE, RB, NOMAX, LDSROW, DEFER, TN> Lane;
+	constexpr int LROW_WORDS = LDSROW == 1 ? K2A_PK_LDSROW_WORDS(C) : LDSROW == 2 ? K2A_PK_LDSCODE_WORDS(C) : 0;
+	constexpr int WB = Lane::TBWORDS * 4;
+	constexpr bool STAGED = MODE != K2A_MODE_SCORE && (WB == 16 || WB == 32);
+	typedef K2aTbStage<STAGED ? WB : 16, K2A_PK_TB_NS(WB, LDSROW)> Stage;
 
-	const int lane = threadIdx.x & 63, wave = k2a_wave_id<(C <= 8 || LDSROW || (NOMAX && DUAL && MODE != K2A_MODE_SCORE))>();   /* 16 rows, two-piece, traceback: part of what gets those kernels to two wavefronts */
-	const int grp = lane / G, gl = lane % G;
-	/* one wavefront-task (NG tasks) per wavefront, by position in the grid; the QUEUE builds (streamed launches) first wait for the
-	 * task's inputs (k2a_queue_wait) */
-	const int wt = blockIdx.x * K2A_WPB + wave;
-	if (DEFER && blockIdx.x == 0 && threadIdx.x == 0) {      /* the list of frozen books (k2a_argmax_kernel fills it, k2a_zscan_kernel works it off): empty */
-		uint32_t *zlist = (uint32_t*)(tb + pairs[order2[0]].tb_off) - K2A_ZLIST_WORDS(ntasks);
-		__hip_atomic_store(&zlist[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	}
-	if (QUEUE && !k2a_queue_wait(qd, wt)) return;
-	{
 	const int task = wt * NG + grp;
 	const bool valid = task < ntasks;
 	const uint32_t piA = order2[valid ? 2 * task : 0], piB = order2[valid ? 2 * task + 1 : 0];
@@ -306,9 +329,6 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	/* a Z-drop test anywhere in the wavefront selects the sequential strip epilogue for all of it */
 	const bool zseq = NOMAX || RB || __builtin_amdgcn_ballot_w64(valid && (zdropA >= 0 || zdropB >= 0)) != 0;   /* NOMAX: books only */
 
-	constexpr int LROW_WORDS = LDSROW == 1 ? K2A_PK_LDSROW_WORDS(C) : LDSROW == 2 ? K2A_PK_LDSCODE_WORDS(C) : 0;
-	__shared__ uint32_t lrows[LDSROW ? K2A_WPB * LROW_WORDS : 1];   /* per-row maxima / arg-max / target codes of the LDSROW classes */
-	__shared__ uint32_t cptab[K2A_WPB][8];
 	k2a_cptab_fill(sc, cptab[wave], lane);
 	Lane L;
 	L.lrow = &lrows[LDSROW ? wave * LROW_WORDS + lane : 0];
@@ -333,11 +353,6 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	L.load_query_group(0, L.knext == 0 ? L.koff_next : L.koff, L.qwA, L.qwB);
 	const size_t tbsteps = (size_t)(klast + 1);
 	uint8_t *tbp = tb + prA.tb_off;
-	constexpr int WB = Lane::TBWORDS * 4;
-	constexpr bool STAGED = MODE != K2A_MODE_SCORE && (WB == 16 || WB == 32);
-	typedef K2aTbStage<STAGED ? WB : 16, K2A_PK_TB_NS(WB, LDSROW)> Stage;
-	__shared__ uint4 tbstage[STAGED ? K2A_WPB * Stage::WORDS : 1];
-	__shared__ unsigned long long tbruns[STAGED ? K2A_WPB * 64 : 1];
 	Stage ST;
 	if (STAGED) ST.init(&tbstage[wave * Stage::WORDS], &tbruns[wave * 64], lane, tbp + k2a_tb_word(0, gl, tbsteps, G, WB));
 	int kdone = -1;
@@ -371,7 +386,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 				if (k & 3) L.reload_query_group(k);                /* the group was fetched under the previous strip's offset */
 				if (ckon) { K2aCkHead h; h.baseA = L.baseA; h.baseB = L.baseB; h.hd0 = L.hd0; h.pad = 0; ckhd[L.S] = h; }
 			}
-			K2A_SYNC_WN(L);
+			if (TN) K2A_SYNC_WN(L);
 		}
 		L.hu_prev = hin;
 		if (RB) { hin = k2a_pk_add(hin, L.delta); ein = k2a_pk_add(ein, L.delta); if (DUAL) e2in = k2a_pk_add(e2in, L.delta); }
@@ -394,7 +409,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 		const bool nfin = L.need_fin(k);
 		const uint64_t finmask = __builtin_amdgcn_ballot_w64(nfin);
 		if (finmask != 0) {
-			uint32_t *rowbuf = &stage[wave][grp * K2A_PK_STAGE(C)];
+			uint32_t *rowbuf = &stage_w[grp * K2A_PK_STAGE(C)];
 			if (NOMAX) {
 				if (nfin) L.fin_score_only(sc, bkA, bkB);
 			} else if (zseq) {
@@ -414,7 +429,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 				if (nfin) L.end_strip();
 				__builtin_amdgcn_wave_barrier();
 			}
-			if (L.wn) K2A_SYNC_WN(L);
+			if (TN && L.wn) K2A_SYNC_WN(L);
 		}
 		if (zseq && __builtin_amdgcn_ballot_w64(!(gdone || k >= klast)) == 0) { stop = true; break; }   /* only a Z-drop ends a group early */
 	}
@@ -424,7 +439,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 	__builtin_amdgcn_wave_barrier();
 	if (!zseq) {
 		/* merge the lane-local bests of each group; the lane that finished the last target row adds mte / score */
-		uint32_t *loc = &stage[wave][0];
+		uint32_t *loc = &stage_w[0];
 		loc[lane * 5 + 0] = L.lmax; loc[lane * 5 + 1] = L.lmax_t; loc[lane * 5 + 2] = L.lmax_q;
 		loc[lane * 5 + 3] = L.lmqe; loc[lane * 5 + 4] = L.lmqe_t;
 		__builtin_amdgcn_wave_barrier();
@@ -443,7 +458,7 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 		__builtin_amdgcn_wave_barrier();
 	}
 	/* a code >= 4 among the bytes this group read: only an unscanned (flat) plan can get here with one; the host re-runs the pair */
-	const uint64_t sawmask = __builtin_amdgcn_ballot_w64(valid && L.saw_wildcard(sc));
+	const uint64_t sawmask = __builtin_amdgcn_ballot_w64(valid && (scan_on ? (scan & 2u) != 0 : L.saw_wildcard()));
 	const bool gsaw = ((sawmask >> (grp * G)) & (G == 64 ? ~0ull : (1ull << (G & 63)) - 1)) != 0;
 	if (valid && gl == 0) {
 		const K2aBook a = *bkA, b = *bkB;
@@ -451,6 +466,52 @@ k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const
 		if (piB != piA) k2a_finish(prB, b, &res[piB]);
 		if (gsaw) { res[piA].pad[0] = 1; res[piB].pad[0] = 1; }
 	}
+}
+
+template<int G, int C, bool DUAL, int MODE, bool RB, bool NOMAX, int LDSROW = 0, bool DEFER = false, bool QUEUE = false>      /* LDSROW: 1 = row state in LDS, 2 = only the target-code planes; DEFER: K2aLanePk; QUEUE: streamed launches */
+__global__ void __launch_bounds__(64 * K2A_WPB, LDSROW == 2 ? (G == 16 ? 4 : 3) : LDSROW ? 2 : 1)      /* no floor elsewhere: capping the register form of the score-only kernels at 168 VGPRs spills and is 18 % slower */
+k2a_fill_pk_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
+                   const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, K2aResult *__restrict__ res, K2aQueueDesc *qd)
+{
+	constexpr int NG = 64 / G;
+	typedef K2aLanePk<G, C, DUAL, MODE, RB, NOMAX, LDSROW, DEFER, false> Lane;      /* (sizes only: both builds of the body have the same) */
+	__shared__ K2aBook book[K2A_WPB][NG][2];
+	__shared__ uint32_t stage[K2A_WPB][(NG * K2A_PK_STAGE(C) > 64 * 5) ? NG * K2A_PK_STAGE(C) : 64 * 5];   /* row buffers / final lane records */
+
+	const int lane = threadIdx.x & 63, wave = k2a_wave_id<(C <= 8 || LDSROW || (NOMAX && DUAL && MODE != K2A_MODE_SCORE))>();   /* 16 rows, two-piece, traceback: part of what gets those kernels to two wavefronts */
+	const int grp = lane / G, gl = lane % G;
+	/* one wavefront-task (NG tasks) per wavefront, by position in the grid; the QUEUE builds (streamed launches) first wait for the
+	 * task's inputs (k2a_queue_wait) */
+	const int wt = blockIdx.x * K2A_WPB + wave;
+	if (DEFER && blockIdx.x == 0 && threadIdx.x == 0) {      /* the list of frozen books (k2a_argmax_kernel fills it, k2a_zscan_kernel works it off): empty */
+		uint32_t *zlist = (uint32_t*)(tb + pairs[order2[0]].tb_off) - K2A_ZLIST_WORDS(ntasks);
+		__hip_atomic_store(&zlist[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	if (QUEUE && !k2a_queue_wait(qd, wt)) return;
+	constexpr int LROW_WORDS = LDSROW == 1 ? K2A_PK_LDSROW_WORDS(C) : LDSROW == 2 ? K2A_PK_LDSCODE_WORDS(C) : 0;
+	__shared__ uint32_t lrows[LDSROW ? K2A_WPB * LROW_WORDS : 1];   /* per-row maxima / arg-max / target codes of the LDSROW classes */
+	__shared__ uint32_t cptab[K2A_WPB][8];
+	constexpr int WB = Lane::TBWORDS * 4;
+	constexpr bool STAGED = MODE != K2A_MODE_SCORE && (WB == 16 || WB == 32);
+	typedef K2aTbStage<STAGED ? WB : 16, K2A_PK_TB_NS(WB, LDSROW)> Stage;
+	__shared__ uint4 tbstage[STAGED ? K2A_WPB * Stage::WORDS : 1];
+	__shared__ unsigned long long tbruns[STAGED ? K2A_WPB * 64 : 1];
+	/* the task's look at its targets (k2a_scan_codes), then the plain or the TN build of the body */
+	const int task = wt * NG + grp;
+	uint32_t scan = 0;
+	const bool scan_on = sc.pk_tn1 != 0;
+	if (scan_on && task < ntasks) {
+		const K2aPair pa = pairs[order2[2 * task]], pb = pairs[order2[2 * task + 1]];
+		scan = k2a_scan_codes<G>(seq + pa.toff, pa.tlen_full, gl) | k2a_scan_codes<G>(seq + pb.toff, pb.tlen_full, gl);
+	}
+	{	/* per group: what any of its lanes saw */
+		const uint64_t m1 = __builtin_amdgcn_ballot_w64((scan & 1u) != 0), m2 = __builtin_amdgcn_ballot_w64((scan & 2u) != 0);
+		const uint64_t gm = (G == 64 ? ~0ull : (1ull << (G & 63)) - 1) << (grp * G);
+		scan = ((m1 & gm) ? 1u : 0u) | ((m2 & gm) ? 2u : 0u);
+		if (m1 != 0)
+			k2a_fill_pk_body<G, C, DUAL, MODE, RB, NOMAX, LDSROW, DEFER, true>(sc, pairs, order2, ntasks, seq, tb, res, wt, wave, lane, grp, gl, scan_on, scan, book, stage[wave], lrows, cptab, tbstage, tbruns);
+		else
+			k2a_fill_pk_body<G, C, DUAL, MODE, RB, NOMAX, LDSROW, DEFER, false>(sc, pairs, order2, ntasks, seq, tb, res, wt, wave, lane, grp, gl, scan_on, scan, book, stage[wave], lrows, cptab, tbstage, tbruns);
 	}
 }
 
@@ -471,7 +532,7 @@ k2a_argmax_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const 
 	 * would index strips megabytes past the task's block.  Nothing to do here then: the host repeats the whole plan unstreamed. */
 	if (qd && (__hip_atomic_load(&qd->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
 	           __hip_atomic_load(&qd->next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != qd->nwt)) return;
-	typedef K2aLanePk<G, C, false, K2A_MODE_SCORE, RB, false, 0, false> Lane;
+	typedef K2aLanePk<G, C, false, K2A_MODE_SCORE, RB, false, 0, false, true> Lane;      /* (the TN build: a re-run strip may hold a target wildcard row) */
 	const int job = blockIdx.x * (64 * K2A_WPB) + threadIdx.x;
 	const int task = job / 3, which = job - 3 * task;
 	bool go = task < ntasks;
@@ -551,7 +612,7 @@ k2a_zscan_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const u
 	constexpr int NG = 64 / G, ZG = 16, ZNG = 64 / ZG;
 	if (qd && (__hip_atomic_load(&qd->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
 	           __hip_atomic_load(&qd->next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != qd->nwt)) return;
-	typedef K2aLanePk<G, C, false, K2A_MODE_SCORE, RB, false, 0, false> Lane;
+	typedef K2aLanePk<G, C, false, K2A_MODE_SCORE, RB, false, 0, false, true> Lane;      /* (the TN build: a re-run strip may hold a target wildcard row) */
 	__shared__ uint32_t stage[K2A_WPB][64][K2A_PK_STAGE(C)];
 	__shared__ K2aBook book[K2A_WPB][ZNG];
 	__shared__ int done[K2A_WPB][ZNG];
@@ -644,22 +705,18 @@ k2a_zscan_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const u
 /* Packed-int16 fill of ONE alignment per wavefront on both register halves (ksw2_lane_solo.h): reads without a partner of
  * identical shape.  The high half's bottom row goes to the next lane's low half (wave_ror:1 + v_alignbit), the low half's
  * bottom row to the lane's own high half one step later. */
-template<int C, bool DUAL, int MODE>
-__global__ void __launch_bounds__(64 * K2A_WPB)
-k2a_fill_solo_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
-                     const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, K2aResult *__restrict__ res)
+template<int C, bool DUAL, int MODE, bool TN>
+__device__ __forceinline__ void
+k2a_fill_solo_body(const K2aScoring &sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
+                   const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, K2aResult *__restrict__ res, int task, int wave, int lane, bool scan_on, uint32_t scan,
+                   K2aBook *book, uint32_t (*stage)[K2A_SOLO_STAGE(C)], uint32_t (*cptab)[8], uint4 *tbstage, unsigned long long *tbruns)
 {
-	typedef K2aLaneSolo<C, DUAL, MODE> Lane;
-	__shared__ K2aBook book[K2A_WPB];
-	__shared__ uint32_t stage[K2A_WPB][K2A_SOLO_STAGE(C)];
+	typedef K2aLaneSolo<C, DUAL, MODE, TN> Lane;
 
-	const int lane = threadIdx.x & 63, wave = k2a_wave_id<true>();
-	const int task = blockIdx.x * K2A_WPB + wave;
 	const bool valid = task < ntasks;
 	const uint32_t pi = order[valid ? task : 0];
 	const K2aPair pr = pairs[pi];
 
-	__shared__ uint32_t cptab[K2A_WPB][8];
 	k2a_cptab_fill(sc, cptab[wave], lane);
 	Lane L;
 	L.setup(pr, seq, lane, valid, cptab[wave]);
@@ -677,8 +734,6 @@ k2a_fill_solo_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 	constexpr int WB = Lane::TBWORDS * 4;
 	constexpr bool STAGED = MODE != K2A_MODE_SCORE && (WB == 16 || WB == 32);
 	typedef K2aTbStage<STAGED ? WB : 16, 8> Stage;
-	__shared__ uint4 tbstage[STAGED ? K2A_WPB * Stage::WORDS : 1];
-	__shared__ unsigned long long tbruns[STAGED ? K2A_WPB * 64 : 1];
 	Stage ST;
 	if (STAGED) ST.init(&tbstage[wave * Stage::WORDS], &tbruns[wave * 64], lane, tbp + k2a_tb_word(0, lane, tbsteps, 64, WB));
 	int kdone = -1;
@@ -699,7 +754,7 @@ k2a_fill_solo_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 		if (__builtin_amdgcn_ballot_w64(ninit) != 0) {
 			const int bs = k2a_rot1<64>(L.baseB);
 			if (ninit) L.do_init(sc, bs);                      /* uses hu_prev = what arrived one step ago; brings its first query group along */
-			K2A_SYNC_WN(L);
+			if (TN) K2A_SYNC_WN(L);
 		}
 		const bool nhigh = L.need_init_high(k);
 		if (__builtin_amdgcn_ballot_w64(nhigh) != 0) {
@@ -734,7 +789,7 @@ k2a_fill_solo_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 				__builtin_amdgcn_wave_barrier();
 				if (bk->dropped) { stop = true; break; }
 			}
-			if (L.wn) K2A_SYNC_WN(L);
+			if (TN && L.wn) K2A_SYNC_WN(L);
 		}
 	}
 	L.qw = qp;
@@ -742,12 +797,41 @@ k2a_fill_solo_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 	if (STAGED) ST.finish(kdone);
 	__builtin_amdgcn_wave_barrier();
 	/* a code >= 4 among the bytes this wavefront read: only an unscanned (flat) plan can get here with one; the host re-runs the pair */
-	const bool saw = __builtin_amdgcn_ballot_w64(valid && L.saw_wildcard(sc)) != 0;
+	const bool saw = scan_on ? (scan & 2u) != 0 : __builtin_amdgcn_ballot_w64(valid && L.saw_wildcard()) != 0;
 	if (valid && lane == 0) {
 		const K2aBook b = *bk;
 		k2a_finish(pr, b, &res[pi]);
 		if (saw) res[pi].pad[0] = 1;
 	}
+}
+
+/* the wavefront-task looks at its target first (k2a_scan_codes) and takes the plain or the TN build of the body */
+template<int C, bool DUAL, int MODE>
+__global__ void __launch_bounds__(64 * K2A_WPB)
+k2a_fill_solo_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
+                     const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, K2aResult *__restrict__ res)
+{
+	typedef K2aLaneSolo<C, DUAL, MODE, false> Lane;      /* (sizes only) */
+	constexpr int WB = Lane::TBWORDS * 4;
+	constexpr bool STAGED = MODE != K2A_MODE_SCORE && (WB == 16 || WB == 32);
+	typedef K2aTbStage<STAGED ? WB : 16, 8> Stage;
+	__shared__ K2aBook book[K2A_WPB];
+	__shared__ uint32_t stage[K2A_WPB][K2A_SOLO_STAGE(C)];
+	__shared__ uint32_t cptab[K2A_WPB][8];
+	__shared__ uint4 tbstage[STAGED ? K2A_WPB * Stage::WORDS : 1];
+	__shared__ unsigned long long tbruns[STAGED ? K2A_WPB * 64 : 1];
+	const int lane = threadIdx.x & 63, wave = k2a_wave_id<true>();
+	const int task = blockIdx.x * K2A_WPB + wave;
+	const bool scan_on = sc.pk_tn1 != 0;
+	uint32_t scan = 0;
+	if (scan_on && task < ntasks) {
+		const K2aPair pr = pairs[order[task]];
+		scan = k2a_scan_codes<64>(seq + pr.toff, pr.tlen_full, lane);
+	}
+	const bool any4 = __builtin_amdgcn_ballot_w64((scan & 1u) != 0) != 0;
+	scan = (any4 ? 1u : 0u) | (__builtin_amdgcn_ballot_w64((scan & 2u) != 0) != 0 ? 2u : 0u);
+	if (any4) k2a_fill_solo_body<C, DUAL, MODE, true>(sc, pairs, order, ntasks, seq, tb, res, task, wave, lane, scan_on, scan, book, stage, cptab, tbstage, tbruns);
+	else k2a_fill_solo_body<C, DUAL, MODE, false>(sc, pairs, order, ntasks, seq, tb, res, task, wave, lane, scan_on, scan, book, stage, cptab, tbstage, tbruns);
 }
 
 template<int C>
@@ -985,31 +1069,23 @@ k2a_trace_pk_kernel(const K2aPair *__restrict__ pairs, const uint32_t *__restric
  * phase, and generation g + 1 starts k2a_pkmp_lag phases after generation g -- late enough that every boundary column it reads
  * was written in an earlier phase and that its strip epilogues (row order!) come after all of generation g's.  The schedule
  * (start phase of every generation) is a function of the shape alone and is tabulated once per workgroup. */
-template<bool DUAL, int MODE>
-__global__ void __launch_bounds__(64 * K2A_PKMP_WAVES, K2A_PKMP_WAVES > 4 ? 3 : 2)
-k2a_fill_pkmp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
-                     const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, uint32_t *bnd, K2aResult *__restrict__ res)
+template<bool DUAL, int MODE, bool TN>
+__device__ __forceinline__ void
+k2a_fill_pkmp_body(const K2aScoring &sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
+                   const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, uint32_t *bnd, K2aResult *__restrict__ res, int task, int wave, int lane,
+                   K2aBook *book, uint32_t (*rowbuf)[16], int *pstart, int *pcount, uint4 *tbstage, unsigned long long *tbruns, uint32_t (*cptab)[8])
 {
 	constexpr int C = 16, G = 64, W = K2A_PKMP_WAVES, T = K2A_PKMP_T, R = G * C;
-	typedef K2aLanePkMp<C, DUAL, MODE> Lane;
+	typedef K2aLanePkMp<C, DUAL, MODE, TN> Lane;
 	constexpr int WB = Lane::TBWORDS * 4;                 /* 16 bytes (single gap: 4-bit codes) or 32 per lane-step */
 	constexpr bool STAGED = MODE != K2A_MODE_SCORE;
 	typedef K2aTbStage<WB, 8> Stage;
-	__shared__ K2aBook book[2];
-	__shared__ uint32_t rowbuf[W][C];
-	__shared__ int pstart[64 + 1], pcount[64];            /* start phase / phases of every generation (at most 64: reads up to 65 000) */
-	__shared__ uint4 tbstage[STAGED ? W * Stage::WORDS : 1];
-	__shared__ unsigned long long tbruns[STAGED ? W * 64 : 1];
 
-	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	const int task = blockIdx.x;
-	if (task >= ntasks) return;
 	const uint32_t piA = order2[2 * task], piB = order2[2 * task + 1];
 	const K2aPair prA = pairs[piA], prB = pairs[piB];
 	const int qlen = prA.qlen, tlen = prA.tlen, w = prA.w;
 	const int ngen = (tlen + R - 1) / R;
 
-	__shared__ uint32_t cptab[W][8];
 	k2a_cptab_fill(sc, cptab[wave], lane);
 	Lane L;
 	/* the task's block of `bnd`: boundary entries, then one block of row-maximum keys per wavefront */
@@ -1105,7 +1181,7 @@ k2a_fill_pkmp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 					if (ninit) L.do_init(sc, bsA, bsB);                  /* uses hu_prev = what arrived one step ago */
 					bsA = k2a_rot1<G>(L.P.baseA); bsB = k2a_rot1<G>(L.P.baseB);
 					L.refresh_delta(bsA, bsB);                           /* a base changed: every lane re-reads its neighbour's */
-					K2A_SYNC_WN(L.P);
+					if (TN) K2A_SYNC_WN(L.P);
 				}
 				if (feeder) {
 					take(jlo + k, cur, cur2);
@@ -1134,7 +1210,7 @@ k2a_fill_pkmp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   /* the keys' atomics (performed at L2) are done; do_fin reads them past L1 */
 					if (nfin) L.do_fin(sc, bkA, bkB, zdropA, zdropB, rowbuf[wave]);
 					__builtin_amdgcn_wave_barrier();
-					if (L.P.wn) K2A_SYNC_WN(L.P);
+					if (TN && L.P.wn) K2A_SYNC_WN(L.P);
 				}
 				L.P.set_qb(qnext);                                       /* next step's codes and column profiles */
 				if ((k & (T - 1)) == T - 1) {
@@ -1162,6 +1238,38 @@ k2a_fill_pkmp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, con
 		k2a_finish(prA, a, &res[piA]);
 		if (piB != piA) k2a_finish(prB, b, &res[piB]);
 	}
+}
+
+/* every wavefront of the workgroup looks at the task's two targets (k2a_scan_codes; the same answer in all of them) and takes the plain
+ * or the TN build of the body */
+template<bool DUAL, int MODE>
+__global__ void __launch_bounds__(64 * K2A_PKMP_WAVES, K2A_PKMP_WAVES > 4 ? 3 : 2)
+k2a_fill_pkmp_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order2, int ntasks,
+                     const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, uint32_t *bnd, K2aResult *__restrict__ res)
+{
+	constexpr int C = 16, W = K2A_PKMP_WAVES;
+	typedef K2aLanePkMp<C, DUAL, MODE, false> Lane;       /* (sizes only) */
+	constexpr int WB = Lane::TBWORDS * 4;
+	constexpr bool STAGED = MODE != K2A_MODE_SCORE;
+	typedef K2aTbStage<WB, 8> Stage;
+	__shared__ K2aBook book[2];
+	__shared__ uint32_t rowbuf[W][C];
+	__shared__ int pstart[64 + 1], pcount[64];            /* start phase / phases of every generation (at most 64: reads up to 65 000) */
+	__shared__ uint4 tbstage[STAGED ? W * Stage::WORDS : 1];
+	__shared__ unsigned long long tbruns[STAGED ? W * 64 : 1];
+	__shared__ uint32_t cptab[W][8];
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int task = blockIdx.x;
+	if (task >= ntasks) return;
+	uint32_t scan = 0;
+	if (sc.pk_tn1) {
+		const K2aPair pa = pairs[order2[2 * task]], pb = pairs[order2[2 * task + 1]];
+		scan = k2a_scan_codes<64>(seq + pa.toff, pa.tlen_full, lane) | k2a_scan_codes<64>(seq + pb.toff, pb.tlen_full, lane);
+	}
+	if (__builtin_amdgcn_ballot_w64((scan & 1u) != 0) != 0)
+		k2a_fill_pkmp_body<DUAL, MODE, true>(sc, pairs, order2, ntasks, seq, tb, bnd, res, task, wave, lane, book, rowbuf, pstart, pcount, tbstage, tbruns, cptab);
+	else
+		k2a_fill_pkmp_body<DUAL, MODE, false>(sc, pairs, order2, ntasks, seq, tb, bnd, res, task, wave, lane, book, rowbuf, pstart, pcount, tbstage, tbruns, cptab);
 }
 
 /* ---------------------------------------------------------------- splice-aware extension, diagonal-major (ksw2_lane_dm.h) */

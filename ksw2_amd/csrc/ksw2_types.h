@@ -124,7 +124,7 @@ typedef struct K2aPair {
 typedef struct K2aResult {
 	int32_t max, zdropped, max_q, max_t, mqe, mqe_t, mte, mte_q, score, reach_end, n_cigar, rows_done;
 	int32_t ti, tj;                  /* traceback start cell chosen by k2a_finish(); -1 = no CIGAR          */
-	int32_t pad[2];                  /* [0]: a packed kernel read a wildcard code in a target (unscanned plans); [1]: deferred arg-max -- 1 = the fill stopped at a row whose Z-drop test needs columns and the second pass could not settle it: the host re-runs the pair; 2 = the second pass settled the drop */
+	int32_t pad[2];                  /* [0]: a packed kernel read a wildcard code in a target (unscanned plans); [1]: deferred arg-max -- 0 = exact (or settled on the device by the third pass, which rewrites the record through k2a_finish), 1 = the fill froze the book at a row whose Z-drop test needs columns and nothing settled it: the host re-runs the pair (needs_rerun).  No other value is written */
 } K2aResult;
 
 /* Streamed launches (ksw2_host_plan.c, "streamed plans"): ONE launch of a packed fill kernel over the whole batch, started under the

@@ -29,6 +29,13 @@ static void make_tabs(const K2aScoring &sc, uint32_t *tabs)
 	for (int x = 0; x < 5; ++x) { tabs[x] = sc.prof[x]; tabs[8 + x] = (uint32_t)sc.colw[x]; }
 }
 
+/* what k2a_scan_codes reports as "a code above 4" (the wavefront-task's look at its targets on the device) */
+static bool sim_codes_above4(const uint8_t *t, int n)
+{
+	for (int i = 0; i < n; ++i) if (t[i] > 4) return true;
+	return false;
+}
+
 template<int G, int C, bool DUAL, int MODE>
 static void sim_fill(const K2aScoring sc, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, uint8_t *tb,
                      K2aResult *res)
@@ -112,7 +119,7 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
                         K2aResult *res, K2aQueueDesc *qd)
 {
 	constexpr int NG = 64 / G;
-	typedef K2aLanePk<G, C, DUAL, MODE, RB, NOMAX, LDSROW, DEFER> Lane;
+	typedef K2aLanePk<G, C, DUAL, MODE, RB, NOMAX, LDSROW, DEFER, true> Lane;      /* the TN build everywhere: it is the plain one plus the wildcard rows (the device picks per wavefront-task, k2a_scan_codes) */
 	const int nwaves = (ntasks + NG - 1) / NG;
 	for (int wv = 0; wv < nwaves; ++wv) {
 		/* streamed launches (k2a_queue_wait): wavefront-tasks in grid order; the simulator's uploads are synchronous, so a piece
@@ -259,7 +266,8 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 		for (int lane = 0; lane < 64; ++lane)
 			if (valid[lane] && lane % G == 0) {
 				bool gsaw = false;
-				for (int l = lane; l < lane + G; ++l) gsaw |= L[l].saw_wildcard(sc);
+				if (sc.pk_tn1) gsaw = sim_codes_above4(seq + prA[lane].toff, prA[lane].tlen_full) || sim_codes_above4(seq + pairs[piB[lane]].toff, pairs[piB[lane]].tlen_full);      /* k2a_scan_codes */
+				else for (int l = lane; l < lane + G; ++l) gsaw |= L[l].saw_wildcard();
 				k2a_finish(prA[lane], book[lane / G][0], &res[piA[lane]]);
 				if (piB[lane] != piA[lane]) k2a_finish(pairs[piB[lane]], book[lane / G][1], &res[piB[lane]]);
 				if (gsaw) { res[piA[lane]].pad[0] = 1; res[piB[lane]].pad[0] = 1; }
@@ -272,7 +280,7 @@ template<int G, int C, bool RB>
 static void sim_argmax(const K2aScoring sc, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *seq, uint8_t *ck, K2aResult *res)
 {
 	constexpr int NG = 64 / G;
-	typedef K2aLanePk<G, C, false, K2A_MODE_SCORE, RB, false, 0, false> Lane;
+	typedef K2aLanePk<G, C, false, K2A_MODE_SCORE, RB, false, 0, false, true> Lane;
 	uint32_t *zlist = (uint32_t*)(ck + pairs[order2[0]].tb_off) - K2A_ZLIST_WORDS(ntasks);
 	zlist[0] = 0;                                         /* (the device's fill kernel does this) */
 	for (int job = 0; job < 3 * ntasks; ++job) {
@@ -319,7 +327,7 @@ template<int G, int C, bool RB>
 static void sim_zscan(const K2aScoring sc, const K2aPair *pairs, const uint32_t *order2, int ntasks, const uint8_t *seq, const uint8_t *ck, K2aResult *res)
 {
 	constexpr int NG = 64 / G, ZG = 16;
-	typedef K2aLanePk<G, C, false, K2A_MODE_SCORE, RB, false, 0, false> Lane;
+	typedef K2aLanePk<G, C, false, K2A_MODE_SCORE, RB, false, 0, false, true> Lane;
 	const uint32_t *zlist = (const uint32_t*)(ck + pairs[order2[0]].tb_off) - K2A_ZLIST_WORDS(ntasks);
 	for (uint32_t gi = 0; gi < zlist[0]; ++gi) {
 		const uint32_t ent = zlist[1 + gi];
@@ -865,7 +873,7 @@ static void sim_fill_pkmp(const K2aScoring sc, const K2aPair *pairs, const uint3
                           uint32_t *bnd, K2aResult *res)
 {
 	constexpr int C = 16, G = 64, W = K2A_PKMP_WAVES, T = K2A_PKMP_T, R = G * C;
-	typedef K2aLanePkMp<C, DUAL, MODE> Lane;
+	typedef K2aLanePkMp<C, DUAL, MODE, true> Lane;
 	constexpr int WB = Lane::TBWORDS * 4;
 	for (int task = 0; task < ntasks; ++task) {
 		static thread_local Lane L[64];
@@ -968,7 +976,7 @@ template<int C, bool DUAL, int MODE>
 static void sim_fill_solo(const K2aScoring sc, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, uint8_t *tb,
                           K2aResult *res)
 {
-	typedef K2aLaneSolo<C, DUAL, MODE> Lane;
+	typedef K2aLaneSolo<C, DUAL, MODE, true> Lane;
 	for (int task = 0; task < ntasks; ++task) {
 		const uint32_t pi = order[task];
 		const K2aPair pr = pairs[pi];
@@ -1024,7 +1032,8 @@ static void sim_fill_solo(const K2aScoring sc, const K2aPair *pairs, const uint3
 		}
 		k2a_finish(pr, book, &res[pi]);
 		bool saw = false;
-		for (int l = 0; l < 64; ++l) saw |= L[l].saw_wildcard(sc);
+		if (sc.pk_tn1) saw = sim_codes_above4(seq + pr.toff, pr.tlen_full);      /* k2a_scan_codes */
+		else for (int l = 0; l < 64; ++l) saw |= L[l].saw_wildcard();
 		if (saw) res[pi].pad[0] = 1;
 	}
 }
