@@ -606,13 +606,13 @@ ksw2amd_plan_t *ksw2amd_sse_plan_create(int dual, const ksw2amd_scoring_t *sc, i
 		mx = imax(a->qlen, a->tlen);
 		if (w < 0 || w > mx) w = mx;                                       /* a wider band than the sequences changes nothing (ksw2_extz2_sse.c:72) */
 		mode = (fl & KSW_EZ_SCORE_ONLY) ? K2A_MODE_SCORE : (fl & KSW_EZ_RIGHT) ? K2A_MODE_RIGHT : K2A_MODE_LEFT;
-		{	/* kernel form.  2: state in registers (k2a_ssec_blk_kernel: simple scoring, bands up to SSECB_SPAN positions;
+		{	/* kernel form.  2: state in registers (k2a_ssec_blk_kernel: simple scoring over at most five codes, bands up to SSECB_SPAN positions;
 			 * KSW2AMD_SSEC_BLK=0: never); 1: state arrays of up to SSEC_LDS_MAX bytes in LDS (k2a_ssec_kernel<.., LDS = true>);
 			 * 0: in HBM scratch (KSW2AMD_SSEC_HBM=1: always, tests) */
 			const size_t sb = (size_t)(dual ? 11 : 9) * (size_t)((a->tlen + 15) / 16 * 16);
 			const char *blk = ENV(SSEC_BLK);
 			int form = sb <= SSEC_LDS_MAX;
-			if (!(fl & KSW_EZ_GENERIC_SC) && imin(imin(a->qlen, a->tlen), w + 1) <= SSECB_SPAN && !(blk && blk[0] == '0')) form = 2;
+			if (!(fl & KSW_EZ_GENERIC_SC) && m <= 5 && imin(imin(a->qlen, a->tlen), w + 1) <= SSECB_SPAN && !(blk && blk[0] == '0')) form = 2;      /* (m <= 5: the register form's score profiles hold query codes 0..3 + the wildcard) */
 			if (ENV(SSEC_HBM)) form = 0;
 			p->h_cls[i] = (int8_t)(mode + 3 * form);
 			++p->s_count[mode][0][form];

@@ -69,6 +69,7 @@
 	X(EXTF_GRP) \
 	X(STREAM_LANES) \
 	X(WIRE4) \
+	X(WIRE2) \
 	X(PLAIN_UP_STREAMS) \
 	X(WORKER_PRIO) \
 	X(SSE_COMPAT) \
@@ -137,7 +138,8 @@ typedef struct {
 	uint8_t *d_seq, *d_wm;
 	const uint32_t *wm_src;
 	void *up;
-	int wire4, wire_bad;                   /* uniform plans: the staging buffer and the upload hold two codes per byte; a source byte above 15 was met (the batch is repeated on the general path) */
+	int wire4, wire_bad;                   /* uniform plans: the staging buffer and the upload hold 2^wire4 codes per byte (1: the 4-bit wire format, 2: the 2-bit one with escape entries, ksw2_lane.h); wire_bad: a source byte above 15, or more escapes in a pair than its slot holds (the batch is repeated on the general path) */
+	uint32_t wire_stride;                  /* ... the pairs' stride in the arena (the 2-bit format's escape slots end a pair's region) */
 	void *up2, *ev2[K2A_MAXPIECES];        /* two copy lanes (KSW2AMD_STREAM_LANES): odd pieces travel on a second stream, an event behind each (stream_issue) */
 	int rc;
 	pthread_mutex_t mu;

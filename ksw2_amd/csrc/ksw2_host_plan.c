@@ -1215,7 +1215,7 @@ ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc
 					need[wt] = nd;
 				}
 				p->h_qd[c->qd].nwt = (uint32_t)nwt; p->h_qd[c->qd].timeout_ticks = ticks;
-				p->h_qd[c->qd].pad = (uint32_t)at;             /* (host side only: where this class's piece counts start) */
+				p->h_qd[c->qd].unp_fmt = (uint32_t)at;         /* (host side only, until the loop below: where this class's piece counts start) */
 				at += (size_t)nwt;
 			}
 			p->need_words = at;
@@ -1256,7 +1256,7 @@ ksw2amd_plan_t *plan_create_ex(int dual, int scalar, const ksw2amd_scoring_t *sc
 		 * were busy with the pieces: round 4, every process but the first on a box.)  up_ev marks the end of the pieces: unstreamed
 		 * classes of the plan, a repeated run after an abort and plan_destroy wait for it. */
 		for (k = 0; k < p->nqd; ++k) {
-			p->h_qd[k].need = p->d_order + p->norder + p->h_qd[k].pad; p->h_qd[k].pad = 0;
+			p->h_qd[k].need = p->d_order + p->norder + p->h_qd[k].unp_fmt; p->h_qd[k].unp_fmt = 0;
 			p->h_qd[k].wm = (const uint32_t*)p->d_wm;
 		}
 		p->meta_ev = k2a_shim_event_create();
@@ -1408,7 +1408,14 @@ static ksw2amd_plan_t *plan_create_uniform(int dual, int scalar, const ksw2amd_s
 	p->cells = (int64_t)n * band_cells(pairs[0].qlen, pairs[0].tlen, w);
 	/* the arena: query 16-aligned, target 16-aligned and readable one strip past its end, like every gathered arena */
 	u->n = (uint32_t)n; u->ntasks = (uint32_t)(n / 2);
-	u->qpad = (uint32_t)align_up((size_t)pairs[0].qlen, 16); u->stride = u->qpad + (uint32_t)align_up((size_t)pairs[0].tlen + 64, 16);
+	/* the wire format (KSW2AMD_WIRE4=0: none; KSW2AMD_WIRE2=0: four bits per code): staging and upload hold two or four residue codes
+	 * per byte -- a half or a quarter of the bytes for the gather to write and for the DMA engines to move -- and every wavefront-task
+	 * expands its own pairs into the arena before it reads them (K2aQueueDesc.unp_*, k2a_queue_wait).  The pieces keep their pair
+	 * boundaries; all offsets of the upload side shift.  Two bits per code (round 6): codes above 3 travel as escape entries in the
+	 * last upload bytes of the pair's region (ksw2_lane.h, K2A_WIRE2_*), for which the target's padding grows by K2A_WIRE2_PAD */
+	wire4 = (ENV(WIRE4) && atoi(ENV(WIRE4)) == 0) ? 0 : (ENV(WIRE2) && atoi(ENV(WIRE2)) == 0) ? 1 : 2;
+	u->qpad = (uint32_t)align_up((size_t)pairs[0].qlen, 16); u->stride = u->qpad + (uint32_t)align_up((size_t)pairs[0].tlen + 64 + (wire4 == 2 ? K2A_WIRE2_PAD : 0), 16);
+	if (wire4 == 2 && u->stride >= (1u << 20)) { wire4 = 1; u->stride = u->qpad + (uint32_t)align_up((size_t)pairs[0].tlen + 64, 16); }      /* (an escape's offset has 20 bits) */
 	if ((uint64_t)n * u->stride > 0xfff00000u - 65536u) { g_err[0] = 0; goto na; }
 	p->seq_bytes = align_up((size_t)n * u->stride + 65536, 256);
 	u->seq_bytes = p->seq_bytes; u->margin = K2A_STREAM_MARGIN;
@@ -1428,12 +1435,8 @@ static ksw2amd_plan_t *plan_create_uniform(int dual, int scalar, const ksw2amd_s
 		p->tb_bytes = zl + (size_t)nwt * bytes;
 	}
 	u->tmpl = tm;
-	/* the 4-bit wire format (KSW2AMD_WIRE4=0: never): staging and upload hold two residue codes per byte -- half the bytes for the
-	 * gather to write and for the DMA engines to move -- and every wavefront-task expands its own pairs into the arena before it
-	 * reads them (K2aQueueDesc.unp_*, k2a_queue_wait).  The pieces keep their pair boundaries; all offsets of the upload side halve. */
-	wire4 = !(ENV(WIRE4) && atoi(ENV(WIRE4)) == 0);
 	/* page-locked staging, device arena, watermark: as every streamed plan */
-	p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, (wire4 ? p->seq_bytes / 2 : p->seq_bytes) + 256, &p->cap[BUF_HSEQ]);
+	p->h_seq = (uint8_t*)cache_get(BUF_HSEQ, (p->seq_bytes >> wire4) + 256, &p->cap[BUF_HSEQ]);
 	su = (stream_up_t*)calloc(1, sizeof(*su));
 	if (!p->h_seq || !su) { free(su); su = 0; fail(KSW2AMD_E_NOMEM, "pinned staging allocation failed: %s", k2a_shim_last_error()); goto err; }
 	p->up_state = su;
@@ -1443,7 +1446,7 @@ static ksw2amd_plan_t *plan_create_uniform(int dual, int scalar, const ksw2amd_s
 		const char *pk_ = ENV(STREAM_PIECE_KB);
 		pbytes = pk_ && atol(pk_) > 0 ? (size_t)atol(pk_) << 10 : p->seq_bytes / 24;
 		if (!(pk_ && atol(pk_) > 0)) { if (pbytes < ((size_t)1 << 20)) pbytes = (size_t)1 << 20; if (pbytes > ((size_t)32 << 20)) pbytes = (size_t)32 << 20; }
-		if (wire4 && pbytes < 2 * (size_t)K2A_WM_BYTES) pbytes = 2 * (size_t)K2A_WM_BYTES;      /* half of it travels: never a copy so small that the runtime moves it with a kernel (K2A_WM_BYTES) */
+		if (wire4 && pbytes < ((size_t)K2A_WM_BYTES << wire4)) pbytes = (size_t)K2A_WM_BYTES << wire4;      /* a half / a quarter of it travels: never a copy so small that the runtime moves it with a kernel (K2A_WM_BYTES) */
 		if (pbytes * (K2A_MAXPIECES - 1) < p->seq_bytes) pbytes = p->seq_bytes / (K2A_MAXPIECES - 1) + 1;
 		ppp = (pbytes + u->stride - 1) / u->stride;              /* pairs per piece: pieces start at pair boundaries (the copy's work units) */
 		if (ppp < 1) ppp = 1;
@@ -1454,9 +1457,9 @@ static ksw2amd_plan_t *plan_create_uniform(int dual, int scalar, const ksw2amd_s
 		const size_t first = (size_t)k * ppp < (size_t)n ? (size_t)k * ppp : (size_t)n;
 		su->pfirst[k] = (int)first; su->pb[k] = k < su->np ? first * u->stride : p->seq_bytes;
 		u->pb[k] = su->pb[k];
-		if (wire4) su->pb[k] >>= 1;                               /* (the device counts pieces in arena offsets, the upload moves half of them) */
+		su->pb[k] >>= wire4;                                      /* (the device counts pieces in arena offsets, the upload moves a half / a quarter of them) */
 	}
-	su->wire4 = wire4;
+	su->wire4 = wire4; su->wire_stride = u->stride;
 	u->npieces = (uint32_t)su->np;
 	su->wm_src = 0;
 	{
@@ -1466,9 +1469,9 @@ static ksw2amd_plan_t *plan_create_uniform(int dual, int scalar, const ksw2amd_s
 	su->up = shared_upload_stream();
 	su->up2 = stream_lanes(0) == 2 ? shared_upload_stream2() : 0;
 	su->fault = env_flag(ENV(STREAM_FAULT), 0); su->sleep_us = ENV(STREAM_SLEEP_US) ? atoi(ENV(STREAM_SLEEP_US)) : 0;
-	su->src = p->h_seq; su->src_bytes = wire4 ? p->seq_bytes / 2 : p->seq_bytes;
+	su->src = p->h_seq; su->src_bytes = p->seq_bytes >> wire4;
 	p->d_seq = (uint8_t*)cache_get(BUF_SEQ, p->seq_bytes, &p->cap[BUF_SEQ]);
-	if (wire4) d_pk = (uint8_t*)cache_get(BUF_PK4, p->seq_bytes / 2, &p->cap[BUF_PK4]);
+	if (wire4) d_pk = (uint8_t*)cache_get(BUF_PK4, p->seq_bytes >> wire4, &p->cap[BUF_PK4]);
 	p->d_wm = (uint8_t*)cache_get(BUF_WM, K2A_WM_BYTES + NCLS_ENTRIES * sizeof(K2aQueueDesc), &p->cap[BUF_WM]);
 	p->d_pairs = (K2aPair*)cache_get(BUF_PAIRS, sizeof(K2aPair) * ((size_t)n + 1), &p->cap[BUF_PAIRS]);
 	p->d_order = (uint32_t*)cache_get(BUF_ORDER, sizeof(uint32_t) * ((size_t)n + (size_t)nwt + 1), &p->cap[BUF_ORDER]);
@@ -1491,6 +1494,7 @@ static ksw2amd_plan_t *plan_create_uniform(int dual, int scalar, const ksw2amd_s
 		if (wire4) {
 			p->h_qd[0].unp_src = d_pk; p->h_qd[0].unp_dst = p->d_seq;
 			p->h_qd[0].unp_bytes = 2u * (uint32_t)NG * u->stride; p->h_qd[0].unp_total = (uint32_t)n * u->stride;
+			p->h_qd[0].unp_fmt = ((uint32_t)wire4 << 30) | u->stride;
 		}
 		memcpy(p->h_meta, p->h_qd, sizeof(K2aQueueDesc));
 	}
@@ -1738,7 +1742,7 @@ int ksw2amd_plan_describe(const ksw2amd_plan_t *p, char *buf, int cap)
 		                                     : (k->cfg == K2A_CFG_MP ? k2a_shim_mp_form(p->dual, k->mode, k->count) : 0);
 		len += snprintf(buf + len, (size_t)(cap - len), "kernel=%s G=%d C=%d gaps=%d mode=%s rebased=%d nomax=%d generic=%d form=%s tasks=%d uniform=%d wire4=%d tn=%d\n",
 		                kind, G, C, p->dual ? 2 : 1, mode_name[k->mode], k->rb, k->nomax, k->generic, form_name[form], k->count, p->uni ? 1 : 0,
-		                p->up_state && p->up_state->wire4 ? 1 : 0, (k->pk || k->solo) && k->sc.pk_tn1 ? 1 : 0);      /* tn: target wildcards are rows of this packed class (K2aScoring.pk_tn1) */
+		                p->up_state ? p->up_state->wire4 : 0, (k->pk || k->solo) && k->sc.pk_tn1 ? 1 : 0);      /* tn: target wildcards are rows of this packed class (K2aScoring.pk_tn1) */
 	}
 	return p->ncls;
 }
@@ -1769,7 +1773,7 @@ static int fetch_results(ksw2amd_plan_t *p)
 			p->streamed = 0;
 			/* (4-bit wire format: the wavefront-tasks that never started have not expanded their pairs -- the whole arena, now) */
 			if ((p->up_ev && k2a_shim_event_sync(p->up_ev)) || k2a_shim_memset(p->d_res, 0, sizeof(K2aResult) * (size_t)p->n, st) ||
-			    (plan_wire4(p) && k2a_shim_launch_wire4_expand(p->d_pk4, p->d_seq, (size_t)p->uni->n * p->uni->stride, st)) ||
+			    (plan_wire4(p) && k2a_shim_launch_wire_expand(p->d_pk4, p->d_seq, (size_t)p->uni->n * p->uni->stride, plan_wire4(p), p->uni->stride, st)) ||
 			    ksw2amd_plan_run(p, st) || k2a_shim_stream_sync(st))
 				return fail(KSW2AMD_E_NODEVICE, "plan_fetch: %s", k2a_shim_last_error());
 		}
@@ -1864,10 +1868,29 @@ void wire4_pair(const ksw2amd_plan_t *p, int i, uint8_t *out)
 {
 	const K2aPair *d = &p->h_pairs[i];
 	int x;
+	if (plan_wire4(p) == 2) {                              /* four codes per byte + the pair's escape entries (ksw2_lane.h) */
+		const uint32_t stride = p->up_state->wire_stride;
+		const uint8_t *slot = p->h_seq + (((size_t)d->qoff + stride) >> 2) - K2A_WIRE2_SLOT;
+		int e;
+		for (x = 0; x < d->qlen; ++x) out[x] = (p->h_seq[((size_t)d->qoff + (size_t)x) >> 2] >> (2 * (x & 3))) & 3;
+		for (x = 0; x < d->tlen_full; ++x) out[d->qlen + x] = (p->h_seq[((size_t)d->toff + (size_t)x) >> 2] >> (2 * (x & 3))) & 3;
+		for (e = 0; e < K2A_WIRE2_ESC; ++e) {
+			uint32_t ent, off, len, y;
+			memcpy(&ent, slot + 4 * e, 4);
+			if (!ent) continue;
+			off = ent & 0xfffffu; len = (ent >> 20) & 0xffu;
+			for (y = 0; y < len; ++y) {                     /* an offset inside the pair's region: the query's bytes, or the target's */
+				const uint32_t o = off + y;
+				if (o < (uint32_t)d->qlen) out[o] = (uint8_t)(ent >> 28);
+				else if (o >= d->toff - d->qoff && o < d->toff - d->qoff + (uint32_t)d->tlen_full) out[d->qlen + (o - (d->toff - d->qoff))] = (uint8_t)(ent >> 28);
+			}
+		}
+		return;
+	}
 	for (x = 0; x < d->qlen; ++x) { const uint8_t b = p->h_seq[((size_t)d->qoff + (size_t)x) >> 1]; out[x] = (x & 1) ? b >> 4 : b & 15; }
 	for (x = 0; x < d->tlen_full; ++x) { const uint8_t b = p->h_seq[((size_t)d->toff + (size_t)x) >> 1]; out[d->qlen + x] = (x & 1) ? b >> 4 : b & 15; }
 }
-int plan_wire4(const ksw2amd_plan_t *p) { return p->up_state && p->up_state->wire4; }
+int plan_wire4(const ksw2amd_plan_t *p) { return p->up_state ? p->up_state->wire4 : 0; }      /* 0: none, 1: four bits per code, 2: two bits + escapes */
 
 int pair_rerun(ksw2amd_plan_t *p, int i, void *km, ksw_extz_t *z)
 {

@@ -288,10 +288,88 @@ static unsigned pack4(uint8_t *dst, const uint8_t *src, int n)
 	if (k < n) { bad |= src[k]; dst[k >> 1] = (uint8_t)(src[k] & 15); }
 	return bad;
 }
+/* The 2-bit wire format (ksw2_lane.h, K2A_WIRE2_*): four codes per byte.  pack2: the plain loop for a sequence without a code above 3,
+ * returning the OR of its bytes; the caller packs a sequence with such a code again through pack2_esc, which writes 0 for it and adds
+ * an escape entry per run -- { offset inside the pair's region + run length + code } -- to the pair's slot.  Returns the number of entries
+ * the pair holds afterwards, or -1 when they do not fit (or a code above 15): the batch then takes the general path. */
+static unsigned pack2(uint8_t *dst, const uint8_t *src, int n)
+{
+	unsigned bad = 0;
+	int k = 0;
+#if defined(__SSE2__)
+	const __m128i lo = _mm_set1_epi16(0x00ff);
+	__m128i acc = _mm_setzero_si128();
+	for (; k + 64 <= n; k += 64) {
+		__m128i v[4], h[2];
+		int x;
+		for (x = 0; x < 4; ++x) {
+			v[x] = _mm_loadu_si128((const __m128i*)(src + k + 16 * x));
+			acc = _mm_or_si128(acc, v[x]);
+			v[x] = _mm_and_si128(_mm_or_si128(v[x], _mm_srli_epi16(v[x], 6)), lo);      /* 16-bit lanes: { even code | odd code << 2 } in the low byte */
+		}
+		h[0] = _mm_packus_epi16(v[0], v[1]); h[1] = _mm_packus_epi16(v[2], v[3]);     /* bytes of two codes each */
+		h[0] = _mm_and_si128(_mm_or_si128(h[0], _mm_srli_epi16(h[0], 4)), lo);
+		h[1] = _mm_and_si128(_mm_or_si128(h[1], _mm_srli_epi16(h[1], 4)), lo);
+		_mm_storeu_si128((__m128i*)(dst + (k >> 2)), _mm_packus_epi16(h[0], h[1]));     /* bytes of four codes */
+	}
+	{
+		uint8_t t[16];
+		int x;
+		_mm_storeu_si128((__m128i*)t, acc);
+		for (x = 0; x < 16; ++x) bad |= t[x];
+	}
+#endif
+	for (; k + 4 <= n; k += 4) { bad |= src[k] | src[k + 1] | src[k + 2] | src[k + 3]; dst[k >> 2] = (uint8_t)((src[k] & 3) | ((src[k + 1] & 3) << 2) | ((src[k + 2] & 3) << 4) | (src[k + 3] << 6)); }
+	if (k < n) {
+		unsigned b = 0;
+		int x;
+		for (x = 0; k + x < n; ++x) { bad |= src[k + x]; b |= (unsigned)(src[k + x] & 3) << (2 * x); }
+		dst[k >> 2] = (uint8_t)b;
+	}
+	return bad;
+}
+static int pack2_esc(uint8_t *dst, const uint8_t *src, int n, uint32_t region_off, uint8_t *slot, int used)
+{
+	int k = 0;
+	memset(dst, 0, (size_t)(n + 3) >> 2);
+	while (k < n) {
+		const unsigned c = src[k];
+		if (c < 4) { dst[k >> 2] |= (uint8_t)(c << (2 * (k & 3))); ++k; continue; }
+		{
+			int len = 1;
+			uint32_t ent;
+			while (k + len < n && src[k + len] == c && len < 255) ++len;
+			if (c > 15 || used >= K2A_WIRE2_ESC) return -1;
+			ent = (region_off + (uint32_t)k) | ((uint32_t)len << 20) | ((uint32_t)c << 28);
+			memcpy(slot + 4 * used, &ent, 4);
+			++used;
+			k += len;
+		}
+	}
+	return used;
+}
 static void pack_range(const copy_ctx_t *c, int beg, int end)
 {
 	unsigned bad = 0;
 	int i;
+	if (c->su->wire4 == 2) {
+		const uint32_t stride = c->su->wire_stride;
+		for (i = beg; i < end; ++i) {
+			const ksw2amd_pair_t *a = &c->pairs[i];
+			uint8_t *q, *t, *slot;
+			int used = 0;
+			if (a->qlen <= 0 || a->tlen <= 0) continue;
+			q = c->h_seq + (c->hp[i].qoff >> 2); t = c->h_seq + (c->hp[i].toff >> 2);
+			slot = c->h_seq + (((size_t)c->hp[i].qoff + stride) >> 2) - K2A_WIRE2_SLOT;
+			memset(slot, 0, K2A_WIRE2_SLOT);
+			if (pack2(q, a->query, a->qlen) > 3) used = pack2_esc(q, a->query, a->qlen, 0, slot, used);
+			if (used >= 0 && pack2(t, a->target, a->tlen) > 3) used = pack2_esc(t, a->target, a->tlen, c->hp[i].toff - c->hp[i].qoff, slot, used);
+			if (used < 0) bad = 16;
+			memset(t + ((a->tlen + 3) >> 2), 0, 16);                                 /* rows read past the target end (copy_range) */
+		}
+		if (bad > 15) __sync_fetch_and_or(&c->su->wire_bad, 1);
+		return;
+	}
 	for (i = beg; i < end; ++i) {
 		const ksw2amd_pair_t *a = &c->pairs[i];
 		uint8_t *t;

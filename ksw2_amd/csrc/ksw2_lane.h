@@ -559,6 +559,23 @@ K2A_FN void k2a_wire4_expand(uint32_t w4, uint32_t &lo, uint32_t &hi)
 	hi = ((ev >> 16) & 0xffu) | (((od >> 16) & 0xffu) << 8) | ((ev >> 24) << 16) | ((od >> 24) << 24);
 }
 
+/* The 2-bit wire format (round 6; K2aQueueDesc.unp_fmt = 2): byte k of the upload holds residue codes 4k .. 4k + 3, two bits each; a
+ * code above 3 travels as 0 plus an ESCAPE entry -- { offset inside the pair's region : 20, run length : 8, code : 4 } -- in the last
+ * K2A_WIRE2_SLOT upload bytes of the pair's region (arena padding nobody reads); a run of wildcards is one entry.  More runs in a
+ * pair than entries, or a code above 15: the host repeats the batch on the general path (stream_up_t.wire_bad).
+ * Four upload bytes -> sixteen arena bytes. */
+/* (K2A_WIRE2_ESC / _SLOT / _PAD: ksw2_types.h -- the host's packing loop uses them) */
+K2A_FN void k2a_wire2_expand(uint32_t w2, uint32_t out[4])
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+	for (int j = 0; j < 4; ++j) {
+		const uint32_t t = (w2 >> (8 * j)) & 0xffu;
+		out[j] = (t | (t << 6) | (t << 12) | (t << 18)) & 0x03030303u;
+	}
+}
+
 /* Uniform plans (K2aUniform): record of pair i, and the pieces wavefront-task wt of a streamed launch waits for -- the rules the
  * host's gather follows when it copies the sequences (ksw2_host_plan.c: uni_fill_range) */
 K2A_FN K2aPair k2a_uniform_pair(const K2aUniform &u, uint32_t i)

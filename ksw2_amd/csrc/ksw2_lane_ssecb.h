@@ -106,8 +106,12 @@ struct K2aSsecBlk {
 	int blk;                                   /* the block this lane holds: positions 16 * blk .. 16 * blk + 15; -1: none yet */
 	k2a_blk U, V, X, Y, X2, Y2, S;             /* the reference's bytes, b << 8 per half (X2, Y2: two-piece only; S of the single-gap kernel: with the 2 (q + e)
 	                                            * its cell adds first (ksw2_extz2_sse.c:163) already in) */
-	k2a_blk TC, TN;                            /* target codes of the block's positions (one per half); 0xffff where the code is the wildcard */
-	k2a_blk QW;                                /* query codes r - p of the block's positions on the current anti-diagonal (0 outside the query), bit 15: wildcard */
+	/* Scores (round 6): one PROFILE dword per position -- byte c = the score byte of the position's target code against query code c
+	 * (0..3; with the 2 (q + e) of the single-gap kernel in) -- P0 = the even slots', P1 = the odd slots'; the query codes of a register's
+	 * two positions are v_perm_b32 selector bytes, so a register's two scores are ONE v_perm_b32 (rounds 4-5: xor, min, mad, two
+	 * selects on target / query code registers).  m <= 5: the host sends wider alphabets to the position-per-lane kernels. */
+	k2a_blk P0, P1;
+	k2a_blk QW;                                /* per half: { 0x0c, query code r - p of the position on the current anti-diagonal } (0 outside the query), bit 15: the wildcard */
 	uint32_t qn;                               /* the query byte slot 0 pairs with on the next anti-diagonal (ask_query) */
 
 	K2A_FN int p0() const { return blk << 4; }
@@ -119,7 +123,17 @@ struct K2aSsecBlk {
 	K2A_FN static uint32_t qcode_of(const K2aSsec &P, uint32_t byte, int r, int p)
 	{
 		const uint32_t c = r - p >= 0 ? byte : 0u;
-		return c | (c == (uint32_t)(P.m - 1) ? 0x8000u : 0u);               /* bit 15: the wildcard (a code is below 128) */
+		return ((c & 0x7fu) << 8) | (c == (uint32_t)(P.m - 1) ? 0x8000u : 0u) | 0x0cu;      /* selector form: the code picks the profile byte, 0x0c the zero low byte; bit 15: the wildcard */
+	}
+	/* the profile of a position whose target code is t: sc_mch at byte t, sc_mis elsewhere, sc_N everywhere for the wildcard and at
+	 * the wildcard's byte (alphabets below five codes) -- k2a_ssec_score for query codes 0..3 */
+	K2A_FN static uint32_t profile_of(const K2aSsec &P, uint32_t t, int ofs)
+	{
+		const uint32_t cm = (uint32_t)(P.sc_mch + ofs) & 0xffu, cd = (uint32_t)(P.sc_mis + ofs) & 0xffu, cn = (uint32_t)(P.sc_N + ofs) & 0xffu, wc = (uint32_t)(P.m - 1);
+		uint32_t v = cd * 0x01010101u;
+		if (t < 4u) v = (v & ~(0xffu << (8 * t))) | (cm << (8 * t));
+		if (wc < 4u) v = (v & ~(0xffu << (8 * wc))) | (cn << (8 * wc));
+		return t == wc ? cn * 0x01010101u : v;
 	}
 	K2A_FN static uint32_t qcode(const K2aSsec &P, const uint8_t *qry, int qlen, int r, int p) { return qcode_of(P, qbyte(qry, qlen, r, p), r, p); }
 
@@ -135,8 +149,7 @@ struct K2aSsecBlk {
 			const uint32_t t0 = p < tlen ? tgt[p] : 0u, t1 = p + 1 < tlen ? tgt[p + 1] : 0u;
 			U[i] = V[i] = X[i] = Y[i] = g1; S[i] = DUAL ? 0u : k2a_sb_c(2 * (P.q + P.e));
 			if (DUAL) { X2[i] = g2; Y2[i] = g2; }
-			TC[i] = t0 | (t1 << 16);
-			TN[i] = (t0 == (uint32_t)(P.m - 1) ? 0xffffu : 0u) | (t1 == (uint32_t)(P.m - 1) ? 0xffff0000u : 0u);
+			P0[i] = profile_of(P, t0, DUAL ? 0 : 2 * (P.q + P.e)); P1[i] = profile_of(P, t1, DUAL ? 0 : 2 * (P.q + P.e));
 			QW[i] = qcode(P, qry, qlen, r, p) | (qcode(P, qry, qlen, r, p + 1) << 16);
 		}
 	}
@@ -170,14 +183,14 @@ struct K2aSsecBlk {
 	{
 		const uint32_t em = slot_mask(st0, pend);
 		if (em == 0) return;
-		const int ofs = DUAL ? 0 : 2 * (P.q + P.e);
-		const uint32_t cm = k2a_sb_c(P.sc_mch + ofs), cd = k2a_sb_c(P.sc_mis - P.sc_mch), cn = k2a_sb_c(P.sc_N + ofs);
+		const uint32_t cn = k2a_sb_c(P.sc_N + (DUAL ? 0 : 2 * (P.q + P.e)));
+		const uint32_t em2 = em | (em << 15);                                                      /* slot 2i at bit 2i, slot 2i + 1 at bit 2i + 16: one shift puts both at their halves' sign bits */
 #pragma unroll
 		for (int i = 0; i < 8; ++i) {
-			const uint32_t ne = k2a_sb_minu(TC[i] ^ QW[i], 0x00010001u);                          /* 1 where the codes differ */
-			uint32_t sc = k2a_pk_mad(ne, cd, cm);                                                  /* sc_mch or sc_mis, << 8 (wrapping like the byte) */
-			sc = k2a_pk_sel(TN[i] | k2a_pk_sign(QW[i]), cn, sc);
-			S[i] = k2a_pk_sel(half_mask(em, i), sc, S[i]);
+			/* { 0, P0[code lo], 0, P1[code hi] }: the selector's high half reads the second operand's bytes (4 + code) */
+			uint32_t sc = k2a_perm(P1[i], P0[i], QW[i] | 0x04000000u);
+			sc = k2a_pk_selv(k2a_pk_sign(QW[i]), cn, sc);                                          /* the query's wildcard */
+			S[i] = k2a_pk_selv(k2a_pk_sign(em2 << (15 - 2 * i)), sc, S[i]);
 		}
 	}
 

@@ -111,7 +111,7 @@ int k2a_shim_launch_trace_pk(int cfg, int dual, const K2aPair *pairs, const uint
 typedef struct K2aGather { uint64_t src; uint32_t dst, len; } K2aGather;
 int k2a_shim_launch_gather(const K2aGather *tab, int n, uint8_t *dst, void *stream);
 /* 4-bit wire format of uniform plans: bytes / 2 upload bytes at src -> bytes arena bytes at dst (bytes a multiple of 8) */
-int k2a_shim_launch_wire4_expand(const uint8_t *src, uint8_t *dst, size_t bytes, void *stream);
+int k2a_shim_launch_wire_expand(const uint8_t *src, uint8_t *dst, size_t bytes, int fmt, uint32_t stride, void *stream);      /* fmt 1: four bits per code, 2: two bits + escapes */
 int k2a_shim_launch_uniform_layout(const K2aUniform *u, K2aPair *pairs, uint32_t *order2, uint32_t *need, void *stream);
 
 /* Packed generation-serial fill (class K2A_PKCFG_MP): one task (two same-shape alignments) per workgroup of four wavefronts that

@@ -224,6 +224,31 @@ struct K2aTbStage {
  * but the pieces arrive whatever the CUs do (the DMA engines move them), so the launch always makes progress.
  * (Round 4 first ran these launches as persistent loops over a task counter: the loop cost the kernels 6-40 registers -- the
  * headline's a resident wavefront, 4 830 -> 4 610 GCUPS -- for nothing a wait in front of the body does not give.) */
+/* 2-bit wire format (ksw2_lane.h): arena bytes [b0, b1) -- whole pairs of `stride` bytes -- out of the upload, by `nl` lanes of which
+ * this is lane `l`: sixteen codes per lane and round, then the pairs' escape entries (codes above 3: rare) on top of what was expanded */
+__device__ __forceinline__ void k2a_wire2_task(const uint8_t *__restrict__ src8, uint8_t *__restrict__ dst8, uint32_t b0, uint32_t b1, uint32_t stride, int l, int nl)
+{
+	const uint32_t *src = (const uint32_t*)(src8 + (b0 >> 2));
+	uint4 *dst = (uint4*)(dst8 + b0);
+	for (uint32_t x = (uint32_t)l; x < (b1 - b0) >> 4; x += (uint32_t)nl) {
+		uint32_t o[4];
+		k2a_wire2_expand(src[x], o);
+		dst[x] = make_uint4(o[0], o[1], o[2], o[3]);
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      /* the expanded bytes before the escapes' */
+	const uint32_t np = (b1 - b0) / stride;
+	for (uint32_t idx = (uint32_t)l; idx < np * 8u; idx += (uint32_t)nl) {
+		const uint32_t pair = idx >> 3, e = idx & 7u;
+		if (e >= K2A_WIRE2_ESC) continue;
+		const uint32_t base = b0 + pair * stride;
+		const uint32_t ent = *(const uint32_t*)(src8 + ((base + stride) >> 2) - K2A_WIRE2_SLOT + 4 * e);
+		if (ent == 0) continue;
+		uint8_t *at = dst8 + base + (ent & 0xfffffu);
+		const uint32_t len = (ent >> 20) & 0xffu, code = ent >> 28;
+		for (uint32_t y = 0; y < len; ++y) at[y] = (uint8_t)code;
+	}
+}
+
 __device__ __forceinline__ bool k2a_queue_wait(K2aQueueDesc *qd, int wt)
 {
 	if ((uint32_t)wt >= qd->nwt) return true;                   /* (an idle wavefront of the last workgroup) */
@@ -248,12 +273,15 @@ __device__ __forceinline__ bool k2a_queue_wait(K2aQueueDesc *qd, int wt)
 	 * recycled arena that a neighbour's look past its own sequences brought in). */
 	if (qd->unp_bytes) {
 		const uint32_t b0 = (uint32_t)wt * qd->unp_bytes, b1 = min(b0 + qd->unp_bytes, qd->unp_total);
-		const uint32_t *src = (const uint32_t*)(qd->unp_src + (b0 >> 1));
-		uint2 *dst = (uint2*)(qd->unp_dst + b0);
-		for (uint32_t x = threadIdx.x & 63; x < (b1 - b0) >> 3; x += 64) {
-			uint32_t lo, hi;
-			k2a_wire4_expand(src[x], lo, hi);
-			dst[x] = make_uint2(lo, hi);
+		if ((qd->unp_fmt >> 30) == 2u) k2a_wire2_task(qd->unp_src, qd->unp_dst, b0, b1, qd->unp_fmt & 0x3fffffffu, (int)(threadIdx.x & 63), 64);
+		else {
+			const uint32_t *src = (const uint32_t*)(qd->unp_src + (b0 >> 1));
+			uint2 *dst = (uint2*)(qd->unp_dst + b0);
+			for (uint32_t x = threadIdx.x & 63; x < (b1 - b0) >> 3; x += 64) {
+				uint32_t lo, hi;
+				k2a_wire4_expand(src[x], lo, hi);
+				dst[x] = make_uint2(lo, hi);
+			}
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1671,7 +1699,7 @@ __device__ __forceinline__ void k2a_ssec_blk_task(const K2aSsec &P, const K2aPai
 
 	K2aSsecBlk<DUAL> B;
 	B.blk = -1; B.qn = 0;
-	B.U = B.V = B.X = B.Y = B.X2 = B.Y2 = B.S = B.TC = B.TN = B.QW = k2a_blk{ 0, 0, 0, 0, 0, 0, 0, 0 };
+	B.U = B.V = B.X = B.Y = B.X2 = B.Y2 = B.S = B.P0 = B.P1 = B.QW = k2a_blk{ 0, 0, 0, 0, 0, 0, 0, 0 };
 	k2a_book_reset(&book);
 	K2aSsecFollow fol = { 0, 0 };
 	int last_st = -1, last_en = -1, last_st0 = 0, last_en0 = 0, hprev = 0;
@@ -1755,7 +1783,7 @@ __device__ __forceinline__ void k2a_ssec_blk_task(const K2aSsec &P, const K2aPai
 			const int l0 = min(max(fol.last, 0), T16 - 1), l1 = min(max(fol.last + 1, 0), T16 - 1);
 			const int vl = __builtin_amdgcn_readlane((int)k2a_sb_get(B.V, l0 & 15), (l0 >> 4) & 63);
 			const int un = __builtin_amdgcn_readlane((int)k2a_sb_get(B.U, l1 & 15), (l1 >> 4) & 63);
-			const int v0 = __builtin_amdgcn_readlane((int)k2a_sb_get(B.V, 0), 0);
+			const int v0 = r == 0 ? __builtin_amdgcn_readlane((int)k2a_sb_get(B.V, 0), 0) : 0;      /* (the first anti-diagonal's only; a select tree per look-up otherwise) */
 			stop = k2a_ssec_follow<DUAL>(P, fol, &book, r, st0, en0, qlen, tlen, pr.zdrop, adrop, vl, un, v0);
 		}
 		if (stop) break;
@@ -2328,8 +2356,25 @@ k2a_wire4_expand_kernel(const uint32_t *__restrict__ src, uint2 *__restrict__ ds
 		dst[x] = make_uint2(lo, hi);
 	}
 }
-int k2a_shim_launch_wire4_expand(const uint8_t *src, uint8_t *dst, size_t bytes, void *stream)
+/* the 2-bit format: one workgroup per group of `ppb` pairs (k2a_wire2_task) */
+__global__ void __launch_bounds__(256)
+k2a_wire2_expand_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint32_t total, uint32_t stride, uint32_t ppb)
 {
+	const uint32_t b0 = blockIdx.x * ppb * stride, b1 = min(b0 + ppb * stride, total);
+	if (b0 < b1) k2a_wire2_task(src, dst, b0, b1, stride, (int)threadIdx.x, 256);
+}
+/* the whole arena out of its upload (a streamed launch that was abandoned: the wavefront-tasks that never started have not expanded
+ * their pairs); fmt / stride: K2aQueueDesc.unp_fmt */
+int k2a_shim_launch_wire_expand(const uint8_t *src, uint8_t *dst, size_t bytes, int fmt, uint32_t stride, void *stream)
+{
+	if (fmt == 2) {
+		const uint32_t ppb = 16, npairs = (uint32_t)(bytes / stride);
+		if (npairs == 0) return 0;
+		/* (the escapes of a pair are written by the workgroup that expanded it, behind its own stores: k2a_wire2_task's fence) */
+		hipLaunchKernelGGL(k2a_wire2_expand_kernel, dim3((npairs + ppb - 1) / ppb), dim3(256), 0, (hipStream_t)stream, src, dst, (uint32_t)bytes, stride, ppb);
+		CHECK(hipGetLastError());
+		return 0;
+	}
 	const size_t n8 = bytes >> 3;
 	if (n8 == 0) return 0;
 	hipLaunchKernelGGL(k2a_wire4_expand_kernel, dim3((unsigned)((n8 + 255) / 256 < 65536 ? (n8 + 255) / 256 : 65536)), dim3(256), 0, (hipStream_t)stream,

@@ -137,15 +137,20 @@ typedef struct K2aResult {
  * task lists. */
 #define K2A_WM_BYTES 65536            /* large enough that the runtime moves it with the DMA engines like the pieces themselves, never with a kernel
                                        * (a launch that fills the device leaves a copy kernel no wavefront slot: tools/probe/stream_publish_probe.hip) */
+/* the 2-bit wire format's escape entries (ksw2_lane.h: k2a_wire2_expand; ksw2_host_pool.c: pack2_esc) */
+#define K2A_WIRE2_ESC 7                                   /* entries per pair */
+#define K2A_WIRE2_SLOT (4 * K2A_WIRE2_ESC)                /* upload bytes: the last ones of the pair's region */
+#define K2A_WIRE2_PAD (4 * K2A_WIRE2_SLOT)                /* arena bytes of extra target padding that make room for them */
+
 typedef struct K2aQueueDesc {
 	uint32_t next;                    /* wavefront-tasks started (atomic); == nwt after a complete run */
 	uint32_t abort;                   /* (the host zeroes these two words before every run) */
 	uint32_t nwt;                     /* wavefront-tasks of the launch */
-	uint32_t pad;
+	uint32_t unp_fmt;                 /* wire format of `unp_src`: bits 31-30 = 1: four bits per code, 2: two bits per code + escapes (ksw2_lane.h, K2A_WIRE2_*); bits 29-0: the pairs' stride in the arena */
 	const uint32_t *need;             /* [nwt] pieces that must have landed before the wavefront-task may start (0 = none) */
 	const uint32_t *wm;               /* the plan's watermark block */
 	uint64_t timeout_ticks;
-	/* uniform plans on the 4-bit wire format (ksw2_host_plan.c): the upload carries two residue codes per byte into `unp_src`; a
+	/* uniform plans on a wire format (ksw2_host_plan.c): the upload carries two or four residue codes per byte into `unp_src`; a
 	 * wavefront-task first expands its own pairs' bytes -- unp_bytes per wavefront-task, the arena's first unp_total bytes in all --
 	 * into the arena the kernels read (unp_dst).  unp_bytes = 0: the upload is the arena itself. */
 	const uint8_t *unp_src;

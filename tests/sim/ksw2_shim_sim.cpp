@@ -29,6 +29,24 @@ static void make_tabs(const K2aScoring &sc, uint32_t *tabs)
 	for (int x = 0; x < 5; ++x) { tabs[x] = sc.prof[x]; tabs[8 + x] = (uint32_t)sc.colw[x]; }
 }
 
+/* k2a_wire2_task (ksw2_shim_hip.hip): arena bytes [b0, b1) out of the 2-bit upload, then the pairs' escape entries */
+static void sim_wire2_task(const uint8_t *src8, uint8_t *dst8, uint32_t b0, uint32_t b1, uint32_t stride)
+{
+	for (uint32_t x = 0; x < (b1 - b0) >> 4; ++x) {
+		uint32_t w, o[4];
+		memcpy(&w, src8 + (b0 >> 2) + 4 * (size_t)x, 4);
+		k2a_wire2_expand(w, o);
+		memcpy(dst8 + b0 + 16 * (size_t)x, o, 16);
+	}
+	for (uint32_t pair = 0; pair < (b1 - b0) / stride; ++pair)
+		for (uint32_t e = 0; e < K2A_WIRE2_ESC; ++e) {
+			const uint32_t base = b0 + pair * stride;
+			uint32_t ent;
+			memcpy(&ent, src8 + ((base + stride) >> 2) - K2A_WIRE2_SLOT + 4 * e, 4);
+			if (ent) memset(dst8 + base + (ent & 0xfffffu), (int)(ent >> 28), (ent >> 20) & 0xffu);
+		}
+}
+
 /* what k2a_scan_codes reports as "a code above 4" (the wavefront-task's look at its targets on the device) */
 static bool sim_codes_above4(const uint8_t *t, int n)
 {
@@ -131,7 +149,8 @@ static void sim_fill_pk(const K2aScoring sc, const K2aPair *pairs, const uint32_
 			if (qd->need[wv] > qd->wm[0]) { qd->abort = 1; break; }
 			if (qd->unp_bytes) {                                 /* 4-bit wire format: the wavefront-task expands its own pairs (k2a_queue_wait) */
 				const uint32_t b0 = (uint32_t)wv * qd->unp_bytes, b1 = std::min(b0 + qd->unp_bytes, qd->unp_total);
-				for (uint32_t x = 0; x < (b1 - b0) >> 3; ++x) {
+				if ((qd->unp_fmt >> 30) == 2u) sim_wire2_task(qd->unp_src, qd->unp_dst, b0, b1, qd->unp_fmt & 0x3fffffffu);
+				else for (uint32_t x = 0; x < (b1 - b0) >> 3; ++x) {
 					uint32_t w4, lo, hi;
 					memcpy(&w4, qd->unp_src + (b0 >> 1) + 4 * (size_t)x, 4);
 					k2a_wire4_expand(w4, lo, hi);
@@ -785,7 +804,7 @@ static void sim_ssec_blk(const K2aSsec P, const K2aPair *pairs, const uint32_t *
 		for (int l = 0; l < 64; ++l) {
 			K2aSsecBlk<DUAL> &B = Bv[l];
 			B.blk = -1; B.qn = 0;
-			B.U = B.V = B.X = B.Y = B.X2 = B.Y2 = B.S = B.TC = B.TN = B.QW = k2a_blk{ 0, 0, 0, 0, 0, 0, 0, 0 };
+			B.U = B.V = B.X = B.Y = B.X2 = B.Y2 = B.S = B.P0 = B.P1 = B.QW = k2a_blk{ 0, 0, 0, 0, 0, 0, 0, 0 };
 		}
 		K2aBook book;
 		k2a_book_reset(&book);
@@ -1230,8 +1249,9 @@ int k2a_shim_launch_gather(const K2aGather *tab, int n, uint8_t *dst, void *)
 	for (int k = 0; k < n; ++k) memcpy(dst + tab[k].dst, (const void*)(uintptr_t)tab[k].src, tab[k].len);
 	return 0;
 }
-int k2a_shim_launch_wire4_expand(const uint8_t *src, uint8_t *dst, size_t bytes, void *)
+int k2a_shim_launch_wire_expand(const uint8_t *src, uint8_t *dst, size_t bytes, int fmt, uint32_t stride, void *)
 {
+	if (fmt == 2) { sim_wire2_task(src, dst, 0, (uint32_t)(bytes / stride * stride), stride); return 0; }
 	for (size_t x = 0; x < bytes >> 3; ++x) {
 		uint32_t w4, lo, hi;
 		memcpy(&w4, src + 4 * x, 4);

@@ -1089,7 +1089,7 @@ def _check_uniform_plans(lib, monkeypatch, shapes):
         fl = po.SCORE_ONLY | (po.EXTZ_ONLY if si % 2 else 0)
 
         def run(**env):
-            for k in ("KSW2AMD_UNIFORM", "KSW2AMD_STREAM_PIECE_KB", "KSW2AMD_STREAM_SLEEP_US", "KSW2AMD_STREAM_FAULT", "KSW2AMD_STREAM_TIMEOUT_MS", "KSW2AMD_DEFER", "KSW2AMD_WIRE4", "KSW2AMD_TN"):
+            for k in ("KSW2AMD_UNIFORM", "KSW2AMD_STREAM_PIECE_KB", "KSW2AMD_STREAM_SLEEP_US", "KSW2AMD_STREAM_FAULT", "KSW2AMD_STREAM_TIMEOUT_MS", "KSW2AMD_DEFER", "KSW2AMD_WIRE4", "KSW2AMD_WIRE2", "KSW2AMD_TN"):
                 monkeypatch.delenv(k, raising=False)
             if defer is not None:
                 monkeypatch.setenv("KSW2AMD_DEFER", str(defer))
@@ -1118,6 +1118,34 @@ def _check_uniform_plans(lib, monkeypatch, shapes):
         # a residue code above 15 does not fit it: the batch is repeated on the general path and comes back as the general path returns it
         w8, ns, na, nr = run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64, KSW2AMD_WIRE4=0)
         assert ns == 1 and na == 0 and not [i for i in range(n) if diff(off[i], w8[i])], (si, "wire4 off", ns, na)
+        # ... and the 2-bit format (round 6, the default: four codes per byte, codes above 3 as escape entries in the pair's padding) against the 4-bit one
+        w4, ns, na, nr = run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64, KSW2AMD_WIRE2=0)
+        assert ns == 1 and na == 0 and not [i for i in range(n) if diff(off[i], w4[i])], (si, "wire2 off", ns, na)
+        if si == 1:
+            # escapes: runs of wildcards (one entry each), runs longer than an entry holds (255), the last slot, both sequences of a pair; then more
+            # runs in a pair than its seven entries (the batch takes the general path: same records)
+            keepq, keept = qs, ts
+            qs, ts = [x.copy() for x in qs], [x.copy() for x in ts]
+            ts[3][5:60] = 4; qs[3][0] = 4; qs[3][ql - 1] = 4; ts[3][tl - 1] = 4
+            for k in range(7):
+                ts[9][3 + 9 * k] = 4
+            qs[11][10:ql - 5] = 4
+            e_off, _, _, _ = run(KSW2AMD_UNIFORM=0)
+            e_on, ns, na, nr = run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64)
+            assert ns == 1 and not [i for i in range(n) if diff(e_off[i], e_on[i])], (si, "escapes")
+            e_flt, ns, na, nr = run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64, KSW2AMD_STREAM_FAULT=1, KSW2AMD_STREAM_TIMEOUT_MS=20)      # the whole-arena expansion of a repeated run
+            assert na == 1 and not [i for i in range(n) if diff(e_off[i], e_flt[i])], (si, "escapes, repeated run")
+            e_tn, ns, na, nr = run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64, KSW2AMD_TN=0)                                              # re-runs read the pairs back out of the staging copy (wire4_pair)
+            assert nr > 0 and not [i for i in range(n) if diff(e_off[i], e_tn[i])], (si, "escapes, handed back")
+            for k in range(8):
+                qs[20][4 + 11 * k] = 4
+            o_off, _, _, _ = run(KSW2AMD_UNIFORM=0)
+            o_on, ns, na, nr = run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64)
+            assert not [i for i in range(n) if diff(o_off[i], o_on[i])], (si, "more escapes than a pair's slot holds")
+            for i in (3, 9, 11, 20):
+                exp = po.align("oracle", "extz2", qs[i], ts[i], mat, 4, 2, w=w, zdrop=zd, end_bonus=7, flag=fl)
+                assert not diff(exp, o_on[i], CMP), (si, "escapes vs oracle", i)
+            qs, ts = keepq, keept
         if si == 0:
             keepq = qs[7].copy()
             qs[7][3] = 20
