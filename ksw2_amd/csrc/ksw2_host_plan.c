@@ -1408,12 +1408,15 @@ static ksw2amd_plan_t *plan_create_uniform(int dual, int scalar, const ksw2amd_s
 	p->cells = (int64_t)n * band_cells(pairs[0].qlen, pairs[0].tlen, w);
 	/* the arena: query 16-aligned, target 16-aligned and readable one strip past its end, like every gathered arena */
 	u->n = (uint32_t)n; u->ntasks = (uint32_t)(n / 2);
-	/* the wire format (KSW2AMD_WIRE4=0: none; KSW2AMD_WIRE2=0: four bits per code): staging and upload hold two or four residue codes
+	/* the wire format (KSW2AMD_WIRE4=0: none; KSW2AMD_WIRE2=1: two bits per code): staging and upload hold two or four residue codes
 	 * per byte -- a half or a quarter of the bytes for the gather to write and for the DMA engines to move -- and every wavefront-task
 	 * expands its own pairs into the arena before it reads them (K2aQueueDesc.unp_*, k2a_queue_wait).  The pieces keep their pair
 	 * boundaries; all offsets of the upload side shift.  Two bits per code (round 6): codes above 3 travel as escape entries in the
-	 * last upload bytes of the pair's region (ksw2_lane.h, K2A_WIRE2_*), for which the target's padding grows by K2A_WIRE2_PAD */
-	wire4 = (ENV(WIRE4) && atoi(ENV(WIRE4)) == 0) ? 0 : (ENV(WIRE2) && atoi(ENV(WIRE2)) == 0) ? 1 : 2;
+	 * last upload bytes of the pair's region (ksw2_lane.h, K2A_WIRE2_*), for which the target's padding grows by K2A_WIRE2_PAD.
+	 * OPT-IN: on config 2 it moved the step by +3 % inside a +-7 % spread (profiles/r6_wire2_ab_ssec_rows.txt: what the step waits
+	 * for after round 5's 4-bit format is the gather and the last task's latency, no longer the link), and a pair with more wildcard
+	 * runs than its slot holds sends the whole batch to the general path -- a cliff the 4-bit format only has for codes above 15. */
+	wire4 = (ENV(WIRE4) && atoi(ENV(WIRE4)) == 0) ? 0 : (ENV(WIRE2) && atoi(ENV(WIRE2)) == 1) ? 2 : 1;
 	u->qpad = (uint32_t)align_up((size_t)pairs[0].qlen, 16); u->stride = u->qpad + (uint32_t)align_up((size_t)pairs[0].tlen + 64 + (wire4 == 2 ? K2A_WIRE2_PAD : 0), 16);
 	if (wire4 == 2 && u->stride >= (1u << 20)) { wire4 = 1; u->stride = u->qpad + (uint32_t)align_up((size_t)pairs[0].tlen + 64, 16); }      /* (an escape's offset has 20 bits) */
 	if ((uint64_t)n * u->stride > 0xfff00000u - 65536u) { g_err[0] = 0; goto na; }

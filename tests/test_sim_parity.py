@@ -1118,9 +1118,9 @@ def _check_uniform_plans(lib, monkeypatch, shapes):
         # a residue code above 15 does not fit it: the batch is repeated on the general path and comes back as the general path returns it
         w8, ns, na, nr = run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64, KSW2AMD_WIRE4=0)
         assert ns == 1 and na == 0 and not [i for i in range(n) if diff(off[i], w8[i])], (si, "wire4 off", ns, na)
-        # ... and the 2-bit format (round 6, the default: four codes per byte, codes above 3 as escape entries in the pair's padding) against the 4-bit one
-        w4, ns, na, nr = run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64, KSW2AMD_WIRE2=0)
-        assert ns == 1 and na == 0 and not [i for i in range(n) if diff(off[i], w4[i])], (si, "wire2 off", ns, na)
+        # ... and the 2-bit format (round 6, opt-in: four codes per byte, codes above 3 as escape entries in the pair's padding)
+        w2, ns, na, nr = run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64, KSW2AMD_WIRE2=1)
+        assert ns == 1 and na == 0 and not [i for i in range(n) if diff(off[i], w2[i])], (si, "wire2 on", ns, na)
         if si == 1:
             # escapes: runs of wildcards (one entry each), runs longer than an entry holds (255), the last slot, both sequences of a pair; then more
             # runs in a pair than its seven entries (the batch takes the general path: same records)
@@ -1131,16 +1131,16 @@ def _check_uniform_plans(lib, monkeypatch, shapes):
                 ts[9][3 + 9 * k] = 4
             qs[11][10:ql - 5] = 4
             e_off, _, _, _ = run(KSW2AMD_UNIFORM=0)
-            e_on, ns, na, nr = run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64)
+            e_on, ns, na, nr = run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64, KSW2AMD_WIRE2=1)
             assert ns == 1 and not [i for i in range(n) if diff(e_off[i], e_on[i])], (si, "escapes")
-            e_flt, ns, na, nr = run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64, KSW2AMD_STREAM_FAULT=1, KSW2AMD_STREAM_TIMEOUT_MS=20)      # the whole-arena expansion of a repeated run
+            e_flt, ns, na, nr = run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64, KSW2AMD_WIRE2=1, KSW2AMD_STREAM_FAULT=1, KSW2AMD_STREAM_TIMEOUT_MS=20)      # the whole-arena expansion of a repeated run
             assert na == 1 and not [i for i in range(n) if diff(e_off[i], e_flt[i])], (si, "escapes, repeated run")
-            e_tn, ns, na, nr = run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64, KSW2AMD_TN=0)                                              # re-runs read the pairs back out of the staging copy (wire4_pair)
+            e_tn, ns, na, nr = run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64, KSW2AMD_WIRE2=1, KSW2AMD_TN=0)                            # re-runs read the pairs back out of the staging copy (wire4_pair)
             assert nr > 0 and not [i for i in range(n) if diff(e_off[i], e_tn[i])], (si, "escapes, handed back")
             for k in range(8):
                 qs[20][4 + 11 * k] = 4
             o_off, _, _, _ = run(KSW2AMD_UNIFORM=0)
-            o_on, ns, na, nr = run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64)
+            o_on, ns, na, nr = run(KSW2AMD_UNIFORM=1, KSW2AMD_STREAM_PIECE_KB=64, KSW2AMD_WIRE2=1)
             assert not [i for i in range(n) if diff(o_off[i], o_on[i])], (si, "more escapes than a pair's slot holds")
             for i in (3, 9, 11, 20):
                 exp = po.align("oracle", "extz2", qs[i], ts[i], mat, 4, 2, w=w, zdrop=zd, end_bonus=7, flag=fl)

@@ -34,7 +34,7 @@ ENVS = [{}, {"KSW2AMD_SOLO": "1"}, {"KSW2AMD_SOLO": "all"}, {"KSW2AMD_LDSROWS": 
         {"KSW2AMD_SSEC_BLK": "0"}, {"KSW2AMD_EXTF_GRP": "0"}, {"KSW2AMD_EXTF_GRP": "1", "KSW2AMD_EXTF_LDS": "1"}, {"KSW2AMD_EXTF_GRP": "1"}, {"KSW2AMD_EXTF_GRP": "2", "KSW2AMD_EXTF_WIN": "1"},
         {"KSW2AMD_STREAM": "1", "KSW2AMD_STREAM_PIECE_KB": "64", "KSW2AMD_STREAM_LANES": "2", "KSW2AMD_SIMDS": "0"},
         # uniform plans (one shape, one parameter set, >= 2 048 pairs: the `uniform` rounds below build such batches; a POOL_MIN here would switch the route off)
-        {"KSW2AMD_UNIFORM": "1", "KSW2AMD_SIMDS": "0"}, {"KSW2AMD_UNIFORM": "1", "KSW2AMD_WIRE4": "0", "KSW2AMD_SIMDS": "0"}, {"KSW2AMD_UNIFORM": "1", "KSW2AMD_WIRE2": "0", "KSW2AMD_SIMDS": "0"},
+        {"KSW2AMD_UNIFORM": "1", "KSW2AMD_SIMDS": "0"}, {"KSW2AMD_UNIFORM": "1", "KSW2AMD_WIRE4": "0", "KSW2AMD_SIMDS": "0"}, {"KSW2AMD_UNIFORM": "1", "KSW2AMD_WIRE2": "1", "KSW2AMD_SIMDS": "0"},
         # round 6: target wildcards as rows of the packed kernels (default) against the rule before it
         {"KSW2AMD_TN": "0"}, {"KSW2AMD_TN": "0", "KSW2AMD_SIMDS": "0", "KSW2AMD_STREAM": "1", "KSW2AMD_STREAM_PIECE_KB": "64"}]
 KEYS = sorted({k for e in ENVS for k in e})
