@@ -66,7 +66,6 @@
 	X(SOLO) \
 	X(SSEC_HBM) \
 	X(SSEC_BLK) \
-	X(SSEC_SPLIT) \
 	X(EXTF_GRP) \
 	X(STREAM_LANES) \
 	X(WIRE4) \

@@ -69,7 +69,6 @@ void env_load(void)
 	if (g_env[ENV_BACKTRACE] && atoi(g_env[ENV_BACKTRACE])) { signal(SIGSEGV, crash_handler); signal(SIGBUS, crash_handler); signal(SIGABRT, crash_handler); }
 	k2a_shim_set_option(K2A_OPT_LDSCODES, env_switch(g_env[ENV_LDSCODES]));
 	k2a_shim_set_option(K2A_OPT_LDSROWS, env_switch(g_env[ENV_LDSROWS]));
-	k2a_shim_set_option(K2A_OPT_SSEC_SPLIT, env_switch(g_env[ENV_SSEC_SPLIT]));
 	++g_env_gen;
 	g_env_ready = 1;
 	pthread_mutex_unlock(&g_env_mu);
@@ -1732,8 +1731,7 @@ int ksw2amd_plan_describe(const ksw2amd_plan_t *p, char *buf, int cap)
 		int nl = 0, mode, lds;
 		for (mode = 0; mode < 3; ++mode) for (lds = 0; lds < 3 && len < cap - 1; ++lds)
 			if (p->s_count[mode][0][lds]) {
-				len += snprintf(buf + len, (size_t)(cap - len), "kernel=ssec gaps=%d mode=%s form=%s tasks=%d\n", p->dual ? 2 : 1, mode_name[mode],
-				                lds == 2 && k2a_shim_ssec_split(p->s_count[mode][0][lds]) ? "blk2" : form_name[lds], p->s_count[mode][0][lds]);      /* blk2: the register form over two wavefronts per alignment */
+				len += snprintf(buf + len, (size_t)(cap - len), "kernel=ssec gaps=%d mode=%s form=%s tasks=%d\n", p->dual ? 2 : 1, mode_name[mode], form_name[lds], p->s_count[mode][0][lds]);
 				++nl;
 			}
 		return nl;

@@ -44,8 +44,7 @@ int   k2a_shim_mem_info(size_t *free_b, size_t *total_b);
 /* launch-time kernel forms: every choice the launcher makes can be forced (-1 = automatic, 0 / 1) and is reported */
 #define K2A_OPT_LDSCODES 0     /* exact score-only packed (64,16) kernels: target-code planes in LDS */
 #define K2A_OPT_LDSROWS  1     /* two-piece traceback packed (64,16) and int32 generation-serial traceback kernels: row state in LDS */
-#define K2A_OPT_SSEC_SPLIT 2   /* SSE-compatible register form, exact mode: one alignment over two wavefronts (cells | H and book) */
-#define K2A_NOPT 3
+#define K2A_NOPT 2
 void  k2a_shim_set_option(int opt, int value);
 int   k2a_shim_pk_form(int cfg, int dual, int mode, int nomax, int ntasks);   /* what k2a_shim_launch_fill_pk takes: 0 registers, 1 row state in LDS, 2 code planes in LDS */
 int   k2a_shim_mp_form(int dual, int mode, int ntasks);                        /* k2a_shim_launch_fill, class K2A_CFG_MP: 1 = row state in LDS */
@@ -162,7 +161,6 @@ int k2a_shim_launch_extf(int cls, const K2aExtf *par, const K2aPair *pairs, cons
 /* lds_bytes > 0: the tasks' state arrays fit that many bytes each and live in LDS (one wavefront per workgroup) instead of `scratch` */
 int k2a_shim_launch_ssec(int dual, int mode, size_t lds_bytes, const K2aSsec *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq,
                          uint8_t *tb, uint8_t *scratch, K2aResult *res, void *stream);
-int k2a_shim_ssec_split(int ntasks);      /* would a launch of that many register-form tasks be split? (plan_describe) */
 int k2a_shim_launch_ssec_blk(int dual, int mode, const K2aSsec *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, void *stream);
 int k2a_shim_launch_ssec_trace(const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *tb, K2aResult *res, uint32_t *cig, void *stream);
 

@@ -1791,196 +1791,6 @@ __device__ __forceinline__ void k2a_ssec_blk_task(const K2aSsec &P, const K2aPai
 	}
 }
 
-/* The exact mode of the register form SPLIT OVER TWO WAVEFRONTS of a workgroup (round 6; batches of at most one alignment per SIMD:
- * a wavefront alone on its SIMD issues one instruction of any kind per 6 - 9 cycles, so what counts there is the number of
- * instructions per anti-diagonal and wavefront -- 590 for this kernel).  Wavefront 0 keeps the cells: k2a_ssec_blk_task's loop without
- * its exact-mode bookkeeping; per anti-diagonal it publishes every lane's block of v bytes and the one u / v byte the last in-band cell
- * needs (K2aSsecRing, slots of K2A_SSEC_RING_D anti-diagonals in LDS).  Wavefront 1 keeps H, the maxima and the book: it tracks
- * which block every lane holds (the same rule), takes the anti-diagonal's v bytes out of the ring and does what the one-wavefront
- * loop does behind its update.  A monotone counter each way (produced / consumed; LDS, workgroup scope), no barrier per step; a Z-drop
- * raises `stop`, the cells wavefront -- at most K2A_SSEC_RING_D anti-diagonals ahead -- leaves at its next look.  Waits are bounded
- * (a trap, never a hang).  The results are the one-wavefront kernel's bit for bit (same lane code on the same bytes). */
-#define K2A_SSEC_RING_D 4
-struct K2aSsecRing {
-	uint32_t v[K2A_SSEC_RING_D][8 * 64];
-	int dl[K2A_SSEC_RING_D];
-	uint32_t prod, cons, stop, pad;
-};
-__device__ __forceinline__ uint32_t k2a_lds_ld(uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void k2a_lds_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-/* wait until *p > than; false: the other side raised `stop` */
-__device__ __forceinline__ bool k2a_ring_wait(uint32_t *p, uint32_t than, uint32_t *stop)
-{
-	for (uint32_t it = 0; ; ++it) {
-		if (k2a_lds_ld(p) > than) return true;
-		if (k2a_lds_ld(stop)) return false;
-		if (it > (1u << 24)) __builtin_trap();               /* seconds: the partner wavefront is gone */
-		__builtin_amdgcn_s_sleep(1);
-	}
-}
-
-/* wavefront 0: the cells */
-template<bool DUAL, int MODE>
-__device__ __forceinline__ void k2a_ssec_split_cells(const K2aSsec &P, const K2aPair &pr, const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, int lane, K2aSsecRing *ring)
-{
-	const int qlen = pr.qlen, tlen = pr.tlen_full, w = pr.w, T16 = (tlen + 15) / 16 * 16, ncol = k2a_ssec_ncol(qlen, tlen, w);
-	const uint8_t *qry = seq + pr.qoff, *tgt = seq + pr.toff;
-	K2aSsecBlk<DUAL> B;
-	B.blk = -1; B.qn = 0;
-	B.U = B.V = B.X = B.Y = B.X2 = B.Y2 = B.S = B.P0 = B.P1 = B.QW = k2a_blk{ 0, 0, 0, 0, 0, 0, 0, 0 };
-	int last_st = -1, last_en = -1;
-	for (int r = 0; r < qlen + tlen - 1; ++r) {
-		int st0, en0, st, en;
-		if (!k2a_ssec_bounds(r, qlen, tlen, w, st0, en0, st, en)) break;                       /* (the book wavefront meets the same anti-diagonal and records the stop) */
-		const int pend = min(st0 + (int)(((uint32_t)(en0 - st0) >> 4) + 1u) * 16, T16);
-		B.shift_query(P, r);
-		{
-			const int need = max(en, pend - 1) >> 4, nb = B.blk < 0 ? lane : B.blk + 64;
-			if (nb <= need) B.init_block(P, nb, tgt, tlen, qry, qlen, r);
-		}
-		B.ask_query(qry, qlen, r);
-		const bool act = B.blk >= (st >> 4) && B.blk <= (en >> 4);
-		const bool prev_ok = st > 0 && st - 1 >= last_st && st - 1 <= last_en;
-		int cv, cx, cx2 = 0;
-		if (!DUAL) {
-			cx = 0; cv = st > 0 ? 0 : (r ? P.q : 0);
-			if (en >= r && B.blk == (r >> 4)) { k2a_sb_set(B.Y, r & 15, 0); k2a_sb_set(B.U, r & 15, r ? P.q : 0); }
-		} else {
-			const int edge = k2a_ssec_edge(P, r);
-			cx = -P.q - P.e; cx2 = -P.q2 - P.e2; cv = st > 0 ? -P.q - P.e : edge;
-			if (en >= r && B.blk == (r >> 4)) { k2a_sb_set(B.Y, r & 15, -P.q - P.e); k2a_sb_set(B.Y2, r & 15, -P.q2 - P.e2); k2a_sb_set(B.U, r & 15, edge); }
-		}
-		uint32_t pv = (uint32_t)k2a_rot1<64>((int)B.V[7]), px = (uint32_t)k2a_rot1<64>((int)B.X[7]), px2 = DUAL ? (uint32_t)k2a_rot1<64>((int)B.X2[7]) : 0u;
-		if (B.blk == (st >> 4) && !prev_ok) { pv = k2a_sb_c(cv); px = k2a_sb_c(cx); px2 = k2a_sb_c(cx2); }
-		B.refresh_scores(P, st0, pend);
-		if (act) {
-			uint32_t dirw[4];
-			B.template update<MODE>(P, pv, px, px2, dirw);
-			if (MODE != K2A_MODE_SCORE)
-				*(uint4*)(tb + pr.tb_off + (size_t)r * ncol + (size_t)(B.p0() - st)) = make_uint4(dirw[0], dirw[1], dirw[2], dirw[3]);
-		}
-		/* publish: the slot of anti-diagonal r is free once the book wavefront has consumed anti-diagonal r - D */
-		int dl;
-		if (r > 0 && en0 > 0) dl = __builtin_amdgcn_readlane((int)k2a_sb_get(B.U, en0 & 15), (en0 >> 4) & 63);
-		else dl = __builtin_amdgcn_readlane((int)k2a_sb_get(B.V, 0), 0);
-		if (r >= K2A_SSEC_RING_D && !k2a_ring_wait(&ring->cons, (uint32_t)(r - K2A_SSEC_RING_D), &ring->stop)) break;
-		{
-			uint32_t *slot = ring->v[r & (K2A_SSEC_RING_D - 1)];
-#pragma unroll
-			for (int i = 0; i < 8; ++i) slot[i * 64 + lane] = B.V[i];
-			if (lane == 0) ring->dl[r & (K2A_SSEC_RING_D - 1)] = dl;
-		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-		if (lane == 0) k2a_lds_st(&ring->prod, (uint32_t)r + 1u);
-		if (k2a_lds_ld(&ring->stop)) break;
-		last_st = st; last_en = en;
-	}
-}
-
-/* wavefront 1: H, the maxima, the book */
-template<bool DUAL>
-__device__ __forceinline__ void k2a_ssec_split_book(const K2aSsec &P, const K2aPair &pr, int *hl, int lane, K2aBook &book, K2aSsecRing *ring)
-{
-	const int qlen = pr.qlen, tlen = pr.tlen_full, w = pr.w, T16 = (tlen + 15) / 16 * 16;
-	const int slope = DUAL ? P.e2 : P.e;
-	K2aSsecBlk<DUAL> B;                                   /* of which only `blk` and `V` live here */
-	B.blk = -1;
-	B.V = k2a_blk{ 0, 0, 0, 0, 0, 0, 0, 0 };
-	k2a_book_reset(&book);
-	int last_st0 = 0, last_en0 = 0, hprev = 0;
-	for (int r = 0; r < qlen + tlen - 1; ++r) {
-		int st0, en0, st, en;
-		if (!k2a_ssec_bounds(r, qlen, tlen, w, st0, en0, st, en)) { book.dropped = 1; break; }
-		const int pend = min(st0 + (int)(((uint32_t)(en0 - st0) >> 4) + 1u) * 16, T16);
-		{
-			const int need = max(en, pend - 1) >> 4, nb = B.blk < 0 ? lane : B.blk + 64;
-			if (nb <= need) {
-				B.blk = nb;
-				int *hp = hl + k2a_ssecb_slot(nb << 4);
-#pragma unroll
-				for (int s = 0; s < 16; ++s) hp[s] = K2A_NEG;
-			}
-		}
-		const bool act = B.blk >= (st >> 4) && B.blk <= (en >> 4);
-		int hv[16], hnew = 0;
-		if (r > 0) {
-			K2A_SSECB_SYNC();
-			if (act) {
-				const int *hp = hl + k2a_ssecb_slot(B.p0());
-#pragma unroll
-				for (int s = 0; s < 16; ++s) hv[s] = hp[s];
-			}
-			hnew = hl[k2a_ssecb_slot(en0 > 0 ? en0 - 1 : en0)];
-		}
-		/* this anti-diagonal's v bytes and the last cell's byte, out of the ring */
-		if (!k2a_ring_wait(&ring->prod, (uint32_t)r, &ring->stop)) break;
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-		int dl;
-		{
-			const uint32_t *slot = ring->v[r & (K2A_SSEC_RING_D - 1)];
-#pragma unroll
-			for (int i = 0; i < 8; ++i) B.V[i] = slot[i * 64 + lane];
-			dl = __builtin_amdgcn_readfirstlane(ring->dl[r & (K2A_SSEC_RING_D - 1)]);
-		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   /* (the loads above have returned: s_waitcnt in front of the counter's store) */
-		if (lane == 0) k2a_lds_st(&ring->cons, (uint32_t)r + 1u);
-		int A, Sv, T0 = K2A_NEG, T1 = K2A_NEG, T2 = K2A_NEG;
-		uint64_t bk = 0;
-		const int en1 = st0 + (int)((uint32_t)(en0 - st0) & ~3u);
-		if (r > 0) {
-			if (!(en0 == last_en0 && en0 - 1 < last_st0 && en0 > 0)) hprev = __builtin_amdgcn_readfirstlane(hnew);
-			A = hprev + k2a_ssec_dh<DUAL>(P, dl);
-			if (act) bk = B.advance_H(P, hl, hv, st0, en1);
-			K2A_SSECB_SYNC();
-			const int pos = lane == 0 ? st0 : en1 + lane - 1;
-			const int hvv = (lane < 4 && pos < en0) ? hl[k2a_ssecb_slot(pos)] : K2A_NEG;
-			Sv = st0 < en0 ? __builtin_amdgcn_readlane(hvv, 0) : A;
-			T0 = __builtin_amdgcn_readlane(hvv, 1); T1 = __builtin_amdgcn_readlane(hvv, 2); T2 = __builtin_amdgcn_readlane(hvv, 3);
-			K2A_SSECB_SYNC();
-			if (lane == 0) hl[k2a_ssecb_slot(en0)] = A;
-		} else {
-			A = Sv = k2a_ssec_dh<DUAL>(P, dl) - (DUAL ? P.qe_first : P.q + P.e);
-			if (lane == 0) hl[0] = A;
-		}
-		K2A_SSECB_SYNC();
-		const uint64_t Bkey = k2a_wave_max_u64(bk);
-		if (k2a_ssec_book(&book, r, st0, en0, en, qlen, tlen, pr.zdrop, slope, A, Bkey, T0, T1, T2, Sv)) break;
-		last_st0 = st0; last_en0 = en0;
-	}
-	if (lane == 0) k2a_lds_st(&ring->stop, 1u);               /* a drop, or the end: the cells wavefront may be waiting for room */
-}
-
-/* one task per workgroup of two wavefronts; an approximate-mode task (nothing to split) runs on wavefront 0 as in k2a_ssec_blk_kernel */
-template<bool DUAL, int MODE>
-__global__ void __launch_bounds__(128)
-k2a_ssec_split_kernel(const K2aSsec P, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
-                      const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, K2aResult *__restrict__ res)
-{
-	__shared__ int hl[K2A_SSECB_RING_WORDS];
-	__shared__ K2aSsecRing ring;
-	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	const int task = blockIdx.x;
-	if (task >= ntasks) return;
-	const uint32_t pi = order[task];
-	const K2aPair pr = pairs[pi];
-	if (pr.pad & K2A_SSEC_APPROX) {
-		if (wave == 0) {
-			K2aBook book;
-			k2a_ssec_blk_task<DUAL, true, MODE>(P, pr, seq, tb, hl, lane, book);
-			if (lane == 0) k2a_finish(pr, book, &res[pi]);
-		}
-		return;
-	}
-	if (threadIdx.x == 0) { ring.prod = 0; ring.cons = 0; ring.stop = 0; }
-	__syncthreads();
-	if (wave == 0) k2a_ssec_split_cells<DUAL, MODE>(P, pr, seq, tb, lane, &ring);
-	else {
-		K2aBook book;
-		k2a_ssec_split_book<DUAL>(P, pr, hl, lane, book, &ring);
-		if (lane == 0) k2a_finish(pr, book, &res[pi]);
-	}
-}
-
 template<bool DUAL, int MODE>
 __global__ void __launch_bounds__(64 * K2A_WPB)
 k2a_ssec_blk_kernel(const K2aSsec P, const K2aPair *__restrict__ pairs, const uint32_t *__restrict__ order, int ntasks,
@@ -2251,7 +2061,7 @@ static const zscan_fn g_zscan[4][2] = { ZSCAN_ROW(8, 18), ZSCAN_ROW(16, 8), ZSCA
 /* Launch-time kernel forms.  Every choice the launcher makes has a forcing switch (k2a_shim_set_option: -1 automatic, 0 / 1
  * forced; the host maps KSW2AMD_LDSCODES / KSW2AMD_LDSROWS onto it) and is reported by k2a_shim_pk_form / k2a_shim_mp_form, so
  * that tests can pin each form against the oracle and check which one an unforced launch took. */
-static int g_opt[K2A_NOPT] = { -1, -1, -1 };
+static int g_opt[K2A_NOPT] = { -1, -1 };
 
 /* code planes in LDS: worth it once SIMDs would hold a third wavefront (a pooled batch launches chunks of two wavefronts
  * per SIMD side by side) */
@@ -2690,24 +2500,14 @@ int k2a_shim_launch_ssec(int dual, int mode, size_t lds_bytes, const K2aSsec *pa
 }
 
 /* tasks with the state in registers (k2a_ssec_blk_kernel); mode != SCORE: direction bytes into tb at pairs[i].tb_off, as k2a_ssec_kernel lays them out */
-/* ... or, for launches of at most one alignment per SIMD (K2A_OPT_SSEC_SPLIT: always / never), split over two wavefronts each
- * (k2a_ssec_split_kernel) */
-int k2a_shim_ssec_split(int ntasks)
-{
-	if (g_opt[K2A_OPT_SSEC_SPLIT] >= 0) return g_opt[K2A_OPT_SSEC_SPLIT] != 0;
-	return k2a_shim_simd_count() > 0 && ntasks <= k2a_shim_simd_count();
-}
 int k2a_shim_launch_ssec_blk(int dual, int mode, const K2aSsec *par, const K2aPair *pairs, const uint32_t *order, int ntasks, const uint8_t *seq, uint8_t *tb, K2aResult *res, void *stream)
 {
 	typedef void (*blk_fn)(const K2aSsec, const K2aPair*, const uint32_t*, int, const uint8_t*, uint8_t*, K2aResult*);
 	static const blk_fn fn[2][3] = { { k2a_ssec_blk_kernel<false, 0>, k2a_ssec_blk_kernel<false, 1>, k2a_ssec_blk_kernel<false, 2> },
 	                                 { k2a_ssec_blk_kernel<true, 0>, k2a_ssec_blk_kernel<true, 1>, k2a_ssec_blk_kernel<true, 2> } };
-	static const blk_fn fn2[2][3] = { { k2a_ssec_split_kernel<false, 0>, k2a_ssec_split_kernel<false, 1>, k2a_ssec_split_kernel<false, 2> },
-	                                  { k2a_ssec_split_kernel<true, 0>, k2a_ssec_split_kernel<true, 1>, k2a_ssec_split_kernel<true, 2> } };
 	if (ntasks <= 0) return 0;
 	if (mode < 0 || mode > 2) { snprintf(g_err, sizeof(g_err), "bad kernel class"); return -1; }
-	if (k2a_shim_ssec_split(ntasks)) hipLaunchKernelGGL(fn2[dual ? 1 : 0][mode], dim3(ntasks), dim3(128), 0, (hipStream_t)stream, *par, pairs, order, ntasks, seq, tb, res);
-	else hipLaunchKernelGGL(fn[dual ? 1 : 0][mode], dim3((ntasks + K2A_WPB - 1) / K2A_WPB), dim3(64 * K2A_WPB), 0, (hipStream_t)stream, *par, pairs, order, ntasks, seq, tb, res);
+	hipLaunchKernelGGL(fn[dual ? 1 : 0][mode], dim3((ntasks + K2A_WPB - 1) / K2A_WPB), dim3(64 * K2A_WPB), 0, (hipStream_t)stream, *par, pairs, order, ntasks, seq, tb, res);
 	CHECK(hipGetLastError());
 	return 0;
 }

@@ -523,8 +523,7 @@ static const fill_pk_fn g_fill_pk_lds[2][2] = {
 static const fill_pk_fn g_fill_pk_ldscodes[3][2][2] = { LDSCODE_SET(64, 16), LDSCODE_SET(8, 18), LDSCODE_SET(16, 8) };      /* [geometry][nomax][rebased] */
 /* launch-time forms (ksw2_shim.h): the simulator takes the LDS forms unless the option says 0 (the GPU launcher decides by the
  * number of tasks when the option is -1) */
-static int g_opt[K2A_NOPT] = { -1, -1, -1 };
-int k2a_shim_ssec_split(int) { return 0; }      /* (the two-wavefront split of the SSE-compatible register form is the device's business: same lane code, same bytes) */
+static int g_opt[K2A_NOPT] = { -1, -1 };
 static bool sim_use_ldscodes(void) { return g_opt[K2A_OPT_LDSCODES] != 0; }
 static bool sim_use_ldsrows(void) { return g_opt[K2A_OPT_LDSROWS] != 0; }
 void k2a_shim_set_option(int opt, int value) { if (opt >= 0 && opt < K2A_NOPT) g_opt[opt] = value < 0 ? -1 : value != 0; }
