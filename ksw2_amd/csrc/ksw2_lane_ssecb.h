@@ -290,14 +290,22 @@ struct K2aSsecBlk {
 	{
 		const uint32_t em = slot_mask(st0, en1);
 		int *hp = hl + k2a_ssecb_slot(p0());
-		int best = INT32_MIN;
+		/* the keys without their lane class first -- (h << 6) + 63 - s, a constant per slot -- and the best of every fourth slot; the class
+		 * term ((s - st0) & 3) << 4 is the same for the slots s = k mod 4 and comes off once per k (round 6: it was sixteen scalar
+		 * shift-and-or chains per anti-diagonal) */
+		const int none = INT32_MIN + 64;                       /* stays below every key when a class term comes off */
+		int b4[4] = { none, none, none, none };
 #pragma unroll
 		for (int s = 0; s < 16; ++s) {
 			const int h = hv[s] + dh(P, s);
 			hp[s] = h;
-			const int key = (int)(((uint32_t)h << 6) + (uint32_t)(63 - ((((s - st0) & 3) << 4) | s)));
-			best = k2a_max(best, (int)k2a_pk_selv(k2a_bit_mask(em, s), (uint32_t)key, (uint32_t)INT32_MIN));
+			const int key = (int)(((uint32_t)h << 6) + (uint32_t)(63 - s));
+			b4[s & 3] = k2a_max(b4[s & 3], (int)k2a_pk_selv(k2a_bit_mask(em, s), (uint32_t)key, (uint32_t)none));
 		}
+		int best = INT32_MIN;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) best = k2a_max(best, b4[k] - (int)((((uint32_t)(k - st0)) & 3u) << 4));
+		if (best < INT32_MIN + 128) best = INT32_MIN;
 		if (best == INT32_MIN) return 0;
 		return k2a_dm_key(best >> 6, p0() + (15 - (best & 15)), st0);
 	}

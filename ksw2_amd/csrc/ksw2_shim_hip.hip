@@ -1318,20 +1318,32 @@ __device__ __forceinline__ uint64_t k2a_dpp_max_u64(uint64_t k)
 	const uint64_t o = ((uint64_t)hi << 32) | lo;
 	return o > k ? o : k;
 }
+template<int CTRL>
+__device__ __forceinline__ uint32_t k2a_dpp_max_u32(uint32_t v)
+{
+	const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+	return o > v ? o : v;
+}
+__device__ __forceinline__ uint32_t k2a_wave_max_u32(uint32_t v)
+{
+	v = k2a_dpp_max_u32<0x121>(v);                    /* row_ror:1, 2, 4, 8: every lane of a row holds the row's maximum */
+	v = k2a_dpp_max_u32<0x122>(v);
+	v = k2a_dpp_max_u32<0x124>(v);
+	v = k2a_dpp_max_u32<0x128>(v);
+	const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+	const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+	const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+	return ab > cd ? ab : cd;
+}
+/* the wavefront's largest 64-bit key, in two 32-bit rounds (round 6): the largest high word, then the largest low word among the
+ * lanes that hold it -- 18 vector instructions where the 64-bit rotate-compare-select (k2a_dpp_max_u64) took 36: the SSE-compatible
+ * register form +4 % at four wavefronts per SIMD, `exts` +3.7 % (profiles/r6_ab_wave_max32.txt) */
 __device__ __forceinline__ uint64_t k2a_wave_max_u64(uint64_t k)
 {
-	k = k2a_dpp_max_u64<0x121>(k);                    /* row_ror:1 */
-	k = k2a_dpp_max_u64<0x122>(k);                    /* row_ror:2 */
-	k = k2a_dpp_max_u64<0x124>(k);                    /* row_ror:4 */
-	k = k2a_dpp_max_u64<0x128>(k);                    /* row_ror:8 */
-	uint64_t best = 0;
-#pragma unroll
-	for (int row = 0; row < 4; ++row) {
-		const uint64_t v = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k >> 32), row * 16) << 32) |
-		                   (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k, row * 16);
-		best = v > best ? v : best;
-	}
-	return best;
+	const uint32_t hi = (uint32_t)(k >> 32), lo = (uint32_t)k;
+	const uint32_t M = k2a_wave_max_u32(hi);
+	const uint32_t L = k2a_wave_max_u32(hi == M ? lo : 0u);
+	return ((uint64_t)M << 32) | L;
 }
 
 template<int MODE, int K>
