@@ -107,21 +107,19 @@ struct K2aExtfBlk {
 			const uint32_t em = b > a ? ((1u << b) - 1u) & ~((1u << a) - 1u) : 0u;
 			if (em) {
 				const uint32_t cm = k2a_sb_c(par.mch + 2 * par.e), cd = k2a_sb_c(par.mis - par.mch);
+				const uint32_t em2 = em | (em << 15);                  /* slot 2i at bit 2i, slot 2i + 1 at bit 2i + 16: one shift puts both at their halves' sign bits (K2aSsecBlk::refresh_scores) */
 #pragma unroll
 				for (int i = 0; i < 8; ++i) {
 					const uint32_t ne = k2a_sb_minu(TC[i] ^ QW[i], 0x00010001u);
 					const uint32_t sc = k2a_pk_mad(ne, cd, cm);
-					const uint32_t hm = k2a_pk_sel(0x0000ffffu, k2a_bit_mask(em, 2 * i), k2a_bit_mask(em, 2 * i + 1));
-					S[i] = k2a_pk_selv(hm, sc, S[i]);
+					S[i] = k2a_pk_selv(k2a_pk_sign(em2 << (15 - 2 * i)), sc, S[i]);
 				}
 			}
 			if (blk >= (d.blo >> 4) && blk <= (d.bhi >> 4)) {
-				uint32_t vb = pv;
 #pragma unroll
-				for (int i = 0; i < 8; ++i) {
-					const uint32_t vo = V[i], av = k2a_sb_shift(vo, vb);
+				for (int i = 7; i >= 0; --i) {                      /* top register down: its left neighbour is the register below, still untouched (no copies of the old values) */
+					const uint32_t av = k2a_sb_shift(V[i], i ? V[i - 1] : pv);
 					const uint32_t z = k2a_pk_maxu(k2a_pk_max(S[i], av), U[i]);
-					vb = vo;
 					V[i] = k2a_pk_sub(z, U[i]); U[i] = k2a_pk_sub(z, av);
 				}
 			}

@@ -205,11 +205,11 @@ struct K2aSsecBlk {
 		uint32_t dd[8];
 		if (!DUAL) {
 			const uint32_t ccap = k2a_sb_c(P.sc_mch + 2 * (P.q + P.e)), cq = k2a_sb_c(P.q);
-			uint32_t vb = pv, xb = px;
+			/* registers from the top one down: a register's left neighbours are the OLD values of the register below it, which is
+			 * still untouched then -- walking upwards, every old V[i] / X[i] had to be kept in a copy for the next register (round 6) */
 #pragma unroll
-			for (int i = 0; i < 8; ++i) {
-				const uint32_t vo = V[i], xo = X[i];
-				const uint32_t vt1 = k2a_sb_shift(vo, vb), xt1 = k2a_sb_shift(xo, xb);
+			for (int i = 7; i >= 0; --i) {
+				const uint32_t vt1 = k2a_sb_shift(V[i], i ? V[i - 1] : pv), xt1 = k2a_sb_shift(X[i], i ? X[i - 1] : px);
 				const uint32_t a = k2a_pk_add(xt1, vt1), b = k2a_pk_add(Y[i], U[i]);
 				const uint32_t z = k2a_pk_max(S[i], a);
 				uint32_t zu = k2a_pk_maxu(z, b);
@@ -225,17 +225,14 @@ struct K2aSsecBlk {
 					d = k2a_pk_selv(k2a_sb_gt(z, b), d, 0x00020002u);
 					dd[i] = d | (~k2a_sb_gt(0u, a1) & 0x00080008u) | (~k2a_sb_gt(0u, b1) & 0x00100010u);
 				}
-				vb = vo; xb = xo;
 				V[i] = k2a_pk_sub(zu, U[i]); U[i] = k2a_pk_sub(zu, vt1);
 				X[i] = k2a_pk_max(a1, 0u); Y[i] = k2a_pk_max(b1, 0u);
 			}
 		} else {
 			const uint32_t cm = k2a_sb_c(P.sc_mch), cq = k2a_sb_c(P.q), cq2 = k2a_sb_c(P.q2), cqe = k2a_sb_c(P.q + P.e), cqe2 = k2a_sb_c(P.q2 + P.e2);
-			uint32_t vb = pv, xb = px, x2b = px2;
 #pragma unroll
-			for (int i = 0; i < 8; ++i) {
-				const uint32_t vo = V[i], xo = X[i], x2o = X2[i];
-				const uint32_t vt1 = k2a_sb_shift(vo, vb), xt1 = k2a_sb_shift(xo, xb), x2t1 = k2a_sb_shift(x2o, x2b);
+			for (int i = 7; i >= 0; --i) {                        /* top register down: see the single-gap loop */
+				const uint32_t vt1 = k2a_sb_shift(V[i], i ? V[i - 1] : pv), xt1 = k2a_sb_shift(X[i], i ? X[i - 1] : px), x2t1 = k2a_sb_shift(X2[i], i ? X2[i - 1] : px2);
 				uint32_t a = k2a_pk_add(xt1, vt1), b = k2a_pk_add(Y[i], U[i]), a2 = k2a_pk_add(x2t1, vt1), b2 = k2a_pk_add(Y2[i], U[i]);
 				uint32_t z = S[i], d = 0;
 				if (MODE == K2A_MODE_SCORE) z = k2a_pk_max(k2a_pk_max(z, a), k2a_pk_max(b, k2a_pk_max(a2, b2)));
@@ -251,7 +248,6 @@ struct K2aSsecBlk {
 					d = k2a_pk_selv(k2a_sb_gt(z, b2), d, 0x00040004u);   z = k2a_pk_max(z, b2);
 				}
 				z = k2a_pk_min(z, cm);
-				vb = vo; xb = xo; x2b = x2o;
 				V[i] = k2a_pk_sub(z, U[i]); U[i] = k2a_pk_sub(z, vt1);
 				uint32_t tmp = k2a_pk_sub(z, cq);
 				a = k2a_pk_sub(a, tmp); b = k2a_pk_sub(b, tmp);
