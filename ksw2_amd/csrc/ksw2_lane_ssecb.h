@@ -179,6 +179,9 @@ struct K2aSsecBlk {
 	}
 
 	/* the scores of positions [st0, pend) below the padded target length (ksw2_extz2_sse.c:125-140, simple scoring) */
+	/* QWILD = false: the build for tasks whose QUERY holds no wildcard code (the kernel looks first, k2a_ssec_blk_kernel): two
+	 * instructions per register less */
+	template<bool QWILD = true>
 	K2A_FN void refresh_scores(const K2aSsec &P, int st0, int pend)
 	{
 		const uint32_t em = slot_mask(st0, pend);
@@ -189,7 +192,7 @@ struct K2aSsecBlk {
 		for (int i = 0; i < 8; ++i) {
 			/* { 0, P0[code lo], 0, P1[code hi] }: the selector's high half reads the second operand's bytes (4 + code) */
 			uint32_t sc = k2a_perm(P1[i], P0[i], QW[i] | 0x04000000u);
-			sc = k2a_pk_selv(k2a_pk_sign(QW[i]), cn, sc);                                          /* the query's wildcard */
+			if (QWILD) sc = k2a_pk_selv(k2a_pk_sign(QW[i]), cn, sc);                               /* the query's wildcard */
 			S[i] = k2a_pk_selv(k2a_pk_sign(em2 << (15 - 2 * i)), sc, S[i]);
 		}
 	}

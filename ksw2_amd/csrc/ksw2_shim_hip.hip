@@ -1701,7 +1701,7 @@ k2a_ssec_kernel(const K2aSsec P, const K2aPair *__restrict__ pairs, const uint32
 /* the anti-diagonals of one task; APPROX: the approximate modes' one followed cell instead of H (a template parameter and not the
  * task's flag tested per anti-diagonal: with both forms in one loop hipcc merges their stores into the book through a selected
  * address and the book moves to scratch memory) */
-template<bool DUAL, bool APPROX, int MODE>
+template<bool DUAL, bool APPROX, int MODE, bool QWILD>
 __device__ __forceinline__ void k2a_ssec_blk_task(const K2aSsec &P, const K2aPair &pr, const uint8_t *__restrict__ seq, uint8_t *__restrict__ tb, int *hl, int lane, K2aBook &book)
 {
 	const int qlen = pr.qlen, tlen = pr.tlen_full, w = pr.w, T16 = (tlen + 15) / 16 * 16, ncol = k2a_ssec_ncol(qlen, tlen, w);
@@ -1758,7 +1758,7 @@ __device__ __forceinline__ void k2a_ssec_blk_task(const K2aSsec &P, const K2aPai
 		}
 		uint32_t pv = (uint32_t)k2a_rot1<64>((int)B.V[7]), px = (uint32_t)k2a_rot1<64>((int)B.X[7]), px2 = DUAL ? (uint32_t)k2a_rot1<64>((int)B.X2[7]) : 0u;
 		if (B.blk == (st >> 4) && !prev_ok) { pv = k2a_sb_c(cv); px = k2a_sb_c(cx); px2 = k2a_sb_c(cx2); }
-		B.refresh_scores(P, st0, pend);
+		B.template refresh_scores<QWILD>(P, st0, pend);
 		if (act) {
 			uint32_t dirw[4];
 			B.template update<MODE>(P, pv, px, px2, dirw);
@@ -1816,8 +1816,24 @@ k2a_ssec_blk_kernel(const K2aSsec P, const K2aPair *__restrict__ pairs, const ui
 	const uint32_t pi = order[task];
 	const K2aPair pr = pairs[pi];
 	K2aBook book;
-	if (pr.pad & K2A_SSEC_APPROX) k2a_ssec_blk_task<DUAL, true, MODE>(P, pr, seq, tb, hl, lane, book);
-	else k2a_ssec_blk_task<DUAL, false, MODE>(P, pr, seq, tb, hl, lane, book);
+	/* does the query hold the wildcard code?  (sixteen bytes per lane and round; the score refresh of a task without one skips the
+	 * wildcard select: round 6) */
+	bool qw = false;
+	{
+		const uint8_t *q = seq + pr.qoff;
+		const uint32_t wc = (uint32_t)(P.m - 1) * 0x01010101u;
+		for (int x = lane * 4; x < pr.qlen; x += 256) {
+			uint32_t d;
+			__builtin_memcpy(&d, q + x, 4);
+			if (x + 4 > pr.qlen) d |= 0xffffff00u << (8 * (pr.qlen - x - 1));      /* bytes past the end: never the wildcard (codes are below 128) */
+			const uint32_t e = d ^ wc;                                            /* a zero byte = the wildcard */
+			qw |= ((e - 0x01010101u) & ~e & 0x80808080u) != 0;
+		}
+		qw = __builtin_amdgcn_ballot_w64(qw) != 0;
+	}
+	if (pr.pad & K2A_SSEC_APPROX) { if (qw) k2a_ssec_blk_task<DUAL, true, MODE, true>(P, pr, seq, tb, hl, lane, book); else k2a_ssec_blk_task<DUAL, true, MODE, false>(P, pr, seq, tb, hl, lane, book); }
+	else if (qw) k2a_ssec_blk_task<DUAL, false, MODE, true>(P, pr, seq, tb, hl, lane, book);
+	else k2a_ssec_blk_task<DUAL, false, MODE, false>(P, pr, seq, tb, hl, lane, book);
 	if (lane == 0) k2a_finish(pr, book, &res[pi]);
 }
 
