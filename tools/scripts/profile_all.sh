@@ -10,3 +10,8 @@ for wl in $WLS; do
 	echo "$wl: $(( $(date +%s) - t0 )) s; $(tail -c 200 gpurun_out/prof_${TAG}_${wl}.log | tr '\n' ' ')"
 	rm -rf gpurun_out/prof_${TAG}_${wl}          # the raw rocprofv3 output; the summaries are under gpurun_out/profiles/
 done
+# the round's host-contention rehearsal (8 gloo ranks sharing the one device and host): part of a full pass
+# (no workload list given) or with REHEARSAL=1
+if [ "${REHEARSAL:-}" = "1" ] || [ -z "${1:-}" ]; then
+	bash tools/scripts/rehearsal_8rank.sh gpurun_out/profiles/${TAG}_rehearsal_8rank_one_device.json 2>&1 | tail -7
+fi
