@@ -2,7 +2,7 @@
 # GPU box: tools/scripts/profile_round.sh for every workload of bench.py's default `also` list + the headline.
 #   usage: tools/scripts/profile_all.sh <tag> [workload ...]      -> gpurun_out/profiles/<tag>_<workload>_{kernel_stats.csv,pmc.json}
 TAG=${1:-r5p}; shift
-WLS=${@:-10k 10k-n1024 10k-cigar cfg2 cfg3 cfg5 cfg4 10k-zdrop 10k-N 10k-generic exts extf 10k-ssec}
+WLS=${@:-10k 10k-n1024 10k-cigar cfg2 cfg3 cfg5 cfg4 10k-zdrop 10k-N 10k-tN 10k-generic 10k-approx exts extf extf-w300 extf-w900 10k-ssec 10k-ssec-n4096 10k-ssec-approx 10k-ssec-cigar}
 for wl in $WLS; do
 	st=3; case $wl in cfg2) st=10;; exts|extf|10k-n1024) st=6;; esac
 	t0=$(date +%s)
