@@ -95,6 +95,8 @@ def check_target_wildcards(lib, setenv, delenv, scale=1):
              (8, 1200, 1250, 300, 400, 0, True, {}),                                           # (64, 16) two-piece with CIGAR (row state in LDS or registers)
              (9, 700, 690, 64, 100, 0, False, {"KSW2AMD_SOLO": "all"}),                        # solo
              (9, 700, 690, 64, 100, po.SCORE_ONLY, True, {"KSW2AMD_SOLO": "all"}),
+             (12, 300, 310, 40, -1, po.SCORE_ONLY | po.APPROX_MAX, False, {}),                 # KSW_EZ_APPROX_MAX alone: the kernels without maximum tracking
+             (12, 900, 880, 300, -1, po.APPROX_MAX, True, {}),                                 # ... two-piece, with the corner CIGAR
              (4, 2300, 2337, -1, -1, 0, False, {}),                                            # generation-serial
              (4, 2300, 2337, -1, 300, po.SCORE_ONLY, True, {})]
     keys = ("KSW2AMD_DEFER", "KSW2AMD_LDSCODES", "KSW2AMD_SOLO", "KSW2AMD_TN", "KSW2AMD_SIMDS")
