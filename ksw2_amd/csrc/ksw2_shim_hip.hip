@@ -693,24 +693,32 @@ k2a_zscan_kernel(const K2aScoring sc, const K2aPair *__restrict__ pairs, const u
 		/* what step t needs from memory -- the checkpoint entry and the two query codes -- is asked for one iteration ahead and by every
 		 * lane, unconditionally (clamped into the lane's own range; a lane without a strip reads step 0 of its block): two wavefronts
 		 * per SIMD do not hide an L2 round trip per step, and hipcc waits right behind a load that sits under a condition */
-		uint2 in_n; uint32_t qa_n, qb_n;
-		{
-			const int k = n > 0 ? kbeg : 0, jc = min(max(k - L.koff, 0), L.qlen - 1);
-			in_n = st[(size_t)k * 64]; qa_n = L.qa[jc]; qb_n = L.qbp[jc];
-		}
-		for (int t = 0; __builtin_amdgcn_ballot_w64(t < off + n) != 0; ++t) {
-			const uint2 in = in_n;
-			const uint32_t qc = k2a_pair16(qa_n, qb_n);
-			{
-				const int k = n > 0 ? kfirst + min(max(t + 1, off), off + n - 1) : 0, jc = min(max(k - L.koff, 0), L.qlen - 1);
-				in_n = st[(size_t)k * 64]; qa_n = L.qa[jc]; qb_n = L.qbp[jc];
+		/* ... and FOUR steps ahead (round 6): the checkpoint stream is 137 GB of write-once data, i.e. HBM, and one step of look-ahead
+		 * left the pass at ~1.5 us per step (9.8 ms of a 105 ms launch when a fifth of the pairs freeze).  Steps in groups of four: the next
+		 * group's three loads per step are issued at the top of a group into registers of their own and taken over below its last step
+		 * (a value that is still in flight must not be copied: k2a_load_early) */
+		uint2 in_c[4]; uint32_t qa_c[4], qb_c[4];
+		auto ask = [&](int t, uint2 &in, uint32_t &qa, uint32_t &qb) {
+			const int k = n > 0 ? kfirst + min(max(t, off), off + n - 1) : 0, jc = min(max(k - L.koff, 0), L.qlen - 1);
+			in = st[(size_t)k * 64]; qa = L.qa[jc]; qb = L.qbp[jc];
+		};
+#pragma unroll
+		for (int y = 0; y < 4; ++y) ask(y, in_c[y], qa_c[y], qb_c[y]);
+		for (int tg = 0; __builtin_amdgcn_ballot_w64(tg < off + n) != 0; tg += 4) {
+			uint2 in_n[4]; uint32_t qa_n[4], qb_n[4];
+#pragma unroll
+			for (int y = 0; y < 4; ++y) ask(tg + 4 + y, in_n[y], qa_n[y], qb_n[y]);
+#pragma unroll
+			for (int y = 0; y < 4; ++y) {
+				const int t = tg + y;
+				if (t >= off && t < off + n) {
+					L.set_qb(k2a_pair16(qa_c[y], qb_c[y]));
+					uint32_t tw[Lane::TBWORDS];
+					L.step(sc, kfirst + t, in_c[y].x, in_c[y].y, 0u, tw);
+				}
 			}
-			if (t >= off && t < off + n) {
-				const int k = kfirst + t;
-				L.set_qb(qc);
-				uint32_t tw[Lane::TBWORDS];
-				L.step(sc, k, in.x, in.y, 0u, tw);
-			}
+#pragma unroll
+			for (int y = 0; y < 4; ++y) { in_c[y] = in_n[y]; qa_c[y] = qa_n[y]; qb_c[y] = qb_n[y]; }
 		}
 		if (go) L.stage_rows(stage[wave][lane]);
 		__builtin_amdgcn_wave_barrier();
